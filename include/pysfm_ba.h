@@ -1,0 +1,159 @@
+/* pysfm_ba.h - C ABI of the MI355X bundle-adjustment inner loop.
+ *
+ * Drop-in boundary for the hot path of alexflint/pysfm's BundleAdjuster
+ * (reference: bundle_adjuster.py).  The reference is pure Python and has no FFI;
+ * every entry point below therefore names the reference *method* (file:line) whose
+ * arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a pysfm
+ * maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, fp64 values, int32 indices, row-major.
+ *   - every function returns a ba_status (0 = ok, negative = error) and never
+ *     throws; ba_last_error() returns a message for the last failure.
+ *   - "host" pointers are ordinary CPU memory; the library owns all device
+ *     memory behind the opaque handle unless an external device buffer is bound
+ *     with ba_bind_reduced_buffers().
+ *   - one handle = one GPU + one HIP stream; calls on one handle are not
+ *     re-entrant.  Calls return after the work they enqueue has been submitted;
+ *     functions that hand results to host memory synchronise the stream first.
+ *   - "camera position" / "track position" = index into the camera_ids /
+ *     track_ids lists chosen in BundleAdjuster.set_bundle
+ *     (bundle_adjuster.py:54-114).
+ */
+#ifndef PYSFM_BA_H
+#define PYSFM_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ba_handle ba_handle;
+
+typedef enum ba_status {
+  BA_OK = 0,
+  BA_ERR_INVALID_ARG = -1,
+  BA_ERR_NO_DEVICE = -2,   /* no usable HIP device / runtime */
+  BA_ERR_HIP = -3,         /* a HIP call failed; see ba_last_error */
+  BA_ERR_STATE = -4,       /* call order violated (e.g. schur before set_params) */
+  BA_ERR_SINGULAR = -5,    /* plain-inverse mode met a singular 3x3 point block */
+  BA_ERR_NOMEM = -6
+} ba_status;
+
+/* sensor_model.py:7-32 (Gaussian), 37-72 (Cauchy); Huber is new (same protocol). */
+typedef enum ba_sensor_kind {
+  BA_SENSOR_GAUSS = 0,  /* params = L row-major 2x2, L = chol(cov^-1): r = L e      */
+  BA_SENSOR_CAUCHY = 1, /* params[0] = sigma                                        */
+  BA_SENSOR_HUBER = 2   /* params[0] = k                                            */
+} ba_sensor_kind;
+
+/* Two resident parameter sets: the accepted bundle and the LM trial
+ * (bundle.py:301-310 clone_params is the reference's rollback snapshot). */
+typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_set;
+
+/* kernel ids for ba_get_timings */
+enum {
+  BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
+  BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_MIRROR, BA_K_EVAL, BA_K_COUNT
+};
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int ba_create(int device_id, ba_handle** out);
+int ba_destroy(ba_handle* h);
+/* message of the last error on this handle (h may be NULL: last ba_create error) */
+const char* ba_last_error(const ba_handle* h);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int ba_set_stream(ba_handle* h, void* hip_stream);
+int ba_synchronize(ba_handle* h);
+
+/* ---- problem definition: BundleAdjuster.set_bundle (bundle_adjuster.py:54-114)
+ * nc cameras, nt tracks, nobs observations ordered by track position
+ * (obs_pt non-decreasing), each (camera, track) pair at most once.
+ *   obs_cam[nobs], obs_pt[nobs]  positions;  obs_z[nobs*2] measurements
+ *   K[9]                         calibration (general 3x3)
+ *   cam_opt_pos[nc]              position in optim_camera_ids, or -1 (frozen)
+ *   pt_opt[nt]                   1 if the track is in optim_track_ids
+ */
+int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs,
+                   const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_z,
+                   const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt);
+
+/* bundle.sensor_model (sensor_model.py:19-32 protocol) */
+int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams);
+
+/* camera / point parameters: R[nc*9], t[nc*3], X[nt*3] (host) */
+int ba_set_params(ba_handle* h, int which, const double* R, const double* t, const double* X);
+int ba_get_params(ba_handle* h, int which, double* R, double* t, double* X);
+/* make the trial set the current one (optimize() accept branch, bundle_adjuster.py:151) */
+int ba_swap_params(ba_handle* h);
+
+/* ---- BundleAdjuster.compute_cost (bundle_adjuster.py:165-171) ----------- */
+int ba_cost(ba_handle* h, int which, double* cost_out);
+
+/* ---- per-observation evaluation: Bundle.reproj_error / residual / Jresidual
+ * (bundle.py:243-277).  Any output may be NULL.  e[nobs*2], r[nobs*2],
+ * Jc[nobs*12] (2x6 row-major), Jp[nobs*6] (2x3). */
+int ba_eval_observations(ba_handle* h, int which, double* e, double* r, double* Jc, double* Jp);
+
+/* sensor_model protocol on a batch of n errors (sensor_model.py:19-32): r[n*2] =
+ * residual_from_error(e), J[n*4] = Jresidual_from_error(e) (2x2 row-major), with the
+ * sensor set by ba_set_sensor.  Needs no problem.  r or J may be NULL. */
+int ba_eval_sensor(ba_handle* h, int64_t n, const double* e, double* r, double* J);
+
+/* ---- BundleAdjuster.prepare_schur_complement (bundle_adjuster.py:211-234)
+ * Undamped blocks stay on the device.  store_W != 0 also keeps the per-observation
+ * HCP blocks W = Jc^T Jp (6x3) for ba_get_blocks. */
+int ba_linearize(ba_handle* h, int which, int store_W);
+/* HCC[nc*36], bC[nc*6], HPP[nt*9], bP[nt*3], W[nobs*18]; any may be NULL */
+int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP, double* W);
+
+/* ---- apply_damping + compute_schur_complement (bundle_adjuster.py:238-278)
+ * damping: diag *= (1+lambda) on every HCC / HPP block (optimize.py:7-9).
+ * pinv_rcond >= 0: numpy.linalg.pinv(HPP, rcond) semantics; < 0: plain inverse
+ * (SCHUR_COMPLIMENT_PINV_THRESHOLD = None).  Needs ba_linearize first.
+ * The reduced system stays on the device as upper-triangular 6x6 blocks. */
+int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond);
+/* S[nco*nco*36] laid out (nco,nco,6,6) and b[nco*6], full symmetric (host) */
+int ba_get_reduced(ba_handle* h, double* S, double* b);
+/* HPP_invs[nt*9] (host) */
+int ba_get_point_inverses(ba_handle* h, double* HPP_inv);
+
+/* Device views of the reduced system for the collective and the solver:
+ * S_blocks = nco*nco*36 doubles (block (i,j) at (i*nco+j)*36, only i<=j filled
+ * until ba_mirror_reduced), b = nco*6 doubles.  With ba_bind_reduced_buffers the
+ * caller supplies the device memory (e.g. a torch tensor) instead. */
+int ba_reduced_device_ptrs(ba_handle* h, void** S_blocks, void** b);
+int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev);
+int ba_mirror_reduced(ba_handle* h);
+/* Flat (6nco x 6nco) system with rows/cols of masked camera parameters deleted
+ * (solve_motion_normal_eqns, bundle_adjuster.py:290-299).  keep[nkeep] lists the
+ * kept flat parameter indices (host).  A_dev[nkeep*nkeep], rhs_dev[nkeep] are
+ * caller-owned DEVICE buffers. */
+int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A_dev, void* rhs_dev);
+
+/* ---- BundleAdjuster.backsubstitute (bundle_adjuster.py:316-331)
+ * dC[nco*6] host (solution of the reduced system, zeros at masked parameters);
+ * dP[nt*3] for every track position (host, may be NULL: result stays on device). */
+int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP);
+
+/* ---- update_motion / update_structure (bundle_adjuster.py:334-343;
+ * Camera.perturb bundle.py:76-80; SO3.exp lie.py:21-34)
+ * dst = src (+) update.  motion[nco*6] / structure[nt*3] are host arrays in the
+ * sign the reference passes to perturb(); if both are NULL the update is
+ * -(dC, dP) of the last ba_backsubstitute, taken from device memory.
+ * Only optimised cameras / tracks move. */
+int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const double* structure);
+
+/* ---- instrumentation ---------------------------------------------------- */
+int ba_enable_timing(ba_handle* h, int on);
+/* accumulated HIP-event time (ms) and launch count per kernel id since the last reset */
+int ba_get_timings(ba_handle* h, double* ms /*[BA_K_COUNT]*/, int64_t* launches /*[BA_K_COUNT]*/, int reset);
+const char* ba_kernel_name(int kernel_id);
+const char* ba_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSFM_BA_H */

@@ -240,8 +240,9 @@ def invert_point_blocks(HPP_damped, rcond):
     """bundle_adjuster.py:252-256: pinv(HPP, rcond), or inv if rcond is None."""
     if rcond is None:
         return np.linalg.inv(HPP_damped)
-    return np.stack([np.linalg.pinv(H, rcond) for H in HPP_damped]) \
-        if len(HPP_damped) else HPP_damped.copy()
+    if not len(HPP_damped):
+        return HPP_damped.copy()
+    return np.linalg.pinv(HPP_damped, rcond)          # stacked: one LAPACK SVD per 3x3 block
 
 
 def schur_complement(HCC_d, HPP_inv, W, bC, bP, obs_cam, obs_pt, cam_opt_pos,

@@ -1,0 +1,117 @@
+"""ctypes binding of libpysfm_ba.so (include/pysfm_ba.h).
+
+There is no CPU fallback: if the HIP library is missing, or no MI355X is
+visible, every entry point raises.  Build the library with
+``make -C pysfm_amd/csrc`` or ``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_NAME = 'libpysfm_ba.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+BA_OK = 0
+BA_ERR_INVALID_ARG, BA_ERR_NO_DEVICE, BA_ERR_HIP, BA_ERR_STATE, BA_ERR_SINGULAR, BA_ERR_NOMEM = \
+    -1, -2, -3, -4, -5, -6
+SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER = 0, 1, 2
+PARAMS_CUR, PARAMS_TRIAL = 0, 1
+KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 'backsub',
+              'update', 'flatten', 'mirror', 'eval')
+K_COUNT = len(KERNEL_IDS)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+_h = C.c_void_p
+
+# name -> (restype, argtypes); one entry per function declared in include/pysfm_ba.h
+PROTOTYPES = {
+    'ba_create': (C.c_int, [C.c_int, C.POINTER(_h)]),
+    'ba_destroy': (C.c_int, [_h]),
+    'ba_last_error': (C.c_char_p, [_h]),
+    'ba_set_stream': (C.c_int, [_h, C.c_void_p]),
+    'ba_synchronize': (C.c_int, [_h]),
+    'ba_set_problem': (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, _dp, _dp, _ip, _bp]),
+    'ba_set_sensor': (C.c_int, [_h, C.c_int, _dp, C.c_int]),
+    'ba_set_params': (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
+    'ba_get_params': (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
+    'ba_swap_params': (C.c_int, [_h]),
+    'ba_cost': (C.c_int, [_h, C.c_int, _dp]),
+    'ba_eval_observations': (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
+    'ba_eval_sensor': (C.c_int, [_h, C.c_int64, _dp, _dp, _dp]),
+    'ba_linearize': (C.c_int, [_h, C.c_int, C.c_int]),
+    'ba_get_blocks': (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp]),
+    'ba_schur': (C.c_int, [_h, C.c_int, C.c_double, C.c_double]),
+    'ba_get_reduced': (C.c_int, [_h, _dp, _dp]),
+    'ba_get_point_inverses': (C.c_int, [_h, _dp]),
+    'ba_reduced_device_ptrs': (C.c_int, [_h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'ba_bind_reduced_buffers': (C.c_int, [_h, C.c_void_p, C.c_void_p]),
+    'ba_mirror_reduced': (C.c_int, [_h]),
+    'ba_flatten_reduced': (C.c_int, [_h, _ip, C.c_int32, C.c_void_p, C.c_void_p]),
+    'ba_backsubstitute': (C.c_int, [_h, C.c_int, _dp, _dp]),
+    'ba_apply_update': (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp]),
+    'ba_enable_timing': (C.c_int, [_h, C.c_int]),
+    'ba_get_timings': (C.c_int, [_h, _dp, C.POINTER(C.c_int64), C.c_int]),
+    'ba_kernel_name': (C.c_char_p, [C.c_int]),
+    'ba_version': (C.c_char_p, []),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    """libpysfm_ba.so is not built / not loadable.  There is no CPU path."""
+
+
+class HipDeviceError(RuntimeError):
+    """The HIP library reported an error (see message)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libpysfm_ba.so and declare every prototype.  Raises HipLibraryMissing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            '%s not found. pysfm_amd has no CPU fallback: build the HIP library with '
+            '`make -C pysfm_amd/csrc` (hipcc --offload-arch=gfx950).' % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryMissing('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipLibraryMissing('%s does not export %s (stale build?)' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def bptr(a):
+    return None if a is None else a.ctypes.data_as(_bp)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)

@@ -1,0 +1,257 @@
+"""HipBackend - NumPy-facing wrapper of one ``ba_handle`` (one GPU, one stream).
+
+This is the only compute backend of the package.  All arithmetic of the
+bundle-adjustment inner loop runs in the HIP kernels of libpysfm_ba.so; this
+class only marshals arrays, owns the torch tensors that alias the reduced camera
+system (for the RCCL all-reduce and the dense reduced solve) and turns C status
+codes into Python exceptions.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import PARAMS_CUR, PARAMS_TRIAL  # noqa: F401  (re-exported)
+
+# reduced systems up to this many unknowns are solved with numpy.linalg.solve on the
+# host (LAPACK gesv - the reference's own call, bundle_adjuster.py:303); larger
+# ones stay on the GPU (torch.linalg.solve_ex -> rocSOLVER getrf/getrs).
+HOST_SOLVE_MAX_UNKNOWNS = 768
+
+
+class SingularPointBlock(np.linalg.LinAlgError):
+    """plain-inverse mode met a singular HPP block (numpy.linalg.inv would raise)."""
+
+
+class ReducedSystemSingular(Exception):
+    """LU of the reduced camera system hit an exactly zero pivot."""
+
+
+class HipBackend(object):
+    def __init__(self, device=0):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        rc = self._lib.ba_create(int(device), C.byref(self._h))
+        if rc != capi.BA_OK:
+            msg = self._lib.ba_last_error(None).decode()
+            self._h = None
+            raise capi.HipDeviceError('ba_create(device=%d) failed (%d): %s' % (device, rc, msg))
+        self.device = int(device)
+        self.nc = self.nt = self.nco = self.nobs = 0
+        self._torch = None
+        self._S_t = self._b_t = self._Sb_t = None
+        self._A_t = self._rhs_t = None
+        self._attach_torch()
+
+    # ---------------------------------------------------------------- plumbing
+    def _attach_torch(self):
+        """Run on torch's current stream so torch ops (all-reduce, solve) and our
+        kernels are ordered without extra synchronisation."""
+        try:
+            import torch
+        except ImportError:       # the C library works stand-alone; only the large solve needs torch
+            return
+        if not torch.cuda.is_available():
+            return
+        self._torch = torch
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.ba_set_stream(self._h, C.c_void_p(stream)))
+
+    def _check(self, rc):
+        if rc == capi.BA_OK:
+            return
+        msg = self._lib.ba_last_error(self._h).decode()
+        if rc == capi.BA_ERR_SINGULAR:
+            raise SingularPointBlock(msg)
+        if rc == capi.BA_ERR_INVALID_ARG:
+            raise ValueError(msg)
+        raise capi.HipDeviceError('libpysfm_ba error %d: %s' % (rc, msg))
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.ba_destroy(self._h)
+            self._h = None
+        self._S_t = self._b_t = self._A_t = self._rhs_t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._lib.ba_synchronize(self._h))
+
+    # ---------------------------------------------------------------- problem
+    def set_problem(self, nc, nt, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt):
+        obs_cam, obs_pt = capi.i32(obs_cam), capi.i32(obs_pt)
+        obs_z = capi.f64(obs_z, (-1, 2))
+        K = capi.f64(K, (3, 3))
+        cam_opt_pos = capi.i32(cam_opt_pos)
+        pt_opt = np.ascontiguousarray(pt_opt, dtype=np.uint8)
+        assert len(obs_cam) == len(obs_pt) == len(obs_z)
+        assert len(cam_opt_pos) == nc and len(pt_opt) == nt
+        self._check(self._lib.ba_set_problem(self._h, nc, nt, len(obs_cam), capi.iptr(obs_cam),
+                                             capi.iptr(obs_pt), capi.dptr(obs_z), capi.dptr(K),
+                                             capi.iptr(cam_opt_pos), capi.bptr(pt_opt)))
+        self.nc, self.nt, self.nobs = int(nc), int(nt), len(obs_cam)
+        self.nco = int(np.sum(cam_opt_pos >= 0))
+        self._S_t = self._b_t = None
+        if self._torch is not None:
+            self._bind_reduced()
+
+    def _bind_reduced(self):
+        torch = self._torch
+        dev = torch.device('cuda', self.device)
+        nS, nb = max(1, self.nco * self.nco * 36), max(1, self.nco * 6)
+        self._Sb_t = torch.empty(nS + nb, dtype=torch.float64, device=dev)   # [S | b]: one collective
+        self._S_t, self._b_t = self._Sb_t[:nS], self._Sb_t[nS:]
+        self._check(self._lib.ba_bind_reduced_buffers(self._h, C.c_void_p(self._S_t.data_ptr()),
+                                                      C.c_void_p(self._b_t.data_ptr())))
+
+    def set_sensor(self, kind, params):
+        p = capi.f64(params).reshape(-1)
+        self._check(self._lib.ba_set_sensor(self._h, int(kind), capi.dptr(p), len(p)))
+
+    def set_params(self, which, R, t, X):
+        R, t, X = capi.f64(R, (-1, 9)), capi.f64(t, (-1, 3)), capi.f64(X, (-1, 3))
+        assert len(R) == len(t) == self.nc and len(X) == self.nt
+        self._check(self._lib.ba_set_params(self._h, which, capi.dptr(R), capi.dptr(t), capi.dptr(X)))
+
+    def get_params(self, which):
+        R = np.empty((self.nc, 3, 3))
+        t = np.empty((self.nc, 3))
+        X = np.empty((self.nt, 3))
+        self._check(self._lib.ba_get_params(self._h, which, capi.dptr(R), capi.dptr(t), capi.dptr(X)))
+        return R, t, X
+
+    def swap_params(self):
+        self._check(self._lib.ba_swap_params(self._h))
+
+    # ---------------------------------------------------------------- evaluation
+    def cost(self, which):
+        out = C.c_double()
+        self._check(self._lib.ba_cost(self._h, which, C.byref(out)))
+        return out.value
+
+    def eval_observations(self, which, e=True, r=True, Jc=True, Jp=True):
+        N = self.nobs
+        oe = np.empty((N, 2)) if e else None
+        orr = np.empty((N, 2)) if r else None
+        oJc = np.empty((N, 2, 6)) if Jc else None
+        oJp = np.empty((N, 2, 3)) if Jp else None
+        self._check(self._lib.ba_eval_observations(self._h, which, capi.dptr(oe), capi.dptr(orr),
+                                                   capi.dptr(oJc), capi.dptr(oJp)))
+        return dict(e=oe, r=orr, Jc=oJc, Jp=oJp)
+
+    def eval_sensor(self, e):
+        e = capi.f64(e, (-1, 2))
+        r = np.empty_like(e)
+        J = np.empty((len(e), 2, 2))
+        self._check(self._lib.ba_eval_sensor(self._h, len(e), capi.dptr(e), capi.dptr(r), capi.dptr(J)))
+        return r, J
+
+    # ---------------------------------------------------------------- normal equations
+    def linearize(self, which, store_W=False):
+        self._check(self._lib.ba_linearize(self._h, which, int(bool(store_W))))
+
+    def get_blocks(self, W=False):
+        HCC = np.empty((self.nc, 6, 6))
+        bC = np.empty((self.nc, 6))
+        HPP = np.empty((self.nt, 3, 3))
+        bP = np.empty((self.nt, 3))
+        Wa = np.empty((self.nobs, 6, 3)) if W else None
+        self._check(self._lib.ba_get_blocks(self._h, capi.dptr(HCC), capi.dptr(bC), capi.dptr(HPP),
+                                            capi.dptr(bP), capi.dptr(Wa)))
+        return dict(HCC=HCC, bC=bC, HPP=HPP, bP=bP, W=Wa)
+
+    def schur(self, which, damping, rcond):
+        """rcond None -> plain inverse (SCHUR_COMPLIMENT_PINV_THRESHOLD = None)."""
+        self._check(self._lib.ba_schur(self._h, which, float(damping), -1.0 if rcond is None else float(rcond)))
+
+    def reduced_tensors(self):
+        """torch views (S_blocks[nco*nco*36], b[nco*6]) of the device-resident reduced
+        system - the payload of the multi-GPU all-reduce.  Upper block triangle only."""
+        if self._S_t is None:
+            raise capi.HipDeviceError('reduced_tensors needs torch with a visible GPU')
+        return self._S_t, self._b_t
+
+    def reduced_payload(self):
+        """[S_blocks | b] as ONE contiguous torch tensor: the all-reduce payload."""
+        self.reduced_tensors()
+        return self._Sb_t
+
+    def get_reduced(self):
+        S = np.empty((self.nco, self.nco, 6, 6))
+        b = np.empty((self.nco, 6))
+        self._check(self._lib.ba_get_reduced(self._h, capi.dptr(S), capi.dptr(b)))
+        return S, b
+
+    def get_point_inverses(self):
+        out = np.empty((self.nt, 3, 3))
+        self._check(self._lib.ba_get_point_inverses(self._h, capi.dptr(out)))
+        return out
+
+    def solve_reduced(self, keep):
+        """Solve the reduced camera system restricted to the flat parameter indices
+        ``keep`` (solve_motion_normal_eqns, bundle_adjuster.py:281-312).  Returns the
+        solution for the kept unknowns; raises ReducedSystemSingular."""
+        keep = capi.i32(keep)
+        n = len(keep)
+        if n == 0:
+            return np.zeros(0)
+        torch = self._torch
+        if torch is None:
+            raise capi.HipDeviceError('solve_reduced needs torch with a visible GPU for the device buffers')
+        dev = torch.device('cuda', self.device)
+        if self._A_t is None or self._A_t.numel() < n * n:
+            self._A_t = torch.empty(n * n, dtype=torch.float64, device=dev)
+            self._rhs_t = torch.empty(max(n, self.nco * 6), dtype=torch.float64, device=dev)
+        A = self._A_t[:n * n].view(n, n)
+        rhs = self._rhs_t[:n]
+        self._check(self._lib.ba_flatten_reduced(self._h, capi.iptr(keep), n, C.c_void_p(A.data_ptr()),
+                                                 C.c_void_p(rhs.data_ptr())))
+        if n <= HOST_SOLVE_MAX_UNKNOWNS:
+            try:
+                return np.linalg.solve(A.cpu().numpy(), rhs.cpu().numpy())
+            except np.linalg.LinAlgError:
+                raise ReducedSystemSingular
+        x, info = torch.linalg.solve_ex(A, rhs.unsqueeze(1), check_errors=False)
+        if int(info.item()) != 0:
+            raise ReducedSystemSingular
+        return x.squeeze(1).cpu().numpy()
+
+    def backsubstitute(self, which, dC, fetch=True):
+        dC = capi.f64(dC, (-1, 6))
+        assert len(dC) == self.nco
+        dP = np.empty((self.nt, 3)) if fetch else None
+        self._check(self._lib.ba_backsubstitute(self._h, which, capi.dptr(dC), capi.dptr(dP)))
+        return dP
+
+    def apply_update(self, src, dst, motion=None, structure=None):
+        if motion is not None:
+            motion, structure = capi.f64(motion, (-1, 6)), capi.f64(structure, (-1, 3))
+            assert len(motion) == self.nco and len(structure) == self.nt
+        self._check(self._lib.ba_apply_update(self._h, src, dst, capi.dptr(motion), capi.dptr(structure)))
+
+    # ---------------------------------------------------------------- instrumentation
+    def enable_timing(self, on=True):
+        self._check(self._lib.ba_enable_timing(self._h, int(bool(on))))
+
+    def timings(self, reset=False):
+        ms = np.zeros(capi.K_COUNT)
+        n = np.zeros(capi.K_COUNT, dtype=np.int64)
+        self._check(self._lib.ba_get_timings(self._h, capi.dptr(ms), n.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             int(bool(reset))))
+        return {name: dict(ms=float(ms[i]), launches=int(n[i])) for i, name in enumerate(capi.KERNEL_IDS)}
+
+
+_default = {}
+
+
+def default_backend(device=0):
+    """Process-wide backend used by the Bundle / sensor-model convenience methods."""
+    if device not in _default:
+        _default[device] = HipBackend(device)
+    return _default[device]

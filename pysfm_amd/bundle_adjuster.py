@@ -1,0 +1,440 @@
+"""BundleAdjuster - pysfm's Levenberg-Marquardt bundle adjuster with its arithmetic
+on an MI355X (reference: bundle_adjuster.py:33-343).
+
+Same constructor, methods, return shapes, attributes and exceptions as the
+reference, plus ``step()`` (one outer LM iteration).  What stays in Python is what
+the reference keeps in Python: id / mask bookkeeping (``set_bundle``) and the
+damping / accept / reject schedule (``optimize``).  Every numeric step is a HIP
+kernel behind the C ABI of include/pysfm_ba.h:
+
+    compute_cost              -> ba_cost                    (k_cost)
+    prepare_schur_complement  -> ba_linearize               (k_linearize)
+    apply_damping + compute_schur_complement -> ba_schur    (k_point_invert, k_schur_init, k_schur_pairs)
+    solve_motion_normal_eqns  -> ba_flatten_reduced (k_flatten) + LAPACK / rocSOLVER LU
+    backsubstitute            -> ba_backsubstitute          (k_backsub)
+    update_motion / update_structure -> ba_apply_update     (k_apply_update)
+
+During ``optimize`` the accepted and the trial parameter sets both live on the GPU;
+``self.bundle`` is materialised on the host only when somebody reads it.
+"""
+from copy import copy
+
+import numpy as np
+
+from ._capi import PARAMS_CUR, PARAMS_TRIAL
+from .backend import ReducedSystemSingular
+from .sensor_model import device_params_of
+
+
+############################################################################
+def select(L, mask):
+    """Subset of L by boolean mask or by explicit ids (bundle_adjuster.py:11-24)."""
+    L = np.asarray(L)
+    mask = np.asarray(mask)
+    if mask.dtype.kind == 'b':
+        assert len(mask) == len(L)
+        subset = L[mask]
+    else:
+        assert mask.dtype.kind == L.dtype.kind
+        assert set(mask.tolist()).issubset(L.tolist()), 'Mask contained some items not in L'
+        subset = mask
+    lookup = {v: i for i, v in enumerate(L.tolist())}
+    subset_indices = [lookup[v] for v in subset.tolist()]
+    return subset, subset_indices
+
+
+############################################################################
+class NormalEquationsIllconditioned(Exception):
+    '''Thrown when the bundle adjuster fails to solve a set of normal
+    equations (bundle_adjuster.py:27-30)'''
+    pass
+
+
+############################################################################
+class BundleAdjuster(object):
+    # The threshold applied to singular values when inverting the lower-diagonal
+    # (HPP) blocks for the schur compliment.  None = full inverse
+    # (bundle_adjuster.py:37).
+    SCHUR_COMPLIMENT_PINV_THRESHOLD = 1e-5
+
+    def __init__(self, bundle=None, backend=None, device=0, comm=None, verbose=True):
+        '''bundle: a Bundle (ours, or any object with the reference Bundle's attributes).
+        backend: compute backend; default = a new HipBackend on `device`.
+        comm: optional pysfm_amd.distributed.ShardComm - this process then holds one
+        shard of the tracks and the reduced camera system is all-reduced over RCCL.'''
+        self.num_steps = 0
+        self.converged = False
+        self.costs = []
+        self.verbose = verbose
+        self._backend = backend
+        self._device = device
+        self._comm = comm
+        self._host_bundle = None
+        self._host_stale = False
+        self._damp_factor = 1.
+        self._have_blocks = False
+        self._damping = 10.
+        self.lm_trials = 0
+        if bundle is not None:
+            self.set_bundle(bundle)
+
+    def _say(self, msg):
+        if self.verbose:
+            print(msg)
+
+    @property
+    def backend(self):
+        if self._backend is None:
+            from .backend import HipBackend      # raises if libpysfm_ba.so / the GPU is missing
+            self._backend = HipBackend(self._device)
+        return self._backend
+
+    # ------------------------------------------------------------------ bundle <-> device
+    @property
+    def bundle(self):
+        '''The current (accepted) bundle.  After optimize() this is a NEW bundle; the
+        one passed to set_bundle is never mutated (bundle_adjuster.py:151).'''
+        if self._host_stale:
+            R, t, X = self.backend.get_params(PARAMS_CUR)
+            b = self._host_bundle.clone_params()
+            for pos, idx in enumerate(self.camera_ids):
+                b.cameras[idx].R = R[pos].copy()
+                b.cameras[idx].t = t[pos].copy()
+            b.reconstruction[np.asarray(self.track_ids, int)] = X
+            self._host_bundle = b
+            self._host_stale = False
+        return self._host_bundle
+
+    @bundle.setter
+    def bundle(self, b):
+        self._host_bundle = b
+        self._host_stale = False
+        if getattr(self, 'camera_ids', None) is not None:
+            self._upload(b, PARAMS_CUR)
+
+    def _params_of(self, bundle):
+        R = np.array([bundle.cameras[i].R for i in self.camera_ids], float).reshape(-1, 3, 3)
+        t = np.array([bundle.cameras[i].t for i in self.camera_ids], float).reshape(-1, 3)
+        X = np.asarray(bundle.reconstruction, float)[np.asarray(self.track_ids, int)].reshape(-1, 3)
+        return R, t, X
+
+    def _upload(self, bundle, which):
+        self.backend.set_params(which, *self._params_of(bundle))
+
+    # ------------------------------------------------------------------ set_bundle
+    def set_bundle(self, bundle, camera_ids=None, track_ids=None, camera_mask=None, track_mask=None):
+        '''Configure the bundle this adjuster operates on (bundle_adjuster.py:54-114).
+        camera_ids / track_ids select the cameras / tracks whose measurements are used;
+        camera_mask / track_mask (bool array over the selection, or a list of ids)
+        select what is updated.  Default: all cameras but the first, all tracks.'''
+        bundle.check_consistency()
+        self._host_bundle = bundle
+        self._host_stale = False
+
+        if camera_ids is None:
+            self.camera_ids = list(range(len(bundle.cameras)))
+        else:
+            self.camera_ids = [c for c in camera_ids]
+            assert isinstance(self.camera_ids[0], (int, np.integer))
+            assert min(self.camera_ids) >= 0
+            assert max(self.camera_ids) < len(bundle.cameras)
+            self.camera_ids = [int(c) for c in self.camera_ids]
+
+        if track_ids is None:
+            self.track_ids = list(range(len(bundle.tracks)))
+        else:
+            self.track_ids = [t for t in track_ids]
+            assert isinstance(self.track_ids[0], (int, np.integer))
+            assert min(self.track_ids) >= 0
+            assert max(self.track_ids) < len(bundle.tracks)
+            self.track_ids = [int(t) for t in self.track_ids]
+
+        self.camera_id_set = set(self.camera_ids)
+
+        if camera_mask is None:
+            assert len(self.camera_ids) > 1, 'Cannot optimize just one camera'
+            self.optim_camera_ids = self.camera_ids[1:]
+            self.optim_camera_indices = list(range(1, len(self.camera_ids)))
+        else:
+            ids, self.optim_camera_indices = select(self.camera_ids, camera_mask)
+            self.optim_camera_ids = [int(c) for c in ids]
+
+        if track_mask is None:
+            self.optim_track_ids = copy(self.track_ids)
+            self.optim_track_indices = list(range(len(self.track_ids)))
+        else:
+            ids, self.optim_track_indices = select(self.track_ids, track_mask)
+            self.optim_track_ids = [int(t) for t in ids]
+
+        assert len(self.optim_track_ids) == len(self.optim_track_indices)
+        assert len(self.optim_camera_ids) == len(self.optim_camera_indices)
+
+        nc, nt = len(self.camera_ids), len(self.track_ids)
+        # device problem: observation SoA ordered by track position, flags, positions
+        if hasattr(bundle, 'select_observations'):
+            obs_cam, obs_pt, obs_z = bundle.select_observations(self.camera_ids, self.track_ids)
+        else:
+            obs_cam, obs_pt, obs_z = _select_observations_generic(bundle, self.camera_ids, self.track_ids)
+        cam_opt_pos = -np.ones(nc, np.int32)
+        cam_opt_pos[np.asarray(self.optim_camera_indices, int)] = np.arange(len(self.optim_camera_indices))
+        pt_opt = np.zeros(nt, np.uint8)
+        pt_opt[np.asarray(self.optim_track_indices, int)] = 1
+        self._cam_opt_pos, self._pt_opt = cam_opt_pos, pt_opt
+        self._nobs = len(obs_cam)
+
+        be = self.backend
+        be.set_problem(nc, nt, obs_cam, obs_pt, obs_z, np.asarray(bundle.K, float), cam_opt_pos, pt_opt)
+        be.set_sensor(*device_params_of(bundle.sensor_model))
+        self._upload(bundle, PARAMS_CUR)
+        self._have_blocks = False
+        self._damp_factor = 1.
+        self._say('Configured a bundle adjuster for %d cameras, %d tracks' % (nc, nt))
+
+    # ------------------------------------------------------------------ LM loop
+    def optimize(self, param_mask=None, max_steps=25, init_damping=10., improvement_threshold=1e-4):
+        '''Optimize the current bundle to convergence (bundle_adjuster.py:117-162).'''
+        self._damping = init_damping
+        self.num_steps = 0
+        self.lm_trials = 0
+        self.converged = False
+        self.costs = [self._cost(PARAMS_CUR)]
+        while not self.converged and self.num_steps < max_steps:
+            self.step(param_mask, improvement_threshold)
+        if self.converged:
+            self._say('Converged after %d steps' % self.num_steps)
+        else:
+            self._say('Failed to converge after %d steps' % self.num_steps)
+
+    def step(self, param_mask=None, improvement_threshold=1e-4):
+        '''One outer iteration of optimize(): retry with growing damping until a trial
+        lowers the cost (bundle_adjuster.py:128-157; cf. optimize.py:110-135).
+        Returns self.converged.'''
+        if not self.costs:
+            self.costs = [self._cost(PARAMS_CUR)]
+        self.num_steps += 1
+        cur_cost = self._cost(PARAMS_CUR)
+        self._say('Step %d: cost=%f, damping=%f' % (self.num_steps, cur_cost, self._damping))
+        while not self.converged and self._damping < 1e+8:
+            accepted, next_cost = self.trial(self._damping, param_mask, cur_cost)
+            if accepted is None:                       # ill-conditioned: raise damping
+                self._damping *= 10.
+                self.converged = self._damping > 1e+8
+                continue
+            if accepted:
+                self._damping *= .1
+                self.costs.append(next_cost)
+                self.converged = abs(cur_cost - next_cost) < improvement_threshold
+                break
+            else:
+                self._damping *= 10.
+                self.converged = self._damping > 1e+8
+        return self.converged
+
+    def trial(self, damping, param_mask, cur_cost):
+        '''One LM trial, entirely device-resident: linearise, damp, Schur, solve,
+        back-substitute, apply to the trial set, evaluate.  Accepts (swaps the
+        parameter sets) iff the cost went down.  Returns (accepted | None, next_cost).'''
+        self.lm_trials += 1
+        try:
+            self._compute_update_device(damping, param_mask, fetch=False)
+        except NormalEquationsIllconditioned:
+            return None, None
+        self.backend.apply_update(PARAMS_CUR, PARAMS_TRIAL)     # bnext = clone; update_motion/structure
+        next_cost = self._cost(PARAMS_TRIAL)
+        if next_cost < cur_cost:
+            self.backend.swap_params()                          # self.bundle = bnext
+            self._host_stale = True
+            self._have_blocks = False
+            return True, next_cost
+        return False, next_cost
+
+    # ------------------------------------------------------------------ cost
+    def _cost(self, which):
+        c = self.backend.cost(which)
+        if self._comm is not None:
+            c = self._comm.allreduce_scalar(c)
+        return c
+
+    def compute_cost(self, bundle):
+        '''Sum of squared residuals over optim_track_ids x optim_camera_ids
+        (bundle_adjuster.py:165-171).'''
+        if bundle is self._host_bundle:          # the device copy is the master of this one
+            return self._cost(PARAMS_CUR)
+        self._upload(bundle, PARAMS_TRIAL)
+        return self._cost(PARAMS_TRIAL)
+
+    # ------------------------------------------------------------------ update
+    def _cam_param_mask(self, param_mask):
+        nc = len(self.optim_camera_ids)
+        nt = len(self.optim_track_ids)
+        nparams = 6 * nc + 3 * nt
+        if param_mask is None:
+            return np.ones(nc * 6, bool)
+        param_mask = np.asarray(param_mask)
+        assert param_mask.dtype.kind == 'b'
+        assert np.shape(param_mask) == (nparams,), \
+            'param_mask had shape %s but there are %d parameters' % (str(np.shape(param_mask)), nparams)
+        assert np.all(param_mask[nc * 6:]), 'Eliminating point parameters not implemented'
+        return param_mask[:nc * 6]
+
+    def _compute_update_device(self, damping, param_mask, fetch):
+        cam_param_mask = self._cam_param_mask(param_mask)
+        be = self.backend
+        be.linearize(PARAMS_CUR)
+        self._have_blocks = True
+        self._damp_factor = 1. + damping
+        self._schur_device()
+        keep = np.nonzero(cam_param_mask)[0].astype(np.int32)
+        try:
+            x = be.solve_reduced(keep)
+        except ReducedSystemSingular:
+            raise NormalEquationsIllconditioned
+        dC = np.zeros(len(cam_param_mask))
+        dC[keep] = x
+        dC = dC.reshape(-1, 6)
+        dP = be.backsubstitute(PARAMS_CUR, dC, fetch=fetch)
+        return dC, dP
+
+    def _schur_device(self):
+        be = self.backend
+        be.schur(PARAMS_CUR, self._damp_factor - 1., self.SCHUR_COMPLIMENT_PINV_THRESHOLD)
+        if self._comm is not None:
+            self._comm.allreduce_reduced(be)
+
+    def compute_update(self, damping, param_mask=None):
+        '''Solve the normal equations using the Schur complement.  Returns
+        (update-for-cameras [nco,6], update-for-points [nto,3]) - bundle_adjuster.py:176-208.'''
+        dC, dP = self._compute_update_device(damping, param_mask, fetch=True)
+        return -dC, -dP[np.asarray(self.optim_track_indices, int)]
+
+    def prepare_schur_complement(self):
+        '''Hessian blocks HCC, HPP, HCP and gradients bC, bP (bundle_adjuster.py:211-234).'''
+        self.backend.linearize(PARAMS_CUR, store_W=True)
+        self._have_blocks = True
+        self._damp_factor = 1.
+        self._blocks_cache = None
+
+    def _blocks(self):
+        assert self._have_blocks, 'call prepare_schur_complement() first'
+        if getattr(self, '_blocks_cache', None) is None:
+            d = self.backend.get_blocks(W=True)
+            if self._comm is not None:          # camera blocks are sums over all shards
+                d['HCC'] = self._comm.allreduce_array(d['HCC'])
+                d['bC'] = self._comm.allreduce_array(d['bC'])
+            self._blocks_cache = d
+        return self._blocks_cache
+
+    @property
+    def HCCs(self):
+        f = np.ones((6, 6)) + (self._damp_factor - 1.) * np.eye(6)
+        return self._blocks()['HCC'] * f
+
+    @property
+    def HPPs(self):
+        f = np.ones((3, 3)) + (self._damp_factor - 1.) * np.eye(3)
+        return self._blocks()['HPP'] * f
+
+    @property
+    def bCs(self):
+        return self._blocks()['bC']
+
+    @property
+    def bPs(self):
+        return self._blocks()['bP']
+
+    @property
+    def HCPs(self):
+        '''Dense (nc, nt, 6, 3) array like the reference's (bundle_adjuster.py:107); built
+        on demand from the per-observation blocks - only sensible for small scenes.'''
+        nc, nt = len(self.camera_ids), len(self.track_ids)
+        if nc * nt * 18 * 8 > 2 ** 31:
+            raise MemoryError('dense HCPs would need %.1f GB; use backend.get_blocks(W=True)' % (nc * nt * 144 / 1e9))
+        out = np.zeros((nc, nt, 6, 3))
+        cam, pt, _ = (self._host_bundle.select_observations(self.camera_ids, self.track_ids)
+                      if hasattr(self._host_bundle, 'select_observations')
+                      else _select_observations_generic(self._host_bundle, self.camera_ids, self.track_ids))
+        out[cam, pt] = self._blocks()['W']
+        return out
+
+    @property
+    def HPP_invs(self):
+        return self.backend.get_point_inverses()
+
+    def apply_damping(self, damping):
+        '''diag *= (1 + damping) on every HCC / HPP block (bundle_adjuster.py:238-242).
+        Calls compound, as in the reference.'''
+        assert self._have_blocks, 'call prepare_schur_complement() first'
+        self._damp_factor *= (1. + damping)
+
+    def compute_schur_complement(self):
+        '''Reduced camera system (S [nco,nco,6,6], b [nco,6]) - bundle_adjuster.py:247-278.'''
+        assert self._have_blocks, 'call prepare_schur_complement() first'
+        self._schur_device()
+        return self.backend.get_reduced()
+
+    def solve_motion_normal_eqns(self, S, b, param_mask):
+        '''Solve the (masked) reduced system given as host arrays (bundle_adjuster.py:281-312).
+        This host step is the reference's own numpy.linalg.solve call; compute_update()
+        uses the device-resident system instead.'''
+        nc = len(self.optim_camera_ids)
+        assert np.shape(S) == (nc, nc, 6, 6)
+        assert np.shape(b) == (nc, 6)
+        assert np.shape(param_mask) == (nc * 6,), 'shape was ' + str(np.shape(param_mask))
+        param_mask = np.asarray(param_mask, bool)
+        AC = np.asarray(S).transpose((0, 2, 1, 3)).reshape((nc * 6, nc * 6))
+        bC = np.asarray(b).reshape(-1)
+        AC_reduced = AC[param_mask].T[param_mask].T
+        bC_reduced = bC[param_mask]
+        try:
+            dC_reduced = np.linalg.solve(AC_reduced, bC_reduced)
+        except np.linalg.LinAlgError:
+            raise NormalEquationsIllconditioned
+        dC = np.zeros(nc * 6)
+        dC[param_mask] = dC_reduced
+        return dC.reshape(nc, 6)
+
+    def backsubstitute(self, dC):
+        '''Point updates from the camera update (bundle_adjuster.py:316-331).'''
+        dP = self.backend.backsubstitute(PARAMS_CUR, np.asarray(dC, float), fetch=True)
+        return dP[np.asarray(self.optim_track_indices, int)]
+
+    # ------------------------------------------------------------------ parameter update
+    def _apply_on_device(self, motion, structure, bundle):
+        be = self.backend
+        self._upload(bundle, PARAMS_TRIAL)
+        be.apply_update(PARAMS_TRIAL, PARAMS_TRIAL, motion, structure)
+        R, t, X = be.get_params(PARAMS_TRIAL)
+        return R, t, X
+
+    def update_motion(self, delta, bundle):
+        '''cam.R <- R exp(delta[:3]), cam.t += delta[3:] for the optimised cameras
+        (bundle_adjuster.py:334-337), evaluated by k_apply_update.'''
+        assert np.shape(delta) == (len(self.optim_camera_ids), 6)
+        R, t, _ = self._apply_on_device(delta, np.zeros((len(self.track_ids), 3)), bundle)
+        for pos, idx in zip(self.optim_camera_indices, self.optim_camera_ids):
+            bundle.cameras[idx].R = R[pos].copy()
+            bundle.cameras[idx].t = t[pos].copy()
+
+    def update_structure(self, delta, bundle):
+        '''reconstruction[idx] += delta for the optimised tracks (bundle_adjuster.py:340-343).'''
+        assert np.shape(delta) == (len(self.optim_track_ids), 3)
+        full = np.zeros((len(self.track_ids), 3))
+        full[np.asarray(self.optim_track_indices, int)] = delta
+        _, _, X = self._apply_on_device(np.zeros((len(self.optim_camera_ids), 6)), full, bundle)
+        for pos, idx in zip(self.optim_track_indices, self.optim_track_ids):
+            bundle.reconstruction[idx] = X[pos]
+
+
+def _select_observations_generic(bundle, camera_ids, track_ids):
+    """select_observations for foreign Bundle objects (e.g. the reference's own class)."""
+    cam_pos = {c: p for p, c in enumerate(camera_ids)}
+    cam, pt, z = [], [], []
+    for jpos, j in enumerate(track_ids):
+        tr = bundle.tracks[j]
+        items = [(cam_pos[i], m) for i, m in tr.measurements.items() if i in cam_pos]
+        items.sort(key=lambda it: it[0])
+        for ipos, m in items:
+            cam.append(ipos)
+            pt.append(jpos)
+            z.append(np.asarray(m, float))
+    return np.array(cam, np.int32), np.array(pt, np.int32), np.array(z, float).reshape(-1, 2)

@@ -1,0 +1,745 @@
+// ba_capi.hip - host side of libpysfm_ba.so: the opaque handle, device buffers,
+// kernel launches and the C ABI declared in include/pysfm_ba.h.
+#include "../../include/pysfm_ba.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ba_kernels.h"
+
+using namespace ba;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t resize(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct TimedLaunch { int id; hipEvent_t a, b; };
+
+}  // namespace
+
+struct ba_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // problem
+  int nc = 0, nt = 0, nco = 0;
+  long long nobs = 0;
+  bool have_problem = false;
+  bool have_params[2] = {false, false};
+  bool have_linearization = false, have_schur = false, have_backsub = false;
+  int glog = 0;              // lanes per point = 2^glog
+  double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0};
+  DevBuf<int> obs_cam, obs_pt, pt_off, cam_opt_pos, keep;
+  DevBuf<double2> obs_z;
+  DevBuf<unsigned char> pt_opt;
+  DevBuf<SchurUnit> units;
+  int nunits = 0;
+  std::vector<int> h_cam_opt_pos;
+  std::vector<unsigned char> h_pt_opt;
+
+  // parameters: cams[which] = nc x [R(9) | t(3)], X[which] = nt x 3
+  DevBuf<double> cams[2], X[2];
+  int cur = 0;               // physical index of BA_PARAMS_CUR
+
+  // normal-equation blocks
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dCfull, dP, partial, scalar, scratch;
+  DevBuf<int> flags;
+  double* S = nullptr;       // nco*nco*36 (own or bound)
+  double* b = nullptr;       // nco*6
+  bool mirrored = false;
+
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<TimedLaunch> pending;
+  double ms[BA_K_COUNT] = {0};
+  long long launches[BA_K_COUNT] = {0};
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  int phys(int which) const { return which == BA_PARAMS_CUR ? cur : 1 - cur; }
+};
+
+#define HIPCHECK(h, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return (h)->fail(e_ == hipErrorOutOfMemory ? BA_ERR_NOMEM : BA_ERR_HIP, "%s failed: %s (%s:%d)", \
+                       #call, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+  } while (0)
+
+#define REQUIRE(h, cond, code, msg) \
+  do { if (!(cond)) return (h)->fail(code, "%s", msg); } while (0)
+
+namespace {
+
+hipEvent_t get_event(ba_handle* h) {
+  if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void resolve_timings(ba_handle* h) {
+  if (h->pending.empty()) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& t : h->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { h->ms[t.id] += ms; h->launches[t.id] += 1; }
+    h->ev_pool.push_back(t.a);
+    h->ev_pool.push_back(t.b);
+  }
+  h->pending.clear();
+}
+
+struct ScopedTimer {
+  ba_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(ba_handle* h_, int id_) : h(h_), id(id_) {
+    if (h->timing) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+  }
+  ~ScopedTimer() {
+    if (h->timing) {
+      (void)hipEventRecord(b, h->stream);
+      h->pending.push_back({id, a, b});
+      if (h->pending.size() >= 8192) resolve_timings(h);
+    }
+  }
+};
+
+inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + kBlock - 1) / kBlock); }
+
+DevProblem dev_problem(const ba_handle* h) {
+  DevProblem P;
+  P.nc = h->nc; P.nt = h->nt; P.nco = h->nco; P.nobs = h->nobs;
+  P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p; P.obs_z = h->obs_z.p; P.pt_off = h->pt_off.p;
+  P.cam_opt_pos = h->cam_opt_pos.p; P.pt_opt = h->pt_opt.p;
+  std::memcpy(P.K, h->K, sizeof P.K);
+  P.sensor = h->sensor;
+  return P;
+}
+
+int ensure_reduced(ba_handle* h) {
+  if (!h->S) {
+    HIPCHECK(h, h->S_own.resize(std::max<size_t>(1, (size_t)h->nco * h->nco * 36)));
+    h->S = h->S_own.p;
+  }
+  if (!h->b) {
+    HIPCHECK(h, h->b_own.resize(std::max<size_t>(1, (size_t)h->nco * 6)));
+    h->b = h->b_own.p;
+  }
+  return BA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ba_version(void) { return "pysfm_ba 0.1 (gfx950)"; }
+
+const char* ba_kernel_name(int id) {
+  static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
+                                          "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
+                                          "k_mirror", "k_eval"};
+  return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
+}
+
+const char* ba_last_error(const ba_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ba_create(int device_id, ba_handle** out) {
+  if (!out) { g_create_error = "ba_create: out is NULL"; return BA_ERR_INVALID_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("ba_create: no HIP device available (") +
+                     (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") + ")";
+    return BA_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    g_create_error = "ba_create: device_id out of range";
+    return BA_ERR_INVALID_ARG;
+  }
+  if ((e = hipSetDevice(device_id)) != hipSuccess) {
+    g_create_error = std::string("ba_create: hipSetDevice failed: ") + hipGetErrorString(e);
+    return BA_ERR_HIP;
+  }
+  ba_handle* h = new ba_handle();
+  h->device = device_id;
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_error = std::string("ba_create: hipStreamCreate failed: ") + hipGetErrorString(e);
+    delete h;
+    return BA_ERR_HIP;
+  }
+  h->own_stream = true;
+  *out = h;
+  return BA_OK;
+}
+
+int ba_destroy(ba_handle* h) {
+  if (!h) return BA_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release();
+  for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
+  h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
+  h->W.release(); h->S_own.release(); h->b_own.release(); h->dCfull.release(); h->dP.release();
+  h->partial.release(); h->scalar.release(); h->scratch.release(); h->flags.release();
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return BA_OK;
+}
+
+int ba_set_stream(ba_handle* h, void* hip_stream) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  HIPCHECK(h, hipSetDevice(h->device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  resolve_timings(h);
+  if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
+  if (hip_stream) {
+    h->stream = (hipStream_t)hip_stream;
+  } else {
+    HIPCHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return BA_OK;
+}
+
+int ba_synchronize(ba_handle* h) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  HIPCHECK(h, hipSetDevice(h->device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
+                   const int32_t* obs_pt, const double* obs_z, const double* K,
+                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
+  REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
+  REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
+          "ba_set_problem: NULL argument");
+  REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
+  HIPCHECK(h, hipSetDevice(h->device));
+
+  // validate + CSR offsets by point
+  std::vector<int> off((size_t)nt + 1, 0);
+  for (int64_t n = 0; n < nobs; ++n) {
+    const int c = obs_cam[n], k = obs_pt[n];
+    if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%lld]=%d out of range", (long long)n, c);
+    if (k < 0 || k >= nt) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%lld]=%d out of range", (long long)n, k);
+    if (n > 0 && k < obs_pt[n - 1]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: observations must be ordered by track position (obs %lld)", (long long)n);
+    off[(size_t)k + 1] += 1;
+  }
+  for (int k = 0; k < nt; ++k) off[(size_t)k + 1] += off[k];
+  // optimised-camera positions must be a permutation of 0..nco-1
+  int nco = 0;
+  for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) ++nco;
+  {
+    std::vector<char> seen((size_t)nco, 0);
+    for (int i = 0; i < nc; ++i) {
+      const int p = cam_opt_pos[i];
+      if (p < 0) continue;
+      if (p >= nco || seen[p]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: cam_opt_pos is not a permutation of 0..nco-1");
+      seen[p] = 1;
+    }
+  }
+  // Schur work units: (point, row tile, col tile >= row tile)
+  std::vector<SchurUnit> units;
+  units.reserve((size_t)nt);
+  long long maxL = 0;
+  for (int k = 0; k < nt; ++k) {
+    const int L = off[(size_t)k + 1] - off[k];
+    maxL = std::max<long long>(maxL, L);
+    for (int r = 0; r < L; r += kTile)
+      for (int c = r; c < L; c += kTile) units.push_back({k, r, c});
+  }
+  // lanes per point: smallest power of two >= mean track length, in [1, 64]
+  int glog = 0;
+  const double meanL = nt > 0 ? (double)nobs / nt : 1.0;
+  while ((1 << glog) < meanL && glog < 6) ++glog;
+
+  h->nc = nc; h->nt = nt; h->nco = nco; h->nobs = nobs; h->glog = glog;
+  std::memcpy(h->K, K, sizeof h->K);
+  h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
+  h->h_pt_opt.assign(pt_opt, pt_opt + nt);
+  h->nunits = (int)units.size();
+
+  HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, nobs)));
+  HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, nobs)));
+  HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, nobs)));
+  HIPCHECK(h, h->pt_off.resize((size_t)nt + 1));
+  HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
+  HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
+  HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
+  if (nobs) {
+    HIPCHECK(h, hipMemcpyAsync(h->obs_cam.p, obs_cam, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->obs_pt.p, obs_pt, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->obs_z.p, obs_z, nobs * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(h, hipMemcpyAsync(h->pt_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (nc) HIPCHECK(h, hipMemcpyAsync(h->cam_opt_pos.p, cam_opt_pos, nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (nt) HIPCHECK(h, hipMemcpyAsync(h->pt_opt.p, pt_opt, nt, hipMemcpyHostToDevice, h->stream));
+  if (!units.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->units.p, units.data(), units.size() * sizeof(SchurUnit), hipMemcpyHostToDevice, h->stream));
+
+  for (int i = 0; i < 2; ++i) {
+    HIPCHECK(h, h->cams[i].resize(std::max<size_t>(1, (size_t)nc * 12)));
+    HIPCHECK(h, h->X[i].resize(std::max<size_t>(1, (size_t)nt * 3)));
+  }
+  HIPCHECK(h, h->HCC.resize(std::max<size_t>(1, (size_t)nc * 36)));
+  HIPCHECK(h, h->bC.resize(std::max<size_t>(1, (size_t)nc * 6)));
+  HIPCHECK(h, h->HPP.resize(std::max<size_t>(1, (size_t)nt * 6)));
+  HIPCHECK(h, h->bP.resize(std::max<size_t>(1, (size_t)nt * 3)));
+  HIPCHECK(h, h->HPPinv.resize(std::max<size_t>(1, (size_t)nt * 6)));
+  HIPCHECK(h, h->dCfull.resize(std::max<size_t>(1, (size_t)nc * 6)));
+  HIPCHECK(h, h->dP.resize(std::max<size_t>(1, (size_t)nt * 3)));
+  HIPCHECK(h, h->partial.resize(2048));
+  HIPCHECK(h, h->scalar.resize(8));
+  HIPCHECK(h, h->flags.resize(8));
+  // a reduced system bound for another problem size is no longer valid
+  h->S = nullptr; h->b = nullptr;
+  h->have_problem = true;
+  h->have_params[0] = h->have_params[1] = false;
+  h->have_linearization = h->have_schur = h->have_backsub = false;
+  h->cur = 0;
+  HIPCHECK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
+  return BA_OK;
+}
+
+int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  Sensor s{kind, {1, 0, 0, 1}, 1.0, 1.0};
+  switch (kind) {
+    case BA_SENSOR_GAUSS:
+      REQUIRE(h, params && nparams == 4, BA_ERR_INVALID_ARG, "ba_set_sensor: Gaussian needs 4 params (L row-major)");
+      for (int i = 0; i < 4; ++i) s.L[i] = params[i];
+      break;
+    case BA_SENSOR_CAUCHY:
+      REQUIRE(h, params && nparams == 1 && params[0] > 0, BA_ERR_INVALID_ARG, "ba_set_sensor: Cauchy needs sigma > 0");
+      s.sigma = params[0];
+      break;
+    case BA_SENSOR_HUBER:
+      REQUIRE(h, params && nparams == 1 && params[0] > 0, BA_ERR_INVALID_ARG, "ba_set_sensor: Huber needs k > 0");
+      s.k = params[0];
+      break;
+    default:
+      return h->fail(BA_ERR_INVALID_ARG, "ba_set_sensor: unknown kind %d", kind);
+  }
+  h->sensor = s;
+  h->have_linearization = h->have_schur = h->have_backsub = false;
+  return BA_OK;
+}
+
+int ba_set_params(ba_handle* h, int which, const double* R, const double* t, const double* X) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_set_params: call ba_set_problem first");
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_set_params: bad parameter set");
+  REQUIRE(h, (h->nc == 0 || (R && t)) && (h->nt == 0 || X), BA_ERR_INVALID_ARG, "ba_set_params: NULL argument");
+  HIPCHECK(h, hipSetDevice(h->device));
+  const int p = h->phys(which);
+  std::vector<double> packed((size_t)h->nc * 12);
+  for (int i = 0; i < h->nc; ++i) {
+    std::memcpy(&packed[(size_t)i * 12], R + (size_t)i * 9, 9 * sizeof(double));
+    std::memcpy(&packed[(size_t)i * 12 + 9], t + (size_t)i * 3, 3 * sizeof(double));
+  }
+  if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->cams[p].p, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->nt) HIPCHECK(h, hipMemcpyAsync(h->X[p].p, X, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  h->have_params[p] = true;
+  if (which == BA_PARAMS_CUR) h->have_linearization = h->have_schur = h->have_backsub = false;
+  return BA_OK;
+}
+
+int ba_get_params(ba_handle* h, int which, double* R, double* t, double* X) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_get_params: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_get_params: parameter set is empty");
+  HIPCHECK(h, hipSetDevice(h->device));
+  std::vector<double> packed((size_t)h->nc * 12);
+  if (h->nc) HIPCHECK(h, hipMemcpyAsync(packed.data(), h->cams[p].p, packed.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (h->nt && X) HIPCHECK(h, hipMemcpyAsync(X, h->X[p].p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->nc; ++i) {
+    if (R) std::memcpy(R + (size_t)i * 9, &packed[(size_t)i * 12], 9 * sizeof(double));
+    if (t) std::memcpy(t + (size_t)i * 3, &packed[(size_t)i * 12 + 9], 3 * sizeof(double));
+  }
+  return BA_OK;
+}
+
+int ba_swap_params(ba_handle* h) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem && h->have_params[1 - h->cur], BA_ERR_STATE, "ba_swap_params: trial set is empty");
+  h->cur = 1 - h->cur;
+  h->have_linearization = h->have_schur = h->have_backsub = false;
+  return BA_OK;
+}
+
+int ba_cost(ba_handle* h, int which, double* cost_out) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, cost_out, BA_ERR_INVALID_ARG, "ba_cost: cost_out is NULL");
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_cost: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_cost: set problem and parameters first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  const int nb = (int)std::min<long long>(2048, blocks_for(h->nobs));
+  {
+    ScopedTimer tm(h, BA_K_COST);
+    hipLaunchKernelGGL(k_cost, dim3(nb), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p, h->partial.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, h->stream, h->partial.p, nb, h->scalar.p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  HIPCHECK(h, hipMemcpyAsync(cost_out, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+int ba_eval_observations(ba_handle* h, int which, double* e, double* r, double* Jc, double* Jp) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_eval_observations: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_eval_observations: set problem and parameters first");
+  if (h->nobs == 0) return BA_OK;
+  HIPCHECK(h, hipSetDevice(h->device));
+  const size_t N = (size_t)h->nobs;
+  const size_t need = (e ? 2 * N : 0) + (r ? 2 * N : 0) + (Jc ? 12 * N : 0) + (Jp ? 6 * N : 0);
+  if (!need) return BA_OK;
+  HIPCHECK(h, h->scratch.resize(need));
+  double* d = h->scratch.p;
+  double* de = nullptr; double* dr = nullptr; double* dJc = nullptr; double* dJp = nullptr;
+  if (e) { de = d; d += 2 * N; }
+  if (r) { dr = d; d += 2 * N; }
+  if (Jc) { dJc = d; d += 12 * N; }
+  if (Jp) { dJp = d; d += 6 * N; }
+  {
+    ScopedTimer tm(h, BA_K_EVAL);
+    hipLaunchKernelGGL(k_eval, dim3(blocks_for(h->nobs)), dim3(kBlock), 0, h->stream, dev_problem(h),
+                       h->cams[p].p, h->X[p].p, de, dr, dJc, dJp);
+  }
+  HIPCHECK(h, hipGetLastError());
+  if (e) HIPCHECK(h, hipMemcpyAsync(e, de, 2 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (r) HIPCHECK(h, hipMemcpyAsync(r, dr, 2 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (Jc) HIPCHECK(h, hipMemcpyAsync(Jc, dJc, 12 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (Jp) HIPCHECK(h, hipMemcpyAsync(Jp, dJp, 6 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+int ba_eval_sensor(ba_handle* h, int64_t n, const double* e, double* r, double* J) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, n >= 0 && (n == 0 || e), BA_ERR_INVALID_ARG, "ba_eval_sensor: bad arguments");
+  if (n == 0 || (!r && !J)) return BA_OK;
+  HIPCHECK(h, hipSetDevice(h->device));
+  const size_t N = (size_t)n;
+  HIPCHECK(h, h->scratch.resize(8 * N));
+  double* de = h->scratch.p;
+  double* dr = de + 2 * N;
+  double* dJ = dr + 2 * N;
+  HIPCHECK(h, hipMemcpyAsync(de, e, 2 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  {
+    ScopedTimer tm(h, BA_K_EVAL);
+    hipLaunchKernelGGL(k_eval_sensor, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, h->sensor, (long long)n, de,
+                       r ? dr : nullptr, J ? dJ : nullptr);
+  }
+  HIPCHECK(h, hipGetLastError());
+  if (r) HIPCHECK(h, hipMemcpyAsync(r, dr, 2 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (J) HIPCHECK(h, hipMemcpyAsync(J, dJ, 4 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+int ba_linearize(ba_handle* h, int which, int store_W) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_linearize: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_linearize: set problem and parameters first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  double* Wd = nullptr;
+  if (store_W) {
+    HIPCHECK(h, h->W.resize(std::max<size_t>(1, (size_t)h->nobs * 18)));
+    Wd = h->W.p;
+  }
+  HIPCHECK(h, hipMemsetAsync(h->HCC.p, 0, (size_t)h->nc * 36 * sizeof(double), h->stream));
+  HIPCHECK(h, hipMemsetAsync(h->bC.p, 0, (size_t)h->nc * 6 * sizeof(double), h->stream));
+  if (h->nt > 0) {
+    ScopedTimer tm(h, BA_K_LINEARIZE);
+    const long long threads = (long long)h->nt << h->glog;
+    hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
+                       h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd);
+  }
+  HIPCHECK(h, hipGetLastError());
+  h->have_linearization = true;
+  h->have_schur = h->have_backsub = false;
+  return BA_OK;
+}
+
+int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP, double* W) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_linearization, BA_ERR_STATE, "ba_get_blocks: call ba_linearize first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  std::vector<double> hpp6;
+  if (HCC && h->nc) HIPCHECK(h, hipMemcpyAsync(HCC, h->HCC.p, (size_t)h->nc * 36 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (bC && h->nc) HIPCHECK(h, hipMemcpyAsync(bC, h->bC.p, (size_t)h->nc * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (HPP && h->nt) {
+    hpp6.resize((size_t)h->nt * 6);
+    HIPCHECK(h, hipMemcpyAsync(hpp6.data(), h->HPP.p, hpp6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  if (bP && h->nt) HIPCHECK(h, hipMemcpyAsync(bP, h->bP.p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (W && h->nobs) {
+    REQUIRE(h, h->W.p && h->W.n >= (size_t)h->nobs * 18, BA_ERR_STATE, "ba_get_blocks: W was not stored (ba_linearize store_W=0)");
+    HIPCHECK(h, hipMemcpyAsync(W, h->W.p, (size_t)h->nobs * 18 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (HCC) {   // device keeps the upper triangle only
+    for (int i = 0; i < h->nc; ++i)
+      for (int a = 0; a < 6; ++a)
+        for (int c = 0; c < a; ++c) HCC[(size_t)i * 36 + a * 6 + c] = HCC[(size_t)i * 36 + c * 6 + a];
+  }
+  if (HPP) {
+    for (int k = 0; k < h->nt; ++k) {
+      const double* s = &hpp6[(size_t)k * 6];
+      double* d = HPP + (size_t)k * 9;
+      d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[1]; d[4] = s[3]; d[5] = s[4]; d[6] = s[2]; d[7] = s[4]; d[8] = s[5];
+    }
+  }
+  return BA_OK;
+}
+
+int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_schur: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_linearization && h->have_params[p], BA_ERR_STATE, "ba_schur: call ba_linearize first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  int rc = ensure_reduced(h);
+  if (rc != BA_OK) return rc;
+  HIPCHECK(h, hipMemsetAsync(h->flags.p, 0, sizeof(int), h->stream));
+  if (h->nt > 0) {
+    ScopedTimer tm(h, BA_K_POINT_INVERT);
+    hipLaunchKernelGGL(k_point_invert, dim3(blocks_for(h->nt)), dim3(kBlock), 0, h->stream, h->nt, h->HPP.p,
+                       damping, pinv_rcond, h->HPPinv.p, h->flags.p);
+  }
+  {
+    ScopedTimer tm(h, BA_K_SCHUR_INIT);
+    HIPCHECK(h, hipMemsetAsync(h->S, 0, (size_t)h->nco * h->nco * 36 * sizeof(double), h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->b, 0, (size_t)h->nco * 6 * sizeof(double), h->stream));
+    if (h->nc > 0)
+      hipLaunchKernelGGL(k_schur_init, dim3(blocks_for((long long)h->nc * 36)), dim3(kBlock), 0, h->stream, h->nc,
+                         h->nco, h->cam_opt_pos.p, h->HCC.p, h->bC.p, damping, h->S, h->b);
+  }
+  if (h->nunits > 0) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    const int per_block = kBlock / kWave;
+    hipLaunchKernelGGL(k_schur_pairs, dim3((h->nunits + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
+                       dev_problem(h), h->cams[p].p, h->X[p].p, h->units.p, h->nunits, h->HPPinv.p, h->bP.p, h->S, h->b);
+  }
+  HIPCHECK(h, hipGetLastError());
+  h->mirrored = false;
+  h->have_schur = true;
+  h->have_backsub = false;
+  if (pinv_rcond < 0.0) {   // plain-inverse mode must report singular blocks (numpy.linalg.inv raises)
+    int nsing = 0;
+    HIPCHECK(h, hipMemcpyAsync(&nsing, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (nsing > 0) return h->fail(BA_ERR_SINGULAR, "ba_schur: %d singular 3x3 point block(s) in plain-inverse mode", nsing);
+  }
+  return BA_OK;
+}
+
+int ba_mirror_reduced(ba_handle* h) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_mirror_reduced: call ba_schur first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  if (h->nco > 0) {
+    ScopedTimer tm(h, BA_K_MIRROR);
+    hipLaunchKernelGGL(k_mirror, dim3(blocks_for((long long)h->nco * h->nco * 36)), dim3(kBlock), 0, h->stream, h->nco, h->S);
+  }
+  HIPCHECK(h, hipGetLastError());
+  h->mirrored = true;
+  return BA_OK;
+}
+
+int ba_get_reduced(ba_handle* h, double* S, double* b) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_get_reduced: call ba_schur first");
+  if (!h->mirrored) { int rc = ba_mirror_reduced(h); if (rc != BA_OK) return rc; }
+  if (S && h->nco) HIPCHECK(h, hipMemcpyAsync(S, h->S, (size_t)h->nco * h->nco * 36 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (b && h->nco) HIPCHECK(h, hipMemcpyAsync(b, h->b, (size_t)h->nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+int ba_get_point_inverses(ba_handle* h, double* out) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur && out, BA_ERR_STATE, "ba_get_point_inverses: call ba_schur first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  std::vector<double> s6((size_t)h->nt * 6);
+  if (h->nt) HIPCHECK(h, hipMemcpyAsync(s6.data(), h->HPPinv.p, s6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  for (int k = 0; k < h->nt; ++k) {
+    const double* s = &s6[(size_t)k * 6];
+    double* d = out + (size_t)k * 9;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[1]; d[4] = s[3]; d[5] = s[4]; d[6] = s[2]; d[7] = s[4]; d[8] = s[5];
+  }
+  return BA_OK;
+}
+
+int ba_reduced_device_ptrs(ba_handle* h, void** S_blocks, void** b) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_reduced_device_ptrs: call ba_set_problem first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  int rc = ensure_reduced(h);
+  if (rc != BA_OK) return rc;
+  if (S_blocks) *S_blocks = h->S;
+  if (b) *b = h->b;
+  return BA_OK;
+}
+
+int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_bind_reduced_buffers: call ba_set_problem first");
+  h->S = (double*)S_blocks_dev;
+  h->b = (double*)b_dev;
+  h->have_schur = false;
+  return BA_OK;
+}
+
+int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A_dev, void* rhs_dev) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_flatten_reduced: call ba_schur first");
+  REQUIRE(h, nkeep >= 0 && (nkeep == 0 || (keep && A_dev && rhs_dev)), BA_ERR_INVALID_ARG, "ba_flatten_reduced: NULL argument");
+  for (int i = 0; i < nkeep; ++i)
+    if (keep[i] < 0 || keep[i] >= h->nco * 6) return h->fail(BA_ERR_INVALID_ARG, "ba_flatten_reduced: keep[%d] out of range", i);
+  if (nkeep == 0) return BA_OK;
+  HIPCHECK(h, hipSetDevice(h->device));
+  HIPCHECK(h, h->keep.resize(nkeep));
+  HIPCHECK(h, hipMemcpyAsync(h->keep.p, keep, nkeep * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  {
+    ScopedTimer tm(h, BA_K_FLATTEN);
+    hipLaunchKernelGGL(k_flatten, dim3(blocks_for((long long)nkeep * nkeep)), dim3(kBlock), 0, h->stream, h->nco, nkeep,
+                       h->keep.p, h->S, h->b, (double*)A_dev, (double*)rhs_dev);
+  }
+  HIPCHECK(h, hipGetLastError());
+  HIPCHECK(h, hipStreamSynchronize(h->stream));   // `keep` is caller memory
+  return BA_OK;
+}
+
+int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_backsubstitute: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_schur && h->have_params[p], BA_ERR_STATE, "ba_backsubstitute: call ba_schur first");
+  REQUIRE(h, dC || h->nco == 0, BA_ERR_INVALID_ARG, "ba_backsubstitute: dC is NULL");
+  HIPCHECK(h, hipSetDevice(h->device));
+  std::vector<double> full((size_t)h->nc * 6, 0.0);
+  for (int i = 0; i < h->nc; ++i) {
+    const int pos = h->h_cam_opt_pos[i];
+    if (pos >= 0) std::memcpy(&full[(size_t)i * 6], dC + (size_t)pos * 6, 6 * sizeof(double));
+  }
+  if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->dCfull.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->nt > 0) {
+    ScopedTimer tm(h, BA_K_BACKSUB);
+    const long long threads = (long long)h->nt << h->glog;
+    hipLaunchKernelGGL(k_backsub, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
+                       h->X[p].p, h->glog, h->dCfull.p, h->HPPinv.p, h->bP.p, h->dP.p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  if (dP && h->nt) HIPCHECK(h, hipMemcpyAsync(dP, h->dP.p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));   // `full` is a host temporary
+  h->have_backsub = true;
+  return BA_OK;
+}
+
+int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const double* structure) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, (src == 0 || src == 1) && (dst == 0 || dst == 1), BA_ERR_INVALID_ARG, "ba_apply_update: bad parameter set");
+  const int ps = h->phys(src), pd = h->phys(dst);
+  REQUIRE(h, h->have_problem && h->have_params[ps], BA_ERR_STATE, "ba_apply_update: source parameter set is empty");
+  REQUIRE(h, (motion == nullptr) == (structure == nullptr), BA_ERR_INVALID_ARG,
+          "ba_apply_update: give both motion and structure, or neither");
+  HIPCHECK(h, hipSetDevice(h->device));
+  double sign = -1.0;
+  std::vector<double> full;
+  if (motion) {
+    sign = 1.0;
+    full.assign((size_t)h->nc * 6, 0.0);
+    for (int i = 0; i < h->nc; ++i) {
+      const int pos = h->h_cam_opt_pos[i];
+      if (pos >= 0) std::memcpy(&full[(size_t)i * 6], motion + (size_t)pos * 6, 6 * sizeof(double));
+    }
+    if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->dCfull.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->nt) HIPCHECK(h, hipMemcpyAsync(h->dP.p, structure, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->have_backsub = false;   // dCfull / dP now hold the caller's update
+  } else {
+    REQUIRE(h, h->have_backsub, BA_ERR_STATE, "ba_apply_update: no update on the device (call ba_backsubstitute)");
+  }
+  if (h->nc + h->nt > 0) {
+    ScopedTimer tm(h, BA_K_UPDATE);
+    hipLaunchKernelGGL(k_apply_update, dim3(blocks_for((long long)h->nc + h->nt)), dim3(kBlock), 0, h->stream, h->nc,
+                       h->nt, h->cam_opt_pos.p, h->pt_opt.p, h->cams[ps].p, h->X[ps].p, h->dCfull.p, h->dP.p, sign,
+                       h->cams[pd].p, h->X[pd].p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  if (motion) HIPCHECK(h, hipStreamSynchronize(h->stream));
+  h->have_params[pd] = true;
+  if (dst == BA_PARAMS_CUR) h->have_linearization = h->have_schur = false;
+  return BA_OK;
+}
+
+int ba_enable_timing(ba_handle* h, int on) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  if (!on) resolve_timings(h);
+  h->timing = on != 0;
+  return BA_OK;
+}
+
+int ba_get_timings(ba_handle* h, double* ms, int64_t* launches, int reset) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  HIPCHECK(h, hipSetDevice(h->device));
+  resolve_timings(h);
+  for (int i = 0; i < BA_K_COUNT; ++i) {
+    if (ms) ms[i] = h->ms[i];
+    if (launches) launches[i] = h->launches[i];
+    if (reset) { h->ms[i] = 0; h->launches[i] = 0; }
+  }
+  return BA_OK;
+}
+
+}  // extern "C"

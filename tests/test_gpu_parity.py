@@ -1,0 +1,449 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+reference's golden vectors.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances (fp64 everywhere; BASELINE north star: each step within 1e-6 relative):
+  * per-observation values, blocks, S, b: 1e-11 relative to the largest entry
+    (pure fp64 arithmetic; differences are summation order + fma contraction)
+  * solves / updates: 1e-8 (conditioning of the reduced system)
+  * LM cost trajectories and final parameters: 1e-6 (the north-star tolerance)
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ba_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-11
+SOLVE = 1e-8
+LM = 1e-6
+
+
+@pytest.fixture(scope='module')
+def be():
+    from pysfm_amd.backend import HipBackend
+    b = HipBackend(0)
+    yield b
+    b.close()
+
+
+def close(a, b, rtol, atol=0.):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if not b.size:
+        return
+    scale = np.max(np.abs(b))
+    err = np.max(np.abs(a - b))
+    assert err <= rtol * scale + atol, 'max abs err %.3e vs scale %.3e (rtol %.1e)' % (err, scale, rtol)
+
+
+def sensor_of(g):
+    return O.Sensor(int(g['sensor_kind']), L=g['sensor_L'], sigma=float(g['sensor_sigma']))
+
+
+def sensor_params(s):
+    if s.kind == O.GAUSS:
+        return 0, s.L.reshape(4)
+    if s.kind == O.CAUCHY:
+        return 1, [s.sigma]
+    return 2, [s.k]
+
+
+def load_problem(be, K, R, t, X, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, sensor):
+    be.set_problem(len(R), len(X), obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt)
+    be.set_sensor(*sensor_params(sensor))
+    be.set_params(0, R, t, X)
+
+
+def default_flags(nc, nt):
+    return np.arange(nc, dtype=np.int32) - 1, np.ones(nt, np.uint8)
+
+
+def scene(g):
+    return (g['K'], g['R'], g['t'], g['X'], g['obs_cam'], g['obs_pt'], g['obs_z'])
+
+
+def hip_update(be, damping, rcond=1e-5, keep=None):
+    be.linearize(0)
+    be.schur(0, damping, rcond)
+    n = be.nco * 6
+    keep = np.arange(n, dtype=np.int32) if keep is None else keep
+    x = be.solve_reduced(keep)
+    dC = np.zeros(n)
+    dC[keep] = x
+    dC = dC.reshape(-1, 6)
+    dP = be.backsubstitute(0, dC)
+    return dC, dP
+
+
+# ------------------------------------------------------------------ golden: functions
+@pytest.mark.parametrize('tag', ['gauss_iso', 'gauss_diag', 'gauss_full', 'cauchy', 'cauchy2'])
+def test_sensor_models_vs_reference(be, tag):
+    g = load_golden('functions')
+    s = O.Sensor(int(g[tag + '_kind']), L=g[tag + '_L'], sigma=float(g[tag + '_sigma']))
+    be.set_sensor(*sensor_params(s))
+    r, J = be.eval_sensor(g['sens_e'])
+    close(r, g[tag + '_r'], 1e-13)
+    close(J, g[tag + '_J'], 1e-12)
+
+
+def test_huber_vs_oracle(be):
+    s = O.Sensor.huber(.06)
+    rs = np.random.RandomState(3)
+    e = np.concatenate((rs.randn(200, 2) * .05, rs.uniform(-10, 10, (50, 2)), [[0, 0], [.06, 0], [0, .0600001]]))
+    be.set_sensor(2, [.06])
+    r, J = be.eval_sensor(e)
+    close(r, O.sensor_residual(s, e), 1e-13)
+    close(J, O.sensor_jacobian(s, e), 1e-12)
+
+
+# ------------------------------------------------------------------ golden: 4x10 Cauchy scene
+def test_per_observation_vs_reference(be):
+    g = load_golden('scene_4x10_cauchy')
+    load_problem(be, *scene(g), g['l0_cam_opt_pos'], g['l0_pt_opt'], sensor_of(g))
+    out = be.eval_observations(0)
+    close(out['e'], g['e'], 1e-13)
+    close(out['r'], g['r'], 1e-13)
+    close(out['Jc'], g['Jc'], 1e-12)
+    close(out['Jp'], g['Jp'], 1e-12)
+    close(be.cost(0), g['l0_cost'], 1e-13)
+
+
+@pytest.mark.parametrize('lam,tag', [(0., 'l0_'), (2., 'l2_')])
+def test_blocks_and_schur_vs_reference(be, lam, tag):
+    g = load_golden('scene_4x10_cauchy')
+    load_problem(be, *scene(g), g[tag + 'cam_opt_pos'], g[tag + 'pt_opt'], sensor_of(g))
+    be.linearize(0, store_W=True)
+    blk = be.get_blocks(W=True)
+    for k in ('HCC', 'bC', 'HPP', 'bP', 'W'):
+        close(blk[k], g[tag + k], TIGHT)
+    be.schur(0, lam, 1e-5)
+    close(be.get_point_inverses(), g[tag + 'HPP_inv'], 1e-10)
+    S, b = be.get_reduced()
+    close(S, g[tag + 'S'], TIGHT)
+    close(b, g[tag + 'b'], TIGHT)
+    assert np.array_equal(S, S.transpose(1, 0, 3, 2))            # exactly symmetric after mirroring
+    if lam > 0:
+        dC, dP = hip_update(be, lam)
+        close(dC, g[tag + 'dC'], SOLVE)
+        close(dP, g[tag + 'dP'], SOLVE)
+        Sflat = S.transpose(0, 2, 1, 3).reshape(18, 18)
+        assert np.sum((np.concatenate((-dC.reshape(-1), -dP.reshape(-1))) - g['dense_delta_l2']) ** 2) <= 1e-7
+        assert np.linalg.norm(Sflat @ dC.reshape(-1) - b.reshape(-1)) < 1e-9 * np.linalg.norm(b)
+    else:
+        Sflat = S.transpose(0, 2, 1, 3).reshape(18, 18)
+        assert np.sum((Sflat - g['dense_S_l0']) ** 2) <= 1e-7      # numpy_test.py:112-118 criterion
+        assert np.sum((b.reshape(-1) - g['dense_b_l0']) ** 2) <= 1e-7
+
+
+def test_subset_and_masks_vs_reference(be):
+    g = load_golden('scene_subset')
+    load_problem(be, *scene(g), g['l2_cam_opt_pos'], g['l2_pt_opt'], sensor_of(g))
+    be.linearize(0)
+    be.schur(0, 2., 1e-5)
+    S, b = be.get_reduced()
+    assert S.shape == (1, 1, 6, 6)
+    close(S, g['l2_S'], TIGHT)
+    close(b, g['l2_b'], TIGHT)
+    close(be.cost(0), g['l2_cost'], 1e-13)
+    dC, dP = hip_update(be, 2.)
+    close(-dC, g['update_l2_motion'], SOLVE)
+    close(-dP[g['l2_pt_opt'].astype(bool)], g['update_l2_structure'], SOLVE)
+
+
+@pytest.mark.parametrize('name', ['scene_oleg_10x50', 'scene_oleg_40x100'])
+def test_pixel_unit_scenes_vs_reference(be, name):
+    """tracks of 10..40 observations (more than one kTile for 40), K with f=1500."""
+    g = load_golden(name)
+    load_problem(be, *scene(g), g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    S, b = be.get_reduced()
+    close(b, g['l10_b'], TIGHT)
+    close(be.get_point_inverses(), g['l10_HPP_inv'], 1e-9)
+    if 'l10_S' in g:
+        close(S, g['l10_S'], TIGHT)
+    else:
+        assert abs(np.linalg.norm(S) / g['l10_S_fro'] - 1) < 1e-11
+    dC, dP = hip_update(be, 10.)
+    close(-dC, g['update_l10_motion'], 1e-7)
+    close(-dP, g['update_l10_structure'], 1e-7)
+
+
+def test_oleg_full_100x1000_vs_reference(be):
+    """100 000 integer-pixel observations, dense tracks of 100 (4 tiles per track, 10 units each)."""
+    g = load_golden('scene_oleg_100x1000')
+    z = g['obs_z'].astype(float)
+    nc, nt = 100, 1000
+    load_problem(be, g['K'], g['R'], g['t'], g['X'], g['obs_cam'], g['obs_pt'], z, *default_flags(nc, nt), sensor_of(g))
+    close(be.cost(0), g['l10_cost'], 1e-12)
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    S, b = be.get_reduced()
+    close(b, g['l10_b'], 1e-10)
+    assert abs(np.linalg.norm(S) / g['l10_S_fro'] - 1) < 1e-11
+    dC, dP = hip_update(be, 10.)
+    close(dC, g['l10_dC'], 1e-6)
+    close(dP[:20], g['l10_dP_head'], 1e-6)
+    assert abs(np.linalg.norm(dP) / g['l10_dP_norm'] - 1) < 1e-6
+
+
+# ------------------------------------------------------------------ LM through the public API
+@pytest.mark.parametrize('name,steps', [('scene_4x10_cauchy', 10), ('scene_5x50_gauss', 5),
+                                        ('scene_5x50_cauchy_masked', 8), ('scene_planar_lm', 50)])
+def test_bundle_adjuster_optimize_vs_reference(name, steps):
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    g = load_golden(name)
+    if int(g['sensor_kind']) == 0:
+        m = sensor_model.GaussianModel(1.)
+        m.L = g['sensor_L']
+    else:
+        m = sensor_model.CauchyModel(float(g['sensor_sigma']))
+    b0 = Bundle.FromObservations(*scene(g), sensor_model=m)
+    ba = BundleAdjuster(b0, verbose=False)
+    ba.optimize(max_steps=steps)
+    assert ba.num_steps == int(g['lm_num_steps'])
+    assert ba.converged == bool(g['lm_converged'])
+    close(ba.costs, g['lm_costs'], LM)
+    out = ba.bundle
+    assert out is not b0 and np.array_equal(b0.Rs(), g['R'])
+    close(out.Rs(), g['lm_R'], LM)
+    close(out.ts(), g['lm_t'], LM, 1e-9)
+    close(out.reconstruction, g['lm_X'], LM)
+    # the reference's unit-test call shapes (bundle_adjuster_unittest.py:47-67)
+    ba2 = BundleAdjuster(b0, verbose=False)
+    mu, su = ba2.compute_update(2.)
+    omu, osu = O.compute_update(sensor_of(g), *scene(g), *default_flags(len(g['R']), len(g['X'])), damping=2.)
+    close(mu, omu, SOLVE)
+    close(su, osu, SOLVE)
+
+
+def test_bundle_api_on_device():
+    from pysfm_amd import Bundle, sensor_model
+    g = load_golden('scene_4x10_cauchy')
+    b = Bundle.FromObservations(*scene(g), sensor_model=sensor_model.CauchyModel(.05))
+    n = 11
+    i, j = int(g['obs_cam'][n]), int(g['obs_pt'][n])
+    close(b.reproj_error(i, j), g['e'][n], 1e-13)
+    close(b.residual(i, j), g['r'][n], 1e-13)
+    Jc, Jp = b.Jresidual(i, j)
+    close(Jc, g['Jc'][n], 1e-12)
+    close(Jp, g['Jp'][n], 1e-12)
+    close(b.complete_cost(), g['complete_cost'], 1e-13)
+    r, J = O.dense_jacobian(sensor_of(g), *scene(g))
+    close(b.Jresiduals(), J, 1e-12)
+    for m in (sensor_model.GaussianModel([2., 3.]), sensor_model.CauchyModel(2.), sensor_model.HuberModel(.7)):
+        assert sensor_model.validate(m)                      # sensor_model.py:76-99 on the device path
+
+
+# ------------------------------------------------------------------ seeded scenes vs the oracle
+def banded(nc, nt, **kw):
+    from pysfm_amd import synthetic_data as sd
+    return sd.generate_banded_scene(nc, nt, **kw)
+
+
+@pytest.mark.parametrize('sensor,outliers', [(O.Sensor.gaussian(1.), 0.), (O.Sensor.cauchy(.05), .1),
+                                             (O.Sensor.huber(.06), .1)])
+def test_banded_scene_full_step_vs_oracle(be, sensor, outliers):
+    s = banded(60, 3000, outlier_frac=outliers)
+    nc, nt = 60, 3000
+    flags = default_flags(nc, nt)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, *flags, sensor)
+    close(be.cost(0), O.cost(sensor, *a, *flags), 1e-12)
+    mu, su, parts = O.compute_update(sensor, *a, *flags, damping=10., return_parts=True)
+    be.linearize(0, store_W=True)
+    blk = be.get_blocks(W=True)
+    for k in ('HCC', 'bC', 'HPP', 'bP', 'W'):
+        close(blk[k], parts[k], TIGHT)
+    be.schur(0, 10., 1e-5)
+    S, b = be.get_reduced()
+    close(S, parts['S'], TIGHT)
+    close(b, parts['b'], TIGHT)
+    close(be.get_point_inverses(), parts['HPP_inv'], 1e-9)
+    dC, dP = hip_update(be, 10.)
+    close(-dC, mu, SOLVE)
+    close(-dP, su, SOLVE)
+    be.apply_update(0, 1)
+    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, flags[0], flags[1])
+    Rh, th, Xh = be.get_params(1)
+    close(Rh, R2, 1e-9)
+    close(th, t2, 1e-9)
+    close(Xh, X2, 1e-9)
+    close(be.cost(1), O.cost(sensor, s['K'], R2, t2, X2, *a[4:], *flags), 1e-8)
+
+
+def test_config2_gauss_newton_100x10k(be):
+    """BASELINE config 2: 100 cameras / 10k points / 100k obs, lambda = 0, Jacobian + Schur only."""
+    s = banded(100, 10000)
+    flags = default_flags(100, 10000)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    sensor = O.Sensor.gaussian(1.)
+    load_problem(be, *a, *flags, sensor)
+    HCC, HPP, W, bC, bP = O.normal_blocks(sensor, *a, 100, 10000)
+    HPPi = O.invert_point_blocks(HPP, 1e-5)
+    S0, b0 = O.schur_complement(HCC, HPPi, W, bC, bP, s['obs_cam'], s['obs_pt'], flags[0])
+    be.linearize(0)
+    be.schur(0, 0., 1e-5)
+    S, b = be.get_reduced()
+    close(S, S0, 1e-10)
+    close(b, b0, 1e-10)
+
+
+def test_rank_deficient_point_blocks_use_pinv_cutoff(be):
+    """Tracks seen by a single camera have a rank-2 HPP: numpy.linalg.pinv(., 1e-5)
+    drops the null direction (bundle_adjuster.py:256).  Plain inverse must raise."""
+    s = banded(12, 40, track_len=10)
+    keep = np.ones(len(s['obs_cam']), bool)
+    for k in (3, 17, 29):                       # cut these tracks down to one observation
+        idx = np.nonzero(s['obs_pt'] == k)[0]
+        keep[idx[1:]] = False
+    keep[s['obs_pt'] == 8] = False              # and one track with no observation at all
+    cam, pt, z = s['obs_cam'][keep], s['obs_pt'][keep], s['obs_z'][keep]
+    flags = default_flags(12, 40)
+    sensor = O.Sensor.gaussian(1.)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
+    load_problem(be, *a, *flags, sensor)
+    mu, su, parts = O.compute_update(sensor, *a, *flags, damping=0.5, return_parts=True)
+    be.linearize(0)
+    be.schur(0, .5, 1e-5)
+    Hi = be.get_point_inverses()
+    close(Hi, parts['HPP_inv'], 1e-9)
+    assert np.all(Hi[8] == 0)
+    assert np.linalg.matrix_rank(Hi[3]) == 2
+    S, b = be.get_reduced()
+    close(S, parts['S'], 1e-10)
+    dC, dP = hip_update(be, .5)
+    close(-dP, su, SOLVE)
+    from pysfm_amd.backend import SingularPointBlock
+    be.linearize(0)
+    with pytest.raises(SingularPointBlock):
+        be.schur(0, .5, None)
+
+
+def test_plain_inverse_mode_matches_numpy_inv(be):
+    g = load_golden('scene_4x10_cauchy')
+    load_problem(be, *scene(g), g['l2_cam_opt_pos'], g['l2_pt_opt'], sensor_of(g))
+    be.linearize(0)
+    be.schur(0, 2., None)
+    HCC, HPP, W, bC, bP = O.normal_blocks(sensor_of(g), *scene(g), 4, 10)
+    close(be.get_point_inverses(), np.linalg.inv(O.damp_blocks(HPP, 2.)), 1e-11)
+
+
+def test_empty_and_degenerate_inputs(be):
+    K = np.eye(3)
+    R = np.stack([np.eye(3)] * 3)
+    t = np.zeros((3, 3))
+    X = np.ones((4, 3))
+    flags = default_flags(3, 4)
+    empty_i, empty_z = np.zeros(0, np.int32), np.zeros((0, 2))
+    be.set_problem(3, 4, empty_i, empty_i, empty_z, K, *flags)
+    be.set_sensor(0, np.eye(2).reshape(4))
+    be.set_params(0, R, t, X)
+    assert be.cost(0) == 0.
+    be.linearize(0)
+    be.schur(0, 1., 1e-5)
+    S, b = be.get_reduced()
+    assert not S.any() and not b.any()
+    with pytest.raises(ValueError):
+        be.set_problem(3, 4, [0, 1], [1, 0], np.zeros((2, 2)), K, *flags)      # not ordered by track
+    with pytest.raises(ValueError):
+        be.set_problem(3, 4, [0, 5], [0, 1], np.zeros((2, 2)), K, *flags)      # camera out of range
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.fixture(scope='module')
+def config3():
+    return banded(1000, 100000)
+
+
+def test_config3_properties_1000x100k(be, config3):
+    """BASELINE config 3 size (1000 cams / 100k pts / 1M obs).  The oracle is too slow for
+    the full Schur here, so check size-independent properties plus the cheap oracle parts."""
+    s = config3
+    nc, nt = 1000, 100000
+    flags = default_flags(nc, nt)
+    sensor = O.Sensor.gaussian(1.)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, *flags, sensor)
+    close(be.cost(0), O.cost(sensor, *a, *flags), 1e-12)
+    HCC, HPP, W, bC, bP = O.normal_blocks(sensor, *a, nc, nt)
+    be.linearize(0)
+    blk = be.get_blocks()
+    close(blk['HCC'], HCC, TIGHT)
+    close(blk['bC'], bC, TIGHT)
+    close(blk['HPP'], HPP, TIGHT)
+    close(blk['bP'], bP, TIGHT)
+    be.schur(0, 10., 1e-5)
+    S, b = be.get_reduced()
+    # (1) symmetry and band structure (each track spans 10 consecutive cameras)
+    assert np.array_equal(S, S.transpose(1, 0, 3, 2))
+    i, j = np.nonzero(np.abs(S).sum(axis=(2, 3)))
+    assert np.max(np.abs(i - j)) == 9
+    # (2) b against the oracle (O(N) to compute)
+    HPPi = O.invert_point_blocks(O.damp_blocks(HPP, 10.), 1e-5)
+    T = W @ HPPi[s['obs_pt']]
+    b0 = np.zeros((nc - 1, 6))
+    pos = flags[0][s['obs_cam']]
+    kk = pos >= 0
+    b0[np.arange(nc - 1)] = bC[1:]
+    np.subtract.at(b0, pos[kk], np.einsum('nij,nj->ni', T[kk], bP[s['obs_pt'][kk]]))
+    close(b, b0, 1e-10)
+    # (3) linearity over points: S(first half) + S(second half) - diag(HCC) terms == S(all)
+    half = nt // 2
+    parts = []
+    for lo, hi in ((0, half), (half, nt)):
+        m = (s['obs_pt'] >= lo) & (s['obs_pt'] < hi)
+        be.set_problem(nc, hi - lo, s['obs_cam'][m], s['obs_pt'][m] - lo, s['obs_z'][m], s['K'], flags[0],
+                       np.ones(hi - lo, np.uint8))
+        be.set_sensor(0, np.eye(2).reshape(4))
+        be.set_params(0, s['R0'], s['t0'], s['X0'][lo:hi])
+        be.linearize(0)
+        be.schur(0, 10., 1e-5)
+        parts.append(be.get_reduced())
+    close(parts[0][0] + parts[1][0], S, 1e-11)
+    close(parts[0][1] + parts[1][1], b, 1e-11)
+    # (4) a few rows of S against the oracle restricted to the tracks that touch them
+    rows = [0, 499, 998]
+    touching = np.zeros(nt, bool)
+    for r in rows:
+        touching[s['obs_pt'][pos == r]] = True
+    m = touching[s['obs_pt']]
+    S0, _ = O.schur_complement(O.damp_blocks(HCC, 10.), HPPi, W[m], bC, bP, s['obs_cam'][m], s['obs_pt'][m], flags[0])
+    for r in rows:
+        close(S[r], S0[r], 1e-10)
+
+
+def test_config3_full_lm_converges(config3):
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd.synthetic_data import reprojection_rmse
+    s = config3
+    b0 = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(b0, verbose=False)
+    ba.optimize(max_steps=25)
+    assert all(c1 < c0 for c0, c1 in zip(ba.costs, ba.costs[1:]))       # accepted steps only ever lower the cost
+    out = ba.bundle
+    be = ba.backend
+    e = be.eval_observations(0, e=True, r=False, Jc=False, Jp=False)['e']
+    rmse = reprojection_rmse(e)
+    assert rmse < 1.1 * .02 * np.sqrt(2)                                 # down to the measurement noise (sigma .02 per axis)
+    assert ba.costs[-1] < .2 * ba.costs[0]
+    # idempotence: restarting from the optimum moves (almost) nothing
+    ba2 = BundleAdjuster(out, verbose=False)
+    ba2.optimize(max_steps=3)
+    assert abs(ba2.costs[-1] - ba.costs[-1]) <= 1e-3 * ba.costs[-1]
+
+
+def test_timing_counters(be):
+    g = load_golden('scene_4x10_cauchy')
+    load_problem(be, *scene(g), g['l2_cam_opt_pos'], g['l2_pt_opt'], sensor_of(g))
+    be.enable_timing(True)
+    be.timings(reset=True)
+    for _ in range(3):
+        hip_update(be, 2.)
+        be.cost(0)
+    tm = be.timings(reset=True)
+    be.enable_timing(False)
+    assert tm['schur_pairs']['launches'] == 3 and tm['linearize']['launches'] == 3 and tm['cost']['launches'] == 3
+    assert tm['schur_pairs']['ms'] > 0

@@ -1,0 +1,327 @@
+"""Host logic of pysfm_amd (set_bundle bookkeeping, masks, the LM schedule, the Bundle
+data model) on CPU.  The arithmetic comes from the OracleBackend test double, the
+expected values from the reference's golden vectors - so these tests pin the Python
+side of the drop-in boundary, not the kernels."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle_backend import OracleBackend
+import pysfm_amd
+from pysfm_amd import Bundle, BundleAdjuster, Camera, Track, sensor_model
+from pysfm_amd import backend as backend_mod
+from pysfm_amd.bundle_adjuster import select, NormalEquationsIllconditioned
+
+
+@pytest.fixture(autouse=True)
+def oracle_default_backend(monkeypatch):
+    """Bundle.predict()/residual()/... use the process-wide default backend."""
+    monkeypatch.setitem(backend_mod._default, 0, OracleBackend())
+
+
+def model_of(g):
+    if int(g['sensor_kind']) == 0:
+        m = sensor_model.GaussianModel(1.)
+        m.L = g['sensor_L']
+        m.covinv = m.L @ m.L.T
+        m.cov = np.linalg.inv(m.covinv)
+        return m
+    return sensor_model.CauchyModel(float(g['sensor_sigma']))
+
+
+def bundle_of(g, prefix=''):
+    return Bundle.FromObservations(g['K'], g[prefix + 'R'], g[prefix + 't'], g[prefix + 'X'],
+                                   g[prefix + 'obs_cam'], g[prefix + 'obs_pt'], g[prefix + 'obs_z'],
+                                   sensor_model=model_of(g))
+
+
+def close(a, b, rtol=1e-9, atol=0.):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = np.max(np.abs(b)) if b.size else 1.
+    assert np.max(np.abs(a - b)) <= rtol * scale + atol if b.size else True
+
+
+# ------------------------------------------------------------------ select()
+def test_select_bool_and_id_masks():
+    s, idx = select([3, 1, 7], [False, True, True])
+    assert list(s) == [1, 7] and idx == [1, 2]
+    s, idx = select([3, 1, 7], np.array([7, 3]))
+    assert list(s) == [7, 3] and idx == [2, 0]
+    with pytest.raises(AssertionError):
+        select([3, 1, 7], np.array([5]))
+    with pytest.raises(AssertionError):
+        select([3, 1, 7], [True, False])
+
+
+# ------------------------------------------------------------------ LM trajectories
+@pytest.mark.parametrize('name,steps', [('scene_4x10_cauchy', 10), ('scene_5x50_gauss', 5),
+                                        ('scene_5x50_cauchy_masked', 8), ('scene_planar_lm', 50)])
+def test_optimize_reproduces_reference_trajectory(name, steps):
+    g = load_golden(name)
+    b0 = bundle_of(g)
+    R_before = b0.Rs().copy()
+    ba = BundleAdjuster(b0, backend=OracleBackend(), verbose=False)
+    assert ba.optim_camera_ids == list(range(1, len(g['R'])))
+    ba.optimize(max_steps=steps)
+    assert ba.num_steps == int(g['lm_num_steps'])
+    assert ba.converged == bool(g['lm_converged'])
+    close(ba.costs, g['lm_costs'], 1e-7)
+    out = ba.bundle
+    assert out is not b0                                   # bundle_adjuster.py:151: a new bundle
+    assert np.array_equal(b0.Rs(), R_before)               # the caller's bundle is never mutated
+    close(out.Rs(), g['lm_R'], 1e-6)
+    close(out.ts(), g['lm_t'], 1e-6, 1e-9)
+    close(out.reconstruction, g['lm_X'], 1e-6)
+
+
+def test_step_is_one_outer_iteration():
+    g = load_golden('scene_5x50_gauss')
+    ba = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    conv = ba.step()
+    assert conv is False and ba.num_steps == 1
+    close(ba.costs, g['lm_costs'][:2], 1e-7)
+    ba.step()
+    close(ba.costs, g['lm_costs'][:3], 1e-7)
+
+
+def test_every_trial_relinearises():
+    """No cached outputs: each LM trial runs linearize -> schur -> solve -> backsub -> cost."""
+    g = load_golden('scene_planar_lm')
+    be = OracleBackend()
+    ba = BundleAdjuster(bundle_of(g), backend=be, verbose=False)
+    ba.optimize(max_steps=50)
+    ntrials = len(g['lm_trials'])
+    assert be.calls.count('linearize') == ntrials
+    assert be.calls.count('schur') == ntrials
+    assert be.calls.count('backsub') == ntrials
+
+
+# ------------------------------------------------------------------ subsets and masks
+def test_subset_schur_matches_reference():
+    """bundle_adjuster_unittest.py:70-119."""
+    g = load_golden('scene_subset')
+    full = Bundle.FromObservations(g['K'], g['full_R'], g['full_t'], g['full_X'], g['full_obs_cam'],
+                                   g['full_obs_pt'], g['full_obs_z'], sensor_model=model_of(g))
+    ba = BundleAdjuster(backend=OracleBackend(), verbose=False)
+    ba.set_bundle(full, [3, 1], [0, 1, 2], [False, True], [False, True, False])
+    assert ba.optim_camera_ids == [1] and ba.optim_camera_indices == [1]
+    assert ba.optim_track_ids == [1] and ba.optim_track_indices == [1]
+    ba.prepare_schur_complement()
+    ba.apply_damping(2.)
+    A, b = ba.compute_schur_complement()
+    assert A.shape == (1, 1, 6, 6) and b.shape == (1, 6)
+    close(A, g['l2_S'])
+    close(b, g['l2_b'])
+    close(ba.HCCs, g['l2_HCC'] * (np.ones((6, 6)) + 2 * np.eye(6)))     # damped in place, like the reference
+    close(ba.HPPs, g['l2_HPP'] * (np.ones((3, 3)) + 2 * np.eye(3)))
+    close(ba.compute_cost(full), g['l2_cost'])
+    mu, su = ba.compute_update(2.)
+    close(mu, g['update_l2_motion'])
+    close(su, g['update_l2_structure'])
+    assert mu.shape == (1, 6) and su.shape == (1, 3)
+
+
+def test_integer_id_masks():
+    g = load_golden('scene_subset')
+    full = Bundle.FromObservations(g['K'], g['full_R'], g['full_t'], g['full_X'], g['full_obs_cam'],
+                                   g['full_obs_pt'], g['full_obs_z'], sensor_model=model_of(g))
+    ba = BundleAdjuster(backend=OracleBackend(), verbose=False)
+    ba.set_bundle(full, g['int_camera_ids'].tolist(), g['int_track_ids'].tolist(),
+                  g['int_cam_mask'], g['int_track_mask'])
+    assert ba.optim_camera_ids == [1, 3] and ba.optim_camera_indices == [3, 2]
+    assert ba.optim_track_ids == [8, 5, 4] and ba.optim_track_indices == [3, 0, 1]
+    close(ba.compute_cost(full), g['int_cost'])
+    mu, su = ba.compute_update(.5)
+    close(mu, g['int_update_motion'])
+    close(su, g['int_update_structure'])
+
+
+def test_compute_update_and_manual_pipeline_4x10():
+    """bundle_adjuster_unittest.py:16-67 call shapes."""
+    g = load_golden('scene_4x10_cauchy')
+    bnd = bundle_of(g)
+    ba = BundleAdjuster(bnd, backend=OracleBackend(), verbose=False)
+    ba.prepare_schur_complement()
+    ba.apply_damping(0.)
+    A, b = ba.compute_schur_complement()
+    close(A, g['l0_S'])
+    close(b, g['l0_b'])
+    nc = len(ba.optim_camera_ids)
+    Aflat = A.transpose((0, 2, 1, 3)).reshape((6 * nc, 6 * nc))
+    assert np.sum((Aflat - g['dense_S_l0']) ** 2) <= 1e-7
+    close(ba.HCPs[g['obs_cam'], g['obs_pt']], g['l0_W'])
+    assert ba.HCPs.shape == (4, 10, 6, 3)
+    close(ba.HPP_invs, g['l0_HPP_inv'])
+    mu, su = ba.compute_update(2.)
+    close(mu, g['update_l2_motion'])
+    close(su, g['update_l2_structure'])
+    # host-array solve + backsubstitute, the way the reference chains them
+    ba.prepare_schur_complement()
+    ba.apply_damping(2.)
+    S, b = ba.compute_schur_complement()
+    dC = ba.solve_motion_normal_eqns(S, b, np.ones(nc * 6, bool))
+    close(dC, g['l2_dC'])
+    close(ba.backsubstitute(dC), g['l2_dP'])
+
+
+def test_param_mask_semantics():
+    g = load_golden('scene_4x10_cauchy')
+    ba = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    nparams = 6 * 3 + 3 * 10
+    mask = np.ones(nparams, bool)
+    mask[[0, 7]] = False
+    mu, su = ba.compute_update(2., mask)
+    assert mu[0, 0] == 0 and mu[1, 1] == 0 and np.all(mu.reshape(-1)[[1, 2, 3]] != 0)
+    with pytest.raises(AssertionError):
+        ba.compute_update(2., np.ones(nparams + 1, bool))
+    bad = mask.copy()
+    bad[-1] = False
+    with pytest.raises(AssertionError):
+        ba.compute_update(2., bad)            # 'Eliminating point parameters not implemented'
+    with pytest.raises(AssertionError):
+        ba.compute_update(2., np.ones(nparams, int))
+
+
+def test_singular_reduced_system_raises_reference_exception():
+    g = load_golden('scene_4x10_cauchy')
+    ba = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    S = np.zeros((3, 3, 6, 6))
+    with pytest.raises(NormalEquationsIllconditioned):
+        ba.solve_motion_normal_eqns(S, np.zeros((3, 6)), np.ones(18, bool))
+
+
+def test_update_motion_and_structure_on_clone():
+    g = load_golden('scene_4x10_cauchy')
+    bnd = bundle_of(g)
+    ba = BundleAdjuster(bnd, backend=OracleBackend(), verbose=False)
+    mu, su = ba.compute_update(2.)
+    bnext = ba.bundle.clone_params()
+    ba.update_motion(mu, bnext)
+    ba.update_structure(su, bnext)
+    from oracle import ba_oracle as O
+    R2, t2, X2 = O.apply_update(g['R'], g['t'], g['X'], mu, su, g['l2_cam_opt_pos'], g['l2_pt_opt'])
+    close(bnext.Rs(), R2, 1e-14)
+    close(bnext.ts(), t2, 1e-14)
+    close(bnext.reconstruction, X2, 1e-14)
+    assert np.array_equal(bnd.Rs(), g['R'])
+    with pytest.raises(AssertionError):
+        ba.update_motion(mu[:2], bnext)
+
+
+def test_set_bundle_assertions():
+    g = load_golden('scene_4x10_cauchy')
+    bnd = bundle_of(g)
+    ba = BundleAdjuster(backend=OracleBackend(), verbose=False)
+    with pytest.raises(AssertionError):
+        ba.set_bundle(bnd, camera_ids=[0])                 # 'Cannot optimize just one camera'
+    with pytest.raises(AssertionError):
+        ba.set_bundle(bnd, camera_ids=[0, 9])
+    with pytest.raises(AssertionError):
+        ba.set_bundle(bnd, track_ids=[-1, 2])
+    empty = Bundle(2, 3)
+    with pytest.raises(AssertionError):
+        ba.set_bundle(empty)                               # 'reconstruction must be initialized'
+
+
+# ------------------------------------------------------------------ Bundle data model
+def test_from_arrays_equals_from_observations():
+    g = load_golden('scene_4x10_cauchy')
+    nc, nt = 4, 10
+    msm = np.zeros((nc, nt, 2))
+    mask = np.zeros((nc, nt), bool)
+    msm[g['obs_cam'], g['obs_pt']] = g['obs_z']
+    mask[g['obs_cam'], g['obs_pt']] = True
+    a = Bundle.FromArrays(g['K'], g['R'], g['t'], g['X'], msm, mask)
+    b = bundle_of(g)
+    for x, y in zip(a.observation_table(), b.observation_table()):
+        assert np.array_equal(x, y)
+    assert len(b.tracks) == 10 and b.tracks[3].has_measurement(int(g['obs_cam'][g['obs_pt'] == 3][0]))
+    assert sorted(a.tracks[2].camera_ids()) == sorted(b.tracks[2].camera_ids())
+    assert np.array_equal(a.measurement(0, 0), b.measurement(0, 0))
+    ci, ti, z = a.select_observations([3, 1], [0, 1, 2])
+    gs = load_golden('scene_subset')
+    assert np.array_equal(ci, gs['obs_cam']) and np.array_equal(ti, gs['obs_pt']) and np.array_equal(z, gs['obs_z'])
+
+
+def test_bundle_per_observation_api():
+    g = load_golden('scene_4x10_cauchy')
+    b = bundle_of(g)
+    n = 7
+    i, j = int(g['obs_cam'][n]), int(g['obs_pt'][n])
+    close(b.reproj_error(i, j), g['e'][n])
+    close(b.residual(i, j), g['r'][n])
+    Jc, Jp = b.Jresidual(i, j)
+    close(Jc, g['Jc'][n])
+    close(Jp, g['Jp'][n])
+    close(b.predict(i, j), g['e'][n] + g['obs_z'][n])
+    close(b.complete_cost(), g['complete_cost'])
+    assert b.residuals().shape == (72,)
+    J, rows, cols = b.Jresiduals_extended()
+    assert J.shape == (72, 4 * 6 + 10 * 3) and rows.shape == (72, 2) and cols.shape == (54, 2)
+    assert b.Jresiduals_partial([3, 1], [0, 1, 2]).shape[1] == 2 * 6 + 3 * 3
+    assert b.num_params() == 54
+
+
+def test_clone_params_and_perturb():
+    g = load_golden('scene_4x10_cauchy')
+    b = bundle_of(g)
+    c = b.clone_params()
+    assert c.tracks is b.tracks and c.sensor_model is b.sensor_model
+    c.perturb(np.full(c.num_params(), .01))
+    assert np.array_equal(b.Rs(), g['R']) and not np.allclose(c.Rs(), g['R'])
+    close(c.reconstruction, g['X'] + .01, 1e-15)
+    cam = Camera(np.eye(3), np.zeros(3))
+    cam.perturb(np.array([0, 0, 0, 1., 2., 3.]))
+    assert np.array_equal(cam.R, np.eye(3)) and np.array_equal(cam.t, [1, 2, 3])
+    assert cam.projection_matrix().shape == (3, 4)
+
+
+def test_track_and_incremental_building():
+    b = Bundle()
+    b.add_camera()
+    b.add_camera(Camera(np.eye(3), np.ones(3)))
+    t = b.add_track(Track([0, 1], [np.zeros(2), np.ones(2)]))
+    assert t.has_measurement(1) and not t.has_measurement(2)
+    t.add_measurement(0, np.array([2., 3.]))
+    assert np.array_equal(b.measurement(0, 0), [2., 3.])
+    assert b.reconstruction.shape == (1, 3)
+    with pytest.raises(Exception):
+        b.add_track(Track([5], [np.zeros(2)]))
+    assert list(b.measurement_ids()) == [(0, 0), (1, 0)]
+
+
+def test_sensor_models_protocol():
+    for m in (sensor_model.GaussianModel([2., 3.]), sensor_model.CauchyModel(2.), sensor_model.HuberModel(.7)):
+        assert sensor_model.validate(m)
+        assert type(m.clone()) is type(m)
+    kind, params = sensor_model.device_params_of(sensor_model.GaussianModel(.1))
+    assert kind == 0 and np.allclose(params.reshape(2, 2), np.eye(2) / np.sqrt(.1))
+    with pytest.raises(TypeError):
+        sensor_model.device_params_of(object())
+
+
+def test_synthetic_generator_matches_reference_scene():
+    from pysfm_amd import synthetic_data as sd
+    g = load_golden('scene_5x50_gauss')
+    K, Rs, ts, pts, msm = sd.generate_sequence(5, 50)
+    close(Rs, g['R'], 1e-15)
+    close(ts, g['t'], 1e-15)
+    close(pts, g['X'], 1e-15)
+    close(msm.transpose(1, 0, 2).reshape(-1, 2), g['obs_z'], 1e-14)
+    b = Bundle.FromArrays(K, Rs, ts, pts, msm)
+    ba = BundleAdjuster(b, backend=OracleBackend(), verbose=False)
+    ba.optimize(max_steps=5)
+    close(ba.costs, g['lm_costs'], 1e-7)
+
+
+def test_banded_scene_shape():
+    from pysfm_amd import synthetic_data as sd
+    s = sd.generate_banded_scene(30, 200, track_len=10, outlier_frac=.1)
+    assert len(s['obs_cam']) == 2000 and np.all(np.diff(s['obs_pt']) >= 0)
+    assert s['outliers'].sum() == 200
+    span = s['obs_cam'].reshape(200, 10)
+    assert np.all(span[:, -1] - span[:, 0] == 9)
+    p = np.einsum('nij,nj->ni', s['R'][s['obs_cam']], s['X'][s['obs_pt']]) + s['t'][s['obs_cam']]
+    assert np.all(p[:, 2] > 3)
+    assert np.array_equal(s['R0'][0], s['R'][0])
