@@ -79,6 +79,13 @@ def load():
         raise HipLibraryMissing(
             '%s not found. pysfm_amd has no CPU fallback: build the HIP library with '
             '`make -C pysfm_amd/csrc` (hipcc --offload-arch=gfx950).' % LIB_PATH)
+    # torch bundles its own HIP runtime (SONAME libamdhip64.so.7).  Import it first so
+    # that libpysfm_ba.so binds to the SAME runtime instance: two HIP runtimes in one
+    # process cannot share streams, device pointers or even see the GPU together.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
