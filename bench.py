@@ -37,29 +37,32 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, nnzb_upper):
+def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
     """HBM bytes one launch of `kernel` has to move, every array touched once
-    (fp64 values, int32 indices, our SoA layout)."""
+    (fp64 values, int32 indices, our SoA layout, block-band S)."""
     obs = 20 * nobs                       # obs_cam (4) + obs_z (16); obs_pt only in k_cost
     cams, pts = 96 * nc, 24 * nt
-    if kernel == 'schur_pairs':
-        return obs + 12 * nunits + 4 * nt + cams + pts + 72 * nt + 2 * 288 * nnzb_upper + 2 * 48 * nco
-    if kernel == 'linearize':
-        return obs + 4 * nt + cams + pts + 72 * nt + 2 * 336 * nc
+    band = 288 * nco * (hb + 1)           # reduced system S in block-band layout
+    if kernel == 'schur_pairs':           # S and b are read-modify-written once
+        return obs + 12 * nunits + 4 * nt + cams + pts + 72 * nt + 2 * band + 2 * 48 * nco
+    if kernel == 'linearize':             # point blocks: HPP (48) + bP (24) written per track
+        return obs + 4 * nt + cams + pts + 72 * nt
+    if kernel == 'camera_blocks':         # camera-ordered pass: perm (4) + obs_pt (4) + obs_z (16) per obs
+        return 24 * nobs + cams + pts + 2 * 336 * nc
     if kernel == 'cost':
         return 24 * nobs + cams + pts + 4 * nc + nt
     if kernel == 'backsub':
-        return obs + 4 * nt + cams + pts + 72 * nt + 48 * nc + 24 * nt
+        return obs + 4 * nt + cams + pts + 72 * nt + 48 * nco + 24 * nt
     if kernel == 'schur_init':
-        return 288 * nco * nco + 336 * nc + 288 * nco
+        return band + 336 * nc + 288 * nco
+    if kernel == 'band_solve':            # read S, write U, re-read U (backward pass)
+        return 3 * band + 4 * 48 * nco
     if kernel == 'flatten':
-        return 2 * 288 * nco * nco
-    if kernel == 'mirror':
-        return 288 * nco * nco
+        return band + 288 * nco * nco
     if kernel == 'point_invert':
         return 96 * nt
     if kernel == 'update':
-        return 2 * (96 * nc + 24 * nt) + 48 * nc + 24 * nt
+        return 2 * (96 * nc + 24 * nt) + 48 * nco + 24 * nt
     return 0
 
 
@@ -199,9 +202,7 @@ def main():
         dom = max(ours, key=lambda k: ours[k]['ms'])
         avg_ms = ours[dom]['ms'] / ours[dom]['launches']
         nco = be.nco
-        track_len = nobs_local / max(1, be.nt)
-        nnzb_upper = int(nco * track_len - track_len * (track_len - 1) / 2)     # band of half-width L-1, upper part
-        B = algorithmic_bytes(dom, be.nc, nco, be.nt, nobs_local, be.nt, nnzb_upper)
+        B = algorithmic_bytes(dom, be.nc, nco, be.nt, nobs_local, be.nt, be.half_bandwidth)
         achieved = B / (avg_ms * 1e-3) / 1e9
         out = {
             'metric': 'LM-iter throughput (obs/sec) + final reproj RMSE, 1k-cam/100k-pt/1M-obs scene',
@@ -217,6 +218,8 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': B,
                          'avg_launch_ms': avg_ms, 'launches': ours[dom]['launches']},
             'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in ours.items()},
+            'reduced_system': {'cameras_optimised': nco, 'block_half_bandwidth': be.half_bandwidth,
+                               'bytes': 8 * be.S_doubles, 'solve_path': getattr(be, 'last_solve_path', None)},
         }
         out.update(lm)
         if ngpus == 1 and not args.no_cpu_baseline:

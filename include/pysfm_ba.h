@@ -56,7 +56,7 @@ typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_se
 /* kernel ids for ba_get_timings */
 enum {
   BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
-  BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_MIRROR, BA_K_EVAL, BA_K_COUNT
+  BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_COUNT
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -113,28 +113,42 @@ int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP
  * damping: diag *= (1+lambda) on every HCC / HPP block (optimize.py:7-9).
  * pinv_rcond >= 0: numpy.linalg.pinv(HPP, rcond) semantics; < 0: plain inverse
  * (SCHUR_COMPLIMENT_PINV_THRESHOLD = None).  Needs ba_linearize first.
- * The reduced system stays on the device as upper-triangular 6x6 blocks. */
+ * The reduced system stays on the device in block-band form (see ba_reduced_layout). */
 int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond);
-/* S[nco*nco*36] laid out (nco,nco,6,6) and b[nco*6], full symmetric (host) */
+/* Layout of the device-resident reduced system.  S is symmetric; only 6x6 blocks (i, j)
+ * with i <= j <= i + hb can be non-zero, hb = widest spread of optimised-camera
+ * positions inside one track (hb = nco-1 is a dense system).  Block (i, i+d) starts at
+ * ((i*(hb+1) + d)*36 doubles; S_doubles = nco*(hb+1)*36.  b has nco*6 doubles. */
+int ba_reduced_layout(ba_handle* h, int32_t* nco, int32_t* half_bandwidth, int64_t* S_doubles);
+/* S[nco*nco*36] laid out (nco,nco,6,6) and b[nco*6], expanded to the reference's dense
+ * symmetric form (host) */
 int ba_get_reduced(ba_handle* h, double* S, double* b);
 /* HPP_invs[nt*9] (host) */
 int ba_get_point_inverses(ba_handle* h, double* HPP_inv);
 
-/* Device views of the reduced system for the collective and the solver:
- * S_blocks = nco*nco*36 doubles (block (i,j) at (i*nco+j)*36, only i<=j filled
- * until ba_mirror_reduced), b = nco*6 doubles.  With ba_bind_reduced_buffers the
- * caller supplies the device memory (e.g. a torch tensor) instead. */
-int ba_reduced_device_ptrs(ba_handle* h, void** S_blocks, void** b);
-int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev);
-int ba_mirror_reduced(ba_handle* h);
-/* Flat (6nco x 6nco) system with rows/cols of masked camera parameters deleted
- * (solve_motion_normal_eqns, bundle_adjuster.py:290-299).  keep[nkeep] lists the
- * kept flat parameter indices (host).  A_dev[nkeep*nkeep], rhs_dev[nkeep] are
- * caller-owned DEVICE buffers. */
+/* Device views of the reduced system for the collective and the dense solver
+ * (sizes: ba_reduced_layout).  With ba_bind_reduced_buffers the caller supplies the
+ * device memory (e.g. one torch tensor holding [S | b]) instead. */
+int ba_reduced_device_ptrs(ba_handle* h, void** S_band, void** b);
+int ba_bind_reduced_buffers(ba_handle* h, void* S_band_dev, void* b_dev);
+
+/* ---- BundleAdjuster.solve_motion_normal_eqns (bundle_adjuster.py:281-312)
+ * Device-resident solve of the block-banded system by block Cholesky (k_band_solve).
+ * cam_param_mask[nco*6] (host, may be NULL = all kept): 0 deletes that camera parameter
+ * from the system (its solution entry is 0).  *info: 0 = solved, solution stays on the
+ * device for ba_backsubstitute / ba_get_solution; > 0 = pivot `info` was not positive
+ * (system not SPD: use the dense path, which has the reference's LU / LinAlgError
+ * semantics); -1 = band too wide for the on-chip window (use the dense path). */
+int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
+int ba_get_solution(ba_handle* h, double* dC /*[nco*6] host*/);
+/* Dense path: flat (6nco x 6nco) system with rows/cols of masked camera parameters
+ * deleted (bundle_adjuster.py:290-299).  keep[nkeep] lists the kept flat parameter
+ * indices (host).  A_dev[nkeep*nkeep], rhs_dev[nkeep] are caller-owned DEVICE buffers. */
 int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A_dev, void* rhs_dev);
 
 /* ---- BundleAdjuster.backsubstitute (bundle_adjuster.py:316-331)
- * dC[nco*6] host (solution of the reduced system, zeros at masked parameters);
+ * dC[nco*6] host (solution of the reduced system, zeros at masked parameters), or NULL
+ * to use the device-resident solution of ba_solve_reduced;
  * dP[nt*3] for every track position (host, may be NULL: result stays on device). */
 int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP);
 

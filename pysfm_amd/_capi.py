@@ -18,7 +18,7 @@ BA_ERR_INVALID_ARG, BA_ERR_NO_DEVICE, BA_ERR_HIP, BA_ERR_STATE, BA_ERR_SINGULAR,
 SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER = 0, 1, 2
 PARAMS_CUR, PARAMS_TRIAL = 0, 1
 KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 'backsub',
-              'update', 'flatten', 'mirror', 'eval')
+              'update', 'flatten', 'band_solve', 'eval', 'camera_blocks')
 K_COUNT = len(KERNEL_IDS)
 
 _dp = C.POINTER(C.c_double)
@@ -48,7 +48,9 @@ PROTOTYPES = {
     'ba_get_point_inverses': (C.c_int, [_h, _dp]),
     'ba_reduced_device_ptrs': (C.c_int, [_h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'ba_bind_reduced_buffers': (C.c_int, [_h, C.c_void_p, C.c_void_p]),
-    'ba_mirror_reduced': (C.c_int, [_h]),
+    'ba_reduced_layout': (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    'ba_solve_reduced': (C.c_int, [_h, _bp, C.POINTER(C.c_int32)]),
+    'ba_get_solution': (C.c_int, [_h, _dp]),
     'ba_flatten_reduced': (C.c_int, [_h, _ip, C.c_int32, C.c_void_p, C.c_void_p]),
     'ba_backsubstitute': (C.c_int, [_h, C.c_int, _dp, _dp]),
     'ba_apply_update': (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp]),

@@ -96,15 +96,18 @@ class HipBackend(object):
                                              capi.iptr(obs_pt), capi.dptr(obs_z), capi.dptr(K),
                                              capi.iptr(cam_opt_pos), capi.bptr(pt_opt)))
         self.nc, self.nt, self.nobs = int(nc), int(nt), len(obs_cam)
-        self.nco = int(np.sum(cam_opt_pos >= 0))
+        nco, hb, nS = C.c_int32(), C.c_int32(), C.c_int64()
+        self._check(self._lib.ba_reduced_layout(self._h, C.byref(nco), C.byref(hb), C.byref(nS)))
+        self.nco, self.half_bandwidth, self.S_doubles = nco.value, hb.value, nS.value
         self._S_t = self._b_t = None
+        self._host_dC = None
         if self._torch is not None:
             self._bind_reduced()
 
     def _bind_reduced(self):
         torch = self._torch
         dev = torch.device('cuda', self.device)
-        nS, nb = max(1, self.nco * self.nco * 36), max(1, self.nco * 6)
+        nS, nb = max(1, self.S_doubles), max(1, self.nco * 6)
         self._Sb_t = torch.empty(nS + nb, dtype=torch.float64, device=dev)   # [S | b]: one collective
         self._S_t, self._b_t = self._Sb_t[:nS], self._Sb_t[nS:]
         self._check(self._lib.ba_bind_reduced_buffers(self._h, C.c_void_p(self._S_t.data_ptr()),
@@ -171,8 +174,8 @@ class HipBackend(object):
         self._check(self._lib.ba_schur(self._h, which, float(damping), -1.0 if rcond is None else float(rcond)))
 
     def reduced_tensors(self):
-        """torch views (S_blocks[nco*nco*36], b[nco*6]) of the device-resident reduced
-        system - the payload of the multi-GPU all-reduce.  Upper block triangle only."""
+        """torch views (S_band[nco*(hb+1)*36], b[nco*6]) of the device-resident reduced
+        system in block-band layout (include/pysfm_ba.h ba_reduced_layout)."""
         if self._S_t is None:
             raise capi.HipDeviceError('reduced_tensors needs torch with a visible GPU')
         return self._S_t, self._b_t
@@ -193,17 +196,36 @@ class HipBackend(object):
         self._check(self._lib.ba_get_point_inverses(self._h, capi.dptr(out)))
         return out
 
-    def solve_reduced(self, keep):
-        """Solve the reduced camera system restricted to the flat parameter indices
-        ``keep`` (solve_motion_normal_eqns, bundle_adjuster.py:281-312).  Returns the
-        solution for the kept unknowns; raises ReducedSystemSingular."""
-        keep = capi.i32(keep)
+    def solve_reduced(self, cam_param_mask=None):
+        """Solve the reduced camera system with the masked camera parameters deleted
+        (solve_motion_normal_eqns, bundle_adjuster.py:281-312).  The solution stays on
+        the device for backsubstitute(); get_solution() fetches it.
+        Path 1: block-band Cholesky in one HIP kernel (k_band_solve).  Path 2, when the
+        band is too wide for its on-chip window or the system is not positive definite:
+        dense LU (numpy.linalg.solve = LAPACK gesv on the host for small systems, the
+        reference's own call; torch.linalg.solve_ex = rocSOLVER on the GPU for large
+        ones).  Raises ReducedSystemSingular where the reference's solve would raise."""
+        self._host_dC = None
+        n = self.nco * 6
+        mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
+        assert mask is None or mask.shape == (n,)
+        info = C.c_int32(0)
+        self._check(self._lib.ba_solve_reduced(self._h, capi.bptr(mask), C.byref(info)))
+        self.last_solve_path = 'band' if info.value == 0 else 'dense'
+        if info.value == 0:
+            return
+        keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
+        dC = np.zeros(n)
+        dC[keep] = self._solve_dense(keep)
+        self._host_dC = dC.reshape(-1, 6)
+
+    def _solve_dense(self, keep):
         n = len(keep)
         if n == 0:
             return np.zeros(0)
         torch = self._torch
         if torch is None:
-            raise capi.HipDeviceError('solve_reduced needs torch with a visible GPU for the device buffers')
+            raise capi.HipDeviceError('the dense reduced solve needs torch with a visible GPU for its device buffers')
         dev = torch.device('cuda', self.device)
         if self._A_t is None or self._A_t.numel() < n * n:
             self._A_t = torch.empty(n * n, dtype=torch.float64, device=dev)
@@ -222,11 +244,24 @@ class HipBackend(object):
             raise ReducedSystemSingular
         return x.squeeze(1).cpu().numpy()
 
-    def backsubstitute(self, which, dC, fetch=True):
-        dC = capi.f64(dC, (-1, 6))
-        assert len(dC) == self.nco
+    def get_solution(self):
+        """dC[nco,6] of the last solve_reduced()."""
+        if self._host_dC is not None:
+            return self._host_dC.copy()
+        dC = np.empty((self.nco, 6))
+        self._check(self._lib.ba_get_solution(self._h, capi.dptr(dC)))
+        return dC
+
+    def backsubstitute(self, which, dC=None, fetch=True):
+        """dC None: use the solution of solve_reduced()."""
+        if dC is None:
+            dC = self._host_dC
+        if dC is not None:
+            dC = capi.f64(dC, (-1, 6))
+            assert len(dC) == self.nco
         dP = np.empty((self.nt, 3)) if fetch else None
         self._check(self._lib.ba_backsubstitute(self._h, which, capi.dptr(dC), capi.dptr(dP)))
+        self._host_dC = None
         return dP
 
     def apply_update(self, src, dst, motion=None, structure=None):

@@ -10,7 +10,7 @@ kernel behind the C ABI of include/pysfm_ba.h:
     compute_cost              -> ba_cost                    (k_cost)
     prepare_schur_complement  -> ba_linearize               (k_linearize)
     apply_damping + compute_schur_complement -> ba_schur    (k_point_invert, k_schur_init, k_schur_pairs)
-    solve_motion_normal_eqns  -> ba_flatten_reduced (k_flatten) + LAPACK / rocSOLVER LU
+    solve_motion_normal_eqns  -> ba_solve_reduced (k_band_solve: block-band Cholesky); dense LU fallback
     backsubstitute            -> ba_backsubstitute          (k_backsub)
     update_motion / update_structure -> ba_apply_update     (k_apply_update)
 
@@ -284,15 +284,12 @@ class BundleAdjuster(object):
         self._have_blocks = True
         self._damp_factor = 1. + damping
         self._schur_device()
-        keep = np.nonzero(cam_param_mask)[0].astype(np.int32)
         try:
-            x = be.solve_reduced(keep)
+            be.solve_reduced(None if np.all(cam_param_mask) else cam_param_mask)
         except ReducedSystemSingular:
             raise NormalEquationsIllconditioned
-        dC = np.zeros(len(cam_param_mask))
-        dC[keep] = x
-        dC = dC.reshape(-1, 6)
-        dP = be.backsubstitute(PARAMS_CUR, dC, fetch=fetch)
+        dC = be.get_solution() if fetch else None
+        dP = be.backsubstitute(PARAMS_CUR, None, fetch=fetch)
         return dC, dP
 
     def _schur_device(self):

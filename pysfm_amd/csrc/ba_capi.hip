@@ -48,6 +48,7 @@ struct ba_handle {
 
   // problem
   int nc = 0, nt = 0, nco = 0;
+  int hb = 0;                // block half-bandwidth of the reduced system
   long long nobs = 0;
   bool have_problem = false;
   bool have_params[2] = {false, false};
@@ -60,6 +61,9 @@ struct ba_handle {
   DevBuf<unsigned char> pt_opt;
   DevBuf<SchurUnit> units;
   int nunits = 0;
+  DevBuf<int> cam_perm;
+  DevBuf<CamUnit> cam_units;
+  int ncam_units = 0;
   std::vector<int> h_cam_opt_pos;
   std::vector<unsigned char> h_pt_opt;
 
@@ -68,11 +72,12 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dCfull, dP, partial, scalar, scratch;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, partial, scalar, scratch, Ufac, ysol, dinv;
+  DevBuf<unsigned char> mask;
+  bool have_solution = false;
   DevBuf<int> flags;
   double* S = nullptr;       // nco*nco*36 (own or bound)
   double* b = nullptr;       // nco*6
-  bool mirrored = false;
 
   // timing
   bool timing = false;
@@ -143,7 +148,7 @@ inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1
 
 DevProblem dev_problem(const ba_handle* h) {
   DevProblem P;
-  P.nc = h->nc; P.nt = h->nt; P.nco = h->nco; P.nobs = h->nobs;
+  P.nc = h->nc; P.nt = h->nt; P.nco = h->nco; P.hb = h->hb; P.nobs = h->nobs;
   P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p; P.obs_z = h->obs_z.p; P.pt_off = h->pt_off.p;
   P.cam_opt_pos = h->cam_opt_pos.p; P.pt_opt = h->pt_opt.p;
   std::memcpy(P.K, h->K, sizeof P.K);
@@ -151,9 +156,37 @@ DevProblem dev_problem(const ba_handle* h) {
   return P;
 }
 
+inline size_t reduced_doubles(const ba_handle* h) { return (size_t)h->nco * (h->hb + 1) * 36; }
+
+// k_band_solve is instantiated per block half-bandwidth (compile-time unrolling)
+template <int HB>
+hipError_t launch_band_solve_hb(size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+                                const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_band_solve<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_band_solve<HB>, dim3(1), dim3(kSolveThreads), lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
+  return hipGetLastError();
+}
+
+hipError_t launch_band_solve(int hb, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+                             const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
+#define BA_HB_CASE(N) case N: return launch_band_solve_hb<N>(lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
+  switch (hb) {
+    BA_HB_CASE(0) BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7)
+    BA_HB_CASE(8) BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11) BA_HB_CASE(12) BA_HB_CASE(13) BA_HB_CASE(14)
+    BA_HB_CASE(15) BA_HB_CASE(16) BA_HB_CASE(17) BA_HB_CASE(18) BA_HB_CASE(19) BA_HB_CASE(20) BA_HB_CASE(21)
+    default: return hipErrorInvalidValue;
+  }
+#undef BA_HB_CASE
+}
+
 int ensure_reduced(ba_handle* h) {
   if (!h->S) {
-    HIPCHECK(h, h->S_own.resize(std::max<size_t>(1, (size_t)h->nco * h->nco * 36)));
+    HIPCHECK(h, h->S_own.resize(std::max<size_t>(1, reduced_doubles(h))));
     h->S = h->S_own.p;
   }
   if (!h->b) {
@@ -172,7 +205,7 @@ const char* ba_version(void) { return "pysfm_ba 0.1 (gfx950)"; }
 const char* ba_kernel_name(int id) {
   static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
                                           "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
-                                          "k_mirror", "k_eval"};
+                                          "k_band_solve", "k_eval", "k_camera_blocks"};
   return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
 }
 
@@ -215,10 +248,10 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
-  h->W.release(); h->S_own.release(); h->b_own.release(); h->dCfull.release(); h->dP.release();
+  h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release(); h->mask.release(); h->dP.release();
   h->partial.release(); h->scalar.release(); h->scratch.release(); h->flags.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -290,16 +323,41 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     for (int r = 0; r < L; r += kTile)
       for (int c = r; c < L; c += kTile) units.push_back({k, r, c});
   }
+  // camera-ordered view of the observations for k_camera_blocks: counting sort by camera
+  std::vector<int> cam_off((size_t)nc + 1, 0), perm((size_t)nobs);
+  for (int64_t n = 0; n < nobs; ++n) cam_off[(size_t)obs_cam[n] + 1] += 1;
+  for (int i = 0; i < nc; ++i) cam_off[(size_t)i + 1] += cam_off[i];
+  {
+    std::vector<int> cursor(cam_off.begin(), cam_off.end() - 1);
+    for (int64_t n = 0; n < nobs; ++n) perm[(size_t)cursor[obs_cam[n]]++] = (int)n;
+  }
+  std::vector<CamUnit> cam_units;
+  for (int i = 0; i < nc; ++i)
+    for (int s = cam_off[i]; s < cam_off[(size_t)i + 1]; s += kCamChunk)
+      cam_units.push_back({i, s, std::min(s + kCamChunk, cam_off[(size_t)i + 1])});
+  // block half-bandwidth of the reduced system: widest spread of optimised-camera
+  // positions within one track
+  int hb = 0;
+  for (int k = 0; k < nt; ++k) {
+    int lo = INT32_MAX, hi = -1;
+    for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+      const int p = cam_opt_pos[obs_cam[n]];
+      if (p < 0) continue;
+      lo = std::min(lo, p); hi = std::max(hi, p);
+    }
+    if (hi >= 0) hb = std::max(hb, hi - lo);
+  }
   // lanes per point: smallest power of two >= mean track length, in [1, 64]
   int glog = 0;
   const double meanL = nt > 0 ? (double)nobs / nt : 1.0;
   while ((1 << glog) < meanL && glog < 6) ++glog;
 
-  h->nc = nc; h->nt = nt; h->nco = nco; h->nobs = nobs; h->glog = glog;
+  h->nc = nc; h->nt = nt; h->nco = nco; h->hb = hb; h->nobs = nobs; h->glog = glog;
   std::memcpy(h->K, K, sizeof h->K);
   h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
   h->h_pt_opt.assign(pt_opt, pt_opt + nt);
   h->nunits = (int)units.size();
+  h->ncam_units = (int)cam_units.size();
 
   HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, nobs)));
   HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, nobs)));
@@ -308,6 +366,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
   HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
   HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
+  HIPCHECK(h, h->cam_perm.resize(std::max<size_t>(1, perm.size())));
+  HIPCHECK(h, h->cam_units.resize(std::max<size_t>(1, cam_units.size())));
+  if (!perm.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->cam_perm.p, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (!cam_units.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->cam_units.p, cam_units.data(), cam_units.size() * sizeof(CamUnit), hipMemcpyHostToDevice, h->stream));
   if (nobs) {
     HIPCHECK(h, hipMemcpyAsync(h->obs_cam.p, obs_cam, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->obs_pt.p, obs_pt, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -328,7 +392,10 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->HPP.resize(std::max<size_t>(1, (size_t)nt * 6)));
   HIPCHECK(h, h->bP.resize(std::max<size_t>(1, (size_t)nt * 3)));
   HIPCHECK(h, h->HPPinv.resize(std::max<size_t>(1, (size_t)nt * 6)));
-  HIPCHECK(h, h->dCfull.resize(std::max<size_t>(1, (size_t)nc * 6)));
+  HIPCHECK(h, h->dC.resize(std::max<size_t>(1, (size_t)nco * 6)));
+  HIPCHECK(h, h->ysol.resize(std::max<size_t>(1, (size_t)nco * 6)));
+  HIPCHECK(h, h->dinv.resize(std::max<size_t>(1, (size_t)nco * 6)));
+  HIPCHECK(h, h->mask.resize(std::max<size_t>(1, (size_t)nco * 6)));
   HIPCHECK(h, h->dP.resize(std::max<size_t>(1, (size_t)nt * 3)));
   HIPCHECK(h, h->partial.resize(2048));
   HIPCHECK(h, h->scalar.resize(8));
@@ -337,7 +404,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->S = nullptr; h->b = nullptr;
   h->have_problem = true;
   h->have_params[0] = h->have_params[1] = false;
-  h->have_linearization = h->have_schur = h->have_backsub = false;
+  h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
   h->cur = 0;
   HIPCHECK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
   return BA_OK;
@@ -502,7 +569,14 @@ int ba_linearize(ba_handle* h, int which, int store_W) {
     ScopedTimer tm(h, BA_K_LINEARIZE);
     const long long threads = (long long)h->nt << h->glog;
     hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
-                       h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd);
+                       h->cams[p].p, h->X[p].p, h->glog, (double*)nullptr, (double*)nullptr, h->HPP.p, h->bP.p, Wd);
+  }
+  if (h->ncam_units > 0) {
+    ScopedTimer tm(h, BA_K_CAMERA_BLOCKS);
+    const int per_block = kBlock / kWave;
+    hipLaunchKernelGGL(k_camera_blocks, dim3((h->ncam_units + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
+                       dev_problem(h), h->cams[p].p, h->X[p].p, h->cam_perm.p, h->cam_units.p, h->ncam_units, h->HCC.p,
+                       h->bC.p);
   }
   HIPCHECK(h, hipGetLastError());
   h->have_linearization = true;
@@ -558,11 +632,11 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   }
   {
     ScopedTimer tm(h, BA_K_SCHUR_INIT);
-    HIPCHECK(h, hipMemsetAsync(h->S, 0, (size_t)h->nco * h->nco * 36 * sizeof(double), h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->S, 0, reduced_doubles(h) * sizeof(double), h->stream));
     HIPCHECK(h, hipMemsetAsync(h->b, 0, (size_t)h->nco * 6 * sizeof(double), h->stream));
     if (h->nc > 0)
       hipLaunchKernelGGL(k_schur_init, dim3(blocks_for((long long)h->nc * 36)), dim3(kBlock), 0, h->stream, h->nc,
-                         h->nco, h->cam_opt_pos.p, h->HCC.p, h->bC.p, damping, h->S, h->b);
+                         h->hb + 1, h->cam_opt_pos.p, h->HCC.p, h->bC.p, damping, h->S, h->b);
   }
   if (h->nunits > 0) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
@@ -571,9 +645,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                        dev_problem(h), h->cams[p].p, h->X[p].p, h->units.p, h->nunits, h->HPPinv.p, h->bP.p, h->S, h->b);
   }
   HIPCHECK(h, hipGetLastError());
-  h->mirrored = false;
   h->have_schur = true;
-  h->have_backsub = false;
+  h->have_backsub = h->have_solution = false;
   if (pinv_rcond < 0.0) {   // plain-inverse mode must report singular blocks (numpy.linalg.inv raises)
     int nsing = 0;
     HIPCHECK(h, hipMemcpyAsync(&nsing, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -583,26 +656,38 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   return BA_OK;
 }
 
-int ba_mirror_reduced(ba_handle* h) {
+int ba_reduced_layout(ba_handle* h, int32_t* nco, int32_t* half_bandwidth, int64_t* S_doubles) {
   if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_mirror_reduced: call ba_schur first");
-  HIPCHECK(h, hipSetDevice(h->device));
-  if (h->nco > 0) {
-    ScopedTimer tm(h, BA_K_MIRROR);
-    hipLaunchKernelGGL(k_mirror, dim3(blocks_for((long long)h->nco * h->nco * 36)), dim3(kBlock), 0, h->stream, h->nco, h->S);
-  }
-  HIPCHECK(h, hipGetLastError());
-  h->mirrored = true;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_reduced_layout: call ba_set_problem first");
+  if (nco) *nco = h->nco;
+  if (half_bandwidth) *half_bandwidth = h->hb;
+  if (S_doubles) *S_doubles = (int64_t)reduced_doubles(h);
   return BA_OK;
 }
 
 int ba_get_reduced(ba_handle* h, double* S, double* b) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_get_reduced: call ba_schur first");
-  if (!h->mirrored) { int rc = ba_mirror_reduced(h); if (rc != BA_OK) return rc; }
-  if (S && h->nco) HIPCHECK(h, hipMemcpyAsync(S, h->S, (size_t)h->nco * h->nco * 36 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (b && h->nco) HIPCHECK(h, hipMemcpyAsync(b, h->b, (size_t)h->nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipSetDevice(h->device));
+  const int nco = h->nco, hb1 = h->hb + 1;
+  std::vector<double> band(S ? reduced_doubles(h) : 0);
+  if (S && nco) HIPCHECK(h, hipMemcpyAsync(band.data(), h->S, band.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (b && nco) HIPCHECK(h, hipMemcpyAsync(b, h->b, (size_t)nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (S && nco) {   // expand the block band to the reference's dense (nco,nco,6,6), mirroring the upper triangle
+    std::memset(S, 0, (size_t)nco * nco * 36 * sizeof(double));
+    for (int i = 0; i < nco; ++i)
+      for (int d = 0; d < hb1 && i + d < nco; ++d) {
+        const double* src = &band[((size_t)i * hb1 + d) * 36];
+        double* up = S + ((size_t)i * nco + (i + d)) * 36;
+        std::memcpy(up, src, 36 * sizeof(double));
+        if (d > 0) {
+          double* lo = S + ((size_t)(i + d) * nco + i) * 36;
+          for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 6; ++c) lo[c * 6 + a] = src[a * 6 + c];
+        }
+      }
+  }
   return BA_OK;
 }
 
@@ -653,11 +738,60 @@ int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A
   HIPCHECK(h, hipMemcpyAsync(h->keep.p, keep, nkeep * sizeof(int), hipMemcpyHostToDevice, h->stream));
   {
     ScopedTimer tm(h, BA_K_FLATTEN);
-    hipLaunchKernelGGL(k_flatten, dim3(blocks_for((long long)nkeep * nkeep)), dim3(kBlock), 0, h->stream, h->nco, nkeep,
-                       h->keep.p, h->S, h->b, (double*)A_dev, (double*)rhs_dev);
+    hipLaunchKernelGGL(k_flatten, dim3(blocks_for((long long)nkeep * nkeep)), dim3(kBlock), 0, h->stream, h->nco, h->hb,
+                       nkeep, h->keep.p, h->S, h->b, (double*)A_dev, (double*)rhs_dev);
   }
   HIPCHECK(h, hipGetLastError());
   HIPCHECK(h, hipStreamSynchronize(h->stream));   // `keep` is caller memory
+  return BA_OK;
+}
+
+int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_solve_reduced: call ba_schur first");
+  REQUIRE(h, info, BA_ERR_INVALID_ARG, "ba_solve_reduced: info is NULL");
+  if (h->hb > kMaxBandSolve) { *info = -1; return BA_OK; }     // band too wide for the LDS window
+  if (h->nco == 0) { *info = 0; h->have_solution = true; return BA_OK; }
+  HIPCHECK(h, hipSetDevice(h->device));
+  HIPCHECK(h, h->Ufac.resize(std::max<size_t>(1, reduced_doubles(h))));
+  const unsigned char* dmask = nullptr;
+  if (cam_param_mask) {
+    bool all = true;
+    for (int i = 0; i < h->nco * 6; ++i) all = all && cam_param_mask[i];
+    if (!all) {
+      HIPCHECK(h, hipMemcpyAsync(h->mask.p, cam_param_mask, (size_t)h->nco * 6, hipMemcpyHostToDevice, h->stream));
+      dmask = h->mask.p;
+    }
+  }
+  const size_t lds_budget = 160 * 1024;
+  const int ch = band_solve_chunk(h->hb, lds_budget);
+  if (ch < 1) { *info = -1; return BA_OK; }
+  const size_t lds = band_solve_lds_bytes(h->hb, ch);
+  {
+    ScopedTimer tm(h, BA_K_BAND_SOLVE);
+    hipError_t le = launch_band_solve(h->hb, lds, h->stream, h->nco, ch, h->S, h->b, dmask, h->Ufac.p, h->ysol.p,
+                                      h->dinv.p, h->dC.p, h->flags.p + 1);
+    if (le != hipSuccess) return h->fail(BA_ERR_HIP, "k_band_solve launch failed: %s", hipGetErrorString(le));
+  }
+  HIPCHECK(h, hipGetLastError());
+  int inf6[6] = {0, 0, 0, 0, 0, 0};
+  HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  const int inf = inf6[0];
+  if (getenv("BA_SOLVE_TRACE"))
+    fprintf(stderr, "[k_band_solve] nco=%d hb=%d ch=%d lds=%zu B | forward: %d cycles, %d ticks(100MHz) | total: %d cycles, %d ticks\n",
+            h->nco, h->hb, ch, lds, inf6[2], inf6[3], inf6[4], inf6[5]);
+  *info = inf;
+  h->have_solution = inf == 0;
+  return BA_OK;
+}
+
+int ba_get_solution(ba_handle* h, double* dC) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_solution && dC, BA_ERR_STATE, "ba_get_solution: no solution on the device (ba_solve_reduced)");
+  HIPCHECK(h, hipSetDevice(h->device));
+  if (h->nco) HIPCHECK(h, hipMemcpyAsync(dC, h->dC.p, (size_t)h->nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
   return BA_OK;
 }
 
@@ -666,23 +800,22 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
   REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_backsubstitute: bad parameter set");
   const int p = h->phys(which);
   REQUIRE(h, h->have_schur && h->have_params[p], BA_ERR_STATE, "ba_backsubstitute: call ba_schur first");
-  REQUIRE(h, dC || h->nco == 0, BA_ERR_INVALID_ARG, "ba_backsubstitute: dC is NULL");
+  REQUIRE(h, dC || h->have_solution || h->nco == 0, BA_ERR_STATE,
+          "ba_backsubstitute: dC is NULL and no device solution exists (ba_solve_reduced)");
   HIPCHECK(h, hipSetDevice(h->device));
-  std::vector<double> full((size_t)h->nc * 6, 0.0);
-  for (int i = 0; i < h->nc; ++i) {
-    const int pos = h->h_cam_opt_pos[i];
-    if (pos >= 0) std::memcpy(&full[(size_t)i * 6], dC + (size_t)pos * 6, 6 * sizeof(double));
+  if (dC && h->nco) {
+    HIPCHECK(h, hipMemcpyAsync(h->dC.p, dC, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->have_solution = true;
   }
-  if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->dCfull.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_BACKSUB);
     const long long threads = (long long)h->nt << h->glog;
     hipLaunchKernelGGL(k_backsub, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
-                       h->X[p].p, h->glog, h->dCfull.p, h->HPPinv.p, h->bP.p, h->dP.p);
+                       h->X[p].p, h->glog, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p);
   }
   HIPCHECK(h, hipGetLastError());
   if (dP && h->nt) HIPCHECK(h, hipMemcpyAsync(dP, h->dP.p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));   // `full` is a host temporary
+  if (dC || dP) HIPCHECK(h, hipStreamSynchronize(h->stream));   // dC is caller memory
   h->have_backsub = true;
   return BA_OK;
 }
@@ -696,24 +829,18 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
           "ba_apply_update: give both motion and structure, or neither");
   HIPCHECK(h, hipSetDevice(h->device));
   double sign = -1.0;
-  std::vector<double> full;
   if (motion) {
     sign = 1.0;
-    full.assign((size_t)h->nc * 6, 0.0);
-    for (int i = 0; i < h->nc; ++i) {
-      const int pos = h->h_cam_opt_pos[i];
-      if (pos >= 0) std::memcpy(&full[(size_t)i * 6], motion + (size_t)pos * 6, 6 * sizeof(double));
-    }
-    if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->dCfull.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->nco) HIPCHECK(h, hipMemcpyAsync(h->dC.p, motion, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (h->nt) HIPCHECK(h, hipMemcpyAsync(h->dP.p, structure, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    h->have_backsub = false;   // dCfull / dP now hold the caller's update
+    h->have_backsub = h->have_solution = false;   // dC / dP now hold the caller's update
   } else {
     REQUIRE(h, h->have_backsub, BA_ERR_STATE, "ba_apply_update: no update on the device (call ba_backsubstitute)");
   }
   if (h->nc + h->nt > 0) {
     ScopedTimer tm(h, BA_K_UPDATE);
     hipLaunchKernelGGL(k_apply_update, dim3(blocks_for((long long)h->nc + h->nt)), dim3(kBlock), 0, h->stream, h->nc,
-                       h->nt, h->cam_opt_pos.p, h->pt_opt.p, h->cams[ps].p, h->X[ps].p, h->dCfull.p, h->dP.p, sign,
+                       h->nt, h->cam_opt_pos.p, h->pt_opt.p, h->cams[ps].p, h->X[ps].p, h->dC.p, h->dP.p, sign,
                        h->cams[pd].p, h->X[pd].p);
   }
   HIPCHECK(h, hipGetLastError());

@@ -27,6 +27,7 @@ constexpr int kTile = 32;         // observations of one track staged per Schur 
 
 struct DevProblem {
   int nc, nt, nco;
+  int hb;                   // block half-bandwidth of the reduced system (see reduced-system layout below)
   long long nobs;
   const int* obs_cam;
   const int* obs_pt;
@@ -51,6 +52,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
+}
+
+// Reduced-system layout ("block band"): S is symmetric with 6x6 blocks; only blocks
+// (i, j) with i <= j <= i + hb can be non-zero, where hb = max over tracks of the spread
+// of their optimised-camera positions.  Block (i, i+d) lives at ((i*(hb+1) + d)*36.
+// A dense system is the special case hb = nco-1; a camera sequence with tracks of
+// length 10 has hb = 9 and stores 5.5 MB instead of 288 MB at 1000 cameras.
+__device__ __forceinline__ size_t band_block(int pi, int pj, int hb1) {
+  return ((size_t)pi * hb1 + (pj - pi)) * 36;
 }
 
 // hardware fp64 atomic add (global_atomic_add_f64 / ds_add_f64 on gfx950)
@@ -152,8 +162,10 @@ __global__ __launch_bounds__(kBlock) void k_eval_sensor(Sensor s, long long n, c
 // prepare_schur_complement (bundle_adjuster.py:211-234).
 // A group of G = 2^glog lanes owns one point: lane l takes observations
 // s+l, s+l+G, ...  HPP / bP are reduced across the group with shuffles and
-// written once (deterministic); HCC / bC go to the camera records with fp64
-// atomics (upper triangle of HCC only).  W is written only on request.
+// written once (deterministic).  W is written only on request.  The camera blocks
+// HCC / bC are produced by k_camera_blocks below (a second, camera-ordered pass over
+// the observations) because 1000 observations per camera hammering 27 addresses with
+// atomics is ~50x slower than re-reading 24 bytes per observation.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double* __restrict__ cams,
                                                       const double* __restrict__ X, int glog,
@@ -178,12 +190,14 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     double cm[12], e[2], r[2], Jc[12], Jp[6];
     load_cam(cams, c, cm);
     obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
-    double* hc = HCC + (size_t)c * 36;
+    if (HCC) {      // normally done by k_camera_blocks (no atomics); kept for completeness
+      double* hc = HCC + (size_t)c * 36;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+      for (int a = 0; a < 6; ++a) {
 #pragma unroll
-      for (int b = a; b < 6; ++b) atomic_add_f64(hc + a * 6 + b, Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
-      atomic_add_f64(bC + (size_t)c * 6 + a, Jc[a] * r[0] + Jc[6 + a] * r[1]);
+        for (int b = a; b < 6; ++b) atomic_add_f64(hc + a * 6 + b, Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
+        atomic_add_f64(bC + (size_t)c * 6 + a, Jc[a] * r[0] + Jc[6 + a] * r[1]);
+      }
     }
     hpp[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
     hpp[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
@@ -216,6 +230,60 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
 }
 
 // --------------------------------------------------------------------------
+// HCC[i] += Jc^T Jc, bC[i] += Jc^T r (bundle_adjuster.py:230,233), camera-ordered:
+// one wavefront per (camera, chunk of <= kCamChunk of its observations) walks the
+// camera's observation list `perm` (observation ids sorted by camera), accumulates the
+// 21 + 6 sums in registers, reduces across the 64 lanes and adds ONE result per unit.
+// --------------------------------------------------------------------------
+constexpr int kCamChunk = 2048;
+struct CamUnit { int cam; int begin; int end; };
+
+__global__ __launch_bounds__(kBlock) void k_camera_blocks(DevProblem P, const double* __restrict__ cams,
+                                                          const double* __restrict__ X,
+                                                          const int* __restrict__ perm,
+                                                          const CamUnit* __restrict__ units, int nunits,
+                                                          double* __restrict__ HCC, double* __restrict__ bC) {
+  const int u = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (u >= nunits) return;                       // whole wavefront
+  const CamUnit un = units[u];
+  double cm[12];
+  load_cam(cams, un.cam, cm);
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+  for (int q = un.begin + lane; q < un.end; q += 64) {
+    const int n = perm[q];
+    const int k = P.obs_pt[n];
+    const double2 z = P.obs_z[n];
+    const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
+    double e[2], r[2], Jc[12], Jp[6];
+    obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = a; b < 6; ++b) acc[idx++] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+  }
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+  if (lane == 0) {
+    double* hc = HCC + (size_t)un.cam * 36;
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = a; b < 6; ++b) atomic_add_f64(hc + a * 6 + b, acc[idx++]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) atomic_add_f64(bC + (size_t)un.cam * 6 + a, acc[21 + a]);
+  }
+}
+
+// --------------------------------------------------------------------------
 // apply_damping on HPP (bundle_adjuster.py:241-242, optimize.py:7-9) and the
 // per-point inverse (bundle_adjuster.py:252-256).  One point per lane.
 // --------------------------------------------------------------------------
@@ -243,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* _
 // S[pos,pos] = damped HCC, b[pos] = bC for optimised cameras
 // (bundle_adjuster.py:238-240, 263-265).  S was zero-filled by the caller.
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_schur_init(int nc, int nco, const int* __restrict__ cam_opt_pos,
+__global__ __launch_bounds__(kBlock) void k_schur_init(int nc, int hb1, const int* __restrict__ cam_opt_pos,
                                                        const double* __restrict__ HCC,
                                                        const double* __restrict__ bC, double damping,
                                                        double* __restrict__ S, double* __restrict__ b) {
@@ -256,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_init(int nc, int nco, const in
   const int lo = a < c ? a : c, hi = a < c ? c : a;
   double v = HCC[(size_t)i * 36 + lo * 6 + hi];
   if (a == c) v *= (1.0 + damping);
-  S[((size_t)pos * nco + pos) * 36 + e] = v;
+  S[band_block(pos, pos, hb1) + e] = v;
   if (e < 6) b[(size_t)pos * 6 + e] = bC[(size_t)i * 6 + e];
 }
 
@@ -347,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(DevProblem P, const doub
   if (!active) return;
 
   // ---- phase B
-  const size_t nco = (size_t)P.nco;
+  const int hb1 = P.hb + 1;
   for (int i = 0; i < nr; ++i) {
     const int pi = sPosR[wv][i];
     if (pi < 0) continue;                       // wave-uniform
@@ -361,8 +429,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(DevProblem P, const doub
       const double v = sT[wv][i][a * 3] * sW[wv][j][c * 3] + sT[wv][i][a * 3 + 1] * sW[wv][j][c * 3 + 1] +
                        sT[wv][i][a * 3 + 2] * sW[wv][j][c * 3 + 2];
       // block (pi,pj) entry (a,c); keep the upper block triangle
-      const size_t off = pi <= pj ? ((size_t)pi * nco + pj) * 36 + a * 6 + c
-                                  : ((size_t)pj * nco + pi) * 36 + c * 6 + a;
+      const size_t off = pi <= pj ? band_block(pi, pj, hb1) + a * 6 + c
+                                  : band_block(pj, pi, hb1) + c * 6 + a;
       atomic_add_f64(S + off, -v);
     }
   }
@@ -371,11 +439,11 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(DevProblem P, const doub
 // --------------------------------------------------------------------------
 // backsubstitute (bundle_adjuster.py:316-331):
 //   dP_k = HPPinv_k (bP_k - sum_i W_ik^T dC_i),  W^T dC = Jp^T (Jc dC).
-// dCfull[nc*6] holds zeros for cameras that are not optimised.
+// dC[nco*6] is indexed by optimised-camera position; frozen cameras contribute nothing.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* __restrict__ cams,
                                                     const double* __restrict__ X, int glog,
-                                                    const double* __restrict__ dCfull,
+                                                    const double* __restrict__ dC,
                                                     const double* __restrict__ HPPinv,
                                                     const double* __restrict__ bP, double* __restrict__ dP) {
   const int G = 1 << glog;
@@ -392,12 +460,13 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   double acc[3] = {0, 0, 0};
   for (int n = s + l; n < e_; n += G) {
     const int c = P.obs_cam[n];
-    if (P.cam_opt_pos[c] < 0) continue;
+    const int pos = P.cam_opt_pos[c];
+    if (pos < 0) continue;
     const double2 z = P.obs_z[n];
     double cm[12], e[2], r[2], Jc[12], Jp[6];
     load_cam(cams, c, cm);
     obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
-    const double* d = dCfull + (size_t)c * 6;
+    const double* d = dC + (size_t)pos * 6;
     double v0 = 0.0, v1 = 0.0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) { v0 += Jc[a] * d[a]; v1 += Jc[6 + a] * d[a]; }
@@ -428,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_update(int nc, int nt, const i
                                                          const unsigned char* __restrict__ pt_opt,
                                                          const double* __restrict__ cams_src,
                                                          const double* __restrict__ X_src,
-                                                         const double* __restrict__ dCfull,
+                                                         const double* __restrict__ dC,
                                                          const double* __restrict__ dP, double sign,
                                                          double* __restrict__ cams_dst,
                                                          double* __restrict__ X_dst) {
@@ -438,10 +507,11 @@ __global__ __launch_bounds__(kBlock) void k_apply_update(int nc, int nt, const i
     double cm[12], out[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) cm[q] = cams_src[(size_t)i * 12 + q];
-    if (cam_opt_pos[i] >= 0) {
+    const int pos = cam_opt_pos[i];
+    if (pos >= 0) {
       double d[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) d[q] = sign * dCfull[(size_t)i * 6 + q];
+      for (int q = 0; q < 6; ++q) d[q] = sign * dC[(size_t)pos * 6 + q];
       camera_perturb(cm, d, out);
     } else {
 #pragma unroll
@@ -459,24 +529,11 @@ __global__ __launch_bounds__(kBlock) void k_apply_update(int nc, int nt, const i
 }
 
 // --------------------------------------------------------------------------
-// S is accumulated as an upper block triangle; fill the lower one in place.
-// --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_mirror(int nco, double* __restrict__ S) {
-  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
-  const long long blk = tid / 36;
-  const int e = (int)(tid % 36);
-  if (blk >= (long long)nco * nco) return;
-  const int i = (int)(blk / nco), j = (int)(blk % nco);
-  if (i <= j) return;
-  const int a = e / 6, c = e % 6;
-  S[(size_t)blk * 36 + e] = S[((size_t)j * nco + i) * 36 + c * 6 + a];
-}
-
-// --------------------------------------------------------------------------
 // solve_motion_normal_eqns, the flatten + mask step (bundle_adjuster.py:290-299):
-// A[r,c] = S.transpose(0,2,1,3).reshape(6nco,6nco)[keep[r], keep[c]].
+// A[r,c] = S.transpose(0,2,1,3).reshape(6nco,6nco)[keep[r], keep[c]] from the block band.
+// Used when the band is too wide for k_band_solve (dense LU on the GPU instead).
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_flatten(int nco, int nkeep, const int* __restrict__ keep,
+__global__ __launch_bounds__(kBlock) void k_flatten(int nco, int hb, int nkeep, const int* __restrict__ keep,
                                                     const double* __restrict__ S,
                                                     const double* __restrict__ b, double* __restrict__ Aout,
                                                     double* __restrict__ rhs) {
@@ -485,10 +542,405 @@ __global__ __launch_bounds__(kBlock) void k_flatten(int nco, int nkeep, const in
   const int r = (int)(tid / nkeep), c = (int)(tid % nkeep);
   const int p = keep[r], q = keep[c];
   const int i = p / 6, a = p % 6, j = q / 6, d = q % 6;
-  const double v = i <= j ? S[((size_t)i * nco + j) * 36 + a * 6 + d]
-                          : S[((size_t)j * nco + i) * 36 + d * 6 + a];
+  double v = 0.0;
+  if (i <= j) {
+    if (j - i <= hb) v = S[band_block(i, j, hb + 1) + a * 6 + d];
+  } else if (i - j <= hb) {
+    v = S[band_block(j, i, hb + 1) + d * 6 + a];
+  }
   Aout[tid] = v;
   if (c == 0) rhs[r] = b[p];
+}
+
+// --------------------------------------------------------------------------
+// solve_motion_normal_eqns on the device (bundle_adjuster.py:281-312) for a block-banded
+// reduced system: S x = b by block Cholesky S = U^T U, forward and backward
+// substitution, all in ONE workgroup that slides an LDS window of the last hb block rows
+// of U down the band (left-looking):
+//   row j:  B[d] = S[j,j+d] - sum_{m=1..hb} U[j-m,j]^T U[j-m,j+d]      (d = 0..hb)
+//           U[j,j] = chol(B[0]);  U[j,j+d] = U[j,j]^-T B[d];  y_j likewise from b
+//   then    x_j = U[j,j]^-1 (y_j - sum_d U[j,j+d] x_{j+d})  for j = nco-1 .. 0.
+// Masked camera parameters (param_mask) become identity rows/columns with zero rhs,
+// which deletes them from the system exactly as the reference's row/column deletion
+// does and leaves x = 0 there.  S is SPD whenever the reference's LU solve is
+// meaningful; a non-positive pivot is reported through *info (caller falls back to
+// the dense LU path, which reproduces the reference's LinAlgError semantics).
+// LDS: hb*(hb+1)*288 B ring + one row; hb <= kMaxBandSolve.
+// --------------------------------------------------------------------------
+constexpr int kMaxBandSolve = 21;
+constexpr int kSolveThreads = 256;
+
+// LDS budget of k_band_solve: the U window, two row buffers and a staging area of `ch`
+// band rows (S on the way down, U on the way back) so that global latency is paid once
+// per chunk instead of once per row.
+__host__ __device__ inline size_t band_solve_fixed_doubles(int hb) {
+  const size_t hbm = hb > 0 ? hb : 1;
+  return hbm * (hb + 1) * 36 + hbm * 6 * 2 + 2 * ((size_t)(hb + 1) * 36 + 6) + 16 * 6 + 8;
+}
+__host__ __device__ inline size_t band_solve_row_doubles(int hb) { return (size_t)(hb + 1) * 36 + 12; }
+__host__ __device__ inline int band_solve_chunk(int hb, size_t lds_bytes) {
+  const size_t fixed = band_solve_fixed_doubles(hb) * 8 + (size_t)(hb + 64) * 6 + 64;
+  if (lds_bytes <= fixed) return 0;
+  size_t ch = (lds_bytes - fixed) / (band_solve_row_doubles(hb) * 8 + 6);
+  return (int)(ch > 32 ? 32 : ch);
+}
+__host__ __device__ inline size_t band_solve_lds_bytes(int hb, int ch) {
+  return band_solve_fixed_doubles(hb) * 8 + (size_t)ch * band_solve_row_doubles(hb) * 8 + (size_t)(ch + hb) * 6 + 64;
+}
+
+// broadcast a double from a compile-time-constant lane through SGPRs (v_readlane_b32 x2):
+// a few cycles, instead of the ~100-cycle LDS round trip of ds_bpermute behind __shfl.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) to fp64 round-off: v_rsq_f64 seed (~2^-26) + two Newton steps.  The library
+// sqrt + divide pair costs ~10x more on the serial critical path of the factorisation.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
+// order LDS traffic between lanes of ONE wavefront (LDS executes a wavefront's
+// instructions in order; this only stops the compiler from moving them and waits for
+// the returns).  Deliberately no vmcnt: a fence would wait for global stores in flight.
+__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// LDS-only workgroup barrier: waits for this wavefront's LDS traffic but leaves global
+// loads / stores in flight (the prefetch of the next band row must not be drained at
+// every barrier; cdna_hip_programming.md "raw s_barrier + lgkmcnt(0) only").
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Pipelined left-looking schedule (HB = block half-bandwidth, compile-time so that the
+// sums over the HB previous rows are fully unrolled and their LDS loads batched):
+//   phase A  wavefront 0: chol + panel of row j (the serial critical path)
+//            wavefronts 1..7: row j+1 minus the contributions of rows j+1-HB .. j-1
+//   phase B  all: row j+1 minus the contribution of row j (which phase A just produced)
+// so the O(HB^2) update of the next row hides behind the serial 6x6 factorisation.
+template <int HB>
+__global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, const double* __restrict__ S,
+                                                              const double* __restrict__ b,
+                                                              const unsigned char* __restrict__ mask,
+                                                              double* __restrict__ U, double* __restrict__ y,
+                                                              double* __restrict__ dinvg, double* __restrict__ x,
+                                                              int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int HB1 = HB + 1, ROWLEN = HB1 * 36, NTASK = ROWLEN + 6, HBM = HB > 0 ? HB : 1;
+  const int tid = threadIdx.x;
+  double* ring = sm;                                  // [HBM][ROWLEN]   rows j-HB .. j-1 of U (zero = no row)
+  double* yring = ring + (size_t)HBM * ROWLEN;        // [HBM][6]
+  double* xring = yring + HBM * 6;                    // [HBM][6]        (backward pass)
+  double* Bbuf = xring + HBM * 6;                     // [2][NTASK]      row being factored / row being built
+  double* part = Bbuf + 2 * NTASK;                    // [16][6]         partial sums (backward pass)
+  int* bad = reinterpret_cast<int*>(part + 16 * 6);
+  double* stage = part + 16 * 6 + 8;                  // [ch][ROWLEN]    chunk of S (forward) / U (backward)
+  double* bstage = stage + (size_t)ch * ROWLEN;       // [ch][6]         chunk of b / y
+  double* dstage = bstage + (size_t)ch * 6;           // [ch][6]         chunk of 1/diag (backward)
+  unsigned char* mstage = reinterpret_cast<unsigned char*>(dstage + (size_t)ch * 6);   // [(ch+HB)*6]
+  if (tid == 0) *bad = 0;
+  for (int i = tid; i < HBM * ROWLEN + HBM * 6; i += kSolveThreads) ring[i] = 0.0;     // ring + yring
+  long long t_c0 = 0, t_w0 = 0;
+  if (tid == 0) { t_c0 = clock64(); t_w0 = wall_clock64(); }
+
+  // stage `rows` contiguous band rows of S, b and the mask starting at row j0
+  auto stage_chunk = [&](int j0) {
+    const int rows = min(ch, nco - j0);
+    const double* src = S + (size_t)j0 * ROWLEN;
+    for (int i = tid; i < rows * ROWLEN; i += kSolveThreads) stage[i] = src[i];
+    for (int i = tid; i < rows * 6; i += kSolveThreads) bstage[i] = b[(size_t)j0 * 6 + i];
+    if (mask) {
+      const int mc = (rows + HB) * 6;
+      for (int i = tid; i < mc; i += kSolveThreads) mstage[i] = (j0 * 6 + i < nco * 6) ? mask[j0 * 6 + i] : 1;
+    }
+  };
+  // entry tk of band row j (jj = j - chunk start), masked parameters replaced by identity rows
+  auto staged = [&](int jj, int tk) -> double {
+    if (tk < ROWLEN) {
+      const int d = tk / 36, e = tk % 36, a = e / 6, c = e % 6;
+      double v = stage[jj * ROWLEN + tk];
+      if (mask && (!mstage[jj * 6 + a] || !mstage[(jj + d) * 6 + c])) v = (d == 0 && a == c) ? 1.0 : 0.0;
+      return v;
+    }
+    const int a = tk - ROWLEN;
+    return (mask && !mstage[jj * 6 + a]) ? 0.0 : bstage[jj * 6 + a];
+  };
+  // contribution of U row (slot) at distance m to entry tk of the row being built
+  auto term = [&](int slot, int m, int tk) -> double {
+    const double* row = ring + (size_t)slot * ROWLEN;
+    double dot = 0.0;
+    if (tk < ROWLEN) {
+      const int d = tk / 36, e = tk % 36, a = e / 6, c = e % 6;
+      const bool ok = m + d <= HB;
+      const double* Uj = row + m * 36 + a;                          // U[r, j][:, a]
+      const double* Ujd = row + (ok ? m + d : m) * 36 + c;          // U[r, j+d][:, c]
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dot += Uj[q * 6] * Ujd[q * 6];
+      return ok ? dot : 0.0;
+    }
+    const int a = tk - ROWLEN;
+    const double* Uj = row + m * 36 + a;
+    const double* yr = yring + slot * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dot += Uj[q * 6] * yr[q];
+    return dot;
+  };
+
+  stage_chunk(0);
+  lds_barrier();
+  for (int tk = tid; tk < NTASK; tk += kSolveThreads) Bbuf[tk] = staged(0, tk);   // row 0 has no predecessors
+  int cur = 0;                                        // Bbuf[cur] = row j, Bbuf[1-cur] = row j+1
+  int jslot = 0;                                      // j % HB
+  int chunk0 = 0;                                     // first row of the staged chunk
+  for (int j = 0; j < nco; ++j) {
+    if (j + 1 < nco && j + 1 == chunk0 + ch) {        // row j+1 opens the next chunk: stage it now
+      lds_barrier();
+      if (*bad) {                                     // uniform (every thread reads the same LDS word);
+        if (tid == 0) *info = *bad;                   // a failed pivot only produces NaNs until here
+        return;
+      }
+      chunk0 = j + 1;
+      stage_chunk(chunk0);
+    }
+    lds_barrier();                                    // Bbuf[cur], ring rows <= j-1 and the staged chunk are visible
+    double* Brow = Bbuf + cur * NTASK;
+    double* Bnext = Bbuf + (1 - cur) * NTASK;
+    const int nslot = (HB > 0 && jslot + 1 == HB) ? 0 : jslot + 1;     // (j+1) % HB
+    if (tid >= 64) {
+      // ---- phase A, wavefronts 1..7: row j+1 from S minus the rows j+1-HB .. j-1 (m = 2..HB).
+      // A group of G adjacent lanes shares one 3x3 sub-block of one 6x6 block: lane g of
+      // the group owns the term m = g + 2 (36 LDS loads feed 54 FMAs, all loads in one
+      // batch), then the G partial 3x3 blocks are summed with cross-lane shuffles.
+      if (j + 1 < nco) {
+        constexpr int NT = HB > 1 ? HB - 1 : 1;                          // number of terms m = 2..HB
+        constexpr int G = NT <= 1 ? 1 : NT <= 2 ? 2 : NT <= 4 ? 4 : NT <= 8 ? 8 : NT <= 16 ? 16 : 32;
+        const int jj1 = j + 1 - chunk0;
+        for (int task = tid - 64; task < HB1 * 4 * G; task += kSolveThreads - 64) {
+          const int g = task % G, blk = task / G;
+          const int d = blk >> 2, a0 = (blk & 2) ? 3 : 0, c0 = (blk & 1) ? 3 : 0;
+          const int m = g + 2;
+          double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+          if (HB >= 2 && m <= HB && m + d <= HB) {
+            int slot = nslot - m;
+            if (slot < 0) slot += HB;
+            const double* row = ring + (size_t)slot * ROWLEN;
+            const double* Uj = row + m * 36 + a0;                         // U[r, j+1][q][a0 .. a0+2]
+            const double* Ujd = row + (m + d) * 36 + c0;                  // U[r, j+1+d][q][c0 .. c0+2]
+            double ua[18], uc[18];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+#pragma unroll
+              for (int i = 0; i < 3; ++i) { ua[q * 3 + i] = Uj[q * 6 + i]; uc[q * 3 + i] = Ujd[q * 6 + i]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[i * 3 + k] += ua[q * 3 + i] * uc[q * 3 + k];
+              }
+            }
+          }
+#pragma unroll
+          for (int msk = 1; msk < G; msk <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] += __shfl_xor(acc[i], msk, 64);
+          }
+          if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                const int tk = d * 36 + (a0 + i) * 6 + c0 + k;
+                Bnext[tk] = staged(jj1, tk) - acc[i * 3 + k];
+              }
+            }
+          }
+        }
+        // right-hand side of row j+1: 6 entries, same split over m
+        for (int task = tid - 64; task < 6 * G; task += kSolveThreads - 64) {
+          const int g = task % G, a = task / G;
+          const int m = g + 2;
+          double acc = 0.0;
+          if (HB >= 2 && m <= HB) {
+            int slot = nslot - m;
+            if (slot < 0) slot += HB;
+            const double* Uj = ring + (size_t)slot * ROWLEN + m * 36 + a;
+            const double* yr = yring + slot * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc += Uj[q * 6] * yr[q];
+          }
+#pragma unroll
+          for (int msk = 1; msk < G; msk <<= 1) acc += __shfl_xor(acc, msk, 64);
+          if (g == 0) Bnext[ROWLEN + a] = staged(jj1, ROWLEN + a) - acc;
+        }
+      }
+    } else {
+      // ---- phase A, wavefront 0: U[j,j] = chol(B[0]) (lane c owns column c), then the panel
+      //      U[j,j+d] = U[j,j]^-T B[d], y_j = U[j,j]^-T rhs, and the stores of row j
+      const int c = tid < 6 ? tid : 5;
+      double col[6];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) col[p] = Brow[p * 6 + c];
+      int fail = 0;
+      double dinv = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double piv = lane_bcast(col[q], q);
+        if (!(piv > 0.0) && !fail) fail = q + 1;
+        const double inv = rsqrt_nr(piv);
+        const double uqq = piv * inv;
+        if (c == q) dinv = inv;
+        const double uqc = c == q ? uqq : (c > q ? col[q] * inv : 0.0);
+        col[q] = uqc;
+#pragma unroll
+        for (int p = q + 1; p < 6; ++p) {
+          const double uqp = lane_bcast(uqc, p);
+          if (p <= c) col[p] -= uqp * uqc;
+        }
+      }
+      if (fail && tid == 0) *bad = 6 * j + fail;
+      // every lane needs the factor: Uf[p][q] (p < q) and 1/U[q][q], broadcast from lane q
+      double Uf[15], di[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        di[q] = lane_bcast(dinv, q);
+#pragma unroll
+        for (int p = 0; p < q; ++p) Uf[q * (q - 1) / 2 + p] = lane_bcast(col[p], q);
+      }
+      if (tid < 6) {                                  // diagonal block of row j (upper triangle, zeros below)
+        dinvg[6 * (size_t)j + c] = dinv;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const double v = p <= c ? col[p] : 0.0;
+          if (HB > 0) ring[(size_t)jslot * ROWLEN + p * 6 + c] = v;
+          U[(size_t)j * ROWLEN + p * 6 + c] = v;
+        }
+      }
+      for (int tk = tid; tk < HB * 6 + 1; tk += 64) {
+        const bool isrhs = tk == HB * 6;
+        const int d = isrhs ? 0 : 1 + tk / 6, cc = isrhs ? 0 : tk % 6;
+        double v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = isrhs ? Brow[ROWLEN + q] : Brow[d * 36 + q * 6 + cc];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                  // forward substitution with U[j,j]^T (lower)
+          double t = v[q];
+#pragma unroll
+          for (int p = 0; p < q; ++p) t -= Uf[q * (q - 1) / 2 + p] * v[p];
+          v[q] = t * di[q];
+        }
+        if (isrhs) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            if (HB > 0) yring[jslot * 6 + q] = v[q];
+            y[6 * (size_t)j + q] = v[q];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            ring[(size_t)jslot * ROWLEN + d * 36 + q * 6 + cc] = v[q];
+            U[(size_t)j * ROWLEN + d * 36 + q * 6 + cc] = v[q];
+          }
+        }
+      }
+    }
+    if (HB > 0 && j + 1 < nco) {
+      lds_barrier();                                  // U row j (ring) and the partial row j+1 are visible
+      // ---- phase B, all wavefronts: row j+1 minus the contribution of row j (m = 1)
+      for (int tk = tid; tk < NTASK; tk += kSolveThreads) Bnext[tk] -= term(jslot, 1, tk);
+    }
+    cur = 1 - cur;
+    jslot = nslot;
+  }
+  __syncthreads();     // full barrier: U, y (global) and *bad of this workgroup are visible
+  if (*bad) {
+    if (tid == 0) *info = *bad;
+    return;
+  }
+  if (tid >= 64) return;
+  if (tid == 0) {      // instrumentation: shader cycles / 100 MHz wall ticks of the forward sweep
+    info[2] = (int)(clock64() - t_c0);
+    info[3] = (int)(wall_clock64() - t_w0);
+  }
+
+  // ---- backward substitution by wavefront 0 alone (no workgroup barriers): rows nco-1 .. 0,
+  // again in chunks staged through LDS.  lane (a = lane % 6, g = lane / 6) owns row a of
+  // blocks d = g, g + 10, g + 20 of a band row.
+  const int a_ = tid % 6, g_ = tid / 6;               // g_ in 0..10 (lanes 60..63 idle)
+  constexpr int NG = HB1 < 10 ? HB1 : 10;
+  int xslot = HB > 0 ? (nco - 1) % HB : 0;            // slot of row j in xring
+  for (int jend = nco; jend > 0; jend -= ch) {
+    const int jbeg = max(0, jend - ch), rows = jend - jbeg;
+    lds_wave_sync();
+    {
+      const double* src = U + (size_t)jbeg * ROWLEN;
+      for (int i = tid; i < rows * ROWLEN; i += 64) stage[i] = src[i];
+      for (int i = tid; i < rows * 6; i += 64) {
+        bstage[i] = y[(size_t)jbeg * 6 + i];
+        dstage[i] = dinvg[(size_t)jbeg * 6 + i];
+      }
+    }
+    lds_wave_sync();
+    for (int jj = rows - 1; jj >= 0; --jj) {
+      const int j = jbeg + jj;
+      const double* urow = stage + (size_t)jj * ROWLEN;
+      if (g_ < NG) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int d = g_ + 10 * r;
+          if (d >= 1 && d <= HB && j + d < nco) {
+            int sl = xslot + d;
+            if (sl >= HB) sl -= HB;
+            const double* xr = xring + sl * 6;
+            const double* ur = urow + d * 36 + a_ * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sacc += ur[c] * xr[c];
+          }
+        }
+        part[g_ * 6 + a_] = sacc;
+      }
+      // lanes 0..5 fetch what the second half needs while the partial sums land
+      double t = 0.0, dv = 1.0, ud[6] = {0, 0, 0, 0, 0, 0};
+      if (g_ == 0) {
+        t = bstage[jj * 6 + a_];
+        dv = dstage[jj * 6 + a_];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ud[c] = urow[a_ * 6 + c];
+      }
+      lds_wave_sync();
+      if (g_ == 0) {
+        double pg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) pg[g] = part[g * 6 + a_];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) t -= pg[g];
+      }
+      double xs = 0.0;
+#pragma unroll
+      for (int q = 5; q >= 0; --q) {
+        const double xq = lane_bcast(t * dv, q);        // x_q, final once rows > q were eliminated
+        if (a_ == q) xs = xq;
+        if (a_ < q) t -= ud[q] * xq;
+      }
+      if (g_ == 0) {
+        if (HB > 0) xring[xslot * 6 + a_] = xs;
+        x[6 * (size_t)j + a_] = xs;
+      }
+      lds_wave_sync();
+      xslot = xslot == 0 ? (HB > 0 ? HB - 1 : 0) : xslot - 1;
+    }
+  }
+  if (tid == 0) {
+    info[4] = (int)(clock64() - t_c0);
+    info[5] = (int)(wall_clock64() - t_w0);
+    *info = 0;
+  }
 }
 
 }  // namespace ba

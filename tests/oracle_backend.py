@@ -128,20 +128,28 @@ class OracleBackend(object):
     def get_point_inverses(self):
         return self.HPP_inv.copy()
 
-    def solve_reduced(self, keep):
+    def solve_reduced(self, cam_param_mask=None):
         self.calls.append('solve')
         S, b = self.get_reduced()
         A, rhs = O.flatten_reduced(S, b)
-        keep = np.asarray(keep, int)
+        n = self.nco * 6
+        keep = np.arange(n) if cam_param_mask is None else np.nonzero(np.asarray(cam_param_mask))[0]
         try:
-            return np.linalg.solve(A[np.ix_(keep, keep)], rhs[keep])
+            x = np.linalg.solve(A[np.ix_(keep, keep)], rhs[keep])
         except np.linalg.LinAlgError:
             raise ReducedSystemSingular
+        dC = np.zeros(n)
+        dC[keep] = x
+        self.dC = dC.reshape(-1, 6)
 
-    def backsubstitute(self, which, dC, fetch=True):
+    def get_solution(self):
+        return self.dC.copy()
+
+    def backsubstitute(self, which, dC=None, fetch=True):
         self.calls.append('backsub')
         HCC, HPP, W, bC, bP = self.blocks
-        self.dC = np.asarray(dC, float).reshape(-1, 6)
+        if dC is not None:
+            self.dC = np.asarray(dC, float).reshape(-1, 6)
         self.dP = O.backsubstitute(self.dC, self.HPP_inv, W, bP, self.obs[0], self.obs[1], self.cam_opt_pos, self.nt)
         return self.dP.copy() if fetch else None
 

@@ -68,12 +68,13 @@ def hip_update(be, damping, rcond=1e-5, keep=None):
     be.linearize(0)
     be.schur(0, damping, rcond)
     n = be.nco * 6
-    keep = np.arange(n, dtype=np.int32) if keep is None else keep
-    x = be.solve_reduced(keep)
-    dC = np.zeros(n)
-    dC[keep] = x
-    dC = dC.reshape(-1, 6)
-    dP = be.backsubstitute(0, dC)
+    mask = None
+    if keep is not None:
+        mask = np.zeros(n, np.uint8)
+        mask[keep] = 1
+    be.solve_reduced(mask)
+    dC = be.get_solution()
+    dP = be.backsubstitute(0)
     return dC, dP
 
 
@@ -444,6 +445,56 @@ def test_config3_full_lm_converges(config3):
     ba2.optimize(max_steps=3)
     assert ba2.costs[0] == pytest.approx(ba.costs[-1], rel=1e-9)
     assert ba2.costs[-1] <= ba2.costs[0] and ba2.costs[0] - ba2.costs[-1] <= 1e-2 * ba.costs[-1]
+
+
+def test_band_solver_vs_dense_lu(be):
+    """k_band_solve (block Cholesky on the band) against the dense LU path on the same
+    device-resident system, with and without masked camera parameters."""
+    s = banded(80, 4000, track_len=7)
+    flags = default_flags(80, 4000)
+    sensor = O.Sensor.cauchy(.05)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, *flags, sensor)
+    assert be.half_bandwidth == 6 and be.S_doubles == 79 * 7 * 36
+    be.linearize(0)
+    be.schur(0, 1., 1e-5)
+    n = 79 * 6
+    for mask in (None, (np.arange(n) % 5 != 0).astype(np.uint8), np.r_[np.zeros(12, np.uint8), np.ones(n - 12, np.uint8)]):
+        be.solve_reduced(mask)
+        assert be.last_solve_path == 'band'
+        x = be.get_solution().reshape(-1)
+        keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
+        xd = np.zeros(n)
+        xd[keep] = be._solve_dense(keep)
+        close(x, xd, 1e-9)
+        if mask is not None:
+            assert np.all(x[mask == 0] == 0)
+        mu, su = O.compute_update(sensor, *a, *flags, damping=1., cam_param_mask=None if mask is None else mask.astype(bool))
+        close(-x.reshape(-1, 6), mu, SOLVE)
+        close(-be.backsubstitute(0), su, SOLVE)
+
+
+def test_wide_band_takes_dense_path(be):
+    g = load_golden('scene_oleg_40x100')
+    load_problem(be, *scene(g), g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
+    assert be.half_bandwidth == 38
+    dC, dP = hip_update(be, 10.)
+    assert be.last_solve_path == 'dense'
+    close(-dC, g['update_l10_motion'], 1e-7)
+
+
+def test_band_solver_reports_non_positive_pivot(be):
+    """An indefinite reduced system must not be 'solved' by Cholesky: info > 0, dense LU takes over."""
+    g = load_golden('scene_4x10_cauchy')
+    load_problem(be, *scene(g), g['l2_cam_opt_pos'], g['l2_pt_opt'], sensor_of(g))
+    be.linearize(0)
+    be.schur(0, -3., 1e-5)                    # (1 + lambda) < 0 flips the sign of every diagonal
+    be.solve_reduced(None)
+    assert be.last_solve_path == 'dense'
+    S, b = be.get_reduced()
+    x = be.get_solution().reshape(-1)
+    A = S.transpose(0, 2, 1, 3).reshape(18, 18)
+    close(A @ x, b.reshape(-1), 1e-9)
 
 
 def test_timing_counters(be):
