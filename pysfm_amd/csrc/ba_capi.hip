@@ -61,6 +61,8 @@ struct ba_handle {
   DevBuf<unsigned char> pt_opt;
   DevBuf<SchurUnit> units;
   int nunits = 0;
+  DevBuf<SchurChunk> chunks;
+  int nchunks = 0, schur_wn = 0;
   DevBuf<int> cam_perm;
   DevBuf<CamUnit> cam_units;
   int ncam_units = 0;
@@ -248,7 +250,7 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release(); h->mask.release(); h->dP.release();
@@ -347,6 +349,34 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     }
     if (hi >= 0) hb = std::max(hb, hi - lo);
   }
+  // Schur chunks: consecutive units whose optimised-camera positions fit a window of wn
+  // band rows, so that a workgroup can accumulate them in an LDS tile
+  int wn = (int)(kSchurTileBytes / (((size_t)(hb + 1) * 36 + 6) * sizeof(double)));
+  wn = std::min(wn, 64);
+  if (wn < hb + 2 || nco == 0) wn = 0;                 // band too wide for an LDS tile: global atomics only
+  std::vector<SchurChunk> chunks;
+  {
+    std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
+    for (int k = 0; k < nt; ++k)
+      for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+        const int p = cam_opt_pos[obs_cam[n]];
+        if (p < 0) continue;
+        plo[k] = std::min(plo[k], p); phi[k] = std::max(phi[k], p);
+      }
+    int begin = 0, lo = INT32_MAX, hi = -1;
+    for (int u = 0; u < (int)units.size(); ++u) {
+      const int k = units[u].pt;
+      const int nlo = std::min(lo, plo[k]), nhi = std::max(hi, phi[k]);
+      const bool fits = wn == 0 || nhi < 0 || nhi - nlo + 1 <= wn;
+      if (u > begin && (!fits || u - begin >= kSchurChunkUnits)) {
+        chunks.push_back({begin, u, lo == INT32_MAX ? 0 : lo});
+        begin = u; lo = plo[k]; hi = phi[k];
+      } else {
+        lo = nlo; hi = nhi;
+      }
+    }
+    if (!units.empty()) chunks.push_back({begin, (int)units.size(), lo == INT32_MAX ? 0 : lo});
+  }
   // lanes per point: smallest power of two >= mean track length, in [1, 64]
   int glog = 0;
   const double meanL = nt > 0 ? (double)nobs / nt : 1.0;
@@ -357,6 +387,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
   h->h_pt_opt.assign(pt_opt, pt_opt + nt);
   h->nunits = (int)units.size();
+  h->nchunks = (int)chunks.size();
+  h->schur_wn = wn;
   h->ncam_units = (int)cam_units.size();
 
   HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, nobs)));
@@ -366,6 +398,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
   HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
   HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
+  HIPCHECK(h, h->chunks.resize(std::max<size_t>(1, chunks.size())));
+  if (!chunks.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->cam_perm.resize(std::max<size_t>(1, perm.size())));
   HIPCHECK(h, h->cam_units.resize(std::max<size_t>(1, cam_units.size())));
   if (!perm.empty())
@@ -638,11 +673,18 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
       hipLaunchKernelGGL(k_schur_init, dim3(blocks_for((long long)h->nc * 36)), dim3(kBlock), 0, h->stream, h->nc,
                          h->hb + 1, h->cam_opt_pos.p, h->HCC.p, h->bC.p, damping, h->S, h->b);
   }
-  if (h->nunits > 0) {
+  if (h->nchunks > 0) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
-    const int per_block = kBlock / kWave;
-    hipLaunchKernelGGL(k_schur_pairs, dim3((h->nunits + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
-                       dev_problem(h), h->cams[p].p, h->X[p].p, h->units.p, h->nunits, h->HPPinv.p, h->bP.p, h->S, h->b);
+    const int NW = kSchurBlock / kWave;
+    const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int) +
+                       (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_schur_pairs, dim3(h->nchunks), dim3(kSchurBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                       h->X[p].p, h->units.p, h->chunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
   }
   HIPCHECK(h, hipGetLastError());
   h->have_schur = true;

@@ -23,7 +23,7 @@ namespace ba {
 
 constexpr int kBlock = 256;       // 4 wavefronts
 constexpr int kWave = 64;
-constexpr int kTile = 32;         // observations of one track staged per Schur work unit
+constexpr int kTile = 16;         // observations of one track staged per Schur work unit
 
 struct DevProblem {
   int nc, nt, nco;
@@ -61,6 +61,34 @@ __device__ __forceinline__ double wave_sum(double v) {
 // length 10 has hb = 9 and stores 5.5 MB instead of 288 MB at 1000 cameras.
 __device__ __forceinline__ size_t band_block(int pi, int pj, int hb1) {
   return ((size_t)pi * hb1 + (pj - pi)) * 36;
+}
+
+// order LDS traffic between lanes of ONE wavefront (LDS executes a wavefront's
+// instructions in order; this only stops the compiler from moving them and waits for
+// the returns).  Deliberately no vmcnt: a fence would wait for global stores in flight.
+__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// LDS-only workgroup barrier: waits for this wavefront's LDS traffic but leaves global
+// loads / stores in flight (the prefetch of the next band row must not be drained at
+// every barrier; cdna_hip_programming.md "raw s_barrier + lgkmcnt(0) only").
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// broadcast a double from a compile-time-constant lane through SGPRs (v_readlane_b32 x2):
+// a few cycles, instead of the ~100-cycle LDS round trip of ds_bpermute behind __shfl.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) to fp64 round-off: v_rsq_f64 seed (~2^-26) + two Newton steps.  The library
+// sqrt + divide pair costs ~10x more on the serial critical path of the factorisation.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
 }
 
 // hardware fp64 atomic add (global_atomic_add_f64 / ds_add_f64 on gfx950)
@@ -332,107 +360,169 @@ __global__ __launch_bounds__(kBlock) void k_schur_init(int nc, int hb1, const in
 // compute_schur_complement, the reduction (bundle_adjuster.py:267-276):
 //   b[i]   -= W_ik HPPinv_k bP_k
 //   S[i,j] -= W_ik HPPinv_k W_jk^T     over the observation pairs of each point.
-// One wavefront per work unit (point k, row tile r, col tile c >= r) of at most
-// kTile x kTile observation pairs.  Phase A: lanes recompute W for the tile's
-// observations and stage T = W HPPinv (rows) and W (cols) in LDS.  Phase B: the
-// 64 lanes walk the (pair, entry) list so that 36 consecutive lanes hit the 36
-// contiguous doubles of one 6x6 block: fp64 atomics on whole 288-byte blocks.
-// Only the upper block triangle (pos_i <= pos_j) is accumulated; S is symmetric
-// (ba_mirror_reduced / k_flatten fill the rest).
+// Work unit = (point k, row tile r, col tile c >= r) of at most kTile x kTile
+// observation pairs; one wavefront handles a unit.  Phase A: lanes recompute W for the
+// tile's observations and stage T = W HPPinv (rows) and W (cols) in LDS.  Phase B: the 64
+// lanes walk the (pair, entry) list so that 36 consecutive lanes hit the 36 contiguous
+// doubles of one 6x6 block.  Only the upper block triangle (pos_i <= pos_j) is
+// accumulated; S is symmetric.
+//
+// Where the products go: a workgroup owns a CHUNK of consecutive units.  Points are
+// sorted, so a chunk only touches cameras in a narrow window [p0, p0 + wn) of
+// optimised positions; the workgroup keeps that slice of the block band
+// (wn rows x (hb+1) blocks, plus b) as an LDS tile, accumulates into it with LDS fp64
+// atomics (ds_add_f64) and flushes the tile to HBM once, with one global atomic per
+// touched entry.  That turns ~2000 global atomics per point into ~20.  Products that
+// fall outside the window (possible for arbitrary scenes) go straight to global
+// atomics, so the result never depends on the chunking.  wn == 0 disables the tile
+// (bands too wide for LDS, e.g. dense co-visibility).
 // --------------------------------------------------------------------------
 struct SchurUnit { int pt; int row0; int col0; };
+struct SchurChunk { int begin; int end; int p0; };     // units [begin, end), window start p0
+constexpr int kSchurChunkUnits = 256;                  // at most this many units per workgroup
+constexpr int kSchurTileBytes = 48 * 1024;             // LDS budget of the accumulation tile
 
-__global__ __launch_bounds__(kBlock) void k_schur_pairs(DevProblem P, const double* __restrict__ cams,
+constexpr int kSchurBlock = 1024;                      // 16 wavefronts share one accumulation tile
+
+// p-th pair (i <= j) of the upper triangle of an n x n grid, rows first
+__device__ __forceinline__ void tri_decode(int p, int n, int& i, int& j) {
+  const float t = 2.0f * n + 1.0f;
+  int r = (int)((t - sqrtf(t * t - 8.0f * p)) * 0.5f);
+  r = max(0, min(r, n - 1));
+  while (r > 0 && r * (2 * n - r + 1) / 2 > p) --r;                 // first index of row r
+  while ((r + 1) * (2 * n - r) / 2 <= p) ++r;
+  i = r;
+  j = r + (p - r * (2 * n - r + 1) / 2);
+}
+
+__global__ __launch_bounds__(kSchurBlock) void k_schur_pairs(DevProblem P, const double* __restrict__ cams,
                                                         const double* __restrict__ X,
-                                                        const SchurUnit* __restrict__ units, int nunits,
+                                                        const SchurUnit* __restrict__ units,
+                                                        const SchurChunk* __restrict__ chunks, int wn,
                                                         const double* __restrict__ HPPinv,
                                                         const double* __restrict__ bP,
                                                         double* __restrict__ S, double* __restrict__ b) {
-  __shared__ double sT[kBlock / kWave][kTile][18];
-  __shared__ double sW[kBlock / kWave][kTile][18];
-  __shared__ int sPosR[kBlock / kWave][kTile];
-  __shared__ int sPosC[kBlock / kWave][kTile];
+  constexpr int NW = kSchurBlock / kWave;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* sT = dyn;                                   // [NW][kTile][18]
+  double* sW = sT + NW * kTile * 18;                  // [NW][kTile][18]
+  int* sPosR = reinterpret_cast<int*>(sW + NW * kTile * 18);   // [NW][kTile]
+  int* sPosC = sPosR + NW * kTile;                    // [NW][kTile]
+  double* tile = reinterpret_cast<double*>(sPosC + NW * kTile);  // [wn][hb1*36] then tb [wn][6]
+  const int hb1 = P.hb + 1;
+  const int rowlen = hb1 * 36;
+  double* tb = tile + (size_t)wn * rowlen;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int u = blockIdx.x * (kBlock / kWave) + wv;
-  const bool active = u < nunits;     // wave-uniform; no early return (block barrier below)
-  SchurUnit un = {0, 0, 0};
-  int k = 0, s = 0, L = 0, nr = 0, ncol = 0;
-  bool diag = false;
-  if (active) {
-    un = units[u];
-    k = un.pt;
-    s = P.pt_off[k];
-    L = P.pt_off[k + 1] - s;
-    nr = min(kTile, L - un.row0);
-    ncol = min(kTile, L - un.col0);
-    diag = un.row0 == un.col0;
-  }
+  const SchurChunk ck = chunks[blockIdx.x];
+  const int p0 = ck.p0;
+  for (int i = threadIdx.x; i < wn * (rowlen + 6); i += kSchurBlock) tile[i] = 0.0;
+  double* mT = sT + wv * kTile * 18;
+  double* mW = sW + wv * kTile * 18;
+  int* mPosR = sPosR + wv * kTile;
+  int* mPosC = sPosC + wv * kTile;
+  __syncthreads();
 
-  // ---- phase A: lanes [0, nr) stage rows, lanes [32, 32+ncol) stage columns
-  {
-    const bool isRow = lane < kTile;
-    const int idx = isRow ? lane : lane - kTile;
-    const int cnt = isRow ? nr : ncol;
-    const bool need = active && idx < cnt && !(diag && !isRow);   // diagonal tile: cols = rows
-    if (need) {
-      const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
-      double A[6];
+  for (int u = ck.begin + wv; u < ck.end; u += NW) {     // wave-uniform loop
+    const SchurUnit un = units[u];
+    const int k = un.pt;
+    const int s = P.pt_off[k];
+    const int L = P.pt_off[k + 1] - s;
+    const int nr = min(kTile, L - un.row0), ncol = min(kTile, L - un.col0);
+    const bool diag = un.row0 == un.col0;
+    // ---- phase A: lanes [0, nr) stage rows, lanes [32, 32+ncol) stage columns
+    {
+      const bool isRow = lane < 32;
+      const int idx = isRow ? lane : lane - 32;
+      const int cnt = isRow ? nr : ncol;
+      if (idx < cnt && !(diag && !isRow)) {              // diagonal tile: cols = rows
+        const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
+        double A[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) A[i] = HPPinv[6 * (size_t)k + i];
-      const int n = s + (isRow ? un.row0 : un.col0) + idx;
-      const int c = P.obs_cam[n];
-      const double2 z = P.obs_z[n];
-      double cm[12], e[2], r[2], Jc[12], Jp[6], W[18];
-      load_cam(cams, c, cm);
-      obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
-      block_W(Jc, Jp, W);
-      const int pos = P.cam_opt_pos[c];
-      if (isRow) {
-        double T[18];
-        block_T(W, A, T);
+        for (int i = 0; i < 6; ++i) A[i] = HPPinv[6 * (size_t)k + i];
+        const int n = s + (isRow ? un.row0 : un.col0) + idx;
+        const int c = P.obs_cam[n];
+        const double2 z = P.obs_z[n];
+        double cm[12], e[2], r[2], Jc[12], Jp[6], W[18];
+        load_cam(cams, c, cm);
+        obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+        block_W(Jc, Jp, W);
+        const int pos = P.cam_opt_pos[c];
+        if (isRow) {
+          double T[18];
+          block_T(W, A, T);
 #pragma unroll
-        for (int i = 0; i < 18; ++i) sT[wv][idx][i] = T[i];
-        sPosR[wv][idx] = pos;
-        if (diag) {
+          for (int i = 0; i < 18; ++i) mT[idx * 18 + i] = T[i];
+          mPosR[idx] = pos;
+          if (diag) {
 #pragma unroll
-          for (int i = 0; i < 18; ++i) sW[wv][idx][i] = W[i];
-          sPosC[wv][idx] = pos;
-          if (pos >= 0) {   // b[i] -= T_i bP_k, once per observation
-            const double g0 = bP[3 * (size_t)k], g1 = bP[3 * (size_t)k + 1], g2 = bP[3 * (size_t)k + 2];
+            for (int i = 0; i < 18; ++i) mW[idx * 18 + i] = W[i];
+            mPosC[idx] = pos;
+            if (pos >= 0) {   // b[i] -= T_i bP_k, once per observation
+              const double g0 = bP[3 * (size_t)k], g1 = bP[3 * (size_t)k + 1], g2 = bP[3 * (size_t)k + 2];
+              const int wr = pos - p0;
+              const bool in = wr >= 0 && wr < wn;
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
-              atomic_add_f64(b + (size_t)pos * 6 + a, -(T[a * 3] * g0 + T[a * 3 + 1] * g1 + T[a * 3 + 2] * g2));
+              for (int a = 0; a < 6; ++a) {
+                const double v = -(T[a * 3] * g0 + T[a * 3 + 1] * g1 + T[a * 3 + 2] * g2);
+                if (in) atomic_add_f64(tb + wr * 6 + a, v);
+                else atomic_add_f64(b + (size_t)pos * 6 + a, v);
+              }
+            }
           }
-        }
-      } else {
+        } else {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) sW[wv][idx][i] = W[i];
-        sPosC[wv][idx] = pos;
+          for (int i = 0; i < 18; ++i) mW[idx * 18 + i] = W[i];
+          mPosC[idx] = pos;
+        }
       }
     }
-  }
-  __syncthreads();
-  if (!active) return;
-
-  // ---- phase B
-  const int hb1 = P.hb + 1;
-  for (int i = 0; i < nr; ++i) {
-    const int pi = sPosR[wv][i];
-    if (pi < 0) continue;                       // wave-uniform
-    const int j0 = diag ? i : 0;
-    const int items = (ncol - j0) * 36;
-    for (int q = lane; q < items; q += 64) {
-      const int j = j0 + q / 36, e = q % 36;
-      const int pj = sPosC[wv][j];
-      if (pj < 0) continue;
-      const int a = e / 6, c = e % 6;
-      const double v = sT[wv][i][a * 3] * sW[wv][j][c * 3] + sT[wv][i][a * 3 + 1] * sW[wv][j][c * 3 + 1] +
-                       sT[wv][i][a * 3 + 2] * sW[wv][j][c * 3 + 2];
-      // block (pi,pj) entry (a,c); keep the upper block triangle
-      const size_t off = pi <= pj ? band_block(pi, pj, hb1) + a * 6 + c
-                                  : band_block(pj, pi, hb1) + c * 6 + a;
-      atomic_add_f64(S + off, -v);
+    lds_wave_sync();                                    // staging of this wavefront is visible to its lanes
+    // ---- phase B: one lane per (pair (i,j), block row a): 3 + 18 staged values feed 18 FMAs and
+    //      6 accumulations into consecutive (or stride-6, when transposed) entries of one block
+    {
+      const int npairs = diag ? nr * (nr + 1) / 2 : nr * ncol;
+      const int items = npairs * 6;
+      for (int q = lane; q < items; q += 64) {
+        const int pr = q / 6, a = q - pr * 6;
+        int i, j;
+        if (diag) tri_decode(pr, nr, i, j);
+        else { i = pr / ncol; j = pr - i * ncol; }
+        const int pi = mPosR[i], pj = mPosC[j];
+        if (pi < 0 || pj < 0) continue;
+        const double t0 = mT[i * 18 + a * 3], t1 = mT[i * 18 + a * 3 + 1], t2 = mT[i * 18 + a * 3 + 2];
+        double v[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          v[c] = t0 * mW[j * 18 + c * 3] + t1 * mW[j * 18 + c * 3 + 1] + t2 * mW[j * 18 + c * 3 + 2];
+        // block (pi,pj) row a; keep the upper block triangle (transpose when pi > pj)
+        const bool up = pi <= pj;
+        const int lo = up ? pi : pj, dd = up ? pj - pi : pi - pj;
+        const int e0 = up ? a * 6 : a, es = up ? 1 : 6;
+        const int wr = lo - p0;
+        if (wr >= 0 && wr < wn) {
+          double* dst = tile + (size_t)wr * rowlen + dd * 36 + e0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) atomic_add_f64(dst + c * es, -v[c]);
+        } else {
+          double* dst = S + ((size_t)lo * hb1 + dd) * 36 + e0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) atomic_add_f64(dst + c * es, -v[c]);
+        }
+      }
     }
+    lds_wave_sync();                                    // all reads of the staging done before it is overwritten
+  }
+  if (wn == 0) return;
+  __syncthreads();
+  // ---- flush the tile: one global atomic per touched entry
+  for (int i = threadIdx.x; i < wn * rowlen; i += kSchurBlock) {
+    const double v = tile[i];
+    const int wr = i / rowlen;
+    if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
+  }
+  for (int i = threadIdx.x; i < wn * 6; i += kSchurBlock) {
+    const double v = tb[i];
+    if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
   }
 }
 
@@ -588,33 +678,7 @@ __host__ __device__ inline size_t band_solve_lds_bytes(int hb, int ch) {
   return band_solve_fixed_doubles(hb) * 8 + (size_t)ch * band_solve_row_doubles(hb) * 8 + (size_t)(ch + hb) * 6 + 64;
 }
 
-// broadcast a double from a compile-time-constant lane through SGPRs (v_readlane_b32 x2):
-// a few cycles, instead of the ~100-cycle LDS round trip of ds_bpermute behind __shfl.
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 
-// 1/sqrt(x) to fp64 round-off: v_rsq_f64 seed (~2^-26) + two Newton steps.  The library
-// sqrt + divide pair costs ~10x more on the serial critical path of the factorisation.
-__device__ __forceinline__ double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5 * x;
-  y = y * fma(-hx * y, y, 1.5);
-  y = y * fma(-hx * y, y, 1.5);
-  return y;
-}
-
-// order LDS traffic between lanes of ONE wavefront (LDS executes a wavefront's
-// instructions in order; this only stops the compiler from moving them and waits for
-// the returns).  Deliberately no vmcnt: a fence would wait for global stores in flight.
-__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// LDS-only workgroup barrier: waits for this wavefront's LDS traffic but leaves global
-// loads / stores in flight (the prefetch of the next band row must not be drained at
-// every barrier; cdna_hip_programming.md "raw s_barrier + lgkmcnt(0) only").
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Pipelined left-looking schedule (HB = block half-bandwidth, compile-time so that the
 // sums over the HB previous rows are fully unrolled and their LDS loads batched):
