@@ -114,7 +114,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get('BA_FORCE_COMM'):      # BA_FORCE_COMM: exercise the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))

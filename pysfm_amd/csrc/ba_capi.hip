@@ -161,17 +161,24 @@ DevProblem dev_problem(const ba_handle* h) {
 inline size_t reduced_doubles(const ba_handle* h) { return (size_t)h->nco * (h->hb + 1) * 36; }
 
 // k_band_solve is instantiated per block half-bandwidth (compile-time unrolling)
-template <int HB>
-hipError_t launch_band_solve_hb(size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
-                                const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
+template <int HB, bool MASKED>
+hipError_t launch_band_solve_hbm(size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+                                 const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_band_solve<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_band_solve<HB, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_band_solve<HB>, dim3(1), dim3(kSolveThreads), lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
+  hipLaunchKernelGGL((k_band_solve<HB, MASKED>), dim3(1), dim3(kSolveThreads), lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
   return hipGetLastError();
+}
+
+template <int HB>
+hipError_t launch_band_solve_hb(size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+                                const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
+  return mask ? launch_band_solve_hbm<HB, true>(lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info)
+              : launch_band_solve_hbm<HB, false>(lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
 }
 
 hipError_t launch_band_solve(int hb, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,

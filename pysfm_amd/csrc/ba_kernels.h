@@ -68,6 +68,48 @@ __device__ __forceinline__ size_t band_block(int pi, int pj, int hb1) {
 // the returns).  Deliberately no vmcnt: a fence would wait for global stores in flight.
 __device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Cross-lane exchange through DPP (VALU data path, no LDS round trip): value of the lane
+// paired by the given DPP control.  0xB1 / 0x4E = quad_perm xor 1 / xor 2, 0x141 =
+// row_half_mirror (i <-> 7-i), 0x140 = row_mirror (i <-> 15-i).
+template <int CTRL>
+__device__ __forceinline__ double dpp_pair(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of G lanes (G = 1, 2, 4, 8, 16, 32); every lane gets the sum
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+  if (G >= 2) v += dpp_pair<0xB1>(v);
+  if (G >= 4) v += dpp_pair<0x4E>(v);
+  if (G >= 8) v += dpp_pair<0x141>(v);
+  if (G >= 16) v += dpp_pair<0x140>(v);
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+// cooperative copy global -> LDS of n doubles (n even, both 16-byte aligned): 16 B per lane
+// and eight loads in flight per lane, so a chunk costs about one global round trip
+template <int NT>
+__device__ __forceinline__ void copy_to_lds(double* __restrict__ dst, const double* __restrict__ src, int n, int tid) {
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+  const int n2 = n >> 1;
+  for (int base = 0; base < n2; base += NT * 8) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      if (idx < n2) v[u] = s2[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      if (idx < n2) d2[idx] = v[u];
+    }
+  }
+}
+
 // LDS-only workgroup barrier: waits for this wavefront's LDS traffic but leaves global
 // loads / stores in flight (the prefetch of the next band row must not be drained at
 // every barrier; cdna_hip_programming.md "raw s_barrier + lgkmcnt(0) only").
@@ -663,9 +705,15 @@ constexpr int kSolveThreads = 256;
 // LDS budget of k_band_solve: the U window, two row buffers and a staging area of `ch`
 // band rows (S on the way down, U on the way back) so that global latency is paid once
 // per chunk instead of once per row.
+// LDS row stride (doubles) of the U window: padded so that the HB rows a wavefront reads
+// together (one per lane of a group, `36` doubles further along in each older row) fall on
+// distinct LDS banks for ds_read2_b64 (32 banks of 4 B): (stride - 36) % 16 == 2.
+__host__ __device__ constexpr int band_ring_stride(int hb) {
+  return (hb + 1) * 36 + ((2 - 36 * hb) % 16 + 16) % 16;
+}
 __host__ __device__ inline size_t band_solve_fixed_doubles(int hb) {
   const size_t hbm = hb > 0 ? hb : 1;
-  return hbm * (hb + 1) * 36 + hbm * 6 * 2 + 2 * ((size_t)(hb + 1) * 36 + 6) + 16 * 6 + 8;
+  return hbm * band_ring_stride(hb) + hbm * 6 * 2 + 2 * ((size_t)(hb + 1) * 36 + 6) + 16 * 6 + 8;
 }
 __host__ __device__ inline size_t band_solve_row_doubles(int hb) { return (size_t)(hb + 1) * 36 + 12; }
 __host__ __device__ inline int band_solve_chunk(int hb, size_t lds_bytes) {
@@ -686,7 +734,7 @@ __host__ __device__ inline size_t band_solve_lds_bytes(int hb, int ch) {
 //            wavefronts 1..7: row j+1 minus the contributions of rows j+1-HB .. j-1
 //   phase B  all: row j+1 minus the contribution of row j (which phase A just produced)
 // so the O(HB^2) update of the next row hides behind the serial 6x6 factorisation.
-template <int HB>
+template <int HB, bool MASKED>
 __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, const double* __restrict__ S,
                                                               const double* __restrict__ b,
                                                               const unsigned char* __restrict__ mask,
@@ -695,9 +743,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
                                                               int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int HB1 = HB + 1, ROWLEN = HB1 * 36, NTASK = ROWLEN + 6, HBM = HB > 0 ? HB : 1;
+  constexpr int RS = band_ring_stride(HB);            // padded LDS stride of a ring row
   const int tid = threadIdx.x;
-  double* ring = sm;                                  // [HBM][ROWLEN]   rows j-HB .. j-1 of U (zero = no row)
-  double* yring = ring + (size_t)HBM * ROWLEN;        // [HBM][6]
+  double* ring = sm;                                  // [HBM][RS]       rows j-HB .. j-1 of U (zero = no row)
+  double* yring = ring + (size_t)HBM * RS;            // [HBM][6]
   double* xring = yring + HBM * 6;                    // [HBM][6]        (backward pass)
   double* Bbuf = xring + HBM * 6;                     // [2][NTASK]      row being factored / row being built
   double* part = Bbuf + 2 * NTASK;                    // [16][6]         partial sums (backward pass)
@@ -707,17 +756,16 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
   double* dstage = bstage + (size_t)ch * 6;           // [ch][6]         chunk of 1/diag (backward)
   unsigned char* mstage = reinterpret_cast<unsigned char*>(dstage + (size_t)ch * 6);   // [(ch+HB)*6]
   if (tid == 0) *bad = 0;
-  for (int i = tid; i < HBM * ROWLEN + HBM * 6; i += kSolveThreads) ring[i] = 0.0;     // ring + yring
+  for (int i = tid; i < HBM * RS + HBM * 6; i += kSolveThreads) ring[i] = 0.0;         // ring + yring
   long long t_c0 = 0, t_w0 = 0;
   if (tid == 0) { t_c0 = clock64(); t_w0 = wall_clock64(); }
 
   // stage `rows` contiguous band rows of S, b and the mask starting at row j0
   auto stage_chunk = [&](int j0) {
     const int rows = min(ch, nco - j0);
-    const double* src = S + (size_t)j0 * ROWLEN;
-    for (int i = tid; i < rows * ROWLEN; i += kSolveThreads) stage[i] = src[i];
+    copy_to_lds<kSolveThreads>(stage, S + (size_t)j0 * ROWLEN, rows * ROWLEN, tid);
     for (int i = tid; i < rows * 6; i += kSolveThreads) bstage[i] = b[(size_t)j0 * 6 + i];
-    if (mask) {
+    if (MASKED) {
       const int mc = (rows + HB) * 6;
       for (int i = tid; i < mc; i += kSolveThreads) mstage[i] = (j0 * 6 + i < nco * 6) ? mask[j0 * 6 + i] : 1;
     }
@@ -727,15 +775,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
     if (tk < ROWLEN) {
       const int d = tk / 36, e = tk % 36, a = e / 6, c = e % 6;
       double v = stage[jj * ROWLEN + tk];
-      if (mask && (!mstage[jj * 6 + a] || !mstage[(jj + d) * 6 + c])) v = (d == 0 && a == c) ? 1.0 : 0.0;
+      if (MASKED && (!mstage[jj * 6 + a] || !mstage[(jj + d) * 6 + c])) v = (d == 0 && a == c) ? 1.0 : 0.0;
       return v;
     }
     const int a = tk - ROWLEN;
-    return (mask && !mstage[jj * 6 + a]) ? 0.0 : bstage[jj * 6 + a];
+    return (MASKED && !mstage[jj * 6 + a]) ? 0.0 : bstage[jj * 6 + a];
   };
   // contribution of U row (slot) at distance m to entry tk of the row being built
   auto term = [&](int slot, int m, int tk) -> double {
-    const double* row = ring + (size_t)slot * ROWLEN;
+    const double* row = ring + (size_t)slot * RS;
     double dot = 0.0;
     if (tk < ROWLEN) {
       const int d = tk / 36, e = tk % 36, a = e / 6, c = e % 6;
@@ -791,7 +839,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
           if (HB >= 2 && m <= HB && m + d <= HB) {
             int slot = nslot - m;
             if (slot < 0) slot += HB;
-            const double* row = ring + (size_t)slot * ROWLEN;
+            const double* row = ring + (size_t)slot * RS;
             const double* Uj = row + m * 36 + a0;                         // U[r, j+1][q][a0 .. a0+2]
             const double* Ujd = row + (m + d) * 36 + c0;                  // U[r, j+1+d][q][c0 .. c0+2]
             double ua[18], uc[18];
@@ -810,18 +858,18 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
             }
           }
 #pragma unroll
-          for (int msk = 1; msk < G; msk <<= 1) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) acc[i] += __shfl_xor(acc[i], msk, 64);
-          }
+          for (int i = 0; i < 9; ++i) acc[i] = group_sum<G>(acc[i]);
           if (g == 0) {
+            double sv[9];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                const int tk = d * 36 + (a0 + i) * 6 + c0 + k;
-                Bnext[tk] = staged(jj1, tk) - acc[i * 3 + k];
-              }
+              for (int k = 0; k < 3; ++k) sv[i * 3 + k] = staged(jj1, d * 36 + (a0 + i) * 6 + c0 + k);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) Bnext[d * 36 + (a0 + i) * 6 + c0 + k] = sv[i * 3 + k] - acc[i * 3 + k];
             }
           }
         }
@@ -833,13 +881,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
           if (HB >= 2 && m <= HB) {
             int slot = nslot - m;
             if (slot < 0) slot += HB;
-            const double* Uj = ring + (size_t)slot * ROWLEN + m * 36 + a;
+            const double* Uj = ring + (size_t)slot * RS + m * 36 + a;
             const double* yr = yring + slot * 6;
 #pragma unroll
             for (int q = 0; q < 6; ++q) acc += Uj[q * 6] * yr[q];
           }
-#pragma unroll
-          for (int msk = 1; msk < G; msk <<= 1) acc += __shfl_xor(acc, msk, 64);
+          acc = group_sum<G>(acc);
           if (g == 0) Bnext[ROWLEN + a] = staged(jj1, ROWLEN + a) - acc;
         }
       }
@@ -881,7 +928,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
           const double v = p <= c ? col[p] : 0.0;
-          if (HB > 0) ring[(size_t)jslot * ROWLEN + p * 6 + c] = v;
+          if (HB > 0) ring[(size_t)jslot * RS + p * 6 + c] = v;
           U[(size_t)j * ROWLEN + p * 6 + c] = v;
         }
       }
@@ -907,7 +954,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
         } else {
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
-            ring[(size_t)jslot * ROWLEN + d * 36 + q * 6 + cc] = v[q];
+            ring[(size_t)jslot * RS + d * 36 + q * 6 + cc] = v[q];
             U[(size_t)j * ROWLEN + d * 36 + q * 6 + cc] = v[q];
           }
         }
@@ -926,30 +973,27 @@ __global__ __launch_bounds__(kSolveThreads) void k_band_solve(int nco, int ch, c
     if (tid == 0) *info = *bad;
     return;
   }
-  if (tid >= 64) return;
   if (tid == 0) {      // instrumentation: shader cycles / 100 MHz wall ticks of the forward sweep
     info[2] = (int)(clock64() - t_c0);
     info[3] = (int)(wall_clock64() - t_w0);
   }
 
-  // ---- backward substitution by wavefront 0 alone (no workgroup barriers): rows nco-1 .. 0,
-  // again in chunks staged through LDS.  lane (a = lane % 6, g = lane / 6) owns row a of
-  // blocks d = g, g + 10, g + 20 of a band row.
-  const int a_ = tid % 6, g_ = tid / 6;               // g_ in 0..10 (lanes 60..63 idle)
+  // ---- backward substitution, rows nco-1 .. 0, again in chunks staged through LDS by the
+  // whole workgroup; the recurrence itself runs on wavefront 0 alone (no barriers inside a
+  // chunk).  lane (a = lane % 6, g = lane / 6) owns row a of blocks d = g, g + 10, g + 20.
+  const int a_ = tid % 6, g_ = tid / 6;               // g_ in 0..10 for wavefront 0 (lanes 60..63 idle)
   constexpr int NG = HB1 < 10 ? HB1 : 10;
   int xslot = HB > 0 ? (nco - 1) % HB : 0;            // slot of row j in xring
   for (int jend = nco; jend > 0; jend -= ch) {
     const int jbeg = max(0, jend - ch), rows = jend - jbeg;
-    lds_wave_sync();
-    {
-      const double* src = U + (size_t)jbeg * ROWLEN;
-      for (int i = tid; i < rows * ROWLEN; i += 64) stage[i] = src[i];
-      for (int i = tid; i < rows * 6; i += 64) {
-        bstage[i] = y[(size_t)jbeg * 6 + i];
-        dstage[i] = dinvg[(size_t)jbeg * 6 + i];
-      }
+    lds_barrier();                                    // wavefront 0 is done with the previous chunk
+    copy_to_lds<kSolveThreads>(stage, U + (size_t)jbeg * ROWLEN, rows * ROWLEN, tid);
+    for (int i = tid; i < rows * 6; i += kSolveThreads) {
+      bstage[i] = y[(size_t)jbeg * 6 + i];
+      dstage[i] = dinvg[(size_t)jbeg * 6 + i];
     }
-    lds_wave_sync();
+    lds_barrier();
+    if (tid >= 64) continue;
     for (int jj = rows - 1; jj >= 0; --jj) {
       const int j = jbeg + jj;
       const double* urow = stage + (size_t)jj * ROWLEN;
