@@ -56,7 +56,7 @@ typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_se
 /* kernel ids for ba_get_timings */
 enum {
   BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
-  BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_COUNT
+  BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_TRIANGULATE, BA_K_COUNT
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -159,6 +159,15 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP);
  * -(dC, dP) of the last ba_backsubstitute, taken from device memory.
  * Only optimised cameras / tracks move. */
 int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const double* structure);
+
+/* ---- Bundle.triangulate_all (bundle.py:313-321; triangulate.algebraic_lsq triangulate.py:6-18)
+ * Re-initialise every point of parameter set `which` by linear least squares from its
+ * observations and the set's cameras (the step before the path: test_bundle.py:175,
+ * window_slam.py:82).  rcond: numpy.linalg.lstsq cut-off on the singular values of A
+ * (< 0 = numpy's default; the kernel solves the 3x3 normal equations, so the effective
+ * cut-off is max(rcond, 1e-7) relative to the largest singular value).
+ * X[nt*3] (host) may be NULL: the result stays on the device. */
+int ba_triangulate(ba_handle* h, int which, double rcond, double* X);
 
 /* ---- instrumentation ---------------------------------------------------- */
 int ba_enable_timing(ba_handle* h, int on);

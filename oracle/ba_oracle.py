@@ -415,6 +415,31 @@ def lm_optimize(sensor, K, R, t, X, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt,
 
 
 # --------------------------------------------------------------------------
+# triangulation (triangulate.py:6-18, bundle.py:313-321)
+# --------------------------------------------------------------------------
+def triangulate_all(K, R, t, obs_cam, obs_pt, obs_z, nt):
+    """Per point: numpy.linalg.lstsq on the 2L x 3 algebraic system."""
+    X = np.zeros((nt, 3))
+    order = np.argsort(obs_pt, kind='stable')
+    cam, pt, z = obs_cam[order], obs_pt[order], obs_z[order]
+    bounds = np.searchsorted(pt, np.arange(nt + 1))
+    for k in range(nt):
+        s, e = bounds[k], bounds[k + 1]
+        if e == s:
+            continue
+        A = np.empty((2 * (e - s), 3))
+        b = np.empty(2 * (e - s))
+        for i, n in enumerate(range(s, e)):
+            Ri, ti = R[cam[n]], t[cam[n]]
+            b[2 * i] = (z[n, 0] * K[2] - K[0]) @ ti
+            b[2 * i + 1] = (z[n, 1] * K[2] - K[1]) @ ti
+            A[2 * i] = (K[0] - z[n, 0] * K[2]) @ Ri
+            A[2 * i + 1] = (K[1] - z[n, 1] * K[2]) @ Ri
+        X[k] = np.linalg.lstsq(A, b, rcond=None)[0]
+    return X
+
+
+# --------------------------------------------------------------------------
 # dense-matrix oracle (schur.py:4-44, bundle.py:452-505) - small scenes only
 # --------------------------------------------------------------------------
 def dense_jacobian(sensor, K, R, t, X, obs_cam, obs_pt, obs_z):

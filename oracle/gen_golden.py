@@ -32,7 +32,8 @@ import numpy as np
 # the reference (fundamental.py, fmat_uncertainty.py) do not even parse for lib2to3
 REF_MODULES = ['algebra', 'lie', 'numpy_test', 'finite_differences', 'sensor_model', 'triangulate',
                'bundle', 'optimize', 'schur', 'bundle_adjuster', 'sequence', 'synthetic_data',
-               'bundle_io', 'bundle_unittest', 'test_bundle', 'draw_bundle', 'geometry']
+               'bundle_io', 'bundle_unittest', 'test_bundle', 'draw_bundle', 'geometry',
+               'window_slam', 'draw_bundle_pca', 'pca']
 
 
 def import_reference(ref_dir):
@@ -186,7 +187,7 @@ def main():
         import importlib
         names = ['bundle', 'bundle_adjuster', 'sensor_model', 'lie', 'schur', 'optimize',
                  'synthetic_data', 'bundle_io', 'triangulate', 'bundle_unittest', 'test_bundle',
-                 'algebra']
+                 'algebra', 'window_slam', 'geometry']
         with quiet():
             ref = {n: importlib.import_module(n) for n in names}
         generate(ref, args)
@@ -366,6 +367,54 @@ def generate(ref, args):
              track0_z=np.array([bo.tracks[0].measurements[i] for i in sorted(bo.tracks[0].measurements.keys())], float),
              nobs=sum(len(t.measurements) for t in bo.tracks))
     save(args.out, 'oleg_io', d)
+
+    # ---- (6b) window_slam.run on the first 10 cameras / 100 tracks, window of 4 --------
+    with quiet():
+        ws = B.Bundle()
+        ws.K = bo.K.copy()
+        for i in range(10):
+            ws.add_camera(B.Camera(bo.cameras[i].R.copy(), bo.cameras[i].t.copy()))
+        for j in range(100):
+            tr = bo.tracks[j]
+            ids = [i for i in range(10) if tr.has_measurement(i)]
+            ws.add_track(B.Track(ids, [np.asarray(tr.get_measurement(i), float) for i in ids]))
+        ws.triangulate_all()
+    d = bundle_arrays(ws)
+    d.update(sensor_arrays(ws.sensor_model))
+    # the reference's run() keeps no history: wrap BundleAdjuster.optimize to record it
+    BA = ref['bundle_adjuster'].BundleAdjuster
+    hist = []
+    orig_opt = BA.optimize
+
+    def rec_opt(self, *a, **kw):
+        orig_opt(self, *a, **kw)
+        hist.append((self.num_steps, self.converged, list(self.costs)))
+    BA.optimize = rec_opt
+    try:
+        import copy
+        state = {}
+        orig_run_ba = ref['window_slam'].BundleAdjuster
+        with quiet():
+            # run() returns nothing: capture the last adjuster's bundle through the recorder
+            last = {}
+            orig_set = BA.set_bundle
+
+            def rec_set(self, *a, **kw):
+                last['ba'] = self
+                return orig_set(self, *a, **kw)
+            BA.set_bundle = rec_set
+            ref['window_slam'].run(copy.deepcopy(ws), 4)
+            BA.set_bundle = orig_set
+    finally:
+        BA.optimize = orig_opt
+    fin = bundle_arrays(last['ba'].bundle)
+    d['ws_R'], d['ws_t'], d['ws_X'] = fin['R'], fin['t'], fin['X']
+    d['ws_num_windows'] = len(hist)
+    d['ws_num_steps'] = np.array([h[0] for h in hist])
+    d['ws_converged'] = np.array([h[1] for h in hist])
+    d['ws_first_cost'] = np.array([h[2][0] for h in hist])
+    d['ws_last_cost'] = np.array([h[2][-1] for h in hist])
+    save(args.out, 'scene_window_slam', d)
 
     # ---- (7) config-2-sized spot check: 100 cams x 1000 tracks ------------
     if args.big:

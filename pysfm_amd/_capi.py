@@ -18,7 +18,7 @@ BA_ERR_INVALID_ARG, BA_ERR_NO_DEVICE, BA_ERR_HIP, BA_ERR_STATE, BA_ERR_SINGULAR,
 SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER = 0, 1, 2
 PARAMS_CUR, PARAMS_TRIAL = 0, 1
 KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 'backsub',
-              'update', 'flatten', 'band_solve', 'eval', 'camera_blocks')
+              'update', 'flatten', 'band_solve', 'eval', 'camera_blocks', 'triangulate')
 K_COUNT = len(KERNEL_IDS)
 
 _dp = C.POINTER(C.c_double)
@@ -54,6 +54,7 @@ PROTOTYPES = {
     'ba_flatten_reduced': (C.c_int, [_h, _ip, C.c_int32, C.c_void_p, C.c_void_p]),
     'ba_backsubstitute': (C.c_int, [_h, C.c_int, _dp, _dp]),
     'ba_apply_update': (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp]),
+    'ba_triangulate': (C.c_int, [_h, C.c_int, C.c_double, _dp]),
     'ba_enable_timing': (C.c_int, [_h, C.c_int]),
     'ba_get_timings': (C.c_int, [_h, _dp, C.POINTER(C.c_int64), C.c_int]),
     'ba_kernel_name': (C.c_char_p, [C.c_int]),

@@ -270,6 +270,13 @@ class HipBackend(object):
             assert len(motion) == self.nco and len(structure) == self.nt
         self._check(self._lib.ba_apply_update(self._h, src, dst, capi.dptr(motion), capi.dptr(structure)))
 
+    def triangulate(self, which, rcond=None, fetch=True):
+        """Linear least-squares re-initialisation of every point from the cameras of
+        parameter set `which` (Bundle.triangulate_all, bundle.py:320-321)."""
+        X = np.empty((self.nt, 3)) if fetch else None
+        self._check(self._lib.ba_triangulate(self._h, which, -1.0 if rcond is None else float(rcond), capi.dptr(X)))
+        return X
+
     # ---------------------------------------------------------------- instrumentation
     def enable_timing(self, on=True):
         self._check(self._lib.ba_enable_timing(self._h, int(bool(on))))

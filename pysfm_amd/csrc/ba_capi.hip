@@ -214,7 +214,7 @@ const char* ba_version(void) { return "pysfm_ba 0.1 (gfx950)"; }
 const char* ba_kernel_name(int id) {
   static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
                                           "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
-                                          "k_band_solve", "k_eval", "k_camera_blocks"};
+                                          "k_band_solve", "k_eval", "k_camera_blocks", "k_triangulate"};
   return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
 }
 
@@ -896,6 +896,30 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   if (motion) HIPCHECK(h, hipStreamSynchronize(h->stream));
   h->have_params[pd] = true;
   if (dst == BA_PARAMS_CUR) h->have_linearization = h->have_schur = false;
+  return BA_OK;
+}
+
+int ba_triangulate(ba_handle* h, int which, double rcond, double* X) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_triangulate: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_triangulate: set problem and parameters first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  if (rcond < 0) rcond = 2.220446049250313e-16 * std::max<double>(3.0, 2.0 * 64);   // numpy's default scale
+  // the normal equations resolve singular values of A only down to sqrt(eps) * s_max: the rank
+  // decision is made at 1e-7 * s_max (tracks with less parallax get the minimum-norm point)
+  if (h->nt > 0) {
+    ScopedTimer tm(h, BA_K_TRIANGULATE);
+    const long long threads = (long long)h->nt << h->glog;
+    hipLaunchKernelGGL(k_triangulate, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
+                       h->glog, std::max(rcond * rcond, 1e-14), h->X[p].p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  if (which == BA_PARAMS_CUR) h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
+  if (X && h->nt) {
+    HIPCHECK(h, hipMemcpyAsync(X, h->X[p].p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+  }
   return BA_OK;
 }
 

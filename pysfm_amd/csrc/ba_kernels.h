@@ -623,6 +623,59 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
 }
 
 // --------------------------------------------------------------------------
+// Bundle.triangulate_all (bundle.py:313-321; triangulate.algebraic_lsq, triangulate.py:6-18):
+// per point the linear least-squares problem with two rows per observation,
+//   A[2i]   = (K[0] - z0 K[2]) R_i ,   b[2i]   = (z0 K[2] - K[0]) . t_i
+//   A[2i+1] = (K[1] - z1 K[2]) R_i ,   b[2i+1] = (z1 K[2] - K[1]) . t_i
+// solved through the 3x3 normal equations x = pinv(A^T A) A^T b (numpy.linalg.lstsq's
+// minimum-norm answer; singular values of A^T A below (rcond * s_max)^2 are dropped).
+// Same lanes-per-point mapping as k_linearize.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_triangulate(DevProblem P, const double* __restrict__ cams, int glog,
+                                                        double rcond2, double* __restrict__ Xout) {
+  const int G = 1 << glog;
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long k = tid >> glog;
+  const int l = (int)(tid & (G - 1));
+  const bool valid = k < P.nt;
+  int s = 0, e_ = 0;
+  if (valid) { s = P.pt_off[k]; e_ = P.pt_off[k + 1]; }
+  double ata[6] = {0, 0, 0, 0, 0, 0}, atb[3] = {0, 0, 0};
+  for (int n = s + l; n < e_; n += G) {
+    const int c = P.obs_cam[n];
+    const double2 z = P.obs_z[n];
+    double cm[12];
+    load_cam(cams, c, cm);
+    const double zz[2] = {z.x, z.y};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double k0 = P.K[3 * r] - zz[r] * P.K[6], k1 = P.K[3 * r + 1] - zz[r] * P.K[7],
+                   k2 = P.K[3 * r + 2] - zz[r] * P.K[8];
+      const double a0 = k0 * cm[0] + k1 * cm[3] + k2 * cm[6];
+      const double a1 = k0 * cm[1] + k1 * cm[4] + k2 * cm[7];
+      const double a2 = k0 * cm[2] + k1 * cm[5] + k2 * cm[8];
+      const double rhs = -(k0 * cm[9] + k1 * cm[10] + k2 * cm[11]);
+      ata[0] += a0 * a0; ata[1] += a0 * a1; ata[2] += a0 * a2;
+      ata[3] += a1 * a1; ata[4] += a1 * a2; ata[5] += a2 * a2;
+      atb[0] += a0 * rhs; atb[1] += a1 * rhs; atb[2] += a2 * rhs;
+    }
+  }
+  for (int m = G >> 1; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ata[i] += __shfl_xor(ata[i], m, 64);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) atb[i] += __shfl_xor(atb[i], m, 64);
+  }
+  if (valid && l == 0) {
+    double inv[6], x[3];
+    sym3_pinv(ata, rcond2, inv);
+    sym3_apply(inv, atb, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Xout[3 * k + i] = x[i];
+  }
+}
+
+// --------------------------------------------------------------------------
 // update_motion / update_structure (bundle_adjuster.py:334-343): dst = src (+) sign*delta
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_apply_update(int nc, int nt, const int* __restrict__ cam_opt_pos,

@@ -153,6 +153,12 @@ class OracleBackend(object):
         self.dP = O.backsubstitute(self.dC, self.HPP_inv, W, bP, self.obs[0], self.obs[1], self.cam_opt_pos, self.nt)
         return self.dP.copy() if fetch else None
 
+    def triangulate(self, which, rcond=None, fetch=True):
+        R, t, X = self.p[self._phys(which)]
+        X2 = O.triangulate_all(self.K, R, t, self.obs[0], self.obs[1], self.obs[2], self.nt)
+        self.p[self._phys(which)] = (R, t, X2)
+        return X2.copy() if fetch else None
+
     def apply_update(self, src, dst, motion=None, structure=None):
         R, t, X = self.p[self._phys(src)]
         if motion is None:

@@ -509,3 +509,69 @@ def test_timing_counters(be):
     be.enable_timing(False)
     assert tm['schur_pairs']['launches'] == 3 and tm['linearize']['launches'] == 3 and tm['cost']['launches'] == 3
     assert tm['schur_pairs']['ms'] > 0
+
+
+# ------------------------------------------------------------------ rows either side of the path
+@pytest.mark.parametrize('name', ['scene_planar_lm', 'scene_oleg_10x50', 'scene_oleg_40x100'])
+def test_triangulation_vs_reference(be, name):
+    """k_triangulate against the reference's Bundle.triangulate_all (the fixture's X)."""
+    g = load_golden(name)
+    nc, nt = len(g['R']), len(g['X'])
+    load_problem(be, g['K'], g['R'], g['t'], np.zeros((nt, 3)), g['obs_cam'], g['obs_pt'], g['obs_z'],
+                 *default_flags(nc, nt), sensor_of(g))
+    X = be.triangulate(0)
+    close(X, g['X'], 1e-7)
+    close(be.get_params(0)[2], X, 0.)
+
+
+def test_triangulation_degenerate_tracks(be):
+    """one observation (rank 2) and no observation: minimum-norm answer like numpy.linalg.lstsq"""
+    s = banded(12, 30, track_len=6)
+    keep = np.ones(len(s['obs_cam']), bool)
+    keep[np.nonzero(s['obs_pt'] == 4)[0][1:]] = False
+    keep[s['obs_pt'] == 9] = False
+    cam, pt, z = s['obs_cam'][keep], s['obs_pt'][keep], s['obs_z'][keep]
+    load_problem(be, s['K'], s['R'], s['t'], np.zeros((30, 3)), cam, pt, z, *default_flags(12, 30), O.Sensor.gaussian(1.))
+    X = be.triangulate(0)
+    X0 = O.triangulate_all(s['K'], s['R'], s['t'], cam, pt, z, 30)
+    close(X, X0, 1e-7)
+    assert np.all(X[9] == 0)
+    ok = (pt != 4) & (pt != 9)               # well-posed tracks reproject to within the measurement noise
+    e = O.reproj_error(s['K'], s['R'], s['t'], X, cam[ok], pt[ok], z[ok])
+    assert np.sqrt(np.mean(np.sum(e * e, axis=1))) < 3 * .02
+
+
+def test_window_slam_vs_reference():
+    from pysfm_amd import Bundle, window_slam
+    g = load_golden('scene_window_slam')
+    b = Bundle.FromObservations(*scene(g))
+    out, hist = window_slam.run(b, 4, verbose=False)
+    assert len(hist) == 7
+    assert [len(h) - 1 <= n for h, n in zip(hist, g['ws_num_steps'])]
+    close([h[0] for h in hist], g['ws_first_cost'], LM)
+    close([h[-1] for h in hist], g['ws_last_cost'], LM)
+    close(out.Rs(), g['ws_R'], LM)
+    close(out.ts(), g['ws_t'], LM, 1e-6)
+    close(out.reconstruction, g['ws_X'], LM)
+
+
+def test_batch_driver_end_to_end(tmp_path):
+    from conftest import GOLDEN
+    from pysfm_amd import batch_ba, bundle_io
+    import os
+    ba = batch_ba.main([os.path.join(GOLDEN, 'oleg_tracks_head5.txt'), os.path.join(GOLDEN, 'oleg_poses.txt'),
+                        str(tmp_path), '--cameras', '40', '--tracks', '5', '--max-steps', '6'])
+    assert len(ba.camera_ids) == 40 and len(ba.track_ids) == 5
+    assert all(c1 < c0 for c0, c1 in zip(ba.costs, ba.costs[1:])) and len(ba.costs) >= 2
+    lines = open(tmp_path / 'adjusted_poses.txt').read().strip().split('\n')
+    assert len(lines) == 40 and len(lines[0].split()) == 12
+    # against the oracle on the same files
+    b = bundle_io.load(os.path.join(GOLDEN, 'oleg_tracks_head5.txt'), os.path.join(GOLDEN, 'oleg_poses.txt'))
+    cam, trk, z = b.observation_table()
+    X0 = O.triangulate_all(b.K, b.Rs(), b.ts(), cam, trk, z, 5)
+    m = cam < 40
+    mask = np.ones(39 * 6, bool)
+    mask[3] = False
+    ref = O.lm_optimize(O.Sensor.gaussian(1.), b.K, b.Rs()[:40], b.ts()[:40], X0, cam[m], trk[m], z[m],
+                        np.arange(40, dtype=np.int32) - 1, np.ones(5, bool), cam_param_mask=mask, max_steps=6)
+    close(ba.costs, ref['costs'], LM)
