@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ba_kernels.h"
+#include "ba_bcr.h"
 
 using namespace ba;
 
@@ -74,7 +75,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, partial, scalar, scratch, Ufac, ysol, dinv;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, partial, scalar, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrX;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   DevBuf<int> flags;
@@ -205,6 +206,42 @@ int ensure_reduced(ba_handle* h) {
   return BA_OK;
 }
 
+// Block cyclic reduction over super-blocks of hb cameras (ba_bcr.h): log2(N) levels, one
+// workgroup per eliminated node.  Leaves the solution in h->dC and the status in flags[1].
+int solve_bcr(ba_handle* h, const unsigned char* dmask) {
+  const int hb = h->hb, B = 6 * hb, N = (h->nco + hb - 1) / hb;
+  const size_t BB = (size_t)B * B;
+  HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
+  HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
+  HIPCHECK(h, h->bcrF.resize((size_t)N * B)); HIPCHECK(h, h->bcrX.resize((size_t)N * B));
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcr_eliminate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcr_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  HIPCHECK(h, hipMemsetAsync(h->flags.p + 1, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
+                     h->bcrU.p, h->bcrF.p);
+  const size_t lds = bcr_lds_bytes(B);
+  std::vector<int> strides;
+  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) {
+    const int cnt = (N / s + 1) / 2;
+    hipLaunchKernelGGL(k_bcr_eliminate, dim3(cnt), dim3(kBcrThreads), lds, h->stream, N, B, s, h->bcrD.p, h->bcrU.p,
+                       h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->flags.p + 1);
+    strides.push_back(s);
+  }
+  const size_t lds2 = ((size_t)B * (B + 1) + 2 * B + 8) * sizeof(double);
+  for (int q = (int)strides.size() - 1; q >= 0; --q) {
+    const int s = strides[q], cnt = (N / s + 1) / 2;
+    hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
+                       h->bcrQ.p, h->bcrG.p, h->bcrX.p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  HIPCHECK(h, hipMemcpyAsync(h->dC.p, h->bcrX.p, (size_t)h->nco * 6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return BA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -260,7 +297,8 @@ int ba_destroy(ba_handle* h) {
   h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
-  h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release(); h->mask.release(); h->dP.release();
+  h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrX.release(); h->mask.release(); h->dP.release();
   h->partial.release(); h->scalar.release(); h->scratch.release(); h->flags.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -812,11 +850,21 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
       dmask = h->mask.p;
     }
   }
+  // multi-CU path: block cyclic reduction when the band is narrow enough for dense
+  // (6 hb)^2 blocks in LDS and there are enough super-blocks to parallelise over
+  const char* force = getenv("BA_SOLVER");
+  const bool bcr_ok = h->hb >= 1 && h->hb <= kBcrMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
+  const bool use_bcr = force ? (strcmp(force, "bcr") == 0 && bcr_ok) : bcr_ok;
   const size_t lds_budget = 160 * 1024;
   const int ch = band_solve_chunk(h->hb, lds_budget);
-  if (ch < 1) { *info = -1; return BA_OK; }
-  const size_t lds = band_solve_lds_bytes(h->hb, ch);
-  {
+  size_t lds = 0;
+  if (use_bcr) {
+    ScopedTimer tm(h, BA_K_BAND_SOLVE);
+    int rc = solve_bcr(h, dmask);
+    if (rc != BA_OK) return rc;
+  } else {
+    if (ch < 1) { *info = -1; return BA_OK; }
+    lds = band_solve_lds_bytes(h->hb, ch);
     ScopedTimer tm(h, BA_K_BAND_SOLVE);
     hipError_t le = launch_band_solve(h->hb, lds, h->stream, h->nco, ch, h->S, h->b, dmask, h->Ufac.p, h->ysol.p,
                                       h->dinv.p, h->dC.p, h->flags.p + 1);
@@ -827,7 +875,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   const int inf = inf6[0];
-  if (getenv("BA_SOLVE_TRACE"))
+  if (getenv("BA_SOLVE_TRACE") && !use_bcr)
     fprintf(stderr, "[k_band_solve] nco=%d hb=%d ch=%d lds=%zu B | forward: %d cycles, %d ticks(100MHz) | total: %d cycles, %d ticks\n",
             h->nco, h->hb, ch, lds, inf6[2], inf6[3], inf6[4], inf6[5]);
   *info = inf;

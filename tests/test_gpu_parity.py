@@ -474,6 +474,36 @@ def test_band_solver_vs_dense_lu(be):
         close(-be.backsubstitute(0), su, SOLVE)
 
 
+@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5)])
+def test_cyclic_reduction_vs_sequential_band_solver(be, monkeypatch, nc, L):
+    """The multi-CU block-cyclic-reduction solve against the single-workgroup band Cholesky and
+    the dense LU on the same device-resident system (odd sizes: padded last super-block,
+    non-power-of-two level counts), with and without masked parameters."""
+    s = banded(nc, 50 * nc, track_len=L)
+    flags = default_flags(nc, 50 * nc)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    assert be.half_bandwidth == L - 1
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    n = (nc - 1) * 6
+    for mask in (None, (np.arange(n) % 7 != 3).astype(np.uint8)):
+        sol = {}
+        for solver in ('bcr', 'seq'):
+            monkeypatch.setenv('BA_SOLVER', solver)
+            be.solve_reduced(mask)
+            assert be.last_solve_path == 'band'
+            sol[solver] = be.get_solution().reshape(-1)
+        keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
+        xd = np.zeros(n)
+        xd[keep] = be._solve_dense(keep)
+        close(sol['bcr'], xd, 1e-9)
+        close(sol['seq'], xd, 1e-9)
+        close(sol['bcr'], sol['seq'], 1e-10)
+        if mask is not None:
+            assert np.all(sol['bcr'][mask == 0] == 0)
+    monkeypatch.delenv('BA_SOLVER')
+
+
 def test_wide_band_takes_dense_path(be):
     g = load_golden('scene_oleg_40x100')
     load_problem(be, *scene(g), g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
