@@ -71,13 +71,18 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
 
 // One elimination level.  blockIdx.x = k-th node of this level: i = s*(2k+1) - 1.
 // Out: Gi[i] = G^-1 (lower triangular), Pm[i] = P, Qm[i] = Q, fm[i] = g; neighbours updated.
-__global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int B, int s, double* __restrict__ Dm,
+// HB is a template parameter so that the dense B x B (B = 6 HB) pieces unroll: a blocked
+// (6-wide) right-looking Cholesky whose 6x6 diagonal factor runs on one wavefront with
+// v_readlane broadcasts, and a forward substitution that keeps a whole solution column in
+// registers (one thread per right-hand side, L read from LDS as broadcasts).
+template <int HB>
+__global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, double* __restrict__ Dm,
                                                                double* __restrict__ Um, double* __restrict__ fm,
                                                                double* __restrict__ Pm, double* __restrict__ Qm,
                                                                double* __restrict__ Gi, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int ld = B + 1;
-  double* G = sm;                       // [B][ld]  D_i -> its Cholesky factor (lower)
+  constexpr int B = 6 * HB, ld = B + 1;
+  double* G = sm;                       // [B][ld]  D_i -> its Cholesky factor L (lower)
   double* Pl = G + (size_t)B * ld;      // [B][ld]  T[i,l] -> P
   double* Ql = Pl + (size_t)B * ld;     // [B][ld]  T[i,r] -> Q
   double* Xi = Ql + (size_t)B * ld;     // [B][ld]  identity -> G^-1
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int B, int
   if (i >= N) return;
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;
-  const size_t BB = (size_t)B * B;
+  constexpr size_t BB = (size_t)B * B;
 
   if (tid == 0) *bad = 0;
   for (int e = tid; e < B * B; e += kBcrThreads) {
@@ -102,18 +107,98 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int B, int
   for (int e = tid; e < B; e += kBcrThreads) g[e] = fm[(size_t)i * B + e];
   __syncthreads();
 
-  // ---- Cholesky D_i = G G^T, right-looking, in place (lower triangle)
-  const int ti = tid >> 4, tj = tid & 15;               // 16 x 16 thread grid over the trailing block
-  for (int k = 0; k < B; ++k) {
-    const double akk = G[k * ld + k];                   // stays as is: only dinv[k] is used from here on
-    if (!(akk > 0.0) && tid == 0) *bad = k + 1;
-    const double inv = rsqrt_nr(akk);
-    for (int i2 = k + 1 + tid; i2 < B; i2 += kBcrThreads) G[i2 * ld + k] *= inv;
-    if (tid == 0) dinv[k] = inv;
+  // ---- blocked Cholesky D_i = L L^T (lower, in place), block size 6
+  for (int kb = 0; kb < HB; ++kb) {
+    const int k0 = 6 * kb;
+    if (tid < 64) {
+      // 6x6 diagonal block on wavefront 0: lane c owns column c of the upper factor U (= L^T)
+      const int c = tid < 6 ? tid : 5;
+      double col[6];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) col[p] = G[(k0 + c) * ld + k0 + p];      // A[p][c] from the lower triangle
+      int fail = 0;
+      double di = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double piv = lane_bcast(col[q], q);
+        if (!(piv > 0.0) && !fail) fail = q + 1;
+        const double inv = rsqrt_nr(piv);
+        if (c == q) di = inv;
+        const double uqc = c == q ? piv * inv : (c > q ? col[q] * inv : 0.0);
+        col[q] = uqc;
+#pragma unroll
+        for (int p = q + 1; p < 6; ++p) {
+          const double uqp = lane_bcast(uqc, p);
+          if (p <= c) col[p] -= uqp * uqc;
+        }
+      }
+      if (fail && tid == 0) *bad = k0 + fail;
+      if (tid < 6) {
+        dinv[k0 + c] = di;
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+          if (p <= c) G[(k0 + c) * ld + k0 + p] = col[p];                    // L[c][p] = U[p][c]
+      }
+    }
     __syncthreads();
-    for (int i2 = k + 1 + ti; i2 < B; i2 += 16) {
-      const double gik = G[i2 * ld + k];
-      for (int j2 = k + 1 + tj; j2 <= i2; j2 += 16) G[i2 * ld + j2] -= gik * G[j2 * ld + k];
+    // panel: rows below the diagonal block, X = A[i2][k0..k0+5] L_kk^-T (one row per thread)
+    {
+      double Lk[15], dk[6];
+      int idx = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        dk[q] = dinv[k0 + q];
+#pragma unroll
+        for (int p = 0; p < q; ++p) Lk[idx++] = G[(k0 + q) * ld + k0 + p];
+      }
+      for (int i2 = k0 + 6 + tid; i2 < B; i2 += kBcrThreads) {
+        double x[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) x[q] = G[i2 * ld + k0 + q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          double t = x[q];
+#pragma unroll
+          for (int p = 0; p < q; ++p) t -= x[p] * Lk[q * (q - 1) / 2 + p];
+          x[q] = t * dk[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) G[i2 * ld + k0 + q] = x[q];
+      }
+    }
+    __syncthreads();
+    // trailing update in 3x3 tiles of the lower triangle: A[i][j] -= sum_q X[i][q] X[j][q]
+    {
+      const int n3 = (B - k0 - 6) / 3;                       // tiles per side
+      const int ntile = n3 * (n3 + 1) / 2;
+      for (int t = tid; t < ntile; t += kBcrThreads) {
+        int ti, tj;
+        tri_decode(t, n3, tj, ti);                           // tj <= ti
+        const int i0 = k0 + 6 + 3 * ti, j0 = k0 + 6 + 3 * tj;
+        double xi[18], xj[18], a[9];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { xi[u * 6 + q] = G[(i0 + u) * ld + k0 + q]; xj[u * 6 + q] = G[(j0 + u) * ld + k0 + q]; }
+#pragma unroll
+          for (int v = 0; v < 3; ++v) a[u * 3 + v] = G[(i0 + u) * ld + j0 + v];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            double acc = a[u * 3 + v];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc -= xi[u * 6 + q] * xj[v * 6 + q];
+            a[u * 3 + v] = acc;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+          for (int v = 0; v < 3; ++v) G[(i0 + u) * ld + j0 + v] = a[u * 3 + v];   // (the strict upper part of diagonal tiles is never read)
+        }
+      }
     }
     __syncthreads();
   }
@@ -122,33 +207,38 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int B, int
     return;
   }
 
-  // ---- forward substitution, one thread per right-hand-side column:
-  //      P (B columns), Q (B columns), G^-1 (B columns), g (1 column)
+  // ---- forward substitution L Y = R, one thread per right-hand-side column, the column kept
+  //      in registers: P (B columns), Q (B columns), G^-1 (B columns), g (1 column)
   {
-    const int ncol = 3 * B + 1;
+    constexpr int ncol = 3 * B + 1;
     for (int c = tid; c < ncol; c += kBcrThreads) {
       double* X = c < B ? Pl + c : c < 2 * B ? Ql + (c - B) : c < 3 * B ? Xi + (c - 2 * B) : g;
       const int st = c < 3 * B ? ld : 1;
-      const int first = (c >= 2 * B && c < 3 * B) ? c - 2 * B : 0;   // identity column: zeros above the diagonal
-      for (int i2 = first; i2 < B; ++i2) {
-        double a0 = X[i2 * st], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int k2 = first;
-        for (; k2 + 3 < i2; k2 += 4) {
-          a0 -= G[i2 * ld + k2] * X[k2 * st];
-          a1 -= G[i2 * ld + k2 + 1] * X[(k2 + 1) * st];
-          a2 -= G[i2 * ld + k2 + 2] * X[(k2 + 2) * st];
-          a3 -= G[i2 * ld + k2 + 3] * X[(k2 + 3) * st];
+      double y[B];
+#pragma unroll
+      for (int i2 = 0; i2 < B; ++i2) y[i2] = X[i2 * st];
+#pragma unroll
+      for (int i2 = 0; i2 < B; ++i2) {
+        double a0 = y[i2], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < i2; ++k2) {
+          const double lv = G[i2 * ld + k2];                  // same address in every lane: one LDS broadcast
+          if ((k2 & 3) == 0) a0 -= lv * y[k2];
+          else if ((k2 & 3) == 1) a1 -= lv * y[k2];
+          else if ((k2 & 3) == 2) a2 -= lv * y[k2];
+          else a3 -= lv * y[k2];
         }
-        for (; k2 < i2; ++k2) a0 -= G[i2 * ld + k2] * X[k2 * st];
-        X[i2 * st] = ((a0 + a1) + (a2 + a3)) * dinv[i2];
+        y[i2] = ((a0 + a1) + (a2 + a3)) * dinv[i2];
       }
+#pragma unroll
+      for (int i2 = 0; i2 < B; ++i2) X[i2 * st] = y[i2];
     }
   }
   __syncthreads();
 
   // ---- neighbour updates: 3x3 register tiles of P^T P, Q^T Q, P^T Q; P^T g, Q^T g
   {
-    const int T = B / 3, TT = T * T;
+    constexpr int T = B / 3, TT = T * T;
     for (int task = tid; task < 3 * TT; task += kBcrThreads) {
       const int which = task / TT, t2 = task - which * TT;
       if ((which == 0 && !haveL) || (which == 1 && !haveR) || (which == 2 && !(haveL && haveR))) continue;
@@ -156,6 +246,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int B, int
       const double* A = which == 1 ? Ql : Pl;
       const double* Bm = which == 0 ? Pl : Ql;
       double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 6
       for (int k = 0; k < B; ++k) {
         const double a0 = A[k * ld + i0], a1 = A[k * ld + i0 + 1], a2 = A[k * ld + i0 + 2];
         const double b0 = Bm[k * ld + j0], b1 = Bm[k * ld + j0 + 1], b2 = Bm[k * ld + j0 + 2];

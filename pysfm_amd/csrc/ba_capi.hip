@@ -206,6 +206,30 @@ int ensure_reduced(ba_handle* h) {
   return BA_OK;
 }
 
+template <int HB>
+hipError_t launch_bcr_eliminate_hb(int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
+                                   double* P, double* Q, double* G, int* info) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_bcr_eliminate<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_bcr_eliminate<HB>, dim3(cnt), dim3(kBcrThreads), lds, st, N, s, D, U, f, P, Q, G, info);
+  return hipSuccess;
+}
+
+hipError_t launch_bcr_eliminate(int hb, int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
+                                double* P, double* Q, double* G, int* info) {
+#define BA_HB_CASE(K) case K: return launch_bcr_eliminate_hb<K>(cnt, lds, st, N, s, D, U, f, P, Q, G, info);
+  switch (hb) {
+    BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
+    BA_HB_CASE(9) BA_HB_CASE(10)
+    default: return hipErrorInvalidValue;
+  }
+#undef BA_HB_CASE
+}
+
 // Block cyclic reduction over super-blocks of hb cameras (ba_bcr.h): log2(N) levels, one
 // workgroup per eliminated node.  Leaves the solution in h->dC and the status in flags[1].
 int solve_bcr(ba_handle* h, const unsigned char* dmask) {
@@ -216,7 +240,6 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->bcrF.resize((size_t)N * B)); HIPCHECK(h, h->bcrX.resize((size_t)N * B));
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcr_eliminate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcr_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -227,8 +250,8 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) {
     const int cnt = (N / s + 1) / 2;
-    hipLaunchKernelGGL(k_bcr_eliminate, dim3(cnt), dim3(kBcrThreads), lds, h->stream, N, B, s, h->bcrD.p, h->bcrU.p,
-                       h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->flags.p + 1);
+    HIPCHECK(h, launch_bcr_eliminate(hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
+                                     h->bcrG.p, h->flags.p + 1));
     strides.push_back(s);
   }
   const size_t lds2 = ((size_t)B * (B + 1) + 2 * B + 8) * sizeof(double);
