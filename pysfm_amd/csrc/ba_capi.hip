@@ -64,6 +64,9 @@ struct ba_handle {
   int nunits = 0;
   DevBuf<SchurChunk> chunks;
   int nchunks = 0, schur_wn = 0;
+  DevBuf<SchurGroup> groups;
+  DevBuf<SchurChunk> gchunks;
+  int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
   DevBuf<int> cam_perm;
   DevBuf<CamUnit> cam_units;
   int ncam_units = 0;
@@ -317,7 +320,7 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->gchunks.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
@@ -445,6 +448,46 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     }
     if (!units.empty()) chunks.push_back({begin, (int)units.size(), lo == INT32_MAX ? 0 : lo});
   }
+  // Groups for k_schur_groups: runs of consecutive points with identical observation lists
+  // (all tracks must have at most kGroupMaxL observations), cut at kGroupMaxPts points,
+  // chunked kGroupChunk at a time under the same LDS-window rule as above.
+  std::vector<SchurGroup> groups;
+  std::vector<SchurChunk> gchunks;
+  int group_rounds = 0;
+  if (maxL >= 1 && maxL <= kGroupMaxL && wn > 0) {
+    std::vector<int> glo, ghi;
+    for (int k = 0; k < nt;) {
+      const int L = off[(size_t)k + 1] - off[k];
+      if (L == 0) { ++k; continue; }
+      int e = k + 1;
+      while (e < nt && e - k < kGroupMaxPts && off[(size_t)e + 1] - off[e] == L &&
+             std::equal(obs_cam + off[k], obs_cam + off[k] + L, obs_cam + off[e]))
+        ++e;
+      int lo = INT32_MAX, hi = -1;
+      for (int n = off[k]; n < off[k] + L; ++n) {
+        const int p = cam_opt_pos[obs_cam[n]];
+        if (p >= 0) { lo = std::min(lo, p); hi = std::max(hi, p); }
+      }
+      groups.push_back({k, e, L, 0});
+      glo.push_back(lo); ghi.push_back(hi);
+      k = e;
+    }
+    int begin = 0, lo = INT32_MAX, hi = -1;
+    for (int g = 0; g < (int)groups.size(); ++g) {
+      const int nlo = std::min(lo, glo[g]), nhi = std::max(hi, ghi[g]);
+      const bool fits = nhi < 0 || nhi - nlo + 1 <= wn;
+      if (g > begin && (!fits || g - begin >= kGroupChunk)) {
+        gchunks.push_back({begin, g, lo == INT32_MAX ? 0 : lo});
+        begin = g; lo = glo[g]; hi = ghi[g];
+      } else {
+        lo = nlo; hi = nhi;
+      }
+    }
+    if (!groups.empty()) gchunks.push_back({begin, (int)groups.size(), lo == INT32_MAX ? 0 : lo});
+    // worth it only when points really share camera lists
+    const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
+    if (mean_group >= 2.0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
+  }
   // lanes per point: smallest power of two >= mean track length, in [1, 64]
   int glog = 0;
   const double meanL = nt > 0 ? (double)nobs / nt : 1.0;
@@ -457,6 +500,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->nunits = (int)units.size();
   h->nchunks = (int)chunks.size();
   h->schur_wn = wn;
+  h->ngchunks = (int)gchunks.size();
+  h->group_rounds = group_rounds;
   h->ncam_units = (int)cam_units.size();
 
   HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, nobs)));
@@ -469,6 +514,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->chunks.resize(std::max<size_t>(1, chunks.size())));
   if (!chunks.empty())
     HIPCHECK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, h->groups.resize(std::max<size_t>(1, groups.size())));
+  HIPCHECK(h, h->gchunks.resize(std::max<size_t>(1, gchunks.size())));
+  if (!groups.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->groups.p, groups.data(), groups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  }
   HIPCHECK(h, h->cam_perm.resize(std::max<size_t>(1, perm.size())));
   HIPCHECK(h, h->cam_units.resize(std::max<size_t>(1, cam_units.size())));
   if (!perm.empty())
@@ -741,7 +792,29 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
       hipLaunchKernelGGL(k_schur_init, dim3(blocks_for((long long)h->nc * 36)), dim3(kBlock), 0, h->stream, h->nc,
                          h->hb + 1, h->cam_opt_pos.p, h->HCC.p, h->bC.p, damping, h->S, h->b);
   }
-  if (h->nchunks > 0) {
+  const char* force_schur = getenv("BA_SCHUR");          // "pairs" / "groups": pick the reduction kernel (tests)
+  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
+  const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
+  const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
+  if (use_groups) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    const int NW = kGroupBlock / kWave;
+    const size_t lds = (size_t)NW * 64 * 24 * sizeof(double) + (size_t)NW * 16 * sizeof(int) +
+                       (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
+    static bool attr_g = false;
+    if (!attr_g) {
+      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_g = true;
+    }
+    const int maxpairs_rounds = h->group_rounds >= 1 ? h->group_rounds : 2;
+    if (maxpairs_rounds == 1)
+      hipLaunchKernelGGL(k_schur_groups<1>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+    else
+      hipLaunchKernelGGL(k_schur_groups<2>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+  } else if (h->nchunks > 0) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kSchurBlock / kWave;
     const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int) +

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_init(int nc, int hb1, const in
 // --------------------------------------------------------------------------
 struct SchurUnit { int pt; int row0; int col0; };
 struct SchurChunk { int begin; int end; int p0; };     // units [begin, end), window start p0
-constexpr int kSchurChunkUnits = 256;                  // at most this many units per workgroup
+constexpr int kSchurChunkUnits = 64;                  // at most this many units per workgroup
 constexpr int kSchurTileBytes = 48 * 1024;             // LDS budget of the accumulation tile
 
 constexpr int kSchurBlock = 1024;                      // 16 wavefronts share one accumulation tile
@@ -563,6 +563,165 @@ __global__ __launch_bounds__(kSchurBlock) void k_schur_pairs(DevProblem P, const
     if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
   }
   for (int i = threadIdx.x; i < wn * 6; i += kSchurBlock) {
+    const double v = tb[i];
+    if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
+  }
+}
+
+// --------------------------------------------------------------------------
+// The same reduction for scenes whose consecutive points share their camera list (image
+// sequences: ~100 points per camera step at config 3).  A GROUP = up to kGroupMaxPts
+// consecutive points with identical observation lists; one wavefront owns a group:
+//   * lane p owns the pair (i, j) of the list (R rounds when there are more than 64 pairs)
+//     and keeps the whole 6x6 block  sum_k W_ik HPPinv_k W_jk^T  in 36 registers while it
+//     walks the group's points - ONE accumulation into S per block per group instead of
+//     one per point, and 36 LDS values feed 162 FMAs;
+//   * the points are linearised 64/L at a time so that all lanes work in phase A.
+// Accumulation target and window logic as in k_schur_pairs.  Requires track length <= 15.
+// --------------------------------------------------------------------------
+struct SchurGroup { int pt_begin; int pt_end; int L; int pad; };
+constexpr int kGroupBlock = 512;                       // 8 wavefronts per workgroup
+constexpr int kGroupMaxPts = 24;
+constexpr int kGroupMaxL = 15;
+constexpr int kGroupChunk = 8;                         // groups per workgroup
+
+template <int R>
+__global__ __launch_bounds__(kGroupBlock) void k_schur_groups(DevProblem P, const double* __restrict__ cams,
+                                                              const double* __restrict__ X,
+                                                              const SchurGroup* __restrict__ groups,
+                                                              const SchurChunk* __restrict__ chunks, int wn,
+                                                              const double* __restrict__ HPPinv,
+                                                              const double* __restrict__ bP,
+                                                              double* __restrict__ S, double* __restrict__ b) {
+  constexpr int NW = kGroupBlock / kWave;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* sW = dyn;                                   // [NW][64][18]  W of the staged observations
+  double* sA = sW + NW * 64 * 18;                     // [NW][64][6]   HPPinv of the staged points
+  int* sPos = reinterpret_cast<int*>(sA + NW * 64 * 6);   // [NW][16]  optimised positions of the group's cameras
+  double* tile = reinterpret_cast<double*>(sPos + NW * 16);
+  const int hb1 = P.hb + 1;
+  const int rowlen = hb1 * 36;
+  double* tb = tile + (size_t)wn * rowlen;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const SchurChunk ck = chunks[blockIdx.x];
+  const int p0 = ck.p0;
+  for (int i = threadIdx.x; i < wn * (rowlen + 6); i += kGroupBlock) tile[i] = 0.0;
+  double* mW = sW + wv * 64 * 18;
+  double* mA = sA + wv * 64 * 6;
+  int* mPos = sPos + wv * 16;
+  __syncthreads();
+
+  for (int g = ck.begin + wv; g < ck.end; g += NW) {       // wave-uniform
+    const SchurGroup gr = groups[g];
+    const int L = gr.L;
+    const int NP = 64 / L;
+    const int npairs = L * (L + 1) / 2;
+    if (lane < L) mPos[lane] = P.cam_opt_pos[P.obs_cam[P.pt_off[gr.pt_begin] + lane]];
+    lds_wave_sync();
+    int pi_[R], pj_[R], oi_[R], oj_[R];
+    bool act[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int pr = lane + 64 * r;
+      int i = 0, j = 0;
+      if (pr < npairs) tri_decode(pr, L, i, j);
+      oi_[r] = i; oj_[r] = j;
+      pi_[r] = mPos[i]; pj_[r] = mPos[j];
+      act[r] = pr < npairs && pi_[r] >= 0 && pj_[r] >= 0;
+    }
+    double acc[R][36];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 36; ++e) acc[r][e] = 0.0;
+    double bacc[6] = {0, 0, 0, 0, 0, 0};
+    const int slot = lane / L, oi = lane - slot * L;          // phase A role: (staged point, observation)
+    const int mypos = lane < NP * L ? mPos[oi] : -1;
+
+    for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+      const int np = min(NP, gr.pt_end - kb);
+      // ---- phase A: up to 64/L points at once, one observation per lane
+      if (slot < np && lane < NP * L) {
+        const int k = kb + slot;
+        const int n = P.pt_off[k] + oi;
+        const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
+        const int c = P.obs_cam[n];
+        const double2 z = P.obs_z[n];
+        double cm[12], e[2], r[2], Jc[12], Jp[6], W[18];
+        load_cam(cams, c, cm);
+        obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+        block_W(Jc, Jp, W);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) mW[lane * 18 + q] = W[q];
+        double A[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) A[q] = HPPinv[6 * (size_t)k + q];
+        if (oi == 0) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) mA[slot * 6 + q] = A[q];
+        }
+        if (mypos >= 0) {                                     // b[i] -= T_i bP_k
+          double T[18];
+          block_T(W, A, T);
+          const double g0 = bP[3 * (size_t)k], g1 = bP[3 * (size_t)k + 1], g2 = bP[3 * (size_t)k + 2];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) bacc[a] -= T[a * 3] * g0 + T[a * 3 + 1] * g1 + T[a * 3 + 2] * g2;
+        }
+      }
+      lds_wave_sync();
+      // ---- phase B: every lane adds W_i A W_j^T of each staged point to its 6x6 block
+      for (int sl = 0; sl < np; ++sl) {
+        double A[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) A[q] = mA[sl * 6 + q];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!act[r]) continue;
+          double Wi[18], Wj[18], T[18];
+          const double* wi = mW + (sl * L + oi_[r]) * 18;
+          const double* wj = mW + (sl * L + oj_[r]) * 18;
+#pragma unroll
+          for (int q = 0; q < 18; ++q) { Wi[q] = wi[q]; Wj[q] = wj[q]; }
+          block_T(Wi, A, T);
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+              acc[r][a * 6 + c] += T[a * 3] * Wj[c * 3] + T[a * 3 + 1] * Wj[c * 3 + 1] + T[a * 3 + 2] * Wj[c * 3 + 2];
+        }
+      }
+      lds_wave_sync();
+    }
+    // ---- one accumulation per block per group (upper block triangle; transpose when pi > pj)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!act[r]) continue;
+      const int pi = pi_[r], pj = pj_[r];
+      const bool up = pi <= pj;
+      const int lo = up ? pi : pj, dd = up ? pj - pi : pi - pj;
+      const int wr = lo - p0;
+      double* dst = (wr >= 0 && wr < wn) ? tile + (size_t)wr * rowlen + dd * 36 : S + ((size_t)lo * hb1 + dd) * 36;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomic_add_f64(dst + (up ? a * 6 + c : c * 6 + a), -acc[r][a * 6 + c]);
+    }
+    if (mypos >= 0) {
+      const int wr = mypos - p0;
+      double* dst = (wr >= 0 && wr < wn) ? tb + wr * 6 : b + (size_t)mypos * 6;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) atomic_add_f64(dst + a, bacc[a]);
+    }
+    lds_wave_sync();                                        // mPos is rewritten by the next group
+  }
+  if (wn == 0) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < wn * rowlen; i += kGroupBlock) {
+    const double v = tile[i];
+    const int wr = i / rowlen;
+    if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
+  }
+  for (int i = threadIdx.x; i < wn * 6; i += kGroupBlock) {
     const double v = tb[i];
     if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
   }

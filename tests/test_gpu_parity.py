@@ -504,6 +504,36 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, monkeypatch, nc, L):
     monkeypatch.delenv('BA_SOLVER')
 
 
+@pytest.mark.parametrize('nc,L,sensor', [(40, 10, O.Sensor.cauchy(.05)), (30, 4, O.Sensor.gaussian(1.)),
+                                         (26, 13, O.Sensor.huber(.06)), (60, 7, O.Sensor.gaussian(1.))])
+def test_group_reduction_kernel_equals_pair_kernel(be, monkeypatch, nc, L, sensor):
+    """k_schur_groups (register accumulation over runs of points with identical camera
+    lists; 1 and 2 pair rounds) against k_schur_pairs and the oracle, also with groups
+    broken up by dropped observations and frozen cameras in the middle of the sequence."""
+    s = banded(nc, 40 * nc, track_len=L, outlier_frac=.05)
+    keep = np.ones(len(s['obs_cam']), bool)
+    keep[::97] = False                                   # ragged tracks: many size-1 groups
+    cam, pt, z = s['obs_cam'][keep], s['obs_pt'][keep], s['obs_z'][keep]
+    cam_opt_pos = np.arange(nc, dtype=np.int32) - 1
+    cam_opt_pos[nc // 2] = -1                            # a frozen camera inside the window
+    cam_opt_pos[nc // 2 + 1:] -= 1
+    pt_opt = np.ones(40 * nc, np.uint8)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
+    load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
+    out = {}
+    for kern in ('pairs', 'groups'):
+        monkeypatch.setenv('BA_SCHUR', kern)
+        be.linearize(0)
+        be.schur(0, 3., 1e-5)
+        out[kern] = be.get_reduced()
+    monkeypatch.delenv('BA_SCHUR')
+    close(out['groups'][0], out['pairs'][0], 1e-12)
+    close(out['groups'][1], out['pairs'][1], 1e-12)
+    mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=3., return_parts=True)
+    close(out['groups'][0], parts['S'], TIGHT)
+    close(out['groups'][1], parts['b'], TIGHT)
+
+
 def test_wide_band_takes_dense_path(be):
     g = load_golden('scene_oleg_40x100')
     load_problem(be, *scene(g), g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
