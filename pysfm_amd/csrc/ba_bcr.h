@@ -21,9 +21,18 @@
 
 #include "ba_kernels.h"
 
+// Build with -DBA_BCR_PROFILE (make PROFILE=1) to have node 2 of the first level write
+// its per-phase shader-cycle counts to info[8..12] (printed under BA_SOLVE_TRACE=1).
+#ifdef BA_BCR_PROFILE
+#define BA_STAMP(var) const long long var = clock64()
+#else
+#define BA_STAMP(var)
+#endif
+
 namespace ba {
 
-constexpr int kBcrThreads = 256;
+constexpr int kBcrThreads = 256;                 // assemble
+constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
 constexpr int kBcrMaxHB = 10;                  // 4 matrices of B x (B+1) doubles must fit in LDS
 
 __host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8) * sizeof(double); }
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
 // v_readlane broadcasts, and a forward substitution that keeps a whole solution column in
 // registers (one thread per right-hand side, L read from LDS as broadcasts).
 template <int HB>
-__global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, double* __restrict__ Dm,
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s, double* __restrict__ Dm,
                                                                double* __restrict__ Um, double* __restrict__ fm,
                                                                double* __restrict__ Pm, double* __restrict__ Qm,
                                                                double* __restrict__ Gi, int* __restrict__ info) {
@@ -96,17 +105,36 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, dou
   const bool haveL = l >= 0, haveR = r < N;
   constexpr size_t BB = (size_t)B * B;
 
+  BA_STAMP(t0);
   if (tid == 0) *bad = 0;
-  for (int e = tid; e < B * B; e += kBcrThreads) {
-    const int rr = e / B, cc = e - rr * B;
-    G[rr * ld + cc] = Dm[(size_t)i * BB + e];
-    Pl[cc * ld + rr] = haveL ? Um[(size_t)l * BB + e] : 0.0;     // T[i,l] = T[l,i]^T
-    Ql[rr * ld + cc] = haveR ? Um[(size_t)i * BB + e] : 0.0;     // T[i,r]
-    Xi[rr * ld + cc] = rr == cc ? 1.0 : 0.0;
+  {
+    // all global loads of a thread are issued before the first LDS store (one round trip)
+    constexpr int NIT = (B * B + kBcrElimThreads - 1) / kBcrElimThreads;
+    double vd[NIT], vp[NIT], vq[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * kBcrElimThreads;
+      const bool ok = e < B * B;
+      vd[it] = ok ? Dm[(size_t)i * BB + e] : 0.0;
+      vp[it] = (ok && haveL) ? Um[(size_t)l * BB + e] : 0.0;
+      vq[it] = (ok && haveR) ? Um[(size_t)i * BB + e] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * kBcrElimThreads;
+      if (e < B * B) {
+        const int rr = e / B, cc = e - rr * B;
+        G[rr * ld + cc] = vd[it];
+        Pl[cc * ld + rr] = vp[it];                                // T[i,l] = T[l,i]^T
+        Ql[rr * ld + cc] = vq[it];                                // T[i,r]
+        Xi[rr * ld + cc] = rr == cc ? 1.0 : 0.0;
+      }
+    }
   }
-  for (int e = tid; e < B; e += kBcrThreads) g[e] = fm[(size_t)i * B + e];
+  for (int e = tid; e < B; e += kBcrElimThreads) g[e] = fm[(size_t)i * B + e];
   __syncthreads();
 
+  BA_STAMP(t1);
   // ---- blocked Cholesky D_i = L L^T (lower, in place), block size 6
   for (int kb = 0; kb < HB; ++kb) {
     const int k0 = 6 * kb;
@@ -151,7 +179,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, dou
 #pragma unroll
         for (int p = 0; p < q; ++p) Lk[idx++] = G[(k0 + q) * ld + k0 + p];
       }
-      for (int i2 = k0 + 6 + tid; i2 < B; i2 += kBcrThreads) {
+      for (int i2 = k0 + 6 + tid; i2 < B; i2 += kBcrElimThreads) {
         double x[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) x[q] = G[i2 * ld + k0 + q];
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, dou
     {
       const int n3 = (B - k0 - 6) / 3;                       // tiles per side
       const int ntile = n3 * (n3 + 1) / 2;
-      for (int t = tid; t < ntile; t += kBcrThreads) {
+      for (int t = tid; t < ntile; t += kBcrElimThreads) {
         int ti, tj;
         tri_decode(t, n3, tj, ti);                           // tj <= ti
         const int i0 = k0 + 6 + 3 * ti, j0 = k0 + 6 + 3 * tj;
@@ -207,42 +235,68 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, dou
     return;
   }
 
-  // ---- forward substitution L Y = R, one thread per right-hand-side column, the column kept
-  //      in registers: P (B columns), Q (B columns), G^-1 (B columns), g (1 column)
+  BA_STAMP(t2);
+  // ---- forward substitution L Y = R for 3B+1 right-hand sides: P (B columns), Q (B), G^-1
+  //      (B), g (1).  FOUR lanes per column: lane q of the quad owns the entries k = q mod 4
+  //      of the solution (registers) and the matching quarter of every dot product; the
+  //      four partial sums meet through DPP (no LDS traffic on the dependent chain).
   {
     constexpr int ncol = 3 * B + 1;
-    for (int c = tid; c < ncol; c += kBcrThreads) {
+    constexpr int NQ = (B + 3) / 4;
+    for (int task = tid; task < ncol * 4; task += kBcrElimThreads) {
+      const int c = task >> 2, q4 = task & 3;
       double* X = c < B ? Pl + c : c < 2 * B ? Ql + (c - B) : c < 3 * B ? Xi + (c - 2 * B) : g;
       const int st = c < 3 * B ? ld : 1;
-      double y[B];
+      double y[NQ];                                         // y[m] = solution entry 4m + q4
+      // software pipeline: the quarter-row of L, the right-hand side and 1/diag of row i2+1
+      // are fetched from LDS while row i2 runs its dependent chain (FMA -> DPP -> scale)
+      double gn[NQ], xn = X[0], dn = dinv[0];
 #pragma unroll
-      for (int i2 = 0; i2 < B; ++i2) y[i2] = X[i2 * st];
+      for (int m = 0; m < NQ; ++m) gn[m] = 0.0;
 #pragma unroll
       for (int i2 = 0; i2 < B; ++i2) {
-        double a0 = y[i2], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        double gc[NQ];
 #pragma unroll
-        for (int k2 = 0; k2 < i2; ++k2) {
-          const double lv = G[i2 * ld + k2];                  // same address in every lane: one LDS broadcast
-          if ((k2 & 3) == 0) a0 -= lv * y[k2];
-          else if ((k2 & 3) == 1) a1 -= lv * y[k2];
-          else if ((k2 & 3) == 2) a2 -= lv * y[k2];
-          else a3 -= lv * y[k2];
+        for (int m = 0; m < NQ; ++m) gc[m] = gn[m];
+        const double xc = xn, dc = dn;
+        if (i2 + 1 < B) {
+#pragma unroll
+          for (int m = 0; 4 * m < i2 + 1; ++m) {
+            const int k2 = 4 * m + q4;
+            gn[m] = k2 < i2 + 1 ? G[(i2 + 1) * ld + k2] : 0.0;
+          }
+          xn = X[(i2 + 1) * st];
+          dn = dinv[i2 + 1];
         }
-        y[i2] = ((a0 + a1) + (a2 + a3)) * dinv[i2];
-      }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;       // independent chains: fp64 FMA latency is 16 cycles
 #pragma unroll
-      for (int i2 = 0; i2 < B; ++i2) X[i2 * st] = y[i2];
+        for (int m = 0; 4 * m < i2; ++m) {                  // my quarter: k2 = 4m + q4 < i2 (gc is 0 beyond)
+          const double t = gc[m] * y[m];
+          if ((m & 3) == 0) a0 -= t;
+          else if ((m & 3) == 1) a1 -= t;
+          else if ((m & 3) == 2) a2 -= t;
+          else a3 -= t;
+        }
+        double acc = (a0 + a1) + (a2 + a3);
+        acc += dpp_pair<0xB1>(acc);
+        acc += dpp_pair<0x4E>(acc);
+        const double yi = (xc + acc) * dc;
+        if ((i2 & 3) == q4) y[i2 >> 2] = yi;
+        if (q4 == 0) X[i2 * st] = yi;                       // rows are final in order: no one reads X[i2] again
+      }
     }
   }
   __syncthreads();
 
+  BA_STAMP(t3);
   // ---- neighbour updates: 3x3 register tiles of P^T P, Q^T Q, P^T Q; P^T g, Q^T g
   {
     constexpr int T = B / 3, TT = T * T;
-    for (int task = tid; task < 3 * TT; task += kBcrThreads) {
+    for (int task = tid; task < 3 * TT; task += kBcrElimThreads) {
       const int which = task / TT, t2 = task - which * TT;
       if ((which == 0 && !haveL) || (which == 1 && !haveR) || (which == 2 && !(haveL && haveR))) continue;
       const int i0 = 3 * (t2 / T), j0 = 3 * (t2 % T);
+      if (which < 2 && j0 > i0) continue;                   // D is only ever read in its lower triangle
       const double* A = which == 1 ? Ql : Pl;
       const double* Bm = which == 0 ? Pl : Ql;
       double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -265,7 +319,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, dou
         }
       }
     }
-    for (int c = tid; c < 2 * B; c += kBcrThreads) {
+    for (int c = tid; c < 2 * B; c += kBcrElimThreads) {
       const bool left = c < B;
       if ((left && !haveL) || (!left && !haveR)) continue;
       const double* A = left ? Pl + c : Ql + (c - B);
@@ -274,55 +328,76 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_eliminate(int N, int s, dou
       atomic_add_f64(fm + (size_t)(left ? l : r) * B + (left ? c : c - B), -acc);
     }
   }
+  BA_STAMP(t4);
   // ---- keep what the back-substitution needs
-  for (int e = tid; e < B * B; e += kBcrThreads) {
+  for (int e = tid; e < B * B; e += kBcrElimThreads) {
     const int rr = e / B, cc = e - rr * B;
     Pm[(size_t)i * BB + e] = Pl[rr * ld + cc];
     Qm[(size_t)i * BB + e] = Ql[rr * ld + cc];
     Gi[(size_t)i * BB + e] = cc <= rr ? Xi[rr * ld + cc] : 0.0;
   }
   __syncthreads();                       // the products above read g; only now overwrite fm[i]
-  for (int e = tid; e < B; e += kBcrThreads) fm[(size_t)i * B + e] = g[e];
+  for (int e = tid; e < B; e += kBcrElimThreads) fm[(size_t)i * B + e] = g[e];
+#ifdef BA_BCR_PROFILE
+  if (tid == 0 && blockIdx.x == 1 && s == 1) {
+    const long long t5 = clock64();
+    int* o = info + 8;
+    o[0] = (int)(t1 - t0); o[1] = (int)(t2 - t1); o[2] = (int)(t3 - t2); o[3] = (int)(t4 - t3); o[4] = (int)(t5 - t4);
+  }
+#endif
 }
 
 // One back-substitution level: x_i = G^-T (g - P x_l - Q x_r) for the nodes of that level.
-__global__ __launch_bounds__(kBcrThreads) void k_bcr_backsolve(int N, int B, int s, const double* __restrict__ fm,
-                                                               const double* __restrict__ Pm,
-                                                               const double* __restrict__ Qm,
-                                                               const double* __restrict__ Gi,
-                                                               double* __restrict__ x) {
+// P, Q and G^-1 are staged into LDS in one round trip; the two matrix-vector products use
+// four lanes per row, the last one four lanes per column.
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve(int N, int B, int s, const double* __restrict__ fm,
+                                                                   const double* __restrict__ Pm,
+                                                                   const double* __restrict__ Qm,
+                                                                   const double* __restrict__ Gi,
+                                                                   double* __restrict__ x) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int ld = B + 1;
-  double* M = sm;                        // [B][ld] staging of P, Q, then G^-1
-  double* w = M + (size_t)B * ld;        // [B]
-  double* xn = w + B;                    // [B] neighbour solution
+  double* MP = sm;                       // [B][ld] P
+  double* MQ = MP + (size_t)B * ld;      // [B][ld] Q
+  double* MG = MQ + (size_t)B * ld;      // [B][ld] G^-1
+  double* w = MG + (size_t)B * ld;       // [B]
+  double* xl = w + B;                    // [B]
+  double* xr = xl + B;                   // [B]
   const int tid = threadIdx.x;
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N) return;
   const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
   const size_t BB = (size_t)B * B;
-  for (int e = tid; e < B; e += kBcrThreads) w[e] = fm[(size_t)i * B + e];
-  for (int side = 0; side < 2; ++side) {
-    const int nb = side == 0 ? l : r;
-    if (nb < 0 || nb >= N) continue;                 // uniform
-    const double* src = (side == 0 ? Pm : Qm) + (size_t)i * BB;
-    __syncthreads();
-    for (int e = tid; e < B * B; e += kBcrThreads) M[(e / B) * ld + e % B] = src[e];
-    for (int e = tid; e < B; e += kBcrThreads) xn[e] = x[(size_t)nb * B + e];
-    __syncthreads();
-    for (int k = tid; k < B; k += kBcrThreads) {
-      double acc = 0.0;
-      for (int c = 0; c < B; ++c) acc += M[k * ld + c] * xn[c];
-      w[k] -= acc;
-    }
+  for (int e = tid; e < B * B; e += kBcrElimThreads) {
+    const int rr = e / B, cc = e - rr * B;
+    const double vp = haveL ? Pm[(size_t)i * BB + e] : 0.0;
+    const double vq = haveR ? Qm[(size_t)i * BB + e] : 0.0;
+    const double vg = Gi[(size_t)i * BB + e];
+    MP[rr * ld + cc] = vp; MQ[rr * ld + cc] = vq; MG[rr * ld + cc] = vg;
+  }
+  for (int e = tid; e < B; e += kBcrElimThreads) {
+    w[e] = fm[(size_t)i * B + e];
+    xl[e] = haveL ? x[(size_t)l * B + e] : 0.0;
+    xr[e] = haveR ? x[(size_t)r * B + e] : 0.0;
   }
   __syncthreads();
-  for (int e = tid; e < B * B; e += kBcrThreads) M[(e / B) * ld + e % B] = Gi[(size_t)i * BB + e];
-  __syncthreads();
-  for (int m = tid; m < B; m += kBcrThreads) {       // x = (G^-1)^T w : column m of the lower-triangular G^-1
+  for (int task = tid; task < 4 * B; task += kBcrElimThreads) {      // w -= P xl + Q xr
+    const int k = task >> 2, q4 = task & 3;
     double acc = 0.0;
-    for (int k = m; k < B; ++k) acc += M[k * ld + m] * w[k];
-    x[(size_t)i * B + m] = acc;
+    for (int c = q4; c < B; c += 4) acc += MP[k * ld + c] * xl[c] + MQ[k * ld + c] * xr[c];
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    if (q4 == 0) w[k] -= acc;
+  }
+  __syncthreads();
+  for (int task = tid; task < 4 * B; task += kBcrElimThreads) {      // x = (G^-1)^T w
+    const int m = task >> 2, q4 = task & 3;
+    double acc = 0.0;
+    for (int k = m + q4; k < B; k += 4) acc += MG[k * ld + m] * w[k];
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    if (q4 == 0) x[(size_t)i * B + m] = acc;
   }
 }
 

@@ -218,7 +218,7 @@ hipError_t launch_bcr_eliminate_hb(int cnt, size_t lds, hipStream_t st, int N, i
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_bcr_eliminate<HB>, dim3(cnt), dim3(kBcrThreads), lds, st, N, s, D, U, f, P, Q, G, info);
+  hipLaunchKernelGGL(k_bcr_eliminate<HB>, dim3(cnt), dim3(kBcrElimThreads), lds, st, N, s, D, U, f, P, Q, G, info);
   return hipSuccess;
 }
 
@@ -257,10 +257,10 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
                                      h->bcrG.p, h->flags.p + 1));
     strides.push_back(s);
   }
-  const size_t lds2 = ((size_t)B * (B + 1) + 2 * B + 8) * sizeof(double);
+  const size_t lds2 = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
   for (int q = (int)strides.size() - 1; q >= 0; --q) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
-    hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
+    hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
                        h->bcrQ.p, h->bcrG.p, h->bcrX.p);
   }
   HIPCHECK(h, hipGetLastError());
@@ -553,7 +553,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->dP.resize(std::max<size_t>(1, (size_t)nt * 3)));
   HIPCHECK(h, h->partial.resize(2048));
   HIPCHECK(h, h->scalar.resize(8));
-  HIPCHECK(h, h->flags.resize(8));
+  HIPCHECK(h, h->flags.resize(64));
   // a reduced system bound for another problem size is no longer valid
   h->S = nullptr; h->b = nullptr;
   h->have_problem = true;
@@ -967,10 +967,15 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     if (le != hipSuccess) return h->fail(BA_ERR_HIP, "k_band_solve launch failed: %s", hipGetErrorString(le));
   }
   HIPCHECK(h, hipGetLastError());
-  int inf6[6] = {0, 0, 0, 0, 0, 0};
+  int inf6[24] = {0};
   HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   const int inf = inf6[0];
+#ifdef BA_BCR_PROFILE
+  if (getenv("BA_SOLVE_TRACE") && use_bcr)
+    fprintf(stderr, "[k_bcr_eliminate level 0 node 2] load %d chol %d trsm %d products %d store %d cycles\n", inf6[8], inf6[9],
+            inf6[10], inf6[11], inf6[12]);
+#endif
   if (getenv("BA_SOLVE_TRACE") && !use_bcr)
     fprintf(stderr, "[k_band_solve] nco=%d hb=%d ch=%d lds=%zu B | forward: %d cycles, %d ticks(100MHz) | total: %d cycles, %d ticks\n",
             h->nco, h->hb, ch, lds, inf6[2], inf6[3], inf6[4], inf6[5]);
