@@ -160,6 +160,16 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP);
  * Only optimised cameras / tracks move. */
 int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const double* structure);
 
+/* ---- one Levenberg-Marquardt trial, the inner-loop body of BundleAdjuster.optimize
+ * (bundle_adjuster.py:132-146): compute_update(damping) on the current set, apply it to
+ * the trial set, evaluate the trial cost.  Identical to calling ba_linearize, ba_schur,
+ * ba_solve_reduced, ba_backsubstitute, ba_apply_update, ba_cost in turn, but enqueued as
+ * one batch with a single host synchronisation.  *info as in ba_solve_reduced: when it is
+ * non-zero the trial set is garbage and the caller repeats the step through the dense
+ * solve path.  The accept / reject decision stays with the caller (ba_swap_params). */
+int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* cam_param_mask, double* next_cost,
+                int32_t* info);
+
 /* ---- Bundle.triangulate_all (bundle.py:313-321; triangulate.algebraic_lsq triangulate.py:6-18)
  * Re-initialise every point of parameter set `which` by linear least squares from its
  * observations and the set's cameras (the step before the path: test_bundle.py:175,

@@ -54,6 +54,7 @@ PROTOTYPES = {
     'ba_flatten_reduced': (C.c_int, [_h, _ip, C.c_int32, C.c_void_p, C.c_void_p]),
     'ba_backsubstitute': (C.c_int, [_h, C.c_int, _dp, _dp]),
     'ba_apply_update': (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp]),
+    'ba_lm_trial': (C.c_int, [_h, C.c_double, C.c_double, _bp, _dp, C.POINTER(C.c_int32)]),
     'ba_triangulate': (C.c_int, [_h, C.c_int, C.c_double, _dp]),
     'ba_enable_timing': (C.c_int, [_h, C.c_int]),
     'ba_get_timings': (C.c_int, [_h, _dp, C.POINTER(C.c_int64), C.c_int]),

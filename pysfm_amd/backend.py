@@ -270,6 +270,18 @@ class HipBackend(object):
             assert len(motion) == self.nco and len(structure) == self.nt
         self._check(self._lib.ba_apply_update(self._h, src, dst, capi.dptr(motion), capi.dptr(structure)))
 
+    def lm_trial(self, damping, rcond, cam_param_mask=None):
+        """One LM trial as a single batch of launches with one synchronisation
+        (ba_lm_trial).  Returns (info, next_cost); info != 0 means the device solve did
+        not apply (band too wide / not SPD) and the caller must take the stepwise path."""
+        mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
+        cost, info = C.c_double(), C.c_int32()
+        self._host_dC = None
+        self._check(self._lib.ba_lm_trial(self._h, float(damping), -1.0 if rcond is None else float(rcond),
+                                          capi.bptr(mask), C.byref(cost), C.byref(info)))
+        self.last_solve_path = 'band' if info.value == 0 else 'dense'
+        return info.value, cost.value
+
     def triangulate(self, which, rcond=None, fetch=True):
         """Linear least-squares re-initialisation of every point from the cameras of
         parameter set `which` (Bundle.triangulate_all, bundle.py:320-321)."""

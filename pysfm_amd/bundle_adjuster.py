@@ -235,12 +235,24 @@ class BundleAdjuster(object):
         back-substitute, apply to the trial set, evaluate.  Accepts (swaps the
         parameter sets) iff the cost went down.  Returns (accepted | None, next_cost).'''
         self.lm_trials += 1
-        try:
-            self._compute_update_device(damping, param_mask, fetch=False)
-        except NormalEquationsIllconditioned:
-            return None, None
-        self.backend.apply_update(PARAMS_CUR, PARAMS_TRIAL)     # bnext = clone; update_motion/structure
-        next_cost = self._cost(PARAMS_TRIAL)
+        next_cost = None
+        be = self.backend
+        if self._comm is None and hasattr(be, 'lm_trial'):
+            # single GPU: the whole trial is one batch of launches with one synchronisation
+            cam_param_mask = self._cam_param_mask(param_mask)
+            self._damp_factor = 1. + damping
+            info, cost = be.lm_trial(damping, self.SCHUR_COMPLIMENT_PINV_THRESHOLD,
+                                     None if np.all(cam_param_mask) else cam_param_mask)
+            self._have_blocks = True
+            if info == 0:
+                next_cost = cost
+        if next_cost is None:
+            try:
+                self._compute_update_device(damping, param_mask, fetch=False)
+            except NormalEquationsIllconditioned:
+                return None, None
+            be.apply_update(PARAMS_CUR, PARAMS_TRIAL)            # bnext = clone; update_motion/structure
+            next_cost = self._cost(PARAMS_TRIAL)
         if next_cost < cur_cost:
             self.backend.swap_params()                          # self.bundle = bnext
             self._host_stale = True

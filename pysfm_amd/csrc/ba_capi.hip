@@ -81,6 +81,7 @@ struct ba_handle {
   DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, partial, scalar, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrX;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
+  bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
   DevBuf<int> flags;
   double* S = nullptr;       // nco*nco*36 (own or bound)
   double* b = nullptr;       // nco*6
@@ -647,6 +648,7 @@ int ba_cost(ba_handle* h, int which, double* cost_out) {
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, h->stream, h->partial.p, nb, h->scalar.p);
   }
   HIPCHECK(h, hipGetLastError());
+  if (h->defer) return BA_OK;
   HIPCHECK(h, hipMemcpyAsync(cost_out, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   return BA_OK;
@@ -830,7 +832,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   HIPCHECK(h, hipGetLastError());
   h->have_schur = true;
   h->have_backsub = h->have_solution = false;
-  if (pinv_rcond < 0.0) {   // plain-inverse mode must report singular blocks (numpy.linalg.inv raises)
+  if (pinv_rcond < 0.0 && !h->defer) {   // plain-inverse mode must report singular blocks (numpy.linalg.inv raises)
     int nsing = 0;
     HIPCHECK(h, hipMemcpyAsync(&nsing, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -967,6 +969,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     if (le != hipSuccess) return h->fail(BA_ERR_HIP, "k_band_solve launch failed: %s", hipGetErrorString(le));
   }
   HIPCHECK(h, hipGetLastError());
+  if (h->defer) { *info = 0; h->have_solution = true; return BA_OK; }   // status is read by ba_lm_trial
   int inf6[24] = {0};
   HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -1045,6 +1048,35 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   if (motion) HIPCHECK(h, hipStreamSynchronize(h->stream));
   h->have_params[pd] = true;
   if (dst == BA_PARAMS_CUR) h->have_linearization = h->have_schur = false;
+  return BA_OK;
+}
+
+int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* cam_param_mask, double* next_cost,
+                int32_t* info) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, next_cost && info, BA_ERR_INVALID_ARG, "ba_lm_trial: NULL output");
+  REQUIRE(h, h->have_problem && h->have_params[h->phys(BA_PARAMS_CUR)], BA_ERR_STATE, "ba_lm_trial: set problem and parameters first");
+  *info = 0;
+  h->defer = true;
+  double unused = 0.0;
+  int32_t pre = 0;
+  int rc = ba_linearize(h, BA_PARAMS_CUR, 0);
+  if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
+  if (rc == BA_OK) rc = ba_solve_reduced(h, cam_param_mask, &pre);
+  if (rc == BA_OK && pre != 0) { h->defer = false; *info = pre; return BA_OK; }   // band too wide: caller takes the dense path
+  if (rc == BA_OK) rc = ba_backsubstitute(h, BA_PARAMS_CUR, nullptr, nullptr);
+  if (rc == BA_OK) rc = ba_apply_update(h, BA_PARAMS_CUR, BA_PARAMS_TRIAL, nullptr, nullptr);
+  if (rc == BA_OK) rc = ba_cost(h, BA_PARAMS_TRIAL, &unused);
+  h->defer = false;
+  if (rc != BA_OK) return rc;
+  int st[2] = {0, 0};
+  HIPCHECK(h, hipMemcpyAsync(st, h->flags.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(next_cost, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (pinv_rcond < 0.0 && st[0] > 0)
+    return h->fail(BA_ERR_SINGULAR, "ba_lm_trial: %d singular 3x3 point block(s) in plain-inverse mode", st[0]);
+  *info = st[1];
+  if (st[1] != 0) h->have_solution = h->have_backsub = false;
   return BA_OK;
 }
 
