@@ -56,7 +56,8 @@ typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_se
 /* kernel ids for ba_get_timings */
 enum {
   BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
-  BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_TRIANGULATE, BA_K_COUNT
+  BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_TRIANGULATE,
+  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_COUNT
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -181,6 +182,9 @@ int ba_triangulate(ba_handle* h, int which, double rcond, double* X);
 
 /* ---- instrumentation ---------------------------------------------------- */
 int ba_enable_timing(ba_handle* h, int on);
+/* bracket only the kernel ids whose bit is set (default: all); an event pair costs a few
+ * microseconds of stream time, which matters when kernels are ~10 us long */
+int ba_set_timing_mask(ba_handle* h, uint64_t kernel_id_mask);
 /* accumulated HIP-event time (ms) and launch count per kernel id since the last reset */
 int ba_get_timings(ba_handle* h, double* ms /*[BA_K_COUNT]*/, int64_t* launches /*[BA_K_COUNT]*/, int reset);
 const char* ba_kernel_name(int kernel_id);

@@ -18,7 +18,8 @@ BA_ERR_INVALID_ARG, BA_ERR_NO_DEVICE, BA_ERR_HIP, BA_ERR_STATE, BA_ERR_SINGULAR,
 SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER = 0, 1, 2
 PARAMS_CUR, PARAMS_TRIAL = 0, 1
 KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 'backsub',
-              'update', 'flatten', 'band_solve', 'eval', 'camera_blocks', 'triangulate')
+              'update', 'flatten', 'band_solve', 'eval', 'camera_blocks', 'triangulate',
+              'bcr_assemble', 'bcr_eliminate', 'bcr_backsolve')
 K_COUNT = len(KERNEL_IDS)
 
 _dp = C.POINTER(C.c_double)
@@ -57,6 +58,7 @@ PROTOTYPES = {
     'ba_lm_trial': (C.c_int, [_h, C.c_double, C.c_double, _bp, _dp, C.POINTER(C.c_int32)]),
     'ba_triangulate': (C.c_int, [_h, C.c_int, C.c_double, _dp]),
     'ba_enable_timing': (C.c_int, [_h, C.c_int]),
+    'ba_set_timing_mask': (C.c_int, [_h, C.c_uint64]),
     'ba_get_timings': (C.c_int, [_h, _dp, C.POINTER(C.c_int64), C.c_int]),
     'ba_kernel_name': (C.c_char_p, [C.c_int]),
     'ba_version': (C.c_char_p, []),

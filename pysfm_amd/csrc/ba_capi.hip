@@ -88,6 +88,7 @@ struct ba_handle {
 
   // timing
   bool timing = false;
+  unsigned long long timing_mask = ~0ull;   // which kernel ids are bracketed with events
   std::vector<hipEvent_t> ev_pool;
   std::vector<TimedLaunch> pending;
   double ms[BA_K_COUNT] = {0};
@@ -139,11 +140,12 @@ void resolve_timings(ba_handle* h) {
 
 struct ScopedTimer {
   ba_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;
-  ScopedTimer(ba_handle* h_, int id_) : h(h_), id(id_) {
-    if (h->timing) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+  bool on;
+  ScopedTimer(ba_handle* h_, int id_) : h(h_), id(id_), on(h_->timing && ((h_->timing_mask >> id_) & 1ull)) {
+    if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
   }
   ~ScopedTimer() {
-    if (h->timing) {
+    if (on) {
       (void)hipEventRecord(b, h->stream);
       h->pending.push_back({id, a, b});
       if (h->pending.size() >= 8192) resolve_timings(h);
@@ -248,12 +250,16 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
     attr_set = true;
   }
   HIPCHECK(h, hipMemsetAsync(h->flags.p + 1, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
-                     h->bcrU.p, h->bcrF.p);
+  {
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
+                       h->bcrU.p, h->bcrF.p);
+  }
   const size_t lds = bcr_lds_bytes(B);
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) {
     const int cnt = (N / s + 1) / 2;
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE);
     HIPCHECK(h, launch_bcr_eliminate(hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
                                      h->bcrG.p, h->flags.p + 1));
     strides.push_back(s);
@@ -261,6 +267,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   const size_t lds2 = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
   for (int q = (int)strides.size() - 1; q >= 0; --q) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
+    ScopedTimer tm(h, BA_K_BCR_BACKSOLVE);
     hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
                        h->bcrQ.p, h->bcrG.p, h->bcrX.p);
   }
@@ -278,7 +285,8 @@ const char* ba_version(void) { return "pysfm_ba 0.1 (gfx950)"; }
 const char* ba_kernel_name(int id) {
   static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
                                           "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
-                                          "k_band_solve", "k_eval", "k_camera_blocks", "k_triangulate"};
+                                          "k_band_solve", "k_eval", "k_camera_blocks", "k_triangulate",
+                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve"};
   return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
 }
 
@@ -957,7 +965,6 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const int ch = band_solve_chunk(h->hb, lds_budget);
   size_t lds = 0;
   if (use_bcr) {
-    ScopedTimer tm(h, BA_K_BAND_SOLVE);
     int rc = solve_bcr(h, dmask);
     if (rc != BA_OK) return rc;
   } else {
@@ -1108,6 +1115,12 @@ int ba_enable_timing(ba_handle* h, int on) {
   if (!h) return BA_ERR_INVALID_ARG;
   if (!on) resolve_timings(h);
   h->timing = on != 0;
+  return BA_OK;
+}
+
+int ba_set_timing_mask(ba_handle* h, uint64_t kernel_id_mask) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  h->timing_mask = kernel_id_mask;
   return BA_OK;
 }
 
