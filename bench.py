@@ -77,6 +77,21 @@ def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
     return 0
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/*_hbm_traffic.csv, written by scripts/summarize_profile.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  None if absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.csv')))
+    if not files:
+        return None, None
+    for row in csv.DictReader(open(files[-1])):
+        if row['kernel'].split('<')[0].endswith('k_' + kernel):
+            return int(row[[k for k in row if k.startswith('hbm_bytes')][0]]), os.path.basename(files[-1])
+    return None, None
+
+
 def cpu_baseline(sample_cams, sample_pts):
     """The oracle (NumPy restatement of the reference, 'port') timed on this box's host
     cores on a bounded sample of the same workload: one full LM trial."""
@@ -227,6 +242,7 @@ def main():
         nco = be.nco
         B = algorithmic_bytes(dom, be.nc, nco, be.nt, nobs_local, be.nt, be.half_bandwidth)
         achieved = B / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom)
         out = {
             'metric': 'LM-iter throughput (obs/sec) + final reproj RMSE, 1k-cam/100k-pt/1M-obs scene',
             'value': value, 'unit': 'obs/s', 'n_gpus': ngpus, 'steps': args.steps, 'warmup': args.warmup,
@@ -238,7 +254,8 @@ def main():
                                       '+RCCL all-reduce' if ngpus > 1 else '', args.sensor),
                        'cameras': nc, 'points': nt, 'observations': nobs_total, 'parallelism': 'points sharded x%d' % ngpus},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': B,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': B,
                          'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
                          'note': 'HIP events on the launch stream around every launch of this kernel during the timed steps'},
             'kernel_ms_per_step': {k: v['ms'] / nprof for k, v in ours.items()},
