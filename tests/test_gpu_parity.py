@@ -474,13 +474,14 @@ def test_band_solver_vs_dense_lu(be):
         close(-be.backsubstitute(0), su, SOLVE)
 
 
-@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5)])
+@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11)])
 def test_cyclic_reduction_vs_sequential_band_solver(be, monkeypatch, nc, L):
     """The multi-CU block-cyclic-reduction solve against the single-workgroup band Cholesky and
     the dense LU on the same device-resident system (odd sizes: padded last super-block,
     non-power-of-two level counts), with and without masked parameters."""
-    s = banded(nc, 50 * nc, track_len=L)
-    flags = default_flags(nc, 50 * nc)
+    npt = (50 if nc < 500 else 12) * nc
+    s = banded(nc, npt, track_len=L)
+    flags = default_flags(nc, npt)
     load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
     assert be.half_bandwidth == L - 1
     be.linearize(0)
@@ -488,7 +489,7 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, monkeypatch, nc, L):
     n = (nc - 1) * 6
     for mask in (None, (np.arange(n) % 7 != 3).astype(np.uint8)):
         sol = {}
-        for solver in ('bcr', 'seq'):
+        for solver in ('bcr', 'seq'):                     # hb = 10 (L = 11) is the widest band BCR takes
             monkeypatch.setenv('BA_SOLVER', solver)
             be.solve_reduced(mask)
             assert be.last_solve_path == 'band'
@@ -555,6 +556,39 @@ def test_band_solver_reports_non_positive_pivot(be):
     x = be.get_solution().reshape(-1)
     A = S.transpose(0, 2, 1, 3).reshape(18, 18)
     close(A @ x, b.reshape(-1), 1e-9)
+
+
+def test_lm_trial_entry_equals_stepwise_calls(be):
+    """ba_lm_trial (one batch, one synchronisation) against the same step made of the
+    individual entry points, including the accept / swap bookkeeping."""
+    s = banded(50, 2500, track_len=8, outlier_frac=.05)
+    flags = default_flags(50, 2500)
+    sensor = O.Sensor.cauchy(.05)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, *flags, sensor)
+    mask = np.ones(49 * 6, np.uint8)
+    mask[[3, 40]] = 0
+    for lam, m in ((10., None), (.1, mask)):
+        be.set_params(0, s['R0'], s['t0'], s['X0'])
+        info, c_fused = be.lm_trial(lam, 1e-5, m)
+        assert info == 0
+        Rf, tf, Xf = be.get_params(1)
+        dC_f = be.get_solution()
+        be.set_params(0, s['R0'], s['t0'], s['X0'])
+        dC, dP = hip_update(be, lam, keep=None if m is None else np.nonzero(m)[0])
+        be.apply_update(0, 1)
+        c_step = be.cost(1)
+        Rs, ts, Xs = be.get_params(1)
+        close(dC_f, dC, 1e-12)
+        close(Rf, Rs, 1e-13)
+        close(tf, ts, 1e-13)
+        close(Xf, Xs, 1e-13)
+        assert abs(c_fused - c_step) <= 1e-12 * c_step
+        mu, su = O.compute_update(sensor, *a, *flags, damping=lam, cam_param_mask=None if m is None else m.astype(bool))
+        R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, *flags)
+        close(c_fused, O.cost(sensor, s['K'], R2, t2, X2, *a[4:], *flags), 1e-8)
+    be.swap_params()                                        # accept: the trial set becomes current
+    close(be.get_params(0)[2], Xs, 0.)
 
 
 def test_timing_counters(be):
