@@ -43,9 +43,10 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
                                                               const double* __restrict__ b,
                                                               const unsigned char* __restrict__ mask,
                                                               double* __restrict__ Dm, double* __restrict__ Um,
-                                                              double* __restrict__ fm) {
+                                                              double* __restrict__ fm, int* __restrict__ info) {
   const int B = 6 * hb, hb1 = hb + 1;
   const int I = blockIdx.x;
+  if (I == 0 && threadIdx.x == 0) *info = 0;      // status word of this solve (the eliminate levels only ever set it)
   for (int e = threadIdx.x; e < B * B; e += kBcrThreads) {
     const int r = e / B, c = e - r * B;
     const int i = I * hb + r / 6, j = I * hb + c / 6, a = r % 6, bb = c % 6;

@@ -57,7 +57,7 @@ struct ba_handle {
   int glog = 0;              // lanes per point = 2^glog
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0};
-  DevBuf<int> obs_cam, obs_pt, pt_off, cam_opt_pos, keep;
+  DevBuf<int> obs_cam, obs_pt, pt_off, cam_opt_pos, opt_cam, keep;
   DevBuf<double2> obs_z;
   DevBuf<unsigned char> pt_opt;
   DevBuf<SchurUnit> units;
@@ -78,11 +78,21 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, partial, scalar, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrX;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
-  DevBuf<int> flags;
+  DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
+                            // counters (alternate per ba_schur call)
+  int sing_epoch = 0;       // which of the two counters the latest ba_schur used
+  HostResult* host_result = nullptr;   // pinned, device-visible: cost + status words of a trial
+  int cost_blocks = 0;      // partials the last k_cost launch wrote
+  int* sing_counter() { return flags.p + 40 + (sing_epoch & 1); }
+  double host_cost() const {           // second, deterministic stage of the cost reduction (after a stream sync)
+    double s = 0.0;
+    for (int i = 0; i < cost_blocks; ++i) s += host_result->partial[i];
+    return s;
+  }
   double* S = nullptr;       // nco*nco*36 (own or bound)
   double* b = nullptr;       // nco*6
 
@@ -243,17 +253,16 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   const size_t BB = (size_t)B * B;
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
-  HIPCHECK(h, h->bcrF.resize((size_t)N * B)); HIPCHECK(h, h->bcrX.resize((size_t)N * B));
+  HIPCHECK(h, h->bcrF.resize((size_t)N * B));
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcr_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  HIPCHECK(h, hipMemsetAsync(h->flags.p + 1, 0, sizeof(int), h->stream));
   {
-    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
     hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
-                       h->bcrU.p, h->bcrF.p);
+                       h->bcrU.p, h->bcrF.p, h->flags.p + 1);
   }
   const size_t lds = bcr_lds_bytes(B);
   std::vector<int> strides;
@@ -269,10 +278,9 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
     ScopedTimer tm(h, BA_K_BCR_BACKSOLVE);
     hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
-                       h->bcrQ.p, h->bcrG.p, h->bcrX.p);
+                       h->bcrQ.p, h->bcrG.p, h->dC.p);    // x[N][B] IS dC's layout (padded to whole super-blocks)
   }
   HIPCHECK(h, hipGetLastError());
-  HIPCHECK(h, hipMemcpyAsync(h->dC.p, h->bcrX.p, (size_t)h->nco * 6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return BA_OK;
 }
 
@@ -318,6 +326,12 @@ int ba_create(int device_id, ba_handle** out) {
     return BA_ERR_HIP;
   }
   h->own_stream = true;
+  if ((e = hipHostMalloc((void**)&h->host_result, sizeof(HostResult), hipHostMallocDefault)) != hipSuccess) {
+    g_create_error = std::string("ba_create: hipHostMalloc failed: ") + hipGetErrorString(e);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return BA_ERR_HIP;
+  }
   *out = h;
   return BA_OK;
 }
@@ -328,13 +342,14 @@ int ba_destroy(ba_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-  h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release();
+  h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
   h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->gchunks.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrX.release(); h->mask.release(); h->dP.release();
-  h->partial.release(); h->scalar.release(); h->scratch.release(); h->flags.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->mask.release(); h->dP.release();
+  h->scratch.release(); h->flags.release();
+  if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BA_OK;
@@ -555,14 +570,20 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->HPP.resize(std::max<size_t>(1, (size_t)nt * 6)));
   HIPCHECK(h, h->bP.resize(std::max<size_t>(1, (size_t)nt * 3)));
   HIPCHECK(h, h->HPPinv.resize(std::max<size_t>(1, (size_t)nt * 6)));
-  HIPCHECK(h, h->dC.resize(std::max<size_t>(1, (size_t)nco * 6)));
+  HIPCHECK(h, h->dC.resize(((size_t)nco + 16) * 6));     // padded: the cyclic-reduction solve writes whole super-blocks
   HIPCHECK(h, h->ysol.resize(std::max<size_t>(1, (size_t)nco * 6)));
   HIPCHECK(h, h->dinv.resize(std::max<size_t>(1, (size_t)nco * 6)));
   HIPCHECK(h, h->mask.resize(std::max<size_t>(1, (size_t)nco * 6)));
   HIPCHECK(h, h->dP.resize(std::max<size_t>(1, (size_t)nt * 3)));
-  HIPCHECK(h, h->partial.resize(2048));
-  HIPCHECK(h, h->scalar.resize(8));
   HIPCHECK(h, h->flags.resize(64));
+  HIPCHECK(h, hipMemsetAsync(h->flags.p, 0, 64 * sizeof(int), h->stream));
+  {
+    std::vector<int> opt_cam(std::max(1, nco), 0);
+    for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) opt_cam[cam_opt_pos[i]] = i;
+    HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
+    HIPCHECK(h, hipMemcpyAsync(h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+  }
   // a reduced system bound for another problem size is no longer valid
   h->S = nullptr; h->b = nullptr;
   h->have_problem = true;
@@ -649,16 +670,17 @@ int ba_cost(ba_handle* h, int which, double* cost_out) {
   const int p = h->phys(which);
   REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_cost: set problem and parameters first");
   HIPCHECK(h, hipSetDevice(h->device));
-  const int nb = (int)std::min<long long>(2048, blocks_for(h->nobs));
+  const int nb = (int)std::max<long long>(1, std::min<long long>(kCostBlocks, blocks_for(h->nobs)));
   {
     ScopedTimer tm(h, BA_K_COST);
-    hipLaunchKernelGGL(k_cost, dim3(nb), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p, h->partial.p);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, h->stream, h->partial.p, nb, h->scalar.p);
+    hipLaunchKernelGGL(k_cost, dim3(nb), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
+                       (const int*)h->sing_counter(), (const int*)(h->flags.p + 1), h->host_result);
   }
+  h->cost_blocks = nb;
   HIPCHECK(h, hipGetLastError());
   if (h->defer) return BA_OK;
-  HIPCHECK(h, hipMemcpyAsync(cost_out, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
+  *cost_out = h->host_cost();
   return BA_OK;
 }
 
@@ -727,13 +749,15 @@ int ba_linearize(ba_handle* h, int which, int store_W) {
     HIPCHECK(h, h->W.resize(std::max<size_t>(1, (size_t)h->nobs * 18)));
     Wd = h->W.p;
   }
-  HIPCHECK(h, hipMemsetAsync(h->HCC.p, 0, (size_t)h->nc * 36 * sizeof(double), h->stream));
-  HIPCHECK(h, hipMemsetAsync(h->bC.p, 0, (size_t)h->nc * 6 * sizeof(double), h->stream));
+  if (h->nt == 0) {     // otherwise k_linearize clears them
+    HIPCHECK(h, hipMemsetAsync(h->HCC.p, 0, (size_t)h->nc * 36 * sizeof(double), h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->bC.p, 0, (size_t)h->nc * 6 * sizeof(double), h->stream));
+  }
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_LINEARIZE);
     const long long threads = (long long)h->nt << h->glog;
     hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
-                       h->cams[p].p, h->X[p].p, h->glog, (double*)nullptr, (double*)nullptr, h->HPP.p, h->bP.p, Wd);
+                       h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd);
   }
   if (h->ncam_units > 0) {
     ScopedTimer tm(h, BA_K_CAMERA_BLOCKS);
@@ -788,19 +812,19 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   HIPCHECK(h, hipSetDevice(h->device));
   int rc = ensure_reduced(h);
   if (rc != BA_OK) return rc;
-  HIPCHECK(h, hipMemsetAsync(h->flags.p, 0, sizeof(int), h->stream));
+  h->sing_epoch ^= 1;       // this call counts singular blocks in sing_counter(); the kernel clears the other one
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_POINT_INVERT);
     hipLaunchKernelGGL(k_point_invert, dim3(blocks_for(h->nt)), dim3(kBlock), 0, h->stream, h->nt, h->HPP.p,
-                       damping, pinv_rcond, h->HPPinv.p, h->flags.p);
+                       damping, pinv_rcond, h->HPPinv.p, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+  } else {
+    HIPCHECK(h, hipMemsetAsync(h->flags.p + 40, 0, 2 * sizeof(int), h->stream));
   }
-  {
-    ScopedTimer tm(h, BA_K_SCHUR_INIT);
-    HIPCHECK(h, hipMemsetAsync(h->S, 0, reduced_doubles(h) * sizeof(double), h->stream));
-    HIPCHECK(h, hipMemsetAsync(h->b, 0, (size_t)h->nco * 6 * sizeof(double), h->stream));
-    if (h->nc > 0)
-      hipLaunchKernelGGL(k_schur_init, dim3(blocks_for((long long)h->nc * 36)), dim3(kBlock), 0, h->stream, h->nc,
-                         h->hb + 1, h->cam_opt_pos.p, h->HCC.p, h->bC.p, damping, h->S, h->b);
+  if (h->nco > 0) {
+    ScopedTimer tm(h, BA_K_SCHUR_INIT);       // clears the band and writes the damped diagonal + b in one pass
+    const long long n = (long long)reduced_doubles(h) + (long long)h->nco * 6;
+    hipLaunchKernelGGL(k_schur_init, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, h->opt_cam.p,
+                       h->HCC.p, h->bC.p, damping, h->S, h->b);
   }
   const char* force_schur = getenv("BA_SCHUR");          // "pairs" / "groups": pick the reduction kernel (tests)
   const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
@@ -842,7 +866,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   h->have_backsub = h->have_solution = false;
   if (pinv_rcond < 0.0 && !h->defer) {   // plain-inverse mode must report singular blocks (numpy.linalg.inv raises)
     int nsing = 0;
-    HIPCHECK(h, hipMemcpyAsync(&nsing, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(&nsing, h->sing_counter(), sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     if (nsing > 0) return h->fail(BA_ERR_SINGULAR, "ba_schur: %d singular 3x3 point block(s) in plain-inverse mode", nsing);
   }
@@ -1015,11 +1039,14 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
     HIPCHECK(h, hipMemcpyAsync(h->dC.p, dC, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->have_solution = true;
   }
+  // inside ba_lm_trial the update of the trial parameter set rides along (one launch less)
+  const bool fuse_update = h->defer && which == BA_PARAMS_CUR && h->nt > 0;
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_BACKSUB);
     const long long threads = (long long)h->nt << h->glog;
     hipLaunchKernelGGL(k_backsub, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
-                       h->X[p].p, h->glog, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p);
+                       h->X[p].p, h->glog, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p, -1.0,
+                       fuse_update ? h->cams[1 - p].p : (double*)nullptr, fuse_update ? h->X[1 - p].p : (double*)nullptr);
   }
   HIPCHECK(h, hipGetLastError());
   if (dP && h->nt) HIPCHECK(h, hipMemcpyAsync(dP, h->dP.p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1072,14 +1099,16 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   if (rc == BA_OK) rc = ba_solve_reduced(h, cam_param_mask, &pre);
   if (rc == BA_OK && pre != 0) { h->defer = false; *info = pre; return BA_OK; }   // band too wide: caller takes the dense path
   if (rc == BA_OK) rc = ba_backsubstitute(h, BA_PARAMS_CUR, nullptr, nullptr);
-  if (rc == BA_OK) rc = ba_apply_update(h, BA_PARAMS_CUR, BA_PARAMS_TRIAL, nullptr, nullptr);
+  if (rc == BA_OK) {
+    if (h->nt > 0) h->have_params[h->phys(BA_PARAMS_TRIAL)] = true;      // k_backsub wrote the trial set
+    else rc = ba_apply_update(h, BA_PARAMS_CUR, BA_PARAMS_TRIAL, nullptr, nullptr);
+  }
   if (rc == BA_OK) rc = ba_cost(h, BA_PARAMS_TRIAL, &unused);
   h->defer = false;
   if (rc != BA_OK) return rc;
-  int st[2] = {0, 0};
-  HIPCHECK(h, hipMemcpyAsync(st, h->flags.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(h, hipMemcpyAsync(next_cost, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));      // k_cost's last block left cost + status words in pinned memory
+  const int st[2] = {h->host_result->singular_points, h->host_result->solve_info};
+  *next_cost = h->host_cost();
   if (pinv_rcond < 0.0 && st[0] > 0)
     return h->fail(BA_ERR_SINGULAR, "ba_lm_trial: %d singular 3x3 point block(s) in plain-inverse mode", st[0]);
   *info = st[1];

@@ -138,12 +138,17 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtom
 
 // --------------------------------------------------------------------------
 // compute_cost (bundle_adjuster.py:165-171): one observation per lane,
-// wavefront + block reduction, one partial per block (second stage is
-// deterministic: k_sum_partials).
+// wavefront + block reduction, one partial per block.  The partials go straight into a
+// pinned host record (with the two status words of the trial) and the CPU adds them in
+// index order after synchronising: deterministic, no second launch, no copy kernels.
 // --------------------------------------------------------------------------
+constexpr int kCostBlocks = 2048;
+struct HostResult { int singular_points; int solve_info; double partial[kCostBlocks]; };
+
 __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __restrict__ cams,
                                                  const double* __restrict__ X,
-                                                 double* __restrict__ partial) {
+                                                 const int* __restrict__ singular_points,
+                                                 const int* __restrict__ solve_info, HostResult* __restrict__ host) {
   __shared__ double wsum[kBlock / kWave];
   double acc = 0.0;
   const long long stride = (long long)gridDim.x * kBlock;
@@ -165,23 +170,11 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __r
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) s += wsum[w];
-    partial[blockIdx.x] = s;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_sum_partials(const double* __restrict__ partial, int n,
-                                                         double* __restrict__ out) {
-  __shared__ double wsum[kBlock / kWave];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += kBlock) acc += partial[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < kBlock / kWave; ++w) s += wsum[w];
-    out[0] = s;
+    host->partial[blockIdx.x] = s;
+    if (blockIdx.x == 0) {
+      host->singular_points = *singular_points;
+      host->solve_info = *solve_info;
+    }
   }
 }
 
@@ -244,6 +237,13 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
                                                       double* __restrict__ Wout) {
   const int G = 1 << glog;
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  // HCC / bC are accumulated with atomics by k_camera_blocks, which runs next: clear them here
+  // (saves two memset launches of ~5 us each on the trial's critical path)
+  if (HCC) {
+    const long long nthreads = (long long)gridDim.x * kBlock;
+    for (long long i = tid; i < (long long)P.nc * 36; i += nthreads) HCC[i] = 0.0;
+    for (long long i = tid; i < (long long)P.nc * 6; i += nthreads) bC[i] = 0.0;
+  }
   const long long k = tid >> glog;
   const int l = (int)(tid & (G - 1));
   const bool valid = k < P.nt;
@@ -260,15 +260,6 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     double cm[12], e[2], r[2], Jc[12], Jp[6];
     load_cam(cams, c, cm);
     obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
-    if (HCC) {      // normally done by k_camera_blocks (no atomics); kept for completeness
-      double* hc = HCC + (size_t)c * 36;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int b = a; b < 6; ++b) atomic_add_f64(hc + a * 6 + b, Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
-        atomic_add_f64(bC + (size_t)c * 6 + a, Jc[a] * r[0] + Jc[6 + a] * r[1]);
-      }
-    }
     hpp[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
     hpp[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
     hpp[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
@@ -360,8 +351,10 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevProblem P, const do
 __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* __restrict__ HPP,
                                                          double damping, double rcond,
                                                          double* __restrict__ HPPinv,
-                                                         int* __restrict__ singular_count) {
+                                                         int* __restrict__ singular_count,
+                                                         int* __restrict__ next_count) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k == 0) *next_count = 0;      // the counter the NEXT call will use (two counters alternate: no memset launch)
   if (k >= nt) return;
   double A[6], out[6];
 #pragma unroll
@@ -379,23 +372,32 @@ __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* _
 
 // --------------------------------------------------------------------------
 // S[pos,pos] = damped HCC, b[pos] = bC for optimised cameras
-// (bundle_adjuster.py:238-240, 263-265).  S was zero-filled by the caller.
+// (bundle_adjuster.py:238-240, 263-265); every other block of the band is cleared in the
+// same pass (one launch instead of two memsets + a scatter).  One thread per double of
+// [S | b]; `opt_cam[pos]` is the camera at optimised position pos.
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_schur_init(int nc, int hb1, const int* __restrict__ cam_opt_pos,
+__global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const int* __restrict__ opt_cam,
                                                        const double* __restrict__ HCC,
                                                        const double* __restrict__ bC, double damping,
                                                        double* __restrict__ S, double* __restrict__ b) {
-  const int tid = blockIdx.x * kBlock + threadIdx.x;
-  const int i = tid / 36, e = tid % 36;
-  if (i >= nc) return;
-  const int pos = cam_opt_pos[i];
-  if (pos < 0) return;
-  const int a = e / 6, c = e % 6;
-  const int lo = a < c ? a : c, hi = a < c ? c : a;
-  double v = HCC[(size_t)i * 36 + lo * 6 + hi];
-  if (a == c) v *= (1.0 + damping);
-  S[band_block(pos, pos, hb1) + e] = v;
-  if (e < 6) b[(size_t)pos * 6 + e] = bC[(size_t)i * 6 + e];
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long nS = (long long)nco * hb1 * 36;
+  if (tid < nS) {
+    const int e = (int)(tid % 36);
+    const long long blk = tid / 36;
+    const int d = (int)(blk % hb1), pos = (int)(blk / hb1);
+    double v = 0.0;
+    if (d == 0) {
+      const int a = e / 6, c = e % 6;
+      const int lo = a < c ? a : c, hi = a < c ? c : a;
+      v = HCC[(size_t)opt_cam[pos] * 36 + lo * 6 + hi];
+      if (a == c) v *= (1.0 + damping);
+    }
+    S[tid] = v;
+  } else if (tid < nS + (long long)nco * 6) {
+    const long long q = tid - nS;
+    b[q] = bC[(size_t)opt_cam[q / 6] * 6 + q % 6];
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -731,14 +733,39 @@ __global__ __launch_bounds__(kGroupBlock) void k_schur_groups(DevProblem P, cons
 // backsubstitute (bundle_adjuster.py:316-331):
 //   dP_k = HPPinv_k (bP_k - sum_i W_ik^T dC_i),  W^T dC = Jp^T (Jc dC).
 // dC[nco*6] is indexed by optimised-camera position; frozen cameras contribute nothing.
+// With cams_dst / X_dst given (ba_lm_trial) the kernel also writes the trial parameters
+// R exp(sign dC), t + sign dt, x + sign dP (k_apply_update's work, one launch less).
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* __restrict__ cams,
                                                     const double* __restrict__ X, int glog,
                                                     const double* __restrict__ dC,
                                                     const double* __restrict__ HPPinv,
-                                                    const double* __restrict__ bP, double* __restrict__ dP) {
+                                                    const double* __restrict__ bP, double* __restrict__ dP,
+                                                    double sign, double* __restrict__ cams_dst,
+                                                    double* __restrict__ X_dst) {
   const int G = 1 << glog;
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  // fused update_motion (bundle_adjuster.py:334-337): dC is complete before this kernel starts
+  if (cams_dst) {
+    const long long nthreads = (long long)gridDim.x * kBlock;
+    for (long long i = tid; i < P.nc; i += nthreads) {
+      double cm[12], out[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) cm[q] = cams[(size_t)i * 12 + q];
+      const int pos = P.cam_opt_pos[i];
+      if (pos >= 0) {
+        double d[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d[q] = sign * dC[(size_t)pos * 6 + q];
+        camera_perturb(cm, d, out);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) out[q] = cm[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) cams_dst[(size_t)i * 12 + q] = out[q];
+    }
+  }
   const long long k = tid >> glog;
   const int l = (int)(tid & (G - 1));
   const bool valid = k < P.nt;
@@ -778,6 +805,11 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
     sym3_apply(A, v, out);
 #pragma unroll
     for (int i = 0; i < 3; ++i) dP[3 * k + i] = out[i];
+    if (X_dst) {                      // fused update_structure (bundle_adjuster.py:340-343)
+      const bool opt = P.pt_opt[k] != 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) X_dst[3 * k + i] = opt ? x[i] + sign * out[i] : x[i];
+    }
   }
 }
 
