@@ -29,6 +29,8 @@
 #define BA_STAMP(var)
 #endif
 
+#include <utility>
+
 namespace ba {
 
 constexpr int kBcrThreads = 256;                 // assemble
@@ -76,6 +78,87 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
   for (int r = threadIdx.x; r < B; r += kBcrThreads) {
     const int i = I * hb + r / 6, a = r % 6;
     fm[(size_t)I * B + r] = (i < nco && (!mask || mask[6 * i + a])) ? b[6 * (size_t)i + a] : 0.0;
+  }
+}
+
+// acc += (lane K of my 16-lane row of `row`) * y      (v_fmac_f64 with a DPP row_newbcast source)
+template <int K>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double row, double y) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
+}
+
+template <int... Rs>
+__device__ __forceinline__ void bcr_rank1_seq(std::integer_sequence<int, Rs...>, double (&acc)[16], double a, double b) {
+  (fmac_rowbcast<Rs>(acc[Rs], a, b), ...);
+}
+// acc[r] += (lane r of my 16-lane row of a) * b   for r < NR
+template <int NR>
+__device__ __forceinline__ void bcr_rank1(double (&acc)[16], double a, double b) {
+  bcr_rank1_seq(std::make_integer_sequence<int, NR>{}, acc, a, b);
+}
+
+// sum_k (lane k%16 of chunk k/16 of Lc) * y[k] over k < T, split over two accumulators
+// (a wavefront issues one fp64 FMA per ~9 cycles, so two chains cover the ~16-cycle latency)
+template <int NBK, int... Ks>
+__device__ __forceinline__ void bcr_dot_seq(std::integer_sequence<int, Ks...>, const double (&Lc)[(NBK + 15) / 16],
+                                            const double (&y)[NBK], double& a0, double& a1) {
+  (fmac_rowbcast<(Ks & 15)>((Ks & 1) ? a1 : a0, Lc[Ks >> 4], y[Ks]), ...);
+}
+
+// row T of the triangular solve with one nb x nb diagonal block (one right-hand side per lane):
+// y[T] = (x[T] - sum_{k<T} L[T][k] y[k]) / L[T][T].  Lb points at L[r0][r0 + lane%16].
+template <int NBK, int T>
+__device__ __forceinline__ void bcr_tri_row(const double* __restrict__ Lb, int ld, const double* __restrict__ dv,
+                                            double* __restrict__ Xb, int st, double (&y)[NBK],
+                                            double (&Lc)[(NBK + 15) / 16], double& xc, double& dc) {
+  double Ln[(NBK + 15) / 16], xn = 0.0, dn = 0.0;                 // row T+1's inputs, in flight during row T's chain
+  if constexpr (T + 1 < NBK) {
+#pragma unroll
+    for (int j = 0; 16 * j < T + 1; ++j) Ln[j] = Lb[(T + 1) * ld + 16 * j];
+    xn = Xb[(T + 1) * st];
+    dn = dv[T + 1];
+  }
+  double a0 = -xc, a1 = 0.0;
+  bcr_dot_seq<NBK>(std::make_integer_sequence<int, T>{}, Lc, y, a0, a1);
+  y[T] = -(a0 + a1) * dc;
+  Xb[T * st] = y[T];
+  if constexpr (T + 1 < NBK) {
+#pragma unroll
+    for (int j = 0; 16 * j < T + 1; ++j) Lc[j] = Ln[j];
+    xc = xn; dc = dn;
+  }
+}
+
+template <int NBK, int... Ts>
+__device__ __forceinline__ void bcr_tri_rows(std::integer_sequence<int, Ts...>, const double* __restrict__ Lb, int ld,
+                                             const double* __restrict__ dv, double* __restrict__ Xb, int st,
+                                             double (&y)[NBK]) {
+  double Lc[(NBK + 15) / 16], xc = Xb[0], dc = dv[0];
+  (bcr_tri_row<NBK, Ts>(Lb, ld, dv, Xb, st, y, Lc, xc, dc), ...);
+}
+
+// rows [ra, rb) of the update X[i] -= sum_k L[i][r0 + k] y[k] (k < nb) for one right-hand side per lane;
+// Lrow points at L[0][r0 + lane%16].
+template <int NBK>
+__device__ __forceinline__ void bcr_update_rows(const double* __restrict__ Lrow, int ld, double* __restrict__ X, int st,
+                                                int ra, int rb, const double (&y)[NBK]) {
+  constexpr int NJ = (NBK + 15) / 16;
+  if (ra >= rb) return;
+  double Ln[NJ], xn;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) Ln[j] = Lrow[ra * ld + 16 * j];
+  xn = X[ra * st];
+  for (int i = ra; i < rb; ++i) {
+    double Lc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) Lc[j] = Ln[j];
+    double a0 = -xn, a1 = 0.0;
+    const int in = i + 1 < rb ? i + 1 : i;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) Ln[j] = Lrow[in * ld + 16 * j];
+    xn = X[in * st];
+    bcr_dot_seq<NBK>(std::make_integer_sequence<int, NBK>{}, Lc, y, a0, a1);
+    X[i * st] = -(a0 + a1);
   }
 }
 
@@ -238,89 +321,114 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 
   BA_STAMP(t2);
   // ---- forward substitution L Y = R for 3B+1 right-hand sides: P (B columns), Q (B), G^-1
-  //      (B), g (1).  FOUR lanes per column: lane q of the quad owns the entries k = q mod 4
-  //      of the solution (registers) and the matching quarter of every dot product; the
-  //      four partial sums meet through DPP (no LDS traffic on the dependent chain).
+  //      (B), g (1); one lane per right-hand side, blocked in three row blocks of nb = 2 HB:
+  //        T(b): Y_b = L_bb^-1 R_b          one wavefront per 64 columns, solution block in registers
+  //        U(b): R_below -= L[below, b] Y_b  all wavefronts, rows shared out
+  //      Every entry of L reaches its FMA as a DPP row_newbcast operand out of a register that
+  //      holds 16 consecutive entries of the row (lane l: entry l%16): one LDS read per 16
+  //      FMA instructions, no cross-lane reduction on the dependent chain.  Lanes past the
+  //      last column repeat it (DPP sources must be live lanes; they store identical values).
   {
-    constexpr int ncol = 3 * B + 1;
-    constexpr int NQ = (B + 3) / 4;
-    for (int task = tid; task < ncol * 4; task += kBcrElimThreads) {
-      const int c = task >> 2, q4 = task & 3;
-      double* X = c < B ? Pl + c : c < 2 * B ? Ql + (c - B) : c < 3 * B ? Xi + (c - 2 * B) : g;
-      const int st = c < 3 * B ? ld : 1;
-      double y[NQ];                                         // y[m] = solution entry 4m + q4
-      // software pipeline: the quarter-row of L, the right-hand side and 1/diag of row i2+1
-      // are fetched from LDS while row i2 runs its dependent chain (FMA -> DPP -> scale)
-      double gn[NQ], xn = X[0], dn = dinv[0];
+    constexpr int ncol = 3 * B + 1, NCG = (ncol + 63) / 64, NQ = (kBcrElimThreads / 64) / NCG, NBK = 2 * HB;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15;
+    const int cg = wave % NCG, q = wave / NCG;
+    const int craw = cg * 64 + lane, c = craw < ncol ? craw : ncol - 1;
+    double* X = c < B ? Pl + c : c < 2 * B ? Ql + (c - B) : c < 3 * B ? Xi + (c - 2 * B) : g;
+    const int st = c < 3 * B ? ld : 1;
+#ifdef BA_BCR_PROFILE
+    long long tsub[7];
+    tsub[0] = clock64();
+#endif
 #pragma unroll
-      for (int m = 0; m < NQ; ++m) gn[m] = 0.0;
-#pragma unroll
-      for (int i2 = 0; i2 < B; ++i2) {
-        double gc[NQ];
-#pragma unroll
-        for (int m = 0; m < NQ; ++m) gc[m] = gn[m];
-        const double xc = xn, dc = dn;
-        if (i2 + 1 < B) {
-#pragma unroll
-          for (int m = 0; 4 * m < i2 + 1; ++m) {
-            const int k2 = 4 * m + q4;
-            gn[m] = k2 < i2 + 1 ? G[(i2 + 1) * ld + k2] : 0.0;
-          }
-          xn = X[(i2 + 1) * st];
-          dn = dinv[i2 + 1];
-        }
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;       // independent chains: fp64 FMA latency is 16 cycles
-#pragma unroll
-        for (int m = 0; 4 * m < i2; ++m) {                  // my quarter: k2 = 4m + q4 < i2 (gc is 0 beyond)
-          const double t = gc[m] * y[m];
-          if ((m & 3) == 0) a0 -= t;
-          else if ((m & 3) == 1) a1 -= t;
-          else if ((m & 3) == 2) a2 -= t;
-          else a3 -= t;
-        }
-        double acc = (a0 + a1) + (a2 + a3);
-        acc += dpp_pair<0xB1>(acc);
-        acc += dpp_pair<0x4E>(acc);
-        const double yi = (xc + acc) * dc;
-        if ((i2 & 3) == q4) y[i2 >> 2] = yi;
-        if (q4 == 0) X[i2 * st] = yi;                       // rows are final in order: no one reads X[i2] again
+    for (int b = 0; b < 3; ++b) {
+      const int r0 = b * NBK;
+      double y[NBK];
+      if (wave < NCG) {
+        bcr_tri_rows<NBK>(std::make_integer_sequence<int, NBK>{}, G + r0 * ld + r0 + lr, ld, dinv + r0, X + r0 * st, st, y);
       }
+#ifdef BA_BCR_PROFILE
+      const long long ta = clock64();
+#endif
+      __syncthreads();
+#ifdef BA_BCR_PROFILE
+      tsub[1 + 2 * b] = clock64();
+      if (tid == 0 && blockIdx.x == 1 && s == 1) info[20 + b] = (int)(ta - tsub[2 * b]);
+#endif
+      if (b < 2 && q < NQ) {
+        if (wave >= NCG) {
+#pragma unroll
+          for (int k = 0; k < NBK; ++k) y[k] = X[(r0 + k) * st];
+        }
+        const int nrows = B - r0 - NBK, per = (nrows + NQ - 1) / NQ;
+        const int ra = r0 + NBK + q * per, rb = ra + per < B ? ra + per : B;
+#ifdef BA_BCR_PROFILE
+        const long long tu0 = clock64();
+#endif
+        bcr_update_rows<NBK>(G + r0 + lr, ld, X, st, ra, rb, y);
+#ifdef BA_BCR_PROFILE
+        if (tid == 0 && blockIdx.x == 1 && s == 1) { info[24 + 2 * b] = (int)(tu0 - tsub[1 + 2 * b]); info[25 + 2 * b] = (int)(clock64() - tu0); }
+        if (lane == 0 && blockIdx.x == 1 && s == 1 && b == 0) info[44 + wave] = (int)(clock64() - tsub[1]);
+#endif
+      }
+      if (b < 2) __syncthreads();
+#ifdef BA_BCR_PROFILE
+      if (b < 2) tsub[2 + 2 * b] = clock64();
+#endif
     }
+#ifdef BA_BCR_PROFILE
+    if (tid == 0 && blockIdx.x == 1 && s == 1) {
+      info[14] = (int)(tsub[1] - tsub[0]); info[15] = (int)(tsub[2] - tsub[1]); info[16] = (int)(tsub[3] - tsub[2]);
+      info[17] = (int)(tsub[4] - tsub[3]); info[18] = (int)(tsub[5] - tsub[4]);
+    }
+#endif
   }
   __syncthreads();
 
   BA_STAMP(t3);
-  // ---- neighbour updates: 3x3 register tiles of P^T P, Q^T Q, P^T Q; P^T g, Q^T g
+  // ---- neighbour updates P^T P, Q^T Q, P^T Q on the fp64 matrix cores: one wavefront per
+  //      16 x 16 output tile (lower tiles only for the two symmetric products), K in steps of
+  //      4 with v_mfma_f64_16x16x4_f64 - per step each lane reads ONE entry of A and of B
+  //      from LDS (A^T tile: lane -> column 16 ti + lane%16, row 4 ks + lane/16).  The vector
+  //      FMA forms of this are bound by LDS reads (3x3 register tiles) or by the issue rate of
+  //      a wavefront; the matrix core runs a tile at 16 FMA/clk from a single wavefront.
   {
-    constexpr int T = B / 3, TT = T * T;
-    for (int task = tid; task < 3 * TT; task += kBcrElimThreads) {
-      const int which = task / TT, t2 = task - which * TT;
-      if ((which == 0 && !haveL) || (which == 1 && !haveR) || (which == 2 && !(haveL && haveR))) continue;
-      const int i0 = 3 * (t2 / T), j0 = 3 * (t2 % T);
-      if (which < 2 && j0 > i0) continue;                   // D is only ever read in its lower triangle
-      const double* A = which == 1 ? Ql : Pl;
-      const double* Bm = which == 0 ? Pl : Ql;
-      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 6
-      for (int k = 0; k < B; ++k) {
-        const double a0 = A[k * ld + i0], a1 = A[k * ld + i0 + 1], a2 = A[k * ld + i0 + 2];
-        const double b0 = Bm[k * ld + j0], b1 = Bm[k * ld + j0 + 1], b2 = Bm[k * ld + j0 + 2];
-        acc[0] += a0 * b0; acc[1] += a0 * b1; acc[2] += a0 * b2;
-        acc[3] += a1 * b0; acc[4] += a1 * b1; acc[5] += a1 * b2;
-        acc[6] += a2 * b0; acc[7] += a2 * b1; acc[8] += a2 * b2;
+    typedef double mfma_acc __attribute__((ext_vector_type(4)));
+    constexpr int NT = (B + 15) / 16, NSYM = NT * (NT + 1) / 2, NTASK = 2 * NSYM + NT * NT, KST = (B + 3) / 4;
+    const int wave = tid >> 6, lane = tid & 63, ln = lane & 15, lk = lane >> 4;
+    for (int task = wave; task < NTASK; task += kBcrElimThreads / 64) {
+      int which, ti, tj;
+      if (task < 2 * NSYM) {
+        which = task < NSYM ? 0 : 1;
+        tri_decode(task - which * NSYM, NT, tj, ti);         // tj <= ti: D is only ever read in its lower triangle
+      } else {
+        which = 2;
+        ti = (task - 2 * NSYM) / NT; tj = (task - 2 * NSYM) % NT;
       }
+      if ((which == 0 && !haveL) || (which == 1 && !haveR) || (which == 2 && !(haveL && haveR))) continue;
+      const double* A = (which == 1 ? Ql : Pl) + 16 * ti + ln;
+      const double* Bm = (which == 0 ? Pl : Ql) + 16 * tj + ln;
+      mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int ks = 0; ks < KST; ++ks) {
+        const int k = 4 * ks + lk;
+        const bool in = 4 * ks + 3 < B || k < B;              // rows past B belong to the next matrix: feed zeros
+        const double a = in ? A[k * ld] : 0.0;
+        const double b = in ? Bm[k * ld] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      // C/D layout of the f64 form: lane -> column lane%16, register v -> row lane/16 + 4 v
+      double* dst = which == 2 ? Um + (size_t)l * BB : Dm + (size_t)(which == 0 ? l : r) * BB;
+      const int col = 16 * tj + ln;
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-          const size_t off = (size_t)(i0 + u) * B + j0 + v;
-          if (which == 0) atomic_add_f64(Dm + (size_t)l * BB + off, -acc[u * 3 + v]);
-          else if (which == 1) atomic_add_f64(Dm + (size_t)r * BB + off, -acc[u * 3 + v]);
-          else Um[(size_t)l * BB + off] = -acc[u * 3 + v];          // new T[l,r]
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * ti + lk + 4 * v;
+        if (row < B && col < B) {
+          if (which == 2) dst[(size_t)row * B + col] = -acc[v];          // new T[l,r]
+          else if (col <= row) atomic_add_f64(dst + (size_t)row * B + col, -acc[v]);
         }
       }
     }
-    for (int c = tid; c < 2 * B; c += kBcrElimThreads) {
+    for (int c = kBcrElimThreads - 1 - tid; c < 2 * B; c += kBcrElimThreads) {     // the last wavefronts have fewer tiles
       const bool left = c < B;
       if ((left && !haveL) || (!left && !haveR)) continue;
       const double* A = left ? Pl + c : Ql + (c - B);
@@ -329,6 +437,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
       atomic_add_f64(fm + (size_t)(left ? l : r) * B + (left ? c : c - B), -acc);
     }
   }
+#ifdef BA_BCR_PROFILE
+  __syncthreads();      // profile builds only: separate the products from the store phase
+#endif
   BA_STAMP(t4);
   // ---- keep what the back-substitution needs
   for (int e = tid; e < B * B; e += kBcrElimThreads) {

@@ -1001,7 +1001,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   }
   HIPCHECK(h, hipGetLastError());
   if (h->defer) { *info = 0; h->have_solution = true; return BA_OK; }   // status is read by ba_lm_trial
-  int inf6[24] = {0};
+  int inf6[62] = {0};
   HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   const int inf = inf6[0];
@@ -1009,6 +1009,15 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   if (getenv("BA_SOLVE_TRACE") && use_bcr)
     fprintf(stderr, "[k_bcr_eliminate level 0 node 2] load %d chol %d trsm %d products %d store %d cycles\n", inf6[8], inf6[9],
             inf6[10], inf6[11], inf6[12]);
+  if (getenv("BA_SOLVE_TRACE") && use_bcr)
+    fprintf(stderr, "    forward substitution: T0 %d (wave0 alone %d) U0 %d T1 %d (%d) U1 %d T2 %d (%d)\n", inf6[14], inf6[20], inf6[15],
+            inf6[16], inf6[21], inf6[17], inf6[18], inf6[22]);
+  if (getenv("BA_SOLVE_TRACE") && use_bcr)
+  {
+    fprintf(stderr, "    wave 0 in U0: load y %d, rows %d; in U1: load y %d, rows %d\n    U0 per wave:", inf6[24], inf6[25], inf6[26], inf6[27]);
+    for (int w = 0; w < 16; ++w) fprintf(stderr, " %d", inf6[44 + w]);
+    fprintf(stderr, "\n");
+  }
 #endif
   if (getenv("BA_SOLVE_TRACE") && !use_bcr)
     fprintf(stderr, "[k_band_solve] nco=%d hb=%d ch=%d lds=%zu B | forward: %d cycles, %d ticks(100MHz) | total: %d cycles, %d ticks\n",

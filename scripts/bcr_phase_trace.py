@@ -1,0 +1,25 @@
+"""Per-phase shader-cycle counts of k_bcr_eliminate (library built with `make PROFILE=1`).
+usage (GPU box): BA_SOLVE_TRACE=1 python scripts/bcr_phase_trace.py [cams] [points]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('BA_SOLVE_TRACE', '1')
+from pysfm_amd import Bundle, BundleAdjuster, sensor_model          # noqa: E402
+from pysfm_amd import synthetic_data as sd                          # noqa: E402
+
+nc = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+s = sd.generate_banded_scene(nc, nt)
+b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
+                            sensor_model=sensor_model.GaussianModel(1.))
+ba = BundleAdjuster(verbose=False)
+ba.set_bundle(b)
+be = ba.backend
+be.linearize(0)
+be.schur(0, 10., 1e-5)
+for _ in range(3):
+    be.solve_reduced(None)
+print('solve path', be.last_solve_path, 'hb', be.half_bandwidth, '|dC|', float(np.linalg.norm(be.get_solution())))
