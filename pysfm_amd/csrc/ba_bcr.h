@@ -29,6 +29,9 @@
 #define BA_STAMP(var)
 #endif
 
+#ifndef BA_EXP
+#define BA_EXP 0
+#endif
 #include <utility>
 
 namespace ba {
@@ -219,11 +222,45 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   __syncthreads();
 
   BA_STAMP(t1);
-  // ---- blocked Cholesky D_i = L L^T (lower, in place), block size 6
+  // ---- blocked Cholesky D_i = L L^T (lower, in place, block size 6) FUSED with the forward
+  //      substitution L Y = R of the right-hand sides P | Q | I | g (one lane per column), as one
+  //      right-looking elimination of the augmented matrix [D_i | R], with one block of look-ahead:
+  //        phase 1  wavefront 0: 6x6 diagonal factor of block kb (v_readlane broadcasts)
+  //                 the others : the LATE part of step kb-1 - trailing update of D right of block
+  //                              column kb (3x3 register tiles) and R_below -= L_panel Y_(kb-1)
+  //                              (L entries as DPP row_newbcast operands, ba: fmac_rowbcast)
+  //        phase 2  panel of block column kb (one row per thread) and Y_kb = L_kk^-1 R_kb
+  //        phase 3  the URGENT part of step kb: update of block column kb+1 only, so that the
+  //                 next diagonal factor can start while the rest of the update is still running
+  //      The chain of 6 HB dependent pivots is what bounds this kernel; everything else rides along.
+  // wave-uniform values live in SGPRs: every VALU instruction of the 16 wavefronts costs a CU issue slot
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15;
+  const int nP = haveL ? B : 0, nQ = haveR ? B : 0, ncol = nP + nQ + B + 1;      // absent neighbours: no columns
+  auto rhs_column = [&](int c, int& st) -> double* {
+    st = c < ncol - 1 ? ld : 1;
+    return c < nP ? Pl + c : c < nP + nQ ? Ql + (c - nP) : c < ncol - 1 ? Xi + (c - nP - nQ) : g;
+  };
+  // fixed roles for the late updates (phase 1): wavefronts 1..12 own 16 right-hand-side columns
+  // each, 13..15 own a 16-column tile of the trailing part of D, wavefront 0 factors
+  const int lk = lane >> 4;
+  const bool rhs_role = wave >= 1 && wave <= 12;
+  const bool wave_active = rhs_role ? 16 * (wave - 1) < ncol : wave >= 13;
+  const int xcol = 16 * (wave - 1) + lr;
+  const bool xok = rhs_role && xcol < ncol;
+  int xst = 1;
+  const int xoff = (int)(rhs_column(xok ? xcol : ncol - 1, xst) - sm);      // my column as an offset into sm[]
+  static_assert(3 * B + 1 <= 12 * 16 && B - 12 <= 3 * 16, "column tiles of the late updates must fit wavefronts 1..12 / 13..15");
+#ifdef BA_BCR_PROFILE
+  long long ph[4] = {0, 0, 0, 0};
+#endif
   for (int kb = 0; kb < HB; ++kb) {
     const int k0 = 6 * kb;
-    if (tid < 64) {
-      // 6x6 diagonal block on wavefront 0: lane c owns column c of the upper factor U (= L^T)
+#ifdef BA_BCR_PROFILE
+    const long long p0 = clock64();
+#endif
+    // ---------------- phase 1
+    if (wave == 0) {
+      // 6x6 diagonal block: lane c owns column c of the upper factor U (= L^T)
       const int c = tid < 6 ? tid : 5;
       double col[6];
 #pragma unroll
@@ -251,10 +288,87 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
         for (int p = 0; p < 6; ++p)
           if (p <= c) G[(k0 + c) * ld + k0 + p] = col[p];                    // L[c][p] = U[p][c]
       }
+    } else if (kb > 0 && wave_active) {
+      // the LATE part of step kb-1 on the matrix cores.  This wavefront owns 16 columns (of the
+      // right-hand sides, or of D) for the whole kernel and updates every 16-row tile below:
+      //   C -= A B,  K = 6: two v_mfma_f64_16x16x4_f64 per tile, the second half-empty,
+      //   A = panel of block kp (rows of the tile), B = Y_kp (right-hand sides) or panel^T (D).
+      // All loads of a task are issued before the first MFMA.  Loads are unconditional:
+      // out-of-range rows / columns stay inside the LDS arrays and only reach accumulator rows /
+      // columns that are never stored; only the k = 6, 7 half of the second MFMA must be zero.
+      // Index arithmetic is 32-bit with 24-bit multiplies (full rate): with 15 wavefronts busy
+      // every VALU instruction costs a CU issue slot, and v_mul_lo_u32 costs four.
+      const int kp = k0 - 6;                                   // the block whose update is still owed
+      int t0, t1, i00;                                         // row tiles [t0, t1), first row of tile 0
+      int bo, bst, co, cst;                                    // offsets into sm[] (doubles) and strides
+      bool cok, skip = false;
+      if (rhs_role) {
+        t0 = 0; t1 = (B - k0 + 15) / 16; i00 = k0;
+        bo = xoff + __mul24(kp + lk, xst); bst = 4 * xst;
+        co = xoff + __mul24(lk, xst); cst = xst; cok = xok;
+        // columns of the identity right of block kp are still zero in rows kp..kp+5: nothing to subtract
+        skip = 16 * (wave - 1) >= nP + nQ + kp + 6 && 16 * (wave - 1) + 15 < ncol - 1;
+      } else {
+        const int gtile = wave - 13, c0 = k0 + 6 + 16 * gtile;
+        t0 = gtile; t1 = (B - k0 - 6 + 15) / 16; i00 = k0 + 6;
+        bo = (c0 + lr) * ld + kp + lk; bst = 4;
+        co = lk * ld + c0 + lr; cst = ld; cok = c0 + lr < B;
+      }
+      if (!skip && t0 < t1) {
+        typedef double mfma_acc __attribute__((ext_vector_type(4)));
+        const double b0 = sm[bo], b1 = sm[bo + bst];
+        const int c4 = 4 * cst;
+        int ao = (i00 + 16 * t0 + lr) * ld + kp + lk;          // A entry of this lane in the first tile
+        int cb = co + __mul24(i00 + 16 * t0, cst);             // first accumulator entry of this lane
+        int rlim = cok ? B - (i00 + 16 * t0) - lk : 0;         // rows v with 4 v < rlim exist
+        // one tile at a time with the next tile's operands in flight (few instructions per tile:
+        // the other wavefronts of this SIMD need the issue slots)
+#ifdef BA_BCR_PROFILE
+        const long long q0 = clock64();
+#endif
+        double a0 = sm[ao], a1 = sm[ao + 4];
+        mfma_acc acc = {sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
+#ifdef BA_BCR_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long q1 = clock64();
+        long long q2 = 0;
+#endif
+        for (int t = t0; t < t1; ++t) {
+          const double a0c = -a0, a1c = lk < 2 ? -a1 : 0.0;
+          mfma_acc accc = acc;
+          const int cbc = cb, rl = rlim;
+          if (t + 1 < t1) {
+            ao += 16 * ld; cb += 16 * cst; rlim -= 16;
+            a0 = sm[ao]; a1 = sm[ao + 4];
+            acc = mfma_acc{sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
+          }
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0c, b0, accc, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1c, b1, accc, 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (4 * v < rl) sm[cbc + v * c4] = accc[v];        // (the strict upper part of diagonal tiles is never read)
+#ifdef BA_BCR_PROFILE
+          if (t == t0) q2 = clock64();
+#endif
+        }
+#ifdef BA_BCR_PROFILE
+        if (blockIdx.x == 1 && s == 1 && kb == 4 && lane == 0 && wave == 1) {
+          info[30] = (int)(q0 - p0); info[31] = (int)(q1 - q0); info[32] = (int)(q2 - q1); info[33] = (int)(clock64() - q2);
+        }
+#endif
+      }
     }
+#ifdef BA_BCR_PROFILE
+    const long long p1a = clock64();
+    if (blockIdx.x == 1 && s == 1 && kb == 4 && lane == 0) info[44 + wave] = (int)(p1a - p0);
+#endif
     __syncthreads();
-    // panel: rows below the diagonal block, X = A[i2][k0..k0+5] L_kk^-T (one row per thread)
-    {
+#ifdef BA_BCR_PROFILE
+    const long long p1 = clock64();
+#endif
+    // ---------------- phase 2
+    if (wave == 1) {
+      // panel: rows below the diagonal block, X = A[i2][k0..k0+5] L_kk^-T (one row per thread)
       double Lk[15], dk[6];
       int idx = 0;
 #pragma unroll
@@ -263,7 +377,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #pragma unroll
         for (int p = 0; p < q; ++p) Lk[idx++] = G[(k0 + q) * ld + k0 + p];
       }
-      for (int i2 = k0 + 6 + tid; i2 < B; i2 += kBcrElimThreads) {
+      for (int i2 = k0 + 6 + lane; i2 < B; i2 += 64) {
         double x[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) x[q] = G[i2 * ld + k0 + q];
@@ -279,110 +393,62 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
       }
     }
     __syncthreads();
-    // trailing update in 3x3 tiles of the lower triangle: A[i][j] -= sum_q X[i][q] X[j][q]
-    {
-      const int n3 = (B - k0 - 6) / 3;                       // tiles per side
-      const int ntile = n3 * (n3 + 1) / 2;
-      for (int t = tid; t < ntile; t += kBcrElimThreads) {
-        int ti, tj;
-        tri_decode(t, n3, tj, ti);                           // tj <= ti
-        const int i0 = k0 + 6 + 3 * ti, j0 = k0 + 6 + 3 * tj;
-        double xi[18], xj[18], a[9];
+#ifdef BA_BCR_PROFILE
+    const long long p2 = clock64();
+#endif
+    // ---------------- phase 3: block column kb+1 (its diagonal block and the rows below it)
+    // ---------------- ... alongside the solve of block row kb of the right-hand sides
+    if (wave >= 5 && wave <= 7) {
+      // Y_kb = L_kk^-1 R_kb, one right-hand side per lane
+      const int craw = (wave - 5) * 64 + lane;
+      if (craw < ncol) {
+        int st;
+        double* X = rhs_column(craw, st) + (size_t)k0 * st;
+        double Lk[15], dk[6], x[6];
+        int idx = 0;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int q = 0; q < 6; ++q) {
+          dk[q] = dinv[k0 + q];
+          x[q] = X[q * st];
 #pragma unroll
-          for (int q = 0; q < 6; ++q) { xi[u * 6 + q] = G[(i0 + u) * ld + k0 + q]; xj[u * 6 + q] = G[(j0 + u) * ld + k0 + q]; }
-#pragma unroll
-          for (int v = 0; v < 3; ++v) a[u * 3 + v] = G[(i0 + u) * ld + j0 + v];
+          for (int p = 0; p < q; ++p) Lk[idx++] = G[(k0 + q) * ld + k0 + p];
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int q = 0; q < 6; ++q) {
+          double t = x[q];
 #pragma unroll
-          for (int v = 0; v < 3; ++v) {
-            double acc = a[u * 3 + v];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) acc -= xi[u * 6 + q] * xj[v * 6 + q];
-            a[u * 3 + v] = acc;
-          }
+          for (int p = 0; p < q; ++p) t -= Lk[q * (q - 1) / 2 + p] * x[p];
+          x[q] = t * dk[q];
+          X[q * st] = x[q];
         }
+      }
+    }
+    if (kb + 1 < HB) {
+      const int nrow = B - k0 - 6;
+      if (tid < 6 * nrow) {
+        const int ii = tid / 6, jj = tid - 6 * ii;
+        const int i2 = k0 + 6 + ii, j2 = k0 + 6 + jj;
+        if (i2 >= j2) {
+          double acc = G[i2 * ld + j2];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-#pragma unroll
-          for (int v = 0; v < 3; ++v) G[(i0 + u) * ld + j0 + v] = a[u * 3 + v];   // (the strict upper part of diagonal tiles is never read)
+          for (int q = 0; q < 6; ++q) acc -= G[i2 * ld + k0 + q] * G[j2 * ld + k0 + q];
+          G[i2 * ld + j2] = acc;
         }
       }
     }
     __syncthreads();
+#ifdef BA_BCR_PROFILE
+    ph[0] += p1a - p0; ph[1] += p1 - p0; ph[2] += p2 - p1; ph[3] += clock64() - p2;
+#endif
   }
+#ifdef BA_BCR_PROFILE
+  if (tid == 0 && blockIdx.x == 1 && s == 1) { info[14] = (int)ph[0]; info[15] = (int)ph[1]; info[16] = (int)ph[2]; info[17] = (int)ph[3]; }
+#endif
   if (*bad) {
     if (tid == 0) atomicMax(info, i * B + *bad);
     return;
   }
-
   BA_STAMP(t2);
-  // ---- forward substitution L Y = R for 3B+1 right-hand sides: P (B columns), Q (B), G^-1
-  //      (B), g (1); one lane per right-hand side, blocked in three row blocks of nb = 2 HB:
-  //        T(b): Y_b = L_bb^-1 R_b          one wavefront per 64 columns, solution block in registers
-  //        U(b): R_below -= L[below, b] Y_b  all wavefronts, rows shared out
-  //      Every entry of L reaches its FMA as a DPP row_newbcast operand out of a register that
-  //      holds 16 consecutive entries of the row (lane l: entry l%16): one LDS read per 16
-  //      FMA instructions, no cross-lane reduction on the dependent chain.  Lanes past the
-  //      last column repeat it (DPP sources must be live lanes; they store identical values).
-  {
-    constexpr int ncol = 3 * B + 1, NCG = (ncol + 63) / 64, NQ = (kBcrElimThreads / 64) / NCG, NBK = 2 * HB;
-    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15;
-    const int cg = wave % NCG, q = wave / NCG;
-    const int craw = cg * 64 + lane, c = craw < ncol ? craw : ncol - 1;
-    double* X = c < B ? Pl + c : c < 2 * B ? Ql + (c - B) : c < 3 * B ? Xi + (c - 2 * B) : g;
-    const int st = c < 3 * B ? ld : 1;
-#ifdef BA_BCR_PROFILE
-    long long tsub[7];
-    tsub[0] = clock64();
-#endif
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const int r0 = b * NBK;
-      double y[NBK];
-      if (wave < NCG) {
-        bcr_tri_rows<NBK>(std::make_integer_sequence<int, NBK>{}, G + r0 * ld + r0 + lr, ld, dinv + r0, X + r0 * st, st, y);
-      }
-#ifdef BA_BCR_PROFILE
-      const long long ta = clock64();
-#endif
-      __syncthreads();
-#ifdef BA_BCR_PROFILE
-      tsub[1 + 2 * b] = clock64();
-      if (tid == 0 && blockIdx.x == 1 && s == 1) info[20 + b] = (int)(ta - tsub[2 * b]);
-#endif
-      if (b < 2 && q < NQ) {
-        if (wave >= NCG) {
-#pragma unroll
-          for (int k = 0; k < NBK; ++k) y[k] = X[(r0 + k) * st];
-        }
-        const int nrows = B - r0 - NBK, per = (nrows + NQ - 1) / NQ;
-        const int ra = r0 + NBK + q * per, rb = ra + per < B ? ra + per : B;
-#ifdef BA_BCR_PROFILE
-        const long long tu0 = clock64();
-#endif
-        bcr_update_rows<NBK>(G + r0 + lr, ld, X, st, ra, rb, y);
-#ifdef BA_BCR_PROFILE
-        if (tid == 0 && blockIdx.x == 1 && s == 1) { info[24 + 2 * b] = (int)(tu0 - tsub[1 + 2 * b]); info[25 + 2 * b] = (int)(clock64() - tu0); }
-        if (lane == 0 && blockIdx.x == 1 && s == 1 && b == 0) info[44 + wave] = (int)(clock64() - tsub[1]);
-#endif
-      }
-      if (b < 2) __syncthreads();
-#ifdef BA_BCR_PROFILE
-      if (b < 2) tsub[2 + 2 * b] = clock64();
-#endif
-    }
-#ifdef BA_BCR_PROFILE
-    if (tid == 0 && blockIdx.x == 1 && s == 1) {
-      info[14] = (int)(tsub[1] - tsub[0]); info[15] = (int)(tsub[2] - tsub[1]); info[16] = (int)(tsub[3] - tsub[2]);
-      info[17] = (int)(tsub[4] - tsub[3]); info[18] = (int)(tsub[5] - tsub[4]);
-    }
-#endif
-  }
-  __syncthreads();
 
   BA_STAMP(t3);
   // ---- neighbour updates P^T P, Q^T Q, P^T Q on the fp64 matrix cores: one wavefront per
@@ -394,7 +460,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   {
     typedef double mfma_acc __attribute__((ext_vector_type(4)));
     constexpr int NT = (B + 15) / 16, NSYM = NT * (NT + 1) / 2, NTASK = 2 * NSYM + NT * NT, KST = (B + 3) / 4;
-    const int wave = tid >> 6, lane = tid & 63, ln = lane & 15, lk = lane >> 4;
+    const int ln = lane & 15, lk = lane >> 4;
     for (int task = wave; task < NTASK; task += kBcrElimThreads / 64) {
       int which, ti, tj;
       if (task < 2 * NSYM) {
@@ -412,8 +478,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
       for (int ks = 0; ks < KST; ++ks) {
         const int k = 4 * ks + lk;
         const bool in = 4 * ks + 3 < B || k < B;              // rows past B belong to the next matrix: feed zeros
-        const double a = in ? A[k * ld] : 0.0;
-        const double b = in ? Bm[k * ld] : 0.0;
+        const double ar = A[k * ld], br = Bm[k * ld];
+        const double a = in ? ar : 0.0, b = in ? br : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
       // C/D layout of the f64 form: lane -> column lane%16, register v -> row lane/16 + 4 v

@@ -1010,11 +1010,11 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     fprintf(stderr, "[k_bcr_eliminate level 0 node 2] load %d chol %d trsm %d products %d store %d cycles\n", inf6[8], inf6[9],
             inf6[10], inf6[11], inf6[12]);
   if (getenv("BA_SOLVE_TRACE") && use_bcr)
-    fprintf(stderr, "    forward substitution: T0 %d (wave0 alone %d) U0 %d T1 %d (%d) U1 %d T2 %d (%d)\n", inf6[14], inf6[20], inf6[15],
-            inf6[16], inf6[21], inf6[17], inf6[18], inf6[22]);
-  if (getenv("BA_SOLVE_TRACE") && use_bcr)
-  {
-    fprintf(stderr, "    wave 0 in U0: load y %d, rows %d; in U1: load y %d, rows %d\n    U0 per wave:", inf6[24], inf6[25], inf6[26], inf6[27]);
+    fprintf(stderr, "    factor+solve, summed over the block steps: diagonal factor (wave 0) %d, phase 1 %d, phase 2 %d, phase 3 %d\n",
+            inf6[14], inf6[15], inf6[16], inf6[17]);
+  if (getenv("BA_SOLVE_TRACE") && use_bcr) {
+    fprintf(stderr, "    wave 1, block step 4: role setup %d, first loads %d, first tile %d, second tile %d\n", inf6[30], inf6[31], inf6[32], inf6[33]);
+    fprintf(stderr, "    phase 1 of block step 4, per wavefront:");
     for (int w = 0; w < 16; ++w) fprintf(stderr, " %d", inf6[44 + w]);
     fprintf(stderr, "\n");
   }

@@ -25,6 +25,17 @@ __global__ void k_probe(double* out, int n, long long* cyc) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, c, acc[u & 3], 0, 0, 0);
     }
+    if (MODE == 4) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, c, acc[0], 0, 0, 0);
+    }
+    if (MODE == 5) {      // two dependent MFMAs, then the result is consumed by a VALU op (as in a tile task)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, c, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(c, b, acc[u], 0, 0, 0);
+      }
+    }
     if (MODE == 3) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) a[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(b, c, a[u], 0, 0, 0);
@@ -45,17 +56,19 @@ __global__ void k_probe(double* out, int n, long long* cyc) {
 int main() {
   double* d; long long* c; hipMalloc(&d, 1 << 20); hipMalloc(&c, 128); hipMemset(d, 0, 1 << 20);
   const int n = 20000;
-  long long h[8];
-  const char* names[4] = {"v_fma_f64", "v_fmac_f64_dpp", "mfma_f64_16x16x4", "mfma_f64_4x4x4"};
+  long long h[12];
+  const char* names[6] = {"v_fma_f64", "v_fmac_f64_dpp", "mfma_f64_16x16x4", "mfma_f64_4x4x4", "mfma16 dependent chain", "mfma16 dependent pairs"};
   for (int threads : {64, 256, 512, 1024}) {
     hipLaunchKernelGGL(k_probe<0>, dim3(1), dim3(threads), 0, 0, d, n, c);
     hipLaunchKernelGGL(k_probe<1>, dim3(1), dim3(threads), 0, 0, d, n, c);
     hipLaunchKernelGGL(k_probe<2>, dim3(1), dim3(threads), 0, 0, d, n, c);
     hipLaunchKernelGGL(k_probe<3>, dim3(1), dim3(threads), 0, 0, d, n, c);
+    hipLaunchKernelGGL(k_probe<4>, dim3(1), dim3(threads), 0, 0, d, n, c);
+    hipLaunchKernelGGL(k_probe<5>, dim3(1), dim3(threads), 0, 0, d, n, c);
     hipDeviceSynchronize();
-    hipMemcpy(h, c, 64, hipMemcpyDeviceToHost);
+    hipMemcpy(h, c, 96, hipMemcpyDeviceToHost);
     const int waves = threads / 64;
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 6; ++m)
       printf("waves=%2d %-18s slowest wave %.2f cycles/instr, fastest %.2f | CU throughput: one wave-instr per %.2f cycles\n", waves, names[m],
              h[2 * m] / (8.0 * n), h[2 * m + 1] / (8.0 * n), h[2 * m] / (8.0 * n * waves));
   }
