@@ -29,9 +29,6 @@
 #define BA_STAMP(var)
 #endif
 
-#ifndef BA_EXP
-#define BA_EXP 0
-#endif
 #include <utility>
 
 namespace ba {
@@ -88,6 +85,43 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
 template <int K>
 __device__ __forceinline__ void fmac_rowbcast(double& acc, double row, double y) {
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
+}
+
+// value of lane K of my 16-lane row (v_mov_b64 with a DPP row_newbcast source)
+template <int K>
+__device__ __forceinline__ double mov_rowbcast(double v) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+  return r;
+}
+
+// acc += (lane K of my row of `row`) * y, with the two wait states a DPP read of a just-written VGPR needs
+template <int K>
+__device__ __forceinline__ void fmac_rowbcast_safe(double& acc, double row, double y) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
+}
+
+template <int Q, int... Ps>
+__device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...>, double (&col)[6], double uqc, double nuqc) {
+  (fmac_rowbcast_safe<Q + 1 + Ps>(col[Q + 1 + Ps], uqc, nuqc), ...);     // col[p] -= U[q][p] U[q][c]   (entries p > c are never used)
+}
+
+// pivot Q of the 6x6 Cholesky on lanes 0..5 (lane c owns column c of U = L^T): all cross-lane
+// traffic is DPP row_newbcast - one instruction per broadcast on the chain of dependent pivots
+template <int Q>
+__device__ __forceinline__ void bcr_diag_pivot(double (&col)[6], int c, double& di, int& fail) {
+  const double piv = mov_rowbcast<Q>(col[Q]);
+  if (!(piv > 0.0) && !fail) fail = Q + 1;
+  const double inv = rsqrt_nr(piv);
+  if (c == Q) di = inv;
+  const double uqc = c == Q ? piv * inv : (c > Q ? col[Q] * inv : 0.0);
+  col[Q] = uqc;
+  bcr_diag_update<Q>(std::make_integer_sequence<int, 5 - Q>{}, col, uqc, -uqc);
+}
+
+template <int... Qs>
+__device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...>, double (&col)[6], int c, double& di, int& fail) {
+  (bcr_diag_pivot<Qs>(col, c, di, fail), ...);
 }
 
 template <int... Rs>
@@ -267,20 +301,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
       for (int p = 0; p < 6; ++p) col[p] = G[(k0 + c) * ld + k0 + p];      // A[p][c] from the lower triangle
       int fail = 0;
       double di = 0.0;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const double piv = lane_bcast(col[q], q);
-        if (!(piv > 0.0) && !fail) fail = q + 1;
-        const double inv = rsqrt_nr(piv);
-        if (c == q) di = inv;
-        const double uqc = c == q ? piv * inv : (c > q ? col[q] * inv : 0.0);
-        col[q] = uqc;
-#pragma unroll
-        for (int p = q + 1; p < 6; ++p) {
-          const double uqp = lane_bcast(uqc, p);
-          if (p <= c) col[p] -= uqp * uqc;
-        }
-      }
+      bcr_diag_pivots(std::make_integer_sequence<int, 6>{}, col, c, di, fail);
       if (fail && tid == 0) *bad = k0 + fail;
       if (tid < 6) {
         dinv[k0 + c] = di;
