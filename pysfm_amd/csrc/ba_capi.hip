@@ -64,9 +64,12 @@ struct ba_handle {
   int nunits = 0;
   DevBuf<SchurChunk> chunks;
   int nchunks = 0, schur_wn = 0;
-  DevBuf<SchurGroup> groups;
-  DevBuf<SchurChunk> gchunks;
+  DevBuf<SchurGroup> groups, mgroups;
+  DevBuf<SchurChunk> gchunks, mchunks;
+  int nmchunks = 0;
+  bool groups_ascending = false;
   int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
+  int group_maxL = 0;                   // longest track (k_schur_groups_mfma takes <= kGmMaxL)
   DevBuf<int> cam_perm;
   DevBuf<CamUnit> cam_units;
   int ncam_units = 0;
@@ -343,7 +346,7 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->gchunks.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
@@ -475,39 +478,59 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   // Groups for k_schur_groups: runs of consecutive points with identical observation lists
   // (all tracks must have at most kGroupMaxL observations), cut at kGroupMaxPts points,
   // chunked kGroupChunk at a time under the same LDS-window rule as above.
-  std::vector<SchurGroup> groups;
-  std::vector<SchurChunk> gchunks;
+  std::vector<SchurGroup> groups, mgroups;           // vector kernel: <= kGroupMaxPts points; MFMA kernel: longer runs
+  std::vector<SchurChunk> gchunks, mchunks;          // kGroupChunk groups per workgroup (vector kernel) / kGmChunk (MFMA kernel)
   int group_rounds = 0;
+  bool groups_ascending = true;                      // optimised positions ascend along every track
   if (maxL >= 1 && maxL <= kGroupMaxL && wn > 0) {
-    std::vector<int> glo, ghi;
-    for (int k = 0; k < nt;) {
-      const int L = off[(size_t)k + 1] - off[k];
-      if (L == 0) { ++k; continue; }
-      int e = k + 1;
-      while (e < nt && e - k < kGroupMaxPts && off[(size_t)e + 1] - off[e] == L &&
-             std::equal(obs_cam + off[k], obs_cam + off[k] + L, obs_cam + off[e]))
-        ++e;
-      int lo = INT32_MAX, hi = -1;
-      for (int n = off[k]; n < off[k] + L; ++n) {
-        const int p = cam_opt_pos[obs_cam[n]];
-        if (p >= 0) { lo = std::min(lo, p); hi = std::max(hi, p); }
+    auto build_groups = [&](int max_pts, std::vector<SchurGroup>& gs, std::vector<int>& glo, std::vector<int>& ghi) {
+      for (int k = 0; k < nt;) {
+        const int L = off[(size_t)k + 1] - off[k];
+        if (L == 0) { ++k; continue; }
+        int e = k + 1;
+        while (e < nt && e - k < max_pts && off[(size_t)e + 1] - off[e] == L &&
+               std::equal(obs_cam + off[k], obs_cam + off[k] + L, obs_cam + off[e]))
+          ++e;
+        int lo = INT32_MAX, hi = -1;
+        for (int n = off[k]; n < off[k] + L; ++n) {
+          const int p = cam_opt_pos[obs_cam[n]];
+          if (p >= 0) {
+            if (p <= hi) groups_ascending = false;
+            lo = std::min(lo, p); hi = std::max(hi, p);
+          }
+        }
+        gs.push_back({k, e, L, 0});
+        glo.push_back(lo); ghi.push_back(hi);
+        k = e;
       }
-      groups.push_back({k, e, L, 0});
-      glo.push_back(lo); ghi.push_back(hi);
-      k = e;
-    }
-    int begin = 0, lo = INT32_MAX, hi = -1;
-    for (int g = 0; g < (int)groups.size(); ++g) {
-      const int nlo = std::min(lo, glo[g]), nhi = std::max(hi, ghi[g]);
-      const bool fits = nhi < 0 || nhi - nlo + 1 <= wn;
-      if (g > begin && (!fits || g - begin >= kGroupChunk)) {
-        gchunks.push_back({begin, g, lo == INT32_MAX ? 0 : lo});
-        begin = g; lo = glo[g]; hi = ghi[g];
-      } else {
-        lo = nlo; hi = nhi;
+    };
+    auto chunk_groups = [&](int limit, const std::vector<SchurGroup>& gs, const std::vector<int>& glo, const std::vector<int>& ghi,
+                            std::vector<SchurChunk>& out) {
+      int begin = 0, lo = INT32_MAX, hi = -1;
+      for (int g = 0; g < (int)gs.size(); ++g) {
+        const int nlo = std::min(lo, glo[g]), nhi = std::max(hi, ghi[g]);
+        const bool fits = nhi < 0 || nhi - nlo + 1 <= wn;
+        if (g > begin && (!fits || g - begin >= limit)) {
+          out.push_back({begin, g, lo == INT32_MAX ? 0 : lo});
+          begin = g; lo = glo[g]; hi = ghi[g];
+        } else {
+          lo = nlo; hi = nhi;
+        }
       }
-    }
-    if (!groups.empty()) gchunks.push_back({begin, (int)groups.size(), lo == INT32_MAX ? 0 : lo});
+      if (!gs.empty()) out.push_back({begin, (int)gs.size(), lo == INT32_MAX ? 0 : lo});
+    };
+    std::vector<int> glo, ghi, mlo, mhi;
+    build_groups(kGroupMaxPts, groups, glo, ghi);
+    chunk_groups(kGroupChunk, groups, glo, ghi, gchunks);
+    // MFMA kernel: one group per wavefront, and its epilogue (LDS atomics) is expensive, so runs are cut
+    // only where the chip would otherwise idle: about one group per wavefront slot (4 per CU)
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+    const int slots = std::max(1, ncu * (kGmBlock / kWave));
+    int cap = std::max(kGroupMaxPts, (int)((5 * ((nt + slots - 1) / slots) / 4 + kGmPts - 1) / kGmPts * kGmPts));
+    if (const char* e = getenv("BA_GM_CAP")) cap = std::max(kGmPts, atoi(e));     // tuning aid
+    build_groups(cap, mgroups, mlo, mhi);
+    chunk_groups(kGmChunk, mgroups, mlo, mhi, mchunks);
     // worth it only when points really share camera lists
     const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
     if (mean_group >= 2.0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
@@ -525,7 +548,10 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->nchunks = (int)chunks.size();
   h->schur_wn = wn;
   h->ngchunks = (int)gchunks.size();
+  h->nmchunks = (int)mchunks.size();
+  h->groups_ascending = groups_ascending;
   h->group_rounds = group_rounds;
+  h->group_maxL = maxL;
   h->ncam_units = (int)cam_units.size();
 
   HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, nobs)));
@@ -540,6 +566,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     HIPCHECK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->groups.resize(std::max<size_t>(1, groups.size())));
   HIPCHECK(h, h->gchunks.resize(std::max<size_t>(1, gchunks.size())));
+  HIPCHECK(h, h->mchunks.resize(std::max<size_t>(1, mchunks.size())));
+  HIPCHECK(h, h->mgroups.resize(std::max<size_t>(1, mgroups.size())));
+  if (!mgroups.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->mgroups.p, mgroups.data(), mgroups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
+  if (!mchunks.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->mchunks.p, mchunks.data(), mchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   if (!groups.empty()) {
     HIPCHECK(h, hipMemcpyAsync(h->groups.p, groups.data(), groups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
@@ -829,8 +861,22 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   const char* force_schur = getenv("BA_SCHUR");          // "pairs" / "groups": pick the reduction kernel (tests)
   const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
   const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
+  const bool mfma_possible = groups_possible && h->group_maxL >= 1 && h->group_maxL <= kGmMaxL && h->groups_ascending && h->nmchunks > 0;
+  const bool use_mfma = force_schur ? (strcmp(force_schur, "mfma") == 0 && mfma_possible) : (groups_ok && mfma_possible);
   const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
-  if (use_groups) {
+  if (use_mfma) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    const int NW = kGmBlock / kWave;
+    const size_t lds = (size_t)NW * 2 * kGmK * kGmLd * sizeof(double) + (size_t)NW * 16 * sizeof(int) +
+                       (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
+    static bool attr_m = false;
+    if (!attr_m) {
+      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_m = true;
+    }
+    hipLaunchKernelGGL(k_schur_groups_mfma, dim3(h->nmchunks), dim3(kGmBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                       h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+  } else if (use_groups) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kGroupBlock / kWave;
     const size_t lds = (size_t)NW * 64 * 24 * sizeof(double) + (size_t)NW * 16 * sizeof(int) +

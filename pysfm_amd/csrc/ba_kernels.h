@@ -730,6 +730,238 @@ __global__ __launch_bounds__(kGroupBlock) void k_schur_groups(DevProblem P, cons
 }
 
 // --------------------------------------------------------------------------
+// The group reduction on the fp64 matrix cores, for track lengths <= 10 (a group's cameras span
+// at most 60 rows of the reduced system: a 64 x 64 window = 4 x 4 MFMA tiles).
+// For the points k of a group,
+//     S_window -= sum_k Tstack_k Wstack_k^T ,   Tstack_k = [W_1k A_k; ...; W_Lk A_k]  (6L x 3)
+// is ONE matrix product with inner dimension 3 * (#points): per batch of 6 points (K = 18, padded
+// to 20) a wavefront
+//   phase A  linearises one observation per lane (60 lanes), forms W and T = W HPPinv, stages
+//            them K-major in LDS ([k][row], row = 6 * observation + a), and adds T bP to b;
+//   phase B  runs 5 k-steps x 10 upper tiles of v_mfma_f64_16x16x4_f64 with the accumulators
+//            (10 tiles x 4 doubles) living in registers across the whole group.
+// The vector version spends 42 LDS reads and 162 FMA instructions per (pair, point); here a
+// batch costs 40 LDS reads and 50 MFMAs per wavefront.  Epilogue and window logic as above.
+// --------------------------------------------------------------------------
+constexpr int kGmBlock = 256;                          // 4 wavefronts per workgroup (20 KB of staging each)
+constexpr int kGmMaxL = 10;
+constexpr int kGmChunk = 4;                            // groups per workgroup: one per wavefront
+constexpr int kGmPts = 6;                              // points per batch
+constexpr int kGmK = 20;                               // staged k rows: 3 per point, two zero rows
+constexpr int kGmLd = 64;                              // staged row length (60 used)
+
+__global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, const double* __restrict__ cams,
+                                                                const double* __restrict__ X,
+                                                                const SchurGroup* __restrict__ groups,
+                                                                const SchurChunk* __restrict__ chunks, int wn,
+                                                                const double* __restrict__ HPPinv,
+                                                                const double* __restrict__ bP,
+                                                                double* __restrict__ S, double* __restrict__ b) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  constexpr int NW = kGmBlock / kWave;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* sT = dyn;                                   // [NW][kGmK][kGmLd]
+  double* sWm = sT + NW * kGmK * kGmLd;               // [NW][kGmK][kGmLd]
+  int* sPos = reinterpret_cast<int*>(sWm + NW * kGmK * kGmLd);   // [NW][16]
+  double* tile = reinterpret_cast<double*>(sPos + NW * 16);
+  const int hb1 = P.hb + 1;
+  const int rowlen = hb1 * 36;
+  double* tb = tile + (size_t)wn * rowlen;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const SchurChunk ck = chunks[blockIdx.x];
+  const int p0 = ck.p0;
+  for (int i = threadIdx.x; i < wn * (rowlen + 6); i += kGmBlock) tile[i] = 0.0;
+  double* mT = sT + wv * kGmK * kGmLd;
+  double* mW = sWm + wv * kGmK * kGmLd;
+  int* mPos = sPos + wv * 16;
+  for (int i = lane; i < kGmK * kGmLd; i += 64) { mT[i] = 0.0; mW[i] = 0.0; }     // incl. the two zero k rows
+  __syncthreads();
+  // column of this lane in each of the 4 column tiles: observation j = n / 6, entry c = n % 6;
+  // row of accumulator register v of row tile ti: m = 16 ti + lane/16 + 4 v -> observation i, entry a
+  int jn[4], cn[4], im[16], am[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const int n = 16 * t + lr; jn[t] = n / 6; cn[t] = n - 6 * jn[t]; }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) { const int m = 16 * (t >> 2) + lk + 4 * (t & 3); im[t] = m / 6; am[t] = m - 6 * im[t]; }
+
+  for (int g = ck.begin + wv; g < ck.end; g += NW) {       // wave-uniform
+    const SchurGroup gr = groups[g];
+    const int L = gr.L;
+    const int NP = 64 / L < kGmPts ? 64 / L : kGmPts;
+    const int nts = (6 * L + 15) >> 4;                     // tiles per side that hold real rows
+    if (lane < 16) mPos[lane] = lane < L ? P.cam_opt_pos[P.obs_cam[P.pt_off[gr.pt_begin] + lane]] : -1;
+    lds_wave_sync();
+    mfma_acc acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+    double bacc[6] = {0, 0, 0, 0, 0, 0};
+    const int slot = lane / L, oi = lane - slot * L;          // phase A role: (staged point, observation)
+    const bool stager = lane < NP * L;
+    const int mypos = stager ? mPos[oi] : -1;
+    // every point of the group sees the same cameras: this lane's camera is loaded once per group,
+    // and its observations sit at a fixed stride (all tracks of the group have L observations)
+    const int n0 = P.pt_off[gr.pt_begin] + oi;
+    double cm[12];
+    {
+      const int c = P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]];
+      load_cam(cams, c, cm);
+    }
+    // per-point inputs of the NEXT batch are fetched while the matrix cores work on this one
+    struct PointIn { double x[3], A[6], g[3]; double2 z; };
+    auto fetch = [&](int kb_, PointIn& in) {
+      const int k = kb_ + slot;
+      if (stager && k < gr.pt_end) {
+        in.z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { in.x[q] = X[3 * (size_t)k + q]; in.g[q] = bP[3 * (size_t)k + q]; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) in.A[q] = HPPinv[6 * (size_t)k + q];
+      }
+    };
+    PointIn nxt;
+    fetch(gr.pt_begin, nxt);
+
+#ifdef BA_BCR_PROFILE
+    long long tA = 0, tB = 0, ta0_first = 0; const long long tg0 = clock64();
+#endif
+    for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+      const int np = min(NP, gr.pt_end - kb);
+      const PointIn cur = nxt;
+#ifdef BA_BCR_PROFILE
+      const long long ta0 = clock64();
+      if (kb == gr.pt_begin) ta0_first = ta0;
+#endif
+      // ---- phase A
+      if (stager) {
+        double W[18], T[18];
+        if (slot < np) {
+          double e[2], r[2], Jc[12], Jp[6];
+          obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
+          block_W(Jc, Jp, W);
+          block_T(W, cur.A, T);
+          if (mypos >= 0) {                                   // b[i] -= T_i bP_k
+#pragma unroll
+            for (int a = 0; a < 6; ++a) bacc[a] -= T[a * 3] * cur.g[0] + T[a * 3 + 1] * cur.g[1] + T[a * 3 + 2] * cur.g[2];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 18; ++q) { W[q] = 0.0; T[q] = 0.0; }     // a short last batch: zero k rows
+        }
+        const int so = 3 * slot * kGmLd + 6 * oi;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { mT[so + d * kGmLd + a] = T[a * 3 + d]; mW[so + d * kGmLd + a] = W[a * 3 + d]; }
+      }
+      fetch(kb + NP, nxt);
+      lds_wave_sync();
+#ifdef BA_BCR_PROFILE
+      const long long tb0 = clock64(); tA += tb0 - ta0;
+#endif
+      // ---- phase B: acc(ti, tj) += T[rows of ti][k] W[rows of tj][k]
+#pragma unroll
+      for (int s4 = 0; s4 < kGmK / 4; ++s4) {
+        double ta[4], wb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ta[t] = mT[(4 * s4 + lk) * kGmLd + 16 * t + lr];
+          wb[t] = mW[(4 * s4 + lk) * kGmLd + 16 * t + lr];
+        }
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int tj = ti; tj < 4; ++tj, ++q)
+            if (tj < nts) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ti], wb[tj], acc[q], 0, 0, 0);
+      }
+      lds_wave_sync();
+#ifdef BA_BCR_PROFILE
+      tB += clock64() - tb0;
+#endif
+    }
+#ifdef BA_BCR_PROFILE
+    const long long te0 = clock64();
+#endif
+    // ---- epilogue: C/D layout lane -> column n = 16 tj + lane%16, register v -> row m = 16 ti + lane/16 + 4 v.
+    // Positions ascend along a track (checked on the host), so block (i, j), i <= j, lives at
+    // row pos_i, offset (pos_j - pos_i) * 36 + a * 6 + c: the address splits into a row part and a
+    // column part, and the LDS window test depends on the row alone.
+    {
+      int colpart[4], pjv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        pjv[t] = jn[t] < L ? mPos[jn[t]] : -1;
+        colpart[t] = pjv[t] * 36 + cn[t];
+      }
+      int q = 0;
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        int rowpart[4], pim[4];
+        bool inwin[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i = im[4 * ti + v];
+          const int pi = i < L ? mPos[i] : -1;
+          const int wr = pi - p0;
+          pim[v] = pi;
+          inwin[v] = wr >= 0 && wr < wn;
+          rowpart[v] = (inwin[v] ? wr * rowlen : pi * rowlen) - pi * 36 + am[4 * ti + v] * 6;
+        }
+#pragma unroll
+        for (int tj = ti; tj < 4; ++tj, ++q) {
+          if (tj >= nts) continue;
+          const int j = jn[tj], c = cn[tj];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int i = im[4 * ti + v], a = am[4 * ti + v];
+            const bool ok = pim[v] >= 0 && pjv[tj] >= 0 && (i < j || (i == j && a <= c));
+            if (ok) {
+              const double val = -acc[q][v];
+              const int off = rowpart[v] + colpart[tj];
+              const int mir = off + 5 * (c - a);               // entry (c, a) of the same block
+              if (inwin[v]) {
+                atomic_add_f64(tile + off, val);
+                if (i == j && a < c) atomic_add_f64(tile + mir, val);     // diagonal blocks are stored in full
+              } else {
+                atomic_add_f64(S + off, val);
+                if (i == j && a < c) atomic_add_f64(S + mir, val);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (mypos >= 0) {
+      const int wr = mypos - p0;
+      double* dst = (wr >= 0 && wr < wn) ? tb + wr * 6 : b + (size_t)mypos * 6;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) atomic_add_f64(dst + a, bacc[a]);
+    }
+    lds_wave_sync();                                        // mPos is rewritten by the next group
+#ifdef BA_BCR_PROFILE
+    if (blockIdx.x == 100 && wv == 0 && lane == 0 && g == ck.begin) {
+      long long* dbg = reinterpret_cast<long long*>(S + (size_t)P.nco * rowlen + 6 * P.nco);   // scratch behind [S | b] (profile builds only)
+      (void)dbg;
+      printf("[k_schur_groups_mfma] group of %d points: setup %lld, phase A %lld, phase B %lld, epilogue %lld cycles\n",
+             gr.pt_end - gr.pt_begin, ta0_first - tg0, tA, tB, clock64() - te0);
+    }
+#endif
+  }
+  if (wn == 0) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < wn * rowlen; i += kGmBlock) {
+    const double v = tile[i];
+    const int wr = i / rowlen;
+    if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
+  }
+  for (int i = threadIdx.x; i < wn * 6; i += kGmBlock) {
+    const double v = tb[i];
+    if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
+  }
+}
+
+// --------------------------------------------------------------------------
 // backsubstitute (bundle_adjuster.py:316-331):
 //   dP_k = HPPinv_k (bP_k - sum_i W_ik^T dC_i),  W^T dC = Jp^T (Jc dC).
 // dC[nco*6] is indexed by optimised-camera position; frozen cameras contribute nothing.

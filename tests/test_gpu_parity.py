@@ -509,7 +509,8 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, monkeypatch, nc, L):
                                          (26, 13, O.Sensor.huber(.06)), (60, 7, O.Sensor.gaussian(1.))])
 def test_group_reduction_kernel_equals_pair_kernel(be, monkeypatch, nc, L, sensor):
     """k_schur_groups (register accumulation over runs of points with identical camera
-    lists; 1 and 2 pair rounds) against k_schur_pairs and the oracle, also with groups
+    lists; 1 and 2 pair rounds) and k_schur_groups_mfma (the same groups on the fp64 matrix
+    cores, track length <= 10) against k_schur_pairs and the oracle, also with groups
     broken up by dropped observations and frozen cameras in the middle of the sequence."""
     s = banded(nc, 40 * nc, track_len=L, outlier_frac=.05)
     keep = np.ones(len(s['obs_cam']), bool)
@@ -522,7 +523,7 @@ def test_group_reduction_kernel_equals_pair_kernel(be, monkeypatch, nc, L, senso
     a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
     load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
     out = {}
-    for kern in ('pairs', 'groups'):
+    for kern in ('pairs', 'groups', 'mfma'):                 # 'mfma' falls back to pairs when L > 10
         monkeypatch.setenv('BA_SCHUR', kern)
         be.linearize(0)
         be.schur(0, 3., 1e-5)
@@ -530,6 +531,8 @@ def test_group_reduction_kernel_equals_pair_kernel(be, monkeypatch, nc, L, senso
     monkeypatch.delenv('BA_SCHUR')
     close(out['groups'][0], out['pairs'][0], 1e-12)
     close(out['groups'][1], out['pairs'][1], 1e-12)
+    close(out['mfma'][0], out['pairs'][0], 1e-12)
+    close(out['mfma'][1], out['pairs'][1], 1e-12)
     mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=3., return_parts=True)
     close(out['groups'][0], parts['S'], TIGHT)
     close(out['groups'][1], parts['b'], TIGHT)
