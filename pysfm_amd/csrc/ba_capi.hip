@@ -54,6 +54,11 @@ struct ba_handle {
   bool have_problem = false;
   bool have_params[2] = {false, false};
   bool have_linearization = false, have_schur = false, have_backsub = false;
+  int lin_phys = 0;                  // physical parameter set of the linearisation
+  bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
+  bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)
+  double inv_damping = 0.0, inv_rcond = 0.0;
+  bool fuse_trial = false;           // inside ba_lm_trial with the MFMA reduction: camera blocks + point inverses ride along
   int glog = 0;              // lanes per point = 2^glog
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0};
@@ -770,26 +775,17 @@ int ba_eval_sensor(ba_handle* h, int64_t n, const double* e, double* r, double* 
   return BA_OK;
 }
 
-int ba_linearize(ba_handle* h, int which, int store_W) {
-  if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_linearize: bad parameter set");
-  const int p = h->phys(which);
-  REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_linearize: set problem and parameters first");
-  HIPCHECK(h, hipSetDevice(h->device));
-  double* Wd = nullptr;
-  if (store_W) {
-    HIPCHECK(h, h->W.resize(std::max<size_t>(1, (size_t)h->nobs * 18)));
-    Wd = h->W.p;
-  }
-  if (h->nt == 0) {     // otherwise k_linearize clears them
+namespace {
+
+bool mfma_reduction_possible(const ba_handle* h) {
+  return h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL >= 1 && h->group_maxL <= kGmMaxL && h->groups_ascending &&
+         h->nmchunks > 0;
+}
+
+int launch_camera_blocks(ba_handle* h, int p, bool clear) {
+  if (clear) {
     HIPCHECK(h, hipMemsetAsync(h->HCC.p, 0, (size_t)h->nc * 36 * sizeof(double), h->stream));
     HIPCHECK(h, hipMemsetAsync(h->bC.p, 0, (size_t)h->nc * 6 * sizeof(double), h->stream));
-  }
-  if (h->nt > 0) {
-    ScopedTimer tm(h, BA_K_LINEARIZE);
-    const long long threads = (long long)h->nt << h->glog;
-    hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
-                       h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd);
   }
   if (h->ncam_units > 0) {
     ScopedTimer tm(h, BA_K_CAMERA_BLOCKS);
@@ -798,16 +794,64 @@ int ba_linearize(ba_handle* h, int which, int store_W) {
                        dev_problem(h), h->cams[p].p, h->X[p].p, h->cam_perm.p, h->cam_units.p, h->ncam_units, h->HCC.p,
                        h->bC.p);
   }
+  h->cam_blocks_valid = true;
+  return BA_OK;
+}
+
+// ba_linearize; with fuse (ba_lm_trial + MFMA reduction) the point inverses for (damping, rcond) are
+// produced by the same kernel and the camera blocks are left to k_schur_groups_mfma
+int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double damping, double rcond) {
+  const int p = h->phys(which);
+  HIPCHECK(h, hipSetDevice(h->device));
+  double* Wd = nullptr;
+  if (store_W) {
+    HIPCHECK(h, h->W.resize(std::max<size_t>(1, (size_t)h->nobs * 18)));
+    Wd = h->W.p;
+  }
+  fuse = fuse && h->nt > 0;
+  h->inv_valid = false;
+  // The point inverses could ride along in k_linearize too, but only one lane in 2^glog holds a point there:
+  // the 3x3 eigen-solve at 1/16 lane occupancy costs 55 us where the dense k_point_invert costs 9 (measured).
+  const bool fuse_inv = false;
+  if (fuse_inv) h->sing_epoch ^= 1;    // the fused inversion counts singular blocks like k_point_invert does
+  if (h->nt > 0) {
+    ScopedTimer tm(h, BA_K_LINEARIZE);
+    const long long threads = (long long)h->nt << h->glog;
+    hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
+                       h->cams[p].p, h->X[p].p, h->glog, fuse ? (double*)nullptr : h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd,
+                       damping, rcond, fuse_inv ? h->HPPinv.p : (double*)nullptr, h->sing_counter(),
+                       h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+  }
+  h->cam_blocks_valid = false;
+  if (fuse_inv) { h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = rcond; }
+  if (!fuse) {
+    int rc = launch_camera_blocks(h, p, h->nt == 0);      // k_linearize cleared HCC / bC otherwise
+    if (rc != BA_OK) return rc;
+  }
   HIPCHECK(h, hipGetLastError());
   h->have_linearization = true;
+  h->lin_phys = p;
   h->have_schur = h->have_backsub = false;
   return BA_OK;
+}
+
+}  // namespace
+
+int ba_linearize(ba_handle* h, int which, int store_W) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_linearize: bad parameter set");
+  REQUIRE(h, h->have_problem && h->have_params[h->phys(which)], BA_ERR_STATE, "ba_linearize: set problem and parameters first");
+  return linearize_impl(h, which, store_W, false, 0.0, 0.0);
 }
 
 int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP, double* W) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_linearization, BA_ERR_STATE, "ba_get_blocks: call ba_linearize first");
   HIPCHECK(h, hipSetDevice(h->device));
+  if ((HCC || bC) && !h->cam_blocks_valid) {       // ba_lm_trial left them to the reduction kernel
+    int rc = launch_camera_blocks(h, h->lin_phys, true);
+    if (rc != BA_OK) return rc;
+  }
   std::vector<double> hpp6;
   if (HCC && h->nc) HIPCHECK(h, hipMemcpyAsync(HCC, h->HCC.p, (size_t)h->nc * 36 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (bC && h->nc) HIPCHECK(h, hipMemcpyAsync(bC, h->bC.p, (size_t)h->nc * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -844,11 +888,28 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   HIPCHECK(h, hipSetDevice(h->device));
   int rc = ensure_reduced(h);
   if (rc != BA_OK) return rc;
-  h->sing_epoch ^= 1;       // this call counts singular blocks in sing_counter(); the kernel clears the other one
-  if (h->nt > 0) {
+  const char* force_schur = getenv("BA_SCHUR");          // "pairs" / "groups" / "mfma": pick the reduction kernel (tests)
+  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
+  const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
+  const bool mfma_possible = mfma_reduction_possible(h);
+  const bool use_mfma = force_schur ? (strcmp(force_schur, "mfma") == 0 && mfma_possible) : (groups_ok && mfma_possible);
+  const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
+  // camera blocks: normally in HCC / bC (k_camera_blocks); ba_lm_trial leaves them to the MFMA reduction
+  const bool fuse_cam = use_mfma && !h->cam_blocks_valid;
+  if (!h->cam_blocks_valid && !fuse_cam) {
+    rc = launch_camera_blocks(h, h->lin_phys, true);
+    if (rc != BA_OK) return rc;
+  }
+  const bool have_inv = h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond;
+  h->inv_valid = false;
+  if (have_inv) {
+    h->inv_valid = true;    // k_linearize already inverted the damped point blocks for this (damping, rcond)
+  } else if (h->nt > 0) {
+    h->sing_epoch ^= 1;     // this call counts singular blocks in sing_counter(); the kernel clears the other one
     ScopedTimer tm(h, BA_K_POINT_INVERT);
     hipLaunchKernelGGL(k_point_invert, dim3(blocks_for(h->nt)), dim3(kBlock), 0, h->stream, h->nt, h->HPP.p,
                        damping, pinv_rcond, h->HPPinv.p, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+    h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
   } else {
     HIPCHECK(h, hipMemsetAsync(h->flags.p + 40, 0, 2 * sizeof(int), h->stream));
   }
@@ -856,14 +917,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     ScopedTimer tm(h, BA_K_SCHUR_INIT);       // clears the band and writes the damped diagonal + b in one pass
     const long long n = (long long)reduced_doubles(h) + (long long)h->nco * 6;
     hipLaunchKernelGGL(k_schur_init, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, h->opt_cam.p,
-                       h->HCC.p, h->bC.p, damping, h->S, h->b);
+                       h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
   }
-  const char* force_schur = getenv("BA_SCHUR");          // "pairs" / "groups": pick the reduction kernel (tests)
-  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
-  const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
-  const bool mfma_possible = groups_possible && h->group_maxL >= 1 && h->group_maxL <= kGmMaxL && h->groups_ascending && h->nmchunks > 0;
-  const bool use_mfma = force_schur ? (strcmp(force_schur, "mfma") == 0 && mfma_possible) : (groups_ok && mfma_possible);
-  const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
   if (use_mfma) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kGmBlock / kWave;
@@ -875,7 +930,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
       attr_m = true;
     }
     hipLaunchKernelGGL(k_schur_groups_mfma, dim3(h->nmchunks), dim3(kGmBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
-                       h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+                       h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
   } else if (use_groups) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kGroupBlock / kWave;
@@ -1149,7 +1204,11 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   h->defer = true;
   double unused = 0.0;
   int32_t pre = 0;
-  int rc = ba_linearize(h, BA_PARAMS_CUR, 0);
+  // with the MFMA reduction the point inverses come out of k_linearize and the camera blocks out of the
+  // reduction itself: two launches and two passes over the observations less
+  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
+  const bool fuse = !getenv("BA_SCHUR") && !getenv("BA_NO_FUSE") && groups_ok && mfma_reduction_possible(h);
+  int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_solve_reduced(h, cam_param_mask, &pre);
   if (rc == BA_OK && pre != 0) { h->defer = false; *info = pre; return BA_OK; }   // band too wide: caller takes the dense path

@@ -234,7 +234,9 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
                                                       const double* __restrict__ X, int glog,
                                                       double* __restrict__ HCC, double* __restrict__ bC,
                                                       double* __restrict__ HPP, double* __restrict__ bP,
-                                                      double* __restrict__ Wout) {
+                                                      double* __restrict__ Wout, double damping, double rcond,
+                                                      double* __restrict__ HPPinv, int* __restrict__ singular_count,
+                                                      int* __restrict__ next_count) {
   const int G = 1 << glog;
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   // HCC / bC are accumulated with atomics by k_camera_blocks, which runs next: clear them here
@@ -282,11 +284,24 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
 #pragma unroll
     for (int i = 0; i < 3; ++i) bp[i] += __shfl_xor(bp[i], m, 64);
   }
+  if (HPPinv && tid == 0) *next_count = 0;       // as k_point_invert: the counter the NEXT inversion will use
   if (valid && l == 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) HPP[6 * k + i] = hpp[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) bP[3 * k + i] = bp[i];
+    if (HPPinv) {                                  // ba_lm_trial: k_point_invert's work rides along (one launch less)
+      double out[6];
+      const double f = 1.0 + damping;
+      hpp[0] *= f; hpp[3] *= f; hpp[5] *= f;
+      if (rcond >= 0.0) {
+        sym3_pinv(hpp, rcond, out);
+      } else if (!sym3_inv(hpp, out)) {
+        atomicAdd(singular_count, 1);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) HPPinv[6 * k + i] = out[i];
+    }
   }
 }
 
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* _
 __global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const int* __restrict__ opt_cam,
                                                        const double* __restrict__ HCC,
                                                        const double* __restrict__ bC, double damping,
-                                                       double* __restrict__ S, double* __restrict__ b) {
+                                                       double* __restrict__ S, double* __restrict__ b, int use_hcc) {
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   const long long nS = (long long)nco * hb1 * 36;
   if (tid < nS) {
@@ -387,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const i
     const long long blk = tid / 36;
     const int d = (int)(blk % hb1), pos = (int)(blk / hb1);
     double v = 0.0;
-    if (d == 0) {
+    if (d == 0 && use_hcc) {                     // (the MFMA reduction can add the camera blocks itself)
       const int a = e / 6, c = e % 6;
       const int lo = a < c ? a : c, hi = a < c ? c : a;
       v = HCC[(size_t)opt_cam[pos] * 36 + lo * 6 + hi];
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const i
     S[tid] = v;
   } else if (tid < nS + (long long)nco * 6) {
     const long long q = tid - nS;
-    b[q] = bC[(size_t)opt_cam[q / 6] * 6 + q % 6];
+    b[q] = use_hcc ? bC[(size_t)opt_cam[q / 6] * 6 + q % 6] : 0.0;
   }
 }
 
@@ -756,7 +771,8 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
                                                                 const SchurChunk* __restrict__ chunks, int wn,
                                                                 const double* __restrict__ HPPinv,
                                                                 const double* __restrict__ bP,
-                                                                double* __restrict__ S, double* __restrict__ b) {
+                                                                double* __restrict__ S, double* __restrict__ b,
+                                                                double damping, int fuse_cam) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   constexpr int NW = kGmBlock / kWave;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -796,6 +812,9 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
     double bacc[6] = {0, 0, 0, 0, 0, 0};
+    double hc[21];                                            // fuse_cam: this lane's share of HCC (upper triangle)
+#pragma unroll
+    for (int q = 0; q < 21; ++q) hc[q] = 0.0;
     const int slot = lane / L, oi = lane - slot * L;          // phase A role: (staged point, observation)
     const bool stager = lane < NP * L;
     const int mypos = stager ? mPos[oi] : -1;
@@ -843,6 +862,15 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
           if (mypos >= 0) {                                   // b[i] -= T_i bP_k
 #pragma unroll
             for (int a = 0; a < 6; ++a) bacc[a] -= T[a * 3] * cur.g[0] + T[a * 3 + 1] * cur.g[1] + T[a * 3 + 2] * cur.g[2];
+            if (fuse_cam) {                                   // HCC[i] += Jc^T Jc, b[i] += Jc^T r (k_camera_blocks' work)
+              int idx = 0;
+#pragma unroll
+              for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int c2 = a; c2 < 6; ++c2) hc[idx++] += Jc[a] * Jc[c2] + Jc[6 + a] * Jc[6 + c2];
+                bacc[a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+              }
+            }
           }
         } else {
 #pragma unroll
@@ -934,9 +962,33 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
     }
     if (mypos >= 0) {
       const int wr = mypos - p0;
-      double* dst = (wr >= 0 && wr < wn) ? tb + wr * 6 : b + (size_t)mypos * 6;
+      const bool in = wr >= 0 && wr < wn;
+      // (separate LDS / global code paths: a pointer select would turn these into slow flat atomics)
+      if (in) {
 #pragma unroll
-      for (int a = 0; a < 6; ++a) atomic_add_f64(dst + a, bacc[a]);
+        for (int a = 0; a < 6; ++a) atomic_add_f64(tb + wr * 6 + a, bacc[a]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) atomic_add_f64(b + (size_t)mypos * 6 + a, bacc[a]);
+      }
+      if (fuse_cam) {                                       // damped camera block onto the diagonal block (stored in full)
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c2 = a; c2 < 6; ++c2) {
+            const double v = a == c2 ? hc[idx] * (1.0 + damping) : hc[idx];
+            ++idx;
+            if (in) {
+              atomic_add_f64(tile + wr * rowlen + a * 6 + c2, v);
+              if (a != c2) atomic_add_f64(tile + wr * rowlen + c2 * 6 + a, v);
+            } else {
+              atomic_add_f64(S + (size_t)mypos * rowlen + a * 6 + c2, v);
+              if (a != c2) atomic_add_f64(S + (size_t)mypos * rowlen + c2 * 6 + a, v);
+            }
+          }
+        }
+      }
     }
     lds_wave_sync();                                        // mPos is rewritten by the next group
 #ifdef BA_BCR_PROFILE
