@@ -35,6 +35,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mfma_f64_16x16x4_f64 measured at 16 FMA/clk/SIMD
+
+
+def schur_flops(nobs, nt):
+    """Useful fp64 flops of one Schur reduction: per point with L observations, L products
+    T = W HPPinv (6x3x3) and L(L+1)/2 block products T W^T (6x3x6), 2 flops per FMA."""
+    L = nobs / max(nt, 1)
+    return nt * (L * 54 + L * (L + 1) / 2 * 108) * 2
 
 
 def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
@@ -86,9 +94,13 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.csv')))
     if not files:
         return None, None
-    for row in csv.DictReader(open(files[-1])):
-        if row['kernel'].split('<')[0].endswith('k_' + kernel):
-            return int(row[[k for k in row if k.startswith('hbm_bytes')][0]]), os.path.basename(files[-1])
+    # the timer id 'schur_pairs' covers the three interchangeable reduction kernels
+    names = ['k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'] if kernel == 'schur_pairs' else ['k_' + kernel]
+    rows = list(csv.DictReader(open(files[-1])))
+    for name in names:
+        for row in rows:
+            if row['kernel'].split('<')[0].endswith(name):
+                return int(row[[k for k in row if k.startswith('hbm_bytes')][0]]), os.path.basename(files[-1])
     return None, None
 
 
@@ -267,7 +279,12 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': B,
                          'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
-                         'note': 'HIP events on the launch stream around every launch of this kernel during the timed steps'},
+                         'note': 'HIP events on the launch stream during the timed steps; back-to-back launches of one kernel (the cyclic-reduction levels) share one event pair, avg = elapsed / launches'},
+            'matrix_cores': {'kernel': 'k_schur_groups_mfma (timer schur_pairs)', 'useful_flops_per_launch': schur_flops(nobs_local, be.nt),
+                             'achieved_tflops': schur_flops(nobs_local, be.nt) / max(1e-9, ours['schur_pairs']['ms'] / max(1, ours['schur_pairs']['launches']) * 1e-3) / 1e12
+                             if 'schur_pairs' in ours else None,
+                             'peak_tflops': FP64_MATRIX_PEAK_TFLOPS,
+                             'note': 'fp64 MFMA is used where the path is GEMM-shaped (Schur reduction, cyclic-reduction nodes); informational'},
             'kernel_ms_per_step': {k: v['ms'] / nprof for k, v in ours.items()},
             'kernel_launches_per_step': {k: v['launches'] / nprof for k, v in ours.items()},
             'all_kernels': {'algorithmic_bytes_per_step': int(sum(

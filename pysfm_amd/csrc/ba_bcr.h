@@ -16,7 +16,11 @@
 // Every Schur complement of an SPD matrix is SPD, so this is the same arithmetic as a
 // Cholesky factorisation in nested-dissection order: results agree with k_band_solve and
 // with the reference's LU to round-off.  A non-positive pivot is reported through *info.
-// All fp64, all blocks dense B x B (B <= 60) in LDS; no MFMA.
+// All fp64, all blocks dense B x B (B <= 60) in LDS.  Inside a node the chain of 6 hb dependent
+// pivots is what cannot be parallelised; everything GEMM-shaped around it (K = 6 updates of the
+// right-hand sides and of the trailing matrix, the three B x B x B neighbour products) runs on
+// the fp64 matrix cores (v_mfma_f64_16x16x4_f64), because the vector forms are bound by LDS
+// reads or by the one-FMA-per-8-cycles issue rate of a wavefront (tools/fma_probe, lds_probe).
 #pragma once
 
 #include "ba_kernels.h"
@@ -81,12 +85,6 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
   }
 }
 
-// acc += (lane K of my 16-lane row of `row`) * y      (v_fmac_f64 with a DPP row_newbcast source)
-template <int K>
-__device__ __forceinline__ void fmac_rowbcast(double& acc, double row, double y) {
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
-}
-
 // value of lane K of my 16-lane row (v_mov_b64 with a DPP row_newbcast source)
 template <int K>
 __device__ __forceinline__ double mov_rowbcast(double v) {
@@ -124,87 +122,10 @@ __device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...
   (bcr_diag_pivot<Qs>(col, c, di, fail), ...);
 }
 
-template <int... Rs>
-__device__ __forceinline__ void bcr_rank1_seq(std::integer_sequence<int, Rs...>, double (&acc)[16], double a, double b) {
-  (fmac_rowbcast<Rs>(acc[Rs], a, b), ...);
-}
-// acc[r] += (lane r of my 16-lane row of a) * b   for r < NR
-template <int NR>
-__device__ __forceinline__ void bcr_rank1(double (&acc)[16], double a, double b) {
-  bcr_rank1_seq(std::make_integer_sequence<int, NR>{}, acc, a, b);
-}
-
-// sum_k (lane k%16 of chunk k/16 of Lc) * y[k] over k < T, split over two accumulators
-// (a wavefront issues one fp64 FMA per ~9 cycles, so two chains cover the ~16-cycle latency)
-template <int NBK, int... Ks>
-__device__ __forceinline__ void bcr_dot_seq(std::integer_sequence<int, Ks...>, const double (&Lc)[(NBK + 15) / 16],
-                                            const double (&y)[NBK], double& a0, double& a1) {
-  (fmac_rowbcast<(Ks & 15)>((Ks & 1) ? a1 : a0, Lc[Ks >> 4], y[Ks]), ...);
-}
-
-// row T of the triangular solve with one nb x nb diagonal block (one right-hand side per lane):
-// y[T] = (x[T] - sum_{k<T} L[T][k] y[k]) / L[T][T].  Lb points at L[r0][r0 + lane%16].
-template <int NBK, int T>
-__device__ __forceinline__ void bcr_tri_row(const double* __restrict__ Lb, int ld, const double* __restrict__ dv,
-                                            double* __restrict__ Xb, int st, double (&y)[NBK],
-                                            double (&Lc)[(NBK + 15) / 16], double& xc, double& dc) {
-  double Ln[(NBK + 15) / 16], xn = 0.0, dn = 0.0;                 // row T+1's inputs, in flight during row T's chain
-  if constexpr (T + 1 < NBK) {
-#pragma unroll
-    for (int j = 0; 16 * j < T + 1; ++j) Ln[j] = Lb[(T + 1) * ld + 16 * j];
-    xn = Xb[(T + 1) * st];
-    dn = dv[T + 1];
-  }
-  double a0 = -xc, a1 = 0.0;
-  bcr_dot_seq<NBK>(std::make_integer_sequence<int, T>{}, Lc, y, a0, a1);
-  y[T] = -(a0 + a1) * dc;
-  Xb[T * st] = y[T];
-  if constexpr (T + 1 < NBK) {
-#pragma unroll
-    for (int j = 0; 16 * j < T + 1; ++j) Lc[j] = Ln[j];
-    xc = xn; dc = dn;
-  }
-}
-
-template <int NBK, int... Ts>
-__device__ __forceinline__ void bcr_tri_rows(std::integer_sequence<int, Ts...>, const double* __restrict__ Lb, int ld,
-                                             const double* __restrict__ dv, double* __restrict__ Xb, int st,
-                                             double (&y)[NBK]) {
-  double Lc[(NBK + 15) / 16], xc = Xb[0], dc = dv[0];
-  (bcr_tri_row<NBK, Ts>(Lb, ld, dv, Xb, st, y, Lc, xc, dc), ...);
-}
-
-// rows [ra, rb) of the update X[i] -= sum_k L[i][r0 + k] y[k] (k < nb) for one right-hand side per lane;
-// Lrow points at L[0][r0 + lane%16].
-template <int NBK>
-__device__ __forceinline__ void bcr_update_rows(const double* __restrict__ Lrow, int ld, double* __restrict__ X, int st,
-                                                int ra, int rb, const double (&y)[NBK]) {
-  constexpr int NJ = (NBK + 15) / 16;
-  if (ra >= rb) return;
-  double Ln[NJ], xn;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) Ln[j] = Lrow[ra * ld + 16 * j];
-  xn = X[ra * st];
-  for (int i = ra; i < rb; ++i) {
-    double Lc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) Lc[j] = Ln[j];
-    double a0 = -xn, a1 = 0.0;
-    const int in = i + 1 < rb ? i + 1 : i;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) Ln[j] = Lrow[in * ld + 16 * j];
-    xn = X[in * st];
-    bcr_dot_seq<NBK>(std::make_integer_sequence<int, NBK>{}, Lc, y, a0, a1);
-    X[i * st] = -(a0 + a1);
-  }
-}
-
 // One elimination level.  blockIdx.x = k-th node of this level: i = s*(2k+1) - 1.
 // Out: Gi[i] = G^-1 (lower triangular), Pm[i] = P, Qm[i] = Q, fm[i] = g; neighbours updated.
-// HB is a template parameter so that the dense B x B (B = 6 HB) pieces unroll: a blocked
-// (6-wide) right-looking Cholesky whose 6x6 diagonal factor runs on one wavefront with
-// v_readlane broadcasts, and a forward substitution that keeps a whole solution column in
-// registers (one thread per right-hand side, L read from LDS as broadcasts).
+// HB is a template parameter so that the dense B x B (B = 6 HB) pieces unroll.  Phases:
+// load -> fused Cholesky + forward substitution (see below) -> neighbour products -> store.
 template <int HB>
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s, double* __restrict__ Dm,
                                                                double* __restrict__ Um, double* __restrict__ fm,
@@ -259,13 +180,13 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   // ---- blocked Cholesky D_i = L L^T (lower, in place, block size 6) FUSED with the forward
   //      substitution L Y = R of the right-hand sides P | Q | I | g (one lane per column), as one
   //      right-looking elimination of the augmented matrix [D_i | R], with one block of look-ahead:
-  //        phase 1  wavefront 0: 6x6 diagonal factor of block kb (v_readlane broadcasts)
-  //                 the others : the LATE part of step kb-1 - trailing update of D right of block
-  //                              column kb (3x3 register tiles) and R_below -= L_panel Y_(kb-1)
-  //                              (L entries as DPP row_newbcast operands, ba: fmac_rowbcast)
-  //        phase 2  panel of block column kb (one row per thread) and Y_kb = L_kk^-1 R_kb
-  //        phase 3  the URGENT part of step kb: update of block column kb+1 only, so that the
-  //                 next diagonal factor can start while the rest of the update is still running
+  //        phase 1  wavefront 0: 6x6 diagonal factor of block kb (DPP row broadcasts)
+  //                 the others : the LATE part of step kb-1 on the matrix cores - trailing update
+  //                              of D right of block column kb and R_below -= L_panel Y_(kb-1)
+  //        phase 2  panel of block column kb (one row per thread)
+  //        phase 3  Y_kb = L_kk^-1 R_kb, and the URGENT part of step kb: update of block column
+  //                 kb+1 only, so that the next diagonal factor can start while the rest of the
+  //                 update is still running
   //      The chain of 6 HB dependent pivots is what bounds this kernel; everything else rides along.
   // wave-uniform values live in SGPRs: every VALU instruction of the 16 wavefronts costs a CU issue slot
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15;

@@ -37,7 +37,7 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-struct TimedLaunch { int id; hipEvent_t a, b; };
+struct TimedLaunch { int id; hipEvent_t a, b; int count; };
 
 }  // namespace
 
@@ -149,7 +149,7 @@ void resolve_timings(ba_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& t : h->pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { h->ms[t.id] += ms; h->launches[t.id] += 1; }
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { h->ms[t.id] += ms; h->launches[t.id] += t.count; }
     h->ev_pool.push_back(t.a);
     h->ev_pool.push_back(t.b);
   }
@@ -157,15 +157,18 @@ void resolve_timings(ba_handle* h) {
 }
 
 struct ScopedTimer {
+  // one event pair around `count` back-to-back launches of the same kernel (the cyclic-reduction levels):
+  // an event pair costs a few microseconds of stream time, seven of them per 0.4 ms step would show
   ba_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;
-  bool on;
-  ScopedTimer(ba_handle* h_, int id_) : h(h_), id(id_), on(h_->timing && ((h_->timing_mask >> id_) & 1ull)) {
+  bool on; int count;
+  ScopedTimer(ba_handle* h_, int id_, int count_ = 1)
+      : h(h_), id(id_), on(h_->timing && ((h_->timing_mask >> id_) & 1ull)), count(count_) {
     if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
   }
   ~ScopedTimer() {
     if (on) {
       (void)hipEventRecord(b, h->stream);
-      h->pending.push_back({id, a, b});
+      h->pending.push_back({id, a, b, count});
       if (h->pending.size() >= 8192) resolve_timings(h);
     }
   }
@@ -274,17 +277,19 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   }
   const size_t lds = bcr_lds_bytes(B);
   std::vector<int> strides;
-  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) {
-    const int cnt = (N / s + 1) / 2;
-    ScopedTimer tm(h, BA_K_BCR_ELIMINATE);
-    HIPCHECK(h, launch_bcr_eliminate(hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
-                                     h->bcrG.p, h->flags.p + 1));
-    strides.push_back(s);
+  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
+  {
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)strides.size());
+    for (int s : strides) {
+      const int cnt = (N / s + 1) / 2;
+      HIPCHECK(h, launch_bcr_eliminate(hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
+                                       h->bcrG.p, h->flags.p + 1));
+    }
   }
   const size_t lds2 = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
+  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)strides.size());
   for (int q = (int)strides.size() - 1; q >= 0; --q) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
-    ScopedTimer tm(h, BA_K_BCR_BACKSOLVE);
     hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
                        h->bcrQ.p, h->bcrG.p, h->dC.p);    // x[N][B] IS dC's layout (padded to whole super-blocks)
   }
