@@ -41,7 +41,7 @@ constexpr int kBcrThreads = 256;                 // assemble
 constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
 constexpr int kBcrMaxHB = 10;                  // 4 matrices of B x (B+1) doubles must fit in LDS
 
-__host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8) * sizeof(double); }
+__host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 200) * sizeof(double); }   // + inverse of the current diagonal block
 
 // band (+ mask) -> D[N][B][B], U[N][B][B] = T[I,I+1], f[N][B]; cameras past nco and masked
 // parameters become identity rows with zero right-hand side.
@@ -99,27 +99,126 @@ __device__ __forceinline__ void fmac_rowbcast_safe(double& acc, double row, doub
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
 }
 
-template <int Q, int... Ps>
-__device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...>, double (&col)[6], double uqc, double nuqc) {
+template <int NB, int Q, int... Ps>
+__device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...>, double (&col)[NB], double uqc, double nuqc) {
   (fmac_rowbcast_safe<Q + 1 + Ps>(col[Q + 1 + Ps], uqc, nuqc), ...);     // col[p] -= U[q][p] U[q][c]   (entries p > c are never used)
 }
 
-// pivot Q of the 6x6 Cholesky on lanes 0..5 (lane c owns column c of U = L^T): all cross-lane
-// traffic is DPP row_newbcast - one instruction per broadcast on the chain of dependent pivots
-template <int Q>
-__device__ __forceinline__ void bcr_diag_pivot(double (&col)[6], int c, double& di, int& fail) {
+// pivot Q of the NB x NB Cholesky on lanes 0..NB-1 of one 16-lane row (lane c owns column c of
+// U = L^T): all cross-lane traffic is DPP row_newbcast - one instruction per broadcast on the chain
+// of dependent pivots
+template <int NB, int Q>
+__device__ __forceinline__ void bcr_diag_pivot(double (&col)[NB], int c, double& di, int& fail) {
   const double piv = mov_rowbcast<Q>(col[Q]);
   if (!(piv > 0.0) && !fail) fail = Q + 1;
   const double inv = rsqrt_nr(piv);
   if (c == Q) di = inv;
   const double uqc = c == Q ? piv * inv : (c > Q ? col[Q] * inv : 0.0);
   col[Q] = uqc;
-  bcr_diag_update<Q>(std::make_integer_sequence<int, 5 - Q>{}, col, uqc, -uqc);
+  bcr_diag_update<NB, Q>(std::make_integer_sequence<int, NB - 1 - Q>{}, col, uqc, -uqc);
 }
 
-template <int... Qs>
-__device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...>, double (&col)[6], int c, double& di, int& fail) {
-  (bcr_diag_pivot<Qs>(col, c, di, fail), ...);
+template <int NB, int... Qs>
+__device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...>, double (&col)[NB], int c, double& di, int& fail) {
+  (bcr_diag_pivot<NB, Qs>(col, c, di, fail), ...);
+}
+
+// diagonal block of NB unknowns at k0 (wavefront 0): factor in place, 1/diag to dinv.  The factor stays
+// in registers (col[p] of lane c = U[p][c] = L[c][p], di = 1 / L[c][c]) for bcr_diag_inverse.
+template <int NB>
+__device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, double* __restrict__ dinv, int* __restrict__ bad,
+                                               int k0, int lane, double (&col)[12], double& di) {
+  const int c = lane < NB ? lane : NB - 1;
+  double cl[NB];
+#pragma unroll
+  for (int p = 0; p < NB; ++p) cl[p] = G[(k0 + c) * ld + k0 + p];      // A[p][c] from the lower triangle
+  int fail = 0;
+  di = 0.0;
+  bcr_diag_pivots<NB>(std::make_integer_sequence<int, NB>{}, cl, c, di, fail);
+  if (fail && lane == 0) *bad = k0 + fail;
+  if (lane < NB) {
+    dinv[k0 + c] = di;
+#pragma unroll
+    for (int p = 0; p < NB; ++p)
+      if (p <= c) G[(k0 + c) * ld + k0 + p] = cl[p];                    // L[c][p] = U[p][c]
+  }
+#pragma unroll
+  for (int p = 0; p < NB; ++p) col[p] = cl[p];
+}
+
+template <int NB, int Q, int... Ps>
+__device__ __forceinline__ void bcr_inv_dot(std::integer_sequence<int, Ps...>, const double (&col)[12], const double (&x)[NB],
+                                            double& s0, double& s1) {
+  (fmac_rowbcast_safe<Q>((Ps & 1) ? s1 : s0, col[Ps], x[Ps]), ...);       // L[Q][p] = col[p] of lane Q
+}
+
+template <int NB, int Q>
+__device__ __forceinline__ void bcr_inv_row(const double (&col)[12], double di, int c, double (&x)[NB]) {
+  double s0 = 0.0, s1 = 0.0;
+  bcr_inv_dot<NB, Q>(std::make_integer_sequence<int, Q>{}, col, x, s0, s1);
+  x[Q] = ((c == Q ? 1.0 : 0.0) - (s0 + s1)) * mov_rowbcast<Q>(di);
+}
+
+template <int NB, int... Qs>
+__device__ __forceinline__ void bcr_inv_rows(std::integer_sequence<int, Qs...>, const double (&col)[12], double di, int c,
+                                             double (&x)[NB]) {
+  (bcr_inv_row<NB, Qs>(col, di, c, x), ...);
+}
+
+// inverse of the diagonal block straight from the registers of the factorisation (no LDS reads on
+// the chain): lane c solves L x = e_c, the entries of L arrive as DPP broadcasts; Li[q][c] = x[q]
+template <int NB>
+__device__ __forceinline__ void bcr_diag_inverse(const double (&col)[12], double di, int lane, double* __restrict__ Li) {
+  const int c = lane < NB ? lane : NB - 1;
+  double x[NB];
+  bcr_inv_rows<NB>(std::make_integer_sequence<int, NB>{}, col, di, c, x);
+  if (lane < NB) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) Li[q * 12 + c] = x[q];
+  }
+}
+
+// acc += (lane K of my 16-lane row of `row`) * y   (the DPP source comes from an LDS load: no hazard)
+template <int K>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double row, double y) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
+}
+
+template <int NB, int... Ps>
+__device__ __forceinline__ void bcr_fwd_dot(std::integer_sequence<int, Ps...>, double chunk, const double (&x)[NB], double& s0, double& s1) {
+  (fmac_rowbcast<Ps>((Ps & 1) ? s1 : s0, chunk, x[Ps]), ...);
+}
+
+template <int NB, int Q>
+__device__ __forceinline__ void bcr_fwd_row(const double* __restrict__ Lrow, int ld, const double* __restrict__ dk,
+                                            double* __restrict__ X, int st, double (&x)[NB], double& chunk, double& dq) {
+  double nchunk = 0.0, ndq = 0.0;
+  if constexpr (Q + 1 < NB) { nchunk = Lrow[(Q + 1) * ld]; ndq = dk[Q + 1]; }      // in flight during row Q's chain
+  double s0 = 0.0, s1 = 0.0;
+  bcr_fwd_dot<NB>(std::make_integer_sequence<int, Q>{}, chunk, x, s0, s1);
+  x[Q] = (x[Q] - (s0 + s1)) * dq;
+  X[Q * st] = x[Q];
+  chunk = nchunk; dq = ndq;
+}
+
+template <int NB, int... Qs>
+__device__ __forceinline__ void bcr_fwd_rows(std::integer_sequence<int, Qs...>, const double* __restrict__ Lrow, int ld,
+                                             const double* __restrict__ dk, double* __restrict__ X, int st, double (&x)[NB]) {
+  double chunk = Lrow[0], dq = dk[0];
+  (bcr_fwd_row<NB, Qs>(Lrow, ld, dk, X, st, x, chunk, dq), ...);
+}
+
+// x <- L_kk^-1 x for the NB entries x[0], x[st], ... (one right-hand side, or one row of the panel,
+// per lane; EVERY lane of the wavefront must call this - DPP sources have to be live lanes).
+// Row q of L_kk is fetched once per wavefront as a 16-lane-periodic register (lane l: entry l%16,
+// Lrow = &L_kk[0][lane%16]) and its entries reach the FMAs as DPP row_newbcast operands.
+template <int NB>
+__device__ __forceinline__ void bcr_block_forward(const double* __restrict__ Lrow, int ld, const double* __restrict__ dk,
+                                                  double* __restrict__ X, int st) {
+  double x[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) x[q] = X[q * st];
+  bcr_fwd_rows<NB>(std::make_integer_sequence<int, NB>{}, Lrow, ld, dk, X, st, x);
 }
 
 // One elimination level.  blockIdx.x = k-th node of this level: i = s*(2k+1) - 1.
@@ -140,6 +239,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   double* g = Xi + (size_t)B * ld;      // [B]
   double* dinv = g + B;                 // [B]
   int* bad = reinterpret_cast<int*>(dinv + B + 2);
+  double* Li = dinv + B + 4;            // [16][12]: rows 0..11 = inverse of the current diagonal block (lower triangular)
   const int tid = threadIdx.x;
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N) return;
@@ -177,205 +277,162 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   __syncthreads();
 
   BA_STAMP(t1);
-  // ---- blocked Cholesky D_i = L L^T (lower, in place, block size 6) FUSED with the forward
-  //      substitution L Y = R of the right-hand sides P | Q | I | g (one lane per column), as one
-  //      right-looking elimination of the augmented matrix [D_i | R], with one block of look-ahead:
-  //        phase 1  wavefront 0: 6x6 diagonal factor of block kb (DPP row broadcasts)
-  //                 the others : the LATE part of step kb-1 on the matrix cores - trailing update
-  //                              of D right of block column kb and R_below -= L_panel Y_(kb-1)
-  //        phase 2  panel of block column kb (one row per thread)
-  //        phase 3  Y_kb = L_kk^-1 R_kb, and the URGENT part of step kb: update of block column
-  //                 kb+1 only, so that the next diagonal factor can start while the rest of the
-  //                 update is still running
-  //      The chain of 6 HB dependent pivots is what bounds this kernel; everything else rides along.
+  // ---- blocked Cholesky D_i = L L^T (lower, in place, blocks of 12 unknowns) FUSED with the forward
+  //      substitution L Y = R of the right-hand sides P | Q | I | g, as one right-looking elimination
+  //      of the augmented matrix [D_i | R] with one block of look-ahead:
+  //        phase 1  wavefront 0: 12x12 diagonal factor of block kb (DPP row broadcasts, registers only)
+  //                 the others : what step kb-1 still owes, on the matrix cores - Y = L_pp^-1 R_p,
+  //                              R_below -= L_panel Y, and the trailing update of D right of block
+  //                              column kb (16-column tasks, three v_mfma_f64_16x16x4_f64 per tile)
+  //        phase 2  panel of block column kb (one row per lane, L entries as DPP operands);
+  //                 wavefront 0: inverse of the diagonal block from its registers (for the next phase 1)
+  //        phase 3  the URGENT part of step kb: update of block column kb+1 only, so that the next
+  //                 diagonal factor can start while the rest of the update is still owed
+  //      The chain of 6 HB dependent pivots (about 300 cycles each) bounds this kernel; the rest rides along.
   // wave-uniform values live in SGPRs: every VALU instruction of the 16 wavefronts costs a CU issue slot
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   const int nP = haveL ? B : 0, nQ = haveR ? B : 0, ncol = nP + nQ + B + 1;      // absent neighbours: no columns
-  auto rhs_column = [&](int c, int& st) -> double* {
+  auto rhs_column = [&](int c, int& st) -> int {                                 // offset into sm[] and row stride
     st = c < ncol - 1 ? ld : 1;
-    return c < nP ? Pl + c : c < nP + nQ ? Ql + (c - nP) : c < ncol - 1 ? Xi + (c - nP - nQ) : g;
+    return (int)((c < nP ? Pl + c : c < nP + nQ ? Ql + (c - nP) : c < ncol - 1 ? Xi + (c - nP - nQ) : g) - sm);
   };
-  // fixed roles for the late updates (phase 1): wavefronts 1..12 own 16 right-hand-side columns
-  // each, 13..15 own a 16-column tile of the trailing part of D, wavefront 0 factors
-  const int lk = lane >> 4;
-  const bool rhs_role = wave >= 1 && wave <= 12;
-  const bool wave_active = rhs_role ? 16 * (wave - 1) < ncol : wave >= 13;
-  const int xcol = 16 * (wave - 1) + lr;
-  const bool xok = rhs_role && xcol < ncol;
-  int xst = 1;
-  const int xoff = (int)(rhs_column(xok ? xcol : ncol - 1, xst) - sm);      // my column as an offset into sm[]
-  static_assert(3 * B + 1 <= 12 * 16 && B - 12 <= 3 * 16, "column tiles of the late updates must fit wavefronts 1..12 / 13..15");
+  // Blocks of 12 unknowns (the last one may have 6).  Late-update tasks: one per 16 right-hand-side
+  // columns, then one per 16-column tile of the trailing matrix, dealt to wavefronts 1..15.  (Keeping
+  // SIMD 0 free for the pivot chain of wavefront 0 speeds that chain up by 25 %, but the MFMA work then
+  // piles up on three SIMDs and phase 1 gets longer, not shorter: measured both ways.)
+  constexpr int NBLK = (B + 11) / 12;
+  const int nct = (ncol + 15) >> 4;
+  const int myslot = wave - 1;            // 0..14 (wavefront 0 factors)
 #ifdef BA_BCR_PROFILE
   long long ph[4] = {0, 0, 0, 0};
 #endif
-  for (int kb = 0; kb < HB; ++kb) {
-    const int k0 = 6 * kb;
+#pragma unroll 1
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const int k0 = 12 * kb;
+    const bool last = kb == NBLK - 1;
+    const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
+    const int kn = k0 + nb;                                 // first unknown after this block
 #ifdef BA_BCR_PROFILE
     const long long p0 = clock64();
 #endif
     // ---------------- phase 1
+    double dcol[12], ddi = 0.0;                             // wavefront 0: the factor of this block, kept for phase 2
     if (wave == 0) {
-      // 6x6 diagonal block: lane c owns column c of the upper factor U (= L^T)
-      const int c = tid < 6 ? tid : 5;
-      double col[6];
-#pragma unroll
-      for (int p = 0; p < 6; ++p) col[p] = G[(k0 + c) * ld + k0 + p];      // A[p][c] from the lower triangle
-      int fail = 0;
-      double di = 0.0;
-      bcr_diag_pivots(std::make_integer_sequence<int, 6>{}, col, c, di, fail);
-      if (fail && tid == 0) *bad = k0 + fail;
-      if (tid < 6) {
-        dinv[k0 + c] = di;
-#pragma unroll
-        for (int p = 0; p < 6; ++p)
-          if (p <= c) G[(k0 + c) * ld + k0 + p] = col[p];                    // L[c][p] = U[p][c]
-      }
-    } else if (kb > 0 && wave_active) {
-      // the LATE part of step kb-1 on the matrix cores.  This wavefront owns 16 columns (of the
-      // right-hand sides, or of D) for the whole kernel and updates every 16-row tile below:
-      //   C -= A B,  K = 6: two v_mfma_f64_16x16x4_f64 per tile, the second half-empty,
-      //   A = panel of block kp (rows of the tile), B = Y_kp (right-hand sides) or panel^T (D).
-      // All loads of a task are issued before the first MFMA.  Loads are unconditional:
-      // out-of-range rows / columns stay inside the LDS arrays and only reach accumulator rows /
-      // columns that are never stored; only the k = 6, 7 half of the second MFMA must be zero.
-      // Index arithmetic is 32-bit with 24-bit multiplies (full rate): with 15 wavefronts busy
-      // every VALU instruction costs a CU issue slot, and v_mul_lo_u32 costs four.
-      const int kp = k0 - 6;                                   // the block whose update is still owed
-      int t0, t1, i00;                                         // row tiles [t0, t1), first row of tile 0
-      int bo, bst, co, cst;                                    // offsets into sm[] (doubles) and strides
-      bool cok, skip = false;
-      if (rhs_role) {
-        t0 = 0; t1 = (B - k0 + 15) / 16; i00 = k0;
-        bo = xoff + __mul24(kp + lk, xst); bst = 4 * xst;
-        co = xoff + __mul24(lk, xst); cst = xst; cok = xok;
-        // columns of the identity right of block kp are still zero in rows kp..kp+5: nothing to subtract
-        skip = 16 * (wave - 1) >= nP + nQ + kp + 6 && 16 * (wave - 1) + 15 < ncol - 1;
-      } else {
-        const int gtile = wave - 13, c0 = k0 + 6 + 16 * gtile;
-        t0 = gtile; t1 = (B - k0 - 6 + 15) / 16; i00 = k0 + 6;
-        bo = (c0 + lr) * ld + kp + lk; bst = 4;
-        co = lk * ld + c0 + lr; cst = ld; cok = c0 + lr < B;
-      }
-      if (!skip && t0 < t1) {
-        typedef double mfma_acc __attribute__((ext_vector_type(4)));
-        const double b0 = sm[bo], b1 = sm[bo + bst];
+      __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
+      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      __builtin_amdgcn_s_setprio(0);
+    } else if (kb > 0 && myslot >= 0) {
+      // what step kb-1 still owes, on the matrix cores: C -= A B with K = 12 (three
+      // v_mfma_f64_16x16x4_f64), A = panel of block kp (16 rows of the tile), and
+      //   right-hand sides, rows >= k0:                       B = Y_kp (12 x 16 columns)
+      //   lower tiles of D right of block column kb:          B = panel^T
+      // Loads are unconditional: out-of-range rows / columns stay inside the LDS arrays and only
+      // reach accumulator rows / columns that are never stored.  Index arithmetic is 32-bit with
+      // 24-bit multiplies: every VALU instruction of the busy wavefronts costs a CU issue slot.
+      typedef double mfma_acc __attribute__((ext_vector_type(4)));
+      const int kp = k0 - 12;
+      const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
+      for (int task = myslot; task < nct + ngt; task += 15) {
+        int t0, t1, i00, co, cst;
+        bool cok, full;
+        double nb0, nb1, nb2;                                  // the NEGATED B operand of the three k-steps
+        if (task < nct) {
+          // columns of the identity right of block kp are still zero in rows kp..kp+11: nothing to subtract
+          if (16 * task >= nP + nQ + kp + 12 && 16 * task + 15 < ncol - 1) continue;
+          const int col = 16 * task + lr;
+          cok = col < ncol; full = 16 * task + 15 < ncol;
+          int xst;
+          const int xoff = rhs_column(cok ? col : ncol - 1, xst);
+          t0 = 0; t1 = (B - k0 + 15) >> 4; i00 = k0;
+          co = xoff + __mul24(lk, xst); cst = xst;
+          // Y_kp = L_pp^-1 R_kp for these 16 columns (the inverse comes from phase 2 of the previous step).
+          // The result lands in exactly the B-operand layout of the updates below: no LDS round trip.
+          const int ro = xoff + __mul24(kp + lk, xst), r4 = 4 * xst;
+          mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+          if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+          nb0 = -y[0]; nb1 = -y[1]; nb2 = -y[2];
+        } else {
+          const int gtile = task - nct, c0 = kn + 16 * gtile;
+          t0 = gtile; t1 = (B - kn + 15) >> 4; i00 = kn;
+          cok = c0 + lr < B; full = c0 + 15 < B;
+          const int bo = (c0 + lr) * ld + kp + lk;
+          co = lk * ld + c0 + lr; cst = ld;
+          nb0 = -sm[bo]; nb1 = -sm[bo + 4]; nb2 = -sm[bo + 8];
+        }
         const int c4 = 4 * cst;
         int ao = (i00 + 16 * t0 + lr) * ld + kp + lk;          // A entry of this lane in the first tile
         int cb = co + __mul24(i00 + 16 * t0, cst);             // first accumulator entry of this lane
-        int rlim = cok ? B - (i00 + 16 * t0) - lk : 0;         // rows v with 4 v < rlim exist
-        // one tile at a time with the next tile's operands in flight (few instructions per tile:
-        // the other wavefronts of this SIMD need the issue slots)
-#ifdef BA_BCR_PROFILE
-        const long long q0 = clock64();
-#endif
-        double a0 = sm[ao], a1 = sm[ao + 4];
+        int rows = B - (i00 + 16 * t0);                        // rows left from the top of the tile
+        double a0 = sm[ao], a1 = sm[ao + 4], a2 = sm[ao + 8];
         mfma_acc acc = {sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
-#ifdef BA_BCR_PROFILE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const long long q1 = clock64();
-        long long q2 = 0;
-#endif
         for (int t = t0; t < t1; ++t) {
-          const double a0c = -a0, a1c = lk < 2 ? -a1 : 0.0;
+          const double a0c = a0, a1c = a1, a2c = a2;
           mfma_acc accc = acc;
-          const int cbc = cb, rl = rlim;
-          if (t + 1 < t1) {
-            ao += 16 * ld; cb += 16 * cst; rlim -= 16;
-            a0 = sm[ao]; a1 = sm[ao + 4];
+          const int cbc = cb, rc = rows;
+          if (t + 1 < t1) {                                    // the next tile's operands are in flight
+            ao += 16 * ld; cb += 16 * cst; rows -= 16;
+            a0 = sm[ao]; a1 = sm[ao + 4]; a2 = sm[ao + 8];
             acc = mfma_acc{sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
           }
-          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0c, b0, accc, 0, 0, 0);
-          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1c, b1, accc, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0c, nb0, accc, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1c, nb1, accc, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2c, nb2, accc, 0, 0, 0);
+          if (full && rc >= 16) {                              // wave-uniform: the whole tile exists
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
-            if (4 * v < rl) sm[cbc + v * c4] = accc[v];        // (the strict upper part of diagonal tiles is never read)
-#ifdef BA_BCR_PROFILE
-          if (t == t0) q2 = clock64();
-#endif
+            for (int v = 0; v < 4; ++v) sm[cbc + v * c4] = accc[v];
+          } else {
+            const int rl = cok ? rc - lk : 0;                  // rows v with 4 v < rl exist
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              if (4 * v < rl) sm[cbc + v * c4] = accc[v];      // (the strict upper part of diagonal tiles is never read)
+          }
         }
-#ifdef BA_BCR_PROFILE
-        if (blockIdx.x == 1 && s == 1 && kb == 4 && lane == 0 && wave == 1) {
-          info[30] = (int)(q0 - p0); info[31] = (int)(q1 - q0); info[32] = (int)(q2 - q1); info[33] = (int)(clock64() - q2);
-        }
-#endif
       }
     }
 #ifdef BA_BCR_PROFILE
     const long long p1a = clock64();
-    if (blockIdx.x == 1 && s == 1 && kb == 4 && lane == 0) info[44 + wave] = (int)(p1a - p0);
+    if (blockIdx.x == 1 && s == 1 && kb == 1 && lane == 0) info[44 + wave] = (int)(p1a - p0);
 #endif
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long p1 = clock64();
 #endif
-    // ---------------- phase 2
-    if (wave == 1) {
-      // panel: rows below the diagonal block, X = A[i2][k0..k0+5] L_kk^-T (one row per thread)
-      double Lk[15], dk[6];
-      int idx = 0;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        dk[q] = dinv[k0 + q];
-#pragma unroll
-        for (int p = 0; p < q; ++p) Lk[idx++] = G[(k0 + q) * ld + k0 + p];
-      }
-      for (int i2 = k0 + 6 + lane; i2 < B; i2 += 64) {
-        double x[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) x[q] = G[i2 * ld + k0 + q];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          double t = x[q];
-#pragma unroll
-          for (int p = 0; p < q; ++p) t -= x[p] * Lk[q * (q - 1) / 2 + p];
-          x[q] = t * dk[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) G[i2 * ld + k0 + q] = x[q];
-      }
+    // ---------------- phase 2: panel, rows below the diagonal block: X = A[i2][k0..] L_kk^-T (one row per lane)
+    if (wave == 1 && kn < B) {
+      const int row = kn + lane < B ? kn + lane : B - 1;      // lanes past the last row repeat it (identical values)
+      if (nb == 12) bcr_block_forward<12>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
+      else bcr_block_forward<6>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
+    } else if (wave == 0) {
+      // inverse of the diagonal block for the right-hand sides (which then need three MFMAs per 16
+      // columns instead of a 12-step chain per column), from the registers of the factorisation
+      if (nb == 12) bcr_diag_inverse<12>(dcol, ddi, lane, Li);
+      else bcr_diag_inverse<6>(dcol, ddi, lane, Li);
     }
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long p2 = clock64();
 #endif
-    // ---------------- phase 3: block column kb+1 (its diagonal block and the rows below it)
-    // ---------------- ... alongside the solve of block row kb of the right-hand sides
-    if (wave >= 5 && wave <= 7) {
-      // Y_kb = L_kk^-1 R_kb, one right-hand side per lane
-      const int craw = (wave - 5) * 64 + lane;
-      if (craw < ncol) {
-        int st;
-        double* X = rhs_column(craw, st) + (size_t)k0 * st;
-        double Lk[15], dk[6], x[6];
-        int idx = 0;
+    // ---------------- phase 3: the URGENT part of the update: block column kb+1 only (its diagonal block and the rows
+    //                  below), so that the next diagonal factor can start while the rest is still owed
+    if (!last && wave >= 8 && wave <= 10) {
+      // rows kn + 16 t .. of the next block column: C -= panel panel^T, K = 12
+      typedef double mfma_acc __attribute__((ext_vector_type(4)));
+      const int i0 = kn + 16 * (wave - 8);
+      if (i0 < B) {
+        const int nbn = B - kn < 12 ? B - kn : 12;             // width of the next block
+        const int ao = (i0 + lr) * ld + k0 + lk, bo = (kn + lr) * ld + k0 + lk, cb = (i0 + lk) * ld + kn + lr;
+        mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
+        const int rl = lr < nbn ? B - i0 - lk : 0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          dk[q] = dinv[k0 + q];
-          x[q] = X[q * st];
-#pragma unroll
-          for (int p = 0; p < q; ++p) Lk[idx++] = G[(k0 + q) * ld + k0 + p];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          double t = x[q];
-#pragma unroll
-          for (int p = 0; p < q; ++p) t -= Lk[q * (q - 1) / 2 + p] * x[p];
-          x[q] = t * dk[q];
-          X[q * st] = x[q];
-        }
-      }
-    }
-    if (kb + 1 < HB) {
-      const int nrow = B - k0 - 6;
-      if (tid < 6 * nrow) {
-        const int ii = tid / 6, jj = tid - 6 * ii;
-        const int i2 = k0 + 6 + ii, j2 = k0 + 6 + jj;
-        if (i2 >= j2) {
-          double acc = G[i2 * ld + j2];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) acc -= G[i2 * ld + k0 + q] * G[j2 * ld + k0 + q];
-          G[i2 * ld + j2] = acc;
-        }
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
       }
     }
     __syncthreads();
@@ -386,6 +443,30 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #ifdef BA_BCR_PROFILE
   if (tid == 0 && blockIdx.x == 1 && s == 1) { info[14] = (int)ph[0]; info[15] = (int)ph[1]; info[16] = (int)ph[2]; info[17] = (int)ph[3]; }
 #endif
+  if (myslot >= 0) {
+    // the last block row of the right-hand sides: Y = L_pp^-1 R_p (nothing below it)
+    typedef double mfma_acc __attribute__((ext_vector_type(4)));
+    constexpr int KL = 12 * (NBLK - 1), NL = B - KL;          // last block: start and size (12 or 6)
+    for (int task = myslot; task < nct; task += 15) {
+      const int col = 16 * task + lr;
+      const bool cok = col < ncol;
+      int xst;
+      const int xoff = rhs_column(cok ? col : ncol - 1, xst);
+      const int ro = xoff + __mul24(KL + lk, xst), r4 = 4 * xst;
+      mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+      if (NL == 12) {
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+        if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+      } else {                                               // 6 rows: k = 4, 5 of the second step only
+        const double r1 = lk < 2 ? sm[ro + (lk < 2 ? r4 : 0)] : 0.0;
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], r1, y, 0, 0, 0);
+        if (cok) { sm[ro] = y[0]; if (lk < 2) sm[ro + r4] = y[1]; }
+      }
+    }
+  }
+  __syncthreads();
   if (*bad) {
     if (tid == 0) atomicMax(info, i * B + *bad);
     return;

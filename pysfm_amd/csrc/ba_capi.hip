@@ -1119,8 +1119,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     fprintf(stderr, "    factor+solve, summed over the block steps: diagonal factor (wave 0) %d, phase 1 %d, phase 2 %d, phase 3 %d\n",
             inf6[14], inf6[15], inf6[16], inf6[17]);
   if (getenv("BA_SOLVE_TRACE") && use_bcr) {
-    fprintf(stderr, "    wave 1, block step 4: role setup %d, first loads %d, first tile %d, second tile %d\n", inf6[30], inf6[31], inf6[32], inf6[33]);
-    fprintf(stderr, "    phase 1 of block step 4, per wavefront:");
+    fprintf(stderr, "    phase 1 of block step 1, per wavefront:");
     for (int w = 0; w < 16; ++w) fprintf(stderr, " %d", inf6[44 + w]);
     fprintf(stderr, "\n");
   }
