@@ -99,9 +99,15 @@ __device__ __forceinline__ void fmac_rowbcast_safe(double& acc, double row, doub
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
 }
 
+// acc -= (lane K of my row of `row`) * y   (negation as a source modifier: nothing extra on the chain)
+template <int K>
+__device__ __forceinline__ void fnmac_rowbcast_safe(double& acc, double row, double y) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(y), "n"(K));
+}
+
 template <int NB, int Q, int... Ps>
-__device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...>, double (&col)[NB], double uqc, double nuqc) {
-  (fmac_rowbcast_safe<Q + 1 + Ps>(col[Q + 1 + Ps], uqc, nuqc), ...);     // col[p] -= U[q][p] U[q][c]   (entries p > c are never used)
+__device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...>, double (&col)[NB], double uqc) {
+  (fnmac_rowbcast_safe<Q + 1 + Ps>(col[Q + 1 + Ps], uqc, uqc), ...);     // col[p] -= U[q][p] U[q][c]   (entries p > c are never used)
 }
 
 // pivot Q of the NB x NB Cholesky on lanes 0..NB-1 of one 16-lane row (lane c owns column c of
@@ -109,13 +115,17 @@ __device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...
 // of dependent pivots
 template <int NB, int Q>
 __device__ __forceinline__ void bcr_diag_pivot(double (&col)[NB], int c, double& di, int& fail) {
+  // the dependent chain is: broadcast pivot -> rsqrt (seed + 2 Newton steps) -> scale -> rank-1 update
+  // of the next column; selects and the failure test stay off it.  col[Q] * inv is right for every lane
+  // that matters: lane Q holds the pivot itself (-> its square root), lanes below Q hold entries that are
+  // never used again.
   const double piv = mov_rowbcast<Q>(col[Q]);
-  if (!(piv > 0.0) && !fail) fail = Q + 1;
   const double inv = rsqrt_nr(piv);
-  if (c == Q) di = inv;
-  const double uqc = c == Q ? piv * inv : (c > Q ? col[Q] * inv : 0.0);
+  const double uqc = col[Q] * inv;
+  bcr_diag_update<NB, Q>(std::make_integer_sequence<int, NB - 1 - Q>{}, col, uqc);
   col[Q] = uqc;
-  bcr_diag_update<NB, Q>(std::make_integer_sequence<int, NB - 1 - Q>{}, col, uqc, -uqc);
+  if (!(piv > 0.0) && !fail) fail = Q + 1;
+  if (c == Q) di = inv;
 }
 
 template <int NB, int... Qs>
