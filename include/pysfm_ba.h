@@ -81,6 +81,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs,
                    const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_z,
                    const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt);
 
+/* Lower bound for the block half-bandwidth chosen by the NEXT ba_set_problem.  The sharded adjuster
+ * sets it to the maximum over the ranks so that every rank stores [S | b] in the same band layout
+ * (the all-reduce adds the buffers element by element). */
+int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb);
+
 /* bundle.sensor_model (sensor_model.py:19-32 protocol) */
 int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams);
 
@@ -170,6 +175,21 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
  * solve path.  The accept / reject decision stays with the caller (ba_swap_params). */
 int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* cam_param_mask, double* next_cost,
                 int32_t* info);
+
+/* The same trial in two halves for the sharded (multi-GPU) adjuster, where the partial reduced
+ * systems have to be summed over the ranks in between (one all-reduce of [S | b],
+ * enqueued by the caller on the handle's stream):
+ *   ba_lm_trial_begin : ba_linearize + ba_schur, nothing read back;
+ *   ba_lm_trial_end   : ba_solve_reduced + ba_backsubstitute + update of the trial set + ba_cost,
+ *                       nothing read back either.  The rank's partial trial cost is left in the
+ *                       device buffer bound with ba_bind_trial_result: result[0 .. BA_TRIAL_PARTIALS)
+ *                       = partial sums (add them), result[BA_TRIAL_PARTIALS] = singular point blocks,
+ *                       result[BA_TRIAL_PARTIALS + 1] = solver status (*info of ba_solve_reduced).
+ * The caller sums / all-reduces that buffer and synchronises once per trial. */
+#define BA_TRIAL_PARTIALS 2048
+int ba_bind_trial_result(ba_handle* h, void* result_dev /* BA_TRIAL_PARTIALS + 2 doubles, or NULL */);
+int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond);
+int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_info);
 
 /* ---- Bundle.triangulate_all (bundle.py:313-321; triangulate.algebraic_lsq triangulate.py:6-18)
  * Re-initialise every point of parameter set `which` by linear least squares from its

@@ -10,6 +10,7 @@ import os
 import numpy as np
 
 LIB_NAME = 'libpysfm_ba.so'
+TRIAL_PARTIALS = 2048          # BA_TRIAL_PARTIALS of include/pysfm_ba.h
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 BA_OK = 0
@@ -56,6 +57,10 @@ PROTOTYPES = {
     'ba_backsubstitute': (C.c_int, [_h, C.c_int, _dp, _dp]),
     'ba_apply_update': (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp]),
     'ba_lm_trial': (C.c_int, [_h, C.c_double, C.c_double, _bp, _dp, C.POINTER(C.c_int32)]),
+    'ba_bind_trial_result': (C.c_int, [_h, C.c_void_p]),
+    'ba_set_min_half_bandwidth': (C.c_int, [_h, C.c_int32]),
+    'ba_lm_trial_begin': (C.c_int, [_h, C.c_double, C.c_double]),
+    'ba_lm_trial_end': (C.c_int, [_h, _bp, C.POINTER(C.c_int32)]),
     'ba_triangulate': (C.c_int, [_h, C.c_int, C.c_double, _dp]),
     'ba_enable_timing': (C.c_int, [_h, C.c_int]),
     'ba_set_timing_mask': (C.c_int, [_h, C.c_uint64]),

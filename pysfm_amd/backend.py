@@ -55,8 +55,16 @@ class HipBackend(object):
             return
         self._torch = torch
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self._lib.ba_set_stream(self._h, C.c_void_p(stream)))
+        # The kernels run on a torch stream of our own: torch's default stream is the NULL stream, which the
+        # C ABI reads as "make your own" - and a private HIP stream is not ordered against torch ops.  Every
+        # torch op that touches the library's device buffers (the RCCL all-reduce of [S | b], the sum of the
+        # trial-cost partials) runs under stream_ctx(), i.e. on this same stream.
+        self._tstream = torch.cuda.Stream(device=self.device)
+        self._check(self._lib.ba_set_stream(self._h, C.c_void_p(self._tstream.cuda_stream)))
+
+    def stream_ctx(self):
+        """Context manager: torch ops inside are enqueued on the stream the kernels run on."""
+        return self._torch.cuda.stream(self._tstream)
 
     def _check(self, rc):
         if rc == capi.BA_OK:
@@ -72,7 +80,7 @@ class HipBackend(object):
         if getattr(self, '_h', None):
             self._lib.ba_destroy(self._h)
             self._h = None
-        self._S_t = self._b_t = self._A_t = self._rhs_t = None
+        self._S_t = self._b_t = self._A_t = self._rhs_t = self._trial_t = None
 
     def __del__(self):
         try:
@@ -84,6 +92,11 @@ class HipBackend(object):
         self._check(self._lib.ba_synchronize(self._h))
 
     # ---------------------------------------------------------------- problem
+    def set_min_half_bandwidth(self, min_hb):
+        """Lower bound for the band width of the next set_problem (ranks of the sharded adjuster
+        must store [S | b] in one common layout)."""
+        self._check(self._lib.ba_set_min_half_bandwidth(self._h, int(min_hb)))
+
     def set_problem(self, nc, nt, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt):
         obs_cam, obs_pt = capi.i32(obs_cam), capi.i32(obs_pt)
         obs_z = capi.f64(obs_z, (-1, 2))
@@ -281,6 +294,30 @@ class HipBackend(object):
                                           capi.bptr(mask), C.byref(cost), C.byref(info)))
         self.last_solve_path = 'band' if info.value == 0 else 'dense'
         return info.value, cost.value
+
+    # the same trial in two halves around the all-reduce of the sharded adjuster
+    def lm_trial_begin(self, damping, rcond):
+        """ba_lm_trial_begin: linearise + Schur reduction of this rank's shard, nothing read back."""
+        self._host_dC = None
+        self._check(self._lib.ba_lm_trial_begin(self._h, float(damping), -1.0 if rcond is None else float(rcond)))
+
+    def lm_trial_end(self, cam_param_mask=None):
+        """ba_lm_trial_end: solve, back-substitute, update the trial set, trial cost - nothing read
+        back; the rank's cost partials + status words are in trial_result().  Returns the
+        pre-check (non-zero: the band solver does not apply, take the stepwise path)."""
+        if getattr(self, '_trial_t', None) is None:
+            torch = self._torch
+            self._trial_t = torch.zeros(capi.TRIAL_PARTIALS + 2, dtype=torch.float64, device=torch.device('cuda', self.device))
+            self._check(self._lib.ba_bind_trial_result(self._h, C.c_void_p(self._trial_t.data_ptr())))
+        mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
+        pre = C.c_int32()
+        self._check(self._lib.ba_lm_trial_end(self._h, capi.bptr(mask), C.byref(pre)))
+        self.last_solve_path = 'band' if pre.value == 0 else 'dense'
+        return pre.value
+
+    def trial_result(self):
+        """Device tensor [TRIAL_PARTIALS cost partials | singular point blocks | solver status]."""
+        return self._trial_t
 
     def triangulate(self, which, rcond=None, fetch=True):
         """Linear least-squares re-initialisation of every point from the cameras of

@@ -183,6 +183,17 @@ class BundleAdjuster(object):
         self._nobs = len(obs_cam)
 
         be = self.backend
+        if self._comm is not None and hasattr(be, 'set_min_half_bandwidth'):
+            # the ranks add their [S | b] buffers element by element: one band layout for all, i.e. the
+            # widest spread of optimised-camera positions inside a track over ALL shards
+            pos = cam_opt_pos[np.asarray(obs_cam, int)]
+            ok = pos >= 0
+            lo = np.full(nt, np.iinfo(np.int32).max, np.int64)
+            hi = np.full(nt, -1, np.int64)
+            np.minimum.at(lo, np.asarray(obs_pt, int)[ok], pos[ok])
+            np.maximum.at(hi, np.asarray(obs_pt, int)[ok], pos[ok])
+            spread = np.where(hi >= 0, hi - lo, 0)
+            be.set_min_half_bandwidth(int(self._comm.allreduce_max(int(spread.max()) if nt else 0)))
         be.set_problem(nc, nt, obs_cam, obs_pt, obs_z, np.asarray(bundle.K, float), cam_opt_pos, pt_opt)
         be.set_sensor(*device_params_of(bundle.sensor_model))
         self._upload(bundle, PARAMS_CUR)
@@ -239,13 +250,35 @@ class BundleAdjuster(object):
         be = self.backend
         if self._comm is None and hasattr(be, 'lm_trial'):
             # single GPU: the whole trial is one batch of launches with one synchronisation
-            cam_param_mask = self._cam_param_mask(param_mask)
+            cam_param_mask = None                              # (the common case costs no array work)
+            if param_mask is not None:
+                cam_param_mask = self._cam_param_mask(param_mask)
+                if np.all(cam_param_mask):
+                    cam_param_mask = None
             self._damp_factor = 1. + damping
-            info, cost = be.lm_trial(damping, self.SCHUR_COMPLIMENT_PINV_THRESHOLD,
-                                     None if np.all(cam_param_mask) else cam_param_mask)
+            info, cost = be.lm_trial(damping, self.SCHUR_COMPLIMENT_PINV_THRESHOLD, cam_param_mask)
             self._have_blocks = True
             if info == 0:
                 next_cost = cost
+        elif self._comm is not None and hasattr(be, 'lm_trial_begin') and str(self._comm.device).startswith('cuda'):
+            # sharded: the same batch in two halves around the all-reduce of [S | b]; the ranks' trial
+            # costs are summed on the device, one synchronisation per trial
+            cam_param_mask = None
+            if param_mask is not None:
+                cam_param_mask = self._cam_param_mask(param_mask)
+                if np.all(cam_param_mask):
+                    cam_param_mask = None
+            self._damp_factor = 1. + damping
+            be.lm_trial_begin(damping, self.SCHUR_COMPLIMENT_PINV_THRESHOLD)
+            self._comm.allreduce_reduced(be)
+            self._have_blocks = True
+            if be.lm_trial_end(cam_param_mask) == 0:
+                from ._capi import TRIAL_PARTIALS
+                cost, nsing, info = self._comm.allreduce_trial_result(be, TRIAL_PARTIALS)
+                if nsing > 0 and self.SCHUR_COMPLIMENT_PINV_THRESHOLD is None:
+                    raise np.linalg.LinAlgError('singular 3x3 point block(s) in plain-inverse mode')
+                if info == 0:
+                    next_cost = cost
         if next_cost is None:
             try:
                 self._compute_update_device(damping, param_mask, fetch=False)

@@ -50,6 +50,7 @@ struct ba_handle {
   // problem
   int nc = 0, nt = 0, nco = 0;
   int hb = 0;                // block half-bandwidth of the reduced system
+  int min_hb = 0;            // ba_set_min_half_bandwidth: lower bound for hb (ranks must agree on the band layout)
   long long nobs = 0;
   bool have_problem = false;
   bool have_params[2] = {false, false};
@@ -58,7 +59,8 @@ struct ba_handle {
   bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
   bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)
   double inv_damping = 0.0, inv_rcond = 0.0;
-  bool fuse_trial = false;           // inside ba_lm_trial with the MFMA reduction: camera blocks + point inverses ride along
+  double* trial_result_dev = nullptr; // bound by ba_bind_trial_result: device copy of the cost partials + status words
+  double trial_rcond = 0.0;          // ba_lm_trial_begin -> ba_lm_trial_end
   int glog = 0;              // lanes per point = 2^glog
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0};
@@ -457,6 +459,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     }
     if (hi >= 0) hb = std::max(hb, hi - lo);
   }
+  hb = std::max(hb, std::min(h->min_hb, std::max(0, nco - 1)));   // sharded adjuster: every rank uses the widest band
   // Schur chunks: consecutive units whose optimised-camera positions fit a window of wn
   // band rows, so that a workgroup can accumulate them in an LDS tile
   int wn = (int)(kSchurTileBytes / (((size_t)(hb + 1) * 36 + 6) * sizeof(double)));
@@ -716,7 +719,7 @@ int ba_cost(ba_handle* h, int which, double* cost_out) {
   {
     ScopedTimer tm(h, BA_K_COST);
     hipLaunchKernelGGL(k_cost, dim3(nb), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
-                       (const int*)h->sing_counter(), (const int*)(h->flags.p + 1), h->host_result);
+                       (const int*)h->sing_counter(), (const int*)(h->flags.p + 1), h->host_result, h->trial_result_dev);
   }
   h->cost_blocks = nb;
   HIPCHECK(h, hipGetLastError());
@@ -1199,23 +1202,44 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   return BA_OK;
 }
 
-int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* cam_param_mask, double* next_cost,
-                int32_t* info) {
+int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb) {
   if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, next_cost && info, BA_ERR_INVALID_ARG, "ba_lm_trial: NULL output");
+  REQUIRE(h, min_hb >= 0, BA_ERR_INVALID_ARG, "ba_set_min_half_bandwidth: negative");
+  h->min_hb = min_hb;
+  return BA_OK;
+}
+
+int ba_bind_trial_result(ba_handle* h, void* result_dev) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  static_assert(BA_TRIAL_PARTIALS == kCostBlocks, "header and kernel disagree on the number of cost partials");
+  h->trial_result_dev = static_cast<double*>(result_dev);
+  return BA_OK;
+}
+
+int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
+  if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem && h->have_params[h->phys(BA_PARAMS_CUR)], BA_ERR_STATE, "ba_lm_trial: set problem and parameters first");
-  *info = 0;
   h->defer = true;
-  double unused = 0.0;
-  int32_t pre = 0;
-  // with the MFMA reduction the point inverses come out of k_linearize and the camera blocks out of the
-  // reduction itself: two launches and two passes over the observations less
+  // with the MFMA reduction the camera blocks come out of the reduction itself: one launch and one pass
+  // over the observations less
   const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
   const bool fuse = !getenv("BA_SCHUR") && !getenv("BA_NO_FUSE") && groups_ok && mfma_reduction_possible(h);
   int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
-  if (rc == BA_OK) rc = ba_solve_reduced(h, cam_param_mask, &pre);
-  if (rc == BA_OK && pre != 0) { h->defer = false; *info = pre; return BA_OK; }   // band too wide: caller takes the dense path
+  h->defer = false;
+  h->trial_rcond = pinv_rcond;
+  return rc;
+}
+
+int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_info) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, pre_info, BA_ERR_INVALID_ARG, "ba_lm_trial_end: NULL output");
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_lm_trial_end: call ba_lm_trial_begin first");
+  *pre_info = 0;
+  h->defer = true;
+  double unused = 0.0;
+  int rc = ba_solve_reduced(h, cam_param_mask, pre_info);
+  if (rc == BA_OK && *pre_info != 0) { h->defer = false; return BA_OK; }   // band too wide: caller takes the dense path
   if (rc == BA_OK) rc = ba_backsubstitute(h, BA_PARAMS_CUR, nullptr, nullptr);
   if (rc == BA_OK) {
     if (h->nt > 0) h->have_params[h->phys(BA_PARAMS_TRIAL)] = true;      // k_backsub wrote the trial set
@@ -1223,8 +1247,20 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   }
   if (rc == BA_OK) rc = ba_cost(h, BA_PARAMS_TRIAL, &unused);
   h->defer = false;
+  return rc;
+}
+
+int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* cam_param_mask, double* next_cost,
+                int32_t* info) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, next_cost && info, BA_ERR_INVALID_ARG, "ba_lm_trial: NULL output");
+  *info = 0;
+  int32_t pre = 0;
+  int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
+  if (rc == BA_OK) rc = ba_lm_trial_end(h, cam_param_mask, &pre);
   if (rc != BA_OK) return rc;
-  HIPCHECK(h, hipStreamSynchronize(h->stream));      // k_cost's last block left cost + status words in pinned memory
+  if (pre != 0) { *info = pre; return BA_OK; }
+  HIPCHECK(h, hipStreamSynchronize(h->stream));      // k_cost left the cost partials + status words in pinned memory
   const int st[2] = {h->host_result->singular_points, h->host_result->solve_info};
   *next_cost = h->host_cost();
   if (pinv_rcond < 0.0 && st[0] > 0)

@@ -148,7 +148,8 @@ struct HostResult { int singular_points; int solve_info; double partial[kCostBlo
 __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __restrict__ cams,
                                                  const double* __restrict__ X,
                                                  const int* __restrict__ singular_points,
-                                                 const int* __restrict__ solve_info, HostResult* __restrict__ host) {
+                                                 const int* __restrict__ solve_info, HostResult* __restrict__ host,
+                                                 double* __restrict__ dev_result) {
   __shared__ double wsum[kBlock / kWave];
   double acc = 0.0;
   const long long stride = (long long)gridDim.x * kBlock;
@@ -171,9 +172,11 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __r
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) s += wsum[w];
     host->partial[blockIdx.x] = s;
+    if (dev_result) dev_result[blockIdx.x] = s;             // sharded adjuster: the ranks' costs meet on the device
     if (blockIdx.x == 0) {
       host->singular_points = *singular_points;
       host->solve_info = *solve_info;
+      if (dev_result) { dev_result[kCostBlocks] = (double)*singular_points; dev_result[kCostBlocks + 1] = (double)*solve_info; }
     }
   }
 }

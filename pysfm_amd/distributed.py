@@ -21,6 +21,7 @@ Usage (torchrun, one rank per GPU):
     ba.set_bundle(bundle, track_ids=ids)
     ba.optimize()
 """
+import contextlib
 import os
 
 import numpy as np
@@ -51,6 +52,13 @@ def shard_tracks(bundle, rank, world_size):
     return list(range(b[rank], b[rank + 1]))
 
 
+def _stream_of(backend):
+    """The stream context of a HipBackend (its kernels and the collectives on its buffers share one
+    stream); nothing for host-side test doubles."""
+    ctx = getattr(backend, 'stream_ctx', None)
+    return ctx() if ctx is not None else contextlib.nullcontext()
+
+
 class ShardComm(object):
     """The collectives the sharded adjuster needs, over torch.distributed
     ('nccl' = RCCL on ROCm for GPU tensors, 'gloo' for the CPU tests)."""
@@ -74,6 +82,11 @@ class ShardComm(object):
         self._dist.all_reduce(t, group=self.group)
         return float(t.item())
 
+    def allreduce_max(self, x):
+        t = self._torch.tensor([float(x)], dtype=self._torch.float64, device=self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     def allreduce_array(self, a):
         t = self._torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
         self._dist.all_reduce(t, group=self.group)
@@ -82,8 +95,21 @@ class ShardComm(object):
     def allreduce_reduced(self, backend):
         """The one data-path collective: sum the partial reduced camera systems."""
         payload = backend.reduced_payload()
-        self._dist.all_reduce(payload, group=self.group)
+        with _stream_of(backend):              # ordered after the kernels that wrote it, before the ones that read it
+            self._dist.all_reduce(payload, group=self.group)
         self.bytes_reduced += payload.numel() * 8
+
+    def allreduce_trial_result(self, backend, npartials):
+        """Sum of the ranks' trial costs from the device buffer HipBackend.trial_result()
+        (no host round trip before the collective); ONE synchronisation for the three numbers.
+        Returns (cost, singular point blocks on this rank, solver status)."""
+        torch = self._torch
+        with _stream_of(backend):
+            t = backend.trial_result()
+            r = torch.cat([t[:npartials].sum().reshape(1), t[npartials:npartials + 2]])
+            self._dist.all_reduce(r[:1], group=self.group)
+            c, nsing, info = r.cpu().tolist()
+        return c, int(nsing), int(info)
 
     def barrier(self):
         self._dist.barrier(group=self.group)

@@ -7,6 +7,8 @@ Tolerances (fp64 everywhere; BASELINE north star: each step within 1e-6 relative
   * solves / updates: 1e-8 (conditioning of the reduced system)
   * LM cost trajectories and final parameters: 1e-6 (the north-star tolerance)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -592,6 +594,47 @@ def test_lm_trial_entry_equals_stepwise_calls(be):
         close(c_fused, O.cost(sensor, s['K'], R2, t2, X2, *a[4:], *flags), 1e-8)
     be.swap_params()                                        # accept: the trial set becomes current
     close(be.get_params(0)[2], Xs, 0.)
+
+
+def test_sharded_trial_path_matches_single_gpu_path():
+    """The multi-GPU trial (ba_lm_trial_begin -> RCCL all-reduce of [S | b] -> ba_lm_trial_end, trial
+    costs summed on the device) with a one-rank RCCL group must walk the same LM trajectory as
+    ba_lm_trial, and both must agree with the oracle's first step."""
+    import torch
+    import torch.distributed as dist
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    from pysfm_amd.distributed import ShardComm
+    s = banded(60, 3000, track_len=8, outlier_frac=.02)
+    model = sensor_model.CauchyModel(.05)
+
+    def run(comm):
+        b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=model)
+        ba = BundleAdjuster(comm=comm, verbose=False)
+        ba.set_bundle(b)
+        ba.optimize(max_steps=6)
+        return ba
+
+    single = run(None)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    created = not dist.is_initialized()
+    if created:
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        comm = ShardComm()
+        sharded = run(comm)
+        assert comm.bytes_reduced > 0                       # the collective really ran
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert len(sharded.costs) == len(single.costs)
+    close(np.array(sharded.costs), np.array(single.costs), 1e-9)
+    assert sharded.lm_trials == single.lm_trials
+    Rs, ts, Xs = sharded.backend.get_params(0)
+    R1, t1, X1 = single.backend.get_params(0)
+    close(Xs, X1, 1e-9)
+    close(ts, t1, 1e-9)
 
 
 def test_timing_counters(be):
