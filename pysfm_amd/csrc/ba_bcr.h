@@ -37,7 +37,7 @@
 
 namespace ba {
 
-constexpr int kBcrThreads = 256;                 // assemble
+constexpr int kBcrThreads = 1024;                // assemble (111 nodes at config 3: few workgroups, so make them wide)
 constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
 constexpr int kBcrMaxHB = 10;                  // 4 matrices of B x (B+1) doubles must fit in LDS
 

@@ -910,22 +910,34 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   }
   const bool have_inv = h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond;
   h->inv_valid = false;
-  if (have_inv) {
-    h->inv_valid = true;    // k_linearize already inverted the damped point blocks for this (damping, rcond)
-  } else if (h->nt > 0) {
+  const long long ninit = (long long)reduced_doubles(h) + (long long)h->nco * 6;
+  if (!have_inv && h->nt > 0 && h->nco > 0) {
+    // point inverses and the initialisation of [S | b] are independent: one launch for both
     h->sing_epoch ^= 1;     // this call counts singular blocks in sing_counter(); the kernel clears the other one
     ScopedTimer tm(h, BA_K_POINT_INVERT);
-    hipLaunchKernelGGL(k_point_invert, dim3(blocks_for(h->nt)), dim3(kBlock), 0, h->stream, h->nt, h->HPP.p,
-                       damping, pinv_rcond, h->HPPinv.p, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+    const unsigned nbi = blocks_for(h->nt);
+    hipLaunchKernelGGL(k_point_invert_schur_init, dim3(nbi + blocks_for(ninit)), dim3(kBlock), 0, h->stream, (int)nbi, h->nt,
+                       h->HPP.p, damping, pinv_rcond, h->HPPinv.p, h->sing_counter(),
+                       h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), h->nco, h->hb + 1, h->opt_cam.p, h->HCC.p, h->bC.p, h->S,
+                       h->b, fuse_cam ? 0 : 1);
     h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
   } else {
-    HIPCHECK(h, hipMemsetAsync(h->flags.p + 40, 0, 2 * sizeof(int), h->stream));
-  }
-  if (h->nco > 0) {
-    ScopedTimer tm(h, BA_K_SCHUR_INIT);       // clears the band and writes the damped diagonal + b in one pass
-    const long long n = (long long)reduced_doubles(h) + (long long)h->nco * 6;
-    hipLaunchKernelGGL(k_schur_init, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, h->opt_cam.p,
-                       h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
+    if (have_inv) {
+      h->inv_valid = true;    // k_linearize already inverted the damped point blocks for this (damping, rcond)
+    } else if (h->nt > 0) {
+      h->sing_epoch ^= 1;
+      ScopedTimer tm(h, BA_K_POINT_INVERT);
+      hipLaunchKernelGGL(k_point_invert, dim3(blocks_for(h->nt)), dim3(kBlock), 0, h->stream, h->nt, h->HPP.p,
+                         damping, pinv_rcond, h->HPPinv.p, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+      h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
+    } else {
+      HIPCHECK(h, hipMemsetAsync(h->flags.p + 40, 0, 2 * sizeof(int), h->stream));
+    }
+    if (h->nco > 0) {
+      ScopedTimer tm(h, BA_K_SCHUR_INIT);       // clears the band and writes the damped diagonal + b in one pass
+      hipLaunchKernelGGL(k_schur_init, dim3(blocks_for(ninit)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, h->opt_cam.p,
+                         h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
+    }
   }
   if (use_mfma) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);

@@ -366,12 +366,9 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevProblem P, const do
 // apply_damping on HPP (bundle_adjuster.py:241-242, optimize.py:7-9) and the
 // per-point inverse (bundle_adjuster.py:252-256).  One point per lane.
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* __restrict__ HPP,
-                                                         double damping, double rcond,
-                                                         double* __restrict__ HPPinv,
-                                                         int* __restrict__ singular_count,
-                                                         int* __restrict__ next_count) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void point_invert_body(int k, int nt, const double* __restrict__ HPP, double damping, double rcond,
+                                                  double* __restrict__ HPPinv, int* __restrict__ singular_count,
+                                                  int* __restrict__ next_count) {
   if (k == 0) *next_count = 0;      // the counter the NEXT call will use (two counters alternate: no memset launch)
   if (k >= nt) return;
   double A[6], out[6];
@@ -388,17 +385,23 @@ __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* _
   for (int i = 0; i < 6; ++i) HPPinv[6 * (size_t)k + i] = out[i];
 }
 
+__global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* __restrict__ HPP,
+                                                         double damping, double rcond,
+                                                         double* __restrict__ HPPinv,
+                                                         int* __restrict__ singular_count,
+                                                         int* __restrict__ next_count) {
+  point_invert_body(blockIdx.x * kBlock + threadIdx.x, nt, HPP, damping, rcond, HPPinv, singular_count, next_count);
+}
+
 // --------------------------------------------------------------------------
 // S[pos,pos] = damped HCC, b[pos] = bC for optimised cameras
 // (bundle_adjuster.py:238-240, 263-265); every other block of the band is cleared in the
 // same pass (one launch instead of two memsets + a scatter).  One thread per double of
 // [S | b]; `opt_cam[pos]` is the camera at optimised position pos.
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const int* __restrict__ opt_cam,
-                                                       const double* __restrict__ HCC,
-                                                       const double* __restrict__ bC, double damping,
-                                                       double* __restrict__ S, double* __restrict__ b, int use_hcc) {
-  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void schur_init_body(long long tid, int nco, int hb1, const int* __restrict__ opt_cam,
+                                                const double* __restrict__ HCC, const double* __restrict__ bC,
+                                                double damping, double* __restrict__ S, double* __restrict__ b, int use_hcc) {
   const long long nS = (long long)nco * hb1 * 36;
   if (tid < nS) {
     const int e = (int)(tid % 36);
@@ -416,6 +419,31 @@ __global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const i
     const long long q = tid - nS;
     b[q] = use_hcc ? bC[(size_t)opt_cam[q / 6] * 6 + q % 6] : 0.0;
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const int* __restrict__ opt_cam,
+                                                       const double* __restrict__ HCC,
+                                                       const double* __restrict__ bC, double damping,
+                                                       double* __restrict__ S, double* __restrict__ b, int use_hcc) {
+  schur_init_body((long long)blockIdx.x * kBlock + threadIdx.x, nco, hb1, opt_cam, HCC, bC, damping, S, b, use_hcc);
+}
+
+// both of the above in ONE launch (they are independent; a dependent launch costs ~3 us on the stream):
+// the first nbi blocks invert the point blocks, the rest initialise [S | b]
+__global__ __launch_bounds__(kBlock) void k_point_invert_schur_init(int nbi, int nt, const double* __restrict__ HPP,
+                                                                    double damping, double rcond,
+                                                                    double* __restrict__ HPPinv,
+                                                                    int* __restrict__ singular_count,
+                                                                    int* __restrict__ next_count, int nco, int hb1,
+                                                                    const int* __restrict__ opt_cam,
+                                                                    const double* __restrict__ HCC,
+                                                                    const double* __restrict__ bC,
+                                                                    double* __restrict__ S, double* __restrict__ b,
+                                                                    int use_hcc) {
+  if ((int)blockIdx.x < nbi)
+    point_invert_body(blockIdx.x * kBlock + threadIdx.x, nt, HPP, damping, rcond, HPPinv, singular_count, next_count);
+  else
+    schur_init_body((long long)(blockIdx.x - nbi) * kBlock + threadIdx.x, nco, hb1, opt_cam, HCC, bC, damping, S, b, use_hcc);
 }
 
 // --------------------------------------------------------------------------
