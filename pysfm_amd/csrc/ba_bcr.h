@@ -239,7 +239,8 @@ template <int HB>
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s, double* __restrict__ Dm,
                                                                double* __restrict__ Um, double* __restrict__ fm,
                                                                double* __restrict__ Pm, double* __restrict__ Qm,
-                                                               double* __restrict__ Gi, int* __restrict__ info) {
+                                                               double* __restrict__ Gi, int* __restrict__ info,
+                                                               double* __restrict__ xout) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int B = 6 * HB, ld = B + 1;
   double* G = sm;                       // [B][ld]  D_i -> its Cholesky factor L (lower)
@@ -549,6 +550,18 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   }
   __syncthreads();                       // the products above read g; only now overwrite fm[i]
   for (int e = tid; e < B; e += kBcrElimThreads) fm[(size_t)i * B + e] = g[e];
+  if (!haveL && !haveR) {
+    // the root of the elimination tree: nothing to wait for, x_i = G^-T g right here (its
+    // back-substitution launch is skipped by the host)
+    for (int task = tid; task < 4 * B; task += kBcrElimThreads) {
+      const int m = task >> 2, q4 = task & 3;
+      double acc = 0.0;
+      for (int k = m + q4; k < B; k += 4) acc += Xi[k * ld + m] * g[k];
+      acc += dpp_pair<0xB1>(acc);
+      acc += dpp_pair<0x4E>(acc);
+      if (q4 == 0) xout[(size_t)i * B + m] = acc;
+    }
+  }
 #ifdef BA_BCR_PROFILE
   if (tid == 0 && blockIdx.x == 1 && s == 1) {
     const long long t5 = clock64();

@@ -237,20 +237,20 @@ int ensure_reduced(ba_handle* h) {
 
 template <int HB>
 hipError_t launch_bcr_eliminate_hb(int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
-                                   double* P, double* Q, double* G, int* info) {
+                                   double* P, double* Q, double* G, int* info, double* x) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_bcr_eliminate<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_bcr_eliminate<HB>, dim3(cnt), dim3(kBcrElimThreads), lds, st, N, s, D, U, f, P, Q, G, info);
+  hipLaunchKernelGGL(k_bcr_eliminate<HB>, dim3(cnt), dim3(kBcrElimThreads), lds, st, N, s, D, U, f, P, Q, G, info, x);
   return hipSuccess;
 }
 
 hipError_t launch_bcr_eliminate(int hb, int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
-                                double* P, double* Q, double* G, int* info) {
-#define BA_HB_CASE(K) case K: return launch_bcr_eliminate_hb<K>(cnt, lds, st, N, s, D, U, f, P, Q, G, info);
+                                double* P, double* Q, double* G, int* info, double* x) {
+#define BA_HB_CASE(K) case K: return launch_bcr_eliminate_hb<K>(cnt, lds, st, N, s, D, U, f, P, Q, G, info, x);
   switch (hb) {
     BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
     BA_HB_CASE(9) BA_HB_CASE(10)
@@ -285,12 +285,15 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
     for (int s : strides) {
       const int cnt = (N / s + 1) / 2;
       HIPCHECK(h, launch_bcr_eliminate(hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
-                                       h->bcrG.p, h->flags.p + 1));
+                                       h->bcrG.p, h->flags.p + 1, h->dC.p));
     }
   }
   const size_t lds2 = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
-  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)strides.size());
-  for (int q = (int)strides.size() - 1; q >= 0; --q) {
+  // a level whose only node has no neighbours (the root) was solved inside its eliminate kernel
+  int top = (int)strides.size() - 1;
+  if (top >= 0 && (N / strides[top] + 1) / 2 == 1 && 2 * strides[top] - 1 >= N) --top;
+  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, top + 1);
+  for (int q = top; q >= 0; --q) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
     hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
                        h->bcrQ.p, h->bcrG.p, h->dC.p);    // x[N][B] IS dC's layout (padded to whole super-blocks)
