@@ -205,6 +205,9 @@ int ba_enable_timing(ba_handle* h, int on);
 /* bracket only the kernel ids whose bit is set (default: all); an event pair costs a few
  * microseconds of stream time, which matters when kernels are ~10 us long */
 int ba_set_timing_mask(ba_handle* h, uint64_t kernel_id_mask);
+/* bracket only every stride-th launch (run of launches) of each selected kernel: an event pair costs
+ * a few microseconds of stream time, which shows in a 0.36 ms step */
+int ba_set_timing_stride(ba_handle* h, int32_t stride);
 /* accumulated HIP-event time (ms) and launch count per kernel id since the last reset */
 int ba_get_timings(ba_handle* h, double* ms /*[BA_K_COUNT]*/, int64_t* launches /*[BA_K_COUNT]*/, int reset);
 const char* ba_kernel_name(int kernel_id);

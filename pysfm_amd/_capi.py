@@ -64,6 +64,7 @@ PROTOTYPES = {
     'ba_triangulate': (C.c_int, [_h, C.c_int, C.c_double, _dp]),
     'ba_enable_timing': (C.c_int, [_h, C.c_int]),
     'ba_set_timing_mask': (C.c_int, [_h, C.c_uint64]),
+    'ba_set_timing_stride': (C.c_int, [_h, C.c_int32]),
     'ba_get_timings': (C.c_int, [_h, _dp, C.POINTER(C.c_int64), C.c_int]),
     'ba_kernel_name': (C.c_char_p, [C.c_int]),
     'ba_version': (C.c_char_p, []),

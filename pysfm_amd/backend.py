@@ -327,7 +327,7 @@ class HipBackend(object):
         return X
 
     # ---------------------------------------------------------------- instrumentation
-    def enable_timing(self, on=True, only=None):
+    def enable_timing(self, on=True, only=None, stride=1):
         """HIP-event timing of the kernels; `only` = iterable of kernel names to bracket
         (each event pair costs a few microseconds of stream time)."""
         mask = (1 << 64) - 1
@@ -336,6 +336,7 @@ class HipBackend(object):
             for name in only:
                 mask |= 1 << capi.KERNEL_IDS.index(name)
         self._check(self._lib.ba_set_timing_mask(self._h, C.c_uint64(mask)))
+        self._check(self._lib.ba_set_timing_stride(self._h, int(stride)))
         self._check(self._lib.ba_enable_timing(self._h, int(bool(on))))
 
     def timings(self, reset=False):

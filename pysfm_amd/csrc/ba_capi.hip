@@ -109,6 +109,8 @@ struct ba_handle {
   // timing
   bool timing = false;
   unsigned long long timing_mask = ~0ull;   // which kernel ids are bracketed with events
+  int timing_stride = 1;                    // bracket every n-th eligible launch (an event pair costs stream time)
+  unsigned timing_seen[BA_K_COUNT] = {0};
   std::vector<hipEvent_t> ev_pool;
   std::vector<TimedLaunch> pending;
   double ms[BA_K_COUNT] = {0};
@@ -164,7 +166,8 @@ struct ScopedTimer {
   ba_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;
   bool on; int count;
   ScopedTimer(ba_handle* h_, int id_, int count_ = 1)
-      : h(h_), id(id_), on(h_->timing && ((h_->timing_mask >> id_) & 1ull)), count(count_) {
+      : h(h_), id(id_), on(h_->timing && ((h_->timing_mask >> id_) & 1ull) && (h_->timing_seen[id_]++ % (unsigned)h_->timing_stride) == 0),
+        count(count_) {
     if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
   }
   ~ScopedTimer() {
@@ -1319,6 +1322,14 @@ int ba_enable_timing(ba_handle* h, int on) {
 int ba_set_timing_mask(ba_handle* h, uint64_t kernel_id_mask) {
   if (!h) return BA_ERR_INVALID_ARG;
   h->timing_mask = kernel_id_mask;
+  return BA_OK;
+}
+
+int ba_set_timing_stride(ba_handle* h, int32_t stride) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, stride >= 1, BA_ERR_INVALID_ARG, "ba_set_timing_stride: stride must be >= 1");
+  h->timing_stride = stride;
+  for (auto& c : h->timing_seen) c = 0;
   return BA_OK;
 }
 
