@@ -56,6 +56,7 @@ struct ba_handle {
   bool have_params[2] = {false, false};
   bool have_linearization = false, have_schur = false, have_backsub = false;
   int lin_phys = 0;                  // physical parameter set of the linearisation
+  bool point_blocks_valid = false;   // HPP / bP hold the point blocks of the linearisation (ba_lm_trial leaves them to the reduction too)
   bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
   bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)
   double inv_damping = 0.0, inv_rcond = 0.0;
@@ -796,6 +797,19 @@ bool mfma_reduction_possible(const ba_handle* h) {
          h->nmchunks > 0;
 }
 
+int launch_point_blocks(ba_handle* h, int p, double* Wd) {
+  if (h->nt > 0) {
+    ScopedTimer tm(h, BA_K_LINEARIZE);
+    const long long threads = (long long)h->nt << h->glog;
+    hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
+                       h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd,
+                       0.0, 0.0, (double*)nullptr, (int*)nullptr, (int*)nullptr);
+  }
+  h->point_blocks_valid = true;
+  h->cam_blocks_valid = false;          // k_linearize cleared HCC / bC
+  return BA_OK;
+}
+
 int launch_camera_blocks(ba_handle* h, int p, bool clear) {
   if (clear) {
     HIPCHECK(h, hipMemsetAsync(h->HCC.p, 0, (size_t)h->nc * 36 * sizeof(double), h->stream));
@@ -822,24 +836,20 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
     HIPCHECK(h, h->W.resize(std::max<size_t>(1, (size_t)h->nobs * 18)));
     Wd = h->W.p;
   }
-  fuse = fuse && h->nt > 0;
+  fuse = fuse && h->nt > 0 && !store_W;
   h->inv_valid = false;
-  // The point inverses could ride along in k_linearize too, but only one lane in 2^glog holds a point there:
-  // the 3x3 eigen-solve at 1/16 lane occupancy costs 55 us where the dense k_point_invert costs 9 (measured).
-  const bool fuse_inv = false;
-  if (fuse_inv) h->sing_epoch ^= 1;    // the fused inversion counts singular blocks like k_point_invert does
-  if (h->nt > 0) {
-    ScopedTimer tm(h, BA_K_LINEARIZE);
-    const long long threads = (long long)h->nt << h->glog;
-    hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
-                       h->cams[p].p, h->X[p].p, h->glog, fuse ? (double*)nullptr : h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd,
-                       damping, rcond, fuse_inv ? h->HPPinv.p : (double*)nullptr, h->sing_counter(),
-                       h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
-  }
   h->cam_blocks_valid = false;
-  if (fuse_inv) { h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = rcond; }
-  if (!fuse) {
-    int rc = launch_camera_blocks(h, p, h->nt == 0);      // k_linearize cleared HCC / bC otherwise
+  h->point_blocks_valid = false;
+  // fuse (ba_lm_trial with the MFMA reduction): the reduction kernel linearises every observation anyway and
+  // adds the camera blocks on the way, so k_camera_blocks is skipped (ba_schur / ba_get_blocks run it lazily
+  // if another path asks for HCC / bC).  The same kernel can form HPP, bP and HPPinv too (BA_FUSE_LIN=1:
+  // then nothing is launched here at all), but that was measured 8 us per trial SLOWER: two more LDS round
+  // trips and a 3x3 inversion per batch on a wavefront that has a SIMD to itself cost more than the two
+  // kernels they replace.
+  static const bool fuse_lin = getenv("BA_FUSE_LIN") != nullptr;
+  if (!(fuse && fuse_lin)) {
+    int rc = launch_point_blocks(h, p, Wd);
+    if (rc == BA_OK && !fuse) rc = launch_camera_blocks(h, p, h->nt == 0);      // k_linearize cleared HCC / bC otherwise
     if (rc != BA_OK) return rc;
   }
   HIPCHECK(h, hipGetLastError());
@@ -862,6 +872,10 @@ int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_linearization, BA_ERR_STATE, "ba_get_blocks: call ba_linearize first");
   HIPCHECK(h, hipSetDevice(h->device));
+  if ((HPP || bP) && !h->point_blocks_valid) {
+    int rc = launch_point_blocks(h, h->lin_phys, nullptr);
+    if (rc != BA_OK) return rc;
+  }
   if ((HCC || bC) && !h->cam_blocks_valid) {       // ba_lm_trial left them to the reduction kernel
     int rc = launch_camera_blocks(h, h->lin_phys, true);
     if (rc != BA_OK) return rc;
@@ -908,14 +922,21 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   const bool mfma_possible = mfma_reduction_possible(h);
   const bool use_mfma = force_schur ? (strcmp(force_schur, "mfma") == 0 && mfma_possible) : (groups_ok && mfma_possible);
   const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
-  // camera blocks: normally in HCC / bC (k_camera_blocks); ba_lm_trial leaves them to the MFMA reduction
+  // point blocks and camera blocks: normally in HPP / bP (k_linearize) and HCC / bC (k_camera_blocks);
+  // ba_lm_trial leaves both to the MFMA reduction, which linearises every observation anyway
+  const bool fuse_lin = use_mfma && !h->point_blocks_valid;
+  if (!h->point_blocks_valid && !fuse_lin) {
+    rc = launch_point_blocks(h, h->lin_phys, nullptr);
+    if (rc != BA_OK) return rc;
+  }
   const bool fuse_cam = use_mfma && !h->cam_blocks_valid;
   if (!h->cam_blocks_valid && !fuse_cam) {
     rc = launch_camera_blocks(h, h->lin_phys, true);
     if (rc != BA_OK) return rc;
   }
-  const bool have_inv = h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond;
+  const bool have_inv = fuse_lin || (h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond);
   h->inv_valid = false;
+  if (fuse_lin) h->sing_epoch ^= 1;   // the reduction kernel counts singular blocks like k_point_invert does
   const long long ninit = (long long)reduced_doubles(h) + (long long)h->nco * 6;
   if (!have_inv && h->nt > 0 && h->nco > 0) {
     // point inverses and the initialisation of [S | b] are independent: one launch for both
@@ -929,7 +950,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
   } else {
     if (have_inv) {
-      h->inv_valid = true;    // k_linearize already inverted the damped point blocks for this (damping, rcond)
+      h->inv_valid = !fuse_lin;   // already inverted for this (damping, rcond) - or about to be, by the reduction kernel
     } else if (h->nt > 0) {
       h->sing_epoch ^= 1;
       ScopedTimer tm(h, BA_K_POINT_INVERT);
@@ -948,15 +969,26 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   if (use_mfma) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kGmBlock / kWave;
-    const size_t lds = (size_t)NW * 2 * kGmK * kGmLd * sizeof(double) + (size_t)NW * 16 * sizeof(int) +
+    const size_t lds = (size_t)NW * 2 * kGmK * kGmLd * sizeof(double) + (size_t)NW * 16 * sizeof(int) + (size_t)NW * 64 * sizeof(double) +
                        (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
     static bool attr_m = false;
     if (!attr_m) {
-      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_m = true;
     }
-    hipLaunchKernelGGL(k_schur_groups_mfma, dim3(h->nmchunks), dim3(kGmBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
-                       h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
+    if (fuse_lin)
+      hipLaunchKernelGGL(k_schur_groups_mfma<true>, dim3(h->nmchunks), dim3(kGmBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b, damping, fuse_cam ? 1 : 0,
+                         h->HPP.p, pinv_rcond, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+    else
+      hipLaunchKernelGGL(k_schur_groups_mfma<false>, dim3(h->nmchunks), dim3(kGmBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b, damping, fuse_cam ? 1 : 0,
+                         h->HPP.p, pinv_rcond, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+    if (fuse_lin) {
+      h->point_blocks_valid = true;
+      h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
+    }
   } else if (use_groups) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kGroupBlock / kWave;

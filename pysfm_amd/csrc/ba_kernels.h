@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
       const double f = 1.0 + damping;
       hpp[0] *= f; hpp[3] *= f; hpp[5] *= f;
       if (rcond >= 0.0) {
-        sym3_pinv(hpp, rcond, out);
+        sym3_pinv_fast(hpp, rcond, out);
       } else if (!sym3_inv(hpp, out)) {
         atomicAdd(singular_count, 1);
       }
@@ -377,7 +377,7 @@ __device__ __forceinline__ void point_invert_body(int k, int nt, const double* _
   const double f = 1.0 + damping;
   A[0] *= f; A[3] *= f; A[5] *= f;
   if (rcond >= 0.0) {
-    sym3_pinv(A, rcond, out);
+    sym3_pinv_fast(A, rcond, out);
   } else if (!sym3_inv(A, out)) {
     atomicAdd(singular_count, 1);
   }
@@ -796,25 +796,31 @@ constexpr int kGmPts = 6;                              // points per batch
 constexpr int kGmK = 20;                               // staged k rows: 3 per point, two zero rows
 constexpr int kGmLd = 64;                              // staged row length (60 used)
 
+template <bool FUSE_LIN>
 __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, const double* __restrict__ cams,
                                                                 const double* __restrict__ X,
                                                                 const SchurGroup* __restrict__ groups,
                                                                 const SchurChunk* __restrict__ chunks, int wn,
-                                                                const double* __restrict__ HPPinv,
-                                                                const double* __restrict__ bP,
+                                                                double* __restrict__ HPPinv,
+                                                                double* __restrict__ bP,
                                                                 double* __restrict__ S, double* __restrict__ b,
-                                                                double damping, int fuse_cam) {
+                                                                double damping, int fuse_cam,
+                                                                double* __restrict__ HPP, double rcond,
+                                                                int* __restrict__ singular_count,
+                                                                int* __restrict__ next_count) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   constexpr int NW = kGmBlock / kWave;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* sT = dyn;                                   // [NW][kGmK][kGmLd]
   double* sWm = sT + NW * kGmK * kGmLd;               // [NW][kGmK][kGmLd]
   int* sPos = reinterpret_cast<int*>(sWm + NW * kGmK * kGmLd);   // [NW][16]
-  double* tile = reinterpret_cast<double*>(sPos + NW * 16);
+  double* sSum = reinterpret_cast<double*>(sPos + NW * 16);       // [NW][64]  FUSE_LIN: HPP | bP of the staged points
+  double* tile = sSum + NW * 64;
   const int hb1 = P.hb + 1;
   const int rowlen = hb1 * 36;
   double* tb = tile + (size_t)wn * rowlen;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (FUSE_LIN && blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;   // as k_point_invert: the counter the NEXT inversion uses
   const int lr = lane & 15, lk = lane >> 4;
   const SchurChunk ck = chunks[blockIdx.x];
   const int p0 = ck.p0;
@@ -822,6 +828,7 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
   double* mT = sT + wv * kGmK * kGmLd;
   double* mW = sWm + wv * kGmK * kGmLd;
   int* mPos = sPos + wv * 16;
+  double* mSum = sSum + wv * 64;
   for (int i = lane; i < kGmK * kGmLd; i += 64) { mT[i] = 0.0; mW[i] = 0.0; }     // incl. the two zero k rows
   __syncthreads();
   // column of this lane in each of the 4 column tiles: observation j = n / 6, entry c = n % 6;
@@ -864,9 +871,13 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
       if (stager && k < gr.pt_end) {
         in.z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { in.x[q] = X[3 * (size_t)k + q]; in.g[q] = bP[3 * (size_t)k + q]; }
+        for (int q = 0; q < 3; ++q) in.x[q] = X[3 * (size_t)k + q];
+        if (!FUSE_LIN) {                                       // otherwise both are formed right here, in phase A
 #pragma unroll
-        for (int q = 0; q < 6; ++q) in.A[q] = HPPinv[6 * (size_t)k + q];
+          for (int q = 0; q < 3; ++q) in.g[q] = bP[3 * (size_t)k + q];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) in.A[q] = HPPinv[6 * (size_t)k + q];
+        }
       }
     };
     PointIn nxt;
@@ -883,16 +894,73 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
       if (kb == gr.pt_begin) ta0_first = ta0;
 #endif
       // ---- phase A
+      double e[2], r[2], Jc[12], Jp[6], Apt[6], gpt[3];
+      const bool live = stager && slot < np;
+      if (live) obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
+      if constexpr (FUSE_LIN) {
+        // prepare_schur_complement for the staged points (k_linearize's and k_point_invert's work):
+        // HPP_k = sum_i Jp^T Jp, bP_k = sum_i Jp^T r over the point's L lanes - 9 sums per point, each
+        // done by one lane of the point through LDS - then every lane of the point inverts the damped
+        // block for itself (same instruction count for the wavefront as one lane doing it).
+        double loc[9];
+        if (live) {
+          loc[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3]; loc[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4]; loc[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+          loc[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4]; loc[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5]; loc[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+          loc[6] = Jp[0] * r[0] + Jp[3] * r[1]; loc[7] = Jp[1] * r[0] + Jp[4] * r[1]; loc[8] = Jp[2] * r[0] + Jp[5] * r[1];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) loc[c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) mT[c * kGmLd + lane] = loc[c];       // rows 0..8 of the staging area are free here
+        lds_wave_sync();
+        if (live) {
+          const int k = kb + slot;
+          for (int c = oi; c < 9; c += L) {
+            double v[kGmMaxL];
+#pragma unroll
+            for (int j = 0; j < kGmMaxL; ++j) v[j] = j < L ? mT[c * kGmLd + slot * L + j] : 0.0;   // one LDS round trip
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < kGmMaxL; ++j) sum += v[j];
+            mSum[slot * 9 + c] = sum;
+            if (c < 6) HPP[6 * (size_t)k + c] = sum; else bP[3 * (size_t)k + c - 6] = sum;
+          }
+        }
+        lds_wave_sync();
+        if (live) {
+          double hp[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) hp[c] = mSum[slot * 9 + c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gpt[c] = mSum[slot * 9 + 6 + c];
+          const double f = 1.0 + damping;
+          hp[0] *= f; hp[3] *= f; hp[5] *= f;
+          if (rcond >= 0.0) {
+            sym3_pinv_fast(hp, rcond, Apt);
+          } else if (!sym3_inv(hp, Apt) && oi == 0) {
+            atomicAdd(singular_count, 1);
+          }
+          if (oi == 0) {
+            const int k = kb + slot;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) HPPinv[6 * (size_t)k + c] = Apt[c];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Apt[c] = cur.A[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gpt[c] = cur.g[c];
+      }
       if (stager) {
         double W[18], T[18];
         if (slot < np) {
-          double e[2], r[2], Jc[12], Jp[6];
-          obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
           block_W(Jc, Jp, W);
-          block_T(W, cur.A, T);
+          block_T(W, Apt, T);
           if (mypos >= 0) {                                   // b[i] -= T_i bP_k
 #pragma unroll
-            for (int a = 0; a < 6; ++a) bacc[a] -= T[a * 3] * cur.g[0] + T[a * 3 + 1] * cur.g[1] + T[a * 3 + 2] * cur.g[2];
+            for (int a = 0; a < 6; ++a) bacc[a] -= T[a * 3] * gpt[0] + T[a * 3 + 1] * gpt[1] + T[a * 3 + 2] * gpt[2];
             if (fuse_cam) {                                   // HCC[i] += Jc^T Jc, b[i] += Jc^T r (k_camera_blocks' work)
               int idx = 0;
 #pragma unroll

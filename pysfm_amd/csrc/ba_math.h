@@ -235,6 +235,28 @@ BA_HD void sym3_pinv(const double A[6], double rcond, double out[6]) {
   }
 }
 
+// numpy.linalg.pinv(A, rcond) again, with a short cut for the common case: for a positive definite
+// block, lambda_min / lambda_max >= det / trace^3 (lambda_min >= det / lambda_max^2, lambda_max <= trace),
+// so when det > rcond * trace^3 nothing is cut off and the pseudo-inverse IS the inverse - 30 flops by
+// cofactors instead of the Jacobi eigen-solve (a few thousand cycles of dependent fp64 work per wavefront).
+BA_HD void sym3_pinv_fast(const double A[6], double rcond, double out[6]) {
+  const double tr = A[0] + A[3] + A[5];
+  const double c00 = A[3] * A[5] - A[4] * A[4];
+  const double c01 = A[2] * A[4] - A[1] * A[5];
+  const double c02 = A[1] * A[4] - A[2] * A[3];
+  const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  const bool easy = A[0] > 0.0 && A[3] > 0.0 && A[5] > 0.0 && c00 > 0.0 && det > rcond * tr * tr * tr && det < INFINITY;
+  if (easy) {
+    const double id = 1.0 / det;
+    out[0] = c00 * id; out[1] = c01 * id; out[2] = c02 * id;
+    out[3] = (A[0] * A[5] - A[2] * A[2]) * id;
+    out[4] = (A[1] * A[2] - A[0] * A[4]) * id;
+    out[5] = (A[0] * A[3] - A[1] * A[1]) * id;
+  } else {
+    sym3_pinv(A, rcond, out);
+  }
+}
+
 // numpy.linalg.inv for a symmetric 3x3 (bundle_adjuster.py:254).  Returns false
 // when the block is singular (numpy raises LinAlgError there).
 BA_HD bool sym3_inv(const double A[6], double out[6]) {

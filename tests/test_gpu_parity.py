@@ -12,6 +12,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from conftest import load_golden
 from oracle import ba_oracle as O
 
@@ -594,6 +596,34 @@ def test_lm_trial_entry_equals_stepwise_calls(be):
         close(c_fused, O.cost(sensor, s['K'], R2, t2, X2, *a[4:], *flags), 1e-8)
     be.swap_params()                                        # accept: the trial set becomes current
     close(be.get_params(0)[2], Xs, 0.)
+
+
+def test_fused_linearisation_variant_of_the_trial():
+    """BA_FUSE_LIN=1: k_schur_groups_mfma also forms HPP, bP and HPPinv (no k_linearize / k_point_invert
+    launch).  Slower than the default and therefore off, but it must give the same trial."""
+    import subprocess
+    import sys
+    code = """
+import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+import numpy as np
+from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+from pysfm_amd import synthetic_data as sd
+s = sd.generate_banded_scene(60, 3000, track_len=8, outlier_frac=.02)
+b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=sensor_model.CauchyModel(.05))
+ba = BundleAdjuster(verbose=False); ba.set_bundle(b); ba.optimize(max_steps=5)
+print('COSTS', ' '.join('%%.15e' %% c for c in ba.costs))
+R, t, X = ba.backend.get_params(0)
+print('HPP', '%%.15e' %% float(np.abs(X).sum()), '%%.15e' %% float(np.abs(t).sum()))
+""" % (ROOT, ROOT)
+    out = {}
+    for tag, extra in (('default', {}), ('fused', {'BA_FUSE_LIN': '1'})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = {l.split()[0]: [float(x) for x in l.split()[1:]] for l in r.stdout.splitlines() if l.startswith(('COSTS', 'HPP'))}
+        out[tag] = lines
+    close(np.array(out['fused']['COSTS']), np.array(out['default']['COSTS']), 1e-9)
+    close(np.array(out['fused']['HPP']), np.array(out['default']['HPP']), 1e-9)
 
 
 def test_sharded_trial_path_matches_single_gpu_path():
