@@ -1,7 +1,10 @@
 // ba_kernels.h - gfx950 (MI355X, CDNA4) kernels of the bundle-adjustment inner loop.
 //
-// Everything here is fp64 on blocks no larger than 6x6, so nothing is MFMA-shaped:
-// the kernels are HBM / L2-atomic bound.  Layout rules used throughout:
+// Everything here is fp64.  The individual blocks are no larger than 6x6; the per-observation
+// kernels are vector code bound by fp64 issue and gather latency, and the one step that becomes a
+// real matrix product once points are grouped - the Schur reduction over points that share their
+// cameras - runs on the fp64 matrix cores (k_schur_groups_mfma; the dense nodes of the reduced solve
+// do the same in ba_bcr.h).  Layout rules used throughout:
 //   * observations are a structure of arrays sorted by point (CSR `pt_off`), so a
 //     wavefront reads `obs_cam` / `obs_z` as contiguous, coalesced runs;
 //   * a camera is one 96-byte record [R | t] and is gathered (L1/L2 resident:
