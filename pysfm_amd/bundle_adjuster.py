@@ -120,6 +120,8 @@ class BundleAdjuster(object):
 
     def _upload(self, bundle, which):
         self.backend.set_params(which, *self._params_of(bundle))
+        if which == PARAMS_CUR:
+            self._cur_cost = None                    # cached cost of the current set
 
     # ------------------------------------------------------------------ set_bundle
     def set_bundle(self, bundle, camera_ids=None, track_ids=None, camera_mask=None, track_mask=None):
@@ -208,7 +210,8 @@ class BundleAdjuster(object):
         self.num_steps = 0
         self.lm_trials = 0
         self.converged = False
-        self.costs = [self._cost(PARAMS_CUR)]
+        self._cur_cost = self._cost(PARAMS_CUR)
+        self.costs = [self._cur_cost]
         while not self.converged and self.num_steps < max_steps:
             self.step(param_mask, improvement_threshold)
         if self.converged:
@@ -220,10 +223,14 @@ class BundleAdjuster(object):
         '''One outer iteration of optimize(): retry with growing damping until a trial
         lowers the cost (bundle_adjuster.py:128-157; cf. optimize.py:110-135).
         Returns self.converged.'''
+        # the cost of the current set is the cost of the trial that was accepted last (same kernel, same
+        # data, deterministic summation order): no need to evaluate it again at the top of every step
+        cur_cost = getattr(self, '_cur_cost', None)
+        if cur_cost is None:
+            cur_cost = self._cur_cost = self._cost(PARAMS_CUR)
         if not self.costs:
-            self.costs = [self._cost(PARAMS_CUR)]
+            self.costs = [cur_cost]
         self.num_steps += 1
-        cur_cost = self._cost(PARAMS_CUR)
         self._say('Step %d: cost=%f, damping=%f' % (self.num_steps, cur_cost, self._damping))
         while not self.converged and self._damping < 1e+8:
             accepted, next_cost = self.trial(self._damping, param_mask, cur_cost)
@@ -290,6 +297,7 @@ class BundleAdjuster(object):
             self.backend.swap_params()                          # self.bundle = bnext
             self._host_stale = True
             self._have_blocks = False
+            self._cur_cost = next_cost
             return True, next_cost
         return False, next_cost
 
