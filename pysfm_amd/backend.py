@@ -17,6 +17,9 @@ from ._capi import PARAMS_CUR, PARAMS_TRIAL  # noqa: F401  (re-exported)
 # host (LAPACK gesv - the reference's own call, bundle_adjuster.py:303); larger
 # ones stay on the GPU (torch.linalg.solve_ex -> rocSOLVER getrf/getrs).
 HOST_SOLVE_MAX_UNKNOWNS = 768
+DENSE_MIN_HALF_BANDWIDTH = 21     # (= kMaxBandSolve: beyond it the solve is dense anyway)
+DENSE_MIN_FILL = 0.25             # observed fraction of the (camera, track) pairs
+DENSE_MAX_BYTES = 2 << 30         # of the two staged operands
 
 
 class SingularPointBlock(np.linalg.LinAlgError):
@@ -41,6 +44,7 @@ class HipBackend(object):
         self._torch = None
         self._S_t = self._b_t = self._Sb_t = None
         self._A_t = self._rhs_t = None
+        self._dense = self._dense_keep = None
         self._attach_torch()
 
     # ---------------------------------------------------------------- plumbing
@@ -81,6 +85,7 @@ class HipBackend(object):
             self._lib.ba_destroy(self._h)
             self._h = None
         self._S_t = self._b_t = self._A_t = self._rhs_t = self._trial_t = None
+        self._dense = self._dense_keep = None
 
     def __del__(self):
         try:
@@ -116,6 +121,7 @@ class HipBackend(object):
         self._host_dC = None
         if self._torch is not None:
             self._bind_reduced()
+        self._bind_dense()
 
     def _bind_reduced(self):
         torch = self._torch
@@ -185,6 +191,33 @@ class HipBackend(object):
     def schur(self, which, damping, rcond):
         """rcond None -> plain inverse (SCHUR_COMPLIMENT_PINV_THRESHOLD = None)."""
         self._check(self._lib.ba_schur(self._h, which, float(damping), -1.0 if rcond is None else float(rcond)))
+        if self._dense is not None:
+            # dense visibility: the reduction is ONE matrix product - a plain library DGEMM (rocBLAS through
+            # torch) on the operands ba_schur has just staged, then subtracted from the band on the device
+            Td, Wd, g = self._dense
+            with self.stream_ctx():
+                Sd = self._torch.mm(Td.t(), Wd)
+                bc = self._torch.mv(Td.t(), g)
+                self._check(self._lib.ba_dense_apply(self._h, C.c_void_p(Sd.data_ptr()), C.c_void_p(bc.data_ptr())))
+                self._dense_keep = (Sd, bc)               # alive until the kernel has run
+
+    def _bind_dense(self):
+        """Dense-visibility reduction (include/pysfm_ba.h ba_bind_dense_stage): when the band is too wide
+        for the device solvers anyway and most (camera, track) pairs are observed."""
+        self._dense = None
+        if self._torch is None or self.nco == 0 or self.nt == 0:
+            return
+        fill = self.nobs / float(self.nco * self.nt)
+        words = 3 * self.nt * 6 * self.nco
+        if self.half_bandwidth > DENSE_MIN_HALF_BANDWIDTH and fill >= DENSE_MIN_FILL and 16 * words <= DENSE_MAX_BYTES:
+            torch = self._torch
+            dev = torch.device('cuda', self.device)
+            Td = torch.empty((3 * self.nt, 6 * self.nco), dtype=torch.float64, device=dev)
+            Wd = torch.empty_like(Td)
+            g = torch.empty(3 * self.nt, dtype=torch.float64, device=dev)
+            self._check(self._lib.ba_bind_dense_stage(self._h, C.c_void_p(Td.data_ptr()), C.c_void_p(Wd.data_ptr()),
+                                                      C.c_void_p(g.data_ptr())))
+            self._dense = (Td, Wd, g)
 
     def reduced_tensors(self):
         """torch views (S_band[nco*(hb+1)*36], b[nco*6]) of the device-resident reduced

@@ -60,6 +60,7 @@ struct ba_handle {
   bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
   bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)
   double inv_damping = 0.0, inv_rcond = 0.0;
+  double *dense_Td = nullptr, *dense_Wd = nullptr, *dense_g = nullptr;   // ba_bind_dense_stage: operands of the dense-visibility reduction
   double* trial_result_dev = nullptr; // bound by ba_bind_trial_result: device copy of the cost partials + status words
   double trial_rcond = 0.0;          // ba_lm_trial_begin -> ba_lm_trial_end
   int glog = 0;              // lanes per point = 2^glog
@@ -638,6 +639,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   }
   // a reduced system bound for another problem size is no longer valid
   h->S = nullptr; h->b = nullptr;
+  h->dense_Td = h->dense_Wd = h->dense_g = nullptr;
   h->have_problem = true;
   h->have_params[0] = h->have_params[1] = false;
   h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
@@ -920,7 +922,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
   const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
   const bool mfma_possible = mfma_reduction_possible(h);
-  const bool use_mfma = force_schur ? (strcmp(force_schur, "mfma") == 0 && mfma_possible) : (groups_ok && mfma_possible);
+  const bool use_mfma = !h->dense_Td && (force_schur ? (strcmp(force_schur, "mfma") == 0 && mfma_possible) : (groups_ok && mfma_possible));
   const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
   // point blocks and camera blocks: normally in HPP / bP (k_linearize) and HCC / bC (k_camera_blocks);
   // ba_lm_trial leaves both to the MFMA reduction, which linearises every observation anyway
@@ -966,7 +968,19 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                          h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
     }
   }
-  if (use_mfma) {
+  if (h->dense_Td) {
+    // dense visibility: stage the operands of the one big matrix product; the caller runs the DGEMM and
+    // hands the result to ba_dense_apply (the reduction kernels below would do 36 global atomics per
+    // (pair, point): 258 M of them at 100 cameras x 1000 tracks)
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    const int M = 6 * h->nco;
+    const size_t bytes = (size_t)3 * h->nt * M * sizeof(double);
+    HIPCHECK(h, hipMemsetAsync(h->dense_Td, 0, bytes, h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->dense_Wd, 0, bytes, h->stream));
+    const long long n = std::max<long long>(h->nobs, (long long)h->nt * 3);
+    hipLaunchKernelGGL(k_dense_stage, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
+                       h->HPPinv.p, h->bP.p, M, h->dense_Td, h->dense_Wd, h->dense_g);
+  } else if (use_mfma) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kGmBlock / kWave;
     const size_t lds = (size_t)NW * 2 * kGmK * kGmLd * sizeof(double) + (size_t)NW * 16 * sizeof(int) + (size_t)NW * 64 * sizeof(double) +
@@ -1252,6 +1266,28 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   return BA_OK;
 }
 
+int ba_bind_dense_stage(ba_handle* h, void* Td_dev, void* Wd_dev, void* g_dev) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, (Td_dev != nullptr) == (Wd_dev != nullptr) && (Td_dev != nullptr) == (g_dev != nullptr), BA_ERR_INVALID_ARG,
+          "ba_bind_dense_stage: give all three buffers, or none");
+  h->dense_Td = static_cast<double*>(Td_dev); h->dense_Wd = static_cast<double*>(Wd_dev); h->dense_g = static_cast<double*>(g_dev);
+  return BA_OK;
+}
+
+int ba_dense_apply(ba_handle* h, const void* Sd_dev, const void* bc_dev) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur && Sd_dev && bc_dev, BA_ERR_STATE, "ba_dense_apply: call ba_schur (with ba_bind_dense_stage) first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  if (h->nco > 0) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    const long long n = (long long)reduced_doubles(h) + (long long)h->nco * 6;
+    hipLaunchKernelGGL(k_dense_apply, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1,
+                       static_cast<const double*>(Sd_dev), 6 * h->nco, static_cast<const double*>(bc_dev), h->S, h->b);
+  }
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
 int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, min_hb >= 0, BA_ERR_INVALID_ARG, "ba_set_min_half_bandwidth: negative");
@@ -1305,6 +1341,8 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, next_cost && info, BA_ERR_INVALID_ARG, "ba_lm_trial: NULL output");
   *info = 0;
+  if (h->have_problem && h->hb > kMaxBandSolve) { *info = -1; return BA_OK; }   // band too wide for the device solvers: do not
+                                                                                // linearise and reduce just to find that out
   int32_t pre = 0;
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_lm_trial_end(h, cam_param_mask, &pre);

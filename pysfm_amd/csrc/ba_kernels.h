@@ -1116,6 +1116,58 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
 }
 
 // --------------------------------------------------------------------------
+// Dense visibility (every track seen by most cameras: the reference's own data sets).  There the
+// reduction  S -= sum_k Tstack_k Wstack_k^T  is ONE dense matrix product with inner dimension 3 nt:
+// k_dense_stage writes the two operands  Td, Wd [3 nt][6 nco]  (row 3 k + d, column 6 pos + a; zero
+// where a camera does not see a point), a library DGEMM forms Td^T Wd and Td^T bP, and k_dense_apply
+// subtracts the result from the band-stored [S | b].  One observation per lane.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_dense_stage(DevProblem P, const double* __restrict__ cams,
+                                                        const double* __restrict__ X,
+                                                        const double* __restrict__ HPPinv,
+                                                        const double* __restrict__ bP, int M,
+                                                        double* __restrict__ Td, double* __restrict__ Wd,
+                                                        double* __restrict__ gvec) {
+  const long long n = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (n < (long long)P.nt * 3) gvec[n] = bP[n];
+  if (n >= P.nobs) return;
+  const int c = P.obs_cam[n], k = P.obs_pt[n];
+  const int pos = P.cam_opt_pos[c];
+  if (pos < 0) return;
+  const double2 z = P.obs_z[n];
+  const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
+  double cm[12], e[2], r[2], Jc[12], Jp[6], W[18], T[18], A[6];
+  load_cam(cams, c, cm);
+  obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+  block_W(Jc, Jp, W);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) A[q] = HPPinv[6 * (size_t)k + q];
+  block_T(W, A, T);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const size_t row = ((size_t)3 * k + d) * M + 6 * (size_t)pos;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { Td[row + a] = T[a * 3 + d]; Wd[row + a] = W[a * 3 + d]; }
+  }
+}
+
+// S_band(i, j >= i) -= Sd[6 i .. , 6 j ..],  b -= bc;  one thread per entry of [S | b]
+__global__ __launch_bounds__(kBlock) void k_dense_apply(int nco, int hb1, const double* __restrict__ Sd, int M,
+                                                        const double* __restrict__ bc, double* __restrict__ S,
+                                                        double* __restrict__ b) {
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long nS = (long long)nco * hb1 * 36;
+  if (tid < nS) {
+    const int e = (int)(tid % 36);
+    const long long blk = tid / 36;
+    const int d = (int)(blk % hb1), i = (int)(blk / hb1), j = i + d;
+    if (j < nco) S[tid] -= Sd[((size_t)6 * i + e / 6) * M + 6 * (size_t)j + e % 6];
+  } else if (tid < nS + (long long)nco * 6) {
+    b[tid - nS] -= bc[tid - nS];
+  }
+}
+
+// --------------------------------------------------------------------------
 // backsubstitute (bundle_adjuster.py:316-331):
 //   dP_k = HPPinv_k (bP_k - sum_i W_ik^T dC_i),  W^T dC = Jp^T (Jc dC).
 // dC[nco*6] is indexed by optimised-camera position; frozen cameras contribute nothing.

@@ -12,6 +12,8 @@ ba = BundleAdjuster(verbose=False)
 ba.set_bundle(b)
 be = ba.backend
 print('cameras', be.nc, 'tracks', be.nt, 'obs', be.nobs, 'half bandwidth', be.half_bandwidth)
+ba.optimize(max_steps=2)                      # warm-up (code objects, rocBLAS handle)
+ba.set_bundle(b)
 t0 = time.perf_counter(); ba.optimize(max_steps=10); t1 = time.perf_counter()
 print('optimize: %d steps, %d trials, %.1f ms, cost %.6g -> %.6g, solve path %s' % (ba.num_steps, ba.lm_trials, (t1 - t0) * 1e3, ba.costs[0], ba.costs[-1], be.last_solve_path))
 be.enable_timing(True); be.timings(reset=True)
