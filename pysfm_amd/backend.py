@@ -285,10 +285,17 @@ class HipBackend(object):
                 return np.linalg.solve(A.cpu().numpy(), rhs.cpu().numpy())
             except np.linalg.LinAlgError:
                 raise ReducedSystemSingular
-        x, info = torch.linalg.solve_ex(A, rhs.unsqueeze(1), check_errors=False)
-        if int(info.item()) != 0:
-            raise ReducedSystemSingular
-        return x.squeeze(1).cpu().numpy()
+        # symmetric positive definite in every regular LM step: rocSOLVER's Cholesky is 2-3x faster than its
+        # LU at these sizes (measured: n = 3000: 10.5 ms against 28 ms); anything else goes through LU, the
+        # reference's own factorisation (numpy.linalg.solve = gesv), with its singular-matrix semantics
+        with self.stream_ctx():
+            L, info = torch.linalg.cholesky_ex(A, check_errors=False)
+            if int(info.item()) == 0:
+                return torch.cholesky_solve(rhs.unsqueeze(1), L).squeeze(1).cpu().numpy()
+            x, info = torch.linalg.solve_ex(A, rhs.unsqueeze(1), check_errors=False)
+            if int(info.item()) != 0:
+                raise ReducedSystemSingular
+            return x.squeeze(1).cpu().numpy()
 
     def get_solution(self):
         """dC[nco,6] of the last solve_reduced()."""

@@ -551,6 +551,22 @@ def test_wide_band_takes_dense_path(be):
     close(-dC, g['update_l10_motion'], 1e-7)
 
 
+def test_large_dense_system_is_solved_on_the_gpu(be):
+    """Band too wide for the device band solvers and more than HOST_SOLVE_MAX_UNKNOWNS unknowns: the
+    flattened system goes through rocSOLVER (Cholesky, LU behind it) and must agree with LAPACK."""
+    nc, L = 160, 30
+    s = banded(nc, 20 * nc, track_len=L)
+    flags = default_flags(nc, 20 * nc)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    assert be.half_bandwidth == L - 1 and be.nco * 6 > 768
+    dC, dP = hip_update(be, 5.)
+    assert be.last_solve_path == 'dense'
+    S, b = be.get_reduced()
+    n = be.nco * 6
+    x = np.linalg.solve(S.transpose(0, 2, 1, 3).reshape(n, n), b.reshape(n))
+    close(dC.reshape(-1), x, 1e-9)
+
+
 def test_band_solver_reports_non_positive_pivot(be):
     """An indefinite reduced system must not be 'solved' by Cholesky: info > 0, dense LU takes over."""
     g = load_golden('scene_4x10_cauchy')
