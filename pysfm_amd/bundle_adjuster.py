@@ -267,7 +267,7 @@ class BundleAdjuster(object):
             self._have_blocks = True
             if info == 0:
                 next_cost = cost
-        elif self._comm is not None and hasattr(be, 'lm_trial_begin') and str(self._comm.device).startswith('cuda'):
+        elif self._comm is not None and hasattr(be, 'lm_trial_begin'):
             # sharded: the same batch in two halves around the all-reduce of [S | b]; the ranks' trial
             # costs are summed on the device, one synchronisation per trial
             cam_param_mask = None

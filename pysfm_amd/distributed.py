@@ -96,7 +96,7 @@ class ShardComm(object):
         """The one data-path collective: sum the partial reduced camera systems."""
         payload = backend.reduced_payload()
         with _stream_of(backend):              # ordered after the kernels that wrote it, before the ones that read it
-            self._dist.all_reduce(payload, group=self.group)
+            self._all_reduce_device(payload)
         self.bytes_reduced += payload.numel() * 8
 
     def allreduce_trial_result(self, backend, npartials):
@@ -107,9 +107,20 @@ class ShardComm(object):
         with _stream_of(backend):
             t = backend.trial_result()
             r = torch.cat([t[:npartials].sum().reshape(1), t[npartials:npartials + 2]])
-            self._dist.all_reduce(r[:1], group=self.group)
-            c, nsing, info = r.cpu().tolist()
+            cost = r[:1].clone()
+            self._all_reduce_device(cost)
+            (c,), (_, nsing, info) = cost.cpu().tolist(), r.cpu().tolist()
         return c, int(nsing), int(info)
+
+    def _all_reduce_device(self, t):
+        """Sum a device tensor over the ranks in place.  RCCL does it on the device; a gloo group (the
+        two-ranks-on-one-GPU test) stages it through the host."""
+        if t.is_cuda and self._dist.get_backend(self.group) != 'nccl':
+            h = t.cpu()
+            self._dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self._dist.all_reduce(t, group=self.group)
 
     def barrier(self):
         self._dist.barrier(group=self.group)

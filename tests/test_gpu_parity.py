@@ -614,6 +614,58 @@ def test_lm_trial_entry_equals_stepwise_calls(be):
     close(be.get_params(0)[2], Xs, 0.)
 
 
+def _two_rank_worker(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    from pysfm_amd import synthetic_data as sd
+    from pysfm_amd.distributed import ShardComm, shard_tracks
+    s = sd.generate_banded_scene(60, 3000, track_len=8, outlier_frac=.02)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
+                                sensor_model=sensor_model.CauchyModel(.05))
+    comm = ShardComm()
+    ba = BundleAdjuster(device=0, comm=comm, verbose=False)          # both ranks on GPU 0
+    ba.set_bundle(b, track_ids=shard_tracks(b, rank, world))
+    ba.optimize(max_steps=6)
+    X = comm.gather_points(ba)
+    R, t, _ = ba.backend.get_params(0)
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), costs=np.array(ba.costs), X=X, R=R, t=t, trials=ba.lm_trials,
+             nbytes=comm.bytes_reduced)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_walk_the_single_gpu_trajectory(tmp_path):
+    """Two processes, each with its half of the tracks on the real HIP backend (same GPU, gloo group
+    staging the collectives through the host): ba_lm_trial_begin -> all-reduce of [S | b] ->
+    ba_lm_trial_end, band layout agreed over the ranks, trial costs summed.  Must reproduce the
+    unsharded run."""
+    import socket
+    import torch.multiprocessing as mp
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    from pysfm_amd import synthetic_data as sd
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s = sd.generate_banded_scene(60, 3000, track_len=8, outlier_frac=.02)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
+                                sensor_model=sensor_model.CauchyModel(.05))
+    ba = BundleAdjuster(verbose=False)
+    ba.set_bundle(b)
+    ba.optimize(max_steps=6)
+    R1, t1, X1 = ba.backend.get_params(0)
+    r0, r1 = (np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in (0, 1))
+    for r in (r0, r1):
+        assert int(r['trials']) == ba.lm_trials and int(r['nbytes']) > 0
+        close(r['costs'], np.array(ba.costs), 1e-9)
+        close(r['t'], t1, 1e-8)
+        close(r['X'], X1, 1e-8)
+
+
 def test_fused_linearisation_variant_of_the_trial():
     """BA_FUSE_LIN=1: k_schur_groups_mfma also forms HPP, bP and HPPinv (no k_linearize / k_point_invert
     launch).  Slower than the default and therefore off, but it must give the same trial."""
