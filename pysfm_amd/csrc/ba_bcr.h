@@ -39,7 +39,7 @@ namespace ba {
 
 constexpr int kBcrThreads = 1024;                // assemble (111 nodes at config 3: few workgroups, so make them wide)
 constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
-constexpr int kBcrMaxHB = 10;                  // 4 matrices of B x (B+1) doubles must fit in LDS
+constexpr int kBcrMaxHB = 11;                  // 4 matrices of B x (B+1) doubles must fit in LDS (B = 66: 145 KB)
 
 __host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 200) * sizeof(double); }   // + inverse of the current diagonal block
 
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #endif
     // ---------------- phase 3: the URGENT part of the update: block column kb+1 only (its diagonal block and the rows
     //                  below), so that the next diagonal factor can start while the rest is still owed
-    if (!last && wave >= 8 && wave <= 10) {
+    if (!last && wave >= 8 && wave <= 11) {
       // rows kn + 16 t .. of the next block column: C -= panel panel^T, K = 12
       typedef double mfma_acc __attribute__((ext_vector_type(4)));
       const int i0 = kn + 16 * (wave - 8);

@@ -258,7 +258,7 @@ hipError_t launch_bcr_eliminate(int hb, int cnt, size_t lds, hipStream_t st, int
 #define BA_HB_CASE(K) case K: return launch_bcr_eliminate_hb<K>(cnt, lds, st, N, s, D, U, f, P, Q, G, info, x);
   switch (hb) {
     BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
-    BA_HB_CASE(9) BA_HB_CASE(10)
+    BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11)
     default: return hipErrorInvalidValue;
   }
 #undef BA_HB_CASE
