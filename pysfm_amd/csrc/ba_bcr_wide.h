@@ -1,0 +1,283 @@
+// ba_bcr_wide.h - block cyclic reduction for half-bandwidths 12..21 (B = 6 hb = 72..126 unknowns per
+// super-block).  Same algebra, node numbering and workspace layout as ba_bcr.h, but one B x B matrix is
+// all that fits in LDS, so a level is three kernels instead of one:
+//
+//   k_bcrw_factor    one workgroup per node:  D_i = L L^T in LDS (the blocked, look-ahead Cholesky of
+//                    ba_bcr.h without right-hand sides), L -> global (1 / L_kk on its diagonal)
+//   k_bcrw_solve     one wavefront per (node, 64 right-hand sides):  [P | Q | G^-1 | g] = L^-1 [T_il | T_ir | I | f]
+//   k_bcrw_products  one workgroup per (node, 32 x 32 outputs):  D_l -= P^T P,  D_r -= Q^T Q,
+//                    T[l,r] = -P^T Q,  f_l -= P^T g,  f_r -= Q^T g
+//   k_bcrw_backsolve x_i = G^-T (g - P x_l - Q x_r)
+//
+// The single-workgroup band Cholesky (k_band_solve) these replace walks 1000 cameras in 7..20 ms at
+// these widths; the levels here are ~60 us each.  The solve and product kernels are plain vector code
+// (first version: correct and parallel; MFMA forms as in ba_bcr.h are the obvious next step).
+#pragma once
+
+#include "ba_bcr.h"
+
+namespace ba {
+
+constexpr int kBcrwMinHB = kBcrMaxHB + 1;
+constexpr int kBcrwMaxHB = 21;                 // B = 126: one B x (B+1) fp64 matrix = 128 KB of the 160 KB LDS
+constexpr int kBcrwSolveCols = 64;            // right-hand sides per wavefront in k_bcrw_solve
+constexpr int kBcrwTile = 32;                 // output tile edge of k_bcrw_products
+
+__host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16) * sizeof(double); }
+
+// ---- factor: Lm[i] = Cholesky factor of Dm[i] (lower, row-major B x B, 1 / L_kk on the diagonal)
+template <int HB>
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, const double* __restrict__ Dm,
+                                                                double* __restrict__ Lm, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int B = 6 * HB, ld = B + 1;
+  double* G = sm;                       // [B][ld]
+  double* dinv = G + (size_t)B * ld;    // [B]
+  int* bad = reinterpret_cast<int*>(dinv + B + 2);
+  const int tid = threadIdx.x;
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N) return;
+  constexpr size_t BB = (size_t)B * B;
+  if (tid == 0) *bad = 0;
+  for (int e = tid; e < B * B; e += kBcrElimThreads) {
+    const int rr = e / B, cc = e - rr * B;
+    G[rr * ld + cc] = Dm[(size_t)i * BB + e];
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  constexpr int NBLK = (B + 11) / 12;
+#pragma unroll 1
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const int k0 = 12 * kb;
+    const bool last = kb == NBLK - 1;
+    const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
+    const int kn = k0 + nb;
+    // ---------------- phase 1: diagonal factor (wavefront 0) | the late part of the previous step's update
+    if (wave == 0) {
+      double dcol[12], ddi = 0.0;
+      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+    } else if (kb > 0) {
+      typedef double mfma_acc __attribute__((ext_vector_type(4)));
+      const int kp = k0 - 12;
+      const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
+      for (int task = wave - 1; task < ngt; task += kBcrElimThreads / 64 - 1) {
+        const int c0 = kn + 16 * task;
+        const bool cok = c0 + lr < B, full = c0 + 15 < B;
+        const int bo = (c0 + lr) * ld + kp + lk;
+        const double nb0 = -sm[bo], nb1 = -sm[bo + 4], nb2 = -sm[bo + 8];
+        const int co = lk * ld + c0 + lr, c4 = 4 * ld;
+        const int t1 = (B - kn + 15) >> 4;
+        int ao = (kn + 16 * task + lr) * ld + kp + lk;
+        int cb = co + (kn + 16 * task) * ld;
+        int rows = B - (kn + 16 * task);
+        for (int t = task; t < t1; ++t) {                    // lower tiles of this column tile, top to bottom
+          const double a0 = sm[ao], a1 = sm[ao + 4], a2 = sm[ao + 8];
+          mfma_acc acc = {sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, nb0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, nb1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, nb2, acc, 0, 0, 0);
+          if (full && rows >= 16) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sm[cb + v * c4] = acc[v];
+          } else {
+            const int rl = cok ? rows - lk : 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              if (4 * v < rl) sm[cb + v * c4] = acc[v];
+          }
+          ao += 16 * ld; cb += 16 * ld; rows -= 16;
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- phase 2: panel, rows below the diagonal block (one row per lane, two wavefronts)
+    if ((wave == 1 || wave == 2) && kn + (wave - 1) * 64 < B) {
+      const int rraw = kn + (wave - 1) * 64 + lane;
+      const int row = rraw < B ? rraw : B - 1;               // lanes past the last row repeat it
+      if (nb == 12) bcr_block_forward<12>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
+      else bcr_block_forward<6>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
+    }
+    __syncthreads();
+    // ---------------- phase 3: the urgent part of the update: block column kb+1 only
+    if (!last && wave >= 8) {
+      typedef double mfma_acc __attribute__((ext_vector_type(4)));
+      const int i0 = kn + 16 * (wave - 8);
+      if (i0 < B) {
+        const int nbn = B - kn < 12 ? B - kn : 12;
+        const int ao = (i0 + lr) * ld + k0 + lk, bo = (kn + lr) * ld + k0 + lk, cb = (i0 + lk) * ld + kn + lr;
+        mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
+        const int rl = lr < nbn ? B - i0 - lk : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+      }
+    }
+    __syncthreads();
+  }
+  if (*bad) {
+    if (tid == 0) atomicMax(info, i * B + *bad);
+    return;
+  }
+  for (int e = tid; e < B * B; e += kBcrElimThreads) {
+    const int rr = e / B, cc = e - rr * B;
+    Lm[(size_t)i * BB + e] = cc < rr ? G[rr * ld + cc] : (cc == rr ? dinv[rr] : 0.0);
+  }
+}
+
+// ---- solve: one lane per right-hand side, forward substitution against L (entries of L are the same for
+// every lane: scalar loads); the solution column lives in LDS.  Columns: [T_il (B) | T_ir (B) | I (B) | f].
+__global__ __launch_bounds__(kBcrwSolveCols) void k_bcrw_solve(int N, int B, int s, const double* __restrict__ Lm,
+                                                               const double* __restrict__ Um, double* __restrict__ fm,
+                                                               double* __restrict__ Pm, double* __restrict__ Qm,
+                                                               double* __restrict__ Gi, const int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];     // Y[B][64]
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N || *info != 0) return;
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  const size_t BB = (size_t)B * B;
+  const int lane = threadIdx.x;
+  const int c = blockIdx.y * kBcrwSolveCols + lane;
+  const int ncol = 3 * B + 1;
+  const bool live = c < ncol;
+  const int grp = c < B ? 0 : c < 2 * B ? 1 : c < 3 * B ? 2 : 3;      // which right-hand side matrix
+  const int cc = c - grp * B;                                        // column inside it
+  const double* Li = Lm + (size_t)i * BB;
+  // identity columns are zero above their own row: start there (the wavefront starts at its first live row)
+  int kfirst = live ? (grp == 2 ? cc : 0) : B;
+  for (int m = 32; m >= 1; m >>= 1) kfirst = min(kfirst, __shfl_xor(kfirst, m, 64));
+  kfirst = __builtin_amdgcn_readfirstlane(kfirst);
+  for (int k = 0; k < kfirst && k < B; ++k) sm[k * kBcrwSolveCols + lane] = 0.0;
+  for (int k = kfirst; k < B; ++k) {
+    double acc = 0.0;
+    if (live) {
+      if (grp == 0) acc = haveL ? Um[(size_t)l * BB + (size_t)cc * B + k] : 0.0;       // T[i,l] = T[l,i]^T
+      else if (grp == 1) acc = haveR ? Um[(size_t)i * BB + (size_t)k * B + cc] : 0.0;  // T[i,r]
+      else if (grp == 2) acc = k == cc ? 1.0 : 0.0;
+      else acc = fm[(size_t)i * B + k];
+    }
+    const double* Lk = Li + (size_t)k * B;
+    double a1 = 0.0;
+    int p = kfirst;
+    for (; p + 1 < k; p += 2) {                              // two chains: the fp64 FMA latency
+      acc -= Lk[p] * sm[p * kBcrwSolveCols + lane];
+      a1 -= Lk[p + 1] * sm[(p + 1) * kBcrwSolveCols + lane];
+    }
+    if (p < k) acc -= Lk[p] * sm[p * kBcrwSolveCols + lane];
+    sm[k * kBcrwSolveCols + lane] = (acc + a1) * Lk[k];     // 1 / L_kk is stored on the diagonal
+  }
+  if (!live) return;
+  if (grp == 3) {
+    for (int k = 0; k < B; ++k) fm[(size_t)i * B + k] = sm[k * kBcrwSolveCols + lane];
+  } else {
+    double* out = (grp == 0 ? Pm : grp == 1 ? Qm : Gi) + (size_t)i * BB + cc;
+    for (int k = 0; k < B; ++k) out[(size_t)k * B] = sm[k * kBcrwSolveCols + lane];
+  }
+}
+
+// ---- products: 32 x 32 output tile per workgroup, operand panels [B][32] staged in LDS.
+// blockIdx.y: 0 .. ntile-1 tiles of P^T P (lower), then Q^T Q (lower), then P^T Q (all), last: the two vectors.
+__global__ __launch_bounds__(kBcrwTile * kBcrwTile) void k_bcrw_products(int N, int B, int s, double* __restrict__ Dm,
+                                                                        double* __restrict__ Um, double* __restrict__ fm,
+                                                                        const double* __restrict__ Pm,
+                                                                        const double* __restrict__ Qm,
+                                                                        const int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];     // A[B][32] | Bp[B][32]
+  constexpr int T = kBcrwTile;
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N || *info != 0) return;
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  const size_t BB = (size_t)B * B;
+  const int nt = (B + T - 1) / T, nsym = nt * (nt + 1) / 2;
+  const int tid = threadIdx.x;
+  int task = blockIdx.y;
+  if (task == 2 * nsym + nt * nt) {                          // f_l -= P^T g, f_r -= Q^T g
+    for (int c = tid; c < 2 * B; c += T * T) {
+      const bool left = c < B;
+      if ((left && !haveL) || (!left && !haveR)) continue;
+      const double* A = (left ? Pm : Qm) + (size_t)i * BB + (left ? c : c - B);
+      double acc = 0.0;
+      for (int k = 0; k < B; ++k) acc += A[(size_t)k * B] * fm[(size_t)i * B + k];
+      atomic_add_f64(fm + (size_t)(left ? l : r) * B + (left ? c : c - B), -acc);
+    }
+    return;
+  }
+  int which, ti, tj;
+  if (task < 2 * nsym) {
+    which = task < nsym ? 0 : 1;
+    tri_decode(task - which * nsym, nt, tj, ti);             // tj <= ti
+  } else {
+    which = 2;
+    ti = (task - 2 * nsym) / nt; tj = (task - 2 * nsym) % nt;
+  }
+  if ((which == 0 && !haveL) || (which == 1 && !haveR) || (which == 2 && !(haveL && haveR))) return;
+  const double* Asrc = (which == 1 ? Qm : Pm) + (size_t)i * BB;
+  const double* Bsrc = (which == 0 ? Pm : Qm) + (size_t)i * BB;
+  double* A = sm;
+  double* Bp = sm + (size_t)B * T;
+  for (int e = tid; e < B * T; e += T * T) {
+    const int k = e / T, c = e - k * T;
+    A[e] = T * ti + c < B ? Asrc[(size_t)k * B + T * ti + c] : 0.0;
+    Bp[e] = T * tj + c < B ? Bsrc[(size_t)k * B + T * tj + c] : 0.0;
+  }
+  __syncthreads();
+  const int ty = tid / T, tx = tid - ty * T;
+  double a0 = 0.0, a1 = 0.0;
+  int k = 0;
+  for (; k + 1 < B; k += 2) {
+    a0 += A[k * T + ty] * Bp[k * T + tx];
+    a1 += A[(k + 1) * T + ty] * Bp[(k + 1) * T + tx];
+  }
+  if (k < B) a0 += A[k * T + ty] * Bp[k * T + tx];
+  const double acc = a0 + a1;
+  const int row = T * ti + ty, col = T * tj + tx;
+  if (row >= B || col >= B) return;
+  if (which == 2) Um[(size_t)l * BB + (size_t)row * B + col] = -acc;                    // new T[l,r]
+  else if (col <= row) atomic_add_f64(Dm + (size_t)(which == 0 ? l : r) * BB + (size_t)row * B + col, -acc);
+}
+
+// ---- back-substitution level: x_i = G^-T (g - P x_l - Q x_r), matrices read straight from global memory
+__global__ __launch_bounds__(512) void k_bcrw_backsolve(int N, int B, int s, const double* __restrict__ fm,
+                                                        const double* __restrict__ Pm, const double* __restrict__ Qm,
+                                                        const double* __restrict__ Gi, double* __restrict__ x) {
+  __shared__ double w[128], xl[128], xr[128];
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N) return;
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  const size_t BB = (size_t)B * B;
+  const int tid = threadIdx.x;
+  if (tid < B) {
+    w[tid] = fm[(size_t)i * B + tid];
+    xl[tid] = haveL ? x[(size_t)l * B + tid] : 0.0;
+    xr[tid] = haveR ? x[(size_t)r * B + tid] : 0.0;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  const int k = tid >> 2, q4 = tid & 3;
+  if (k < B) {
+    const double* Pk = Pm + (size_t)i * BB + (size_t)k * B;
+    const double* Qk = Qm + (size_t)i * BB + (size_t)k * B;
+    for (int c = q4; c < B; c += 4) acc += (haveL ? Pk[c] * xl[c] : 0.0) + (haveR ? Qk[c] * xr[c] : 0.0);
+  }
+  acc += dpp_pair<0xB1>(acc);
+  acc += dpp_pair<0x4E>(acc);
+  __syncthreads();
+  if (k < B && q4 == 0) w[k] -= acc;
+  __syncthreads();
+  acc = 0.0;
+  if (k < B) {                                               // x[m] = sum_{kk >= m} Ginv[kk][m] w[kk], m = k
+    const double* Gc = Gi + (size_t)i * BB + k;
+    for (int kk = k + q4; kk < B; kk += 4) acc += Gc[(size_t)kk * B] * w[kk];
+  }
+  acc += dpp_pair<0xB1>(acc);
+  acc += dpp_pair<0x4E>(acc);
+  if (k < B && q4 == 0) x[(size_t)i * B + k] = acc;
+}
+
+}  // namespace ba

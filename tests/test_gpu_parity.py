@@ -478,7 +478,7 @@ def test_band_solver_vs_dense_lu(be):
         close(-be.backsubstitute(0), su, SOLVE)
 
 
-@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11), (400, 12)])
+@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11), (400, 12), (300, 13), (500, 16), (400, 22), (97, 19)])
 def test_cyclic_reduction_vs_sequential_band_solver(be, monkeypatch, nc, L):
     """The multi-CU block-cyclic-reduction solve against the single-workgroup band Cholesky and
     the dense LU on the same device-resident system (odd sizes: padded last super-block,
@@ -493,7 +493,7 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, monkeypatch, nc, L):
     n = (nc - 1) * 6
     for mask in (None, (np.arange(n) % 7 != 3).astype(np.uint8)):
         sol = {}
-        for solver in ('bcr', 'seq'):                     # hb = 11 (L = 12) is the widest band BCR takes
+        for solver in ('bcr', 'seq'):                     # hb <= 11: one kernel per level; 12..21: ba_bcr_wide.h
             monkeypatch.setenv('BA_SOLVER', solver)
             be.solve_reduced(mask)
             assert be.last_solve_path == 'band'
