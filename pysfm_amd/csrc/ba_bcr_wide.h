@@ -10,8 +10,8 @@
 //   k_bcrw_backsolve x_i = G^-T (g - P x_l - Q x_r)
 //
 // The single-workgroup band Cholesky (k_band_solve) these replace walks 1000 cameras in 7..20 ms at
-// these widths; the levels here are ~60 us each.  The solve and product kernels are plain vector code
-// (first version: correct and parallel; MFMA forms as in ba_bcr.h are the obvious next step).
+// these widths; the levels here are ~90 us each at hb = 21 (factor 36, solve 21, products 22, backsolve 11).
+// k_bcrw_solve (one lane per right-hand side, 442 us per level) is kept as the plain reference form.
 #pragma once
 
 #include "ba_bcr.h"
@@ -24,11 +24,34 @@ constexpr int kBcrwSolveCols = 64;            // right-hand sides per wavefront 
 constexpr int kBcrwTile = 32;                 // output tile edge of k_bcrw_products
 
 __host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16) * sizeof(double); }
+__host__ __device__ inline size_t bcrw_solve_lds_bytes(int B) { return ((size_t)B * (B + 1) + (size_t)((B + 11) / 12) * 144 + 64) * sizeof(double); }
+
+// B x B row-major global matrix -> LDS with row stride B + 1; loads issued U at a time so that their
+// latencies overlap (one load - store pair per iteration costs a full memory round trip each)
+template <int B, int THREADS, int U>
+__device__ __forceinline__ void bcrw_fill(double* __restrict__ dst, const double* __restrict__ src, int tid) {
+  constexpr int NE = B * B;
+#pragma unroll 1
+  for (int e0 = tid; e0 < NE; e0 += THREADS * U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + THREADS * u;
+      v[u] = e < NE ? src[e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + THREADS * u;
+      if (e < NE) dst[e + e / B] = v[u];
+    }
+  }
+}
 
 // ---- factor: Lm[i] = Cholesky factor of Dm[i] (lower, row-major B x B, 1 / L_kk on the diagonal)
 template <int HB>
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, const double* __restrict__ Dm,
-                                                                double* __restrict__ Lm, int* __restrict__ info) {
+                                                                double* __restrict__ Lm, double* __restrict__ Lvm,
+                                                                int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int B = 6 * HB, ld = B + 1;
   double* G = sm;                       // [B][ld]
@@ -39,10 +62,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
   if (i >= N) return;
   constexpr size_t BB = (size_t)B * B;
   if (tid == 0) *bad = 0;
-  for (int e = tid; e < B * B; e += kBcrElimThreads) {
-    const int rr = e / B, cc = e - rr * B;
-    G[rr * ld + cc] = Dm[(size_t)i * BB + e];
-  }
+  bcrw_fill<B, kBcrElimThreads, 16>(G, Dm + (size_t)i * BB, tid);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   constexpr int NBLK = (B + 11) / 12;
@@ -55,8 +75,15 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
     // ---------------- phase 1: diagonal factor (wavefront 0) | the late part of the previous step's update
     if (wave == 0) {
       double dcol[12], ddi = 0.0;
-      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
-      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      double* Lv = Lvm + ((size_t)i * NBLK + kb) * 144;      // inverse of this diagonal block, [12][12], zero padded
+      if (nb == 12) {
+        bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+        bcr_diag_inverse<12>(dcol, ddi, lane, Lv);
+      } else {
+        for (int e = lane; e < 144; e += 64) Lv[e] = 0.0;
+        bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+        bcr_diag_inverse<6>(dcol, ddi, lane, Lv);
+      }
     } else if (kb > 0) {
       typedef double mfma_acc __attribute__((ext_vector_type(4)));
       const int kp = k0 - 12;
@@ -179,6 +206,103 @@ __global__ __launch_bounds__(kBcrwSolveCols) void k_bcrw_solve(int N, int B, int
   }
 }
 
+// ---- solve on the matrix cores: one workgroup (4 wavefronts) per (node, 4 column tiles of 16 right-hand
+// sides); L and the inverses of its 12 x 12 diagonal blocks sit in LDS, a wavefront walks its tile block
+// row by block row:  acc = R_kb - sum_{j<kb} L[kb,j] Y_j  (3 MFMAs per block, Y_j in registers in exactly
+// the B-operand layout it came out of the MFMA in), then  Y_kb = L_kk^-1 acc  (3 more).
+template <int HB>
+__global__ __launch_bounds__(1024) void k_bcrw_solve_mfma(int N, int s, const double* __restrict__ Lm,
+                                                         const double* __restrict__ Lvm, const double* __restrict__ Um,
+                                                         double* __restrict__ fm, double* __restrict__ Pm,
+                                                         double* __restrict__ Qm, double* __restrict__ Gi,
+                                                         const int* __restrict__ info) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int B = 6 * HB, ld = B + 1, NBLK = (B + 11) / 12;
+  double* Ls = sm;                       // [B][ld]
+  double* Lv = Ls + (size_t)B * ld;      // [NBLK][144]
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N || *info != 0) return;
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  constexpr size_t BB = (size_t)B * B;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  constexpr int ncol = 3 * B + 1;
+  const int ct = blockIdx.y * 4 + wave;
+  const int c = 16 * ct + lr;
+  const bool live = c < ncol && wave < 4;
+  const int grp = c < B ? 0 : c < 2 * B ? 1 : c < 3 * B ? 2 : 3;
+  const int cc = c - grp * B;
+  // right-hand side entry (row, my column): one unconditional load per entry (address clamped, value
+  // selected afterwards) - branches around the loads serialise their latencies
+  const bool loads = live && ((grp == 0 && haveL) || (grp == 1 && haveR) || grp == 3);
+  const double* rbase = !loads ? fm + (size_t)i * B
+                        : grp == 0 ? Um + (size_t)l * BB + (size_t)cc * B      // T[i,l] = T[l,i]^T
+                        : grp == 1 ? Um + (size_t)i * BB + cc                  // T[i,r]
+                                   : fm + (size_t)i * B;
+  const int rstride = (loads && grp == 1) ? B : 1;
+  const bool ident = live && grp == 2;
+  auto rhs = [&](int row) -> double {
+    const int rc = row < B ? row : B - 1;
+    const double v = rbase[rc * rstride];                    // always finite: a valid entry of U or f
+    // arithmetic instead of a select: the compiler turns selects back into branches around the load
+    return v * ((loads && row < B) ? 1.0 : 0.0) + ((ident && row == cc) ? 1.0 : 0.0);
+  };
+  double* out = grp == 0 ? Pm + (size_t)i * BB + cc : grp == 1 ? Qm + (size_t)i * BB + cc : grp == 2 ? Gi + (size_t)i * BB + cc
+                                                                                              : fm + (size_t)i * B;
+  const int ost = grp == 3 ? 1 : B;
+  // identity columns are zero above their own row: the whole tile is zero in block rows above its first column
+  const int c_lo = 16 * ct, zero_rows = (c_lo >= 2 * B && c_lo + 15 < 3 * B) ? c_lo - 2 * B : 0;
+  double ny[NBLK][3];
+  // the whole right-hand side tile goes to registers first (3 NBLK values per lane), its latency hides
+  // under the fill of L below
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) ny[kb][v] = rhs(12 * kb + lk + 4 * v);
+  {
+    const double* Lg = Lm + (size_t)i * BB;
+    bcrw_fill<B, 1024, 16>(Ls, Lg, tid);                      // all 16 wavefronts fetch, 4 of them compute
+    for (int e = tid; e < NBLK * 144; e += 1024) Lv[e] = Lvm[(size_t)i * NBLK * 144 + e];
+  }
+  __syncthreads();
+  if (wave >= 4 || 16 * ct >= ncol) return;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const int r0 = 12 * kb;
+    if (r0 + 12 <= zero_rows) {                              // wave-uniform
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        ny[kb][v] = 0.0;
+        const int row = r0 + lk + 4 * v;
+        if (live && row < B) out[(size_t)row * ost] = 0.0;
+      }
+      continue;
+    }
+    mfma_acc acc = {ny[kb][0], ny[kb][1], ny[kb][2], 0.0};
+#pragma unroll
+    for (int j = 0; j < kb; ++j) {
+      if (12 * j + 12 <= zero_rows) continue;                // Y_j is zero
+      const double* ap = Ls + (r0 + lr) * ld + 12 * j + lk;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], ny[j][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4], ny[j][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[8], ny[j][2], acc, 0, 0, 0);
+    }
+    const double* lp = Lv + kb * 144 + lr * 12 + lk;          // rows lr >= 12 run into the next block: unused rows of y
+    mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+    y = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[0], acc[0], y, 0, 0, 0);
+    y = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[4], acc[1], y, 0, 0, 0);
+    y = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[8], acc[2], y, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      ny[kb][v] = -y[v];
+      const int row = r0 + lk + 4 * v;
+      if (live && row < B) out[(size_t)row * ost] = y[v];
+    }
+  }
+}
+
 // ---- products: 32 x 32 output tile per workgroup, operand panels [B][32] staged in LDS.
 // blockIdx.y: 0 .. ntile-1 tiles of P^T P (lower), then Q^T Q (lower), then P^T Q (all), last: the two vectors.
 __global__ __launch_bounds__(kBcrwTile * kBcrwTile) void k_bcrw_products(int N, int B, int s, double* __restrict__ Dm,
@@ -242,10 +366,12 @@ __global__ __launch_bounds__(kBcrwTile * kBcrwTile) void k_bcrw_products(int N, 
 }
 
 // ---- back-substitution level: x_i = G^-T (g - P x_l - Q x_r), matrices read straight from global memory
-__global__ __launch_bounds__(512) void k_bcrw_backsolve(int N, int B, int s, const double* __restrict__ fm,
-                                                        const double* __restrict__ Pm, const double* __restrict__ Qm,
-                                                        const double* __restrict__ Gi, double* __restrict__ x) {
-  __shared__ double w[128], xl[128], xr[128];
+// (8 lanes per row for the two products, then lanes along the columns of G^-1 so that both passes read
+// whole cache lines)
+__global__ __launch_bounds__(1024) void k_bcrw_backsolve(int N, int B, int s, const double* __restrict__ fm,
+                                                         const double* __restrict__ Pm, const double* __restrict__ Qm,
+                                                         const double* __restrict__ Gi, double* __restrict__ x) {
+  __shared__ double w[128], xl[128], xr[128], red[8][128];
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N) return;
   const int l = i - s, r = i + s;
@@ -258,26 +384,40 @@ __global__ __launch_bounds__(512) void k_bcrw_backsolve(int N, int B, int s, con
     xr[tid] = haveR ? x[(size_t)r * B + tid] : 0.0;
   }
   __syncthreads();
-  double acc = 0.0;
-  const int k = tid >> 2, q4 = tid & 3;
+  const int k = tid >> 3, q8 = tid & 7;
+  double a0 = 0.0, a1 = 0.0;
   if (k < B) {
     const double* Pk = Pm + (size_t)i * BB + (size_t)k * B;
     const double* Qk = Qm + (size_t)i * BB + (size_t)k * B;
-    for (int c = q4; c < B; c += 4) acc += (haveL ? Pk[c] * xl[c] : 0.0) + (haveR ? Qk[c] * xr[c] : 0.0);
+    if (haveL)
+#pragma unroll 4
+      for (int c = q8; c < B; c += 8) a0 += Pk[c] * xl[c];
+    if (haveR)
+#pragma unroll 4
+      for (int c = q8; c < B; c += 8) a1 += Qk[c] * xr[c];
   }
+  double acc = a0 + a1;
   acc += dpp_pair<0xB1>(acc);
   acc += dpp_pair<0x4E>(acc);
+  acc += __shfl_xor(acc, 4);
+  if (k < B && q8 == 0) w[k] -= acc;
   __syncthreads();
-  if (k < B && q4 == 0) w[k] -= acc;
-  __syncthreads();
+  const int m = tid & 127, g = tid >> 7;                     // x[m] = sum_{kk >= m} Ginv[kk][m] w[kk]
   acc = 0.0;
-  if (k < B) {                                               // x[m] = sum_{kk >= m} Ginv[kk][m] w[kk], m = k
-    const double* Gc = Gi + (size_t)i * BB + k;
-    for (int kk = k + q4; kk < B; kk += 4) acc += Gc[(size_t)kk * B] * w[kk];
+  if (m < B) {
+    const double* Gc = Gi + (size_t)i * BB + m;
+    int kk = m + g;
+#pragma unroll 4
+    for (; kk < B; kk += 8) acc += Gc[kk * B] * w[kk];
   }
-  acc += dpp_pair<0xB1>(acc);
-  acc += dpp_pair<0x4E>(acc);
-  if (k < B && q4 == 0) x[(size_t)i * B + k] = acc;
+  red[g][m] = acc;
+  __syncthreads();
+  if (tid < B) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][tid];
+    x[(size_t)i * B + tid] = t;
+  }
 }
 
 }  // namespace ba

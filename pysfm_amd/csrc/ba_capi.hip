@@ -91,7 +91,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
@@ -308,20 +308,29 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   return BA_OK;
 }
 
+// factor + solve of one level (both are templates on the half-bandwidth)
 template <int HB>
-hipError_t launch_bcrw_factor_hb(int cnt, hipStream_t st, int N, int s, const double* D, double* L, int* info) {
+hipError_t launch_bcrw_factor_hb(int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
+                                 double* f, double* P, double* Q, double* G, int* info) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_bcrw_factor<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)k_bcrw_solve_mfma<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_bcrw_factor<HB>, dim3(cnt), dim3(kBcrElimThreads), bcrw_factor_lds_bytes(6 * HB), st, N, s, D, L, info);
+  constexpr int B = 6 * HB;
+  hipLaunchKernelGGL(k_bcrw_factor<HB>, dim3(cnt), dim3(kBcrElimThreads), bcrw_factor_lds_bytes(B), st, N, s, D, L, Lv, info);
+  const int ntile = (3 * B + 1 + 15) / 16;
+  hipLaunchKernelGGL(k_bcrw_solve_mfma<HB>, dim3(cnt, (ntile + 3) / 4), dim3(1024), bcrw_solve_lds_bytes(B), st, N, s, L, Lv, U, f,
+                     P, Q, G, info);
   return hipSuccess;
 }
 
-hipError_t launch_bcrw_factor(int hb, int cnt, hipStream_t st, int N, int s, const double* D, double* L, int* info) {
-#define BA_HB_CASE(K) case K: return launch_bcrw_factor_hb<K>(cnt, st, N, s, D, L, info);
+hipError_t launch_bcrw_factor(int hb, int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
+                              double* f, double* P, double* Q, double* G, int* info) {
+#define BA_HB_CASE(K) case K: return launch_bcrw_factor_hb<K>(cnt, st, N, s, D, L, Lv, U, f, P, Q, G, info);
   switch (hb) {
     BA_HB_CASE(12) BA_HB_CASE(13) BA_HB_CASE(14) BA_HB_CASE(15) BA_HB_CASE(16) BA_HB_CASE(17) BA_HB_CASE(18) BA_HB_CASE(19)
     BA_HB_CASE(20) BA_HB_CASE(21)
@@ -337,10 +346,10 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB)); HIPCHECK(h, h->bcrL.resize(N * BB));
   HIPCHECK(h, h->bcrF.resize((size_t)N * B));
+  HIPCHECK(h, h->bcrLv.resize((size_t)N * ((B + 11) / 12) * 144));
   HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcrw_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcrw_products, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -352,14 +361,12 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
   const int nt = (B + kBcrwTile - 1) / kBcrwTile, ntask = nt * (nt + 1) + nt * nt + 1;
-  const int nchunk = (3 * B + 1 + kBcrwSolveCols - 1) / kBcrwSolveCols;
   {
     ScopedTimer tm(h, BA_K_BCR_ELIMINATE, 3 * (int)strides.size());
     for (int s : strides) {
       const int cnt = (N / s + 1) / 2;
-      HIPCHECK(h, launch_bcrw_factor(hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrL.p, h->flags.p + 1));
-      hipLaunchKernelGGL(k_bcrw_solve, dim3(cnt, nchunk), dim3(kBcrwSolveCols), (size_t)B * kBcrwSolveCols * sizeof(double), h->stream,
-                         N, B, s, h->bcrL.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->flags.p + 1);
+      HIPCHECK(h, launch_bcrw_factor(hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrL.p, h->bcrLv.p, h->bcrU.p, h->bcrF.p, h->bcrP.p,
+                                     h->bcrQ.p, h->bcrG.p, h->flags.p + 1));
       hipLaunchKernelGGL(k_bcrw_products, dim3(cnt, ntask), dim3(kBcrwTile * kBcrwTile), (size_t)2 * B * kBcrwTile * sizeof(double),
                          h->stream, N, B, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->flags.p + 1);
     }
@@ -367,7 +374,7 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)strides.size());
   for (int q = (int)strides.size() - 1; q >= 0; --q) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
-    hipLaunchKernelGGL(k_bcrw_backsolve, dim3(cnt), dim3(512), 0, h->stream, N, B, s, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
+    hipLaunchKernelGGL(k_bcrw_backsolve, dim3(cnt), dim3(1024), 0, h->stream, N, B, s, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
                        h->dC.p);
   }
   HIPCHECK(h, hipGetLastError());
@@ -437,7 +444,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);

@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pysfm_amd import Bundle, BundleAdjuster, sensor_model
 from pysfm_amd import synthetic_data as sd
-for L in (6, 10, 12, 13, 16, 22, 23):
+import os as _os
+LS = tuple(int(v) for v in _os.environ['BAND_L'].split(',')) if 'BAND_L' in _os.environ else (6, 10, 12, 13, 16, 22, 23)
+for L in LS:
     s = sd.generate_banded_scene(1000, 20000, track_len=L)
     b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=sensor_model.GaussianModel(1.))
     ba = BundleAdjuster(verbose=False); ba.set_bundle(b); be = ba.backend
