@@ -57,7 +57,7 @@ typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_se
 enum {
   BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
   BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_TRIANGULATE,
-  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_COUNT
+  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_DENSE_SOLVE, BA_K_COUNT
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -143,18 +143,24 @@ int ba_bind_reduced_buffers(ba_handle* h, void* S_band_dev, void* b_dev);
  * Td, Wd [3 nt][6 nco] (row 3 k + d, column 6 pos + a, row-major, zero where a camera does not see a
  * point) and g [3 nt] = bP instead of running a reduction kernel; the caller computes
  * Sd = Td^T Wd [6 nco][6 nco] and bc = Td^T g [6 nco] with a library DGEMM on the handle's stream and
- * calls ba_dense_apply, which subtracts them from the band-stored [S | b].  NULL unbinds. */
+ * calls ba_dense_apply, which subtracts them from the band-stored [S | b] (bc_dev NULL: the library forms
+ * Td^T g itself - cheaper than a BLAS GEMV at these sizes).  ba_bind_dense_stage(NULL...) unbinds. */
 int ba_bind_dense_stage(ba_handle* h, void* Td_dev, void* Wd_dev, void* g_dev);
 int ba_dense_apply(ba_handle* h, const void* Sd_dev, const void* bc_dev);
 
 /* ---- BundleAdjuster.solve_motion_normal_eqns (bundle_adjuster.py:281-312)
- * Device-resident solve of the block-banded system by block Cholesky (k_band_solve).
+ * Device-resident Cholesky solve of the reduced camera system, by block half-bandwidth hb:
+ * block cyclic reduction (hb <= 21), a single-workgroup band Cholesky (fewer than 4 super-blocks), or a
+ * dense blocked Cholesky of the whole matrix (hb > 21, up to 16000 unknowns).
  * cam_param_mask[nco*6] (host, may be NULL = all kept): 0 deletes that camera parameter
  * from the system (its solution entry is 0).  *info: 0 = solved, solution stays on the
  * device for ba_backsubstitute / ba_get_solution; > 0 = pivot `info` was not positive
- * (system not SPD: use the dense path, which has the reference's LU / LinAlgError
- * semantics); -1 = band too wide for the on-chip window (use the dense path). */
+ * (system not SPD: use ba_flatten_reduced + LU, which has the reference's LinAlgError
+ * semantics); -1 = too large for the device solvers (same fallback).
+ * ba_last_solve_kind: which solver the last ba_solve_reduced launched. */
+enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY };
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
+int ba_last_solve_kind(const ba_handle* h);
 int ba_get_solution(ba_handle* h, double* dC /*[nco*6] host*/);
 /* Dense path: flat (6nco x 6nco) system with rows/cols of masked camera parameters
  * deleted (bundle_adjuster.py:290-299).  keep[nkeep] lists the kept flat parameter

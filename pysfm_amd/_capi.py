@@ -20,8 +20,9 @@ SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER = 0, 1, 2
 PARAMS_CUR, PARAMS_TRIAL = 0, 1
 KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 'backsub',
               'update', 'flatten', 'band_solve', 'eval', 'camera_blocks', 'triangulate',
-              'bcr_assemble', 'bcr_eliminate', 'bcr_backsolve')
+              'bcr_assemble', 'bcr_eliminate', 'bcr_backsolve', 'dense_solve')
 K_COUNT = len(KERNEL_IDS)
+SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky')
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -52,6 +53,7 @@ PROTOTYPES = {
     'ba_bind_reduced_buffers': (C.c_int, [_h, C.c_void_p, C.c_void_p]),
     'ba_reduced_layout': (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'ba_solve_reduced': (C.c_int, [_h, _bp, C.POINTER(C.c_int32)]),
+    'ba_last_solve_kind': (C.c_int, [_h]),
     'ba_get_solution': (C.c_int, [_h, _dp]),
     'ba_flatten_reduced': (C.c_int, [_h, _ip, C.c_int32, C.c_void_p, C.c_void_p]),
     'ba_backsubstitute': (C.c_int, [_h, C.c_int, _dp, _dp]),

@@ -13,10 +13,7 @@ import numpy as np
 from . import _capi as capi
 from ._capi import PARAMS_CUR, PARAMS_TRIAL  # noqa: F401  (re-exported)
 
-# reduced systems up to this many unknowns are solved with numpy.linalg.solve on the
-# host (LAPACK gesv - the reference's own call, bundle_adjuster.py:303); larger
-# ones stay on the GPU (torch.linalg.solve_ex -> rocSOLVER getrf/getrs).
-HOST_SOLVE_MAX_UNKNOWNS = 768
+DEVICE_CHOLESKY_MAX_UNKNOWNS = 16000   # (= kDcMaxN of ba_dense.h)
 DENSE_MIN_HALF_BANDWIDTH = 21     # (= kMaxBandSolve: beyond it the solve is dense anyway)
 DENSE_MIN_FILL = 0.25             # observed fraction of the (camera, track) pairs
 DENSE_MAX_BYTES = 2 << 30         # of the two staged operands
@@ -197,9 +194,8 @@ class HipBackend(object):
             Td, Wd, g = self._dense
             with self.stream_ctx():
                 Sd = self._torch.mm(Td.t(), Wd)
-                bc = self._torch.mv(Td.t(), g)
-                self._check(self._lib.ba_dense_apply(self._h, C.c_void_p(Sd.data_ptr()), C.c_void_p(bc.data_ptr())))
-                self._dense_keep = (Sd, bc)               # alive until the kernel has run
+                self._check(self._lib.ba_dense_apply(self._h, C.c_void_p(Sd.data_ptr()), None))    # Td^T g: library kernel
+                self._dense_keep = Sd                     # alive until the kernel has run
 
     def _bind_dense(self):
         """Dense-visibility reduction (include/pysfm_ba.h ba_bind_dense_stage): when the band is too wide
@@ -246,18 +242,20 @@ class HipBackend(object):
         """Solve the reduced camera system with the masked camera parameters deleted
         (solve_motion_normal_eqns, bundle_adjuster.py:281-312).  The solution stays on
         the device for backsubstitute(); get_solution() fetches it.
-        Path 1: block-band Cholesky in one HIP kernel (k_band_solve).  Path 2, when the
-        band is too wide for its on-chip window or the system is not positive definite:
-        dense LU (numpy.linalg.solve = LAPACK gesv on the host for small systems, the
-        reference's own call; torch.linalg.solve_ex = rocSOLVER on the GPU for large
-        ones).  Raises ReducedSystemSingular where the reference's solve would raise."""
+        Path 1 (last_solve_path 'band' / 'dense_cholesky', last_solve_kind says which kernel
+        family): Cholesky on the device inside ba_solve_reduced - block cyclic reduction for
+        block half-bandwidths up to 21, a dense blocked Cholesky beyond.  Path 2 ('dense'),
+        when the system is not positive definite or has more than 16000 unknowns: LU of the
+        flattened system, the reference's own factorisation (numpy.linalg.solve = gesv,
+        bundle_adjuster.py:303), here rocSOLVER through torch.linalg.solve_ex - on the GPU as
+        well.  Raises ReducedSystemSingular where the reference's solve would raise."""
         self._host_dC = None
         n = self.nco * 6
         mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
         assert mask is None or mask.shape == (n,)
         info = C.c_int32(0)
         self._check(self._lib.ba_solve_reduced(self._h, capi.bptr(mask), C.byref(info)))
-        self.last_solve_path = 'band' if info.value == 0 else 'dense'
+        self._note_solve(info.value)
         if info.value == 0:
             return
         keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
@@ -280,18 +278,14 @@ class HipBackend(object):
         rhs = self._rhs_t[:n]
         self._check(self._lib.ba_flatten_reduced(self._h, capi.iptr(keep), n, C.c_void_p(A.data_ptr()),
                                                  C.c_void_p(rhs.data_ptr())))
-        if n <= HOST_SOLVE_MAX_UNKNOWNS:
-            try:
-                return np.linalg.solve(A.cpu().numpy(), rhs.cpu().numpy())
-            except np.linalg.LinAlgError:
-                raise ReducedSystemSingular
-        # symmetric positive definite in every regular LM step: rocSOLVER's Cholesky is 2-3x faster than its
-        # LU at these sizes (measured: n = 3000: 10.5 ms against 28 ms); anything else goes through LU, the
-        # reference's own factorisation (numpy.linalg.solve = gesv), with its singular-matrix semantics
+        # only systems the device Cholesky solvers refused get here (not positive definite, or too large for
+        # them): rocSOLVER's Cholesky first when the size was the reason (2-3x faster than its LU: n = 3000:
+        # 10.5 ms against 28 ms), then LU, the reference's own factorisation, with its singular-matrix semantics
         with self.stream_ctx():
-            L, info = torch.linalg.cholesky_ex(A, check_errors=False)
-            if int(info.item()) == 0:
-                return torch.cholesky_solve(rhs.unsqueeze(1), L).squeeze(1).cpu().numpy()
+            if n > DEVICE_CHOLESKY_MAX_UNKNOWNS:
+                L, info = torch.linalg.cholesky_ex(A, check_errors=False)
+                if int(info.item()) == 0:
+                    return torch.cholesky_solve(rhs.unsqueeze(1), L).squeeze(1).cpu().numpy()
             x, info = torch.linalg.solve_ex(A, rhs.unsqueeze(1), check_errors=False)
             if int(info.item()) != 0:
                 raise ReducedSystemSingular
@@ -332,7 +326,7 @@ class HipBackend(object):
         self._host_dC = None
         self._check(self._lib.ba_lm_trial(self._h, float(damping), -1.0 if rcond is None else float(rcond),
                                           capi.bptr(mask), C.byref(cost), C.byref(info)))
-        self.last_solve_path = 'band' if info.value == 0 else 'dense'
+        self._note_solve(info.value)
         return info.value, cost.value
 
     # the same trial in two halves around the all-reduce of the sharded adjuster
@@ -352,8 +346,18 @@ class HipBackend(object):
         mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
         pre = C.c_int32()
         self._check(self._lib.ba_lm_trial_end(self._h, capi.bptr(mask), C.byref(pre)))
-        self.last_solve_path = 'band' if pre.value == 0 else 'dense'
+        self._note_solve(pre.value)
         return pre.value
+
+    def _note_solve(self, info):
+        """last_solve_kind: the device solver ba_solve_reduced launched ('bcr', 'bcr_wide', 'band',
+        'dense_cholesky'); last_solve_path: 'band' / 'dense_cholesky' when it succeeded, 'dense' when
+        the flattened system went (or has to go) through LU instead."""
+        self.last_solve_kind = capi.SOLVE_KINDS[self._lib.ba_last_solve_kind(self._h)]
+        if info != 0:
+            self.last_solve_path = 'dense'
+        else:
+            self.last_solve_path = 'dense_cholesky' if self.last_solve_kind == 'dense_cholesky' else 'band'
 
     def trial_result(self):
         """Device tensor [TRIAL_PARTIALS cost partials | singular point blocks | solver status]."""

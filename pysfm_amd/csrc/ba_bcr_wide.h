@@ -4,14 +4,14 @@
 //
 //   k_bcrw_factor    one workgroup per node:  D_i = L L^T in LDS (the blocked, look-ahead Cholesky of
 //                    ba_bcr.h without right-hand sides), L -> global (1 / L_kk on its diagonal)
-//   k_bcrw_solve     one wavefront per (node, 64 right-hand sides):  [P | Q | G^-1 | g] = L^-1 [T_il | T_ir | I | f]
+//   k_bcrw_solve_mfma  one wavefront per (node, 16 right-hand sides):  [P | Q | G^-1 | g] = L^-1 [T_il | T_ir | I | f]
 //   k_bcrw_products  one workgroup per (node, 32 x 32 outputs):  D_l -= P^T P,  D_r -= Q^T Q,
 //                    T[l,r] = -P^T Q,  f_l -= P^T g,  f_r -= Q^T g
 //   k_bcrw_backsolve x_i = G^-T (g - P x_l - Q x_r)
 //
 // The single-workgroup band Cholesky (k_band_solve) these replace walks 1000 cameras in 7..20 ms at
 // these widths; the levels here are ~90 us each at hb = 21 (factor 36, solve 21, products 22, backsolve 11).
-// k_bcrw_solve (one lane per right-hand side, 442 us per level) is kept as the plain reference form.
+// (The first form of the solve, one lane per right-hand side with L through scalar loads, took 442 us per level.)
 #pragma once
 
 #include "ba_bcr.h"
@@ -20,7 +20,6 @@ namespace ba {
 
 constexpr int kBcrwMinHB = kBcrMaxHB + 1;
 constexpr int kBcrwMaxHB = 21;                 // B = 126: one B x (B+1) fp64 matrix = 128 KB of the 160 KB LDS
-constexpr int kBcrwSolveCols = 64;            // right-hand sides per wavefront in k_bcrw_solve
 constexpr int kBcrwTile = 32;                 // output tile edge of k_bcrw_products
 
 __host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16) * sizeof(double); }
@@ -152,57 +151,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
   for (int e = tid; e < B * B; e += kBcrElimThreads) {
     const int rr = e / B, cc = e - rr * B;
     Lm[(size_t)i * BB + e] = cc < rr ? G[rr * ld + cc] : (cc == rr ? dinv[rr] : 0.0);
-  }
-}
-
-// ---- solve: one lane per right-hand side, forward substitution against L (entries of L are the same for
-// every lane: scalar loads); the solution column lives in LDS.  Columns: [T_il (B) | T_ir (B) | I (B) | f].
-__global__ __launch_bounds__(kBcrwSolveCols) void k_bcrw_solve(int N, int B, int s, const double* __restrict__ Lm,
-                                                               const double* __restrict__ Um, double* __restrict__ fm,
-                                                               double* __restrict__ Pm, double* __restrict__ Qm,
-                                                               double* __restrict__ Gi, const int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];     // Y[B][64]
-  const int i = s * (2 * blockIdx.x + 1) - 1;
-  if (i >= N || *info != 0) return;
-  const int l = i - s, r = i + s;
-  const bool haveL = l >= 0, haveR = r < N;
-  const size_t BB = (size_t)B * B;
-  const int lane = threadIdx.x;
-  const int c = blockIdx.y * kBcrwSolveCols + lane;
-  const int ncol = 3 * B + 1;
-  const bool live = c < ncol;
-  const int grp = c < B ? 0 : c < 2 * B ? 1 : c < 3 * B ? 2 : 3;      // which right-hand side matrix
-  const int cc = c - grp * B;                                        // column inside it
-  const double* Li = Lm + (size_t)i * BB;
-  // identity columns are zero above their own row: start there (the wavefront starts at its first live row)
-  int kfirst = live ? (grp == 2 ? cc : 0) : B;
-  for (int m = 32; m >= 1; m >>= 1) kfirst = min(kfirst, __shfl_xor(kfirst, m, 64));
-  kfirst = __builtin_amdgcn_readfirstlane(kfirst);
-  for (int k = 0; k < kfirst && k < B; ++k) sm[k * kBcrwSolveCols + lane] = 0.0;
-  for (int k = kfirst; k < B; ++k) {
-    double acc = 0.0;
-    if (live) {
-      if (grp == 0) acc = haveL ? Um[(size_t)l * BB + (size_t)cc * B + k] : 0.0;       // T[i,l] = T[l,i]^T
-      else if (grp == 1) acc = haveR ? Um[(size_t)i * BB + (size_t)k * B + cc] : 0.0;  // T[i,r]
-      else if (grp == 2) acc = k == cc ? 1.0 : 0.0;
-      else acc = fm[(size_t)i * B + k];
-    }
-    const double* Lk = Li + (size_t)k * B;
-    double a1 = 0.0;
-    int p = kfirst;
-    for (; p + 1 < k; p += 2) {                              // two chains: the fp64 FMA latency
-      acc -= Lk[p] * sm[p * kBcrwSolveCols + lane];
-      a1 -= Lk[p + 1] * sm[(p + 1) * kBcrwSolveCols + lane];
-    }
-    if (p < k) acc -= Lk[p] * sm[p * kBcrwSolveCols + lane];
-    sm[k * kBcrwSolveCols + lane] = (acc + a1) * Lk[k];     // 1 / L_kk is stored on the diagonal
-  }
-  if (!live) return;
-  if (grp == 3) {
-    for (int k = 0; k < B; ++k) fm[(size_t)i * B + k] = sm[k * kBcrwSolveCols + lane];
-  } else {
-    double* out = (grp == 0 ? Pm : grp == 1 ? Qm : Gi) + (size_t)i * BB + cc;
-    for (int k = 0; k < B; ++k) out[(size_t)k * B] = sm[k * kBcrwSolveCols + lane];
   }
 }
 

@@ -15,6 +15,7 @@
 #include "ba_kernels.h"
 #include "ba_bcr.h"
 #include "ba_bcr_wide.h"
+#include "ba_dense.h"
 
 using namespace ba;
 
@@ -51,6 +52,7 @@ struct ba_handle {
   // problem
   int nc = 0, nt = 0, nco = 0;
   int hb = 0;                // block half-bandwidth of the reduced system
+  int solve_kind = 0;        // BA_SOLVE_*: what the last ba_solve_reduced launched
   int min_hb = 0;            // ba_set_min_half_bandwidth: lower bound for hb (ranks must agree on the band layout)
   long long nobs = 0;
   bool have_problem = false;
@@ -91,7 +93,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
@@ -381,6 +383,38 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   return BA_OK;
 }
 
+// Dense Cholesky of the whole reduced system (ba_dense.h): bands wider than the cyclic reduction's blocks.
+int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
+  const int n = 6 * h->nco;
+  HIPCHECK(h, h->denseA.resize((size_t)(n + 1) * n));
+  HIPCHECK(h, h->dC.resize((size_t)n + 16));
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHECK(h, hipFuncSetAttribute((const void*)k_dense_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHECK(h, hipFuncSetAttribute((const void*)k_dense_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int* info = h->flags.p + 1;
+  double* A = h->denseA.p;
+  const int nsteps = (n + kDcNB - 1) / kDcNB;
+  ScopedTimer tm(h, BA_K_DENSE_SOLVE, 2 * nsteps + 1);
+  hipLaunchKernelGGL(k_dense_gather, dim3(n + 1), dim3(256), 0, h->stream, h->nco, h->hb, h->S, h->b, dmask, A, info);
+  const int bw = std::min(n, 6 * (h->hb + 1) - 1);            // S[r][c] = 0 for |r - c| > bw
+  for (int k0 = 0; k0 < n; k0 += kDcNB) {
+    const int nb = std::min(kDcNB, n - k0), kn = k0 + nb;
+    const int total = std::min(n, kn + bw) - kn + 1;           // rows below the block that can be non-zero + the rhs row
+    hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows), dim3(1024), dense_panel_lds_bytes(), h->stream, n,
+                       k0, nb, total, A, info);
+    if (total > 1) {
+      const int T = (total + kDcTile - 1) / kDcTile;
+      hipLaunchKernelGGL(k_dense_update, dim3(T, T), dim3(1024), 0, h->stream, n, k0, nb, total, A);
+    }
+  }
+  hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(1024), dense_backsolve_lds_bytes(n), h->stream, n, bw, A, h->dC.p, info);
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -391,7 +425,7 @@ const char* ba_kernel_name(int id) {
   static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
                                           "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
                                           "k_band_solve", "k_eval", "k_camera_blocks", "k_triangulate",
-                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve"};
+                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve", "k_dense_solve"};
   return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
 }
 
@@ -444,7 +478,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1214,8 +1248,11 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_solve_reduced: call ba_schur first");
   REQUIRE(h, info, BA_ERR_INVALID_ARG, "ba_solve_reduced: info is NULL");
-  if (h->hb > kMaxBandSolve) { *info = -1; return BA_OK; }     // band too wide for the LDS window
   if (h->nco == 0) { *info = 0; h->have_solution = true; return BA_OK; }
+  const char* force = getenv("BA_SOLVER");
+  const bool dense_ok = 6 * h->nco <= kDcMaxN && !(force && strcmp(force, "lu") == 0);
+  const bool use_dense = dense_ok && (h->hb > kMaxBandSolve || (force && strcmp(force, "dense") == 0));
+  if (h->hb > kMaxBandSolve && !use_dense) { *info = -1; return BA_OK; }     // caller's dense LU
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, h->Ufac.resize(std::max<size_t>(1, reduced_doubles(h))));
   const unsigned char* dmask = nullptr;
@@ -1229,7 +1266,6 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   }
   // multi-CU path: block cyclic reduction when the band is narrow enough for dense
   // (6 hb)^2 blocks in LDS and there are enough super-blocks to parallelise over
-  const char* force = getenv("BA_SOLVER");
   const bool bcr_ok = h->hb >= 1 && h->hb <= kBcrMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
   const bool use_bcr = force ? (strcmp(force, "bcr") == 0 && bcr_ok) : bcr_ok;
   const size_t lds_budget = 160 * 1024;
@@ -1237,7 +1273,11 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   size_t lds = 0;
   const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
   const bool use_bcrw = force ? (strcmp(force, "bcr") == 0 && bcrw_ok) : bcrw_ok;
-  if (use_bcr) {
+  h->solve_kind = use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
+  if (use_dense) {
+    int rc = solve_dense_chol(h, dmask);
+    if (rc != BA_OK) return rc;
+  } else if (use_bcr) {
     int rc = solve_bcr(h, dmask);
     if (rc != BA_OK) return rc;
   } else if (use_bcrw) {
@@ -1270,13 +1310,15 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     fprintf(stderr, "\n");
   }
 #endif
-  if (getenv("BA_SOLVE_TRACE") && !use_bcr && !use_bcrw)
+  if (getenv("BA_SOLVE_TRACE") && !use_bcr && !use_bcrw && !use_dense)
     fprintf(stderr, "[k_band_solve] nco=%d hb=%d ch=%d lds=%zu B | forward: %d cycles, %d ticks(100MHz) | total: %d cycles, %d ticks\n",
             h->nco, h->hb, ch, lds, inf6[2], inf6[3], inf6[4], inf6[5]);
   *info = inf;
   h->have_solution = inf == 0;
   return BA_OK;
 }
+
+int ba_last_solve_kind(const ba_handle* h) { return h ? h->solve_kind : BA_SOLVE_NONE; }
 
 int ba_get_solution(ba_handle* h, double* dC) {
   if (!h) return BA_ERR_INVALID_ARG;
@@ -1355,11 +1397,17 @@ int ba_bind_dense_stage(ba_handle* h, void* Td_dev, void* Wd_dev, void* g_dev) {
 
 int ba_dense_apply(ba_handle* h, const void* Sd_dev, const void* bc_dev) {
   if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, h->have_schur && Sd_dev && bc_dev, BA_ERR_STATE, "ba_dense_apply: call ba_schur (with ba_bind_dense_stage) first");
+  REQUIRE(h, h->have_schur && Sd_dev && (bc_dev || h->dense_Td), BA_ERR_STATE,
+          "ba_dense_apply: call ba_schur (with ba_bind_dense_stage) first");
   HIPCHECK(h, hipSetDevice(h->device));
   if (h->nco > 0) {
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, bc_dev ? 1 : 2);
     const long long n = (long long)reduced_doubles(h) + (long long)h->nco * 6;
+    if (!bc_dev && h->nt > 0) {
+      const int M = 6 * h->nco, R = 3 * h->nt;
+      hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
+                         h->stream, M, R, h->dense_Td, h->dense_g, h->b);
+    }
     hipLaunchKernelGGL(k_dense_apply, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1,
                        static_cast<const double*>(Sd_dev), 6 * h->nco, static_cast<const double*>(bc_dev), h->S, h->b);
   }
@@ -1420,8 +1468,9 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, next_cost && info, BA_ERR_INVALID_ARG, "ba_lm_trial: NULL output");
   *info = 0;
-  if (h->have_problem && h->hb > kMaxBandSolve) { *info = -1; return BA_OK; }   // band too wide for the device solvers: do not
-                                                                                // linearise and reduce just to find that out
+  // the dense-visibility reduction is driven by the caller (its matrix product is a library call), and systems
+  // too large for the dense device solve go to the caller's LU: do not linearise and reduce just to find that out
+  if (h->have_problem && h->hb > kMaxBandSolve && (h->dense_Td || 6 * h->nco > kDcMaxN)) { *info = -1; return BA_OK; }
   int32_t pre = 0;
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_lm_trial_end(h, cam_param_mask, &pre);

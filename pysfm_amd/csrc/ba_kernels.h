@@ -1151,6 +1151,20 @@ __global__ __launch_bounds__(kBlock) void k_dense_stage(DevProblem P, const doub
   }
 }
 
+// b -= Td^T g without a library call (a GEMV through the BLAS costs more than the DGEMM next to it at these
+// sizes): lanes along the columns of Td (whole cache lines), 32 rows per workgroup, one atomic per thread
+constexpr int kDenseRhsRows = 32;
+__global__ __launch_bounds__(kBlock) void k_dense_rhs(int M, int R, const double* __restrict__ Td, const double* __restrict__ g,
+                                                      double* __restrict__ b) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const int r0 = blockIdx.y * kDenseRhsRows;
+  if (c >= M) return;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int r = r0; r < min(R, r0 + kDenseRhsRows); ++r) acc += Td[(size_t)r * M + c] * g[r];
+  atomic_add_f64(b + c, -acc);
+}
+
 // S_band(i, j >= i) -= Sd[6 i .. , 6 j ..],  b -= bc;  one thread per entry of [S | b]
 __global__ __launch_bounds__(kBlock) void k_dense_apply(int nco, int hb1, const double* __restrict__ Sd, int M,
                                                         const double* __restrict__ bc, double* __restrict__ S,
@@ -1162,7 +1176,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int nco, int hb1, const 
     const long long blk = tid / 36;
     const int d = (int)(blk % hb1), i = (int)(blk / hb1), j = i + d;
     if (j < nco) S[tid] -= Sd[((size_t)6 * i + e / 6) * M + 6 * (size_t)j + e % 6];
-  } else if (tid < nS + (long long)nco * 6) {
+  } else if (bc && tid < nS + (long long)nco * 6) {
     b[tid - nS] -= bc[tid - nS];
   }
 }

@@ -547,24 +547,83 @@ def test_wide_band_takes_dense_path(be):
     load_problem(be, *scene(g), g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
     assert be.half_bandwidth == 38
     dC, dP = hip_update(be, 10.)
-    assert be.last_solve_path == 'dense'
+    assert be.last_solve_path == 'dense_cholesky'
     close(-dC, g['update_l10_motion'], 1e-7)
 
 
-def test_large_dense_system_is_solved_on_the_gpu(be):
-    """Band too wide for the device band solvers and more than HOST_SOLVE_MAX_UNKNOWNS unknowns: the
-    flattened system goes through rocSOLVER (Cholesky, LU behind it) and must agree with LAPACK."""
+def _dense_reference(be, mask=None):
+    S, b = be.get_reduced()
+    n = be.nco * 6
+    A, r = S.transpose(0, 2, 1, 3).reshape(n, n), b.reshape(n)
+    keep = np.arange(n) if mask is None else np.nonzero(mask)[0]
+    x = np.zeros(n)
+    x[keep] = np.linalg.solve(A[np.ix_(keep, keep)], r[keep])
+    return x
+
+
+@pytest.mark.parametrize('nc,L', [(160, 30), (23, 23), (58, 40), (9, 9)])
+def test_dense_cholesky_on_the_device_matches_lapack(be, monkeypatch, nc, L):
+    """Band too wide for the cyclic reduction: ba_solve_reduced factors the whole matrix on the device
+    (ba_dense.h: block columns of 48; 6 (nc - 1) is not a multiple of 48 in any of these, one ends in a
+    block of 6, one has fewer panel rows than a workgroup takes) - against LAPACK on the same system,
+    with and without deleted camera parameters."""
+    s = banded(nc, 20 * nc, track_len=L)
+    flags = default_flags(nc, 20 * nc)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    if be.half_bandwidth <= 21:
+        monkeypatch.setenv('BA_SOLVER', 'dense')
+    be.linearize(0)
+    be.schur(0, 5., 1e-5)
+    rng = np.random.RandomState(nc)
+    mask = (rng.rand(be.nco * 6) > .1).astype(np.uint8)
+    for m in (None, mask):
+        be.solve_reduced(m)
+        assert be.last_solve_path == 'dense_cholesky'
+        x = be.get_solution().reshape(-1)
+        ref = _dense_reference(be, m)
+        assert np.abs(x - ref).max() <= 1e-9 * max(1., np.abs(ref).max())
+
+
+def test_dense_cholesky_equals_cyclic_reduction(be, monkeypatch):
+    """The same banded system through the cyclic reduction and (BA_SOLVER=dense) the dense factorisation."""
+    s = banded(120, 3000, track_len=8)
+    flags = default_flags(120, 3000)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    be.linearize(0)
+    be.schur(0, 2., 1e-5)
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'bcr'
+    x0 = be.get_solution()
+    monkeypatch.setenv('BA_SOLVER', 'dense')
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'dense_cholesky' and be.last_solve_path == 'dense_cholesky'
+    close(be.get_solution(), x0, 1e-10)
+
+
+def test_lu_fallback_runs_on_the_gpu(be, monkeypatch):
+    """BA_SOLVER=lu keeps the device Cholesky out: the flattened system goes through rocSOLVER (the path
+    systems that are not positive definite take) and must agree with LAPACK."""
     nc, L = 160, 30
     s = banded(nc, 20 * nc, track_len=L)
     flags = default_flags(nc, 20 * nc)
     load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
-    assert be.half_bandwidth == L - 1 and be.nco * 6 > 768
+    monkeypatch.setenv('BA_SOLVER', 'lu')
     dC, dP = hip_update(be, 5.)
     assert be.last_solve_path == 'dense'
+    close(dC.reshape(-1), _dense_reference(be), 1e-9)
+
+
+def test_dense_cholesky_reports_non_positive_pivot(be):
+    g = load_golden('scene_oleg_40x100')
+    load_problem(be, *scene(g), g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
+    be.linearize(0)
+    be.schur(0, -3., 1e-5)
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'dense_cholesky' and be.last_solve_path == 'dense'       # LU took over
+    x = be.get_solution().reshape(-1)
     S, b = be.get_reduced()
     n = be.nco * 6
-    x = np.linalg.solve(S.transpose(0, 2, 1, 3).reshape(n, n), b.reshape(n))
-    close(dC.reshape(-1), x, 1e-9)
+    close(S.transpose(0, 2, 1, 3).reshape(n, n) @ x, b.reshape(-1), 1e-8)
 
 
 def test_band_solver_reports_non_positive_pivot(be):
