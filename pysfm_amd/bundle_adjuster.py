@@ -22,7 +22,7 @@ from copy import copy
 import numpy as np
 
 from ._capi import PARAMS_CUR, PARAMS_TRIAL
-from .backend import ReducedSystemSingular
+from .backend import ReducedSystemSingular, LU_FALLBACK_MAX_UNKNOWNS
 from .sensor_model import device_params_of
 
 
@@ -267,6 +267,8 @@ class BundleAdjuster(object):
             self._have_blocks = True
             if info == 0:
                 next_cost = cost
+            elif info > 0 and be.nco * 6 > LU_FALLBACK_MAX_UNKNOWNS:
+                return None, None                              # not positive definite, too large for LU: ill-conditioned
         elif self._comm is not None and hasattr(be, 'lm_trial_begin'):
             # sharded: the same batch in two halves around the all-reduce of [S | b]; the ranks' trial
             # costs are summed on the device, one synchronisation per trial
@@ -286,6 +288,8 @@ class BundleAdjuster(object):
                     raise np.linalg.LinAlgError('singular 3x3 point block(s) in plain-inverse mode')
                 if info == 0:
                     next_cost = cost
+                elif info > 0 and be.nco * 6 > LU_FALLBACK_MAX_UNKNOWNS:
+                    return None, None
         if next_cost is None:
             try:
                 self._compute_update_device(damping, param_mask, fetch=False)

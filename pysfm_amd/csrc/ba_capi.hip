@@ -52,6 +52,7 @@ struct ba_handle {
   // problem
   int nc = 0, nt = 0, nco = 0;
   int hb = 0;                // block half-bandwidth of the reduced system
+  bool fac_valid = false;    // fac[] (L D L^T of the point inverses + HPPinv bP) matches HPPinv
   int solve_kind = 0;        // BA_SOLVE_*: what the last ba_solve_reduced launched
   int min_hb = 0;            // ba_set_min_half_bandwidth: lower bound for hb (ranks must agree on the band layout)
   long long nobs = 0;
@@ -93,7 +94,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA, fac;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
@@ -478,7 +479,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -948,6 +949,7 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
   }
   fuse = fuse && h->nt > 0 && !store_W;
   h->inv_valid = false;
+  h->fac_valid = false;
   h->cam_blocks_valid = false;
   h->point_blocks_valid = false;
   // fuse (ba_lm_trial with the MFMA reduction): the reduction kernel linearises every observation anyway and
@@ -1030,7 +1032,9 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
   const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
   const bool mfma_possible = mfma_reduction_possible(h);
-  const bool use_mfma = !h->dense_Td && (force_schur ? (strcmp(force_schur, "mfma") == 0 && mfma_possible) : (groups_ok && mfma_possible));
+  const bool force_v1 = force_schur && strcmp(force_schur, "mfma1") == 0;     // the single-wavefront-per-group form
+  const bool use_mfma = !h->dense_Td && (force_schur ? ((strcmp(force_schur, "mfma") == 0 || force_v1) && mfma_possible)
+                                                     : (groups_ok && mfma_possible));
   const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
   // point blocks and camera blocks: normally in HPP / bP (k_linearize) and HCC / bC (k_camera_blocks);
   // ba_lm_trial leaves both to the MFMA reduction, which linearises every observation anyway
@@ -1046,6 +1050,12 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   }
   const bool have_inv = fuse_lin || (h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond);
   h->inv_valid = false;
+  // producer / consumer form of the MFMA reduction: needs the factorised point inverses, which the merged
+  // inversion + initialisation launch below writes (or has written, for the same damping)
+  const bool merged_inv = !have_inv && h->nt > 0 && h->nco > 0;
+  const bool use_v2 = use_mfma && !fuse_lin && !force_v1 && (merged_inv || (have_inv && h->fac_valid));
+  if (use_v2) HIPCHECK(h, h->fac.resize((size_t)9 * std::max(1, h->nt)));
+  if (!have_inv) h->fac_valid = false;
   if (fuse_lin) h->sing_epoch ^= 1;   // the reduction kernel counts singular blocks like k_point_invert does
   const long long ninit = (long long)reduced_doubles(h) + (long long)h->nco * 6;
   if (!have_inv && h->nt > 0 && h->nco > 0) {
@@ -1056,8 +1066,9 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     hipLaunchKernelGGL(k_point_invert_schur_init, dim3(nbi + blocks_for(ninit)), dim3(kBlock), 0, h->stream, (int)nbi, h->nt,
                        h->HPP.p, damping, pinv_rcond, h->HPPinv.p, h->sing_counter(),
                        h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), h->nco, h->hb + 1, h->opt_cam.p, h->HCC.p, h->bC.p, h->S,
-                       h->b, fuse_cam ? 0 : 1);
+                       h->b, fuse_cam ? 0 : 1, h->bP.p, use_v2 ? h->fac.p : (double*)nullptr);
     h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
+    h->fac_valid = use_v2;
   } else {
     if (have_inv) {
       h->inv_valid = !fuse_lin;   // already inverted for this (damping, rcond) - or about to be, by the reduction kernel
@@ -1088,6 +1099,16 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     const long long n = std::max<long long>(h->nobs, (long long)h->nt * 3);
     hipLaunchKernelGGL(k_dense_stage, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
                        h->HPPinv.p, h->bP.p, M, h->dense_Td, h->dense_Wd, h->dense_g);
+  } else if (use_v2) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    static bool attr_m2 = false;
+    if (!attr_m2) {
+      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_m2 = true;
+    }
+    hipLaunchKernelGGL(k_schur_groups_mfma2, dim3(h->nmchunks), dim3(kGm2Block), schur_mfma2_lds_bytes(h->schur_wn, h->hb + 1), h->stream,
+                       dev_problem(h), h->cams[p].p, h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->fac.p, h->S, h->b, damping,
+                       fuse_cam ? 1 : 0);
   } else if (use_mfma) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kGmBlock / kWave;
@@ -1110,6 +1131,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     if (fuse_lin) {
       h->point_blocks_valid = true;
       h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
+      h->fac_valid = false;
     }
   } else if (use_groups) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);

@@ -371,7 +371,8 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevProblem P, const do
 // --------------------------------------------------------------------------
 __device__ __forceinline__ void point_invert_body(int k, int nt, const double* __restrict__ HPP, double damping, double rcond,
                                                   double* __restrict__ HPPinv, int* __restrict__ singular_count,
-                                                  int* __restrict__ next_count) {
+                                                  int* __restrict__ next_count, const double* __restrict__ bP = nullptr,
+                                                  double* __restrict__ fac = nullptr) {
   if (k == 0) *next_count = 0;      // the counter the NEXT call will use (two counters alternate: no memset launch)
   if (k >= nt) return;
   double A[6], out[6];
@@ -386,6 +387,16 @@ __device__ __forceinline__ void point_invert_body(int k, int nt, const double* _
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) HPPinv[6 * (size_t)k + i] = out[i];
+  if (fac) {                                   // HPPinv = L D L^T and HPPinv bP for k_schur_groups_mfma2
+    double f[9];
+    sym3_ldl(out, f, f + 3);
+    const double g0 = bP[3 * (size_t)k], g1 = bP[3 * (size_t)k + 1], g2 = bP[3 * (size_t)k + 2];
+    f[6] = out[0] * g0 + out[1] * g1 + out[2] * g2;
+    f[7] = out[1] * g0 + out[3] * g1 + out[4] * g2;
+    f[8] = out[2] * g0 + out[4] * g1 + out[5] * g2;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fac[9 * (size_t)k + i] = f[i];
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* __restrict__ HPP,
@@ -442,9 +453,10 @@ __global__ __launch_bounds__(kBlock) void k_point_invert_schur_init(int nbi, int
                                                                     const double* __restrict__ HCC,
                                                                     const double* __restrict__ bC,
                                                                     double* __restrict__ S, double* __restrict__ b,
-                                                                    int use_hcc) {
+                                                                    int use_hcc, const double* __restrict__ bP,
+                                                                    double* __restrict__ fac) {
   if ((int)blockIdx.x < nbi)
-    point_invert_body(blockIdx.x * kBlock + threadIdx.x, nt, HPP, damping, rcond, HPPinv, singular_count, next_count);
+    point_invert_body(blockIdx.x * kBlock + threadIdx.x, nt, HPP, damping, rcond, HPPinv, singular_count, next_count, bP, fac);
   else
     schur_init_body((long long)(blockIdx.x - nbi) * kBlock + threadIdx.x, nco, hb1, opt_cam, HCC, bC, damping, S, b, use_hcc);
 }
@@ -1110,6 +1122,281 @@ __global__ __launch_bounds__(kGmBlock) void k_schur_groups_mfma(DevProblem P, co
     if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
   }
   for (int i = threadIdx.x; i < wn * 6; i += kGmBlock) {
+    const double v = tb[i];
+    if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
+  }
+}
+
+// --------------------------------------------------------------------------
+// The same reduction with the two phases on DIFFERENT wavefronts (producer / consumer), so that the
+// vector unit (linearisation) and the matrix core (products) of a SIMD work at the same time:
+// a workgroup is 4 producer + 4 consumer wavefronts, pair p = wavefronts p and p + 4, which the
+// hardware places on the same SIMD; a pair owns one group at a time and two staging buffers.
+//
+// What makes two buffers per pair fit in LDS is the symmetric form of the product: with the
+// per-point factorisation  HPPinv_k = L_k D_k L_k^T  (unit lower L, diagonal D: k_point_invert
+// writes it next to the inverse, ba_math.h sym3_ldl)
+//     S_window -= sum_k (Wstack_k L_k) D_k (Wstack_k L_k)^T
+// needs ONE staged operand U = W L per observation (the other MFMA operand is the same rows scaled
+// by D), and  b -= W (HPPinv_k bP_k)  needs no T either (the vector HPPinv bP comes with the factor).
+//   producer  one observation per lane: linearise, U, stage it k-major, b and the camera-block sums
+//   consumer  5 k-steps x 10 upper tiles of v_mfma_f64_16x16x4_f64 per batch, then the epilogue
+// Hand-over through two counters per pair in LDS (batches staged / batches consumed); LDS executes
+// one wavefront's instructions in order, so the data is there when the counter says so.
+// fac[k] = {D0, D1, D2, L10, L20, L21, v0, v1, v2}.
+// --------------------------------------------------------------------------
+constexpr int kGm2Block = 512;
+constexpr int kGm2Pairs = 4;
+constexpr int kGm2DRows = 24;                          // D values per buffer (20 used)
+
+__host__ __device__ inline size_t schur_mfma2_lds_bytes(int wn, int hb1) {
+  return (size_t)kGm2Pairs * 2 * kGmK * kGmLd * sizeof(double) + (size_t)kGm2Pairs * 2 * kGm2DRows * sizeof(double) +
+         (size_t)kGm2Pairs * (16 + 4) * sizeof(int) + (size_t)wn * ((size_t)hb1 * 36 + 6) * sizeof(double);
+}
+
+__device__ __forceinline__ void gm2_wait(int* flag, int need) {
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void gm2_post(int* flag, int value, int lane) {
+  lds_wave_sync();                                         // my LDS reads / writes are done (in-order LDS: and visible)
+  if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, const double* __restrict__ cams,
+                                                                  const double* __restrict__ X,
+                                                                  const SchurGroup* __restrict__ groups,
+                                                                  const SchurChunk* __restrict__ chunks, int wn,
+                                                                  const double* __restrict__ fac,
+                                                                  double* __restrict__ S, double* __restrict__ b,
+                                                                  double damping, int fuse_cam) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  constexpr int BUF = kGmK * kGmLd;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* sU = dyn;                                            // [pair][2][kGmK][kGmLd]
+  double* sD = sU + kGm2Pairs * 2 * BUF;                       // [pair][2][kGm2DRows]
+  int* sPos = reinterpret_cast<int*>(sD + kGm2Pairs * 2 * kGm2DRows);   // [pair][16]
+  int* sFlag = sPos + kGm2Pairs * 16;                          // [pair][4]: staged, consumed
+  double* tile = reinterpret_cast<double*>(sFlag + kGm2Pairs * 4);
+  const int hb1 = P.hb + 1;
+  const int rowlen = hb1 * 36;
+  double* tb = tile + (size_t)wn * rowlen;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int pair = wv & 3;
+  const bool producer = wv < kGm2Pairs;
+  const SchurChunk ck = chunks[blockIdx.x];
+  const int p0 = ck.p0;
+  for (int i = threadIdx.x; i < wn * (rowlen + 6); i += kGm2Block) tile[i] = 0.0;
+  for (int i = threadIdx.x; i < kGm2Pairs * 2 * (BUF + kGm2DRows); i += kGm2Block) sU[i] = 0.0;   // incl. sD, the zero k rows
+  if (threadIdx.x < kGm2Pairs * 4) sFlag[threadIdx.x] = 0;
+  __syncthreads();
+  int* fStaged = sFlag + pair * 4;
+  int* fConsumed = fStaged + 1;
+  int nbatch = 0;                                              // batches this pair has handed over so far
+
+  if (producer) {
+    for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
+      const SchurGroup gr = groups[g];
+      const int L = gr.L;
+      const int NP = 64 / L < kGmPts ? 64 / L : kGmPts;
+      const int slot = lane / L, oi = lane - slot * L;
+      const bool stager = lane < NP * L;
+      const int n0 = P.pt_off[gr.pt_begin] + oi;
+      const int c = P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]];
+      const int mypos = stager ? P.cam_opt_pos[c] : -1;
+      double cm[12];
+      load_cam(cams, c, cm);
+      double bacc[6] = {0, 0, 0, 0, 0, 0};
+      double hc[21];
+#pragma unroll
+      for (int q = 0; q < 21; ++q) hc[q] = 0.0;
+      struct PointIn { double x[3], f[9]; double2 z; };
+      auto fetch = [&](int kb_, PointIn& in) {
+        const int k = kb_ + slot;
+        if (stager && k < gr.pt_end) {
+          in.z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) in.x[q] = X[3 * (size_t)k + q];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) in.f[q] = fac[9 * (size_t)k + q];
+        }
+      };
+      PointIn nxt;
+      fetch(gr.pt_begin, nxt);
+      for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+        const int np = min(NP, gr.pt_end - kb);
+        const PointIn cur = nxt;
+        fetch(kb + NP, nxt);
+        const bool live = stager && slot < np;
+        double U[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) U[q] = 0.0;                // a short last batch stages zero k rows
+        if (live) {
+          double e[2], r[2], Jc[12], Jp[6], W[18];
+          obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
+          block_W(Jc, Jp, W);
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            U[a * 3] = W[a * 3] + cur.f[3] * W[a * 3 + 1] + cur.f[4] * W[a * 3 + 2];
+            U[a * 3 + 1] = W[a * 3 + 1] + cur.f[5] * W[a * 3 + 2];
+            U[a * 3 + 2] = W[a * 3 + 2];
+          }
+          if (mypos >= 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) bacc[a] -= W[a * 3] * cur.f[6] + W[a * 3 + 1] * cur.f[7] + W[a * 3 + 2] * cur.f[8];
+            if (fuse_cam) {                                     // HCC[i] += Jc^T Jc, b[i] += Jc^T r (k_camera_blocks' work)
+              int idx = 0;
+#pragma unroll
+              for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int c2 = a; c2 < 6; ++c2) hc[idx++] += Jc[a] * Jc[c2] + Jc[6 + a] * Jc[6 + c2];
+                bacc[a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+              }
+            }
+          }
+        }
+        gm2_wait(fConsumed, nbatch - 1);                         // the buffer's previous batch (nbatch - 2) has been read
+        double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
+        double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
+        if (stager) {
+          const int so = 3 * slot * kGmLd + 6 * oi;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) mU[so + d * kGmLd + a] = U[a * 3 + d];
+          if (oi == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) mD[3 * slot + d] = live ? cur.f[d] : 0.0;
+          }
+        }
+        ++nbatch;
+        gm2_post(fStaged, nbatch, lane);
+      }
+      if (mypos >= 0) {
+        const int wr = mypos - p0;
+        const bool in = wr >= 0 && wr < wn;
+        if (in) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) atomic_add_f64(tb + wr * 6 + a, bacc[a]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) atomic_add_f64(b + (size_t)mypos * 6 + a, bacc[a]);
+        }
+        if (fuse_cam) {                                          // damped camera block onto the diagonal block (stored in full)
+          int idx = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int c2 = a; c2 < 6; ++c2) {
+              const double v = a == c2 ? hc[idx] * (1.0 + damping) : hc[idx];
+              ++idx;
+              if (in) {
+                atomic_add_f64(tile + wr * rowlen + a * 6 + c2, v);
+                if (a != c2) atomic_add_f64(tile + wr * rowlen + c2 * 6 + a, v);
+              } else {
+                atomic_add_f64(S + (size_t)mypos * rowlen + a * 6 + c2, v);
+                if (a != c2) atomic_add_f64(S + (size_t)mypos * rowlen + c2 * 6 + a, v);
+              }
+            }
+          }
+        }
+      }
+    }
+  } else {
+    const int lr = lane & 15, lk = lane >> 4;
+    int* mPos = sPos + pair * 16;
+    for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
+      const SchurGroup gr = groups[g];
+      const int L = gr.L;
+      const int NP = 64 / L < kGmPts ? 64 / L : kGmPts;
+      const int nts = (6 * L + 15) >> 4;
+      const int nb = (gr.pt_end - gr.pt_begin + NP - 1) / NP;
+      if (lane < 16) mPos[lane] = lane < L ? P.cam_opt_pos[P.obs_cam[P.pt_off[gr.pt_begin] + lane]] : -1;
+      mfma_acc acc[10];
+#pragma unroll
+      for (int t = 0; t < 10; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+      for (int ib = 0; ib < nb; ++ib) {
+        gm2_wait(fStaged, nbatch + 1);
+        const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
+        const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
+#pragma unroll
+        for (int s4 = 0; s4 < kGmK / 4; ++s4) {
+          double ta[4], wb[4];
+          const double dk = mD[4 * s4 + lk];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) wb[t] = mU[(4 * s4 + lk) * kGmLd + 16 * t + lr];
+          if (s4 == kGmK / 4 - 1) { ++nbatch; gm2_post(fConsumed, nbatch, lane); }     // everything of this buffer is in registers
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ta[t] = wb[t] * dk;
+          int q = 0;
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < 4; ++tj, ++q)
+              if (tj < nts) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ti], wb[tj], acc[q], 0, 0, 0);
+        }
+      }
+      lds_wave_sync();                                          // mPos
+      // ---- epilogue (as in k_schur_groups_mfma): C/D layout lane -> column n = 16 tj + lane%16,
+      // register v -> row m = 16 ti + lane/16 + 4 v
+      {
+        int colpart[4], pjv[4], jn[4], cn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int n = 16 * t + lr;
+          jn[t] = n / 6; cn[t] = n - 6 * jn[t];
+          pjv[t] = jn[t] < L ? mPos[jn[t]] : -1;
+          colpart[t] = pjv[t] * 36 + cn[t];
+        }
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          int rowpart[4], pim[4], im[4], am[4];
+          bool inwin[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int m = 16 * ti + lk + 4 * v;
+            im[v] = m / 6; am[v] = m - 6 * im[v];
+            const int pi = im[v] < L ? mPos[im[v]] : -1;
+            const int wr = pi - p0;
+            pim[v] = pi;
+            inwin[v] = wr >= 0 && wr < wn;
+            rowpart[v] = (inwin[v] ? wr * rowlen : pi * rowlen) - pi * 36 + am[v] * 6;
+          }
+#pragma unroll
+          for (int tj = ti; tj < 4; ++tj, ++q) {
+            if (tj >= nts) continue;
+            const int j = jn[tj], c = cn[tj];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int i = im[v], a = am[v];
+              const bool ok = pim[v] >= 0 && pjv[tj] >= 0 && (i < j || (i == j && a <= c));
+              if (ok) {
+                const double val = -acc[q][v];
+                const int off = rowpart[v] + colpart[tj];
+                const int mir = off + 5 * (c - a);               // entry (c, a) of the same block
+                if (inwin[v]) {
+                  atomic_add_f64(tile + off, val);
+                  if (i == j && a < c) atomic_add_f64(tile + mir, val);     // diagonal blocks are stored in full
+                } else {
+                  atomic_add_f64(S + off, val);
+                  if (i == j && a < c) atomic_add_f64(S + mir, val);
+                }
+              }
+            }
+          }
+        }
+      }
+      lds_wave_sync();                                          // mPos is rewritten by the next group
+    }
+  }
+  if (wn == 0) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < wn * rowlen; i += kGm2Block) {
+    const double v = tile[i];
+    const int wr = i / rowlen;
+    if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
+  }
+  for (int i = threadIdx.x; i < wn * 6; i += kGm2Block) {
     const double v = tb[i];
     if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
   }

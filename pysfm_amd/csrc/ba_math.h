@@ -259,6 +259,27 @@ BA_HD void sym3_pinv_fast(const double A[6], double rcond, double out[6]) {
 
 // numpy.linalg.inv for a symmetric 3x3 (bundle_adjuster.py:254).  Returns false
 // when the block is singular (numpy raises LinAlgError there).
+// A = L D L^T for a symmetric 3 x 3 matrix [a00 a01 a02 a11 a12 a22], L unit lower: D[3], Lo = {L10, L20, L21}.
+// Made for the per-point pseudo-inverse (positive semi-definite, possibly rank deficient: eigenvalues
+// either >= rcond * largest or exactly cut to zero): a pivot below 1e-10 * trace is a cut direction -
+// its column of L and its D are zero (for a semi-definite matrix the rest of that column is zero too).
+BA_HD void sym3_ldl(const double A[6], double D[3], double Lo[3]) {
+  const double tol = 1e-10 * (fabs(A[0]) + fabs(A[3]) + fabs(A[5]));
+  const bool z0 = !(fabs(A[0]) > tol);
+  const double i0 = z0 ? 0.0 : 1.0 / A[0];
+  D[0] = z0 ? 0.0 : A[0];
+  Lo[0] = A[1] * i0;
+  Lo[1] = A[2] * i0;
+  const double d1 = A[3] - Lo[0] * A[1];
+  const bool z1 = !(fabs(d1) > tol);
+  const double i1 = z1 ? 0.0 : 1.0 / d1;
+  D[1] = z1 ? 0.0 : d1;
+  const double t = A[4] - Lo[1] * A[1];
+  Lo[2] = t * i1;
+  const double d2 = A[5] - Lo[1] * A[2] - Lo[2] * t;
+  D[2] = fabs(d2) > tol ? d2 : 0.0;
+}
+
 BA_HD bool sym3_inv(const double A[6], double out[6]) {
   const double c00 = A[3] * A[5] - A[4] * A[4];
   const double c01 = A[2] * A[4] - A[1] * A[5];

@@ -640,6 +640,27 @@ def test_band_solver_reports_non_positive_pivot(be):
     close(A @ x, b.reshape(-1), 1e-9)
 
 
+def test_large_system_that_is_not_positive_definite_is_reported_ill_conditioned(be):
+    """More unknowns than the LU fallback takes (backend.LU_FALLBACK_MAX_UNKNOWNS): a failed Cholesky is
+    answered like the reference's LinAlgError (NormalEquationsIllconditioned -> the LM loop raises the
+    damping, bundle_adjuster.py:134-140) instead of a dense LU of a 16000+ square matrix."""
+    from pysfm_amd.backend import ReducedSystemSingular, LU_FALLBACK_MAX_UNKNOWNS
+    nc = LU_FALLBACK_MAX_UNKNOWNS // 6 + 40
+    s = banded(nc, 3 * nc, track_len=6)
+    flags = default_flags(nc, 3 * nc)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    assert be.nco * 6 > LU_FALLBACK_MAX_UNKNOWNS
+    be.linearize(0)
+    be.schur(0, -3., 1e-5)                    # (1 + lambda) < 0: indefinite
+    with pytest.raises(ReducedSystemSingular):
+        be.solve_reduced(None)
+    info, _ = be.lm_trial(-3., 1e-5, None)
+    assert info > 0
+    be.schur(0, 10., 1e-5)                    # and the same scene, damped properly, solves on the device
+    be.solve_reduced(None)
+    assert be.last_solve_path == 'band'
+
+
 def test_lm_trial_entry_equals_stepwise_calls(be):
     """ba_lm_trial (one batch, one synchronisation) against the same step made of the
     individual entry points, including the accept / swap bookkeeping."""
