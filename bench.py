@@ -94,8 +94,8 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.csv')))
     if not files:
         return None, None
-    # the timer id 'schur_pairs' covers the three interchangeable reduction kernels
-    names = ['k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'] if kernel == 'schur_pairs' else ['k_' + kernel]
+    # the timer id 'schur_pairs' covers the interchangeable reduction kernels
+    names = ['k_schur_groups_mfma2', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'] if kernel == 'schur_pairs' else ['k_' + kernel]
     rows = list(csv.DictReader(open(files[-1])))
     for name in names:
         for row in rows:
@@ -280,7 +280,7 @@ def main():
                          'algorithmic_bytes_per_launch': B,
                          'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
                          'note': 'HIP events on the launch stream during the timed steps, every 4th step; back-to-back launches of one kernel (the cyclic-reduction levels) share one event pair, avg = elapsed / launches'},
-            'matrix_cores': {'kernel': 'k_schur_groups_mfma (timer schur_pairs)', 'useful_flops_per_launch': schur_flops(nobs_local, be.nt),
+            'matrix_cores': {'kernel': 'k_schur_groups_mfma2 (timer schur_pairs)', 'useful_flops_per_launch': schur_flops(nobs_local, be.nt),
                              'achieved_tflops': schur_flops(nobs_local, be.nt) / max(1e-9, ours['schur_pairs']['ms'] / max(1, ours['schur_pairs']['launches']) * 1e-3) / 1e12
                              if 'schur_pairs' in ours else None,
                              'peak_tflops': FP64_MATRIX_PEAK_TFLOPS,
