@@ -138,15 +138,13 @@ int ba_get_point_inverses(ba_handle* h, double* HPP_inv);
 int ba_reduced_device_ptrs(ba_handle* h, void** S_band, void** b);
 int ba_bind_reduced_buffers(ba_handle* h, void* S_band_dev, void* b_dev);
 
-/* Dense visibility (every track seen by most cameras - the reference's own data sets): the Schur
- * reduction is one dense matrix product.  With these buffers bound, ba_schur stages its operands
- * Td, Wd [3 nt][6 nco] (row 3 k + d, column 6 pos + a, row-major, zero where a camera does not see a
- * point) and g [3 nt] = bP instead of running a reduction kernel; the caller computes
- * Sd = Td^T Wd [6 nco][6 nco] and bc = Td^T g [6 nco] with a library DGEMM on the handle's stream and
- * calls ba_dense_apply, which subtracts them from the band-stored [S | b] (bc_dev NULL: the library forms
- * Td^T g itself - cheaper than a BLAS GEMV at these sizes).  ba_bind_dense_stage(NULL...) unbinds. */
-int ba_bind_dense_stage(ba_handle* h, void* Td_dev, void* Wd_dev, void* g_dev);
-int ba_dense_apply(ba_handle* h, const void* Sd_dev, const void* bc_dev);
+/* Dense visibility (every track seen by most cameras: the reference's data/oleg_synthetic).  With `on`,
+ * ba_schur forms the reduction as ONE symmetric matrix product over all points,
+ * S -= Ud^T diag(D) Ud with Ud [3 nt][6 nco] (library-owned, 8 * 3 nt * 6 nco bytes), on the fp64 matrix
+ * cores, instead of the per-pair kernels whose global atomics dominate when every camera pair shares
+ * every track.  The caller decides (the Python host: band wider than 21 blocks and >= 25 % of the
+ * (camera, track) pairs observed); results do not depend on it beyond rounding. */
+int ba_set_dense_visibility(ba_handle* h, int32_t on);
 
 /* ---- BundleAdjuster.solve_motion_normal_eqns (bundle_adjuster.py:281-312)
  * Device-resident Cholesky solve of the reduced camera system, by block half-bandwidth hb:

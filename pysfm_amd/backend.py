@@ -23,7 +23,7 @@ DEVICE_CHOLESKY_MAX_UNKNOWNS = 16000   # (= kDcMaxN of ba_dense.h)
 LU_FALLBACK_MAX_UNKNOWNS = 16000
 DENSE_MIN_HALF_BANDWIDTH = 21     # (= kMaxBandSolve: beyond it the solve is dense anyway)
 DENSE_MIN_FILL = 0.25             # observed fraction of the (camera, track) pairs
-DENSE_MAX_BYTES = 2 << 30         # of the two staged operands
+DENSE_MAX_BYTES = 2 << 30         # of the staged operand
 
 
 class SingularPointBlock(np.linalg.LinAlgError):
@@ -195,32 +195,19 @@ class HipBackend(object):
     def schur(self, which, damping, rcond):
         """rcond None -> plain inverse (SCHUR_COMPLIMENT_PINV_THRESHOLD = None)."""
         self._check(self._lib.ba_schur(self._h, which, float(damping), -1.0 if rcond is None else float(rcond)))
-        if self._dense is not None:
-            # dense visibility: the reduction is ONE matrix product - a plain library DGEMM (rocBLAS through
-            # torch) on the operands ba_schur has just staged, then subtracted from the band on the device
-            Td, Wd, g = self._dense
-            with self.stream_ctx():
-                Sd = self._torch.mm(Td.t(), Wd)
-                self._check(self._lib.ba_dense_apply(self._h, C.c_void_p(Sd.data_ptr()), None))    # Td^T g: library kernel
-                self._dense_keep = Sd                     # alive until the kernel has run
 
     def _bind_dense(self):
-        """Dense-visibility reduction (include/pysfm_ba.h ba_bind_dense_stage): when the band is too wide
-        for the device solvers anyway and most (camera, track) pairs are observed."""
-        self._dense = None
-        if self._torch is None or self.nco == 0 or self.nt == 0:
+        """Dense-visibility reduction (include/pysfm_ba.h ba_set_dense_visibility): when the band is too wide
+        for the cyclic reduction anyway and most (camera, track) pairs are observed, ba_schur forms the
+        reduction as one symmetric matrix product on the matrix cores."""
+        self._dense = False
+        if self.nco == 0 or self.nt == 0:
             return
         fill = self.nobs / float(self.nco * self.nt)
         words = 3 * self.nt * 6 * self.nco
-        if self.half_bandwidth > DENSE_MIN_HALF_BANDWIDTH and fill >= DENSE_MIN_FILL and 16 * words <= DENSE_MAX_BYTES:
-            torch = self._torch
-            dev = torch.device('cuda', self.device)
-            Td = torch.empty((3 * self.nt, 6 * self.nco), dtype=torch.float64, device=dev)
-            Wd = torch.empty_like(Td)
-            g = torch.empty(3 * self.nt, dtype=torch.float64, device=dev)
-            self._check(self._lib.ba_bind_dense_stage(self._h, C.c_void_p(Td.data_ptr()), C.c_void_p(Wd.data_ptr()),
-                                                      C.c_void_p(g.data_ptr())))
-            self._dense = (Td, Wd, g)
+        self._dense = bool(self.half_bandwidth > DENSE_MIN_HALF_BANDWIDTH and fill >= DENSE_MIN_FILL
+                           and 8 * words <= DENSE_MAX_BYTES)
+        self._check(self._lib.ba_set_dense_visibility(self._h, int(self._dense)))
 
     def reduced_tensors(self):
         """torch views (S_band[nco*(hb+1)*36], b[nco*6]) of the device-resident reduced

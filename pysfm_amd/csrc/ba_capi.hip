@@ -64,7 +64,7 @@ struct ba_handle {
   bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
   bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)
   double inv_damping = 0.0, inv_rcond = 0.0;
-  double *dense_Td = nullptr, *dense_Wd = nullptr, *dense_g = nullptr;   // ba_bind_dense_stage: operands of the dense-visibility reduction
+  bool dense_mode = false;           // ba_set_dense_visibility: the reduction is one SYRK over all points (k_dense_*)
   double* trial_result_dev = nullptr; // bound by ba_bind_trial_result: device copy of the cost partials + status words
   double trial_rcond = 0.0;          // ba_lm_trial_begin -> ba_lm_trial_end
   int glog = 0;              // lanes per point = 2^glog
@@ -94,7 +94,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA, fac;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA, fac, dUd, dDd, dyd, dpart;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
@@ -479,7 +479,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -748,7 +748,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   }
   // a reduced system bound for another problem size is no longer valid
   h->S = nullptr; h->b = nullptr;
-  h->dense_Td = h->dense_Wd = h->dense_g = nullptr;
   h->have_problem = true;
   h->have_params[0] = h->have_params[1] = false;
   h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
@@ -1033,7 +1032,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
   const bool mfma_possible = mfma_reduction_possible(h);
   const bool force_v1 = force_schur && strcmp(force_schur, "mfma1") == 0;     // the single-wavefront-per-group form
-  const bool use_mfma = !h->dense_Td && (force_schur ? ((strcmp(force_schur, "mfma") == 0 || force_v1) && mfma_possible)
+  const bool dense = h->dense_mode && h->nt > 0 && h->nco > 0;
+  const bool use_mfma = !dense && (force_schur ? ((strcmp(force_schur, "mfma") == 0 || force_v1) && mfma_possible)
                                                      : (groups_ok && mfma_possible));
   const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
   // point blocks and camera blocks: normally in HPP / bP (k_linearize) and HCC / bC (k_camera_blocks);
@@ -1048,13 +1048,14 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     rc = launch_camera_blocks(h, h->lin_phys, true);
     if (rc != BA_OK) return rc;
   }
-  const bool have_inv = fuse_lin || (h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond);
+  const bool have_inv = fuse_lin || (h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond && (!dense || h->fac_valid));
   h->inv_valid = false;
   // producer / consumer form of the MFMA reduction: needs the factorised point inverses, which the merged
   // inversion + initialisation launch below writes (or has written, for the same damping)
   const bool merged_inv = !have_inv && h->nt > 0 && h->nco > 0;
   const bool use_v2 = use_mfma && !fuse_lin && !force_v1 && (merged_inv || (have_inv && h->fac_valid));
-  if (use_v2) HIPCHECK(h, h->fac.resize((size_t)9 * std::max(1, h->nt)));
+  const bool want_fac = use_v2 || dense;
+  if (want_fac) HIPCHECK(h, h->fac.resize((size_t)9 * std::max(1, h->nt)));
   if (!have_inv) h->fac_valid = false;
   if (fuse_lin) h->sing_epoch ^= 1;   // the reduction kernel counts singular blocks like k_point_invert does
   const long long ninit = (long long)reduced_doubles(h) + (long long)h->nco * 6;
@@ -1066,9 +1067,9 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     hipLaunchKernelGGL(k_point_invert_schur_init, dim3(nbi + blocks_for(ninit)), dim3(kBlock), 0, h->stream, (int)nbi, h->nt,
                        h->HPP.p, damping, pinv_rcond, h->HPPinv.p, h->sing_counter(),
                        h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), h->nco, h->hb + 1, h->opt_cam.p, h->HCC.p, h->bC.p, h->S,
-                       h->b, fuse_cam ? 0 : 1, h->bP.p, use_v2 ? h->fac.p : (double*)nullptr);
+                       h->b, fuse_cam ? 0 : 1, h->bP.p, want_fac ? h->fac.p : (double*)nullptr);
     h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
-    h->fac_valid = use_v2;
+    h->fac_valid = want_fac;
   } else {
     if (have_inv) {
       h->inv_valid = !fuse_lin;   // already inverted for this (damping, rcond) - or about to be, by the reduction kernel
@@ -1087,18 +1088,26 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                          h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
     }
   }
-  if (h->dense_Td) {
-    // dense visibility: stage the operands of the one big matrix product; the caller runs the DGEMM and
-    // hands the result to ba_dense_apply (the reduction kernels below would do 36 global atomics per
-    // (pair, point): 258 M of them at 100 cameras x 1000 tracks)
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
-    const int M = 6 * h->nco;
-    const size_t bytes = (size_t)3 * h->nt * M * sizeof(double);
-    HIPCHECK(h, hipMemsetAsync(h->dense_Td, 0, bytes, h->stream));
-    HIPCHECK(h, hipMemsetAsync(h->dense_Wd, 0, bytes, h->stream));
-    const long long n = std::max<long long>(h->nobs, (long long)h->nt * 3);
+  if (dense) {
+    // dense visibility: the reduction is one symmetric matrix product over all points (the kernels below
+    // would do 36 global atomics per (pair, point): 258 M of them at 100 cameras x 1000 tracks)
+    const int M = 6 * h->nco, R = 3 * h->nt;
+    const int T = (M + kSyrkTile - 1) / kSyrkTile, pairs = T * (T + 1) / 2;
+    int nsplit = std::max(1, std::min(16, (768 + pairs - 1) / pairs));
+    const int chunk = ((R + nsplit - 1) / nsplit + kSyrkKc - 1) / kSyrkKc * kSyrkKc;
+    nsplit = (R + chunk - 1) / chunk;
+    HIPCHECK(h, h->dUd.resize((size_t)R * M)); HIPCHECK(h, h->dDd.resize(R)); HIPCHECK(h, h->dyd.resize(R));
+    HIPCHECK(h, h->dpart.resize((size_t)nsplit * M * M));
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, 5);
+    HIPCHECK(h, hipMemsetAsync(h->dUd.p, 0, (size_t)R * M * sizeof(double), h->stream));
+    const long long n = std::max<long long>(h->nobs, (long long)h->nt);
     hipLaunchKernelGGL(k_dense_stage, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
-                       h->HPPinv.p, h->bP.p, M, h->dense_Td, h->dense_Wd, h->dense_g);
+                       h->fac.p, h->bP.p, M, h->dUd.p, h->dDd.p, h->dyd.p);
+    hipLaunchKernelGGL(k_dense_syrk, dim3(T, T, nsplit), dim3(1024), 0, h->stream, M, R, chunk, h->dUd.p, h->dDd.p, h->dpart.p);
+    hipLaunchKernelGGL(k_dense_apply, dim3(blocks_for(reduced_doubles(h))), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, M, nsplit,
+                       h->dpart.p, h->S);
+    hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
+                       h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
   } else if (use_v2) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     static bool attr_m2 = false;
@@ -1409,31 +1418,11 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   return BA_OK;
 }
 
-int ba_bind_dense_stage(ba_handle* h, void* Td_dev, void* Wd_dev, void* g_dev) {
+int ba_set_dense_visibility(ba_handle* h, int32_t on) {
   if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, (Td_dev != nullptr) == (Wd_dev != nullptr) && (Td_dev != nullptr) == (g_dev != nullptr), BA_ERR_INVALID_ARG,
-          "ba_bind_dense_stage: give all three buffers, or none");
-  h->dense_Td = static_cast<double*>(Td_dev); h->dense_Wd = static_cast<double*>(Wd_dev); h->dense_g = static_cast<double*>(g_dev);
-  return BA_OK;
-}
-
-int ba_dense_apply(ba_handle* h, const void* Sd_dev, const void* bc_dev) {
-  if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, h->have_schur && Sd_dev && (bc_dev || h->dense_Td), BA_ERR_STATE,
-          "ba_dense_apply: call ba_schur (with ba_bind_dense_stage) first");
-  HIPCHECK(h, hipSetDevice(h->device));
-  if (h->nco > 0) {
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, bc_dev ? 1 : 2);
-    const long long n = (long long)reduced_doubles(h) + (long long)h->nco * 6;
-    if (!bc_dev && h->nt > 0) {
-      const int M = 6 * h->nco, R = 3 * h->nt;
-      hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
-                         h->stream, M, R, h->dense_Td, h->dense_g, h->b);
-    }
-    hipLaunchKernelGGL(k_dense_apply, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1,
-                       static_cast<const double*>(Sd_dev), 6 * h->nco, static_cast<const double*>(bc_dev), h->S, h->b);
-  }
-  HIPCHECK(h, hipGetLastError());
+  h->dense_mode = on != 0;
+  h->inv_valid = false;
+  if (!on) { h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); }
   return BA_OK;
 }
 
@@ -1492,7 +1481,7 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   *info = 0;
   // the dense-visibility reduction is driven by the caller (its matrix product is a library call), and systems
   // too large for the dense device solve go to the caller's LU: do not linearise and reduce just to find that out
-  if (h->have_problem && h->hb > kMaxBandSolve && (h->dense_Td || 6 * h->nco > kDcMaxN)) { *info = -1; return BA_OK; }
+  if (h->have_problem && h->hb > kMaxBandSolve && 6 * h->nco > kDcMaxN) { *info = -1; return BA_OK; }
   int32_t pre = 0;
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_lm_trial_end(h, cam_param_mask, &pre);

@@ -1404,68 +1404,136 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
 
 // --------------------------------------------------------------------------
 // Dense visibility (every track seen by most cameras: the reference's own data sets).  There the
-// reduction  S -= sum_k Tstack_k Wstack_k^T  is ONE dense matrix product with inner dimension 3 nt:
-// k_dense_stage writes the two operands  Td, Wd [3 nt][6 nco]  (row 3 k + d, column 6 pos + a; zero
-// where a camera does not see a point), a library DGEMM forms Td^T Wd and Td^T bP, and k_dense_apply
-// subtracts the result from the band-stored [S | b].  One observation per lane.
+// reduction  S -= sum_k Wstack_k HPPinv_k Wstack_k^T  is ONE dense matrix product with inner dimension
+// 3 nt, and with the factorised point inverses (HPPinv = L D L^T, see k_schur_groups_mfma2) a symmetric
+// one:  S -= Ud^T diag(Dd) Ud,  Ud [3 nt][6 nco]  (row 3 k + d, column 6 pos + a; zero where a camera
+// does not see a point),  b -= Ud^T y  with  y_k = D_k L_k^T bP_k.
+//   k_dense_stage  one observation per lane: linearise, U = W L, scatter into Ud; Dd, y per point
+//   k_dense_syrk   upper 64 x 64 tiles of Ud^T D Ud on the matrix cores, split along the 3 nt rows so
+//                  that a 594 x 594 result still fills the chip; partial sums to their own slabs
+//   k_dense_apply  S_band -= sum of the slabs;  k_dense_rhs  b -= Ud^T y
+// (The first version staged T and W and called the BLAS: a 594 x 594 x 3000 DGEMM ran at 12 TFLOP/s,
+// 172 us, and the GEMV for b took another 118.)
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_dense_stage(DevProblem P, const double* __restrict__ cams,
                                                         const double* __restrict__ X,
-                                                        const double* __restrict__ HPPinv,
+                                                        const double* __restrict__ fac,
                                                         const double* __restrict__ bP, int M,
-                                                        double* __restrict__ Td, double* __restrict__ Wd,
-                                                        double* __restrict__ gvec) {
+                                                        double* __restrict__ Ud, double* __restrict__ Dd,
+                                                        double* __restrict__ yd) {
   const long long n = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (n < (long long)P.nt * 3) gvec[n] = bP[n];
+  if (n < P.nt) {
+    const double* f = fac + 9 * (size_t)n;
+    const double g0 = bP[3 * n], g1 = bP[3 * n + 1], g2 = bP[3 * n + 2];
+    Dd[3 * n] = f[0]; Dd[3 * n + 1] = f[1]; Dd[3 * n + 2] = f[2];
+    yd[3 * n] = f[0] * (g0 + f[3] * g1 + f[4] * g2);          // D L^T bP
+    yd[3 * n + 1] = f[1] * (g1 + f[5] * g2);
+    yd[3 * n + 2] = f[2] * g2;
+  }
   if (n >= P.nobs) return;
   const int c = P.obs_cam[n], k = P.obs_pt[n];
   const int pos = P.cam_opt_pos[c];
   if (pos < 0) return;
   const double2 z = P.obs_z[n];
   const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
-  double cm[12], e[2], r[2], Jc[12], Jp[6], W[18], T[18], A[6];
+  double cm[12], e[2], r[2], Jc[12], Jp[6], W[18];
   load_cam(cams, c, cm);
   obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
   block_W(Jc, Jp, W);
+  const double l10 = fac[9 * (size_t)k + 3], l20 = fac[9 * (size_t)k + 4], l21 = fac[9 * (size_t)k + 5];
+  const size_t row = (size_t)3 * k * M + 6 * (size_t)pos;
 #pragma unroll
-  for (int q = 0; q < 6; ++q) A[q] = HPPinv[6 * (size_t)k + q];
-  block_T(W, A, T);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const size_t row = ((size_t)3 * k + d) * M + 6 * (size_t)pos;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) { Td[row + a] = T[a * 3 + d]; Wd[row + a] = W[a * 3 + d]; }
+  for (int a = 0; a < 6; ++a) {
+    Ud[row + a] = W[a * 3] + l10 * W[a * 3 + 1] + l20 * W[a * 3 + 2];
+    Ud[row + M + a] = W[a * 3 + 1] + l21 * W[a * 3 + 2];
+    Ud[row + 2 * (size_t)M + a] = W[a * 3 + 2];
   }
 }
 
-// b -= Td^T g without a library call (a GEMV through the BLAS costs more than the DGEMM next to it at these
-// sizes): lanes along the columns of Td (whole cache lines), 32 rows per workgroup, one atomic per thread
+constexpr int kSyrkTile = 64;                          // output tile edge
+constexpr int kSyrkKc = 32;                            // rows of Ud per LDS panel
+
+__global__ __launch_bounds__(1024) void k_dense_syrk(int M, int R, int chunk, const double* __restrict__ Ud,
+                                                     const double* __restrict__ Dd, double* __restrict__ part) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  __shared__ double pA[kSyrkKc * kSyrkTile], pB[kSyrkKc * kSyrkTile];    // [k][column]: A = D Ud (rows of tile ti), B = Ud (tile tj)
+  const int ti = blockIdx.x, tj = blockIdx.y, ks = blockIdx.z;
+  if (tj < ti) return;                                                   // upper triangle of tiles
+  const int i0 = kSyrkTile * ti, j0 = kSyrkTile * tj;
+  const int r0 = ks * chunk, r1 = min(R, r0 + chunk);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  const int wi = wave >> 2, wj = wave & 3;
+  // loader role: two entries of each panel per thread
+  const int lrow = tid >> 6, lcol = tid & 63;                            // rows lrow and lrow + 16
+  mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
+  double va[2], vb[2];
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = kk + lrow + 16 * u;
+      const bool rok = r < r1;
+      const double d = rok ? Dd[r] : 0.0;
+      va[u] = (rok && i0 + lcol < M) ? Ud[(size_t)r * M + i0 + lcol] * d : 0.0;
+      vb[u] = (rok && j0 + lcol < M) ? Ud[(size_t)r * M + j0 + lcol] : 0.0;
+    }
+  };
+  fetch(r0);
+  for (int kk = r0; kk < r1; kk += kSyrkKc) {
+    __syncthreads();                                                     // the previous panel has been consumed
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pA[(lrow + 16 * u) * kSyrkTile + lcol] = va[u];
+      pB[(lrow + 16 * u) * kSyrkTile + lcol] = vb[u];
+    }
+    __syncthreads();
+    if (kk + kSyrkKc < r1) fetch(kk + kSyrkKc);                          // in flight during the MFMAs
+    if (!(ti == tj && wj < wi)) {
+#pragma unroll
+      for (int s = 0; s < kSyrkKc / 4; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[(4 * s + lk) * kSyrkTile + 16 * wi + lr],
+                                                   pB[(4 * s + lk) * kSyrkTile + 16 * wj + lr], acc, 0, 0, 0);
+    }
+  }
+  if (ti == tj && wj < wi) return;
+  double* out = part + (size_t)ks * M * M;
+  const int col = j0 + 16 * wj + lr;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = i0 + 16 * wi + lk + 4 * v;
+    if (row < M && col < M) out[(size_t)row * M + col] = acc[v];
+  }
+}
+
+// S_band(i, j >= i) -= sum over the split slabs of part[.][6 i .. , 6 j ..];  one thread per entry of S
+__global__ __launch_bounds__(kBlock) void k_dense_apply(int nco, int hb1, int M, int nsplit, const double* __restrict__ part,
+                                                        double* __restrict__ S) {
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long nS = (long long)nco * hb1 * 36;
+  if (tid >= nS) return;
+  const int e = (int)(tid % 36);
+  const long long blk = tid / 36;
+  const int d = (int)(blk % hb1), i = (int)(blk / hb1), j = i + d;
+  if (j >= nco) return;
+  int ea = e / 6, ec = e % 6;
+  if (d == 0 && ea > ec) { const int t = ea; ea = ec; ec = t; }            // only the upper triangle of the product is formed
+  const size_t off = ((size_t)6 * i + ea) * M + 6 * (size_t)j + ec;
+  double sum = 0.0;
+  for (int q = 0; q < nsplit; ++q) sum += part[(size_t)q * M * M + off];
+  S[tid] -= sum;
+}
+
+// b -= Ud^T y: lanes along the columns of Ud (whole cache lines), 32 rows per workgroup, one atomic per thread
 constexpr int kDenseRhsRows = 32;
-__global__ __launch_bounds__(kBlock) void k_dense_rhs(int M, int R, const double* __restrict__ Td, const double* __restrict__ g,
+__global__ __launch_bounds__(kBlock) void k_dense_rhs(int M, int R, const double* __restrict__ Ud, const double* __restrict__ y,
                                                       double* __restrict__ b) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
   const int r0 = blockIdx.y * kDenseRhsRows;
   if (c >= M) return;
   double acc = 0.0;
 #pragma unroll 8
-  for (int r = r0; r < min(R, r0 + kDenseRhsRows); ++r) acc += Td[(size_t)r * M + c] * g[r];
+  for (int r = r0; r < min(R, r0 + kDenseRhsRows); ++r) acc += Ud[(size_t)r * M + c] * y[r];
   atomic_add_f64(b + c, -acc);
-}
-
-// S_band(i, j >= i) -= Sd[6 i .. , 6 j ..],  b -= bc;  one thread per entry of [S | b]
-__global__ __launch_bounds__(kBlock) void k_dense_apply(int nco, int hb1, const double* __restrict__ Sd, int M,
-                                                        const double* __restrict__ bc, double* __restrict__ S,
-                                                        double* __restrict__ b) {
-  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
-  const long long nS = (long long)nco * hb1 * 36;
-  if (tid < nS) {
-    const int e = (int)(tid % 36);
-    const long long blk = tid / 36;
-    const int d = (int)(blk % hb1), i = (int)(blk / hb1), j = i + d;
-    if (j < nco) S[tid] -= Sd[((size_t)6 * i + e / 6) * M + 6 * (size_t)j + e % 6];
-  } else if (bc && tid < nS + (long long)nco * 6) {
-    b[tid - nS] -= bc[tid - nS];
-  }
 }
 
 // --------------------------------------------------------------------------

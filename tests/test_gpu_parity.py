@@ -551,6 +551,28 @@ def test_wide_band_takes_dense_path(be):
     close(-dC, g['update_l10_motion'], 1e-7)
 
 
+def test_dense_visibility_reduction_equals_pair_kernels(be):
+    """ba_set_dense_visibility: the reduction as one symmetric matrix product over all points
+    (k_dense_stage / k_dense_syrk / k_dense_apply / k_dense_rhs, factorised point inverses) against the
+    per-pair kernels on the same linearisation, and against the oracle."""
+    g = load_golden('scene_oleg_40x100')
+    a = scene(g)
+    load_problem(be, *a, g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
+    assert be._dense                                         # the host picked the dense form for this scene
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    Sd, bd = be.get_reduced()
+    be._check(be._lib.ba_set_dense_visibility(be._h, 0))
+    be.schur(0, 10., 1e-5)
+    Sp, bp = be.get_reduced()
+    be._check(be._lib.ba_set_dense_visibility(be._h, 1))
+    close(Sd, Sp, 1e-11)
+    close(bd, bp, 1e-11)
+    mu, su, parts = O.compute_update(sensor_of(g), *a, g['l10_cam_opt_pos'], g['l10_pt_opt'], damping=10., return_parts=True)
+    close(Sd, parts['S'], TIGHT)
+    close(bd, parts['b'], TIGHT)
+
+
 def _dense_reference(be, mask=None):
     S, b = be.get_reduced()
     n = be.nco * 6
