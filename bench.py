@@ -265,6 +265,7 @@ def main():
         B = algorithmic_bytes(dom, be.nc, nco, be.nt, nobs_local, be.nt, be.half_bandwidth)
         achieved = B / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dom)
+        copy_gbs = be.measure_copy_bandwidth()
         out = {
             'metric': 'LM-iter throughput (obs/sec) + final reproj RMSE, 1k-cam/100k-pt/1M-obs scene',
             'value': value, 'unit': 'obs/s', 'n_gpus': ngpus, 'steps': args.steps, 'warmup': args.warmup,
@@ -277,6 +278,7 @@ def main():
                        'cameras': nc, 'points': nt, 'observations': nobs_total, 'parallelism': 'points sharded x%d' % ngpus},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
                          'algorithmic_bytes_per_launch': B,
                          'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
                          'note': 'HIP events on the launch stream during the timed steps, every 4th step; back-to-back launches of one kernel (the cyclic-reduction levels) share one event pair, avg = elapsed / launches'},

@@ -223,6 +223,8 @@ int ba_set_timing_mask(ba_handle* h, uint64_t kernel_id_mask);
 int ba_set_timing_stride(ba_handle* h, int32_t stride);
 /* accumulated HIP-event time (ms) and launch count per kernel id since the last reset */
 int ba_get_timings(ba_handle* h, double* ms /*[BA_K_COUNT]*/, int64_t* launches /*[BA_K_COUNT]*/, int reset);
+/* achievable HBM rate of this device: a streaming copy of `bytes` bytes, `repeats` times (read + write counted) */
+int ba_measure_copy_bandwidth(ba_handle* h, int64_t bytes, int32_t repeats, double* gbytes_per_s);
 const char* ba_kernel_name(int kernel_id);
 const char* ba_version(void);
 

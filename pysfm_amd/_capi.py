@@ -61,6 +61,7 @@ PROTOTYPES = {
     'ba_lm_trial': (C.c_int, [_h, C.c_double, C.c_double, _bp, _dp, C.POINTER(C.c_int32)]),
     'ba_bind_trial_result': (C.c_int, [_h, C.c_void_p]),
     'ba_set_dense_visibility': (C.c_int, [_h, C.c_int32]),
+    'ba_measure_copy_bandwidth': (C.c_int, [_h, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     'ba_set_min_half_bandwidth': (C.c_int, [_h, C.c_int32]),
     'ba_lm_trial_begin': (C.c_int, [_h, C.c_double, C.c_double]),
     'ba_lm_trial_end': (C.c_int, [_h, _bp, C.POINTER(C.c_int32)]),

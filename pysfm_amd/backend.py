@@ -367,6 +367,12 @@ class HipBackend(object):
         return X
 
     # ---------------------------------------------------------------- instrumentation
+    def measure_copy_bandwidth(self, nbytes=1 << 30, repeats=10):
+        """GB/s (read + write) of a streaming copy on this device: the achievable HBM rate."""
+        out = C.c_double()
+        self._check(self._lib.ba_measure_copy_bandwidth(self._h, int(nbytes), int(repeats), C.byref(out)))
+        return out.value
+
     def enable_timing(self, on=True, only=None, stride=1):
         """HIP-event timing of the kernels; `only` = iterable of kernel names to bracket
         (each event pair costs a few microseconds of stream time)."""

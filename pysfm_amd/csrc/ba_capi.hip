@@ -418,6 +418,13 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
 
 }  // namespace
 
+// The achievable HBM rate of this box (SURVEY 8d asks for the roofline fraction against it as well as
+// against the 8 TB/s of the data sheet): a plain streaming copy, 16 bytes per lane per iteration.
+__global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 extern "C" {
 
 const char* ba_version(void) { return "pysfm_ba 0.1 (gfx950)"; }
@@ -1539,6 +1546,30 @@ int ba_set_timing_stride(ba_handle* h, int32_t stride) {
   REQUIRE(h, stride >= 1, BA_ERR_INVALID_ARG, "ba_set_timing_stride: stride must be >= 1");
   h->timing_stride = stride;
   for (auto& c : h->timing_seen) c = 0;
+  return BA_OK;
+}
+
+int ba_measure_copy_bandwidth(ba_handle* h, int64_t bytes, int32_t repeats, double* gbytes_per_s) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, bytes >= 4096 && repeats >= 1 && gbytes_per_s, BA_ERR_INVALID_ARG, "ba_measure_copy_bandwidth: bad argument");
+  HIPCHECK(h, hipSetDevice(h->device));
+  const size_t n = (size_t)bytes / sizeof(double2);
+  DevBuf<double2> src, dst;
+  HIPCHECK(h, src.resize(n)); HIPCHECK(h, dst.resize(n));
+  HIPCHECK(h, hipMemsetAsync(src.p, 0, n * sizeof(double2), h->stream));
+  hipEvent_t a, b;
+  HIPCHECK(h, hipEventCreate(&a)); HIPCHECK(h, hipEventCreate(&b));
+  const int grid = 256 * 32;
+  hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, h->stream, src.p, dst.p, n);     // warm-up
+  HIPCHECK(h, hipEventRecord(a, h->stream));
+  for (int r = 0; r < repeats; ++r) hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, h->stream, src.p, dst.p, n);
+  HIPCHECK(h, hipEventRecord(b, h->stream));
+  HIPCHECK(h, hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPCHECK(h, hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  src.release(); dst.release();
+  *gbytes_per_s = 2.0 * (double)(n * sizeof(double2)) * repeats / (ms * 1e-3) / 1e9;           // read + write
   return BA_OK;
 }
 
