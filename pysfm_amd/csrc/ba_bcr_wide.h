@@ -5,12 +5,12 @@
 //   k_bcrw_factor    one workgroup per node:  D_i = L L^T in LDS (the blocked, look-ahead Cholesky of
 //                    ba_bcr.h without right-hand sides), L -> global (1 / L_kk on its diagonal)
 //   k_bcrw_solve_mfma  one wavefront per (node, 16 right-hand sides):  [P | Q | G^-1 | g] = L^-1 [T_il | T_ir | I | f]
-//   k_bcrw_products  one workgroup per (node, 32 x 32 outputs):  D_l -= P^T P,  D_r -= Q^T Q,
+//   k_bcrw_products  one workgroup per (node, 64 x 64 outputs, MFMA):  D_l -= P^T P,  D_r -= Q^T Q,
 //                    T[l,r] = -P^T Q,  f_l -= P^T g,  f_r -= Q^T g
 //   k_bcrw_backsolve x_i = G^-T (g - P x_l - Q x_r)
 //
 // The single-workgroup band Cholesky (k_band_solve) these replace walks 1000 cameras in 7..20 ms at
-// these widths; the levels here are ~90 us each at hb = 21 (factor 36, solve 21, products 22, backsolve 11).
+// these widths; the levels here are ~80 us each at hb = 21 (factor 36, solve 24, products 10, backsolve 11).
 // (The first form of the solve, one lane per right-hand side with L through scalar loads, took 442 us per level.)
 #pragma once
 
@@ -20,7 +20,6 @@ namespace ba {
 
 constexpr int kBcrwMinHB = kBcrMaxHB + 1;
 constexpr int kBcrwMaxHB = 21;                 // B = 126: one B x (B+1) fp64 matrix = 128 KB of the 160 KB LDS
-constexpr int kBcrwTile = 32;                 // output tile edge of k_bcrw_products
 
 __host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16) * sizeof(double); }
 __host__ __device__ inline size_t bcrw_solve_lds_bytes(int B) { return ((size_t)B * (B + 1) + (size_t)((B + 11) / 12) * 144 + 64) * sizeof(double); }
@@ -251,15 +250,18 @@ __global__ __launch_bounds__(1024) void k_bcrw_solve_mfma(int N, int s, const do
   }
 }
 
-// ---- products: 32 x 32 output tile per workgroup, operand panels [B][32] staged in LDS.
-// blockIdx.y: 0 .. ntile-1 tiles of P^T P (lower), then Q^T Q (lower), then P^T Q (all), last: the two vectors.
-__global__ __launch_bounds__(kBcrwTile * kBcrwTile) void k_bcrw_products(int N, int B, int s, double* __restrict__ Dm,
-                                                                        double* __restrict__ Um, double* __restrict__ fm,
-                                                                        const double* __restrict__ Pm,
-                                                                        const double* __restrict__ Qm,
-                                                                        const int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];     // A[B][32] | Bp[B][32]
-  constexpr int T = kBcrwTile;
+// ---- products on the matrix cores: one workgroup (16 wavefronts) per (node, 64 x 64 output tile), the two
+// operand panels [32 rows][64 columns] staged through LDS, next panel in flight during the MFMAs.
+// blockIdx.y: tiles of P^T P (lower), then Q^T Q (lower), then P^T Q (all), last: the two vectors.
+constexpr int kBcrwPTile = 64, kBcrwPKc = 32;
+
+__global__ __launch_bounds__(1024) void k_bcrw_products(int N, int B, int s, double* __restrict__ Dm,
+                                                        double* __restrict__ Um, double* __restrict__ fm,
+                                                        const double* __restrict__ Pm, const double* __restrict__ Qm,
+                                                        const int* __restrict__ info) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  constexpr int T = kBcrwPTile, KC = kBcrwPKc;
+  __shared__ double pA[KC * T], pB[KC * T];
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N || *info != 0) return;
   const int l = i - s, r = i + s;
@@ -267,13 +269,14 @@ __global__ __launch_bounds__(kBcrwTile * kBcrwTile) void k_bcrw_products(int N, 
   const size_t BB = (size_t)B * B;
   const int nt = (B + T - 1) / T, nsym = nt * (nt + 1) / 2;
   const int tid = threadIdx.x;
-  int task = blockIdx.y;
+  const int task = blockIdx.y;
   if (task == 2 * nsym + nt * nt) {                          // f_l -= P^T g, f_r -= Q^T g
-    for (int c = tid; c < 2 * B; c += T * T) {
+    for (int c = tid; c < 2 * B; c += 1024) {
       const bool left = c < B;
       if ((left && !haveL) || (!left && !haveR)) continue;
       const double* A = (left ? Pm : Qm) + (size_t)i * BB + (left ? c : c - B);
       double acc = 0.0;
+#pragma unroll 8
       for (int k = 0; k < B; ++k) acc += A[(size_t)k * B] * fm[(size_t)i * B + k];
       atomic_add_f64(fm + (size_t)(left ? l : r) * B + (left ? c : c - B), -acc);
     }
@@ -288,29 +291,49 @@ __global__ __launch_bounds__(kBcrwTile * kBcrwTile) void k_bcrw_products(int N, 
     ti = (task - 2 * nsym) / nt; tj = (task - 2 * nsym) % nt;
   }
   if ((which == 0 && !haveL) || (which == 1 && !haveR) || (which == 2 && !(haveL && haveR))) return;
-  const double* Asrc = (which == 1 ? Qm : Pm) + (size_t)i * BB;
+  const double* Asrc = (which == 1 ? Qm : Pm) + (size_t)i * BB;      // C = A^T B, A and B stored [k][column]
   const double* Bsrc = (which == 0 ? Pm : Qm) + (size_t)i * BB;
-  double* A = sm;
-  double* Bp = sm + (size_t)B * T;
-  for (int e = tid; e < B * T; e += T * T) {
-    const int k = e / T, c = e - k * T;
-    A[e] = T * ti + c < B ? Asrc[(size_t)k * B + T * ti + c] : 0.0;
-    Bp[e] = T * tj + c < B ? Bsrc[(size_t)k * B + T * tj + c] : 0.0;
+  const int i0 = T * ti, j0 = T * tj;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  const int wi = wave >> 2, wj = wave & 3;
+  const int lrow = tid >> 6, lcol = tid & 63;                 // loader: rows lrow and lrow + 16 of the panel
+  double va[2], vb[2];
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kk + lrow + 16 * u;
+      va[u] = (k < B && i0 + lcol < B) ? Asrc[(size_t)k * B + i0 + lcol] : 0.0;
+      vb[u] = (k < B && j0 + lcol < B) ? Bsrc[(size_t)k * B + j0 + lcol] : 0.0;
+    }
+  };
+  mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
+  const bool skip = which != 2 && ti == tj && wj > wi;       // strictly upper sub-tile of a symmetric diagonal tile
+  fetch(0);
+  for (int kk = 0; kk < B; kk += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pA[(lrow + 16 * u) * T + lcol] = va[u];
+      pB[(lrow + 16 * u) * T + lcol] = vb[u];
+    }
+    __syncthreads();
+    if (kk + KC < B) fetch(kk + KC);
+    if (!skip) {
+#pragma unroll
+      for (int q = 0; q < KC / 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[(4 * q + lk) * T + 16 * wi + lr], pB[(4 * q + lk) * T + 16 * wj + lr], acc, 0, 0,
+                                                   0);
+    }
   }
-  __syncthreads();
-  const int ty = tid / T, tx = tid - ty * T;
-  double a0 = 0.0, a1 = 0.0;
-  int k = 0;
-  for (; k + 1 < B; k += 2) {
-    a0 += A[k * T + ty] * Bp[k * T + tx];
-    a1 += A[(k + 1) * T + ty] * Bp[(k + 1) * T + tx];
+  if (skip) return;
+  const int col = j0 + 16 * wj + lr;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = i0 + 16 * wi + lk + 4 * v;
+    if (row >= B || col >= B) continue;
+    if (which == 2) Um[(size_t)l * BB + (size_t)row * B + col] = -acc[v];                    // new T[l,r]
+    else if (col <= row) atomic_add_f64(Dm + (size_t)(which == 0 ? l : r) * BB + (size_t)row * B + col, -acc[v]);
   }
-  if (k < B) a0 += A[k * T + ty] * Bp[k * T + tx];
-  const double acc = a0 + a1;
-  const int row = T * ti + ty, col = T * tj + tx;
-  if (row >= B || col >= B) return;
-  if (which == 2) Um[(size_t)l * BB + (size_t)row * B + col] = -acc;                    // new T[l,r]
-  else if (col <= row) atomic_add_f64(Dm + (size_t)(which == 0 ? l : r) * BB + (size_t)row * B + col, -acc);
 }
 
 // ---- back-substitution level: x_i = G^-T (g - P x_l - Q x_r), matrices read straight from global memory

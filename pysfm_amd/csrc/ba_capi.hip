@@ -351,11 +351,6 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->bcrF.resize((size_t)N * B));
   HIPCHECK(h, h->bcrLv.resize((size_t)N * ((B + 11) / 12) * 144));
   HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcrw_products, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
     hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
@@ -363,15 +358,14 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   }
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
-  const int nt = (B + kBcrwTile - 1) / kBcrwTile, ntask = nt * (nt + 1) + nt * nt + 1;
+  const int nt = (B + kBcrwPTile - 1) / kBcrwPTile, ntask = nt * (nt + 1) + nt * nt + 1;
   {
     ScopedTimer tm(h, BA_K_BCR_ELIMINATE, 3 * (int)strides.size());
     for (int s : strides) {
       const int cnt = (N / s + 1) / 2;
       HIPCHECK(h, launch_bcrw_factor(hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrL.p, h->bcrLv.p, h->bcrU.p, h->bcrF.p, h->bcrP.p,
                                      h->bcrQ.p, h->bcrG.p, h->flags.p + 1));
-      hipLaunchKernelGGL(k_bcrw_products, dim3(cnt, ntask), dim3(kBcrwTile * kBcrwTile), (size_t)2 * B * kBcrwTile * sizeof(double),
-                         h->stream, N, B, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->flags.p + 1);
+      hipLaunchKernelGGL(k_bcrw_products, dim3(cnt, ntask), dim3(1024), 0, h->stream, N, B, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->flags.p + 1);
     }
   }
   ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)strides.size());
