@@ -257,6 +257,7 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = nobs_total * args.steps / dt
 
+    out = None
     if rank == 0:
         # dominant kernel of OUR kernels, by HIP-event time on the launch stream
         ours = {k: v for k, v in tm.items() if v['launches'] > 0}
@@ -300,11 +301,18 @@ def main():
         out.update(lm)
         if ngpus == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(300, 30000)
-        print(json.dumps(out))
     if comm is not None:
+        import ctypes
         import torch.distributed as dist
+        ctypes.CDLL(None).fflush(None)          # (every rank's buffered C output is out before rank 0 prints)
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes a version banner to the C stdout buffer, which is flushed at exit, i.e. AFTER anything Python
+    # prints: flush it now so that the JSON line is the last line of stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def comm_max(comm, x):
