@@ -593,17 +593,31 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve(int N, int B,
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;
   const size_t BB = (size_t)B * B;
-  for (int e = tid; e < B * B; e += kBcrElimThreads) {
-    const int rr = e / B, cc = e - rr * B;
-    const double vp = haveL ? Pm[(size_t)i * BB + e] : 0.0;
-    const double vq = haveR ? Qm[(size_t)i * BB + e] : 0.0;
-    const double vg = Gi[(size_t)i * BB + e];
-    MP[rr * ld + cc] = vp; MQ[rr * ld + cc] = vq; MG[rr * ld + cc] = vg;
-  }
-  for (int e = tid; e < B; e += kBcrElimThreads) {
-    w[e] = fm[(size_t)i * B + e];
-    xl[e] = haveL ? x[(size_t)l * B + e] : 0.0;
-    xr[e] = haveR ? x[(size_t)r * B + e] : 0.0;
+  // all loads first (up to 5 entries of each matrix per thread: B <= 66), then the LDS stores: one memory
+  // round trip for the whole staging instead of one per loop iteration
+  {
+    constexpr int U = (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
+    double vp[U], vq[U], vg[U];
+    const double wv = tid < B ? fm[(size_t)i * B + tid] : 0.0;
+    const double xlv = (tid < B && haveL) ? x[(size_t)l * B + tid] : 0.0;
+    const double xrv = (tid < B && haveR) ? x[(size_t)r * B + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + kBcrElimThreads * u;
+      const bool in = e < B * B;
+      vp[u] = (in && haveL) ? Pm[(size_t)i * BB + e] : 0.0;
+      vq[u] = (in && haveR) ? Qm[(size_t)i * BB + e] : 0.0;
+      vg[u] = in ? Gi[(size_t)i * BB + e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + kBcrElimThreads * u;
+      if (e < B * B) {
+        const int rr = e / B, cc = e - rr * B;
+        MP[rr * ld + cc] = vp[u]; MQ[rr * ld + cc] = vq[u]; MG[rr * ld + cc] = vg[u];
+      }
+    }
+    if (tid < B) { w[tid] = wv; xl[tid] = xlv; xr[tid] = xrv; }
   }
   __syncthreads();
   for (int task = tid; task < 4 * B; task += kBcrElimThreads) {      // w -= P xl + Q xr
