@@ -562,9 +562,13 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     for (int64_t n = 0; n < nobs; ++n) perm[(size_t)cursor[obs_cam[n]]++] = (int)n;
   }
   std::vector<CamUnit> cam_units;
+  // one wavefront per unit: few cameras with long observation lists (dense visibility) would leave the chip
+  // empty at kCamChunk observations per unit, so shrink the chunk until there are about 500 units (measured: 100 000 observations of 100 cameras: 28 us at 2048 per unit, 14 at 256, 19 at 64); many
+  // cameras with ~1000 observations each keep one unit per camera (one atomic result per camera)
+  const int cam_chunk = (int)std::min<int64_t>(kCamChunk, std::max<int64_t>(64, (nobs / 512 + 63) / 64 * 64));
   for (int i = 0; i < nc; ++i)
-    for (int s = cam_off[i]; s < cam_off[(size_t)i + 1]; s += kCamChunk)
-      cam_units.push_back({i, s, std::min(s + kCamChunk, cam_off[(size_t)i + 1])});
+    for (int s = cam_off[i]; s < cam_off[(size_t)i + 1]; s += cam_chunk)
+      cam_units.push_back({i, s, std::min(s + cam_chunk, cam_off[(size_t)i + 1])});
   // block half-bandwidth of the reduced system: widest spread of optimised-camera
   // positions within one track
   int hb = 0;

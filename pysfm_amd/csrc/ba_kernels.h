@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
 // camera's observation list `perm` (observation ids sorted by camera), accumulates the
 // 21 + 6 sums in registers, reduces across the 64 lanes and adds ONE result per unit.
 // --------------------------------------------------------------------------
-constexpr int kCamChunk = 2048;
+constexpr int kCamChunk = 2048;    // at most; the host shrinks it for scenes with few cameras (ba_set_problem)
 struct CamUnit { int cam; int begin; int end; };
 
 __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevProblem P, const double* __restrict__ cams,
