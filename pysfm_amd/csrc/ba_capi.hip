@@ -82,6 +82,8 @@ struct ba_handle {
   int nmchunks = 0;
   bool groups_ascending = false;
   int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
+  int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
+  bool point_groups = false;            // every point sits in a group and groups are worth it: group-packed k_linearize / k_backsub
   int group_maxL = 0;                   // longest track (k_schur_groups_mfma takes <= kGmMaxL)
   DevBuf<int> cam_perm;
   DevBuf<CamUnit> cam_units;
@@ -685,6 +687,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
   h->groups_ascending = groups_ascending;
+  h->ngroups = (int)groups.size();
+  {
+    long long covered = 0;
+    for (const SchurGroup& g : groups) covered += g.pt_end - g.pt_begin;
+    h->point_groups = group_rounds > 0 && covered == nt;        // (points without observations are in no group)
+  }
   h->group_rounds = group_rounds;
   h->group_maxL = maxL;
   h->ncam_units = (int)cam_units.size();
@@ -916,9 +924,15 @@ int launch_point_blocks(ba_handle* h, int p, double* Wd) {
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_LINEARIZE);
     const long long threads = (long long)h->nt << h->glog;
-    hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
-                       h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd,
-                       0.0, 0.0, (double*)nullptr, (int*)nullptr, (int*)nullptr);
+    if (!Wd && h->point_groups && !getenv("BA_POINT_KERNELS_V1")) {
+      const int per_block = kBlock / kWave;
+      hipLaunchKernelGGL(k_linearize_groups, dim3((h->ngroups + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
+                         dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p);
+    } else {
+      hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
+                         h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd,
+                         0.0, 0.0, (double*)nullptr, (int*)nullptr, (int*)nullptr);
+    }
   }
   h->point_blocks_valid = true;
   h->cam_blocks_valid = false;          // k_linearize cleared HCC / bC
@@ -1382,9 +1396,16 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_BACKSUB);
     const long long threads = (long long)h->nt << h->glog;
-    hipLaunchKernelGGL(k_backsub, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
-                       h->X[p].p, h->glog, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p, -1.0,
-                       fuse_update ? h->cams[1 - p].p : (double*)nullptr, fuse_update ? h->X[1 - p].p : (double*)nullptr);
+    if (h->point_groups && !getenv("BA_POINT_KERNELS_V1")) {
+      const int per_block = kBlock / kWave;
+      hipLaunchKernelGGL(k_backsub_groups, dim3((h->ngroups + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
+                         dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p,
+                         -1.0, fuse_update ? h->cams[1 - p].p : (double*)nullptr, fuse_update ? h->X[1 - p].p : (double*)nullptr);
+    } else {
+      hipLaunchKernelGGL(k_backsub, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->glog, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p, -1.0,
+                         fuse_update ? h->cams[1 - p].p : (double*)nullptr, fuse_update ? h->X[1 - p].p : (double*)nullptr);
+    }
   }
   HIPCHECK(h, hipGetLastError());
   if (dP && h->nt) HIPCHECK(h, hipMemcpyAsync(dP, h->dP.p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

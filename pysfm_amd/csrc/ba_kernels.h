@@ -1621,6 +1621,169 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
 }
 
 // --------------------------------------------------------------------------
+// k_linearize / k_backsub for scenes whose points come in runs with identical camera lists (the groups
+// of k_schur_groups: <= kGroupMaxPts points, L <= kGroupMaxL cameras).  The lanes-per-point kernels
+// above give a point a power-of-two lane group (16 lanes for 10 observations: 10 of 16 busy); here
+// one wavefront owns a group and lane = (point slot, observation): 64 / L points at a time, 60 of 64
+// lanes busy at L = 10, the camera of a lane loaded once per group.  The per-point sums (9 values in
+// k_linearize, 3 in k_backsub) go through LDS: every lane writes its terms, one lane per (point,
+// value) adds the point's L entries in index order - deterministic, like the shuffle tree it replaces.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const double* __restrict__ cams,
+                                                             const double* __restrict__ X,
+                                                             const SchurGroup* __restrict__ groups, int ngroups,
+                                                             double* __restrict__ HCC, double* __restrict__ bC,
+                                                             double* __restrict__ HPP, double* __restrict__ bP) {
+  __shared__ double sx[kBlock / kWave][9][64];
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (HCC) {                                           // as k_linearize: the camera-block kernels accumulate with atomics
+    const long long nthreads = (long long)gridDim.x * kBlock;
+    for (long long i = tid; i < (long long)P.nc * 36; i += nthreads) HCC[i] = 0.0;
+    for (long long i = tid; i < (long long)P.nc * 6; i += nthreads) bC[i] = 0.0;
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (kBlock / kWave) + wv;
+  if (g >= ngroups) return;                            // whole wavefront
+  const SchurGroup gr = groups[g];
+  const int L = gr.L, NP = 64 / L;
+  const int slot = lane / L, oi = lane - slot * L;
+  const bool stager = lane < NP * L;
+  const int n0 = P.pt_off[gr.pt_begin] + oi;
+  double cm[12];
+  load_cam(cams, P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]], cm);
+  double (*mx)[64] = sx[wv];
+  for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+    const int k = kb + slot;
+    const bool live = stager && k < gr.pt_end;
+    double loc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) loc[c] = 0.0;
+    if (live) {
+      const double2 z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+      const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
+      double e[2], r[2], Jc[12], Jp[6];
+      obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+      loc[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3]; loc[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4]; loc[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+      loc[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4]; loc[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5]; loc[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+      loc[6] = Jp[0] * r[0] + Jp[3] * r[1]; loc[7] = Jp[1] * r[0] + Jp[4] * r[1]; loc[8] = Jp[2] * r[0] + Jp[5] * r[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) mx[c][lane] = loc[c];
+    lds_wave_sync();
+    if (live) {
+      for (int c = oi; c < 9; c += L) {
+        double v[kGroupMaxL];
+#pragma unroll
+        for (int j = 0; j < kGroupMaxL; ++j) v[j] = j < L ? mx[c][slot * L + j] : 0.0;       // one LDS round trip
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < kGroupMaxL; ++j) sum += v[j];
+        if (c < 6) HPP[6 * (size_t)k + c] = sum; else bP[3 * (size_t)k + c - 6] = sum;
+      }
+    }
+    lds_wave_sync();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_backsub_groups(DevProblem P, const double* __restrict__ cams,
+                                                           const double* __restrict__ X,
+                                                           const SchurGroup* __restrict__ groups, int ngroups,
+                                                           const double* __restrict__ dC,
+                                                           const double* __restrict__ HPPinv,
+                                                           const double* __restrict__ bP, double* __restrict__ dP,
+                                                           double sign, double* __restrict__ cams_dst,
+                                                           double* __restrict__ X_dst) {
+  __shared__ double sx[kBlock / kWave][3][64], sw[kBlock / kWave][3][64];
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (cams_dst) {                                      // fused update_motion, as in k_backsub
+    const long long nthreads = (long long)gridDim.x * kBlock;
+    for (long long i = tid; i < P.nc; i += nthreads) {
+      double cm[12], out[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) cm[q] = cams[(size_t)i * 12 + q];
+      const int pos = P.cam_opt_pos[i];
+      if (pos >= 0) {
+        double d[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d[q] = sign * dC[(size_t)pos * 6 + q];
+        camera_perturb(cm, d, out);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) out[q] = cm[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) cams_dst[(size_t)i * 12 + q] = out[q];
+    }
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (kBlock / kWave) + wv;
+  if (g >= ngroups) return;
+  const SchurGroup gr = groups[g];
+  const int L = gr.L, NP = 64 / L;
+  const int slot = lane / L, oi = lane - slot * L;
+  const bool stager = lane < NP * L;
+  const int n0 = P.pt_off[gr.pt_begin] + oi;
+  const int c = P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]];
+  const int pos = stager ? P.cam_opt_pos[c] : -1;
+  double cm[12], d[6];
+  load_cam(cams, c, cm);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) d[a] = pos >= 0 ? dC[(size_t)pos * 6 + a] : 0.0;
+  double (*mx)[64] = sx[wv];
+  double (*mw)[64] = sw[wv];
+  for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+    const int k = kb + slot;
+    const bool live = stager && k < gr.pt_end;
+    double x[3] = {0, 0, 0}, loc[3] = {0, 0, 0};
+    if (live) {
+      x[0] = X[3 * (size_t)k]; x[1] = X[3 * (size_t)k + 1]; x[2] = X[3 * (size_t)k + 2];
+      if (pos >= 0) {                                  // frozen cameras contribute nothing (bundle_adjuster.py:316-331)
+        const double2 z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+        double e[2], r[2], Jc[12], Jp[6];
+        obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { v0 += Jc[a] * d[a]; v1 += Jc[6 + a] * d[a]; }
+        loc[0] = Jp[0] * v0 + Jp[3] * v1;
+        loc[1] = Jp[1] * v0 + Jp[4] * v1;
+        loc[2] = Jp[2] * v0 + Jp[5] * v1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) mx[q][lane] = loc[q];
+    lds_wave_sync();
+    if (live) {                                        // lane q of a point adds component q of its L terms
+      for (int q = oi; q < 3; q += L) {
+        double v[kGroupMaxL];
+#pragma unroll
+        for (int j = 0; j < kGroupMaxL; ++j) v[j] = j < L ? mx[q][slot * L + j] : 0.0;
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < kGroupMaxL; ++j) sum += v[j];
+        mw[q][slot] = bP[3 * (size_t)k + q] - sum;
+      }
+    }
+    lds_wave_sync();
+    if (live && oi == 0) {
+      double A[6], v[3], out[3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) A[i] = HPPinv[6 * (size_t)k + i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) v[i] = mw[i][slot];
+      sym3_apply(A, v, out);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dP[3 * (size_t)k + i] = out[i];
+      if (X_dst) {                                     // fused update_structure (bundle_adjuster.py:340-343)
+        const bool opt = P.pt_opt[k] != 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) X_dst[3 * (size_t)k + i] = opt ? x[i] + sign * out[i] : x[i];
+      }
+    }
+    lds_wave_sync();
+  }
+}
+
+// --------------------------------------------------------------------------
 // Bundle.triangulate_all (bundle.py:313-321; triangulate.algebraic_lsq, triangulate.py:6-18):
 // per point the linear least-squares problem with two rows per observation,
 //   A[2i]   = (K[0] - z0 K[2]) R_i ,   b[2i]   = (z0 K[2] - K[0]) . t_i
