@@ -105,6 +105,7 @@ struct ba_handle {
   int sing_epoch = 0;       // which of the two counters the latest ba_schur used
   HostResult* host_result = nullptr;   // pinned, device-visible: cost + status words of a trial
   int cost_blocks = 0;      // partials the last k_cost launch wrote
+  bool cost_fused = false;  // the last ba_backsubstitute evaluated the trial cost as well (k_backsub_groups)
   int* sing_counter() { return flags.p + 40 + (sing_epoch & 1); }
   double host_cost() const {           // second, deterministic stage of the cost reduction (after a stream sync)
     double s = 0.0;
@@ -1396,11 +1397,18 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_BACKSUB);
     const long long threads = (long long)h->nt << h->glog;
+    h->cost_fused = false;
     if (h->point_groups && !getenv("BA_POINT_KERNELS_V1")) {
+      // inside ba_lm_trial the cost of the trial set rides along as well (k_cost's work)
       const int per_block = kBlock / kWave;
-      hipLaunchKernelGGL(k_backsub_groups, dim3((h->ngroups + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
-                         dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p,
-                         -1.0, fuse_update ? h->cams[1 - p].p : (double*)nullptr, fuse_update ? h->X[1 - p].p : (double*)nullptr);
+      const int nblk = std::min(kCostBlocks, (h->ngroups + per_block - 1) / per_block);
+      const bool fuse_cost = fuse_update && !getenv("BA_NO_FUSE_COST");
+      hipLaunchKernelGGL(k_backsub_groups, dim3(nblk), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
+                         h->groups.p, h->ngroups, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p, -1.0,
+                         fuse_update ? h->cams[1 - p].p : (double*)nullptr, fuse_update ? h->X[1 - p].p : (double*)nullptr,
+                         (const int*)h->sing_counter(), (const int*)(h->flags.p + 1),
+                         fuse_cost ? h->host_result : (HostResult*)nullptr, fuse_cost ? h->trial_result_dev : (double*)nullptr);
+      if (fuse_cost) { h->cost_fused = true; h->cost_blocks = nblk; }
     } else {
       hipLaunchKernelGGL(k_backsub, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
                          h->X[p].p, h->glog, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p, -1.0,
@@ -1495,7 +1503,7 @@ int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_in
     if (h->nt > 0) h->have_params[h->phys(BA_PARAMS_TRIAL)] = true;      // k_backsub wrote the trial set
     else rc = ba_apply_update(h, BA_PARAMS_CUR, BA_PARAMS_TRIAL, nullptr, nullptr);
   }
-  if (rc == BA_OK) rc = ba_cost(h, BA_PARAMS_TRIAL, &unused);
+  if (rc == BA_OK && !(h->cost_fused && h->nt > 0)) rc = ba_cost(h, BA_PARAMS_TRIAL, &unused);
   h->defer = false;
   return rc;
 }

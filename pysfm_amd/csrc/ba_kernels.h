@@ -1685,15 +1685,24 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_backsub_groups(DevProblem P, const double* __restrict__ cams,
+// With `host` given (ba_lm_trial: the trial parameter set is written here as well) the kernel also
+// evaluates compute_cost of the TRIAL set (bundle_adjuster.py:165-171) - k_cost's work: the lanes of a
+// point hold its observations and the old camera; the updated camera R exp(sign dC), t + sign dt is
+// formed once per group per lane, the updated point comes from the point's first lane through LDS.
+// Partials and status words go where k_cost puts them (one partial per workgroup, <= kCostBlocks).
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_backsub_groups(DevProblem P, const double* __restrict__ cams,
                                                            const double* __restrict__ X,
                                                            const SchurGroup* __restrict__ groups, int ngroups,
                                                            const double* __restrict__ dC,
                                                            const double* __restrict__ HPPinv,
                                                            const double* __restrict__ bP, double* __restrict__ dP,
                                                            double sign, double* __restrict__ cams_dst,
-                                                           double* __restrict__ X_dst) {
-  __shared__ double sx[kBlock / kWave][3][64], sw[kBlock / kWave][3][64];
+                                                           double* __restrict__ X_dst,
+                                                           const int* __restrict__ singular_points,
+                                                           const int* __restrict__ solve_info, HostResult* __restrict__ host,
+                                                           double* __restrict__ dev_result) {
+  __shared__ double sx[kBlock / kWave][3][64], sw[kBlock / kWave][3][64], wsum[kBlock / kWave];
+  __shared__ double spx[kBlock / kWave][kGroupMaxPts][4];          // the group's updated points (x, y, z, optimised?) for the cost pass
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (cams_dst) {                                      // fused update_motion, as in k_backsub
     const long long nthreads = (long long)gridDim.x * kBlock;
@@ -1716,71 +1725,116 @@ __global__ __launch_bounds__(kBlock) void k_backsub_groups(DevProblem P, const d
     }
   }
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int g = blockIdx.x * (kBlock / kWave) + wv;
-  if (g >= ngroups) return;
-  const SchurGroup gr = groups[g];
-  const int L = gr.L, NP = 64 / L;
-  const int slot = lane / L, oi = lane - slot * L;
-  const bool stager = lane < NP * L;
-  const int n0 = P.pt_off[gr.pt_begin] + oi;
-  const int c = P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]];
-  const int pos = stager ? P.cam_opt_pos[c] : -1;
-  double cm[12], d[6];
-  load_cam(cams, c, cm);
-#pragma unroll
-  for (int a = 0; a < 6; ++a) d[a] = pos >= 0 ? dC[(size_t)pos * 6 + a] : 0.0;
   double (*mx)[64] = sx[wv];
   double (*mw)[64] = sw[wv];
-  for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
-    const int k = kb + slot;
-    const bool live = stager && k < gr.pt_end;
-    double x[3] = {0, 0, 0}, loc[3] = {0, 0, 0};
-    if (live) {
-      x[0] = X[3 * (size_t)k]; x[1] = X[3 * (size_t)k + 1]; x[2] = X[3 * (size_t)k + 2];
-      if (pos >= 0) {                                  // frozen cameras contribute nothing (bundle_adjuster.py:316-331)
-        const double2 z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
-        double e[2], r[2], Jc[12], Jp[6];
-        obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
-        double v0 = 0.0, v1 = 0.0;
+  const bool want_cost = host != nullptr && X_dst != nullptr;
+  double cost_acc = 0.0;
+  for (int g = blockIdx.x * (kBlock / kWave) + wv; g < ngroups; g += gridDim.x * (kBlock / kWave)) {   // wave-uniform
+    const SchurGroup gr = groups[g];
+    const int L = gr.L, NP = 64 / L;
+    const int slot = lane / L, oi = lane - slot * L;
+    const bool stager = lane < NP * L;
+    const int n0 = P.pt_off[gr.pt_begin] + oi;
+    const int c = P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]];
+    const int pos = stager ? P.cam_opt_pos[c] : -1;
+    double cm[12], d[6];
+    load_cam(cams, c, cm);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { v0 += Jc[a] * d[a]; v1 += Jc[6 + a] * d[a]; }
-        loc[0] = Jp[0] * v0 + Jp[3] * v1;
-        loc[1] = Jp[1] * v0 + Jp[4] * v1;
-        loc[2] = Jp[2] * v0 + Jp[5] * v1;
+    for (int a = 0; a < 6; ++a) d[a] = pos >= 0 ? dC[(size_t)pos * 6 + a] : 0.0;
+    double (*px)[4] = spx[wv];
+    for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+      const int k = kb + slot;
+      const bool live = stager && k < gr.pt_end;
+      double x[3] = {0, 0, 0}, loc[3] = {0, 0, 0};
+      if (live) {
+        x[0] = X[3 * (size_t)k]; x[1] = X[3 * (size_t)k + 1]; x[2] = X[3 * (size_t)k + 2];
+        if (pos >= 0) {                                  // frozen cameras contribute nothing (bundle_adjuster.py:316-331)
+          const double2 z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+          double e[2], r[2], Jc[12], Jp[6];
+          obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+          double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) { v0 += Jc[a] * d[a]; v1 += Jc[6 + a] * d[a]; }
+          loc[0] = Jp[0] * v0 + Jp[3] * v1;
+          loc[1] = Jp[1] * v0 + Jp[4] * v1;
+          loc[2] = Jp[2] * v0 + Jp[5] * v1;
+        }
       }
-    }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) mx[q][lane] = loc[q];
-    lds_wave_sync();
-    if (live) {                                        // lane q of a point adds component q of its L terms
-      for (int q = oi; q < 3; q += L) {
-        double v[kGroupMaxL];
+      for (int q = 0; q < 3; ++q) mx[q][lane] = loc[q];
+      lds_wave_sync();
+      if (live) {                                        // lane q of a point adds component q of its L terms
+        for (int q = oi; q < 3; q += L) {
+          double v[kGroupMaxL];
 #pragma unroll
-        for (int j = 0; j < kGroupMaxL; ++j) v[j] = j < L ? mx[q][slot * L + j] : 0.0;
-        double sum = 0.0;
+          for (int j = 0; j < kGroupMaxL; ++j) v[j] = j < L ? mx[q][slot * L + j] : 0.0;
+          double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < kGroupMaxL; ++j) sum += v[j];
-        mw[q][slot] = bP[3 * (size_t)k + q] - sum;
+          for (int j = 0; j < kGroupMaxL; ++j) sum += v[j];
+          mw[q][slot] = bP[3 * (size_t)k + q] - sum;
+        }
       }
+      lds_wave_sync();
+      if (live && oi == 0) {
+        double A[6], v[3], out[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i] = HPPinv[6 * (size_t)k + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = mw[i][slot];
+        sym3_apply(A, v, out);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dP[3 * (size_t)k + i] = out[i];
+        if (X_dst) {                                     // fused update_structure (bundle_adjuster.py:340-343)
+          const bool opt = P.pt_opt[k] != 0;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double xn = opt ? x[i] + sign * out[i] : x[i];
+            X_dst[3 * (size_t)k + i] = xn;
+            px[k - gr.pt_begin][i] = xn;
+          }
+          px[k - gr.pt_begin][3] = opt ? 1.0 : 0.0;
+        }
+      }
+      lds_wave_sync();
     }
-    lds_wave_sync();
-    if (live && oi == 0) {
-      double A[6], v[3], out[3];
+    // second pass over the group: compute_cost of the trial set (optimised camera AND optimised point).  Its
+    // registers (updated camera, residual) replace the first pass's instead of adding to them.
+    if (want_cost && pos >= 0) {
+      double ds[6], cmn[12];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) A[i] = HPPinv[6 * (size_t)k + i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) v[i] = mw[i][slot];
-      sym3_apply(A, v, out);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) dP[3 * (size_t)k + i] = out[i];
-      if (X_dst) {                                     // fused update_structure (bundle_adjuster.py:340-343)
-        const bool opt = P.pt_opt[k] != 0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) X_dst[3 * (size_t)k + i] = opt ? x[i] + sign * out[i] : x[i];
+      for (int a = 0; a < 6; ++a) ds[a] = sign * d[a];
+      camera_perturb(cm, ds, cmn);
+      for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+        const int k = kb + slot;
+        if (stager && k < gr.pt_end && px[k - gr.pt_begin][3] != 0.0) {
+          const double2 z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+          const double xn[3] = {px[k - gr.pt_begin][0], px[k - gr.pt_begin][1], px[k - gr.pt_begin][2]};
+          double e[2], r[2];
+          obs_residual(P.K, cmn, xn, z.x, z.y, P.sensor, e, r);
+          cost_acc += r[0] * r[0] + r[1] * r[1];
+        }
       }
     }
     lds_wave_sync();
   }
+  if (!host) return;
+  cost_acc = wave_sum(cost_acc);
+  if (lane == 0) wsum[wv] = cost_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) s += wsum[w];
+    host->partial[blockIdx.x] = s;
+    if (dev_result) dev_result[blockIdx.x] = s;
+    if (blockIdx.x == 0) {
+      host->singular_points = *singular_points;
+      host->solve_info = *solve_info;
+      if (dev_result) { dev_result[kCostBlocks] = (double)*singular_points; dev_result[kCostBlocks + 1] = (double)*solve_info; }
+    }
+  }
+  if (dev_result && blockIdx.x == 0)                     // the sharded adjuster sums ALL kCostBlocks entries
+    for (int i = gridDim.x + threadIdx.x; i < kCostBlocks; i += kBlock) dev_result[i] = 0.0;
 }
 
 // --------------------------------------------------------------------------
