@@ -716,6 +716,45 @@ def test_lm_trial_entry_equals_stepwise_calls(be):
     close(be.get_params(0)[2], Xs, 0.)
 
 
+@pytest.mark.parametrize('L', [2, 3, 7, 10, 13, 15])
+def test_group_packed_point_kernels_equal_lanes_per_point_kernels(be, monkeypatch, L):
+    """k_linearize_groups / k_backsub_groups (lane = (point slot, observation), trial cost fused into the
+    back-substitution) against k_linearize / k_backsub / k_cost (BA_POINT_KERNELS_V1) for track lengths that
+    do and do not divide 64, with a second frozen camera and points that are not optimised; both against
+    the oracle."""
+    nc, nt = 40, 1200
+    s = banded(nc, nt, track_len=L, outlier_frac=.03)
+    cam_opt_pos = np.arange(nc, dtype=np.int32) - 1
+    cam_opt_pos[17] = -1                                   # a frozen camera in the middle of the sequence
+    cam_opt_pos[18:] -= 1
+    pt_opt = np.ones(nt, np.uint8)
+    pt_opt[::7] = 0
+    sensor = O.Sensor.cauchy(.05)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    out = {}
+    for tag in ('groups', 'v1'):
+        if tag == 'v1':
+            monkeypatch.setenv('BA_POINT_KERNELS_V1', '1')
+        load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
+        be.linearize(0)
+        blk = be.get_blocks()
+        info, cost = be.lm_trial(3., 1e-5, None)
+        assert info == 0
+        out[tag] = (blk['HPP'], blk['bP'], be.get_params(1), cost, be.cost(1))
+    monkeypatch.delenv('BA_POINT_KERNELS_V1')
+    g, v = out['groups'], out['v1']
+    close(g[0], v[0], 1e-13)
+    close(g[1], v[1], 1e-12)
+    for x, y in zip(g[2], v[2]):
+        close(x, y, 1e-11)
+    assert abs(g[3] - v[3]) <= 1e-10 * v[3] and abs(g[3] - g[4]) <= 1e-12 * g[4]     # fused cost = k_cost of the trial set
+    mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=3., return_parts=True)
+    close(g[0], parts['HPP'], TIGHT)
+    close(g[1], parts['bP'], TIGHT)
+    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, cam_opt_pos, pt_opt)
+    close(g[3], O.cost(sensor, s['K'], R2, t2, X2, *a[4:], cam_opt_pos, pt_opt), 1e-8)
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import sys
     for p in (ROOT, os.path.join(ROOT, 'tests')):
