@@ -276,7 +276,8 @@ def main():
                                    '(linearise+damp+pinv+Schur%s+reduced solve+backsub+update+cost), %s sensor model, camera 0 frozen'
                                    % (nc, nt, nobs_total, ' (%d points / %d obs per GPU)' % (args.pts_per_gpu, nobs_local) if ngpus > 1 else '',
                                       '+RCCL all-reduce' if ngpus > 1 else '', args.sensor),
-                       'cameras': nc, 'points': nt, 'observations': nobs_total, 'parallelism': 'points sharded x%d' % ngpus},
+                       'cameras': nc, 'points': nt, 'observations': nobs_total, 'parallelism': 'points sharded x%d' % ngpus,
+                       'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False) else 'torch.distributed (RCCL)')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,

@@ -81,6 +81,22 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs,
                    const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_z,
                    const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt);
 
+/* ---- multi-GPU: the shards' collectives inside the library (one all-reduce of the reduced camera
+ * system per linearisation, plus the 16 KB trial record), issued with RCCL on the handle's OWN stream - no
+ * stream hand-over to a framework's communicator, no host round trip between the halves of a trial.
+ * ba_comm_load resolves RCCL at run time from the given librccl.so (pass the one the process has already
+ * loaded, e.g. torch's: one RCCL instance per process; NULL = "librccl.so" on the loader path).
+ * Rank 0 calls ba_comm_unique_id and ships the 128 bytes to the other ranks by any means; every rank then
+ * calls ba_comm_init (collective, like ncclCommInitRank).  With a communicator attached ba_lm_trial is the
+ * sharded trial: linearise + reduce the shard, all-reduce [S | b], solve (replicated), back-substitute and
+ * update the shard, all-reduce the trial record, return the global cost. */
+int ba_comm_load(const char* librccl_path);
+int ba_comm_unique_id(void* id128 /*[128] out*/);
+int ba_comm_init(ba_handle* h, const void* id128, int32_t rank, int32_t nranks);
+int ba_comm_destroy(ba_handle* h);
+int ba_comm_allreduce_reduced(ba_handle* h);                          /* after ba_schur: [S | b] summed over the shards, in place */
+int ba_comm_allreduce_sum(ba_handle* h, double* values /*host, in place*/, int32_t n);
+
 /* Lower bound for the block half-bandwidth chosen by the NEXT ba_set_problem.  The sharded adjuster
  * sets it to the maximum over the ranks so that every rank stores [S | b] in the same band layout
  * (the all-reduce adds the buffers element by element). */

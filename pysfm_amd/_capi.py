@@ -63,6 +63,12 @@ PROTOTYPES = {
     'ba_set_dense_visibility': (C.c_int, [_h, C.c_int32]),
     'ba_measure_copy_bandwidth': (C.c_int, [_h, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     'ba_set_min_half_bandwidth': (C.c_int, [_h, C.c_int32]),
+    'ba_comm_load': (C.c_int, [C.c_char_p]),
+    'ba_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'ba_comm_init': (C.c_int, [_h, C.c_void_p, C.c_int32, C.c_int32]),
+    'ba_comm_destroy': (C.c_int, [_h]),
+    'ba_comm_allreduce_reduced': (C.c_int, [_h]),
+    'ba_comm_allreduce_sum': (C.c_int, [_h, C.POINTER(C.c_double), C.c_int32]),
     'ba_lm_trial_begin': (C.c_int, [_h, C.c_double, C.c_double]),
     'ba_lm_trial_end': (C.c_int, [_h, _bp, C.POINTER(C.c_int32)]),
     'ba_triangulate': (C.c_int, [_h, C.c_int, C.c_double, _dp]),

@@ -367,6 +367,36 @@ class HipBackend(object):
         return X
 
     # ---------------------------------------------------------------- instrumentation
+    # ---- the shards' collectives inside the library (include/pysfm_ba.h ba_comm_*)
+    direct_comm = False
+
+    def comm_load(self, librccl_path):
+        """Resolve RCCL from the given shared object (the one torch has loaded).  False if that fails."""
+        return self._lib.ba_comm_load(librccl_path.encode() if librccl_path else None) == 0
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        if self._lib.ba_comm_unique_id(buf) != 0:
+            raise capi.HipDeviceError('ba_comm_unique_id failed')
+        return buf.raw
+
+    def comm_attach(self, id128, rank, nranks):
+        assert len(id128) == 128
+        self._check(self._lib.ba_comm_init(self._h, C.c_char_p(id128), int(rank), int(nranks)))
+        self.direct_comm = True
+
+    def comm_detach(self):
+        self._check(self._lib.ba_comm_destroy(self._h))
+        self.direct_comm = False
+
+    def comm_allreduce_reduced(self):
+        self._check(self._lib.ba_comm_allreduce_reduced(self._h))
+
+    def comm_allreduce_sum(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self._lib.ba_comm_allreduce_sum(self._h, capi.dptr(v), v.size))
+        return v
+
     def measure_copy_bandwidth(self, nbytes=1 << 30, repeats=10):
         """GB/s (read + write) of a streaming copy on this device: the achievable HBM rate."""
         out = C.c_double()

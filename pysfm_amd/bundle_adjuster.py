@@ -87,6 +87,13 @@ class BundleAdjuster(object):
         if self._backend is None:
             from .backend import HipBackend      # raises if libpysfm_ba.so / the GPU is missing
             self._backend = HipBackend(self._device)
+        if self._comm is not None and not getattr(self, '_comm_checked', False):
+            # the shards' collectives move into the library when they can (RCCL on the handle's own stream);
+            # every rank takes the same decision (ShardComm.enable_direct agrees on it)
+            self._comm_checked = True
+            enable = getattr(self._comm, 'enable_direct', None)
+            if enable is not None and hasattr(self._backend, 'comm_attach'):
+                enable(self._backend)
         return self._backend
 
     # ------------------------------------------------------------------ bundle <-> device
@@ -255,8 +262,9 @@ class BundleAdjuster(object):
         self.lm_trials += 1
         next_cost = None
         be = self.backend
-        if self._comm is None and hasattr(be, 'lm_trial'):
-            # single GPU: the whole trial is one batch of launches with one synchronisation
+        if (self._comm is None or getattr(be, 'direct_comm', False)) and hasattr(be, 'lm_trial'):
+            # single GPU - or shards whose collectives the library issues itself (ba_comm_init): the whole trial is
+            # one batch of launches with one synchronisation; the cost that comes back is the sum over the shards
             cam_param_mask = None                              # (the common case costs no array work)
             if param_mask is not None:
                 cam_param_mask = self._cam_param_mask(param_mask)

@@ -17,6 +17,9 @@
 #include "ba_bcr_wide.h"
 #include "ba_dense.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types only: the entry points are resolved at run time from the librccl torch has loaded
+
 using namespace ba;
 
 namespace {
@@ -66,6 +69,9 @@ struct ba_handle {
   double inv_damping = 0.0, inv_rcond = 0.0;
   bool dense_mode = false;           // ba_set_dense_visibility: the reduction is one SYRK over all points (k_dense_*)
   double* trial_result_dev = nullptr; // bound by ba_bind_trial_result: device copy of the cost partials + status words
+  ncclComm_t comm = nullptr;          // ba_comm_init: the shards' communicator; collectives run on `stream`
+  int comm_ranks = 0;
+  double* comm_host = nullptr;        // pinned [kCostBlocks + 2]: the all-reduced trial record
   double trial_rcond = 0.0;          // ba_lm_trial_begin -> ba_lm_trial_end
   int glog = 0;              // lanes per point = 2^glog
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -96,7 +102,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA, fac, dUd, dDd, dyd, dpart;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA, fac, dUd, dDd, dyd, dpart, comm_dev;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
@@ -415,6 +421,42 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
 
 }  // namespace
 
+namespace {
+// ---- RCCL, resolved at run time (ba_comm_load): the library does not link against it, it uses the one the
+// process already has (torch's), so that there is a single RCCL instance per process
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok() const { return GetUniqueId && CommInitRank && AllReduce && CommDestroy; }
+};
+RcclApi g_rccl;
+
+#define RCCLCHECK(h, call)                                                                                   \
+  do {                                                                                                       \
+    ncclResult_t r_ = (call);                                                                                \
+    if (r_ != ncclSuccess)                                                                                   \
+      return (h)->fail(BA_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+  } while (0)
+
+// in-place sum over the shards of the band-stored [S | b] (contiguous), on the handle's stream
+int comm_allreduce_reduced(ba_handle* h) {
+  const size_t nS = reduced_doubles(h), nb = (size_t)h->nco * 6;
+  if (nS + nb == 0) return BA_OK;
+  if (h->b == h->S + nS) {                            // the usual case: one contiguous [S | b]
+    RCCLCHECK(h, g_rccl.AllReduce(h->S, h->S, nS + nb, ncclFloat64, ncclSum, h->comm, h->stream));
+  } else {
+    RCCLCHECK(h, g_rccl.AllReduce(h->S, h->S, nS, ncclFloat64, ncclSum, h->comm, h->stream));
+    RCCLCHECK(h, g_rccl.AllReduce(h->b, h->b, nb, ncclFloat64, ncclSum, h->comm, h->stream));
+  }
+  return BA_OK;
+}
+
+}  // namespace
+
 // The achievable HBM rate of this box (SURVEY 8d asks for the roofline fraction against it as well as
 // against the 8 TB/s of the data sheet): a plain streaming copy, 16 bytes per lane per iteration.
 __global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
@@ -476,6 +518,7 @@ int ba_destroy(ba_handle* h) {
   if (!h) return BA_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  (void)ba_comm_destroy(h);
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
@@ -1460,6 +1503,81 @@ int ba_set_dense_visibility(ba_handle* h, int32_t on) {
   return BA_OK;
 }
 
+// ---- the shards' collectives inside the library (RCCL over xGMI on the handle's own stream)
+int ba_comm_load(const char* librccl_path) {
+  if (g_rccl.ok()) return BA_OK;
+  void* lib = dlopen(librccl_path && *librccl_path ? librccl_path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) { g_create_error = std::string("ba_comm_load: ") + dlerror(); return BA_ERR_HIP; }
+  g_rccl.lib = lib;
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!g_rccl.ok()) { g_create_error = "ba_comm_load: librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce"; return BA_ERR_HIP; }
+  return BA_OK;
+}
+
+int ba_comm_unique_id(void* id128) {
+  if (!id128 || !g_rccl.ok()) return BA_ERR_STATE;
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return BA_ERR_HIP;
+  std::memcpy(id128, &id, sizeof id);
+  return BA_OK;
+}
+
+int ba_comm_init(ba_handle* h, const void* id128, int32_t rank, int32_t nranks) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, g_rccl.ok(), BA_ERR_STATE, "ba_comm_init: call ba_comm_load first");
+  REQUIRE(h, id128 && nranks >= 1 && rank >= 0 && rank < nranks, BA_ERR_INVALID_ARG, "ba_comm_init: bad argument");
+  REQUIRE(h, !h->comm, BA_ERR_STATE, "ba_comm_init: communicator already attached");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  HIPCHECK(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  RCCLCHECK(h, g_rccl.CommInitRank(&h->comm, nranks, id, rank));
+  h->comm_ranks = nranks;
+  HIPCHECK(h, h->comm_dev.resize(kCostBlocks + 2));
+  HIPCHECK(h, hipMemsetAsync(h->comm_dev.p, 0, (kCostBlocks + 2) * sizeof(double), h->stream));
+  HIPCHECK(h, hipHostMalloc((void**)&h->comm_host, (kCostBlocks + 2) * sizeof(double), hipHostMallocDefault));
+  h->trial_result_dev = h->comm_dev.p;               // k_cost / k_backsub_groups leave the trial record here
+  return BA_OK;
+}
+
+int ba_comm_destroy(ba_handle* h) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  if (h->comm) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_ranks = 0;
+    if (h->trial_result_dev == h->comm_dev.p) h->trial_result_dev = nullptr;
+    if (h->comm_host) { (void)hipHostFree(h->comm_host); h->comm_host = nullptr; }
+    h->comm_dev.release();
+  }
+  return BA_OK;
+}
+
+int ba_comm_allreduce_reduced(ba_handle* h) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->comm, BA_ERR_STATE, "ba_comm_allreduce_reduced: no communicator (ba_comm_init)");
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_comm_allreduce_reduced: call ba_schur first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  return comm_allreduce_reduced(h);
+}
+
+int ba_comm_allreduce_sum(ba_handle* h, double* values, int32_t n) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->comm, BA_ERR_STATE, "ba_comm_allreduce_sum: no communicator (ba_comm_init)");
+  REQUIRE(h, values && n >= 1 && n <= kCostBlocks, BA_ERR_INVALID_ARG, "ba_comm_allreduce_sum: bad argument");
+  HIPCHECK(h, hipSetDevice(h->device));
+  HIPCHECK(h, h->scratch.resize((size_t)n));
+  HIPCHECK(h, hipMemcpyAsync(h->scratch.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RCCLCHECK(h, g_rccl.AllReduce(h->scratch.p, h->scratch.p, (size_t)n, ncclFloat64, ncclSum, h->comm, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(values, h->scratch.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
 int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, min_hb >= 0, BA_ERR_INVALID_ARG, "ba_set_min_half_bandwidth: negative");
@@ -1518,12 +1636,27 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   if (h->have_problem && h->hb > kMaxBandSolve && 6 * h->nco > kDcMaxN) { *info = -1; return BA_OK; }
   int32_t pre = 0;
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
+  if (rc == BA_OK && h->comm) rc = comm_allreduce_reduced(h);      // sharded: the one data-path collective
   if (rc == BA_OK) rc = ba_lm_trial_end(h, cam_param_mask, &pre);
   if (rc != BA_OK) return rc;
   if (pre != 0) { *info = pre; return BA_OK; }
-  HIPCHECK(h, hipStreamSynchronize(h->stream));      // k_cost left the cost partials + status words in pinned memory
-  const int st[2] = {h->host_result->singular_points, h->host_result->solve_info};
-  *next_cost = h->host_cost();
+  int st[2];
+  if (h->comm) {
+    // the shards' trial records (cost partials | singular blocks | solver status) are summed in place - 16 KB, the
+    // latency of 8 bytes - and come back with one copy; the partials are added on the host in index order
+    RCCLCHECK(h, g_rccl.AllReduce(h->comm_dev.p, h->comm_dev.p, (size_t)kCostBlocks + 2, ncclFloat64, ncclSum, h->comm, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->comm_host, h->comm_dev.p, (kCostBlocks + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    double sum = 0.0;
+    for (int i = 0; i < kCostBlocks; ++i) sum += h->comm_host[i];
+    *next_cost = sum;
+    st[0] = (int)std::llround(h->comm_host[kCostBlocks]);                          // over all shards
+    st[1] = (int)std::llround(h->comm_host[kCostBlocks + 1] / h->comm_ranks);      // every rank solves the same system
+  } else {
+    HIPCHECK(h, hipStreamSynchronize(h->stream));    // k_cost left the cost partials + status words in pinned memory
+    st[0] = h->host_result->singular_points; st[1] = h->host_result->solve_info;
+    *next_cost = h->host_cost();
+  }
   if (pinv_rcond < 0.0 && st[0] > 0)
     return h->fail(BA_ERR_SINGULAR, "ba_lm_trial: %d singular 3x3 point block(s) in plain-inverse mode", st[0]);
   *info = st[1];

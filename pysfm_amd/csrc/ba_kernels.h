@@ -182,6 +182,8 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __r
       if (dev_result) { dev_result[kCostBlocks] = (double)*singular_points; dev_result[kCostBlocks + 1] = (double)*solve_info; }
     }
   }
+  if (dev_result && blockIdx.x == 0)                     // the sharded adjuster sums ALL kCostBlocks entries
+    for (int i = gridDim.x + threadIdx.x; i < kCostBlocks; i += kBlock) dev_result[i] = 0.0;
 }
 
 // --------------------------------------------------------------------------

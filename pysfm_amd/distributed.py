@@ -77,6 +77,41 @@ class ShardComm(object):
         self.device = device
         self.bytes_reduced = 0
 
+    def enable_direct(self, backend):
+        """Move the data-path collectives into the library (ba_comm_*: RCCL issued on the handle's own stream,
+        a sharded trial is then ONE C call).  Collective: every rank calls it, and every decision on the way is
+        agreed on over torch.distributed, so that either all ranks switch or none does.  BA_COMM=torch keeps
+        the torch.distributed path.  Returns True when the library took over."""
+        torch, dist = self._torch, self._dist
+        self.direct = None
+        ok = (os.environ.get('BA_COMM', '') != 'torch' and dist.get_backend(self.group) == 'nccl'
+              and hasattr(backend, 'comm_attach'))
+        if ok:
+            ok = backend.comm_load(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'))
+        if not self._agree(ok):
+            return False
+        ident = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(backend.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        try:
+            backend.comm_attach(bytes(ident.cpu().numpy().tobytes()), self.rank, self.world_size)
+            got = backend.comm_allreduce_sum([self.rank + 1.0, 1.0])           # self-test against the known answer
+            ok = abs(got[0] - self.world_size * (self.world_size + 1) / 2.0) < 1e-9 and abs(got[1] - self.world_size) < 1e-9
+        except Exception:                                                        # noqa: BLE001 - any failure: stay on torch
+            ok = False
+        if not self._agree(ok):
+            if getattr(backend, 'direct_comm', False):
+                backend.comm_detach()
+            return False
+        self.direct = backend
+        return True
+
+    def _agree(self, flag):
+        t = self._torch.tensor([1.0 if flag else 0.0], dtype=self._torch.float64, device=self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item() > 0.5)
+
     def allreduce_scalar(self, x):
         t = self._torch.tensor([x], dtype=self._torch.float64, device=self.device)
         self._dist.all_reduce(t, group=self.group)
@@ -94,6 +129,9 @@ class ShardComm(object):
 
     def allreduce_reduced(self, backend):
         """The one data-path collective: sum the partial reduced camera systems."""
+        if getattr(self, 'direct', None) is backend:
+            backend.comm_allreduce_reduced()        # RCCL inside the library, on its own stream
+            return
         payload = backend.reduced_payload()
         with _stream_of(backend):              # ordered after the kernels that wrote it, before the ones that read it
             self._all_reduce_device(payload)

@@ -835,10 +835,14 @@ print('HPP', '%%.15e' %% float(np.abs(X).sum()), '%%.15e' %% float(np.abs(t).sum
     close(np.array(out['fused']['HPP']), np.array(out['default']['HPP']), 1e-9)
 
 
-def test_sharded_trial_path_matches_single_gpu_path():
-    """The multi-GPU trial (ba_lm_trial_begin -> RCCL all-reduce of [S | b] -> ba_lm_trial_end, trial
-    costs summed on the device) with a one-rank RCCL group must walk the same LM trajectory as
-    ba_lm_trial, and both must agree with the oracle's first step."""
+@pytest.mark.parametrize('collectives', ['library', 'torch'])
+def test_sharded_trial_path_matches_single_gpu_path(monkeypatch, collectives):
+    """The multi-GPU trial with a one-rank RCCL group must walk the same LM trajectory as the single-GPU
+    ba_lm_trial.  'library': the collectives are issued by the library itself on its own stream
+    (ba_comm_init; ba_lm_trial is then the sharded trial); 'torch' (BA_COMM=torch): ba_lm_trial_begin ->
+    torch.distributed all-reduce of [S | b] -> ba_lm_trial_end -> all-reduce of the trial record."""
+    if collectives == 'torch':
+        monkeypatch.setenv('BA_COMM', 'torch')
     import torch
     import torch.distributed as dist
     from pysfm_amd import Bundle, BundleAdjuster, sensor_model
@@ -863,7 +867,12 @@ def test_sharded_trial_path_matches_single_gpu_path():
     try:
         comm = ShardComm()
         sharded = run(comm)
-        assert comm.bytes_reduced > 0                       # the collective really ran
+        if collectives == 'torch':
+            assert comm.bytes_reduced > 0 and not sharded.backend.direct_comm      # the collective really ran
+        else:
+            assert sharded.backend.direct_comm and comm.direct is sharded.backend
+            got = sharded.backend.comm_allreduce_sum([1.5, -2.])
+            assert got[0] == 1.5 and got[1] == -2.
     finally:
         if created:
             dist.destroy_process_group()
