@@ -391,7 +391,7 @@ __device__ __forceinline__ void point_invert_body(int k, int nt, const double* _
   for (int i = 0; i < 6; ++i) HPPinv[6 * (size_t)k + i] = out[i];
   if (fac) {                                   // HPPinv = L D L^T and HPPinv bP for k_schur_groups_mfma2
     double f[9];
-    sym3_ldl(out, f, f + 3);
+    sym3_ldl(out, sym3_ldl_tolerance(rcond), f, f + 3);
     const double g0 = bP[3 * (size_t)k], g1 = bP[3 * (size_t)k + 1], g2 = bP[3 * (size_t)k + 2];
     f[6] = out[0] * g0 + out[1] * g1 + out[2] * g2;
     f[7] = out[1] * g0 + out[3] * g1 + out[4] * g2;

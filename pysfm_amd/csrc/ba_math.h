@@ -260,11 +260,17 @@ BA_HD void sym3_pinv_fast(const double A[6], double rcond, double out[6]) {
 // numpy.linalg.inv for a symmetric 3x3 (bundle_adjuster.py:254).  Returns false
 // when the block is singular (numpy raises LinAlgError there).
 // A = L D L^T for a symmetric 3 x 3 matrix [a00 a01 a02 a11 a12 a22], L unit lower: D[3], Lo = {L10, L20, L21}.
-// Made for the per-point pseudo-inverse (positive semi-definite, possibly rank deficient: eigenvalues
-// either >= rcond * largest or exactly cut to zero): a pivot below 1e-10 * trace is a cut direction -
-// its column of L and its D are zero (for a semi-definite matrix the rest of that column is zero too).
-BA_HD void sym3_ldl(const double A[6], double D[3], double Lo[3]) {
-  const double tol = 1e-10 * (fabs(A[0]) + fabs(A[3]) + fabs(A[5]));
+// Made for the per-point pseudo-inverse (positive semi-definite, possibly rank deficient: its eigenvalues
+// are either >= rcond * the largest, or exactly cut to zero, which the factorisation sees as a pivot of
+// ~1e-16 * trace): a pivot below tol_rel * trace is a cut direction - its column of L and its D are zero
+// (for a semi-definite matrix the rest of that column is zero too).  sym3_ldl_tolerance puts tol_rel into
+// the gap between the two; 0 for the plain inverse (no cut: only an exactly zero pivot is dropped).
+BA_HD double sym3_ldl_tolerance(double rcond) {
+  return rcond < 0.0 ? 0.0 : fmin(1e-10, fmax(1e-15, 1e-3 * rcond));
+}
+
+BA_HD void sym3_ldl(const double A[6], double tol_rel, double D[3], double Lo[3]) {
+  const double tol = tol_rel * (fabs(A[0]) + fabs(A[3]) + fabs(A[5]));
   const bool z0 = !(fabs(A[0]) > tol);
   const double i0 = z0 ? 0.0 : 1.0 / A[0];
   D[0] = z0 ? 0.0 : A[0];

@@ -542,6 +542,34 @@ def test_group_reduction_kernel_equals_pair_kernel(be, monkeypatch, nc, L, senso
     close(out['groups'][1], parts['b'], TIGHT)
 
 
+@pytest.mark.parametrize('rcond', [None, 1e-13, 1e-5])
+def test_factorised_point_inverses_with_ill_conditioned_blocks(be, monkeypatch, rcond):
+    """The producer / consumer MFMA reduction works from HPPinv = L D L^T (ba_math.h sym3_ldl).  Points far
+    from the cameras make the 3 x 3 blocks ill-conditioned along the viewing direction (eigenvalue ratios up
+    to ~1e9); without damping, with the plain inverse (rcond None), a tiny and the default pinv cut-off the
+    reduction must still agree with the pair kernel, which multiplies by HPPinv itself - the tolerance of
+    the factorisation's "cut direction" test follows rcond."""
+    nc, nt = 40, 1600
+    s = banded(nc, nt, track_len=10)
+    X0 = s['X0'].copy()
+    X0[::3, 2] *= 400.                                     # every third point far away
+    cam_opt_pos, pt_opt = default_flags(nc, nt)
+    a = (s['K'], s['R0'], s['t0'], X0, s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, cam_opt_pos, pt_opt, O.Sensor.gaussian(1.))
+    out = {}
+    for kern in ('pairs', 'mfma'):
+        monkeypatch.setenv('BA_SCHUR', kern)
+        be.linearize(0)
+        be.schur(0, 1e-9, rcond)
+        out[kern] = be.get_reduced()
+    monkeypatch.delenv('BA_SCHUR')
+    blk = be.get_blocks()
+    w = np.linalg.eigvalsh(blk['HPP'])
+    assert (w[:, -1] / np.maximum(w[:, 0], 1e-300)).max() > 1e6       # the scene really is ill-conditioned
+    close(out['mfma'][0], out['pairs'][0], 1e-10)
+    close(out['mfma'][1], out['pairs'][1], 1e-10)
+
+
 def test_wide_band_takes_dense_path(be):
     g = load_golden('scene_oleg_40x100')
     load_problem(be, *scene(g), g['l10_cam_opt_pos'], g['l10_pt_opt'], sensor_of(g))
