@@ -205,12 +205,14 @@ def main():
         be = ba.backend
 
     # ---- timed region: K complete LM trials, continuing the LM schedule
-    state = dict(damping=10., cur=None)
+    state = dict(damping=10., cur=None, paths={})
 
     def one_trial():
         if state['cur'] is None:
             state['cur'] = ba._cost(PARAMS_CUR)
         accepted, nxt = ba.trial(state['damping'], None, state['cur'])
+        key = '%s/%s' % (getattr(be, 'last_solve_path', '?'), 'accepted' if accepted else ('rejected' if accepted is not None else 'ill-conditioned'))
+        state['paths'][key] = state['paths'].get(key, 0) + 1
         if accepted:
             state['damping'] *= .1
             state['cur'] = nxt
@@ -236,11 +238,13 @@ def main():
     # microseconds of stream time - bracketing all ~25 launches of a 0.6 ms step would slow it ~15 %)
     be.enable_timing(not args.no_kernel_table, only=[dom], stride=4)     # every 4th step: the events themselves cost stream time
     sync()
+    state['paths'] = {}
     t0 = time.time()
     for _ in range(args.steps):
         one_trial()
     sync()
     dt = time.time() - t0
+    timed_paths = dict(state['paths'])
     tm_dom = be.timings(reset=True)[dom]
     if args.no_kernel_table:
         tm_dom, tm, nprof = tm_w[dom], tm_w, max(1, nwarm)
@@ -297,7 +301,8 @@ def main():
                             'kernel_ms_per_step': sum(v['ms'] for v in ours.values()) / nprof,
                             'note': 'measured on %d extra trials outside the timed region, every kernel bracketed' % nprof},
             'reduced_system': {'cameras_optimised': nco, 'block_half_bandwidth': be.half_bandwidth,
-                               'bytes': 8 * be.S_doubles, 'solve_path': getattr(be, 'last_solve_path', None)},
+                               'bytes': 8 * be.S_doubles, 'solve_path': getattr(be, 'last_solve_path', None),
+                               'timed_trials_by_solver_and_outcome': timed_paths},
         }
         out.update(lm)
         if ngpus == 1 and not args.no_cpu_baseline:

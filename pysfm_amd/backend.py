@@ -15,12 +15,14 @@ from ._capi import PARAMS_CUR, PARAMS_TRIAL  # noqa: F401  (re-exported)
 
 DEVICE_CHOLESKY_MAX_UNKNOWNS = 16000   # (= kDcMaxN of ba_dense.h)
 # A reduced system the device Cholesky rejects as not positive definite goes through LU like the reference's
-# (numpy.linalg.solve) - up to this many unknowns.  Beyond (a 2 GB matrix, seconds of LU; the reference would
-# be factoring 60000 x 60000 on the host) the system is reported as ill-conditioned instead, which the LM loop
-# answers exactly as it answers the reference's LinAlgError: raise the damping and try again
+# (numpy.linalg.solve) - up to this many unknowns (the sizes of the reference's own data sets: 594 at 100
+# cameras; LU takes 1-3 ms there).  Beyond, the system is reported as ill-conditioned instead, which the LM
+# loop answers exactly as it answers the reference's LinAlgError: raise the damping and try again
 # (bundle_adjuster.py:134-140).  S is symmetric positive definite in exact arithmetic for damping > 0, so a
-# failed fp64 Cholesky means a condition number beyond 1e15 - an LU step of such a system carries no digits.
-LU_FALLBACK_MAX_UNKNOWNS = 16000
+# failed fp64 Cholesky means a condition number beyond 1e15 - an LU step of such a system carries no digits
+# (it happens at the noise floor, when the damping has decayed to ~1e-10 and the free scale of a monocular
+# reconstruction makes S numerically singular; at 1000 cameras every such LU costs 70 ms = 200 trials).
+LU_FALLBACK_MAX_UNKNOWNS = 2048
 DENSE_MIN_HALF_BANDWIDTH = 21     # (= kMaxBandSolve: beyond it the solve is dense anyway)
 DENSE_MIN_FILL = 0.25             # observed fraction of the (camera, track) pairs
 DENSE_MAX_BYTES = 2 << 30         # of the staged operand

@@ -693,7 +693,7 @@ def test_band_solver_reports_non_positive_pivot(be):
 def test_large_system_that_is_not_positive_definite_is_reported_ill_conditioned(be):
     """More unknowns than the LU fallback takes (backend.LU_FALLBACK_MAX_UNKNOWNS): a failed Cholesky is
     answered like the reference's LinAlgError (NormalEquationsIllconditioned -> the LM loop raises the
-    damping, bundle_adjuster.py:134-140) instead of a dense LU of a 16000+ square matrix."""
+    damping, bundle_adjuster.py:134-140) instead of a dense LU of the flattened system."""
     from pysfm_amd.backend import ReducedSystemSingular, LU_FALLBACK_MAX_UNKNOWNS
     nc = LU_FALLBACK_MAX_UNKNOWNS // 6 + 40
     s = banded(nc, 3 * nc, track_len=6)
