@@ -265,6 +265,11 @@ def main():
     if rank == 0:
         # dominant kernel of OUR kernels, by HIP-event time on the launch stream
         ours = {k: v for k, v in tm.items() if v['launches'] > 0}
+        # the kernel the timed region bracketed was picked from the warm-up; the table measured after the timed
+        # region (every kernel bracketed, `nprof` trials) has the last word on which kernel dominates
+        dom_table = max(ours, key=lambda k: ours[k]['ms']) if ours else dom
+        if dom_table != dom or not tm_dom['launches'] or not tm_dom['ms'] > 0.:
+            dom, tm_dom = dom_table, ours.get(dom_table, tm_dom)
         avg_ms = tm_dom['ms'] / max(1, tm_dom['launches'])
         nco = be.nco
         B = algorithmic_bytes(dom, be.nc, nco, be.nt, nobs_local, be.nt, be.half_bandwidth)
