@@ -1153,7 +1153,7 @@ constexpr int kGm2DRows = 24;                          // D values per buffer (2
 
 __host__ __device__ inline size_t schur_mfma2_lds_bytes(int wn, int hb1) {
   return (size_t)kGm2Pairs * 2 * kGmK * kGmLd * sizeof(double) + (size_t)kGm2Pairs * 2 * kGm2DRows * sizeof(double) +
-         (size_t)kGm2Pairs * (16 + 4) * sizeof(int) + (size_t)wn * ((size_t)hb1 * 36 + 6) * sizeof(double);
+         (size_t)kGm2Pairs * (16 + 4) * sizeof(int) + 64 * sizeof(double) + (size_t)wn * ((size_t)hb1 * 36 + 6) * sizeof(double);
 }
 
 __device__ __forceinline__ void gm2_wait(int* flag, int need) {
@@ -1178,7 +1178,8 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
   double* sD = sU + kGm2Pairs * 2 * BUF;                       // [pair][2][kGm2DRows]
   int* sPos = reinterpret_cast<int*>(sD + kGm2Pairs * 2 * kGm2DRows);   // [pair][16]
   int* sFlag = sPos + kGm2Pairs * 16;                          // [pair][4]: staged, consumed
-  double* tile = reinterpret_cast<double*>(sFlag + kGm2Pairs * 4);
+  double* sDummy = reinterpret_cast<double*>(sFlag + kGm2Pairs * 4);   // [64]: where the epilogue's masked-out lanes add
+  double* tile = sDummy + 64;
   const int hb1 = P.hb + 1;
   const int rowlen = hb1 * 36;
   double* tb = tile + (size_t)wn * rowlen;
@@ -1338,9 +1339,55 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
         }
       }
       lds_wave_sync();                                          // mPos
-      // ---- epilogue (as in k_schur_groups_mfma): C/D layout lane -> column n = 16 tj + lane%16,
-      // register v -> row m = 16 ti + lane/16 + 4 v
-      {
+      // ---- epilogue: C/D layout lane -> column n = 16 tj + lane%16, register v -> row m = 16 ti + lane/16 + 4 v.
+      // Usual case (wave-uniform test): every optimised camera of the group lies inside the workgroup's LDS
+      // window.  Then there is ONE unconditional ds_add_f64 per accumulator register (+ one for the mirrored
+      // entry in the diagonal tiles): lanes that have nothing to add (frozen cameras, the lower triangle, padding)
+      // add to a private dummy slot instead of branching around the instruction - the branchy form below costs
+      // ~13 k cycles per group, mostly exec-mask bookkeeping.
+      const int mp = lane < 16 ? mPos[lane] : -1;
+      const bool allin = __all(mp < 0 || (mp - p0 >= 0 && mp - p0 < wn));
+      if (allin) {
+        double* dummy = sDummy + lane;
+        int colpart[4], pjv[4], jn[4], cn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int n = 16 * t + lr;
+          jn[t] = n / 6; cn[t] = n - 6 * jn[t];
+          pjv[t] = jn[t] < L ? mPos[jn[t]] : -1;
+          colpart[t] = pjv[t] * 36 + cn[t];
+        }
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          int rowpart[4], pim[4], im[4], am[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int m = 16 * ti + lk + 4 * v;
+            im[v] = m / 6; am[v] = m - 6 * im[v];
+            pim[v] = im[v] < L ? mPos[im[v]] : -1;
+            rowpart[v] = (pim[v] - p0) * rowlen - pim[v] * 36 + am[v] * 6;
+          }
+#pragma unroll
+          for (int tj = ti; tj < 4; ++tj, ++q) {
+            if (tj >= nts) continue;
+            const int j = jn[tj], c = cn[tj];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int i = im[v], a = am[v];
+              const bool both = pim[v] >= 0 && pjv[tj] >= 0;
+              const double val = -acc[q][v];
+              const int off = rowpart[v] + colpart[tj];
+              const bool ok = both && (i < j || (i == j && a <= c));
+              atomic_add_f64(ok ? tile + off : dummy, val);
+              if (tj <= ti + 1) {                                // compile time: only these tiles can hold a piece of a diagonal
+                const bool mirror = both && i == j && a < c;   // block (6 rows of a camera may straddle a tile edge); they are
+                atomic_add_f64(mirror ? tile + off + 5 * (c - a) : dummy, val);      // stored in full
+              }
+            }
+          }
+        }
+      } else {
         int colpart[4], pjv[4], jn[4], cn[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
