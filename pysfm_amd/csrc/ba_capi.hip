@@ -457,6 +457,11 @@ int comm_allreduce_reduced(ba_handle* h) {
 
 }  // namespace
 
+__global__ __launch_bounds__(256) void k_copy_doubles(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 // The achievable HBM rate of this box (SURVEY 8d asks for the roofline fraction against it as well as
 // against the 8 TB/s of the data sheet): a plain streaming copy, 16 bytes per lane per iteration.
 __global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
@@ -1671,7 +1676,9 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
     // the shards' trial records (cost partials | singular blocks | solver status) are summed in place - 16 KB, the
     // latency of 8 bytes - and come back with one copy; the partials are added on the host in index order
     RCCLCHECK(h, g_rccl.AllReduce(h->comm_dev.p, h->comm_dev.p, (size_t)kCostBlocks + 2, ncclFloat64, ncclSum, h->comm, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->comm_host, h->comm_dev.p, (kCostBlocks + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // (a kernel storing into the pinned record: a 16 KB hipMemcpyAsync goes through the DMA engine and costs more)
+    hipLaunchKernelGGL(k_copy_doubles, dim3((kCostBlocks + 2 + 255) / 256), dim3(256), 0, h->stream, h->comm_dev.p, h->comm_host,
+                       kCostBlocks + 2);
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     double sum = 0.0;
     for (int i = 0; i < kCostBlocks; ++i) sum += h->comm_host[i];
