@@ -2,16 +2,21 @@
 """bench.py - LM-iteration throughput of the MI355X bundle-adjustment inner loop.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8                       # starts its own 8 ranks (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
-1000 cameras / 100 000 points / 1 000 000 observations, full Levenberg-Marquardt
-(lambda0 = 10, x0.1 / x10), Gaussian sensor model, synthetic banded scene
-(pysfm_amd.synthetic_data.generate_banded_scene, seed 654), camera 0 frozen.
-With N > 1 GPUs the points are sharded (weak scaling: 100 000 points / 1M
-observations PER GPU, the 1000 cameras replicated) and the reduced camera system is
-summed with one RCCL all-reduce per trial.
+Workloads (BASELINE.json `configs`; synthetic banded scene of pysfm_amd.synthetic_data, seed 654, camera 0 frozen):
+  --config 3  (default, the configuration the metric is quoted on) 1000 cameras / 100 000 points / 1 000 000
+              observations, full Levenberg-Marquardt (lambda0 = 10, x0.1 / x10), Gaussian sensor model.
+              With N > 1 GPUs: WEAK scaling - 100 000 points / 1M observations PER GPU, the 1000 cameras replicated.
+  --config 4  config 3 with the Huber robustifier (k = 0.06) and 10 % gross outliers.
+  --config 2  100 cameras / 10 000 points / 100 000 observations.
+  --config 5  10 000 cameras / 1 000 000 points / 10 000 000 observations in total, STRONG split of the points over
+              the N GPUs (N = 1 runs the whole scene on one GPU).
+  --shuffle-points   hand the tracks (and their observations) over in random order: the library orders them itself.
+  --track-len L      observations per point (default 10; the band half-width of the reduced system is L - 1).
+Points are sharded over the GPUs; the reduced camera system is summed with one RCCL all-reduce per trial.
 
 One "step" = one complete LM trial, nothing cached or skipped:
   linearise (residuals + 2x6/2x3 Jacobians + block assembly)  -> damp -> per-point 3x3
@@ -25,6 +30,8 @@ Rank 0 prints ONE JSON line; see DESIGN.md for `roofline` and `cpu_baseline`.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +43,15 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mfma_f64_16x16x4_f64 measured at 16 FMA/clk/SIMD
+
+# What binds each kernel at the bench sizes; `roofline.bound` reports it.  The contract prices
+# `achieved` against HBM for every kernel that is not MFMA-bound, so `frac` is always achieved / 8 TB/s.
+KERNEL_BOUND = {'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
+                'dense_solve': 'latency', 'schur_pairs': 'mfma', 'linearize': 'hbm', 'backsub': 'hbm', 'cost': 'hbm',
+                'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
+# reference rates measured in SURVEY.md section 6 (the reference itself, imported in the build container, 1 core Xeon 2.1 GHz)
+SURVEY_REFERENCE_RATES = {'assemble_obs_per_s': 2.8e4, 'whole_update_obs_per_s': 3.5e3,
+                          'source': 'SURVEY.md section 6: alexflint/pysfm bundle_adjuster.py on 1 core (Xeon 2.1 GHz)'}
 
 
 def schur_flops(nobs, nt):
@@ -78,8 +94,8 @@ def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
         return 8 * N * (3 * B * B + 4 * B) // levels
     if kernel == 'flatten':
         return band + 288 * nco * nco
-    if kernel == 'point_invert':
-        return 96 * nt
+    if kernel == 'point_invert':          # HPP read, HPPinv + its factorisation written, [S | b] initialised
+        return 48 * nt + 48 * nt + 72 * nt + 24 * nt + band + 48 * nco
     if kernel == 'update':
         return 2 * (96 * nc + 24 * nt) + 48 * nco + 24 * nt
     return 0
@@ -95,7 +111,9 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     # the timer id 'schur_pairs' covers the interchangeable reduction kernels
-    names = ['k_schur_groups_mfma2', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'] if kernel == 'schur_pairs' else ['k_' + kernel]
+    names = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
+             'linearize': ['k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
+             'point_invert': ['k_point_invert_schur_init', 'k_point_invert']}.get(kernel, ['k_' + kernel])
     rows = list(csv.DictReader(open(files[-1])))
     for name in names:
         for row in rows:
@@ -104,30 +122,85 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def cpu_baseline(sample_cams, sample_pts):
-    """The oracle (NumPy restatement of the reference, 'port') timed on this box's host
-    cores on a bounded sample of the same workload: one full LM trial."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(s, loop_obs=10000):
+    """the oracle (NumPy restatement of the reference, kind 'port') timed on this box's host cores in
+    the same run: (i) the literal per-observation assembly loop (the shape of the reference's own hot loop,
+    bundle_adjuster.py:211-234) on a `loop_obs`-observation subsample, ONE core; (ii) the vectorised port, one full LM
+    trial (cost, blocks, Schur, LU solve, back-substitution, update, trial cost) on the FULL scene, one process, BLAS
+    threads as the box configures them.  `value` is (ii)."""
     from oracle import ba_oracle as O
-    from pysfm_amd import synthetic_data as sd
-    s = sd.generate_banded_scene(sample_cams, sample_pts)
-    flags = (np.arange(sample_cams, dtype=np.int32) - 1, np.ones(sample_pts, bool))
-    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
-    sen = O.Sensor.gaussian(1.)
-    t0 = time.time()
-    c0 = O.cost(sen, *a, *flags)
-    mu, su = O.compute_update(sen, *a, *flags, damping=10.)
-    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, *flags)
-    c1 = O.cost(sen, s['K'], R2, t2, X2, *a[4:], *flags)
-    dt = time.time() - t0
+    nc, nt = len(s['R0']), len(s['X0'])
     try:
         import threadpoolctl
         threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] + [1])
     except Exception:
         threads = 1
-    return dict(value=len(s['obs_cam']) / dt, unit='obs/s', cores=int(threads), kind='port',
-                sample='one full LM trial of oracle/ba_oracle.py (NumPy) on a %d-camera / %d-point / %d-observation '
-                       'scene from the same generator, %.1f s; host has %d cores, BLAS threads=%d; '
-                       'cost %.4f -> %.4f' % (sample_cams, sample_pts, len(s['obs_cam']), dt, os.cpu_count(), threads, c0, c1))
+    sen = O.Sensor.gaussian(1.)
+    # (i) per-observation loop: the first `loop_obs` observations (whole tracks), their cameras and points
+    n = int(min(loop_obs, len(s['obs_cam'])))
+    n = int(np.searchsorted(s['obs_pt'], s['obs_pt'][n - 1], side='right')) if n else 0
+    t0 = time.time()
+    O.normal_blocks_loop(sen, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'][:n], s['obs_pt'][:n], s['obs_z'][:n], nc, nt)
+    dt_loop = time.time() - t0
+    # (ii) vectorised port, full scene, one full LM trial
+    flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    t0 = time.time()
+    c0 = O.cost(sen, *a, *flags)
+    t1 = time.time()
+    blocks = O.normal_blocks(sen, *a, nc, nt)
+    t_asm = time.time() - t1
+    del blocks
+    mu, su = O.compute_update(sen, *a, *flags, damping=10.)
+    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, *flags)
+    c1 = O.cost(sen, s['K'], R2, t2, X2, *a[4:], *flags)
+    dt = time.time() - t0 - t_asm                      # (the stand-alone assembly above is timed on its own, not twice)
+    N = len(s['obs_cam'])
+    return dict(value=N / dt, unit='obs/s', cores=int(threads), kind='port',
+                sample='one full LM trial of oracle/ba_oracle.py (vectorised NumPy port of the reference) on the FULL %d-camera / '
+                       '%d-point / %d-observation scene: %.1f s (cost %.4f -> %.4f); assembly alone %.2f s'
+                       % (nc, nt, N, dt, c0, c1, t_asm),
+                per_observation_loop={'value': n / dt_loop, 'unit': 'obs/s', 'cores': 1,
+                                      'sample': 'normal_blocks_loop (literal bundle_adjuster.py:211-234 loop) on the first %d observations, %.2f s' % (n, dt_loop)},
+                vectorised_assembly_obs_per_s=N / t_asm,
+                host={'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(), 'blas_threads': int(threads)},
+                reference_measured_in_survey=SURVEY_REFERENCE_RATES)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write('bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to run fewer ranks than asked for\n' % (n, have))
+        sys.exit(2)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+CONFIGS = {2: dict(cams=100, points=10000), 3: dict(cams=1000, points=100000),
+           4: dict(cams=1000, points=100000, sensor='huber', outliers=.1), 5: dict(cams=10000, points=1000000, strong=True)}
 
 
 def main():
@@ -135,41 +208,70 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--cams', type=int, default=1000)
-    ap.add_argument('--pts-per-gpu', type=int, default=100000)
-    ap.add_argument('--sensor', default='gaussian', choices=['gaussian', 'cauchy', 'huber'])
-    ap.add_argument('--outliers', type=float, default=0.)
+    ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument('--cams', type=int, default=None, help='override the number of cameras of the configuration')
+    ap.add_argument('--pts-per-gpu', type=int, default=None, help='override: points per GPU (weak scaling)')
+    ap.add_argument('--track-len', type=int, default=10)
+    ap.add_argument('--shuffle-points', action='store_true')
+    ap.add_argument('--sensor', default=None, choices=['gaussian', 'cauchy', 'huber'])
+    ap.add_argument('--outliers', type=float, default=None)
+    ap.add_argument('--windows', type=int, default=5, help='extra timed windows of --steps trials after the headline one (min / median)')
+    ap.add_argument('--force-comm', action='store_true', help='run the sharded path with a one-rank RCCL group on one GPU')
+    ap.add_argument('--collectives', default='library', choices=['library', 'torch'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true',
                     help='no HIP events at all in the timed region (for external kernel traces); roofline uses the warm-up timings')
     ap.add_argument('--no-lm', action='store_true', help='skip the untimed full optimize() that yields the RMSE')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args.gpus)                      # does not return
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
+
     import torch
     from pysfm_amd import Bundle, BundleAdjuster, sensor_model
     from pysfm_amd import synthetic_data as sd
     from pysfm_amd._capi import PARAMS_CUR
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU path)'
     comm = None
-    if world > 1 or os.environ.get('BA_FORCE_COMM'):      # BA_FORCE_COMM: exercise the RCCL path on one GPU
+    if world > 1 or args.force_comm:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         from pysfm_amd.distributed import ShardComm, shard_tracks
-        comm = ShardComm()
+        comm = ShardComm(collectives=args.collectives)
     ngpus = world
-    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU path)'
 
     # ---- scene (identical on every rank), then this rank's shard of the tracks
-    nc, nt = args.cams, args.pts_per_gpu * ngpus
-    s = sd.generate_banded_scene(nc, nt, outlier_frac=args.outliers)
+    cfg = CONFIGS[args.config]
+    nc = args.cams or cfg['cams']
+    strong = bool(cfg.get('strong')) and args.pts_per_gpu is None
+    nt = cfg['points'] if strong else (args.pts_per_gpu or cfg['points']) * ngpus
+    sensor_name = args.sensor or cfg.get('sensor', 'gaussian')
+    outliers = cfg.get('outliers', 0.) if args.outliers is None else args.outliers
+    s = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers)
+    obs_cam, obs_pt, obs_z, X0 = s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0']
+    if args.shuffle_points:                        # tracks renumbered at random, observations in random order
+        rs = np.random.RandomState(7)
+        new_id = rs.permutation(nt)                # track k becomes track new_id[k]
+        X0 = np.empty_like(s['X0'])
+        X0[new_id] = s['X0']
+        o = rs.permutation(len(obs_cam))
+        obs_cam, obs_pt, obs_z = obs_cam[o], new_id[obs_pt[o]].astype(np.int32), obs_z[o]
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
-             'huber': sensor_model.HuberModel(.06)}[args.sensor]
-    bundle = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
-                                     sensor_model=model)
+             'huber': sensor_model.HuberModel(.06)}[sensor_name]
+    bundle = Bundle.FromObservations(s['K'], s['R0'], s['t0'], X0, obs_cam, obs_pt, obs_z, sensor_model=model)
     ba = BundleAdjuster(device=local_rank, comm=comm, verbose=False)
     track_ids = None
     if comm is not None:
@@ -185,7 +287,7 @@ def main():
             comm.barrier()
             torch.cuda.synchronize()
 
-    # ---- (untimed) the full LM run of config 3: final cost + reprojection RMSE
+    # ---- (untimed) the full LM run: final cost + reprojection RMSE
     lm = {}
     if not args.no_lm:
         sync()
@@ -199,7 +301,8 @@ def main():
             sq, cnt = comm.allreduce_scalar(sq), comm.allreduce_scalar(cnt)
         lm = dict(final_reproj_rmse=float(np.sqrt(sq / cnt)), lm_steps=ba.num_steps,
                   lm_trials=int(ba.lm_trials), lm_converged=bool(ba.converged),
-                  lm_cost_initial=ba.costs[0], lm_cost_final=ba.costs[-1], lm_wall_s=lm_wall)
+                  lm_cost_initial=ba.costs[0], lm_cost_final=ba.costs[-1], lm_wall_s=lm_wall,
+                  lm_cholesky_rejections=int(getattr(ba, 'cholesky_rejections', 0)))
         # restart from the initial guess for the timed trials
         ba.set_bundle(bundle, track_ids=track_ids)
         be = ba.backend
@@ -235,7 +338,7 @@ def main():
     cand = {k: v for k, v in tm_w.items() if v['launches'] > 0}
     dom = max(cand, key=lambda k: cand[k]['ms']) if cand else 'schur_pairs'
     # timed region: only the dominant kernel keeps its events (an event pair costs a few
-    # microseconds of stream time - bracketing all ~25 launches of a 0.6 ms step would slow it ~15 %)
+    # microseconds of stream time - bracketing all ~25 launches of a 0.3 ms step would slow it ~15 %)
     be.enable_timing(not args.no_kernel_table, only=[dom], stride=4)     # every 4th step: the events themselves cost stream time
     sync()
     state['paths'] = {}
@@ -246,6 +349,19 @@ def main():
     dt = time.time() - t0
     timed_paths = dict(state['paths'])
     tm_dom = be.timings(reset=True)[dom]
+    # further windows of the same length, no events at all: spread of the headline number
+    be.enable_timing(False)
+    window_ms = []
+    for _ in range(max(0, args.windows)):
+        sync()
+        tw = time.time()
+        for _ in range(args.steps):
+            one_trial()
+        sync()
+        wdt = time.time() - tw
+        if comm is not None:
+            wdt = comm_max(comm, wdt)
+        window_ms.append(1e3 * wdt / args.steps)
     if args.no_kernel_table:
         tm_dom, tm, nprof = tm_w[dom], tm_w, max(1, nwarm)
     else:
@@ -270,48 +386,83 @@ def main():
         dom_table = max(ours, key=lambda k: ours[k]['ms']) if ours else dom
         if dom_table != dom or not tm_dom['launches'] or not tm_dom['ms'] > 0.:
             dom, tm_dom = dom_table, ours.get(dom_table, tm_dom)
+        nco, hb = be.nco, be.half_bandwidth
+        ab = lambda k: algorithmic_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, hb)   # noqa: E731
         avg_ms = tm_dom['ms'] / max(1, tm_dom['launches'])
-        nco = be.nco
-        B = algorithmic_bytes(dom, be.nc, nco, be.nt, nobs_local, be.nt, be.half_bandwidth)
+        B = ab(dom)
         achieved = B / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dom)
         copy_gbs = be.measure_copy_bandwidth()
+        sflops = schur_flops(nobs_local, be.nt)
+        schur_ms = ours['schur_pairs']['ms'] / max(1, ours['schur_pairs']['launches']) if 'schur_pairs' in ours else None
+        bound = KERNEL_BOUND.get(dom, 'hbm')
+        roof = {'bound': bound, 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
+                'algorithmic_bytes_per_launch': B, 'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
+                'note': 'HIP events on the launch stream during the timed steps, every 4th step; back-to-back launches of one kernel '
+                        '(the cyclic-reduction levels) share one event pair, avg = elapsed / launches.  bound = what limits this kernel '
+                        '(latency: a chain of dependent pivots, neither HBM nor the matrix cores); achieved / frac are priced against HBM'}
+        if bound == 'mfma' and schur_ms:
+            roof.update({'achieved': sflops / (schur_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': sflops / (schur_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'useful_flops_per_launch': sflops,
+                         'hbm_GBps': achieved})
+        # the pass BASELINE's metric counts: linearise + point inversion + Schur reduction
+        pass_kernels = [k for k in ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs') if k in ours]
+        pass_ms = sum(ours[k]['ms'] for k in pass_kernels) / nprof
+        pass_bytes = 20 * nobs_local + 96 * be.nc + 24 * be.nt + 96 * be.nt + 72 * be.nt + 288 * nco * (hb + 1) + 48 * nco
+        pass_traffic = [pmc_traffic(k)[0] for k in pass_kernels]
+        pass_traffic = sum(pass_traffic) if pass_traffic and all(t is not None for t in pass_traffic) else None
         out = {
             'metric': 'LM-iter throughput (obs/sec) + final reproj RMSE, 1k-cam/100k-pt/1M-obs scene',
             'value': value, 'unit': 'obs/s', 'n_gpus': ngpus, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: %d cameras / %d points / %d observations%s, full LM trial per step '
-                                   '(linearise+damp+pinv+Schur%s+reduced solve+backsub+update+cost), %s sensor model, camera 0 frozen'
-                                   % (nc, nt, nobs_total, ' (%d points / %d obs per GPU)' % (args.pts_per_gpu, nobs_local) if ngpus > 1 else '',
-                                      '+RCCL all-reduce' if ngpus > 1 else '', args.sensor),
-                       'cameras': nc, 'points': nt, 'observations': nobs_total, 'parallelism': 'points sharded x%d' % ngpus,
-                       'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False) else 'torch.distributed (RCCL)')},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
-                         'algorithmic_bytes_per_launch': B,
-                         'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
-                         'note': 'HIP events on the launch stream during the timed steps, every 4th step; back-to-back launches of one kernel (the cyclic-reduction levels) share one event pair, avg = elapsed / launches'},
-            'matrix_cores': {'kernel': 'k_schur_groups_mfma2 (timer schur_pairs)', 'useful_flops_per_launch': schur_flops(nobs_local, be.nt),
-                             'achieved_tflops': schur_flops(nobs_local, be.nt) / max(1e-9, ours['schur_pairs']['ms'] / max(1, ours['schur_pairs']['launches']) * 1e-3) / 1e12
-                             if 'schur_pairs' in ours else None,
+            'ms_per_step_windows': {'n': len(window_ms), 'steps_each': args.steps, 'min': min(window_ms) if window_ms else None,
+                                    'median': float(np.median(window_ms)) if window_ms else None, 'max': max(window_ms) if window_ms else None,
+                                    'note': 'further windows after the headline one, no HIP events in flight'},
+            'config': {'workload': 'BASELINE configs[%d]%s: %d cameras / %d points / %d observations (track length %d)%s, full LM trial per step '
+                                   '(linearise+damp+pinv+Schur%s+reduced solve+backsub+update+cost), %s sensor model%s, camera 0 frozen%s'
+                                   % (args.config - 1, '' if (args.cams is None and args.pts_per_gpu is None and args.track_len == 10) else ' (modified by flags)',
+                                      nc, nt, nobs_total, args.track_len,
+                                      ' (%s scaling: %d points / %d obs on this GPU)' % ('strong' if strong else 'weak', be.nt, nobs_local) if ngpus > 1 else '',
+                                      '+RCCL all-reduce' if comm is not None else '', sensor_name,
+                                      ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
+                                      ', tracks and observations handed over in random order' if args.shuffle_points else ''),
+                       'cameras': nc, 'points': nt, 'observations': nobs_total, 'track_len': args.track_len,
+                       'shuffled': bool(args.shuffle_points), 'parallelism': 'points sharded x%d' % ngpus,
+                       'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False)
+                                                                 else 'torch.distributed (RCCL): ' + str(getattr(comm, 'direct_fallback_reason', None))),
+                       'allreduce_payload_bytes_per_rank_per_trial': None if comm is None else 8 * (be.S_doubles + 6 * nco) + 8 * 2050},
+            'roofline': roof,
+            'roofline_linearise_schur_pass': {
+                'kernels': ['k_' + k for k in pass_kernels], 'ms': pass_ms, 'algorithmic_bytes': pass_bytes,
+                'achieved_GBps': pass_bytes / max(1e-9, pass_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': pass_bytes / max(1e-9, pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'traffic': pass_traffic, 'traffic_over_algorithmic': None if pass_traffic is None else pass_traffic / pass_bytes,
+                'obs_jacobians_per_s': nobs_local / max(1e-9, pass_ms * 1e-3),
+                'note': 'bytes: observations 20/obs + cameras + points + point blocks and inverses (96 + 72 per point) + band S + b, each once; '
+                        'W is never materialised'},
+            'matrix_cores': {'kernel': 'k_schur_groups_mfma2 (timer schur_pairs)', 'useful_flops_per_launch': sflops,
+                             'achieved_tflops': sflops / (schur_ms * 1e-3) / 1e12 if schur_ms else None,
                              'peak_tflops': FP64_MATRIX_PEAK_TFLOPS,
-                             'note': 'fp64 MFMA is used where the path is GEMM-shaped (Schur reduction, cyclic-reduction nodes); informational'},
+                             'note': 'fp64 MFMA is used where the path is GEMM-shaped (Schur reduction, cyclic-reduction nodes)'},
             'kernel_ms_per_step': {k: v['ms'] / nprof for k, v in ours.items()},
             'kernel_launches_per_step': {k: v['launches'] / nprof for k, v in ours.items()},
-            'all_kernels': {'algorithmic_bytes_per_step': int(sum(
-                                algorithmic_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, be.half_bandwidth) * v['launches']
-                                for k, v in ours.items()) / nprof),
+            'all_kernels': {'algorithmic_bytes_per_step': int(sum(ab(k) * v['launches'] for k, v in ours.items()) / nprof),
                             'kernel_ms_per_step': sum(v['ms'] for v in ours.values()) / nprof,
                             'note': 'measured on %d extra trials outside the timed region, every kernel bracketed' % nprof},
-            'reduced_system': {'cameras_optimised': nco, 'block_half_bandwidth': be.half_bandwidth,
+            'reduced_system': {'cameras_optimised': nco, 'block_half_bandwidth': hb,
                                'bytes': 8 * be.S_doubles, 'solve_path': getattr(be, 'last_solve_path', None),
+                               'solve_kind': getattr(be, 'last_solve_kind', None),
                                'timed_trials_by_solver_and_outcome': timed_paths},
         }
         out.update(lm)
         if ngpus == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(300, 30000)
+            if nc <= 1500 and nt <= 150000:
+                out['cpu_baseline'] = cpu_baseline(s)
+            else:       # the oracle's dense S does not fit at this size: bounded sample = the config-3 scene from the same generator
+                out['cpu_baseline'] = cpu_baseline(sd.generate_banded_scene(1000, 100000, track_len=args.track_len, outlier_frac=outliers))
+                out['cpu_baseline']['sample'] += ' (bounded sample: the 1000-camera / 100 000-point scene of the same generator, not the benched one)'
     if comm is not None:
         import ctypes
         import torch.distributed as dist

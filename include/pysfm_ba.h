@@ -68,10 +68,25 @@ const char* ba_last_error(const ba_handle* h);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
 int ba_set_stream(ba_handle* h, void* hip_stream);
 int ba_synchronize(ba_handle* h);
+/* Test / measurement switches; the defaults are the product path and the library never reads the environment.
+ *   "schur"         auto | pairs | groups | mfma1 | mfma   force a Schur-reduction kernel (falls back to pairs when not applicable)
+ *   "solver"        auto | bcr | band | dense | lu         force the reduced solver (lu: always report -1 = caller's LU)
+ *   "point_kernels" auto | v1                              lanes-per-point k_linearize / k_backsub instead of the group-packed ones
+ *   "fuse_cost" "fuse_cam" "fuse_lin"   1 | 0              pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1, 0)
+ *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
+ *   "gm_cap"        n                                      points per group of the MFMA reduction (0 = automatic)
+ *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
+ * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap") take effect at
+ * the next ba_set_problem. */
+int ba_set_option(ba_handle* h, const char* name, const char* value);
 
 /* ---- problem definition: BundleAdjuster.set_bundle (bundle_adjuster.py:54-114)
- * nc cameras, nt tracks, nobs observations ordered by track position
- * (obs_pt non-decreasing), each (camera, track) pair at most once.
+ * nc cameras, nt tracks, nobs observations in ANY order (the reference visits tracks and their measurements
+ * in whatever order its containers yield, bundle_adjuster.py:222-226), each (camera, track) pair at most once.
+ * The library keeps its own internal order - a track's observations by optimised-camera position, tracks with
+ * identical camera lists next to each other, lists ordered by their first optimised camera - so that every
+ * scene reaches the grouped kernels; all host-facing per-track / per-observation arrays (X, HPP, bP, dP, W,
+ * e, r, Jc, Jp) are in the caller's order.  Option "sort_points" = 0 keeps the caller's order as it is.
  *   obs_cam[nobs], obs_pt[nobs]  positions;  obs_z[nobs*2] measurements
  *   K[9]                         calibration (general 3x3)
  *   cam_opt_pos[nc]              position in optim_camera_ids, or -1 (frozen)
@@ -80,6 +95,24 @@ int ba_synchronize(ba_handle* h);
 int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs,
                    const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_z,
                    const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt);
+
+/* What ba_set_problem made of the scene (work lists are built once per problem): out[i] for i < n, see BA_INFO_*.
+ * Tests and bench.py use it to assert that a scene takes the kernels it is meant to take. */
+enum {
+  BA_INFO_POINTS_PERMUTED = 0, /* 1: the internal point order differs from the caller's track order                */
+  BA_INFO_OBS_PERMUTED,        /* 1: the internal observation order differs from the caller's                      */
+  BA_INFO_GROUPS,              /* runs of points with identical camera lists (<= 24 points each)                   */
+  BA_INFO_MFMA_GROUPS,         /* groups of the matrix-core reduction                                              */
+  BA_INFO_POINT_GROUPS,        /* 1: the group-packed k_linearize_groups / k_backsub_groups are used               */
+  BA_INFO_MAX_TRACK_LEN,
+  BA_INFO_HALF_BANDWIDTH,
+  BA_INFO_SCHUR_MFMA,          /* 1: the Schur reduction runs on the fp64 matrix cores                             */
+  BA_INFO_SCHUR_GROUPS,        /* 1: a group reduction (vector or MFMA) applies; 0: k_schur_pairs                  */
+  BA_INFO_LDS_WINDOW_ROWS,     /* band rows of the reduction's LDS accumulation window (0: global atomics only)   */
+  BA_INFO_PAIR_UNITS,
+  BA_INFO_COUNT
+};
+int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);
 
 /* ---- multi-GPU: the shards' collectives inside the library (one all-reduce of the reduced camera
  * system per linearisation, plus the 16 KB trial record), issued with RCCL on the handle's OWN stream - no

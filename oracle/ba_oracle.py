@@ -250,6 +250,10 @@ def schur_complement(HCC_d, HPP_inv, W, bC, bP, obs_cam, obs_pt, cam_opt_pos,
     """(S[nco,nco,6,6], b[nco,6]) per bundle_adjuster.py:259-278, visiting only
     the nonzero HCP blocks.  HCC_d is already damped (bundle_adjuster.py:199-201)."""
     cam_opt_pos = np.asarray(cam_opt_pos)
+    obs_cam, obs_pt = np.asarray(obs_cam), np.asarray(obs_pt)
+    if len(obs_pt) > 1 and np.any(np.diff(obs_pt) < 0):     # the pair enumeration below walks the observations point by
+        order = np.argsort(obs_pt, kind='stable')             # point: bring them into that order (the sums do not care)
+        obs_cam, obs_pt, W = obs_cam[order], obs_pt[order], W[order]
     nco = int(np.sum(cam_opt_pos >= 0))
     S = np.zeros((nco, nco, 6, 6))
     b = np.zeros((nco, 6))

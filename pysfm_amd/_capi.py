@@ -22,6 +22,8 @@ KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 
               'update', 'flatten', 'band_solve', 'eval', 'camera_blocks', 'triangulate',
               'bcr_assemble', 'bcr_eliminate', 'bcr_backsolve', 'dense_solve')
 K_COUNT = len(KERNEL_IDS)
+INFO_KEYS = ('points_permuted', 'obs_permuted', 'groups', 'mfma_groups', 'point_groups', 'max_track_len',
+             'half_bandwidth', 'schur_mfma', 'schur_groups', 'lds_window_rows', 'pair_units')      # BA_INFO_*
 SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky')
 
 _dp = C.POINTER(C.c_double)
@@ -36,7 +38,9 @@ PROTOTYPES = {
     'ba_last_error': (C.c_char_p, [_h]),
     'ba_set_stream': (C.c_int, [_h, C.c_void_p]),
     'ba_synchronize': (C.c_int, [_h]),
+    'ba_set_option': (C.c_int, [_h, C.c_char_p, C.c_char_p]),
     'ba_set_problem': (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, _dp, _dp, _ip, _bp]),
+    'ba_problem_info': (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32]),
     'ba_set_sensor': (C.c_int, [_h, C.c_int, _dp, C.c_int]),
     'ba_set_params': (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     'ba_get_params': (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),

@@ -37,6 +37,8 @@ class ReducedSystemSingular(Exception):
 
 
 class HipBackend(object):
+    lu_fallback_max_unknowns = LU_FALLBACK_MAX_UNKNOWNS     # per instance: BundleAdjuster(lu_fallback_max_unknowns=...)
+
     def __init__(self, device=0):
         self._lib = capi.load()
         self._h = C.c_void_p()
@@ -102,6 +104,13 @@ class HipBackend(object):
     def synchronize(self):
         self._check(self._lib.ba_synchronize(self._h))
 
+    def set_option(self, name, value):
+        """Test / measurement switch of the library (include/pysfm_ba.h ba_set_option); the defaults are the
+        product path.  Options that shape the work lists take effect at the next set_problem."""
+        if isinstance(value, bool):
+            value = '1' if value else '0'
+        self._check(self._lib.ba_set_option(self._h, str(name).encode(), str(value).encode()))
+
     # ---------------------------------------------------------------- problem
     def set_min_half_bandwidth(self, min_hb):
         """Lower bound for the band width of the next set_problem (ranks of the sharded adjuster
@@ -128,6 +137,12 @@ class HipBackend(object):
         if self._torch is not None:
             self._bind_reduced()
         self._bind_dense()
+
+    def problem_info(self):
+        """What ba_set_problem made of the scene (include/pysfm_ba.h BA_INFO_*), as a dict."""
+        out = (C.c_int64 * len(capi.INFO_KEYS))()
+        self._check(self._lib.ba_problem_info(self._h, out, len(capi.INFO_KEYS)))
+        return dict(zip(capi.INFO_KEYS, [int(v) for v in out]))
 
     def _bind_reduced(self):
         torch = self._torch
@@ -254,7 +269,7 @@ class HipBackend(object):
         self._note_solve(info.value)
         if info.value == 0:
             return
-        if info.value > 0 and n > LU_FALLBACK_MAX_UNKNOWNS:
+        if info.value > 0 and n > self.lu_fallback_max_unknowns:
             raise ReducedSystemSingular
         keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
         dC = np.zeros(n)

@@ -7,12 +7,16 @@ the reference keeps in Python: id / mask bookkeeping (``set_bundle``) and the
 damping / accept / reject schedule (``optimize``).  Every numeric step is a HIP
 kernel behind the C ABI of include/pysfm_ba.h:
 
-    compute_cost              -> ba_cost                    (k_cost)
-    prepare_schur_complement  -> ba_linearize               (k_linearize)
-    apply_damping + compute_schur_complement -> ba_schur    (k_point_invert, k_schur_init, k_schur_pairs)
-    solve_motion_normal_eqns  -> ba_solve_reduced (k_band_solve: block-band Cholesky); dense LU fallback
-    backsubstitute            -> ba_backsubstitute          (k_backsub)
-    update_motion / update_structure -> ba_apply_update     (k_apply_update)
+    optimize / step           -> ba_lm_trial                one LM trial = one batch of launches, one synchronisation
+    compute_cost              -> ba_cost                    (k_cost; inside a trial: fused into k_backsub_groups)
+    prepare_schur_complement  -> ba_linearize               (k_linearize_groups | k_linearize, k_camera_blocks)
+    apply_damping + compute_schur_complement -> ba_schur    (k_point_invert_schur_init, k_schur_groups_mfma2;
+                                                             other scenes: k_schur_groups, k_schur_pairs, k_dense_*)
+    solve_motion_normal_eqns  -> ba_solve_reduced           (block cyclic reduction k_bcr_* / k_bcrw_*; k_band_solve for tiny
+                                                             systems; dense blocked Cholesky k_dense_* for wide bands;
+                                                             LU (rocSOLVER) when the system is not positive definite)
+    backsubstitute            -> ba_backsubstitute          (k_backsub_groups | k_backsub)
+    update_motion / update_structure -> ba_apply_update     (k_apply_update; inside a trial: fused into the back-substitution)
 
 During ``optimize`` the accepted and the trial parameter sets both live on the GPU;
 ``self.bundle`` is materialised on the host only when somebody reads it.
@@ -22,7 +26,7 @@ from copy import copy
 import numpy as np
 
 from ._capi import PARAMS_CUR, PARAMS_TRIAL
-from .backend import ReducedSystemSingular, LU_FALLBACK_MAX_UNKNOWNS
+from .backend import ReducedSystemSingular
 from .sensor_model import device_params_of
 
 
@@ -57,11 +61,16 @@ class BundleAdjuster(object):
     # (bundle_adjuster.py:37).
     SCHUR_COMPLIMENT_PINV_THRESHOLD = 1e-5
 
-    def __init__(self, bundle=None, backend=None, device=0, comm=None, verbose=True):
+    def __init__(self, bundle=None, backend=None, device=0, comm=None, verbose=True, lu_fallback_max_unknowns=None):
         '''bundle: a Bundle (ours, or any object with the reference Bundle's attributes).
         backend: compute backend; default = a new HipBackend on `device`.
         comm: optional pysfm_amd.distributed.ShardComm - this process then holds one
-        shard of the tracks and the reduced camera system is all-reduced over RCCL.'''
+        shard of the tracks and the reduced camera system is all-reduced over RCCL.
+        lu_fallback_max_unknowns: a reduced system the device Cholesky rejects as not positive
+        definite is solved by LU like the reference's (numpy.linalg.solve, bundle_adjuster.py:303)
+        up to this many unknowns and reported as ill-conditioned beyond (None = the backend's
+        default, backend.LU_FALLBACK_MAX_UNKNOWNS; float('inf') = strict reference behaviour).'''
+        self._lu_max = lu_fallback_max_unknowns
         self.num_steps = 0
         self.converged = False
         self.costs = []
@@ -87,6 +96,8 @@ class BundleAdjuster(object):
         if self._backend is None:
             from .backend import HipBackend      # raises if libpysfm_ba.so / the GPU is missing
             self._backend = HipBackend(self._device)
+        if self._lu_max is not None and hasattr(self._backend, 'lu_fallback_max_unknowns'):
+            self._backend.lu_fallback_max_unknowns = self._lu_max
         if self._comm is not None and not getattr(self, '_comm_checked', False):
             # the shards' collectives move into the library when they can (RCCL on the handle's own stream);
             # every rank takes the same decision (ShardComm.enable_direct agrees on it)
@@ -144,18 +155,20 @@ class BundleAdjuster(object):
             self.camera_ids = list(range(len(bundle.cameras)))
         else:
             self.camera_ids = [c for c in camera_ids]
-            assert isinstance(self.camera_ids[0], (int, np.integer))
-            assert min(self.camera_ids) >= 0
-            assert max(self.camera_ids) < len(bundle.cameras)
+            if self.camera_ids:
+                assert isinstance(self.camera_ids[0], (int, np.integer))
+                assert min(self.camera_ids) >= 0
+                assert max(self.camera_ids) < len(bundle.cameras)
             self.camera_ids = [int(c) for c in self.camera_ids]
 
         if track_ids is None:
             self.track_ids = list(range(len(bundle.tracks)))
         else:
             self.track_ids = [t for t in track_ids]
-            assert isinstance(self.track_ids[0], (int, np.integer))
-            assert min(self.track_ids) >= 0
-            assert max(self.track_ids) < len(bundle.tracks)
+            if self.track_ids:              # (a shard of a sharded adjuster may be empty)
+                assert isinstance(self.track_ids[0], (int, np.integer))
+                assert min(self.track_ids) >= 0
+                assert max(self.track_ids) < len(bundle.tracks)
             self.track_ids = [int(t) for t in self.track_ids]
 
         self.camera_id_set = set(self.camera_ids)
@@ -207,6 +220,8 @@ class BundleAdjuster(object):
         be.set_sensor(*device_params_of(bundle.sensor_model))
         self._upload(bundle, PARAMS_CUR)
         self._have_blocks = False
+        self._blocks_cache = None
+        self._have_W = False
         self._damp_factor = 1.
         self._say('Configured a bundle adjuster for %d cameras, %d tracks' % (nc, nt))
 
@@ -262,6 +277,8 @@ class BundleAdjuster(object):
         self.lm_trials += 1
         next_cost = None
         be = self.backend
+        self._blocks_cache = None
+        self._have_W = False
         if (self._comm is None or getattr(be, 'direct_comm', False)) and hasattr(be, 'lm_trial'):
             # single GPU - or shards whose collectives the library issues itself (ba_comm_init): the whole trial is
             # one batch of launches with one synchronisation; the cost that comes back is the sum over the shards
@@ -275,7 +292,8 @@ class BundleAdjuster(object):
             self._have_blocks = True
             if info == 0:
                 next_cost = cost
-            elif info > 0 and be.nco * 6 > LU_FALLBACK_MAX_UNKNOWNS:
+            elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', 0):
+                self._note_ill_conditioned(be, damping)
                 return None, None                              # not positive definite, too large for LU: ill-conditioned
         elif self._comm is not None and hasattr(be, 'lm_trial_begin'):
             # sharded: the same batch in two halves around the all-reduce of [S | b]; the ranks' trial
@@ -296,7 +314,8 @@ class BundleAdjuster(object):
                     raise np.linalg.LinAlgError('singular 3x3 point block(s) in plain-inverse mode')
                 if info == 0:
                     next_cost = cost
-                elif info > 0 and be.nco * 6 > LU_FALLBACK_MAX_UNKNOWNS:
+                elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', 0):
+                    self._note_ill_conditioned(be, damping)
                     return None, None
         if next_cost is None:
             try:
@@ -309,9 +328,20 @@ class BundleAdjuster(object):
             self.backend.swap_params()                          # self.bundle = bnext
             self._host_stale = True
             self._have_blocks = False
+            self._blocks_cache = None
             self._cur_cost = next_cost
             return True, next_cost
         return False, next_cost
+
+    def _note_ill_conditioned(self, be, damping):
+        """The device Cholesky found the reduced system not positive definite and it is too large for the LU
+        fallback: the trial is reported as ill-conditioned (the LM loop raises the damping, as it does for the
+        reference's LinAlgError).  Counted, and said once, so that a trajectory that differs from the
+        reference's LU-based one can be diagnosed (lu_fallback_max_unknowns=float('inf') is the strict mode)."""
+        self.cholesky_rejections = getattr(self, 'cholesky_rejections', 0) + 1
+        if self.cholesky_rejections == 1:
+            self._say('reduced system (%d unknowns) not positive definite at damping %g: reported as ill-conditioned '
+                      '(LU fallback only up to %s unknowns)' % (be.nco * 6, damping, getattr(be, 'lu_fallback_max_unknowns', 0)))
 
     # ------------------------------------------------------------------ cost
     def _cost(self, which):
@@ -323,7 +353,13 @@ class BundleAdjuster(object):
     def compute_cost(self, bundle):
         '''Sum of squared residuals over optim_track_ids x optim_camera_ids
         (bundle_adjuster.py:165-171).'''
-        if bundle is self._host_bundle:          # the device copy is the master of this one
+        # The reference evaluates the bundle it is given.  The device copy of the current set stands in for it only
+        # when it IS that bundle: the caller's object, not stale (no step accepted since it was uploaded).  It is
+        # uploaded again even then - the caller may have edited it in place (cameras[i].perturb, transform).
+        if bundle is self._host_bundle and not self._host_stale:
+            self._upload(bundle, PARAMS_CUR)
+            self._have_blocks = False
+            self._blocks_cache = None
             return self._cost(PARAMS_CUR)
         self._upload(bundle, PARAMS_TRIAL)
         return self._cost(PARAMS_TRIAL)
@@ -347,6 +383,8 @@ class BundleAdjuster(object):
         be = self.backend
         be.linearize(PARAMS_CUR)
         self._have_blocks = True
+        self._blocks_cache = None                     # the block properties must reflect THIS linearisation
+        self._have_W = False
         self._damp_factor = 1. + damping
         self._schur_device()
         try:
@@ -373,13 +411,21 @@ class BundleAdjuster(object):
         '''Hessian blocks HCC, HPP, HCP and gradients bC, bP (bundle_adjuster.py:211-234).'''
         self.backend.linearize(PARAMS_CUR, store_W=True)
         self._have_blocks = True
+        self._have_W = True
         self._damp_factor = 1.
         self._blocks_cache = None
 
-    def _blocks(self):
+    def _blocks(self, W=False):
         assert self._have_blocks, 'call prepare_schur_complement() first'
-        if getattr(self, '_blocks_cache', None) is None:
-            d = self.backend.get_blocks(W=True)
+        if W and not getattr(self, '_have_W', False):
+            # the last linearisation (compute_update / a trial) did not keep the per-observation blocks:
+            # linearise the same point again, this time with W
+            self.backend.linearize(PARAMS_CUR, store_W=True)
+            self._have_W = True
+            self._blocks_cache = None
+        c = getattr(self, '_blocks_cache', None)
+        if c is None or (W and c['W'] is None):
+            d = self.backend.get_blocks(W=W)
             if self._comm is not None:          # camera blocks are sums over all shards
                 d['HCC'] = self._comm.allreduce_array(d['HCC'])
                 d['bC'] = self._comm.allreduce_array(d['bC'])
@@ -415,7 +461,7 @@ class BundleAdjuster(object):
         cam, pt, _ = (self._host_bundle.select_observations(self.camera_ids, self.track_ids)
                       if hasattr(self._host_bundle, 'select_observations')
                       else _select_observations_generic(self._host_bundle, self.camera_ids, self.track_ids))
-        out[cam, pt] = self._blocks()['W']
+        out[cam, pt] = self._blocks(W=True)['W']
         return out
 
     @property

@@ -44,6 +44,22 @@ struct DevBuf {
 
 struct TimedLaunch { int id; hipEvent_t a, b; int count; };
 
+// Test / measurement switches (ba_set_option).  The defaults are the product path; nothing in the library
+// reads the environment.
+enum { SCHUR_AUTO = 0, SCHUR_PAIRS, SCHUR_GROUPS, SCHUR_MFMA1, SCHUR_MFMA };
+enum { SOLVER_AUTO = 0, SOLVER_BCR, SOLVER_BAND, SOLVER_DENSE, SOLVER_LU };
+struct Options {
+  int schur = SCHUR_AUTO;
+  int solver = SOLVER_AUTO;
+  bool point_kernels_v1 = false;   // lanes-per-point k_linearize / k_backsub instead of the group-packed kernels
+  bool fuse_cost = true;           // trial cost inside k_backsub_groups
+  bool fuse_cam = true;            // camera blocks inside the MFMA reduction
+  bool fuse_lin = false;           // point blocks + inverses inside the single-wavefront MFMA reduction
+  bool sort_points = true;         // internal point order (ba_set_problem); off = the caller's order as given
+  int gm_cap = 0;                  // points per MFMA group (0 = chosen by ba_set_problem)
+  bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
+};
+
 }  // namespace
 
 struct ba_handle {
@@ -51,6 +67,8 @@ struct ba_handle {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
+  Options opt;
+  std::vector<const void*> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on THIS handle's device
 
   // problem
   int nc = 0, nt = 0, nco = 0;
@@ -85,7 +103,7 @@ struct ba_handle {
   int nchunks = 0, schur_wn = 0;
   DevBuf<SchurGroup> groups, mgroups;
   DevBuf<SchurChunk> gchunks, mchunks;
-  int nmchunks = 0;
+  int nmchunks = 0, nmgroups_total = 0;
   bool groups_ascending = false;
   int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
   int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
@@ -96,6 +114,9 @@ struct ba_handle {
   int ncam_units = 0;
   std::vector<int> h_cam_opt_pos;
   std::vector<unsigned char> h_pt_opt;
+  // internal order (ba_set_problem): internal point i = the caller's track pperm[i], internal observation n = the
+  // caller's operm[n]; empty = identity
+  std::vector<int> pperm, operm;
 
   // parameters: cams[which] = nc x [R(9) | t(3)], X[which] = nt x 3
   DevBuf<double> cams[2], X[2];
@@ -194,6 +215,25 @@ struct ScopedTimer {
   }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: remembered per handle (one handle = one device)
+hipError_t ensure_lds_attr(ba_handle* h, const void* fn) {
+  for (const void* f : h->lds_attr_done) if (f == fn) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) h->lds_attr_done.push_back(fn);
+  return e;
+}
+
+// Host-facing per-point / per-observation arrays go through the internal order of ba_set_problem:
+// rows of w doubles, perm[i] = the caller's index of internal row i.
+void rows_to_internal(const std::vector<int>& perm, const double* src, double* dst, int w) {
+  for (size_t i = 0; i < perm.size(); ++i) std::memcpy(dst + i * w, src + (size_t)perm[i] * w, w * sizeof(double));
+}
+void rows_to_caller(const std::vector<int>& perm, const double* src, double* dst, int w) {
+  for (size_t i = 0; i < perm.size(); ++i) std::memcpy(dst + (size_t)perm[i] * w, src + i * w, w * sizeof(double));
+}
+// device rows -> caller's host array (synchronises the stream when a permutation is in the way)
+int download_rows(ba_handle* h, const std::vector<int>& perm, const double* dev, double* host, size_t n, int w);
+
 inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + kBlock - 1) / kBlock); }
 
 DevProblem dev_problem(const ba_handle* h) {
@@ -210,28 +250,23 @@ inline size_t reduced_doubles(const ba_handle* h) { return (size_t)h->nco * (h->
 
 // k_band_solve is instantiated per block half-bandwidth (compile-time unrolling)
 template <int HB, bool MASKED>
-hipError_t launch_band_solve_hbm(size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+hipError_t launch_band_solve_hbm(ba_handle* h, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
                                  const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_band_solve<HB, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_band_solve<HB, MASKED>); e != hipSuccess) return e;
   hipLaunchKernelGGL((k_band_solve<HB, MASKED>), dim3(1), dim3(kSolveThreads), lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
   return hipGetLastError();
 }
 
 template <int HB>
-hipError_t launch_band_solve_hb(size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+hipError_t launch_band_solve_hb(ba_handle* h, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
                                 const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
-  return mask ? launch_band_solve_hbm<HB, true>(lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info)
-              : launch_band_solve_hbm<HB, false>(lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
+  return mask ? launch_band_solve_hbm<HB, true>(h, lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info)
+              : launch_band_solve_hbm<HB, false>(h, lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
 }
 
-hipError_t launch_band_solve(int hb, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+hipError_t launch_band_solve(ba_handle* h, int hb, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
                              const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info) {
-#define BA_HB_CASE(N) case N: return launch_band_solve_hb<N>(lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
+#define BA_HB_CASE(N) case N: return launch_band_solve_hb<N>(h, lds, stream, nco, ch, S, b, mask, U, y, dinv, x, info);
   switch (hb) {
     BA_HB_CASE(0) BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7)
     BA_HB_CASE(8) BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11) BA_HB_CASE(12) BA_HB_CASE(13) BA_HB_CASE(14)
@@ -254,21 +289,16 @@ int ensure_reduced(ba_handle* h) {
 }
 
 template <int HB>
-hipError_t launch_bcr_eliminate_hb(int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
+hipError_t launch_bcr_eliminate_hb(ba_handle* h, int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
                                    double* P, double* Q, double* G, int* info, double* x) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_bcr_eliminate<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcr_eliminate<HB>); e != hipSuccess) return e;
   hipLaunchKernelGGL(k_bcr_eliminate<HB>, dim3(cnt), dim3(kBcrElimThreads), lds, st, N, s, D, U, f, P, Q, G, info, x);
   return hipSuccess;
 }
 
-hipError_t launch_bcr_eliminate(int hb, int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
+hipError_t launch_bcr_eliminate(ba_handle* h, int hb, int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
                                 double* P, double* Q, double* G, int* info, double* x) {
-#define BA_HB_CASE(K) case K: return launch_bcr_eliminate_hb<K>(cnt, lds, st, N, s, D, U, f, P, Q, G, info, x);
+#define BA_HB_CASE(K) case K: return launch_bcr_eliminate_hb<K>(h, cnt, lds, st, N, s, D, U, f, P, Q, G, info, x);
   switch (hb) {
     BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
     BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11)
@@ -285,11 +315,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
   HIPCHECK(h, h->bcrF.resize((size_t)N * B));
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHECK(h, hipFuncSetAttribute((const void*)k_bcr_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_bcr_backsolve));
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
     hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
@@ -302,7 +328,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
     ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)strides.size());
     for (int s : strides) {
       const int cnt = (N / s + 1) / 2;
-      HIPCHECK(h, launch_bcr_eliminate(hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
+      HIPCHECK(h, launch_bcr_eliminate(h, hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
                                        h->bcrG.p, h->flags.p + 1, h->dC.p));
     }
   }
@@ -322,16 +348,10 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
 
 // factor + solve of one level (both are templates on the half-bandwidth)
 template <int HB>
-hipError_t launch_bcrw_factor_hb(int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
+hipError_t launch_bcrw_factor_hb(ba_handle* h, int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
                                  double* f, double* P, double* Q, double* G, int* info) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_bcrw_factor<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)k_bcrw_solve_mfma<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcrw_factor<HB>); e != hipSuccess) return e;
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcrw_solve_mfma<HB>); e != hipSuccess) return e;
   constexpr int B = 6 * HB;
   hipLaunchKernelGGL(k_bcrw_factor<HB>, dim3(cnt), dim3(kBcrElimThreads), bcrw_factor_lds_bytes(B), st, N, s, D, L, Lv, info);
   const int ntile = (3 * B + 1 + 15) / 16;
@@ -340,9 +360,9 @@ hipError_t launch_bcrw_factor_hb(int cnt, hipStream_t st, int N, int s, const do
   return hipSuccess;
 }
 
-hipError_t launch_bcrw_factor(int hb, int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
+hipError_t launch_bcrw_factor(ba_handle* h, int hb, int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
                               double* f, double* P, double* Q, double* G, int* info) {
-#define BA_HB_CASE(K) case K: return launch_bcrw_factor_hb<K>(cnt, st, N, s, D, L, Lv, U, f, P, Q, G, info);
+#define BA_HB_CASE(K) case K: return launch_bcrw_factor_hb<K>(h, cnt, st, N, s, D, L, Lv, U, f, P, Q, G, info);
   switch (hb) {
     BA_HB_CASE(12) BA_HB_CASE(13) BA_HB_CASE(14) BA_HB_CASE(15) BA_HB_CASE(16) BA_HB_CASE(17) BA_HB_CASE(18) BA_HB_CASE(19)
     BA_HB_CASE(20) BA_HB_CASE(21)
@@ -372,7 +392,7 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
     ScopedTimer tm(h, BA_K_BCR_ELIMINATE, 3 * (int)strides.size());
     for (int s : strides) {
       const int cnt = (N / s + 1) / 2;
-      HIPCHECK(h, launch_bcrw_factor(hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrL.p, h->bcrLv.p, h->bcrU.p, h->bcrF.p, h->bcrP.p,
+      HIPCHECK(h, launch_bcrw_factor(h, hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrL.p, h->bcrLv.p, h->bcrU.p, h->bcrF.p, h->bcrP.p,
                                      h->bcrQ.p, h->bcrG.p, h->flags.p + 1));
       hipLaunchKernelGGL(k_bcrw_products, dim3(cnt, ntask), dim3(1024), 0, h->stream, N, B, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->flags.p + 1);
     }
@@ -392,12 +412,8 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
   const int n = 6 * h->nco;
   HIPCHECK(h, h->denseA.resize((size_t)(n + 1) * n));
   HIPCHECK(h, h->dC.resize((size_t)n + 16));
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHECK(h, hipFuncSetAttribute((const void*)k_dense_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHECK(h, hipFuncSetAttribute((const void*)k_dense_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_panel));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_backsolve));
   int* info = h->flags.p + 1;
   double* A = h->denseA.p;
   const int nsteps = (n + kDcNB - 1) / kDcNB;
@@ -416,6 +432,19 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
   }
   hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(1024), dense_backsolve_lds_bytes(n), h->stream, n, bw, A, h->dC.p, info);
   HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+int download_rows(ba_handle* h, const std::vector<int>& perm, const double* dev, double* host, size_t n, int w) {
+  if (n == 0) return BA_OK;
+  if (perm.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(host, dev, n * w * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return BA_OK;
+  }
+  std::vector<double> tmp(n * w);
+  HIPCHECK(h, hipMemcpyAsync(tmp.data(), dev, n * w * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  rows_to_caller(perm, tmp.data(), host, w);
   return BA_OK;
 }
 
@@ -463,10 +492,14 @@ __global__ __launch_bounds__(256) void k_copy_doubles(const double* __restrict__
 }
 
 // The achievable HBM rate of this box (SURVEY 8d asks for the roofline fraction against it as well as
-// against the 8 TB/s of the data sheet): a plain streaming copy, 16 bytes per lane per iteration.
-__global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+// against the 8 TB/s of the data sheet): a streaming copy, ONE 16-byte element per lane, no loop, non-temporal
+// loads and stores.  tools/copy_probe.hip compares the forms on an MI355X (read + write, 1 GiB): this one
+// 6.5 TB/s; the grid-stride loop it replaces 4.5 - 5.0; four elements per lane in flight 5.6 - 6.2;
+// hipMemcpyAsync device-to-device 5.2.  (The guide quotes 6.29 TB/s for its float4 copy.)
+typedef float copy_vec __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_copy(const copy_vec* __restrict__ src, copy_vec* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 extern "C" {
@@ -539,6 +572,36 @@ int ba_destroy(ba_handle* h) {
   return BA_OK;
 }
 
+int ba_set_option(ba_handle* h, const char* name, const char* value) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, name && value, BA_ERR_INVALID_ARG, "ba_set_option: NULL argument");
+  const std::string n(name), v(value);
+  auto choice = [&](std::initializer_list<const char*> names, int& out) {
+    int i = 0;
+    for (const char* c : names) { if (v == c) { out = i; return true; } ++i; }
+    return false;
+  };
+  auto flag = [&](bool& out) {
+    if (v == "1" || v == "on" || v == "true") { out = true; return true; }
+    if (v == "0" || v == "off" || v == "false") { out = false; return true; }
+    return false;
+  };
+  bool ok = false;
+  if (n == "schur") ok = choice({"auto", "pairs", "groups", "mfma1", "mfma"}, h->opt.schur);
+  else if (n == "solver") ok = choice({"auto", "bcr", "band", "dense", "lu"}, h->opt.solver);
+  else if (n == "point_kernels") { int c = 0; ok = choice({"auto", "v1"}, c); if (ok) h->opt.point_kernels_v1 = c == 1; }
+  else if (n == "fuse_cost") ok = flag(h->opt.fuse_cost);
+  else if (n == "fuse_cam") ok = flag(h->opt.fuse_cam);
+  else if (n == "fuse_lin") ok = flag(h->opt.fuse_lin);
+  else if (n == "sort_points") ok = flag(h->opt.sort_points);
+  else if (n == "solve_trace") ok = flag(h->opt.solve_trace);
+  else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
+  else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);
+  if (!ok) return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: bad value '%s' for option '%s'", value, name);
+  h->inv_valid = h->fac_valid = false;          // a different kernel family may need different by-products
+  return BA_OK;
+}
+
 int ba_set_stream(ba_handle* h, void* hip_stream) {
   if (!h) return BA_ERR_INVALID_ARG;
   HIPCHECK(h, hipSetDevice(h->device));
@@ -572,16 +635,15 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
   HIPCHECK(h, hipSetDevice(h->device));
 
-  // validate + CSR offsets by point
-  std::vector<int> off((size_t)nt + 1, 0);
+  // validate; caller-order CSR by point (any observation order is accepted: stable counting sort)
+  std::vector<int> coff((size_t)nt + 1, 0);
   for (int64_t n = 0; n < nobs; ++n) {
     const int c = obs_cam[n], k = obs_pt[n];
     if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%lld]=%d out of range", (long long)n, c);
     if (k < 0 || k >= nt) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%lld]=%d out of range", (long long)n, k);
-    if (n > 0 && k < obs_pt[n - 1]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: observations must be ordered by track position (obs %lld)", (long long)n);
-    off[(size_t)k + 1] += 1;
+    coff[(size_t)k + 1] += 1;
   }
-  for (int k = 0; k < nt; ++k) off[(size_t)k + 1] += off[k];
+  for (int k = 0; k < nt; ++k) coff[(size_t)k + 1] += coff[k];
   // optimised-camera positions must be a permutation of 0..nco-1
   int nco = 0;
   for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) ++nco;
@@ -594,6 +656,96 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       seen[p] = 1;
     }
   }
+  // ---- internal order.  The reference visits tracks and their measurements in any order
+  // (bundle_adjuster.py:222-226); the kernels want (a) a track's observations by ascending optimised-camera
+  // position, frozen cameras first, and (b) tracks with identical camera lists next to each other, lists
+  // ordered by their first optimised camera (image sequences: the reduction's LDS window slides along the
+  // band).  So: rank the cameras (frozen ones by index, then the optimised ones by position), sort each
+  // track's observations by rank, sort the tracks by (first optimised position, rank list).  `pperm` /
+  // `operm` map internal point / observation indices to the caller's; every host-facing array goes through
+  // them (identity for a scene that already comes in this order: then they stay empty).
+  std::vector<int> by_pt((size_t)nobs);                      // caller observation ids, grouped by caller point
+  {
+    std::vector<int> cursor(coff.begin(), coff.end() - 1);
+    for (int64_t n = 0; n < nobs; ++n) by_pt[(size_t)cursor[obs_pt[n]]++] = (int)n;
+  }
+  std::vector<int> crank((size_t)nc);
+  {
+    int f = 0;
+    const int nfrozen = nc - nco;
+    for (int i = 0; i < nc; ++i) crank[i] = cam_opt_pos[i] < 0 ? f++ : nfrozen + cam_opt_pos[i];
+  }
+  const bool sort_points = h->opt.sort_points;
+  if (sort_points) {
+    for (int k = 0; k < nt; ++k) {
+      int* b0 = by_pt.data() + coff[k];
+      int* b1 = by_pt.data() + coff[(size_t)k + 1];
+      auto less = [&](int a, int b) { return crank[obs_cam[a]] < crank[obs_cam[b]]; };
+      if (!std::is_sorted(b0, b1, less)) std::stable_sort(b0, b1, less);
+    }
+  }
+  for (int k = 0; k < nt; ++k) {                             // each (camera, track) pair at most once (bundle.py: a dict per track)
+    std::vector<int> seen;
+    const int L = coff[(size_t)k + 1] - coff[k];
+    if (sort_points) {
+      for (int q = coff[k] + 1; q < coff[(size_t)k + 1]; ++q)
+        if (obs_cam[by_pt[q]] == obs_cam[by_pt[q - 1]])
+          return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in camera %d", k, obs_cam[by_pt[q]]);
+    } else if (L > 1) {
+      seen.assign(by_pt.begin() + coff[k], by_pt.begin() + coff[(size_t)k + 1]);
+      for (int& v : seen) v = obs_cam[v];
+      std::sort(seen.begin(), seen.end());
+      if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
+        return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in one camera", k);
+    }
+  }
+  std::vector<int> pperm((size_t)nt);
+  for (int k = 0; k < nt; ++k) pperm[k] = k;
+  if (sort_points && nt > 1) {
+    std::vector<int> minpos((size_t)nt, INT32_MAX);
+    for (int k = 0; k < nt; ++k)
+      for (int q = coff[k]; q < coff[(size_t)k + 1]; ++q) {
+        const int p = cam_opt_pos[obs_cam[by_pt[q]]];
+        if (p >= 0) { minpos[k] = p; break; }               // (sorted by rank: the first optimised one is the smallest)
+      }
+    auto less = [&](int a, int b) {
+      if (minpos[a] != minpos[b]) return minpos[a] < minpos[b];
+      const int la = coff[(size_t)a + 1] - coff[a], lb = coff[(size_t)b + 1] - coff[b];
+      const int* pa = by_pt.data() + coff[a];
+      const int* pb = by_pt.data() + coff[b];
+      for (int q = 0; q < std::min(la, lb); ++q) {
+        const int ra = crank[obs_cam[pa[q]]], rb = crank[obs_cam[pb[q]]];
+        if (ra != rb) return ra < rb;
+      }
+      return la < lb;
+    };
+    if (!std::is_sorted(pperm.begin(), pperm.end(), less)) std::stable_sort(pperm.begin(), pperm.end(), less);
+  }
+  // internal observation arrays + CSR
+  std::vector<int> ic((size_t)nobs), ip((size_t)nobs), operm((size_t)nobs), off((size_t)nt + 1, 0);
+  std::vector<double2> iz((size_t)nobs);
+  std::vector<unsigned char> ipt_opt((size_t)nt);
+  {
+    size_t w = 0;
+    for (int i = 0; i < nt; ++i) {
+      const int k = pperm[i];
+      ipt_opt[i] = pt_opt[k];
+      for (int q = coff[k]; q < coff[(size_t)k + 1]; ++q, ++w) {
+        const int n = by_pt[q];
+        operm[w] = n; ic[w] = obs_cam[n]; ip[w] = i;
+        iz[w] = double2{obs_z[2 * (size_t)n], obs_z[2 * (size_t)n + 1]};
+      }
+      off[(size_t)i + 1] = (int)w;
+    }
+  }
+  bool pid = true, oid = true;
+  for (int i = 0; i < nt && pid; ++i) pid = pperm[i] == i;
+  for (int64_t n = 0; n < nobs && oid; ++n) oid = operm[(size_t)n] == (int)n;
+  h->pperm = pid ? std::vector<int>() : pperm;
+  h->operm = oid ? std::vector<int>() : operm;
+  // from here on everything is in internal order
+  obs_cam = ic.data(); obs_pt = ip.data(); pt_opt = ipt_opt.data();
+
   // Schur work units: (point, row tile, col tile >= row tile)
   std::vector<SchurUnit> units;
   units.reserve((size_t)nt);
@@ -740,7 +892,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     int longest = 0;
     for (const SchurGroup& r : runs) longest = std::max(longest, r.pt_end - r.pt_begin);
     while (cap < longest && split_runs(cap, false) > (size_t)slots) cap += kGmPts;     // (beyond the longest run nothing changes)
-    if (const char* e = getenv("BA_GM_CAP")) cap = std::max(kGmPts, atoi(e));     // tuning aid
+    if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);     // tuning aid (ba_set_option "gm_cap")
     split_runs(cap, true);
     chunk_groups(kGmChunk, mgroups, mlo, mhi, mchunks);
     // worth it only when points really share camera lists
@@ -761,6 +913,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->schur_wn = wn;
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
+  h->nmgroups_total = (int)mgroups.size();
   h->groups_ascending = groups_ascending;
   h->ngroups = (int)groups.size();
   {
@@ -803,7 +956,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   if (nobs) {
     HIPCHECK(h, hipMemcpyAsync(h->obs_cam.p, obs_cam, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->obs_pt.p, obs_pt, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->obs_z.p, obs_z, nobs * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->obs_z.p, iz.data(), nobs * sizeof(double2), hipMemcpyHostToDevice, h->stream));
   }
   HIPCHECK(h, hipMemcpyAsync(h->pt_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (nc) HIPCHECK(h, hipMemcpyAsync(h->cam_opt_pos.p, cam_opt_pos, nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -881,6 +1034,12 @@ int ba_set_params(ba_handle* h, int which, const double* R, const double* t, con
     std::memcpy(&packed[(size_t)i * 12 + 9], t + (size_t)i * 3, 3 * sizeof(double));
   }
   if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->cams[p].p, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  std::vector<double> Xi;
+  if (h->nt && !h->pperm.empty()) {
+    Xi.resize((size_t)h->nt * 3);
+    rows_to_internal(h->pperm, X, Xi.data(), 3);
+    X = Xi.data();
+  }
   if (h->nt) HIPCHECK(h, hipMemcpyAsync(h->X[p].p, X, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   h->have_params[p] = true;
@@ -896,7 +1055,7 @@ int ba_get_params(ba_handle* h, int which, double* R, double* t, double* X) {
   HIPCHECK(h, hipSetDevice(h->device));
   std::vector<double> packed((size_t)h->nc * 12);
   if (h->nc) HIPCHECK(h, hipMemcpyAsync(packed.data(), h->cams[p].p, packed.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (h->nt && X) HIPCHECK(h, hipMemcpyAsync(X, h->X[p].p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (X) { const int rc = download_rows(h, h->pperm, h->X[p].p, X, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < h->nc; ++i) {
     if (R) std::memcpy(R + (size_t)i * 9, &packed[(size_t)i * 12], 9 * sizeof(double));
@@ -957,10 +1116,12 @@ int ba_eval_observations(ba_handle* h, int which, double* e, double* r, double* 
                        h->cams[p].p, h->X[p].p, de, dr, dJc, dJp);
   }
   HIPCHECK(h, hipGetLastError());
-  if (e) HIPCHECK(h, hipMemcpyAsync(e, de, 2 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (r) HIPCHECK(h, hipMemcpyAsync(r, dr, 2 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (Jc) HIPCHECK(h, hipMemcpyAsync(Jc, dJc, 12 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (Jp) HIPCHECK(h, hipMemcpyAsync(Jp, dJp, 6 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  int rc = BA_OK;
+  if (e && rc == BA_OK) rc = download_rows(h, h->operm, de, e, N, 2);
+  if (r && rc == BA_OK) rc = download_rows(h, h->operm, dr, r, N, 2);
+  if (Jc && rc == BA_OK) rc = download_rows(h, h->operm, dJc, Jc, N, 12);
+  if (Jp && rc == BA_OK) rc = download_rows(h, h->operm, dJp, Jp, N, 6);
+  if (rc != BA_OK) return rc;
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   return BA_OK;
 }
@@ -999,7 +1160,7 @@ int launch_point_blocks(ba_handle* h, int p, double* Wd) {
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_LINEARIZE);
     const long long threads = (long long)h->nt << h->glog;
-    if (!Wd && h->point_groups && !getenv("BA_POINT_KERNELS_V1")) {
+    if (!Wd && h->point_groups && !h->opt.point_kernels_v1) {
       const int per_block = kBlock / kWave;
       hipLaunchKernelGGL(k_linearize_groups, dim3((h->ngroups + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
                          dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p);
@@ -1051,7 +1212,7 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
   // then nothing is launched here at all), but that was measured 8 us per trial SLOWER: two more LDS round
   // trips and a 3x3 inversion per batch on a wavefront that has a SIMD to itself cost more than the two
   // kernels they replace.
-  static const bool fuse_lin = getenv("BA_FUSE_LIN") != nullptr;
+  const bool fuse_lin = h->opt.fuse_lin;
   if (!(fuse && fuse_lin)) {
     int rc = launch_point_blocks(h, p, Wd);
     if (rc == BA_OK && !fuse) rc = launch_camera_blocks(h, p, h->nt == 0);      // k_linearize cleared HCC / bC otherwise
@@ -1065,6 +1226,18 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
 }
 
 }  // namespace
+
+int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_problem_info: call ba_set_problem first");
+  REQUIRE(h, out && n >= 1, BA_ERR_INVALID_ARG, "ba_problem_info: bad argument");
+  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
+  const int64_t v[BA_INFO_COUNT] = {
+      h->pperm.empty() ? 0 : 1, h->operm.empty() ? 0 : 1, h->ngroups, (int64_t)h->nmgroups_total, h->point_groups ? 1 : 0,
+      h->group_maxL, h->hb, groups_ok && mfma_reduction_possible(h) ? 1 : 0, groups_ok ? 1 : 0, h->schur_wn, h->nunits};
+  for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];
+  return BA_OK;
+}
 
 int ba_linearize(ba_handle* h, int which, int store_W) {
   if (!h) return BA_ERR_INVALID_ARG;
@@ -1092,10 +1265,11 @@ int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP
     hpp6.resize((size_t)h->nt * 6);
     HIPCHECK(h, hipMemcpyAsync(hpp6.data(), h->HPP.p, hpp6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
-  if (bP && h->nt) HIPCHECK(h, hipMemcpyAsync(bP, h->bP.p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (bP) { const int rc = download_rows(h, h->pperm, h->bP.p, bP, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   if (W && h->nobs) {
     REQUIRE(h, h->W.p && h->W.n >= (size_t)h->nobs * 18, BA_ERR_STATE, "ba_get_blocks: W was not stored (ba_linearize store_W=0)");
-    HIPCHECK(h, hipMemcpyAsync(W, h->W.p, (size_t)h->nobs * 18 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const int rc = download_rows(h, h->operm, h->W.p, W, (size_t)h->nobs, 18);
+    if (rc != BA_OK) return rc;
   }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   if (HCC) {   // device keeps the upper triangle only
@@ -1106,7 +1280,7 @@ int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP
   if (HPP) {
     for (int k = 0; k < h->nt; ++k) {
       const double* s = &hpp6[(size_t)k * 6];
-      double* d = HPP + (size_t)k * 9;
+      double* d = HPP + (size_t)(h->pperm.empty() ? k : h->pperm[k]) * 9;
       d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[1]; d[4] = s[3]; d[5] = s[4]; d[6] = s[2]; d[7] = s[4]; d[8] = s[5];
     }
   }
@@ -1121,15 +1295,15 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   HIPCHECK(h, hipSetDevice(h->device));
   int rc = ensure_reduced(h);
   if (rc != BA_OK) return rc;
-  const char* force_schur = getenv("BA_SCHUR");          // "pairs" / "groups" / "mfma": pick the reduction kernel (tests)
+  const int force_schur = h->opt.schur;          // ba_set_option "schur": pick the reduction kernel (tests)
   const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
   const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
   const bool mfma_possible = mfma_reduction_possible(h);
-  const bool force_v1 = force_schur && strcmp(force_schur, "mfma1") == 0;     // the single-wavefront-per-group form
+  const bool force_v1 = force_schur == SCHUR_MFMA1;     // the single-wavefront-per-group form
   const bool dense = h->dense_mode && h->nt > 0 && h->nco > 0;
-  const bool use_mfma = !dense && (force_schur ? ((strcmp(force_schur, "mfma") == 0 || force_v1) && mfma_possible)
+  const bool use_mfma = !dense && (force_schur ? ((force_schur == SCHUR_MFMA || force_v1) && mfma_possible)
                                                      : (groups_ok && mfma_possible));
-  const bool use_groups = force_schur ? (strcmp(force_schur, "groups") == 0 && groups_possible) : groups_ok;
+  const bool use_groups = force_schur ? (force_schur == SCHUR_GROUPS && groups_possible) : groups_ok;
   // point blocks and camera blocks: normally in HPP / bP (k_linearize) and HCC / bC (k_camera_blocks);
   // ba_lm_trial leaves both to the MFMA reduction, which linearises every observation anyway
   const bool fuse_lin = use_mfma && !h->point_blocks_valid;
@@ -1204,11 +1378,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                        h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
   } else if (use_v2) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
-    static bool attr_m2 = false;
-    if (!attr_m2) {
-      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_m2 = true;
-    }
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma2));
     hipLaunchKernelGGL(k_schur_groups_mfma2, dim3(h->nmchunks), dim3(kGm2Block), schur_mfma2_lds_bytes(h->schur_wn, h->hb + 1), h->stream,
                        dev_problem(h), h->cams[p].p, h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->fac.p, h->S, h->b, damping,
                        fuse_cam ? 1 : 0);
@@ -1217,12 +1387,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     const int NW = kGmBlock / kWave;
     const size_t lds = (size_t)NW * 2 * kGmK * kGmLd * sizeof(double) + (size_t)NW * 16 * sizeof(int) + (size_t)NW * 64 * sizeof(double) +
                        (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
-    static bool attr_m = false;
-    if (!attr_m) {
-      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_m = true;
-    }
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma<false>));
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma<true>));
     if (fuse_lin)
       hipLaunchKernelGGL(k_schur_groups_mfma<true>, dim3(h->nmchunks), dim3(kGmBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
                          h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b, damping, fuse_cam ? 1 : 0,
@@ -1241,12 +1407,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     const int NW = kGroupBlock / kWave;
     const size_t lds = (size_t)NW * 64 * 24 * sizeof(double) + (size_t)NW * 16 * sizeof(int) +
                        (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
-    static bool attr_g = false;
-    if (!attr_g) {
-      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_groups<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_g = true;
-    }
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups<1>));
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups<2>));
     const int maxpairs_rounds = h->group_rounds >= 1 ? h->group_rounds : 2;
     if (maxpairs_rounds == 1)
       hipLaunchKernelGGL(k_schur_groups<1>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
@@ -1259,11 +1421,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     const int NW = kSchurBlock / kWave;
     const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int) +
                        (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIPCHECK(h, hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_pairs));
     hipLaunchKernelGGL(k_schur_pairs, dim3(h->nchunks), dim3(kSchurBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
                        h->X[p].p, h->units.p, h->chunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
   }
@@ -1323,7 +1481,7 @@ int ba_get_point_inverses(ba_handle* h, double* out) {
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   for (int k = 0; k < h->nt; ++k) {
     const double* s = &s6[(size_t)k * 6];
-    double* d = out + (size_t)k * 9;
+    double* d = out + (size_t)(h->pperm.empty() ? k : h->pperm[k]) * 9;
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[1]; d[4] = s[3]; d[5] = s[4]; d[6] = s[2]; d[7] = s[4]; d[8] = s[5];
   }
   return BA_OK;
@@ -1374,9 +1532,9 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_solve_reduced: call ba_schur first");
   REQUIRE(h, info, BA_ERR_INVALID_ARG, "ba_solve_reduced: info is NULL");
   if (h->nco == 0) { *info = 0; h->have_solution = true; return BA_OK; }
-  const char* force = getenv("BA_SOLVER");
-  const bool dense_ok = 6 * h->nco <= kDcMaxN && !(force && strcmp(force, "lu") == 0);
-  const bool use_dense = dense_ok && (h->hb > kMaxBandSolve || (force && strcmp(force, "dense") == 0));
+  const int force = h->opt.solver;                 // ba_set_option "solver"
+  const bool dense_ok = 6 * h->nco <= kDcMaxN && force != SOLVER_LU;
+  const bool use_dense = dense_ok && (h->hb > kMaxBandSolve || force == SOLVER_DENSE);
   if (h->hb > kMaxBandSolve && !use_dense) { *info = -1; return BA_OK; }     // caller's dense LU
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, h->Ufac.resize(std::max<size_t>(1, reduced_doubles(h))));
@@ -1392,12 +1550,12 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   // multi-CU path: block cyclic reduction when the band is narrow enough for dense
   // (6 hb)^2 blocks in LDS and there are enough super-blocks to parallelise over
   const bool bcr_ok = h->hb >= 1 && h->hb <= kBcrMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
-  const bool use_bcr = force ? (strcmp(force, "bcr") == 0 && bcr_ok) : bcr_ok;
+  const bool use_bcr = force ? (force == SOLVER_BCR && bcr_ok) : bcr_ok;
   const size_t lds_budget = 160 * 1024;
   const int ch = band_solve_chunk(h->hb, lds_budget);
   size_t lds = 0;
   const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
-  const bool use_bcrw = force ? (strcmp(force, "bcr") == 0 && bcrw_ok) : bcrw_ok;
+  const bool use_bcrw = force ? (force == SOLVER_BCR && bcrw_ok) : bcrw_ok;
   h->solve_kind = use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
   if (use_dense) {
     int rc = solve_dense_chol(h, dmask);
@@ -1412,7 +1570,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     if (ch < 1) { *info = -1; return BA_OK; }
     lds = band_solve_lds_bytes(h->hb, ch);
     ScopedTimer tm(h, BA_K_BAND_SOLVE);
-    hipError_t le = launch_band_solve(h->hb, lds, h->stream, h->nco, ch, h->S, h->b, dmask, h->Ufac.p, h->ysol.p,
+    hipError_t le = launch_band_solve(h, h->hb, lds, h->stream, h->nco, ch, h->S, h->b, dmask, h->Ufac.p, h->ysol.p,
                                       h->dinv.p, h->dC.p, h->flags.p + 1);
     if (le != hipSuccess) return h->fail(BA_ERR_HIP, "k_band_solve launch failed: %s", hipGetErrorString(le));
   }
@@ -1423,19 +1581,19 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   const int inf = inf6[0];
 #ifdef BA_BCR_PROFILE
-  if (getenv("BA_SOLVE_TRACE") && use_bcr)
+  if (h->opt.solve_trace && use_bcr)
     fprintf(stderr, "[k_bcr_eliminate level 0 node 2] load %d chol %d trsm %d products %d store %d cycles\n", inf6[8], inf6[9],
             inf6[10], inf6[11], inf6[12]);
-  if (getenv("BA_SOLVE_TRACE") && use_bcr)
+  if (h->opt.solve_trace && use_bcr)
     fprintf(stderr, "    factor+solve, summed over the block steps: diagonal factor (wave 0) %d, phase 1 %d, phase 2 %d, phase 3 %d\n",
             inf6[14], inf6[15], inf6[16], inf6[17]);
-  if (getenv("BA_SOLVE_TRACE") && use_bcr) {
+  if (h->opt.solve_trace && use_bcr) {
     fprintf(stderr, "    phase 1 of block step 1, per wavefront:");
     for (int w = 0; w < 16; ++w) fprintf(stderr, " %d", inf6[44 + w]);
     fprintf(stderr, "\n");
   }
 #endif
-  if (getenv("BA_SOLVE_TRACE") && !use_bcr && !use_bcrw && !use_dense)
+  if (h->opt.solve_trace && !use_bcr && !use_bcrw && !use_dense)
     fprintf(stderr, "[k_band_solve] nco=%d hb=%d ch=%d lds=%zu B | forward: %d cycles, %d ticks(100MHz) | total: %d cycles, %d ticks\n",
             h->nco, h->hb, ch, lds, inf6[2], inf6[3], inf6[4], inf6[5]);
   *info = inf;
@@ -1472,11 +1630,11 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
     ScopedTimer tm(h, BA_K_BACKSUB);
     const long long threads = (long long)h->nt << h->glog;
     h->cost_fused = false;
-    if (h->point_groups && !getenv("BA_POINT_KERNELS_V1")) {
+    if (h->point_groups && !h->opt.point_kernels_v1) {
       // inside ba_lm_trial the cost of the trial set rides along as well (k_cost's work)
       const int per_block = kBlock / kWave;
       const int nblk = std::min(kCostBlocks, (h->ngroups + per_block - 1) / per_block);
-      const bool fuse_cost = fuse_update && !getenv("BA_NO_FUSE_COST");
+      const bool fuse_cost = fuse_update && h->opt.fuse_cost;
       hipLaunchKernelGGL(k_backsub_groups, dim3(nblk), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
                          h->groups.p, h->ngroups, h->dC.p, h->HPPinv.p, h->bP.p, h->dP.p, -1.0,
                          fuse_update ? h->cams[1 - p].p : (double*)nullptr, fuse_update ? h->X[1 - p].p : (double*)nullptr,
@@ -1490,7 +1648,7 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
     }
   }
   HIPCHECK(h, hipGetLastError());
-  if (dP && h->nt) HIPCHECK(h, hipMemcpyAsync(dP, h->dP.p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (dP) { const int rc = download_rows(h, h->pperm, h->dP.p, dP, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   if (dC || dP) HIPCHECK(h, hipStreamSynchronize(h->stream));   // dC is caller memory
   h->have_backsub = true;
   return BA_OK;
@@ -1508,7 +1666,14 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   if (motion) {
     sign = 1.0;
     if (h->nco) HIPCHECK(h, hipMemcpyAsync(h->dC.p, motion, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (h->nt) HIPCHECK(h, hipMemcpyAsync(h->dP.p, structure, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->nt && !h->pperm.empty()) {
+      std::vector<double> si((size_t)h->nt * 3);
+      rows_to_internal(h->pperm, structure, si.data(), 3);
+      HIPCHECK(h, hipMemcpyAsync(h->dP.p, si.data(), si.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIPCHECK(h, hipStreamSynchronize(h->stream));         // `si` goes out of scope
+    } else if (h->nt) {
+      HIPCHECK(h, hipMemcpyAsync(h->dP.p, structure, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     h->have_backsub = h->have_solution = false;   // dC / dP now hold the caller's update
   } else {
     REQUIRE(h, h->have_backsub, BA_ERR_STATE, "ba_apply_update: no update on the device (call ba_backsubstitute)");
@@ -1630,7 +1795,7 @@ int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   // with the MFMA reduction the camera blocks come out of the reduction itself: one launch and one pass
   // over the observations less
   const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
-  const bool fuse = !getenv("BA_SCHUR") && !getenv("BA_NO_FUSE") && groups_ok && mfma_reduction_possible(h);
+  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && groups_ok && mfma_reduction_possible(h);
   int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
   h->defer = false;
@@ -1715,7 +1880,8 @@ int ba_triangulate(ba_handle* h, int which, double rcond, double* X) {
   HIPCHECK(h, hipGetLastError());
   if (which == BA_PARAMS_CUR) h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
   if (X && h->nt) {
-    HIPCHECK(h, hipMemcpyAsync(X, h->X[p].p, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const int rc = download_rows(h, h->pperm, h->X[p].p, X, (size_t)h->nt, 3);
+    if (rc != BA_OK) return rc;
     HIPCHECK(h, hipStreamSynchronize(h->stream));
   }
   return BA_OK;
@@ -1746,13 +1912,14 @@ int ba_measure_copy_bandwidth(ba_handle* h, int64_t bytes, int32_t repeats, doub
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, bytes >= 4096 && repeats >= 1 && gbytes_per_s, BA_ERR_INVALID_ARG, "ba_measure_copy_bandwidth: bad argument");
   HIPCHECK(h, hipSetDevice(h->device));
-  const size_t n = (size_t)bytes / sizeof(double2);
-  DevBuf<double2> src, dst;
+  const size_t n = (size_t)bytes / sizeof(copy_vec);
+  REQUIRE(h, (n + 255) / 256 < (1ull << 31), BA_ERR_INVALID_ARG, "ba_measure_copy_bandwidth: too large");
+  DevBuf<copy_vec> src, dst;
   HIPCHECK(h, src.resize(n)); HIPCHECK(h, dst.resize(n));
-  HIPCHECK(h, hipMemsetAsync(src.p, 0, n * sizeof(double2), h->stream));
+  HIPCHECK(h, hipMemsetAsync(src.p, 0, n * sizeof(copy_vec), h->stream));
   hipEvent_t a, b;
   HIPCHECK(h, hipEventCreate(&a)); HIPCHECK(h, hipEventCreate(&b));
-  const int grid = 256 * 32;
+  const unsigned grid = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, h->stream, src.p, dst.p, n);     // warm-up
   HIPCHECK(h, hipEventRecord(a, h->stream));
   for (int r = 0; r < repeats; ++r) hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, h->stream, src.p, dst.p, n);
@@ -1762,7 +1929,7 @@ int ba_measure_copy_bandwidth(ba_handle* h, int64_t bytes, int32_t repeats, doub
   HIPCHECK(h, hipEventElapsedTime(&ms, a, b));
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   src.release(); dst.release();
-  *gbytes_per_s = 2.0 * (double)(n * sizeof(double2)) * repeats / (ms * 1e-3) / 1e9;           // read + write
+  *gbytes_per_s = 2.0 * (double)(n * sizeof(copy_vec)) * repeats / (ms * 1e-3) / 1e9;           // read + write
   return BA_OK;
 }
 

@@ -23,6 +23,7 @@ Usage (torchrun, one rank per GPU):
 """
 import contextlib
 import os
+import sys
 
 import numpy as np
 
@@ -45,11 +46,18 @@ def shard_bounds(track_lengths, world_size):
 
 
 def shard_tracks(bundle, rank, world_size):
-    """Track ids owned by `rank` (a contiguous, observation-balanced range)."""
+    """Track ids owned by `rank`: the tracks ordered by their first camera (the caller's order when that is
+    already ascending), cut into `world_size` consecutive, observation-balanced ranges - a rank's partial
+    reduced system then covers one stretch of the band instead of all of it, whatever order the tracks
+    come in.  A rank may get no tracks when there are more ranks than usable tracks."""
     cam, trk, _ = bundle.observation_table()
-    L = np.bincount(trk, minlength=len(bundle.tracks))
-    b = shard_bounds(L, world_size)
-    return list(range(b[rank], b[rank + 1]))
+    nt = len(bundle.tracks)
+    L = np.bincount(trk, minlength=nt)
+    first = np.full(nt, np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(first, trk, cam)
+    order = np.arange(nt) if np.all(np.diff(first) >= 0) else np.argsort(first, kind='stable')
+    b = shard_bounds(L[order], world_size)
+    return [int(k) for k in order[b[rank]:b[rank + 1]]]
 
 
 def _stream_of(backend):
@@ -63,7 +71,12 @@ class ShardComm(object):
     """The collectives the sharded adjuster needs, over torch.distributed
     ('nccl' = RCCL on ROCm for GPU tensors, 'gloo' for the CPU tests)."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, collectives='library'):
+        """collectives: 'library' = the data-path collectives are issued by libpysfm_ba itself (RCCL on the
+        handle's own stream, ba_comm_*) whenever that is possible; 'torch' = always through torch.distributed."""
+        assert collectives in ('library', 'torch')
+        self.collectives = collectives
+        self.direct_fallback_reason = None
         import torch
         import torch.distributed as dist
         assert dist.is_initialized(), 'call torch.distributed.init_process_group first'
@@ -80,16 +93,24 @@ class ShardComm(object):
     def enable_direct(self, backend):
         """Move the data-path collectives into the library (ba_comm_*: RCCL issued on the handle's own stream,
         a sharded trial is then ONE C call).  Collective: every rank calls it, and every decision on the way is
-        agreed on over torch.distributed, so that either all ranks switch or none does.  BA_COMM=torch keeps
-        the torch.distributed path.  Returns True when the library took over."""
+        agreed on over torch.distributed, so that either all ranks switch or none does.
+        ShardComm(collectives='torch') keeps the torch.distributed path.  Returns True when the library took
+        over; otherwise `direct_fallback_reason` says why not, and anything other than a deliberate choice is
+        reported on stderr (a broken direct path must not hide behind a merely slower number)."""
         torch, dist = self._torch, self._dist
         self.direct = None
-        ok = (os.environ.get('BA_COMM', '') != 'torch' and dist.get_backend(self.group) == 'nccl'
-              and hasattr(backend, 'comm_attach'))
-        if ok:
-            ok = backend.comm_load(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'))
-        if not self._agree(ok):
-            return False
+        why = None
+        if self.collectives == 'torch':
+            why = "collectives='torch' requested"
+        elif dist.get_backend(self.group) != 'nccl':
+            why = 'process group backend is %s, not nccl (RCCL)' % dist.get_backend(self.group)
+        elif not hasattr(backend, 'comm_attach'):
+            why = 'backend %s has no collectives of its own' % type(backend).__name__
+        elif not backend.comm_load(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')):
+            why = 'ba_comm_load could not resolve RCCL from torch\'s librccl.so'
+        if not self._agree(why is None):
+            return self._stay_on_torch(why or 'another rank could not switch', quiet=why is not None and (
+                self.collectives == 'torch' or dist.get_backend(self.group) != 'nccl' or not hasattr(backend, 'comm_attach')))
         ident = torch.zeros(128, dtype=torch.uint8, device=self.device)
         if self.rank == 0:
             ident.copy_(torch.frombuffer(bytearray(backend.comm_unique_id()), dtype=torch.uint8))
@@ -98,14 +119,23 @@ class ShardComm(object):
             backend.comm_attach(bytes(ident.cpu().numpy().tobytes()), self.rank, self.world_size)
             got = backend.comm_allreduce_sum([self.rank + 1.0, 1.0])           # self-test against the known answer
             ok = abs(got[0] - self.world_size * (self.world_size + 1) / 2.0) < 1e-9 and abs(got[1] - self.world_size) < 1e-9
-        except Exception:                                                        # noqa: BLE001 - any failure: stay on torch
+            if not ok:
+                why = 'self-test all-reduce returned %r' % (list(got),)
+        except Exception as e:                                                   # noqa: BLE001 - any failure: stay on torch, loudly
             ok = False
+            why = 'ba_comm_init / self-test failed: %s: %s' % (type(e).__name__, e)
         if not self._agree(ok):
             if getattr(backend, 'direct_comm', False):
                 backend.comm_detach()
-            return False
+            return self._stay_on_torch(why or 'another rank failed its self-test', quiet=False)
         self.direct = backend
         return True
+
+    def _stay_on_torch(self, why, quiet):
+        self.direct_fallback_reason = why
+        if not quiet:
+            sys.stderr.write('[pysfm_amd rank %d] collectives stay on torch.distributed: %s\n' % (self.rank, why))
+        return False
 
     def _agree(self, flag):
         t = self._torch.tensor([1.0 if flag else 0.0], dtype=self._torch.float64, device=self.device)

@@ -42,7 +42,7 @@ def generate_sequence(nframes, npts, msm_noise=.02):
 
 def generate_banded_scene(ncams, npts, track_len=10, seed=654, spacing=.2, msm_noise=.02,
                           init_perturbation=.01, init_seed=1888, outlier_frac=0., outlier_range=10.,
-                          outlier_seed=101):
+                          outlier_seed=101, init_mode='pose'):
     """Cameras k = 0..ncams-1 at (k*spacing, 0, 0) + N(0,.02^2) jitter, rotations
     exp(.02 randn(3)); points uniform in x in [0, spacing*ncams], y in [-1,1],
     z in [4,8], sorted by x; each point observed by the `track_len` consecutive
@@ -53,7 +53,15 @@ def generate_banded_scene(ncams, npts, track_len=10, seed=654, spacing=.2, msm_n
     Returns a dict: K, true (R,t,X), initial guess (R0,t0,X0) = truth perturbed by
     N(0, init_perturbation^2) on all 6 camera + 3 point parameters (cf.
     test_bundle.py:165-167; camera 0 is left at its true pose since it is the frozen
-    gauge camera), obs_cam, obs_pt (sorted by point), obs_z, outlier mask."""
+    gauge camera), obs_cam, obs_pt (sorted by point), obs_z, outlier mask.
+
+    init_mode: how the 6 camera numbers are applied.  'pose' (default): the camera is turned about its OWN
+    centre and the centre moved, R0 = R exp(dw), c0 = c + dc, t0 = -R0 c0 - the size of the initial error does
+    not depend on where the world origin is.  'params': Camera.perturb on the raw parameters, R0 = R exp(dw),
+    t0 = t + dt (bundle.py:76-80), which turns the camera about the WORLD origin: a camera 200 units down the
+    track (config 3) is thrown 2 units off by 0.01 rad, one 2000 units away (config 5) by 20 units, with a
+    quarter of the points behind the cameras - a start no LM run recovers from.  Round 1 used 'params'."""
+    assert init_mode in ('pose', 'params')
     assert ncams >= track_len
     rs = np.random.RandomState(seed)
     X = np.empty((npts, 3))
@@ -85,7 +93,10 @@ def generate_banded_scene(ncams, npts, track_len=10, seed=654, spacing=.2, msm_n
     dcam = ri.randn(ncams, 6) * init_perturbation
     dcam[0] = 0.
     R0 = np.einsum('nij,njk->nik', R, _so3_exp_batch(dcam[:, :3]))
-    t0 = t + dcam[:, 3:]
+    if init_mode == 'pose':
+        t0 = -np.einsum('nij,nj->ni', R0, centers + dcam[:, 3:])
+    else:
+        t0 = t + dcam[:, 3:]
     X0 = X + ri.randn(npts, 3) * init_perturbation
     return dict(K=np.eye(3), R=R, t=t, X=X, R0=R0, t0=t0, X0=X0,
                 obs_cam=obs_cam, obs_pt=obs_pt, obs_z=z, outliers=outliers)

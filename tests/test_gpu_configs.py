@@ -1,0 +1,448 @@
+"""BASELINE configurations 4 and 5 at full size, scenes handed over in arbitrary track order, and the sharded path
+on a config-5-shaped scene - through the C ABI, against the CPU oracle where it finishes in seconds and through
+size-independent properties elsewhere.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances as in test_gpu_parity.py (fp64 everywhere): blocks / S / b 1e-11 ... 1e-10 relative to the largest entry,
+solves 1e-8 ... 1e-9, LM trajectories 1e-6 (the north-star tolerance).
+"""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import ba_oracle as O
+from test_gpu_parity import DEFAULT_OPTIONS, banded, close, default_flags, load_problem, sensor_params  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-11
+
+
+@pytest.fixture(scope='module')
+def be():
+    from pysfm_amd.backend import HipBackend
+    b = HipBackend(0)
+    yield b
+    b.close()
+
+
+@pytest.fixture(autouse=True)
+def _default_options(request):
+    yield
+    if 'be' in request.fixturenames:
+        b = request.getfixturevalue('be')
+        for k, v in DEFAULT_OPTIONS.items():
+            b.set_option(k, v)
+
+
+def shuffled(s, seed=7):
+    """The same scene with the tracks renumbered at random and the observations in random order."""
+    rs = np.random.RandomState(seed)
+    nt = len(s['X0'])
+    new_id = rs.permutation(nt)
+    X0 = np.empty_like(s['X0'])
+    X0[new_id] = s['X0']
+    o = rs.permutation(len(s['obs_cam']))
+    out = dict(s)
+    out.update(X0=X0, obs_cam=s['obs_cam'][o], obs_pt=new_id[s['obs_pt'][o]].astype(np.int32), obs_z=s['obs_z'][o])
+    return out, new_id, o
+
+
+# ------------------------------------------------------------------ any track order (bundle_adjuster.py:222-226)
+@pytest.mark.parametrize('sensor,L', [(O.Sensor.gaussian(1.), 10), (O.Sensor.cauchy(.05), 7), (O.Sensor.huber(.06), 12)])
+def test_shuffled_tracks_full_step_vs_oracle(be, sensor, L):
+    """Tracks and observations in random order, a frozen camera in the middle, tracks that are not optimised:
+    every host-facing array must come back in the CALLER's order and agree with the oracle on the same arrays."""
+    nc, nt = 40, 1500
+    s, new_id, o = shuffled(banded(nc, nt, track_len=L, outlier_frac=.03))
+    cam_opt_pos = np.arange(nc, dtype=np.int32) - 1
+    cam_opt_pos[17] = -1
+    cam_opt_pos[18:] -= 1
+    pt_opt = np.ones(nt, np.uint8)
+    pt_opt[::7] = 0
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
+    info = be.problem_info()
+    assert info['points_permuted'] == 1 and info['obs_permuted'] == 1
+    assert info['point_groups'] == 1 and info['schur_groups'] == 1         # the grouped kernels, despite the order
+    # per-observation values in the caller's observation order
+    ev = be.eval_observations(0)
+    r0, Jc0, Jp0 = O.jacobians(sensor, *a)
+    close(ev['e'], O.reproj_error(*a), 1e-13)
+    close(ev['r'], r0, 1e-13)
+    close(ev['Jc'], Jc0, 1e-12)
+    close(ev['Jp'], Jp0, 1e-12)
+    close(be.cost(0), O.cost(sensor, *a, cam_opt_pos, pt_opt), 1e-12)
+    mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=3., return_parts=True)
+    be.linearize(0, store_W=True)
+    blk = be.get_blocks(W=True)
+    for k in ('HCC', 'bC', 'HPP', 'bP', 'W'):
+        close(blk[k], parts[k], TIGHT)
+    be.schur(0, 3., 1e-5)
+    S, b = be.get_reduced()
+    close(S, parts['S'], TIGHT)
+    close(b, parts['b'], TIGHT)
+    close(be.get_point_inverses(), parts['HPP_inv'], 1e-10)
+    be.solve_reduced(None)
+    dC = be.get_solution()
+    dP = be.backsubstitute(0)
+    close(-dC, mu, 1e-8)
+    close(-dP[pt_opt.astype(bool)], su, 1e-8)
+    # the whole trial in one call, and the trial parameter set in the caller's order
+    infoT, cost = be.lm_trial(3., 1e-5, None)
+    assert infoT == 0
+    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, cam_opt_pos, pt_opt)
+    Rg, tg, Xg = be.get_params(1)
+    close(Xg, X2, 1e-9)
+    close(tg, t2, 1e-9)
+    close(cost, O.cost(sensor, s['K'], R2, t2, X2, *a[4:], cam_opt_pos, pt_opt), 1e-8)
+    # caller-supplied structure update goes through the permutation too
+    delta = np.random.RandomState(1).randn(nt, 3) * 1e-3
+    be.apply_update(0, 1, np.zeros((be.nco, 6)), delta)
+    close(be.get_params(1)[2], s['X0'] + delta * pt_opt[:, None], 1e-14)
+    # triangulation writes X in the caller's order
+    Xt = be.triangulate(1)
+    close(Xt, O.triangulate_all(s['K'], s['R0'], s['t0'], s['obs_cam'], s['obs_pt'], s['obs_z'], nt), 1e-6)
+
+
+def test_internal_order_is_invisible(be):
+    """The same scene sorted and shuffled, with and without the internal sort: identical S, b (as sets of blocks the
+    band layout is the same) and updates mapped through the renumbering."""
+    nc, nt = 60, 3000
+    s0 = banded(nc, nt, track_len=8)
+    s1, new_id, o = shuffled(s0)
+    flags = default_flags(nc, nt)
+    res = []
+    for s, sort in ((s0, 1), (s0, 0), (s1, 1)):
+        be.set_option('sort_points', sort)
+        load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+        be.linearize(0)
+        be.schur(0, 2., 1e-5)
+        S, b = be.get_reduced()
+        be.solve_reduced(None)
+        res.append((S, b, be.get_solution(), be.backsubstitute(0), be.problem_info()))
+    assert res[0][4]['points_permuted'] == 0 and res[1][4]['points_permuted'] == 0 and res[2][4]['points_permuted'] == 1
+    for r in res[1:]:
+        close(r[0], res[0][0], 1e-12)
+        close(r[1], res[0][1], 1e-12)
+        close(r[2], res[0][2], 1e-9)
+    close(res[1][3], res[0][3], 1e-9)
+    close(res[2][3][new_id], res[0][3], 1e-9)
+
+
+def test_shuffled_config3_takes_the_matrix_core_path(be):
+    """BASELINE config 3 with its tracks in random order: same kernels as the sorted scene (the verdict's cliff), same
+    reduced system, same LM trajectory."""
+    from pysfm_amd import Bundle, BundleAdjuster
+    nc, nt = 1000, 100000
+    s0 = banded(nc, nt)
+    s1, new_id, o = shuffled(s0)
+    flags = default_flags(nc, nt)
+    bands = []
+    for s in (s0, s1):
+        load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+        info = be.problem_info()
+        assert info['schur_mfma'] == 1 and info['point_groups'] == 1 and info['half_bandwidth'] == 9
+        i2, c2 = be.lm_trial(10., 1e-5, None)
+        assert i2 == 0
+        St, bt = be.reduced_tensors()
+        bands.append((St.cpu().numpy().copy(), bt.cpu().numpy().copy(), c2, info))
+    assert bands[0][3]['mfma_groups'] == bands[1][3]['mfma_groups']
+    close(bands[1][0], bands[0][0], 1e-11)
+    close(bands[1][1], bands[0][1], 1e-11)
+    assert abs(bands[1][2] - bands[0][2]) <= 1e-10 * bands[0][2]
+    costs = []
+    for s in (s0, s1):
+        b0 = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+        ba = BundleAdjuster(b0, verbose=False)
+        ba.optimize(max_steps=6)
+        costs.append(np.array(ba.costs))
+        ba.backend.close()
+    assert len(costs[0]) == len(costs[1])
+    close(costs[1], costs[0], 1e-6)
+
+
+# ------------------------------------------------------------------ config 4 at full size
+@pytest.mark.parametrize('sensor', [O.Sensor.huber(.06), O.Sensor.cauchy(.05)], ids=['huber', 'cauchy'])
+def test_config4_properties_1000x100k_outliers(be, sensor):
+    """BASELINE config 4 (1000 cams / 100k pts / 1M obs, 10 % gross outliers, Huber k = .06; Cauchy sigma = .05 is the
+    reference's own robustifier): cost, blocks and b against the oracle (O(N)), rows of S against the oracle on the
+    tracks that touch them, symmetry / band structure, linearity over point shards."""
+    nc, nt = 1000, 100000
+    s = banded(nc, nt, outlier_frac=.1)
+    assert abs(s['outliers'].mean() - .1) < 1e-3
+    flags = default_flags(nc, nt)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, *flags, sensor)
+    close(be.cost(0), O.cost(sensor, *a, *flags), 1e-12)
+    HCC, HPP, W, bC, bP = O.normal_blocks(sensor, *a, nc, nt)
+    be.linearize(0)
+    blk = be.get_blocks()
+    close(blk['HCC'], HCC, TIGHT)
+    close(blk['bC'], bC, TIGHT)
+    close(blk['HPP'], HPP, TIGHT)
+    close(blk['bP'], bP, TIGHT)
+    be.schur(0, 10., 1e-5)
+    S, b = be.get_reduced()
+    close(S, S.transpose(1, 0, 3, 2), 1e-13)
+    i, j = np.nonzero(np.abs(S).sum(axis=(2, 3)))
+    assert np.max(np.abs(i - j)) == 9
+    HPPi = O.invert_point_blocks(O.damp_blocks(HPP, 10.), 1e-5)
+    T = W @ HPPi[s['obs_pt']]
+    pos = flags[0][s['obs_cam']]
+    kk = pos >= 0
+    b0 = bC[1:].copy()
+    np.subtract.at(b0, pos[kk], np.einsum('nij,nj->ni', T[kk], bP[s['obs_pt'][kk]]))
+    close(b, b0, 1e-10)
+    rows = [0, 317, 998]
+    touching = np.zeros(nt, bool)
+    for r in rows:
+        touching[s['obs_pt'][pos == r]] = True
+    m = touching[s['obs_pt']]
+    S0, _ = O.schur_complement(O.damp_blocks(HCC, 10.), HPPi, W[m], bC, bP, s['obs_cam'][m], s['obs_pt'][m], flags[0])
+    for r in rows:
+        close(S[r], S0[r], 1e-10)
+    half = nt // 2
+    parts = []
+    for lo, hi in ((0, half), (half, nt)):
+        m = (s['obs_pt'] >= lo) & (s['obs_pt'] < hi)
+        be.set_problem(nc, hi - lo, s['obs_cam'][m], s['obs_pt'][m] - lo, s['obs_z'][m], s['K'], flags[0], np.ones(hi - lo, np.uint8))
+        be.set_sensor(*sensor_params(sensor))
+        be.set_params(0, s['R0'], s['t0'], s['X0'][lo:hi])
+        be.linearize(0)
+        be.schur(0, 10., 1e-5)
+        parts.append(be.get_reduced())
+    close(parts[0][0] + parts[1][0], S, 1e-11)
+    close(parts[0][1] + parts[1][1], b, 1e-11)
+
+
+@pytest.mark.parametrize('model', ['huber', 'cauchy'])
+def test_config4_full_lm_rejects_the_outliers(model):
+    """Full LM on config 4: the robust cost falls monotonically and the INLIERS end at the measurement noise although
+    10 % of the observations are gross outliers (an L2 cost would be dragged far off)."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    s = banded(1000, 100000, outlier_frac=.1)
+    sm = sensor_model.HuberModel(.06) if model == 'huber' else sensor_model.CauchyModel(.05)
+    b0 = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=sm)
+    ba = BundleAdjuster(b0, verbose=False)
+    ba.optimize(max_steps=25)
+    assert all(c1 < c0 for c0, c1 in zip(ba.costs, ba.costs[1:]))
+    e = ba.backend.eval_observations(0, e=True, r=False, Jc=False, Jp=False)['e']
+    inl = ~s['outliers']
+    rmse_in = float(np.sqrt(np.sum(e[inl] ** 2) / inl.sum()))
+    assert rmse_in < 1.25 * .02 * np.sqrt(2), rmse_in
+    ba.backend.close()
+
+
+# ------------------------------------------------------------------ config 5 at full size on ONE GPU
+@pytest.fixture(scope='module')
+def config5():
+    return banded(10000, 1000000)
+
+
+def _chunked_cost(sensor, s, flags, chunk=2000000):
+    tot = 0.
+    for lo in range(0, len(s['obs_cam']), chunk):
+        sl = slice(lo, lo + chunk)
+        tot += O.cost(sensor, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'][sl], s['obs_pt'][sl], s['obs_z'][sl], *flags)
+    return tot
+
+
+def test_config5_properties_10000x1M(be, config5):
+    """BASELINE config 5 size (10 000 cams / 1M pts / 10M obs) unsharded on one GPU: cost vs the oracle; blocks, b and
+    rows of S vs the oracle on the window of tracks that touch them; band structure; linearity over 8 point shards
+    (what the 8 ranks would add up); the 1112-node cyclic reduction vs the sequential band Cholesky and vs LAPACK on a
+    masked sub-block."""
+    s = config5
+    nc, nt = 10000, 1000000
+    flags = default_flags(nc, nt)
+    sensor = O.Sensor.gaussian(1.)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, sensor)
+    info = be.problem_info()
+    assert info['schur_mfma'] == 1 and info['point_groups'] == 1 and info['half_bandwidth'] == 9
+    assert abs(be.cost(0) - _chunked_cost(sensor, s, flags)) <= 1e-11 * be.cost(0)
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    St, bt = be.reduced_tensors()
+    band = St.cpu().numpy().reshape(nc - 1, 10, 6, 6).copy()
+    bfull = bt.cpu().numpy().reshape(nc - 1, 6).copy()
+    assert np.abs(band[:, 9]).max() > 0                               # the band is as wide as the tracks are long
+    assert np.abs(band[-9:][np.arange(9)[:, None] + np.arange(10)[None, :] >= 9]).max() == 0      # nothing beyond the last camera
+    close(band[:, 0], band[:, 0].transpose(0, 2, 1), 1e-13)         # diagonal blocks stored in full, symmetric
+    # window: the tracks seen by cameras 5000 .. 5040 -> oracle on that sub-scene gives their rows of S and b exactly
+    lo_c, hi_c = 5000, 5040
+    touching = np.zeros(nt, bool)
+    touching[s['obs_pt'][(s['obs_cam'] >= lo_c) & (s['obs_cam'] <= hi_c)]] = True
+    m = touching[s['obs_pt']]
+    ids = np.nonzero(touching)[0]
+    renum = -np.ones(nt, np.int64)
+    renum[ids] = np.arange(len(ids))
+    sub = (s['K'], s['R0'], s['t0'], s['X0'][ids], s['obs_cam'][m], renum[s['obs_pt'][m]].astype(np.int32), s['obs_z'][m])
+    HCC, HPP, W, bC, bP = O.normal_blocks(sensor, *sub, nc, len(ids))
+    blk = be.get_blocks()
+    close(blk['HPP'][ids], HPP, TIGHT)
+    close(blk['bP'][ids], bP, TIGHT)
+    close(blk['HCC'][lo_c:hi_c + 1], HCC[lo_c:hi_c + 1], TIGHT)
+    close(blk['bC'][lo_c:hi_c + 1], bC[lo_c:hi_c + 1], TIGHT)
+    # reduced rows of cameras lo_c .. hi_c: restrict the oracle to a camera window so that its dense S stays small
+    w0, w1 = lo_c - 12, hi_c + 12
+    cpos = -np.ones(nc, np.int32)
+    cpos[w0:w1 + 1] = np.arange(w1 - w0 + 1)
+    HPPi = O.invert_point_blocks(O.damp_blocks(HPP, 10.), 1e-5)
+    S0, b0 = O.schur_complement(O.damp_blocks(HCC, 10.), HPPi, W, bC, bP, sub[4], sub[5], cpos)
+    for cam in range(lo_c, hi_c + 1):
+        p, q = cam - 1, cam - w0                                       # optimised position in the full / windowed system
+        for d in range(10):
+            close(band[p, d], S0[q, q + d], 1e-10, atol=1e-9 * np.abs(band[p, 0]).max())
+        close(bfull[p], b0[q], 1e-10)
+    # linearity over 8 contiguous point shards (the 8 ranks of config 5)
+    from pysfm_amd.distributed import shard_bounds
+    bounds = shard_bounds(np.full(nt, 10), 8)
+    acc_S, acc_b = np.zeros_like(band), np.zeros_like(bfull)
+    be.set_min_half_bandwidth(9)
+    for g in range(8):
+        lo, hi = bounds[g], bounds[g + 1]
+        mm = (s['obs_pt'] >= lo) & (s['obs_pt'] < hi)
+        be.set_problem(nc, hi - lo, s['obs_cam'][mm], s['obs_pt'][mm] - lo, s['obs_z'][mm], s['K'], flags[0], np.ones(hi - lo, np.uint8))
+        be.set_sensor(0, np.eye(2).reshape(4))
+        be.set_params(0, s['R0'], s['t0'], s['X0'][lo:hi])
+        assert be.half_bandwidth == 9
+        be.linearize(0)
+        be.schur(0, 10., 1e-5)
+        St, bt = be.reduced_tensors()
+        acc_S += St.cpu().numpy().reshape(band.shape)
+        acc_b += bt.cpu().numpy().reshape(bfull.shape)
+    be.set_min_half_bandwidth(0)
+    close(acc_S, band, 1e-11)
+    close(acc_b, bfull, 1e-11)
+
+
+def test_config5_reduced_solve_1112_nodes(be, config5):
+    """The 11-level cyclic reduction over 1112 super-blocks (59 994 unknowns) against the single-workgroup band
+    Cholesky on the same device-resident system, and against LAPACK on a 300-camera sub-block (all other camera
+    parameters masked out: the reference's row / column deletion, bundle_adjuster.py:290-299)."""
+    s = config5
+    nc, nt = 10000, 1000000
+    flags = default_flags(nc, nt)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'bcr' and be.last_solve_path == 'band'
+    x = be.get_solution()
+    be.set_option('solver', 'band')
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'band'
+    close(x, be.get_solution(), 1e-9)
+    be.set_option('solver', 'auto')
+    # residual of the full solve through the band itself:  S x = b
+    St, bt = be.reduced_tensors()
+    band = St.cpu().numpy().reshape(nc - 1, 10, 6, 6)
+    bb = bt.cpu().numpy().reshape(nc - 1, 6)
+    y = np.einsum('nab,nb->na', band[:, 0], x)
+    for d in range(1, 10):
+        y[:-d] += np.einsum('nab,nb->na', band[:-d, d], x[d:])
+        y[d:] += np.einsum('nba,nb->na', band[:-d, d], x[:-d])
+    assert np.abs(y - bb).max() <= 1e-9 * np.abs(bb).max()
+    # masked sub-block vs LAPACK
+    p0, p1 = 4000, 4300
+    mask = np.zeros((nc - 1) * 6, np.uint8)
+    mask[6 * p0:6 * p1] = 1
+    mask[6 * p0 + 3::97] = 0                                           # and some single parameters inside it
+    be.solve_reduced(mask)
+    xm = be.get_solution().reshape(-1)
+    assert np.all(xm[mask == 0] == 0)
+    n = 6 * (p1 - p0)
+    A = np.zeros((n, n))
+    for i in range(p0, p1):
+        for d in range(10):
+            if i + d < p1:
+                blk = band[i, d]
+                A[6 * (i - p0):6 * (i - p0) + 6, 6 * (i + d - p0):6 * (i + d - p0) + 6] = blk
+                if d:
+                    A[6 * (i + d - p0):6 * (i + d - p0) + 6, 6 * (i - p0):6 * (i - p0) + 6] = blk.T
+    keep = np.nonzero(mask[6 * p0:6 * p1])[0]
+    ref = np.linalg.solve(A[np.ix_(keep, keep)], bb.reshape(-1)[6 * p0:6 * p1][keep])
+    close(xm[6 * p0:6 * p1][keep], ref, 1e-9)
+
+
+def test_config5_full_lm_converges(config5):
+    from pysfm_amd import Bundle, BundleAdjuster
+    s = config5
+    b0 = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(b0, verbose=False)
+    ba.optimize(max_steps=12)
+    assert all(c1 < c0 for c0, c1 in zip(ba.costs, ba.costs[1:]))
+    e = ba.backend.eval_observations(0, e=True, r=False, Jc=False, Jp=False)['e']
+    rmse = float(np.sqrt(np.sum(e * e) / len(e)))
+    assert rmse < 1.1 * .02 * np.sqrt(2), rmse
+    assert ba.backend.last_solve_kind == 'bcr'
+    ba.backend.close()
+
+
+# ------------------------------------------------------------------ sharded, config-5-shaped
+def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd import synthetic_data as sd
+    from pysfm_amd.distributed import ShardComm, shard_tracks
+    s = sd.generate_banded_scene(nc, nt)
+    if shuffle:
+        s = shuffled(s)[0]
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    comm = ShardComm()
+    ba = BundleAdjuster(device=0, comm=comm, verbose=False)          # all ranks on GPU 0
+    ids = shard_tracks(b, rank, world)
+    ba.set_bundle(b, track_ids=ids)
+    ba.optimize(max_steps=5)
+    X = comm.gather_points(ba)
+    R, t, _ = ba.backend.get_params(0)
+    # the shard's cameras: a contiguous stretch of the sequence even when the tracks came shuffled
+    cams = np.unique(s['obs_cam'][np.isin(s['obs_pt'], ids)])
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), costs=np.array(ba.costs), X=X, R=R, t=t, trials=ba.lm_trials,
+             nbytes=comm.bytes_reduced, hb=ba.backend.half_bandwidth, kind=ba.backend.last_solve_kind, cam_lo=cams.min(),
+             cam_hi=cams.max(), ntracks=len(ids))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,shuffle', [(2, False), (4, True)])
+def test_ranks_on_one_gpu_config5_shape(tmp_path, world, shuffle):
+    """A config-5-shaped scene (2400 cameras: 267 cyclic-reduction nodes, 9 levels; 60 000 points) split by points over
+    `world` processes on the one GPU (gloo group staging the collectives through the host): the sharded LM trajectory,
+    cameras and points must reproduce the unsharded run; each shard covers one stretch of the camera sequence."""
+    import socket
+    import torch.multiprocessing as mp
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd import synthetic_data as sd
+    nc, nt = 2400, 60000
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(_c5_rank_worker, args=(world, port, str(tmp_path), nc, nt, shuffle), nprocs=world, join=True)
+    s = sd.generate_banded_scene(nc, nt)
+    if shuffle:
+        s = shuffled(s)[0]
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(verbose=False)
+    ba.set_bundle(b)
+    ba.optimize(max_steps=5)
+    R1, t1, X1 = ba.backend.get_params(0)
+    total = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        assert int(d['trials']) == ba.lm_trials and int(d['nbytes']) > 0
+        assert int(d['hb']) == 9 and str(d['kind']) == 'bcr'
+        close(d['costs'], np.array(ba.costs), 1e-9)
+        close(d['t'], t1, 1e-8)
+        close(d['X'], X1, 1e-8)
+        assert int(d['cam_hi']) - int(d['cam_lo']) <= nc // world + 40
+        total += int(d['ntracks'])
+    assert total == nt
+    ba.backend.close()
