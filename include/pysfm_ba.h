@@ -69,7 +69,8 @@ const char* ba_last_error(const ba_handle* h);
 int ba_set_stream(ba_handle* h, void* hip_stream);
 int ba_synchronize(ba_handle* h);
 /* Test / measurement switches; the defaults are the product path and the library never reads the environment.
- *   "schur"         auto | pairs | groups | mfma1 | mfma   force a Schur-reduction kernel (falls back to pairs when not applicable)
+ *   "schur"         auto | pairs | groups | mfma1 | mfma2 | mfma   force a Schur-reduction kernel (falls back to pairs when not applicable)
+ *   "lds_window"    1 | 0                                  LDS accumulation window of the matrix-core reduction (0: global atomics only)
  *   "solver"        auto | bcr | band | dense | lu         force the reduced solver (lu: always report -1 = caller's LU)
  *   "point_kernels" auto | v1                              lanes-per-point k_linearize / k_backsub instead of the group-packed ones
  *   "fuse_cost" "fuse_cam" "fuse_lin"   1 | 0              pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1, 0)
@@ -110,6 +111,10 @@ enum {
   BA_INFO_SCHUR_GROUPS,        /* 1: a group reduction (vector or MFMA) applies; 0: k_schur_pairs                  */
   BA_INFO_LDS_WINDOW_ROWS,     /* band rows of the reduction's LDS accumulation window (0: global atomics only)   */
   BA_INFO_PAIR_UNITS,
+  BA_INFO_SCHUR_KERNEL,        /* 0 pairs, 1 vector groups, 2 / 3 / 4 matrix-core reductions (single wavefront, producer-consumer L <= 10,
+                                  producer-consumer any L <= 24), 5 dense visibility                                                   */
+  BA_INFO_MFMA_POINTS_PER_BATCH_CAP,
+  BA_INFO_MFMA_K_ROWS,
   BA_INFO_COUNT
 };
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);

@@ -23,7 +23,8 @@ KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 
               'bcr_assemble', 'bcr_eliminate', 'bcr_backsolve', 'dense_solve')
 K_COUNT = len(KERNEL_IDS)
 INFO_KEYS = ('points_permuted', 'obs_permuted', 'groups', 'mfma_groups', 'point_groups', 'max_track_len',
-             'half_bandwidth', 'schur_mfma', 'schur_groups', 'lds_window_rows', 'pair_units')      # BA_INFO_*
+             'half_bandwidth', 'schur_mfma', 'schur_groups', 'lds_window_rows', 'pair_units', 'schur_kernel',
+             'mfma_points_per_batch_cap', 'mfma_k_rows')      # BA_INFO_*
 SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky')
 
 _dp = C.POINTER(C.c_double)

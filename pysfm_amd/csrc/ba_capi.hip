@@ -46,7 +46,7 @@ struct TimedLaunch { int id; hipEvent_t a, b; int count; };
 
 // Test / measurement switches (ba_set_option).  The defaults are the product path; nothing in the library
 // reads the environment.
-enum { SCHUR_AUTO = 0, SCHUR_PAIRS, SCHUR_GROUPS, SCHUR_MFMA1, SCHUR_MFMA };
+enum { SCHUR_AUTO = 0, SCHUR_PAIRS, SCHUR_GROUPS, SCHUR_MFMA1, SCHUR_MFMA2, SCHUR_MFMA };
 enum { SOLVER_AUTO = 0, SOLVER_BCR, SOLVER_BAND, SOLVER_DENSE, SOLVER_LU };
 struct Options {
   int schur = SCHUR_AUTO;
@@ -57,6 +57,7 @@ struct Options {
   bool fuse_lin = false;           // point blocks + inverses inside the single-wavefront MFMA reduction
   bool sort_points = true;         // internal point order (ba_set_problem); off = the caller's order as given
   int gm_cap = 0;                  // points per MFMA group (0 = chosen by ba_set_problem)
+  bool lds_window = true;          // k_schur_groups_mfma3 accumulates in an LDS window of the band when one fits
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
 
@@ -106,6 +107,10 @@ struct ba_handle {
   int nmchunks = 0, nmgroups_total = 0;
   bool groups_ascending = false;
   int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
+  bool groups_worth = false;            // points really share camera lists (mean run >= 2 points)
+  Gm3Params gm3{0, 0, 0, 0, 0, 1};      // k_schur_groups_mfma3: tile count, staged row length, k-rows per buffer, points per batch, window
+  DevBuf<SchurChunk> m3chunks;          // its chunks (window rows gm3.wn may differ from schur_wn)
+  int nm3chunks = 0;
   int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
   bool point_groups = false;            // every point sits in a group and groups are worth it: group-packed k_linearize / k_backsub
   int group_maxL = 0;                   // longest track (k_schur_groups_mfma takes <= kGmMaxL)
@@ -560,7 +565,7 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
@@ -587,7 +592,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
     return false;
   };
   bool ok = false;
-  if (n == "schur") ok = choice({"auto", "pairs", "groups", "mfma1", "mfma"}, h->opt.schur);
+  if (n == "schur") ok = choice({"auto", "pairs", "groups", "mfma1", "mfma2", "mfma"}, h->opt.schur);
   else if (n == "solver") ok = choice({"auto", "bcr", "band", "dense", "lu"}, h->opt.solver);
   else if (n == "point_kernels") { int c = 0; ok = choice({"auto", "v1"}, c); if (ok) h->opt.point_kernels_v1 = c == 1; }
   else if (n == "fuse_cost") ok = flag(h->opt.fuse_cost);
@@ -595,6 +600,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "fuse_lin") ok = flag(h->opt.fuse_lin);
   else if (n == "sort_points") ok = flag(h->opt.sort_points);
   else if (n == "solve_trace") ok = flag(h->opt.solve_trace);
+  else if (n == "lds_window") ok = flag(h->opt.lds_window);
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);
   if (!ok) return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: bad value '%s' for option '%s'", value, name);
@@ -813,14 +819,18 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     }
     if (!units.empty()) chunks.push_back({begin, (int)units.size(), lo == INT32_MAX ? 0 : lo});
   }
-  // Groups for k_schur_groups: runs of consecutive points with identical observation lists
-  // (all tracks must have at most kGroupMaxL observations), cut at kGroupMaxPts points,
-  // chunked kGroupChunk at a time under the same LDS-window rule as above.
-  std::vector<SchurGroup> groups, mgroups;           // vector kernel: <= kGroupMaxPts points; MFMA kernel: longer runs
-  std::vector<SchurChunk> gchunks, mchunks;          // kGroupChunk groups per workgroup (vector kernel) / kGmChunk (MFMA kernel)
+  // Groups: runs of consecutive points (internal order) with identical observation lists.
+  //   groups / gchunks   <= kGroupMaxPts points each: k_schur_groups (vector kernel, track length <= 15) and the
+  //                      group-packed point kernels k_linearize_groups / k_backsub_groups (<= kGm3MaxL)
+  //   mgroups / mchunks  longer runs for the matrix-core reductions; mchunks under the LDS window `wn` of the older
+  //                      kernels (track length <= 10), m3chunks under k_schur_groups_mfma3's own window
+  std::vector<SchurGroup> groups, mgroups;
+  std::vector<SchurChunk> gchunks, mchunks, m3chunks;
   int group_rounds = 0;
+  bool groups_worth = false;
   bool groups_ascending = true;                      // optimised positions ascend along every track
-  if (maxL >= 1 && maxL <= kGroupMaxL && wn > 0) {
+  Gm3Params gm3{0, 0, 0, 0, 0, 1};
+  if (maxL >= 1 && maxL <= kGm3MaxL) {
     auto build_groups = [&](int max_pts, std::vector<SchurGroup>& gs, std::vector<int>& glo, std::vector<int>& ghi) {
       for (int k = 0; k < nt;) {
         const int L = off[(size_t)k + 1] - off[k];
@@ -842,12 +852,13 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         k = e;
       }
     };
-    auto chunk_groups = [&](int limit, const std::vector<SchurGroup>& gs, const std::vector<int>& glo, const std::vector<int>& ghi,
+    // consecutive groups whose optimised positions fit a window of `win` band rows (win == 0: no window, by count only)
+    auto chunk_groups = [&](int limit, int win, const std::vector<SchurGroup>& gs, const std::vector<int>& glo, const std::vector<int>& ghi,
                             std::vector<SchurChunk>& out) {
       int begin = 0, lo = INT32_MAX, hi = -1;
       for (int g = 0; g < (int)gs.size(); ++g) {
         const int nlo = std::min(lo, glo[g]), nhi = std::max(hi, ghi[g]);
-        const bool fits = nhi < 0 || nhi - nlo + 1 <= wn;
+        const bool fits = win == 0 || nhi < 0 || nhi - nlo + 1 <= win;
         if (g > begin && (!fits || g - begin >= limit)) {
           out.push_back({begin, g, lo == INT32_MAX ? 0 : lo});
           begin = g; lo = glo[g]; hi = ghi[g];
@@ -859,9 +870,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     };
     std::vector<int> glo, ghi, mlo, mhi;
     build_groups(kGroupMaxPts, groups, glo, ghi);
-    chunk_groups(kGroupChunk, groups, glo, ghi, gchunks);
-    // MFMA kernel: one group per wavefront, and its epilogue (LDS atomics) is expensive, so runs are cut
-    // only where the chip would otherwise idle: about one group per wavefront slot (4 per CU)
+    if (maxL <= kGroupMaxL) chunk_groups(kGroupChunk, wn, groups, glo, ghi, gchunks);
+    // MFMA kernels: one group per wavefront pair, and the epilogue is expensive, so runs are cut
+    // only where the chip would otherwise idle: about one group per wavefront-pair slot (4 per CU)
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
     const int slots = std::max(1, ncu * (kGmBlock / kWave));
@@ -894,10 +905,32 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     while (cap < longest && split_runs(cap, false) > (size_t)slots) cap += kGmPts;     // (beyond the longest run nothing changes)
     if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);     // tuning aid (ba_set_option "gm_cap")
     split_runs(cap, true);
-    chunk_groups(kGmChunk, mgroups, mlo, mhi, mchunks);
+    if (maxL <= kGmMaxL && wn > 0) chunk_groups(kGmChunk, wn, mgroups, mlo, mhi, mchunks);
+    // k_schur_groups_mfma3: staged rows of 16 * nts doubles; four wavefront pairs with two buffers each must fit in
+    // LDS next to the (optional) accumulation window
+    {
+      gm3.nts = (int)((6 * maxL + 15) / 16);
+      gm3.Ld = 16 * gm3.nts;
+      const size_t lds_total = 160 * 1024, fixed = schur_mfma3_lds_bytes(0, 0, 0, hb + 1) + 1024;
+      for (gm3.np_cap = kGmPts; gm3.np_cap >= 1; --gm3.np_cap) {
+        int kmax = 4;
+        for (const SchurGroup& g : mgroups) kmax = std::max(kmax, (3 * gm3_np(g.L, gm3.np_cap) + 3) / 4 * 4);
+        gm3.Kbuf = kmax;
+        if ((size_t)kGm2Pairs * 2 * gm3.Kbuf * gm3.Ld * sizeof(double) <= 96 * 1024) break;
+      }
+      gm3.np_cap = std::max(1, gm3.np_cap);
+      const size_t staging = (size_t)kGm2Pairs * 2 * gm3.Kbuf * gm3.Ld * sizeof(double);
+      const size_t rowbytes = ((size_t)(hb + 1) * 36 + 6) * sizeof(double);
+      int w3 = (int)((lds_total - fixed - staging) / rowbytes);
+      w3 = std::min(w3, std::max(16, hb + 7));
+      if (w3 < hb + 2 || nco == 0 || !h->opt.lds_window) w3 = 0;
+      gm3.wn = w3;
+      chunk_groups(kGmChunk, w3, mgroups, mlo, mhi, m3chunks);
+    }
     // worth it only when points really share camera lists
     const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
-    if (mean_group >= 2.0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
+    groups_worth = mean_group >= 2.0;
+    if (groups_worth && maxL <= kGroupMaxL && wn > 0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
   }
   // lanes per point: smallest power of two >= mean track length, in [1, 64]
   int glog = 0;
@@ -913,13 +946,16 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->schur_wn = wn;
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
+  h->nm3chunks = (int)m3chunks.size();
+  h->gm3 = gm3;
+  h->groups_worth = groups_worth;
   h->nmgroups_total = (int)mgroups.size();
   h->groups_ascending = groups_ascending;
   h->ngroups = (int)groups.size();
   {
     long long covered = 0;
     for (const SchurGroup& g : groups) covered += g.pt_end - g.pt_begin;
-    h->point_groups = group_rounds > 0 && covered == nt;        // (points without observations are in no group)
+    h->point_groups = groups_worth && covered == nt;        // (points without observations are in no group)
   }
   h->group_rounds = group_rounds;
   h->group_maxL = maxL;
@@ -938,6 +974,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->groups.resize(std::max<size_t>(1, groups.size())));
   HIPCHECK(h, h->gchunks.resize(std::max<size_t>(1, gchunks.size())));
   HIPCHECK(h, h->mchunks.resize(std::max<size_t>(1, mchunks.size())));
+  HIPCHECK(h, h->m3chunks.resize(std::max<size_t>(1, m3chunks.size())));
+  if (!m3chunks.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->mgroups.resize(std::max<size_t>(1, mgroups.size())));
   if (!mgroups.empty())
     HIPCHECK(h, hipMemcpyAsync(h->mgroups.p, mgroups.data(), mgroups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
@@ -945,7 +984,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     HIPCHECK(h, hipMemcpyAsync(h->mchunks.p, mchunks.data(), mchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   if (!groups.empty()) {
     HIPCHECK(h, hipMemcpyAsync(h->groups.p, groups.data(), groups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+    if (!gchunks.empty())
+      HIPCHECK(h, hipMemcpyAsync(h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   }
   HIPCHECK(h, h->cam_perm.resize(std::max<size_t>(1, perm.size())));
   HIPCHECK(h, h->cam_units.resize(std::max<size_t>(1, cam_units.size())));
@@ -1151,10 +1191,56 @@ int ba_eval_sensor(ba_handle* h, int64_t n, const double* e, double* r, double* 
 
 namespace {
 
-bool mfma_reduction_possible(const ba_handle* h) {
-  return h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL >= 1 && h->group_maxL <= kGmMaxL && h->groups_ascending &&
-         h->nmchunks > 0;
+// Which kernel forms the Schur reduction (bundle_adjuster.py:259-278) for this problem and these options.
+enum { KERN_PAIRS = 0, KERN_GROUPS, KERN_MFMA1, KERN_MFMA2, KERN_MFMA3, KERN_DENSE };
+int pick_schur_kernel(const ba_handle* h) {
+  if (h->dense_mode && h->nt > 0 && h->nco > 0) return KERN_DENSE;
+  const bool asc = h->groups_ascending && h->group_maxL >= 1;
+  const bool m3 = asc && h->nm3chunks > 0 && h->group_maxL <= kGm3MaxL;
+  const bool m12 = asc && h->nmchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGmMaxL;      // the L <= 10 kernels
+  const bool vec = h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGroupMaxL;
+  switch (h->opt.schur) {
+    case SCHUR_PAIRS: return KERN_PAIRS;
+    case SCHUR_GROUPS: return vec ? KERN_GROUPS : KERN_PAIRS;
+    case SCHUR_MFMA1: return m12 ? KERN_MFMA1 : KERN_PAIRS;
+    case SCHUR_MFMA2: return m12 ? KERN_MFMA2 : KERN_PAIRS;
+    case SCHUR_MFMA: return m3 ? KERN_MFMA3 : KERN_PAIRS;
+    default: break;
+  }
+  if (!h->groups_worth) return KERN_PAIRS;
+  if (h->opt.fuse_lin && m12) return KERN_MFMA1;          // (the variant that forms the point blocks itself: measured slower, kept tested)
+  if (m12) return KERN_MFMA2;                             // track length <= 10: the fixed-shape kernel is 12 % faster than the general one's <0, 4> instance
+  if (m3) return KERN_MFMA3;
+  if (vec && h->group_rounds >= 1 && h->group_rounds <= 2) return KERN_GROUPS;
+  return KERN_PAIRS;
 }
+inline bool kern_is_mfma(int k) { return k == KERN_MFMA1 || k == KERN_MFMA2 || k == KERN_MFMA3; }
+
+extern "C++" {
+// k_schur_groups_mfma3 over the tile columns [TJ0, TJ1) of every group's window
+template <int TJ0, int TJ1>
+int launch_mfma3(ba_handle* h, int p, double damping, bool fuse_cam, bool first) {
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma3<TJ0, TJ1>));
+  Gm3Params G = h->gm3;
+  G.do_rhs = first ? 1 : 0;
+  hipLaunchKernelGGL((k_schur_groups_mfma3<TJ0, TJ1>), dim3(h->nm3chunks), dim3(kGm2Block),
+                     schur_mfma3_lds_bytes(G.Kbuf, G.Ld, G.wn, h->hb + 1), h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
+                     h->mgroups.p, h->m3chunks.p, G, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
+  return BA_OK;
+}
+
+int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
+  const int nts = h->gm3.nts;       // tiles per side of the widest window; at most 15 accumulator tiles per launch
+  if (nts < 1 || nts > 9) return h->fail(BA_ERR_STATE, "k_schur_groups_mfma3: %d tiles per side", nts);
+  int rc = nts == 5 ? launch_mfma3<0, 5>(h, p, damping, fuse_cam, true) : launch_mfma3<0, 4>(h, p, damping, fuse_cam, true);
+  if (rc == BA_OK && nts >= 6) rc = launch_mfma3<4, 6>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts == 9) rc = launch_mfma3<8, 9>(h, p, damping, fuse_cam, false);
+  return rc;
+}
+inline int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 : 4; }
+}  // extern "C++"
 
 int launch_point_blocks(ba_handle* h, int p, double* Wd) {
   if (h->nt > 0) {
@@ -1231,10 +1317,11 @@ int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_problem_info: call ba_set_problem first");
   REQUIRE(h, out && n >= 1, BA_ERR_INVALID_ARG, "ba_problem_info: bad argument");
-  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
+  const int kern = pick_schur_kernel(h);
   const int64_t v[BA_INFO_COUNT] = {
       h->pperm.empty() ? 0 : 1, h->operm.empty() ? 0 : 1, h->ngroups, (int64_t)h->nmgroups_total, h->point_groups ? 1 : 0,
-      h->group_maxL, h->hb, groups_ok && mfma_reduction_possible(h) ? 1 : 0, groups_ok ? 1 : 0, h->schur_wn, h->nunits};
+      h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
+      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf};
   for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];
   return BA_OK;
 }
@@ -1295,18 +1382,14 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   HIPCHECK(h, hipSetDevice(h->device));
   int rc = ensure_reduced(h);
   if (rc != BA_OK) return rc;
-  const int force_schur = h->opt.schur;          // ba_set_option "schur": pick the reduction kernel (tests)
-  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
-  const bool groups_possible = h->ngchunks > 0 && h->schur_wn > 0;
-  const bool mfma_possible = mfma_reduction_possible(h);
-  const bool force_v1 = force_schur == SCHUR_MFMA1;     // the single-wavefront-per-group form
-  const bool dense = h->dense_mode && h->nt > 0 && h->nco > 0;
-  const bool use_mfma = !dense && (force_schur ? ((force_schur == SCHUR_MFMA || force_v1) && mfma_possible)
-                                                     : (groups_ok && mfma_possible));
-  const bool use_groups = force_schur ? (force_schur == SCHUR_GROUPS && groups_possible) : groups_ok;
+  const int kern = pick_schur_kernel(h);         // (ba_set_option "schur" forces one: tests)
+  const bool force_v1 = kern == KERN_MFMA1;      // the single-wavefront-per-group form
+  const bool dense = kern == KERN_DENSE;
+  const bool use_mfma = kern_is_mfma(kern);
+  const bool use_groups = kern == KERN_GROUPS;
   // point blocks and camera blocks: normally in HPP / bP (k_linearize) and HCC / bC (k_camera_blocks);
   // ba_lm_trial leaves both to the MFMA reduction, which linearises every observation anyway
-  const bool fuse_lin = use_mfma && !h->point_blocks_valid;
+  const bool fuse_lin = (kern == KERN_MFMA1) && !h->point_blocks_valid;
   if (!h->point_blocks_valid && !fuse_lin) {
     rc = launch_point_blocks(h, h->lin_phys, nullptr);
     if (rc != BA_OK) return rc;
@@ -1316,13 +1399,12 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     rc = launch_camera_blocks(h, h->lin_phys, true);
     if (rc != BA_OK) return rc;
   }
-  const bool have_inv = fuse_lin || (h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond && (!dense || h->fac_valid));
-  h->inv_valid = false;
-  // producer / consumer form of the MFMA reduction: needs the factorised point inverses, which the merged
+  // the producer / consumer reductions and the dense one work from the factorised point inverses, which the merged
   // inversion + initialisation launch below writes (or has written, for the same damping)
-  const bool merged_inv = !have_inv && h->nt > 0 && h->nco > 0;
-  const bool use_v2 = use_mfma && !fuse_lin && !force_v1 && (merged_inv || (have_inv && h->fac_valid));
-  const bool want_fac = use_v2 || dense;
+  const bool want_fac = kern == KERN_MFMA2 || kern == KERN_MFMA3 || dense;
+  const bool have_inv = fuse_lin || (h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond && (!want_fac || h->fac_valid));
+  h->inv_valid = false;
+  (void)force_v1;
   if (want_fac) HIPCHECK(h, h->fac.resize((size_t)9 * std::max(1, h->nt)));
   if (!have_inv) h->fac_valid = false;
   if (fuse_lin) h->sing_epoch ^= 1;   // the reduction kernel counts singular blocks like k_point_invert does
@@ -1376,7 +1458,11 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                        h->dpart.p, h->S);
     hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
                        h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
-  } else if (use_v2) {
+  } else if (kern == KERN_MFMA3) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, mfma3_launches(h->gm3.nts));
+    rc = launch_mfma3_all(h, p, damping, fuse_cam);
+    if (rc != BA_OK) return rc;
+  } else if (kern == KERN_MFMA2) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma2));
     hipLaunchKernelGGL(k_schur_groups_mfma2, dim3(h->nmchunks), dim3(kGm2Block), schur_mfma2_lds_bytes(h->schur_wn, h->hb + 1), h->stream,
@@ -1794,8 +1880,7 @@ int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   h->defer = true;
   // with the MFMA reduction the camera blocks come out of the reduction itself: one launch and one pass
   // over the observations less
-  const bool groups_ok = h->group_rounds >= 1 && h->group_rounds <= 2 && h->ngchunks > 0;
-  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && groups_ok && mfma_reduction_possible(h);
+  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(pick_schur_kernel(h));
   int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
   h->defer = false;

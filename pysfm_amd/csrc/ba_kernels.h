@@ -1452,6 +1452,278 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
 }
 
 // --------------------------------------------------------------------------
+// The producer / consumer reduction for ANY track length up to kGm3MaxL = 24 (ragged runs included): the
+// 6L x 6L window of a group is NT = ceil(6L / 16) tiles on a side (up to 9), its upper triangle up to 45
+// tiles - more accumulators than one wavefront has registers for beyond NT = 6.  So the kernel is a template
+// on a range of tile COLUMNS [TJ0, TJ1): a launch forms the tiles (ti <= tj, TJ0 <= tj < TJ1) of every group
+// (at most 15 tiles = 120 accumulator registers: the producer half of the kernel needs ~237 VGPRs, and 18 or 21
+// tiles on the consumer side spill), and the host covers the window with one launch (NT <= 5: L <= 13) or two
+// to four (NT = 6 ... 9), each of which linearises the observations again.  Only the first launch of a set adds
+// the right-hand side and the camera blocks (do_rhs).
+// Differences from k_schur_groups_mfma2, which this kernel contains as its <0, 4> instance:
+//   * staged rows are Ld = 16 NT doubles long, a buffer holds Kbuf >= 4 ceil(3 NP / 4) k-rows, NP = points per
+//     batch = min(64 / L, 6, np_cap) - sized by the host so that four pairs of buffers fit in LDS;
+//   * a group runs ceil(3 NP / 4) k-steps, not always five; the k-rows of a short last step carry D = 0;
+//   * the LDS accumulation window is optional (wn = 0 when hb is too wide for it: every group then adds its
+//     window straight to S with global atomics, one per entry per ~100 points).
+// --------------------------------------------------------------------------
+constexpr int kGm3MaxL = 24;
+constexpr int kGm3PosLen = 32;                          // optimised positions of a group's cameras (24 used)
+constexpr int kGm3MaxTiles = 15;                        // accumulator tiles of one launch
+
+struct Gm3Params { int nts; int Ld; int Kbuf; int np_cap; int wn; int do_rhs; };
+
+__host__ __device__ constexpr int gm3_ntiles(int tj0, int tj1) { return (tj1 * (tj1 + 1) - tj0 * (tj0 + 1)) / 2; }
+__host__ __device__ inline int gm3_np(int L, int np_cap) { int np = 64 / L; if (np > kGmPts) np = kGmPts; if (np > np_cap) np = np_cap; return np; }
+__host__ __device__ inline size_t schur_mfma3_lds_bytes(int Kbuf, int Ld, int wn, int hb1) {
+  return (size_t)kGm2Pairs * 2 * Kbuf * Ld * sizeof(double) + (size_t)kGm2Pairs * 2 * kGm2DRows * sizeof(double) +
+         (size_t)kGm2Pairs * (kGm3PosLen + 4) * sizeof(int) + 64 * sizeof(double) + (size_t)wn * ((size_t)hb1 * 36 + 6) * sizeof(double);
+}
+
+template <int TJ0, int TJ1>
+__global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, const double* __restrict__ cams,
+                                                                  const double* __restrict__ X,
+                                                                  const SchurGroup* __restrict__ groups,
+                                                                  const SchurChunk* __restrict__ chunks, Gm3Params G,
+                                                                  const double* __restrict__ fac,
+                                                                  double* __restrict__ S, double* __restrict__ b,
+                                                                  double damping, int fuse_cam) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  constexpr int NTILE = gm3_ntiles(TJ0, TJ1);
+  static_assert(NTILE <= kGm3MaxTiles, "too many accumulator tiles for one wavefront");
+  const int Ld = G.Ld, BUF = G.Kbuf * G.Ld, wn = G.wn;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* sU = dyn;                                            // [pair][2][Kbuf][Ld]
+  double* sD = sU + kGm2Pairs * 2 * BUF;                       // [pair][2][kGm2DRows]
+  int* sPos = reinterpret_cast<int*>(sD + kGm2Pairs * 2 * kGm2DRows);   // [pair][kGm3PosLen]
+  int* sFlag = sPos + kGm2Pairs * kGm3PosLen;                  // [pair][4]: staged, consumed
+  double* sDummy = reinterpret_cast<double*>(sFlag + kGm2Pairs * 4);   // [64]: where the epilogue's masked-out lanes add
+  double* tile = sDummy + 64;
+  const int hb1 = P.hb + 1;
+  const int rowlen = hb1 * 36;
+  double* tb = tile + (size_t)wn * rowlen;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int pair = wv & 3;
+  const bool producer = wv < kGm2Pairs;
+  const SchurChunk ck = chunks[blockIdx.x];
+  const int p0 = ck.p0;
+  for (int i = threadIdx.x; i < wn * (rowlen + 6); i += kGm2Block) tile[i] = 0.0;
+  for (int i = threadIdx.x; i < kGm2Pairs * 2 * (BUF + kGm2DRows); i += kGm2Block) sU[i] = 0.0;   // incl. sD
+  if (threadIdx.x < kGm2Pairs * 4) sFlag[threadIdx.x] = 0;
+  __syncthreads();
+  int* fStaged = sFlag + pair * 4;
+  int* fConsumed = fStaged + 1;
+  int nbatch = 0;                                              // batches this pair has handed over so far
+
+  if (producer) {
+    for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
+      const SchurGroup gr = groups[g];
+      const int L = gr.L;
+      const int NP = gm3_np(L, G.np_cap);
+      const int ks = (3 * NP + 3) >> 2;
+      const int slot = lane / L, oi = lane - slot * L;
+      const bool stager = lane < NP * L;
+      const int n0 = P.pt_off[gr.pt_begin] + oi;
+      const int c = P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]];
+      const int mypos = stager ? P.cam_opt_pos[c] : -1;
+      double cm[12];
+      load_cam(cams, c, cm);
+      double bacc[6] = {0, 0, 0, 0, 0, 0};
+      double hc[21];
+#pragma unroll
+      for (int q = 0; q < 21; ++q) hc[q] = 0.0;
+      struct PointIn { double x[3], f[9]; double2 z; };
+      auto fetch = [&](int kb_, PointIn& in) {
+        const int k = kb_ + slot;
+        if (stager && k < gr.pt_end) {
+          in.z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) in.x[q] = X[3 * (size_t)k + q];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) in.f[q] = fac[9 * (size_t)k + q];
+        }
+      };
+      PointIn nxt;
+      fetch(gr.pt_begin, nxt);
+      for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
+        const int np = min(NP, gr.pt_end - kb);
+        const PointIn cur = nxt;
+        fetch(kb + NP, nxt);
+        const bool live = stager && slot < np;
+        double U[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) U[q] = 0.0;                // a short last batch stages zero k rows
+        if (live) {
+          double e[2], r[2], Jc[12], Jp[6], W[18];
+          obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
+          block_W(Jc, Jp, W);
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            U[a * 3] = W[a * 3] + cur.f[3] * W[a * 3 + 1] + cur.f[4] * W[a * 3 + 2];
+            U[a * 3 + 1] = W[a * 3 + 1] + cur.f[5] * W[a * 3 + 2];
+            U[a * 3 + 2] = W[a * 3 + 2];
+          }
+          if (mypos >= 0 && G.do_rhs) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) bacc[a] -= W[a * 3] * cur.f[6] + W[a * 3 + 1] * cur.f[7] + W[a * 3 + 2] * cur.f[8];
+            if (fuse_cam) {                                     // HCC[i] += Jc^T Jc, b[i] += Jc^T r (k_camera_blocks' work)
+              int idx = 0;
+#pragma unroll
+              for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int c2 = a; c2 < 6; ++c2) hc[idx++] += Jc[a] * Jc[c2] + Jc[6 + a] * Jc[6 + c2];
+                bacc[a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+              }
+            }
+          }
+        }
+        gm2_wait(fConsumed, nbatch - 1);                         // the buffer's previous batch (nbatch - 2) has been read
+        double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
+        double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
+        if (stager) {
+          const int so = 3 * slot * Ld + 6 * oi;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) mU[so + d * Ld + a] = U[a * 3 + d];
+          if (oi == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) mD[3 * slot + d] = live ? cur.f[d] : 0.0;
+          }
+        }
+        if (lane >= 60 && 3 * NP + (lane - 60) < 4 * ks) mD[3 * NP + (lane - 60)] = 0.0;    // k rows that pad the last step
+        ++nbatch;
+        gm2_post(fStaged, nbatch, lane);
+      }
+      if (mypos >= 0 && G.do_rhs) {
+        const int wr = mypos - p0;
+        const bool in = wr >= 0 && wr < wn;
+        if (in) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) atomic_add_f64(tb + wr * 6 + a, bacc[a]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) atomic_add_f64(b + (size_t)mypos * 6 + a, bacc[a]);
+        }
+        if (fuse_cam) {                                          // damped camera block onto the diagonal block (stored in full)
+          int idx = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int c2 = a; c2 < 6; ++c2) {
+              const double v = a == c2 ? hc[idx] * (1.0 + damping) : hc[idx];
+              ++idx;
+              if (in) {
+                atomic_add_f64(tile + wr * rowlen + a * 6 + c2, v);
+                if (a != c2) atomic_add_f64(tile + wr * rowlen + c2 * 6 + a, v);
+              } else {
+                atomic_add_f64(S + (size_t)mypos * rowlen + a * 6 + c2, v);
+                if (a != c2) atomic_add_f64(S + (size_t)mypos * rowlen + c2 * 6 + a, v);
+              }
+            }
+          }
+        }
+      }
+    }
+  } else {
+    const int lr = lane & 15, lk = lane >> 4;
+    int* mPos = sPos + pair * kGm3PosLen;
+    for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
+      const SchurGroup gr = groups[g];
+      const int L = gr.L;
+      const int NP = gm3_np(L, G.np_cap);
+      const int ks = (3 * NP + 3) >> 2;
+      const int nts = (6 * L + 15) >> 4;                        // tiles per side that hold rows of THIS group
+      const int nb = (gr.pt_end - gr.pt_begin + NP - 1) / NP;
+      if (lane < kGm3PosLen) mPos[lane] = lane < L ? P.cam_opt_pos[P.obs_cam[P.pt_off[gr.pt_begin] + lane]] : -1;
+      mfma_acc acc[NTILE];
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+      const bool any = nts > TJ0;                                // this launch's tile columns exist for the group
+      for (int ib = 0; ib < nb; ++ib) {
+        gm2_wait(fStaged, nbatch + 1);
+        const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
+        const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
+        for (int s4 = 0; s4 < ks; ++s4) {
+          double ta[TJ1], wb[TJ1];
+          const double dk = mD[4 * s4 + lk];
+          const double* row = mU + (4 * s4 + lk) * Ld + lr;
+#pragma unroll
+          for (int t = 0; t < TJ1; ++t) wb[t] = (t < nts && any) ? row[16 * t] : 0.0;
+          if (s4 == ks - 1) { ++nbatch; gm2_post(fConsumed, nbatch, lane); }     // everything of this buffer is in registers
+#pragma unroll
+          for (int t = 0; t < TJ1; ++t) ta[t] = wb[t] * dk;
+          int q = 0;
+#pragma unroll
+          for (int tj = TJ0; tj < TJ1; ++tj)
+#pragma unroll
+            for (int ti = 0; ti <= tj; ++ti, ++q)
+              if (tj < nts) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ti], wb[tj], acc[q], 0, 0, 0);
+        }
+      }
+      lds_wave_sync();                                          // mPos
+      // ---- epilogue (see k_schur_groups_mfma2): C/D layout lane -> column n = 16 tj + lane%16, register v -> row
+      // m = 16 ti + lane/16 + 4 v; block (i, j), i <= j, at row pos_i, offset (pos_j - pos_i) * 36 + a * 6 + c
+      const int mp = lane < kGm3PosLen ? mPos[lane] : -1;
+      const bool allin = wn > 0 && __all(mp < 0 || (mp - p0 >= 0 && mp - p0 < wn));
+      double* dummy = sDummy + lane;
+      int q = 0;
+#pragma unroll
+      for (int tj = TJ0; tj < TJ1; ++tj) {
+        const int n = 16 * tj + lr;
+        const int j = n / 6, c = n - 6 * j;
+        const int pj = mPos[j];                                  // (j < 32 always: n <= 143)
+        const int colpart = pj * 36 + c;
+#pragma unroll
+        for (int ti = 0; ti <= tj; ++ti, ++q) {
+          if (tj >= nts) continue;                               // wave-uniform
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int m = 16 * ti + lk + 4 * v;
+            const int i = m / 6, a = m - 6 * i;
+            const int pi = mPos[i];
+            const bool both = pi >= 0 && pj >= 0;
+            const bool ok = both && (i < j || (i == j && a <= c));
+            const bool mirror = both && i == j && a < c;       // diagonal blocks are stored in full
+            const double val = -acc[q][v];
+            if (allin) {
+              // ONE unconditional ds_add_f64 per accumulator register (+ one for the mirrored entry in the tiles that can
+              // hold a piece of a diagonal block): lanes with nothing to add hit a private dummy slot
+              const int off = (pi - p0) * rowlen - pi * 36 + a * 6 + colpart;
+              atomic_add_f64(ok ? tile + off : dummy, val);
+              if (tj <= ti + 1) atomic_add_f64(mirror ? tile + off + 5 * (c - a) : dummy, val);
+            } else if (ok) {
+              const int wr = pi - p0;
+              if (wr >= 0 && wr < wn) {
+                const int off = wr * rowlen - pi * 36 + a * 6 + colpart;
+                atomic_add_f64(tile + off, val);
+                if (mirror) atomic_add_f64(tile + off + 5 * (c - a), val);
+              } else {
+                const size_t off = (size_t)pi * rowlen - pi * 36 + a * 6 + colpart;
+                atomic_add_f64(S + off, val);
+                if (mirror) atomic_add_f64(S + off + 5 * (c - a), val);
+              }
+            }
+          }
+        }
+      }
+      lds_wave_sync();                                          // mPos is rewritten by the next group
+    }
+  }
+  if (wn == 0) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < wn * rowlen; i += kGm2Block) {
+    const double v = tile[i];
+    const int wr = i / rowlen;
+    if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
+  }
+  for (int i = threadIdx.x; i < wn * 6; i += kGm2Block) {
+    const double v = tb[i];
+    if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
+  }
+}
+
+// --------------------------------------------------------------------------
 // Dense visibility (every track seen by most cameras: the reference's own data sets).  There the
 // reduction  S -= sum_k Wstack_k HPPinv_k Wstack_k^T  is ONE dense matrix product with inner dimension
 // 3 nt, and with the factorised point inverses (HPPinv = L D L^T, see k_schur_groups_mfma2) a symmetric
@@ -1671,13 +1943,30 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
 
 // --------------------------------------------------------------------------
 // k_linearize / k_backsub for scenes whose points come in runs with identical camera lists (the groups
-// of k_schur_groups: <= kGroupMaxPts points, L <= kGroupMaxL cameras).  The lanes-per-point kernels
+// of k_schur_groups: <= kGroupMaxPts points, L <= kPtGroupMaxL cameras).  The lanes-per-point kernels
 // above give a point a power-of-two lane group (16 lanes for 10 observations: 10 of 16 busy); here
 // one wavefront owns a group and lane = (point slot, observation): 64 / L points at a time, 60 of 64
 // lanes busy at L = 10, the camera of a lane loaded once per group.  The per-point sums (9 values in
 // k_linearize, 3 in k_backsub) go through LDS: every lane writes its terms, one lane per (point,
 // value) adds the point's L entries in index order - deterministic, like the shuffle tree it replaces.
 // --------------------------------------------------------------------------
+constexpr int kPtGroupMaxL = 24;    // (= kGm3MaxL: every scene the matrix-core reduction takes also takes the group-packed point kernels)
+// sum of the L <= 24 consecutive LDS values at p, in index order (deterministic): twelve per LDS round trip
+__device__ __forceinline__ double lds_sum_in_order(const double* p, int L) {
+  double v[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) v[j] = j < L ? p[j] : 0.0;
+  double sum = 0.0;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) sum += v[j];
+  if (L > 12) {                                          // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v[j] = 12 + j < L ? p[12 + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) sum += v[j];
+  }
+  return sum;
+}
 __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const double* __restrict__ cams,
                                                              const double* __restrict__ X,
                                                              const SchurGroup* __restrict__ groups, int ngroups,
@@ -1721,12 +2010,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
     lds_wave_sync();
     if (live) {
       for (int c = oi; c < 9; c += L) {
-        double v[kGroupMaxL];
-#pragma unroll
-        for (int j = 0; j < kGroupMaxL; ++j) v[j] = j < L ? mx[c][slot * L + j] : 0.0;       // one LDS round trip
-        double sum = 0.0;
-#pragma unroll
-        for (int j = 0; j < kGroupMaxL; ++j) sum += v[j];
+        const double sum = lds_sum_in_order(&mx[c][slot * L], L);
         if (c < 6) HPP[6 * (size_t)k + c] = sum; else bP[3 * (size_t)k + c - 6] = sum;
       }
     }
@@ -1814,12 +2098,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       lds_wave_sync();
       if (live) {                                        // lane q of a point adds component q of its L terms
         for (int q = oi; q < 3; q += L) {
-          double v[kGroupMaxL];
-#pragma unroll
-          for (int j = 0; j < kGroupMaxL; ++j) v[j] = j < L ? mx[q][slot * L + j] : 0.0;
-          double sum = 0.0;
-#pragma unroll
-          for (int j = 0; j < kGroupMaxL; ++j) sum += v[j];
+          const double sum = lds_sum_in_order(&mx[q][slot * L], L);
           mw[q][slot] = bP[3 * (size_t)k + q] - sum;
         }
       }

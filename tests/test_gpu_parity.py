@@ -33,7 +33,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1, fuse_lin=0,
-                       sort_points=1, gm_cap=0)
+                       sort_points=1, gm_cap=0, lds_window=1)
 
 
 @pytest.fixture(autouse=True)
@@ -528,12 +528,16 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
 
 
 @pytest.mark.parametrize('nc,L,sensor', [(40, 10, O.Sensor.cauchy(.05)), (30, 4, O.Sensor.gaussian(1.)),
-                                         (26, 13, O.Sensor.huber(.06)), (60, 7, O.Sensor.gaussian(1.))])
+                                         (26, 13, O.Sensor.huber(.06)), (60, 7, O.Sensor.gaussian(1.)),
+                                         (40, 11, O.Sensor.gaussian(1.)), (50, 16, O.Sensor.cauchy(.05)),
+                                         (44, 17, O.Sensor.gaussian(1.)), (48, 20, O.Sensor.gaussian(1.)),
+                                         (100, 22, O.Sensor.huber(.06)), (110, 24, O.Sensor.gaussian(1.))])    # (sparse enough not to be 'dense visibility')
 def test_group_reduction_kernel_equals_pair_kernel(be, nc, L, sensor):
-    """k_schur_groups (register accumulation over runs of points with identical camera
-    lists; 1 and 2 pair rounds) and k_schur_groups_mfma (the same groups on the fp64 matrix
-    cores, track length <= 10) against k_schur_pairs and the oracle, also with groups
-    broken up by dropped observations and frozen cameras in the middle of the sequence."""
+    """k_schur_groups (register accumulation over runs of points with identical camera lists; 1 and 2 pair rounds),
+    k_schur_groups_mfma2 (the same groups on the fp64 matrix cores, track length <= 10) and k_schur_groups_mfma3 (any
+    track length up to 24: one to four launches over the tile columns of the window, with and without the LDS
+    accumulation window) against k_schur_pairs and the oracle, also with groups broken up by dropped observations
+    (ragged track lengths) and frozen cameras in the middle of the sequence."""
     s = banded(nc, 40 * nc, track_len=L, outlier_frac=.05)
     keep = np.ones(len(s['obs_cam']), bool)
     keep[::97] = False                                   # ragged tracks: many size-1 groups
@@ -543,20 +547,74 @@ def test_group_reduction_kernel_equals_pair_kernel(be, nc, L, sensor):
     cam_opt_pos[nc // 2 + 1:] -= 1
     pt_opt = np.ones(40 * nc, np.uint8)
     a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
-    load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
     out = {}
-    for kern in ('pairs', 'groups', 'mfma'):                 # 'mfma' falls back to pairs when L > 10
-        be.set_option('schur', kern)
+    for kern in ('pairs', 'groups', 'mfma2', 'mfma', 'mfma-nowindow'):    # 'groups' / 'mfma2' fall back to pairs beyond L = 15 / 10
+        be.set_option('lds_window', 0 if kern == 'mfma-nowindow' else 1)
+        be.set_option('schur', kern.split('-')[0])
+        load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
+        info = be.problem_info()
+        if kern.startswith('mfma') and kern != 'mfma2':
+            assert info['schur_kernel'] == 4 and info['schur_mfma'] == 1
+            assert kern != 'mfma-nowindow' or info['lds_window_rows'] == 0
         be.linearize(0)
         be.schur(0, 3., 1e-5)
         out[kern] = be.get_reduced()
-    close(out['groups'][0], out['pairs'][0], 1e-12)
-    close(out['groups'][1], out['pairs'][1], 1e-12)
+    for kern in ('groups', 'mfma2', 'mfma', 'mfma-nowindow'):
+        close(out[kern][0], out['pairs'][0], 1e-12)
+        close(out[kern][1], out['pairs'][1], 1e-12)
+    mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=3., return_parts=True)
+    close(out['mfma'][0], parts['S'], TIGHT)
+    close(out['mfma'][1], parts['b'], TIGHT)
+    # the whole trial through the same kernels (camera blocks and right-hand side inside the reduction)
+    be.set_option('schur', 'auto')
+    be.set_option('lds_window', 1)
+    load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
+    assert be.problem_info()['schur_kernel'] == (3 if L <= 10 else 4)       # the fixed-shape kernel up to L = 10, the general one beyond
+    info, cost = be.lm_trial(3., 1e-5, None)
+    assert info == 0
+    St, bt = be.get_reduced()
+    close(St, parts['S'], TIGHT)
+    close(bt, parts['b'], TIGHT)
+    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, cam_opt_pos, pt_opt)
+    close(cost, O.cost(sensor, s['K'], R2, t2, X2, cam, pt, z, cam_opt_pos, pt_opt), 1e-8)
+
+
+def test_ragged_track_lengths_through_the_matrix_core_reduction(be):
+    """Track lengths 2 ... 24 in ONE scene (a third of the observations dropped at random), tracks in random order: runs
+    of every length share the launches of k_schur_groups_mfma3 (windows of fewer tiles than the launch covers, batches of
+    different sizes sharing the staging buffers)."""
+    nc, nt, L = 70, 6000, 24
+    s = banded(nc, nt, track_len=L)
+    rs = np.random.RandomState(5)
+    keep = rs.rand(len(s['obs_cam'])) > .33
+    keep[::L] = True                                     # every track keeps at least two observations
+    keep[1::L] = True
+    o = rs.permutation(int(keep.sum()))
+    cam, pt, z = s['obs_cam'][keep][o], s['obs_pt'][keep][o], s['obs_z'][keep][o]
+    flags = default_flags(nc, nt)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
+    sensor = O.Sensor.cauchy(.05)
+    out = {}
+    for kern in ('pairs', 'mfma'):
+        be.set_option('schur', kern)
+        load_problem(be, *a, *flags, sensor)
+        be.linearize(0)
+        be.schur(0, 1., 1e-5)
+        out[kern] = be.get_reduced()
+    assert be.problem_info()['schur_kernel'] == 4
     close(out['mfma'][0], out['pairs'][0], 1e-12)
     close(out['mfma'][1], out['pairs'][1], 1e-12)
-    mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=3., return_parts=True)
-    close(out['groups'][0], parts['S'], TIGHT)
-    close(out['groups'][1], parts['b'], TIGHT)
+    mu, su, parts = O.compute_update(sensor, *a, *flags, damping=1., return_parts=True)
+    close(out['mfma'][0], parts['S'], TIGHT)
+    close(out['mfma'][1], parts['b'], TIGHT)
+    be.set_option('schur', 'auto')
+    load_problem(be, *a, *flags, sensor)
+    info, cost = be.lm_trial(1., 1e-5, None)
+    assert info == 0
+    Rg, tg, Xg = be.get_params(1)
+    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, *flags)
+    close(Xg, X2, 1e-8)
+    close(tg, t2, 1e-8)
 
 
 @pytest.mark.parametrize('rcond', [None, 1e-13, 1e-5])
@@ -574,7 +632,7 @@ def test_factorised_point_inverses_with_ill_conditioned_blocks(be, rcond):
     a = (s['K'], s['R0'], s['t0'], X0, s['obs_cam'], s['obs_pt'], s['obs_z'])
     load_problem(be, *a, cam_opt_pos, pt_opt, O.Sensor.gaussian(1.))
     out = {}
-    for kern in ('pairs', 'mfma'):
+    for kern in ('pairs', 'mfma2', 'mfma'):
         be.set_option('schur', kern)
         be.linearize(0)
         be.schur(0, 1e-9, rcond)
@@ -582,8 +640,9 @@ def test_factorised_point_inverses_with_ill_conditioned_blocks(be, rcond):
     blk = be.get_blocks()
     w = np.linalg.eigvalsh(blk['HPP'])
     assert (w[:, -1] / np.maximum(w[:, 0], 1e-300)).max() > 1e6       # the scene really is ill-conditioned
-    close(out['mfma'][0], out['pairs'][0], 1e-10)
-    close(out['mfma'][1], out['pairs'][1], 1e-10)
+    for kern in ('mfma2', 'mfma'):
+        close(out[kern][0], out['pairs'][0], 1e-10)
+        close(out[kern][1], out['pairs'][1], 1e-10)
 
 
 def test_wide_band_takes_dense_path(be):
