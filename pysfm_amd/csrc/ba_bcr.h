@@ -571,6 +571,383 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #endif
 }
 
+// --------------------------------------------------------------------------
+// The same elimination level with a node SPREAD OVER THREE COMPUTE UNITS (blockIdx.y = role).  What bounds
+// k_bcr_eliminate is, in equal parts, the chain of 6 HB dependent pivots and the matrix-core throughput of ONE
+// compute unit for the 3 B + 1 right-hand-side columns [T_il | T_ir | I | f] and the three B^3 neighbour products.
+// The columns are independent, so each role factors D_i for itself (redundant: the chain cannot be shared anyway) and
+// takes a third of the rest:
+//     role 0 (left)     P = G^-1 T_il, g       ->  Pm[i];   D_l -= P^T P,  f_l -= P^T g
+//     role 1 (right)    Q = G^-1 T_ir, g       ->  Qm[i];   D_r -= Q^T Q,  f_r -= Q^T g
+//     role 2 (inverse)  G^-1 (lower), g        ->  Gi[i], gm[i];  the root node also solves x_i = G^-T g
+// The cross product T[l,r] = -P^T Q would need both P and Q in one place; it is not formed at all at this level.
+// The NEXT level forms the couplings it needs from the stored factors of the node eliminated between the two
+// survivors (j = i -/+ s/2):  T[i,l] = -Q_j^T P_j,  T[i,r] = -P_j'^T Q_j'  (one B^3 product on the matrix cores in the
+// prologue of roles 0 / 1; level s = 1 reads the assembled couplings Um).  Pm, Qm are kept for the back-substitution
+// anyway, so nothing extra is stored, and U is no longer read and written inside one launch.
+// With a third of the columns the late-update tasks of a step (<= 7) fit on the wavefronts of SIMDs 1..3, so SIMD 0
+// is left to the pivot chain of wavefront 0 (25 % faster chain; with all columns on one CU that lost more than it won).
+// --------------------------------------------------------------------------
+__host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 200) * sizeof(double); }
+
+template <int HB>
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, int s, double* __restrict__ Dm,
+                                                                     const double* __restrict__ Um, double* __restrict__ fm,
+                                                                     double* __restrict__ Pm, double* __restrict__ Qm,
+                                                                     double* __restrict__ Gi, double* __restrict__ gm,
+                                                                     int* __restrict__ info, double* __restrict__ xout) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  constexpr int B = 6 * HB, ld = B + 1;
+  double* G = sm;                       // [B][ld]  D_i -> its Cholesky factor L (lower)
+  double* R = G + (size_t)B * ld;       // [B][ld]  right-hand sides of this role: T_il | T_ir | I  ->  P | Q | G^-1
+  double* Ta = R + (size_t)B * ld;      // [B][ld]  prologue: factors of the node eliminated one level down
+  double* Tb = Ta + (size_t)B * ld;     // [B][ld]
+  double* g = Tb + (size_t)B * ld;      // [B]
+  double* dinv = g + B;                 // [B]
+  int* bad = reinterpret_cast<int*>(dinv + B + 2);
+  double* Li = dinv + B + 4;            // [16][12]: inverse of the current diagonal block (lower triangular)
+  const int tid = threadIdx.x;
+  const int role = blockIdx.y;
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N) return;
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  if ((role == 0 && !haveL) || (role == 1 && !haveR)) return;       // no such neighbour: nothing to do for this role
+  constexpr size_t BB = (size_t)B * B;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+
+  if (tid == 0) *bad = 0;
+#ifdef BA_BCR_PROFILE
+  long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long pt0 = clock64();
+#endif
+  {
+    // all global loads of a thread are issued before the first LDS store (one round trip)
+    constexpr int NIT = (B * B + kBcrElimThreads - 1) / kBcrElimThreads;
+    const bool direct = s == 1 && role < 2;                           // level 1: the assembled couplings
+    const bool prod = s > 1 && role < 2;                              // deeper: form the coupling from the factors of node j
+    const int j = role == 0 ? i - (s >> 1) : i + (s >> 1);
+    const double* srcU = Um + (size_t)(role == 0 ? l : i) * BB;
+    double vd[NIT], va[NIT], vb[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * kBcrElimThreads;
+      const bool ok = e < B * B;
+      vd[it] = ok ? Dm[(size_t)i * BB + e] : 0.0;
+      va[it] = (ok && direct) ? srcU[e] : (ok && prod) ? Pm[(size_t)j * BB + e] : 0.0;
+      vb[it] = (ok && prod) ? Qm[(size_t)j * BB + e] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * kBcrElimThreads;
+      if (e < B * B) {
+        const int rr = e / B, cc = e - rr * B;
+        G[rr * ld + cc] = vd[it];
+        if (direct) {
+          if (role == 0) R[cc * ld + rr] = va[it];                  // T[i,l] = T[l,i]^T
+          else R[rr * ld + cc] = va[it];                            // T[i,r]
+        } else if (prod) {
+          Ta[rr * ld + cc] = va[it];                                // P_j
+          Tb[rr * ld + cc] = vb[it];                                // Q_j
+        } else {
+          R[rr * ld + cc] = rr == cc ? 1.0 : 0.0;
+        }
+      }
+    }
+    for (int e = tid; e < B; e += kBcrElimThreads) g[e] = fm[(size_t)i * B + e];
+    __syncthreads();
+#ifdef BA_BCR_PROFILE
+    pst[0] = clock64() - pt0;
+#endif
+  }
+  // ---- block 0's diagonal factor (wavefront 0: it needs D_i only) WHILE the other wavefronts form this role's coupling
+  //      from the factors of the node eliminated one level down
+  constexpr int NBLK = (B + 11) / 12;
+  double dcol[12], ddi = 0.0;                               // wavefront 0: the factor of the current block, kept for phase 2
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    if (B >= 12) bcr_diag_block<12>(G, ld, dinv, bad, 0, lane, dcol, ddi);
+    else bcr_diag_block<6>(G, ld, dinv, bad, 0, lane, dcol, ddi);
+    __builtin_amdgcn_s_setprio(0);
+#ifdef BA_BCR_PROFILE
+    pst[2] += clock64() - pt0 - pst[0];
+#endif
+  } else if (s > 1 && role < 2) {
+    // R = -A^T Bm with (A, Bm) = (Q_j, P_j) for the left role, (P_j', Q_j') for the right one: 16 x 16 output tiles over
+    // wavefronts 1..15, K in steps of 4 (lane -> column 16 t + lane % 16 of the k-major operand, k = 4 ks + lane / 16)
+    constexpr int NT = (B + 15) / 16, KST = (B + 3) / 4;
+    const double* A = role == 0 ? Tb : Ta;
+    const double* Bm = role == 0 ? Ta : Tb;
+    // the wavefronts of SIMDs 1..3 (12 of them; 16 tiles are two rounds on 12 as on 15): SIMD 0 belongs to the chain
+    const int pslot = (wave & 3) ? wave - 1 - (wave >> 2) : -1;
+    for (int task = pslot; task >= 0 && task < NT * NT; task += 12) {
+      const int ti = task / NT, tj = task - ti * NT;
+      // all operands of the tile first (one LDS round trip), then the chain of MFMAs; two accumulators halve the chain
+      double ar[KST], br[KST];
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks) {
+        const int k = 4 * ks + lk;
+        const bool in = 4 * ks + 3 < B || k < B;              // rows past B belong to the next matrix: feed zeros
+        const int kc = in ? k : 0;
+        const double a_ = A[kc * ld + 16 * ti + lr], b_ = Bm[kc * ld + 16 * tj + lr];
+        ar[ks] = in ? a_ : 0.0; br[ks] = in ? b_ : 0.0;
+      }
+      mfma_acc acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KST; ks += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ks], br[ks], acc, 0, 0, 0);
+        if (ks + 1 < KST) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ks + 1], br[ks + 1], acc2, 0, 0, 0);
+      }
+      const int col = 16 * tj + lr;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * ti + lk + 4 * v;
+        if (row < B && col < B) R[row * ld + col] = -(acc[v] + acc2[v]);
+      }
+    }
+  }
+  __syncthreads();
+
+#ifdef BA_BCR_PROFILE
+  const long long pt1 = clock64();
+  pst[1] = pt1 - pt0 - pst[0];
+#endif
+  // ---- blocked Cholesky D_i = L L^T fused with the forward substitution L Y = [R | g], one block of look-ahead:
+  //      the structure of k_bcr_eliminate (see there) with B + 1 right-hand-side columns instead of 3 B + 1
+  constexpr int ncol = B + 1;
+  auto rhs_column = [&](int c, int& st) -> int {                                 // offset into sm[] and row stride
+    st = c < B ? ld : 1;
+    return (int)((c < B ? R + c : g) - sm);
+  };
+  constexpr int nct = (ncol + 15) >> 4;
+  // late-update workers: the wavefronts of SIMDs 1..3 (wave % 4 != 0): 12 slots; SIMD 0 belongs to the pivot chain
+  const int myslot = (wave & 3) ? wave - 1 - (wave >> 2) : -1;
+#pragma unroll 1
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const int k0 = 12 * kb;
+    const bool last = kb == NBLK - 1;
+    const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
+    const int kn = k0 + nb;                                 // first unknown after this block
+    // ---------------- phase 1 (block 0 was factored above, next to the prologue; it has no late updates)
+#ifdef BA_BCR_PROFILE
+    const long long q0 = clock64();
+#endif
+    if (kb == 0) {
+    } else if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
+      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      __builtin_amdgcn_s_setprio(0);
+#ifdef BA_BCR_PROFILE
+      pst[2] += clock64() - q0;
+#endif
+    } else if (myslot >= 0) {
+      const int kp = k0 - 12;
+      const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
+      for (int task = myslot; task < nct + ngt; task += 12) {
+        int t0, t1, i00, co, cst;
+        bool cok, full;
+        double nb0, nb1, nb2;                                  // the NEGATED B operand of the three k-steps
+        if (task < nct) {
+          // the inverse role: columns of the identity right of block kp are still zero in rows kp..kp+11
+          if (role == 2 && 16 * task >= kp + 12 && 16 * task + 15 < ncol - 1) continue;
+          const int col = 16 * task + lr;
+          cok = col < ncol; full = 16 * task + 15 < ncol;
+          int xst;
+          const int xoff = rhs_column(cok ? col : ncol - 1, xst);
+          t0 = 0; t1 = (B - k0 + 15) >> 4; i00 = k0;
+          co = xoff + __mul24(lk, xst); cst = xst;
+          const int ro = xoff + __mul24(kp + lk, xst), r4 = 4 * xst;
+          mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+          if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+          nb0 = -y[0]; nb1 = -y[1]; nb2 = -y[2];
+        } else {
+          const int gtile = task - nct, c0 = kn + 16 * gtile;
+          t0 = gtile; t1 = (B - kn + 15) >> 4; i00 = kn;
+          cok = c0 + lr < B; full = c0 + 15 < B;
+          const int bo = (c0 + lr) * ld + kp + lk;
+          co = lk * ld + c0 + lr; cst = ld;
+          nb0 = -sm[bo]; nb1 = -sm[bo + 4]; nb2 = -sm[bo + 8];
+        }
+        const int c4 = 4 * cst;
+        int ao = (i00 + 16 * t0 + lr) * ld + kp + lk;          // A entry of this lane in the first tile
+        int cb = co + __mul24(i00 + 16 * t0, cst);             // first accumulator entry of this lane
+        int rows = B - (i00 + 16 * t0);                        // rows left from the top of the tile
+        double a0 = sm[ao], a1 = sm[ao + 4], a2 = sm[ao + 8];
+        mfma_acc acc = {sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
+        for (int t = t0; t < t1; ++t) {
+          const double a0c = a0, a1c = a1, a2c = a2;
+          mfma_acc accc = acc;
+          const int cbc = cb, rc = rows;
+          if (t + 1 < t1) {                                    // the next tile's operands are in flight
+            ao += 16 * ld; cb += 16 * cst; rows -= 16;
+            a0 = sm[ao]; a1 = sm[ao + 4]; a2 = sm[ao + 8];
+            acc = mfma_acc{sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
+          }
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0c, nb0, accc, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1c, nb1, accc, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2c, nb2, accc, 0, 0, 0);
+          if (full && rc >= 16) {                              // wave-uniform: the whole tile exists
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sm[cbc + v * c4] = accc[v];
+          } else {
+            const int rl = cok ? rc - lk : 0;                  // rows v with 4 v < rl exist
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              if (4 * v < rl) sm[cbc + v * c4] = accc[v];
+          }
+        }
+      }
+    }
+    if (kb > 0) __syncthreads();
+#ifdef BA_BCR_PROFILE
+    const long long q1 = clock64();
+    pst[3] += q1 - q0;
+#endif
+    // ---------------- phase 2: panel, rows below the diagonal block (one row per lane) | inverse of the diagonal block
+    if (wave == 1 && kn < B) {
+      const int row = kn + lane < B ? kn + lane : B - 1;      // lanes past the last row repeat it (identical values)
+      if (nb == 12) bcr_block_forward<12>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
+      else bcr_block_forward<6>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
+    } else if (wave == 0) {
+      if (nb == 12) bcr_diag_inverse<12>(dcol, ddi, lane, Li);
+      else bcr_diag_inverse<6>(dcol, ddi, lane, Li);
+    }
+    __syncthreads();
+#ifdef BA_BCR_PROFILE
+    const long long q2 = clock64();
+    pst[4] += q2 - q1;
+#endif
+    // ---------------- phase 3: the URGENT part of the update: block column kb+1 only
+    if (!last && wave >= 8 && wave <= 11) {
+      const int i0 = kn + 16 * (wave - 8);
+      if (i0 < B) {
+        const int nbn = B - kn < 12 ? B - kn : 12;             // width of the next block
+        const int ao = (i0 + lr) * ld + k0 + lk, bo = (kn + lr) * ld + k0 + lk, cb = (i0 + lk) * ld + kn + lr;
+        mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
+        const int rl = lr < nbn ? B - i0 - lk : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+      }
+    }
+    __syncthreads();
+#ifdef BA_BCR_PROFILE
+    pst[5] += clock64() - q2;
+#endif
+  }
+#ifdef BA_BCR_PROFILE
+  const long long pt2 = clock64();
+#endif
+  if (myslot >= 0) {
+    // the last block row of the right-hand sides: Y = L_pp^-1 R_p (nothing below it)
+    constexpr int KL = 12 * (NBLK - 1), NL = B - KL;          // last block: start and size (12 or 6)
+    for (int task = myslot; task < nct; task += 12) {
+      const int col = 16 * task + lr;
+      const bool cok = col < ncol;
+      int xst;
+      const int xoff = rhs_column(cok ? col : ncol - 1, xst);
+      const int ro = xoff + __mul24(KL + lk, xst), r4 = 4 * xst;
+      mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+      if (NL == 12) {
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+        if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+      } else {                                               // 6 rows: k = 4, 5 of the second step only
+        const double r1 = lk < 2 ? sm[ro + (lk < 2 ? r4 : 0)] : 0.0;
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], r1, y, 0, 0, 0);
+        if (cok) { sm[ro] = y[0]; if (lk < 2) sm[ro + r4] = y[1]; }
+      }
+    }
+  }
+  __syncthreads();
+  if (*bad) {
+    if (tid == 0 && role == 2) atomicMax(info, i * B + *bad);
+    return;
+  }
+#ifdef BA_BCR_PROFILE
+  const long long pt3 = clock64();
+  pst[6] = pt3 - pt2;
+#endif
+
+  if (role < 2) {
+    // ---- this role's neighbour update: D_nb -= R^T R (lower tiles), f_nb -= R^T g; R is kept for the back-substitution
+    const int nbr = role == 0 ? l : r;
+    constexpr int NT = (B + 15) / 16, NSYM = NT * (NT + 1) / 2, KST = (B + 3) / 4;
+    for (int task = wave; task < NSYM; task += kBcrElimThreads / 64) {
+      int ti, tj;
+      tri_decode(task, NT, tj, ti);                          // tj <= ti: D is only ever read in its lower triangle
+      const double* A = R + 16 * ti + lr;
+      const double* Bm = R + 16 * tj + lr;
+      double ar[KST], br[KST];
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks) {
+        const int k = 4 * ks + lk;
+        const bool in = 4 * ks + 3 < B || k < B;
+        const int kc = in ? k : 0;
+        const double a_ = A[kc * ld], b_ = Bm[kc * ld];
+        ar[ks] = in ? a_ : 0.0; br[ks] = in ? b_ : 0.0;
+      }
+      mfma_acc acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KST; ks += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ks], br[ks], acc, 0, 0, 0);
+        if (ks + 1 < KST) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ks + 1], br[ks + 1], acc2, 0, 0, 0);
+      }
+      double* dst = Dm + (size_t)nbr * BB;
+      const int col = 16 * tj + lr;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * ti + lk + 4 * v;
+        if (row < B && col <= row) atomic_add_f64(dst + (size_t)row * B + col, -(acc[v] + acc2[v]));
+      }
+    }
+    for (int c = kBcrElimThreads - 1 - tid; c < B; c += kBcrElimThreads) {       // the last wavefronts have fewer tiles
+      double acc = 0.0;
+      for (int k = 0; k < B; ++k) acc += R[k * ld + c] * g[k];
+      atomic_add_f64(fm + (size_t)nbr * B + c, -acc);
+    }
+    double* out = (role == 0 ? Pm : Qm) + (size_t)i * BB;
+    for (int e = tid; e < B * B; e += kBcrElimThreads) {
+      const int rr = e / B, cc = e - rr * B;
+      out[e] = R[rr * ld + cc];
+    }
+  } else {
+    for (int e = tid; e < B * B; e += kBcrElimThreads) {
+      const int rr = e / B, cc = e - rr * B;
+      Gi[(size_t)i * BB + e] = cc <= rr ? R[rr * ld + cc] : 0.0;
+    }
+    for (int e = tid; e < B; e += kBcrElimThreads) gm[(size_t)i * B + e] = g[e];
+    if (!haveL && !haveR) {
+      // the root of the elimination tree: x_i = G^-T g right here (its back-substitution launch is skipped by the host)
+      for (int task = tid; task < 4 * B; task += kBcrElimThreads) {
+        const int m = task >> 2, q4 = task & 3;
+        double acc = 0.0;
+        for (int k = m + q4; k < B; k += 4) acc += R[k * ld + m] * g[k];
+        acc += dpp_pair<0xB1>(acc);
+        acc += dpp_pair<0x4E>(acc);
+        if (q4 == 0) xout[(size_t)i * B + m] = acc;
+      }
+    }
+  }
+#ifdef BA_BCR_PROFILE
+  __syncthreads();
+  if (tid == 0 && blockIdx.x == 1 && s == 2) {
+    int* o = info + 8 + 10 * role;              // [load, prologue, diag factor (wave 0), phase 1, phase 2, phase 3, last rhs block, products + store]
+    for (int q = 0; q < 7; ++q) o[q] = (int)pst[q];
+    o[7] = (int)(clock64() - pt3);
+  }
+#endif
+}
+
 // One back-substitution level: x_i = G^-T (g - P x_l - Q x_r) for the nodes of that level.
 // P, Q and G^-1 are staged into LDS in one round trip; the two matrix-vector products use
 // four lanes per row, the last one four lanes per column.

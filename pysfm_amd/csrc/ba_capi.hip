@@ -47,7 +47,7 @@ struct TimedLaunch { int id; hipEvent_t a, b; int count; };
 // Test / measurement switches (ba_set_option).  The defaults are the product path; nothing in the library
 // reads the environment.
 enum { SCHUR_AUTO = 0, SCHUR_PAIRS, SCHUR_GROUPS, SCHUR_MFMA1, SCHUR_MFMA2, SCHUR_MFMA };
-enum { SOLVER_AUTO = 0, SOLVER_BCR, SOLVER_BAND, SOLVER_DENSE, SOLVER_LU };
+enum { SOLVER_AUTO = 0, SOLVER_BCR, SOLVER_BAND, SOLVER_DENSE, SOLVER_LU, SOLVER_BCR1 };
 struct Options {
   int schur = SCHUR_AUTO;
   int solver = SOLVER_AUTO;
@@ -65,6 +65,7 @@ struct Options {
 
 struct ba_handle {
   int device = 0;
+  int ncu = 256;             // compute units of the device
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -128,7 +129,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrL, bcrLv, denseA, fac, dUd, dDd, dyd, dpart, comm_dev;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, fac, dUd, dDd, dyd, dpart, comm_dev;
   DevBuf<unsigned char> mask;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
@@ -301,6 +302,26 @@ hipError_t launch_bcr_eliminate_hb(ba_handle* h, int cnt, size_t lds, hipStream_
   return hipSuccess;
 }
 
+template <int HB>
+hipError_t launch_bcr_split_hb(ba_handle* h, int cnt, hipStream_t st, int N, int s, double* D, const double* U, double* f,
+                               double* P, double* Q, double* G, double* gv, int* info, double* x) {
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcr_eliminate_split<HB>); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bcr_eliminate_split<HB>, dim3(cnt, 3), dim3(kBcrElimThreads), bcr_split_lds_bytes(6 * HB), st, N, s, D, U, f, P,
+                     Q, G, gv, info, x);
+  return hipSuccess;
+}
+
+hipError_t launch_bcr_split(ba_handle* h, int hb, int cnt, hipStream_t st, int N, int s, double* D, const double* U, double* f,
+                            double* P, double* Q, double* G, double* gv, int* info, double* x) {
+#define BA_HB_CASE(K) case K: return launch_bcr_split_hb<K>(h, cnt, st, N, s, D, U, f, P, Q, G, gv, info, x);
+  switch (hb) {
+    BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
+    BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11)
+    default: return hipErrorInvalidValue;
+  }
+#undef BA_HB_CASE
+}
+
 hipError_t launch_bcr_eliminate(ba_handle* h, int hb, int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
                                 double* P, double* Q, double* G, int* info, double* x) {
 #define BA_HB_CASE(K) case K: return launch_bcr_eliminate_hb<K>(h, cnt, lds, st, N, s, D, U, f, P, Q, G, info, x);
@@ -320,7 +341,14 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
   HIPCHECK(h, h->bcrF.resize((size_t)N * B));
+  HIPCHECK(h, h->bcrGv.resize((size_t)N * B));
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_bcr_backsolve));
+  // a node over three compute units (k_bcr_eliminate_split) on the levels whose nodes then still fit the chip in one
+  // round of workgroups; one compute unit per node (k_bcr_eliminate) on the wide levels below them and with "bcr1".
+  // (A split level takes its couplings from the factors of the level below, whichever kernel wrote them; a one-unit
+  // level needs the couplings U the split kernel does not form: so never one-unit above split - node counts only fall.)
+  const bool split = h->opt.solver != SOLVER_BCR1;
+  std::vector<char> level_split;
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
     hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
@@ -333,8 +361,13 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
     ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)strides.size());
     for (int s : strides) {
       const int cnt = (N / s + 1) / 2;
-      HIPCHECK(h, launch_bcr_eliminate(h, hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
-                                       h->bcrG.p, h->flags.p + 1, h->dC.p));
+      level_split.push_back(split && (3 * cnt <= h->ncu || (!level_split.empty() && level_split.back())));
+      if (level_split.back())
+        HIPCHECK(h, launch_bcr_split(h, hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
+                                     h->bcrGv.p, h->flags.p + 1, h->dC.p));
+      else
+        HIPCHECK(h, launch_bcr_eliminate(h, hb, cnt, lds, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
+                                         h->bcrG.p, h->flags.p + 1, h->dC.p));
     }
   }
   const size_t lds2 = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
@@ -344,8 +377,8 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, top + 1);
   for (int q = top; q >= 0; --q) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
-    hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p,
-                       h->bcrQ.p, h->bcrG.p, h->dC.p);    // x[N][B] IS dC's layout (padded to whole super-blocks)
+    hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s,
+                       level_split[q] ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p);    // x[N][B] IS dC's layout (padded to whole super-blocks)
   }
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
@@ -541,6 +574,8 @@ int ba_create(int device_id, ba_handle** out) {
   }
   ba_handle* h = new ba_handle();
   h->device = device_id;
+  (void)hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device_id);
+  if (h->ncu <= 0) h->ncu = 256;
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
     g_create_error = std::string("ba_create: hipStreamCreate failed: ") + hipGetErrorString(e);
     delete h;
@@ -569,7 +604,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -593,7 +628,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   };
   bool ok = false;
   if (n == "schur") ok = choice({"auto", "pairs", "groups", "mfma1", "mfma2", "mfma"}, h->opt.schur);
-  else if (n == "solver") ok = choice({"auto", "bcr", "band", "dense", "lu"}, h->opt.solver);
+  else if (n == "solver") ok = choice({"auto", "bcr", "band", "dense", "lu", "bcr1"}, h->opt.solver);
   else if (n == "point_kernels") { int c = 0; ok = choice({"auto", "v1"}, c); if (ok) h->opt.point_kernels_v1 = c == 1; }
   else if (n == "fuse_cost") ok = flag(h->opt.fuse_cost);
   else if (n == "fuse_cam") ok = flag(h->opt.fuse_cam);
@@ -1636,7 +1671,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   // multi-CU path: block cyclic reduction when the band is narrow enough for dense
   // (6 hb)^2 blocks in LDS and there are enough super-blocks to parallelise over
   const bool bcr_ok = h->hb >= 1 && h->hb <= kBcrMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
-  const bool use_bcr = force ? (force == SOLVER_BCR && bcr_ok) : bcr_ok;
+  const bool use_bcr = force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok;
   const size_t lds_budget = 160 * 1024;
   const int ch = band_solve_chunk(h->hb, lds_budget);
   size_t lds = 0;
@@ -1667,6 +1702,13 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   const int inf = inf6[0];
 #ifdef BA_BCR_PROFILE
+  if (h->opt.solve_trace && use_bcr && h->opt.solver != SOLVER_BCR1) {
+    for (int role = 0; role < 3; ++role) {
+      const int* o = inf6 + 8 + 10 * role;
+      fprintf(stderr, "[k_bcr_eliminate_split level 2 node 1 role %d] load %d prologue %d | diag factor (wave 0) %d, phase 1 %d, phase 2 %d, phase 3 %d | last rhs %d, products+store %d cycles\n",
+              role, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+    }
+  } else
   if (h->opt.solve_trace && use_bcr)
     fprintf(stderr, "[k_bcr_eliminate level 0 node 2] load %d chol %d trsm %d products %d store %d cycles\n", inf6[8], inf6[9],
             inf6[10], inf6[11], inf6[12]);

@@ -1,12 +1,11 @@
 """Per-phase shader-cycle counts of k_bcr_eliminate (library built with `make PROFILE=1`).
-usage (GPU box): BA_SOLVE_TRACE=1 python scripts/bcr_phase_trace.py [cams] [points]"""
+usage (GPU box): python scripts/bcr_phase_trace.py [cams] [points] [solver: bcr | bcr1]"""
 import os
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault('BA_SOLVE_TRACE', '1')
 from pysfm_amd import Bundle, BundleAdjuster, sensor_model          # noqa: E402
 from pysfm_amd import synthetic_data as sd                          # noqa: E402
 
@@ -18,6 +17,8 @@ b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['
 ba = BundleAdjuster(verbose=False)
 ba.set_bundle(b)
 be = ba.backend
+be.set_option('solve_trace', 1)
+be.set_option('solver', sys.argv[3] if len(sys.argv) > 3 else 'bcr')
 be.linearize(0)
 be.schur(0, 10., 1e-5)
 for _ in range(3):

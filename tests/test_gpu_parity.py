@@ -512,10 +512,11 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
     n = (nc - 1) * 6
     for mask in (None, (np.arange(n) % 7 != 3).astype(np.uint8)):
         sol = {}
-        for solver in ('bcr', 'band'):                    # hb <= 11: one kernel per level; 12..21: ba_bcr_wide.h
+        for solver in ('bcr', 'bcr1', 'band'):            # hb <= 11: a node over three CUs (bcr) / on one (bcr1); 12..21: ba_bcr_wide.h
             be.set_option('solver', solver)
             be.solve_reduced(mask)
             assert be.last_solve_path == 'band'
+            assert be.last_solve_kind == ('band' if solver == 'band' or (solver == 'bcr1' and L > 12) else 'bcr' if L <= 12 else 'bcr_wide')
             sol[solver] = be.get_solution().reshape(-1)
         keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
         xd = np.zeros(n)
@@ -523,6 +524,7 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
         close(sol['bcr'], xd, 1e-9)
         close(sol['band'], xd, 1e-9)
         close(sol['bcr'], sol['band'], 1e-10)
+        close(sol['bcr1'], sol['band'], 1e-10)
         if mask is not None:
             assert np.all(sol['bcr'][mask == 0] == 0)
 
