@@ -111,9 +111,10 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     # the timer id 'schur_pairs' covers the interchangeable reduction kernels
-    names = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
+    names = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
              'linearize': ['k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
-             'point_invert': ['k_point_invert_schur_init', 'k_point_invert']}.get(kernel, ['k_' + kernel])
+             'point_invert': ['k_point_invert_schur_init', 'k_point_invert'],
+             'bcr_eliminate': ['k_bcr_eliminate_split', 'k_bcr_eliminate']}.get(kernel, ['k_' + kernel])
     rows = list(csv.DictReader(open(files[-1])))
     for name in names:
         for row in rows:

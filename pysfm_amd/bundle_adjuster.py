@@ -84,6 +84,7 @@ class BundleAdjuster(object):
         self._have_blocks = False
         self._damping = 10.
         self.lm_trials = 0
+        self.trial_log = []       # one (damping, outcome, cost of the trial set) per LM trial; outcome 'accepted' / 'rejected' / 'ill-conditioned'
         if bundle is not None:
             self.set_bundle(bundle)
 
@@ -231,6 +232,7 @@ class BundleAdjuster(object):
         self._damping = init_damping
         self.num_steps = 0
         self.lm_trials = 0
+        self.trial_log = []
         self.converged = False
         self._cur_cost = self._cost(PARAMS_CUR)
         self.costs = [self._cur_cost]
@@ -256,6 +258,7 @@ class BundleAdjuster(object):
         self._say('Step %d: cost=%f, damping=%f' % (self.num_steps, cur_cost, self._damping))
         while not self.converged and self._damping < 1e+8:
             accepted, next_cost = self.trial(self._damping, param_mask, cur_cost)
+            self.trial_log.append((self._damping, 'ill-conditioned' if accepted is None else 'accepted' if accepted else 'rejected', next_cost))
             if accepted is None:                       # ill-conditioned: raise damping
                 self._damping *= 10.
                 self.converged = self._damping > 1e+8

@@ -446,3 +446,38 @@ def test_ranks_on_one_gpu_config5_shape(tmp_path, world, shuffle):
         total += int(d['ntracks'])
     assert total == nt
     ba.backend.close()
+
+
+# ------------------------------------------------------------------ LU semantics beyond the fallback size
+def test_large_reduced_systems_follow_the_reference_lu_trajectory():
+    """More unknowns than the LU fallback takes (400 cameras: 2394 > backend.LU_FALLBACK_MAX_UNKNOWNS): the reference solves
+    the reduced system by LU (numpy.linalg.solve, bundle_adjuster.py:302-305), which also 'succeeds' on a numerically singular
+    matrix; the GPU path solves by Cholesky and reports a failed factorisation as ill-conditioned (damping x 10, exactly what
+    the LM loop does with a rejected step).  The two must walk the same LM trajectory: identical accept / reject sequence
+    (ill-conditioned counting as rejected), accepted costs to 1e-6 - from round 1's hard start to the noise floor, and
+    restarted at the floor with the damping at 1e-13, where S is singular along the scale gauge to working precision.
+    (scripts/lu_semantics_experiment.py prints the two sequences side by side.)"""
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd.backend import LU_FALLBACK_MAX_UNKNOWNS
+    nc, nt = 400, 6000
+    assert (nc - 1) * 6 > LU_FALLBACK_MAX_UNKNOWNS
+    s = banded(nc, nt, init_mode='params')
+    flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
+    sen = O.Sensor.gaussian(1.)
+    R, t, X = s['R0'], s['t0'], s['X0']
+    for damping0, steps in ((10., 14), (1e-13, 3)):
+        b = Bundle.FromObservations(s['K'], R, t, X, s['obs_cam'], s['obs_pt'], s['obs_z'])
+        ba = BundleAdjuster(b, verbose=False)
+        ba.optimize(max_steps=steps, init_damping=damping0)
+        trace = []
+        ref = O.lm_optimize(sen, s['K'], R, t, X, s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, max_steps=steps,
+                            init_damping=damping0, trace=trace)
+        got = [(d, 'accepted' if o == 'accepted' else 'rejected') for d, o, c in ba.trial_log]
+        want = [(tr['damping'], 'accepted' if tr['next'] < tr['cur'] else 'rejected') for tr in trace]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g[1] == w[1] and abs(g[0] - w[0]) <= 1e-12 * w[0], (got, want)
+        assert ba.num_steps == ref['num_steps'] and ba.converged == ref['converged']
+        close(np.array(ba.costs), np.array(ref['costs']), 1e-6)
+        R, t, X = ref['R'], ref['t'], ref['X']
+        ba.backend.close()
