@@ -1,4 +1,4 @@
-// ba_bcr_wide.h - block cyclic reduction for half-bandwidths 12..21 (B = 6 hb = 72..126 unknowns per
+// ba_bcr_wide.h - block cyclic reduction for half-bandwidths 12..23 (B = 6 hb = 72..138 unknowns per
 // super-block).  Same algebra, node numbering and workspace layout as ba_bcr.h, but one B x B matrix is
 // all that fits in LDS, so a level is three kernels instead of one:
 //
@@ -19,10 +19,13 @@
 namespace ba {
 
 constexpr int kBcrwMinHB = kBcrMaxHB + 1;
-constexpr int kBcrwMaxHB = 21;                 // B = 126: one B x (B+1) fp64 matrix = 128 KB of the 160 KB LDS
+constexpr int kBcrwMaxHB = 23;                 // B = 138: one B x (B+1) fp64 matrix = 150 KB of the 160 KB LDS (track length 24)
+constexpr int kBcrwLvLdsMaxB = 126;            // up to here the inverses of the diagonal blocks sit in LDS next to L; beyond, in L2
 
 __host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16) * sizeof(double); }
-__host__ __device__ inline size_t bcrw_solve_lds_bytes(int B) { return ((size_t)B * (B + 1) + (size_t)((B + 11) / 12) * 144 + 64) * sizeof(double); }
+__host__ __device__ inline size_t bcrw_solve_lds_bytes(int B) {
+  return ((size_t)B * (B + 1) + (B <= kBcrwLvLdsMaxB ? (size_t)((B + 11) / 12) * 144 : 0) + 64) * sizeof(double);
+}
 
 // B x B row-major global matrix -> LDS with row stride B + 1; loads issued U at a time so that their
 // latencies overlap (one load - store pair per iteration costs a full memory round trip each)
@@ -166,10 +169,12 @@ __global__ __launch_bounds__(1024) void k_bcrw_solve_mfma(int N, int s, const do
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int B = 6 * HB, ld = B + 1, NBLK = (B + 11) / 12;
+  constexpr bool LV_LDS = B <= kBcrwLvLdsMaxB;
   double* Ls = sm;                       // [B][ld]
-  double* Lv = Ls + (size_t)B * ld;      // [NBLK][144]
+  double* Lvs = Ls + (size_t)B * ld;     // [NBLK][144] (LV_LDS)
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N || *info != 0) return;
+  const double* Lv = LV_LDS ? Lvs : Lvm + (size_t)i * NBLK * 144;
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;
   constexpr size_t BB = (size_t)B * B;
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(1024) void k_bcrw_solve_mfma(int N, int s, const do
   {
     const double* Lg = Lm + (size_t)i * BB;
     bcrw_fill<B, 1024, 16>(Ls, Lg, tid);                      // all 16 wavefronts fetch, 4 of them compute
-    for (int e = tid; e < NBLK * 144; e += 1024) Lv[e] = Lvm[(size_t)i * NBLK * 144 + e];
+    if (LV_LDS)
+      for (int e = tid; e < NBLK * 144; e += 1024) Lvs[e] = Lvm[(size_t)i * NBLK * 144 + e];
   }
   __syncthreads();
   if (wave >= 4 || 16 * ct >= ncol) return;
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(1024) void k_bcrw_products(int N, int B, int s, dou
 __global__ __launch_bounds__(1024) void k_bcrw_backsolve(int N, int B, int s, const double* __restrict__ fm,
                                                          const double* __restrict__ Pm, const double* __restrict__ Qm,
                                                          const double* __restrict__ Gi, double* __restrict__ x) {
-  __shared__ double w[128], xl[128], xr[128], red[8][128];
+  __shared__ double w[144], xl[144], xr[144], red[8][144];     // B <= 138
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N) return;
   const int l = i - s, r = i + s;
@@ -355,33 +361,36 @@ __global__ __launch_bounds__(1024) void k_bcrw_backsolve(int N, int B, int s, co
     xr[tid] = haveR ? x[(size_t)r * B + tid] : 0.0;
   }
   __syncthreads();
-  const int k = tid >> 3, q8 = tid & 7;
-  double a0 = 0.0, a1 = 0.0;
-  if (k < B) {
-    const double* Pk = Pm + (size_t)i * BB + (size_t)k * B;
-    const double* Qk = Qm + (size_t)i * BB + (size_t)k * B;
-    if (haveL)
+  const int q8 = tid & 7;
+  for (int k0 = 0; k0 < B; k0 += 128) {                      // 128 rows per pass (B > 128: a second, short pass)
+    const int k = k0 + (tid >> 3);
+    double a0 = 0.0, a1 = 0.0;
+    if (k < B) {
+      const double* Pk = Pm + (size_t)i * BB + (size_t)k * B;
+      const double* Qk = Qm + (size_t)i * BB + (size_t)k * B;
+      if (haveL)
 #pragma unroll 4
-      for (int c = q8; c < B; c += 8) a0 += Pk[c] * xl[c];
-    if (haveR)
+        for (int c = q8; c < B; c += 8) a0 += Pk[c] * xl[c];
+      if (haveR)
 #pragma unroll 4
-      for (int c = q8; c < B; c += 8) a1 += Qk[c] * xr[c];
+        for (int c = q8; c < B; c += 8) a1 += Qk[c] * xr[c];
+    }
+    double acc = a0 + a1;
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    acc += __shfl_xor(acc, 4);
+    if (k < B && q8 == 0) w[k] -= acc;
   }
-  double acc = a0 + a1;
-  acc += dpp_pair<0xB1>(acc);
-  acc += dpp_pair<0x4E>(acc);
-  acc += __shfl_xor(acc, 4);
-  if (k < B && q8 == 0) w[k] -= acc;
   __syncthreads();
-  const int m = tid & 127, g = tid >> 7;                     // x[m] = sum_{kk >= m} Ginv[kk][m] w[kk]
-  acc = 0.0;
-  if (m < B) {
+  const int g = tid >> 7;                                    // x[m] = sum_{kk >= m} Ginv[kk][m] w[kk]
+  for (int m = tid & 127; m < B; m += 128) {
+    double acc = 0.0;
     const double* Gc = Gi + (size_t)i * BB + m;
     int kk = m + g;
 #pragma unroll 4
     for (; kk < B; kk += 8) acc += Gc[kk * B] * w[kk];
+    red[g][m] = acc;
   }
-  red[g][m] = acc;
   __syncthreads();
   if (tid < B) {
     double t = 0.0;

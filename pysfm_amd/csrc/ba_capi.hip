@@ -403,7 +403,7 @@ hipError_t launch_bcrw_factor(ba_handle* h, int hb, int cnt, hipStream_t st, int
 #define BA_HB_CASE(K) case K: return launch_bcrw_factor_hb<K>(h, cnt, st, N, s, D, L, Lv, U, f, P, Q, G, info);
   switch (hb) {
     BA_HB_CASE(12) BA_HB_CASE(13) BA_HB_CASE(14) BA_HB_CASE(15) BA_HB_CASE(16) BA_HB_CASE(17) BA_HB_CASE(18) BA_HB_CASE(19)
-    BA_HB_CASE(20) BA_HB_CASE(21)
+    BA_HB_CASE(20) BA_HB_CASE(21) BA_HB_CASE(22) BA_HB_CASE(23)
     default: return hipErrorInvalidValue;
   }
 #undef BA_HB_CASE
@@ -1654,9 +1654,15 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   REQUIRE(h, info, BA_ERR_INVALID_ARG, "ba_solve_reduced: info is NULL");
   if (h->nco == 0) { *info = 0; h->have_solution = true; return BA_OK; }
   const int force = h->opt.solver;                 // ba_set_option "solver"
+  const int nodes = h->hb > 0 ? (h->nco + h->hb - 1) / h->hb : 0;
+  const bool bcr_ok = h->hb >= 1 && h->hb <= kBcrMaxHB && nodes >= 4;
+  const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && nodes >= 4;
+  const bool band_ok = h->hb <= kMaxBandSolve;       // (the single-workgroup band Cholesky is instantiated up to there)
   const bool dense_ok = 6 * h->nco <= kDcMaxN && force != SOLVER_LU;
-  const bool use_dense = dense_ok && (h->hb > kMaxBandSolve || force == SOLVER_DENSE);
-  if (h->hb > kMaxBandSolve && !use_dense) { *info = -1; return BA_OK; }     // caller's dense LU
+  const bool use_dense = dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR))));
+  const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);
+  const bool use_bcrw = !use_dense && !use_bcr && (force ? (force == SOLVER_BCR && bcrw_ok) : bcrw_ok);
+  if (force == SOLVER_LU || (!use_dense && !use_bcr && !use_bcrw && !band_ok)) { *info = -1; return BA_OK; }     // caller's dense LU
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, h->Ufac.resize(std::max<size_t>(1, reduced_doubles(h))));
   const unsigned char* dmask = nullptr;
@@ -1668,15 +1674,11 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
       dmask = h->mask.p;
     }
   }
-  // multi-CU path: block cyclic reduction when the band is narrow enough for dense
-  // (6 hb)^2 blocks in LDS and there are enough super-blocks to parallelise over
-  const bool bcr_ok = h->hb >= 1 && h->hb <= kBcrMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
-  const bool use_bcr = force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok;
+  // multi-CU paths: block cyclic reduction when the band is narrow enough for dense (6 hb)^2 blocks in LDS and there
+  // are enough super-blocks to parallelise over (decided above)
   const size_t lds_budget = 160 * 1024;
   const int ch = band_solve_chunk(h->hb, lds_budget);
   size_t lds = 0;
-  const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && (h->nco + h->hb - 1) / h->hb >= 4;
-  const bool use_bcrw = force ? (force == SOLVER_BCR && bcrw_ok) : bcrw_ok;
   h->solve_kind = use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
   if (use_dense) {
     int rc = solve_dense_chol(h, dmask);
@@ -1956,7 +1958,7 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   *info = 0;
   // the dense-visibility reduction is driven by the caller (its matrix product is a library call), and systems
   // too large for the dense device solve go to the caller's LU: do not linearise and reduce just to find that out
-  if (h->have_problem && h->hb > kMaxBandSolve && 6 * h->nco > kDcMaxN) { *info = -1; return BA_OK; }
+  if (h->have_problem && h->hb > kBcrwMaxHB && 6 * h->nco > kDcMaxN) { *info = -1; return BA_OK; }
   int32_t pre = 0;
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
   if (rc == BA_OK && h->comm) rc = comm_allreduce_reduced(h);      // sharded: the one data-path collective

@@ -497,7 +497,7 @@ def test_band_solver_vs_dense_lu(be):
         close(-be.backsubstitute(0), su, SOLVE)
 
 
-@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11), (400, 12), (300, 13), (500, 16), (400, 22), (97, 19)])
+@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11), (400, 12), (300, 13), (500, 16), (400, 22), (97, 19), (300, 23), (260, 24)])
 def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
     """The multi-CU block-cyclic-reduction solve against the single-workgroup band Cholesky and
     the dense LU on the same device-resident system (odd sizes: padded last super-block,
@@ -515,8 +515,11 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
         for solver in ('bcr', 'bcr1', 'band'):            # hb <= 11: a node over three CUs (bcr) / on one (bcr1); 12..21: ba_bcr_wide.h
             be.set_option('solver', solver)
             be.solve_reduced(mask)
-            assert be.last_solve_path == 'band'
-            assert be.last_solve_kind == ('band' if solver == 'band' or (solver == 'bcr1' and L > 12) else 'bcr' if L <= 12 else 'bcr_wide')
+            if L > 22 and solver != 'bcr':                 # no single-workgroup band solver this wide: the dense Cholesky stands in
+                assert be.last_solve_kind == 'dense_cholesky'
+            else:
+                assert be.last_solve_path == 'band'
+                assert be.last_solve_kind == ('band' if solver == 'band' or (solver == 'bcr1' and L > 12) else 'bcr' if L <= 12 else 'bcr_wide')
             sol[solver] = be.get_solution().reshape(-1)
         keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
         xd = np.zeros(n)
