@@ -39,6 +39,7 @@ namespace ba {
 
 constexpr int kBcrThreads = 1024;                // assemble (111 nodes at config 3: few workgroups, so make them wide)
 constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
+constexpr long long kBcrNotYet = 0x7FFA5A5A5A5A5A5All;    // a NaN no computation produces: the mark of a solution entry that is not there yet
 constexpr int kBcrMaxHB = 11;                  // 4 matrices of B x (B+1) doubles must fit in LDS (B = 66: 145 KB)
 
 __host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 200) * sizeof(double); }   // + inverse of the current diagonal block
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
                                                               const double* __restrict__ b,
                                                               const unsigned char* __restrict__ mask,
                                                               double* __restrict__ Dm, double* __restrict__ Um,
-                                                              double* __restrict__ fm, int* __restrict__ info) {
+                                                              double* __restrict__ fm, int* __restrict__ info,
+                                                              double* __restrict__ xsol = nullptr) {
   const int B = 6 * hb, hb1 = hb + 1;
   const int I = blockIdx.x;
   if (I == 0 && threadIdx.x == 0) *info = 0;      // status word of this solve (the eliminate levels only ever set it)
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
   for (int r = threadIdx.x; r < B; r += kBcrThreads) {
     const int i = I * hb + r / 6, a = r % 6;
     fm[(size_t)I * B + r] = (i < nco && (!mask || mask[6 * i + a])) ? b[6 * (size_t)i + a] : 0.0;
+    if (xsol) xsol[(size_t)I * B + r] = __longlong_as_double(kBcrNotYet);      // "not solved yet" (k_bcr_backsolve_fused polls the data itself)
   }
 }
 
@@ -1013,6 +1016,92 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve(int N, int B,
     acc += dpp_pair<0xB1>(acc);
     acc += dpp_pair<0x4E>(acc);
     if (q4 == 0) x[(size_t)i * B + m] = acc;
+  }
+}
+
+// --------------------------------------------------------------------------
+// ALL back-substitution levels in one launch, for systems whose N nodes are resident at once (N <= compute units).
+// What a level's launch spends most of its ~5 us on - staging P, Q, G^-1 of its nodes into LDS - does not depend on
+// the levels above it, so here every node's workgroup stages its matrices at once, then waits for x_l and x_r to be
+// PUBLISHED by the nodes above (k_bcr_assemble marks every entry of x "not yet"; a node polls the entries it needs),
+// forms x_i = G^-T (g - P x_l - Q x_r) and stores it.  The root was solved by its elimination kernel.
+// Six dependent launches of 4.7 us become one of ~2 us + 6 hand-overs.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double bcr_wait_value(const double* p) {
+  // relaxed agent-scope polls of the DATA (write-through stores, cache-bypassing loads): one memory round trip per
+  // hand-over.  Acquire loads / release fences here invalidate and write back whole L2s: 20 - 30 us per hand-over
+  // with a hundred workgroups doing it at once (measured), and a separate ready flag costs a second round trip.
+  double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (__double_as_longlong(v) == kBcrNotYet) {
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, int B, const double* __restrict__ gm,
+                                                                         const double* __restrict__ Pm,
+                                                                         const double* __restrict__ Qm,
+                                                                         const double* __restrict__ Gi, double* x) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int ld = B + 1;
+  double* MP = sm;                       // [B][ld] P
+  double* MQ = MP + (size_t)B * ld;      // [B][ld] Q
+  double* MG = MQ + (size_t)B * ld;      // [B][ld] G^-1
+  double* w = MG + (size_t)B * ld;       // [B]
+  double* xl = w + B;                    // [B]
+  double* xr = xl + B;                   // [B]
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x;
+  const int s = (i + 1) & -(i + 1);      // the level that eliminated node i: i = s (2 k + 1) - 1
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  if (!haveL && !haveR) return;          // the root: its elimination kernel wrote x_i
+  const size_t BB = (size_t)B * B;
+  {
+    constexpr int U = (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
+    double vp[U], vq[U], vg[U];
+    const double wv = tid < B ? gm[(size_t)i * B + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + kBcrElimThreads * u;
+      const bool in = e < B * B;
+      vp[u] = (in && haveL) ? Pm[(size_t)i * BB + e] : 0.0;
+      vq[u] = (in && haveR) ? Qm[(size_t)i * BB + e] : 0.0;
+      vg[u] = in ? Gi[(size_t)i * BB + e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + kBcrElimThreads * u;
+      if (e < B * B) {
+        const int rr = e / B, cc = e - rr * B;
+        MP[rr * ld + cc] = vp[u]; MQ[rr * ld + cc] = vq[u]; MG[rr * ld + cc] = vg[u];
+      }
+    }
+    if (tid < B) w[tid] = wv;
+  }
+  // x_l, x_r from the nodes above, as soon as they are there (k_bcr_assemble marked every entry "not yet")
+  if (tid < B) {
+    xl[tid] = haveL ? bcr_wait_value(x + (size_t)l * B + tid) : 0.0;
+    xr[tid] = haveR ? bcr_wait_value(x + (size_t)r * B + tid) : 0.0;
+  }
+  __syncthreads();
+  for (int task = tid; task < 4 * B; task += kBcrElimThreads) {      // w -= P xl + Q xr
+    const int k = task >> 2, q4 = task & 3;
+    double acc = 0.0;
+    for (int c = q4; c < B; c += 4) acc += MP[k * ld + c] * xl[c] + MQ[k * ld + c] * xr[c];
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    if (q4 == 0) w[k] -= acc;
+  }
+  __syncthreads();
+  for (int task = tid; task < 4 * B; task += kBcrElimThreads) {      // x = (G^-1)^T w
+    const int m = task >> 2, q4 = task & 3;
+    double acc = 0.0;
+    for (int k = m + q4; k < B; k += 4) acc += MG[k * ld + m] * w[k];
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    if (q4 == 0) __hip_atomic_store(x + (size_t)i * B + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

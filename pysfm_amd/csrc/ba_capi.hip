@@ -58,6 +58,7 @@ struct Options {
   bool sort_points = true;         // internal point order (ba_set_problem); off = the caller's order as given
   int gm_cap = 0;                  // points per MFMA group (0 = chosen by ba_set_problem)
   bool lds_window = true;          // k_schur_groups_mfma3 accumulates in an LDS window of the band when one fits
+  bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
 
@@ -350,9 +351,9 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   const bool split = h->opt.solver != SOLVER_BCR1;
   std::vector<char> level_split;
   {
-    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1] and marks the solution "not there yet"
     hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
-                       h->bcrU.p, h->bcrF.p, h->flags.p + 1);
+                       h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p);
   }
   const size_t lds = bcr_lds_bytes(B);
   std::vector<int> strides;
@@ -374,11 +375,21 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   // a level whose only node has no neighbours (the root) was solved inside its eliminate kernel
   int top = (int)strides.size() - 1;
   if (top >= 0 && (N / strides[top] + 1) / 2 == 1 && 2 * strides[top] - 1 >= N) --top;
+  const bool uniform = level_split.empty() || level_split.front() == level_split.back();     // one source of g for all levels
+  if (h->opt.fused_backsolve && N <= h->ncu && uniform && top >= 0) {
+    // every node's workgroup is resident at once: all levels in ONE launch, handing x down through flags
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_bcr_backsolve_fused));
+    ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, 1);
+    hipLaunchKernelGGL(k_bcr_backsolve_fused, dim3(N), dim3(kBcrElimThreads), lds2, h->stream, N, B,
+                       (!level_split.empty() && level_split.front()) ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p);
+    HIPCHECK(h, hipGetLastError());
+    return BA_OK;
+  }
   ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, top + 1);
   for (int q = top; q >= 0; --q) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
     hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s,
-                       level_split[q] ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p);    // x[N][B] IS dC's layout (padded to whole super-blocks)
+                       level_split[q] ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p);
   }
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
@@ -421,7 +432,7 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
     hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
-                       h->bcrU.p, h->bcrF.p, h->flags.p + 1);
+                       h->bcrU.p, h->bcrF.p, h->flags.p + 1, (double*)nullptr);
   }
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
@@ -636,6 +647,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "sort_points") ok = flag(h->opt.sort_points);
   else if (n == "solve_trace") ok = flag(h->opt.solve_trace);
   else if (n == "lds_window") ok = flag(h->opt.lds_window);
+  else if (n == "fused_backsolve") ok = flag(h->opt.fused_backsolve);
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);
   if (!ok) return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: bad value '%s' for option '%s'", value, name);

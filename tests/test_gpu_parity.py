@@ -33,7 +33,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1, fuse_lin=0,
-                       sort_points=1, gm_cap=0, lds_window=1)
+                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1)
 
 
 @pytest.fixture(autouse=True)
@@ -528,6 +528,11 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
         close(sol['band'], xd, 1e-9)
         close(sol['bcr'], sol['band'], 1e-10)
         close(sol['bcr1'], sol['band'], 1e-10)
+        be.set_option('solver', 'bcr')                    # the back-substitution level by level instead of in one launch
+        be.set_option('fused_backsolve', 0)
+        be.solve_reduced(mask)
+        be.set_option('fused_backsolve', 1)
+        close(be.get_solution().reshape(-1), sol['bcr'], 1e-13)
         if mask is not None:
             assert np.all(sol['bcr'][mask == 0] == 0)
 
