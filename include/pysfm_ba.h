@@ -71,6 +71,8 @@ int ba_synchronize(ba_handle* h);
 /* Test / measurement switches; the defaults are the product path and the library never reads the environment.
  *   "schur"         auto | pairs | groups | mfma1 | mfma2 | mfma   force a Schur-reduction kernel (falls back to pairs when not applicable)
  *   "lds_window"    1 | 0                                  LDS accumulation window of the matrix-core reduction (0: global atomics only)
+ *   "fast_paths"    1 | 0                                  short cuts of the per-observation arithmetic for K = I and the unit Gaussian
+ *                                                          sensor model (the reference's defaults); 0: the general formulas always
  *   "fused_backsolve" 1 | 0                                all back-substitution levels of the cyclic reduction in one launch (when its
  *                                                          nodes fit the chip at once) / one launch per level
  *   "solver"        auto | bcr | band | dense | lu | bcr1  force the reduced solver (lu: always report -1 = caller's LU; bcr1: the

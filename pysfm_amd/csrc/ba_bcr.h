@@ -39,6 +39,7 @@ namespace ba {
 
 constexpr int kBcrThreads = 1024;                // assemble (111 nodes at config 3: few workgroups, so make them wide)
 constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
+constexpr int kBcrTicketWord = 61;             // info[61]: tickets of k_bcr_backsolve_fused (info = flags + 1, 64 flag words)
 constexpr long long kBcrNotYet = 0x7FFA5A5A5A5A5A5All;    // a NaN no computation produces: the mark of a solution entry that is not there yet
 constexpr int kBcrMaxHB = 11;                  // 4 matrices of B x (B+1) doubles must fit in LDS (B = 66: 145 KB)
 
@@ -54,7 +55,10 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
                                                               double* __restrict__ xsol = nullptr) {
   const int B = 6 * hb, hb1 = hb + 1;
   const int I = blockIdx.x;
-  if (I == 0 && threadIdx.x == 0) *info = 0;      // status word of this solve (the eliminate levels only ever set it)
+  if (I == 0 && threadIdx.x == 0) {
+    *info = 0;                                    // status word of this solve (the eliminate levels only ever set it)
+    info[kBcrTicketWord] = 0;                     // ticket counter of k_bcr_backsolve_fused
+  }
   for (int e = threadIdx.x; e < B * B; e += kBcrThreads) {
     const int r = e / B, c = e - r * B;
     const int i = I * hb + r / 6, j = I * hb + c / 6, a = r % 6, bb = c % 6;
@@ -1042,7 +1046,8 @@ __device__ __forceinline__ double bcr_wait_value(const double* p) {
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, int B, const double* __restrict__ gm,
                                                                          const double* __restrict__ Pm,
                                                                          const double* __restrict__ Qm,
-                                                                         const double* __restrict__ Gi, double* x) {
+                                                                         const double* __restrict__ Gi, double* x,
+                                                                         const int* __restrict__ order, int* ticket) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int ld = B + 1;
   double* MP = sm;                       // [B][ld] P
@@ -1052,7 +1057,17 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, 
   double* xl = w + B;                    // [B]
   double* xr = xl + B;                   // [B]
   const int tid = threadIdx.x;
-  const int i = blockIdx.x;
+  // NO DEADLOCK, whatever else shares the GPU: a workgroup takes a ticket when it STARTS and works on order[ticket],
+  // and `order` lists the nodes level by level from the root down - so a node only ever waits for nodes whose
+  // workgroups have started before it (they are resident or done: started workgroups are never preempted).  Waiting
+  // by blockIdx instead hung two processes on one GPU, each kernel holding compute units the other's parents needed.
+  // a failed elimination (matrix not positive definite: status word set by an earlier launch) leaves solution entries
+  // unwritten: nobody may wait for them
+  if (ticket[-kBcrTicketWord] != 0) return;
+  int* my_ticket = reinterpret_cast<int*>(xr + B);      // (in the dynamic area: the kernel may ask for all 160 KB of it)
+  if (tid == 0) *my_ticket = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int i = order[*my_ticket];
   const int s = (i + 1) & -(i + 1);      // the level that eliminated node i: i = s (2 k + 1) - 1
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;

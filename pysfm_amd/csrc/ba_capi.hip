@@ -58,6 +58,7 @@ struct Options {
   bool sort_points = true;         // internal point order (ba_set_problem); off = the caller's order as given
   int gm_cap = 0;                  // points per MFMA group (0 = chosen by ba_set_problem)
   bool lds_window = true;          // k_schur_groups_mfma3 accumulates in an LDS window of the band when one fits
+  bool fast_paths = true;          // K = I / unit-Gaussian short cuts of the per-observation arithmetic (ba_math.h)
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
@@ -96,7 +97,7 @@ struct ba_handle {
   double trial_rcond = 0.0;          // ba_lm_trial_begin -> ba_lm_trial_end
   int glog = 0;              // lanes per point = 2^glog
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0};
+  Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0, FAST_UNIT_GAUSS};
   DevBuf<int> obs_cam, obs_pt, pt_off, cam_opt_pos, opt_cam, keep;
   DevBuf<double2> obs_z;
   DevBuf<unsigned char> pt_opt;
@@ -132,6 +133,8 @@ struct ba_handle {
   // normal-equation blocks
   DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, fac, dUd, dDd, dyd, dpart, comm_dev;
   DevBuf<unsigned char> mask;
+  DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)
+  int bcr_order_n = 0;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
   DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
@@ -250,6 +253,10 @@ DevProblem dev_problem(const ba_handle* h) {
   P.cam_opt_pos = h->cam_opt_pos.p; P.pt_opt = h->pt_opt.p;
   std::memcpy(P.K, h->K, sizeof P.K);
   P.sensor = h->sensor;
+  const double* K = h->K;
+  if (K[0] == 1.0 && K[4] == 1.0 && K[8] == 1.0 && K[1] == 0.0 && K[2] == 0.0 && K[3] == 0.0 && K[5] == 0.0 && K[6] == 0.0 && K[7] == 0.0)
+    P.sensor.fast |= FAST_K_IDENTITY;
+  if (!h->opt.fast_paths) P.sensor.fast = 0;
   return P;
 }
 
@@ -376,12 +383,26 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   int top = (int)strides.size() - 1;
   if (top >= 0 && (N / strides[top] + 1) / 2 == 1 && 2 * strides[top] - 1 >= N) --top;
   const bool uniform = level_split.empty() || level_split.front() == level_split.back();     // one source of g for all levels
-  if (h->opt.fused_backsolve && N <= h->ncu && uniform && top >= 0) {
+  if (h->opt.fused_backsolve && N <= 4 * h->ncu && uniform && top >= 0) {
     // every node's workgroup is resident at once: all levels in ONE launch, handing x down through flags
+    if (h->bcr_order_n != N) {
+      std::vector<int> order;
+      for (int q = (int)strides.size() - 1; q >= 0; --q)
+        for (int k = 0, cnt = (N / strides[q] + 1) / 2; k < cnt; ++k) {
+          const int i = strides[q] * (2 * k + 1) - 1;
+          if (i < N) order.push_back(i);
+        }
+      if ((int)order.size() != N) return h->fail(BA_ERR_STATE, "cyclic reduction: %d of %d nodes in the level lists", (int)order.size(), N);
+      HIPCHECK(h, h->bcr_order.resize((size_t)N));
+      HIPCHECK(h, hipMemcpyAsync(h->bcr_order.p, order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      HIPCHECK(h, hipStreamSynchronize(h->stream));          // `order` goes out of scope
+      h->bcr_order_n = N;
+    }
     HIPCHECK(h, ensure_lds_attr(h, (const void*)k_bcr_backsolve_fused));
     ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, 1);
     hipLaunchKernelGGL(k_bcr_backsolve_fused, dim3(N), dim3(kBcrElimThreads), lds2, h->stream, N, B,
-                       (!level_split.empty() && level_split.front()) ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p);
+                       (!level_split.empty() && level_split.front()) ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p,
+                       h->bcr_order.p, h->flags.p + 1 + kBcrTicketWord);
     HIPCHECK(h, hipGetLastError());
     return BA_OK;
   }
@@ -615,7 +636,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -648,6 +669,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "solve_trace") ok = flag(h->opt.solve_trace);
   else if (n == "lds_window") ok = flag(h->opt.lds_window);
   else if (n == "fused_backsolve") ok = flag(h->opt.fused_backsolve);
+  else if (n == "fast_paths") ok = flag(h->opt.fast_paths);
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);
   if (!ok) return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: bad value '%s' for option '%s'", value, name);
@@ -1086,11 +1108,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
 
 int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams) {
   if (!h) return BA_ERR_INVALID_ARG;
-  Sensor s{kind, {1, 0, 0, 1}, 1.0, 1.0};
+  Sensor s{kind, {1, 0, 0, 1}, 1.0, 1.0, 0};
   switch (kind) {
     case BA_SENSOR_GAUSS:
       REQUIRE(h, params && nparams == 4, BA_ERR_INVALID_ARG, "ba_set_sensor: Gaussian needs 4 params (L row-major)");
       for (int i = 0; i < 4; ++i) s.L[i] = params[i];
+      if (s.L[0] == 1.0 && s.L[1] == 0.0 && s.L[2] == 0.0 && s.L[3] == 1.0) s.fast |= FAST_UNIT_GAUSS;
       break;
     case BA_SENSOR_CAUCHY:
       REQUIRE(h, params && nparams == 1 && params[0] > 0, BA_ERR_INVALID_ARG, "ba_set_sensor: Cauchy needs sigma > 0");

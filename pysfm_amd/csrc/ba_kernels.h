@@ -1186,6 +1186,9 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int pair = wv & 3;
   const bool producer = wv < kGm2Pairs;
+#ifdef BA_BCR_PROFILE
+  const long long pkk = clock64();
+#endif
   const SchurChunk ck = chunks[blockIdx.x];
   const int p0 = ck.p0;
   for (int i = threadIdx.x; i < wn * (rowlen + 6); i += kGm2Block) tile[i] = 0.0;
@@ -1196,6 +1199,10 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
   int* fConsumed = fStaged + 1;
   int nbatch = 0;                                              // batches this pair has handed over so far
 
+#ifdef BA_BCR_PROFILE
+  long long pw = 0, pc = 0, pe = 0, pn = 0;                   // cycles: waiting / working / epilogue, batches
+  const long long pk0 = clock64();
+#endif
   if (producer) {
     for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
       const SchurGroup gr = groups[g];
@@ -1257,7 +1264,13 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
             }
           }
         }
+#ifdef BA_BCR_PROFILE
+        const long long w0 = clock64();
+#endif
         gm2_wait(fConsumed, nbatch - 1);                         // the buffer's previous batch (nbatch - 2) has been read
+#ifdef BA_BCR_PROFILE
+        pw += clock64() - w0; ++pn;
+#endif
         double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
         double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
         if (stager) {
@@ -1274,6 +1287,9 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
         ++nbatch;
         gm2_post(fStaged, nbatch, lane);
       }
+#ifdef BA_BCR_PROFILE
+      const long long e0 = clock64();
+#endif
       if (mypos >= 0) {
         const int wr = mypos - p0;
         const bool in = wr >= 0 && wr < wn;
@@ -1303,6 +1319,9 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
           }
         }
       }
+#ifdef BA_BCR_PROFILE
+      pe += clock64() - e0;
+#endif
     }
   } else {
     const int lr = lane & 15, lk = lane >> 4;
@@ -1318,7 +1337,13 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
 #pragma unroll
       for (int t = 0; t < 10; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
       for (int ib = 0; ib < nb; ++ib) {
+#ifdef BA_BCR_PROFILE
+        const long long w0 = clock64();
+#endif
         gm2_wait(fStaged, nbatch + 1);
+#ifdef BA_BCR_PROFILE
+        pw += clock64() - w0; ++pn;
+#endif
         const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
         const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
 #pragma unroll
@@ -1339,6 +1364,9 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
         }
       }
       lds_wave_sync();                                          // mPos
+#ifdef BA_BCR_PROFILE
+      const long long e0 = clock64();
+#endif
       // ---- epilogue: C/D layout lane -> column n = 16 tj + lane%16, register v -> row m = 16 ti + lane/16 + 4 v.
       // Usual case (wave-uniform test): every optimised camera of the group lies inside the workgroup's LDS
       // window.  Then there is ONE unconditional ds_add_f64 per accumulator register (+ one for the mirrored
@@ -1436,8 +1464,15 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
         }
       }
       lds_wave_sync();                                          // mPos is rewritten by the next group
+#ifdef BA_BCR_PROFILE
+      pe += clock64() - e0;
+#endif
     }
   }
+#ifdef BA_BCR_PROFILE
+  const long long pk1 = clock64();
+  (void)pc;
+#endif
   if (wn == 0) return;
   __syncthreads();
   for (int i = threadIdx.x; i < wn * rowlen; i += kGm2Block) {
@@ -1449,9 +1484,13 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
     const double v = tb[i];
     if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
   }
+#ifdef BA_BCR_PROFILE
+  if (blockIdx.x == 100 && lane == 0 && (wv == 0 || wv == 4))
+    printf("[k_schur_groups_mfma2 wg 100 %s] batches %lld: total %lld cycles, waiting for the partner %lld, epilogue %lld; workgroup setup %lld, tail (barrier + flush) %lld\n",
+           wv == 0 ? "producer" : "consumer", pn, pk1 - pk0, pw, pe, pk0 - pkk, clock64() - pk1);
+#endif
 }
 
-// --------------------------------------------------------------------------
 // The producer / consumer reduction for ANY track length up to kGm3MaxL = 24 (ragged runs included): the
 // 6L x 6L window of a group is NT = ceil(6L / 16) tiles on a side (up to 9), its upper triangle up to 45
 // tiles - more accumulators than one wavefront has registers for beyond NT = 6.  So the kernel is a template

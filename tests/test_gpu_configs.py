@@ -265,6 +265,7 @@ def test_config5_properties_10000x1M(be, config5):
     assert abs(be.cost(0) - _chunked_cost(sensor, s, flags)) <= 1e-11 * be.cost(0)
     be.linearize(0)
     be.schur(0, 10., 1e-5)
+    be.synchronize()                                                  # (the kernels run on the backend's own stream, .cpu() on torch's)
     St, bt = be.reduced_tensors()
     band = St.cpu().numpy().reshape(nc - 1, 10, 6, 6).copy()
     bfull = bt.cpu().numpy().reshape(nc - 1, 6).copy()
@@ -311,6 +312,7 @@ def test_config5_properties_10000x1M(be, config5):
         assert be.half_bandwidth == 9
         be.linearize(0)
         be.schur(0, 10., 1e-5)
+        be.synchronize()
         St, bt = be.reduced_tensors()
         acc_S += St.cpu().numpy().reshape(band.shape)
         acc_b += bt.cpu().numpy().reshape(bfull.shape)

@@ -33,7 +33,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1, fuse_lin=0,
-                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1)
+                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fast_paths=1)
 
 
 @pytest.fixture(autouse=True)
@@ -116,6 +116,30 @@ def test_huber_vs_oracle(be):
     r, J = be.eval_sensor(e)
     close(r, O.sensor_residual(s, e), 1e-13)
     close(J, O.sensor_jacobian(s, e), 1e-12)
+
+
+def test_fast_paths_equal_the_general_formulas(be):
+    """K = I and the unit Gaussian sensor model take short cuts in ba_math.h (no K products, no 2 x 2 sensor Jacobian):
+    same per-observation values, blocks, reduced system and trial as the general code (option fast_paths = 0)."""
+    s = banded(40, 2000, track_len=9)
+    flags = default_flags(40, 2000)
+    out = {}
+    for fast in (1, 0):
+        be.set_option('fast_paths', fast)
+        load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+        ev = be.eval_observations(0)
+        be.linearize(0)
+        blk = be.get_blocks()
+        info, cost = be.lm_trial(2., 1e-5, None)
+        assert info == 0
+        out[fast] = [ev['e'], ev['r'], ev['Jc'], ev['Jp'], blk['HCC'], blk['HPP'], blk['bC'], blk['bP'], *be.get_reduced(), be.get_params(1)[2],
+                     np.array([cost, be.cost(0)])]
+    for x, y in zip(out[1], out[0]):
+        close(x, y, 1e-13)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    r0, Jc0, Jp0 = O.jacobians(O.Sensor.gaussian(1.), *a)
+    close(out[1][2], Jc0, 1e-13)
+    close(out[1][3], Jp0, 1e-13)
 
 
 # ------------------------------------------------------------------ golden: 4x10 Cauchy scene
