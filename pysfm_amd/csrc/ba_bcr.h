@@ -1043,7 +1043,8 @@ __device__ __forceinline__ double bcr_wait_value(const double* p) {
   return v;
 }
 
-__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, int B, const double* __restrict__ gm,
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, int B, const double* __restrict__ gm_split,
+                                                                         const double* __restrict__ gm_one, int split_stride,
                                                                          const double* __restrict__ Pm,
                                                                          const double* __restrict__ Qm,
                                                                          const double* __restrict__ Gi, double* x,
@@ -1076,6 +1077,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, 
   {
     constexpr int U = (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
     double vp[U], vq[U], vg[U];
+    const double* gm = s >= split_stride ? gm_split : gm_one;          // which elimination kernel left this node's g
     const double wv = tid < B ? gm[(size_t)i * B + tid] : 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {

@@ -382,8 +382,10 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   // a level whose only node has no neighbours (the root) was solved inside its eliminate kernel
   int top = (int)strides.size() - 1;
   if (top >= 0 && (N / strides[top] + 1) / 2 == 1 && 2 * strides[top] - 1 >= N) --top;
-  const bool uniform = level_split.empty() || level_split.front() == level_split.back();     // one source of g for all levels
-  if (h->opt.fused_backsolve && N <= 4 * h->ncu && uniform && top >= 0) {
+  int split_stride = INT32_MAX;                            // the first (smallest-stride) level eliminated by the split kernel
+  for (size_t q = 0; q < strides.size(); ++q)
+    if (level_split[q]) { split_stride = strides[q]; break; }
+  if (h->opt.fused_backsolve && N <= 8 * h->ncu && top >= 0) {
     // every node's workgroup is resident at once: all levels in ONE launch, handing x down through flags
     if (h->bcr_order_n != N) {
       std::vector<int> order;
@@ -400,8 +402,8 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
     }
     HIPCHECK(h, ensure_lds_attr(h, (const void*)k_bcr_backsolve_fused));
     ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, 1);
-    hipLaunchKernelGGL(k_bcr_backsolve_fused, dim3(N), dim3(kBcrElimThreads), lds2, h->stream, N, B,
-                       (!level_split.empty() && level_split.front()) ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p,
+    hipLaunchKernelGGL(k_bcr_backsolve_fused, dim3(N), dim3(kBcrElimThreads), lds2, h->stream, N, B, h->bcrGv.p, h->bcrF.p,
+                       split_stride, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p,
                        h->bcr_order.p, h->flags.p + 1 + kBcrTicketWord);
     HIPCHECK(h, hipGetLastError());
     return BA_OK;
