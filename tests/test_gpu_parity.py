@@ -400,6 +400,17 @@ def test_empty_and_degenerate_inputs(be):
     be.schur(0, 1., 1e-5)
     S, b = be.get_reduced()
     assert not S.any() and not b.any()
+    # an empty shard of a sharded adjuster (no tracks at all): its half of a trial runs and contributes zeros
+    be.set_problem(3, 0, empty_i, empty_i, empty_z, K, flags[0], np.zeros(0, np.uint8))
+    be.set_sensor(0, np.eye(2).reshape(4))
+    be.set_params(0, R, t, np.zeros((0, 3)))
+    be.lm_trial_begin(10., 1e-5)
+    S, b = be.get_reduced()
+    assert not S.any() and not b.any() and be.cost(0) == 0.
+    with pytest.raises(ValueError):
+        be.set_option('schur', 'no-such-kernel')
+    with pytest.raises(ValueError):
+        be.set_option('no-such-option', 1)
     be.set_problem(3, 4, [0, 1], [1, 0], np.zeros((2, 2)), K, *flags)          # any observation order is accepted
     with pytest.raises(ValueError):
         be.set_problem(3, 4, [1, 1], [2, 2], np.zeros((2, 2)), K, *flags)      # a (camera, track) pair twice
