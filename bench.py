@@ -101,13 +101,21 @@ def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
     return 0
 
 
+PMC_WORKLOAD = 'config3'           # set by main(): which committed profile the traffic numbers may come from
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/*_hbm_traffic.csv, written by scripts/summarize_profile.py from separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  None if absent."""
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary OF THIS WORKLOAD
+    (profiles/<round>_hbm_traffic.csv for config 3, profiles/<round>_config5_hbm_traffic.csv for config 5; written by
+    scripts/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
+    None if absent (other workloads have no committed counter run)."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.csv')))
+    if PMC_WORKLOAD == 'config3':
+        files = [f for f in files if '_config' not in os.path.basename(f)]
+    else:
+        files = [f for f in files if ('_%s_' % PMC_WORKLOAD) in os.path.basename(f)]
     if not files:
         return None, None
     # the timer id 'schur_pairs' covers the interchangeable reduction kernels
@@ -219,11 +227,16 @@ def main():
     ap.add_argument('--windows', type=int, default=5, help='extra timed windows of --steps trials after the headline one (min / median)')
     ap.add_argument('--force-comm', action='store_true', help='run the sharded path with a one-rank RCCL group on one GPU')
     ap.add_argument('--collectives', default='library', choices=['library', 'torch'])
+    ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
+                    help='library option for experiments (HipBackend.set_option), e.g. --option solver=bcr1; recorded in the JSON line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true',
                     help='no HIP events at all in the timed region (for external kernel traces); roofline uses the warm-up timings')
     ap.add_argument('--no-lm', action='store_true', help='skip the untimed full optimize() that yields the RMSE')
     args = ap.parse_args()
+    global PMC_WORKLOAD
+    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
+    PMC_WORKLOAD = ('config3' if args.config == 3 else 'config%d' % args.config) if plain and args.gpus == 1 and args.sensor is None and args.outliers is None else 'none'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args.gpus)                      # does not return
@@ -274,6 +287,9 @@ def main():
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
     bundle = Bundle.FromObservations(s['K'], s['R0'], s['t0'], X0, obs_cam, obs_pt, obs_z, sensor_model=model)
     ba = BundleAdjuster(device=local_rank, comm=comm, verbose=False)
+    for kv in args.option:
+        name, _, val = kv.partition('=')
+        ba.backend.set_option(name, val)
     track_ids = None
     if comm is not None:
         track_ids = shard_tracks(bundle, rank, world)
@@ -433,6 +449,7 @@ def main():
                                       ', tracks and observations handed over in random order' if args.shuffle_points else ''),
                        'cameras': nc, 'points': nt, 'observations': nobs_total, 'track_len': args.track_len,
                        'shuffled': bool(args.shuffle_points), 'parallelism': 'points sharded x%d' % ngpus,
+                       'library_options': args.option or None,
                        'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False)
                                                                  else 'torch.distributed (RCCL): ' + str(getattr(comm, 'direct_fallback_reason', None))),
                        'allreduce_payload_bytes_per_rank_per_trial': None if comm is None else 8 * (be.S_doubles + 6 * nco) + 8 * 2050},
@@ -469,6 +486,10 @@ def main():
         import ctypes
         import torch.distributed as dist
         ctypes.CDLL(None).fflush(None)          # (every rank's buffered C output is out before rank 0 prints)
+        dist.barrier()
+        if getattr(be, 'direct_comm', False):   # the library's own communicator goes before the process group does
+            be.synchronize()
+            be.comm_detach()
         dist.barrier()
         dist.destroy_process_group()
     # RCCL writes a version banner to the C stdout buffer, which is flushed at exit, i.e. AFTER anything Python
