@@ -1,0 +1,94 @@
+"""Randomised parity sweep: seeded scenes of random shape (cameras, track length 2 ... 24, ragged tracks, frozen cameras
+anywhere, tracks that are not optimised, masked camera parameters, tracks and observations in random order, all three
+sensor models) through the C ABI against the CPU oracle - the net under the internal point order, the general
+matrix-core reduction and the split-node cyclic reduction, whose work lists depend on the shape of the scene.
+Needs a real MI355X: run with ``-m gpu``."""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as O
+from test_gpu_parity import DEFAULT_OPTIONS, banded, close, load_problem  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    from pysfm_amd.backend import HipBackend
+    b = HipBackend(0)
+    yield b
+    b.close()
+
+
+def make_case(seed):
+    rs = np.random.RandomState(1000 + seed)
+    L = int(rs.choice([2, 3, 5, 7, 9, 10, 11, 12, 13, 15, 16, 17, 19, 21, 24]))
+    nc = int(rs.randint(max(L + 3, 12), 90))
+    if L >= 22:
+        nc = max(nc, 100)                                  # (sparse enough not to be taken for a dense-visibility scene)
+    nt = int(rs.randint(60, 1500))
+    s = banded(nc, nt, track_len=L, outlier_frac=float(rs.choice([0., .05])), seed=int(rs.randint(1, 10000)))
+    keep = rs.rand(len(s['obs_cam'])) >= float(rs.choice([0., .1, .35]))          # ragged tracks
+    keep[::L] = True                                                               # (every track keeps an observation)
+    cam, pt, z = s['obs_cam'][keep], s['obs_pt'][keep], s['obs_z'][keep]
+    X0 = s['X0']
+    if rs.rand() < .6:                                                             # random track numbering and observation order
+        new_id = rs.permutation(nt)
+        X0 = np.empty_like(s['X0'])
+        X0[new_id] = s['X0']
+        o = rs.permutation(len(cam))
+        cam, pt, z = cam[o], new_id[pt[o]].astype(np.int32), z[o]
+    frozen = set([0] if rs.rand() < .7 else []) | set(rs.choice(nc, int(rs.randint(0, 3)), replace=False).tolist())
+    if len(frozen) == nc:
+        frozen = {0}
+    cam_opt_pos = -np.ones(nc, np.int32)
+    opt = [c for c in range(nc) if c not in frozen]
+    if rs.rand() < .3:
+        opt = rs.permutation(opt).tolist()                                         # optimised positions in another order than the cameras
+    cam_opt_pos[opt] = np.arange(len(opt))
+    pt_opt = (rs.rand(nt) >= float(rs.choice([0., .2]))).astype(np.uint8)
+    sensor = [O.Sensor.gaussian(1.), O.Sensor.cauchy(.05), O.Sensor.huber(.06),
+              O.Sensor(O.GAUSS, L=np.array([[1.3, 0.], [.2, .8]]))][int(rs.randint(0, 4))]
+    mask = None
+    if rs.rand() < .4:
+        mask = (rs.rand(len(opt) * 6) > .1).astype(np.uint8)
+    damping = float(rs.choice([1e-3, .5, 10.]))
+    return dict(a=(s['K'], s['R0'], s['t0'], X0, cam, pt, z), cam_opt_pos=cam_opt_pos, pt_opt=pt_opt, sensor=sensor, mask=mask,
+                damping=damping, L=L, nc=nc, nt=nt)
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_random_scene_full_step_vs_oracle(be, seed):
+    c = make_case(seed)
+    a, cp, po, sensor = c['a'], c['cam_opt_pos'], c['pt_opt'], c['sensor']
+    load_problem(be, *a, cp, po, sensor)
+    close(be.cost(0), O.cost(sensor, *a, cp, po), 1e-12, atol=1e-300)
+    cmask = None if c['mask'] is None else c['mask'].astype(bool)
+    mu, su, parts = O.compute_update(sensor, *a, cp, po, damping=c['damping'], cam_param_mask=cmask, return_parts=True)
+    be.linearize(0)
+    blk = be.get_blocks()
+    for k in ('HCC', 'bC', 'HPP', 'bP'):
+        close(blk[k], parts[k], 1e-11)
+    be.schur(0, c['damping'], 1e-5)
+    S, b = be.get_reduced()
+    close(S, parts['S'], 1e-11)
+    close(b, parts['b'], 1e-11)
+    be.solve_reduced(c['mask'])
+    dC = be.get_solution()
+    dP = be.backsubstitute(0)
+    cond = np.linalg.cond(O.flatten_reduced(parts['S'], parts['b'])[0][np.ix_(*(2 * [np.nonzero(cmask)[0] if cmask is not None else np.arange(S.shape[0] * 6)]))])
+    tol = max(1e-9, 1e-14 * cond)                           # (a solve is as good as its condition number allows)
+    close(-dC, mu, tol)
+    close(-dP[po.astype(bool)], su, tol)
+    # the whole trial as one batch (camera blocks and right-hand side inside the reduction, cost inside the back-substitution)
+    info, cost = be.lm_trial(c['damping'], 1e-5, c['mask'])
+    assert info == 0
+    S2, b2 = be.get_reduced()
+    close(S2, parts['S'], 1e-11)
+    close(b2, parts['b'], 1e-11)
+    R2, t2, X2 = O.apply_update(a[1], a[2], a[3], mu, su, cp, po)
+    Rg, tg, Xg = be.get_params(1)
+    close(Xg, X2, tol, atol=1e-12)
+    close(tg, t2, tol, atol=1e-12)
+    ref_cost = O.cost(sensor, a[0], R2, t2, X2, a[4], a[5], a[6], cp, po)
+    assert abs(cost - ref_cost) <= max(1e-8, 10 * tol) * max(ref_cost, 1e-300)
