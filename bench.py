@@ -222,6 +222,8 @@ def main():
     ap.add_argument('--pts-per-gpu', type=int, default=None, help='override: points per GPU (weak scaling)')
     ap.add_argument('--track-len', type=int, default=10)
     ap.add_argument('--shuffle-points', action='store_true')
+    ap.add_argument('--drop-observations', type=float, default=0., metavar='FRAC',
+                    help='drop this fraction of the observations at random (every track keeps two): camera lists no longer repeat')
     ap.add_argument('--sensor', default=None, choices=['gaussian', 'cauchy', 'huber'])
     ap.add_argument('--outliers', type=float, default=None)
     ap.add_argument('--windows', type=int, default=5, help='extra timed windows of --steps trials after the headline one (min / median)')
@@ -235,7 +237,7 @@ def main():
     ap.add_argument('--no-lm', action='store_true', help='skip the untimed full optimize() that yields the RMSE')
     args = ap.parse_args()
     global PMC_WORKLOAD
-    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
+    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations
     PMC_WORKLOAD = ('config3' if args.config == 3 else 'config%d' % args.config) if plain and args.gpus == 1 and args.sensor is None and args.outliers is None else 'none'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -276,6 +278,12 @@ def main():
     outliers = cfg.get('outliers', 0.) if args.outliers is None else args.outliers
     s = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers)
     obs_cam, obs_pt, obs_z, X0 = s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0']
+    if args.drop_observations > 0:                 # ragged tracks: points no longer share their camera lists
+        rs = np.random.RandomState(11)
+        keep = rs.rand(len(obs_cam)) >= args.drop_observations
+        keep[::args.track_len] = True
+        keep[1::args.track_len] = True
+        obs_cam, obs_pt, obs_z = obs_cam[keep], obs_pt[keep], obs_z[keep]
     if args.shuffle_points:                        # tracks renumbered at random, observations in random order
         rs = np.random.RandomState(7)
         new_id = rs.permutation(nt)                # track k becomes track new_id[k]
@@ -296,7 +304,7 @@ def main():
     ba.set_bundle(bundle, track_ids=track_ids)
     be = ba.backend
     nobs_local = be.nobs
-    nobs_total = len(s['obs_cam'])
+    nobs_total = len(obs_cam)
 
     def sync():
         torch.cuda.synchronize()
@@ -446,7 +454,8 @@ def main():
                                       ' (%s scaling: %d points / %d obs on this GPU)' % ('strong' if strong else 'weak', be.nt, nobs_local) if ngpus > 1 else '',
                                       '+RCCL all-reduce' if comm is not None else '', sensor_name,
                                       ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
-                                      ', tracks and observations handed over in random order' if args.shuffle_points else ''),
+                                      (', tracks and observations handed over in random order' if args.shuffle_points else '') +
+                                      (', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * args.drop_observations) if args.drop_observations else '')),
                        'cameras': nc, 'points': nt, 'observations': nobs_total, 'track_len': args.track_len,
                        'shuffled': bool(args.shuffle_points), 'parallelism': 'points sharded x%d' % ngpus,
                        'library_options': args.option or None,

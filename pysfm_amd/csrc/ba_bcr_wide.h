@@ -234,15 +234,22 @@ __global__ __launch_bounds__(1024) void k_bcrw_solve_mfma(int N, int s, const do
       continue;
     }
     mfma_acc acc = {ny[kb][0], ny[kb][1], ny[kb][2], 0.0};
+    // The last block row of a B that is not a multiple of 12 has 6 real rows; rows 6..11 of its A operand lie beyond L.
+    // They must be ZERO, not "whatever is there": the zero-padded inverse of the diagonal block multiplies them by 0,
+    // and 0 x NaN = NaN (beyond B = 126 "whatever is there" is LDS no kernel of ours initialised - found by the
+    // randomised sweep as a solve that failed only after other problems had run on the handle).
+    const bool tail = kb == NBLK - 1 && B % 12 != 0;         // compile time (the loop is unrolled)
+    const double rowok = (!tail || r0 + lr < B) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < kb; ++j) {
       if (12 * j + 12 <= zero_rows) continue;                // Y_j is zero
-      const double* ap = Ls + (r0 + lr) * ld + 12 * j + lk;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], ny[j][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4], ny[j][1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[8], ny[j][2], acc, 0, 0, 0);
+      const double* ap = Ls + (tail && r0 + lr >= B ? B - 1 : r0 + lr) * ld + 12 * j + lk;
+      const double a0 = tail ? ap[0] * rowok : ap[0], a1 = tail ? ap[4] * rowok : ap[4], a2 = tail ? ap[8] * rowok : ap[8];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, ny[j][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, ny[j][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, ny[j][2], acc, 0, 0, 0);
     }
-    const double* lp = Lv + kb * 144 + lr * 12 + lk;          // rows lr >= 12 run into the next block: unused rows of y
+    const double* lp = Lv + kb * 144 + (lr < 12 ? lr : 11) * 12 + lk;      // rows lr >= 12 repeat row 11: unused rows of y, reads stay inside the block
     mfma_acc y = {0.0, 0.0, 0.0, 0.0};
     y = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[0], acc[0], y, 0, 0, 0);
     y = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[4], acc[1], y, 0, 0, 0);

@@ -113,7 +113,10 @@ struct ba_handle {
   bool groups_worth = false;            // points really share camera lists (mean run >= 2 points)
   Gm3Params gm3{0, 0, 0, 0, 0, 1};      // k_schur_groups_mfma3: tile count, staged row length, k-rows per buffer, points per batch, window
   DevBuf<SchurChunk> m3chunks;          // its chunks (window rows gm3.wn may differ from schur_wn)
-  int nm3chunks = 0;
+  DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
+  DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
+  int nm3chunks = 0, nwgroups = 0;
+  bool wgroups_worth = false;           // enough points per window group for the matrix-core reduction to pay
   int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
   bool point_groups = false;            // every point sits in a group and groups are worth it: group-packed k_linearize / k_backsub
   int group_maxL = 0;                   // longest track (k_schur_groups_mfma takes <= kGmMaxL)
@@ -634,7 +637,7 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->wgroups.release(); h->wtab.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
@@ -977,15 +980,91 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);     // tuning aid (ba_set_option "gm_cap")
     split_runs(cap, true);
     if (maxL <= kGmMaxL && wn > 0) chunk_groups(kGmChunk, wn, mgroups, mlo, mhi, mchunks);
-    // k_schur_groups_mfma3: staged rows of 16 * nts doubles; four wavefront pairs with two buffers each must fit in
-    // LDS next to the (optional) accumulation window
-    {
-      gm3.nts = (int)((6 * maxL + 15) / 16);
+    // worth it only when points really share camera lists
+    const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
+    groups_worth = mean_group >= 2.0;
+    if (groups_worth && maxL <= kGroupMaxL && wn > 0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
+  }
+  // Window groups for k_schur_groups_mfma3: consecutive points (internal order: by first optimised position) whose
+  // optimised cameras all lie within `wmax` consecutive positions - identical camera lists are NOT required, so tracks
+  // of different lengths, tracks with missing observations and tracks that start anywhere all join.  wmax = the
+  // widest window that costs no more 16-row tiles than the widest track needs.
+  std::vector<WinGroup> wgroups;
+  std::vector<int> wtab;
+  bool wgroups_worth = false;
+  {
+    std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
+    int maxspan = 0;
+    for (int k = 0; k < nt; ++k) {
+      for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+        const int p = cam_opt_pos[obs_cam[n]];
+        if (p < 0) continue;
+        plo[k] = std::min(plo[k], p); phi[k] = std::max(phi[k], p);
+      }
+      if (phi[k] >= 0) maxspan = std::max(maxspan, phi[k] - plo[k] + 1);
+    }
+    bool sorted_by_lo = true;                          // (the internal sort guarantees it; "sort_points" = 0 may not)
+    for (int k = 1, last = -1; k < nt && sorted_by_lo; ++k) {
+      if (phi[k - 1] >= 0) last = plo[k - 1];
+      if (phi[k] >= 0 && plo[k] < last) sorted_by_lo = false;
+    }
+    if (maxspan >= 1 && maxspan <= kGm3MaxL && sorted_by_lo && nco > 0) {
+      gm3.nts = (6 * maxspan + 15) / 16;
       gm3.Ld = 16 * gm3.nts;
+      const int wmax = std::min(kGm3MaxL, gm3.Ld / 6);
+      // natural groups: extend while the window still holds everybody
+      struct Run { int b, e, lo, hi; };
+      std::vector<Run> runs;
+      for (int k = 0; k < nt;) {
+        if (phi[k] < 0) { ++k; continue; }             // (points without an optimised camera add nothing to S or b)
+        int e = k + 1, lo = plo[k], hi = phi[k];
+        while (e < nt && (phi[e] < 0 || std::max(hi, phi[e]) - lo + 1 <= wmax)) {
+          if (phi[e] >= 0) hi = std::max(hi, phi[e]);
+          ++e;
+        }
+        while (e > k + 1 && phi[e - 1] < 0) --e;       // no trailing points without cameras
+        runs.push_back({k, e, lo, hi});
+        k = e;
+      }
+      // cut long groups into equal parts so that one round of workgroups holds them all and none lasts much longer
+      // than the rest (as for the identical-list groups above)
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+      const int slots = std::max(1, ncu * kGm2Pairs);
+      auto parts_of = [&](const Run& r, int cap) { return (r.e - r.b + cap - 1) / cap; };
+      int cap = std::max(kGroupMaxPts, (int)(((nt + slots - 1) / slots + kGmPts - 1) / kGmPts * kGmPts));
+      int longest = 0;
+      for (const Run& r : runs) longest = std::max(longest, r.e - r.b);
+      auto count = [&](int c) { size_t n = 0; for (const Run& r : runs) n += parts_of(r, c); return n; };
+      while (cap < longest && count(cap) > (size_t)slots) cap += kGmPts;
+      if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);
+      std::vector<int> wlo, whi;
+      for (const Run& r : runs) {
+        const int n = r.e - r.b, k = parts_of(r, cap);
+        const int part = ((n + k - 1) / k + kGmPts - 1) / kGmPts * kGmPts;
+        for (int b0 = r.b; b0 < r.e; b0 += part) {
+          const int e0 = std::min(b0 + part, r.e);
+          int lo = INT32_MAX, hi = -1;
+          for (int q = b0; q < e0; ++q)
+            if (phi[q] >= 0) { lo = std::min(lo, plo[q]); hi = std::max(hi, phi[q]); }
+          if (hi < 0) continue;
+          const int W = hi - lo + 1;
+          WinGroup g{b0, e0, W, lo, (int)wtab.size(), 0, 0, 0};
+          wtab.resize(wtab.size() + (size_t)(e0 - b0) * W, -1);
+          for (int q = b0; q < e0; ++q)
+            for (int n2 = off[q]; n2 < off[(size_t)q + 1]; ++n2) {
+              const int p = cam_opt_pos[obs_cam[n2]];
+              if (p >= 0) wtab[(size_t)g.tab + (size_t)(q - b0) * W + (p - lo)] = n2;
+            }
+          wgroups.push_back(g);
+          wlo.push_back(lo); whi.push_back(hi);
+        }
+      }
+      // staging: four wavefront pairs with two buffers each must fit in LDS next to the (optional) accumulation window
       const size_t lds_total = 160 * 1024, fixed = schur_mfma3_lds_bytes(0, 0, 0, hb + 1) + 1024;
       for (gm3.np_cap = kGmPts; gm3.np_cap >= 1; --gm3.np_cap) {
         int kmax = 4;
-        for (const SchurGroup& g : mgroups) kmax = std::max(kmax, (3 * gm3_np(g.L, gm3.np_cap) + 3) / 4 * 4);
+        for (const WinGroup& g : wgroups) kmax = std::max(kmax, (3 * gm3_np(g.W, gm3.np_cap) + 3) / 4 * 4);
         gm3.Kbuf = kmax;
         if ((size_t)kGm2Pairs * 2 * gm3.Kbuf * gm3.Ld * sizeof(double) <= 96 * 1024) break;
       }
@@ -994,14 +1073,26 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       const size_t rowbytes = ((size_t)(hb + 1) * 36 + 6) * sizeof(double);
       int w3 = (int)((lds_total - fixed - staging) / rowbytes);
       w3 = std::min(w3, std::max(16, hb + 7));
-      if (w3 < hb + 2 || nco == 0 || !h->opt.lds_window) w3 = 0;
+      if (w3 < hb + 2 || !h->opt.lds_window) w3 = 0;
       gm3.wn = w3;
-      chunk_groups(kGmChunk, w3, mgroups, mlo, mhi, m3chunks);
+      {
+        int begin = 0, lo = INT32_MAX, hi = -1;          // chunks of <= kGmChunk groups under the LDS window
+        for (int g = 0; g < (int)wgroups.size(); ++g) {
+          const int nlo = std::min(lo, wlo[g]), nhi = std::max(hi, whi[g]);
+          const bool fits = w3 == 0 || nhi - nlo + 1 <= w3;
+          if (g > begin && (!fits || g - begin >= kGmChunk)) {
+            m3chunks.push_back({begin, g, lo});
+            begin = g; lo = wlo[g]; hi = whi[g];
+          } else {
+            lo = nlo; hi = nhi;
+          }
+        }
+        if (!wgroups.empty()) m3chunks.push_back({begin, (int)wgroups.size(), lo});
+      }
+      long long covered = 0;
+      for (const WinGroup& g : wgroups) covered += g.pt_end - g.pt_begin;
+      wgroups_worth = !wgroups.empty() && covered >= 12ll * (long long)wgroups.size();      // an epilogue per >= 12 points
     }
-    // worth it only when points really share camera lists
-    const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
-    groups_worth = mean_group >= 2.0;
-    if (groups_worth && maxL <= kGroupMaxL && wn > 0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
   }
   // lanes per point: smallest power of two >= mean track length, in [1, 64]
   int glog = 0;
@@ -1018,6 +1109,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
   h->nm3chunks = (int)m3chunks.size();
+  h->nwgroups = (int)wgroups.size();
+  h->wgroups_worth = wgroups_worth;
   h->gm3 = gm3;
   h->groups_worth = groups_worth;
   h->nmgroups_total = (int)mgroups.size();
@@ -1048,6 +1141,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->m3chunks.resize(std::max<size_t>(1, m3chunks.size())));
   if (!m3chunks.empty())
     HIPCHECK(h, hipMemcpyAsync(h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, h->wgroups.resize(std::max<size_t>(1, wgroups.size())));
+  HIPCHECK(h, h->wtab.resize(std::max<size_t>(1, wtab.size())));
+  if (!wgroups.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->wgroups.p, wgroups.data(), wgroups.size() * sizeof(WinGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->wtab.p, wtab.data(), wtab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
   HIPCHECK(h, h->mgroups.resize(std::max<size_t>(1, mgroups.size())));
   if (!mgroups.empty())
     HIPCHECK(h, hipMemcpyAsync(h->mgroups.p, mgroups.data(), mgroups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
@@ -1268,7 +1367,7 @@ enum { KERN_PAIRS = 0, KERN_GROUPS, KERN_MFMA1, KERN_MFMA2, KERN_MFMA3, KERN_DEN
 int pick_schur_kernel(const ba_handle* h) {
   if (h->dense_mode && h->nt > 0 && h->nco > 0) return KERN_DENSE;
   const bool asc = h->groups_ascending && h->group_maxL >= 1;
-  const bool m3 = asc && h->nm3chunks > 0 && h->group_maxL <= kGm3MaxL;
+  const bool m3 = h->nm3chunks > 0 && h->nwgroups > 0;           // window groups: no identical camera lists needed
   const bool m12 = asc && h->nmchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGmMaxL;      // the L <= 10 kernels
   const bool vec = h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGroupMaxL;
   switch (h->opt.schur) {
@@ -1279,11 +1378,11 @@ int pick_schur_kernel(const ba_handle* h) {
     case SCHUR_MFMA: return m3 ? KERN_MFMA3 : KERN_PAIRS;
     default: break;
   }
-  if (!h->groups_worth) return KERN_PAIRS;
-  if (h->opt.fuse_lin && m12) return KERN_MFMA1;          // (the variant that forms the point blocks itself: measured slower, kept tested)
-  if (m12) return KERN_MFMA2;                             // track length <= 10: the fixed-shape kernel is 12 % faster than the general one's <0, 4> instance
-  if (m3) return KERN_MFMA3;
-  if (vec && h->group_rounds >= 1 && h->group_rounds <= 2) return KERN_GROUPS;
+  if (h->groups_worth && h->opt.fuse_lin && m12) return KERN_MFMA1;   // (forms the point blocks itself: measured slower, kept tested)
+  if (h->groups_worth && m12) return KERN_MFMA2;          // runs of identical camera lists, track length <= 10: the fixed-shape kernel
+                                                          // is 12 % faster than the general one's <0, 4> instance
+  if (m3 && h->wgroups_worth) return KERN_MFMA3;
+  if (h->groups_worth && vec && h->group_rounds >= 1 && h->group_rounds <= 2) return KERN_GROUPS;
   return KERN_PAIRS;
 }
 inline bool kern_is_mfma(int k) { return k == KERN_MFMA1 || k == KERN_MFMA2 || k == KERN_MFMA3; }
@@ -1297,7 +1396,7 @@ int launch_mfma3(ba_handle* h, int p, double damping, bool fuse_cam, bool first)
   G.do_rhs = first ? 1 : 0;
   hipLaunchKernelGGL((k_schur_groups_mfma3<TJ0, TJ1>), dim3(h->nm3chunks), dim3(kGm2Block),
                      schur_mfma3_lds_bytes(G.Kbuf, G.Ld, G.wn, h->hb + 1), h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
-                     h->mgroups.p, h->m3chunks.p, G, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
+                     h->wgroups.p, h->wtab.p, h->opt_cam.p, h->m3chunks.p, G, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
   return BA_OK;
 }
 
@@ -1391,7 +1490,7 @@ int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   REQUIRE(h, out && n >= 1, BA_ERR_INVALID_ARG, "ba_problem_info: bad argument");
   const int kern = pick_schur_kernel(h);
   const int64_t v[BA_INFO_COUNT] = {
-      h->pperm.empty() ? 0 : 1, h->operm.empty() ? 0 : 1, h->ngroups, (int64_t)h->nmgroups_total, h->point_groups ? 1 : 0,
+      h->pperm.empty() ? 0 : 1, h->operm.empty() ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
       h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
       kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf};
   for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];

@@ -1511,6 +1511,11 @@ constexpr int kGm3PosLen = 32;                          // optimised positions o
 constexpr int kGm3MaxTiles = 15;                        // accumulator tiles of one launch
 
 struct Gm3Params { int nts; int Ld; int Kbuf; int np_cap; int wn; int do_rhs; };
+// A group of k_schur_groups_mfma3: consecutive points (internal order) whose optimised cameras all lie in the window of
+// W <= 24 consecutive optimised positions starting at `lo`.  tab[(k - pt_begin) * W + w] = the observation of point k
+// in the camera at position lo + w, or -1: the camera lists need NOT be identical, only close (tracks of different
+// lengths, missing observations) - a run of points with one camera list is the special case of a full table.
+struct WinGroup { int pt_begin; int pt_end; int W; int lo; int tab; int pad0; int pad1; int pad2; };
 
 __host__ __device__ constexpr int gm3_ntiles(int tj0, int tj1) { return (tj1 * (tj1 + 1) - tj0 * (tj0 + 1)) / 2; }
 __host__ __device__ inline int gm3_np(int L, int np_cap) { int np = 64 / L; if (np > kGmPts) np = kGmPts; if (np > np_cap) np = np_cap; return np; }
@@ -1522,7 +1527,9 @@ __host__ __device__ inline size_t schur_mfma3_lds_bytes(int Kbuf, int Ld, int wn
 template <int TJ0, int TJ1>
 __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, const double* __restrict__ cams,
                                                                   const double* __restrict__ X,
-                                                                  const SchurGroup* __restrict__ groups,
+                                                                  const WinGroup* __restrict__ groups,
+                                                                  const int* __restrict__ wtab,
+                                                                  const int* __restrict__ opt_cam,
                                                                   const SchurChunk* __restrict__ chunks, Gm3Params G,
                                                                   const double* __restrict__ fac,
                                                                   double* __restrict__ S, double* __restrict__ b,
@@ -1556,26 +1563,28 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
 
   if (producer) {
     for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
-      const SchurGroup gr = groups[g];
-      const int L = gr.L;
+      const WinGroup gr = groups[g];
+      const int L = gr.W;                                       // lanes per point = window columns (cameras lo .. lo + W - 1)
       const int NP = gm3_np(L, G.np_cap);
       const int ks = (3 * NP + 3) >> 2;
       const int slot = lane / L, oi = lane - slot * L;
       const bool stager = lane < NP * L;
-      const int n0 = P.pt_off[gr.pt_begin] + oi;
-      const int c = P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]];
-      const int mypos = stager ? P.cam_opt_pos[c] : -1;
+      // a lane keeps ONE camera for the whole group - the one at its window column - and handles whichever points observe it
+      const int mypos = (stager && gr.lo + oi < P.nco) ? gr.lo + oi : -1;
+      const int c = opt_cam[mypos >= 0 ? mypos : gr.lo];
       double cm[12];
       load_cam(cams, c, cm);
       double bacc[6] = {0, 0, 0, 0, 0, 0};
       double hc[21];
 #pragma unroll
       for (int q = 0; q < 21; ++q) hc[q] = 0.0;
-      struct PointIn { double x[3], f[9]; double2 z; };
+      struct PointIn { double x[3], f[9]; double2 z; int n; };
       auto fetch = [&](int kb_, PointIn& in) {
         const int k = kb_ + slot;
+        in.n = -1;
         if (stager && k < gr.pt_end) {
-          in.z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+          in.n = mypos >= 0 ? wtab[gr.tab + (k - gr.pt_begin) * L + oi] : -1;      // this point's observation in my camera, if any
+          in.z = P.obs_z[in.n >= 0 ? in.n : 0];
 #pragma unroll
           for (int q = 0; q < 3; ++q) in.x[q] = X[3 * (size_t)k + q];
 #pragma unroll
@@ -1588,10 +1597,10 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
         const int np = min(NP, gr.pt_end - kb);
         const PointIn cur = nxt;
         fetch(kb + NP, nxt);
-        const bool live = stager && slot < np;
+        const bool live = stager && slot < np && cur.n >= 0;
         double U[18];
 #pragma unroll
-        for (int q = 0; q < 18; ++q) U[q] = 0.0;                // a short last batch stages zero k rows
+        for (int q = 0; q < 18; ++q) U[q] = 0.0;                // a short last batch, a point that does not see my camera: zero rows
         if (live) {
           double e[2], r[2], Jc[12], Jp[6], W[18];
           obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
@@ -1627,7 +1636,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
             for (int d = 0; d < 3; ++d) mU[so + d * Ld + a] = U[a * 3 + d];
           if (oi == 0) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) mD[3 * slot + d] = live ? cur.f[d] : 0.0;
+            for (int d = 0; d < 3; ++d) mD[3 * slot + d] = slot < np ? cur.f[d] : 0.0;
           }
         }
         if (lane >= 60 && 3 * NP + (lane - 60) < 4 * ks) mD[3 * NP + (lane - 60)] = 0.0;    // k rows that pad the last step
@@ -1668,13 +1677,13 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
     const int lr = lane & 15, lk = lane >> 4;
     int* mPos = sPos + pair * kGm3PosLen;
     for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
-      const SchurGroup gr = groups[g];
-      const int L = gr.L;
+      const WinGroup gr = groups[g];
+      const int L = gr.W;
       const int NP = gm3_np(L, G.np_cap);
       const int ks = (3 * NP + 3) >> 2;
       const int nts = (6 * L + 15) >> 4;                        // tiles per side that hold rows of THIS group
       const int nb = (gr.pt_end - gr.pt_begin + NP - 1) / NP;
-      if (lane < kGm3PosLen) mPos[lane] = lane < L ? P.cam_opt_pos[P.obs_cam[P.pt_off[gr.pt_begin] + lane]] : -1;
+      if (lane < kGm3PosLen) mPos[lane] = (lane < L && gr.lo + lane < P.nco) ? gr.lo + lane : -1;
       mfma_acc acc[NTILE];
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};

@@ -29,7 +29,14 @@ def make_case(seed):
     nt = int(rs.randint(60, 1500))
     s = banded(nc, nt, track_len=L, outlier_frac=float(rs.choice([0., .05])), seed=int(rs.randint(1, 10000)))
     keep = rs.rand(len(s['obs_cam'])) >= float(rs.choice([0., .1, .35]))          # ragged tracks
-    keep[::L] = True                                                               # (every track keeps an observation)
+    if rs.rand() < .5 and L >= 4:                                                  # tracks of different lengths that start anywhere
+        a0 = rs.randint(0, L - 1, nt)
+        b0 = np.minimum(L, a0 + rs.randint(2, L + 1, nt))
+        j = np.arange(len(s['obs_cam'])) % L
+        keep &= (j >= np.repeat(a0, L)) & (j < np.repeat(b0, L))
+        keep[np.arange(nt) * L + a0] = True                                        # (every track keeps an observation)
+    else:
+        keep[::L] = True
     cam, pt, z = s['obs_cam'][keep], s['obs_pt'][keep], s['obs_z'][keep]
     X0 = s['X0']
     if rs.rand() < .6:                                                             # random track numbering and observation order
@@ -57,14 +64,21 @@ def make_case(seed):
                 damping=damping, L=L, nc=nc, nt=nt)
 
 
-@pytest.mark.parametrize('seed', range(40))
+KERNELS_SEEN = set()
+
+
+@pytest.mark.parametrize('seed', range(60))
 def test_random_scene_full_step_vs_oracle(be, seed):
     c = make_case(seed)
     a, cp, po, sensor = c['a'], c['cam_opt_pos'], c['pt_opt'], c['sensor']
     load_problem(be, *a, cp, po, sensor)
+    KERNELS_SEEN.add(be.problem_info()['schur_kernel'])
     close(be.cost(0), O.cost(sensor, *a, cp, po), 1e-12, atol=1e-300)
     cmask = None if c['mask'] is None else c['mask'].astype(bool)
-    mu, su, parts = O.compute_update(sensor, *a, cp, po, damping=c['damping'], cam_param_mask=cmask, return_parts=True)
+    try:
+        mu, su, parts = O.compute_update(sensor, *a, cp, po, damping=c['damping'], cam_param_mask=cmask, return_parts=True)
+    except O.NormalEquationsIllconditioned:
+        pytest.skip('degenerate draw: a camera lost all its observations, the reference LU itself raises')
     be.linearize(0)
     blk = be.get_blocks()
     for k in ('HCC', 'bC', 'HPP', 'bP'):
@@ -92,3 +106,8 @@ def test_random_scene_full_step_vs_oracle(be, seed):
     close(tg, t2, tol, atol=1e-12)
     ref_cost = O.cost(sensor, a[0], R2, t2, X2, a[4], a[5], a[6], cp, po)
     assert abs(cost - ref_cost) <= max(1e-8, 10 * tol) * max(ref_cost, 1e-300)
+
+
+def test_the_sweep_reached_the_matrix_core_kernels():
+    """(runs after the sweep) both producer / consumer reductions and the pair kernel were exercised."""
+    assert {0, 4} <= KERNELS_SEEN, KERNELS_SEEN
