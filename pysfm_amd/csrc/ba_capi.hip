@@ -116,6 +116,7 @@ struct ba_handle {
   DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
   DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
   int nm3chunks = 0, nwgroups = 0;
+  bool gm3_uniform_ks = false;          // every window group has 6 points per batch (width <= 10): five k-steps
   bool wgroups_worth = false;           // enough points per window group for the matrix-core reduction to pay
   int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
   bool point_groups = false;            // every point sits in a group and groups are worth it: group-packed k_linearize / k_backsub
@@ -1110,6 +1111,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->nmchunks = (int)mchunks.size();
   h->nm3chunks = (int)m3chunks.size();
   h->nwgroups = (int)wgroups.size();
+  h->gm3_uniform_ks = !wgroups.empty();
+  for (const WinGroup& g : wgroups) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(g.W, gm3.np_cap) == kGmPts;
   h->wgroups_worth = wgroups_worth;
   h->gm3 = gm3;
   h->groups_worth = groups_worth;
@@ -1379,8 +1382,8 @@ int pick_schur_kernel(const ba_handle* h) {
     default: break;
   }
   if (h->groups_worth && h->opt.fuse_lin && m12) return KERN_MFMA1;   // (forms the point blocks itself: measured slower, kept tested)
-  if (h->groups_worth && m12) return KERN_MFMA2;          // runs of identical camera lists, track length <= 10: the fixed-shape kernel
-                                                          // is 12 % faster than the general one's <0, 4> instance
+  if (h->groups_worth && m12) return KERN_MFMA2;          // runs of identical camera lists, track length <= 10: the fixed-shape kernel (with the
+                                                          // camera blocks folded in it is 6 % faster than the general one's <0, 4, 64, 5> instance)
   if (m3 && h->wgroups_worth) return KERN_MFMA3;
   if (h->groups_worth && vec && h->group_rounds >= 1 && h->group_rounds <= 2) return KERN_GROUPS;
   return KERN_PAIRS;
@@ -1389,12 +1392,12 @@ inline bool kern_is_mfma(int k) { return k == KERN_MFMA1 || k == KERN_MFMA2 || k
 
 extern "C++" {
 // k_schur_groups_mfma3 over the tile columns [TJ0, TJ1) of every group's window
-template <int TJ0, int TJ1>
+template <int TJ0, int TJ1, int LDC = 0, int KSC = 0>
 int launch_mfma3(ba_handle* h, int p, double damping, bool fuse_cam, bool first) {
-  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma3<TJ0, TJ1>));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma3<TJ0, TJ1, LDC, KSC>));
   Gm3Params G = h->gm3;
   G.do_rhs = first ? 1 : 0;
-  hipLaunchKernelGGL((k_schur_groups_mfma3<TJ0, TJ1>), dim3(h->nm3chunks), dim3(kGm2Block),
+  hipLaunchKernelGGL((k_schur_groups_mfma3<TJ0, TJ1, LDC, KSC>), dim3(h->nm3chunks), dim3(kGm2Block),
                      schur_mfma3_lds_bytes(G.Kbuf, G.Ld, G.wn, h->hb + 1), h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
                      h->wgroups.p, h->wtab.p, h->opt_cam.p, h->m3chunks.p, G, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
   return BA_OK;
@@ -1403,6 +1406,8 @@ int launch_mfma3(ba_handle* h, int p, double damping, bool fuse_cam, bool first)
 int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
   const int nts = h->gm3.nts;       // tiles per side of the widest window; at most 15 accumulator tiles per launch
   if (nts < 1 || nts > 9) return h->fail(BA_ERR_STATE, "k_schur_groups_mfma3: %d tiles per side", nts);
+  // windows of at most 10 cameras with 6 points per batch everywhere (the north-star scenes): row length and k-steps fixed
+  if (nts == 4 && h->gm3.np_cap == kGmPts && h->gm3.Kbuf == kGmK && h->gm3_uniform_ks) return launch_mfma3<0, 4, 64, 5>(h, p, damping, fuse_cam, true);
   int rc = nts == 5 ? launch_mfma3<0, 5>(h, p, damping, fuse_cam, true) : launch_mfma3<0, 4>(h, p, damping, fuse_cam, true);
   if (rc == BA_OK && nts >= 6) rc = launch_mfma3<4, 6>(h, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, p, damping, fuse_cam, false);

@@ -1524,7 +1524,7 @@ __host__ __device__ inline size_t schur_mfma3_lds_bytes(int Kbuf, int Ld, int wn
          (size_t)kGm2Pairs * (kGm3PosLen + 4) * sizeof(int) + 64 * sizeof(double) + (size_t)wn * ((size_t)hb1 * 36 + 6) * sizeof(double);
 }
 
-template <int TJ0, int TJ1>
+template <int TJ0, int TJ1, int LDC = 0, int KSC = 0>      // LDC / KSC != 0: staged row length / k-steps per batch known at compile time
 __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, const double* __restrict__ cams,
                                                                   const double* __restrict__ X,
                                                                   const WinGroup* __restrict__ groups,
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   constexpr int NTILE = gm3_ntiles(TJ0, TJ1);
   static_assert(NTILE <= kGm3MaxTiles, "too many accumulator tiles for one wavefront");
-  const int Ld = G.Ld, BUF = G.Kbuf * G.Ld, wn = G.wn;
+  const int Ld = LDC ? LDC : G.Ld, BUF = G.Kbuf * Ld, wn = G.wn;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* sU = dyn;                                            // [pair][2][Kbuf][Ld]
   double* sD = sU + kGm2Pairs * 2 * BUF;                       // [pair][2][kGm2DRows]
@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
       const WinGroup gr = groups[g];
       const int L = gr.W;                                       // lanes per point = window columns (cameras lo .. lo + W - 1)
       const int NP = gm3_np(L, G.np_cap);
-      const int ks = (3 * NP + 3) >> 2;
+      const int ks = KSC ? KSC : (3 * NP + 3) >> 2;
       const int slot = lane / L, oi = lane - slot * L;
       const bool stager = lane < NP * L;
       // a lane keeps ONE camera for the whole group - the one at its window column - and handles whichever points observe it
@@ -1680,7 +1680,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
       const WinGroup gr = groups[g];
       const int L = gr.W;
       const int NP = gm3_np(L, G.np_cap);
-      const int ks = (3 * NP + 3) >> 2;
+      const int ks = KSC ? KSC : (3 * NP + 3) >> 2;
       const int nts = (6 * L + 15) >> 4;                        // tiles per side that hold rows of THIS group
       const int nb = (gr.pt_end - gr.pt_begin + NP - 1) / NP;
       if (lane < kGm3PosLen) mPos[lane] = (lane < L && gr.lo + lane < P.nco) ? gr.lo + lane : -1;
@@ -1692,7 +1692,8 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
         gm2_wait(fStaged, nbatch + 1);
         const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
         const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
-        for (int s4 = 0; s4 < ks; ++s4) {
+#pragma unroll
+        for (int s4 = 0; s4 < (KSC ? KSC : ks); ++s4) {
           double ta[TJ1], wb[TJ1];
           const double dk = mD[4 * s4 + lk];
           const double* row = mU + (4 * s4 + lk) * Ld + lr;
