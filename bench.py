@@ -49,6 +49,12 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mf
 KERNEL_BOUND = {'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
                 'dense_solve': 'latency', 'schur_pairs': 'mfma', 'linearize': 'hbm', 'backsub': 'hbm', 'cost': 'hbm',
                 'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
+# timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
+KERNEL_NAMES = {'linearize': 'k_linearize_groups (k_linearize when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init',
+                'schur_pairs': 'k_schur_groups_mfma2 | k_schur_groups_mfma3 (k_schur_groups / k_schur_pairs otherwise)',
+                'backsub': 'k_backsub_groups (k_backsub when points do not come in runs)', 'bcr_eliminate': 'k_bcr_eliminate_split (k_bcr_eliminate on levels wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
+                'bcr_backsolve': 'k_bcr_backsolve_fused (k_bcr_backsolve / k_bcrw_backsolve per level otherwise)', 'bcr_assemble': 'k_bcr_assemble', 'cost': 'k_cost',
+                'camera_blocks': 'k_camera_blocks', 'dense_solve': 'k_dense_gather/panel/update/backsolve', 'band_solve': 'k_band_solve'}
 # reference rates measured in SURVEY.md section 6 (the reference itself, imported in the build container, 1 core Xeon 2.1 GHz)
 SURVEY_REFERENCE_RATES = {'assemble_obs_per_s': 2.8e4, 'whole_update_obs_per_s': 3.5e3,
                           'source': 'SURVEY.md section 6: alexflint/pysfm bundle_adjuster.py on 1 core (Xeon 2.1 GHz)'}
@@ -422,7 +428,7 @@ def main():
         # the whole reduction of one trial (one launch up to track length 13, two to four beyond: DESIGN.md)
         schur_ms = ours['schur_pairs']['ms'] / nprof if 'schur_pairs' in ours else None
         bound = KERNEL_BOUND.get(dom, 'hbm')
-        roof = {'bound': bound, 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        roof = {'bound': bound, 'kernel': KERNEL_NAMES.get(dom, 'k_' + dom), 'timer': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
                 'algorithmic_bytes_per_launch': B, 'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
@@ -464,7 +470,7 @@ def main():
                        'allreduce_payload_bytes_per_rank_per_trial': None if comm is None else 8 * (be.S_doubles + 6 * nco) + 8 * 2050},
             'roofline': roof,
             'roofline_linearise_schur_pass': {
-                'kernels': ['k_' + k for k in pass_kernels], 'ms': pass_ms, 'algorithmic_bytes': pass_bytes,
+                'kernels': [KERNEL_NAMES.get(k, 'k_' + k) for k in pass_kernels], 'ms': pass_ms, 'algorithmic_bytes': pass_bytes,
                 'achieved_GBps': pass_bytes / max(1e-9, pass_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': pass_bytes / max(1e-9, pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'traffic': pass_traffic, 'traffic_over_algorithmic': None if pass_traffic is None else pass_traffic / pass_bytes,
                 'obs_jacobians_per_s': nobs_local / max(1e-9, pass_ms * 1e-3),

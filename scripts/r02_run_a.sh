@@ -20,7 +20,7 @@ import json,glob
 for f in sorted(glob.glob('gpurun_out/r02a_bench_*.json')):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
-        print(f, 'ms/step %.4f'%d['ms_per_step'], 'win', d['ms_per_step_windows']['min'], d['ms_per_step_windows']['median'], 'value %.3e'%d['value'], d['roofline']['kernel'], d['roofline']['bound'], '%.4f'%d['roofline']['frac'], d.get('final_reproj_rmse'), d['reduced_system']['solve_kind'])
+        print(f, 'ms/step %.4f'%d['ms_per_step'], 'win', d['ms_per_step_windows']['min'], d['ms_per_step_windows']['median'], 'value %.3e'%d['value'], d["roofline"]["timer"], d['roofline']['bound'], '%.4f'%d['roofline']['frac'], d.get('final_reproj_rmse'), d['reduced_system']['solve_kind'])
         print('   ', {k: round(v,4) for k,v in d['kernel_ms_per_step'].items()})
     except Exception as e:
         print(f, 'FAILED', e)

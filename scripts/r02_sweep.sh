@@ -20,7 +20,7 @@ for f in sorted(glob.glob(sys.argv[1]+'/*.json')):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
         w=d['ms_per_step_windows']
-        print('%-22s ms/step %.4f  windows min %.4f med %.4f  %.3e obs/s  dom %s (%s, frac %.4f)  solve %s  rmse %s trials %s' % (os.path.basename(f)[:-5], d['ms_per_step'], w['min'], w['median'], d['value'], d['roofline']['kernel'], d['roofline']['bound'], d['roofline']['frac'], d['reduced_system']['solve_kind'], d.get('final_reproj_rmse'), d.get('lm_trials')))
+        print('%-22s ms/step %.4f  windows min %.4f med %.4f  %.3e obs/s  dom %s (%s, frac %.4f)  solve %s  rmse %s trials %s' % (os.path.basename(f)[:-5], d['ms_per_step'], w['min'], w['median'], d['value'], d["roofline"]["timer"], d['roofline']['bound'], d['roofline']['frac'], d['reduced_system']['solve_kind'], d.get('final_reproj_rmse'), d.get('lm_trials')))
         print('      ', {k: round(v,4) for k,v in d['kernel_ms_per_step'].items()})
     except Exception as e:
         print(f, 'FAILED', e)
