@@ -307,7 +307,9 @@ def main():
     track_ids = None
     if comm is not None:
         track_ids = shard_tracks(bundle, rank, world)
+    t_setup = time.time()
     ba.set_bundle(bundle, track_ids=track_ids)
+    t_setup = time.time() - t_setup
     be = ba.backend
     nobs_local = be.nobs
     nobs_total = len(obs_cam)
@@ -480,6 +482,8 @@ def main():
                              'achieved_tflops': sflops / (schur_ms * 1e-3) / 1e12 if schur_ms else None,
                              'peak_tflops': FP64_MATRIX_PEAK_TFLOPS,
                              'note': 'fp64 MFMA is used where the path is GEMM-shaped (Schur reduction, cyclic-reduction nodes)'},
+            'set_bundle_s': t_setup,          # host-side bookkeeping + internal order + work lists + upload (outside the timed region)
+            'problem_info': be.problem_info(),
             'kernel_ms_per_step': {k: v['ms'] / nprof for k, v in ours.items()},
             'kernel_launches_per_step': {k: v['launches'] / nprof for k, v in ours.items()},
             'all_kernels': {'algorithmic_bytes_per_step': int(sum(ab(k) * v['launches'] for k, v in ours.items()) / nprof),
