@@ -85,6 +85,10 @@ int ba_synchronize(ba_handle* h);
  * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap") take effect at
  * the next ba_set_problem. */
 int ba_set_option(ba_handle* h, const char* name, const char* value);
+/* Test aid: fills the LDS of every compute unit and every workspace buffer of the handle (normal-equation blocks, reduced
+ * system, solver workspace, updates, the trial parameter set - not the problem, not the current parameter set) with NaNs
+ * and forgets every cached intermediate.  A following computation that reads anything it did not write itself shows it. */
+int ba_debug_poison(ba_handle* h);
 
 /* ---- problem definition: BundleAdjuster.set_bundle (bundle_adjuster.py:54-114)
  * nc cameras, nt tracks, nobs observations in ANY order (the reference visits tracks and their measurements

@@ -40,6 +40,7 @@ PROTOTYPES = {
     'ba_set_stream': (C.c_int, [_h, C.c_void_p]),
     'ba_synchronize': (C.c_int, [_h]),
     'ba_set_option': (C.c_int, [_h, C.c_char_p, C.c_char_p]),
+    'ba_debug_poison': (C.c_int, [_h]),
     'ba_set_problem': (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, _dp, _dp, _ip, _bp]),
     'ba_problem_info': (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32]),
     'ba_set_sensor': (C.c_int, [_h, C.c_int, _dp, C.c_int]),

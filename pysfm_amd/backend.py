@@ -38,6 +38,7 @@ class ReducedSystemSingular(Exception):
 
 class HipBackend(object):
     lu_fallback_max_unknowns = LU_FALLBACK_MAX_UNKNOWNS     # per instance: BundleAdjuster(lu_fallback_max_unknowns=...)
+    poison_after_set_problem = False    # tests/conftest.py sets it: every problem starts from NaNs in all LDS / workspace (ba_debug_poison)
 
     def __init__(self, device=0):
         self._lib = capi.load()
@@ -104,6 +105,11 @@ class HipBackend(object):
     def synchronize(self):
         self._check(self._lib.ba_synchronize(self._h))
 
+    def debug_poison(self):
+        """Test aid (ba_debug_poison): NaNs into every LDS and workspace buffer, cached intermediates forgotten."""
+        self._check(self._lib.ba_debug_poison(self._h))
+        self._host_dC = None
+
     def set_option(self, name, value):
         """Test / measurement switch of the library (include/pysfm_ba.h ba_set_option); the defaults are the
         product path.  Options that shape the work lists take effect at the next set_problem."""
@@ -137,6 +143,8 @@ class HipBackend(object):
         if self._torch is not None:
             self._bind_reduced()
         self._bind_dense()
+        if self.poison_after_set_problem:
+            self.debug_poison()
 
     def problem_info(self):
         """What ba_set_problem made of the scene (include/pysfm_ba.h BA_INFO_*), as a dict."""

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 
   BA_STAMP(t0);
   if (tid == 0) *bad = 0;
+  if (tid < 192) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
   {
     // all global loads of a thread are issued before the first LDS store (one round trip)
     constexpr int NIT = (B * B + kBcrElimThreads - 1) / kBcrElimThreads;
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
 
   if (tid == 0) *bad = 0;
+  if (tid < 192) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
 #ifdef BA_BCR_PROFILE
   long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long pt0 = clock64();

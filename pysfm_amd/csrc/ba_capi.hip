@@ -578,6 +578,18 @@ __global__ __launch_bounds__(256) void k_stream_copy(const copy_vec* __restrict_
   if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// test aid (ba_debug_poison): every LDS word of a compute unit / every double of a workspace buffer becomes a NaN
+__global__ __launch_bounds__(1024) void k_poison_lds(int ndoubles) {
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  for (int i = threadIdx.x; i < ndoubles; i += 1024) dyn[i] = __longlong_as_double(0x7FF8DEADDEADDEADll);
+  __syncthreads();
+  if (dyn[(threadIdx.x * 7) % ndoubles] == 0.0) dyn[0] = 1.0;      // (keeps the stores)
+}
+__global__ __launch_bounds__(256) void k_poison_doubles(double* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = __longlong_as_double(0x7FF8DEADDEADDEADll);
+}
+
 extern "C" {
 
 const char* ba_version(void) { return "pysfm_ba 0.1 (gfx950)"; }
@@ -647,6 +659,26 @@ int ba_destroy(ba_handle* h) {
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
+  return BA_OK;
+}
+
+int ba_debug_poison(ba_handle* h) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  HIPCHECK(h, hipSetDevice(h->device));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_poison_lds));
+  hipLaunchKernelGGL(k_poison_lds, dim3(8 * h->ncu), dim3(1024), 160 * 1024, h->stream, 160 * 1024 / 8);
+  DevBuf<double>* bufs[] = {&h->HCC, &h->bC, &h->HPP, &h->bP, &h->HPPinv, &h->W, &h->dC, &h->dP, &h->scratch, &h->Ufac, &h->ysol, &h->dinv,
+                            &h->bcrD, &h->bcrU, &h->bcrF, &h->bcrP, &h->bcrQ, &h->bcrG, &h->bcrGv, &h->bcrL, &h->bcrLv, &h->denseA, &h->fac,
+                            &h->dUd, &h->dDd, &h->dyd, &h->dpart, &h->cams[1 - h->cur], &h->X[1 - h->cur]};
+  for (DevBuf<double>* b : bufs)
+    if (b->p && b->n) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, h->stream, b->p, b->n);
+  if (h->S) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((reduced_doubles(h) + 255) / 256)), dim3(256), 0, h->stream, h->S, reduced_doubles(h));
+  if (h->b && h->nco) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)(((size_t)h->nco * 6 + 255) / 256)), dim3(256), 0, h->stream, h->b, (size_t)h->nco * 6);
+  HIPCHECK(h, hipGetLastError());
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  h->have_params[1 - h->cur] = false;
+  h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
+  h->inv_valid = h->fac_valid = h->point_blocks_valid = h->cam_blocks_valid = false;
   return BA_OK;
 }
 

@@ -284,7 +284,9 @@ __global__ __launch_bounds__(1024) void k_dense_backsolve(int n, int bw, const d
           }
         }
       }
-      if (lane < nb) { w[k0 + lane] = wc; xk[lane] = wc; }
+      if (lane < nb) w[k0 + lane] = wc;
+      if (lane < kDcNB) xk[lane] = lane < nb ? wc : 0.0;      // (a short last block: the update below multiplies entries nb.. by zero
+                                                               //  rows of L - they must be zeros, not stale LDS: 0 x NaN = NaN)
     }
     __syncthreads();
     // (3) the update

@@ -23,6 +23,10 @@ def pytest_collection_modifyitems(config, items):
     except Exception:
         have_gpu = False
     if have_gpu:
+        # every problem of every GPU test starts from NaNs in all LDS and workspace buffers (a read of something nobody
+        # wrote must show, not depend on what ran before)
+        from pysfm_amd.backend import HipBackend
+        HipBackend.poison_after_set_problem = True
         # a kernel that waits for something that never comes must fail a test, not hang the box (pytest-timeout)
         for item in items:
             if 'gpu' in item.keywords:

@@ -111,3 +111,33 @@ def test_random_scene_full_step_vs_oracle(be, seed):
 def test_the_sweep_reached_the_matrix_core_kernels():
     """(runs after the sweep) both producer / consumer reductions and the pair kernel were exercised."""
     assert {0, 4} <= KERNELS_SEEN, KERNELS_SEEN
+
+
+def test_results_do_not_depend_on_what_ran_before_on_the_handle(be):
+    """The same 60 scenes as one LM trial each, in three different orders on ONE handle (buffers grow, get reused, keep
+    stale contents; LDS keeps what the previous kernel left): every scene must give the same trial whatever ran before
+    it.  (The sweep above found a 0 x NaN this way: a read of memory nobody had initialised, harmless until another
+    problem had left a NaN there.)"""
+    import time
+    cases = [make_case(seed) for seed in range(60)]
+    ref = {}
+    for rep, order in enumerate([list(range(60)), list(np.random.RandomState(1).permutation(60)), list(range(59, -1, -1))]):
+        for i in order:
+            c = cases[i]
+            load_problem(be, *c['a'], c['cam_opt_pos'], c['pt_opt'], c['sensor'])
+            if rep == 1:
+                time.sleep(.02)                             # (an idle GPU made the stale-LDS failure deterministic)
+            if rep == 2:
+                be.debug_poison()                           # NaNs in every LDS and every workspace buffer: whatever is read must have been written
+            info, cost = be.lm_trial(c['damping'], 1e-5, c['mask'])
+            S, b = be.get_reduced()
+            X = be.get_params(1)[2] if info == 0 else np.zeros(1)
+            out = (info, cost if info == 0 else 0., S, b, X)
+            if i not in ref:
+                ref[i] = out
+                continue
+            assert out[0] == ref[i][0], (i, out[0], ref[i][0])
+            close(np.array([out[1]]), np.array([ref[i][1]]), 1e-9)
+            close(out[2], ref[i][2], 1e-12)
+            close(out[3], ref[i][3], 1e-12)
+            close(out[4], ref[i][4], 1e-7, atol=1e-12)

@@ -73,6 +73,9 @@ def load_problem(be, K, R, t, X, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, se
     be.set_problem(len(R), len(X), obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt)
     be.set_sensor(*sensor_params(sensor))
     be.set_params(0, R, t, X)
+    # every test starts from NaNs in all LDS and all workspace buffers of the handle: a kernel that reads something it
+    # (or an earlier kernel of the same computation) did not write shows up as a NaN instead of depending on what ran before
+    be.debug_poison()
 
 
 def default_flags(nc, nt):
