@@ -14,6 +14,10 @@ run c3_forcecomm --force-comm --no-cpu-baseline --no-lm
 run c3_forcecomm_torch --force-comm --collectives torch --no-cpu-baseline --no-lm
 for L in 11 12 13 16 20 24; do run L$L --track-len $L --no-cpu-baseline --no-lm; done
 run L16_shuffled --track-len 16 --shuffle-points --no-cpu-baseline --no-lm
+run c3_ragged --drop-observations 0.3 --no-cpu-baseline
+run c3_ragged_shuffled --drop-observations 0.3 --shuffle-points --no-cpu-baseline --no-lm
+run c3_ragged_pairs --drop-observations 0.3 --option schur=pairs --no-cpu-baseline --no-lm
+run c5_shuffled --config 5 --shuffle-points --no-cpu-baseline --no-lm
 python - $O <<'PY'
 import json,glob,sys,os
 for f in sorted(glob.glob(sys.argv[1]+'/*.json')):
