@@ -1692,7 +1692,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
         gm2_wait(fStaged, nbatch + 1);
         const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
         const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
-#pragma unroll
+#pragma unroll KSC ? KSC : 1
         for (int s4 = 0; s4 < (KSC ? KSC : ks); ++s4) {
           double ta[TJ1], wb[TJ1];
           const double dk = mD[4 * s4 + lk];
