@@ -596,6 +596,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 // With a third of the columns the late-update tasks of a step (<= 7) fit on the wavefronts of SIMDs 1..3, so SIMD 0
 // is left to the pivot chain of wavefront 0 (25 % faster chain; with all columns on one CU that lost more than it won).
 // --------------------------------------------------------------------------
+#ifndef BA_BCR_PRODUCT_WAVES
+#define BA_BCR_PRODUCT_WAVES 15     // wavefronts of the prologue's coupling product: all but the chain's (15), or only those of SIMDs 1..3 (12)
+#endif
 __host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 200) * sizeof(double); }
 
 template <int HB>
@@ -688,9 +691,11 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     constexpr int NT = (B + 15) / 16, KST = (B + 3) / 4;
     const double* A = role == 0 ? Tb : Ta;
     const double* Bm = role == 0 ? Ta : Tb;
-    // the wavefronts of SIMDs 1..3 (12 of them; 16 tiles are two rounds on 12 as on 15): SIMD 0 belongs to the chain
-    const int pslot = (wave & 3) ? wave - 1 - (wave >> 2) : -1;
-    for (int task = pslot; task >= 0 && task < NT * NT; task += 12) {
+    // 16 tiles on the 15 wavefronts that do not run the chain (measured against the 12 of SIMDs 1..3, which leave SIMD 0
+    // to the chain alone: 129.6 against 131.1 us for the seven levels - the product is bound by MFMA throughput, and
+    // three more wavefronts on SIMD 0 shorten it by more than they slow the first diagonal factor down)
+    const int pslot = BA_BCR_PRODUCT_WAVES == 15 ? wave - 1 : ((wave & 3) ? wave - 1 - (wave >> 2) : -1);
+    for (int task = pslot; task >= 0 && task < NT * NT; task += BA_BCR_PRODUCT_WAVES) {
       const int ti = task / NT, tj = task - ti * NT;
       // all operands of the tile first (one LDS round trip), then the chain of MFMAs; two accumulators halve the chain
       double ar[KST], br[KST];
