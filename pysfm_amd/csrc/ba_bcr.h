@@ -336,8 +336,25 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #endif
     // ---------------- phase 1
     double dcol[12], ddi = 0.0;                             // wavefront 0: the factor of this block, kept for phase 2
+    // the update block column kb still owes to the panel of block kb - 1 (C -= panel panel^T, K = 12), one 16-row tile per task:
+    // the tile that holds the diagonal block by wavefront 0 itself right before it factors it (no barrier in between), the
+    // tiles below it as late-update tasks of this phase (they are due at the next barrier, when the panel needs them)
+    auto urgent_tile = [&](int t) {
+      typedef double mfma_acc __attribute__((ext_vector_type(4)));
+      const int kp = k0 - 12, i0 = k0 + 16 * t;
+      const int ao = (i0 + lr) * ld + kp + lk, bo = (k0 + lr) * ld + kp + lk, cb = (i0 + lk) * ld + k0 + lr;
+      mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
+      const int rl = lr < nb ? B - i0 - lk : 0;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+    };
     if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
+      if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
       if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
       else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
       __builtin_amdgcn_s_setprio(0);
@@ -352,7 +369,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
       typedef double mfma_acc __attribute__((ext_vector_type(4)));
       const int kp = k0 - 12;
       const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
-      for (int task = myslot; task < nct + ngt; task += 15) {
+      const int nsu = ((B - k0 + 15) >> 4) - 1;             // tiles of block column kb below the one wavefront 0 takes
+      for (int task = myslot; task < nct + ngt + nsu; task += 15) {
+        if (task >= nct + ngt) { urgent_tile(task - nct - ngt + 1); continue; }
         int t0, t1, i00, co, cst;
         bool cok, full;
         double nb0, nb1, nb2;                                  // the NEGATED B operand of the three k-steps
@@ -435,28 +454,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #ifdef BA_BCR_PROFILE
     const long long p2 = clock64();
 #endif
-    // ---------------- phase 3: the URGENT part of the update: block column kb+1 only (its diagonal block and the rows
-    //                  below), so that the next diagonal factor can start while the rest is still owed
-    if (!last && wave >= 8 && wave <= 11) {
-      // rows kn + 16 t .. of the next block column: C -= panel panel^T, K = 12
-      typedef double mfma_acc __attribute__((ext_vector_type(4)));
-      const int i0 = kn + 16 * (wave - 8);
-      if (i0 < B) {
-        const int nbn = B - kn < 12 ? B - kn : 12;             // width of the next block
-        const int ao = (i0 + lr) * ld + k0 + lk, bo = (kn + lr) * ld + k0 + lk, cb = (i0 + lk) * ld + kn + lr;
-        mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
-        const int rl = lr < nbn ? B - i0 - lk : 0;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
-      }
-    }
-    __syncthreads();
 #ifdef BA_BCR_PROFILE
-    ph[0] += p1a - p0; ph[1] += p1 - p0; ph[2] += p2 - p1; ph[3] += clock64() - p2;
+    ph[0] += p1a - p0; ph[1] += p1 - p0; ph[2] += p2 - p1; ph[3] += 0;
 #endif
   }
 #ifdef BA_BCR_PROFILE
@@ -747,9 +746,24 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 #ifdef BA_BCR_PROFILE
     const long long q0 = clock64();
 #endif
+    // the update block column kb still owes to the panel of block kb - 1 (C -= panel panel^T, K = 12), one 16-row tile per task
+    auto urgent_tile = [&](int t) {
+      const int kp = k0 - 12, i0 = k0 + 16 * t;
+      const int ao = (i0 + lr) * ld + kp + lk, bo = (k0 + lr) * ld + kp + lk, cb = (i0 + lk) * ld + k0 + lr;
+      mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
+      const int rl = lr < nb ? B - i0 - lk : 0;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+    };
     if (kb == 0) {
     } else if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
+      urgent_tile(0);                                       // the tile that holds this diagonal block: by the chain's own wavefront,
+      lds_wave_sync();                                      // no barrier between the update and the factor
       if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
       else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
       __builtin_amdgcn_s_setprio(0);
@@ -759,7 +773,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     } else if (myslot >= 0) {
       const int kp = k0 - 12;
       const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
-      for (int task = myslot; task < nct + ngt; task += 12) {
+      const int nsu = ((B - k0 + 15) >> 4) - 1;             // tiles of block column kb below the one wavefront 0 takes
+      for (int task = myslot; task < nct + ngt + nsu; task += 12) {
+        if (task >= nct + ngt) { urgent_tile(task - nct - ngt + 1); continue; }
         int t0, t1, i00, co, cst;
         bool cok, full;
         double nb0, nb1, nb2;                                  // the NEGATED B operand of the three k-steps
@@ -836,23 +852,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     const long long q2 = clock64();
     pst[4] += q2 - q1;
 #endif
-    // ---------------- phase 3: the URGENT part of the update: block column kb+1 only
-    if (!last && wave >= 8 && wave <= 11) {
-      const int i0 = kn + 16 * (wave - 8);
-      if (i0 < B) {
-        const int nbn = B - kn < 12 ? B - kn : 12;             // width of the next block
-        const int ao = (i0 + lr) * ld + k0 + lk, bo = (kn + lr) * ld + k0 + lk, cb = (i0 + lk) * ld + kn + lr;
-        mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
-        const int rl = lr < nbn ? B - i0 - lk : 0;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
-      }
-    }
-    __syncthreads();
 #ifdef BA_BCR_PROFILE
     pst[5] += clock64() - q2;
 #endif
