@@ -74,8 +74,24 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
     const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
     const int kn = k0 + nb;
     // ---------------- phase 1: diagonal factor (wavefront 0) | the late part of the previous step's update
+    // what block column kb still owes to the panel of block kb - 1 (C -= panel panel^T, K = 12), one 16-row tile per call: the
+    // tile holding the diagonal block by wavefront 0 right before it factors it, the tiles below as tasks of the other wavefronts
+    auto urgent_tile = [&](int t) {
+      typedef double mfma_acc __attribute__((ext_vector_type(4)));
+      const int kp = k0 - 12, i0 = k0 + 16 * t;
+      const int ao = (i0 + lr) * ld + kp + lk, bo = (k0 + lr) * ld + kp + lk, cb = (i0 + lk) * ld + k0 + lr;
+      mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
+      const int rl = lr < nb ? B - i0 - lk : 0;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+    };
     if (wave == 0) {
       double dcol[12], ddi = 0.0;
+      if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
       double* Lv = Lvm + ((size_t)i * NBLK + kb) * 144;      // inverse of this diagonal block, [12][12], zero padded
       if (nb == 12) {
         bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
@@ -89,7 +105,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
       typedef double mfma_acc __attribute__((ext_vector_type(4)));
       const int kp = k0 - 12;
       const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
-      for (int task = wave - 1; task < ngt; task += kBcrElimThreads / 64 - 1) {
+      const int nsu = ((B - k0 + 15) >> 4) - 1;             // tiles of block column kb below the one wavefront 0 takes
+      for (int task = wave - 1; task < ngt + nsu; task += kBcrElimThreads / 64 - 1) {
+        if (task >= ngt) { urgent_tile(task - ngt + 1); continue; }
         const int c0 = kn + 16 * task;
         const bool cok = c0 + lr < B, full = c0 + 15 < B;
         const int bo = (c0 + lr) * ld + kp + lk;
@@ -125,24 +143,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
       const int row = rraw < B ? rraw : B - 1;               // lanes past the last row repeat it
       if (nb == 12) bcr_block_forward<12>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
       else bcr_block_forward<6>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
-    }
-    __syncthreads();
-    // ---------------- phase 3: the urgent part of the update: block column kb+1 only
-    if (!last && wave >= 8) {
-      typedef double mfma_acc __attribute__((ext_vector_type(4)));
-      const int i0 = kn + 16 * (wave - 8);
-      if (i0 < B) {
-        const int nbn = B - kn < 12 ? B - kn : 12;
-        const int ao = (i0 + lr) * ld + k0 + lk, bo = (kn + lr) * ld + k0 + lk, cb = (i0 + lk) * ld + kn + lr;
-        mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
-        const int rl = lr < nbn ? B - i0 - lk : 0;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
-      }
     }
     __syncthreads();
   }
