@@ -43,7 +43,7 @@ constexpr int kBcrTicketWord = 61;             // info[61]: tickets of k_bcr_bac
 constexpr long long kBcrNotYet = 0x7FFA5A5A5A5A5A5All;    // a NaN no computation produces: the mark of a solution entry that is not there yet
 constexpr int kBcrMaxHB = 11;                  // 4 matrices of B x (B+1) doubles must fit in LDS (B = 66: 145 KB)
 
-__host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 200) * sizeof(double); }   // + inverse of the current diagonal block
+__host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 392) * sizeof(double); }   // + inverses of the current and the previous diagonal block
 
 // band (+ mask) -> D[N][B][B], U[N][B][B] = T[I,I+1], f[N][B]; cameras past nco and masked
 // parameters become identity rows with zero right-hand side.
@@ -140,59 +140,59 @@ __device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...
   (bcr_diag_pivot<NB, Qs>(col, c, di, fail), ...);
 }
 
-// diagonal block of NB unknowns at k0 (wavefront 0): factor in place, 1/diag to dinv.  The factor stays
-// in registers (col[p] of lane c = U[p][c] = L[c][p], di = 1 / L[c][c]) for bcr_diag_inverse.
+// diagonal block of NB unknowns at k0 (wavefront 0): factor in place, 1/diag to dinv, and the INVERSE of the factor
+// to Li ([.][12], lower triangular) out of the same pivots.  Lanes 0..NB-1 of every 16-lane row own the columns of
+// the block (each row a replica: the DPP broadcasts are row-local), the lanes above them own columns of the identity.
+// The rank-1 updates of the elimination turn those into L^-1 (right-looking Cholesky of [A | I] gives [L^T | L^-1]):
+// the same instructions, nothing added to the chain of dependent pivots, and no triangular solve afterwards.
 template <int NB>
 __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, double* __restrict__ dinv, int* __restrict__ bad,
-                                               int k0, int lane, double (&col)[12], double& di) {
-  const int c = lane < NB ? lane : NB - 1;
+                                               int k0, int lane, double* __restrict__ Li) {
+  constexpr int NA = 16 - NB;                                           // identity columns per 16-lane row
+  const int i = lane & 15;
+  const bool own = i < NB;
+  const int c = own ? i : NB - 1;
+  const int j = (lane >> 4) * NA + (i - NB);                            // identity column of a lane that owns one (j < NB)
   double cl[NB];
 #pragma unroll
-  for (int p = 0; p < NB; ++p) cl[p] = G[(k0 + c) * ld + k0 + p];      // A[p][c] from the lower triangle
+  for (int p = 0; p < NB; ++p) {
+    const double a = G[(k0 + c) * ld + k0 + p];                         // A[p][c] from the lower triangle
+    cl[p] = own ? a : (p == j ? 1.0 : 0.0);
+  }
   int fail = 0;
-  di = 0.0;
-  bcr_diag_pivots<NB>(std::make_integer_sequence<int, NB>{}, cl, c, di, fail);
+  double di = 0.0;
+  bcr_diag_pivots<NB>(std::make_integer_sequence<int, NB>{}, cl, own ? i : -1, di, fail);
   if (fail && lane == 0) *bad = k0 + fail;
   if (lane < NB) {
     dinv[k0 + c] = di;
 #pragma unroll
     for (int p = 0; p < NB; ++p)
       if (p <= c) G[(k0 + c) * ld + k0 + p] = cl[p];                    // L[c][p] = U[p][c]
-  }
+  } else if (!own && j < NB) {
 #pragma unroll
-  for (int p = 0; p < NB; ++p) col[p] = cl[p];
-}
-
-template <int NB, int Q, int... Ps>
-__device__ __forceinline__ void bcr_inv_dot(std::integer_sequence<int, Ps...>, const double (&col)[12], const double (&x)[NB],
-                                            double& s0, double& s1) {
-  (fmac_rowbcast_safe<Q>((Ps & 1) ? s1 : s0, col[Ps], x[Ps]), ...);       // L[Q][p] = col[p] of lane Q
-}
-
-template <int NB, int Q>
-__device__ __forceinline__ void bcr_inv_row(const double (&col)[12], double di, int c, double (&x)[NB]) {
-  double s0 = 0.0, s1 = 0.0;
-  bcr_inv_dot<NB, Q>(std::make_integer_sequence<int, Q>{}, col, x, s0, s1);
-  x[Q] = ((c == Q ? 1.0 : 0.0) - (s0 + s1)) * mov_rowbcast<Q>(di);
-}
-
-template <int NB, int... Qs>
-__device__ __forceinline__ void bcr_inv_rows(std::integer_sequence<int, Qs...>, const double (&col)[12], double di, int c,
-                                             double (&x)[NB]) {
-  (bcr_inv_row<NB, Qs>(col, di, c, x), ...);
-}
-
-// inverse of the diagonal block straight from the registers of the factorisation (no LDS reads on
-// the chain): lane c solves L x = e_c, the entries of L arrive as DPP broadcasts; Li[q][c] = x[q]
-template <int NB>
-__device__ __forceinline__ void bcr_diag_inverse(const double (&col)[12], double di, int lane, double* __restrict__ Li) {
-  const int c = lane < NB ? lane : NB - 1;
-  double x[NB];
-  bcr_inv_rows<NB>(std::make_integer_sequence<int, NB>{}, col, di, c, x);
-  if (lane < NB) {
-#pragma unroll
-    for (int q = 0; q < NB; ++q) Li[q * 12 + c] = x[q];
+    for (int q = 0; q < NB; ++q) Li[q * 12 + j] = cl[q];                // L^-1[q][j] (exact zeros above the diagonal)
   }
+}
+
+// rows i0 .. i0+15 of the panel below the diagonal block of nbw (12 or 6) unknowns at k0: X = A L_kk^-T on the matrix
+// cores (K = 12, three v_mfma_f64_16x16x4_f64), in place.  Li = [16][12], rows 12..15 zero; for a 6-unknown block the
+// entries of Li outside its 6 x 6 corner are whatever the block before left there: their A operands are fed as zeros.
+__device__ __forceinline__ void bcr_panel_tile(double* __restrict__ G, int ld, int B, int k0, int i0, const double* __restrict__ Li,
+                                               int lr, int lk, int nbw = 12) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  const int row = i0 + lr < B ? i0 + lr : B - 1;                        // rows past the end repeat the last one (never stored)
+  const int ao = row * ld + k0 + lk, bo = lr * 12 + lk;
+  double a0 = G[ao], a1 = G[ao + 4], a2 = G[ao + 8];
+  if (nbw < 12) { a1 = lk < 2 ? a1 : 0.0; a2 = 0.0; }
+  mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Li[bo], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Li[bo + 4], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Li[bo + 8], acc, 0, 0, 0);
+  const int rl = lr < nbw ? B - i0 - lk : 0;
+  const int cb = (i0 + lk) * ld + k0 + lr;
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    if (4 * v < rl) G[cb + 4 * v * ld] = acc[v];
 }
 
 // acc += (lane K of my 16-lane row of `row`) * y   (the DPP source comes from an LDS load: no hazard)
@@ -257,7 +257,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   double* g = Xi + (size_t)B * ld;      // [B]
   double* dinv = g + B;                 // [B]
   int* bad = reinterpret_cast<int*>(dinv + B + 2);
-  double* Li = dinv + B + 4;            // [16][12]: rows 0..11 = inverse of the current diagonal block (lower triangular)
+  double* Li = dinv + B + 4;            // [2][16][12]: rows 0..11 = inverse of diagonal block kb in half kb & 1 (lower triangular;
+                                        // phase 1 reads block kb-1's while wavefront 0 writes block kb's), rows 12..15 zero
   const int tid = threadIdx.x;
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N) return;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 
   BA_STAMP(t0);
   if (tid == 0) *bad = 0;
-  if (tid < 192) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
+  if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
   {
     // all global loads of a thread are issued before the first LDS store (one round trip)
     constexpr int NIT = (B * B + kBcrElimThreads - 1) / kBcrElimThreads;
@@ -335,7 +336,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
     const long long p0 = clock64();
 #endif
     // ---------------- phase 1
-    double dcol[12], ddi = 0.0;                             // wavefront 0: the factor of this block, kept for phase 2
     // the update block column kb still owes to the panel of block kb - 1 (C -= panel panel^T, K = 12), one 16-row tile per task:
     // the tile that holds the diagonal block by wavefront 0 itself right before it factors it (no barrier in between), the
     // tiles below it as late-update tasks of this phase (they are due at the next barrier, when the panel needs them)
@@ -355,10 +355,11 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
     if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
       if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
-      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
-      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
       __builtin_amdgcn_s_setprio(0);
     } else if (kb > 0 && myslot >= 0) {
+      const double* Lp = Li + 192 * ((kb - 1) & 1);         // inverse of the previous diagonal block
       // what step kb-1 still owes, on the matrix cores: C -= A B with K = 12 (three
       // v_mfma_f64_16x16x4_f64), A = panel of block kp (16 rows of the tile), and
       //   right-hand sides, rows >= k0:                       B = Y_kp (12 x 16 columns)
@@ -388,9 +389,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
           // The result lands in exactly the B-operand layout of the updates below: no LDS round trip.
           const int ro = xoff + __mul24(kp + lk, xst), r4 = 4 * xst;
           mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
           if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
           nb0 = -y[0]; nb1 = -y[1]; nb2 = -y[2];
         } else {
@@ -439,17 +440,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #ifdef BA_BCR_PROFILE
     const long long p1 = clock64();
 #endif
-    // ---------------- phase 2: panel, rows below the diagonal block: X = A[i2][k0..] L_kk^-T (one row per lane)
-    if (wave == 1 && kn < B) {
-      const int row = kn + lane < B ? kn + lane : B - 1;      // lanes past the last row repeat it (identical values)
-      if (nb == 12) bcr_block_forward<12>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
-      else bcr_block_forward<6>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
-    } else if (wave == 0) {
-      // inverse of the diagonal block for the right-hand sides (which then need three MFMAs per 16
-      // columns instead of a 12-step chain per column), from the registers of the factorisation
-      if (nb == 12) bcr_diag_inverse<12>(dcol, ddi, lane, Li);
-      else bcr_diag_inverse<6>(dcol, ddi, lane, Li);
-    }
+    // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
+    if (kn + 16 * wave < B) bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk);      // (nb == 12 here; at most 4 tiles)
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long p2 = clock64();
@@ -465,6 +457,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
     // the last block row of the right-hand sides: Y = L_pp^-1 R_p (nothing below it)
     typedef double mfma_acc __attribute__((ext_vector_type(4)));
     constexpr int KL = 12 * (NBLK - 1), NL = B - KL;          // last block: start and size (12 or 6)
+    const double* Ll = Li + 192 * ((NBLK - 1) & 1);         // inverse of the last diagonal block
     for (int task = myslot; task < nct; task += 15) {
       const int col = 16 * task + lr;
       const bool cok = col < ncol;
@@ -472,14 +465,14 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
       const int xoff = rhs_column(cok ? col : ncol - 1, xst);
       const int ro = xoff + __mul24(KL + lk, xst), r4 = 4 * xst;
       mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + lk], sm[ro], y, 0, 0, 0);
       if (NL == 12) {
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
         if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
       } else {                                               // 6 rows: k = 4, 5 of the second step only
         const double r1 = lk < 2 ? sm[ro + (lk < 2 ? r4 : 0)] : 0.0;
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], r1, y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], r1, y, 0, 0, 0);
         if (cok) { sm[ro] = y[0]; if (lk < 2) sm[ro + r4] = y[1]; }
       }
     }
@@ -598,7 +591,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #ifndef BA_BCR_PRODUCT_WAVES
 #define BA_BCR_PRODUCT_WAVES 15     // wavefronts of the prologue's coupling product: all but the chain's (15), or only those of SIMDs 1..3 (12)
 #endif
-__host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 200) * sizeof(double); }
+__host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 392) * sizeof(double); }
 
 template <int HB>
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, int s, double* __restrict__ Dm,
@@ -616,7 +609,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   double* g = Tb + (size_t)B * ld;      // [B]
   double* dinv = g + B;                 // [B]
   int* bad = reinterpret_cast<int*>(dinv + B + 2);
-  double* Li = dinv + B + 4;            // [16][12]: inverse of the current diagonal block (lower triangular)
+  double* Li = dinv + B + 4;            // [2][16][12]: inverse of diagonal block kb in half kb & 1 (lower triangular), rows 12..15 zero
   const int tid = threadIdx.x;
   const int role = blockIdx.y;
   const int i = s * (2 * blockIdx.x + 1) - 1;
@@ -628,7 +621,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
 
   if (tid == 0) *bad = 0;
-  if (tid < 192) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
+  if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
 #ifdef BA_BCR_PROFILE
   long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long pt0 = clock64();
@@ -675,11 +668,10 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   // ---- block 0's diagonal factor (wavefront 0: it needs D_i only) WHILE the other wavefronts form this role's coupling
   //      from the factors of the node eliminated one level down
   constexpr int NBLK = (B + 11) / 12;
-  double dcol[12], ddi = 0.0;                               // wavefront 0: the factor of the current block, kept for phase 2
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
-    if (B >= 12) bcr_diag_block<12>(G, ld, dinv, bad, 0, lane, dcol, ddi);
-    else bcr_diag_block<6>(G, ld, dinv, bad, 0, lane, dcol, ddi);
+    if (B >= 12) bcr_diag_block<12>(G, ld, dinv, bad, 0, lane, Li);
+    else bcr_diag_block<6>(G, ld, dinv, bad, 0, lane, Li);
     __builtin_amdgcn_s_setprio(0);
 #ifdef BA_BCR_PROFILE
     pst[2] += clock64() - pt0 - pst[0];
@@ -764,13 +756,14 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
       urgent_tile(0);                                       // the tile that holds this diagonal block: by the chain's own wavefront,
       lds_wave_sync();                                      // no barrier between the update and the factor
-      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
-      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
+      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
       __builtin_amdgcn_s_setprio(0);
 #ifdef BA_BCR_PROFILE
       pst[2] += clock64() - q0;
 #endif
     } else if (myslot >= 0) {
+      const double* Lp = Li + 192 * ((kb - 1) & 1);         // inverse of the previous diagonal block
       const int kp = k0 - 12;
       const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
       const int nsu = ((B - k0 + 15) >> 4) - 1;             // tiles of block column kb below the one wavefront 0 takes
@@ -790,9 +783,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
           co = xoff + __mul24(lk, xst); cst = xst;
           const int ro = xoff + __mul24(kp + lk, xst), r4 = 4 * xst;
           mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
           if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
           nb0 = -y[0]; nb1 = -y[1]; nb2 = -y[2];
         } else {
@@ -838,15 +831,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     const long long q1 = clock64();
     pst[3] += q1 - q0;
 #endif
-    // ---------------- phase 2: panel, rows below the diagonal block (one row per lane) | inverse of the diagonal block
-    if (wave == 1 && kn < B) {
-      const int row = kn + lane < B ? kn + lane : B - 1;      // lanes past the last row repeat it (identical values)
-      if (nb == 12) bcr_block_forward<12>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
-      else bcr_block_forward<6>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
-    } else if (wave == 0) {
-      if (nb == 12) bcr_diag_inverse<12>(dcol, ddi, lane, Li);
-      else bcr_diag_inverse<6>(dcol, ddi, lane, Li);
-    }
+    // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
+    if (kn + 16 * wave < B) bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk);      // (nb == 12 here; at most 4 tiles)
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long q2 = clock64();
@@ -862,6 +848,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   if (myslot >= 0) {
     // the last block row of the right-hand sides: Y = L_pp^-1 R_p (nothing below it)
     constexpr int KL = 12 * (NBLK - 1), NL = B - KL;          // last block: start and size (12 or 6)
+    const double* Ll = Li + 192 * ((NBLK - 1) & 1);         // inverse of the last diagonal block
     for (int task = myslot; task < nct; task += 12) {
       const int col = 16 * task + lr;
       const bool cok = col < ncol;
@@ -869,14 +856,14 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       const int xoff = rhs_column(cok ? col : ncol - 1, xst);
       const int ro = xoff + __mul24(KL + lk, xst), r4 = 4 * xst;
       mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + lk], sm[ro], y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + lk], sm[ro], y, 0, 0, 0);
       if (NL == 12) {
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
         if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
       } else {                                               // 6 rows: k = 4, 5 of the second step only
         const double r1 = lk < 2 ? sm[ro + (lk < 2 ? r4 : 0)] : 0.0;
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[lr * 12 + 4 + lk], r1, y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], r1, y, 0, 0, 0);
         if (cok) { sm[ro] = y[0]; if (lk < 2) sm[ro + r4] = y[1]; }
       }
     }

@@ -22,7 +22,7 @@ constexpr int kBcrwMinHB = kBcrMaxHB + 1;
 constexpr int kBcrwMaxHB = 23;                 // B = 138: one B x (B+1) fp64 matrix = 150 KB of the 160 KB LDS (track length 24)
 constexpr int kBcrwLvLdsMaxB = 126;            // up to here the inverses of the diagonal blocks sit in LDS next to L; beyond, in L2
 
-__host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16) * sizeof(double); }
+__host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16 + 192) * sizeof(double); }
 __host__ __device__ inline size_t bcrw_solve_lds_bytes(int B) {
   return ((size_t)B * (B + 1) + (B <= kBcrwLvLdsMaxB ? (size_t)((B + 11) / 12) * 144 : 0) + 64) * sizeof(double);
 }
@@ -58,11 +58,13 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
   double* G = sm;                       // [B][ld]
   double* dinv = G + (size_t)B * ld;    // [B]
   int* bad = reinterpret_cast<int*>(dinv + B + 2);
+  double* Li = dinv + B + 16;           // [16][12]: inverse of the current diagonal block (rows 12..15 stay zero)
   const int tid = threadIdx.x;
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N) return;
   constexpr size_t BB = (size_t)B * B;
   if (tid == 0) *bad = 0;
+  if (tid < 192) Li[tid] = 0.0;
   bcrw_fill<B, kBcrElimThreads, 16>(G, Dm + (size_t)i * BB, tid);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -90,17 +92,17 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
         if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
     };
     if (wave == 0) {
-      double dcol[12], ddi = 0.0;
       if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
-      double* Lv = Lvm + ((size_t)i * NBLK + kb) * 144;      // inverse of this diagonal block, [12][12], zero padded
+      double* Lv = Lvm + ((size_t)i * NBLK + kb) * 144;      // inverse of this diagonal block, [12][12], zero padded, for k_bcrw_solve_mfma
       if (nb == 12) {
-        bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, dcol, ddi);
-        bcr_diag_inverse<12>(dcol, ddi, lane, Lv);
+        bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li);
       } else {
-        for (int e = lane; e < 144; e += 64) Lv[e] = 0.0;
-        bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, dcol, ddi);
-        bcr_diag_inverse<6>(dcol, ddi, lane, Lv);
+        for (int e = lane; e < 144; e += 64) Li[e] = 0.0;
+        lds_wave_sync();
+        bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Li);
       }
+      lds_wave_sync();
+      for (int e = lane; e < 144; e += 64) Lv[e] = Li[e];
     } else if (kb > 0) {
       typedef double mfma_acc __attribute__((ext_vector_type(4)));
       const int kp = k0 - 12;
@@ -137,13 +139,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
       }
     }
     __syncthreads();
-    // ---------------- phase 2: panel, rows below the diagonal block (one row per lane, two wavefronts)
-    if ((wave == 1 || wave == 2) && kn + (wave - 1) * 64 < B) {
-      const int rraw = kn + (wave - 1) * 64 + lane;
-      const int row = rraw < B ? rraw : B - 1;               // lanes past the last row repeat it
-      if (nb == 12) bcr_block_forward<12>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
-      else bcr_block_forward<6>(G + k0 * ld + k0 + lr, ld, dinv + k0, G + row * ld + k0, 1);
-    }
+    // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
+    if (kn + 16 * wave < B) bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li, lr, lk);      // (B <= 138: at most 8 tiles; nb == 12 here)
     __syncthreads();
   }
   if (*bad) {

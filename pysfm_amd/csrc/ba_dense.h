@@ -31,7 +31,7 @@ constexpr int kDcM = kDcNB + kDcRows + 16;     // LDS rows: diagonal block + pan
 constexpr int kDcTile = 64;
 constexpr int kDcMaxN = 16000;                 // k_dense_backsolve keeps w[n] in LDS
 
-__host__ __device__ inline size_t dense_panel_lds_bytes() { return ((size_t)kDcM * kDcLd + kDcNB + 8) * sizeof(double); }
+__host__ __device__ inline size_t dense_panel_lds_bytes() { return ((size_t)kDcM * kDcLd + kDcNB + 8 + 192) * sizeof(double); }
 __host__ __device__ inline size_t dense_backsolve_lds_bytes(int n) {
   return ((size_t)n + kDcNB * kDcLd + kDcNB + 1024 + 8) * sizeof(double);
 }
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
   double* G = sm;                                  // [kDcM][ld]: rows 0..nb-1 = A_kk, rows nb.. = my panel rows
   double* dinv = G + (size_t)kDcM * ld;            // [48]
   int* bad = reinterpret_cast<int*>(dinv + kDcNB);
+  double* Li = dinv + kDcNB + 8;                   // [16][12]: inverse of the current 12 x 12 diagonal block, rows 12..15 zero
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   const int kn = k0 + nb;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
   const int cnt = max(0, min(kDcRows, total - q0));
   const int M = nb + cnt;
   if (tid == 0) *bad = 0;
+  if (tid < 192) Li[tid] = 0.0;
   // fill: 9 entries per thread, loads first (their latencies overlap), then the LDS stores
   {
     constexpr int NE = kDcM * kDcNB, U = (NE + 1023) / 1024;
@@ -103,18 +105,12 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
     const int nbi = nb - j0 < 12 ? nb - j0 : 12;    // 12, or 6 at the very end of the matrix
     const int jn = j0 + nbi;
     if (wave == 0) {
-      double dcol[12], ddi = 0.0;
-      if (nbi == 12) bcr_diag_block<12>(G, ld, dinv, bad, j0, lane, dcol, ddi);
-      else bcr_diag_block<6>(G, ld, dinv, bad, j0, lane, dcol, ddi);
+      if (nbi == 12) bcr_diag_block<12>(G, ld, dinv, bad, j0, lane, Li);
+      else bcr_diag_block<6>(G, ld, dinv, bad, j0, lane, Li);
     }
     __syncthreads();
-    const int nrow = M - jn;                        // rows below the diagonal block, one per lane
-    if (wave * 64 < nrow) {
-      const int rraw = jn + wave * 64 + lane;
-      const int row = rraw < M ? rraw : M - 1;      // lanes past the last row repeat it (DPP needs live lanes)
-      if (nbi == 12) bcr_block_forward<12>(G + j0 * ld + j0 + lr, ld, dinv + j0, G + row * ld + j0, 1);
-      else bcr_block_forward<6>(G + j0 * ld + j0 + lr, ld, dinv + j0, G + row * ld + j0, 1);
-    }
+    // rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront (below a 6-unknown block: the right-hand side row)
+    for (int i0 = jn + 16 * wave; i0 < M; i0 += 256) bcr_panel_tile(G, ld, M, j0, i0, Li, lr, lk, nbi);
     __syncthreads();
     if (jn < nb) {                                  // rank-12 update of the columns right of this block (nbi == 12 here)
       const int nct = (nb - jn + 15) >> 4;
