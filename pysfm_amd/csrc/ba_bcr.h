@@ -121,9 +121,11 @@ __device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...
 // U = L^T): all cross-lane traffic is DPP row_newbcast - one instruction per broadcast on the chain
 // of dependent pivots
 template <int NB, int Q>
-__device__ __forceinline__ void bcr_diag_pivot(double (&col)[NB], int c, double& di, int& fail) {
+__device__ __forceinline__ void bcr_diag_pivot(double (&col)[NB], int c, double& di) {
   // the dependent chain is: broadcast pivot -> rsqrt (seed + 2 Newton steps) -> scale -> rank-1 update
-  // of the next column; selects and the failure test stay off it.  col[Q] * inv is right for every lane
+  // of the next column, and the one wavefront that runs it pays 8 cycles of issue for every fp64 instruction, on the
+  // chain or off it: no selects and no failure test here (a pivot <= 0 turns its own 1/sqrt and everything after it
+  // into NaN or inf - bcr_diag_block finds the first such lane afterwards).  col[Q] * inv is right for every lane
   // that matters: lane Q holds the pivot itself (-> its square root), lanes below Q hold entries that are
   // never used again.
   const double piv = mov_rowbcast<Q>(col[Q]);
@@ -131,13 +133,12 @@ __device__ __forceinline__ void bcr_diag_pivot(double (&col)[NB], int c, double&
   const double uqc = col[Q] * inv;
   bcr_diag_update<NB, Q>(std::make_integer_sequence<int, NB - 1 - Q>{}, col, uqc);
   col[Q] = uqc;
-  if (!(piv > 0.0) && !fail) fail = Q + 1;
   if (c == Q) di = inv;
 }
 
 template <int NB, int... Qs>
-__device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...>, double (&col)[NB], int c, double& di, int& fail) {
-  (bcr_diag_pivot<NB, Qs>(col, c, di, fail), ...);
+__device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...>, double (&col)[NB], int c, double& di) {
+  (bcr_diag_pivot<NB, Qs>(col, c, di), ...);
 }
 
 // diagonal block of NB unknowns at k0 (wavefront 0): factor in place, 1/diag to dinv, and the INVERSE of the factor
@@ -159,10 +160,11 @@ __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, d
     const double a = G[(k0 + c) * ld + k0 + p];                         // A[p][c] from the lower triangle
     cl[p] = own ? a : (p == j ? 1.0 : 0.0);
   }
-  int fail = 0;
   double di = 0.0;
-  bcr_diag_pivots<NB>(std::make_integer_sequence<int, NB>{}, cl, own ? i : -1, di, fail);
-  if (fail && lane == 0) *bad = k0 + fail;
+  bcr_diag_pivots<NB>(std::make_integer_sequence<int, NB>{}, cl, own ? i : -1, di);
+  // not positive definite: the first lane whose 1 / sqrt(pivot) is not a positive finite number is the first bad pivot
+  const unsigned long long notpd = __ballot(lane < NB && !(di > 0.0 && di < __builtin_huge_val()));
+  if (notpd && lane == 0) *bad = k0 + __ffsll((long long)notpd);
   if (lane < NB) {
     dinv[k0 + c] = di;
 #pragma unroll
