@@ -120,33 +120,43 @@ __device__ __forceinline__ void bcr_diag_update(std::integer_sequence<int, Ps...
 // pivot Q of the NB x NB Cholesky on lanes 0..NB-1 of one 16-lane row (lane c owns column c of
 // U = L^T): all cross-lane traffic is DPP row_newbcast - one instruction per broadcast on the chain
 // of dependent pivots
-template <int NB, int Q>
+template <int NB, int Q, bool KEEP_L>
 __device__ __forceinline__ void bcr_diag_pivot(double (&col)[NB], int c, double& di) {
-  // the dependent chain is: broadcast pivot -> rsqrt (seed + 2 Newton steps) -> scale -> rank-1 update
-  // of the next column, and the one wavefront that runs it pays 8 cycles of issue for every fp64 instruction, on the
-  // chain or off it: no selects and no failure test here (a pivot <= 0 turns its own 1/sqrt and everything after it
-  // into NaN or inf - bcr_diag_block finds the first such lane afterwards).  col[Q] * inv is right for every lane
-  // that matters: lane Q holds the pivot itself (-> its square root), lanes below Q hold entries that are
-  // never used again.
+  // The dependent chain is: broadcast pivot -> 1/sqrt (seed, then ONE cubic step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2, folded
+  // into the scaling: u = w + (w e)(1/2 + 3 e / 8) with w = col y) -> rank-1 update of the next column; measured
+  // (tools/chain_probe) 14.6 + 20 + 4 x 8.4 + 16.9 cycles.  The one wavefront that runs it also pays 5 - 8 cycles of issue for
+  // every instruction off the chain: no selects and no failure test here (a pivot <= 0 turns its own 1/sqrt and everything after
+  // it into NaN or inf - bcr_diag_block looks afterwards), and 1/sqrt itself is only formed where somebody needs it.
+  // u is right for every lane that matters: lane Q holds the pivot itself (-> its square root), lanes below Q hold entries that
+  // are never used again.
   const double piv = mov_rowbcast<Q>(col[Q]);
-  const double inv = rsqrt_nr(piv);
-  const double uqc = col[Q] * inv;
+  const double y = __builtin_amdgcn_rsq(piv);
+  const double e = fma(-(piv * y), y, 1.0);
+  const double pe = fma(e, 0.375, 0.5);
+  const double w = col[Q] * y;
+  const double uqc = fma(w * e, pe, w);
   bcr_diag_update<NB, Q>(std::make_integer_sequence<int, NB - 1 - Q>{}, col, uqc);
   col[Q] = uqc;
-  if (c == Q) di = inv;
+  if constexpr (KEEP_L) {
+    const double inv = fma(y * e, pe, y);
+    if (c == Q) di = inv;
+  } else if constexpr (Q == NB - 1) {
+    di = fma(y * e, pe, y);                                            // (wave-uniform: the health of the whole block, see below)
+  }
 }
 
-template <int NB, int... Qs>
+template <int NB, bool KEEP_L, int... Qs>
 __device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...>, double (&col)[NB], int c, double& di) {
-  (bcr_diag_pivot<NB, Qs>(col, c, di), ...);
+  (bcr_diag_pivot<NB, Qs, KEEP_L>(col, c, di), ...);
 }
 
-// diagonal block of NB unknowns at k0 (wavefront 0): factor in place, 1/diag to dinv, and the INVERSE of the factor
-// to Li ([.][12], lower triangular) out of the same pivots.  Lanes 0..NB-1 of every 16-lane row own the columns of
+// diagonal block of NB unknowns at k0 (wavefront 0): the INVERSE of its Cholesky factor to Li ([.][12], lower triangular) and,
+// with KEEP_L, the factor itself in place and 1/diag to dinv (the kernels that hand the factor on; the node kernels of the
+// narrow reduction only ever use the inverse).  Lanes 0..NB-1 of every 16-lane row own the columns of
 // the block (each row a replica: the DPP broadcasts are row-local), the lanes above them own columns of the identity.
 // The rank-1 updates of the elimination turn those into L^-1 (right-looking Cholesky of [A | I] gives [L^T | L^-1]):
 // the same instructions, nothing added to the chain of dependent pivots, and no triangular solve afterwards.
-template <int NB>
+template <int NB, bool KEEP_L = true>
 __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, double* __restrict__ dinv, int* __restrict__ bad,
                                                int k0, int lane, double* __restrict__ Li) {
   constexpr int NA = 16 - NB;                                           // identity columns per 16-lane row
@@ -161,11 +171,16 @@ __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, d
     cl[p] = own ? a : (p == j ? 1.0 : 0.0);
   }
   double di = 0.0;
-  bcr_diag_pivots<NB>(std::make_integer_sequence<int, NB>{}, cl, own ? i : -1, di);
-  // not positive definite: the first lane whose 1 / sqrt(pivot) is not a positive finite number is the first bad pivot
-  const unsigned long long notpd = __ballot(lane < NB && !(di > 0.0 && di < __builtin_huge_val()));
-  if (notpd && lane == 0) *bad = k0 + __ffsll((long long)notpd);
-  if (lane < NB) {
+  bcr_diag_pivots<NB, KEEP_L>(std::make_integer_sequence<int, NB>{}, cl, own ? i : -1, di);
+  if constexpr (KEEP_L) {
+    // not positive definite: the first lane whose 1 / sqrt(pivot) is not a positive finite number is the first bad pivot
+    const unsigned long long notpd = __ballot(lane < NB && !(di > 0.0 && di < __builtin_huge_val()));
+    if (notpd && lane == 0) *bad = k0 + __ffsll((long long)notpd);
+  } else {
+    // a bad pivot poisons every later one: 1 / sqrt of the LAST pivot tells whether all of them were positive
+    if (lane == 0 && !(di > 0.0 && di < __builtin_huge_val())) *bad = k0 + 1;
+  }
+  if (KEEP_L && lane < NB) {
     dinv[k0 + c] = di;
 #pragma unroll
     for (int p = 0; p < NB; ++p)
@@ -357,8 +372,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
     if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
       if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
-      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
-      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+      else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
       __builtin_amdgcn_s_setprio(0);
     } else if (kb > 0 && myslot >= 0) {
       const double* Lp = Li + 192 * ((kb - 1) & 1);         // inverse of the previous diagonal block
@@ -672,8 +687,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   constexpr int NBLK = (B + 11) / 12;
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
-    if (B >= 12) bcr_diag_block<12>(G, ld, dinv, bad, 0, lane, Li);
-    else bcr_diag_block<6>(G, ld, dinv, bad, 0, lane, Li);
+    if (B >= 12) bcr_diag_block<12, false>(G, ld, dinv, bad, 0, lane, Li);
+    else bcr_diag_block<6, false>(G, ld, dinv, bad, 0, lane, Li);
     __builtin_amdgcn_s_setprio(0);
 #ifdef BA_BCR_PROFILE
     pst[2] += clock64() - pt0 - pst[0];
@@ -758,8 +773,11 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
       urgent_tile(0);                                       // the tile that holds this diagonal block: by the chain's own wavefront,
       lds_wave_sync();                                      // no barrier between the update and the factor
-      if (nb == 12) bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
-      else bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+#ifdef BA_BCR_PROFILE
+      pst[5] += clock64() - q0;
+#endif
+      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+      else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
       __builtin_amdgcn_s_setprio(0);
 #ifdef BA_BCR_PROFILE
       pst[2] += clock64() - q0;
@@ -839,9 +857,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 #ifdef BA_BCR_PROFILE
     const long long q2 = clock64();
     pst[4] += q2 - q1;
-#endif
-#ifdef BA_BCR_PROFILE
-    pst[5] += clock64() - q2;
 #endif
   }
 #ifdef BA_BCR_PROFILE

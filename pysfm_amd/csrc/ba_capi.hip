@@ -1880,7 +1880,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   if (h->opt.solve_trace && use_bcr && h->opt.solver != SOLVER_BCR1) {
     for (int role = 0; role < 3; ++role) {
       const int* o = inf6 + 8 + 10 * role;
-      fprintf(stderr, "[k_bcr_eliminate_split level 2 node 1 role %d] load %d prologue %d | diag factor (wave 0) %d, phase 1 %d, phase 2 %d, phase 3 %d | last rhs %d, products+store %d cycles\n",
+      fprintf(stderr, "[k_bcr_eliminate_split level 2 node 1 role %d] load %d prologue %d | diag factor (wave 0, with block 0 and the urgent tiles) %d, phase 1 %d, phase 2 %d, urgent tile 0 %d | last rhs %d, products+store %d cycles\n",
               role, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
     }
   } else
