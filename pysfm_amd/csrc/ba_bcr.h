@@ -43,7 +43,7 @@ constexpr int kBcrTicketWord = 61;             // info[61]: tickets of k_bcr_bac
 constexpr long long kBcrNotYet = 0x7FFA5A5A5A5A5A5All;    // a NaN no computation produces: the mark of a solution entry that is not there yet
 constexpr int kBcrMaxHB = 11;                  // 4 matrices of B x (B+1) doubles must fit in LDS (B = 66: 145 KB)
 
-__host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 392) * sizeof(double); }   // + inverses of the current and the previous diagonal block
+__host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 560) * sizeof(double); }   // + inverses of the current and the previous diagonal block, identity table
 
 // band (+ mask) -> D[N][B][B], U[N][B][B] = T[I,I+1], f[N][B]; cameras past nco and masked
 // parameters become identity rows with zero right-hand side.
@@ -156,22 +156,39 @@ __device__ __forceinline__ void bcr_diag_pivots(std::integer_sequence<int, Qs...
 // the block (each row a replica: the DPP broadcasts are row-local), the lanes above them own columns of the identity.
 // The rank-1 updates of the elimination turn those into L^-1 (right-looking Cholesky of [A | I] gives [L^T | L^-1]):
 // the same instructions, nothing added to the chain of dependent pivots, and no triangular solve afterwards.
+constexpr int kBcrIdtDoubles = 160;                                     // identity table [13][12] (+ padding)
+__device__ __forceinline__ void bcr_identity_table(double* Idt, int tid) {
+  if (tid < 156) Idt[tid] = (tid / 12 == tid % 12) ? 1.0 : 0.0;
+}
+
 template <int NB, bool KEEP_L = true>
 __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, double* __restrict__ dinv, int* __restrict__ bad,
-                                               int k0, int lane, double* __restrict__ Li) {
+                                               int k0, int lane, double* __restrict__ Li, const double* __restrict__ Idt,
+                                               long long* trace = nullptr) {
   constexpr int NA = 16 - NB;                                           // identity columns per 16-lane row
+#ifdef BA_BCR_PROFILE
+  const long long tr0 = clock64();
+#endif
   const int i = lane & 15;
   const bool own = i < NB;
   const int c = own ? i : NB - 1;
   const int j = (lane >> 4) * NA + (i - NB);                            // identity column of a lane that owns one (j < NB)
+  // A[p][c] from the lower triangle, or column j of the identity out of a table in LDS (Idt = [13][12], row 12 zero): one
+  // address select and NB unconditional loads (selects on the loaded values compile to a branch around every load)
+  const double* src = own ? G + (k0 + c) * ld + k0 : Idt + (j < NB ? j : 12) * 12;
   double cl[NB];
 #pragma unroll
-  for (int p = 0; p < NB; ++p) {
-    const double a = G[(k0 + c) * ld + k0 + p];                         // A[p][c] from the lower triangle
-    cl[p] = own ? a : (p == j ? 1.0 : 0.0);
-  }
+  for (int p = 0; p < NB; ++p) cl[p] = src[p];
   double di = 0.0;
+#ifdef BA_BCR_PROFILE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const long long tr1 = clock64();
+#endif
   bcr_diag_pivots<NB, KEEP_L>(std::make_integer_sequence<int, NB>{}, cl, own ? i : -1, di);
+#ifdef BA_BCR_PROFILE
+  asm volatile("" ::"v"(cl[NB - 1]), "v"(di));
+  const long long tr2 = clock64();
+#endif
   if constexpr (KEEP_L) {
     // not positive definite: the first lane whose 1 / sqrt(pivot) is not a positive finite number is the first bad pivot
     const unsigned long long notpd = __ballot(lane < NB && !(di > 0.0 && di < __builtin_huge_val()));
@@ -189,6 +206,13 @@ __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, d
 #pragma unroll
     for (int q = 0; q < NB; ++q) Li[q * 12 + j] = cl[q];                // L^-1[q][j] (exact zeros above the diagonal)
   }
+#ifdef BA_BCR_PROFILE
+  if (trace) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long tr3 = clock64();
+    if (lane == 0) { trace[0] = tr1 - tr0; trace[1] = tr2 - tr1; trace[2] = tr3 - tr2; }
+  }
+#endif
 }
 
 // rows i0 .. i0+15 of the panel below the diagonal block of nbw (12 or 6) unknowns at k0: X = A L_kk^-T on the matrix
@@ -205,11 +229,18 @@ __device__ __forceinline__ void bcr_panel_tile(double* __restrict__ G, int ld, i
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Li[bo], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Li[bo + 4], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Li[bo + 8], acc, 0, 0, 0);
-  const int rl = lr < nbw ? B - i0 - lk : 0;
   const int cb = (i0 + lk) * ld + k0 + lr;
+  if (i0 + 16 <= B) {                                                   // (wave-uniform) all 16 rows exist
+    if (lr < nbw) {
 #pragma unroll
-  for (int v = 0; v < 4; ++v)
-    if (4 * v < rl) G[cb + 4 * v * ld] = acc[v];
+      for (int v = 0; v < 4; ++v) G[cb + 4 * v * ld] = acc[v];
+    }
+  } else {
+    const int rl = lr < nbw ? B - i0 - lk : 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (4 * v < rl) G[cb + 4 * v * ld] = acc[v];
+  }
 }
 
 // acc += (lane K of my 16-lane row of `row`) * y   (the DPP source comes from an LDS load: no hazard)
@@ -286,6 +317,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
   BA_STAMP(t0);
   if (tid == 0) *bad = 0;
   if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
+  double* Idt = Li + 384;
+  bcr_identity_table(Idt, tid);
   {
     // all global loads of a thread are issued before the first LDS store (one round trip)
     constexpr int NIT = (B * B + kBcrElimThreads - 1) / kBcrElimThreads;
@@ -364,16 +397,23 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
-      const int rl = lr < nb ? B - i0 - lk : 0;
+      if (i0 + 16 <= B) {                                    // (wave-uniform) all 16 rows exist: one lane mask for the four stores
+        if (lr < nb) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+          for (int v = 0; v < 4; ++v) sm[cb + 4 * v * ld] = acc[v];
+        }
+      } else {
+        const int rl = lr < nb ? B - i0 - lk : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+      }
     };
     if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
       if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
-      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
-      else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
+      else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
       __builtin_amdgcn_s_setprio(0);
     } else if (kb > 0 && myslot >= 0) {
       const double* Lp = Li + 192 * ((kb - 1) & 1);         // inverse of the previous diagonal block
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #ifndef BA_BCR_PRODUCT_WAVES
 #define BA_BCR_PRODUCT_WAVES 15     // wavefronts of the prologue's coupling product: all but the chain's (15), or only those of SIMDs 1..3 (12)
 #endif
-__host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 392) * sizeof(double); }
+__host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 560) * sizeof(double); }
 
 template <int HB>
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, int s, double* __restrict__ Dm,
@@ -639,8 +679,11 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 
   if (tid == 0) *bad = 0;
   if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
+  double* Idt = Li + 384;
+  bcr_identity_table(Idt, tid);
 #ifdef BA_BCR_PROFILE
   long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long* dtrace = reinterpret_cast<long long*>(Li + 384 + kBcrIdtDoubles);
   const long long pt0 = clock64();
 #endif
   {
@@ -687,8 +730,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   constexpr int NBLK = (B + 11) / 12;
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
-    if (B >= 12) bcr_diag_block<12, false>(G, ld, dinv, bad, 0, lane, Li);
-    else bcr_diag_block<6, false>(G, ld, dinv, bad, 0, lane, Li);
+    if (B >= 12) bcr_diag_block<12, false>(G, ld, dinv, bad, 0, lane, Li, Idt);
+    else bcr_diag_block<6, false>(G, ld, dinv, bad, 0, lane, Li, Idt);
     __builtin_amdgcn_s_setprio(0);
 #ifdef BA_BCR_PROFILE
     pst[2] += clock64() - pt0 - pst[0];
@@ -763,10 +806,17 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
-      const int rl = lr < nb ? B - i0 - lk : 0;
+      if (i0 + 16 <= B) {                                    // (wave-uniform) all 16 rows exist: one lane mask for the four stores
+        if (lr < nb) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+          for (int v = 0; v < 4; ++v) sm[cb + 4 * v * ld] = acc[v];
+        }
+      } else {
+        const int rl = lr < nb ? B - i0 - lk : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+      }
     };
     if (kb == 0) {
     } else if (wave == 0) {
@@ -776,8 +826,12 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 #ifdef BA_BCR_PROFILE
       pst[5] += clock64() - q0;
 #endif
-      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
-      else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+#ifdef BA_BCR_PROFILE
+      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt, kb == 2 ? dtrace : nullptr);
+#else
+      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
+#endif
+      else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
       __builtin_amdgcn_s_setprio(0);
 #ifdef BA_BCR_PROFILE
       pst[2] += clock64() - q0;
@@ -961,6 +1015,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     int* o = info + 8 + 10 * role;              // [load, prologue, diag factor (wave 0), phase 1, phase 2, phase 3, last rhs block, products + store]
     for (int q = 0; q < 7; ++q) o[q] = (int)pst[q];
     o[7] = (int)(clock64() - pt3);
+    if (role == 0) { info[40] = (int)dtrace[0]; info[41] = (int)dtrace[1]; info[42] = (int)dtrace[2]; }
   }
 #endif
 }

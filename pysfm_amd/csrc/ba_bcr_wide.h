@@ -22,7 +22,7 @@ constexpr int kBcrwMinHB = kBcrMaxHB + 1;
 constexpr int kBcrwMaxHB = 23;                 // B = 138: one B x (B+1) fp64 matrix = 150 KB of the 160 KB LDS (track length 24)
 constexpr int kBcrwLvLdsMaxB = 126;            // up to here the inverses of the diagonal blocks sit in LDS next to L; beyond, in L2
 
-__host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16 + 192) * sizeof(double); }
+__host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16 + 192 + kBcrIdtDoubles) * sizeof(double); }
 __host__ __device__ inline size_t bcrw_solve_lds_bytes(int B) {
   return ((size_t)B * (B + 1) + (B <= kBcrwLvLdsMaxB ? (size_t)((B + 11) / 12) * 144 : 0) + 64) * sizeof(double);
 }
@@ -65,6 +65,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
   constexpr size_t BB = (size_t)B * B;
   if (tid == 0) *bad = 0;
   if (tid < 192) Li[tid] = 0.0;
+  double* Idt = Li + 192;
+  bcr_identity_table(Idt, tid);
   bcrw_fill<B, kBcrElimThreads, 16>(G, Dm + (size_t)i * BB, tid);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -86,20 +88,27 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
-      const int rl = lr < nb ? B - i0 - lk : 0;
+      if (i0 + 16 <= B) {                                    // (wave-uniform) all 16 rows exist: one lane mask for the four stores
+        if (lr < nb) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+          for (int v = 0; v < 4; ++v) sm[cb + 4 * v * ld] = acc[v];
+        }
+      } else {
+        const int rl = lr < nb ? B - i0 - lk : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+      }
     };
     if (wave == 0) {
       if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
       double* Lv = Lvm + ((size_t)i * NBLK + kb) * 144;      // inverse of this diagonal block, [12][12], zero padded, for k_bcrw_solve_mfma
       if (nb == 12) {
-        bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li);
+        bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li, Idt);
       } else {
         for (int e = lane; e < 144; e += 64) Li[e] = 0.0;
         lds_wave_sync();
-        bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Li);
+        bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Li, Idt);
       }
       lds_wave_sync();
       for (int e = lane; e < 144; e += 64) Lv[e] = Li[e];

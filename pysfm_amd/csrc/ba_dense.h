@@ -31,7 +31,7 @@ constexpr int kDcM = kDcNB + kDcRows + 16;     // LDS rows: diagonal block + pan
 constexpr int kDcTile = 64;
 constexpr int kDcMaxN = 16000;                 // k_dense_backsolve keeps w[n] in LDS
 
-__host__ __device__ inline size_t dense_panel_lds_bytes() { return ((size_t)kDcM * kDcLd + kDcNB + 8 + 192) * sizeof(double); }
+__host__ __device__ inline size_t dense_panel_lds_bytes() { return ((size_t)kDcM * kDcLd + kDcNB + 8 + 192 + kBcrIdtDoubles) * sizeof(double); }
 __host__ __device__ inline size_t dense_backsolve_lds_bytes(int n) {
   return ((size_t)n + kDcNB * kDcLd + kDcNB + 1024 + 8) * sizeof(double);
 }
@@ -80,6 +80,8 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
   const int M = nb + cnt;
   if (tid == 0) *bad = 0;
   if (tid < 192) Li[tid] = 0.0;
+  double* Idt = Li + 192;
+  bcr_identity_table(Idt, tid);
   // fill: 9 entries per thread, loads first (their latencies overlap), then the LDS stores
   {
     constexpr int NE = kDcM * kDcNB, U = (NE + 1023) / 1024;
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
     const int nbi = nb - j0 < 12 ? nb - j0 : 12;    // 12, or 6 at the very end of the matrix
     const int jn = j0 + nbi;
     if (wave == 0) {
-      if (nbi == 12) bcr_diag_block<12>(G, ld, dinv, bad, j0, lane, Li);
-      else bcr_diag_block<6>(G, ld, dinv, bad, j0, lane, Li);
+      if (nbi == 12) bcr_diag_block<12>(G, ld, dinv, bad, j0, lane, Li, Idt);
+      else bcr_diag_block<6>(G, ld, dinv, bad, j0, lane, Li, Idt);
     }
     __syncthreads();
     // rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront (below a 6-unknown block: the right-hand side row)

@@ -6,17 +6,18 @@
 using namespace ba;
 
 __global__ __launch_bounds__(1024) void k_probe(const double* A, long long* out, int reps) {
-  __shared__ double G[16 * 17], dinv[16], Li[192];
+  __shared__ double G[16 * 17], dinv[16], Li[192], Idt[160];
   __shared__ int bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long tb = 0, tp = 0;
   for (int r = 0; r < reps; ++r) {
     if (tid < 192) Li[tid] = 0.0;
+    bcr_identity_table(Idt, tid);
     for (int e = tid; e < 144; e += blockDim.x) G[(e / 12) * 17 + e % 12] = A[e];
     __syncthreads();
     if (wave == 0) {
       const long long t0 = clock64();
-      bcr_diag_block<12, false>(G, 17, dinv, &bad, 0, lane, Li);
+      bcr_diag_block<12, false>(G, 17, dinv, &bad, 0, lane, Li, Idt);
       lds_wave_sync();
       const long long dt = clock64() - t0;
       tb += dt;
