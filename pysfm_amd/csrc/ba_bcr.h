@@ -216,30 +216,57 @@ __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, d
 }
 
 // rows i0 .. i0+15 of the panel below the diagonal block of nbw (12 or 6) unknowns at k0: X = A L_kk^-T on the matrix
-// cores (K = 12, three v_mfma_f64_16x16x4_f64), in place.  Li = [16][12], rows 12..15 zero; for a 6-unknown block the
-// entries of Li outside its 6 x 6 corner are whatever the block before left there: their A operands are fed as zeros.
+// cores, in place, computed as its transpose X^T = L_kk^-1 A^T (K = 12, three v_mfma_f64_16x16x4_f64): the result leaves the
+// matrix core as lane (row of the tile, k % 4) -> X[row][k], which is where the lane read A from (the stores reuse the load
+// addresses) AND the layout of both operands of the update X X^T that comes next - pr[] hands the tile on in registers.
+// Li = [16][12], rows 12..15 zero; for a 6-unknown block the entries of Li outside its 6 x 6 corner are whatever the block
+// before left there: the columns of A they meet are fed as zeros.
 __device__ __forceinline__ void bcr_panel_tile(double* __restrict__ G, int ld, int B, int k0, int i0, const double* __restrict__ Li,
-                                               int lr, int lk, int nbw = 12) {
+                                               int lr, int lk, double (&pr)[3], int nbw = 12) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   const int row = i0 + lr < B ? i0 + lr : B - 1;                        // rows past the end repeat the last one (never stored)
   const int ao = row * ld + k0 + lk, bo = lr * 12 + lk;
   double a0 = G[ao], a1 = G[ao + 4], a2 = G[ao + 8];
   if (nbw < 12) { a1 = lk < 2 ? a1 : 0.0; a2 = 0.0; }
   mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Li[bo], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Li[bo + 4], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Li[bo + 8], acc, 0, 0, 0);
-  const int cb = (i0 + lk) * ld + k0 + lr;
-  if (i0 + 16 <= B) {                                                   // (wave-uniform) all 16 rows exist
-    if (lr < nbw) {
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[bo], a0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[bo + 4], a1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[bo + 8], a2, acc, 0, 0, 0);
+  pr[0] = acc[0]; pr[1] = acc[1]; pr[2] = acc[2];
+  if (i0 + lr < B) {
+    G[ao] = acc[0];
+    if (nbw == 12 || lk < 2) G[ao + 4] = acc[1];
+    if (nbw == 12) G[ao + 8] = acc[2];
+  }
+}
+
+typedef double bcr_acc4 __attribute__((ext_vector_type(4)));
+
+// Wavefront 0 between two diagonal blocks.  The tile of the next block column that holds the next diagonal block (rows
+// kn .. kn+15) owes the panel one update, C -= X X^T over the first 16 rows X of the panel - the tile wavefront 0 computed
+// itself and still holds in registers (pr, in the layout of BOTH operands).  The accumulator tile is fetched while the panel
+// is being computed (it has been final since the barrier before), so after the barrier that ends the panel phase the three
+// MFMAs start without an LDS round trip.
+__device__ __forceinline__ bcr_acc4 bcr_prefetch_tile0(const double* __restrict__ sm, int ld, int kn, int lr, int lk) {
+  const int cb = (kn + lk) * ld + kn + lr;
+  return bcr_acc4{sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+}
+__device__ __forceinline__ void bcr_urgent_tile0(double* __restrict__ sm, int ld, int B, int k0, int nb, int lr, int lk,
+                                                 const double (&pr)[3], bcr_acc4 acc) {
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[0], -pr[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[1], -pr[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[2], -pr[2], acc, 0, 0, 0);
+  const int cb = (k0 + lk) * ld + k0 + lr;
+  if (k0 + 16 <= B) {                                                   // (wave-uniform) all 16 rows exist
+    if (lr < nb) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) G[cb + 4 * v * ld] = acc[v];
+      for (int v = 0; v < 4; ++v) sm[cb + 4 * v * ld] = acc[v];
     }
   } else {
-    const int rl = lr < nbw ? B - i0 - lk : 0;
+    const int rl = lr < nb ? B - k0 - lk : 0;
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      if (4 * v < rl) G[cb + 4 * v * ld] = acc[v];
+      if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
   }
 }
 
@@ -376,6 +403,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #ifdef BA_BCR_PROFILE
   long long ph[4] = {0, 0, 0, 0};
 #endif
+  double pr[3] = {0.0, 0.0, 0.0};                           // wavefront 0: the first tile of the panel, handed from phase 2 to the next phase 1
+  bcr_acc4 cpre = {0.0, 0.0, 0.0, 0.0};                     // and the tile it updates there
 #pragma unroll 1
   for (int kb = 0; kb < NBLK; ++kb) {
     const int k0 = 12 * kb;
@@ -411,7 +440,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
     };
     if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
-      if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
+      if (kb > 0) { bcr_urgent_tile0(sm, ld, B, k0, nb, lr, lk, pr, cpre); lds_wave_sync(); }
       if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
       else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
       __builtin_amdgcn_s_setprio(0);
@@ -498,7 +527,10 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
     const long long p1 = clock64();
 #endif
     // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
-    if (kn + 16 * wave < B) bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk);      // (nb == 12 here; at most 4 tiles)
+    if (kn + 16 * wave < B) {                                // (nb == 12 here; at most 4 tiles)
+      if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
+      bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
+    }
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long p2 = clock64();
@@ -788,6 +820,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   constexpr int nct = (ncol + 15) >> 4;
   // late-update workers: the wavefronts of SIMDs 1..3 (wave % 4 != 0): 12 slots; SIMD 0 belongs to the pivot chain
   const int myslot = (wave & 3) ? wave - 1 - (wave >> 2) : -1;
+  double pr[3] = {0.0, 0.0, 0.0};                           // wavefront 0: the first tile of the panel, handed from phase 2 to the next phase 1
+  bcr_acc4 cpre = {0.0, 0.0, 0.0, 0.0};                     // and the tile it updates there
 #pragma unroll 1
   for (int kb = 0; kb < NBLK; ++kb) {
     const int k0 = 12 * kb;
@@ -821,8 +855,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     if (kb == 0) {
     } else if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
-      urgent_tile(0);                                       // the tile that holds this diagonal block: by the chain's own wavefront,
-      lds_wave_sync();                                      // no barrier between the update and the factor
+      bcr_urgent_tile0(sm, ld, B, k0, nb, lr, lk, pr, cpre);       // the tile that holds this diagonal block: by the chain's own
+      lds_wave_sync();                                      // wavefront, no barrier between the update and the factor
 #ifdef BA_BCR_PROFILE
       pst[5] += clock64() - q0;
 #endif
@@ -906,7 +940,10 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     pst[3] += q1 - q0;
 #endif
     // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
-    if (kn + 16 * wave < B) bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk);      // (nb == 12 here; at most 4 tiles)
+    if (kn + 16 * wave < B) {                                // (nb == 12 here; at most 4 tiles)
+      if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
+      bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
+    }
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long q2 = clock64();

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   constexpr int NBLK = (B + 11) / 12;
+  double pr[3] = {0.0, 0.0, 0.0};                           // wavefront 0: the first tile of the panel, handed from phase 2 to the next phase 1
+  bcr_acc4 cpre = {0.0, 0.0, 0.0, 0.0};                     // and the tile it updates there
 #pragma unroll 1
   for (int kb = 0; kb < NBLK; ++kb) {
     const int k0 = 12 * kb;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
       }
     };
     if (wave == 0) {
-      if (kb > 0) { urgent_tile(0); lds_wave_sync(); }
+      if (kb > 0) { bcr_urgent_tile0(sm, ld, B, k0, nb, lr, lk, pr, cpre); lds_wave_sync(); }
       double* Lv = Lvm + ((size_t)i * NBLK + kb) * 144;      // inverse of this diagonal block, [12][12], zero padded, for k_bcrw_solve_mfma
       if (nb == 12) {
         bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Li, Idt);
@@ -149,7 +151,10 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
     }
     __syncthreads();
     // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
-    if (kn + 16 * wave < B) bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li, lr, lk);      // (B <= 138: at most 8 tiles; nb == 12 here)
+    if (kn + 16 * wave < B) {                                // (B <= 138: at most 8 tiles; nb == 12 here)
+      if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
+      bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li, lr, lk, pr);
+    }
     __syncthreads();
   }
   if (*bad) {

@@ -112,7 +112,10 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
     }
     __syncthreads();
     // rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront (below a 6-unknown block: the right-hand side row)
-    for (int i0 = jn + 16 * wave; i0 < M; i0 += 256) bcr_panel_tile(G, ld, M, j0, i0, Li, lr, lk, nbi);
+    for (int i0 = jn + 16 * wave; i0 < M; i0 += 256) {
+      double pr[3];
+      bcr_panel_tile(G, ld, M, j0, i0, Li, lr, lk, pr, nbi);
+    }
     __syncthreads();
     if (jn < nb) {                                  // rank-12 update of the columns right of this block (nbi == 12 here)
       const int nct = (nb - jn + 15) >> 4;
