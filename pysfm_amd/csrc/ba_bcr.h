@@ -804,6 +804,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       }
     }
   }
+#ifdef BA_BCR_PROFILE
+  if (blockIdx.x == 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt0 - pst[0]);      // prologue, per wavefront
+#endif
   __syncthreads();
 
 #ifdef BA_BCR_PROFILE

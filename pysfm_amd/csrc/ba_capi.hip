@@ -1883,6 +1883,9 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
       fprintf(stderr, "[k_bcr_eliminate_split level 2 node 1 role %d] load %d prologue %d | diag factor (wave 0, with block 0 and the urgent tiles) %d, phase 1 %d, phase 2 %d, urgent tile 0 %d | last rhs %d, products+store %d cycles\n",
               role, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
     }
+    fprintf(stderr, "    prologue of role 0 per wavefront:");
+    for (int w = 0; w < 16; ++w) fprintf(stderr, " %d", inf6[44 + w]);
+    fprintf(stderr, "\n");
     fprintf(stderr, "    diagonal block 2 of role 0: loads %d, 12 pivots %d, stores of the inverse %d cycles\n", inf6[40], inf6[41], inf6[42]);
   } else
   if (h->opt.solve_trace && use_bcr)
