@@ -28,6 +28,9 @@
 // Build with -DBA_BCR_PROFILE (make PROFILE=1) to have node 2 of the first level write
 // its per-phase shader-cycle counts to info[8..12] (printed under BA_SOLVE_TRACE=1).
 #ifdef BA_BCR_PROFILE
+#ifndef BA_BCR_TRACE_KB
+#define BA_BCR_TRACE_KB 0      // per-wavefront stamps of the split kernel: 0 = the prologue, k > 0 = phase 1 of block step k
+#endif
 #define BA_STAMP(var) const long long var = clock64()
 #else
 #define BA_STAMP(var)
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     }
   }
 #ifdef BA_BCR_PROFILE
-  if (blockIdx.x == 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt0 - pst[0]);      // prologue, per wavefront
+  if (BA_BCR_TRACE_KB == 0 && blockIdx.x == 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt0 - pst[0]);      // prologue, per wavefront
 #endif
   __syncthreads();
 
@@ -823,6 +826,24 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   constexpr int nct = (ncol + 15) >> 4;
   // late-update workers: the wavefronts of SIMDs 1..3 (wave % 4 != 0): 12 slots; SIMD 0 belongs to the pivot chain
   const int myslot = (wave & 3) ? wave - 1 - (wave >> 2) : -1;
+  // the last nct of them own 16 columns of the right-hand sides each (none of the wavefronts 0..3, which compute the panel in phase 2)
+  const int rhs_ct = (myslot >= 12 - nct) ? 11 - myslot : -1;
+  const int rhs_col = 16 * (rhs_ct >= 0 ? rhs_ct : 0) + lr;
+  const bool rhs_cok = rhs_col < ncol;
+  int rhs_xst;
+  const int rhs_xoff = rhs_column(rhs_cok ? rhs_col : ncol - 1, rhs_xst);
+  mfma_acc racc[NBLK];                                      // all their block rows, in the accumulator layout of the matrix core
+#pragma unroll
+  for (int r = 0; r < NBLK; ++r) {
+    racc[r] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+    if (rhs_ct >= 0) {
+      const int ro = rhs_xoff + __mul24(12 * r + lk, rhs_xst), r4 = 4 * rhs_xst;
+      const bool six = 12 * r + 12 > B;                       // the 6-unknown block at the end: rows 6.. do not exist
+      racc[r][0] = sm[ro];
+      racc[r][1] = (!six || lk < 2) ? sm[(!six || lk < 2) ? ro + r4 : ro] : 0.0;
+      racc[r][2] = !six ? sm[!six ? ro + 2 * r4 : ro] : 0.0;
+    }
+  }
   double pr[3] = {0.0, 0.0, 0.0};                           // wavefront 0: the first tile of the panel, handed from phase 2 to the next phase 1
   bcr_acc4 cpre = {0.0, 0.0, 0.0, 0.0};                     // and the tile it updates there
 #pragma unroll 1
@@ -873,44 +894,54 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 #ifdef BA_BCR_PROFILE
       pst[2] += clock64() - q0;
 #endif
-    } else if (myslot >= 0) {
-      const double* Lp = Li + 192 * ((kb - 1) & 1);         // inverse of the previous diagonal block
+    } else if (rhs_ct >= 0) {
+      // Right-hand sides: this wavefront owns 16 columns of them and keeps ALL their block rows in registers (racc[r], as they
+      // leave the matrix core).  Step kb: finish block row kb-1, Y = L_pp^-1 racc[kb-1] (three MFMAs, stored in place), and take
+      // it out of every block row below, racc[r] -= L[r, kb-1] Y (three independent MFMAs per row; L[r, kb-1] = rows of panel
+      // kb-1) - all while wavefront 0 factors diagonal block kb, and well inside that time.  The form this replaces carried every
+      // remaining row of the right-hand sides through LDS at every step, which made LDS traffic, not the pivot chain, the
+      // length of phase 1 (4.5 k cycles against 3.0 k at the first step).
+      if (!(role == 2 && 16 * rhs_ct >= k0 && 16 * rhs_ct + 15 < ncol - 1)) {      // (identity columns right of block kb-1: Y is zero)
+        const double* Lp = Li + 192 * ((kb - 1) & 1);       // inverse of the previous diagonal block
+        const int kp = k0 - 12;
+        mfma_acc cur = racc[0];
+#pragma unroll
+        for (int r = 1; r < NBLK; ++r)
+          if (r == kb - 1) cur = racc[r];
+        mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + lk], cur[0], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 4 + lk], cur[1], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 8 + lk], cur[2], y, 0, 0, 0);
+        const int ro = rhs_xoff + __mul24(kp + lk, rhs_xst), r4 = 4 * rhs_xst;
+        if (rhs_cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+        const double ny0 = -y[0], ny1 = -y[1], ny2 = -y[2];
+#pragma unroll
+        for (int r = 1; r < NBLK; ++r) {
+          if (r >= kb) {                                       // (wave-uniform)
+            const int arow = 12 * r + lr < B ? 12 * r + lr : B - 1;      // rows past the end repeat the last one (results never used)
+            const int ao = arow * ld + kp + lk;
+            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], ny0, racc[r], 0, 0, 0);
+            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], ny1, racc[r], 0, 0, 0);
+            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], ny2, racc[r], 0, 0, 0);
+          }
+        }
+      }
+    } else if (myslot >= 0 && myslot < 12 - nct) {
       const int kp = k0 - 12;
       const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
       const int nsu = ((B - k0 + 15) >> 4) - 1;             // tiles of block column kb below the one wavefront 0 takes
-      for (int task = myslot; task < nct + ngt + nsu; task += 12) {
-        if (task >= nct + ngt) { urgent_tile(task - nct - ngt + 1); continue; }
-        int t0, t1, i00, co, cst;
-        bool cok, full;
-        double nb0, nb1, nb2;                                  // the NEGATED B operand of the three k-steps
-        if (task < nct) {
-          // the inverse role: columns of the identity right of block kp are still zero in rows kp..kp+11
-          if (role == 2 && 16 * task >= kp + 12 && 16 * task + 15 < ncol - 1) continue;
-          const int col = 16 * task + lr;
-          cok = col < ncol; full = 16 * task + 15 < ncol;
-          int xst;
-          const int xoff = rhs_column(cok ? col : ncol - 1, xst);
-          t0 = 0; t1 = (B - k0 + 15) >> 4; i00 = k0;
-          co = xoff + __mul24(lk, xst); cst = xst;
-          const int ro = xoff + __mul24(kp + lk, xst), r4 = 4 * xst;
-          mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + lk], sm[ro], y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
-          if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
-          nb0 = -y[0]; nb1 = -y[1]; nb2 = -y[2];
-        } else {
-          const int gtile = task - nct, c0 = kn + 16 * gtile;
-          t0 = gtile; t1 = (B - kn + 15) >> 4; i00 = kn;
-          cok = c0 + lr < B; full = c0 + 15 < B;
-          const int bo = (c0 + lr) * ld + kp + lk;
-          co = lk * ld + c0 + lr; cst = ld;
-          nb0 = -sm[bo]; nb1 = -sm[bo + 4]; nb2 = -sm[bo + 8];
-        }
-        const int c4 = 4 * cst;
-        int ao = (i00 + 16 * t0 + lr) * ld + kp + lk;          // A entry of this lane in the first tile
-        int cb = co + __mul24(i00 + 16 * t0, cst);             // first accumulator entry of this lane
-        int rows = B - (i00 + 16 * t0);                        // rows left from the top of the tile
+      for (int task = myslot; task < ngt + nsu; task += 12 - nct) {
+        if (task >= ngt) { urgent_tile(task - ngt + 1); continue; }
+        // lower tiles of D right of block column kb: C -= A B with K = 12, A = panel of block kp (16 rows of the tile), B = panel^T
+        const int gtile = task, c0 = kn + 16 * gtile;
+        const int t0 = gtile, t1 = (B - kn + 15) >> 4;
+        const bool cok = c0 + lr < B, full = c0 + 15 < B;
+        const int bo = (c0 + lr) * ld + kp + lk;
+        const int co = lk * ld + c0 + lr, c4 = 4 * ld;
+        const double nb0 = -sm[bo], nb1 = -sm[bo + 4], nb2 = -sm[bo + 8];      // the NEGATED B operand of the three k-steps
+        int ao = (kn + 16 * t0 + lr) * ld + kp + lk;           // A entry of this lane in the first tile
+        int cb = co + (kn + 16 * t0) * ld;                     // first accumulator entry of this lane
+        int rows = B - (kn + 16 * t0);                         // rows left from the top of the tile
         double a0 = sm[ao], a1 = sm[ao + 4], a2 = sm[ao + 8];
         mfma_acc acc = {sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
         for (int t = t0; t < t1; ++t) {
@@ -918,7 +949,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
           mfma_acc accc = acc;
           const int cbc = cb, rc = rows;
           if (t + 1 < t1) {                                    // the next tile's operands are in flight
-            ao += 16 * ld; cb += 16 * cst; rows -= 16;
+            ao += 16 * ld; cb += 16 * ld; rows -= 16;
             a0 = sm[ao]; a1 = sm[ao + 4]; a2 = sm[ao + 8];
             acc = mfma_acc{sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
           }
@@ -932,21 +963,29 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
             const int rl = cok ? rc - lk : 0;                  // rows v with 4 v < rl exist
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-              if (4 * v < rl) sm[cbc + v * c4] = accc[v];
+              if (4 * v < rl) sm[cbc + v * c4] = accc[v];      // (the strict upper part of diagonal tiles is never read)
           }
         }
       }
     }
+#ifdef BA_BCR_PROFILE
+    if (blockIdx.x == 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q0);      // phase 1 of one block step, per wavefront
+#endif
     if (kb > 0) __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long q1 = clock64();
     pst[3] += q1 - q0;
 #endif
     // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
-    if (kn + 16 * wave < B) {                                // (nb == 12 here; at most 4 tiles)
-      if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
-      bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
+    if (wave < 4) {
+      if (kn + 16 * wave < B) {                              // (nb == 12 here; at most 4 tiles)
+        if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
+        bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
+      }
     }
+#if defined(BA_BCR_PROFILE) && defined(BA_BCR_TRACE_PH2)
+    if (blockIdx.x == 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q1);      // phase 2 of one block step, per wavefront
+#endif
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long q2 = clock64();
@@ -956,27 +995,21 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 #ifdef BA_BCR_PROFILE
   const long long pt2 = clock64();
 #endif
-  if (myslot >= 0) {
-    // the last block row of the right-hand sides: Y = L_pp^-1 R_p (nothing below it)
+  if (rhs_ct >= 0) {
+    // the last block row of the right-hand sides: Y = L_pp^-1 racc[NBLK - 1] (nothing below it)
     constexpr int KL = 12 * (NBLK - 1), NL = B - KL;          // last block: start and size (12 or 6)
     const double* Ll = Li + 192 * ((NBLK - 1) & 1);         // inverse of the last diagonal block
-    for (int task = myslot; task < nct; task += 12) {
-      const int col = 16 * task + lr;
-      const bool cok = col < ncol;
-      int xst;
-      const int xoff = rhs_column(cok ? col : ncol - 1, xst);
-      const int ro = xoff + __mul24(KL + lk, xst), r4 = 4 * xst;
-      mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + lk], sm[ro], y, 0, 0, 0);
-      if (NL == 12) {
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], sm[ro + r4], y, 0, 0, 0);
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 8 + lk], sm[ro + 2 * r4], y, 0, 0, 0);
-        if (cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
-      } else {                                               // 6 rows: k = 4, 5 of the second step only
-        const double r1 = lk < 2 ? sm[ro + (lk < 2 ? r4 : 0)] : 0.0;
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], r1, y, 0, 0, 0);
-        if (cok) { sm[ro] = y[0]; if (lk < 2) sm[ro + r4] = y[1]; }
-      }
+    const mfma_acc cur = racc[NBLK - 1];
+    const int ro = rhs_xoff + __mul24(KL + lk, rhs_xst), r4 = 4 * rhs_xst;
+    mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+    y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + lk], cur[0], y, 0, 0, 0);
+    if (NL == 12) {
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], cur[1], y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 8 + lk], cur[2], y, 0, 0, 0);
+      if (rhs_cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+    } else {                                                 // 6 rows: k = 4, 5 of the second step only (what Ll holds beyond is finite)
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ll[lr * 12 + 4 + lk], lk < 2 ? cur[1] : 0.0, y, 0, 0, 0);
+      if (rhs_cok) { sm[ro] = y[0]; if (lk < 2) sm[ro + r4] = y[1]; }
     }
   }
   __syncthreads();
