@@ -76,6 +76,38 @@ __global__ __launch_bounds__(1024) void k_probe(const double* A, long long* out,
     for (int k = 0; k < 128; ++k) asm volatile("v_rsq_f64 %0, %0\n\ts_nop 0\n\tv_mul_f64 %0, %0, %1" : "+v"(x) : "v"(y));
     t1 = clock64();
     if (lane == 0) out[7] = (t1 - t0);
+    // v_mfma_f64_16x16x4_f64: one dependent chain, two and four interleaved chains (cycles per MFMA)
+    {
+      typedef double acc4 __attribute__((ext_vector_type(4)));
+      acc4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+      t0 = clock64();
+#pragma unroll
+      for (int k = 0; k < 64; ++k) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c0, 0, 0, 0);
+      asm volatile("" ::"v"(c0));
+      t1 = clock64();
+      if (lane == 0) out[10] = t1 - t0;
+      t0 = clock64();
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, c1, 0, 0, 0);
+      }
+      asm volatile("" ::"v"(c0), "v"(c1));
+      t1 = clock64();
+      if (lane == 0) out[11] = t1 - t0;
+      t0 = clock64();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, c3, 0, 0, 0);
+      }
+      asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));
+      t1 = clock64();
+      if (lane == 0) out[12] = t1 - t0;
+      if (c0[0] + c1[1] + c2[2] + c3[3] == 1234.5) out[9] = 3;
+    }
     if (a0 + a1 + a2 + a3 + x + z == 1234.5) out[9] = 2;
   }
 }
@@ -97,6 +129,8 @@ int main(int argc, char** argv) {
     printf("   dependent chains, cycles per instruction: v_fma_f64 %.1f, v_rsq_f64 %.1f, v_mov_b64_dpp (+ s_nop 1) %.1f, v_fmac_f64_dpp (+ s_nop 1) %.1f; "
            "independent v_fma_f64 %.1f; v_rsq_f64 -> v_mul_f64 pair %.1f\n",
            o[2] / 256.0, o[3] / 256.0, o[4] / 256.0, o[5] / 256.0, o[6] / 256.0, o[7] / 128.0);
+    printf("   v_mfma_f64_16x16x4_f64 from one wavefront, cycles per MFMA: one dependent chain %.1f, two interleaved %.1f, four interleaved %.1f\n",
+           o[10] / 64.0, o[11] / 64.0, o[12] / 64.0);
   }
   return 0;
 }
