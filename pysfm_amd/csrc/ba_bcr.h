@@ -908,21 +908,31 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 #pragma unroll
         for (int r = 1; r < NBLK; ++r)
           if (r == kb - 1) cur = racc[r];
+        // every operand of this step in ONE LDS round trip, before the first MFMA: the rows of panel kb-1 for all block rows
+        // (those above kb are fetched for nothing - cheaper than a round trip per row, which is what a branch per row compiles to)
+        const double l0 = Lp[lr * 12 + lk], l1 = Lp[lr * 12 + 4 + lk], l2 = Lp[lr * 12 + 8 + lk];
+        double a[NBLK > 1 ? NBLK - 1 : 1][3];
+#pragma unroll
+        for (int r = 1; r < NBLK; ++r) {
+          const int arow = 12 * r + lr < B ? 12 * r + lr : B - 1;        // rows past the end repeat the last one (results never used)
+          const int ao = arow * ld + kp + lk;
+          a[r - 1][0] = sm[ao]; a[r - 1][1] = sm[ao + 4]; a[r - 1][2] = sm[ao + 8];
+        }
+#pragma unroll
+        for (int r = 1; r < NBLK; ++r) asm volatile("" : "+v"(a[r - 1][0]), "+v"(a[r - 1][1]), "+v"(a[r - 1][2]));
         mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + lk], cur[0], y, 0, 0, 0);
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 4 + lk], cur[1], y, 0, 0, 0);
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 8 + lk], cur[2], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, cur[0], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, cur[1], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(l2, cur[2], y, 0, 0, 0);
         const int ro = rhs_xoff + __mul24(kp + lk, rhs_xst), r4 = 4 * rhs_xst;
         if (rhs_cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
         const double ny0 = -y[0], ny1 = -y[1], ny2 = -y[2];
 #pragma unroll
         for (int r = 1; r < NBLK; ++r) {
           if (r >= kb) {                                       // (wave-uniform)
-            const int arow = 12 * r + lr < B ? 12 * r + lr : B - 1;      // rows past the end repeat the last one (results never used)
-            const int ao = arow * ld + kp + lk;
-            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], ny0, racc[r], 0, 0, 0);
-            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], ny1, racc[r], 0, 0, 0);
-            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], ny2, racc[r], 0, 0, 0);
+            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][0], ny0, racc[r], 0, 0, 0);
+            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][1], ny1, racc[r], 0, 0, 0);
+            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][2], ny2, racc[r], 0, 0, 0);
           }
         }
       }
