@@ -372,7 +372,8 @@ def main():
     dom = max(cand, key=lambda k: cand[k]['ms']) if cand else 'schur_pairs'
     # timed region: only the dominant kernel keeps its events (an event pair costs a few
     # microseconds of stream time - bracketing all ~25 launches of a 0.3 ms step would slow it ~15 %)
-    be.enable_timing(not args.no_kernel_table, only=[dom], stride=4)     # every 4th step: the events themselves cost stream time
+    ev_stride = max(4, args.steps // 3)                 # (20 steps: steps 0, 6, 12, 18) - a sampled step costs ~45 us of stream and host time
+    be.enable_timing(not args.no_kernel_table, only=[dom], stride=ev_stride)
     sync()
     state['paths'] = {}
     t0 = time.time()
@@ -434,7 +435,7 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
                 'algorithmic_bytes_per_launch': B, 'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
-                'note': 'HIP events on the launch stream during the timed steps, every 4th step; back-to-back launches of one kernel '
+                'note': 'HIP events on the launch stream during the timed steps, every %d-th step; back-to-back launches of one kernel ' % ev_stride +
                         '(the cyclic-reduction levels) share one event pair, avg = elapsed / launches.  bound = what limits this kernel '
                         '(latency: a chain of dependent pivots, neither HBM nor the matrix cores); achieved / frac are priced against HBM'}
         if bound == 'mfma' and schur_ms:
