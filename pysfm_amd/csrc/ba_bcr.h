@@ -685,6 +685,44 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #endif
 __host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 560) * sizeof(double); }
 
+// Four independent 4 x 4 blocks of A^T Bm (all B rows of the two k-major operands) in one chain of v_mfma_f64_4x4x4_4b_f64
+// (tools/mfma4_probe.hip: lane 16 k + 4 b + i feeds A_b[i][k], lane 16 k + 4 b + j feeds B_b[k][j], D_b[i][j] comes out in
+// lane 16 i + 4 b + j; 17.5 cycles per instruction).  Block b = (lane >> 2) & 3 of this lane covers columns acol .. acol+3 of
+// A and bcol .. bcol+3 of Bm; returns the lane's entry, row acol + (lane >> 4), column bcol + (lane & 3), of the product.
+// For the edge strips of a B x B product when B is a few columns past a multiple of 16 (B = 54: 6): a 6-wide strip costs
+// two of these chains (2 x 14 x 17.5 cycles) per 16 columns, where the 16 x 16 x 4 form pays a whole tile (14 x 64).
+// Columns past the end of a row read the start of the next one: whatever is there only reaches entries nobody stores.
+template <int B>
+__device__ __forceinline__ double bcr_mfma4_blocks(const double* __restrict__ A, const double* __restrict__ Bm, int ld, int acol,
+                                                   int bcol, int lane) {
+  constexpr int KST = (B + 3) / 4;
+  const int kq = lane >> 4, m = lane & 3;
+  double ar[KST], br[KST];
+#pragma unroll
+  for (int ks = 0; ks < KST; ++ks) {
+    const int k = 4 * ks + kq;
+    const bool in = 4 * ks + 3 < B || k < B;                            // rows past B belong to the next matrix: feed zeros
+    const int kc = in ? k : 0;
+    const double a_ = A[kc * ld + acol + m], b_ = Bm[kc * ld + bcol + m];
+    ar[ks] = in ? a_ : 0.0; br[ks] = in ? b_ : 0.0;
+  }
+  double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+  for (int ks = 0; ks < KST; ks += 2) {
+    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[ks], br[ks], acc, 0, 0, 0);
+    if (ks + 1 < KST) acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[ks + 1], br[ks + 1], acc2, 0, 0, 0);
+  }
+  return acc + acc2;
+}
+// the edge of such a product in tasks of one chain each: q < NG * RB: rows of the edge (block row q % RB) x 16 columns (group
+// q / RB); then the same number for columns of the edge x 16 rows (with_right only); last the corner (2 x 2 blocks)
+__device__ __forceinline__ void bcr_edge_task(int q, int NG, int RB, bool with_right, int EB, int lane, int& acol, int& bcol) {
+  const int blk = (lane >> 2) & 3, nb = NG * RB;
+  if (q < nb) { acol = EB + 4 * (q % RB); bcol = 16 * (q / RB) + 4 * blk; }
+  else if (with_right && q < 2 * nb) { const int q2 = q - nb; acol = 16 * (q2 / RB) + 4 * blk; bcol = EB + 4 * (q2 % RB); }
+  else { acol = EB + 4 * (blk >> 1); bcol = EB + 4 * (blk & 1); }
+}
+
 template <int HB>
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, int s, double* __restrict__ Dm,
                                                                      const double* __restrict__ Um, double* __restrict__ fm,
@@ -777,12 +815,26 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     constexpr int NT = (B + 15) / 16, KST = (B + 3) / 4;
     const double* A = role == 0 ? Tb : Ta;
     const double* Bm = role == 0 ? Ta : Tb;
-    // 16 tiles on the 15 wavefronts that do not run the chain (measured against the 12 of SIMDs 1..3, which leave SIMD 0
-    // to the chain alone: 129.6 against 131.1 us for the seven levels - the product is bound by MFMA throughput, and
-    // three more wavefronts on SIMD 0 shorten it by more than they slow the first diagonal factor down)
+    // B a few columns past a multiple of 16 (54 = 48 + 6): the last tile row and column on v_mfma_f64_4x4x4 (bcr_mfma4_blocks),
+    // 13 chains of 245 cycles for what would be 7 tiles of 896; the 9 full tiles one per wavefront, the chains on the other six
+    constexpr int EB = 16 * (NT - 1), EE = B - EB, RB = (EE + 3) / 4;
+    constexpr bool kEdge4 = NT > 1 && EE <= 8 && BA_BCR_PRODUCT_WAVES == 15;
+    constexpr int NTF = kEdge4 ? NT - 1 : NT;                 // tile rows / columns done as 16 x 16 tiles
+    if (kEdge4) {
+      constexpr int NF = NTF * NTF, NS = 2 * NTF * RB + 1, base = NF < 15 ? NF : 0, nsw = 15 - base;
+      const int p = wave - 1;
+      if (p >= base)
+        for (int q = p - base; q < NS; q += nsw) {
+          int acol, bcol;
+          bcr_edge_task(q, NTF, RB, true, EB, lane, acol, bcol);
+          const double v = bcr_mfma4_blocks<B>(A, Bm, ld, acol, bcol, lane);
+          const int row = acol + (lane >> 4), col = bcol + (lane & 3);
+          if (row < B && col < B) R[row * ld + col] = -v;
+        }
+    }
     const int pslot = BA_BCR_PRODUCT_WAVES == 15 ? wave - 1 : ((wave & 3) ? wave - 1 - (wave >> 2) : -1);
-    for (int task = pslot; task >= 0 && task < NT * NT; task += BA_BCR_PRODUCT_WAVES) {
-      const int ti = task / NT, tj = task - ti * NT;
+    for (int task = pslot; task >= 0 && task < NTF * NTF; task += BA_BCR_PRODUCT_WAVES) {
+      const int ti = task / NTF, tj = task - ti * NTF;
       // all operands of the tile first (one LDS round trip), then the chain of MFMAs; two accumulators halve the chain
       double ar[KST], br[KST];
 #pragma unroll
@@ -1035,10 +1087,25 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   if (role < 2) {
     // ---- this role's neighbour update: D_nb -= R^T R (lower tiles), f_nb -= R^T g; R is kept for the back-substitution
     const int nbr = role == 0 ? l : r;
-    constexpr int NT = (B + 15) / 16, NSYM = NT * (NT + 1) / 2, KST = (B + 3) / 4;
+    constexpr int NT = (B + 15) / 16, KST = (B + 3) / 4;
+    constexpr int EB = 16 * (NT - 1), EE = B - EB, RB = (EE + 3) / 4;
+    constexpr bool kEdge4 = NT > 1 && EE <= 8;               // the last tile row as chains of v_mfma_f64_4x4x4 (see the prologue)
+    constexpr int NTF = kEdge4 ? NT - 1 : NT, NSYM = NTF * (NTF + 1) / 2;
+    if (kEdge4) {
+      constexpr int NS = NTF * RB + 1, base = NSYM < 16 ? NSYM : 0, nsw = 16 - base;
+      double* dst = Dm + (size_t)nbr * BB;
+      if (wave >= base)
+        for (int q = wave - base; q < NS; q += nsw) {
+          int acol, bcol;
+          bcr_edge_task(q, NTF, RB, false, EB, lane, acol, bcol);
+          const double v = bcr_mfma4_blocks<B>(R, R, ld, acol, bcol, lane);
+          const int row = acol + (lane >> 4), col = bcol + (lane & 3);
+          if (row < B && col <= row) atomic_add_f64(dst + (size_t)row * B + col, -v);
+        }
+    }
     for (int task = wave; task < NSYM; task += kBcrElimThreads / 64) {
       int ti, tj;
-      tri_decode(task, NT, tj, ti);                          // tj <= ti: D is only ever read in its lower triangle
+      tri_decode(task, NTF, tj, ti);                         // tj <= ti: D is only ever read in its lower triangle
       const double* A = R + 16 * ti + lr;
       const double* Bm = R + 16 * tj + lr;
       double ar[KST], br[KST];
@@ -1069,6 +1136,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       for (int k = 0; k < B; ++k) acc += R[k * ld + c] * g[k];
       atomic_add_f64(fm + (size_t)nbr * B + c, -acc);
     }
+#ifdef BA_BCR_PROFILE
+    if (BA_BCR_TRACE_KB == 99 && blockIdx.x == 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt3);      // products, per wavefront
+#endif
     double* out = (role == 0 ? Pm : Qm) + (size_t)i * BB;
     for (int e = tid; e < B * B; e += kBcrElimThreads) {
       const int rr = e / B, cc = e - rr * B;
