@@ -137,7 +137,10 @@ def test_results_do_not_depend_on_what_ran_before_on_the_handle(be):
                 ref[i] = out
                 continue
             assert out[0] == ref[i][0], (i, out[0], ref[i][0])
-            close(np.array([out[1]]), np.array([ref[i][1]]), 1e-9)
+            # the trial cost follows the solved update, whose last bits depend on the order the fp64 atomics of the reduced solve
+            # land in: the new points are compared to 1e-7 below, and a trial that overshoots (cost up by orders of magnitude:
+            # some draws do at damping 1e-3) amplifies that into the cost - seen once at 1.05e-9 in some fifty runs
+            close(np.array([out[1]]), np.array([ref[i][1]]), 1e-7)
             close(out[2], ref[i][2], 1e-12)
             close(out[3], ref[i][3], 1e-12)
             close(out[4], ref[i][4], 1e-7, atol=1e-12)
