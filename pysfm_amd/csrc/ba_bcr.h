@@ -164,16 +164,14 @@ __device__ __forceinline__ void bcr_identity_table(double* Idt, int tid) {
   if (tid < 156) Idt[tid] = (tid / 12 == tid % 12) ? 1.0 : 0.0;
 }
 
-template <int NB, bool KEEP_L>
-__device__ __forceinline__ void bcr_diag_block_regs(double (&cl)[NB], double* __restrict__ G, int ld, double* __restrict__ dinv,
-                                                    int* __restrict__ bad, int k0, int lane, double* __restrict__ Li,
-                                                    long long* trace = nullptr);
-
 template <int NB, bool KEEP_L = true>
 __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, double* __restrict__ dinv, int* __restrict__ bad,
                                                int k0, int lane, double* __restrict__ Li, const double* __restrict__ Idt,
                                                long long* trace = nullptr) {
   constexpr int NA = 16 - NB;                                           // identity columns per 16-lane row
+#ifdef BA_BCR_PROFILE
+  const long long tr0 = clock64();
+#endif
   const int i = lane & 15;
   const bool own = i < NB;
   const int c = own ? i : NB - 1;
@@ -184,22 +182,6 @@ __device__ __forceinline__ void bcr_diag_block(double* __restrict__ G, int ld, d
   double cl[NB];
 #pragma unroll
   for (int p = 0; p < NB; ++p) cl[p] = src[p];
-  bcr_diag_block_regs<NB, KEEP_L>(cl, G, ld, dinv, bad, k0, lane, Li, trace);
-}
-
-// ... the same from columns already in registers (bcr_urgent_to_chain)
-template <int NB, bool KEEP_L>
-__device__ __forceinline__ void bcr_diag_block_regs(double (&cl)[NB], double* __restrict__ G, int ld, double* __restrict__ dinv,
-                                                    int* __restrict__ bad, int k0, int lane, double* __restrict__ Li,
-                                                    long long* trace) {
-  constexpr int NA = 16 - NB;
-  const int i = lane & 15;
-  const bool own = i < NB;
-  const int c = own ? i : NB - 1;
-  const int j = (lane >> 4) * NA + (i - NB);
-#ifdef BA_BCR_PROFILE
-  const long long tr0 = clock64();
-#endif
   double di = 0.0;
 #ifdef BA_BCR_PROFILE
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -288,57 +270,6 @@ __device__ __forceinline__ void bcr_urgent_tile0(double* __restrict__ sm, int ld
 #pragma unroll
     for (int v = 0; v < 4; ++v)
       if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
-  }
-}
-
-// The same hand-over without LDS, for a 12-unknown block: the updated tile goes from the matrix core's accumulators straight
-// into the registers of the pivot chain.  The accumulator tile is fetched TRANSPOSED (lane (j, q) holds C[j][q + 4 v]: the
-// update X X^T is symmetric, so the same three MFMAs update it), which leaves row j of the block in the four lanes of
-// position j, three entries in each 16-lane row; v_permlane32_swap + v_permlane16_swap (tools/permlane_probe.hip) gather the
-// four rows, after which EVERY 16-lane row holds all twelve entries of its positions' rows - the replicated layout
-// bcr_diag_pivots works on.  Positions 12..15 (the first four rows of the next panel) store theirs, then become the
-// identity columns (idc: fetched from the table before the MFMAs).  36 cross-lane moves and 24 selects instead of 4 stores,
-// their drain, and 12 loads on the critical path of every block step.
-__device__ __forceinline__ bcr_acc4 bcr_prefetch_tile0_t(const double* __restrict__ sm, int ld, int B, int kn, int lr, int lk) {
-  const int row = kn + lr < B ? kn + lr : B - 1;
-  const int cb = row * ld + kn + lk;
-  return bcr_acc4{sm[cb], sm[cb + 4], sm[cb + 8], 0.0};
-}
-__device__ __forceinline__ void bcr_gather_rows(double x, double& y0, double& y1, double& y2, double& y3) {
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  unsigned w[2] = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)}, o[4][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const u2 s1 = __builtin_amdgcn_permlane32_swap(w[h], w[h], false, false);      // (x0 x1 x0 x1), (x2 x3 x2 x3) by 16-lane row
-    const u2 s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[0], false, false);    // (x0 x0 x0 x0), (x1 x1 x1 x1)
-    const u2 s3 = __builtin_amdgcn_permlane16_swap(s1[1], s1[1], false, false);
-    o[0][h] = s2[0]; o[1][h] = s2[1]; o[2][h] = s3[0]; o[3][h] = s3[1];
-  }
-  y0 = __hiloint2double((int)o[0][1], (int)o[0][0]); y1 = __hiloint2double((int)o[1][1], (int)o[1][0]);
-  y2 = __hiloint2double((int)o[2][1], (int)o[2][0]); y3 = __hiloint2double((int)o[3][1], (int)o[3][0]);
-}
-__device__ __forceinline__ void bcr_urgent_to_chain(double* __restrict__ sm, int ld, int B, int k0, int lane, const double (&pr)[3],
-                                                    bcr_acc4 acc, const double* __restrict__ Idt, double (&cl)[12]) {
-  const int lr = lane & 15, lk = lane >> 4;
-  const bool own = lr < 12;
-  const int ja = lk * 4 + (lr - 12);                                    // identity column of positions 12..15
-  const double* src = Idt + ((own || ja >= 12) ? 12 : ja) * 12;         // (row 12 of the table is zero)
-  double idc[12];
-#pragma unroll
-  for (int p = 0; p < 12; ++p) idc[p] = src[p];
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[0], -pr[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[1], -pr[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[2], -pr[2], acc, 0, 0, 0);
-  if (!own && k0 + lr < B) {                                            // rows k0+12 .. k0+15: the top of the next panel
-    const int cb = (k0 + lr) * ld + k0 + lk;
-    sm[cb] = acc[0]; sm[cb + 4] = acc[1]; sm[cb + 8] = acc[2];
-  }
-#pragma unroll
-  for (int v = 0; v < 3; ++v) {
-    double y0, y1, y2, y3;
-    bcr_gather_rows(acc[v], y0, y1, y2, y3);
-    cl[4 * v] = own ? y0 : idc[4 * v]; cl[4 * v + 1] = own ? y1 : idc[4 * v + 1];
-    cl[4 * v + 2] = own ? y2 : idc[4 * v + 2]; cl[4 * v + 3] = own ? y3 : idc[4 * v + 3];
   }
 }
 
@@ -1000,22 +931,17 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     if (kb == 0) {
     } else if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path of the node
-      // the tile that holds this diagonal block owes the previous panel one update: by the chain's own wavefront, from the
-      // registers it kept, and (12-unknown blocks) straight into the registers of the chain
-      if (nb == 12) {
-        double cl[12];
-        bcr_urgent_to_chain(sm, ld, B, k0, lane, pr, cpre, Idt, cl);
+      bcr_urgent_tile0(sm, ld, B, k0, nb, lr, lk, pr, cpre);       // the tile that holds this diagonal block: by the chain's own
+      lds_wave_sync();                                      // wavefront, no barrier between the update and the factor
 #ifdef BA_BCR_PROFILE
-        pst[5] += clock64() - q0;
-        bcr_diag_block_regs<12, false>(cl, G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), kb == 2 ? dtrace : nullptr);
-#else
-        bcr_diag_block_regs<12, false>(cl, G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1));
+      pst[5] += clock64() - q0;
 #endif
-      } else {
-        bcr_urgent_tile0(sm, ld, B, k0, nb, lr, lk, pr, cpre);
-        lds_wave_sync();
-        bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
-      }
+#ifdef BA_BCR_PROFILE
+      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt, kb == 2 ? dtrace : nullptr);
+#else
+      if (nb == 12) bcr_diag_block<12, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
+#endif
+      else bcr_diag_block<6, false>(G, ld, dinv, bad, k0, lane, Li + 192 * (kb & 1), Idt);
       __builtin_amdgcn_s_setprio(0);
 #ifdef BA_BCR_PROFILE
       pst[2] += clock64() - q0;
@@ -1115,7 +1041,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
     if (wave < 4) {
       if (kn + 16 * wave < B) {                              // (nb == 12 here; at most 4 tiles)
-        if (wave == 0) cpre = B - kn >= 12 ? bcr_prefetch_tile0_t(sm, ld, B, kn, lr, lk) : bcr_prefetch_tile0(sm, ld, kn, lr, lk);
+        if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
         bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
       }
     }
