@@ -535,7 +535,8 @@ def test_band_solver_vs_dense_lu(be):
         close(-be.backsubstitute(0), su, SOLVE)
 
 
-@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11), (400, 12), (300, 13), (500, 16), (400, 22), (97, 19), (300, 23), (260, 24)])
+@pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11), (400, 12), (300, 13), (500, 16), (400, 22), (97, 19), (300, 23), (260, 24),
+                                  (120, 4), (150, 6), (160, 8), (180, 9)])      # (with these every half-bandwidth 1..11 of the node kernels: 16 x 16 tiles with and without the 4 x 4 x 4 edge)
 def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
     """The multi-CU block-cyclic-reduction solve against the single-workgroup band Cholesky and
     the dense LU on the same device-resident system (odd sizes: padded last super-block,
