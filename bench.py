@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - LM-iteration throughput of the MI355X bundle-adjustment inner loop.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 20
     python bench.py --gpus 8                       # starts its own 8 ranks (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -222,7 +222,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=20,
+                    help='untimed trials before the timed ones (the first ~20 run 2-3 %% slower: clocks and caches settling)')
     ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument('--cams', type=int, default=None, help='override the number of cameras of the configuration')
     ap.add_argument('--pts-per-gpu', type=int, default=None, help='override: points per GPU (weak scaling)')
