@@ -1321,22 +1321,30 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, 
     xr[tid] = haveR ? bcr_wait_value(x + (size_t)r * B + tid) : 0.0;
   }
   __syncthreads();
-  for (int task = tid; task < 4 * B; task += kBcrElimThreads) {      // w -= P xl + Q xr
-    const int k = task >> 2, q4 = task & 3;
+  // the two matrix-vector products of a hand-over with 16 lanes per row (the whole workgroup busy for four terms each
+  // instead of a fifth of it for fourteen: every cycle here is on the chain of six dependent hand-overs)
+  for (int base = 0; base < 16 * B; base += kBcrElimThreads) {         // w -= P xl + Q xr
+    const int task = base + tid, kraw = task >> 4, q = task & 15;
+    const int k = kraw < B ? kraw : B - 1;                               // (rows past the end repeat the last: DPP sources must be live lanes)
     double acc = 0.0;
-    for (int c = q4; c < B; c += 4) acc += MP[k * ld + c] * xl[c] + MQ[k * ld + c] * xr[c];
+    for (int c = q; c < B; c += 16) acc += MP[k * ld + c] * xl[c] + MQ[k * ld + c] * xr[c];
     acc += dpp_pair<0xB1>(acc);
     acc += dpp_pair<0x4E>(acc);
-    if (q4 == 0) w[k] -= acc;
+    acc += dpp_pair<0x141>(acc);
+    acc += dpp_pair<0x140>(acc);
+    if (q == 0 && kraw < B) w[k] -= acc;
   }
   __syncthreads();
-  for (int task = tid; task < 4 * B; task += kBcrElimThreads) {      // x = (G^-1)^T w
-    const int m = task >> 2, q4 = task & 3;
+  for (int base = 0; base < 16 * B; base += kBcrElimThreads) {         // x = (G^-1)^T w
+    const int task = base + tid, mraw = task >> 4, q = task & 15;
+    const int m = mraw < B ? mraw : B - 1;
     double acc = 0.0;
-    for (int k = m + q4; k < B; k += 4) acc += MG[k * ld + m] * w[k];
+    for (int k = m + q; k < B; k += 16) acc += MG[k * ld + m] * w[k];
     acc += dpp_pair<0xB1>(acc);
     acc += dpp_pair<0x4E>(acc);
-    if (q4 == 0) __hip_atomic_store(x + (size_t)i * B + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc += dpp_pair<0x141>(acc);
+    acc += dpp_pair<0x140>(acc);
+    if (q == 0 && mraw < B) __hip_atomic_store(x + (size_t)i * B + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
