@@ -1249,12 +1249,18 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve(int N, int B,
 // forms x_i = G^-T (g - P x_l - Q x_r) and stores it.  The root was solved by its elimination kernel.
 // Six dependent launches of 4.7 us become one of ~2 us + 6 hand-overs.
 // --------------------------------------------------------------------------
-__device__ __forceinline__ double bcr_wait_value(const double* p) {
+constexpr int kBcrMaxSpins = 1 << 20;           // polls of ~1 us each
+constexpr int kBcrTimedOut = 0x7f000001;        // status word of a back-substitution that gave up waiting
+__device__ __forceinline__ double bcr_wait_value(const double* p, int* status) {
   // relaxed agent-scope polls of the DATA (write-through stores, cache-bypassing loads): one memory round trip per
   // hand-over.  Acquire loads / release fences here invalidate and write back whole L2s: 20 - 30 us per hand-over
   // with a hundred workgroups doing it at once (measured), and a separate ready flag costs a second round trip.
+  // The spin is bounded (about a second): whatever goes wrong upstream that nobody has thought of must end in a failed solve
+  // (status word > 0: the caller rejects the trial / falls back), not in a GPU that never comes back.  The "not yet" NaN this
+  // returns then turns into ordinary NaNs downstream, which nobody waits on.
   double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  while (__double_as_longlong(v) == kBcrNotYet) {
+  for (int spins = 0; __double_as_longlong(v) == kBcrNotYet; ++spins) {
+    if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
     __builtin_amdgcn_s_sleep(2);
     v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1317,8 +1323,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, 
   }
   // x_l, x_r from the nodes above, as soon as they are there (k_bcr_assemble marked every entry "not yet")
   if (tid < B) {
-    xl[tid] = haveL ? bcr_wait_value(x + (size_t)l * B + tid) : 0.0;
-    xr[tid] = haveR ? bcr_wait_value(x + (size_t)r * B + tid) : 0.0;
+    xl[tid] = haveL ? bcr_wait_value(x + (size_t)l * B + tid, ticket - kBcrTicketWord) : 0.0;
+    xr[tid] = haveR ? bcr_wait_value(x + (size_t)r * B + tid, ticket - kBcrTicketWord) : 0.0;
   }
   __syncthreads();
   // the two matrix-vector products of a hand-over with 16 lanes per row (the whole workgroup busy for four terms each
