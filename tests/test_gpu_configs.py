@@ -6,6 +6,7 @@ Tolerances as in test_gpu_parity.py (fp64 everywhere): blocks / S / b 1e-11 ... 
 solves 1e-8 ... 1e-9, LM trajectories 1e-6 (the north-star tolerance).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -483,3 +484,29 @@ def test_large_reduced_systems_follow_the_reference_lu_trajectory():
         close(np.array(ba.costs), np.array(ref['costs']), 1e-6)
         R, t, X = ref['R'], ref['t'], ref['X']
         ba.backend.close()
+
+
+@pytest.mark.gpu
+def test_bench_line_keeps_the_drivers_contract():
+    """`python bench.py` (small K / W) prints ONE JSON line as its last line of stdout with the keys the driver and the judge read:
+    the metric of BASELINE.json, whole-job value, the timing fields, `roofline` (with a live per-launch average and the committed
+    counter traffic) and `cpu_baseline` (the oracle timed on this box)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '3', '--windows', '1'],
+                         capture_output=True, text=True, timeout=500, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    base = json.load(open(os.path.join(root, 'BASELINE.json')))
+    assert d['metric'] == base['metric'] and d['unit'] == (base.get('unit') or d['unit'])
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 3 and d['higher_is_better'] is True
+    assert d['scaling'] in ('weak', 'strong') and d['vs_baseline'] is None and d['dtype'] == 'f64' and 'synthetic' in d['data']
+    assert isinstance(d['config'].get('workload'), str) and 'model' not in d['config']
+    assert d['value'] > 1e8 and abs(d['value'] - 1e6 * d['steps'] / (d['ms_per_step'] * 1e-3 * d['steps'])) / d['value'] < 1e-6
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma', 'latency') and r['unit'] in ('GB/s', 'TFLOP/s') and r['peak'] > 0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['avg_launch_ms'] > 0 and r['launches'] > 0
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and isinstance(c['sample'], str) and c['unit'] == d['unit']
