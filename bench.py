@@ -214,6 +214,170 @@ def spawn_ranks(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def make_trial_runner(ba, be):
+    """One LM trial per call, continuing the LM schedule (damping x0.1 on acceptance, x10 on rejection; restarted when exhausted)."""
+    from pysfm_amd._capi import PARAMS_CUR
+    one_trial, state = make_trial_runner(ba, be)
+    if args.pmc_child:
+        # the run rocprofv3 --pmc wraps (live_pmc_traffic): a few complete trials, nothing printed
+        for _ in range(max(1, args.warmup) + max(1, args.steps)):
+            one_trial()
+        torch.cuda.synchronize()
+        be.close()
+        return
+    return one_trial, state
+
+
+def scene_variant(s, track_len, shuffle, drop):
+    """The generator's scene with a fraction of its observations dropped at random (every track keeps two) and / or
+    its tracks renumbered and its observations permuted at random."""
+    obs_cam, obs_pt, obs_z, X0 = s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0']
+    nt = len(X0)
+    if drop > 0:                                   # ragged tracks: points no longer share their camera lists
+        rs = np.random.RandomState(11)
+        keep = rs.rand(len(obs_cam)) >= drop
+        keep[::track_len] = True
+        keep[1::track_len] = True
+        obs_cam, obs_pt, obs_z = obs_cam[keep], obs_pt[keep], obs_z[keep]
+    if shuffle:                                    # tracks renumbered at random, observations in random order
+        rs = np.random.RandomState(7)
+        new_id = rs.permutation(nt)                # track k becomes track new_id[k]
+        X0 = np.empty_like(s['X0'])
+        X0[new_id] = s['X0']
+        o = rs.permutation(len(obs_cam))
+        obs_cam, obs_pt, obs_z = obs_cam[o], new_id[obs_pt[o]].astype(np.int32), obs_z[o]
+    return obs_cam, obs_pt, obs_z, X0
+
+
+PASS_KERNELS = ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs')
+OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
+    ('config2', 2, 'gaussian', 0., False, 0.),
+    ('config4_huber', 4, 'huber', .1, False, 0.),
+    ('config4_cauchy', 4, 'cauchy', .1, False, 0.),
+    ('config3_shuffled', 3, 'gaussian', 0., True, 0.),
+    ('config3_30pct_dropped', 3, 'gaussian', 0., False, .3),
+    ('config5_one_gpu', 5, 'gaussian', 0., False, 0.),
+]
+
+
+def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, steps=20, warmup=8, scene_cache=None):
+    """`other_configs`: a short run of one of the other BASELINE configurations / scene shapes on this GPU, the same
+    complete LM trial per step, timed the same way (no events in the timed window; the per-kernel numbers come from
+    bracketed trials before it)."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    from pysfm_amd import synthetic_data as sd
+    import torch
+    cfg = CONFIGS[cfg_id]
+    nc, nt = cfg['cams'], cfg['points']
+    init_mode = 'pose' if cfg_id == 5 else 'params'
+    key = (nc, nt, outliers, init_mode)
+    if scene_cache is not None and key in scene_cache:
+        s = scene_cache[key]
+    else:
+        s = sd.generate_banded_scene(nc, nt, outlier_frac=outliers, init_mode=init_mode)
+        if scene_cache is not None:
+            scene_cache.clear()                     # (one scene at a time: config 5 is 400 MB of host arrays)
+            scene_cache[key] = s
+    obs_cam, obs_pt, obs_z, X0 = scene_variant(s, 10, shuffle, drop)
+    model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
+             'huber': sensor_model.HuberModel(.06)}[sensor_name]
+    bundle = Bundle.FromObservations(s['K'], s['R0'], s['t0'], X0, obs_cam, obs_pt, obs_z, sensor_model=model)
+    ba = BundleAdjuster(device=device, verbose=False)
+    t0 = time.time()
+    ba.set_bundle(bundle)
+    t_setup = time.time() - t0
+    be = ba.backend
+    one_trial, state = make_trial_runner(ba, be)
+    one_trial()                                     # lazy code-object loading
+    be.enable_timing(True)
+    be.timings(reset=True)
+    for _ in range(warmup):
+        one_trial()
+    tm = {k: v for k, v in be.timings(reset=True).items() if v['launches'] > 0}
+    be.enable_timing(False)
+    torch.cuda.synchronize()
+    state['paths'] = {}
+    t0 = time.time()
+    for _ in range(steps):
+        one_trial()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    nobs = len(obs_cam)
+    dom = max(tm, key=lambda k: tm[k]['ms']) if tm else None
+    kms = {k: v['ms'] / warmup for k, v in tm.items()}
+    pass_ms = sum(kms[k] for k in PASS_KERNELS if k in kms)
+    info = be.problem_info()
+    out = {'workload': 'BASELINE configs[%d]: %d cameras / %d points / %d observations, %s sensor model%s%s%s' % (
+               cfg_id - 1, nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
+               ', tracks and observations in random order' if shuffle else '',
+               ', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * drop) if drop else ''),
+           'init_mode': init_mode, 'steps': steps, 'warmup': warmup + 1, 'ms_per_step': 1e3 * dt / steps, 'obs_per_s': nobs * steps / dt,
+           'dominant_kernel': None if dom is None else KERNEL_NAMES.get(dom, 'k_' + dom), 'dominant_kernel_ms_per_step': None if dom is None else kms[dom],
+           'kernel_ms_per_step': kms, 'linearise_schur_pass_ms': pass_ms,
+           'linearise_schur_pass_fraction_of_kernel_time': pass_ms / max(1e-12, sum(kms.values())),
+           'obs_jacobians_per_s': nobs / max(1e-9, pass_ms * 1e-3),
+           'schur_kernel': info.get('schur_kernel'), 'half_bandwidth': be.half_bandwidth, 'solve_kind': getattr(be, 'last_solve_kind', None),
+           'trials_by_solver_and_outcome': dict(state['paths']), 'set_bundle_s': t_setup}
+    be.close()
+    return out
+
+
+def live_pmc_traffic(argv, kernels, timeout_s=150):
+    """`roofline.traffic` measured in THIS run: two rocprofv3 passes of this same command (`--pmc FETCH_SIZE`, then
+    `--pmc WRITE_SIZE`: the two do not fit one pass; counters only, no trace domains), a few trials each, and per kernel
+    HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section: KB units, and on gfx950
+    FETCH_SIZE reads half of a wide coalesced stream).  Returns ({timer id: bytes per launch}, note); ({}, reason) when
+    rocprofv3 is absent or a pass fails - the caller then falls back to the committed summary and says so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return {}, 'rocprofv3 not on PATH'
+    tmp = tempfile.mkdtemp(prefix='ba_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    agg = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--', sys.executable,
+                   os.path.abspath(__file__)] + argv + ['--pmc-child']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, 'rocprofv3 --pmc %s failed (rc %d): %s' % (counter, r.returncode, (r.stderr or r.stdout)[-300:])
+            for row in csv.DictReader(open(files[0])):
+                if row.get('Counter_Name') != counter:
+                    continue
+                name = row['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0].split('::')[-1]
+                a = agg.setdefault(name, {'FETCH_SIZE': 0., 'WRITE_SIZE': 0., 'n': 0})
+                a[counter] += float(row['Counter_Value'])
+                if counter == 'FETCH_SIZE':
+                    a['n'] += 1
+    except Exception as e:          # a time-out, a parse error: the bench line must still come out
+        return {}, 'live PMC pass failed: %r' % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for timer, names in kernels.items():
+        for name in names:
+            if name in agg and agg[name]['n'] > 0:
+                a = agg[name]
+                out[timer] = int((2 * a['FETCH_SIZE'] + a['WRITE_SIZE']) / a['n'] * 1024)
+                break
+    return out, 'live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command inside this run'
+
+
+# timer id -> kernel names (without template arguments) that run under it, most specific first
+PMC_KERNEL_NAMES = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
+                    'linearize': ['k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
+                    'point_invert': ['k_point_invert_schur_init', 'k_point_invert'],
+                    'bcr_eliminate': ['k_bcr_eliminate_fused', 'k_bcr_eliminate_split', 'k_bcr_eliminate'],
+                    'bcr_backsolve': ['k_bcr_backsolve_fused', 'k_bcr_backsolve'], 'bcr_assemble': ['k_bcr_assemble'],
+                    'camera_blocks': ['k_camera_blocks'], 'cost': ['k_cost'], 'schur_init': ['k_schur_init']}
+
+
 CONFIGS = {2: dict(cams=100, points=10000), 3: dict(cams=1000, points=100000),
            4: dict(cams=1000, points=100000, sensor='huber', outliers=.1), 5: dict(cams=10000, points=1000000, strong=True)}
 
@@ -242,6 +406,13 @@ def main():
     ap.add_argument('--no-kernel-table', action='store_true',
                     help='no HIP events at all in the timed region (for external kernel traces); roofline uses the warm-up timings')
     ap.add_argument('--no-lm', action='store_true', help='skip the untimed full optimize() that yields the RMSE')
+    ap.add_argument('--init-mode', default=None, choices=['params', 'pose'],
+                    help="initial guess of the scene generator: 'params' = Camera.perturb on the raw parameters (SURVEY 8d / the "
+                         "reference's test_bundle.py:165-167; default for configs 2-4), 'pose' = the camera turned about its own "
+                         "centre (default for config 5, where 'params' throws cameras 20 units off and no LM run recovers)")
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other configurations (`other_configs`)')
+    ap.add_argument('--no-live-pmc', action='store_true', help='do not run the two rocprofv3 --pmc passes that measure `roofline.traffic` live')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)       # the run rocprofv3 wraps: a few trials, no JSON line
     args = ap.parse_args()
     global PMC_WORKLOAD
     plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations
@@ -283,21 +454,9 @@ def main():
     nt = cfg['points'] if strong else (args.pts_per_gpu or cfg['points']) * ngpus
     sensor_name = args.sensor or cfg.get('sensor', 'gaussian')
     outliers = cfg.get('outliers', 0.) if args.outliers is None else args.outliers
-    s = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers)
-    obs_cam, obs_pt, obs_z, X0 = s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0']
-    if args.drop_observations > 0:                 # ragged tracks: points no longer share their camera lists
-        rs = np.random.RandomState(11)
-        keep = rs.rand(len(obs_cam)) >= args.drop_observations
-        keep[::args.track_len] = True
-        keep[1::args.track_len] = True
-        obs_cam, obs_pt, obs_z = obs_cam[keep], obs_pt[keep], obs_z[keep]
-    if args.shuffle_points:                        # tracks renumbered at random, observations in random order
-        rs = np.random.RandomState(7)
-        new_id = rs.permutation(nt)                # track k becomes track new_id[k]
-        X0 = np.empty_like(s['X0'])
-        X0[new_id] = s['X0']
-        o = rs.permutation(len(obs_cam))
-        obs_cam, obs_pt, obs_z = obs_cam[o], new_id[obs_pt[o]].astype(np.int32), obs_z[o]
+    init_mode = args.init_mode or ('pose' if args.config == 5 else 'params')
+    s = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers, init_mode=init_mode)
+    obs_cam, obs_pt, obs_z, X0 = scene_variant(s, args.track_len, args.shuffle_points, args.drop_observations)
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
     bundle = Bundle.FromObservations(s['K'], s['R0'], s['t0'], X0, obs_cam, obs_pt, obs_z, sensor_model=model)
@@ -337,26 +496,31 @@ def main():
                   lm_trials=int(ba.lm_trials), lm_converged=bool(ba.converged),
                   lm_cost_initial=ba.costs[0], lm_cost_final=ba.costs[-1], lm_wall_s=lm_wall,
                   lm_cholesky_rejections=int(getattr(ba, 'cholesky_rejections', 0)))
+        if comm is None and nt <= 150000 and args.init_mode is None and not args.pmc_child:
+            # the same LM run from the generator's other initial guess (round 1 / SURVEY 8d used 'params', round 2 'pose')
+            other = 'pose' if init_mode == 'params' else 'params'
+            s2 = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers, init_mode=other)
+            oc2, op2, oz2, X02 = scene_variant(s2, args.track_len, args.shuffle_points, args.drop_observations)
+            ba.set_bundle(Bundle.FromObservations(s2['K'], s2['R0'], s2['t0'], X02, oc2, op2, oz2, sensor_model=model))
+            ba.optimize(max_steps=25)
+            e2 = ba.backend.eval_observations(PARAMS_CUR, e=True, r=False, Jc=False, Jp=False)['e']
+            lm['lm_other_start'] = dict(init_mode=other, final_reproj_rmse=float(np.sqrt(np.sum(e2 * e2) / len(e2))), lm_steps=ba.num_steps,
+                                        lm_trials=int(ba.lm_trials), lm_converged=bool(ba.converged), lm_cost_initial=ba.costs[0],
+                                        lm_cost_final=ba.costs[-1])
+            del s2
         # restart from the initial guess for the timed trials
         ba.set_bundle(bundle, track_ids=track_ids)
         be = ba.backend
 
     # ---- timed region: K complete LM trials, continuing the LM schedule
-    state = dict(damping=10., cur=None, paths={})
-
-    def one_trial():
-        if state['cur'] is None:
-            state['cur'] = ba._cost(PARAMS_CUR)
-        accepted, nxt = ba.trial(state['damping'], None, state['cur'])
-        key = '%s/%s' % (getattr(be, 'last_solve_path', '?'), 'accepted' if accepted else ('rejected' if accepted is not None else 'ill-conditioned'))
-        state['paths'][key] = state['paths'].get(key, 0) + 1
-        if accepted:
-            state['damping'] *= .1
-            state['cur'] = nxt
-        else:
-            state['damping'] *= 10.
-        if state['damping'] >= 1e8 or state['damping'] < 1e-12:      # schedule exhausted: restart it
-            state['damping'] = 10.
+    one_trial, state = make_trial_runner(ba, be)
+    if args.pmc_child:
+        # the run rocprofv3 --pmc wraps (live_pmc_traffic): a few complete trials, nothing printed
+        for _ in range(max(1, args.warmup) + max(1, args.steps)):
+            one_trial()
+        torch.cuda.synchronize()
+        be.close()
+        return
 
     # warm-up with every kernel bracketed by HIP events: finds the dominant kernel
     be.enable_timing(True)
@@ -426,7 +590,30 @@ def main():
         avg_ms = tm_dom['ms'] / max(1, tm_dom['launches'])
         B = ab(dom)
         achieved = B / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom)
+        # HBM traffic of the kernels from the PMC counters: measured live (two rocprofv3 --pmc passes of this same
+        # workload, a few trials each) when rocprofv3 is there; else from the newest committed summary of this workload,
+        # flagged as possibly stale
+        live, live_note = {}, 'not attempted (--no-live-pmc, N > 1, or a communicator attached)'
+        if ngpus == 1 and comm is None and not args.no_live_pmc:
+            child = ['--config', str(args.config), '--track-len', str(args.track_len), '--steps', '4', '--warmup', '2', '--windows', '0',
+                     '--no-lm', '--no-cpu-baseline', '--no-other-configs', '--no-live-pmc', '--init-mode', init_mode]
+            child += ['--cams', str(args.cams)] if args.cams else []
+            child += ['--pts-per-gpu', str(args.pts_per_gpu)] if args.pts_per_gpu else []
+            child += ['--shuffle-points'] if args.shuffle_points else []
+            child += ['--drop-observations', str(args.drop_observations)] if args.drop_observations else []
+            child += ['--sensor', args.sensor] if args.sensor else []
+            child += ['--outliers', str(args.outliers)] if args.outliers is not None else []
+            for kv in args.option:
+                child += ['--option', kv]
+            t_pmc = time.time()
+            live, live_note = live_pmc_traffic(child, PMC_KERNEL_NAMES)
+            live_note += ' (%.0f s)' % (time.time() - t_pmc)
+
+        def traffic_of(k):
+            if k in live:
+                return live[k], 'live'
+            return pmc_traffic(k)
+        traffic, traffic_src = traffic_of(dom)
         copy_gbs = be.measure_copy_bandwidth()
         sflops = schur_flops(nobs_local, be.nt)
         # the whole reduction of one trial (one launch up to track length 13, two to four beyond: DESIGN.md)
@@ -434,6 +621,7 @@ def main():
         bound = KERNEL_BOUND.get(dom, 'hbm')
         roof = {'bound': bound, 'kernel': KERNEL_NAMES.get(dom, 'k_' + dom), 'timer': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                'traffic_stale_possible': bool(traffic is not None and traffic_src != 'live'), 'traffic_note': live_note,
                 'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
                 'algorithmic_bytes_per_launch': B, 'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
                 'note': 'HIP events on the launch stream during the timed steps, every %d-th step; back-to-back launches of one kernel ' % ev_stride +
@@ -447,7 +635,8 @@ def main():
         pass_kernels = [k for k in ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs') if k in ours]
         pass_ms = sum(ours[k]['ms'] for k in pass_kernels) / nprof
         pass_bytes = 20 * nobs_local + 96 * be.nc + 24 * be.nt + 96 * be.nt + 72 * be.nt + 288 * nco * (hb + 1) + 48 * nco
-        pass_traffic = [pmc_traffic(k)[0] for k in pass_kernels]
+        pass_traffic = [traffic_of(k)[0] for k in pass_kernels]
+        pass_traffic_live = all(k in live for k in pass_kernels)
         pass_traffic = sum(pass_traffic) if pass_traffic and all(t is not None for t in pass_traffic) else None
         out = {
             'metric': 'LM-iter throughput (obs/sec) + final reproj RMSE, 1k-cam/100k-pt/1M-obs scene',
@@ -467,7 +656,7 @@ def main():
                                       (', tracks and observations handed over in random order' if args.shuffle_points else '') +
                                       (', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * args.drop_observations) if args.drop_observations else '')),
                        'cameras': nc, 'points': nt, 'observations': nobs_total, 'track_len': args.track_len,
-                       'shuffled': bool(args.shuffle_points), 'parallelism': 'points sharded x%d' % ngpus,
+                       'init_mode': init_mode, 'shuffled': bool(args.shuffle_points), 'parallelism': 'points sharded x%d' % ngpus,
                        'library_options': args.option or None,
                        'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False)
                                                                  else 'torch.distributed (RCCL): ' + str(getattr(comm, 'direct_fallback_reason', None))),
@@ -477,6 +666,8 @@ def main():
                 'kernels': [KERNEL_NAMES.get(k, 'k_' + k) for k in pass_kernels], 'ms': pass_ms, 'algorithmic_bytes': pass_bytes,
                 'achieved_GBps': pass_bytes / max(1e-9, pass_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': pass_bytes / max(1e-9, pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'traffic': pass_traffic, 'traffic_over_algorithmic': None if pass_traffic is None else pass_traffic / pass_bytes,
+                'traffic_source': 'live' if pass_traffic_live else 'committed summary (possibly stale)',
+                'traffic_per_kernel': {k: traffic_of(k)[0] for k in ours},
                 'obs_jacobians_per_s': nobs_local / max(1e-9, pass_ms * 1e-3),
                 'note': 'bytes: observations 20/obs + cameras + points + point blocks and inverses (96 + 72 per point) + band S + b, each once; '
                         'W is never materialised'},
@@ -497,6 +688,19 @@ def main():
                                'timed_trials_by_solver_and_outcome': timed_paths},
         }
         out.update(lm)
+        plain3 = (args.config == 3 and args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
+                  and not args.drop_observations and not args.shuffle_points and args.sensor is None and args.outliers is None)
+        if ngpus == 1 and comm is None and plain3 and not args.no_other_configs:
+            # the other BASELINE configurations and scene shapes, a short run each on this same GPU (the headline handle is idle)
+            t_oc = time.time()
+            cache, oc = {}, {}
+            for spec in OTHER_CONFIGS:
+                try:
+                    oc[spec[0]] = quick_config(local_rank, *spec, scene_cache=cache)
+                except Exception as e:                     # one failing variant must not take the headline line with it
+                    oc[spec[0]] = {'error': repr(e)}
+            oc['wall_s'] = time.time() - t_oc
+            out['other_configs'] = oc
         if ngpus == 1 and not args.no_cpu_baseline:
             if nc <= 1500 and nt <= 150000:
                 out['cpu_baseline'] = cpu_baseline(s)

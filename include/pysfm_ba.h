@@ -222,6 +222,7 @@ int ba_set_dense_visibility(ba_handle* h, int32_t on);
  * -1 = too large for the device solvers (same fallback).
  * ba_last_solve_kind: which solver the last ba_solve_reduced launched. */
 enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY };
+#define BA_SOLVE_TIMED_OUT 0x7f000001   /* *info of a cyclic reduction whose workgroups gave up waiting for each other */
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);
 int ba_get_solution(ba_handle* h, double* dC /*[nco*6] host*/);

@@ -26,6 +26,7 @@ INFO_KEYS = ('points_permuted', 'obs_permuted', 'groups', 'mfma_groups', 'point_
              'half_bandwidth', 'schur_mfma', 'schur_groups', 'lds_window_rows', 'pair_units', 'schur_kernel',
              'mfma_points_per_batch_cap', 'mfma_k_rows')      # BA_INFO_*
 SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky')
+SOLVE_TIMED_OUT = 0x7f000001            # BA_SOLVE_TIMED_OUT of include/pysfm_ba.h
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -23,7 +23,10 @@ DEVICE_CHOLESKY_MAX_UNKNOWNS = 16000   # (= kDcMaxN of ba_dense.h)
 # (it happens at the noise floor, when the damping has decayed to ~1e-10 and the free scale of a monocular
 # reconstruction makes S numerically singular; at 1000 cameras every such LU costs 70 ms = 200 trials).
 LU_FALLBACK_MAX_UNKNOWNS = 2048
-DENSE_MIN_HALF_BANDWIDTH = 21     # (= kMaxBandSolve: beyond it the solve is dense anyway)
+# the dense-visibility REDUCTION (ba_set_dense_visibility) is worth it once the band is this wide; it does not decide the
+# solver: half-bandwidths up to 23 (kBcrwMaxHB of ba_bcr_wide.h) still go through the wide cyclic reduction, the dense
+# blocked Cholesky takes over beyond
+DENSE_MIN_HALF_BANDWIDTH = 21
 DENSE_MIN_FILL = 0.25             # observed fraction of the (camera, track) pairs
 DENSE_MAX_BYTES = 2 << 30         # of the staged operand
 
@@ -263,7 +266,7 @@ class HipBackend(object):
         the device for backsubstitute(); get_solution() fetches it.
         Path 1 (last_solve_path 'band' / 'dense_cholesky', last_solve_kind says which kernel
         family): Cholesky on the device inside ba_solve_reduced - block cyclic reduction for
-        block half-bandwidths up to 21, a dense blocked Cholesky beyond.  Path 2 ('dense'),
+        block half-bandwidths up to 23 (one kernel per level up to 11, three beyond), a dense blocked Cholesky beyond.  Path 2 ('dense'),
         when the system is not positive definite or has more than 16000 unknowns: LU of the
         flattened system, the reference's own factorisation (numpy.linalg.solve = gesv,
         bundle_adjuster.py:303), here rocSOLVER through torch.linalg.solve_ex - on the GPU as
@@ -277,7 +280,11 @@ class HipBackend(object):
         self._note_solve(info.value)
         if info.value == 0:
             return
-        if info.value > 0 and n > self.lu_fallback_max_unknowns:
+        if info.value == capi.SOLVE_TIMED_OUT:
+            import warnings
+            warnings.warn('pysfm_amd: the device solve of the reduced system timed out (status 0x%x): a solver fault, '
+                          'not a property of the matrix; solving through LU' % info.value, RuntimeWarning)
+        elif info.value > 0 and n > self.lu_fallback_max_unknowns:
             raise ReducedSystemSingular
         keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
         dC = np.zeros(n)

@@ -25,8 +25,8 @@ from copy import copy
 
 import numpy as np
 
-from ._capi import PARAMS_CUR, PARAMS_TRIAL
-from .backend import ReducedSystemSingular
+from ._capi import PARAMS_CUR, PARAMS_TRIAL, SOLVE_TIMED_OUT as SOLVER_TIMED_OUT
+from .backend import LU_FALLBACK_MAX_UNKNOWNS, ReducedSystemSingular
 from .sensor_model import device_params_of
 
 
@@ -138,9 +138,11 @@ class BundleAdjuster(object):
         return R, t, X
 
     def _upload(self, bundle, which):
-        self.backend.set_params(which, *self._params_of(bundle))
+        params = self._params_of(bundle)
+        self.backend.set_params(which, *params)
         if which == PARAMS_CUR:
             self._cur_cost = None                    # cached cost of the current set
+            self._uploaded_cur = params              # what the device's current set holds (compute_cost compares)
 
     # ------------------------------------------------------------------ set_bundle
     def set_bundle(self, bundle, camera_ids=None, track_ids=None, camera_mask=None, track_mask=None):
@@ -295,7 +297,9 @@ class BundleAdjuster(object):
             self._have_blocks = True
             if info == 0:
                 next_cost = cost
-            elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', 0):
+            elif info == SOLVER_TIMED_OUT:
+                self._note_solver_timeout(damping)                 # a solver bug, not a property of the system: said loudly,
+            elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):     # the stepwise path below solves again
                 self._note_ill_conditioned(be, damping)
                 return None, None                              # not positive definite, too large for LU: ill-conditioned
         elif self._comm is not None and hasattr(be, 'lm_trial_begin'):
@@ -317,7 +321,9 @@ class BundleAdjuster(object):
                     raise np.linalg.LinAlgError('singular 3x3 point block(s) in plain-inverse mode')
                 if info == 0:
                     next_cost = cost
-                elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', 0):
+                elif info == SOLVER_TIMED_OUT:
+                    self._note_solver_timeout(damping)
+                elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):
                     self._note_ill_conditioned(be, damping)
                     return None, None
         if next_cost is None:
@@ -346,6 +352,16 @@ class BundleAdjuster(object):
             self._say('reduced system (%d unknowns) not positive definite at damping %g: reported as ill-conditioned '
                       '(LU fallback only up to %s unknowns)' % (be.nco * 6, damping, getattr(be, 'lu_fallback_max_unknowns', 0)))
 
+    def _note_solver_timeout(self, damping):
+        """A workgroup of the one-launch cyclic reduction gave up waiting for its neighbours (status word
+        BA_SOLVE_TIMED_OUT of include/pysfm_ba.h): that is a fault of the solver or of the GPU, never a property of
+        the matrix - it must not hide behind a damping increase.  Counted and always reported; the trial is then
+        repeated through the stepwise entry points."""
+        import warnings
+        self.solver_timeouts = getattr(self, 'solver_timeouts', 0) + 1
+        warnings.warn('pysfm_amd: the device solve of the reduced system timed out at damping %g (status 0x%x); '
+                      'repeating the trial stepwise' % (damping, SOLVER_TIMED_OUT), RuntimeWarning)
+
     # ------------------------------------------------------------------ cost
     def _cost(self, which):
         c = self.backend.cost(which)
@@ -360,9 +376,15 @@ class BundleAdjuster(object):
         # when it IS that bundle: the caller's object, not stale (no step accepted since it was uploaded).  It is
         # uploaded again even then - the caller may have edited it in place (cameras[i].perturb, transform).
         if bundle is self._host_bundle and not self._host_stale:
-            self._upload(bundle, PARAMS_CUR)
-            self._have_blocks = False
-            self._blocks_cache = None
+            # ... but only if it differs from what was uploaded last: prepare_schur_complement() -> compute_cost(ba.bundle)
+            # -> compute_schur_complement() is a sequence the reference allows, and an unchanged bundle must not
+            # throw the device's linearisation away
+            up = getattr(self, '_uploaded_cur', None)
+            params = self._params_of(bundle)
+            if up is None or any(a.shape != b.shape or not np.array_equal(a, b) for a, b in zip(params, up)):
+                self._upload(bundle, PARAMS_CUR)
+                self._have_blocks = False
+                self._blocks_cache = None
             return self._cost(PARAMS_CUR)
         self._upload(bundle, PARAMS_TRIAL)
         return self._cost(PARAMS_TRIAL)

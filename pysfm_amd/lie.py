@@ -5,7 +5,13 @@ a scene.  The adjuster itself never does: its parameter update is the
 ``k_apply_update`` HIP kernel (ba_math.h ``so3_exp``)."""
 import numpy as np
 
-from .algebra import skew
+
+
+def skew(m):
+    """The cross-product matrix [m]x of a 3-vector (algebra.py:51-56): skew(m) @ v == cross(m, v)."""
+    m = np.asarray(m, float)
+    assert m.shape == (3,)
+    return np.cross(m[None, :], -np.eye(3))
 
 
 class SO3(object):

@@ -10,8 +10,33 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+GPU_TEST_TIMEOUT_S = 600
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # hang protection of the GPU tests: pytest-timeout (tests/requirements.txt) - or, where that plugin is not installed,
+    # a SIGALRM of our own around every gpu test, so that the protection does not silently go away
+    config._ba_own_alarm = not config.pluginmanager.hasplugin('timeout')
+    if config._ba_own_alarm:
+        config.addinivalue_line('markers', 'timeout(seconds): per-test time limit (fallback implementation in tests/conftest.py)')
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    import signal
+    own = getattr(item.config, '_ba_own_alarm', False) and 'gpu' in item.keywords and hasattr(signal, 'SIGALRM')
+    if own:
+        def on_alarm(signum, frame):
+            raise TimeoutError('gpu test exceeded %d s (a kernel waiting for something that never comes?)' % GPU_TEST_TIMEOUT_S)
+        old = signal.signal(signal.SIGALRM, on_alarm)
+        signal.alarm(GPU_TEST_TIMEOUT_S)
+    try:
+        yield
+    finally:
+        if own:
+            signal.alarm(0)
+            signal.signal(signal.SIGALRM, old)
 
 
 def pytest_collection_modifyitems(config, items):
@@ -30,7 +55,7 @@ def pytest_collection_modifyitems(config, items):
         # a kernel that waits for something that never comes must fail a test, not hang the box (pytest-timeout)
         for item in items:
             if 'gpu' in item.keywords:
-                item.add_marker(pytest.mark.timeout(600))
+                item.add_marker(pytest.mark.timeout(GPU_TEST_TIMEOUT_S))
         return
     skip = pytest.mark.skip(reason='needs an MI355X (no GPU visible)')
     for item in items:
