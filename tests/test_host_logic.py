@@ -345,6 +345,46 @@ def test_compute_cost_evaluates_the_bundle_it_is_given_after_an_accepted_step():
     assert ba.compute_cost(cur) > ba.costs[-1]
 
 
+def test_compute_cost_of_the_unchanged_current_bundle_keeps_the_linearisation():
+    """round-3 ADVICE: prepare_schur_complement() -> compute_cost(ba.bundle) -> compute_schur_complement() is a sequence the
+    reference allows (its compute_cost touches no block array, bundle_adjuster.py:165-171).  An unchanged bundle must neither
+    trip 'call prepare_schur_complement() first' nor be uploaded again; an edited one is uploaded and invalidates the blocks."""
+    g = load_golden('scene_4x10_cauchy')
+    ba = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    uploads = []
+    orig = ba.backend.set_params
+    ba.backend.set_params = lambda which, *a: (uploads.append(which), orig(which, *a))[1]
+    ba.prepare_schur_complement()
+    ba.apply_damping(2.)
+    c = ba.compute_cost(ba.bundle)
+    assert uploads == [] and c == pytest.approx(float(g['l2_cost']), rel=1e-12)
+    S, b = ba.compute_schur_complement()                              # still linearised, still damped
+    close(S, g['l2_S'])
+    close(b, g['l2_b'])
+    cur = ba.bundle
+    cur.reconstruction[2] += .01                                       # edited in place: seen, uploaded, blocks gone
+    assert ba.compute_cost(cur) != pytest.approx(c, rel=1e-9) and uploads == [0]
+    with pytest.raises(AssertionError):
+        ba.compute_schur_complement()
+
+
+def test_solver_timeout_is_not_reported_as_ill_conditioned():
+    """round-3 ADVICE: status BA_SOLVE_TIMED_OUT of the one-launch cyclic reduction is a solver fault: warned about on its
+    own and the trial repeated stepwise - never folded into 'not positive definite' (a damping increase would hide it)."""
+    from pysfm_amd._capi import SOLVE_TIMED_OUT
+    g = load_golden('scene_5x50_gauss')
+    be = OracleBackend()
+    ba = BundleAdjuster(bundle_of(g), backend=be, verbose=False)
+    ref = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    be.lm_trial = lambda damping, rcond, mask=None: (SOLVE_TIMED_OUT, float('nan'))
+    be.lu_fallback_max_unknowns = 0                                     # (even with every non-SPD system declared ill-conditioned)
+    with pytest.warns(RuntimeWarning, match='timed out'):
+        ba.optimize(max_steps=2)
+    ref.optimize(max_steps=2)
+    assert ba.solver_timeouts >= 2 and getattr(ba, 'cholesky_rejections', 0) == 0
+    close(ba.costs, ref.costs)
+
+
 def test_block_properties_follow_the_latest_linearisation():
     """HCCs / HPPs / bCs / bPs / HCPs always reflect the last prepare_schur_complement / compute_update, as the
     reference's arrays do - also after a step moved the linearisation point (no stale cache, W on demand)."""
