@@ -217,14 +217,21 @@ def spawn_ranks(n):
 def make_trial_runner(ba, be):
     """One LM trial per call, continuing the LM schedule (damping x0.1 on acceptance, x10 on rejection; restarted when exhausted)."""
     from pysfm_amd._capi import PARAMS_CUR
-    one_trial, state = make_trial_runner(ba, be)
-    if args.pmc_child:
-        # the run rocprofv3 --pmc wraps (live_pmc_traffic): a few complete trials, nothing printed
-        for _ in range(max(1, args.warmup) + max(1, args.steps)):
-            one_trial()
-        torch.cuda.synchronize()
-        be.close()
-        return
+    state = dict(damping=10., cur=None, paths={})
+
+    def one_trial():
+        if state['cur'] is None:
+            state['cur'] = ba._cost(PARAMS_CUR)
+        accepted, nxt = ba.trial(state['damping'], None, state['cur'])
+        key = '%s/%s' % (getattr(be, 'last_solve_path', '?'), 'accepted' if accepted else ('rejected' if accepted is not None else 'ill-conditioned'))
+        state['paths'][key] = state['paths'].get(key, 0) + 1
+        if accepted:
+            state['damping'] *= .1
+            state['cur'] = nxt
+        else:
+            state['damping'] *= 10.
+        if state['damping'] >= 1e8 or state['damping'] < 1e-12:      # schedule exhausted: restart it
+            state['damping'] = 10.
     return one_trial, state
 
 

@@ -44,6 +44,8 @@ constexpr int kBcrThreads = 1024;                // assemble (111 nodes at confi
 constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
 constexpr int kBcrTicketWord = 61;             // info[61]: tickets of k_bcr_backsolve_fused (info = flags + 1, 64 flag words)
 constexpr long long kBcrNotYet = 0x7FFA5A5A5A5A5A5All;    // a NaN no computation produces: the mark of a solution entry that is not there yet
+constexpr int kBcrMaxSpins = 1 << 20;           // bounded waits of the one-launch kernels: polls of ~1 us each
+constexpr int kBcrTimedOut = 0x7f000001;        // status word of a workgroup that gave up waiting for another (BA_SOLVE_TIMED_OUT)
 constexpr int kBcrMaxHB = 11;                  // 4 matrices of B x (B+1) doubles must fit in LDS (B = 66: 145 KB)
 
 __host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 560) * sizeof(double); }   // + inverses of the current and the previous diagonal block, identity table
@@ -55,13 +57,15 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
                                                               const unsigned char* __restrict__ mask,
                                                               double* __restrict__ Dm, double* __restrict__ Um,
                                                               double* __restrict__ fm, int* __restrict__ info,
-                                                              double* __restrict__ xsol = nullptr) {
+                                                              double* __restrict__ xsol = nullptr, int* __restrict__ done = nullptr) {
   const int B = 6 * hb, hb1 = hb + 1;
   const int I = blockIdx.x;
   if (I == 0 && threadIdx.x == 0) {
     *info = 0;                                    // status word of this solve (the eliminate levels only ever set it)
     info[kBcrTicketWord] = 0;                     // ticket counter of k_bcr_backsolve_fused
+    info[kBcrTicketWord - 1] = 0;                 // ... and of k_bcr_eliminate_fused (kBcrElimTicketWord)
   }
+  if (done && threadIdx.x < 4) done[4 * I + threadIdx.x] = 0;      // "this (node, role) has handed its results on": not yet
   for (int e = threadIdx.x; e < B * B; e += kBcrThreads) {
     const int r = e / B, c = e - r * B;
     const int i = I * hb + r / 6, j = I * hb + c / 6, a = r % 6, bb = c % 6;
@@ -723,13 +727,32 @@ __device__ __forceinline__ void bcr_edge_task(int q, int NG, int RB, bool with_r
   else { acol = EB + 4 * (blk >> 1); bcol = EB + 4 * (blk & 1); }
 }
 
-template <int HB>
-__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, int s, double* __restrict__ Dm,
-                                                                     const double* __restrict__ Um, double* __restrict__ fm,
-                                                                     double* __restrict__ Pm, double* __restrict__ Qm,
-                                                                     double* __restrict__ Gi, double* __restrict__ gm,
-                                                                     int* __restrict__ info, double* __restrict__ xout) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+// What crosses workgroups INSIDE one launch (k_bcr_eliminate_fused: a level's outputs are the next level's inputs) goes
+// through relaxed agent-scope accesses, which bypass / write through the caches that are not coherent across the chip's
+// eight L2s; k_bcr_eliminate_split (one launch per level) uses plain ones.
+template <bool COHERENT>
+__device__ __forceinline__ double bcr_ld(const double* p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COHERENT>
+__device__ __forceinline__ void bcr_st(double* p, double v) {
+  if constexpr (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+#ifndef BA_BCR_STORE_FIRST
+#define BA_BCR_STORE_FIRST 1        // fused kernel: the factors P / Q leave for memory BEFORE the neighbour products (their latency rides under the MFMAs)
+#endif
+
+// One (node, role) of a split elimination level - the body of k_bcr_eliminate_split and of k_bcr_eliminate_fused.
+// `wait()` is called after the LDS set-up that needs no input and before the first global load (the fused kernel waits for
+// its producers there).  Returns false when D_i turned out not to be positive definite (status word set, nothing handed on).
+template <int HB, bool FUSED, typename Wait>
+__device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, int s, int i, int role, double* __restrict__ Dm,
+                                               const double* __restrict__ Um, double* __restrict__ fm,
+                                               double* Pm, double* Qm, double* __restrict__ Gi, double* __restrict__ gm,
+                                               int* __restrict__ info, double* __restrict__ xout, Wait wait) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   constexpr int B = 6 * HB, ld = B + 1;
   double* G = sm;                       // [B][ld]  D_i -> its Cholesky factor L (lower)
@@ -741,12 +764,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   int* bad = reinterpret_cast<int*>(dinv + B + 2);
   double* Li = dinv + B + 4;            // [2][16][12]: inverse of diagonal block kb in half kb & 1 (lower triangular), rows 12..15 zero
   const int tid = threadIdx.x;
-  const int role = blockIdx.y;
-  const int i = s * (2 * blockIdx.x + 1) - 1;
-  if (i >= N) return;
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;
-  if ((role == 0 && !haveL) || (role == 1 && !haveR)) return;       // no such neighbour: nothing to do for this role
   constexpr size_t BB = (size_t)B * B;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
 
@@ -754,6 +773,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
   double* Idt = Li + 384;
   bcr_identity_table(Idt, tid);
+  wait();
 #ifdef BA_BCR_PROFILE
   long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long* dtrace = reinterpret_cast<long long*>(Li + 384 + kBcrIdtDoubles);
@@ -771,9 +791,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + it * kBcrElimThreads;
       const bool ok = e < B * B;
-      vd[it] = ok ? Dm[(size_t)i * BB + e] : 0.0;
-      va[it] = (ok && direct) ? srcU[e] : (ok && prod) ? Pm[(size_t)j * BB + e] : 0.0;
-      vb[it] = (ok && prod) ? Qm[(size_t)j * BB + e] : 0.0;
+      vd[it] = ok ? bcr_ld<FUSED>(Dm + (size_t)i * BB + e) : 0.0;
+      va[it] = (ok && direct) ? srcU[e] : (ok && prod) ? bcr_ld<FUSED>(Pm + (size_t)j * BB + e) : 0.0;
+      vb[it] = (ok && prod) ? bcr_ld<FUSED>(Qm + (size_t)j * BB + e) : 0.0;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -792,7 +812,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
         }
       }
     }
-    for (int e = tid; e < B; e += kBcrElimThreads) g[e] = fm[(size_t)i * B + e];
+    for (int e = tid; e < B; e += kBcrElimThreads) g[e] = bcr_ld<FUSED>(fm + (size_t)i * B + e);
     __syncthreads();
 #ifdef BA_BCR_PROFILE
     pst[0] = clock64() - pt0;
@@ -860,7 +880,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
     }
   }
 #ifdef BA_BCR_PROFILE
-  if (BA_BCR_TRACE_KB == 0 && blockIdx.x == 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt0 - pst[0]);      // prologue, per wavefront
+  if (BA_BCR_TRACE_KB == 0 && i == 3 * s - 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt0 - pst[0]);      // prologue, per wavefront
 #endif
   __syncthreads();
 
@@ -1031,7 +1051,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       }
     }
 #ifdef BA_BCR_PROFILE
-    if (blockIdx.x == 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q0);      // phase 1 of one block step, per wavefront
+    if (i == 3 * s - 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q0);      // phase 1 of one block step, per wavefront
 #endif
     if (kb > 0) __syncthreads();
 #ifdef BA_BCR_PROFILE
@@ -1046,7 +1066,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       }
     }
 #if defined(BA_BCR_PROFILE) && defined(BA_BCR_TRACE_PH2)
-    if (blockIdx.x == 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q1);      // phase 2 of one block step, per wavefront
+    if (i == 3 * s - 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q1);      // phase 2 of one block step, per wavefront
 #endif
     __syncthreads();
 #ifdef BA_BCR_PROFILE
@@ -1077,7 +1097,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   __syncthreads();
   if (*bad) {
     if (tid == 0 && role == 2) atomicMax(info, i * B + *bad);
-    return;
+    return false;
   }
 #ifdef BA_BCR_PROFILE
   const long long pt3 = clock64();
@@ -1085,6 +1105,14 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 #endif
 
   if (role < 2) {
+    if constexpr (FUSED && BA_BCR_STORE_FIRST) {
+      // the factor leaves for memory first: the next level multiplies it (and the back-substitution reads it)
+      double* out = (role == 0 ? Pm : Qm) + (size_t)i * BB;
+      for (int e = tid; e < B * B; e += kBcrElimThreads) {
+        const int rr = e / B, cc = e - rr * B;
+        bcr_st<true>(out + e, R[rr * ld + cc]);
+      }
+    }
     // ---- this role's neighbour update: D_nb -= R^T R (lower tiles), f_nb -= R^T g; R is kept for the back-substitution
     const int nbr = role == 0 ? l : r;
     constexpr int NT = (B + 15) / 16, KST = (B + 3) / 4;
@@ -1137,12 +1165,14 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
       atomic_add_f64(fm + (size_t)nbr * B + c, -acc);
     }
 #ifdef BA_BCR_PROFILE
-    if (BA_BCR_TRACE_KB == 99 && blockIdx.x == 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt3);      // products, per wavefront
+    if (BA_BCR_TRACE_KB == 99 && i == 3 * s - 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt3);      // products, per wavefront
 #endif
-    double* out = (role == 0 ? Pm : Qm) + (size_t)i * BB;
-    for (int e = tid; e < B * B; e += kBcrElimThreads) {
-      const int rr = e / B, cc = e - rr * B;
-      out[e] = R[rr * ld + cc];
+    if constexpr (!(FUSED && BA_BCR_STORE_FIRST)) {
+      double* out = (role == 0 ? Pm : Qm) + (size_t)i * BB;
+      for (int e = tid; e < B * B; e += kBcrElimThreads) {
+        const int rr = e / B, cc = e - rr * B;
+        bcr_st<FUSED>(out + e, R[rr * ld + cc]);
+      }
     }
   } else {
     for (int e = tid; e < B * B; e += kBcrElimThreads) {
@@ -1164,13 +1194,99 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   }
 #ifdef BA_BCR_PROFILE
   __syncthreads();
-  if (tid == 0 && blockIdx.x == 1 && s == 2) {
+  if (tid == 0 && i == 3 * s - 1 && s == 2) {
     int* o = info + 8 + 10 * role;              // [load, prologue, diag factor (wave 0), phase 1, phase 2, phase 3, last rhs block, products + store]
     for (int q = 0; q < 7; ++q) o[q] = (int)pst[q];
     o[7] = (int)(clock64() - pt3);
     if (role == 0) { info[40] = (int)dtrace[0]; info[41] = (int)dtrace[1]; info[42] = (int)dtrace[2]; }
   }
 #endif
+  return true;
+}
+
+template <int HB>
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, int s, double* __restrict__ Dm,
+                                                                     const double* __restrict__ Um, double* __restrict__ fm,
+                                                                     double* __restrict__ Pm, double* __restrict__ Qm,
+                                                                     double* __restrict__ Gi, double* __restrict__ gm,
+                                                                     int* __restrict__ info, double* __restrict__ xout) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int role = blockIdx.y;
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N) return;
+  if ((role == 0 && i - s < 0) || (role == 1 && i + s >= N)) return;       // no such neighbour: nothing to do for this role
+  bcr_split_node<HB, false>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, [] {});
+}
+
+// --------------------------------------------------------------------------
+// ALL split elimination levels in ONE launch.  One workgroup per (node, role) of every level from stride s_first up; a
+// workgroup takes a ticket when it STARTS and works on work[ticket], `work` listing the (node, role) pairs level by level
+// from the leaves up - so a workgroup only ever waits for workgroups that started before it (resident or done; the same
+// argument as in k_bcr_backsolve_fused: no deadlock whatever else shares the GPU, and levels wider than the chip simply run
+// in rounds).  What a (node i, stride s) needs from the level below arrives through global memory:
+//     D_i, f_i  final once every node that adds to them is done:  (i - s/2, right role) and (i + s', left role), s' the
+//               largest stride <= s/2 with i + s' < N  (those two waited, each in its turn, for the smaller strides on its side)
+//     P_j, Q_j  of the node eliminated between i and its neighbour (j = i -/+ s/2, both roles): the coupling of the left /
+//               right role
+// Every workgroup ends by publishing done[node][role] AFTER its stores and atomics have been acknowledged (s_waitcnt
+// vmcnt(0), barrier, one relaxed agent-scope store); a consumer polls the (at most three) words it needs with one lane each,
+// then loads.  All of that data moves with relaxed agent-scope accesses: no fences (an acquire / release at agent scope
+// invalidates / writes back a whole L2: DESIGN.md).  The wait is bounded (~1 s): status word, not a hung GPU.
+// What the launch boundaries cost before: the set-up of a node (LDS tables, identity right-hand sides) now happens while it
+// waits, the factors leave for memory under the neighbour products, a level's early finishers hand over at once instead
+// of at the end of the launch, and workgroups of the upper levels never queue behind a kernel boundary.
+// --------------------------------------------------------------------------
+constexpr int kBcrElimTicketWord = kBcrTicketWord - 1;         // info[60]: tickets of k_bcr_eliminate_fused (k_bcr_assemble clears it)
+__device__ __forceinline__ void bcr_wait_done(const int* flag, int* status) {
+  int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int spins = 0; v == 0; ++spins) {
+    if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
+    __builtin_amdgcn_s_sleep(1);
+    v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int HB>
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, int s_first, double* __restrict__ Dm,
+                                                                     const double* __restrict__ Um, double* __restrict__ fm,
+                                                                     double* Pm, double* Qm, double* __restrict__ Gi,
+                                                                     double* __restrict__ gm, int* __restrict__ info,
+                                                                     double* __restrict__ xout, const int* __restrict__ work,
+                                                                     int* done) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  int* my_work = reinterpret_cast<int*>(sm + (bcr_split_lds_bytes(6 * HB) / sizeof(double)) - 2);      // (the last two doubles of the area: nothing else lives there)
+  if (threadIdx.x == 0) *my_work = work[atomicAdd(info + kBcrElimTicketWord, 1)];
+  __syncthreads();
+  const int item = __builtin_amdgcn_readfirstlane(*my_work);
+  const int i = item >> 2, role = item & 3;
+  const int s = (i + 1) & -(i + 1);             // the level that eliminates node i: i = s (2 k + 1) - 1
+  __syncthreads();                              // (my_work is read; the body may use the whole area)
+  auto wait = [&] {
+    if (s > s_first) {
+      // which of the nodes below must be done (see above); one lane per word
+      const int h = s >> 1;
+      int sr = h;
+      while (sr >= s_first && i + sr >= N) sr >>= 1;
+      const int right = sr >= s_first ? i + sr : -1;        // the largest-stride node that adds to D_i from the right (role 0 of it)
+      if (threadIdx.x < 3) {
+        int node = -1, rl = 0;
+        if (role == 0) {
+          if (threadIdx.x == 0) { node = i - h; rl = 0; } else if (threadIdx.x == 1) { node = i - h; rl = 1; } else { node = right; rl = 0; }
+        } else if (role == 1) {
+          if (threadIdx.x == 0) { node = i - h; rl = 1; } else if (threadIdx.x == 1) { node = i + h; rl = 0; } else { node = i + h; rl = 1; }
+        } else {
+          if (threadIdx.x == 0) { node = i - h; rl = 1; } else if (threadIdx.x == 1) { node = right; rl = 0; }
+        }
+        if (node >= 0) bcr_wait_done(done + 4 * node + rl, info);
+      }
+    }
+    __syncthreads();
+  };
+  bcr_split_node<HB, true>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, wait);
+  // publish: everything this workgroup stored or added is acknowledged by memory before the word says so
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(done + 4 * i + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One back-substitution level: x_i = G^-T (g - P x_l - Q x_r) for the nodes of that level.
@@ -1249,8 +1365,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve(int N, int B,
 // forms x_i = G^-T (g - P x_l - Q x_r) and stores it.  The root was solved by its elimination kernel.
 // Six dependent launches of 4.7 us become one of ~2 us + 6 hand-overs.
 // --------------------------------------------------------------------------
-constexpr int kBcrMaxSpins = 1 << 20;           // polls of ~1 us each
-constexpr int kBcrTimedOut = 0x7f000001;        // status word of a back-substitution that gave up waiting
 __device__ __forceinline__ double bcr_wait_value(const double* p, int* status) {
   // relaxed agent-scope polls of the DATA (write-through stores, cache-bypassing loads): one memory round trip per
   // hand-over.  Acquire loads / release fences here invalidate and write back whole L2s: 20 - 30 us per hand-over
@@ -1288,11 +1402,17 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, 
   // by blockIdx instead hung two processes on one GPU, each kernel holding compute units the other's parents needed.
   // a failed elimination (matrix not positive definite: status word set by an earlier launch) leaves solution entries
   // unwritten: nobody may wait for them
-  if (ticket[-kBcrTicketWord] != 0) return;
+  // (ONE thread reads the status word and takes the ticket, the workgroup decides on what it broadcast: every thread reading
+  // the word for itself could split the workgroup when another one sets it in between)
   int* my_ticket = reinterpret_cast<int*>(xr + B);      // (in the dynamic area: the kernel may ask for all 160 KB of it)
-  if (tid == 0) *my_ticket = atomicAdd(ticket, 1);
+  if (tid == 0) {
+    const int st = __hip_atomic_load(ticket - kBcrTicketWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    my_ticket[1] = st;
+    my_ticket[0] = st != 0 ? 0 : atomicAdd(ticket, 1);
+  }
   __syncthreads();
-  const int i = order[*my_ticket];
+  if (my_ticket[1] != 0) return;
+  const int i = order[my_ticket[0]];
   const int s = (i + 1) & -(i + 1);      // the level that eliminated node i: i = s (2 k + 1) - 1
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;

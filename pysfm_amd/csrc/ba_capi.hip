@@ -60,6 +60,7 @@ struct Options {
   bool lds_window = true;          // k_schur_groups_mfma3 accumulates in an LDS window of the band when one fits
   bool fast_paths = true;          // K = I / unit-Gaussian short cuts of the per-observation arithmetic (ba_math.h)
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
+  bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
 
@@ -139,6 +140,8 @@ struct ba_handle {
   DevBuf<unsigned char> mask;
   DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)
   int bcr_order_n = 0;
+  DevBuf<int> bcr_work, bcr_done;   // k_bcr_eliminate_fused: 4 node + role of every workgroup, leaves first; "handed on" words [4 N]
+  int bcr_work_n = 0, bcr_work_s = 0, bcr_work_len = 0;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
   DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
@@ -323,6 +326,26 @@ hipError_t launch_bcr_split_hb(ba_handle* h, int cnt, hipStream_t st, int N, int
   return hipSuccess;
 }
 
+template <int HB>
+hipError_t launch_bcr_fused_hb(ba_handle* h, int nwork, hipStream_t st, int N, int s_first, double* D, const double* U, double* f,
+                               double* P, double* Q, double* G, double* gv, int* info, double* x, const int* work, int* done) {
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcr_eliminate_fused<HB>); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bcr_eliminate_fused<HB>, dim3(nwork), dim3(kBcrElimThreads), bcr_split_lds_bytes(6 * HB), st, N, s_first, D, U, f,
+                     P, Q, G, gv, info, x, work, done);
+  return hipSuccess;
+}
+
+hipError_t launch_bcr_fused(ba_handle* h, int hb, int nwork, hipStream_t st, int N, int s_first, double* D, const double* U, double* f,
+                            double* P, double* Q, double* G, double* gv, int* info, double* x, const int* work, int* done) {
+#define BA_HB_CASE(K) case K: return launch_bcr_fused_hb<K>(h, nwork, st, N, s_first, D, U, f, P, Q, G, gv, info, x, work, done);
+  switch (hb) {
+    BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
+    BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11)
+    default: return hipErrorInvalidValue;
+  }
+#undef BA_HB_CASE
+}
+
 hipError_t launch_bcr_split(ba_handle* h, int hb, int cnt, hipStream_t st, int N, int s, double* D, const double* U, double* f,
                             double* P, double* Q, double* G, double* gv, int* info, double* x) {
 #define BA_HB_CASE(K) case K: return launch_bcr_split_hb<K>(h, cnt, st, N, s, D, U, f, P, Q, G, gv, info, x);
@@ -361,20 +384,55 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   // level needs the couplings U the split kernel does not form: so never one-unit above split - node counts only fall.)
   const bool split = h->opt.solver != SOLVER_BCR1;
   std::vector<char> level_split;
-  {
-    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1] and marks the solution "not there yet"
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
-                       h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p);
-  }
   const size_t lds = bcr_lds_bytes(B);
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
+  for (int s : strides) {
+    const int cnt = (N / s + 1) / 2;
+    level_split.push_back(split && (3 * cnt <= h->ncu || (!level_split.empty() && level_split.back())));
+  }
+  // the split levels in ONE launch (k_bcr_eliminate_fused): its work list = the (node, role) pairs of those levels, leaves first
+  int s_fused = 0, nwork = 0;
+  if (split && h->opt.fused_eliminate) {
+    for (size_t q = 0; q < strides.size(); ++q)
+      if (level_split[q]) { s_fused = strides[q]; break; }
+    if (s_fused && !(h->bcr_work_n == N && h->bcr_work_s == s_fused)) {
+      std::vector<int> work;
+      for (size_t q = 0; q < strides.size(); ++q) {
+        if (!level_split[q]) continue;
+        const int s = strides[q];
+        for (int k = 0, cnt = (N / s + 1) / 2; k < cnt; ++k) {
+          const int i = s * (2 * k + 1) - 1;
+          if (i >= N) continue;
+          if (i - s >= 0) work.push_back(4 * i + 0);
+          if (i + s < N) work.push_back(4 * i + 1);
+          work.push_back(4 * i + 2);
+        }
+      }
+      HIPCHECK(h, h->bcr_work.resize(work.size()));
+      HIPCHECK(h, hipMemcpyAsync(h->bcr_work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      HIPCHECK(h, hipStreamSynchronize(h->stream));          // `work` goes out of scope
+      h->bcr_work_n = N; h->bcr_work_s = s_fused; h->bcr_work_len = (int)work.size();
+    }
+    nwork = s_fused ? h->bcr_work_len : 0;
+    if (s_fused) HIPCHECK(h, h->bcr_done.resize((size_t)4 * N));
+  }
   {
-    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)strides.size());
-    for (int s : strides) {
-      const int cnt = (N / s + 1) / 2;
-      level_split.push_back(split && (3 * cnt <= h->ncu || (!level_split.empty() && level_split.back())));
-      if (level_split.back())
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1], marks the solution "not there yet", clears done[]
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
+                       h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, s_fused ? h->bcr_done.p : nullptr);
+  }
+  {
+    int launches = 0;
+    for (size_t q = 0; q < strides.size(); ++q) launches += (s_fused && level_split[q]) ? (strides[q] == s_fused ? 1 : 0) : 1;
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, launches);
+    for (size_t q = 0; q < strides.size(); ++q) {
+      const int s = strides[q], cnt = (N / s + 1) / 2;
+      if (s_fused && level_split[q]) {
+        if (s == s_fused)
+          HIPCHECK(h, launch_bcr_fused(h, hb, nwork, h->stream, N, s_fused, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
+                                       h->bcrGv.p, h->flags.p + 1, h->dC.p, h->bcr_work.p, h->bcr_done.p));
+      } else if (level_split[q])
         HIPCHECK(h, launch_bcr_split(h, hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
                                      h->bcrGv.p, h->flags.p + 1, h->dC.p));
       else
@@ -654,7 +712,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -672,6 +730,8 @@ int ba_debug_poison(ba_handle* h) {
                             &h->dUd, &h->dDd, &h->dyd, &h->dpart, &h->cams[1 - h->cur], &h->X[1 - h->cur]};
   for (DevBuf<double>* b : bufs)
     if (b->p && b->n) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, h->stream, b->p, b->n);
+  if (h->bcr_done.p && h->bcr_done.n >= 2)          // the "handed on" words of k_bcr_eliminate_fused: garbage that reads as "done" unless k_bcr_assemble clears it
+    hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((h->bcr_done.n / 2 + 255) / 256)), dim3(256), 0, h->stream, reinterpret_cast<double*>(h->bcr_done.p), h->bcr_done.n / 2);
   if (h->S) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((reduced_doubles(h) + 255) / 256)), dim3(256), 0, h->stream, h->S, reduced_doubles(h));
   if (h->b && h->nco) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)(((size_t)h->nco * 6 + 255) / 256)), dim3(256), 0, h->stream, h->b, (size_t)h->nco * 6);
   HIPCHECK(h, hipGetLastError());
@@ -707,6 +767,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "solve_trace") ok = flag(h->opt.solve_trace);
   else if (n == "lds_window") ok = flag(h->opt.lds_window);
   else if (n == "fused_backsolve") ok = flag(h->opt.fused_backsolve);
+  else if (n == "fused_eliminate") ok = flag(h->opt.fused_eliminate);
   else if (n == "fast_paths") ok = flag(h->opt.fast_paths);
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);
