@@ -741,19 +741,46 @@ __device__ __forceinline__ void bcr_st(double* p, double v) {
   else *p = v;
 }
 
+#ifndef BA_BCR_TWO_STAGE
+#define BA_BCR_TWO_STAGE 0          // fused kernel: a second, early word per role for its factor (see bcr_split_node)
+#endif
 #ifndef BA_BCR_STORE_FIRST
 #define BA_BCR_STORE_FIRST 1        // fused kernel: the factors P / Q leave for memory BEFORE the neighbour products (their latency rides under the MFMAs)
 #endif
 
-// One (node, role) of a split elimination level - the body of k_bcr_eliminate_split and of k_bcr_eliminate_fused.
-// `wait()` is called after the LDS set-up that needs no input and before the first global load (the fused kernel waits for
-// its producers there).  Returns false when D_i turned out not to be positive definite (status word set, nothing handed on).
-template <int HB, bool FUSED, typename Wait>
+// What a (node, role) of the one-launch elimination waits for and publishes (words of done[], see k_bcr_eliminate_fused):
+// pq[0..1]: the two factors P_j, Q_j its coupling is formed from are in memory; d[0..1]: every node that adds to D_i, f_i
+// has added; my_pq / my_d: this role's own two words.  Null = nothing to wait for / to say.
+struct BcrDeps {
+  const int* pq[2];
+  const int* d[2];
+  int* my_pq;
+  int* status;
+};
+__device__ __forceinline__ void bcr_wait_done(const int* flag, int* status) {
+  int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int spins = 0; v == 0; ++spins) {
+    if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
+    __builtin_amdgcn_s_sleep(1);
+    v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// One (node, role) of a split elimination level - the body of k_bcr_eliminate_split and of k_bcr_eliminate_fused (FUSED: the
+// inputs come from workgroups of the same launch, `dep` says which words to wait for).  Returns false when D_i turned out
+// not to be positive definite (status word set, nothing handed on).
+template <int HB, bool FUSED>
 __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, int s, int i, int role, double* __restrict__ Dm,
                                                const double* __restrict__ Um, double* __restrict__ fm,
                                                double* Pm, double* Qm, double* __restrict__ Gi, double* __restrict__ gm,
-                                               int* __restrict__ info, double* __restrict__ xout, Wait wait) {
+                                               int* __restrict__ info, double* __restrict__ xout, const BcrDeps dep,
+                                               long long* __restrict__ tline = nullptr) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
+#ifdef BA_BCR_PROFILE
+#define BA_TLINE(k) do { if (tline && threadIdx.x == 0) tline[k] = wall_clock64(); } while (0)
+#else
+#define BA_TLINE(k)
+#endif
   constexpr int B = 6 * HB, ld = B + 1;
   double* G = sm;                       // [B][ld]  D_i -> its Cholesky factor L (lower)
   double* R = G + (size_t)B * ld;       // [B][ld]  right-hand sides of this role: T_il | T_ir | I  ->  P | Q | G^-1
@@ -769,11 +796,30 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   constexpr size_t BB = (size_t)B * B;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
 
-  if (tid == 0) *bad = 0;
+  if (tid == 0) { bad[0] = 0; bad[1] = 0; }      // bad[1]: wavefronts of this workgroup whose factor stores have landed (fused kernel)
   if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
   double* Idt = Li + 384;
   bcr_identity_table(Idt, tid);
-  wait();
+  // FUSED, a role with a coupling to form (TWO_STAGE): the factors it is formed from are published early by their producers
+  // (right after their factorisation, before their neighbour products), D_i late (after those products): all wavefronts
+  // fetch P_j, Q_j and 15 of them form the coupling while wavefront 0 alone waits for D_i, fetches it and factors block 0
+  // (BA_BCR_TWO_STAGE, measured and left off: the early word is seen only 0.35 us before the late one - the stores of the
+  // factor take as long to be acknowledged as the neighbour products take to run - and wavefront 0 alone needs 3.3 us for
+  // fetching D_i and factoring block 0, against 2.4 us for the coupling product it runs beside: 98.0 us for the seven
+  // levels of config 3 against 95.9 us with one word per role, everything fetched by all wavefronts at once)
+  const bool two_stage = FUSED && BA_BCR_TWO_STAGE && s > 1 && role < 2 && dep.pq[0] != nullptr;
+  if constexpr (FUSED) {
+    // (selects, not indexing: a runtime index would put the struct into scratch memory)
+    if (two_stage) {
+      const int* word = tid == 0 ? dep.pq[0] : dep.pq[1];
+      if (tid < 2 && word) bcr_wait_done(word, dep.status);
+    } else {
+      const int* word = tid == 0 ? dep.d[0] : tid == 1 ? dep.d[1] : tid == 2 ? dep.pq[0] : dep.pq[1];
+      if (tid < 4 && word) bcr_wait_done(word, dep.status);
+    }
+    __syncthreads();
+  }
+  BA_TLINE(1);
 #ifdef BA_BCR_PROFILE
   long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long* dtrace = reinterpret_cast<long long*>(Li + 384 + kBcrIdtDoubles);
@@ -791,7 +837,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + it * kBcrElimThreads;
       const bool ok = e < B * B;
-      vd[it] = ok ? bcr_ld<FUSED>(Dm + (size_t)i * BB + e) : 0.0;
+      vd[it] = (ok && !two_stage) ? bcr_ld<FUSED>(Dm + (size_t)i * BB + e) : 0.0;
       va[it] = (ok && direct) ? srcU[e] : (ok && prod) ? bcr_ld<FUSED>(Pm + (size_t)j * BB + e) : 0.0;
       vb[it] = (ok && prod) ? bcr_ld<FUSED>(Qm + (size_t)j * BB + e) : 0.0;
     }
@@ -800,7 +846,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
       const int e = tid + it * kBcrElimThreads;
       if (e < B * B) {
         const int rr = e / B, cc = e - rr * B;
-        G[rr * ld + cc] = vd[it];
+        if (!two_stage) G[rr * ld + cc] = vd[it];
         if (direct) {
           if (role == 0) R[cc * ld + rr] = va[it];                  // T[i,l] = T[l,i]^T
           else R[rr * ld + cc] = va[it];                            // T[i,r]
@@ -812,8 +858,10 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
         }
       }
     }
-    for (int e = tid; e < B; e += kBcrElimThreads) g[e] = bcr_ld<FUSED>(fm + (size_t)i * B + e);
+    if (!two_stage)
+      for (int e = tid; e < B; e += kBcrElimThreads) g[e] = bcr_ld<FUSED>(fm + (size_t)i * B + e);
     __syncthreads();
+    BA_TLINE(2);
 #ifdef BA_BCR_PROFILE
     pst[0] = clock64() - pt0;
 #endif
@@ -822,6 +870,32 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   //      from the factors of the node eliminated one level down
   constexpr int NBLK = (B + 11) / 12;
   if (wave == 0) {
+    if constexpr (FUSED) {
+      if (two_stage) {
+        // D_i, f_i: once everybody who adds to them has (one lane per word), fetched by this wavefront alone in two rounds
+        const int* word = lane == 0 ? dep.d[0] : dep.d[1];
+        if (lane < 2 && word) bcr_wait_done(word, dep.status);
+        constexpr int NW = (B * B + 63) / 64, H0 = (NW + 1) / 2;
+        const double gv = lane < B ? bcr_ld<true>(fm + (size_t)i * B + lane) : 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int w0 = half ? H0 : 0, w1 = half ? NW : H0;
+          double v[H0];
+#pragma unroll
+          for (int w = 0; w < H0; ++w) {
+            const int e = lane + 64 * (w0 + w);
+            v[w] = (w0 + w < w1 && e < B * B) ? bcr_ld<true>(Dm + (size_t)i * BB + e) : 0.0;
+          }
+#pragma unroll
+          for (int w = 0; w < H0; ++w) {
+            const int e = lane + 64 * (w0 + w);
+            if (w0 + w < w1 && e < B * B) { const int rr = e / B, cc = e - rr * B; G[rr * ld + cc] = v[w]; }
+          }
+        }
+        for (int e = lane; e < B; e += 64) g[e] = e == lane ? gv : bcr_ld<true>(fm + (size_t)i * B + e);
+        lds_wave_sync();
+      }
+    }
     __builtin_amdgcn_s_setprio(3);
     if (B >= 12) bcr_diag_block<12, false>(G, ld, dinv, bad, 0, lane, Li, Idt);
     else bcr_diag_block<6, false>(G, ld, dinv, bad, 0, lane, Li, Idt);
@@ -883,6 +957,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   if (BA_BCR_TRACE_KB == 0 && i == 3 * s - 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt0 - pst[0]);      // prologue, per wavefront
 #endif
   __syncthreads();
+  BA_TLINE(3);
 
 #ifdef BA_BCR_PROFILE
   const long long pt1 = clock64();
@@ -1095,6 +1170,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     }
   }
   __syncthreads();
+  BA_TLINE(4);
   if (*bad) {
     if (tid == 0 && role == 2) atomicMax(info, i * B + *bad);
     return false;
@@ -1113,6 +1189,20 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
         bcr_st<true>(out + e, R[rr * ld + cc]);
       }
     }
+    // ... and is PUBLISHED as soon as every wavefront's stores have been acknowledged - which each wavefront checks when its
+    // matrix products are done, right before its first atomic (no stall: the stores left a microsecond earlier); the last one
+    // to arrive says so.  The consumers form their coupling from it while this workgroup is still adding to its neighbour.
+    bool arrived = !(FUSED && BA_BCR_STORE_FIRST && BA_BCR_TWO_STAGE);
+    auto arrive = [&] {
+      if constexpr (FUSED && BA_BCR_STORE_FIRST) {
+        if (!arrived) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0 && atomicAdd(bad + 1, 1) == kBcrElimThreads / 64 - 1 && dep.my_pq)
+            __hip_atomic_store(dep.my_pq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          arrived = true;
+        }
+      }
+    };
     // ---- this role's neighbour update: D_nb -= R^T R (lower tiles), f_nb -= R^T g; R is kept for the back-substitution
     const int nbr = role == 0 ? l : r;
     constexpr int NT = (B + 15) / 16, KST = (B + 3) / 4;
@@ -1128,6 +1218,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
           bcr_edge_task(q, NTF, RB, false, EB, lane, acol, bcol);
           const double v = bcr_mfma4_blocks<B>(R, R, ld, acol, bcol, lane);
           const int row = acol + (lane >> 4), col = bcol + (lane & 3);
+          arrive();
           if (row < B && col <= row) atomic_add_f64(dst + (size_t)row * B + col, -v);
         }
     }
@@ -1153,12 +1244,14 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
       }
       double* dst = Dm + (size_t)nbr * BB;
       const int col = 16 * tj + lr;
+      arrive();
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = 16 * ti + lk + 4 * v;
         if (row < B && col <= row) atomic_add_f64(dst + (size_t)row * B + col, -(acc[v] + acc2[v]));
       }
     }
+    arrive();                                                                    // (wavefronts without a tile)
     for (int c = kBcrElimThreads - 1 - tid; c < B; c += kBcrElimThreads) {       // the last wavefronts have fewer tiles
       double acc = 0.0;
       for (int k = 0; k < B; ++k) acc += R[k * ld + c] * g[k];
@@ -1215,7 +1308,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   const int i = s * (2 * blockIdx.x + 1) - 1;
   if (i >= N) return;
   if ((role == 0 && i - s < 0) || (role == 1 && i + s >= N)) return;       // no such neighbour: nothing to do for this role
-  bcr_split_node<HB, false>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, [] {});
+  bcr_split_node<HB, false>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, BcrDeps{{nullptr, nullptr}, {nullptr, nullptr}, nullptr, info});
 }
 
 // --------------------------------------------------------------------------
@@ -1237,14 +1330,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
 // of at the end of the launch, and workgroups of the upper levels never queue behind a kernel boundary.
 // --------------------------------------------------------------------------
 constexpr int kBcrElimTicketWord = kBcrTicketWord - 1;         // info[60]: tickets of k_bcr_eliminate_fused (k_bcr_assemble clears it)
-__device__ __forceinline__ void bcr_wait_done(const int* flag, int* status) {
-  int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int spins = 0; v == 0; ++spins) {
-    if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
-    __builtin_amdgcn_s_sleep(1);
-    v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 
 template <int HB>
 __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, int s_first, double* __restrict__ Dm,
@@ -1252,41 +1337,58 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, 
                                                                      double* Pm, double* Qm, double* __restrict__ Gi,
                                                                      double* __restrict__ gm, int* __restrict__ info,
                                                                      double* __restrict__ xout, const int* __restrict__ work,
-                                                                     int* done) {
+                                                                     int* done, long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   int* my_work = reinterpret_cast<int*>(sm + (bcr_split_lds_bytes(6 * HB) / sizeof(double)) - 2);      // (the last two doubles of the area: nothing else lives there)
-  if (threadIdx.x == 0) *my_work = work[atomicAdd(info + kBcrElimTicketWord, 1)];
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(info + kBcrElimTicketWord, 1);
+    my_work[0] = work[ticket];
+    my_work[1] = ticket;
+  }
   __syncthreads();
   const int item = __builtin_amdgcn_readfirstlane(*my_work);
+#ifdef BA_BCR_PROFILE
+  // time line of this workgroup (100 MHz wall clock, the same on every compute unit): [start, producers done, loaded, coupling
+  // formed, factored, handed on, 4 node + role, XCD] at trace[8 ticket]
+  long long* tline = trace ? trace + 8 * (size_t)my_work[1] : nullptr;
+  if (tline && threadIdx.x == 0) {
+    tline[0] = wall_clock64();
+    tline[6] = item;
+    tline[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID
+  }
+#else
+  long long* tline = nullptr;
+#endif
   const int i = item >> 2, role = item & 3;
   const int s = (i + 1) & -(i + 1);             // the level that eliminates node i: i = s (2 k + 1) - 1
   __syncthreads();                              // (my_work is read; the body may use the whole area)
-  auto wait = [&] {
-    if (s > s_first) {
-      // which of the nodes below must be done (see above); one lane per word
-      const int h = s >> 1;
-      int sr = h;
-      while (sr >= s_first && i + sr >= N) sr >>= 1;
-      const int right = sr >= s_first ? i + sr : -1;        // the largest-stride node that adds to D_i from the right (role 0 of it)
-      if (threadIdx.x < 3) {
-        int node = -1, rl = 0;
-        if (role == 0) {
-          if (threadIdx.x == 0) { node = i - h; rl = 0; } else if (threadIdx.x == 1) { node = i - h; rl = 1; } else { node = right; rl = 0; }
-        } else if (role == 1) {
-          if (threadIdx.x == 0) { node = i - h; rl = 1; } else if (threadIdx.x == 1) { node = i + h; rl = 0; } else { node = i + h; rl = 1; }
-        } else {
-          if (threadIdx.x == 0) { node = i - h; rl = 1; } else if (threadIdx.x == 1) { node = right; rl = 0; }
-        }
-        if (node >= 0) bcr_wait_done(done + 4 * node + rl, info);
-      }
+  // the words of done[4 node + k]: k = 0 / 1: the left / right role's factor (P / Q) is in memory; k = 2 / 3: the left / right
+  // role has added to its neighbour's D and f
+  BcrDeps dep{{nullptr, nullptr}, {nullptr, nullptr}, role < 2 ? done + 4 * i + role : nullptr, info};
+  if (s > s_first) {
+    const int h = s >> 1;
+    int sr = h;
+    while (sr >= s_first && i + sr >= N) sr >>= 1;
+    const int right = sr >= s_first ? i + sr : -1;        // the largest-stride node that adds to D_i from the right (its left role)
+    dep.d[0] = done + 4 * (i - h) + 3;                     // ... and from the left: the right role of i - s/2
+    dep.d[1] = right >= 0 ? done + 4 * right + 2 : nullptr;
+    if (role < 2) {
+      const int j = role == 0 ? i - h : i + h;             // the node eliminated between i and this role's neighbour
+      dep.pq[0] = done + 4 * j + (BA_BCR_TWO_STAGE ? 0 : 2);
+      dep.pq[1] = done + 4 * j + (BA_BCR_TWO_STAGE ? 1 : 3);
     }
-    __syncthreads();
-  };
-  bcr_split_node<HB, true>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, wait);
+  }
+  const bool ok = bcr_split_node<HB, true>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, dep, tline);
   // publish: everything this workgroup stored or added is acknowledged by memory before the word says so
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(done + 4 * i + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0 && role < 2) {
+    if (!ok) __hip_atomic_store(done + 4 * i + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (not positive definite: nobody may wait)
+    __hip_atomic_store(done + 4 * i + 2 + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#ifdef BA_BCR_PROFILE
+  if (tline && threadIdx.x == 0) tline[5] = wall_clock64();
+#endif
 }
 
 // One back-substitution level: x_i = G^-T (g - P x_l - Q x_r) for the nodes of that level.

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -142,6 +143,8 @@ struct ba_handle {
   int bcr_order_n = 0;
   DevBuf<int> bcr_work, bcr_done;   // k_bcr_eliminate_fused: 4 node + role of every workgroup, leaves first; "handed on" words [4 N]
   int bcr_work_n = 0, bcr_work_s = 0, bcr_work_len = 0;
+  DevBuf<long long> bcr_trace;      // PROFILE builds, option solve_trace: the time line of k_bcr_eliminate_fused, 8 words per workgroup
+  int bcr_trace_n = 0;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
   DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
@@ -330,8 +333,16 @@ template <int HB>
 hipError_t launch_bcr_fused_hb(ba_handle* h, int nwork, hipStream_t st, int N, int s_first, double* D, const double* U, double* f,
                                double* P, double* Q, double* G, double* gv, int* info, double* x, const int* work, int* done) {
   if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcr_eliminate_fused<HB>); e != hipSuccess) return e;
+  long long* trace = nullptr;
+#ifdef BA_BCR_PROFILE
+  if (h->opt.solve_trace) {
+    if (hipError_t e = h->bcr_trace.resize((size_t)8 * nwork); e != hipSuccess) return e;
+    trace = h->bcr_trace.p;
+    h->bcr_trace_n = nwork;
+  }
+#endif
   hipLaunchKernelGGL(k_bcr_eliminate_fused<HB>, dim3(nwork), dim3(kBcrElimThreads), bcr_split_lds_bytes(6 * HB), st, N, s_first, D, U, f,
-                     P, Q, G, gv, info, x, work, done);
+                     P, Q, G, gv, info, x, work, done, trace);
   return hipSuccess;
 }
 
@@ -712,7 +723,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1938,6 +1949,30 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   const int inf = inf6[0];
 #ifdef BA_BCR_PROFILE
+  if (h->opt.solve_trace && use_bcr && h->bcr_trace_n > 0 && h->opt.fused_eliminate) {
+    // time line of k_bcr_eliminate_fused: per level, when its workgroups passed each stage (us after the first workgroup started)
+    std::vector<long long> tr((size_t)8 * h->bcr_trace_n);
+    HIPCHECK(h, hipMemcpy(tr.data(), h->bcr_trace.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    long long t0 = LLONG_MAX;
+    for (int w = 0; w < h->bcr_trace_n; ++w) t0 = std::min(t0, tr[8 * w]);
+    static const char* names[6] = {"start", "producers done", "loaded", "coupling formed", "factored", "handed on"};
+    for (int s = 1; s < 2 * h->bcr_trace_n; s *= 2) {
+      for (int role = 0; role < 3; ++role) {
+        double lo[6], hi[6], sum[6]; int cnt = 0, xcds = 0;
+        for (int k = 0; k < 6; ++k) { lo[k] = 1e30; hi[k] = -1e30; sum[k] = 0; }
+        for (int w = 0; w < h->bcr_trace_n; ++w) {
+          const int item = (int)tr[8 * w + 6], i = item >> 2;
+          if (((i + 1) & -(i + 1)) != s || (item & 3) != role) continue;
+          ++cnt; xcds |= 1 << (int)(tr[8 * w + 7] & 15);
+          for (int k = 0; k < 6; ++k) { const double v = (tr[8 * w + k] - t0) * 0.01; lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); sum[k] += v; }
+        }
+        if (!cnt) continue;
+        fprintf(stderr, "[k_bcr_eliminate_fused stride %4d role %d: %3d workgroups]", s, role, cnt);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.2f..%.2f (mean %.2f) |", names[k], lo[k], hi[k], sum[k] / cnt);
+        fprintf(stderr, " us, on %d XCDs\n", __builtin_popcount(xcds));
+      }
+    }
+  }
   if (h->opt.solve_trace && use_bcr && h->opt.solver != SOLVER_BCR1) {
     for (int role = 0; role < 3; ++role) {
       const int* o = inf6 + 8 + 10 * role;
