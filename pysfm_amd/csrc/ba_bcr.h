@@ -741,6 +741,35 @@ __device__ __forceinline__ void bcr_st(double* p, double v) {
   else *p = v;
 }
 
+// 16-byte agent-coherent loads, K of them in flight at once and ONE wait - all inside one asm statement, so that nothing can
+// read a destination register before its data is there.  (tools/handover_probe.hip: what a workgroup pays for fetching the
+// three B x B inputs of a node with relaxed agent-scope accesses is their NUMBER, not a latency - 8748 eight-byte loads take
+// 2.7 us, 2916 take 1.1 us, 54 take 0.35 us: these loads bypass the L2, every wavefront instruction is its own trip to memory.)
+typedef double bcr_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bcr_ld16(const double* p0, const double* p1, const double* p2, bcr_d2& v0, bcr_d2& v1, bcr_d2& v2) {
+  asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+__device__ __forceinline__ void bcr_ld16(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4,
+                                         const double* p5, bcr_d2& v0, bcr_d2& v1, bcr_d2& v2, bcr_d2& v3, bcr_d2& v4, bcr_d2& v5) {
+  asm volatile("global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %7, off sc1\n\tglobal_load_dwordx4 %2, %8, off sc1\n\t"
+               "global_load_dwordx4 %3, %9, off sc1\n\tglobal_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %11, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5)
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5) : "memory");
+}
+__device__ __forceinline__ void bcr_ld16(const double* p0, const double* p1, bcr_d2& v0, bcr_d2& v1) {
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ void bcr_st16(double* p, bcr_d2 v) {       // (acknowledged like any store: s_waitcnt vmcnt(0) before the word that publishes it)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+#ifndef BA_BCR_WIDE_HANDOVER
+#define BA_BCR_WIDE_HANDOVER 1      // fused kernel: the inputs of a node and the factor it hands on move 16 bytes per lane
+#endif
 #ifndef BA_BCR_TWO_STAGE
 #define BA_BCR_TWO_STAGE 0          // fused kernel: a second, early word per role for its factor (see bcr_split_node)
 #endif
@@ -832,7 +861,37 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     const bool prod = s > 1 && role < 2;                              // deeper: form the coupling from the factors of node j
     const int j = role == 0 ? i - (s >> 1) : i + (s >> 1);
     const double* srcU = Um + (size_t)(role == 0 ? l : i) * BB;
+    // FUSED, above the first level: D_i and the two factors as 16-byte pairs (entries 2 q, 2 q + 1 share a row: B is even),
+    // half as many trips to memory; pairs past the end read pair 0 again (never stored)
+    constexpr int NPAIR = B * B / 2, NITW = (NPAIR + kBcrElimThreads - 1) / kBcrElimThreads;
+    const bool wide = FUSED && BA_BCR_WIDE_HANDOVER && NITW <= 2 && s > 1 && !two_stage;
+    if (wide) {
+      const double* pd = Dm + (size_t)i * BB;
+      const double* pa = prod ? Pm + (size_t)j * BB : pd;
+      const double* pb = prod ? Qm + (size_t)j * BB : pd;
+      const int q0 = tid, q1 = tid + kBcrElimThreads;
+      const int o0 = 2 * (q0 < NPAIR ? q0 : 0), o1 = 2 * (q1 < NPAIR ? q1 : 0);
+      bcr_d2 d0, a0, b0, d1 = {0.0, 0.0}, a1 = {0.0, 0.0}, b1 = {0.0, 0.0};
+      if (!prod) { bcr_ld16(pd + o0, pd + o1, d0, d1); a0 = b0 = d0; }      // (the inverse role: D_i only)
+      else if (NITW == 1) bcr_ld16(pd + o0, pa + o0, pb + o0, d0, a0, b0);
+      else bcr_ld16(pd + o0, pa + o0, pb + o0, pd + o1, pa + o1, pb + o1, d0, a0, b0, d1, a1, b1);
+      auto put = [&](int q, bcr_d2 dv, bcr_d2 av, bcr_d2 bv) {
+        if (q < NPAIR) {
+          const int e = 2 * q, rr = e / B, cc = e - rr * B, o = rr * ld + cc;
+          G[o] = dv[0]; G[o + 1] = dv[1];
+          if (prod) {
+            Ta[o] = av[0]; Ta[o + 1] = av[1];                        // P_j
+            Tb[o] = bv[0]; Tb[o + 1] = bv[1];                        // Q_j
+          } else {
+            R[o] = rr == cc ? 1.0 : 0.0; R[o + 1] = rr == cc + 1 ? 1.0 : 0.0;
+          }
+        }
+      };
+      put(q0, d0, a0, b0);
+      if (NITW > 1) put(q1, d1, a1, b1);
+    }
     double vd[NIT], va[NIT], vb[NIT];
+    if (!wide) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + it * kBcrElimThreads;
@@ -857,6 +916,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
           R[rr * ld + cc] = rr == cc ? 1.0 : 0.0;
         }
       }
+    }
     }
     if (!two_stage)
       for (int e = tid; e < B; e += kBcrElimThreads) g[e] = bcr_ld<FUSED>(fm + (size_t)i * B + e);
@@ -1184,9 +1244,16 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     if constexpr (FUSED && BA_BCR_STORE_FIRST) {
       // the factor leaves for memory first: the next level multiplies it (and the back-substitution reads it)
       double* out = (role == 0 ? Pm : Qm) + (size_t)i * BB;
-      for (int e = tid; e < B * B; e += kBcrElimThreads) {
-        const int rr = e / B, cc = e - rr * B;
-        bcr_st<true>(out + e, R[rr * ld + cc]);
+      if constexpr (BA_BCR_WIDE_HANDOVER) {
+        for (int q = tid; q < B * B / 2; q += kBcrElimThreads) {
+          const int e = 2 * q, rr = e / B, cc = e - rr * B;
+          bcr_st16(out + e, bcr_d2{R[rr * ld + cc], R[rr * ld + cc + 1]});
+        }
+      } else {
+        for (int e = tid; e < B * B; e += kBcrElimThreads) {
+          const int rr = e / B, cc = e - rr * B;
+          bcr_st<true>(out + e, R[rr * ld + cc]);
+        }
       }
     }
     // ... and is PUBLISHED as soon as every wavefront's stores have been acknowledged - which each wavefront checks when its
