@@ -52,7 +52,8 @@ KERNEL_BOUND = {'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_ass
 # timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
 KERNEL_NAMES = {'linearize': 'k_linearize_groups (k_linearize when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init',
                 'schur_pairs': 'k_schur_groups_mfma2 | k_schur_groups_mfma3 (k_schur_groups / k_schur_pairs otherwise)',
-                'backsub': 'k_backsub_groups (k_backsub when points do not come in runs)', 'bcr_eliminate': 'k_bcr_eliminate_split (k_bcr_eliminate on levels wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
+                'backsub': 'k_backsub_groups (k_backsub when points do not come in runs)',
+                'bcr_eliminate': 'k_bcr_eliminate_fused: all levels of the cyclic reduction in one launch (k_bcr_eliminate per level where a level is wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
                 'bcr_backsolve': 'k_bcr_backsolve_fused (k_bcr_backsolve / k_bcrw_backsolve per level otherwise)', 'bcr_assemble': 'k_bcr_assemble', 'cost': 'k_cost',
                 'camera_blocks': 'k_camera_blocks', 'dense_solve': 'k_dense_gather/panel/update/backsolve', 'band_solve': 'k_band_solve'}
 # reference rates measured in SURVEY.md section 6 (the reference itself, imported in the build container, 1 core Xeon 2.1 GHz)
@@ -67,7 +68,7 @@ def schur_flops(nobs, nt):
     return nt * (L * 54 + L * (L + 1) / 2 * 108) * 2
 
 
-def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
+def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb, launches=1.):
     """HBM bytes one launch of `kernel` has to move, every array touched once
     (fp64 values, int32 indices, our SoA layout, block-band S)."""
     obs = 20 * nobs                       # obs_cam (4) + obs_z (16); obs_pt only in k_cost
@@ -88,16 +89,15 @@ def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
     if kernel == 'band_solve':            # read S, write U, re-read U (backward pass)
         return 3 * band + 4 * 48 * nco
     if kernel in ('bcr_assemble', 'bcr_eliminate', 'bcr_backsolve'):
-        # block cyclic reduction over N super-blocks of B = 6 hb unknowns; per AVERAGE launch
-        # (levels = ceil(log2 N) launches share the N nodes)
+        # block cyclic reduction over N super-blocks of B = 6 hb unknowns; per AVERAGE launch: the N nodes of a solve are
+        # shared by its `launches` launches (one with k_bcr_eliminate_fused / k_bcr_backsolve_fused, one per level without)
         B = 6 * max(hb, 1)
         N = -(-nco // max(hb, 1))
-        levels = max(1, int(np.ceil(np.log2(max(N, 2)))))
         if kernel == 'bcr_assemble':
             return band + 8 * (2 * N * B * B + N * B)
         if kernel == 'bcr_eliminate':     # read D, T[l,i], T[i,r]; write G^-1, P, Q, T[l,r]; RMW D_l, D_r
-            return 8 * N * (11 * B * B + 6 * B) // levels
-        return 8 * N * (3 * B * B + 4 * B) // levels
+            return int(8 * N * (11 * B * B + 6 * B) / max(1., launches))
+        return int(8 * N * (3 * B * B + 4 * B) / max(1., launches))
     if kernel == 'flatten':
         return band + 288 * nco * nco
     if kernel == 'point_invert':          # HPP read, HPPinv + its factorisation written, [S | b] initialised
@@ -407,6 +407,9 @@ def main():
     ap.add_argument('--windows', type=int, default=5, help='extra timed windows of --steps trials after the headline one (min / median)')
     ap.add_argument('--force-comm', action='store_true', help='run the sharded path with a one-rank RCCL group on one GPU')
     ap.add_argument('--collectives', default='library', choices=['library', 'torch'])
+    ap.add_argument('--distributed-solve', default='auto', choices=['auto', 'on', 'off'],
+                    help='N > 1: spread the reduced camera solve over the ranks (three small sums per trial) instead of summing the whole '
+                         'band and solving it on every rank; auto = when the band is larger than 4 MB (config 5)')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
                     help='library option for experiments (HipBackend.set_option), e.g. --option solver=bcr1; recorded in the JSON line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -473,7 +476,11 @@ def main():
         ba.backend.set_option(name, val)
     track_ids = None
     if comm is not None:
-        track_ids = shard_tracks(bundle, rank, world)
+        if args.distributed_solve != 'auto':
+            ba.distributed_solve = args.distributed_solve == 'on'
+        # (cut where the distributed reduced solve wants the tracks cut, when it is going to be used; balanced by observations otherwise)
+        use_plan = args.distributed_solve == 'on' or (args.distributed_solve == 'auto' and args.config == 5 and world > 1)
+        track_ids = shard_tracks(bundle, rank, world, plan=ba.backend.dist_plan if use_plan else None)
     t_setup = time.time()
     ba.set_bundle(bundle, track_ids=track_ids)
     t_setup = time.time() - t_setup
@@ -593,7 +600,8 @@ def main():
         if dom_table != dom or not tm_dom['launches'] or not tm_dom['ms'] > 0.:
             dom, tm_dom = dom_table, ours.get(dom_table, tm_dom)
         nco, hb = be.nco, be.half_bandwidth
-        ab = lambda k: algorithmic_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, hb)   # noqa: E731
+        ab = lambda k: algorithmic_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, hb,   # noqa: E731
+                                         launches=(ours[k]['launches'] / nprof) if k in ours else 1.)
         avg_ms = tm_dom['ms'] / max(1, tm_dom['launches'])
         B = ab(dom)
         achieved = B / (avg_ms * 1e-3) / 1e9
@@ -632,7 +640,7 @@ def main():
                 'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
                 'algorithmic_bytes_per_launch': B, 'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
                 'note': 'HIP events on the launch stream during the timed steps, every %d-th step; back-to-back launches of one kernel ' % ev_stride +
-                        '(the cyclic-reduction levels) share one event pair, avg = elapsed / launches.  bound = what limits this kernel '
+                        'share one event pair, avg = elapsed / launches; algorithmic bytes per launch = bytes of the whole step / its launches.  bound = what limits this kernel '
                         '(latency: a chain of dependent pivots, neither HBM nor the matrix cores); achieved / frac are priced against HBM'}
         if bound == 'mfma' and schur_ms:
             roof.update({'achieved': sflops / (schur_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -667,7 +675,14 @@ def main():
                        'library_options': args.option or None,
                        'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False)
                                                                  else 'torch.distributed (RCCL): ' + str(getattr(comm, 'direct_fallback_reason', None))),
-                       'allreduce_payload_bytes_per_rank_per_trial': None if comm is None else 8 * (be.S_doubles + 6 * nco) + 8 * 2050},
+                       'reduced_solve': None if comm is None else (
+                           'spread over the ranks: %(cams_per_node)d cameras per node, %(nodes)d nodes, %(nodes_per_rank)d per rank, %(separators)d separators '
+                           'eliminated by every rank; three sums per trial (shared band rows, separators + subtree roots, solution)' % be._dist_info
+                           if getattr(ba, '_dist', False) else 'whole band summed over the ranks, solved by every rank'),
+                       'allreduce_payload_bytes_per_rank_per_trial': None if comm is None else (
+                           8 * sum(be._dist_info['exchange%d_doubles' % k] for k in (1, 2, 3)) + 8 * 2050 if getattr(ba, '_dist', False)
+                           else 8 * (be.S_doubles + 6 * nco) + 8 * 2050),
+                       'band_bytes': 8 * (be.S_doubles + 6 * nco)},
             'roofline': roof,
             'roofline_linearise_schur_pass': {
                 'kernels': [KERNEL_NAMES.get(k, 'k_' + k) for k in pass_kernels], 'ms': pass_ms, 'algorithmic_bytes': pass_bytes,

@@ -269,6 +269,29 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
 int ba_bind_trial_result(ba_handle* h, void* result_dev /* BA_TRIAL_PARTIALS + 2 doubles, or NULL */);
 int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond);
 int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_info);
+/* the tail of ba_lm_trial_end once a solution is on the device: back-substitution, trial set, trial cost */
+int ba_lm_trial_finish(ba_handle* h);
+
+/* ---- the reduced solve SPREAD OVER THE RANKS of a sharded adjuster (pysfm_amd/csrc/ba_dist.h; no counterpart in the
+ * single-process reference: same arithmetic as ba_solve_reduced, bundle_adjuster.py:281-312).  For block-banded systems whose
+ * band is too large to be summed over the ranks and solved by each of them (BASELINE config 5).  The elimination tree of the
+ * cyclic reduction is cut along the ranks: super-blocks of cams_per_node >= half_bandwidth cameras, rank r owns the
+ * nodes_per_rank - 1 nodes from r * nodes_per_rank, the separator node behind them, and must be given the tracks whose first
+ * optimised camera lies in those (positions [r, r + 1) * nodes_per_rank * cams_per_node).  Needs nranks = 2^g >= 2.
+ *   ba_dist_plan    pure function: the cut for (nco, half_bandwidth, nranks); BA_ERR_STATE when it does not apply
+ *   ba_dist_enable  after ba_set_problem (with the common band width): switches ba_lm_trial (communicator attached) to the
+ *                   distributed solve; nranks <= 1 switches it off.  ba_dist_info: [on, cams_per_node, nodes, nodes_per_rank,
+ *                   first / end own node, first / end own camera position, doubles of the three exchanges, separators]
+ *   ba_dist_stage   for callers that run the collectives themselves (torch.distributed): after ba_lm_trial_begin, stages
+ *                   1, 2, 3 each leave *doubles_to_sum doubles in the exchange buffer (ba_dist_bind_exchange: caller-owned
+ *                   device memory of at least the largest exchange), to be summed over the ranks in place before the next
+ *                   stage; stage 4 takes the solution out of it; then ba_lm_trial_finish.  cam_param_mask as in ba_solve_reduced
+ *                   (stage 2 reads it).  The status word of the solve is this rank's: non-zero on ANY rank = failed. */
+int ba_dist_plan(int32_t nco, int32_t half_bandwidth, int32_t nranks, int32_t* cams_per_node, int32_t* nodes, int32_t* nodes_per_rank);
+int ba_dist_enable(ba_handle* h, int32_t rank, int32_t nranks);
+int ba_dist_info(ba_handle* h, int64_t* out, int32_t n);
+int ba_dist_bind_exchange(ba_handle* h, void* exchange_dev, int64_t doubles);
+int ba_dist_stage(ba_handle* h, int32_t stage, const uint8_t* cam_param_mask, int64_t* doubles_to_sum);
 
 /* ---- Bundle.triangulate_all (bundle.py:313-321; triangulate.algebraic_lsq triangulate.py:6-18)
  * Re-initialise every point of parameter set `which` by linear least squares from its

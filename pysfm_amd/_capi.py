@@ -27,6 +27,8 @@ INFO_KEYS = ('points_permuted', 'obs_permuted', 'groups', 'mfma_groups', 'point_
              'mfma_points_per_batch_cap', 'mfma_k_rows')      # BA_INFO_*
 SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky')
 SOLVE_TIMED_OUT = 0x7f000001            # BA_SOLVE_TIMED_OUT of include/pysfm_ba.h
+DIST_INFO_KEYS = ('on', 'cams_per_node', 'nodes', 'nodes_per_rank', 'node_lo', 'node_hi', 'cam_lo', 'cam_hi',
+                  'exchange1_doubles', 'exchange2_doubles', 'exchange3_doubles', 'separators')      # ba_dist_info
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -78,6 +80,12 @@ PROTOTYPES = {
     'ba_comm_allreduce_sum': (C.c_int, [_h, C.POINTER(C.c_double), C.c_int32]),
     'ba_lm_trial_begin': (C.c_int, [_h, C.c_double, C.c_double]),
     'ba_lm_trial_end': (C.c_int, [_h, _bp, C.POINTER(C.c_int32)]),
+    'ba_lm_trial_finish': (C.c_int, [_h]),
+    'ba_dist_plan': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'ba_dist_enable': (C.c_int, [_h, C.c_int32, C.c_int32]),
+    'ba_dist_info': (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32]),
+    'ba_dist_bind_exchange': (C.c_int, [_h, C.c_void_p, C.c_int64]),
+    'ba_dist_stage': (C.c_int, [_h, C.c_int32, _bp, C.POINTER(C.c_int64)]),
     'ba_triangulate': (C.c_int, [_h, C.c_int, C.c_double, _dp]),
     'ba_enable_timing': (C.c_int, [_h, C.c_int]),
     'ba_set_timing_mask': (C.c_int, [_h, C.c_uint64]),

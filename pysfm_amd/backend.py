@@ -377,6 +377,52 @@ class HipBackend(object):
         self._note_solve(pre.value)
         return pre.value
 
+    # ---- the reduced solve spread over the ranks (include/pysfm_ba.h ba_dist_*; pysfm_amd/csrc/ba_dist.h)
+    dist_on = False
+
+    def dist_plan(self, nco, half_bandwidth, nranks):
+        """(cameras per node, nodes, nodes per rank) of the cut the library would make, or None when the distributed
+        solve does not apply (ba_dist_plan: a pure function of its arguments, the same on every rank)."""
+        cb, N, P = C.c_int32(), C.c_int32(), C.c_int32()
+        if self._lib.ba_dist_plan(int(nco), int(half_bandwidth), int(nranks), C.byref(cb), C.byref(N), C.byref(P)) != capi.BA_OK:
+            return None
+        return cb.value, N.value, P.value
+
+    def dist_enable(self, rank, nranks):
+        """Switch the trial to the distributed solve (nranks <= 1: off).  Returns ba_dist_info as a dict."""
+        self._check(self._lib.ba_dist_enable(self._h, int(rank), int(nranks)))
+        out = (C.c_int64 * len(capi.DIST_INFO_KEYS))()
+        self._check(self._lib.ba_dist_info(self._h, out, len(capi.DIST_INFO_KEYS)))
+        info = dict(zip(capi.DIST_INFO_KEYS, [int(v) for v in out]))
+        self.dist_on = bool(info['on'])
+        self._dist_info = info
+        self._dist_t = None
+        if self.dist_on and self._torch is not None:
+            # the exchange buffer as a torch tensor (the caller's collectives sum it in place between the stages)
+            torch = self._torch
+            n = max(info['exchange1_doubles'], info['exchange2_doubles'], info['exchange3_doubles'])
+            self._dist_t = torch.zeros(n, dtype=torch.float64, device=torch.device('cuda', self.device))
+            self._check(self._lib.ba_dist_bind_exchange(self._h, C.c_void_p(self._dist_t.data_ptr()), n))
+        return info
+
+    def dist_stage(self, stage, cam_param_mask=None):
+        """ba_dist_stage: returns the slice of the exchange tensor to be summed over the ranks before the next stage
+        (None after stage 4)."""
+        mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
+        n = C.c_int64()
+        self._check(self._lib.ba_dist_stage(self._h, int(stage), capi.bptr(mask), C.byref(n)))
+        return self._dist_t[:n.value] if n.value else None
+
+    def lm_trial_finish(self):
+        """ba_lm_trial_finish: back-substitution, trial set and trial cost once the solution is on the device; the
+        rank's record is in trial_result()."""
+        if getattr(self, '_trial_t', None) is None:
+            torch = self._torch
+            self._trial_t = torch.zeros(capi.TRIAL_PARTIALS + 2, dtype=torch.float64, device=torch.device('cuda', self.device))
+            self._check(self._lib.ba_bind_trial_result(self._h, C.c_void_p(self._trial_t.data_ptr())))
+        self._check(self._lib.ba_lm_trial_finish(self._h))
+        self._note_solve(0)
+
     def _note_solve(self, info):
         """last_solve_kind: the device solver ba_solve_reduced launched ('bcr', 'bcr_wide', 'band',
         'dense_cholesky'); last_solve_path: 'band' / 'dense_cholesky' when it succeeded, 'dense' when

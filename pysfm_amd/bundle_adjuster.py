@@ -220,6 +220,7 @@ class BundleAdjuster(object):
             spread = np.where(hi >= 0, hi - lo, 0)
             be.set_min_half_bandwidth(int(self._comm.allreduce_max(int(spread.max()) if nt else 0)))
         be.set_problem(nc, nt, obs_cam, obs_pt, obs_z, np.asarray(bundle.K, float), cam_opt_pos, pt_opt)
+        self._configure_distributed_solve(be, cam_opt_pos, obs_cam, obs_pt, nt)
         be.set_sensor(*device_params_of(bundle.sensor_model))
         self._upload(bundle, PARAMS_CUR)
         self._have_blocks = False
@@ -227,6 +228,39 @@ class BundleAdjuster(object):
         self._have_W = False
         self._damp_factor = 1.
         self._say('Configured a bundle adjuster for %d cameras, %d tracks' % (nc, nt))
+
+    # bytes of [S | b] above which the sharded adjuster spreads the reduced SOLVE over its ranks instead of summing the whole
+    # band and solving it on every rank (csrc/ba_dist.h): below, one all-reduce of a few MB and a 0.1 ms solve are the faster way
+    DISTRIBUTED_SOLVE_MIN_BYTES = 4 << 20
+    distributed_solve = 'auto'           # 'auto' | True | False
+
+    def _configure_distributed_solve(self, be, cam_opt_pos, obs_cam, obs_pt, nt):
+        """Sharded adjuster: switch the trial to the solve that is spread over the ranks when it applies - the band is large,
+        the library has a cut for (cameras, band width, ranks), and EVERY rank's tracks start inside its own interval
+        (distributed.shard_tracks(plan=...) cuts them that way).  All ranks decide together."""
+        self._dist = False
+        if self._comm is None or not hasattr(be, 'dist_enable'):
+            return
+        comm = self._comm
+        want = self.distributed_solve
+        ok = bool(want) and comm.world_size > 1
+        if want == 'auto':
+            ok = ok and 8 * be.S_doubles >= self.DISTRIBUTED_SOLVE_MIN_BYTES
+        cut = be.dist_plan(be.nco, be.half_bandwidth, comm.world_size) if ok else None
+        ok = ok and cut is not None
+        if ok:
+            cb, N, P = cut
+            pos = cam_opt_pos[np.asarray(obs_cam, int)]
+            first = np.full(nt, np.iinfo(np.int64).max, np.int64)
+            np.minimum.at(first, np.asarray(obs_pt, int)[pos >= 0], pos[pos >= 0])
+            first = first[first < np.iinfo(np.int64).max]
+            lo, hi = comm.rank * P * cb, (comm.rank + 1) * P * cb
+            ok = len(first) == 0 or (first.min() >= lo and (first.max() < hi or comm.rank == comm.world_size - 1))
+        ok = comm._agree(ok)
+        info = be.dist_enable(comm.rank, comm.world_size if ok else 1)
+        self._dist = bool(info['on'])
+        if ok and not self._dist:
+            raise RuntimeError('ba_dist_enable refused a plan ba_dist_plan had accepted')
 
     # ------------------------------------------------------------------ LM loop
     def optimize(self, param_mask=None, max_steps=25, init_damping=10., improvement_threshold=1e-4):
@@ -312,9 +346,18 @@ class BundleAdjuster(object):
                     cam_param_mask = None
             self._damp_factor = 1. + damping
             be.lm_trial_begin(damping, self.SCHUR_COMPLIMENT_PINV_THRESHOLD)
-            self._comm.allreduce_reduced(be)
+            if getattr(self, '_dist', False):
+                # the solve spread over the ranks: three small sums instead of the whole band (csrc/ba_dist.h)
+                for stage in (1, 2, 3):
+                    self._comm.allreduce_exchange(be, be.dist_stage(stage, cam_param_mask))
+                be.dist_stage(4)
+                be.lm_trial_finish()
+                pre = 0
+            else:
+                self._comm.allreduce_reduced(be)
+                pre = be.lm_trial_end(cam_param_mask)
             self._have_blocks = True
-            if be.lm_trial_end(cam_param_mask) == 0:
+            if pre == 0:
                 from ._capi import TRIAL_PARTIALS
                 cost, nsing, info = self._comm.allreduce_trial_result(be, TRIAL_PARTIALS)
                 if nsing > 0 and self.SCHUR_COMPLIMENT_PINV_THRESHOLD is None:

@@ -51,14 +51,15 @@ constexpr int kBcrMaxHB = 11;                  // 4 matrices of B x (B+1) double
 __host__ __device__ inline size_t bcr_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 560) * sizeof(double); }   // + inverses of the current and the previous diagonal block, identity table
 
 // band (+ mask) -> D[N][B][B], U[N][B][B] = T[I,I+1], f[N][B]; cameras past nco and masked
-// parameters become identity rows with zero right-hand side.
-__global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, const double* __restrict__ S,
+// parameters become identity rows with zero right-hand side.  Super-blocks of cb >= hb cameras (B = 6 cb; cb = hb
+// everywhere but in the solve that is spread over several GPUs, which picks cb so that the elimination tree splits evenly).
+__global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, int cb, const double* __restrict__ S,
                                                               const double* __restrict__ b,
                                                               const unsigned char* __restrict__ mask,
                                                               double* __restrict__ Dm, double* __restrict__ Um,
                                                               double* __restrict__ fm, int* __restrict__ info,
                                                               double* __restrict__ xsol = nullptr, int* __restrict__ done = nullptr) {
-  const int B = 6 * hb, hb1 = hb + 1;
+  const int B = 6 * cb, hb1 = hb + 1;
   const int I = blockIdx.x;
   if (I == 0 && threadIdx.x == 0) {
     *info = 0;                                    // status word of this solve (the eliminate levels only ever set it)
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
   if (done && threadIdx.x < 4) done[4 * I + threadIdx.x] = 0;      // "this (node, role) has handed its results on": not yet
   for (int e = threadIdx.x; e < B * B; e += kBcrThreads) {
     const int r = e / B, c = e - r * B;
-    const int i = I * hb + r / 6, j = I * hb + c / 6, a = r % 6, bb = c % 6;
+    const int i = I * cb + r / 6, j = I * cb + c / 6, a = r % 6, bb = c % 6;
     double v;
     if (i >= nco || j >= nco) {
       v = r == c ? 1.0 : 0.0;
@@ -77,14 +78,14 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
         const double* blk = S + band_block(i, i, hb1);                 // diagonal block: use its upper triangle
         v = a <= bb ? blk[a * 6 + bb] : blk[bb * 6 + a];
       } else if (i < j) {
-        v = S[band_block(i, j, hb1) + a * 6 + bb];
+        v = j - i <= hb ? S[band_block(i, j, hb1) + a * 6 + bb] : 0.0;
       } else {
-        v = S[band_block(j, i, hb1) + bb * 6 + a];
+        v = i - j <= hb ? S[band_block(j, i, hb1) + bb * 6 + a] : 0.0;
       }
       if (mask && (!mask[6 * i + a] || !mask[6 * j + bb])) v = (r == c) ? 1.0 : 0.0;
     }
     Dm[(size_t)I * B * B + e] = v;
-    const int j2 = j + hb;
+    const int j2 = j + cb;
     double v2 = 0.0;
     if (i < nco && j2 < nco && j2 - i <= hb) {
       v2 = S[band_block(i, j2, hb1) + a * 6 + bb];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, c
     Um[(size_t)I * B * B + e] = v2;
   }
   for (int r = threadIdx.x; r < B; r += kBcrThreads) {
-    const int i = I * hb + r / 6, a = r % 6;
+    const int i = I * cb + r / 6, a = r % 6;
     fm[(size_t)I * B + r] = (i < nco && (!mask || mask[6 * i + a])) ? b[6 * (size_t)i + a] : 0.0;
     if (xsol) xsol[(size_t)I * B + r] = __longlong_as_double(kBcrNotYet);      // "not solved yet" (k_bcr_backsolve_fused polls the data itself)
   }

@@ -17,6 +17,7 @@
 #include "ba_bcr.h"
 #include "ba_bcr_wide.h"
 #include "ba_dense.h"
+#include "ba_dist.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types only: the entry points are resolved at run time from the librccl torch has loaded
@@ -145,6 +146,20 @@ struct ba_handle {
   int bcr_work_n = 0, bcr_work_s = 0, bcr_work_len = 0;
   DevBuf<long long> bcr_trace;      // PROFILE builds, option solve_trace: the time line of k_bcr_eliminate_fused, 8 words per workgroup
   int bcr_trace_n = 0;
+  // the reduced solve spread over the ranks of a sharded adjuster (ba_dist.h; ba_dist_enable)
+  struct DistPlan {
+    bool on = false;
+    int rank = 0, nranks = 1;
+    int cb = 0, N = 0, P = 0;           // cameras per node, nodes, nodes per interval (its separator included)
+    int n_lo = 0, n_hi = 0;             // this rank's own nodes [n_lo, n_hi) (interior) ...
+    int own_lo = 0, own_hi = 0;         // ... and the camera positions whose solution it contributes (interior + its separator)
+    int nrows = 0, nsep = 0, nroot = 0, nwork_local = 0, nwork_top = 0, norder = 0;
+    DevBuf<int> rows, sep, sep_owner, root, root_owner, work, order;   // work = [local items | separator items]
+    double* xbuf = nullptr;             // the exchange buffer (bound by the caller, or our own)
+    size_t xcap = 0;
+    DevBuf<double> xown;
+    size_t xcount[3] = {0, 0, 0};       // doubles of the three exchanges
+  } dist;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
   DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
@@ -430,7 +445,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   }
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1], marks the solution "not there yet", clears done[]
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, hb, h->S, h->b, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, s_fused ? h->bcr_done.p : nullptr);
   }
   {
@@ -491,6 +506,160 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   return BA_OK;
 }
 
+// ---- the reduced solve spread over the ranks (ba_dist.h) --------------------------------------------------------------
+// Which super-block size cuts nco cameras (band half-width hb) into an elimination tree that splits evenly over nranks = 2^g
+// ranks: the smallest number of levels L, then the smallest cb in [hb, kBcrMaxHB], such that every rank's interval has nodes
+// (the last one at least a quarter of a full interval) and a rank has at least 8 nodes.  false = does not apply.
+bool dist_plan_static(int nco, int hb, int nranks, int* cb_out, int* N_out, int* P_out) {
+  if (nranks < 2 || (nranks & (nranks - 1)) || hb < 1 || hb > kBcrMaxHB) return false;
+  int bestL = 1 << 30, best_cb = 0, bestN = 0, bestP = 0;
+  for (int cb = hb; cb <= kBcrMaxHB; ++cb) {
+    const int N = (nco + cb - 1) / cb;
+    int L = 0;
+    while ((1 << L) - 1 < N) ++L;
+    const int P = (1 << L) / nranks;
+    if (P < 8) continue;
+    const int last = N - (nranks - 1) * P;                  // nodes of the last interval
+    if (last < P / 4) continue;
+    if (L < bestL) { bestL = L; best_cb = cb; bestN = N; bestP = P; }
+  }
+  if (!best_cb) return false;
+  *cb_out = best_cb; *N_out = bestN; *P_out = bestP;
+  return true;
+}
+
+int dist_build_plan(ba_handle* h, int rank, int nranks) {
+  auto& d = h->dist;
+  d.on = false;
+  int cb, N, P;
+  if (!h->have_problem || h->nco == 0 || !dist_plan_static(h->nco, h->hb, nranks, &cb, &N, &P)) return BA_OK;
+  d.rank = rank; d.nranks = nranks; d.cb = cb; d.N = N; d.P = P;
+  d.n_lo = rank * P; d.n_hi = std::min(N, rank * P + P - 1);
+  d.own_lo = std::min(h->nco, d.n_lo * cb); d.own_hi = std::min(h->nco, (rank + 1) * P * cb);
+  const int hb = h->hb, nco = h->nco;
+  std::vector<int> rows, sep, sep_owner, root, root_owner, work, order;
+  for (int t = P - 1; t < N; t += P) {                       // separators: nodes whose stride is >= P
+    sep.push_back(t); sep_owner.push_back((t + 1) / P - 1);
+    for (int c = t * cb; c < std::min(nco, (t + 1) * cb + hb); ++c) rows.push_back(c);      // its rows and the first hb behind it
+  }
+  for (int r = 0; r < nranks; ++r) {
+    const int j = r * P + P / 2 - 1;                         // root of rank r's subtree (stride P / 2)
+    if (j < N) { root.push_back(j); root_owner.push_back(r); }
+  }
+  auto push_items = [&](int i, int s) {
+    if (i - s >= 0) work.push_back(4 * i + 0);
+    if (i + s < N) work.push_back(4 * i + 1);
+    work.push_back(4 * i + 2);
+  };
+  for (int s = 1; s < P; s *= 2)                             // local phase: own interval, leaves first
+    for (int i = s - 1; i < N; i += 2 * s)
+      if (i >= d.n_lo && i < d.n_hi) push_items(i, s);
+  d.nwork_local = (int)work.size();
+  int s_top = P;
+  while (2 * s_top - 1 < N) s_top *= 2;                      // (the largest stride that has a node)
+  for (int s = P; s <= s_top; s *= 2)                        // separator phase (every rank), leaves first
+    for (int i = s - 1; i < N; i += 2 * s) push_items(i, s);
+  d.nwork_top = (int)work.size() - d.nwork_local;
+  for (int s = s_top; s >= 1; s /= 2)                        // back-substitution: separators, then the own interval, root down
+    for (int i = s - 1; i < N; i += 2 * s)
+      if (s >= P || (i >= d.n_lo && i < d.n_hi)) order.push_back(i);
+  d.nrows = (int)rows.size(); d.nsep = (int)sep.size(); d.nroot = (int)root.size(); d.norder = (int)order.size();
+  const size_t B = 6 * (size_t)cb, BB = B * B;
+  d.xcount[0] = (size_t)d.nrows * ((size_t)(hb + 1) * 36 + 6);
+  d.xcount[1] = (size_t)d.nsep * (BB + B) + (size_t)d.nroot * 2 * BB;
+  d.xcount[2] = (size_t)nco * 6;
+  auto up = [&](DevBuf<int>& b, const std::vector<int>& v) -> hipError_t {
+    if (hipError_t e = b.resize(std::max<size_t>(1, v.size())); e != hipSuccess) return e;
+    return v.empty() ? hipSuccess : hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream);
+  };
+  HIPCHECK(h, up(d.rows, rows)); HIPCHECK(h, up(d.sep, sep)); HIPCHECK(h, up(d.sep_owner, sep_owner));
+  HIPCHECK(h, up(d.root, root)); HIPCHECK(h, up(d.root_owner, root_owner)); HIPCHECK(h, up(d.work, work)); HIPCHECK(h, up(d.order, order));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));              // the vectors go out of scope
+  const size_t need = std::max(d.xcount[0], std::max(d.xcount[1], d.xcount[2]));
+  if (!d.xbuf || d.xcap < need) {
+    HIPCHECK(h, d.xown.resize(need));
+    d.xbuf = d.xown.p; d.xcap = need;
+  }
+  d.on = true;
+  return BA_OK;
+}
+
+int dist_upload_mask(ba_handle* h, const uint8_t* cam_param_mask, const unsigned char** dmask) {
+  *dmask = nullptr;
+  if (!cam_param_mask) return BA_OK;
+  bool all = true;
+  for (int i = 0; i < h->nco * 6; ++i) all = all && cam_param_mask[i];
+  if (all) return BA_OK;
+  HIPCHECK(h, hipMemcpyAsync(h->mask.p, cam_param_mask, (size_t)h->nco * 6, hipMemcpyHostToDevice, h->stream));
+  *dmask = h->mask.p;
+  return BA_OK;
+}
+
+// Stage 1: shared rows of this rank's partial [S | b] -> exchange buffer.  Stage 2 (after the sum): rows back, assemble,
+// eliminate the own interval, separators + subtree roots -> buffer.  Stage 3 (after the sum): separators back, eliminate them,
+// back-substitute separators + own interval, owned solution entries -> buffer.  Stage 4 (after the sum): the full dC.
+int dist_stage(ba_handle* h, int stage, const uint8_t* cam_param_mask, size_t* count) {
+  auto& d = h->dist;
+  const int cb = d.cb, B = 6 * cb, N = d.N, hb1 = h->hb + 1;
+  const size_t BB = (size_t)B * B;
+  *count = 0;
+  if (stage == 1) {
+    hipLaunchKernelGGL(k_dist_rows, dim3(std::max(1u, std::min(1024u, blocks_for((long long)d.xcount[0])))), dim3(256), 0, h->stream, d.nrows,
+                       d.rows.p, hb1, h->S, h->b, d.xbuf, 0);
+    *count = d.xcount[0];
+  } else if (stage == 2) {
+    hipLaunchKernelGGL(k_dist_rows, dim3(std::max(1u, std::min(1024u, blocks_for((long long)d.xcount[0])))), dim3(256), 0, h->stream, d.nrows,
+                       d.rows.p, hb1, h->S, h->b, d.xbuf, 1);
+    HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
+    HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
+    HIPCHECK(h, h->bcrF.resize((size_t)N * B)); HIPCHECK(h, h->bcrGv.resize((size_t)N * B));
+    HIPCHECK(h, h->bcr_done.resize((size_t)4 * N));
+    const unsigned char* dmask = nullptr;
+    if (int rc = dist_upload_mask(h, cam_param_mask, &dmask); rc != BA_OK) return rc;
+    {
+      ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
+      hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, cb, h->S, h->b, dmask, h->bcrD.p,
+                         h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, h->bcr_done.p);
+      hipLaunchKernelGGL(k_dist_zero_separators, dim3(8, std::max(1, d.nsep)), dim3(256), 0, h->stream, d.nsep, d.sep.p, d.sep_owner.p, d.rank, B,
+                         h->bcrD.p, h->bcrF.p);
+    }
+    if (d.nwork_local > 0) {
+      ScopedTimer tm(h, BA_K_BCR_ELIMINATE, 1);
+      HIPCHECK(h, launch_bcr_fused(h, cb, d.nwork_local, h->stream, N, 1, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
+                                   h->bcrGv.p, h->flags.p + 1, h->dC.p, d.work.p, h->bcr_done.p));
+    }
+    hipLaunchKernelGGL(k_dist_top, dim3(8, d.nsep + d.nroot), dim3(256), 0, h->stream, d.nsep, d.sep.p, d.nroot, d.root.p, d.root_owner.p,
+                       d.rank, B, h->bcrD.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, d.xbuf, 0);
+    *count = d.xcount[1];
+  } else if (stage == 3) {
+    hipLaunchKernelGGL(k_dist_top, dim3(8, d.nsep + d.nroot), dim3(256), 0, h->stream, d.nsep, d.sep.p, d.nroot, d.root.p, d.root_owner.p,
+                       d.rank, B, h->bcrD.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, d.xbuf, 1);
+    if (d.nwork_top > 0) {
+      ScopedTimer tm(h, BA_K_BCR_ELIMINATE, 1);      // (the tickets go on from where the local phase stopped: one work list)
+      HIPCHECK(h, launch_bcr_fused(h, cb, d.nwork_top, h->stream, N, d.P, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
+                                   h->bcrGv.p, h->flags.p + 1, h->dC.p, d.work.p, h->bcr_done.p));
+    }
+    {
+      const size_t lds2 = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
+      HIPCHECK(h, ensure_lds_attr(h, (const void*)k_bcr_backsolve_fused));
+      ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, 1);
+      hipLaunchKernelGGL(k_bcr_backsolve_fused, dim3(d.norder), dim3(kBcrElimThreads), lds2, h->stream, N, B, h->bcrGv.p, h->bcrF.p, 1,
+                         h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p, d.order.p, h->flags.p + 1 + kBcrTicketWord);
+    }
+    hipLaunchKernelGGL(k_dist_solution, dim3(blocks_for((long long)h->nco * 6)), dim3(256), 0, h->stream, h->nco * 6, d.own_lo * 6, d.own_hi * 6,
+                       h->dC.p, d.xbuf, 0);
+    *count = d.xcount[2];
+  } else if (stage == 4) {
+    hipLaunchKernelGGL(k_dist_solution, dim3(blocks_for((long long)h->nco * 6)), dim3(256), 0, h->stream, h->nco * 6, 0, 0, h->dC.p, d.xbuf, 1);
+    h->solve_kind = BA_SOLVE_BCR;
+    h->have_solution = true;
+  } else {
+    return h->fail(BA_ERR_INVALID_ARG, "ba_dist_stage: stage %d", stage);
+  }
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
 // factor + solve of one level (both are templates on the half-bandwidth)
 template <int HB>
 hipError_t launch_bcrw_factor_hb(ba_handle* h, int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
@@ -527,7 +696,7 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, h->S, h->b, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, hb, h->S, h->b, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, (double*)nullptr);
   }
   std::vector<int> strides;
@@ -723,7 +892,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->dist.order.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1307,6 +1476,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   // a reduced system bound for another problem size is no longer valid
   h->S = nullptr; h->b = nullptr;
   h->have_problem = true;
+  h->dist.on = false;                 // (a cut of the solve over the ranks belongs to the problem it was made for: ba_dist_enable)
   h->have_params[0] = h->have_params[1] = false;
   h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
   h->cur = 0;
@@ -2205,22 +2375,83 @@ int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   return rc;
 }
 
-int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_info) {
+// the tail of a trial once the solution is on the device: back-substitution, trial parameter set, trial cost - nothing read back
+int ba_lm_trial_finish(ba_handle* h) {
   if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, pre_info, BA_ERR_INVALID_ARG, "ba_lm_trial_end: NULL output");
-  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_lm_trial_end: call ba_lm_trial_begin first");
-  *pre_info = 0;
+  REQUIRE(h, h->have_schur && h->have_solution, BA_ERR_STATE, "ba_lm_trial_finish: no solution on the device");
   h->defer = true;
   double unused = 0.0;
-  int rc = ba_solve_reduced(h, cam_param_mask, pre_info);
-  if (rc == BA_OK && *pre_info != 0) { h->defer = false; return BA_OK; }   // band too wide: caller takes the dense path
-  if (rc == BA_OK) rc = ba_backsubstitute(h, BA_PARAMS_CUR, nullptr, nullptr);
+  int rc = ba_backsubstitute(h, BA_PARAMS_CUR, nullptr, nullptr);
   if (rc == BA_OK) {
     if (h->nt > 0) h->have_params[h->phys(BA_PARAMS_TRIAL)] = true;      // k_backsub wrote the trial set
     else rc = ba_apply_update(h, BA_PARAMS_CUR, BA_PARAMS_TRIAL, nullptr, nullptr);
   }
   if (rc == BA_OK && !(h->cost_fused && h->nt > 0)) rc = ba_cost(h, BA_PARAMS_TRIAL, &unused);
   h->defer = false;
+  return rc;
+}
+
+int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_info) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, pre_info, BA_ERR_INVALID_ARG, "ba_lm_trial_end: NULL output");
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_lm_trial_end: call ba_lm_trial_begin first");
+  *pre_info = 0;
+  h->defer = true;
+  int rc = ba_solve_reduced(h, cam_param_mask, pre_info);
+  h->defer = false;
+  if (rc == BA_OK && *pre_info != 0) return BA_OK;   // band too wide: caller takes the dense path
+  if (rc == BA_OK) rc = ba_lm_trial_finish(h);
+  return rc;
+}
+
+// ---- the reduced solve spread over the ranks (ba_dist.h)
+int ba_dist_plan(int32_t nco, int32_t half_bandwidth, int32_t nranks, int32_t* cams_per_node, int32_t* nodes, int32_t* nodes_per_rank) {
+  int cb = 0, N = 0, P = 0;
+  if (!dist_plan_static(nco, half_bandwidth, nranks, &cb, &N, &P)) return BA_ERR_STATE;
+  if (cams_per_node) *cams_per_node = cb;
+  if (nodes) *nodes = N;
+  if (nodes_per_rank) *nodes_per_rank = P;
+  return BA_OK;
+}
+
+int ba_dist_enable(ba_handle* h, int32_t rank, int32_t nranks) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_dist_enable: set the problem first");
+  REQUIRE(h, nranks < 2 || (rank >= 0 && rank < nranks), BA_ERR_INVALID_ARG, "ba_dist_enable: bad rank");
+  HIPCHECK(h, hipSetDevice(h->device));
+  h->dist.on = false;
+  if (nranks < 2 || h->dense_mode) return BA_OK;
+  return dist_build_plan(h, rank, nranks);
+}
+
+int ba_dist_info(ba_handle* h, int64_t* out, int32_t n) {
+  if (!h || !out) return BA_ERR_INVALID_ARG;
+  const auto& d = h->dist;
+  const int64_t v[12] = {d.on, d.cb, d.N, d.P, d.n_lo, d.n_hi, d.own_lo, d.own_hi, (int64_t)d.xcount[0], (int64_t)d.xcount[1],
+                         (int64_t)d.xcount[2], d.nsep};
+  for (int i = 0; i < n && i < 12; ++i) out[i] = d.on || i == 0 ? v[i] : 0;
+  return BA_OK;
+}
+
+int ba_dist_bind_exchange(ba_handle* h, void* dev, int64_t doubles) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  auto& d = h->dist;
+  REQUIRE(h, d.on, BA_ERR_STATE, "ba_dist_bind_exchange: the distributed solve is off");
+  const size_t need = std::max(d.xcount[0], std::max(d.xcount[1], d.xcount[2]));
+  REQUIRE(h, dev && (size_t)doubles >= need, BA_ERR_INVALID_ARG, "ba_dist_bind_exchange: buffer too small");
+  d.xbuf = (double*)dev; d.xcap = (size_t)doubles;
+  return BA_OK;
+}
+
+int ba_dist_stage(ba_handle* h, int32_t stage, const uint8_t* cam_param_mask, int64_t* doubles_to_sum) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->dist.on, BA_ERR_STATE, "ba_dist_stage: the distributed solve is off (ba_dist_enable)");
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_dist_stage: call ba_lm_trial_begin first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  size_t count = 0;
+  h->have_solution = false;
+  int rc = dist_stage(h, stage, cam_param_mask, &count);
+  if (doubles_to_sum) *doubles_to_sum = (int64_t)count;
   return rc;
 }
 
@@ -2234,8 +2465,19 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   if (h->have_problem && h->hb > kBcrwMaxHB && 6 * h->nco > kDcMaxN) { *info = -1; return BA_OK; }
   int32_t pre = 0;
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
-  if (rc == BA_OK && h->comm) rc = comm_allreduce_reduced(h);      // sharded: the one data-path collective
-  if (rc == BA_OK) rc = ba_lm_trial_end(h, cam_param_mask, &pre);
+  const bool dist = h->comm && h->dist.on && h->hb <= kBcrMaxHB;
+  if (dist) {
+    // the solve spread over the ranks (ba_dist.h): three small sums instead of one of the whole band
+    for (int stage = 1; stage <= 4 && rc == BA_OK; ++stage) {
+      size_t count = 0;
+      rc = dist_stage(h, stage, cam_param_mask, &count);
+      if (rc == BA_OK && count) RCCLCHECK(h, g_rccl.AllReduce(h->dist.xbuf, h->dist.xbuf, count, ncclFloat64, ncclSum, h->comm, h->stream));
+    }
+    if (rc == BA_OK) rc = ba_lm_trial_finish(h);
+  } else {
+    if (rc == BA_OK && h->comm) rc = comm_allreduce_reduced(h);      // sharded: the one data-path collective
+    if (rc == BA_OK) rc = ba_lm_trial_end(h, cam_param_mask, &pre);
+  }
   if (rc != BA_OK) return rc;
   if (pre != 0) { *info = pre; return BA_OK; }
   int st[2];
@@ -2251,7 +2493,9 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
     for (int i = 0; i < kCostBlocks; ++i) sum += h->comm_host[i];
     *next_cost = sum;
     st[0] = (int)std::llround(h->comm_host[kCostBlocks]);                          // over all shards
-    st[1] = (int)std::llround(h->comm_host[kCostBlocks + 1] / h->comm_ranks);      // every rank solves the same system
+    // every rank solves the same system (status x ranks) - or, with the solve spread over the ranks, its own part of it
+    st[1] = dist ? (h->comm_host[kCostBlocks + 1] != 0.0 ? (int)std::min(2.0e9, std::max(1.0, std::fabs(h->comm_host[kCostBlocks + 1]))) : 0)
+                 : (int)std::llround(h->comm_host[kCostBlocks + 1] / h->comm_ranks);
   } else {
     HIPCHECK(h, hipStreamSynchronize(h->stream));    // k_cost left the cost partials + status words in pinned memory
     st[0] = h->host_result->singular_points; st[1] = h->host_result->solve_info;

@@ -45,18 +45,49 @@ def shard_bounds(track_lengths, world_size):
     return bounds
 
 
-def shard_tracks(bundle, rank, world_size):
+def tree_cut(bundle, world_size, plan):
+    """Where the reduced solve spread over the ranks (csrc/ba_dist.h) wants the tracks cut: `plan(nco, hb, world)` is
+    HipBackend.dist_plan; assumes the adjuster's default selection (every camera but the first optimised: position =
+    camera index - 1).  Returns the camera INDICES at which rank r's tracks start (length world + 1), or None."""
+    cam, trk, _ = bundle.observation_table()
+    nc, nt = len(bundle.cameras), len(bundle.tracks)
+    if nc < 3 or nt == 0:
+        return None
+    pos = np.asarray(cam, np.int64) - 1
+    ok = pos >= 0
+    lo = np.full(nt, np.iinfo(np.int64).max, np.int64)
+    hi = np.full(nt, -1, np.int64)
+    np.minimum.at(lo, np.asarray(trk)[ok], pos[ok])
+    np.maximum.at(hi, np.asarray(trk)[ok], pos[ok])
+    hb = int(np.max(np.where(hi >= 0, hi - lo, 0)))
+    cut = plan(nc - 1, max(hb, 1), world_size)
+    if cut is None:
+        return None
+    cb, N, P = cut
+    return [0] + [min(nc, r * P * cb + 1) for r in range(1, world_size)] + [nc]
+
+
+def shard_tracks(bundle, rank, world_size, plan=None):
     """Track ids owned by `rank`: the tracks ordered by their first camera (the caller's order when that is
-    already ascending), cut into `world_size` consecutive, observation-balanced ranges - a rank's partial
-    reduced system then covers one stretch of the band instead of all of it, whatever order the tracks
-    come in.  A rank may get no tracks when there are more ranks than usable tracks."""
+    already ascending), cut into `world_size` consecutive ranges - a rank's partial reduced system then covers one
+    stretch of the band instead of all of it, whatever order the tracks come in.  Where the cuts fall: with `plan`
+    (HipBackend.dist_plan) and a scene the distributed reduced solve applies to, at the camera positions its elimination
+    tree is cut at (tree_cut); otherwise balanced by observation count.  A rank may get no tracks when there are more
+    ranks than usable tracks."""
     cam, trk, _ = bundle.observation_table()
     nt = len(bundle.tracks)
     L = np.bincount(trk, minlength=nt)
     first = np.full(nt, np.iinfo(np.int64).max, np.int64)
     np.minimum.at(first, trk, cam)
     order = np.arange(nt) if np.all(np.diff(first) >= 0) else np.argsort(first, kind='stable')
-    b = shard_bounds(L[order], world_size)
+    cuts = tree_cut(bundle, world_size, plan) if plan is not None and world_size > 1 else None
+    if cuts is not None:
+        # a track belongs to the rank whose interval holds its first OPTIMISED camera (camera 0, the frozen one, counts as 1)
+        f = np.maximum(first[order], 1)
+        b = [int(np.searchsorted(f, c, side='left')) for c in cuts[:-1]] + [nt]
+        b[0] = 0
+    else:
+        b = shard_bounds(L[order], world_size)
     return [int(k) for k in order[b[rank]:b[rank + 1]]]
 
 
@@ -167,6 +198,12 @@ class ShardComm(object):
             self._all_reduce_device(payload)
         self.bytes_reduced += payload.numel() * 8
 
+    def allreduce_exchange(self, backend, t):
+        """One of the three small sums of the distributed reduced solve (HipBackend.dist_stage), in place."""
+        with _stream_of(backend):
+            self._all_reduce_device(t)
+        self.bytes_reduced += t.numel() * 8
+
     def allreduce_trial_result(self, backend, npartials):
         """Sum of the ranks' trial costs from the device buffer HipBackend.trial_result()
         (no host round trip before the collective); ONE synchronisation for the three numbers.
@@ -185,7 +222,12 @@ class ShardComm(object):
                 torch.cuda.current_stream().synchronize()
         h = self._trial_host.numpy()
         world = self._dist.get_world_size(self.group)
-        return float(h[:npartials].sum()), int(round(h[npartials])), int(round(h[npartials + 1] / world))
+        status = h[npartials + 1]
+        if getattr(backend, 'dist_on', False):          # every rank reports on its own part of the solve: any non-zero = failed
+            status = 0 if status == 0 else max(1., min(2e9, abs(status)))
+        else:
+            status = status / world
+        return float(h[:npartials].sum()), int(round(h[npartials])), int(round(status))
 
     def _all_reduce_device(self, t):
         """Sum a device tensor over the ranks in place.  RCCL does it on the device; a gloo group (the

@@ -465,7 +465,7 @@ def test_config5_trial_end_to_end_on_a_masked_sub_block(be, config5):
 
 
 # ------------------------------------------------------------------ sharded, config-5-shaped
-def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle):
+def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle, dist_solve=True, mask_some=False):
     import sys
     for p in (ROOT, os.path.join(ROOT, 'tests')):
         if p not in sys.path:
@@ -482,49 +482,67 @@ def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle):
     b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
     comm = ShardComm()
     ba = BundleAdjuster(device=0, comm=comm, verbose=False)          # all ranks on GPU 0
-    ids = shard_tracks(b, rank, world)
+    ba.distributed_solve = bool(dist_solve)
+    ids = shard_tracks(b, rank, world, plan=ba.backend.dist_plan if dist_solve else None)
     ba.set_bundle(b, track_ids=ids)
-    ba.optimize(max_steps=5)
+    mask = None
+    if mask_some:
+        mask = np.ones(6 * (nc - 1) + 3 * len(ids), bool)
+        mask[6 * 700 + 2:6 * 760:7] = False                         # some camera parameters deleted from the system
+    ba.optimize(param_mask=mask, max_steps=5)
     X = comm.gather_points(ba)
     R, t, _ = ba.backend.get_params(0)
     # the shard's cameras: a contiguous stretch of the sequence even when the tracks came shuffled
     cams = np.unique(s['obs_cam'][np.isin(s['obs_pt'], ids)])
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), costs=np.array(ba.costs), X=X, R=R, t=t, trials=ba.lm_trials,
              nbytes=comm.bytes_reduced, hb=ba.backend.half_bandwidth, kind=ba.backend.last_solve_kind, cam_lo=cams.min(),
-             cam_hi=cams.max(), ntracks=len(ids))
+             cam_hi=cams.max(), ntracks=len(ids), dist=int(getattr(ba, '_dist', False)), band_bytes=8 * ba.backend.S_doubles)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,shuffle', [(2, False), (4, True)])
-def test_ranks_on_one_gpu_config5_shape(tmp_path, world, shuffle):
-    """A config-5-shaped scene (2400 cameras: 267 cyclic-reduction nodes, 9 levels; 60 000 points) split by points over
-    `world` processes on the one GPU (gloo group staging the collectives through the host): the sharded LM trajectory,
-    cameras and points must reproduce the unsharded run; each shard covers one stretch of the camera sequence."""
+@pytest.mark.parametrize('world,shuffle,dist_solve,mask_some', [(2, False, True, False), (4, True, True, True), (8, False, True, False),
+                                                               (2, False, False, False), (4, True, False, True)])
+def test_ranks_on_one_gpu_config5_shape(tmp_path, world, shuffle, dist_solve, mask_some):
+    """A config-5-shaped scene (2400 cameras: 240 cyclic-reduction nodes of 10 cameras, 8 levels; 60 000 points) split by
+    points over `world` processes on the one GPU (gloo group staging the collectives through the host): the sharded LM
+    trajectory, cameras and points must reproduce the unsharded run; each shard covers one stretch of the camera sequence.
+    dist_solve: the reduced solve spread over the ranks (csrc/ba_dist.h: three small sums per trial) - or, off, the whole
+    band summed and solved by every rank.  mask_some: camera parameters deleted from the system (bundle_adjuster.py:290-299)."""
     import socket
     import torch.multiprocessing as mp
     from pysfm_amd import Bundle, BundleAdjuster
     from pysfm_amd import synthetic_data as sd
     nc, nt = 2400, 60000
     sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
-    mp.spawn(_c5_rank_worker, args=(world, port, str(tmp_path), nc, nt, shuffle), nprocs=world, join=True)
+    mp.spawn(_c5_rank_worker, args=(world, port, str(tmp_path), nc, nt, shuffle, dist_solve, mask_some), nprocs=world, join=True)
     s = sd.generate_banded_scene(nc, nt)
     if shuffle:
         s = shuffled(s)[0]
     b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
     ba = BundleAdjuster(verbose=False)
     ba.set_bundle(b)
-    ba.optimize(max_steps=5)
+    mask = None
+    if mask_some:
+        mask = np.ones(6 * (nc - 1) + 3 * nt, bool)
+        mask[6 * 700 + 2:6 * 760:7] = False
+    ba.optimize(param_mask=mask, max_steps=5)
     R1, t1, X1 = ba.backend.get_params(0)
     total = 0
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
         assert int(d['trials']) == ba.lm_trials and int(d['nbytes']) > 0
+        assert int(d['dist']) == int(dist_solve)
+        per_trial = int(d['nbytes']) / int(d['trials'])
+        if dist_solve:        # three small sums per trial: a fraction of the band [S | b] (2 ranks: one separator; more ranks: more of them)
+            assert per_trial <= int(d['band_bytes']) / (5 if world <= 4 else 2.5), (per_trial, int(d['band_bytes']))
+        else:
+            assert per_trial >= int(d['band_bytes'])
         assert int(d['hb']) == 9 and str(d['kind']) == 'bcr'
         close(d['costs'], np.array(ba.costs), 1e-9)
         close(d['t'], t1, 1e-8)
         close(d['X'], X1, 1e-8)
-        assert int(d['cam_hi']) - int(d['cam_lo']) <= nc // world + 40
+        assert int(d['cam_hi']) - int(d['cam_lo']) <= (nc // world + 40 if not dist_solve else 2 * nc // world + 40)
         total += int(d['ntracks'])
     assert total == nt
     ba.backend.close()
