@@ -67,31 +67,41 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, i
     info[kBcrTicketWord - 1] = 0;                 // ... and of k_bcr_eliminate_fused (kBcrElimTicketWord)
   }
   if (done && threadIdx.x < 4) done[4 * I + threadIdx.x] = 0;      // "this (node, role) has handed its results on": not yet
-  for (int e = threadIdx.x; e < B * B; e += kBcrThreads) {
-    const int r = e / B, c = e - r * B;
+  // every load of a thread is issued before its first store (one round trip to memory instead of one per entry): the address
+  // of an entry that is not in the band is that of S[0], its value is then multiplied away - a select on the loaded value
+  // would compile to a branch around every load
+  constexpr int NIT = 3;             // entries per thread and round (B = 54: one round; the wide solver's B = 138: seven)
+  for (int base = 0; base < B * B; base += NIT * kBcrThreads) {
+  double vd[NIT], vu[NIT], kd[NIT], ku[NIT], idv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = base + threadIdx.x + it * kBcrThreads;
+    const int ec = e < B * B ? e : 0;
+    const int r = ec / B, c = ec - r * B;
     const int i = I * cb + r / 6, j = I * cb + c / 6, a = r % 6, bb = c % 6;
-    double v;
-    if (i >= nco || j >= nco) {
-      v = r == c ? 1.0 : 0.0;
-    } else {
-      if (i == j) {
-        const double* blk = S + band_block(i, i, hb1);                 // diagonal block: use its upper triangle
-        v = a <= bb ? blk[a * 6 + bb] : blk[bb * 6 + a];
-      } else if (i < j) {
-        v = j - i <= hb ? S[band_block(i, j, hb1) + a * 6 + bb] : 0.0;
-      } else {
-        v = i - j <= hb ? S[band_block(j, i, hb1) + bb * 6 + a] : 0.0;
-      }
-      if (mask && (!mask[6 * i + a] || !mask[6 * j + bb])) v = (r == c) ? 1.0 : 0.0;
-    }
-    Dm[(size_t)I * B * B + e] = v;
+    const bool inside = i < nco && j < nco;
+    const bool masked = inside && mask && (!mask[6 * i + a] || !mask[6 * j + bb]);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const bool inband = inside && !masked && hi - lo <= hb;
+    // diagonal block: its upper triangle; above the diagonal (i < j): entry (a, bb) of block (i, j); below: (bb, a) of block (j, i)
+    const bool flip = i > j || (i == j && a > bb);
+    const size_t off = inband ? band_block(lo, hi, hb1) + (flip ? bb * 6 + a : a * 6 + bb) : 0;
+    vd[it] = S[off];
+    kd[it] = inband ? 1.0 : 0.0;
+    idv[it] = (!inside || masked) && r == c ? 1.0 : 0.0;           // cameras past the end, masked parameters: identity rows
     const int j2 = j + cb;
-    double v2 = 0.0;
-    if (i < nco && j2 < nco && j2 - i <= hb) {
-      v2 = S[band_block(i, j2, hb1) + a * 6 + bb];
-      if (mask && (!mask[6 * i + a] || !mask[6 * j2 + bb])) v2 = 0.0;
+    const bool uin = i < nco && j2 < nco && j2 - i <= hb && !(mask && (!mask[6 * i + a] || !mask[6 * j2 + bb]));
+    vu[it] = S[uin ? band_block(i, j2, hb1) + a * 6 + bb : 0];
+    ku[it] = uin ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = base + threadIdx.x + it * kBcrThreads;
+    if (e < B * B) {
+      Dm[(size_t)I * B * B + e] = kd[it] != 0.0 ? vd[it] : idv[it];
+      Um[(size_t)I * B * B + e] = ku[it] != 0.0 ? vu[it] : 0.0;
     }
-    Um[(size_t)I * B * B + e] = v2;
+  }
   }
   for (int r = threadIdx.x; r < B; r += kBcrThreads) {
     const int i = I * cb + r / 6, a = r % 6;

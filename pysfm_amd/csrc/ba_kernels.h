@@ -2081,7 +2081,10 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
 // point hold its observations and the old camera; the updated camera R exp(sign dC), t + sign dt is
 // formed once per group per lane, the updated point comes from the point's first lane through LDS.
 // Partials and status words go where k_cost puts them (one partial per workgroup, <= kCostBlocks).
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_backsub_groups(DevProblem P, const double* __restrict__ cams,
+#ifndef BA_BACKSUB_WAVES
+#define BA_BACKSUB_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKSUB_WAVES, BA_BACKSUB_WAVES))) void k_backsub_groups(DevProblem P, const double* __restrict__ cams,
                                                            const double* __restrict__ X,
                                                            const SchurGroup* __restrict__ groups, int ngroups,
                                                            const double* __restrict__ dC,
