@@ -215,13 +215,16 @@ int ba_set_dense_visibility(ba_handle* h, int32_t on);
  * dense blocked Cholesky of the whole matrix (hb > 23, up to 16000 unknowns).
  * cam_param_mask[nco*6] (host, may be NULL = all kept): 0 deletes that camera parameter
  * from the system (its solution entry is 0).  *info: 0 = solved, solution stays on the
- * device for ba_backsubstitute / ba_get_solution; > 0 = pivot `info` was not positive
- * (system not SPD: use ba_flatten_reduced + LU, which has the reference's LinAlgError
+ * device for ba_backsubstitute / ba_get_solution; > 0 = pivot `info` was not positive and, for half-bandwidths
+ * up to 11, the second attempt - the same cyclic reduction with LU nodes (partial pivoting inside a node: what the
+ * reference's numpy.linalg.solve does with a matrix that is not positive definite; option device_lu, kind
+ * BA_SOLVE_BCR_LU) - met a singular node
+ * (use ba_flatten_reduced + LU, which has the reference's LinAlgError
  * semantics; 0x7f000001 = the back-substitution of the cyclic reduction gave up waiting for a value that
  * never came - a bug upstream, reported instead of hanging the GPU; treat like any other failed solve);
  * -1 = too large for the device solvers (same fallback).
  * ba_last_solve_kind: which solver the last ba_solve_reduced launched. */
-enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY };
+enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY, BA_SOLVE_BCR_LU };
 #define BA_SOLVE_TIMED_OUT 0x7f000001   /* *info of a cyclic reduction whose workgroups gave up waiting for each other */
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);

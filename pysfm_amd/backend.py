@@ -41,6 +41,7 @@ class ReducedSystemSingular(Exception):
 
 class HipBackend(object):
     lu_fallback_max_unknowns = LU_FALLBACK_MAX_UNKNOWNS     # per instance: BundleAdjuster(lu_fallback_max_unknowns=...)
+    device_lu = True                    # ba_solve_reduced retries a not-positive-definite system with LU nodes (option device_lu)
     poison_after_set_problem = False    # tests/conftest.py sets it: every problem starts from NaNs in all LDS / workspace (ba_debug_poison)
 
     def __init__(self, device=0):
@@ -119,6 +120,8 @@ class HipBackend(object):
         if isinstance(value, bool):
             value = '1' if value else '0'
         self._check(self._lib.ba_set_option(self._h, str(name).encode(), str(value).encode()))
+        if name == 'device_lu':
+            self.device_lu = str(value) not in ('0', 'False')
 
     # ---------------------------------------------------------------- problem
     def set_min_half_bandwidth(self, min_hb):
@@ -425,7 +428,7 @@ class HipBackend(object):
 
     def _note_solve(self, info):
         """last_solve_kind: the device solver ba_solve_reduced launched ('bcr', 'bcr_wide', 'band',
-        'dense_cholesky'); last_solve_path: 'band' / 'dense_cholesky' when it succeeded, 'dense' when
+        'dense_cholesky'; 'bcr_lu' = the cyclic reduction with LU nodes, after 'bcr' found the system not positive definite); last_solve_path: 'band' / 'dense_cholesky' when it succeeded, 'dense' when
         the flattened system went (or has to go) through LU instead."""
         self.last_solve_kind = capi.SOLVE_KINDS[self._lib.ba_last_solve_kind(self._h)]
         if info != 0:

@@ -333,9 +333,10 @@ class BundleAdjuster(object):
                 next_cost = cost
             elif info == SOLVER_TIMED_OUT:
                 self._note_solver_timeout(damping)                 # a solver bug, not a property of the system: said loudly,
-            elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):     # the stepwise path below solves again
+            elif info > 0 and not self._device_lu_applies(be) and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):
                 self._note_ill_conditioned(be, damping)
                 return None, None                              # not positive definite, too large for LU: ill-conditioned
+            # (otherwise the stepwise path below solves again: cyclic reduction with LU nodes on the device, or LU of the flattened system)
         elif self._comm is not None and hasattr(be, 'lm_trial_begin'):
             # sharded: the same batch in two halves around the all-reduce of [S | b]; the ranks' trial
             # costs are summed on the device, one synchronisation per trial
@@ -366,7 +367,7 @@ class BundleAdjuster(object):
                     next_cost = cost
                 elif info == SOLVER_TIMED_OUT:
                     self._note_solver_timeout(damping)
-                elif info > 0 and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):
+                elif info > 0 and not self._device_lu_applies(be) and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):
                     self._note_ill_conditioned(be, damping)
                     return None, None
         if next_cost is None:
@@ -384,6 +385,13 @@ class BundleAdjuster(object):
             self._cur_cost = next_cost
             return True, next_cost
         return False, next_cost
+
+    @staticmethod
+    def _device_lu_applies(be):
+        """A reduced system the device Cholesky reported as not positive definite is solved again on the device by the cyclic
+        reduction with LU nodes (ba_solve_reduced, option device_lu) - the reference's own LU semantics at any size - when the
+        solver was the narrow cyclic reduction and the adjuster is not sharded over ranks with the solve spread over them."""
+        return bool(getattr(be, 'device_lu', False)) and getattr(be, 'last_solve_kind', None) == 'bcr' and not getattr(be, 'dist_on', False)
 
     def _note_ill_conditioned(self, be, damping):
         """The device Cholesky found the reduced system not positive definite and it is too large for the LU
@@ -459,6 +467,8 @@ class BundleAdjuster(object):
             be.solve_reduced(None if np.all(cam_param_mask) else cam_param_mask)
         except ReducedSystemSingular:
             raise NormalEquationsIllconditioned
+        if getattr(be, 'last_solve_kind', None) == 'bcr_lu':
+            self.lu_node_solves = getattr(self, 'lu_node_solves', 0) + 1      # (diagnostics: how often the LU semantics were needed)
         dC = be.get_solution() if fetch else None
         dP = be.backsubstitute(PARAMS_CUR, None, fetch=fetch)
         return dC, dP

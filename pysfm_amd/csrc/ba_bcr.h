@@ -1469,6 +1469,136 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, 
 #endif
 }
 
+// --------------------------------------------------------------------------
+// The elimination level for reduced systems that are NOT positive definite - the reference solves its reduced system by LU
+// (numpy.linalg.solve = gesv, bundle_adjuster.py:302-305), which also "succeeds" on a symmetric matrix that the round-off of
+// a nearly singular scene (the damping decayed to 1e-10 at the noise floor, the free scale of a monocular reconstruction) has
+// pushed indefinite; a Cholesky factorisation reports such a matrix, it cannot solve it.  Here a node is eliminated by
+// Gauss-Jordan with PARTIAL PIVOTING inside its B x B block:  [Zl | Zr | z] = D_i^-1 [T_il | T_ir | f_i]  with row
+// interchanges among the B rows of the node; the neighbours take the same Schur-complement updates as in the Cholesky kernels,
+//     D_l -= T_il^T Zl,  D_r -= T_ir^T Zr,  T[l,r] = -T_il^T Zr,  f_l -= T_il^T z,  f_r -= T_ir^T z,
+// and the back-substitution kernels run unchanged on  P = Zl, Q = Zr, g = z, G^-1 = I  (x_i = z - Zl x_l - Zr x_r).
+// This is block LU in the cyclic-reduction order with pivoting restricted to a node: it needs every D_i it meets to be
+// non-singular (status word = first zero pivot, like LAPACK's info), not positive.  Plain vector code, one workgroup per node,
+// a launch per level: it only runs after the Cholesky solve has failed (~0.2 ms for 1000 cameras against 70 ms for
+// rocSOLVER's LU of the flattened 5994 x 5994 system).
+// --------------------------------------------------------------------------
+__host__ __device__ inline size_t bcr_lu_lds_bytes(int B) { return ((size_t)B * (3 * B + 1) + 2 * B + 16) * sizeof(double); }
+
+template <int HB>
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_lu(int N, int s, double* __restrict__ Dm, double* __restrict__ Um,
+                                                                      double* __restrict__ fm, double* __restrict__ Pm,
+                                                                      double* __restrict__ Qm, double* __restrict__ Gi,
+                                                                      int* __restrict__ info, double* __restrict__ xout) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int B = 6 * HB, W = 3 * B + 1;                  // row of the augmented matrix: D | T_il | T_ir | f
+  double* A = sm;                                           // [B][W]
+  double* colk = A + (size_t)B * W;                         // [B]  column k of the current step
+  int* rowof = reinterpret_cast<int*>(colk + B);            // [B]  row that was pivot of column k; then [B] used flags
+  int* used = rowof + B;
+  int* piv = used + B;                                      // [2]  pivot row of this step, singular flag
+  const int tid = threadIdx.x;
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N) return;
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  constexpr size_t BB = (size_t)B * B;
+  // T[i,l] = T[l,i]^T and T[i,r] come from U of the level below (k_bcr_eliminate_lu writes T[l,r] into U[l] like k_bcr_eliminate)
+  for (int e = tid; e < B * B; e += kBcrElimThreads) {
+    const int rr = e / B, cc = e - rr * B;
+    A[rr * W + cc] = rr >= cc ? Dm[(size_t)i * BB + e] : Dm[(size_t)i * BB + cc * B + rr];       // D is kept in its lower triangle
+    A[rr * W + B + cc] = haveL ? Um[(size_t)l * BB + cc * B + rr] : 0.0;
+    A[rr * W + 2 * B + cc] = haveR ? Um[(size_t)i * BB + e] : 0.0;
+  }
+  for (int e = tid; e < B; e += kBcrElimThreads) { A[e * W + 3 * B] = fm[(size_t)i * B + e]; used[e] = 0; }
+  if (tid == 0) piv[1] = 0;
+  __syncthreads();
+  for (int k = 0; k < B; ++k) {
+    // pivot: the largest |A[r][k]| among the rows that have not been a pivot row yet (first wavefront; B <= 66: two rows per lane)
+    if (tid < 64) {
+      double best = -1.0; int brow = -1;
+      for (int rr = tid; rr < B; rr += 64) {
+        const double v = used[rr] ? -1.0 : fabs(A[rr * W + k]);
+        if (v > best) { best = v; brow = rr; }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int orow = __shfl_xor(brow, off);
+        if (ob > best || (ob == best && orow >= 0 && (brow < 0 || orow < brow))) { best = ob; brow = orow; }
+      }
+      if (tid == 0) {
+        piv[0] = brow;
+        if (!(best > 0.0) || !(best < __builtin_huge_val())) piv[1] = k + 1;       // exactly singular (or NaN): LAPACK's info
+        else { used[brow] = 1; rowof[k] = brow; }
+      }
+    }
+    __syncthreads();
+    if (piv[1]) break;
+    const int p = piv[0];
+    const double inv = 1.0 / A[p * W + k];
+    for (int rr = tid; rr < B; rr += kBcrElimThreads) colk[rr] = rr == p ? 0.0 : A[rr * W + k];
+    __syncthreads();
+    // scale the pivot row (columns > k only: the rest is never read again), then eliminate column k from every other row
+    for (int c = k + 1 + tid; c < W; c += kBcrElimThreads) A[p * W + c] *= inv;
+    __syncthreads();
+    const int ncol = W - (k + 1);
+    for (int e = tid; e < B * ncol; e += kBcrElimThreads) {
+      const int rr = e / ncol, c = k + 1 + (e - rr * ncol);
+      A[rr * W + c] -= colk[rr] * A[p * W + c];             // (colk[p] = 0: the pivot row stays)
+    }
+    __syncthreads();
+  }
+  if (piv[1]) {
+    if (tid == 0) atomicMax(info, i * B + piv[1]);
+    return;
+  }
+  // unknown k sits in row rowof[k]:  Zl = rows of columns B..2B-1, Zr = 2B..3B-1, z = column 3B
+  // ---- neighbour updates with the ORIGINAL couplings (re-read from U: the copies in A are overwritten)
+  for (int e = tid; e < B * B; e += kBcrElimThreads) {
+    const int a = e / B, b = e - a * B;                     // entry (a, b) of the B x B results
+    double sll = 0.0, srr = 0.0, slr = 0.0;
+    for (int k = 0; k < B; ++k) {
+      const int row = rowof[k];
+      const double til = haveL ? Um[(size_t)l * BB + (size_t)a * B + k] : 0.0;      // T_il[k][a] = U_l[a][k]
+      const double tir = haveR ? Um[(size_t)i * BB + (size_t)k * B + a] : 0.0;      // T_ir[k][a]
+      sll += til * A[row * W + B + b];
+      srr += tir * A[row * W + 2 * B + b];
+      slr += til * A[row * W + 2 * B + b];
+    }
+    if (haveL && b <= a) atomic_add_f64(Dm + (size_t)l * BB + e, -sll);
+    if (haveR && b <= a) atomic_add_f64(Dm + (size_t)r * BB + e, -srr);
+    A[a * W + b] = slr;             // T[l,r] = -slr goes to U[l] below, once everybody has read U[l]; until then in the D part of A (free now)
+  }
+  for (int c = tid; c < 2 * B; c += kBcrElimThreads) {
+    const bool left = c < B;
+    const int a = left ? c : c - B;
+    if ((left && !haveL) || (!left && !haveR)) continue;
+    double acc = 0.0;
+    for (int k = 0; k < B; ++k) {
+      const double t = left ? Um[(size_t)l * BB + (size_t)a * B + k] : Um[(size_t)i * BB + (size_t)k * B + a];
+      acc += t * A[rowof[k] * W + 3 * B];
+    }
+    atomic_add_f64(fm + (size_t)(left ? l : r) * B + a, -acc);
+  }
+  __syncthreads();                                          // every read of U[l] is done
+  // ---- what the back-substitution needs: P = Zl, Q = Zr, G^-1 = I, g = z; the new coupling T[l,r] = -T_il^T Zr into U[l]
+  for (int e = tid; e < B * B; e += kBcrElimThreads) {
+    const int k = e / B, c = e - k * B;
+    const int row = rowof[k];
+    Pm[(size_t)i * BB + e] = A[row * W + B + c];
+    Qm[(size_t)i * BB + e] = A[row * W + 2 * B + c];
+    Gi[(size_t)i * BB + e] = k == c ? 1.0 : 0.0;
+    if (haveL && haveR) Um[(size_t)l * BB + e] = -A[k * W + c];       // (the stash: entry (k, c) of T_il^T Zr)
+  }
+  __syncthreads();
+  for (int k = tid; k < B; k += kBcrElimThreads) {
+    const double z = A[rowof[k] * W + 3 * B];
+    fm[(size_t)i * B + k] = z;
+    if (!haveL && !haveR) xout[(size_t)i * B + k] = z;      // the root: x_i = z
+  }
+}
+
 // One back-substitution level: x_i = G^-T (g - P x_l - Q x_r) for the nodes of that level.
 // P, Q and G^-1 are staged into LDS in one round trip; the two matrix-vector products use
 // four lanes per row, the last one four lanes per column.

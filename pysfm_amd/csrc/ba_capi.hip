@@ -63,6 +63,7 @@ struct Options {
   bool fast_paths = true;          // K = I / unit-Gaussian short cuts of the per-observation arithmetic (ba_math.h)
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
   bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
+  bool device_lu = true;           // a reduced system the Cholesky solve reports as not positive definite is solved again by the cyclic reduction with LU nodes
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
 
@@ -501,6 +502,58 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
     const int s = strides[q], cnt = (N / s + 1) / 2;
     hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s,
                        level_split[q] ? h->bcrGv.p : h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->dC.p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+template <int HB>
+hipError_t launch_bcr_lu_hb(ba_handle* h, int cnt, hipStream_t st, int N, int s, double* D, double* U, double* f, double* P, double* Q,
+                            double* G, int* info, double* x) {
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcr_eliminate_lu<HB>); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bcr_eliminate_lu<HB>, dim3(cnt), dim3(kBcrElimThreads), bcr_lu_lds_bytes(6 * HB), st, N, s, D, U, f, P, Q, G, info, x);
+  return hipSuccess;
+}
+
+// The cyclic reduction with LU nodes (k_bcr_eliminate_lu): for reduced systems the Cholesky solvers reported as not positive
+// definite.  Same layout and back-substitution as solve_bcr; leaves the solution in h->dC and the status in flags[1].
+int solve_bcr_lu(ba_handle* h, const unsigned char* dmask) {
+  const int hb = h->hb, B = 6 * hb, N = (h->nco + hb - 1) / hb;
+  const size_t BB = (size_t)B * B;
+  HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
+  HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
+  HIPCHECK(h, h->bcrF.resize((size_t)N * B));
+  {
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, hb, h->S, h->b, dmask, h->bcrD.p,
+                       h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p);
+  }
+  std::vector<int> strides;
+  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
+  {
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)strides.size());
+    for (int s : strides) {
+      const int cnt = (N / s + 1) / 2;
+      hipError_t e = hipErrorInvalidValue;
+#define BA_HB_CASE(K) case K: e = launch_bcr_lu_hb<K>(h, cnt, h->stream, N, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p, h->flags.p + 1, h->dC.p); break;
+      switch (hb) {
+        BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
+        BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11)
+        default: break;
+      }
+#undef BA_HB_CASE
+      HIPCHECK(h, e);
+    }
+  }
+  const size_t lds2 = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_bcr_backsolve));
+  int top = (int)strides.size() - 1;
+  if (top >= 0 && (N / strides[top] + 1) / 2 == 1 && 2 * strides[top] - 1 >= N) --top;      // the root solved itself
+  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, top + 1);
+  for (int q = top; q >= 0; --q) {
+    const int s = strides[q], cnt = (N / s + 1) / 2;
+    hipLaunchKernelGGL(k_bcr_backsolve, dim3(cnt), dim3(kBcrElimThreads), lds2, h->stream, N, B, s, h->bcrF.p, h->bcrP.p, h->bcrQ.p,
+                       h->bcrG.p, h->dC.p);
   }
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
@@ -948,6 +1001,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "lds_window") ok = flag(h->opt.lds_window);
   else if (n == "fused_backsolve") ok = flag(h->opt.fused_backsolve);
   else if (n == "fused_eliminate") ok = flag(h->opt.fused_eliminate);
+  else if (n == "device_lu") ok = flag(h->opt.device_lu);
   else if (n == "fast_paths") ok = flag(h->opt.fast_paths);
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);
@@ -2117,7 +2171,17 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   int inf6[62] = {0};
   HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
-  const int inf = inf6[0];
+  int inf = inf6[0];
+  if (inf > 0 && inf != kBcrTimedOut && use_bcr && h->opt.device_lu) {
+    // not positive definite: the reference's LU would still solve it (bundle_adjuster.py:302-305) - cyclic reduction with LU nodes
+    int rc = solve_bcr_lu(h, dmask);
+    if (rc != BA_OK) return rc;
+    int inf2 = 0;
+    HIPCHECK(h, hipMemcpyAsync(&inf2, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    h->solve_kind = BA_SOLVE_BCR_LU;
+    inf = inf2;
+  }
 #ifdef BA_BCR_PROFILE
   if (h->opt.solve_trace && use_bcr && h->bcr_trace_n > 0 && h->opt.fused_eliminate) {
     // time line of k_bcr_eliminate_fused: per level, when its workgroups passed each stage (us after the first workgroup started)

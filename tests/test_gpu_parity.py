@@ -17,6 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from conftest import load_golden
 from oracle import ba_oracle as O
 
+from contextlib import nullcontext as _nullcontext
+
 pytestmark = pytest.mark.gpu
 
 TIGHT = 1e-11
@@ -33,7 +35,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1, fuse_lin=0,
-                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fast_paths=1)
+                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1)
 
 
 @pytest.fixture(autouse=True)
@@ -815,9 +817,11 @@ def test_band_solver_reports_non_positive_pivot(be):
 
 
 def test_large_system_that_is_not_positive_definite_is_reported_ill_conditioned(be):
-    """More unknowns than the LU fallback takes (backend.LU_FALLBACK_MAX_UNKNOWNS): a failed Cholesky is
-    answered like the reference's LinAlgError (NormalEquationsIllconditioned -> the LM loop raises the
-    damping, bundle_adjuster.py:134-140) instead of a dense LU of the flattened system."""
+    """More unknowns than the LU fallback takes (backend.LU_FALLBACK_MAX_UNKNOWNS), and the device's LU nodes switched
+    off (option device_lu = 0: round 2's behaviour, still what wide bands get): a failed Cholesky is answered like the
+    reference's LinAlgError (NormalEquationsIllconditioned -> the LM loop raises the damping, bundle_adjuster.py:134-140)
+    instead of a dense LU of the flattened system.  With the LU nodes (the default) the same system is SOLVED on the
+    device, as the reference's LU solves it."""
     from pysfm_amd.backend import ReducedSystemSingular, LU_FALLBACK_MAX_UNKNOWNS
     nc = LU_FALLBACK_MAX_UNKNOWNS // 6 + 40
     s = banded(nc, 3 * nc, track_len=6)
@@ -826,9 +830,16 @@ def test_large_system_that_is_not_positive_definite_is_reported_ill_conditioned(
     assert be.nco * 6 > LU_FALLBACK_MAX_UNKNOWNS
     be.linearize(0)
     be.schur(0, -3., 1e-5)                    # (1 + lambda) < 0: indefinite
+    be.set_option('device_lu', 0)
     with pytest.raises(ReducedSystemSingular):
         be.solve_reduced(None)
     info, _ = be.lm_trial(-3., 1e-5, None)
+    assert info > 0
+    be.set_option('device_lu', 1)
+    be.schur(0, -3., 1e-5)
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'band'
+    info, _ = be.lm_trial(-3., 1e-5, None)    # (the one-batch trial only reports: the caller solves again, stepwise)
     assert info > 0
     be.schur(0, 10., 1e-5)                    # and the same scene, damped properly, solves on the device
     be.solve_reduced(None)
@@ -1067,6 +1078,58 @@ def test_triangulation_degenerate_tracks(be):
     ok = (pt != 4) & (pt != 9)               # well-posed tracks reproject to within the measurement noise
     e = O.reproj_error(s['K'], s['R'], s['t'], X, cam[ok], pt[ok], z[ok])
     assert np.sqrt(np.mean(np.sum(e * e, axis=1))) < 3 * .02
+
+
+@pytest.mark.parametrize('nc,L', [(64, 4), (300, 10), (1000, 10), (257, 12)])
+def test_not_positive_definite_systems_are_solved_like_the_reference_lu(be, nc, L):
+    """The reference solves its reduced system by LU (numpy.linalg.solve, bundle_adjuster.py:302-305): a symmetric matrix that is
+    NOT positive definite is still solved.  A NEGATIVE damping makes such a system on purpose (diag(H) scaled by 0.4: indefinite,
+    far from singular): the device Cholesky must report it, the cyclic reduction with LU nodes (k_bcr_eliminate_lu: partial
+    pivoting inside a node) must solve it, and the solution must be LAPACK's - for the whole system and with parameters masked."""
+    nt = 30 * nc
+    s = banded(nc, nt, track_len=L)
+    flags = default_flags(nc, nt)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    be.linearize(0)
+    be.schur(0, -.6, 1e-5)
+    be.synchronize()
+    St, bt = be.reduced_tensors()
+    hb = be.half_bandwidth
+    band = St.cpu().numpy().reshape(nc - 1, hb + 1, 6, 6)
+    b = bt.cpu().numpy().reshape(-1)
+    n = 6 * (nc - 1)
+    A = np.zeros((n, n))
+    for d in range(hb + 1):
+        for i in range(nc - 1 - d):
+            A[6 * i:6 * i + 6, 6 * (i + d):6 * (i + d) + 6] = band[i, d]
+            if d:
+                A[6 * (i + d):6 * (i + d) + 6, 6 * i:6 * i + 6] = band[i, d].T
+    if n <= 2000:
+        w = np.linalg.eigvalsh(A)
+        assert w[0] < 0 < w[-1] and np.min(np.abs(w)) > 1e-9 * np.max(np.abs(w))      # indefinite, not singular
+    else:
+        with pytest.raises(np.linalg.LinAlgError):
+            np.linalg.cholesky(A)
+    for mask in (None, (np.arange(n) % 11 != 3).astype(np.uint8)):
+        be.set_option('device_lu', 0)
+        with pytest.raises(Exception) if n > be.lu_fallback_max_unknowns else _nullcontext():
+            be.solve_reduced(mask)
+        if n <= be.lu_fallback_max_unknowns:
+            assert be.last_solve_path == 'dense'                                      # (without the device LU: the flattened system through rocSOLVER)
+        be.set_option('device_lu', 1)
+        be.solve_reduced(mask)
+        assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'band'
+        x = be.get_solution().reshape(-1)
+        keep = np.arange(n) if mask is None else np.nonzero(mask)[0]
+        ref = np.linalg.solve(A[np.ix_(keep, keep)], b[keep])
+        cond = np.linalg.cond(A[np.ix_(keep, keep)]) if n <= 2000 else 1e6
+        close(x[keep], ref, max(1e-9, 1e-13 * cond))
+        res = A[np.ix_(keep, keep)] @ x[keep] - b[keep]
+        assert np.max(np.abs(res)) <= 1e-9 * (np.max(np.abs(A)) * np.max(np.abs(x)) + np.max(np.abs(b)))
+        assert mask is None or np.all(x[mask == 0] == 0)
+        # the solution goes on into the back-substitution like any other
+        dP = be.backsubstitute(0)
+        assert np.all(np.isfinite(dP))
 
 
 def test_window_slam_vs_reference():
