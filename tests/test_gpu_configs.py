@@ -583,6 +583,71 @@ def test_large_reduced_systems_follow_the_reference_lu_trajectory():
         ba.backend.close()
 
 
+def test_lm_on_systems_that_are_not_positive_definite_follows_the_reference_lu():
+    """LM trials on reduced systems that are indefinite on purpose (NEGATIVE damping): the reference's LU solves every one of
+    them (bundle_adjuster.py:302-305) and the loop accepts or rejects the step by its cost.  2394 unknowns: beyond the
+    flattened-LU fallback, so every trial here goes through the cyclic reduction with LU nodes - same decision, same trial cost,
+    same trial parameters as the oracle's LU; none reported ill-conditioned."""
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd.backend import LU_FALLBACK_MAX_UNKNOWNS
+    nc, nt = 400, 6000
+    assert (nc - 1) * 6 > LU_FALLBACK_MAX_UNKNOWNS
+    s = banded(nc, nt)
+    flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
+    sen = O.Sensor.gaussian(1.)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    b = Bundle.FromObservations(*a)
+    ba = BundleAdjuster(b, verbose=False)
+    R, t, X = s['R0'], s['t0'], s['X0']
+    cur = O.cost(sen, s['K'], R, t, X, *a[4:], *flags)
+    for n, damping in enumerate((-.6, -.3, -.85, -.5)):
+        accepted, nxt = ba.trial(damping, None, cur)
+        assert accepted is not None and ba.lu_node_solves == n + 1 and ba.backend.last_solve_kind == 'bcr_lu'
+        mu, su = O.compute_update(sen, s['K'], R, t, X, *a[4:], *flags, damping=damping)
+        R2, t2, X2 = O.apply_update(R, t, X, mu, su, *flags)
+        ref_next = O.cost(sen, s['K'], R2, t2, X2, *a[4:], *flags)
+        # (a step that overshoots by orders of magnitude - these indefinite systems produce them - amplifies the last digits of
+        # the solve into its cost: 2e-4 relative at a cost 1e9 times the current one)
+        assert abs(nxt - ref_next) <= (1e-7 if ref_next < 100 * cur else 1e-2) * ref_next, (damping, nxt, ref_next)
+        assert bool(accepted) == bool(ref_next < cur)
+        if accepted:
+            R, t, X, cur = R2, t2, X2, ref_next
+    ba.backend.close()
+
+
+def test_lu_semantics_at_1000_cameras_on_the_device():
+    """BASELINE config-3 size at the noise floor, the damping restarted at 1e-13: the reduced system (5994 unknowns) is
+    singular along the scale gauge to working precision and a Cholesky factorisation fails; the reference's LU
+    (numpy.linalg.solve, bundle_adjuster.py:302-305) returns a step all the same, the LM loop judges it by its cost.  The device
+    path now does the same - the cyclic reduction with LU nodes, no trial declared ill-conditioned - and must walk the oracle's
+    accept / reject sequence with the oracle's accepted costs."""
+    from pysfm_amd import Bundle, BundleAdjuster
+    nc, nt = 1000, 100000
+    s = banded(nc, nt)
+    flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
+    sen = O.Sensor.gaussian(1.)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(b, verbose=False)
+    ba.optimize(max_steps=25)                                            # to the floor (every system on the way is positive definite)
+    R, t, X = ba.backend.get_params(0)
+    ba.backend.close()
+    b = Bundle.FromObservations(s['K'], R, t, X, s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(b, verbose=False)
+    ba.optimize(max_steps=2, init_damping=1e-13)
+    trace = []
+    ref = O.lm_optimize(sen, s['K'], R, t, X, s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, max_steps=2, init_damping=1e-13, trace=trace)
+    got = [(d, o) for d, o, c in ba.trial_log]
+    want = [(tr['damping'], 'accepted' if tr['next'] < tr['cur'] else 'rejected') for tr in trace]
+    assert all(o != 'ill-conditioned' for d, o in got), got             # LU semantics: every trial returns a step
+    assert getattr(ba, 'cholesky_rejections', 0) == 0                    # (whether the LU nodes were needed depends on the round-off: ba.lu_node_solves)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[1] == w[1] and abs(g[0] - w[0]) <= 1e-12 * w[0], (got, want)
+    assert ba.num_steps == ref['num_steps'] and ba.converged == ref['converged']
+    close(np.array(ba.costs), np.array(ref['costs']), 1e-6)
+    ba.backend.close()
+
+
 @pytest.mark.gpu
 def test_bench_line_keeps_the_drivers_contract():
     """`python bench.py` (small K / W) prints ONE JSON line as its last line of stdout with the keys the driver and the judge read:
