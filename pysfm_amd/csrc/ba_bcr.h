@@ -58,10 +58,11 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, i
                                                               const unsigned char* __restrict__ mask,
                                                               double* __restrict__ Dm, double* __restrict__ Um,
                                                               double* __restrict__ fm, int* __restrict__ info,
-                                                              double* __restrict__ xsol = nullptr, int* __restrict__ done = nullptr) {
+                                                              double* __restrict__ xsol = nullptr, int* __restrict__ done = nullptr,
+                                                              const int* __restrict__ nodes = nullptr) {
   const int B = 6 * cb, hb1 = hb + 1;
-  const int I = blockIdx.x;
-  if (I == 0 && threadIdx.x == 0) {
+  const int I = nodes ? nodes[blockIdx.x] : blockIdx.x;      // (a rank of the distributed solve assembles its own nodes and the separators only)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     *info = 0;                                    // status word of this solve (the eliminate levels only ever set it)
     info[kBcrTicketWord] = 0;                     // ticket counter of k_bcr_backsolve_fused
     info[kBcrTicketWord - 1] = 0;                 // ... and of k_bcr_eliminate_fused (kBcrElimTicketWord)

@@ -155,7 +155,8 @@ struct ba_handle {
     int n_lo = 0, n_hi = 0;             // this rank's own nodes [n_lo, n_hi) (interior) ...
     int own_lo = 0, own_hi = 0;         // ... and the camera positions whose solution it contributes (interior + its separator)
     int nrows = 0, nsep = 0, nroot = 0, nwork_local = 0, nwork_top = 0, norder = 0;
-    DevBuf<int> rows, sep, sep_owner, root, root_owner, work, order;   // work = [local items | separator items]
+    DevBuf<int> rows, sep, sep_owner, root, root_owner, work, order, asm_nodes;   // work = [local items | separator items]
+    int nasm = 0;                       // nodes this rank assembles: its own interval and every separator
     double* xbuf = nullptr;             // the exchange buffer (bound by the caller, or our own)
     size_t xcap = 0;
     DevBuf<double> xown;
@@ -616,6 +617,9 @@ int dist_build_plan(ba_handle* h, int rank, int nranks) {
   for (int s = s_top; s >= 1; s /= 2)                        // back-substitution: separators, then the own interval, root down
     for (int i = s - 1; i < N; i += 2 * s)
       if (s >= P || (i >= d.n_lo && i < d.n_hi)) order.push_back(i);
+  std::vector<int> asm_nodes(sep);
+  for (int i = d.n_lo; i < d.n_hi; ++i) asm_nodes.push_back(i);
+  d.nasm = (int)asm_nodes.size();
   d.nrows = (int)rows.size(); d.nsep = (int)sep.size(); d.nroot = (int)root.size(); d.norder = (int)order.size();
   const size_t B = 6 * (size_t)cb, BB = B * B;
   d.xcount[0] = (size_t)d.nrows * ((size_t)(hb + 1) * 36 + 6);
@@ -627,6 +631,7 @@ int dist_build_plan(ba_handle* h, int rank, int nranks) {
   };
   HIPCHECK(h, up(d.rows, rows)); HIPCHECK(h, up(d.sep, sep)); HIPCHECK(h, up(d.sep_owner, sep_owner));
   HIPCHECK(h, up(d.root, root)); HIPCHECK(h, up(d.root_owner, root_owner)); HIPCHECK(h, up(d.work, work)); HIPCHECK(h, up(d.order, order));
+  HIPCHECK(h, up(d.asm_nodes, asm_nodes));
   HIPCHECK(h, hipStreamSynchronize(h->stream));              // the vectors go out of scope
   const size_t need = std::max(d.xcount[0], std::max(d.xcount[1], d.xcount[2]));
   if (!d.xbuf || d.xcap < need) {
@@ -671,8 +676,8 @@ int dist_stage(ba_handle* h, int stage, const uint8_t* cam_param_mask, size_t* c
     if (int rc = dist_upload_mask(h, cam_param_mask, &dmask); rc != BA_OK) return rc;
     {
       ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
-      hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, cb, h->S, h->b, dmask, h->bcrD.p,
-                         h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, h->bcr_done.p);
+      hipLaunchKernelGGL(k_bcr_assemble, dim3(d.nasm), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, cb, h->S, h->b, dmask, h->bcrD.p,
+                         h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, h->bcr_done.p, d.asm_nodes.p);
       hipLaunchKernelGGL(k_dist_zero_separators, dim3(8, std::max(1, d.nsep)), dim3(256), 0, h->stream, d.nsep, d.sep.p, d.sep_owner.p, d.rank, B,
                          h->bcrD.p, h->bcrF.p);
     }
@@ -945,7 +950,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->dist.order.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
