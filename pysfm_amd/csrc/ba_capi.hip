@@ -1341,10 +1341,10 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       if (phi[k - 1] >= 0) last = plo[k - 1];
       if (phi[k] >= 0 && plo[k] < last) sorted_by_lo = false;
     }
-    if (maxspan >= 1 && maxspan <= kGm3MaxL && sorted_by_lo && nco > 0) {
+    if (maxspan >= 1 && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
       gm3.nts = (6 * maxspan + 15) / 16;
       gm3.Ld = 16 * gm3.nts;
-      const int wmax = std::min(kGm3MaxL, gm3.Ld / 6);
+      const int wmax = std::min(kGm3MaxSpan, gm3.Ld / 6);
       // natural groups: extend while the window still holds everybody
       struct Run { int b, e, lo, hi; };
       std::vector<Run> runs;
@@ -1738,17 +1738,24 @@ int launch_mfma3(ba_handle* h, int p, double damping, bool fuse_cam, bool first)
 
 int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
   const int nts = h->gm3.nts;       // tiles per side of the widest window; at most 15 accumulator tiles per launch
-  if (nts < 1 || nts > 9) return h->fail(BA_ERR_STATE, "k_schur_groups_mfma3: %d tiles per side", nts);
+  if (nts < 1 || nts > 15) return h->fail(BA_ERR_STATE, "k_schur_groups_mfma3: %d tiles per side", nts);
   // windows of at most 10 cameras with 6 points per batch everywhere (the north-star scenes): row length and k-steps fixed
   if (nts == 4 && h->gm3.np_cap == kGmPts && h->gm3.Kbuf == kGmK && h->gm3_uniform_ks) return launch_mfma3<0, 4, 64, 5>(h, p, damping, fuse_cam, true);
   int rc = nts == 5 ? launch_mfma3<0, 5>(h, p, damping, fuse_cam, true) : launch_mfma3<0, 4>(h, p, damping, fuse_cam, true);
   if (rc == BA_OK && nts >= 6) rc = launch_mfma3<4, 6>(h, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts == 9) rc = launch_mfma3<8, 9>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 9) rc = launch_mfma3<8, 9>(h, p, damping, fuse_cam, false);
+  // windows of 25 .. 40 cameras (tracks that long: video): one launch per further tile column (tj + 1 <= 15 tiles each)
+  if (rc == BA_OK && nts >= 10) rc = launch_mfma3<9, 10>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 11) rc = launch_mfma3<10, 11>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 12) rc = launch_mfma3<11, 12>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 13) rc = launch_mfma3<12, 13>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 14) rc = launch_mfma3<13, 14>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 15) rc = launch_mfma3<14, 15>(h, p, damping, fuse_cam, false);
   return rc;
 }
-inline int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 : 4; }
+inline int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 : nts - 5; }
 }  // extern "C++"
 
 int launch_point_blocks(ba_handle* h, int p, double* Wd) {

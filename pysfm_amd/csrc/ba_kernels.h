@@ -1515,13 +1515,14 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
 //   * the LDS accumulation window is optional (wn = 0 when hb is too wide for it: every group then adds its
 //     window straight to S with global atomics, one per entry per ~100 points).
 // --------------------------------------------------------------------------
-constexpr int kGm3MaxL = 24;
-constexpr int kGm3PosLen = 32;                          // optimised positions of a group's cameras (24 used)
+constexpr int kGm3MaxL = 24;                            // track length up to which the launches re-linearise at most four times
+constexpr int kGm3MaxSpan = 40;                         // widest window: 15 tiles per side, the last tile COLUMN alone fills the 15 accumulator tiles of a launch
+constexpr int kGm3PosLen = 64;                          // optimised positions of a group's cameras (40 used)
 constexpr int kGm3MaxTiles = 15;                        // accumulator tiles of one launch
 
 struct Gm3Params { int nts; int Ld; int Kbuf; int np_cap; int wn; int do_rhs; };
 // A group of k_schur_groups_mfma3: consecutive points (internal order) whose optimised cameras all lie in the window of
-// W <= 24 consecutive optimised positions starting at `lo`.  tab[(k - pt_begin) * W + w] = the observation of point k
+// W <= 40 (kGm3MaxSpan) consecutive optimised positions starting at `lo`.  tab[(k - pt_begin) * W + w] = the observation of point k
 // in the camera at position lo + w, or -1: the camera lists need NOT be identical, only close (tracks of different
 // lengths, missing observations) - a run of points with one camera list is the special case of a full table.
 struct WinGroup { int pt_begin; int pt_end; int W; int lo; int tab; int pad0; int pad1; int pad2; };
@@ -1730,7 +1731,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
       for (int tj = TJ0; tj < TJ1; ++tj) {
         const int n = 16 * tj + lr;
         const int j = n / 6, c = n - 6 * j;
-        const int pj = mPos[j];                                  // (j < 32 always: n <= 143)
+        const int pj = mPos[j];                                  // (j < 64 always: n <= 239)
         const int colpart = pj * 36 + c;
 #pragma unroll
         for (int ti = 0; ti <= tj; ++ti, ++q) {

@@ -582,11 +582,13 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
                                          (26, 13, O.Sensor.huber(.06)), (60, 7, O.Sensor.gaussian(1.)),
                                          (40, 11, O.Sensor.gaussian(1.)), (50, 16, O.Sensor.cauchy(.05)),
                                          (44, 17, O.Sensor.gaussian(1.)), (48, 20, O.Sensor.gaussian(1.)),
-                                         (100, 22, O.Sensor.huber(.06)), (110, 24, O.Sensor.gaussian(1.))])    # (sparse enough not to be 'dense visibility')
+                                         (100, 22, O.Sensor.huber(.06)), (110, 24, O.Sensor.gaussian(1.)),
+                                         (150, 25, O.Sensor.gaussian(1.)), (160, 32, O.Sensor.cauchy(.05)),
+                                         (200, 40, O.Sensor.huber(.06))])    # (sparse enough not to be 'dense visibility')
 def test_group_reduction_kernel_equals_pair_kernel(be, nc, L, sensor):
     """k_schur_groups (register accumulation over runs of points with identical camera lists; 1 and 2 pair rounds),
     k_schur_groups_mfma2 (the same groups on the fp64 matrix cores, track length <= 10) and k_schur_groups_mfma3 (any
-    track length up to 24: one to four launches over the tile columns of the window, with and without the LDS
+    track length up to 40: one to ten launches over the tile columns of the window, with and without the LDS
     accumulation window) against k_schur_pairs and the oracle, also with groups broken up by dropped observations
     (ragged track lengths) and frozen cameras in the middle of the sequence."""
     s = banded(nc, 40 * nc, track_len=L, outlier_frac=.05)
