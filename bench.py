@@ -53,7 +53,7 @@ KERNEL_BOUND = {'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_ass
 KERNEL_NAMES = {'linearize': 'k_linearize_groups (k_linearize when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init',
                 'schur_pairs': 'k_schur_groups_mfma2 | k_schur_groups_mfma3 (k_schur_groups / k_schur_pairs otherwise)',
                 'backsub': 'k_backsub_groups (k_backsub when points do not come in runs)',
-                'bcr_eliminate': 'k_bcr_eliminate_fused: all levels of the cyclic reduction in one launch (k_bcr_eliminate per level where a level is wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
+                'bcr_eliminate': 'k_bcr_eliminate_fused: all elimination levels of the cyclic reduction AND its back-substitution in one launch (k_bcr_eliminate per level where a level is wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
                 'bcr_backsolve': 'k_bcr_backsolve_fused (k_bcr_backsolve / k_bcrw_backsolve per level otherwise)', 'bcr_assemble': 'k_bcr_assemble', 'cost': 'k_cost',
                 'camera_blocks': 'k_camera_blocks', 'dense_solve': 'k_dense_gather/panel/update/backsolve', 'band_solve': 'k_band_solve'}
 # reference rates measured in SURVEY.md section 6 (the reference itself, imported in the build container, 1 core Xeon 2.1 GHz)
@@ -600,8 +600,12 @@ def main():
         if dom_table != dom or not tm_dom['launches'] or not tm_dom['ms'] > 0.:
             dom, tm_dom = dom_table, ours.get(dom_table, tm_dom)
         nco, hb = be.nco, be.half_bandwidth
-        ab = lambda k: algorithmic_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, hb,   # noqa: E731
-                                         launches=(ours[k]['launches'] / nprof) if k in ours else 1.)
+        def ab(k):
+            n = (ours[k]['launches'] / nprof) if k in ours else 1.
+            v = algorithmic_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, hb, launches=n)
+            if k == 'bcr_eliminate' and 'bcr_backsolve' not in ours:      # the back-substitution items ride in the elimination's launch
+                v += algorithmic_bytes('bcr_backsolve', be.nc, nco, be.nt, nobs_local, be.nt, hb, launches=n)
+            return v
         avg_ms = tm_dom['ms'] / max(1, tm_dom['launches'])
         B = ab(dom)
         achieved = B / (avg_ms * 1e-3) / 1e9

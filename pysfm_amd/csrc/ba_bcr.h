@@ -1349,9 +1349,9 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   } else {
     for (int e = tid; e < B * B; e += kBcrElimThreads) {
       const int rr = e / B, cc = e - rr * B;
-      Gi[(size_t)i * BB + e] = cc <= rr ? R[rr * ld + cc] : 0.0;
+      bcr_st<FUSED>(Gi + (size_t)i * BB + e, cc <= rr ? R[rr * ld + cc] : 0.0);
     }
-    for (int e = tid; e < B; e += kBcrElimThreads) gm[(size_t)i * B + e] = g[e];
+    for (int e = tid; e < B; e += kBcrElimThreads) bcr_st<FUSED>(gm + (size_t)i * B + e, g[e]);
     if (!haveL && !haveR) {
       // the root of the elimination tree: x_i = G^-T g right here (its back-substitution launch is skipped by the host)
       for (int task = tid; task < 4 * B; task += kBcrElimThreads) {
@@ -1360,7 +1360,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
         for (int k = m + q4; k < B; k += 4) acc += R[k * ld + m] * g[k];
         acc += dpp_pair<0xB1>(acc);
         acc += dpp_pair<0x4E>(acc);
-        if (q4 == 0) xout[(size_t)i * B + m] = acc;
+        if (q4 == 0) bcr_st<FUSED>(xout + (size_t)i * B + m, acc);
       }
     }
   }
@@ -1388,6 +1388,137 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_split(int N, 
   if (i >= N) return;
   if ((role == 0 && i - s < 0) || (role == 1 && i + s >= N)) return;       // no such neighbour: nothing to do for this role
   bcr_split_node<HB, false>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, BcrDeps{{nullptr, nullptr}, {nullptr, nullptr}, nullptr, info});
+}
+
+// --------------------------------------------------------------------------
+// ALL back-substitution levels in one launch, for systems whose N nodes are resident at once (N <= compute units).
+// What a level's launch spends most of its ~5 us on - staging P, Q, G^-1 of its nodes into LDS - does not depend on
+// the levels above it, so here every node's workgroup stages its matrices at once, then waits for x_l and x_r to be
+// PUBLISHED by the nodes above (k_bcr_assemble marks every entry of x "not yet"; a node polls the entries it needs),
+// forms x_i = G^-T (g - P x_l - Q x_r) and stores it.  The root was solved by its elimination kernel.
+// Six dependent launches of 4.7 us become one of ~2 us + 6 hand-overs.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double bcr_wait_value(const double* p, int* status) {
+  // relaxed agent-scope polls of the DATA (write-through stores, cache-bypassing loads): one memory round trip per
+  // hand-over.  Acquire loads / release fences here invalidate and write back whole L2s: 20 - 30 us per hand-over
+  // with a hundred workgroups doing it at once (measured), and a separate ready flag costs a second round trip.
+  // The spin is bounded (about a second): whatever goes wrong upstream that nobody has thought of must end in a failed solve
+  // (status word > 0: the caller rejects the trial / falls back), not in a GPU that never comes back.  The "not yet" NaN this
+  // returns then turns into ordinary NaNs downstream, which nobody waits on.
+  // A FAILED elimination (a pivot that is not positive: status word set by some node of this or an earlier launch) leaves
+  // solution entries unwritten for good - the root never solves: nobody may wait for them, so every poll looks at the status
+  // word as well.
+  double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int spins = 0; __double_as_longlong(v) == kBcrNotYet; ++spins) {
+    if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
+}
+
+// node i of the back-substitution: stage P_i, Q_i, G_i^-1, g_i (COHERENT: they were written by workgroups of this same launch -
+// relaxed agent-scope loads), wait for x_l, x_r, form and publish x_i
+template <bool COHERENT>
+__device__ __forceinline__ void bcr_backsolve_node(double* __restrict__ sm, int N, int B, int i, const double* gm,
+                                                   const double* Pm, const double* Qm, const double* Gi, double* x, int* status) {
+  const int ld = B + 1;
+  double* MP = sm;                       // [B][ld] P
+  double* MQ = MP + (size_t)B * ld;      // [B][ld] Q
+  double* MG = MQ + (size_t)B * ld;      // [B][ld] G^-1
+  double* w = MG + (size_t)B * ld;       // [B]
+  double* xl = w + B;                    // [B]
+  double* xr = xl + B;                   // [B]
+  const int tid = threadIdx.x;
+  const int s = (i + 1) & -(i + 1);      // the level that eliminated node i: i = s (2 k + 1) - 1
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  if (!haveL && !haveR) return;          // the root: its elimination kernel wrote x_i
+  const size_t BB = (size_t)B * B;
+  {
+    constexpr int U = (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
+    double vp[U], vq[U], vg[U];
+    const double wv = tid < B ? bcr_ld<COHERENT>(gm + (size_t)i * B + tid) : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + kBcrElimThreads * u;
+      const bool in = e < B * B;
+      vp[u] = (in && haveL) ? bcr_ld<COHERENT>(Pm + (size_t)i * BB + e) : 0.0;
+      vq[u] = (in && haveR) ? bcr_ld<COHERENT>(Qm + (size_t)i * BB + e) : 0.0;
+      vg[u] = in ? bcr_ld<COHERENT>(Gi + (size_t)i * BB + e) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + kBcrElimThreads * u;
+      if (e < B * B) {
+        const int rr = e / B, cc = e - rr * B;
+        MP[rr * ld + cc] = vp[u]; MQ[rr * ld + cc] = vq[u]; MG[rr * ld + cc] = vg[u];
+      }
+    }
+    if (tid < B) w[tid] = wv;
+  }
+  // x_l, x_r from the nodes above, as soon as they are there (k_bcr_assemble marked every entry "not yet")
+  if (tid < B) {
+    xl[tid] = haveL ? bcr_wait_value(x + (size_t)l * B + tid, status) : 0.0;
+    xr[tid] = haveR ? bcr_wait_value(x + (size_t)r * B + tid, status) : 0.0;
+  }
+  __syncthreads();
+  // the two matrix-vector products of a hand-over with 16 lanes per row (the whole workgroup busy for four terms each
+  // instead of a fifth of it for fourteen: every cycle here is on the chain of six dependent hand-overs)
+  for (int base = 0; base < 16 * B; base += kBcrElimThreads) {         // w -= P xl + Q xr
+    const int task = base + tid, kraw = task >> 4, q = task & 15;
+    const int k = kraw < B ? kraw : B - 1;                               // (rows past the end repeat the last: DPP sources must be live lanes)
+    double acc = 0.0;
+    for (int c = q; c < B; c += 16) acc += MP[k * ld + c] * xl[c] + MQ[k * ld + c] * xr[c];
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    acc += dpp_pair<0x141>(acc);
+    acc += dpp_pair<0x140>(acc);
+    if (q == 0 && kraw < B) w[k] -= acc;
+  }
+  __syncthreads();
+  for (int base = 0; base < 16 * B; base += kBcrElimThreads) {         // x = (G^-1)^T w
+    const int task = base + tid, mraw = task >> 4, q = task & 15;
+    const int m = mraw < B ? mraw : B - 1;
+    double acc = 0.0;
+    for (int k = m + q; k < B; k += 16) acc += MG[k * ld + m] * w[k];
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    acc += dpp_pair<0x141>(acc);
+    acc += dpp_pair<0x140>(acc);
+    if (q == 0 && mraw < B) __hip_atomic_store(x + (size_t)i * B + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, int B, const double* __restrict__ gm_split,
+                                                                         const double* __restrict__ gm_one, int split_stride,
+                                                                         const double* __restrict__ Pm,
+                                                                         const double* __restrict__ Qm,
+                                                                         const double* __restrict__ Gi, double* x,
+                                                                         const int* __restrict__ order, int* ticket) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x;
+  // NO DEADLOCK, whatever else shares the GPU: a workgroup takes a ticket when it STARTS and works on order[ticket],
+  // and `order` lists the nodes level by level from the root down - so a node only ever waits for nodes whose
+  // workgroups have started before it (they are resident or done: started workgroups are never preempted).  Waiting
+  // by blockIdx instead hung two processes on one GPU, each kernel holding compute units the other's parents needed.
+  // a failed elimination (matrix not positive definite: status word set by an earlier launch) leaves solution entries
+  // unwritten: nobody may wait for them
+  // (ONE thread reads the status word and takes the ticket, the workgroup decides on what it broadcast: every thread reading
+  // the word for itself could split the workgroup when another one sets it in between)
+  int* my_ticket = reinterpret_cast<int*>(sm + (size_t)3 * B * (B + 1) + 3 * B);      // (in the dynamic area: the kernel may ask for all 160 KB of it)
+  if (tid == 0) {
+    const int st = __hip_atomic_load(ticket - kBcrTicketWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    my_ticket[1] = st;
+    my_ticket[0] = st != 0 ? 0 : atomicAdd(ticket, 1);
+  }
+  __syncthreads();
+  if (my_ticket[1] != 0) return;
+  const int i = order[my_ticket[0]];
+  const int s = (i + 1) & -(i + 1);
+  __syncthreads();
+  bcr_backsolve_node<false>(sm, N, B, i, s >= split_stride ? gm_split : gm_one, Pm, Qm, Gi, x, ticket - kBcrTicketWord);
 }
 
 // --------------------------------------------------------------------------
@@ -1426,6 +1557,22 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, 
   }
   __syncthreads();
   const int item = __builtin_amdgcn_readfirstlane(*my_work);
+  if ((item & 3) == 3) {
+    // a BACK-SUBSTITUTION item (they follow the elimination items in the work list, root down: their tickets are later than
+    // everything they wait for): node i's factors are in memory once its three roles have said so - words 2, 3 (left / right
+    // role) and 0 (inverse role) of done[4 i ...]; nodes eliminated by an earlier launch (stride < s_first) wait for nothing
+    const int i = item >> 2, s = (i + 1) & -(i + 1);
+    __syncthreads();
+    if (s >= s_first) {
+      const int* word = threadIdx.x == 0 ? done + 4 * i : threadIdx.x == 1 ? (i - s >= 0 ? done + 4 * i + 2 : nullptr)
+                                                                            : (i + s < N ? done + 4 * i + 3 : nullptr);
+      if (threadIdx.x < 3 && word) bcr_wait_done(word, info);
+    }
+    __syncthreads();
+    if (s >= s_first) bcr_backsolve_node<true>(sm, N, 6 * HB, i, gm, Pm, Qm, Gi, xout, info);
+    else bcr_backsolve_node<false>(sm, N, 6 * HB, i, fm, Pm, Qm, Gi, xout, info);
+    return;
+  }
 #ifdef BA_BCR_PROFILE
   // time line of this workgroup (100 MHz wall clock, the same on every compute unit): [start, producers done, loaded, coupling
   // formed, factored, handed on, 4 node + role, XCD] at trace[8 ticket]
@@ -1465,6 +1612,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, 
     if (!ok) __hip_atomic_store(done + 4 * i + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (not positive definite: nobody may wait)
     __hip_atomic_store(done + 4 * i + 2 + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (threadIdx.x == 0 && role == 2 && !BA_BCR_TWO_STAGE)      // the inverse role: G^-1 and g are in memory (the back-substitution items wait for this)
+    __hip_atomic_store(done + 4 * i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef BA_BCR_PROFILE
   if (tline && threadIdx.x == 0) tline[5] = wall_clock64();
 #endif
@@ -1665,123 +1814,6 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve(int N, int B,
     acc += dpp_pair<0xB1>(acc);
     acc += dpp_pair<0x4E>(acc);
     if (q4 == 0) x[(size_t)i * B + m] = acc;
-  }
-}
-
-// --------------------------------------------------------------------------
-// ALL back-substitution levels in one launch, for systems whose N nodes are resident at once (N <= compute units).
-// What a level's launch spends most of its ~5 us on - staging P, Q, G^-1 of its nodes into LDS - does not depend on
-// the levels above it, so here every node's workgroup stages its matrices at once, then waits for x_l and x_r to be
-// PUBLISHED by the nodes above (k_bcr_assemble marks every entry of x "not yet"; a node polls the entries it needs),
-// forms x_i = G^-T (g - P x_l - Q x_r) and stores it.  The root was solved by its elimination kernel.
-// Six dependent launches of 4.7 us become one of ~2 us + 6 hand-overs.
-// --------------------------------------------------------------------------
-__device__ __forceinline__ double bcr_wait_value(const double* p, int* status) {
-  // relaxed agent-scope polls of the DATA (write-through stores, cache-bypassing loads): one memory round trip per
-  // hand-over.  Acquire loads / release fences here invalidate and write back whole L2s: 20 - 30 us per hand-over
-  // with a hundred workgroups doing it at once (measured), and a separate ready flag costs a second round trip.
-  // The spin is bounded (about a second): whatever goes wrong upstream that nobody has thought of must end in a failed solve
-  // (status word > 0: the caller rejects the trial / falls back), not in a GPU that never comes back.  The "not yet" NaN this
-  // returns then turns into ordinary NaNs downstream, which nobody waits on.
-  double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int spins = 0; __double_as_longlong(v) == kBcrNotYet; ++spins) {
-    if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
-    __builtin_amdgcn_s_sleep(2);
-    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return v;
-}
-
-__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve_fused(int N, int B, const double* __restrict__ gm_split,
-                                                                         const double* __restrict__ gm_one, int split_stride,
-                                                                         const double* __restrict__ Pm,
-                                                                         const double* __restrict__ Qm,
-                                                                         const double* __restrict__ Gi, double* x,
-                                                                         const int* __restrict__ order, int* ticket) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int ld = B + 1;
-  double* MP = sm;                       // [B][ld] P
-  double* MQ = MP + (size_t)B * ld;      // [B][ld] Q
-  double* MG = MQ + (size_t)B * ld;      // [B][ld] G^-1
-  double* w = MG + (size_t)B * ld;       // [B]
-  double* xl = w + B;                    // [B]
-  double* xr = xl + B;                   // [B]
-  const int tid = threadIdx.x;
-  // NO DEADLOCK, whatever else shares the GPU: a workgroup takes a ticket when it STARTS and works on order[ticket],
-  // and `order` lists the nodes level by level from the root down - so a node only ever waits for nodes whose
-  // workgroups have started before it (they are resident or done: started workgroups are never preempted).  Waiting
-  // by blockIdx instead hung two processes on one GPU, each kernel holding compute units the other's parents needed.
-  // a failed elimination (matrix not positive definite: status word set by an earlier launch) leaves solution entries
-  // unwritten: nobody may wait for them
-  // (ONE thread reads the status word and takes the ticket, the workgroup decides on what it broadcast: every thread reading
-  // the word for itself could split the workgroup when another one sets it in between)
-  int* my_ticket = reinterpret_cast<int*>(xr + B);      // (in the dynamic area: the kernel may ask for all 160 KB of it)
-  if (tid == 0) {
-    const int st = __hip_atomic_load(ticket - kBcrTicketWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    my_ticket[1] = st;
-    my_ticket[0] = st != 0 ? 0 : atomicAdd(ticket, 1);
-  }
-  __syncthreads();
-  if (my_ticket[1] != 0) return;
-  const int i = order[my_ticket[0]];
-  const int s = (i + 1) & -(i + 1);      // the level that eliminated node i: i = s (2 k + 1) - 1
-  const int l = i - s, r = i + s;
-  const bool haveL = l >= 0, haveR = r < N;
-  if (!haveL && !haveR) return;          // the root: its elimination kernel wrote x_i
-  const size_t BB = (size_t)B * B;
-  {
-    constexpr int U = (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
-    double vp[U], vq[U], vg[U];
-    const double* gm = s >= split_stride ? gm_split : gm_one;          // which elimination kernel left this node's g
-    const double wv = tid < B ? gm[(size_t)i * B + tid] : 0.0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = tid + kBcrElimThreads * u;
-      const bool in = e < B * B;
-      vp[u] = (in && haveL) ? Pm[(size_t)i * BB + e] : 0.0;
-      vq[u] = (in && haveR) ? Qm[(size_t)i * BB + e] : 0.0;
-      vg[u] = in ? Gi[(size_t)i * BB + e] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = tid + kBcrElimThreads * u;
-      if (e < B * B) {
-        const int rr = e / B, cc = e - rr * B;
-        MP[rr * ld + cc] = vp[u]; MQ[rr * ld + cc] = vq[u]; MG[rr * ld + cc] = vg[u];
-      }
-    }
-    if (tid < B) w[tid] = wv;
-  }
-  // x_l, x_r from the nodes above, as soon as they are there (k_bcr_assemble marked every entry "not yet")
-  if (tid < B) {
-    xl[tid] = haveL ? bcr_wait_value(x + (size_t)l * B + tid, ticket - kBcrTicketWord) : 0.0;
-    xr[tid] = haveR ? bcr_wait_value(x + (size_t)r * B + tid, ticket - kBcrTicketWord) : 0.0;
-  }
-  __syncthreads();
-  // the two matrix-vector products of a hand-over with 16 lanes per row (the whole workgroup busy for four terms each
-  // instead of a fifth of it for fourteen: every cycle here is on the chain of six dependent hand-overs)
-  for (int base = 0; base < 16 * B; base += kBcrElimThreads) {         // w -= P xl + Q xr
-    const int task = base + tid, kraw = task >> 4, q = task & 15;
-    const int k = kraw < B ? kraw : B - 1;                               // (rows past the end repeat the last: DPP sources must be live lanes)
-    double acc = 0.0;
-    for (int c = q; c < B; c += 16) acc += MP[k * ld + c] * xl[c] + MQ[k * ld + c] * xr[c];
-    acc += dpp_pair<0xB1>(acc);
-    acc += dpp_pair<0x4E>(acc);
-    acc += dpp_pair<0x141>(acc);
-    acc += dpp_pair<0x140>(acc);
-    if (q == 0 && kraw < B) w[k] -= acc;
-  }
-  __syncthreads();
-  for (int base = 0; base < 16 * B; base += kBcrElimThreads) {         // x = (G^-1)^T w
-    const int task = base + tid, mraw = task >> 4, q = task & 15;
-    const int m = mraw < B ? mraw : B - 1;
-    double acc = 0.0;
-    for (int k = m + q; k < B; k += 16) acc += MG[k * ld + m] * w[k];
-    acc += dpp_pair<0xB1>(acc);
-    acc += dpp_pair<0x4E>(acc);
-    acc += dpp_pair<0x141>(acc);
-    acc += dpp_pair<0x140>(acc);
-    if (q == 0 && mraw < B) __hip_atomic_store(x + (size_t)i * B + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

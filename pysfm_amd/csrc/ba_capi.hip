@@ -144,7 +144,7 @@ struct ba_handle {
   DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)
   int bcr_order_n = 0;
   DevBuf<int> bcr_work, bcr_done;   // k_bcr_eliminate_fused: 4 node + role of every workgroup, leaves first; "handed on" words [4 N]
-  int bcr_work_n = 0, bcr_work_s = 0, bcr_work_len = 0;
+  int bcr_work_n = 0, bcr_work_s = 0, bcr_work_len = 0, bcr_work_elim = 0;   // (elimination items first, then the back-substitution items)
   DevBuf<long long> bcr_trace;      // PROFILE builds, option solve_trace: the time line of k_bcr_eliminate_fused, 8 words per workgroup
   int bcr_trace_n = 0;
   // the reduced solve spread over the ranks of a sharded adjuster (ba_dist.h; ba_dist_enable)
@@ -437,12 +437,21 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
           work.push_back(4 * i + 2);
         }
       }
+      h->bcr_work_elim = (int)work.size();
+      // ... followed by the back-substitution items, root down (k_bcr_eliminate_fused role 3): the whole solve behind
+      // k_bcr_assemble is then ONE launch.  (Not with the two-stage words, which use the word the inverse role publishes.)
+      for (int q = (int)strides.size() - 1; q >= 0; --q)
+        for (int k = 0, cnt = (N / strides[q] + 1) / 2; k < cnt; ++k) {
+          const int i = strides[q] * (2 * k + 1) - 1;
+          if (i < N && (i - strides[q] >= 0 || i + strides[q] < N)) work.push_back(4 * i + 3);
+        }
       HIPCHECK(h, h->bcr_work.resize(work.size()));
       HIPCHECK(h, hipMemcpyAsync(h->bcr_work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
       HIPCHECK(h, hipStreamSynchronize(h->stream));          // `work` goes out of scope
       h->bcr_work_n = N; h->bcr_work_s = s_fused; h->bcr_work_len = (int)work.size();
     }
-    nwork = s_fused ? h->bcr_work_len : 0;
+    const bool back_in_launch = s_fused && h->opt.fused_backsolve && !BA_BCR_TWO_STAGE && N <= 8 * h->ncu;
+    nwork = s_fused ? (back_in_launch ? h->bcr_work_len : h->bcr_work_elim) : 0;
     if (s_fused) HIPCHECK(h, h->bcr_done.resize((size_t)4 * N));
   }
   {
@@ -475,6 +484,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   int split_stride = INT32_MAX;                            // the first (smallest-stride) level eliminated by the split kernel
   for (size_t q = 0; q < strides.size(); ++q)
     if (level_split[q]) { split_stride = strides[q]; break; }
+  if (s_fused && h->opt.fused_backsolve && !BA_BCR_TWO_STAGE && N <= 8 * h->ncu) return BA_OK;      // (done inside k_bcr_eliminate_fused)
   if (h->opt.fused_backsolve && N <= 8 * h->ncu && top >= 0) {
     // every node's workgroup is resident at once: all levels in ONE launch, handing x down through flags
     if (h->bcr_order_n != N) {
