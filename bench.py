@@ -551,7 +551,7 @@ def main():
     dom = max(cand, key=lambda k: cand[k]['ms']) if cand else 'schur_pairs'
     # timed region: only the dominant kernel keeps its events (an event pair costs a few
     # microseconds of stream time - bracketing all ~25 launches of a 0.3 ms step would slow it ~15 %)
-    ev_stride = max(4, args.steps // 3)                 # (20 steps: steps 0, 6, 12, 18) - a sampled step costs ~45 us of stream and host time
+    ev_stride = max(4, args.steps // 2)                 # (20 steps: steps 0 and 10) - a sampled step costs ~45 us of stream and host time: two samples of a kernel whose duration varies by 0.5 % are enough
     be.enable_timing(not args.no_kernel_table, only=[dom], stride=ev_stride)
     sync()
     state['paths'] = {}
