@@ -396,10 +396,15 @@ hipError_t launch_bcr_eliminate(ba_handle* h, int hb, int cnt, size_t lds, hipSt
 #undef BA_HB_CASE
 }
 
+// Cameras per node of the narrow cyclic reduction: the half-bandwidth - or, for systems of at most kBcrMaxHB cameras (the
+// sliding-window caller's 10-camera windows, the reference's own small scenes), ALL of them: one node, one workgroup, one
+// 6 nco x 6 nco Cholesky with the node kernel's pivot chain (~10 us where k_band_solve's nco dependent 6 x 6 pivots take 33).
+inline int bcr_node_size(const ba_handle* h) { return h->nco <= kBcrMaxHB ? std::max(1, h->nco) : std::max(1, h->hb); }
+
 // Block cyclic reduction over super-blocks of hb cameras (ba_bcr.h): log2(N) levels, one
 // workgroup per eliminated node.  Leaves the solution in h->dC and the status in flags[1].
 int solve_bcr(ba_handle* h, const unsigned char* dmask) {
-  const int hb = h->hb, B = 6 * hb, N = (h->nco + hb - 1) / hb;
+  const int hb = bcr_node_size(h), B = 6 * hb, N = (h->nco + hb - 1) / hb;      // (hb: cameras per node from here on)
   const size_t BB = (size_t)B * B;
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
@@ -456,7 +461,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   }
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1], marks the solution "not there yet", clears done[]
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, hb, h->S, h->b, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, s_fused ? h->bcr_done.p : nullptr);
   }
   {
@@ -529,14 +534,14 @@ hipError_t launch_bcr_lu_hb(ba_handle* h, int cnt, hipStream_t st, int N, int s,
 // The cyclic reduction with LU nodes (k_bcr_eliminate_lu): for reduced systems the Cholesky solvers reported as not positive
 // definite.  Same layout and back-substitution as solve_bcr; leaves the solution in h->dC and the status in flags[1].
 int solve_bcr_lu(ba_handle* h, const unsigned char* dmask) {
-  const int hb = h->hb, B = 6 * hb, N = (h->nco + hb - 1) / hb;
+  const int hb = bcr_node_size(h), B = 6 * hb, N = (h->nco + hb - 1) / hb;
   const size_t BB = (size_t)B * B;
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
   HIPCHECK(h, h->bcrF.resize((size_t)N * B));
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, hb, h->S, h->b, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p);
   }
   std::vector<int> strides;
@@ -2146,7 +2151,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   if (h->nco == 0) { *info = 0; h->have_solution = true; return BA_OK; }
   const int force = h->opt.solver;                 // ba_set_option "solver"
   const int nodes = h->hb > 0 ? (h->nco + h->hb - 1) / h->hb : 0;
-  const bool bcr_ok = h->hb >= 1 && h->hb <= kBcrMaxHB && nodes >= 4;
+  const bool bcr_ok = h->nco <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrMaxHB);      // (any number of nodes: even two levels beat k_band_solve's chain of nco pivots)
   const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && nodes >= 4;
   const bool band_ok = h->hb <= kMaxBandSolve;       // (the single-workgroup band Cholesky is instantiated up to there)
   const bool dense_ok = 6 * h->nco <= kDcMaxN && force != SOLVER_LU;

@@ -805,13 +805,20 @@ def test_dense_cholesky_reports_non_positive_pivot(be):
 
 
 def test_band_solver_reports_non_positive_pivot(be):
-    """An indefinite reduced system must not be 'solved' by Cholesky: info > 0, dense LU takes over."""
+    """An indefinite reduced system must not be 'solved' by Cholesky: the single-workgroup band solver (forced: systems this
+    small are one node of the cyclic reduction by default) reports info > 0 and the dense LU takes over; the default path
+    reports it too and solves again with an LU node on the device."""
     g = load_golden('scene_4x10_cauchy')
     load_problem(be, *scene(g), g['l2_cam_opt_pos'], g['l2_pt_opt'], sensor_of(g))
     be.linearize(0)
     be.schur(0, -3., 1e-5)                    # (1 + lambda) < 0 flips the sign of every diagonal
     be.solve_reduced(None)
-    assert be.last_solve_path == 'dense'
+    assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'band'
+    x_lu = be.get_solution().reshape(-1)
+    be.set_option('solver', 'band')
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'band' and be.last_solve_path == 'dense'
+    close(x_lu, be.get_solution().reshape(-1), 1e-9)
     S, b = be.get_reduced()
     x = be.get_solution().reshape(-1)
     A = S.transpose(0, 2, 1, 3).reshape(18, 18)
