@@ -247,13 +247,28 @@ class Bundle(object):
         cam, trk, z = self.observation_table()
         cpos = -np.ones(max(len(self.cameras), 1), np.int64)
         cpos[np.asarray(camera_ids, np.int64)] = np.arange(len(camera_ids))
-        tpos = -np.ones(max(len(self.tracks), 1), np.int64)
-        tpos[np.asarray(track_ids, np.int64)] = np.arange(len(track_ids))
-        ci, ti = cpos[cam], tpos[trk]
-        keep = (ci >= 0) & (ti >= 0)
-        ci, ti, z = ci[keep], ti[keep], z[keep]
+        tids = np.asarray(track_ids, np.int64)
+        if len(tids) * 4 < len(self.tracks) and len(trk):
+            # few of many tracks (the sliding-window caller: 100 of 1000, window after window): only their rows of the
+            # table (sorted by track) instead of a pass over all of it
+            off = getattr(self, '_track_offsets', None)
+            if off is None or len(off) != len(self.tracks) + 1 or off[-1] != len(trk):
+                off = np.zeros(len(self.tracks) + 1, np.int64)
+                np.cumsum(np.bincount(trk, minlength=len(self.tracks)), out=off[1:])
+                self._track_offsets = off
+            cnt = off[tids + 1] - off[tids]
+            rows = np.repeat(off[tids] - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(int(cnt.sum()))
+            ci, ti, zz = cpos[cam[rows]], np.repeat(np.arange(len(tids)), cnt), z[rows]
+            keep = ci >= 0
+            ci, ti, zz = ci[keep], ti[keep], zz[keep]
+        else:
+            tpos = -np.ones(max(len(self.tracks), 1), np.int64)
+            tpos[tids] = np.arange(len(tids))
+            ci, ti = cpos[cam], tpos[trk]
+            keep = (ci >= 0) & (ti >= 0)
+            ci, ti, zz = ci[keep], ti[keep], z[keep]
         order = np.lexsort((ci, ti))
-        return ci[order].astype(np.int32), ti[order].astype(np.int32), np.ascontiguousarray(z[order])
+        return ci[order].astype(np.int32), ti[order].astype(np.int32), np.ascontiguousarray(zz[order])
 
     def Rs(self):
         return np.array([cam.R for cam in self.cameras])
