@@ -1141,6 +1141,34 @@ def test_not_positive_definite_systems_are_solved_like_the_reference_lu(be, nc, 
         assert np.all(np.isfinite(dP))
 
 
+@pytest.mark.parametrize('nc,nt,L,reps', [(1000, 20000, 10, 200), (97, 3000, 7, 300), (523, 9000, 11, 150), (12, 400, 3, 300)])
+def test_one_launch_solve_repeats_itself_and_equals_the_per_level_launches(be, nc, nt, L, reps):
+    """k_bcr_eliminate_fused hands data from workgroup to workgroup INSIDE one launch (words in memory, relaxed agent-scope
+    accesses, no fences): a stale read would show as a solve that differs from the others.  The same reduced system solved
+    `reps` times through the one launch (every third time from poisoned LDS and workspace, re-reduced) must agree with the
+    solve made of one launch per level to 1e-13 of its largest entry (only the order of two fp64 atomics may differ), and no
+    solve may time out.  (scripts/bcr_fused_stress.py runs thousands, also with two processes sharing the GPU.)"""
+    s = banded(nc, nt, track_len=L)
+    flags = default_flags(nc, nt)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    be.set_option('fused_eliminate', 0)
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'bcr' and be.last_solve_path == 'band'
+    ref = be.get_solution()
+    be.set_option('fused_eliminate', 1)
+    for r in range(reps):
+        if r % 3 == 2:
+            be.debug_poison()
+            be.linearize(0)
+            be.schur(0, 10., 1e-5)
+        be.solve_reduced(None)
+        assert be.last_solve_kind == 'bcr' and be.last_solve_path == 'band'
+        x = be.get_solution()
+        assert np.all(np.isfinite(x)) and np.max(np.abs(x - ref)) <= 1e-13 * np.max(np.abs(ref)), r
+
+
 def test_window_slam_vs_reference():
     from pysfm_amd import Bundle, window_slam
     g = load_golden('scene_window_slam')
