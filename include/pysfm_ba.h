@@ -300,8 +300,9 @@ int ba_dist_stage(ba_handle* h, int32_t stage, const uint8_t* cam_param_mask, in
  * Re-initialise every point of parameter set `which` by linear least squares from its
  * observations and the set's cameras (the step before the path: test_bundle.py:175,
  * window_slam.py:82).  rcond: numpy.linalg.lstsq cut-off on the singular values of A
- * (< 0 = numpy's default; the kernel solves the 3x3 normal equations, so the effective
- * cut-off is max(rcond, 1e-7) relative to the largest singular value).
+ * (< 0 = numpy's default; the kernel solves the 2L x 3 system by QR - Givens row updates - so a track
+ * seen under little parallax keeps cond(A) * eps accuracy like lstsq's; a system that is rank deficient
+ * at max(rcond, 1e-13) relative to the largest diagonal entry of R gets the minimum-norm point).
  * X[nt*3] (host) may be NULL: the result stays on the device. */
 int ba_triangulate(ba_handle* h, int which, double rcond, double* X);
 

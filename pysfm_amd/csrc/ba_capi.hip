@@ -2606,13 +2606,13 @@ int ba_triangulate(ba_handle* h, int which, double rcond, double* X) {
   REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_triangulate: set problem and parameters first");
   HIPCHECK(h, hipSetDevice(h->device));
   if (rcond < 0) rcond = 2.220446049250313e-16 * std::max<double>(3.0, 2.0 * 64);   // numpy's default scale
-  // the normal equations resolve singular values of A only down to sqrt(eps) * s_max: the rank
-  // decision is made at 1e-7 * s_max (tracks with less parallax get the minimum-norm point)
+  // QR of the 2L x 3 system (k_triangulate): full-rank systems are solved to cond(A) * eps like lstsq's; the rank decision
+  // (|R_jj| <= rcond * max |R_ii|, never below 1e-13) sends what is rank deficient to working precision to the minimum-norm answer
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_TRIANGULATE);
     const long long threads = (long long)h->nt << h->glog;
     hipLaunchKernelGGL(k_triangulate, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p,
-                       h->glog, std::max(rcond * rcond, 1e-14), h->X[p].p);
+                       h->glog, std::max(rcond, 1e-13), h->X[p].p);
   }
   HIPCHECK(h, hipGetLastError());
   if (which == BA_PARAMS_CUR) h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;

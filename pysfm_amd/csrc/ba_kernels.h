@@ -2232,12 +2232,46 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
 // per point the linear least-squares problem with two rows per observation,
 //   A[2i]   = (K[0] - z0 K[2]) R_i ,   b[2i]   = (z0 K[2] - K[0]) . t_i
 //   A[2i+1] = (K[1] - z1 K[2]) R_i ,   b[2i+1] = (z1 K[2] - K[1]) . t_i
-// solved through the 3x3 normal equations x = pinv(A^T A) A^T b (numpy.linalg.lstsq's
-// minimum-norm answer; singular values of A^T A below (rcond * s_max)^2 are dropped).
+// which the reference hands to numpy.linalg.lstsq (triangulate.py:17).  Solved here by QR, not through the 3 x 3 normal
+// equations (round 2 did that: a track seen under little parallax - condition number 1e5 - lost ten digits to the squared
+// condition number): every lane rotates its rows into a 3 x 3 upper triangle R and c = Q^T b (Givens row updates), the
+// lanes of a point merge their triangles the same way (the partner's three rows are three more rows), R x = c by back-
+// substitution.  A track whose system is rank deficient to working precision (|R_jj| <= rcond max|R_ii|: one observation,
+// a point at infinity) takes lstsq's minimum-norm answer through the pseudo-inverse of A^T A = R^T R, as before.
 // Same lanes-per-point mapping as k_linearize.
 // --------------------------------------------------------------------------
+__device__ __forceinline__ void tri_givens_row(double (&R)[6], double (&c)[3], double a0, double a1, double a2, double rhs) {
+  // R = [r00 r01 r02; 0 r11 r12; 0 0 r22] as R[0..5]; rotate the row (a0 a1 a2 | rhs) into it
+  {
+    const double r = sqrt(R[0] * R[0] + a0 * a0);
+    if (r > 0.0) {
+      const double cs = R[0] / r, sn = a0 / r;
+      const double t1 = cs * R[1] + sn * a1, t2 = cs * R[2] + sn * a2, tc = cs * c[0] + sn * rhs;
+      a1 = cs * a1 - sn * R[1]; a2 = cs * a2 - sn * R[2]; rhs = cs * rhs - sn * c[0];
+      R[0] = r; R[1] = t1; R[2] = t2; c[0] = tc;
+    }
+  }
+  {
+    const double r = sqrt(R[3] * R[3] + a1 * a1);
+    if (r > 0.0) {
+      const double cs = R[3] / r, sn = a1 / r;
+      const double t2 = cs * R[4] + sn * a2, tc = cs * c[1] + sn * rhs;
+      a2 = cs * a2 - sn * R[4]; rhs = cs * rhs - sn * c[1];
+      R[3] = r; R[4] = t2; c[1] = tc;
+    }
+  }
+  {
+    const double r = sqrt(R[5] * R[5] + a2 * a2);
+    if (r > 0.0) {
+      const double cs = R[5] / r, sn = a2 / r;
+      c[2] = cs * c[2] + sn * rhs;
+      R[5] = r;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_triangulate(DevProblem P, const double* __restrict__ cams, int glog,
-                                                        double rcond2, double* __restrict__ Xout) {
+                                                        double rcond, double* __restrict__ Xout) {
   const int G = 1 << glog;
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   const long long k = tid >> glog;
@@ -2245,12 +2279,12 @@ __global__ __launch_bounds__(kBlock) void k_triangulate(DevProblem P, const doub
   const bool valid = k < P.nt;
   int s = 0, e_ = 0;
   if (valid) { s = P.pt_off[k]; e_ = P.pt_off[k + 1]; }
-  double ata[6] = {0, 0, 0, 0, 0, 0}, atb[3] = {0, 0, 0};
+  double R[6] = {0, 0, 0, 0, 0, 0}, c[3] = {0, 0, 0};
   for (int n = s + l; n < e_; n += G) {
-    const int c = P.obs_cam[n];
+    const int cam = P.obs_cam[n];
     const double2 z = P.obs_z[n];
     double cm[12];
-    load_cam(cams, c, cm);
+    load_cam(cams, cam, cm);
     const double zz[2] = {z.x, z.y};
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -2260,21 +2294,36 @@ __global__ __launch_bounds__(kBlock) void k_triangulate(DevProblem P, const doub
       const double a1 = k0 * cm[1] + k1 * cm[4] + k2 * cm[7];
       const double a2 = k0 * cm[2] + k1 * cm[5] + k2 * cm[8];
       const double rhs = -(k0 * cm[9] + k1 * cm[10] + k2 * cm[11]);
-      ata[0] += a0 * a0; ata[1] += a0 * a1; ata[2] += a0 * a2;
-      ata[3] += a1 * a1; ata[4] += a1 * a2; ata[5] += a2 * a2;
-      atb[0] += a0 * rhs; atb[1] += a1 * rhs; atb[2] += a2 * rhs;
+      tri_givens_row(R, c, a0, a1, a2, rhs);
     }
   }
-  for (int m = G >> 1; m >= 1; m >>= 1) {
+  for (int m = G >> 1; m >= 1; m >>= 1) {          // merge with the partner's triangle: its three rows are three more rows
+    double Rp[6], cp[3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ata[i] += __shfl_xor(ata[i], m, 64);
+    for (int i = 0; i < 6; ++i) Rp[i] = __shfl_xor(R[i], m, 64);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) atb[i] += __shfl_xor(atb[i], m, 64);
+    for (int i = 0; i < 3; ++i) cp[i] = __shfl_xor(c[i], m, 64);
+    tri_givens_row(R, c, Rp[0], Rp[1], Rp[2], cp[0]);
+    tri_givens_row(R, c, 0.0, Rp[3], Rp[4], cp[1]);
+    tri_givens_row(R, c, 0.0, 0.0, Rp[5], cp[2]);
   }
   if (valid && l == 0) {
-    double inv[6], x[3];
-    sym3_pinv(ata, rcond2, inv);
-    sym3_apply(inv, atb, x);
+    double x[3];
+    const double d0 = fabs(R[0]), d1 = fabs(R[3]), d2 = fabs(R[5]);
+    const double dmax = fmax(d0, fmax(d1, d2)), dmin = fmin(d0, fmin(d1, d2));
+    if (dmin > rcond * dmax) {
+      x[2] = c[2] / R[5];
+      x[1] = (c[1] - R[4] * x[2]) / R[3];
+      x[0] = (c[0] - R[1] * x[1] - R[2] * x[2]) / R[0];
+    } else {
+      // rank deficient: lstsq's minimum-norm solution, x = pinv(R^T R) R^T c
+      const double ata[6] = {R[0] * R[0], R[0] * R[1], R[0] * R[2], R[1] * R[1] + R[3] * R[3], R[1] * R[2] + R[3] * R[4],
+                             R[2] * R[2] + R[4] * R[4] + R[5] * R[5]};
+      const double atb[3] = {R[0] * c[0], R[1] * c[0] + R[3] * c[1], R[2] * c[0] + R[4] * c[1] + R[5] * c[2]};
+      double inv[6];
+      sym3_pinv(ata, fmax(rcond * rcond, 1e-14), inv);
+      sym3_apply(inv, atb, x);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) Xout[3 * k + i] = x[i];
   }

@@ -1169,6 +1169,43 @@ def test_one_launch_solve_repeats_itself_and_equals_the_per_level_launches(be, n
         assert np.all(np.isfinite(x)) and np.max(np.abs(x - ref)) <= 1e-13 * np.max(np.abs(ref)), r
 
 
+def test_triangulation_of_low_parallax_tracks_equals_lstsq(be):
+    """triangulate.py:17 hands the 2L x 3 system to numpy.linalg.lstsq.  Tracks seen under very little parallax (cameras a
+    few 1e-4 apart looking at points 5 - 50 units away: condition numbers 1e4 ... 1e6) must come out like lstsq's: the QR in
+    k_triangulate keeps cond * eps, the 3 x 3 normal equations of round 2 lost cond^2 * eps (1e-4 relative at 1e6)."""
+    rs = np.random.RandomState(5)
+    nc, nt, L = 12, 400, 6
+    K = np.array([[1.2, 0., .1], [0., 1.1, -.05], [0., 0., 1.]])
+    w = rs.randn(nc, 3) * 1e-3
+    R = O.so3_exp(w)
+    centers = np.cumsum(rs.rand(nc, 3) * 3e-4, axis=0)                     # a baseline of ~1e-3 over the whole sequence
+    t = -np.einsum('nij,nj->ni', R, centers)
+    X = np.column_stack((rs.rand(nt) * 2 - 1, rs.rand(nt) * 2 - 1, 5 + 45 * rs.rand(nt)))
+    first = rs.randint(0, nc - L + 1, nt)
+    cam = (first[:, None] + np.arange(L)[None, :]).reshape(-1).astype(np.int32)
+    pt = np.repeat(np.arange(nt, dtype=np.int32), L)
+    p = np.einsum('nij,nj->ni', R[cam], X[pt]) + t[cam]
+    p = p @ K.T
+    z = p[:, :2] / p[:, 2:3] + rs.randn(len(cam), 2) * 1e-9
+    be.set_problem(nc, nt, cam, pt, z, K, np.arange(nc, dtype=np.int32), np.ones(nt, np.uint8))
+    be.set_sensor(0, np.eye(2).reshape(4))
+    be.set_params(0, R, t, np.zeros((nt, 3)))
+    got = be.triangulate(0)
+    worst_cond = 0.
+    for k in range(nt):
+        A = np.empty((2 * L, 3)); b = np.empty(2 * L)
+        for q in range(L):
+            n = k * L + q
+            for r in range(2):
+                A[2 * q + r] = (K[r] - z[n, r] * K[2]) @ R[cam[n]]
+                b[2 * q + r] = (z[n, r] * K[2] - K[r]) @ t[cam[n]]
+        ref = np.linalg.lstsq(A, b, rcond=None)[0]
+        cond = np.linalg.cond(A)
+        worst_cond = max(worst_cond, cond)
+        assert np.max(np.abs(got[k] - ref)) <= 1e-12 * cond * np.max(np.abs(ref)) + 1e-12, (k, cond, got[k], ref)
+    assert worst_cond > 1e5                                              # (the normal equations would be off by 1e-6 and more here)
+
+
 def test_window_slam_vs_reference():
     from pysfm_amd import Bundle, window_slam
     g = load_golden('scene_window_slam')
