@@ -782,6 +782,15 @@ __device__ __forceinline__ void bcr_st16(double* p, bcr_d2 v) {       // (acknow
 #ifndef BA_BCR_WIDE_HANDOVER
 #define BA_BCR_WIDE_HANDOVER 1      // fused kernel: the inputs of a node and the factor it hands on move 16 bytes per lane
 #endif
+#ifndef BA_BCR_FLAG_SLEEP
+#define BA_BCR_FLAG_SLEEP 1
+#endif
+__device__ __forceinline__ void bcr_lds_wait(int* flag, int need) {
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(BA_BCR_FLAG_SLEEP);
+}
+#ifndef BA_BCR_LDS_FLAGS
+#define BA_BCR_LDS_FLAGS 0          // split / fused node kernels: LDS counters instead of the two barriers of a block step (measured: slower)
+#endif
 #ifndef BA_BCR_TWO_STAGE
 #define BA_BCR_TWO_STAGE 0          // fused kernel: a second, early word per role for its factor (see bcr_split_node)
 #endif
@@ -838,6 +847,12 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
 
   if (tid == 0) { bad[0] = 0; bad[1] = 0; }      // bad[1]: wavefronts of this workgroup whose factor stores have landed (fused kernel)
+  // BA_BCR_LDS_FLAGS: the two barriers of a block step as counters in LDS (who waits for whom is written at the waits below):
+  // wavefront 0, whose pivot chain is the length of the node, then never waits for a wavefront that is not ahead of it anyway
+  int* cP1 = reinterpret_cast<int*>(Li + 384 + kBcrIdtDoubles + 8);      // helper wavefronts (1..15) done with phase 1, summed over the steps
+  int* cP2 = cP1 + 1;                                                    // panel wavefronts (0..3) done with phase 2, summed over the steps
+  int* fLi = cP1 + 2;                                                    // diagonal blocks factored so far (their inverses are in Li)
+  if (tid == 0) { *cP1 = 0; *cP2 = 0; *fLi = 1; }                        // (block 0 is factored before the barrier that ends the prologue)
   if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
   double* Idt = Li + 384;
   bcr_identity_table(Idt, tid);
@@ -1072,6 +1087,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
     const int kn = k0 + nb;                                 // first unknown after this block
     // ---------------- phase 1 (block 0 was factored above, next to the prologue; it has no late updates)
+    if (BA_BCR_LDS_FLAGS && kb > 0 && wave != 0) bcr_lds_wait(cP2, 4 * kb);      // the helpers need the whole panel of block kb - 1
 #ifdef BA_BCR_PROFILE
     const long long q0 = clock64();
 #endif
@@ -1200,7 +1216,20 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
 #ifdef BA_BCR_PROFILE
     if (i == 3 * s - 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q0);      // phase 1 of one block step, per wavefront
 #endif
-    if (kb > 0) __syncthreads();
+    if (BA_BCR_LDS_FLAGS) {
+      if (kb > 0) {
+        if (wave == 0) gm2_post(fLi, kb + 1, lane);                        // the inverse of diagonal block kb is in Li
+        else { lds_wave_sync(); if (lane == 0) __hip_atomic_fetch_add(cP1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      }
+      if (wave < 4) {
+        // the panel needs the helpers' updates of block column kb (and wavefront 0's prefetch their update of the next diagonal
+        // tile): all of phase 1 of this step; wavefronts 1..3 also the inverse of the diagonal block
+        if (kb > 0) bcr_lds_wait(cP1, 15 * kb);
+        if (wave > 0) bcr_lds_wait(fLi, kb + 1);
+      }
+    } else if (kb > 0) {
+      __syncthreads();
+    }
 #ifdef BA_BCR_PROFILE
     const long long q1 = clock64();
     pst[3] += q1 - q0;
@@ -1211,11 +1240,12 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
         if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
         bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
       }
+      if (BA_BCR_LDS_FLAGS) { lds_wave_sync(); if (lane == 0) __hip_atomic_fetch_add(cP2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
     }
 #if defined(BA_BCR_PROFILE) && defined(BA_BCR_TRACE_PH2)
     if (i == 3 * s - 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q1);      // phase 2 of one block step, per wavefront
 #endif
-    __syncthreads();
+    if (!BA_BCR_LDS_FLAGS) __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long q2 = clock64();
     pst[4] += q2 - q1;
@@ -1224,6 +1254,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
 #ifdef BA_BCR_PROFILE
   const long long pt2 = clock64();
 #endif
+  if (BA_BCR_LDS_FLAGS && rhs_ct >= 0) bcr_lds_wait(fLi, NBLK);                // (the last diagonal block's inverse)
   if (rhs_ct >= 0) {
     // the last block row of the right-hand sides: Y = L_pp^-1 racc[NBLK - 1] (nothing below it)
     constexpr int KL = 12 * (NBLK - 1), NL = B - KL;          // last block: start and size (12 or 6)
