@@ -264,10 +264,11 @@ OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config3_shuffled', 3, 'gaussian', 0., True, 0.),
     ('config3_30pct_dropped', 3, 'gaussian', 0., False, .3),
     ('config5_one_gpu', 5, 'gaussian', 0., False, 0.),
+    ('config3_track_length_32', 3, 'gaussian', 0., False, 0., 32),      # long tracks: windows of 32 cameras on the matrix cores, band-limited dense solve
 ]
 
 
-def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, steps=20, warmup=8, scene_cache=None):
+def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, track_len=10, steps=20, warmup=8, scene_cache=None):
     """`other_configs`: a short run of one of the other BASELINE configurations / scene shapes on this GPU, the same
     complete LM trial per step, timed the same way (no events in the timed window; the per-kernel numbers come from
     bracketed trials before it)."""
@@ -277,15 +278,15 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, st
     cfg = CONFIGS[cfg_id]
     nc, nt = cfg['cams'], cfg['points']
     init_mode = 'pose' if cfg_id == 5 else 'params'
-    key = (nc, nt, outliers, init_mode)
+    key = (nc, nt, outliers, init_mode, track_len)
     if scene_cache is not None and key in scene_cache:
         s = scene_cache[key]
     else:
-        s = sd.generate_banded_scene(nc, nt, outlier_frac=outliers, init_mode=init_mode)
+        s = sd.generate_banded_scene(nc, nt, track_len=track_len, outlier_frac=outliers, init_mode=init_mode)
         if scene_cache is not None:
             scene_cache.clear()                     # (one scene at a time: config 5 is 400 MB of host arrays)
             scene_cache[key] = s
-    obs_cam, obs_pt, obs_z, X0 = scene_variant(s, 10, shuffle, drop)
+    obs_cam, obs_pt, obs_z, X0 = scene_variant(s, track_len, shuffle, drop)
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
     bundle = Bundle.FromObservations(s['K'], s['R0'], s['t0'], X0, obs_cam, obs_pt, obs_z, sensor_model=model)
@@ -314,8 +315,8 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, st
     kms = {k: v['ms'] / warmup for k, v in tm.items()}
     pass_ms = sum(kms[k] for k in PASS_KERNELS if k in kms)
     info = be.problem_info()
-    out = {'workload': 'BASELINE configs[%d]: %d cameras / %d points / %d observations, %s sensor model%s%s%s' % (
-               cfg_id - 1, nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
+    out = {'workload': 'BASELINE configs[%d]%s: %d cameras / %d points / %d observations, %s sensor model%s%s%s' % (
+               cfg_id - 1, '' if track_len == 10 else ' with track length %d' % track_len, nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
                ', tracks and observations in random order' if shuffle else '',
                ', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * drop) if drop else ''),
            'init_mode': init_mode, 'steps': steps, 'warmup': warmup + 1, 'ms_per_step': 1e3 * dt / steps, 'obs_per_s': nobs * steps / dt,
