@@ -1,32 +1,33 @@
-import time, sys, os
-sys.path.insert(0, '/root/repo')
-import numpy as np
-from pysfm_amd import Bundle, BundleAdjuster, sensor_model
-from pysfm_amd import synthetic_data as sd
-from pysfm_amd._capi import PARAMS_CUR
+"""How much of a trial's wall-clock is the host: ba.trial (Python accept / reject bookkeeping) against HipBackend.lm_trial
+(the ctypes call alone) against the sum of the kernels (HIP events).  usage (GPU box): python scripts/host_gap.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pysfm_amd import Bundle, BundleAdjuster          # noqa: E402
+from pysfm_amd import synthetic_data as sd            # noqa: E402
+
 s = sd.generate_banded_scene(1000, 100000)
-b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=sensor_model.GaussianModel(1.))
-ba = BundleAdjuster(verbose=False); ba.set_bundle(b); be = ba.backend
-cur = ba._cost(PARAMS_CUR)
-lam = 10.
-t_c = 0.; t_all = 0.
-for it in range(60):
+b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+ba = BundleAdjuster(verbose=False)
+ba.set_bundle(b)
+be = ba.backend
+for _ in range(30):
+    be.lm_trial(10., 1e-5, None)
+n = 400
+for name, f in (('HipBackend.lm_trial (rejected every time: damping 1e9)', lambda: be.lm_trial(1e9, 1e-5, None)),
+                ('HipBackend.lm_trial (damping 10)', lambda: be.lm_trial(10., 1e-5, None)),
+                ('BundleAdjuster.trial (damping 10, never accepted: cur_cost 0)', lambda: ba.trial(10., None, 0.))):
+    be.synchronize()
     t0 = time.perf_counter()
-    # replicate ba.trial inline to time the C call
-    t1 = time.perf_counter()
-    info, cost = be.lm_trial(lam, 1e-5, None)
-    t2 = time.perf_counter()
-    if cost < cur:
-        be.swap_params(); cur = cost; lam *= .1
-    else:
-        lam *= 10.
-    if lam > 1e8 or lam < 1e-12: lam = 10.
-    t3 = time.perf_counter()
-    if it >= 10:
-        t_c += t2 - t1; t_all += t3 - t0
-print('C call %.1f us, python around it %.1f us per trial' % (t_c / 50 * 1e6, (t_all - t_c) / 50 * 1e6))
-t0 = time.perf_counter()
-for it in range(50):
-    acc, nxt = ba.trial(lam, None, cur)
-t1 = time.perf_counter()
-print('ba.trial: %.1f us per trial' % ((t1 - t0) / 50 * 1e6))
+    for _ in range(n):
+        f()
+    be.synchronize()
+    print('%-70s %.2f us per call' % (name, (time.perf_counter() - t0) / n * 1e6))
+be.enable_timing(True)
+be.timings(reset=True)
+for _ in range(50):
+    be.lm_trial(10., 1e-5, None)
+tm = be.timings(reset=True)
+print('kernels (HIP events, each bracket adds ~2.5 us): %.1f us per trial' % (sum(v['ms'] for v in tm.values()) / 50 * 1e3))
