@@ -434,3 +434,49 @@ def test_shard_tracks_any_order_and_empty_shards():
     empty = [p for p in parts if not p][0]
     ba.set_bundle(tiny, camera_ids=list(range(12)), track_ids=empty)     # must not raise
     assert ba.track_ids == [] and ba.optim_track_ids == []
+
+
+# ------------------------------------------------------------------ round 3: the cut of the distributed reduced solve (no GPU needed)
+def _dist_plan(nco, hb, world):
+    """ba_dist_plan through ctypes: a pure function of its arguments (HipBackend.dist_plan without a device)."""
+    import ctypes as C
+    from pysfm_amd import _capi
+    lib = _capi.load()
+    cb, N, P = C.c_int32(), C.c_int32(), C.c_int32()
+    if lib.ba_dist_plan(int(nco), int(hb), int(world), C.byref(cb), C.byref(N), C.byref(P)) != _capi.BA_OK:
+        return None
+    return cb.value, N.value, P.value
+
+
+def test_distributed_solve_plan_and_track_cut():
+    """csrc/ba_dist.h: the elimination tree of the cyclic reduction cut along the ranks.  The plan for BASELINE config 5
+    (9999 optimised cameras, half-bandwidth 9, 8 ranks) is 1000 nodes of 10 cameras, 128 per rank; it exists only for 2^g
+    ranks and systems with enough nodes; shard_tracks(plan=...) cuts the tracks where the plan says - consecutive ranges
+    that cover every track, each rank's tracks STARTING inside its own interval of camera positions."""
+    from pysfm_amd import synthetic_data as sd
+    from pysfm_amd.distributed import shard_tracks, tree_cut
+    assert _dist_plan(9999, 9, 8) == (10, 1000, 128)
+    assert _dist_plan(9999, 9, 2) == (10, 1000, 512)
+    assert _dist_plan(9999, 9, 3) is None and _dist_plan(9999, 9, 1) is None       # 2^g ranks only
+    assert _dist_plan(50, 9, 8) is None                                             # too few nodes to cut
+    assert _dist_plan(9999, 12, 8) is None                                          # beyond the narrow cyclic reduction
+    cb, N, P = _dist_plan(2399, 9, 4)
+    assert cb >= 9 and N == -(-2399 // cb) and 3 * P < N <= 4 * P and P & (P - 1) == 0
+    nc, nt, world = 2400, 6000, 4
+    s = sd.generate_banded_scene(nc, nt)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    cuts = tree_cut(b, world, _dist_plan)
+    assert cuts[0] == 0 and cuts[-1] == nc and cuts[1:-1] == [r * P * cb + 1 for r in range(1, world)]
+    first = np.full(nt, nc, np.int64)
+    np.minimum.at(first, s['obs_pt'], s['obs_cam'])
+    seen = []
+    for r in range(world):
+        ids = shard_tracks(b, r, world, plan=_dist_plan)
+        seen += ids
+        pos = np.maximum(first[ids], 1) - 1                     # first OPTIMISED position (camera 0 is frozen)
+        assert len(ids) > 0 and pos.min() >= r * P * cb and (pos.max() < (r + 1) * P * cb or r == world - 1)
+    assert sorted(seen) == list(range(nt))
+    # without a plan (or where none exists) the cut is the observation-balanced one
+    sizes = [len(shard_tracks(b, r, 3)) for r in range(3)]
+    assert sum(sizes) == nt and max(sizes) - min(sizes) <= 2
+    assert [len(shard_tracks(b, r, 3, plan=_dist_plan)) for r in range(3)] == sizes
