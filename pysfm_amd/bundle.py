@@ -479,9 +479,48 @@ def Jpr(x):
 
 def project(K, R, t, x):
     """Pinhole projection of a single point through the GPU evaluator (bundle.py:14-19)."""
+    return _one_observation(K, R, t, x).predict(0, 0)
+
+
+def _one_observation(K, R, t, x):
+    """A one-camera, one-point bundle with the unit Gaussian sensor model: residual = projection - measurement, so the
+    evaluator's residual Jacobians ARE the Jacobians of the projection."""
     b = Bundle()
     b.K = np.asarray(K, float)
     b.add_camera(Camera(np.asarray(R, float), np.asarray(t, float)))
     b.tracks.append(Track())
     b.reconstruction = np.asarray(x, float).reshape(1, 3)
-    return b.predict(0, 0)
+    return b
+
+
+def project2(K, R0, m, t, x):
+    """Projection through the camera turned by exp(m) on the right, R = R0 exp(m) (bundle.py:22-24: the function whose
+    derivative at m = 0 is Jproject_R)."""
+    return project(K, np.dot(np.asarray(R0, float), lie.SO3.exp(m)), t, x)
+
+
+def Jproject_all(K, R, t, x):
+    """(2x6 Jacobian w.r.t. the camera [rotation | translation], 2x3 Jacobian w.r.t. the point) of project() - evaluated
+    by the GPU evaluator (k_eval), as Bundle.Jresidual is (bundle.py:45-50)."""
+    out = _one_observation(K, R, t, x)._device_eval([0], [0], np.zeros((1, 2)), e=False, r=False, Jc=True, Jp=True)
+    return out['Jc'][0], out['Jp'][0]
+
+
+def Jproject_cam(K, R, t, x):
+    """2x6 Jacobian of project() w.r.t. the camera parameters (bundle.py:40-42)."""
+    return Jproject_all(K, R, t, x)[0]
+
+
+def Jproject_R(K, R, t, x):
+    """2x3 Jacobian of project() w.r.t. the rotation update m of R exp(m) (bundle.py:27-29)."""
+    return Jproject_all(K, R, t, x)[0][:, :3]
+
+
+def Jproject_t(K, R, t, x):
+    """2x3 Jacobian of project() w.r.t. the translation (bundle.py:32-33)."""
+    return Jproject_all(K, R, t, x)[0][:, 3:]
+
+
+def Jproject_x(K, R, t, x):
+    """2x3 Jacobian of project() w.r.t. the point (bundle.py:36-37)."""
+    return Jproject_all(K, R, t, x)[1]

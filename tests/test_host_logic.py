@@ -480,3 +480,37 @@ def test_distributed_solve_plan_and_track_cut():
     sizes = [len(shard_tracks(b, r, 3)) for r in range(3)]
     assert sum(sizes) == nt and max(sizes) - min(sizes) <= 2
     assert [len(shard_tracks(b, r, 3, plan=_dist_plan)) for r in range(3)] == sizes
+
+
+def test_projection_jacobian_helpers_and_plane_rotations():
+    """The module-level helpers the reference's own tests use (bundle.py:22-50, geometry.py:28-41; bundle_unittest.py:146-162
+    checks exactly this): Jproject_R / _t / _x against central differences of project2 / project, Jproject_cam / _all
+    consistent with them; rotation_xy / _xz / _yz with the reference's sign conventions."""
+    from pysfm_amd import bundle as B, geometry as G
+    K0 = np.array([[1.2, 0., .1], [0., .9, -.05], [0., 0., 1.]])
+    R0 = G.rotation_xy(1.1)
+    t0 = np.array([3., 4., 5.5])
+    x0 = np.array([-1., 2., 6.])
+
+    def fd(f, at):
+        J = np.empty((2, 3))
+        for k in range(3):
+            d = np.zeros(3)
+            d[k] = 1e-6
+            J[:, k] = (f(at + d) - f(at - d)) / 2e-6
+        return J
+    close(B.Jproject_R(K0, R0, t0, x0), fd(lambda m: B.project2(K0, R0, m, t0, x0), np.zeros(3)), 1e-7)
+    close(B.Jproject_t(K0, R0, t0, x0), fd(lambda t: B.project(K0, R0, t, x0), t0), 1e-7)
+    close(B.Jproject_x(K0, R0, t0, x0), fd(lambda x: B.project(K0, R0, t0, x), x0), 1e-7)
+    Jc, Jx = B.Jproject_all(K0, R0, t0, x0)
+    close(Jc, np.hstack((B.Jproject_R(K0, R0, t0, x0), B.Jproject_t(K0, R0, t0, x0))), 1e-14)
+    close(Jc, B.Jproject_cam(K0, R0, t0, x0), 1e-14)
+    close(Jx, B.Jproject_x(K0, R0, t0, x0), 1e-14)
+    th = .37
+    c, s_ = np.cos(th), np.sin(th)
+    close(G.rotation_xy(th), [[c, -s_, 0], [s_, c, 0], [0, 0, 1]], 1e-15)
+    close(G.rotation_xz(th), [[c, 0, -s_], [0, 1, 0], [s_, 0, c]], 1e-15)
+    close(G.rotation_yz(th), [[1, 0, 0], [0, c, -s_], [0, s_, c]], 1e-15)
+    for R in (G.rotation_xy(th), G.rotation_xz(th), G.rotation_yz(th)):
+        close(R @ R.T, np.eye(3), 1e-15)
+        assert abs(np.linalg.det(R) - 1.) < 1e-15
