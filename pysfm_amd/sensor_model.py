@@ -134,3 +134,10 @@ def validate(sensor_model):
         Jn[:, c] = (sensor_model.residual_from_error(error + d) - sensor_model.residual_from_error(error - d)) / (2 * h)
     assert np.max(np.abs(J - Jn)) < 1e-5, 'Jacobian seems to be incorrect at ' + str(error)
     return True
+
+
+def run_tests():
+    """The reference's self-check entry point (sensor_model.py:104-110): every model of the package through validate()."""
+    for name, model in (('Gaussian', GaussianModel([2., 3.])), ('Cauchy', CauchyModel(2.)), ('Huber', HuberModel(1.5))):
+        print('Validating %s sensor model...' % name)
+        validate(model)

@@ -291,6 +291,11 @@ def test_track_and_incremental_building():
     assert list(b.measurement_ids()) == [(0, 0), (1, 0)]
 
 
+def test_sensor_model_run_tests_entry_point(capsys):
+    sensor_model.run_tests()
+    assert 'Huber' in capsys.readouterr().out
+
+
 def test_sensor_models_protocol():
     for m in (sensor_model.GaussianModel([2., 3.]), sensor_model.CauchyModel(2.), sensor_model.HuberModel(.7)):
         assert sensor_model.validate(m)
