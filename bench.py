@@ -256,6 +256,27 @@ def scene_variant(s, track_len, shuffle, drop):
     return obs_cam, obs_pt, obs_z, X0
 
 
+def with_long_tracks(s, nc, nt, L, every, llen, seed=3):
+    """The generator's scene with every `every`-th point seen by `llen` consecutive cameras instead of L (measurements from
+    the true parameters + the scene's noise level)."""
+    rs = np.random.RandomState(seed)
+    long_pts = np.arange(every // 2, nt, every)
+    keep = np.ones(len(s['obs_cam']), bool)
+    keep.reshape(nt, L)[long_pts] = False
+    c0 = np.clip(s['obs_cam'][long_pts * L] - llen // 2, 0, nc - llen)
+    cam = (c0[:, None] + np.arange(llen)[None, :]).reshape(-1)
+    pt = np.repeat(long_pts, llen)
+    p = np.einsum('nij,nj->ni', s['R'][cam], s['X'][pt]) + s['t'][cam]
+    z = p[:, :2] / p[:, 2:3] + rs.randn(len(cam), 2) * .02
+    oc = np.concatenate((s['obs_cam'][keep], cam)).astype(np.int32)
+    op = np.concatenate((s['obs_pt'][keep], pt)).astype(np.int32)
+    oz = np.concatenate((s['obs_z'][keep], z))
+    o = np.lexsort((oc, op))
+    out = dict(s)
+    out.update(obs_cam=oc[o], obs_pt=op[o], obs_z=oz[o])
+    return out
+
+
 PASS_KERNELS = ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs')
 OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config2', 2, 'gaussian', 0., False, 0.),
@@ -403,6 +424,9 @@ def main():
     ap.add_argument('--shuffle-points', action='store_true')
     ap.add_argument('--drop-observations', type=float, default=0., metavar='FRAC',
                     help='drop this fraction of the observations at random (every track keeps two): camera lists no longer repeat')
+    ap.add_argument('--long-tracks', default=None, metavar='EVERY,LENGTH',
+                    help='every EVERY-th point is seen by LENGTH consecutive cameras instead of --track-len (features that survive for a long '
+                         'stretch of the video): e.g. 50,80')
     ap.add_argument('--sensor', default=None, choices=['gaussian', 'cauchy', 'huber'])
     ap.add_argument('--outliers', type=float, default=None)
     ap.add_argument('--windows', type=int, default=5, help='extra timed windows of --steps trials after the headline one (min / median)')
@@ -426,7 +450,7 @@ def main():
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)       # the run rocprofv3 wraps: a few trials, no JSON line
     args = ap.parse_args()
     global PMC_WORKLOAD
-    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations
+    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations and not args.long_tracks
     PMC_WORKLOAD = ('config3' if args.config == 3 else 'config%d' % args.config) if plain and args.gpus == 1 and args.sensor is None and args.outliers is None else 'none'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -467,7 +491,11 @@ def main():
     outliers = cfg.get('outliers', 0.) if args.outliers is None else args.outliers
     init_mode = args.init_mode or ('pose' if args.config == 5 else 'params')
     s = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers, init_mode=init_mode)
-    obs_cam, obs_pt, obs_z, X0 = scene_variant(s, args.track_len, args.shuffle_points, args.drop_observations)
+    if args.long_tracks:
+        every, llen = [int(v) for v in args.long_tracks.split(',')]
+        s = with_long_tracks(s, nc, nt, args.track_len, every, llen)
+    obs_cam, obs_pt, obs_z, X0 = scene_variant(s, args.track_len, args.shuffle_points, args.drop_observations) if not args.long_tracks \
+        else (s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0'])
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
     bundle = Bundle.FromObservations(s['K'], s['R0'], s['t0'], X0, obs_cam, obs_pt, obs_z, sensor_model=model)
@@ -716,7 +744,7 @@ def main():
         }
         out.update(lm)
         plain3 = (args.config == 3 and args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
-                  and not args.drop_observations and not args.shuffle_points and args.sensor is None and args.outliers is None)
+                  and not args.drop_observations and not args.shuffle_points and args.sensor is None and args.outliers is None and not args.long_tracks)
         if ngpus == 1 and comm is None and plain3 and not args.no_other_configs:
             # the other BASELINE configurations and scene shapes, a short run each on this same GPU (the headline handle is idle)
             t_oc = time.time()

@@ -120,6 +120,11 @@ struct ba_handle {
   DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
   DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
   int nm3chunks = 0, nwgroups = 0;
+  // hybrid reduction: most tracks fit a window of <= kGm3MaxSpan cameras (matrix cores), a FEW span more (video tracks that
+  // survive for hundreds of frames, loop closures): only those go through k_schur_pairs (lunits / lchunks)
+  DevBuf<SchurUnit> lunits;
+  DevBuf<SchurChunk> lchunks;
+  int nlchunks = 0, nlong_points = 0;
   bool gm3_uniform_ks = false;          // every window group has 6 points per batch (width <= 10): five k-steps
   bool wgroups_worth = false;           // enough points per window group for the matrix-core reduction to pay
   int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
@@ -965,7 +970,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->lunits.release(); h->lchunks.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1340,6 +1345,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   std::vector<WinGroup> wgroups;
   std::vector<int> wtab;
   bool wgroups_worth = false;
+  std::vector<SchurUnit> lunits;
+  std::vector<SchurChunk> lchunks;
+  int nlong_points = 0;
   {
     std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
     int maxspan = 0;
@@ -1356,6 +1364,28 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       if (phi[k - 1] >= 0) last = plo[k - 1];
       if (phi[k] >= 0 && plo[k] < last) sorted_by_lo = false;
     }
+    // points whose optimised cameras span more than the widest window: if they are few, everybody else keeps the matrix cores
+    // and only they take the pair kernel
+    auto is_long = [&](int k) { return phi[k] >= 0 && phi[k] - plo[k] + 1 > kGm3MaxSpan; };
+    long long nlong = 0, nshort = 0;
+    int shortspan = 0;
+    for (int k = 0; k < nt; ++k) {
+      if (phi[k] < 0) continue;
+      if (is_long(k)) ++nlong; else { ++nshort; shortspan = std::max(shortspan, phi[k] - plo[k] + 1); }
+    }
+    const bool hybrid = nlong > 0 && nshort >= 3 * nlong && shortspan >= 1 && sorted_by_lo && nco > 0;
+    if (hybrid) {
+      maxspan = shortspan;
+      for (int k = 0; k < nt; ++k) {
+        if (!is_long(k)) continue;
+        const int L = off[(size_t)k + 1] - off[k];
+        for (int r = 0; r < L; r += kTile)
+          for (int c = r; c < L; c += kTile) lunits.push_back({k, r, c});
+      }
+      for (int u = 0; u < (int)lunits.size(); u += kSchurChunkUnits)      // (no LDS window at these band widths: chunks by count)
+        lchunks.push_back({u, std::min(u + kSchurChunkUnits, (int)lunits.size()), 0});
+      nlong_points = (int)nlong;
+    }
     if (maxspan >= 1 && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
       gm3.nts = (6 * maxspan + 15) / 16;
       gm3.Ld = 16 * gm3.nts;
@@ -1364,9 +1394,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       struct Run { int b, e, lo, hi; };
       std::vector<Run> runs;
       for (int k = 0; k < nt;) {
-        if (phi[k] < 0) { ++k; continue; }             // (points without an optimised camera add nothing to S or b)
+        if (phi[k] < 0 || (hybrid && is_long(k))) { ++k; continue; }      // (points without an optimised camera add nothing to S or b; long ones take the pair kernel)
         int e = k + 1, lo = plo[k], hi = phi[k];
-        while (e < nt && (phi[e] < 0 || std::max(hi, phi[e]) - lo + 1 <= wmax)) {
+        while (e < nt && !(hybrid && is_long(e)) && (phi[e] < 0 || std::max(hi, phi[e]) - lo + 1 <= wmax)) {
           if (phi[e] >= 0) hi = std::max(hi, phi[e]);
           ++e;
         }
@@ -1461,6 +1491,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->gm3_uniform_ks = !wgroups.empty();
   for (const WinGroup& g : wgroups) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(g.W, gm3.np_cap) == kGmPts;
   h->wgroups_worth = wgroups_worth;
+  h->nlchunks = wgroups.empty() ? 0 : (int)lchunks.size();      // (the hybrid only exists next to the matrix-core reduction)
+  h->nlong_points = h->nlchunks ? nlong_points : 0;
   h->gm3 = gm3;
   h->groups_worth = groups_worth;
   h->nmgroups_total = (int)mgroups.size();
@@ -1481,6 +1513,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->pt_off.resize((size_t)nt + 1));
   HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
   HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
+  HIPCHECK(h, h->lunits.resize(std::max<size_t>(1, lunits.size())));
+  HIPCHECK(h, h->lchunks.resize(std::max<size_t>(1, lchunks.size())));
+  if (!lunits.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->lunits.p, lunits.data(), lunits.size() * sizeof(SchurUnit), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->lchunks.p, lchunks.data(), lchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  }
   HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
   HIPCHECK(h, h->chunks.resize(std::max<size_t>(1, chunks.size())));
   if (!chunks.empty())
@@ -1925,7 +1963,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     rc = launch_point_blocks(h, h->lin_phys, nullptr);
     if (rc != BA_OK) return rc;
   }
-  const bool fuse_cam = use_mfma && !h->cam_blocks_valid;
+  const bool hybrid = kern == KERN_MFMA3 && h->nlchunks > 0;       // a few long tracks beside the window groups: their pairs through k_schur_pairs
+  const bool fuse_cam = use_mfma && !h->cam_blocks_valid && !hybrid;  // (the camera blocks of the long tracks' observations need k_camera_blocks)
   if (!h->cam_blocks_valid && !fuse_cam) {
     rc = launch_camera_blocks(h, h->lin_phys, true);
     if (rc != BA_OK) return rc;
@@ -1990,9 +2029,16 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
                        h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
   } else if (kern == KERN_MFMA3) {
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, mfma3_launches(h->gm3.nts));
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, mfma3_launches(h->gm3.nts) + (hybrid ? 1 : 0));
     rc = launch_mfma3_all(h, p, damping, fuse_cam);
     if (rc != BA_OK) return rc;
+    if (hybrid) {
+      const int NW = kSchurBlock / kWave;
+      const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int);
+      HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_pairs));
+      hipLaunchKernelGGL(k_schur_pairs, dim3(h->nlchunks), dim3(kSchurBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->lunits.p, h->lchunks.p, 0, h->HPPinv.p, h->bP.p, h->S, h->b);
+    }
   } else if (kern == KERN_MFMA2) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma2));
@@ -2458,7 +2504,8 @@ int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   h->defer = true;
   // with the MFMA reduction the camera blocks come out of the reduction itself: one launch and one pass
   // over the observations less
-  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(pick_schur_kernel(h));
+  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(pick_schur_kernel(h)) &&
+                    !(pick_schur_kernel(h) == KERN_MFMA3 && h->nlchunks > 0);
   int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
   h->defer = false;

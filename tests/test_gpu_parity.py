@@ -1206,6 +1206,60 @@ def test_triangulation_of_low_parallax_tracks_equals_lstsq(be):
     assert worst_cond > 1e5                                              # (the normal equations would be off by 1e-6 and more here)
 
 
+def _with_long_tracks(s, nc, nt, every, Llong, seed=3):
+    """The banded scene with every `every`-th point seen by Llong consecutive cameras instead of 10 (a feature that survives
+    for a long stretch of the video): measurements from the true parameters + the scene's noise."""
+    rs = np.random.RandomState(seed)
+    cam, pt, z = [], [], []
+    L = len(s['obs_cam']) // nt
+    for k in range(nt):
+        if k % every == every // 2:
+            c0 = int(np.clip(s['obs_cam'][k * L] - Llong // 2, 0, nc - Llong))
+            cs = np.arange(c0, c0 + Llong)
+            p = np.einsum('nij,j->ni', s['R'][cs], s['X'][k]) + s['t'][cs]
+            zz = p[:, :2] / p[:, 2:3] + rs.randn(Llong, 2) * .02
+            cam.append(cs); pt.append(np.full(Llong, k)); z.append(zz)
+        else:
+            sl = slice(k * L, (k + 1) * L)
+            cam.append(s['obs_cam'][sl]); pt.append(s['obs_pt'][sl]); z.append(s['obs_z'][sl])
+    return np.concatenate(cam).astype(np.int32), np.concatenate(pt).astype(np.int32), np.concatenate(z)
+
+
+@pytest.mark.parametrize('Llong,sensor', [(60, O.Sensor.gaussian(1.)), (140, O.Sensor.cauchy(.05))])
+def test_a_few_long_tracks_leave_the_rest_on_the_matrix_cores(be, Llong, sensor):
+    """Tracks that span more than the widest window of the matrix-core reduction (40 cameras) used to send the WHOLE scene to the
+    pair kernel.  When they are few (here 2.5 % of the points, 60 / 140 cameras long) the window groups keep everybody else
+    and only the long tracks' pairs go through k_schur_pairs (+ k_camera_blocks for the camera blocks): S, b, the solve and
+    the whole trial against the oracle, and against the pair kernel alone."""
+    nc, nt = 300, 6000
+    s = banded(nc, nt)
+    cam, pt, z = _with_long_tracks(s, nc, nt, 40, Llong)
+    flags = default_flags(nc, nt)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
+    out = {}
+    for kern in ('pairs', 'auto'):
+        be.set_option('schur', kern)
+        load_problem(be, *a, *flags, sensor)
+        info = be.problem_info()
+        assert info['schur_kernel'] == (0 if kern == 'pairs' else 4) and info['half_bandwidth'] == Llong - 1
+        be.linearize(0)
+        be.schur(0, 3., 1e-5)
+        out[kern] = be.get_reduced()
+    close(out['auto'][0], out['pairs'][0], 1e-12)
+    close(out['auto'][1], out['pairs'][1], 1e-12)
+    mu, su, parts = O.compute_update(sensor, *a, *flags, damping=3., return_parts=True)
+    close(out['auto'][0], parts['S'], TIGHT)
+    close(out['auto'][1], parts['b'], TIGHT)
+    info, cost = be.lm_trial(3., 1e-5, None)
+    assert info == 0
+    St, bt = be.get_reduced()
+    close(St, parts['S'], TIGHT)
+    close(bt, parts['b'], TIGHT)
+    R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, *flags)
+    close(be.get_params(1)[2], X2, 1e-8)
+    close(cost, O.cost(sensor, s['K'], R2, t2, X2, cam, pt, z, *flags), 1e-8)
+
+
 def test_window_slam_vs_reference():
     from pysfm_amd import Bundle, window_slam
     g = load_golden('scene_window_slam')
