@@ -1260,6 +1260,32 @@ def test_a_few_long_tracks_leave_the_rest_on_the_matrix_cores(be, Llong, sensor)
     close(cost, O.cost(sensor, s['K'], R2, t2, X2, cam, pt, z, *flags), 1e-8)
 
 
+def test_distributed_solve_entry_points_fail_loudly_when_misused(be):
+    """include/pysfm_ba.h ba_dist_*: a stage without an enabled plan, an exchange buffer that is too small, a plan for a rank
+    count that is not a power of two - status codes and messages, never a silent fall-back."""
+    import ctypes as C
+    from pysfm_amd import _capi as capi
+    s = banded(300, 6000)
+    flags = default_flags(300, 6000)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    lib, h = be._lib, be._h
+    n = C.c_int64()
+    assert lib.ba_dist_stage(h, 1, None, C.byref(n)) == capi.BA_ERR_STATE and b'ba_dist_enable' in lib.ba_last_error(h)
+    assert be.dist_plan(299, 9, 3) is None and be.dist_plan(299, 9, 2) is not None
+    info = be.dist_enable(0, 3)                      # no plan for three ranks: stays off, no error
+    assert info['on'] == 0 and not be.dist_on
+    info = be.dist_enable(1, 2)
+    assert info['on'] == 1 and info['cams_per_node'] >= 9 and info['node_lo'] == info['nodes_per_rank']
+    assert lib.ba_dist_bind_exchange(h, C.c_void_p(be._dist_t.data_ptr()), 8) == capi.BA_ERR_INVALID_ARG
+    assert lib.ba_dist_stage(h, 1, None, C.byref(n)) == capi.BA_ERR_STATE            # (no reduction yet: ba_lm_trial_begin first)
+    be.lm_trial_begin(10., 1e-5)
+    assert lib.ba_dist_stage(h, 7, None, C.byref(n)) == capi.BA_ERR_INVALID_ARG
+    assert be.dist_stage(1).numel() == info['exchange1_doubles']
+    be.dist_enable(0, 1)                             # off again: the shared backend goes back to the plain trial
+    assert not be.dist_on
+    assert be.lm_trial(10., 1e-5, None)[0] == 0
+
+
 def test_window_slam_vs_reference():
     from pysfm_amd import Bundle, window_slam
     g = load_golden('scene_window_slam')
