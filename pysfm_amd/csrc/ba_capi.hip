@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -120,11 +121,10 @@ struct ba_handle {
   DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
   DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
   int nm3chunks = 0, nwgroups = 0;
-  // hybrid reduction: most tracks fit a window of <= kGm3MaxSpan cameras (matrix cores), a FEW span more (video tracks that
-  // survive for hundreds of frames, loop closures): only those go through k_schur_pairs (lunits / lchunks)
-  DevBuf<SchurUnit> lunits;
-  DevBuf<SchurChunk> lchunks;
-  int nlchunks = 0, nlong_points = 0;
+  // tracks that span more than kGm3MaxSpan cameras: members of their segments' window groups + rectangular groups between segments
+  DevBuf<RectGroup> rgroups;
+  DevBuf<int> rtab;
+  int nrgroups = 0, nlong_points = 0;
   bool gm3_uniform_ks = false;          // every window group has 6 points per batch (width <= 10): five k-steps
   bool wgroups_worth = false;           // enough points per window group for the matrix-core reduction to pay
   int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
@@ -970,7 +970,7 @@ int ba_destroy(ba_handle* h) {
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->lunits.release(); h->lchunks.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->rgroups.release(); h->rtab.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1345,8 +1345,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   std::vector<WinGroup> wgroups;
   std::vector<int> wtab;
   bool wgroups_worth = false;
-  std::vector<SchurUnit> lunits;
-  std::vector<SchurChunk> lchunks;
+  std::vector<RectGroup> rgroups;
+  std::vector<int> rtab;
   int nlong_points = 0;
   {
     std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
@@ -1364,27 +1364,46 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       if (phi[k - 1] >= 0) last = plo[k - 1];
       if (phi[k] >= 0 && plo[k] < last) sorted_by_lo = false;
     }
-    // points whose optimised cameras span more than the widest window: if they are few, everybody else keeps the matrix cores
-    // and only they take the pair kernel
+    // Points whose optimised cameras span MORE than the widest window (features that survive for a long stretch of a video):
+    // their cameras are cut along a grid of SEGMENTS of kRectSeg positions.  Inside a segment such a point is one more member of
+    // a window group (the segment is its window; a point list instead of a range of points) - right-hand side and camera
+    // blocks come from there, every observation lies in exactly one segment.  The blocks BETWEEN two segments a point touches
+    // are rectangular products, S[A, B] -= U_A^T D U_B: k_schur_rect_mfma over the points that touch both (rgroups).
     auto is_long = [&](int k) { return phi[k] >= 0 && phi[k] - plo[k] + 1 > kGm3MaxSpan; };
-    long long nlong = 0, nshort = 0;
+    long long nlong = 0;
     int shortspan = 0;
     for (int k = 0; k < nt; ++k) {
       if (phi[k] < 0) continue;
-      if (is_long(k)) ++nlong; else { ++nshort; shortspan = std::max(shortspan, phi[k] - plo[k] + 1); }
+      if (is_long(k)) ++nlong; else shortspan = std::max(shortspan, phi[k] - plo[k] + 1);
     }
-    const bool hybrid = nlong > 0 && nshort >= 3 * nlong && shortspan >= 1 && sorted_by_lo && nco > 0;
+    const bool hybrid = nlong > 0 && sorted_by_lo && nco > 0;
+    struct SegTask { int qa, qb; std::vector<int> pts; };
+    std::vector<SegTask> sym_tasks, rect_tasks;
     if (hybrid) {
-      maxspan = shortspan;
+      maxspan = std::max(shortspan, kRectSeg);
+      nlong_points = (int)nlong;
+      std::map<long long, int> sym_id, rect_id;
       for (int k = 0; k < nt; ++k) {
         if (!is_long(k)) continue;
-        const int L = off[(size_t)k + 1] - off[k];
-        for (int r = 0; r < L; r += kTile)
-          for (int c = r; c < L; c += kTile) lunits.push_back({k, r, c});
+        std::vector<int> segs;
+        for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+          const int p = cam_opt_pos[obs_cam[n]];
+          if (p >= 0) segs.push_back(p / kRectSeg);
+        }
+        std::sort(segs.begin(), segs.end());
+        segs.erase(std::unique(segs.begin(), segs.end()), segs.end());
+        for (size_t x = 0; x < segs.size(); ++x) {
+          auto it = sym_id.find(segs[x]);
+          if (it == sym_id.end()) { it = sym_id.emplace(segs[x], (int)sym_tasks.size()).first; sym_tasks.push_back({segs[x], segs[x], {}}); }
+          sym_tasks[it->second].pts.push_back(k);
+          for (size_t y = x + 1; y < segs.size(); ++y) {
+            const long long key = ((long long)segs[x] << 32) | (unsigned)segs[y];
+            auto jt = rect_id.find(key);
+            if (jt == rect_id.end()) { jt = rect_id.emplace(key, (int)rect_tasks.size()).first; rect_tasks.push_back({segs[x], segs[y], {}}); }
+            rect_tasks[jt->second].pts.push_back(k);
+          }
+        }
       }
-      for (int u = 0; u < (int)lunits.size(); u += kSchurChunkUnits)      // (no LDS window at these band widths: chunks by count)
-        lchunks.push_back({u, std::min(u + kSchurChunkUnits, (int)lunits.size()), 0});
-      nlong_points = (int)nlong;
     }
     if (maxspan >= 1 && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
       gm3.nts = (6 * maxspan + 15) / 16;
@@ -1394,7 +1413,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       struct Run { int b, e, lo, hi; };
       std::vector<Run> runs;
       for (int k = 0; k < nt;) {
-        if (phi[k] < 0 || (hybrid && is_long(k))) { ++k; continue; }      // (points without an optimised camera add nothing to S or b; long ones take the pair kernel)
+        if (phi[k] < 0 || (hybrid && is_long(k))) { ++k; continue; }      // (points without an optimised camera add nothing to S or b; long ones are members of their segments' groups)
         int e = k + 1, lo = plo[k], hi = phi[k];
         while (e < nt && !(hybrid && is_long(e)) && (phi[e] < 0 || std::max(hi, phi[e]) - lo + 1 <= wmax)) {
           if (phi[e] >= 0) hi = std::max(hi, phi[e]);
@@ -1436,6 +1455,46 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
             }
           wgroups.push_back(g);
           wlo.push_back(lo); whi.push_back(hi);
+        }
+      }
+      // the long points inside their segments: window = the segment, members = a list (stored in wtab in front of the table)
+      for (const SegTask& t : sym_tasks) {
+        const int lo = t.qa * kRectSeg, W = std::min(kRectSeg, nco - lo);
+        for (size_t b0 = 0; b0 < t.pts.size(); b0 += kRectGroupPts) {
+          const int cnt = (int)std::min<size_t>(kRectGroupPts, t.pts.size() - b0);
+          const int pl = (int)wtab.size();
+          wtab.insert(wtab.end(), t.pts.begin() + b0, t.pts.begin() + b0 + cnt);
+          WinGroup g{0, cnt, W, lo, (int)wtab.size(), pl + 1, 0, 0};
+          wtab.resize(wtab.size() + (size_t)cnt * W, -1);
+          for (int q = 0; q < cnt; ++q) {
+            const int k = t.pts[b0 + q];
+            for (int n2 = off[k]; n2 < off[(size_t)k + 1]; ++n2) {
+              const int p = cam_opt_pos[obs_cam[n2]];
+              if (p >= lo && p < lo + W) wtab[(size_t)g.tab + (size_t)q * W + (p - lo)] = n2;
+            }
+          }
+          wgroups.push_back(g);
+          wlo.push_back(lo); whi.push_back(lo + W - 1);
+        }
+      }
+      // ... and between two segments: rectangular groups (k_schur_rect_mfma), table rows of 2 kRectSeg columns [A | B]
+      for (const SegTask& t : rect_tasks) {
+        const int loA = t.qa * kRectSeg, loB = t.qb * kRectSeg, WB = std::min(kRectSeg, nco - loB);
+        for (size_t b0 = 0; b0 < t.pts.size(); b0 += kRectGroupPts) {
+          const int cnt = (int)std::min<size_t>(kRectGroupPts, t.pts.size() - b0);
+          RectGroup g{cnt, (int)rtab.size(), 0, loA, loB, WB, 0, 0};
+          rtab.insert(rtab.end(), t.pts.begin() + b0, t.pts.begin() + b0 + cnt);
+          g.tab = (int)rtab.size();
+          rtab.resize(rtab.size() + (size_t)cnt * 2 * kRectSeg, -1);
+          for (int q = 0; q < cnt; ++q) {
+            const int k = t.pts[b0 + q];
+            for (int n2 = off[k]; n2 < off[(size_t)k + 1]; ++n2) {
+              const int p = cam_opt_pos[obs_cam[n2]];
+              if (p >= loA && p < loA + kRectSeg) rtab[(size_t)g.tab + (size_t)q * 2 * kRectSeg + (p - loA)] = n2;
+              else if (p >= loB && p < loB + WB) rtab[(size_t)g.tab + (size_t)q * 2 * kRectSeg + kRectSeg + (p - loB)] = n2;
+            }
+          }
+          rgroups.push_back(g);
         }
       }
       // staging: four wavefront pairs with two buffers each must fit in LDS next to the (optional) accumulation window
@@ -1491,8 +1550,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->gm3_uniform_ks = !wgroups.empty();
   for (const WinGroup& g : wgroups) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(g.W, gm3.np_cap) == kGmPts;
   h->wgroups_worth = wgroups_worth;
-  h->nlchunks = wgroups.empty() ? 0 : (int)lchunks.size();      // (the hybrid only exists next to the matrix-core reduction)
-  h->nlong_points = h->nlchunks ? nlong_points : 0;
+  h->nrgroups = wgroups.empty() ? 0 : (int)rgroups.size();      // (the long points' rectangular groups only exist next to the window groups)
+  h->nlong_points = wgroups.empty() ? 0 : nlong_points;
   h->gm3 = gm3;
   h->groups_worth = groups_worth;
   h->nmgroups_total = (int)mgroups.size();
@@ -1513,11 +1572,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->pt_off.resize((size_t)nt + 1));
   HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
   HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
-  HIPCHECK(h, h->lunits.resize(std::max<size_t>(1, lunits.size())));
-  HIPCHECK(h, h->lchunks.resize(std::max<size_t>(1, lchunks.size())));
-  if (!lunits.empty()) {
-    HIPCHECK(h, hipMemcpyAsync(h->lunits.p, lunits.data(), lunits.size() * sizeof(SchurUnit), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->lchunks.p, lchunks.data(), lchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, h->rgroups.resize(std::max<size_t>(1, rgroups.size())));
+  HIPCHECK(h, h->rtab.resize(std::max<size_t>(1, rtab.size())));
+  if (!rgroups.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->rgroups.p, rgroups.data(), rgroups.size() * sizeof(RectGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->rtab.p, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   }
   HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
   HIPCHECK(h, h->chunks.resize(std::max<size_t>(1, chunks.size())));
@@ -1963,8 +2022,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     rc = launch_point_blocks(h, h->lin_phys, nullptr);
     if (rc != BA_OK) return rc;
   }
-  const bool hybrid = kern == KERN_MFMA3 && h->nlchunks > 0;       // a few long tracks beside the window groups: their pairs through k_schur_pairs
-  const bool fuse_cam = use_mfma && !h->cam_blocks_valid && !hybrid;  // (the camera blocks of the long tracks' observations need k_camera_blocks)
+  const bool hybrid = kern == KERN_MFMA3 && h->nrgroups > 0;       // long tracks: rectangular groups between their segments
+  const bool fuse_cam = use_mfma && !h->cam_blocks_valid;
   if (!h->cam_blocks_valid && !fuse_cam) {
     rc = launch_camera_blocks(h, h->lin_phys, true);
     if (rc != BA_OK) return rc;
@@ -2029,15 +2088,15 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
                        h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
   } else if (kern == KERN_MFMA3) {
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, mfma3_launches(h->gm3.nts) + (hybrid ? 1 : 0));
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, mfma3_launches(h->gm3.nts) + (hybrid ? kRectTiles : 0));
     rc = launch_mfma3_all(h, p, damping, fuse_cam);
     if (rc != BA_OK) return rc;
     if (hybrid) {
-      const int NW = kSchurBlock / kWave;
-      const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int);
-      HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_pairs));
-      hipLaunchKernelGGL(k_schur_pairs, dim3(h->nlchunks), dim3(kSchurBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
-                         h->X[p].p, h->lunits.p, h->lchunks.p, 0, h->HPPinv.p, h->bP.p, h->S, h->b);
+      HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_rect_mfma));
+      const int nwg = (h->nrgroups + kGm2Pairs - 1) / kGm2Pairs;
+      for (int tj = 0; tj < kRectTiles; ++tj)          // one launch per tile column of the B segment: kRectTiles accumulator tiles each
+        hipLaunchKernelGGL(k_schur_rect_mfma, dim3(nwg), dim3(kGm2Block), schur_rect_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
+                           h->X[p].p, h->rgroups.p, h->nrgroups, h->rtab.p, h->opt_cam.p, h->fac.p, h->S, tj);
     }
   } else if (kern == KERN_MFMA2) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
@@ -2504,8 +2563,7 @@ int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   h->defer = true;
   // with the MFMA reduction the camera blocks come out of the reduction itself: one launch and one pass
   // over the observations less
-  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(pick_schur_kernel(h)) &&
-                    !(pick_schur_kernel(h) == KERN_MFMA3 && h->nlchunks > 0);
+  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(pick_schur_kernel(h));
   int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
   h->defer = false;

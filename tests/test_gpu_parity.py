@@ -1206,9 +1206,10 @@ def test_triangulation_of_low_parallax_tracks_equals_lstsq(be):
     assert worst_cond > 1e5                                              # (the normal equations would be off by 1e-6 and more here)
 
 
-def _with_long_tracks(s, nc, nt, every, Llong, seed=3):
+def _with_long_tracks(s, nc, nt, every, Llong, seed=3, holes=0.):
     """The banded scene with every `every`-th point seen by Llong consecutive cameras instead of 10 (a feature that survives
-    for a long stretch of the video): measurements from the true parameters + the scene's noise."""
+    for a long stretch of the video; `holes`: the fraction of those frames in which it was not detected): measurements from
+    the true parameters + the scene's noise."""
     rs = np.random.RandomState(seed)
     cam, pt, z = [], [], []
     L = len(s['obs_cam']) // nt
@@ -1216,32 +1217,42 @@ def _with_long_tracks(s, nc, nt, every, Llong, seed=3):
         if k % every == every // 2:
             c0 = int(np.clip(s['obs_cam'][k * L] - Llong // 2, 0, nc - Llong))
             cs = np.arange(c0, c0 + Llong)
+            if holes > 0:
+                keep = rs.rand(Llong) >= holes
+                keep[[0, -1]] = True
+                cs = cs[keep]
             p = np.einsum('nij,j->ni', s['R'][cs], s['X'][k]) + s['t'][cs]
-            zz = p[:, :2] / p[:, 2:3] + rs.randn(Llong, 2) * .02
-            cam.append(cs); pt.append(np.full(Llong, k)); z.append(zz)
+            zz = p[:, :2] / p[:, 2:3] + rs.randn(len(cs), 2) * .02
+            cam.append(cs); pt.append(np.full(len(cs), k)); z.append(zz)
         else:
             sl = slice(k * L, (k + 1) * L)
             cam.append(s['obs_cam'][sl]); pt.append(s['obs_pt'][sl]); z.append(s['obs_z'][sl])
     return np.concatenate(cam).astype(np.int32), np.concatenate(pt).astype(np.int32), np.concatenate(z)
 
 
-@pytest.mark.parametrize('Llong,sensor', [(60, O.Sensor.gaussian(1.)), (140, O.Sensor.cauchy(.05))])
-def test_a_few_long_tracks_leave_the_rest_on_the_matrix_cores(be, Llong, sensor):
-    """Tracks that span more than the widest window of the matrix-core reduction (40 cameras) used to send the WHOLE scene to the
-    pair kernel.  When they are few (here 2.5 % of the points, 60 / 140 cameras long) the window groups keep everybody else
-    and only the long tracks' pairs go through k_schur_pairs (+ k_camera_blocks for the camera blocks): S, b, the solve and
-    the whole trial against the oracle, and against the pair kernel alone."""
-    nc, nt = 300, 6000
+@pytest.mark.parametrize('nc,nt,every,Llong,holes,sensor', [
+    (300, 6000, 40, 60, 0., O.Sensor.gaussian(1.)),
+    (300, 6000, 40, 140, 0., O.Sensor.cauchy(.05)),
+    (300, 6000, 7, 75, .4, O.Sensor.gaussian(1.)),            # many of them, with holes
+    (150, 1200, 1, 50, .2, O.Sensor.cauchy(.05)),             # nothing but long tracks
+    (83, 900, 1, 83, .5, O.Sensor.gaussian(1.)),              # ... every one of them over all cameras (a short last segment)
+])
+def test_long_tracks_stay_on_the_matrix_cores(be, nc, nt, every, Llong, holes, sensor):
+    """Tracks that span more than the widest window of the matrix-core reduction (40 cameras): their cameras are cut along
+    segments of 32 positions - inside a segment they are members of a window group (a point list), between two segments
+    k_schur_rect_mfma forms the rectangular products.  S, b, the solve and the whole trial against the oracle, and against
+    the pair kernel alone."""
     s = banded(nc, nt)
-    cam, pt, z = _with_long_tracks(s, nc, nt, 40, Llong)
+    cam, pt, z = _with_long_tracks(s, nc, nt, every, Llong, holes=holes)
     flags = default_flags(nc, nt)
     a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
     out = {}
     for kern in ('pairs', 'auto'):
         be.set_option('schur', kern)
         load_problem(be, *a, *flags, sensor)
+        be._check(be._lib.ba_set_dense_visibility(be._h, 0))       # (the last two scenes are dense enough for the SYRK reduction: not the subject here)
         info = be.problem_info()
-        assert info['schur_kernel'] == (0 if kern == 'pairs' else 4) and info['half_bandwidth'] == Llong - 1
+        assert info['schur_kernel'] == (0 if kern == 'pairs' else 4) and Llong - 2 <= info['half_bandwidth'] <= Llong - 1      # (camera 0 is fixed)
         be.linearize(0)
         be.schur(0, 3., 1e-5)
         out[kern] = be.get_reduced()
