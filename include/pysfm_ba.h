@@ -211,8 +211,10 @@ int ba_set_dense_visibility(ba_handle* h, int32_t on);
 
 /* ---- BundleAdjuster.solve_motion_normal_eqns (bundle_adjuster.py:281-312)
  * Device-resident Cholesky solve of the reduced camera system, by block half-bandwidth hb:
- * block cyclic reduction (hb <= 23), a single-workgroup band Cholesky (fewer than 4 super-blocks), or a
- * dense blocked Cholesky of the whole matrix (hb > 23, up to 16000 unknowns).
+ * block cyclic reduction with LDS-resident nodes (hb <= 23), a single-workgroup band Cholesky (fewer than 4
+ * super-blocks), block cyclic reduction with nodes in device memory - every level a batched partial dense Cholesky
+ * (hb > 23 and at least four nodes of hb cameras: BA_SOLVE_BCR_BIG, any number of cameras), or a dense blocked
+ * Cholesky of the whole matrix (hb > 23 and fewer nodes, up to 16000 unknowns).
  * cam_param_mask[nco*6] (host, may be NULL = all kept): 0 deletes that camera parameter
  * from the system (its solution entry is 0).  *info: 0 = solved, solution stays on the
  * device for ba_backsubstitute / ba_get_solution; > 0 = pivot `info` was not positive and, for half-bandwidths
@@ -224,7 +226,7 @@ int ba_set_dense_visibility(ba_handle* h, int32_t on);
  * never came - a bug upstream, reported instead of hanging the GPU; treat like any other failed solve);
  * -1 = too large for the device solvers (same fallback).
  * ba_last_solve_kind: which solver the last ba_solve_reduced launched. */
-enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY, BA_SOLVE_BCR_LU };
+enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY, BA_SOLVE_BCR_LU, BA_SOLVE_BCR_BIG };
 #define BA_SOLVE_TIMED_OUT 0x7f000001   /* *info of a cyclic reduction whose workgroups gave up waiting for each other */
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);

@@ -269,7 +269,7 @@ class HipBackend(object):
         the device for backsubstitute(); get_solution() fetches it.
         Path 1 (last_solve_path 'band' / 'dense_cholesky', last_solve_kind says which kernel
         family): Cholesky on the device inside ba_solve_reduced - block cyclic reduction for
-        block half-bandwidths up to 23 (one kernel per level up to 11, three beyond), a dense blocked Cholesky beyond.  Path 2 ('dense'),
+        block half-bandwidths up to 23 (one kernel per level up to 11, three beyond), with nodes in device memory beyond ('bcr_big': a batched partial dense Cholesky per level), a dense blocked Cholesky when there are fewer than four such nodes.  Path 2 ('dense'),
         when the system is not positive definite or has more than 16000 unknowns: LU of the
         flattened system, the reference's own factorisation (numpy.linalg.solve = gesv,
         bundle_adjuster.py:303), here rocSOLVER through torch.linalg.solve_ex - on the GPU as
@@ -428,7 +428,7 @@ class HipBackend(object):
 
     def _note_solve(self, info):
         """last_solve_kind: the device solver ba_solve_reduced launched ('bcr', 'bcr_wide', 'band',
-        'dense_cholesky'; 'bcr_lu' = the cyclic reduction with LU nodes, after 'bcr' found the system not positive definite); last_solve_path: 'band' / 'dense_cholesky' when it succeeded, 'dense' when
+        'dense_cholesky', 'bcr_big'; 'bcr_lu' = the cyclic reduction with LU nodes, after 'bcr' found the system not positive definite); last_solve_path: 'band' / 'dense_cholesky' when it succeeded, 'dense' when
         the flattened system went (or has to go) through LU instead."""
         self.last_solve_kind = capi.SOLVE_KINDS[self._lib.ba_last_solve_kind(self._h)]
         if info != 0:

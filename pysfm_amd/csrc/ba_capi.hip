@@ -18,6 +18,7 @@
 #include "ba_bcr.h"
 #include "ba_bcr_wide.h"
 #include "ba_dense.h"
+#include "ba_bcr_big.h"
 #include "ba_dist.h"
 
 #include <dlfcn.h>
@@ -116,11 +117,14 @@ struct ba_handle {
   bool groups_ascending = false;
   int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
   bool groups_worth = false;            // points really share camera lists (mean run >= 2 points)
-  Gm3Params gm3{0, 0, 0, 0, 0, 1};      // k_schur_groups_mfma3: tile count, staged row length, k-rows per buffer, points per batch, window
+  Gm3Params gm3{0, 0, 0, 0, 0, 1, 1};   // k_schur_groups_mfma3: tile count, staged row length, k-rows per buffer, points per batch, window
   DevBuf<SchurChunk> m3chunks;          // its chunks (window rows gm3.wn may differ from schur_wn)
   DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
   DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
   int nm3chunks = 0, nwgroups = 0;
+  Gm3Params gm3w{0, 0, 0, 0, 0, 1, 1};  // the same for the groups of LISTED points (long tracks inside their segments of kRectSeg positions): their own
+  DevBuf<SchurChunk> m3chunks_w;        // staged row length and launches, so that the short tracks' groups run exactly as without them
+  int nm3chunks_w = 0;
   // tracks that span more than kGm3MaxSpan cameras: members of their segments' window groups + rectangular groups between segments
   DevBuf<RectGroup> rgroups;
   DevBuf<int> rtab;
@@ -144,7 +148,7 @@ struct ba_handle {
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, fac, dUd, dDd, dyd, dpart, comm_dev;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, bigK, fac, dUd, dDd, dyd, dpart, comm_dev;
   DevBuf<unsigned char> mask;
   DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)
   int bcr_order_n = 0;
@@ -799,6 +803,57 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   return BA_OK;
 }
 
+// Block cyclic reduction with nodes too large for LDS (ba_bcr_big.h): half-bandwidths beyond kBcrwMaxHB.  A level is a batched
+// partial dense Cholesky of one 3B x 3B matrix per eliminated node.
+inline int big_node_cameras(int hb) { return (hb + 1) & ~1; }      // cb >= hb, even: B = 6 cb is a multiple of the panel kernel's 12-column steps
+int solve_bcr_big(ba_handle* h, const unsigned char* dmask) {
+  const int hb = h->hb, cb = big_node_cameras(hb), B = 6 * cb, N = (h->nco + cb - 1) / cb, n = 3 * B;
+  const size_t BB = (size_t)B * B, KS = big_matrix_doubles(B);
+  HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrF.resize((size_t)N * B));
+  HIPCHECK(h, h->bigK.resize((size_t)N * KS));
+  HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_panel));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_big_backsolve));
+  int* info = h->flags.p + 1;
+  {
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, cb, h->S, h->b, dmask, h->bcrD.p,
+                       h->bcrU.p, h->bcrF.p, info, (double*)nullptr);
+  }
+  struct Level { int s, cnt; size_t base; };
+  std::vector<Level> levels;
+  size_t slots = 0;
+  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) { levels.push_back({s, (N / s + 1) / 2, slots}); slots += (N / s + 1) / 2; }
+  const int npanels = (B + kDcNB - 1) / kDcNB;
+  {
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)levels.size() * (2 * npanels + 2));
+    for (const Level& L : levels) {
+      double* K = h->bigK.p + L.base * KS;
+      hipLaunchKernelGGL(k_big_gather, dim3(std::min(n + 1, 128), L.cnt), dim3(256), 0, h->stream, N, B, L.s, h->bcrD.p, h->bcrU.p,
+                         h->bcrF.p, K, KS);
+      for (int k0 = 0; k0 < B; k0 += kDcNB) {
+        const int nb = std::min(kDcNB, B - k0), kn = k0 + nb, total = n - kn + 1;      // every row below the block + the right-hand side row
+        hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows, 1, L.cnt), dim3(1024), dense_panel_lds_bytes(), h->stream,
+                           n, k0, nb, total, K, info, KS);
+        const int T = (total + kDcTile - 1) / kDcTile;
+        hipLaunchKernelGGL(k_dense_update, dim3(T, T, L.cnt), dim3(1024), 0, h->stream, n, k0, nb, total, K, KS);
+      }
+      const int nsurv = (N + 1) / (2 * L.s);       // nodes m = 2 s (y + 1) - 1 < N
+      if (nsurv > 0)
+        hipLaunchKernelGGL(k_big_scatter, dim3(std::min(B + 1, 64), nsurv), dim3(256), 0, h->stream, N, B, L.s, L.cnt, h->bcrD.p, h->bcrU.p,
+                           h->bcrF.p, K, KS);
+    }
+  }
+  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)levels.size());
+  for (int q = (int)levels.size() - 1; q >= 0; --q) {
+    const Level& L = levels[q];
+    hipLaunchKernelGGL(k_big_backsolve, dim3(L.cnt), dim3(1024), big_backsolve_lds_bytes(B), h->stream, N, B, L.s,
+                       h->bigK.p + L.base * KS, KS, h->dC.p, info);
+  }
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
 // Dense Cholesky of the whole reduced system (ba_dense.h): bands wider than the cyclic reduction's blocks.
 int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
   const int n = 6 * h->nco;
@@ -966,11 +1021,11 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->wgroups.release(); h->wtab.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->m3chunks_w.release(); h->wgroups.release(); h->wtab.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
-  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->rgroups.release(); h->rtab.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
+  h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->rgroups.release(); h->rtab.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->bigK.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
   h->scratch.release(); h->flags.release();
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -984,7 +1039,7 @@ int ba_debug_poison(ba_handle* h) {
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_poison_lds));
   hipLaunchKernelGGL(k_poison_lds, dim3(8 * h->ncu), dim3(1024), 160 * 1024, h->stream, 160 * 1024 / 8);
   DevBuf<double>* bufs[] = {&h->HCC, &h->bC, &h->HPP, &h->bP, &h->HPPinv, &h->W, &h->dC, &h->dP, &h->scratch, &h->Ufac, &h->ysol, &h->dinv,
-                            &h->bcrD, &h->bcrU, &h->bcrF, &h->bcrP, &h->bcrQ, &h->bcrG, &h->bcrGv, &h->bcrL, &h->bcrLv, &h->denseA, &h->fac,
+                            &h->bcrD, &h->bcrU, &h->bcrF, &h->bcrP, &h->bcrQ, &h->bcrG, &h->bcrGv, &h->bcrL, &h->bcrLv, &h->denseA, &h->bigK, &h->fac,
                             &h->dUd, &h->dDd, &h->dyd, &h->dpart, &h->cams[1 - h->cur], &h->X[1 - h->cur]};
   for (DevBuf<double>* b : bufs)
     if (b->p && b->n) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, h->stream, b->p, b->n);
@@ -1252,11 +1307,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   //   mgroups / mchunks  longer runs for the matrix-core reductions; mchunks under the LDS window `wn` of the older
   //                      kernels (track length <= 10), m3chunks under k_schur_groups_mfma3's own window
   std::vector<SchurGroup> groups, mgroups;
-  std::vector<SchurChunk> gchunks, mchunks, m3chunks;
+  std::vector<SchurChunk> gchunks, mchunks, m3chunks, m3chunks_w;
   int group_rounds = 0;
   bool groups_worth = false;
   bool groups_ascending = true;                      // optimised positions ascend along every track
-  Gm3Params gm3{0, 0, 0, 0, 0, 1};
+  Gm3Params gm3{0, 0, 0, 0, 0, 1, 1}, gm3w{0, 0, 0, 0, 0, 1, 1};
   if (maxL >= 1 && maxL <= kGm3MaxL) {
     auto build_groups = [&](int max_pts, std::vector<SchurGroup>& gs, std::vector<int>& glo, std::vector<int>& ghi) {
       for (int k = 0; k < nt;) {
@@ -1380,7 +1435,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     struct SegTask { int qa, qb; std::vector<int> pts; };
     std::vector<SegTask> sym_tasks, rect_tasks;
     if (hybrid) {
-      maxspan = std::max(shortspan, kRectSeg);
+      maxspan = shortspan;
       nlong_points = (int)nlong;
       std::map<long long, int> sym_id, rect_id;
       for (int k = 0; k < nt; ++k) {
@@ -1405,10 +1460,10 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         }
       }
     }
-    if (maxspan >= 1 && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
+    if ((maxspan >= 1 || hybrid) && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
       gm3.nts = (6 * maxspan + 15) / 16;
       gm3.Ld = 16 * gm3.nts;
-      const int wmax = std::min(kGm3MaxSpan, gm3.Ld / 6);
+      const int wmax = std::max(1, std::min(kGm3MaxSpan, gm3.Ld / 6));
       // natural groups: extend while the window still holds everybody
       struct Run { int b, e, lo, hi; };
       std::vector<Run> runs;
@@ -1458,10 +1513,24 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         }
       }
       // the long points inside their segments: window = the segment, members = a list (stored in wtab in front of the table)
+      const int nshort_groups = (int)wgroups.size();
+      // points per group: a group is one serial chain of batches on one wavefront pair, and there are few long tracks - halve
+      // the groups until they fill the chip (24 points at least: an epilogue of up to 78 tiles is paid per group)
+      auto group_points = [&](const std::vector<SegTask>& tasks, size_t want) {
+        int pts = kRectGroupPts;
+        for (; pts > 24; pts /= 2) {
+          size_t n = 0;
+          for (const SegTask& t : tasks) n += (t.pts.size() + pts - 1) / pts;
+          if (n >= want) break;
+        }
+        return pts;
+      };
+      const int sym_pts = group_points(sym_tasks, (size_t)slots), rect_pts = group_points(rect_tasks, (size_t)slots / 8);
       for (const SegTask& t : sym_tasks) {
         const int lo = t.qa * kRectSeg, W = std::min(kRectSeg, nco - lo);
-        for (size_t b0 = 0; b0 < t.pts.size(); b0 += kRectGroupPts) {
-          const int cnt = (int)std::min<size_t>(kRectGroupPts, t.pts.size() - b0);
+        const size_t parts = (t.pts.size() + sym_pts - 1) / sym_pts, part = (t.pts.size() + parts - 1) / parts;
+        for (size_t b0 = 0; b0 < t.pts.size(); b0 += part) {
+          const int cnt = (int)std::min<size_t>(part, t.pts.size() - b0);
           const int pl = (int)wtab.size();
           wtab.insert(wtab.end(), t.pts.begin() + b0, t.pts.begin() + b0 + cnt);
           WinGroup g{0, cnt, W, lo, (int)wtab.size(), pl + 1, 0, 0};
@@ -1480,8 +1549,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       // ... and between two segments: rectangular groups (k_schur_rect_mfma), table rows of 2 kRectSeg columns [A | B]
       for (const SegTask& t : rect_tasks) {
         const int loA = t.qa * kRectSeg, loB = t.qb * kRectSeg, WB = std::min(kRectSeg, nco - loB);
-        for (size_t b0 = 0; b0 < t.pts.size(); b0 += kRectGroupPts) {
-          const int cnt = (int)std::min<size_t>(kRectGroupPts, t.pts.size() - b0);
+        const size_t parts = (t.pts.size() + rect_pts - 1) / rect_pts, part = (t.pts.size() + parts - 1) / parts;
+        for (size_t b0 = 0; b0 < t.pts.size(); b0 += part) {
+          const int cnt = (int)std::min<size_t>(part, t.pts.size() - b0);
           RectGroup g{cnt, (int)rtab.size(), 0, loA, loB, WB, 0, 0};
           rtab.insert(rtab.end(), t.pts.begin() + b0, t.pts.begin() + b0 + cnt);
           g.tab = (int)rtab.size();
@@ -1498,37 +1568,46 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         }
       }
       // staging: four wavefront pairs with two buffers each must fit in LDS next to the (optional) accumulation window
-      const size_t lds_total = 160 * 1024, fixed = schur_mfma3_lds_bytes(0, 0, 0, hb + 1) + 1024;
-      for (gm3.np_cap = kGmPts; gm3.np_cap >= 1; --gm3.np_cap) {
-        int kmax = 4;
-        for (const WinGroup& g : wgroups) kmax = std::max(kmax, (3 * gm3_np(g.W, gm3.np_cap) + 3) / 4 * 4);
-        gm3.Kbuf = kmax;
-        if ((size_t)kGm2Pairs * 2 * gm3.Kbuf * gm3.Ld * sizeof(double) <= 96 * 1024) break;
-      }
-      gm3.np_cap = std::max(1, gm3.np_cap);
-      const size_t staging = (size_t)kGm2Pairs * 2 * gm3.Kbuf * gm3.Ld * sizeof(double);
-      const size_t rowbytes = ((size_t)(hb + 1) * 36 + 6) * sizeof(double);
-      int w3 = (int)((lds_total - fixed - staging) / rowbytes);
-      w3 = std::min(w3, std::max(16, hb + 7));
-      if (w3 < hb + 2 || !h->opt.lds_window) w3 = 0;
-      gm3.wn = w3;
-      {
-        int begin = 0, lo = INT32_MAX, hi = -1;          // chunks of <= kGmChunk groups under the LDS window
-        for (int g = 0; g < (int)wgroups.size(); ++g) {
+      auto finish_set = [&](int g0, int g1, Gm3Params& G, std::vector<SchurChunk>& out) {
+        if (g1 <= g0) return;
+        const size_t lds_total = 160 * 1024, fixed = schur_mfma3_lds_bytes(0, 0, 0, hb + 1) + 1024;
+        G.wb1 = 1;                                        // rows of the LDS window: as many blocks as the widest group spans
+        for (int g = g0; g < g1; ++g) G.wb1 = std::max(G.wb1, std::min(hb + 1, wgroups[g].W));
+        for (G.np_cap = kGmPts; G.np_cap >= 1; --G.np_cap) {
+          int kmax = 4;
+          for (int g = g0; g < g1; ++g) kmax = std::max(kmax, (3 * gm3_np(wgroups[g].W, G.np_cap) + 3) / 4 * 4);
+          G.Kbuf = kmax;
+          if ((size_t)kGm2Pairs * 2 * G.Kbuf * G.Ld * sizeof(double) <= 96 * 1024) break;
+        }
+        G.np_cap = std::max(1, G.np_cap);
+        const size_t staging = (size_t)kGm2Pairs * 2 * G.Kbuf * G.Ld * sizeof(double);
+        const size_t rowbytes = ((size_t)G.wb1 * 36 + 6) * sizeof(double);
+        int w3 = (int)((lds_total - fixed - staging) / rowbytes);
+        w3 = std::min(w3, std::max(16, G.wb1 + 6));
+        if (w3 < G.wb1 + 1 || !h->opt.lds_window) w3 = 0;
+        G.wn = w3;
+        int begin = g0, lo = INT32_MAX, hi = -1;          // chunks of <= kGmChunk groups under the LDS window
+        for (int g = g0; g < g1; ++g) {
           const int nlo = std::min(lo, wlo[g]), nhi = std::max(hi, whi[g]);
           const bool fits = w3 == 0 || nhi - nlo + 1 <= w3;
           if (g > begin && (!fits || g - begin >= kGmChunk)) {
-            m3chunks.push_back({begin, g, lo});
+            out.push_back({begin, g, lo});
             begin = g; lo = wlo[g]; hi = whi[g];
           } else {
             lo = nlo; hi = nhi;
           }
         }
-        if (!wgroups.empty()) m3chunks.push_back({begin, (int)wgroups.size(), lo});
-      }
+        out.push_back({begin, g1, lo});
+      };
+      finish_set(0, nshort_groups, gm3, m3chunks);
+      gm3w.nts = kRectTiles;
+      gm3w.Ld = 16 * gm3w.nts;
+      finish_set(nshort_groups, (int)wgroups.size(), gm3w, m3chunks_w);
+      // an epilogue per >= 12 points (judged on the short tracks' groups when there are any: a few long tracks do not decide it)
+      const int j0 = nshort_groups > 0 ? 0 : nshort_groups, j1 = nshort_groups > 0 ? nshort_groups : (int)wgroups.size();
       long long covered = 0;
-      for (const WinGroup& g : wgroups) covered += g.pt_end - g.pt_begin;
-      wgroups_worth = !wgroups.empty() && covered >= 12ll * (long long)wgroups.size();      // an epilogue per >= 12 points
+      for (int g = j0; g < j1; ++g) covered += wgroups[g].pt_end - wgroups[g].pt_begin;
+      wgroups_worth = j1 > j0 && covered >= 12ll * (long long)(j1 - j0);
     }
   }
   // lanes per point: smallest power of two >= mean track length, in [1, 64]
@@ -1546,9 +1625,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
   h->nm3chunks = (int)m3chunks.size();
+  h->nm3chunks_w = (int)m3chunks_w.size();
+  h->gm3w = gm3w;
   h->nwgroups = (int)wgroups.size();
-  h->gm3_uniform_ks = !wgroups.empty();
-  for (const WinGroup& g : wgroups) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(g.W, gm3.np_cap) == kGmPts;
+  h->gm3_uniform_ks = !m3chunks.empty();
+  for (const SchurChunk& c : m3chunks)
+    for (int g = c.begin; g < c.end; ++g) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(wgroups[g].W, gm3.np_cap) == kGmPts;
   h->wgroups_worth = wgroups_worth;
   h->nrgroups = wgroups.empty() ? 0 : (int)rgroups.size();      // (the long points' rectangular groups only exist next to the window groups)
   h->nlong_points = wgroups.empty() ? 0 : nlong_points;
@@ -1588,6 +1670,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->m3chunks.resize(std::max<size_t>(1, m3chunks.size())));
   if (!m3chunks.empty())
     HIPCHECK(h, hipMemcpyAsync(h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, h->m3chunks_w.resize(std::max<size_t>(1, m3chunks_w.size())));
+  if (!m3chunks_w.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->m3chunks_w.p, m3chunks_w.data(), m3chunks_w.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->wgroups.resize(std::max<size_t>(1, wgroups.size())));
   HIPCHECK(h, h->wtab.resize(std::max<size_t>(1, wtab.size())));
   if (!wgroups.empty()) {
@@ -1815,7 +1900,7 @@ enum { KERN_PAIRS = 0, KERN_GROUPS, KERN_MFMA1, KERN_MFMA2, KERN_MFMA3, KERN_DEN
 int pick_schur_kernel(const ba_handle* h) {
   if (h->dense_mode && h->nt > 0 && h->nco > 0) return KERN_DENSE;
   const bool asc = h->groups_ascending && h->group_maxL >= 1;
-  const bool m3 = h->nm3chunks > 0 && h->nwgroups > 0;           // window groups: no identical camera lists needed
+  const bool m3 = (h->nm3chunks > 0 || h->nm3chunks_w > 0) && h->nwgroups > 0;           // window groups: no identical camera lists needed
   const bool m12 = asc && h->nmchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGmMaxL;      // the L <= 10 kernels
   const bool vec = h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGroupMaxL;
   switch (h->opt.schur) {
@@ -1836,35 +1921,42 @@ int pick_schur_kernel(const ba_handle* h) {
 inline bool kern_is_mfma(int k) { return k == KERN_MFMA1 || k == KERN_MFMA2 || k == KERN_MFMA3; }
 
 extern "C++" {
-// k_schur_groups_mfma3 over the tile columns [TJ0, TJ1) of every group's window
+// k_schur_groups_mfma3 over the tile columns [TJ0, TJ1) of every group's window; one set of groups (chunks) with its parameters
+struct M3Launch { Gm3Params G; const SchurChunk* chunks; int nchunks; bool uniform_ks; };
 template <int TJ0, int TJ1, int LDC = 0, int KSC = 0>
-int launch_mfma3(ba_handle* h, int p, double damping, bool fuse_cam, bool first) {
+int launch_mfma3(ba_handle* h, const M3Launch& L, int p, double damping, bool fuse_cam, bool first) {
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma3<TJ0, TJ1, LDC, KSC>));
-  Gm3Params G = h->gm3;
+  Gm3Params G = L.G;
   G.do_rhs = first ? 1 : 0;
-  hipLaunchKernelGGL((k_schur_groups_mfma3<TJ0, TJ1, LDC, KSC>), dim3(h->nm3chunks), dim3(kGm2Block),
-                     schur_mfma3_lds_bytes(G.Kbuf, G.Ld, G.wn, h->hb + 1), h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
-                     h->wgroups.p, h->wtab.p, h->opt_cam.p, h->m3chunks.p, G, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
+  hipLaunchKernelGGL((k_schur_groups_mfma3<TJ0, TJ1, LDC, KSC>), dim3(L.nchunks), dim3(kGm2Block),
+                     schur_mfma3_lds_bytes(G.Kbuf, G.Ld, G.wn, G.wb1), h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
+                     h->wgroups.p, h->wtab.p, h->opt_cam.p, L.chunks, G, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
   return BA_OK;
 }
 
-int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
-  const int nts = h->gm3.nts;       // tiles per side of the widest window; at most 15 accumulator tiles per launch
+int launch_mfma3_set(ba_handle* h, const M3Launch& L, int p, double damping, bool fuse_cam) {
+  if (L.nchunks <= 0) return BA_OK;
+  const int nts = L.G.nts;          // tiles per side of the widest window; at most 15 accumulator tiles per launch
   if (nts < 1 || nts > 15) return h->fail(BA_ERR_STATE, "k_schur_groups_mfma3: %d tiles per side", nts);
   // windows of at most 10 cameras with 6 points per batch everywhere (the north-star scenes): row length and k-steps fixed
-  if (nts == 4 && h->gm3.np_cap == kGmPts && h->gm3.Kbuf == kGmK && h->gm3_uniform_ks) return launch_mfma3<0, 4, 64, 5>(h, p, damping, fuse_cam, true);
-  int rc = nts == 5 ? launch_mfma3<0, 5>(h, p, damping, fuse_cam, true) : launch_mfma3<0, 4>(h, p, damping, fuse_cam, true);
-  if (rc == BA_OK && nts >= 6) rc = launch_mfma3<4, 6>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 9) rc = launch_mfma3<8, 9>(h, p, damping, fuse_cam, false);
+  if (nts == 4 && L.G.np_cap == kGmPts && L.G.Kbuf == kGmK && L.uniform_ks) return launch_mfma3<0, 4, 64, 5>(h, L, p, damping, fuse_cam, true);
+  int rc = nts == 5 ? launch_mfma3<0, 5>(h, L, p, damping, fuse_cam, true) : launch_mfma3<0, 4>(h, L, p, damping, fuse_cam, true);
+  if (rc == BA_OK && nts >= 6) rc = launch_mfma3<4, 6>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 9) rc = launch_mfma3<8, 9>(h, L, p, damping, fuse_cam, false);
   // windows of 25 .. 40 cameras (tracks that long: video): one launch per further tile column (tj + 1 <= 15 tiles each)
-  if (rc == BA_OK && nts >= 10) rc = launch_mfma3<9, 10>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 11) rc = launch_mfma3<10, 11>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 12) rc = launch_mfma3<11, 12>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 13) rc = launch_mfma3<12, 13>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 14) rc = launch_mfma3<13, 14>(h, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 15) rc = launch_mfma3<14, 15>(h, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 10) rc = launch_mfma3<9, 10>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 11) rc = launch_mfma3<10, 11>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 12) rc = launch_mfma3<11, 12>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 13) rc = launch_mfma3<12, 13>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 14) rc = launch_mfma3<13, 14>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 15) rc = launch_mfma3<14, 15>(h, L, p, damping, fuse_cam, false);
+  return rc;
+}
+int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
+  int rc = launch_mfma3_set(h, M3Launch{h->gm3, h->m3chunks.p, h->nm3chunks, h->gm3_uniform_ks}, p, damping, fuse_cam);
+  if (rc == BA_OK) rc = launch_mfma3_set(h, M3Launch{h->gm3w, h->m3chunks_w.p, h->nm3chunks_w, false}, p, damping, fuse_cam);
   return rc;
 }
 inline int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 : nts - 5; }
@@ -2088,15 +2180,14 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
                        h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
   } else if (kern == KERN_MFMA3) {
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, mfma3_launches(h->gm3.nts) + (hybrid ? kRectTiles : 0));
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, (h->nm3chunks ? mfma3_launches(h->gm3.nts) : 0) + (h->nm3chunks_w ? mfma3_launches(h->gm3w.nts) : 0) + (hybrid ? 1 : 0));
     rc = launch_mfma3_all(h, p, damping, fuse_cam);
     if (rc != BA_OK) return rc;
     if (hybrid) {
       HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_rect_mfma));
-      const int nwg = (h->nrgroups + kGm2Pairs - 1) / kGm2Pairs;
-      for (int tj = 0; tj < kRectTiles; ++tj)          // one launch per tile column of the B segment: kRectTiles accumulator tiles each
-        hipLaunchKernelGGL(k_schur_rect_mfma, dim3(nwg), dim3(kGm2Block), schur_rect_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
-                           h->X[p].p, h->rgroups.p, h->nrgroups, h->rtab.p, h->opt_cam.p, h->fac.p, h->S, tj);
+      const int nwg = (h->nrgroups + kGm2Pairs - 1) / kGm2Pairs;      // blockIdx.y = tile column of the B segment: kRectTiles accumulator tiles each
+      hipLaunchKernelGGL(k_schur_rect_mfma, dim3(nwg, kRectTiles), dim3(kGm2Block), schur_rect_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->rgroups.p, h->nrgroups, h->rtab.p, h->opt_cam.p, h->fac.p, h->S);
     }
   } else if (kern == KERN_MFMA2) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
@@ -2260,10 +2351,15 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && nodes >= 4;
   const bool band_ok = h->hb <= kMaxBandSolve;       // (the single-workgroup band Cholesky is instantiated up to there)
   const bool dense_ok = 6 * h->nco <= kDcMaxN && force != SOLVER_LU;
-  const bool use_dense = dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR))));
+  // wider than that: nodes that do not fit in LDS (ba_bcr_big.h), as long as there are a few of them to reduce over
+  const int big_nodes = h->hb > kBcrwMaxHB ? (h->nco + big_node_cameras(h->hb) - 1) / big_node_cameras(h->hb) : 0;
+  // (measured at 1000 cameras: 13 nodes of 80 cameras 2.2 ms against the dense factorisation's 3.8 ms, 5 nodes of 200 cameras 7.7 against 6.5)
+  const bool big_ok = (force == SOLVER_BCR && big_nodes >= 4) || (force == SOLVER_AUTO && big_nodes >= (dense_ok ? 8 : 4));
+  const bool use_big = big_ok;
+  const bool use_dense = !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);
   const bool use_bcrw = !use_dense && !use_bcr && (force ? (force == SOLVER_BCR && bcrw_ok) : bcrw_ok);
-  if (force == SOLVER_LU || (!use_dense && !use_bcr && !use_bcrw && !band_ok)) { *info = -1; return BA_OK; }     // caller's dense LU
+  if (force == SOLVER_LU || (!use_big && !use_dense && !use_bcr && !use_bcrw && !band_ok)) { *info = -1; return BA_OK; }     // caller's dense LU
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, h->Ufac.resize(std::max<size_t>(1, reduced_doubles(h))));
   const unsigned char* dmask = nullptr;
@@ -2280,8 +2376,11 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const size_t lds_budget = 160 * 1024;
   const int ch = band_solve_chunk(h->hb, lds_budget);
   size_t lds = 0;
-  h->solve_kind = use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
-  if (use_dense) {
+  h->solve_kind = use_big ? BA_SOLVE_BCR_BIG : use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
+  if (use_big) {
+    int rc = solve_bcr_big(h, dmask);
+    if (rc != BA_OK) return rc;
+  } else if (use_dense) {
     int rc = solve_dense_chol(h, dmask);
     if (rc != BA_OK) return rc;
   } else if (use_bcr) {
@@ -2362,7 +2461,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     fprintf(stderr, "\n");
   }
 #endif
-  if (h->opt.solve_trace && !use_bcr && !use_bcrw && !use_dense)
+  if (h->opt.solve_trace && !use_bcr && !use_bcrw && !use_dense && !use_big)
     fprintf(stderr, "[k_band_solve] nco=%d hb=%d ch=%d lds=%zu B | forward: %d cycles, %d ticks(100MHz) | total: %d cycles, %d ticks\n",
             h->nco, h->hb, ch, lds, inf6[2], inf6[3], inf6[4], inf6[5]);
   *info = inf;

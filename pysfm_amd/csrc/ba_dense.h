@@ -63,9 +63,11 @@ __global__ __launch_bounds__(256) void k_dense_gather(int nco, int hb, const dou
 // list index idx -> matrix row:
 __device__ __forceinline__ int dense_row(int idx, int total, int kn, int n) { return idx == total - 1 ? n : kn + idx; }
 
+// blockIdx.z: one of several matrices (batch_stride doubles apart: the big-node cyclic reduction of ba_bcr_big.h)
 __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int total, double* __restrict__ A,
-                                                      int* __restrict__ info) {
+                                                      int* __restrict__ info, size_t batch_stride = 0) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  A += (size_t)blockIdx.z * batch_stride;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int ld = kDcLd;
   double* G = sm;                                  // [kDcM][ld]: rows 0..nb-1 = A_kk, rows nb.. = my panel rows
@@ -156,8 +158,9 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
 }
 
 // ---- trailing update: A[i][j] -= sum_c P[i][c] P[j][c] for kn <= j <= i <= n, P = A[., k0 .. k0 + nb)
-__global__ __launch_bounds__(1024) void k_dense_update(int n, int k0, int nb, int total, double* __restrict__ A) {
+__global__ __launch_bounds__(1024) void k_dense_update(int n, int k0, int nb, int total, double* __restrict__ A, size_t batch_stride = 0) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  A += (size_t)blockIdx.z * batch_stride;
   __shared__ double Pi[kDcTile * kDcLd], Pj[kDcTile * kDcLd];
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (tj > ti) return;
@@ -211,28 +214,25 @@ __global__ __launch_bounds__(1024) void k_dense_update(int n, int k0, int nb, in
 //       rows split over as many groups as the workgroup has threads for, reduced through LDS.
 constexpr int kDcBsRows = 24;                      // update rows per thread that are prefetched
 
-__device__ __forceinline__ double dense_lkk_entry(const double* __restrict__ A, int n, int k0, int nb, int e) {
+__device__ __forceinline__ double dense_lkk_entry(const double* __restrict__ A, int ld, int k0, int nb, int e) {
   const int row = e / kDcNB, col = e - row * kDcNB;
-  return (e < kDcNB * kDcNB && row < nb && col <= row) ? A[(size_t)(k0 + row) * n + k0 + col] : 0.0;
+  return (e < kDcNB * kDcNB && row < nb && col <= row) ? A[(size_t)(k0 + row) * ld + k0 + col] : 0.0;
 }
 
-__global__ __launch_bounds__(1024) void k_dense_backsolve(int n, int bw, const double* __restrict__ A, double* __restrict__ x,
-                                                          const int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+// w[0..n) in LDS (the caller has NOT synchronised after filling it) -> x = L^-T w in place; L = rows 0..n-1 of A, row stride ld
+__device__ __forceinline__ void dense_backsolve_body(int n, int ld, int bw, const double* __restrict__ A, double* __restrict__ sm) {
   double* w = sm;                                  // [n]
   double* Lk = w + n;                              // [48][49]
   double* xk = Lk + kDcNB * kDcLd;                 // [48]
   double* red = xk + kDcNB;                        // [1024]
-  if (*info != 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int nblk = (n + kDcNB - 1) / kDcNB;
   double lv[3];
   {
     const int k0 = kDcNB * (nblk - 1), nb = n - k0;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) lv[u] = dense_lkk_entry(A, n, k0, nb, tid + 1024 * u);
+    for (int u = 0; u < 3; ++u) lv[u] = dense_lkk_entry(A, ld, k0, nb, tid + 1024 * u);
   }
-  for (int j = tid; j < n; j += 1024) w[j] = A[(size_t)n * n + j];
 #pragma unroll 1
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kDcNB * kb, nb = min(kDcNB, n - k0);
@@ -253,13 +253,13 @@ __global__ __launch_bounds__(1024) void k_dense_backsolve(int n, int bw, const d
     const int rend = min(rp, nb - g * rp);
     double uv[kDcBsRows];
     {
-      const double* Lp = A + (size_t)(k0 + g * rp) * n + jlo + j;
+      const double* Lp = A + (size_t)(k0 + g * rp) * ld + jlo + j;
 #pragma unroll
-      for (int r = 0; r < kDcBsRows; ++r) uv[r] = (mine && r < rend) ? Lp[(size_t)r * n] : 0.0;
+      for (int r = 0; r < kDcBsRows; ++r) uv[r] = (mine && r < rend) ? Lp[(size_t)r * ld] : 0.0;
     }
     if (kb > 0) {
 #pragma unroll
-      for (int u = 0; u < 3; ++u) lv[u] = dense_lkk_entry(A, n, k0 - kDcNB, kDcNB, tid + 1024 * u);
+      for (int u = 0; u < 3; ++u) lv[u] = dense_lkk_entry(A, ld, k0 - kDcNB, kDcNB, tid + 1024 * u);
     }
     // (2b) the triangular solve
     if (tid < 64) {
@@ -305,17 +305,26 @@ __global__ __launch_bounds__(1024) void k_dense_backsolve(int n, int bw, const d
         }
       } else {
         for (int jj = jlo + tid; jj < k0; jj += 1024) {
-          const double* Lp = A + (size_t)k0 * n + jj;
+          const double* Lp = A + (size_t)k0 * ld + jj;
           double acc = 0.0;
 #pragma unroll 12
-          for (int r = 0; r < nb; ++r) acc += Lp[(size_t)r * n] * xk[r];
+          for (int r = 0; r < nb; ++r) acc += Lp[(size_t)r * ld] * xk[r];
           w[jj] -= acc;
         }
       }
     }
   }
   __syncthreads();
-  for (int j = tid; j < n; j += 1024) x[j] = w[j];
+}
+
+__global__ __launch_bounds__(1024) void k_dense_backsolve(int n, int bw, const double* __restrict__ A, double* __restrict__ x,
+                                                          const int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  if (*info != 0) return;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < n; j += 1024) sm[j] = A[(size_t)n * n + j];
+  dense_backsolve_body(n, n, bw, A, sm);
+  for (int j = tid; j < n; j += 1024) x[j] = sm[j];
 }
 
 }  // namespace ba

@@ -1520,7 +1520,7 @@ constexpr int kGm3MaxSpan = 40;                         // widest window: 15 til
 constexpr int kGm3PosLen = 64;                          // optimised positions of a group's cameras (40 used)
 constexpr int kGm3MaxTiles = 15;                        // accumulator tiles of one launch
 
-struct Gm3Params { int nts; int Ld; int Kbuf; int np_cap; int wn; int do_rhs; };
+struct Gm3Params { int nts; int Ld; int Kbuf; int np_cap; int wn; int do_rhs; int wb1; };      // wb1: blocks per row of the LDS window (the widest group)
 // A group of k_schur_groups_mfma3: consecutive points (internal order) whose optimised cameras all lie in the window of
 // W <= 40 (kGm3MaxSpan) consecutive optimised positions starting at `lo`.  tab[(k - pt_begin) * W + w] = the observation of point k
 // in the camera at position lo + w, or -1: the camera lists need NOT be identical, only close (tracks of different
@@ -1529,7 +1529,7 @@ struct WinGroup { int pt_begin; int pt_end; int W; int lo; int tab; int pad0; in
 
 __host__ __device__ constexpr int gm3_ntiles(int tj0, int tj1) { return (tj1 * (tj1 + 1) - tj0 * (tj0 + 1)) / 2; }
 __host__ __device__ inline int gm3_np(int L, int np_cap) { int np = 64 / L; if (np > kGmPts) np = kGmPts; if (np > np_cap) np = np_cap; return np; }
-__host__ __device__ inline size_t schur_mfma3_lds_bytes(int Kbuf, int Ld, int wn, int hb1) {
+__host__ __device__ inline size_t schur_mfma3_lds_bytes(int Kbuf, int Ld, int wn, int hb1) {      // hb1: blocks per window row (Gm3Params::wb1)
   return (size_t)kGm2Pairs * 2 * Kbuf * Ld * sizeof(double) + (size_t)kGm2Pairs * 2 * kGm2DRows * sizeof(double) +
          (size_t)kGm2Pairs * (kGm3PosLen + 4) * sizeof(int) + 64 * sizeof(double) + (size_t)wn * ((size_t)hb1 * 36 + 6) * sizeof(double);
 }
@@ -1557,13 +1557,14 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
   double* tile = sDummy + 64;
   const int hb1 = P.hb + 1;
   const int rowlen = hb1 * 36;
-  double* tb = tile + (size_t)wn * rowlen;
+  const int wrow = G.wb1 * 36;                                 // the LDS window holds the first wb1 blocks of each band row (no group of this launch reaches further)
+  double* tb = tile + (size_t)wn * wrow;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int pair = wv & 3;
   const bool producer = wv < kGm2Pairs;
   const SchurChunk ck = chunks[blockIdx.x];
   const int p0 = ck.p0;
-  for (int i = threadIdx.x; i < wn * (rowlen + 6); i += kGm2Block) tile[i] = 0.0;
+  for (int i = threadIdx.x; i < wn * (wrow + 6); i += kGm2Block) tile[i] = 0.0;
   for (int i = threadIdx.x; i < kGm2Pairs * 2 * (BUF + kGm2DRows); i += kGm2Block) sU[i] = 0.0;   // incl. sD
   if (threadIdx.x < kGm2Pairs * 4) sFlag[threadIdx.x] = 0;
   __syncthreads();
@@ -1575,6 +1576,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
     for (int g = ck.begin + pair; g < ck.end; g += kGm2Pairs) {
       const WinGroup gr = groups[g];
       const int L = gr.W;                                       // lanes per point = window columns (cameras lo .. lo + W - 1)
+      if (TJ0 > 0 && ((6 * L + 15) >> 4) <= TJ0) continue;      // no tile column of this launch exists for the group (the consumer skips it too)
       const int NP = gm3_np(L, G.np_cap);
       const int ks = KSC ? KSC : (3 * NP + 3) >> 2;
       const int slot = lane / L, oi = lane - slot * L;
@@ -1673,8 +1675,8 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
               const double v = a == c2 ? hc[idx] * (1.0 + damping) : hc[idx];
               ++idx;
               if (in) {
-                atomic_add_f64(tile + wr * rowlen + a * 6 + c2, v);
-                if (a != c2) atomic_add_f64(tile + wr * rowlen + c2 * 6 + a, v);
+                atomic_add_f64(tile + wr * wrow + a * 6 + c2, v);
+                if (a != c2) atomic_add_f64(tile + wr * wrow + c2 * 6 + a, v);
               } else {
                 atomic_add_f64(S + (size_t)mypos * rowlen + a * 6 + c2, v);
                 if (a != c2) atomic_add_f64(S + (size_t)mypos * rowlen + c2 * 6 + a, v);
@@ -1693,6 +1695,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
       const int NP = gm3_np(L, G.np_cap);
       const int ks = KSC ? KSC : (3 * NP + 3) >> 2;
       const int nts = (6 * L + 15) >> 4;                        // tiles per side that hold rows of THIS group
+      if (TJ0 > 0 && nts <= TJ0) continue;
       const int nb = (gr.pt_end - gr.pt_begin + NP - 1) / NP;
       if (lane < kGm3PosLen) mPos[lane] = (lane < L && gr.lo + lane < P.nco) ? gr.lo + lane : -1;
       mfma_acc acc[NTILE];
@@ -1749,13 +1752,13 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
             if (allin) {
               // ONE unconditional ds_add_f64 per accumulator register (+ one for the mirrored entry in the tiles that can
               // hold a piece of a diagonal block): lanes with nothing to add hit a private dummy slot
-              const int off = (pi - p0) * rowlen - pi * 36 + a * 6 + colpart;
+              const int off = (pi - p0) * wrow - pi * 36 + a * 6 + colpart;
               atomic_add_f64(ok ? tile + off : dummy, val);
               if (tj <= ti + 1) atomic_add_f64(mirror ? tile + off + 5 * (c - a) : dummy, val);
             } else if (ok) {
               const int wr = pi - p0;
               if (wr >= 0 && wr < wn) {
-                const int off = wr * rowlen - pi * 36 + a * 6 + colpart;
+                const int off = wr * wrow - pi * 36 + a * 6 + colpart;
                 atomic_add_f64(tile + off, val);
                 if (mirror) atomic_add_f64(tile + off + 5 * (c - a), val);
               } else {
@@ -1772,10 +1775,10 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
   }
   if (wn == 0) return;
   __syncthreads();
-  for (int i = threadIdx.x; i < wn * rowlen; i += kGm2Block) {
+  for (int i = threadIdx.x; i < wn * wrow; i += kGm2Block) {
     const double v = tile[i];
-    const int wr = i / rowlen;
-    if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * rowlen), v);
+    const int wr = i / wrow;
+    if (v != 0.0 && p0 + wr < P.nco) atomic_add_f64(S + (size_t)(p0 + wr) * rowlen + (i - wr * wrow), v);
   }
   for (int i = threadIdx.x; i < wn * 6; i += kGm2Block) {
     const double v = tb[i];
@@ -1798,7 +1801,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
 constexpr int kRectSeg = 32;                            // positions per segment
 constexpr int kRectTiles = 6 * kRectSeg / 16;           // 12 tiles per side of a segment
 constexpr int kRectLd = 2 * 6 * kRectSeg;               // staged row: [A | B], 384 doubles
-constexpr int kRectGroupPts = 96;                       // listed points per group
+constexpr int kRectGroupPts = 96;                       // listed points per group at most (the host halves it until the groups fill the chip)
 struct RectGroup { int n; int pts; int tab; int loA; int loB; int WB; int pad0; int pad1; };      // points rtab[pts ...], table rtab[tab + q * 64 + column]
 
 __host__ __device__ inline size_t schur_rect_lds_bytes() {
@@ -1808,7 +1811,7 @@ __host__ __device__ inline size_t schur_rect_lds_bytes() {
 __global__ __launch_bounds__(kGm2Block) void k_schur_rect_mfma(DevProblem P, const double* __restrict__ cams, const double* __restrict__ X,
                                                                const RectGroup* __restrict__ groups, int ngroups,
                                                                const int* __restrict__ rtab, const int* __restrict__ opt_cam,
-                                                               const double* __restrict__ fac, double* __restrict__ S, int tj) {
+                                                               const double* __restrict__ fac, double* __restrict__ S) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   constexpr int BUF = 4 * kRectLd;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -1819,6 +1822,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_rect_mfma(DevProblem P, con
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int pair = wv & 3;
   const bool producer = wv < kGm2Pairs;
+  const int tj = blockIdx.y;                                   // this workgroup's tile column of the B segments
   for (int i = threadIdx.x; i < kGm2Pairs * 2 * (BUF + 4); i += kGm2Block) sU[i] = 0.0;      // incl. sD and the zero rows
   if (threadIdx.x < kGm2Pairs * 4) sFlag[threadIdx.x] = 0;
   __syncthreads();
@@ -1836,21 +1840,31 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_rect_mfma(DevProblem P, con
     const int c = opt_cam[col_ok ? pos : gr.loA];
     double cm[12];
     load_cam(cams, c, cm);
+    struct PointIn { double x[3], f[9]; double2 z; int n; };
+    auto fetch = [&](int q, PointIn& in) {
+      in.n = -1;
+      if (q < gr.n) {
+        const size_t k = (size_t)rtab[gr.pts + q];
+        in.n = col_ok ? rtab[gr.tab + q * 2 * kRectSeg + lane] : -1;
+        in.z = P.obs_z[in.n >= 0 ? in.n : 0];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) in.x[v] = X[3 * k + v];
+#pragma unroll
+        for (int v = 0; v < 9; ++v) in.f[v] = fac[9 * k + v];
+      }
+    };
+    PointIn nxt;
+    fetch(0, nxt);
     for (int q = 0; q < gr.n; ++q) {
-      const int k = rtab[gr.pts + q];
-      const int n = col_ok ? rtab[gr.tab + q * 2 * kRectSeg + lane] : -1;
+      const PointIn cur = nxt;
+      fetch(q + 1, nxt);
       double U[18];
 #pragma unroll
       for (int v = 0; v < 18; ++v) U[v] = 0.0;
-      double f[9];
-#pragma unroll
-      for (int v = 0; v < 9; ++v) f[v] = fac[9 * (size_t)k + v];
-      if (n >= 0) {
-        const double2 z = P.obs_z[n];
-        double x[3], e[2], r[2], Jc[12], Jp[6], W[18];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) x[v] = X[3 * (size_t)k + v];
-        obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+      const double* f = cur.f;
+      if (cur.n >= 0) {
+        double e[2], r[2], Jc[12], Jp[6], W[18];
+        obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
         block_W(Jc, Jp, W);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {

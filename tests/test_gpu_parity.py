@@ -748,8 +748,7 @@ def test_dense_cholesky_on_the_device_matches_lapack(be, nc, L):
     s = banded(nc, 20 * nc, track_len=L)
     flags = default_flags(nc, 20 * nc)
     load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
-    if be.half_bandwidth <= 21:
-        be.set_option('solver', 'dense')
+    be.set_option('solver', 'dense')                  # (narrower bands and more nodes: the cyclic reductions)
     be.linearize(0)
     be.schur(0, 5., 1e-5)
     rng = np.random.RandomState(nc)
@@ -760,6 +759,42 @@ def test_dense_cholesky_on_the_device_matches_lapack(be, nc, L):
         x = be.get_solution().reshape(-1)
         ref = _dense_reference(be, m)
         assert np.abs(x - ref).max() <= 1e-9 * max(1., np.abs(ref).max())
+
+
+@pytest.mark.parametrize('nc,L', [(160, 30), (400, 26), (333, 41), (700, 33), (217, 25), (600, 81)])
+def test_big_node_cyclic_reduction_matches_lapack(be, nc, L):
+    """Half-bandwidths beyond 23 (tracks of 25 and more cameras) with at least four nodes of hb cameras: ba_bcr_big.h - every
+    level a batched partial dense Cholesky of one 3B x 3B matrix per eliminated node (B = 150 .. 480 here; node counts that
+    are and are not powers of two, a padded last node, hb odd and even).  Against LAPACK on the same system and against the
+    dense blocked Cholesky, with and without deleted camera parameters; the status word of a system that is not positive
+    definite."""
+    s = banded(nc, 12 * nc, track_len=L)
+    flags = default_flags(nc, 12 * nc)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    assert be.half_bandwidth == L - 1
+    be.linearize(0)
+    be.schur(0, 5., 1e-5)
+    rng = np.random.RandomState(nc)
+    mask = (rng.rand(be.nco * 6) > .1).astype(np.uint8)
+    for m in (None, mask):
+        be.set_option('solver', 'auto' if nc >= 333 else 'bcr')        # (on its own from eight nodes on; 160 / 30: six)
+        be.solve_reduced(m)
+        assert be.last_solve_kind == 'bcr_big' and be.last_solve_path == 'band'
+        x = be.get_solution().reshape(-1)
+        ref = _dense_reference(be, m)
+        assert np.abs(x - ref).max() <= 1e-9 * max(1., np.abs(ref).max())
+        be.set_option('solver', 'dense')
+        be.solve_reduced(m)
+        assert be.last_solve_kind == 'dense_cholesky'
+        close(be.get_solution().reshape(-1), x, 1e-10)
+        if m is not None:
+            assert np.all(x[m == 0] == 0)
+    be.set_option('solver', 'bcr')
+    if nc <= 217:
+        be.schur(0, -3., 1e-5)                        # negative damping: not positive definite - reported, the caller's LU takes over
+        be.solve_reduced(None)
+        assert be.last_solve_kind == 'bcr_big' and be.last_solve_path == 'dense'
+        close(be.get_solution().reshape(-1), _dense_reference(be), 1e-7)
 
 
 def test_dense_cholesky_equals_cyclic_reduction(be):
