@@ -11,7 +11,7 @@
 // y = L^-1 b.  Right-looking, block columns of 48:
 //
 //   k_dense_gather     band-stored [S | b] -> A
-//   k_dense_panel      one workgroup per 128 panel rows; EVERY workgroup factors the 48 x 48 diagonal block
+//   k_dense_panel      one workgroup per 64 panel rows (128: 12 % slower per panel step, measured on the batched use of ba_bcr_big.h); EVERY workgroup factors the 48 x 48 diagonal block
 //                      itself in LDS (12 x 12 steps: DPP pivots, one-row-per-lane panel, MFMA update - the
 //                      pieces of ba_bcr.h) instead of waiting for another launch to do it once
 //   k_dense_update     trailing matrix -= panel panel^T, 64 x 64 tiles, 16 x 16 x 4 fp64 MFMAs from LDS panels
@@ -25,7 +25,10 @@
 namespace ba {
 
 constexpr int kDcNB = 48;                      // block column width (a multiple of 12)
-constexpr int kDcRows = 128;                   // panel rows per workgroup
+#ifndef BA_DC_ROWS
+#define BA_DC_ROWS 64
+#endif
+constexpr int kDcRows = BA_DC_ROWS;            // panel rows per workgroup
 constexpr int kDcLd = kDcNB + 1;
 constexpr int kDcM = kDcNB + kDcRows + 16;     // LDS rows: diagonal block + panel rows + one tile of slack for the MFMA reads
 constexpr int kDcTile = 64;
