@@ -122,10 +122,7 @@ struct ba_handle {
   DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
   DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
   int nm3chunks = 0, nwgroups = 0;
-  Gm3Params gm3w{0, 0, 0, 0, 0, 1, 1};  // the same for the groups of LISTED points (long tracks inside their segments of kRectSeg positions): their own
-  DevBuf<SchurChunk> m3chunks_w;        // staged row length and launches, so that the short tracks' groups run exactly as without them
-  int nm3chunks_w = 0;
-  // tracks that span more than kGm3MaxSpan cameras: members of their segments' window groups + rectangular groups between segments
+  // tracks that span more than kGm3MaxSpan cameras: groups of k_schur_rect_mfma, one per pair of segments (A <= B) they touch
   DevBuf<RectGroup> rgroups;
   DevBuf<int> rtab;
   int nrgroups = 0, nlong_points = 0;
@@ -1021,7 +1018,7 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->m3chunks_w.release(); h->wgroups.release(); h->wtab.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->wgroups.release(); h->wtab.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
@@ -1307,11 +1304,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   //   mgroups / mchunks  longer runs for the matrix-core reductions; mchunks under the LDS window `wn` of the older
   //                      kernels (track length <= 10), m3chunks under k_schur_groups_mfma3's own window
   std::vector<SchurGroup> groups, mgroups;
-  std::vector<SchurChunk> gchunks, mchunks, m3chunks, m3chunks_w;
+  std::vector<SchurChunk> gchunks, mchunks, m3chunks;
   int group_rounds = 0;
   bool groups_worth = false;
   bool groups_ascending = true;                      // optimised positions ascend along every track
-  Gm3Params gm3{0, 0, 0, 0, 0, 1, 1}, gm3w{0, 0, 0, 0, 0, 1, 1};
+  Gm3Params gm3{0, 0, 0, 0, 0, 1, 1};
   if (maxL >= 1 && maxL <= kGm3MaxL) {
     auto build_groups = [&](int max_pts, std::vector<SchurGroup>& gs, std::vector<int>& glo, std::vector<int>& ghi) {
       for (int k = 0; k < nt;) {
@@ -1420,10 +1417,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       if (phi[k] >= 0 && plo[k] < last) sorted_by_lo = false;
     }
     // Points whose optimised cameras span MORE than the widest window (features that survive for a long stretch of a video):
-    // their cameras are cut along a grid of SEGMENTS of kRectSeg positions.  Inside a segment such a point is one more member of
-    // a window group (the segment is its window; a point list instead of a range of points) - right-hand side and camera
-    // blocks come from there, every observation lies in exactly one segment.  The blocks BETWEEN two segments a point touches
-    // are rectangular products, S[A, B] -= U_A^T D U_B: k_schur_rect_mfma over the points that touch both (rgroups).
+    // their cameras are cut along a grid of SEGMENTS of kRectSeg positions, and what a point adds to S is a sum over the pairs
+    // (A <= B) of segments it touches, S[A, B] -= U_A^T D U_B: k_schur_rect_mfma over the points that touch both (rgroups).
+    // A == B also carries the right-hand side and the camera blocks - every observation lies in exactly one segment.
     auto is_long = [&](int k) { return phi[k] >= 0 && phi[k] - plo[k] + 1 > kGm3MaxSpan; };
     long long nlong = 0;
     int shortspan = 0;
@@ -1433,11 +1429,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     }
     const bool hybrid = nlong > 0 && sorted_by_lo && nco > 0;
     struct SegTask { int qa, qb; std::vector<int> pts; };
-    std::vector<SegTask> sym_tasks, rect_tasks;
+    std::vector<SegTask> rect_tasks;
     if (hybrid) {
       maxspan = shortspan;
       nlong_points = (int)nlong;
-      std::map<long long, int> sym_id, rect_id;
+      std::map<long long, int> rect_id;
       for (int k = 0; k < nt; ++k) {
         if (!is_long(k)) continue;
         std::vector<int> segs;
@@ -1448,10 +1444,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         std::sort(segs.begin(), segs.end());
         segs.erase(std::unique(segs.begin(), segs.end()), segs.end());
         for (size_t x = 0; x < segs.size(); ++x) {
-          auto it = sym_id.find(segs[x]);
-          if (it == sym_id.end()) { it = sym_id.emplace(segs[x], (int)sym_tasks.size()).first; sym_tasks.push_back({segs[x], segs[x], {}}); }
-          sym_tasks[it->second].pts.push_back(k);
-          for (size_t y = x + 1; y < segs.size(); ++y) {
+          for (size_t y = x; y < segs.size(); ++y) {
             const long long key = ((long long)segs[x] << 32) | (unsigned)segs[y];
             auto jt = rect_id.find(key);
             if (jt == rect_id.end()) { jt = rect_id.emplace(key, (int)rect_tasks.size()).first; rect_tasks.push_back({segs[x], segs[y], {}}); }
@@ -1512,41 +1505,16 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
           wlo.push_back(lo); whi.push_back(hi);
         }
       }
-      // the long points inside their segments: window = the segment, members = a list (stored in wtab in front of the table)
       const int nshort_groups = (int)wgroups.size();
-      // points per group: a group is one serial chain of batches on one wavefront pair, and there are few long tracks - halve
-      // the groups until they fill the chip (24 points at least: an epilogue of up to 78 tiles is paid per group)
-      auto group_points = [&](const std::vector<SegTask>& tasks, size_t want) {
-        int pts = kRectGroupPts;
-        for (; pts > 24; pts /= 2) {
-          size_t n = 0;
-          for (const SegTask& t : tasks) n += (t.pts.size() + pts - 1) / pts;
-          if (n >= want) break;
-        }
-        return pts;
-      };
-      const int sym_pts = group_points(sym_tasks, (size_t)slots), rect_pts = group_points(rect_tasks, (size_t)slots / 8);
-      for (const SegTask& t : sym_tasks) {
-        const int lo = t.qa * kRectSeg, W = std::min(kRectSeg, nco - lo);
-        const size_t parts = (t.pts.size() + sym_pts - 1) / sym_pts, part = (t.pts.size() + parts - 1) / parts;
-        for (size_t b0 = 0; b0 < t.pts.size(); b0 += part) {
-          const int cnt = (int)std::min<size_t>(part, t.pts.size() - b0);
-          const int pl = (int)wtab.size();
-          wtab.insert(wtab.end(), t.pts.begin() + b0, t.pts.begin() + b0 + cnt);
-          WinGroup g{0, cnt, W, lo, (int)wtab.size(), pl + 1, 0, 0};
-          wtab.resize(wtab.size() + (size_t)cnt * W, -1);
-          for (int q = 0; q < cnt; ++q) {
-            const int k = t.pts[b0 + q];
-            for (int n2 = off[k]; n2 < off[(size_t)k + 1]; ++n2) {
-              const int p = cam_opt_pos[obs_cam[n2]];
-              if (p >= lo && p < lo + W) wtab[(size_t)g.tab + (size_t)q * W + (p - lo)] = n2;
-            }
-          }
-          wgroups.push_back(g);
-          wlo.push_back(lo); whi.push_back(lo + W - 1);
-        }
+      // points per group: a group is one serial chain of batches on one workgroup, and there are few long tracks - halve the
+      // groups until they fill the chip twice (24 points at least: an epilogue of up to 144 tiles is paid per group)
+      int rect_pts = kRectGroupPts;
+      for (; rect_pts > 24; rect_pts /= 2) {
+        size_t ngr = 0;
+        for (const SegTask& t : rect_tasks) ngr += (t.pts.size() + rect_pts - 1) / rect_pts;
+        if (ngr >= (size_t)2 * ncu) break;                 // one workgroup per group, one workgroup per compute unit (its consumers' registers)
       }
-      // ... and between two segments: rectangular groups (k_schur_rect_mfma), table rows of 2 kRectSeg columns [A | B]
+      // groups of the pairs of segments: table rows of 2 kRectSeg columns [A | B] (A == B: the B half stays empty)
       for (const SegTask& t : rect_tasks) {
         const int loA = t.qa * kRectSeg, loB = t.qb * kRectSeg, WB = std::min(kRectSeg, nco - loB);
         const size_t parts = (t.pts.size() + rect_pts - 1) / rect_pts, part = (t.pts.size() + parts - 1) / parts;
@@ -1561,7 +1529,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
             for (int n2 = off[k]; n2 < off[(size_t)k + 1]; ++n2) {
               const int p = cam_opt_pos[obs_cam[n2]];
               if (p >= loA && p < loA + kRectSeg) rtab[(size_t)g.tab + (size_t)q * 2 * kRectSeg + (p - loA)] = n2;
-              else if (p >= loB && p < loB + WB) rtab[(size_t)g.tab + (size_t)q * 2 * kRectSeg + kRectSeg + (p - loB)] = n2;
+              else if (t.qa != t.qb && p >= loB && p < loB + WB) rtab[(size_t)g.tab + (size_t)q * 2 * kRectSeg + kRectSeg + (p - loB)] = n2;
             }
           }
           rgroups.push_back(g);
@@ -1600,14 +1568,10 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         out.push_back({begin, g1, lo});
       };
       finish_set(0, nshort_groups, gm3, m3chunks);
-      gm3w.nts = kRectTiles;
-      gm3w.Ld = 16 * gm3w.nts;
-      finish_set(nshort_groups, (int)wgroups.size(), gm3w, m3chunks_w);
-      // an epilogue per >= 12 points (judged on the short tracks' groups when there are any: a few long tracks do not decide it)
-      const int j0 = nshort_groups > 0 ? 0 : nshort_groups, j1 = nshort_groups > 0 ? nshort_groups : (int)wgroups.size();
+      // an epilogue per >= 12 points (the short tracks' groups decide; a scene of nothing but long tracks: its segment groups)
       long long covered = 0;
-      for (int g = j0; g < j1; ++g) covered += wgroups[g].pt_end - wgroups[g].pt_begin;
-      wgroups_worth = j1 > j0 && covered >= 12ll * (long long)(j1 - j0);
+      for (const WinGroup& g : wgroups) covered += g.pt_end - g.pt_begin;
+      wgroups_worth = wgroups.empty() ? !rgroups.empty() : covered >= 12ll * (long long)wgroups.size();
     }
   }
   // lanes per point: smallest power of two >= mean track length, in [1, 64]
@@ -1625,15 +1589,13 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
   h->nm3chunks = (int)m3chunks.size();
-  h->nm3chunks_w = (int)m3chunks_w.size();
-  h->gm3w = gm3w;
   h->nwgroups = (int)wgroups.size();
   h->gm3_uniform_ks = !m3chunks.empty();
   for (const SchurChunk& c : m3chunks)
     for (int g = c.begin; g < c.end; ++g) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(wgroups[g].W, gm3.np_cap) == kGmPts;
   h->wgroups_worth = wgroups_worth;
-  h->nrgroups = wgroups.empty() ? 0 : (int)rgroups.size();      // (the long points' rectangular groups only exist next to the window groups)
-  h->nlong_points = wgroups.empty() ? 0 : nlong_points;
+  h->nrgroups = (int)rgroups.size();
+  h->nlong_points = rgroups.empty() ? 0 : nlong_points;
   h->gm3 = gm3;
   h->groups_worth = groups_worth;
   h->nmgroups_total = (int)mgroups.size();
@@ -1670,9 +1632,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->m3chunks.resize(std::max<size_t>(1, m3chunks.size())));
   if (!m3chunks.empty())
     HIPCHECK(h, hipMemcpyAsync(h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
-  HIPCHECK(h, h->m3chunks_w.resize(std::max<size_t>(1, m3chunks_w.size())));
-  if (!m3chunks_w.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->m3chunks_w.p, m3chunks_w.data(), m3chunks_w.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->wgroups.resize(std::max<size_t>(1, wgroups.size())));
   HIPCHECK(h, h->wtab.resize(std::max<size_t>(1, wtab.size())));
   if (!wgroups.empty()) {
@@ -1900,7 +1859,7 @@ enum { KERN_PAIRS = 0, KERN_GROUPS, KERN_MFMA1, KERN_MFMA2, KERN_MFMA3, KERN_DEN
 int pick_schur_kernel(const ba_handle* h) {
   if (h->dense_mode && h->nt > 0 && h->nco > 0) return KERN_DENSE;
   const bool asc = h->groups_ascending && h->group_maxL >= 1;
-  const bool m3 = (h->nm3chunks > 0 || h->nm3chunks_w > 0) && h->nwgroups > 0;           // window groups: no identical camera lists needed
+  const bool m3 = (h->nm3chunks > 0 && h->nwgroups > 0) || h->nrgroups > 0;           // window groups: no identical camera lists needed
   const bool m12 = asc && h->nmchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGmMaxL;      // the L <= 10 kernels
   const bool vec = h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGroupMaxL;
   switch (h->opt.schur) {
@@ -1955,9 +1914,7 @@ int launch_mfma3_set(ba_handle* h, const M3Launch& L, int p, double damping, boo
   return rc;
 }
 int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
-  int rc = launch_mfma3_set(h, M3Launch{h->gm3, h->m3chunks.p, h->nm3chunks, h->gm3_uniform_ks}, p, damping, fuse_cam);
-  if (rc == BA_OK) rc = launch_mfma3_set(h, M3Launch{h->gm3w, h->m3chunks_w.p, h->nm3chunks_w, false}, p, damping, fuse_cam);
-  return rc;
+  return launch_mfma3_set(h, M3Launch{h->gm3, h->m3chunks.p, h->nm3chunks, h->gm3_uniform_ks}, p, damping, fuse_cam);
 }
 inline int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 : nts - 5; }
 }  // extern "C++"
@@ -2180,14 +2137,13 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
                        h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
   } else if (kern == KERN_MFMA3) {
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, (h->nm3chunks ? mfma3_launches(h->gm3.nts) : 0) + (h->nm3chunks_w ? mfma3_launches(h->gm3w.nts) : 0) + (hybrid ? 1 : 0));
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, (h->nm3chunks ? mfma3_launches(h->gm3.nts) : 0) + (hybrid ? 1 : 0));
     rc = launch_mfma3_all(h, p, damping, fuse_cam);
     if (rc != BA_OK) return rc;
     if (hybrid) {
       HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_rect_mfma));
-      const int nwg = (h->nrgroups + kGm2Pairs - 1) / kGm2Pairs;      // blockIdx.y = tile column of the B segment: kRectTiles accumulator tiles each
-      hipLaunchKernelGGL(k_schur_rect_mfma, dim3(nwg, kRectTiles), dim3(kGm2Block), schur_rect_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
-                         h->X[p].p, h->rgroups.p, h->nrgroups, h->rtab.p, h->opt_cam.p, h->fac.p, h->S);
+      hipLaunchKernelGGL(k_schur_rect_mfma, dim3(h->nrgroups), dim3(kRectBlock), schur_rect_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->rgroups.p, h->nrgroups, h->rtab.p, h->opt_cam.p, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
     }
   } else if (kern == KERN_MFMA2) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);

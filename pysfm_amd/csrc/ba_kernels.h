@@ -1525,7 +1525,7 @@ struct Gm3Params { int nts; int Ld; int Kbuf; int np_cap; int wn; int do_rhs; in
 // W <= 40 (kGm3MaxSpan) consecutive optimised positions starting at `lo`.  tab[(k - pt_begin) * W + w] = the observation of point k
 // in the camera at position lo + w, or -1: the camera lists need NOT be identical, only close (tracks of different
 // lengths, missing observations) - a run of points with one camera list is the special case of a full table.
-struct WinGroup { int pt_begin; int pt_end; int W; int lo; int tab; int pad0; int pad1; int pad2; };      // pad0 != 0: the points are wtab[pad0 - 1 ...] (pt_begin = 0), not a range
+struct WinGroup { int pt_begin; int pt_end; int W; int lo; int tab; int pad0; int pad1; int pad2; };
 
 __host__ __device__ constexpr int gm3_ntiles(int tj0, int tj1) { return (tj1 * (tj1 + 1) - tj0 * (tj0 + 1)) / 2; }
 __host__ __device__ inline int gm3_np(int L, int np_cap) { int np = 64 / L; if (np > kGmPts) np = kGmPts; if (np > np_cap) np = np_cap; return np; }
@@ -1597,11 +1597,10 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
         if (stager && k < gr.pt_end) {
           in.n = mypos >= 0 ? wtab[gr.tab + (k - gr.pt_begin) * L + oi] : -1;      // this point's observation in my camera, if any
           in.z = P.obs_z[in.n >= 0 ? in.n : 0];
-          const size_t kk = gr.pad0 ? (size_t)wtab[gr.pad0 - 1 + (k - gr.pt_begin)] : (size_t)k;      // (a group of listed points: long tracks inside one of their segments)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) in.x[q] = X[3 * kk + q];
+          for (int q = 0; q < 3; ++q) in.x[q] = X[3 * (size_t)k + q];
 #pragma unroll
-          for (int q = 0; q < 9; ++q) in.f[q] = fac[9 * kk + q];
+          for (int q = 0; q < 9; ++q) in.f[q] = fac[9 * (size_t)k + q];
         }
       };
       PointIn nxt;
@@ -1788,58 +1787,69 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
 
 // --------------------------------------------------------------------------
 // Tracks that span MORE cameras than the widest window of k_schur_groups_mfma3 (kGm3MaxSpan): their optimised positions are
-// cut along a grid of segments of kRectSeg = 32 positions (192 unknowns = 12 tiles).  Inside a segment such a point is a member
-// of an ordinary window group (a listed point, WinGroup::pad0); what is left are the blocks BETWEEN two segments A < B that a
-// point touches:  S[A, B] -= U_A^T D U_B  - a rectangular product with the same staged operand U = W L per observation.
-// This kernel forms it for groups of (listed) points that touch the same two segments: producer / consumer wavefront pairs as
-// in k_schur_groups_mfma3, one point per batch - lane = column of the table row [A | B], 64 cameras; the consumer keeps the
-// kRectTiles tiles (row tiles of A) x (ONE column tile tj of B) in registers for the whole group, the host launches it once
-// per column tile.  No right-hand side, no camera blocks (the segments' window groups add them), no LDS window: the few
-// long tracks of a video scene are what this is for (2 % of config 3's points seen by 80 cameras: 8 ms through the pair
-// kernel's global atomics).
+// cut along a grid of segments of kRectSeg = 32 positions (192 unknowns = 12 tiles), and what such a point adds to S is a sum
+// over the PAIRS (A <= B) of segments it touches:  S[A, B] -= U_A^T D U_B  with the staged operand U = W L per observation.
+// This kernel forms these products for groups of (listed) points that touch the same two segments, one group per workgroup:
+// TWO producer wavefronts (lane = column of the table row [A | B]: 64 cameras, one point per batch; even / odd points of the
+// group, a staging buffer each) stage for SIX consumer wavefronts, each of which keeps kRectTiles row tiles of A x TWO column
+// tiles of B in registers for the whole group (24 accumulator tiles: 192 VGPRs) - the linearisation of an observation is paid
+// once per pair of segments, not once per tile column, and the consumers' 24 MFMAs per batch hide behind it.
+// A == B (the point inside one segment): the B operand is the A half of the staged row, tiles more than one below the
+// diagonal are skipped, blocks with pj >= pi are added (diagonal blocks in full); the producer also adds the segment's share of
+// the right-hand side and of the camera blocks - every observation of a long point lies in exactly one segment.
+// No LDS window: the few long tracks of a video scene are what this is for (2 % of config 3's points seen by 80 cameras:
+// 8 ms through the pair kernel's global atomics).
 // --------------------------------------------------------------------------
 constexpr int kRectSeg = 32;                            // positions per segment
 constexpr int kRectTiles = 6 * kRectSeg / 16;           // 12 tiles per side of a segment
 constexpr int kRectLd = 2 * 6 * kRectSeg;               // staged row: [A | B], 384 doubles
 constexpr int kRectGroupPts = 96;                       // listed points per group at most (the host halves it until the groups fill the chip)
+constexpr int kRectConsumers = kRectTiles / 2;          // consumer wavefronts of a workgroup: two tile columns each
+constexpr int kRectBlock = 64 * (2 + kRectConsumers);      // two producers (even / odd points of the group) + the consumers
 struct RectGroup { int n; int pts; int tab; int loA; int loB; int WB; int pad0; int pad1; };      // points rtab[pts ...], table rtab[tab + q * 64 + column]
 
 __host__ __device__ inline size_t schur_rect_lds_bytes() {
-  return (size_t)kGm2Pairs * 2 * 4 * kRectLd * sizeof(double) + (size_t)kGm2Pairs * 2 * 4 * sizeof(double) + (size_t)kGm2Pairs * (64 + 4) * sizeof(int);
+  return (size_t)2 * 4 * kRectLd * sizeof(double) + (size_t)2 * 4 * sizeof(double) + (size_t)(64 + 8) * sizeof(int);
 }
 
-__global__ __launch_bounds__(kGm2Block) void k_schur_rect_mfma(DevProblem P, const double* __restrict__ cams, const double* __restrict__ X,
-                                                               const RectGroup* __restrict__ groups, int ngroups,
-                                                               const int* __restrict__ rtab, const int* __restrict__ opt_cam,
-                                                               const double* __restrict__ fac, double* __restrict__ S) {
+__global__ __launch_bounds__(kRectBlock) void k_schur_rect_mfma(DevProblem P, const double* __restrict__ cams, const double* __restrict__ X,
+                                                                const RectGroup* __restrict__ groups, int ngroups,
+                                                                const int* __restrict__ rtab, const int* __restrict__ opt_cam,
+                                                                const double* __restrict__ fac, double* __restrict__ S,
+                                                                double* __restrict__ b, double damping, int fuse_cam) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
   constexpr int BUF = 4 * kRectLd;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
-  double* sU = dyn;                                            // [pair][2][4][kRectLd]: three k rows of a point + a zero row
-  double* sD = sU + kGm2Pairs * 2 * BUF;                       // [pair][2][4]
-  int* sPos = reinterpret_cast<int*>(sD + kGm2Pairs * 2 * 4);  // [pair][64]
-  int* sFlag = sPos + kGm2Pairs * 64;                          // [pair][4]: staged, consumed
+  double* sU = dyn;                                            // [2][4][kRectLd]: three k rows of a point + a zero row
+  double* sD = sU + 2 * BUF;                                   // [2][4]
+  int* sPos = reinterpret_cast<int*>(sD + 2 * 4);              // [64]
+  int* sFlag = sPos + 64;                                      // [8]: staged (one word per buffer), consumed by each of the six
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int pair = wv & 3;
-  const bool producer = wv < kGm2Pairs;
-  const int tj = blockIdx.y;                                   // this workgroup's tile column of the B segments
-  for (int i = threadIdx.x; i < kGm2Pairs * 2 * (BUF + 4); i += kGm2Block) sU[i] = 0.0;      // incl. sD and the zero rows
-  if (threadIdx.x < kGm2Pairs * 4) sFlag[threadIdx.x] = 0;
-  __syncthreads();
-  const int g = blockIdx.x * kGm2Pairs + pair;
-  if (g >= ngroups) return;
-  const RectGroup gr = groups[g];
-  if (16 * tj >= 6 * gr.WB) return;                            // (a short last segment has fewer column tiles)
-  int* fStaged = sFlag + pair * 4;
-  int* fConsumed = fStaged + 1;
-  const int hb1 = P.hb + 1, rowlen = hb1 * 36;
-  if (producer) {
-    // lane = column of the table row: A's cameras (positions loA ..), then B's
+  const RectGroup gr = groups[blockIdx.x];
+  for (int i = threadIdx.x; i < 2 * (BUF + 4); i += kRectBlock) sU[i] = 0.0;      // incl. sD and the zero rows
+  if (threadIdx.x < 8) sFlag[threadIdx.x] = 0;
+  if (threadIdx.x < 64) {
     const int pos = lane < kRectSeg ? gr.loA + lane : gr.loB + (lane - kRectSeg);
-    const bool col_ok = lane < kRectSeg ? pos < P.nco : lane - kRectSeg < gr.WB;
+    const bool there = lane < kRectSeg ? pos < P.nco : lane - kRectSeg < gr.WB;
+    sPos[lane] = there ? pos : -1;
+  }
+  __syncthreads();
+  const bool sym = gr.loA == gr.loB;
+  int* fStaged = sFlag;                                        // [2]
+  int* fConsumed = sFlag + 2;
+  const int hb1 = P.hb + 1, rowlen = hb1 * 36;
+  if (wv < 2) {
+    // lane = column of the table row: A's cameras (positions loA ..), then B's (A == B: the second half stays empty)
+    const int pos = lane < kRectSeg ? gr.loA + lane : gr.loB + (lane - kRectSeg);
+    const bool col_ok = lane < kRectSeg ? pos < P.nco : (!sym && lane - kRectSeg < gr.WB);
+    const bool rhs = sym && col_ok;                            // this lane's camera: right-hand side (and camera block) of the segment's observations
     const int c = opt_cam[col_ok ? pos : gr.loA];
     double cm[12];
     load_cam(cams, c, cm);
+    double bacc[6] = {0, 0, 0, 0, 0, 0};
+    double hc[21];
+#pragma unroll
+    for (int q = 0; q < 21; ++q) hc[q] = 0.0;
     struct PointIn { double x[3], f[9]; double2 z; int n; };
     auto fetch = [&](int q, PointIn& in) {
       in.n = -1;
@@ -1854,73 +1864,118 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_rect_mfma(DevProblem P, con
       }
     };
     PointIn nxt;
-    fetch(0, nxt);
-    for (int q = 0; q < gr.n; ++q) {
+    fetch(wv, nxt);
+    for (int q = wv; q < gr.n; q += 2) {
       const PointIn cur = nxt;
-      fetch(q + 1, nxt);
+      fetch(q + 2, nxt);
       double U[18];
 #pragma unroll
       for (int v = 0; v < 18; ++v) U[v] = 0.0;
-      const double* f = cur.f;
       if (cur.n >= 0) {
         double e[2], r[2], Jc[12], Jp[6], W[18];
         obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
         block_W(Jc, Jp, W);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          U[a * 3] = W[a * 3] + f[3] * W[a * 3 + 1] + f[4] * W[a * 3 + 2];
-          U[a * 3 + 1] = W[a * 3 + 1] + f[5] * W[a * 3 + 2];
+          U[a * 3] = W[a * 3] + cur.f[3] * W[a * 3 + 1] + cur.f[4] * W[a * 3 + 2];
+          U[a * 3 + 1] = W[a * 3 + 1] + cur.f[5] * W[a * 3 + 2];
           U[a * 3 + 2] = W[a * 3 + 2];
         }
+        if (rhs) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) bacc[a] -= W[a * 3] * cur.f[6] + W[a * 3 + 1] * cur.f[7] + W[a * 3 + 2] * cur.f[8];
+          if (fuse_cam) {                                       // HCC[i] += Jc^T Jc, b[i] += Jc^T r (k_camera_blocks' work)
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+              for (int c2 = a; c2 < 6; ++c2) hc[idx++] += Jc[a] * Jc[c2] + Jc[6 + a] * Jc[6 + c2];
+              bacc[a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+            }
+          }
+        }
       }
-      gm2_wait(fConsumed, q - 1);                              // the buffer's previous batch (q - 2) has been read
-      double* mU = sU + (pair * 2 + (q & 1)) * BUF;
-      double* mD = sD + (pair * 2 + (q & 1)) * 4;
+      // my buffer's previous batch (q - 2) has been read by every consumer
+      for (;;) {
+        const int v = lane < kRectConsumers ? __hip_atomic_load(fConsumed + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+        if (__all(v >= q - 1)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      double* mU = sU + (q & 1) * BUF;
+      double* mD = sD + (q & 1) * 4;
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int d = 0; d < 3; ++d) mU[d * kRectLd + 6 * lane + a] = U[a * 3 + d];
-      if (lane < 3) mD[lane] = f[lane];
-      gm2_post(fStaged, q + 1, lane);
+      if (lane < 3) mD[lane] = lane == 0 ? cur.f[0] : lane == 1 ? cur.f[1] : cur.f[2];
+      gm2_post(fStaged + (q & 1), q + 1, lane);
+    }
+    if (rhs) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) atomic_add_f64(b + (size_t)pos * 6 + a, bacc[a]);
+      if (fuse_cam) {                                          // damped camera block onto the diagonal block (stored in full)
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c2 = a; c2 < 6; ++c2) {
+            const double v = a == c2 ? hc[idx] * (1.0 + damping) : hc[idx];
+            ++idx;
+            atomic_add_f64(S + (size_t)pos * rowlen + a * 6 + c2, v);
+            if (a != c2) atomic_add_f64(S + (size_t)pos * rowlen + c2 * 6 + a, v);
+          }
+        }
+      }
     }
   } else {
-    const int lr = lane & 15, lk = lane >> 4;
-    int* mPos = sPos + pair * 64;
-    {
-      const int pos = lane < kRectSeg ? gr.loA + lane : gr.loB + (lane - kRectSeg);
-      const bool col_ok = lane < kRectSeg ? pos < P.nco : lane - kRectSeg < gr.WB;
-      mPos[lane] = col_ok ? pos : -1;
+    const int cw = wv - 2, tj0 = 2 * cw;                       // my tile columns of B: tj0, tj0 + 1
+    int* mine = fConsumed + cw;
+    if (16 * tj0 >= 6 * gr.WB) {                               // (a short last segment has fewer column tiles: nobody waits for me)
+      gm2_post(mine, 0x7ffffff0, lane);
+      return;
     }
-    mfma_acc acc[kRectTiles];
+    const int lr = lane & 15, lk = lane >> 4;
+    const int* mPos = sPos;
+    mfma_acc acc[2][kRectTiles];
 #pragma unroll
-    for (int t = 0; t < kRectTiles; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < kRectTiles; ++t) acc[u][t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+    const int boff = sym ? 16 * tj0 : 6 * kRectSeg + 16 * tj0;   // A == B: the B operand is the A half
     for (int q = 0; q < gr.n; ++q) {
-      gm2_wait(fStaged, q + 1);
-      const double* mU = sU + (pair * 2 + (q & 1)) * BUF;
-      const double dk = sD[(pair * 2 + (q & 1)) * 4 + lk];     // (k row 3: D = 0, the row itself is zero)
+      gm2_wait(fStaged + (q & 1), q + 1);
+      const double* mU = sU + (q & 1) * BUF;
+      const double dk = sD[(q & 1) * 4 + lk];                  // (k row 3: D = 0, the row itself is zero)
       const double* row = mU + lk * kRectLd + lr;
       double ta[kRectTiles];
 #pragma unroll
-      for (int t = 0; t < kRectTiles; ++t) ta[t] = row[16 * t];
-      const double wb = row[6 * kRectSeg + 16 * tj];
-      gm2_post(fConsumed, q + 1, lane);                        // everything of this buffer is in registers
+      for (int t = 0; t < kRectTiles; ++t) ta[t] = row[16 * t] * dk;
+      const double wb0 = row[boff], wb1 = row[boff + 16];
+      gm2_post(mine, q + 1, lane);                             // everything of this buffer is in registers
 #pragma unroll
-      for (int t = 0; t < kRectTiles; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t] * dk, wb, acc[t], 0, 0, 0);
+      for (int t = 0; t < kRectTiles; ++t) {
+        if (!sym || t <= tj0 + 1) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wb0, acc[0][t], 0, 0, 0);      // (wave-uniform)
+        if (!sym || t <= tj0 + 2) acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wb1, acc[1][t], 0, 0, 0);
+      }
     }
-    lds_wave_sync();                                           // mPos
     // C/D layout: lane -> column n = 16 tj + lane % 16 (of B), register v -> row m = 16 ti + lane / 16 + 4 v (of A);
-    // block (i, j), position pi < pj, sits in band row pi at (pj - pi) * 36 + a * 6 + c
-    const int n = 16 * tj + lr, j = n / 6, cc = n - 6 * j;
-    const int pj = j < kRectSeg ? mPos[kRectSeg + j] : -1;
+    // block (i, j), position pi <= pj, sits in band row pi at (pj - pi) * 36 + a * 6 + c
 #pragma unroll
-    for (int ti = 0; ti < kRectTiles; ++ti) {
+    for (int u = 0; u < 2; ++u) {
+      const int tj = tj0 + u;
+      const int n = 16 * tj + lr, j = n / 6, cc = n - 6 * j;
+      const int pj = j < kRectSeg ? mPos[kRectSeg + j] : -1;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int m = 16 * ti + lk + 4 * v, i = m / 6, a = m - 6 * i;
-        const int pi = mPos[i];
-        const double val = -acc[ti][v];
-        if (pi >= 0 && pj >= 0 && val != 0.0 && pj - pi <= P.hb)      // (a zero entry: no point of the group sees both cameras)
-          atomic_add_f64(S + (size_t)pi * rowlen + (size_t)(pj - pi) * 36 + a * 6 + cc, val);
+      for (int ti = 0; ti < kRectTiles; ++ti) {
+        if (sym && ti > tj + 1) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = 16 * ti + lk + 4 * v, i = m / 6, a = m - 6 * i;
+          const int pi = mPos[i];
+          const double val = -acc[u][ti][v];
+          if (pi >= 0 && pj >= pi && val != 0.0 && pj - pi <= P.hb)      // (a zero entry: no point of the group sees both cameras)
+            atomic_add_f64(S + (size_t)pi * rowlen + (size_t)(pj - pi) * 36 + a * 6 + cc, val);
+        }
       }
     }
   }
