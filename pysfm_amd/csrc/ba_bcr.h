@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, i
   // of an entry that is not in the band is that of S[0], its value is then multiplied away - a select on the loaded value
   // would compile to a branch around every load
   constexpr int NIT = 3;             // entries per thread and round (B = 54: one round; the wide solver's B = 138: seven)
-  for (int base = 0; base < B * B; base += NIT * kBcrThreads) {
+  for (int base = blockIdx.y * NIT * kBcrThreads; base < B * B; base += gridDim.y * NIT * kBcrThreads) {      // (gridDim.y > 1: the big nodes of ba_bcr_big.h)
   double vd[NIT], vu[NIT], kd[NIT], ku[NIT], idv[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, i
     }
   }
   }
+  if (blockIdx.y != 0) return;
   for (int r = threadIdx.x; r < B; r += kBcrThreads) {
     const int i = I * cb + r / 6, a = r % 6;
     fm[(size_t)I * B + r] = (i < nco && (!mask || mask[6 * i + a])) ? b[6 * (size_t)i + a] : 0.0;

@@ -814,8 +814,9 @@ int solve_bcr_big(ba_handle* h, const unsigned char* dmask) {
   int* info = h->flags.p + 1;
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, hb, cb, h->S, h->b, dmask, h->bcrD.p,
-                       h->bcrU.p, h->bcrF.p, info, (double*)nullptr);
+    const int rounds = (int)((BB + 3 * kBcrThreads - 1) / (3 * kBcrThreads));        // (three entries per thread and round)
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N, std::max(1, std::min(rounds, 2048 / N))), dim3(kBcrThreads), 0, h->stream, h->nco, hb, cb, h->S,
+                       h->b, dmask, h->bcrD.p, h->bcrU.p, h->bcrF.p, info, (double*)nullptr);
   }
   struct Level { int s, cnt; size_t base; };
   std::vector<Level> levels;
