@@ -2310,8 +2310,8 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const bool dense_ok = 6 * h->nco <= kDcMaxN && force != SOLVER_LU;
   // wider than that: nodes that do not fit in LDS (ba_bcr_big.h), as long as there are a few of them to reduce over
   const int big_nodes = h->hb > kBcrwMaxHB ? (h->nco + big_node_cameras(h->hb) - 1) / big_node_cameras(h->hb) : 0;
-  // (measured at 1000 cameras: 13 nodes of 80 cameras 2.2 ms against the dense factorisation's 3.8 ms, 5 nodes of 200 cameras 7.7 against 6.5)
-  const bool big_ok = (force == SOLVER_BCR && big_nodes >= 4) || (force == SOLVER_AUTO && big_nodes >= (dense_ok ? 8 : 4));
+  // (measured at 1000 cameras: 13 nodes of 80 cameras 1.6 ms against the dense factorisation's 3.4 ms, 5 nodes of 200 cameras 5.1 against 6.3)
+  const bool big_ok = (force == SOLVER_BCR && big_nodes >= 4) || (force == SOLVER_AUTO && big_nodes >= (dense_ok ? 5 : 4));
   const bool use_big = big_ok;
   const bool use_dense = !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);

@@ -777,7 +777,7 @@ def test_big_node_cyclic_reduction_matches_lapack(be, nc, L):
     rng = np.random.RandomState(nc)
     mask = (rng.rand(be.nco * 6) > .1).astype(np.uint8)
     for m in (None, mask):
-        be.set_option('solver', 'auto' if nc >= 333 else 'bcr')        # (on its own from eight nodes on; 160 / 30: six)
+        be.set_option('solver', 'auto')
         be.solve_reduced(m)
         assert be.last_solve_kind == 'bcr_big' and be.last_solve_path == 'band'
         x = be.get_solution().reshape(-1)
