@@ -122,6 +122,9 @@ struct ba_handle {
   DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
   DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
   int nm3chunks = 0, nwgroups = 0;
+  DevBuf<int> wide_list;                // window groups of 25 .. 40 cameras (k_schur_wide_mfma, one workgroup each): indices into wgroups,
+  int nwide = 0;                        // by tiles per side: those of NT tiles are wide_list[wide_begin[NT - kGwMinTiles] .. wide_begin[NT - kGwMinTiles + 1])
+  int wide_begin[kGwMaxTiles - kGwMinTiles + 2] = {0};
   // tracks that span more than kGm3MaxSpan cameras: groups of k_schur_rect_mfma, one per pair of segments (A <= B) they touch
   DevBuf<RectGroup> rgroups;
   DevBuf<int> rtab;
@@ -1019,7 +1022,7 @@ int ba_destroy(ba_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
-  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->wgroups.release(); h->wtab.release(); h->cam_perm.release(); h->cam_units.release();
+  h->keep.release(); h->obs_z.release(); h->pt_opt.release(); h->units.release(); h->chunks.release(); h->groups.release(); h->mgroups.release(); h->gchunks.release(); h->mchunks.release(); h->m3chunks.release(); h->wide_list.release(); h->wgroups.release(); h->wtab.release(); h->cam_perm.release(); h->cam_units.release();
   for (int i = 0; i < 2; ++i) { h->cams[i].release(); h->X[i].release(); }
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
@@ -1399,7 +1402,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   std::vector<int> wtab;
   bool wgroups_worth = false;
   std::vector<RectGroup> rgroups;
-  std::vector<int> rtab;
+  std::vector<int> rtab, wide_list;
+  int wide_begin[kGwMaxTiles - kGwMinTiles + 2] = {0};
   int nlong_points = 0;
   {
     std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
@@ -1506,7 +1510,37 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
           wlo.push_back(lo); whi.push_back(hi);
         }
       }
-      const int nshort_groups = (int)wgroups.size();
+      // groups of 27 .. 40 cameras go through k_schur_wide_mfma (every observation linearised once): narrow ones first.  When the
+      // narrow ones are few beside them (tracks cut short by the end of the sequence), they go the same way - their own two to
+      // five launches of k_schur_groups_mfma3 would each last as long as one group
+      {
+        auto tiles = [&](int g) { return (6 * wgroups[g].W + 15) >> 4; };
+        long long pn = 0, pw = 0;
+        for (size_t g = 0; g < wgroups.size(); ++g) (tiles((int)g) >= kGwMinTiles ? pw : pn) += wgroups[g].pt_end - wgroups[g].pt_begin;
+        const bool all_wide = pw > 0 && 4 * pn <= pw;
+        auto cls = [&](int g) { return (tiles(g) >= kGwMinTiles || all_wide) ? std::max(tiles(g), kGwMinTiles) : 0; };      // 0: narrow
+        std::vector<int> order(wgroups.size());
+        for (size_t g = 0; g < order.size(); ++g) order[g] = (int)g;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cls(x) < cls(y); });
+        std::vector<WinGroup> wg2(wgroups.size());
+        std::vector<int> lo2(wgroups.size()), hi2(wgroups.size()), cl2(wgroups.size());
+        for (size_t g = 0; g < order.size(); ++g) { wg2[g] = wgroups[order[g]]; lo2[g] = wlo[order[g]]; hi2[g] = whi[order[g]]; cl2[g] = cls(order[g]); }
+        wgroups.swap(wg2); wlo.swap(lo2); whi.swap(hi2);
+        for (size_t g = 0; g < cl2.size(); ++g)
+          if (cl2[g] > 0) wide_list.push_back((int)g);
+        for (int t = kGwMinTiles; t <= kGwMaxTiles + 1; ++t) {      // wide_list is sorted by class: where class t begins
+          int n = 0;
+          for (size_t g = 0; g < cl2.size(); ++g) n += (cl2[g] > 0 && cl2[g] < t) ? 1 : 0;
+          wide_begin[t - kGwMinTiles] = n;
+        }
+      }
+      const int nshort_groups = (int)wgroups.size() - (int)wide_list.size();
+      if (nshort_groups > 0) {                              // the narrow groups' launches: as many tiles as THEY need
+        int wn = 1;
+        for (int g = 0; g < nshort_groups; ++g) wn = std::max(wn, wgroups[g].W);
+        gm3.nts = (6 * wn + 15) / 16;
+        gm3.Ld = 16 * gm3.nts;
+      }
       // points per group: a group is one serial chain of batches on one workgroup, and there are few long tracks - halve the
       // groups until they fill the chip twice (24 points at least: an epilogue of up to 144 tiles is paid per group)
       int rect_pts = kRectGroupPts;
@@ -1596,6 +1630,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     for (int g = c.begin; g < c.end; ++g) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(wgroups[g].W, gm3.np_cap) == kGmPts;
   h->wgroups_worth = wgroups_worth;
   h->nrgroups = (int)rgroups.size();
+  h->nwide = (int)wide_list.size();
+  std::memcpy(h->wide_begin, wide_begin, sizeof wide_begin);
   h->nlong_points = rgroups.empty() ? 0 : nlong_points;
   h->gm3 = gm3;
   h->groups_worth = groups_worth;
@@ -1617,6 +1653,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->pt_off.resize((size_t)nt + 1));
   HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
   HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
+  HIPCHECK(h, h->wide_list.resize(std::max<size_t>(1, wide_list.size())));
+  if (!wide_list.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->wide_list.p, wide_list.data(), wide_list.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->rgroups.resize(std::max<size_t>(1, rgroups.size())));
   HIPCHECK(h, h->rtab.resize(std::max<size_t>(1, rtab.size())));
   if (!rgroups.empty()) {
@@ -1860,7 +1899,7 @@ enum { KERN_PAIRS = 0, KERN_GROUPS, KERN_MFMA1, KERN_MFMA2, KERN_MFMA3, KERN_DEN
 int pick_schur_kernel(const ba_handle* h) {
   if (h->dense_mode && h->nt > 0 && h->nco > 0) return KERN_DENSE;
   const bool asc = h->groups_ascending && h->group_maxL >= 1;
-  const bool m3 = (h->nm3chunks > 0 && h->nwgroups > 0) || h->nrgroups > 0;           // window groups: no identical camera lists needed
+  const bool m3 = (h->nm3chunks > 0 && h->nwgroups > 0) || h->nrgroups > 0 || h->nwide > 0;           // window groups: no identical camera lists needed
   const bool m12 = asc && h->nmchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGmMaxL;      // the L <= 10 kernels
   const bool vec = h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGroupMaxL;
   switch (h->opt.schur) {
@@ -1914,6 +1953,30 @@ int launch_mfma3_set(ba_handle* h, const M3Launch& L, int p, double damping, boo
   if (rc == BA_OK && nts >= 15) rc = launch_mfma3<14, 15>(h, L, p, damping, fuse_cam, false);
   return rc;
 }
+// k_schur_wide_mfma<NT> over the window groups of NT tiles per side (25 .. 40 cameras)
+template <int NT>
+int launch_wide(ba_handle* h, int p, double damping, bool fuse_cam) {
+  const int g0 = h->wide_begin[NT - kGwMinTiles], n = h->wide_begin[NT - kGwMinTiles + 1] - g0;
+  if (n <= 0) return BA_OK;
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_wide_mfma<NT>));
+  hipLaunchKernelGGL(k_schur_wide_mfma<NT>, dim3(n), dim3(kGwBlock), schur_wide_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
+                     h->X[p].p, h->wgroups.p, h->wide_list.p + g0, h->wtab.p, h->opt_cam.p, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
+  return BA_OK;
+}
+int launch_wide_all(ba_handle* h, int p, double damping, bool fuse_cam) {
+  int rc = launch_wide<11>(h, p, damping, fuse_cam);
+  if (rc == BA_OK) rc = launch_wide<12>(h, p, damping, fuse_cam);
+  if (rc == BA_OK) rc = launch_wide<13>(h, p, damping, fuse_cam);
+  if (rc == BA_OK) rc = launch_wide<14>(h, p, damping, fuse_cam);
+  if (rc == BA_OK) rc = launch_wide<15>(h, p, damping, fuse_cam);
+  return rc;
+}
+int wide_launches(const ba_handle* h) {
+  int n = 0;
+  for (int t = 0; t <= kGwMaxTiles - kGwMinTiles; ++t) n += h->wide_begin[t + 1] > h->wide_begin[t] ? 1 : 0;
+  return n;
+}
+
 int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
   return launch_mfma3_set(h, M3Launch{h->gm3, h->m3chunks.p, h->nm3chunks, h->gm3_uniform_ks}, p, damping, fuse_cam);
 }
@@ -2138,9 +2201,13 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
                        h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
   } else if (kern == KERN_MFMA3) {
-    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, (h->nm3chunks ? mfma3_launches(h->gm3.nts) : 0) + (hybrid ? 1 : 0));
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, (h->nm3chunks ? mfma3_launches(h->gm3.nts) : 0) + (hybrid ? 1 : 0) + wide_launches(h));
     rc = launch_mfma3_all(h, p, damping, fuse_cam);
     if (rc != BA_OK) return rc;
+    if (h->nwide > 0) {
+      rc = launch_wide_all(h, p, damping, fuse_cam);
+      if (rc != BA_OK) return rc;
+    }
     if (hybrid) {
       HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_rect_mfma));
       hipLaunchKernelGGL(k_schur_rect_mfma, dim3(h->nrgroups), dim3(kRectBlock), schur_rect_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,

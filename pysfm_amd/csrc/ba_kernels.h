@@ -1786,6 +1786,219 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
 }
 
 // --------------------------------------------------------------------------
+// Window groups of 25 .. 40 cameras (NT = 10 .. 15 tiles per side, 55 .. 120 tiles): more accumulators than ONE consumer
+// wavefront holds, so k_schur_groups_mfma3 covers them with one launch per tile column, each linearising every observation
+// again (seven launches at W = 32).  Here ONE producer wavefront (the producer of k_schur_groups_mfma3: a lane keeps the
+// camera at its window column, NP = 64 / W points per batch) stages for SEVEN consumers that split the group's tiles among
+// themselves (column-major list of the tiles ti <= tj, ceil(T / 7) <= 18 consecutive ones each, operands read from LDS per
+// tile): one workgroup per group, every observation linearised once.  A template on the tiles per side (the host launches it
+// once per tile count that occurs): the consumer's loop over its tiles is straight-line code.  (Two producers and six
+// consumers: slower - the consumers are what bounds it.)  Epilogue: global atomics (the window of
+// such a group does not fit in LDS beside the staging).
+// --------------------------------------------------------------------------
+constexpr int kGw7 = 7;                                 // consumers
+constexpr int kGwBlock = 64 * (1 + kGw7);
+constexpr int kGwMinTiles = 11;                         // tiles per side from which a group comes here (10: five launches of k_schur_groups_mfma3 are faster, 0.68 against 0.90 ms at L = 25)
+constexpr int kGwMaxTiles = 15;
+constexpr int kGwLd = 16 * kGwMaxTiles;                 // staged row: 240 doubles
+constexpr int kGwK = 8;                                 // k rows per buffer (two points: 6 + 2 zero rows)
+__host__ __device__ constexpr int gw_own(int nts) { return (nts * (nts + 1) / 2 + kGw7 - 1) / kGw7; }      // tiles per consumer: 8 .. 18
+
+__host__ __device__ inline size_t schur_wide_lds_bytes() {
+  return (size_t)2 * kGwK * kGwLd * sizeof(double) + (size_t)2 * kGwK * sizeof(double) + (size_t)(64 + 8 + 128) * sizeof(int);
+}
+
+template <int NTS>
+__global__ __launch_bounds__(kGwBlock) void k_schur_wide_mfma(DevProblem P, const double* __restrict__ cams, const double* __restrict__ X,
+                                                              const WinGroup* __restrict__ groups, const int* __restrict__ glist,
+                                                              const int* __restrict__ wtab, const int* __restrict__ opt_cam,
+                                                              const double* __restrict__ fac, double* __restrict__ S,
+                                                              double* __restrict__ b, double damping, int fuse_cam) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  constexpr int BUF = kGwK * kGwLd;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* sU = dyn;                                            // [2][kGwK][kGwLd]
+  double* sD = sU + 2 * BUF;                                   // [2][kGwK]
+  int* sPos = reinterpret_cast<int*>(sD + 2 * kGwK);           // [64]
+  int* sFlag = sPos + 64;                                      // [8]: staged, consumed by each of the seven
+  int* sTile = sFlag + 8;                                      // [128]: tile q of the column-major list -> ti | tj << 8
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const WinGroup gr = groups[glist[blockIdx.x]];
+  const int L = gr.W;                                          // window columns (cameras lo .. lo + W - 1): 25 .. 40
+  const int NP = L <= 32 ? 2 : 1;                              // points per batch (a few narrower groups of a scene of wide ones come here too)
+  const int ks = NP == 2 ? 2 : 1;                              // k-steps of four rows per batch
+  constexpr int nts = NTS, T = nts * (nts + 1) / 2, OWN = gw_own(NTS);      // (6 L + 15) / 16 <= NTS for every group of this launch
+  for (int i = threadIdx.x; i < 2 * (BUF + kGwK); i += kGwBlock) sU[i] = 0.0;      // incl. sD and the zero rows
+  if (threadIdx.x < 8) sFlag[threadIdx.x] = 0;
+  if (threadIdx.x < 64) sPos[lane] = (lane < L && gr.lo + lane < P.nco) ? gr.lo + lane : -1;
+  if (threadIdx.x < 128) {
+    int q = threadIdx.x, tj = 0;
+    while (tj < nts && q > tj) { q -= tj + 1; ++tj; }          // column tj holds tiles ti = 0 .. tj
+    sTile[threadIdx.x] = tj < nts ? (q | tj << 8) : -1;
+  }
+  __syncthreads();
+  int* fStaged = sFlag;
+  int* fConsumed = sFlag + 1;
+  const int rowlen = (P.hb + 1) * 36;
+  const int nb = (gr.pt_end - gr.pt_begin + NP - 1) / NP;
+  if (wv == 0) {
+    const int slot = lane / L, oi = lane - slot * L;
+    const bool stager = lane < NP * L;
+    // a lane keeps ONE camera for the whole group - the one at its window column - and handles whichever points observe it
+    const int mypos = (stager && gr.lo + oi < P.nco) ? gr.lo + oi : -1;
+    const int c = opt_cam[mypos >= 0 ? mypos : gr.lo];
+    double cm[12];
+    load_cam(cams, c, cm);
+    double bacc[6] = {0, 0, 0, 0, 0, 0};
+    double hc[21];
+#pragma unroll
+    for (int q = 0; q < 21; ++q) hc[q] = 0.0;
+    struct PointIn { double x[3], f[9]; double2 z; int n; };
+    auto fetch = [&](int kb_, PointIn& in) {
+      const int k = kb_ + slot;
+      in.n = -1;
+      if (stager && k < gr.pt_end) {
+        in.n = mypos >= 0 ? wtab[gr.tab + (k - gr.pt_begin) * L + oi] : -1;      // this point's observation in my camera, if any
+        in.z = P.obs_z[in.n >= 0 ? in.n : 0];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) in.x[q] = X[3 * (size_t)k + q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) in.f[q] = fac[9 * (size_t)k + q];
+      }
+    };
+    PointIn nxt;
+    fetch(gr.pt_begin, nxt);
+    for (int ib = 0; ib < nb; ++ib) {
+      const int kb = gr.pt_begin + ib * NP;
+      const int np = min(NP, gr.pt_end - kb);
+      const PointIn cur = nxt;
+      fetch(kb + NP, nxt);
+      const bool live = stager && slot < np && cur.n >= 0;
+      double U[18];
+#pragma unroll
+      for (int q = 0; q < 18; ++q) U[q] = 0.0;                  // a short last batch, a point that does not see my camera: zero rows
+      if (live) {
+        double e[2], r[2], Jc[12], Jp[6], W[18];
+        obs_linearize(P.K, cm, cur.x, cur.z.x, cur.z.y, P.sensor, e, r, Jc, Jp);
+        block_W(Jc, Jp, W);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          U[a * 3] = W[a * 3] + cur.f[3] * W[a * 3 + 1] + cur.f[4] * W[a * 3 + 2];
+          U[a * 3 + 1] = W[a * 3 + 1] + cur.f[5] * W[a * 3 + 2];
+          U[a * 3 + 2] = W[a * 3 + 2];
+        }
+        if (mypos >= 0) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) bacc[a] -= W[a * 3] * cur.f[6] + W[a * 3 + 1] * cur.f[7] + W[a * 3 + 2] * cur.f[8];
+          if (fuse_cam) {                                       // HCC[i] += Jc^T Jc, b[i] += Jc^T r (k_camera_blocks' work)
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+              for (int c2 = a; c2 < 6; ++c2) hc[idx++] += Jc[a] * Jc[c2] + Jc[6 + a] * Jc[6 + c2];
+              bacc[a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+            }
+          }
+        }
+      }
+      // the buffer's previous batch (ib - 2) has been read by every consumer
+      for (;;) {
+        const int v = lane < kGw7 ? __hip_atomic_load(fConsumed + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+        if (__all(v >= ib - 1)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      double* mU = sU + (ib & 1) * BUF;
+      double* mD = sD + (ib & 1) * kGwK;
+      if (stager) {
+        const int so = 3 * slot * kGwLd + 6 * oi;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) mU[so + d * kGwLd + a] = U[a * 3 + d];
+        if (oi == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) mD[3 * slot + d] = slot < np ? cur.f[d] : 0.0;
+        }
+      }
+      gm2_post(fStaged, ib + 1, lane);                          // (k rows 3 NP .. 4 ks - 1 and their D stay zero: nobody writes them)
+    }
+    if (mypos >= 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) atomic_add_f64(b + (size_t)mypos * 6 + a, bacc[a]);
+      if (fuse_cam) {                                            // damped camera block onto the diagonal block (stored in full)
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c2 = a; c2 < 6; ++c2) {
+            const double v = a == c2 ? hc[idx] * (1.0 + damping) : hc[idx];
+            ++idx;
+            atomic_add_f64(S + (size_t)mypos * rowlen + a * 6 + c2, v);
+            if (a != c2) atomic_add_f64(S + (size_t)mypos * rowlen + c2 * 6 + a, v);
+          }
+        }
+      }
+    }
+  } else {
+    const int cw = wv - 1;
+    const int q0 = cw * OWN, cnt = max(0, min(OWN, T - q0));    // my tiles: q0 .. q0 + cnt - 1 (the last consumer: a few less; it forms tile 0 in their place)
+    int* mine = fConsumed + cw;
+    const int lr = lane & 15, lk = lane >> 4;
+    int tcode[OWN];                                             // (wave-uniform: scalar registers)
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) tcode[u] = __builtin_amdgcn_readfirstlane(u < cnt ? sTile[q0 + u] : 0);
+    mfma_acc acc[OWN];
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) acc[u] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+    for (int ib = 0; ib < nb; ++ib) {
+      gm2_wait(fStaged, ib + 1);
+      const double* mU = sU + (ib & 1) * BUF;
+      const double* mD = sD + (ib & 1) * kGwK;
+      for (int s4 = 0; s4 < ks; ++s4) {
+        const double dk = mD[4 * s4 + lk];
+        const double* row = mU + (4 * s4 + lk) * kGwLd + lr;
+        constexpr int CH = OWN > 15 ? OWN / 2 : OWN;            // operands of all my tiles at once, of half of them when 18 (registers)
+#pragma unroll
+        for (int u0 = 0; u0 < OWN; u0 += CH) {
+          double ta[CH], wb[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) { ta[u] = row[16 * (tcode[u0 + u] & 255)]; wb[u] = row[16 * (tcode[u0 + u] >> 8)]; }
+          if (s4 == ks - 1 && u0 + CH >= OWN) gm2_post(mine, ib + 1, lane);      // everything of this buffer is in registers
+#pragma unroll
+          for (int u = 0; u < CH; ++u) ta[u] *= dk;
+#pragma unroll
+          for (int u = 0; u < CH; ++u) acc[u0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[u], wb[u], acc[u0 + u], 0, 0, 0);
+        }
+      }
+    }
+    if (nb == 0) gm2_post(mine, 1, lane);
+    // ---- epilogue: C/D layout lane -> column n = 16 tj + lane % 16, register v -> row m = 16 ti + lane / 16 + 4 v;
+    // block (i, j), i <= j, at band row pos_i, offset (pos_j - pos_i) * 36 + a * 6 + c; diagonal blocks are stored in full
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) {
+      if (u >= cnt) continue;
+      const int ti = tcode[u] & 255, tj = tcode[u] >> 8;
+      const int n = 16 * tj + lr, j = n / 6, c = n - 6 * j;
+      const int pj = j < 64 ? sPos[j] : -1;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int m = 16 * ti + lk + 4 * v, i = m / 6, a = m - 6 * i;
+        const int pi = i < 64 ? sPos[i] : -1;
+        const bool both = pi >= 0 && pj >= 0;
+        const bool ok = both && (i < j || (i == j && a <= c));
+        const bool mirror = both && i == j && a < c;
+        const double val = -acc[u][v];
+        if (ok && val != 0.0) {
+          const size_t off = (size_t)pi * rowlen + (size_t)(pj - pi) * 36 + a * 6 + c;
+          atomic_add_f64(S + off, val);
+          if (mirror) atomic_add_f64(S + off + 5 * (c - a), val);
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // Tracks that span MORE cameras than the widest window of k_schur_groups_mfma3 (kGm3MaxSpan): their optimised positions are
 // cut along a grid of segments of kRectSeg = 32 positions (192 unknowns = 12 tiles), and what such a point adds to S is a sum
 // over the PAIRS (A <= B) of segments it touches:  S[A, B] -= U_A^T D U_B  with the staged operand U = W L per observation.
