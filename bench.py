@@ -125,7 +125,7 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     # the timer id 'schur_pairs' covers the interchangeable reduction kernels
-    names = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
+    names = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_wide_mfma', 'k_schur_rect_mfma', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
              'linearize': ['k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
              'point_invert': ['k_point_invert_schur_init', 'k_point_invert'],
              'bcr_eliminate': ['k_bcr_eliminate_split', 'k_bcr_eliminate']}.get(kernel, ['k_' + kernel])
@@ -284,12 +284,13 @@ OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config4_cauchy', 4, 'cauchy', .1, False, 0.),
     ('config3_shuffled', 3, 'gaussian', 0., True, 0.),
     ('config3_30pct_dropped', 3, 'gaussian', 0., False, .3),
+    ('config3_2pct_tracks_of_80_cameras', 3, 'gaussian', 0., False, 0., 10, (50, 80)),      # a few long tracks: pairs of 32-camera segments on the matrix cores, half-bandwidth 79
     ('config5_one_gpu', 5, 'gaussian', 0., False, 0.),
-    ('config3_track_length_32', 3, 'gaussian', 0., False, 0., 32),      # long tracks: windows of 32 cameras on the matrix cores, band-limited dense solve
+    ('config3_track_length_32', 3, 'gaussian', 0., False, 0., 32),      # long tracks: windows of 32 cameras on the matrix cores (k_schur_wide_mfma), cyclic reduction with 192-unknown nodes in device memory
 ]
 
 
-def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, track_len=10, steps=20, warmup=8, scene_cache=None):
+def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, track_len=10, long_tracks=None, steps=20, warmup=8, scene_cache=None):
     """`other_configs`: a short run of one of the other BASELINE configurations / scene shapes on this GPU, the same
     complete LM trial per step, timed the same way (no events in the timed window; the per-kernel numbers come from
     bracketed trials before it)."""
@@ -307,6 +308,8 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
         if scene_cache is not None:
             scene_cache.clear()                     # (one scene at a time: config 5 is 400 MB of host arrays)
             scene_cache[key] = s
+    if long_tracks:                                 # (every, length): every `every`-th point seen by `length` consecutive cameras
+        s = with_long_tracks(s, nc, nt, track_len, long_tracks[0], long_tracks[1])
     obs_cam, obs_pt, obs_z, X0 = scene_variant(s, track_len, shuffle, drop)
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
@@ -337,7 +340,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     pass_ms = sum(kms[k] for k in PASS_KERNELS if k in kms)
     info = be.problem_info()
     out = {'workload': 'BASELINE configs[%d]%s: %d cameras / %d points / %d observations, %s sensor model%s%s%s' % (
-               cfg_id - 1, '' if track_len == 10 else ' with track length %d' % track_len, nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
+               cfg_id - 1, ('' if track_len == 10 else ' with track length %d' % track_len) + ('' if not long_tracks else ' and every %d-th point seen by %d cameras' % tuple(long_tracks)), nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
                ', tracks and observations in random order' if shuffle else '',
                ', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * drop) if drop else ''),
            'init_mode': init_mode, 'steps': steps, 'warmup': warmup + 1, 'ms_per_step': 1e3 * dt / steps, 'obs_per_s': nobs * steps / dt,
@@ -399,7 +402,7 @@ def live_pmc_traffic(argv, kernels, timeout_s=150):
 
 
 # timer id -> kernel names (without template arguments) that run under it, most specific first
-PMC_KERNEL_NAMES = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
+PMC_KERNEL_NAMES = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_wide_mfma', 'k_schur_rect_mfma', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
                     'linearize': ['k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
                     'point_invert': ['k_point_invert_schur_init', 'k_point_invert'],
                     'bcr_eliminate': ['k_bcr_eliminate_fused', 'k_bcr_eliminate_split', 'k_bcr_eliminate'],

@@ -673,11 +673,14 @@ def test_bench_line_keeps_the_drivers_contract():
     assert isinstance(r['traffic_stale_possible'], bool) and (r['traffic_source'] == 'live') != r['traffic_stale_possible'] or r['traffic'] is None
     # the other BASELINE configurations and scene shapes, driver-visible: a short run each
     oc = d['other_configs']
-    for name in ('config2', 'config4_huber', 'config4_cauchy', 'config3_shuffled', 'config3_30pct_dropped', 'config5_one_gpu', 'config3_track_length_32'):
+    for name in ('config2', 'config4_huber', 'config4_cauchy', 'config3_shuffled', 'config3_30pct_dropped', 'config3_2pct_tracks_of_80_cameras', 'config5_one_gpu', 'config3_track_length_32'):
         assert 'error' not in oc[name], oc[name]
         assert oc[name]['ms_per_step'] > 0 and oc[name]['dominant_kernel'] and 0 < oc[name]['linearise_schur_pass_fraction_of_kernel_time'] < 1
     assert oc['config5_one_gpu']['ms_per_step'] < 3.0 and oc['config2']['ms_per_step'] < oc['config4_huber']['ms_per_step']
-    assert oc['config3_track_length_32']['ms_per_step'] < 8.0 and oc['config3_track_length_32']['schur_kernel'] == 4      # (the matrix cores, not the pair kernel)
+    # wide bands: the matrix cores (not the pair kernel) and the cyclic reduction with nodes in device memory (not the dense Cholesky)
+    assert oc['config3_track_length_32']['ms_per_step'] < 3.0 and oc['config3_track_length_32']['schur_kernel'] == 4 and oc['config3_track_length_32']['solve_kind'] == 'bcr_big'
+    lt = oc['config3_2pct_tracks_of_80_cameras']
+    assert lt['ms_per_step'] < 4.0 and lt['schur_kernel'] == 4 and lt['half_bandwidth'] == 79 and lt['solve_kind'] == 'bcr_big'
     assert d['config']['init_mode'] in ('params', 'pose') and d['lm_other_start']['init_mode'] != d['config']['init_mode']
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and isinstance(c['sample'], str) and c['unit'] == d['unit']
