@@ -226,7 +226,7 @@ namespace {
 hipEvent_t get_event(ba_handle* h) {
   if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);      // (timing only: nobody reads memory on the strength of these events; the system-scope fence of a default event costs the stream ~20 us)
   return e;
 }
 
