@@ -548,6 +548,44 @@ def test_ranks_on_one_gpu_config5_shape(tmp_path, world, shuffle, dist_solve, ma
     ba.backend.close()
 
 
+# ------------------------------------------------------------------ wide bands through the whole LM loop
+@pytest.mark.parametrize('nc,nt,L,long_every,long_len,sensor', [
+    (200, 1500, 30, 0, 0, 'gaussian'),           # windows of 30 cameras (k_schur_wide_mfma), 7 nodes of 30 cameras (ba_bcr_big.h)
+    (300, 4200, 10, 25, 70, 'cauchy'),           # 4 % of the tracks seen by 70 cameras (k_schur_rect_mfma beside the window groups), hb = 69: 5 nodes
+])
+def test_lm_on_wide_band_scenes_follows_the_oracle(nc, nt, L, long_every, long_len, sensor):
+    """BundleAdjuster.optimize on scenes whose tracks span 30 / 70 cameras - reduction through the wide-window and the
+    segment-pair kernels, reduced solve through the cyclic reduction with nodes in device memory - against the oracle's LM
+    loop: the same accept / reject sequence, accepted costs to 1e-6, the same final parameters."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    from test_gpu_parity import _with_long_tracks
+    s = banded(nc, nt, track_len=L, init_mode='params')
+    cam, pt, z = (s['obs_cam'], s['obs_pt'], s['obs_z']) if not long_every else _with_long_tracks(s, nc, nt, long_every, long_len, holes=.15)
+    flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
+    sen = O.Sensor.gaussian(1.) if sensor == 'gaussian' else O.Sensor.cauchy(.05)
+    model = sensor_model.GaussianModel(1.) if sensor == 'gaussian' else sensor_model.CauchyModel(.05)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z, sensor_model=model)
+    ba = BundleAdjuster(b, verbose=False)
+    steps = 6
+    ba.optimize(max_steps=steps, init_damping=10.)
+    info = ba.backend.problem_info()
+    assert info['schur_kernel'] == 4 and ba.backend.last_solve_kind == 'bcr_big'
+    assert ba.backend.half_bandwidth == (L - 1 if not long_every else long_len - 1)
+    trace = []
+    ref = O.lm_optimize(sen, s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z, *flags, max_steps=steps, init_damping=10., trace=trace)
+    got = [(d, 'accepted' if o == 'accepted' else 'rejected') for d, o, c in ba.trial_log]
+    want = [(tr['damping'], 'accepted' if tr['next'] < tr['cur'] else 'rejected') for tr in trace]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[1] == w[1] and abs(g[0] - w[0]) <= 1e-12 * w[0], (got, want)
+    assert ba.num_steps == ref['num_steps'] and ba.converged == ref['converged']
+    close(np.array(ba.costs), np.array(ref['costs']), 1e-6)
+    out = ba.bundle
+    close(out.ts(), ref['t'], 1e-6, 1e-8)
+    close(out.reconstruction, ref['X'], 1e-6, 1e-8)
+    ba.backend.close()
+
+
 # ------------------------------------------------------------------ LU semantics beyond the fallback size
 def test_large_reduced_systems_follow_the_reference_lu_trajectory():
     """More unknowns than the LU fallback takes (400 cameras: 2394 > backend.LU_FALLBACK_MAX_UNKNOWNS): the reference solves
