@@ -1265,19 +1265,21 @@ def _with_long_tracks(s, nc, nt, every, Llong, seed=3, holes=0.):
     return np.concatenate(cam).astype(np.int32), np.concatenate(pt).astype(np.int32), np.concatenate(z)
 
 
-@pytest.mark.parametrize('nc,nt,every,Llong,holes,sensor', [
-    (300, 6000, 40, 60, 0., O.Sensor.gaussian(1.)),
-    (300, 6000, 40, 140, 0., O.Sensor.cauchy(.05)),
-    (300, 6000, 7, 75, .4, O.Sensor.gaussian(1.)),            # many of them, with holes
-    (150, 1200, 1, 50, .2, O.Sensor.cauchy(.05)),             # nothing but long tracks
-    (83, 900, 1, 83, .5, O.Sensor.gaussian(1.)),              # ... every one of them over all cameras (a short last segment)
+@pytest.mark.parametrize('nc,nt,every,Llong,holes,sensor,L', [
+    (300, 6000, 40, 60, 0., O.Sensor.gaussian(1.), 10),
+    (300, 6000, 40, 140, 0., O.Sensor.cauchy(.05), 10),
+    (300, 6000, 7, 75, .4, O.Sensor.gaussian(1.), 10),            # many of them, with holes
+    (150, 1200, 1, 50, .2, O.Sensor.cauchy(.05), 10),             # nothing but long tracks
+    (83, 900, 1, 83, .5, O.Sensor.gaussian(1.), 10),              # ... every one of them over all cameras (a short last segment)
+    (300, 3000, 20, 90, .1, O.Sensor.cauchy(.05), 30),            # beside tracks of 30 cameras: wide window groups (k_schur_wide_mfma) + pairs of segments
+    (260, 4000, 30, 64, 0., O.Sensor.gaussian(1.), 18),           # beside tracks of 18 cameras: three launches of k_schur_groups_mfma3 + pairs of segments
 ])
-def test_long_tracks_stay_on_the_matrix_cores(be, nc, nt, every, Llong, holes, sensor):
+def test_long_tracks_stay_on_the_matrix_cores(be, nc, nt, every, Llong, holes, sensor, L):
     """Tracks that span more than the widest window of the matrix-core reduction (40 cameras): their cameras are cut along
     segments of 32 positions - inside a segment they are members of a window group (a point list), between two segments
     k_schur_rect_mfma forms the rectangular products.  S, b, the solve and the whole trial against the oracle, and against
     the pair kernel alone."""
-    s = banded(nc, nt)
+    s = banded(nc, nt, track_len=L)
     cam, pt, z = _with_long_tracks(s, nc, nt, every, Llong, holes=holes)
     flags = default_flags(nc, nt)
     a = (s['K'], s['R0'], s['t0'], s['X0'], cam, pt, z)
