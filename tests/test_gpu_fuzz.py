@@ -1,4 +1,4 @@
-"""Randomised parity sweep: seeded scenes of random shape (cameras, track length 2 ... 24, ragged tracks, frozen cameras
+"""Randomised parity sweep: seeded scenes of random shape (cameras, track length 2 ... 40, a few tracks of 45 ... 120 cameras, ragged tracks, frozen cameras
 anywhere, tracks that are not optimised, masked camera parameters, tracks and observations in random order, all three
 sensor models) through the C ABI against the CPU oracle - the net under the internal point order, the general
 matrix-core reduction and the split-node cyclic reduction, whose work lists depend on the shape of the scene.
@@ -22,7 +22,11 @@ def be():
 
 def make_case(seed):
     rs = np.random.RandomState(1000 + seed)
-    if seed < 60:
+    long_tracks = seed >= 72                               # a few tracks that span 45 .. 120 cameras beside the others (round 3): pairs of segments
+    if long_tracks:
+        L = int(rs.choice([5, 10, 12, 18, 30]))
+        nc = int(rs.randint(200, 320))
+    elif seed < 60:
         L = int(rs.choice([2, 3, 5, 7, 9, 10, 11, 12, 13, 15, 16, 17, 19, 21, 24]))
         nc = int(rs.randint(max(L + 3, 12), 90))
     else:                                                  # long tracks (round 3): windows of 25 .. 40 cameras
@@ -30,10 +34,19 @@ def make_case(seed):
         nc = int(rs.randint(5 * L, 6 * L))
     if L >= 22:
         nc = max(nc, 100)                                  # (sparse enough not to be taken for a dense-visibility scene)
-    nt = int(rs.randint(60, 1500))
+    nt = int(rs.randint(60, 1500)) if not long_tracks else int(rs.randint(14 * nc, 20 * nc))
     s = banded(nc, nt, track_len=L, outlier_frac=float(rs.choice([0., .05])), seed=int(rs.randint(1, 10000)))
-    keep = rs.rand(len(s['obs_cam'])) >= float(rs.choice([0., .1, .35]))          # ragged tracks
-    if rs.rand() < .5 and L >= 4:                                                  # tracks of different lengths that start anywhere
+    if long_tracks:
+        from test_gpu_parity import _with_long_tracks
+        cam, pt, z = _with_long_tracks(s, nc, nt, int(rs.choice([9, 25, 60])), int(rs.randint(45, 121)), seed=seed, holes=float(rs.choice([0., .2, .5])))
+        keep = rs.rand(len(cam)) >= float(rs.choice([0., .1]))                     # ragged tracks (every track keeps its first observation)
+        keep[np.unique(pt, return_index=True)[1]] = True
+        s = dict(s, obs_cam=cam, obs_pt=pt, obs_z=z)
+    else:
+        keep = rs.rand(len(s['obs_cam'])) >= float(rs.choice([0., .1, .35]))      # ragged tracks
+    if long_tracks:
+        pass
+    elif rs.rand() < .5 and L >= 4:                                                # tracks of different lengths that start anywhere
         a0 = rs.randint(0, L - 1, nt)
         b0 = np.minimum(L, a0 + rs.randint(2, L + 1, nt))
         j = np.arange(len(s['obs_cam'])) % L
@@ -71,7 +84,7 @@ def make_case(seed):
 KERNELS_SEEN = set()
 
 
-@pytest.mark.parametrize('seed', range(72))
+@pytest.mark.parametrize('seed', range(84))
 def test_random_scene_full_step_vs_oracle(be, seed):
     c = make_case(seed)
     a, cp, po, sensor = c['a'], c['cam_opt_pos'], c['pt_opt'], c['sensor']
