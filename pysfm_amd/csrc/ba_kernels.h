@@ -2495,7 +2495,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
 // formed once per group per lane, the updated point comes from the point's first lane through LDS.
 // Partials and status words go where k_cost puts them (one partial per workgroup, <= kCostBlocks).
 #ifndef BA_BACKSUB_WAVES
-#define BA_BACKSUB_WAVES 4
+#define BA_BACKSUB_WAVES 3      // 168 VGPRs, 12 bytes of scratch per lane; with the next batch's inputs in flight: 27.5 us at config 3 (4 waves: 164 bytes of scratch per lane, 45 us; 2 waves: 35 us; without the prefetch 4 waves were best: 31.2 us)
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKSUB_WAVES, BA_BACKSUB_WAVES))) void k_backsub_groups(DevProblem P, const double* __restrict__ cams,
                                                            const double* __restrict__ X,
@@ -2549,14 +2549,34 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
 #pragma unroll
     for (int a = 0; a < 6; ++a) d[a] = pos >= 0 ? dC[(size_t)pos * 6 + a] : 0.0;
     double (*px)[4] = spx[wv];
+    // the inputs of the NEXT batch are in flight while this one is worked on (a wavefront walks its group batch by batch,
+    // about one wavefront per SIMD: without this every batch pays a trip to memory); what the end of a batch needs -
+    // bP, HPPinv - is asked for at its beginning
+    struct PointIn { double2 z; double x[3]; };
+    auto fetch = [&](int kb_, PointIn& in) {
+      const int k = kb_ + slot;
+      if (stager && k < gr.pt_end) {
+        in.z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) in.x[q] = X[3 * (size_t)k + q];
+      }
+    };
+    PointIn nxt;
+    fetch(gr.pt_begin, nxt);
     for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
       const int k = kb + slot;
       const bool live = stager && k < gr.pt_end;
+      const PointIn cur = nxt;
+      fetch(kb + NP, nxt);
+      const double bpv = (live && oi < 3) ? bP[3 * (size_t)k + oi] : 0.0;
+      double A[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) A[i] = (live && oi == 0) ? HPPinv[6 * (size_t)k + i] : 0.0;
       double x[3] = {0, 0, 0}, loc[3] = {0, 0, 0};
       if (live) {
-        x[0] = X[3 * (size_t)k]; x[1] = X[3 * (size_t)k + 1]; x[2] = X[3 * (size_t)k + 2];
+        x[0] = cur.x[0]; x[1] = cur.x[1]; x[2] = cur.x[2];
         if (pos >= 0) {                                  // frozen cameras contribute nothing (bundle_adjuster.py:316-331)
-          const double2 z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
+          const double2 z = cur.z;
           double e[2], r[2], Jc[12], Jp[6];
           obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
           double v0 = 0.0, v1 = 0.0;
@@ -2573,14 +2593,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
       if (live) {                                        // lane q of a point adds component q of its L terms
         for (int q = oi; q < 3; q += L) {
           const double sum = lds_sum_in_order(&mx[q][slot * L], L);
-          mw[q][slot] = bP[3 * (size_t)k + q] - sum;
+          mw[q][slot] = (q == oi ? bpv : bP[3 * (size_t)k + q]) - sum;      // (L < 3: a lane adds more than one component)
         }
       }
       lds_wave_sync();
       if (live && oi == 0) {
-        double A[6], v[3], out[3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) A[i] = HPPinv[6 * (size_t)k + i];
+        double v[3], out[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) v[i] = mw[i][slot];
         sym3_apply(A, v, out);
@@ -2606,10 +2624,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
 #pragma unroll
       for (int a = 0; a < 6; ++a) ds[a] = sign * d[a];
       camera_perturb(cm, ds, cmn);
+      double2 zn = (stager && gr.pt_begin + slot < gr.pt_end) ? P.obs_z[n0 + (size_t)slot * L] : double2{0.0, 0.0};
       for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
         const int k = kb + slot;
+        const double2 z = zn;
+        if (stager && k + NP < gr.pt_end) zn = P.obs_z[n0 + (size_t)(k + NP - gr.pt_begin) * L];
         if (stager && k < gr.pt_end && px[k - gr.pt_begin][3] != 0.0) {
-          const double2 z = P.obs_z[n0 + (size_t)(k - gr.pt_begin) * L];
           const double xn[3] = {px[k - gr.pt_begin][0], px[k - gr.pt_begin][1], px[k - gr.pt_begin][2]};
           double e[2], r[2];
           obs_residual(P.K, cmn, xn, z.x, z.y, P.sensor, e, r);
