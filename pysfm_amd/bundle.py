@@ -251,11 +251,14 @@ class Bundle(object):
         if len(tids) * 4 < len(self.tracks) and len(trk):
             # few of many tracks (the sliding-window caller: 100 of 1000, window after window): only their rows of the
             # table (sorted by track) instead of a pass over all of it
-            off = getattr(self, '_track_offsets', None)
+            # (the offsets are cached only beside the immutable table of an array-native bundle: a bundle of Track objects
+            # can be edited between calls - a measurement moved to another track keeps every count this cache could check)
+            off = getattr(self, '_track_offsets', None) if self._table is not None else None
             if off is None or len(off) != len(self.tracks) + 1 or off[-1] != len(trk):
                 off = np.zeros(len(self.tracks) + 1, np.int64)
                 np.cumsum(np.bincount(trk, minlength=len(self.tracks)), out=off[1:])
-                self._track_offsets = off
+                if self._table is not None:
+                    self._track_offsets = off
             cnt = off[tids + 1] - off[tids]
             rows = np.repeat(off[tids] - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(int(cnt.sum()))
             ci, ti, zz = cpos[cam[rows]], np.repeat(np.arange(len(tids)), cnt), z[rows]

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(1024) void k_big_backsolve(int N, int B, int s, con
   }
   __syncthreads();
   // w = y_f - [Y_a^T; Y_c^T]^T x: thread groups over the 2 B rows of K below L, lanes along a row
-  const int cols = (B + 63) & ~63, ng = max(1, 1024 / cols), g = tid / cols, k = tid - g * cols;
-  for (int k0 = 0; k0 < B; k0 += cols) {                             // (one round unless B > 1024)
+  // (B > 1024, half-bandwidths from 171: rounds of 1024 columns, one thread group)
+  const int cols = min((B + 63) & ~63, 1024), ng = max(1, 1024 / cols), g = tid / cols, k = tid - g * cols;
+  for (int k0 = 0; k0 < B; k0 += cols) {
     double acc = 0.0;
     const bool mine = g < ng && k0 + k < B;
     if (mine) {

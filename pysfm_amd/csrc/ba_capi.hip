@@ -2379,7 +2379,19 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const int big_nodes = h->hb > kBcrwMaxHB ? (h->nco + big_node_cameras(h->hb) - 1) / big_node_cameras(h->hb) : 0;
   // (measured at 1000 cameras: 13 nodes of 80 cameras 1.6 ms against the dense factorisation's 3.4 ms, 5 nodes of 200 cameras 5.1 against 6.3)
   const bool big_ok = (force == SOLVER_BCR && big_nodes >= 4) || (force == SOLVER_AUTO && big_nodes >= (dense_ok ? 5 : 4));
-  const bool use_big = big_ok;
+  // ... and as long as their workspace (72 N B^2 bytes of K, 16 N B^2 of D and U) fits the device: otherwise the dense
+  // factorisation, or - too large for that as well - *info = -1 (not a hard allocation error)
+  bool use_big = big_ok;
+  if (use_big) {
+    const size_t cb = big_node_cameras(h->hb), B = 6 * cb, N = big_nodes;
+    const size_t need = (N * big_matrix_doubles((int)B) + 2 * N * B * B + N * B) * sizeof(double);
+    const size_t have = (h->bigK.n + h->bcrD.n + h->bcrU.n + h->bcrF.n) * sizeof(double);
+    if (need > have) {
+      size_t free_b = 0, total_b = 0;
+      HIPCHECK(h, hipSetDevice(h->device));
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need - have > free_b - free_b / 16) use_big = false;
+    }
+  }
   const bool use_dense = !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);
   const bool use_bcrw = !use_dense && !use_bcr && (force ? (force == SOLVER_BCR && bcrw_ok) : bcrw_ok);
@@ -2812,9 +2824,7 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
     for (int i = 0; i < kCostBlocks; ++i) sum += h->comm_host[i];
     *next_cost = sum;
     st[0] = (int)std::llround(h->comm_host[kCostBlocks]);                          // over all shards
-    // every rank solves the same system (status x ranks) - or, with the solve spread over the ranks, its own part of it
-    st[1] = dist ? (h->comm_host[kCostBlocks + 1] != 0.0 ? (int)std::min(2.0e9, std::max(1.0, std::fabs(h->comm_host[kCostBlocks + 1]))) : 0)
-                 : (int)std::llround(h->comm_host[kCostBlocks + 1] / h->comm_ranks);
+    st[1] = trial_status_of_sum(h->comm_host[kCostBlocks + 1], h->comm_ranks, dist);      // (a time-out on any rank stays a time-out)
   } else {
     HIPCHECK(h, hipStreamSynchronize(h->stream));    // k_cost left the cost partials + status words in pinned memory
     st[0] = h->host_result->singular_points; st[1] = h->host_result->solve_info;

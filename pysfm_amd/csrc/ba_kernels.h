@@ -156,6 +156,18 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtom
 // --------------------------------------------------------------------------
 constexpr int kCostBlocks = 2048;
 struct HostResult { int singular_points; int solve_info; double partial[kCostBlocks]; };
+// The solver status as it travels in the shards' trial record, which is SUMMED over the ranks: a time-out (a fault, never a
+// property of the matrix) must still be recognisable after the sum, so it weighs more than any sum of pivot indices can.
+constexpr double kTrialTimedOutWord = 1099511627776.0;      // 2^40 > ranks * 2^31
+__host__ __device__ inline double trial_status_word(int solve_info) { return solve_info == 0x7f000001 ? kTrialTimedOutWord : (double)solve_info; }
+__host__ __device__ inline int trial_status_of_sum(double sum, int ranks, bool own_parts) {
+  if (sum >= kTrialTimedOutWord) return 0x7f000001;
+  if (sum == 0.0) return 0;
+  // every rank solved the same system (status x ranks) - or, with the solve spread over the ranks, its own part of it: any non-zero = failed
+  const double v = own_parts ? fabs(sum) : sum / ranks;
+  const double c = v < 1.0 ? (own_parts ? 1.0 : v) : (v > 2.0e9 ? 2.0e9 : v);
+  return (int)(c + (c >= 0 ? 0.5 : -0.5));
+}
 
 __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __restrict__ cams,
                                                  const double* __restrict__ X,
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __r
     if (blockIdx.x == 0) {
       host->singular_points = *singular_points;
       host->solve_info = *solve_info;
-      if (dev_result) { dev_result[kCostBlocks] = (double)*singular_points; dev_result[kCostBlocks + 1] = (double)*solve_info; }
+      if (dev_result) { dev_result[kCostBlocks] = (double)*singular_points; dev_result[kCostBlocks + 1] = trial_status_word(*solve_info); }
     }
   }
   if (dev_result && blockIdx.x == 0)                     // the sharded adjuster sums ALL kCostBlocks entries
@@ -2652,7 +2664,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
     if (blockIdx.x == 0) {
       host->singular_points = *singular_points;
       host->solve_info = *solve_info;
-      if (dev_result) { dev_result[kCostBlocks] = (double)*singular_points; dev_result[kCostBlocks + 1] = (double)*solve_info; }
+      if (dev_result) { dev_result[kCostBlocks] = (double)*singular_points; dev_result[kCostBlocks + 1] = trial_status_word(*solve_info); }
     }
   }
   if (dev_result && blockIdx.x == 0)                     // the sharded adjuster sums ALL kCostBlocks entries

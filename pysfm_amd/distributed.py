@@ -98,6 +98,24 @@ def _stream_of(backend):
     return ctx() if ctx is not None else contextlib.nullcontext()
 
 
+TRIAL_TIMED_OUT_WORD = float(1 << 40)      # kTrialTimedOutWord of csrc/ba_kernels.h
+
+
+def trial_status_of_sum(total, world, own_parts):
+    """Solver status from the status word of the shards' trial records after their SUM over the ranks (csrc/ba_kernels.h
+    trial_status_of_sum): a rank whose solve timed out wrote 2^40 instead of its status, more than any sum of pivot indices,
+    so a time-out stays a time-out (SOLVE_TIMED_OUT) instead of turning into a pivot index.  Otherwise every rank solved the
+    same system (total / world) or, with the solve spread over the ranks (own_parts), its own part: any non-zero = failed."""
+    from ._capi import SOLVE_TIMED_OUT
+    if total >= TRIAL_TIMED_OUT_WORD:
+        return SOLVE_TIMED_OUT
+    if total == 0:
+        return 0
+    if own_parts:
+        return int(round(max(1., min(2e9, abs(total)))))
+    return int(round(total / world))
+
+
 class ShardComm(object):
     """The collectives the sharded adjuster needs, over torch.distributed
     ('nccl' = RCCL on ROCm for GPU tensors, 'gloo' for the CPU tests)."""
@@ -222,12 +240,7 @@ class ShardComm(object):
                 torch.cuda.current_stream().synchronize()
         h = self._trial_host.numpy()
         world = self._dist.get_world_size(self.group)
-        status = h[npartials + 1]
-        if getattr(backend, 'dist_on', False):          # every rank reports on its own part of the solve: any non-zero = failed
-            status = 0 if status == 0 else max(1., min(2e9, abs(status)))
-        else:
-            status = status / world
-        return float(h[:npartials].sum()), int(round(h[npartials])), int(round(status))
+        return float(h[:npartials].sum()), int(round(h[npartials])), trial_status_of_sum(h[npartials + 1], world, getattr(backend, 'dist_on', False))
 
     def _all_reduce_device(self, t):
         """Sum a device tensor over the ranks in place.  RCCL does it on the device; a gloo group (the

@@ -761,10 +761,11 @@ def test_dense_cholesky_on_the_device_matches_lapack(be, nc, L):
         assert np.abs(x - ref).max() <= 1e-9 * max(1., np.abs(ref).max())
 
 
-@pytest.mark.parametrize('nc,L', [(160, 30), (400, 26), (333, 41), (700, 33), (217, 25), (600, 81)])
+@pytest.mark.parametrize('nc,L', [(160, 30), (400, 26), (333, 41), (700, 33), (217, 25), (600, 81), (900, 175), (1000, 200)])
 def test_big_node_cyclic_reduction_matches_lapack(be, nc, L):
     """Half-bandwidths beyond 23 (tracks of 25 and more cameras) with at least four nodes of hb cameras: ba_bcr_big.h - every
-    level a batched partial dense Cholesky of one 3B x 3B matrix per eliminated node (B = 150 .. 480 here; node counts that
+    level a batched partial dense Cholesky of one 3B x 3B matrix per eliminated node (B = 150 .. 480 and, nodes wider than one
+    round of the back-substitution's 1024 threads, B = 1044 and 1200; node counts that
     are and are not powers of two, a padded last node, hb odd and even).  Against LAPACK on the same system and against the
     dense blocked Cholesky, with and without deleted camera parameters; the status word of a system that is not positive
     definite."""
