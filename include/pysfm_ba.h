@@ -69,7 +69,7 @@ const char* ba_last_error(const ba_handle* h);
 int ba_set_stream(ba_handle* h, void* hip_stream);
 int ba_synchronize(ba_handle* h);
 /* Test / measurement switches; the defaults are the product path and the library never reads the environment.
- *   "schur"         auto | pairs | groups | mfma1 | mfma2 | mfma   force a Schur-reduction kernel (falls back to pairs when not applicable)
+ *   "schur"         auto | pairs | groups | mfma2 | mfma   force a Schur-reduction kernel (falls back to pairs when not applicable)
  *   "lds_window"    1 | 0                                  LDS accumulation window of the matrix-core reduction (0: global atomics only)
  *   "fast_paths"    1 | 0                                  short cuts of the per-observation arithmetic for K = I and the unit Gaussian
  *                                                          sensor model (the reference's defaults); 0: the general formulas always
@@ -78,7 +78,7 @@ int ba_synchronize(ba_handle* h);
  *   "solver"        auto | bcr | band | dense | lu | bcr1  force the reduced solver (lu: always report -1 = caller's LU; bcr1: the
  *                                                          cyclic reduction with one compute unit per node instead of three)
  *   "point_kernels" auto | v1                              lanes-per-point k_linearize / k_backsub instead of the group-packed ones
- *   "fuse_cost" "fuse_cam" "fuse_lin"   1 | 0              pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1, 0)
+ *   "fuse_cost" "fuse_cam"   1 | 0                         pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1)
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
  *   "gm_cap"        n                                      points per group of the MFMA reduction (0 = automatic)
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)

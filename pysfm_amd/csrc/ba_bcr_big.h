@@ -26,7 +26,6 @@ namespace ba {
 
 constexpr int kBigSlack = 16;        // entries right of the diagonal that the trailing update reads (16 x 16 sub-tiles)
 
-__host__ __device__ inline size_t big_matrix_doubles(int B) { return (size_t)(3 * B + 1) * (3 * B); }
 __host__ __device__ inline size_t big_backsolve_lds_bytes(int B) { return dense_backsolve_lds_bytes(B) + (size_t)2 * B * sizeof(double); }
 
 // K of every node eliminated at stride s: blockIdx.y = k (node i = s (2 k + 1) - 1), matrices batch_stride doubles apart.

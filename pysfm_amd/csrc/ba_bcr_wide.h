@@ -14,12 +14,10 @@
 // (The first form of the solve, one lane per right-hand side with L through scalar loads, took 442 us per level.)
 #pragma once
 
-#include "ba_bcr.h"
+#include "ba_bcr_blocks.h"
 
 namespace ba {
 
-constexpr int kBcrwMinHB = kBcrMaxHB + 1;
-constexpr int kBcrwMaxHB = 23;                 // B = 138: one B x (B+1) fp64 matrix = 150 KB of the 160 KB LDS (track length 24)
 constexpr int kBcrwLvLdsMaxB = 126;            // up to here the inverses of the diagonal blocks sit in LDS next to L; beyond, in L2
 
 __host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16 + 192 + kBcrIdtDoubles) * sizeof(double); }

@@ -20,7 +20,7 @@
 // 2 launches per block column: n = 594 (100 cameras) is 25 launches.
 #pragma once
 
-#include "ba_bcr.h"
+#include "ba_bcr_blocks.h"
 
 namespace ba {
 
@@ -32,7 +32,6 @@ constexpr int kDcRows = BA_DC_ROWS;            // panel rows per workgroup
 constexpr int kDcLd = kDcNB + 1;
 constexpr int kDcM = kDcNB + kDcRows + 16;     // LDS rows: diagonal block + panel rows + one tile of slack for the MFMA reads
 constexpr int kDcTile = 64;
-constexpr int kDcMaxN = 16000;                 // k_dense_backsolve keeps w[n] in LDS
 
 __host__ __device__ inline size_t dense_panel_lds_bytes() { return ((size_t)kDcM * kDcLd + kDcNB + 8 + 192 + kBcrIdtDoubles) * sizeof(double); }
 __host__ __device__ inline size_t dense_backsolve_lds_bytes(int n) {

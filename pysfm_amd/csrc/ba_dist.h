@@ -25,7 +25,7 @@
 // the g top ones are replicated work.  The kernels here only move data between the library's arrays and the exchange buffer.
 #pragma once
 
-#include "ba_kernels.h"
+#include "ba_device.h"
 
 namespace ba {
 

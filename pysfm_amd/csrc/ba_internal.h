@@ -1,0 +1,330 @@
+// ba_internal.h - what the translation units of libpysfm_ba.so share on the HOST side: the opaque handle behind the C ABI of
+// include/pysfm_ba.h, its device buffers, the option table, error / timing helpers, and the few functions one unit offers
+// the others.  Kernels live in the *_kernels.h / ba_bcr*.h / ba_dense.h / ba_band.h / ba_dist.h headers, each of which is
+// included by exactly one unit (the Makefile builds the units in parallel).
+#pragma once
+
+#include "../../include/pysfm_ba.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ba_types.h"
+
+#include <rccl/rccl.h>     // types only: the entry points are resolved at run time from the librccl torch has loaded
+
+namespace ba {
+
+extern thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t resize(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct TimedLaunch { int id; hipEvent_t a, b; int count; };
+
+// Test / measurement switches (ba_set_option).  The defaults are the product path; nothing in the library
+// reads the environment.
+enum { SCHUR_AUTO = 0, SCHUR_PAIRS, SCHUR_GROUPS, SCHUR_MFMA2, SCHUR_MFMA };
+enum { SOLVER_AUTO = 0, SOLVER_BCR, SOLVER_BAND, SOLVER_DENSE, SOLVER_LU, SOLVER_BCR1 };
+struct Options {
+  int schur = SCHUR_AUTO;
+  int solver = SOLVER_AUTO;
+  bool point_kernels_v1 = false;   // lanes-per-point k_linearize / k_backsub instead of the group-packed kernels
+  bool fuse_cost = true;           // trial cost inside k_backsub_groups
+  bool fuse_cam = true;            // camera blocks inside the MFMA reduction
+  bool sort_points = true;         // internal point order (ba_set_problem); off = the caller's order as given
+  int gm_cap = 0;                  // points per MFMA group (0 = chosen by ba_set_problem)
+  bool lds_window = true;          // k_schur_groups_mfma3 accumulates in an LDS window of the band when one fits
+  bool fast_paths = true;          // K = I / unit-Gaussian short cuts of the per-observation arithmetic (ba_math.h)
+  bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
+  bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
+  bool device_lu = true;           // a reduced system the Cholesky solve reports as not positive definite is solved again by the cyclic reduction with LU nodes
+  bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
+};
+
+}  // namespace ba
+
+using namespace ba;
+
+struct ba_handle {
+  int device = 0;
+  int ncu = 256;             // compute units of the device
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  Options opt;
+  std::vector<const void*> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on THIS handle's device
+
+  // problem
+  int nc = 0, nt = 0, nco = 0;
+  int hb = 0;                // block half-bandwidth of the reduced system
+  bool fac_valid = false;    // fac[] (L D L^T of the point inverses + HPPinv bP) matches HPPinv
+  int solve_kind = 0;        // BA_SOLVE_*: what the last ba_solve_reduced launched
+  int min_hb = 0;            // ba_set_min_half_bandwidth: lower bound for hb (ranks must agree on the band layout)
+  long long nobs = 0;
+  bool have_problem = false;
+  bool have_params[2] = {false, false};
+  bool have_linearization = false, have_schur = false, have_backsub = false;
+  int lin_phys = 0;                  // physical parameter set of the linearisation
+  bool point_blocks_valid = false;   // HPP / bP hold the point blocks of the linearisation (ba_lm_trial leaves them to the reduction too)
+  bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
+  bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)
+  double inv_damping = 0.0, inv_rcond = 0.0;
+  bool dense_mode = false;           // ba_set_dense_visibility: the reduction is one SYRK over all points (k_dense_*)
+  double* trial_result_dev = nullptr; // bound by ba_bind_trial_result: device copy of the cost partials + status words
+  ncclComm_t comm = nullptr;          // ba_comm_init: the shards' communicator; collectives run on `stream`
+  int comm_ranks = 0;
+  double* comm_host = nullptr;        // pinned [kCostBlocks + 2]: the all-reduced trial record
+  double trial_rcond = 0.0;          // ba_lm_trial_begin -> ba_lm_trial_end
+  int glog = 0;              // lanes per point = 2^glog
+  double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0, FAST_UNIT_GAUSS};
+  DevBuf<int> obs_cam, obs_pt, pt_off, cam_opt_pos, opt_cam, keep;
+  DevBuf<double2> obs_z;
+  DevBuf<unsigned char> pt_opt;
+  DevBuf<SchurUnit> units;
+  int nunits = 0;
+  DevBuf<SchurChunk> chunks;
+  int nchunks = 0, schur_wn = 0;
+  DevBuf<SchurGroup> groups, mgroups;
+  DevBuf<SchurChunk> gchunks, mchunks;
+  int nmchunks = 0, nmgroups_total = 0;
+  bool groups_ascending = false;
+  int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
+  bool groups_worth = false;            // points really share camera lists (mean run >= 2 points)
+  Gm3Params gm3{0, 0, 0, 0, 0, 1, 1};   // k_schur_groups_mfma3: tile count, staged row length, k-rows per buffer, points per batch, window
+  DevBuf<SchurChunk> m3chunks;          // its chunks (window rows gm3.wn may differ from schur_wn)
+  DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions
+  DevBuf<int> wtab;                     // ... and their (point, window column) -> observation tables
+  int nm3chunks = 0, nwgroups = 0;
+  DevBuf<int> wide_list;                // window groups of 25 .. 40 cameras (k_schur_wide_mfma, one workgroup each): indices into wgroups,
+  int nwide = 0;                        // by tiles per side: those of NT tiles are wide_list[wide_begin[NT - kGwMinTiles] .. wide_begin[NT - kGwMinTiles + 1])
+  int wide_begin[kGwMaxTiles - kGwMinTiles + 2] = {0};
+  // tracks that span more than kGm3MaxSpan cameras: groups of k_schur_rect_mfma, one per pair of segments (A <= B) they touch
+  DevBuf<RectGroup> rgroups;
+  DevBuf<int> rtab;
+  int nrgroups = 0, nlong_points = 0;
+  bool gm3_uniform_ks = false;          // every window group has 6 points per batch (width <= 10): five k-steps
+  bool wgroups_worth = false;           // enough points per window group for the matrix-core reduction to pay
+  int ngroups = 0;                      // groups[] (<= kGroupMaxPts points each)
+  bool point_groups = false;            // every point sits in a group and groups are worth it: group-packed k_linearize / k_backsub
+  int group_maxL = 0;                   // longest track (k_schur_groups_mfma takes <= kGmMaxL)
+  DevBuf<int> cam_perm;
+  DevBuf<CamUnit> cam_units;
+  int ncam_units = 0;
+  std::vector<int> h_cam_opt_pos;
+  std::vector<unsigned char> h_pt_opt;
+  // internal order (ba_set_problem): internal point i = the caller's track pperm[i], internal observation n = the
+  // caller's operm[n]; empty = identity
+  std::vector<int> pperm, operm;
+
+  // parameters: cams[which] = nc x [R(9) | t(3)], X[which] = nt x 3
+  DevBuf<double> cams[2], X[2];
+  int cur = 0;               // physical index of BA_PARAMS_CUR
+
+  // normal-equation blocks
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, bigK, fac, dUd, dDd, dyd, dpart, comm_dev;
+  DevBuf<unsigned char> mask;
+  DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)
+  int bcr_order_n = 0;
+  DevBuf<int> bcr_work, bcr_done;   // k_bcr_eliminate_fused: 4 node + role of every workgroup, leaves first; "handed on" words [4 N]
+  int bcr_work_n = 0, bcr_work_s = 0, bcr_work_len = 0, bcr_work_elim = 0;   // (elimination items first, then the back-substitution items)
+  DevBuf<long long> bcr_trace;      // PROFILE builds, option solve_trace: the time line of k_bcr_eliminate_fused, 8 words per workgroup
+  int bcr_trace_n = 0;
+  // the reduced solve spread over the ranks of a sharded adjuster (ba_dist.h; ba_dist_enable)
+  struct DistPlan {
+    bool on = false;
+    int rank = 0, nranks = 1;
+    int cb = 0, N = 0, P = 0;           // cameras per node, nodes, nodes per interval (its separator included)
+    int n_lo = 0, n_hi = 0;             // this rank's own nodes [n_lo, n_hi) (interior) ...
+    int own_lo = 0, own_hi = 0;         // ... and the camera positions whose solution it contributes (interior + its separator)
+    int nrows = 0, nsep = 0, nroot = 0, nwork_local = 0, nwork_top = 0, norder = 0;
+    DevBuf<int> rows, sep, sep_owner, root, root_owner, work, order, asm_nodes;   // work = [local items | separator items]
+    int nasm = 0;                       // nodes this rank assembles: its own interval and every separator
+    double* xbuf = nullptr;             // the exchange buffer (bound by the caller, or our own)
+    size_t xcap = 0;
+    DevBuf<double> xown;
+    size_t xcount[3] = {0, 0, 0};       // doubles of the three exchanges
+  } dist;
+  bool have_solution = false;
+  bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
+  DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
+                            // counters (alternate per ba_schur call)
+  int sing_epoch = 0;       // which of the two counters the latest ba_schur used
+  HostResult* host_result = nullptr;   // pinned, device-visible: cost + status words of a trial
+  int cost_blocks = 0;      // partials the last k_cost launch wrote
+  bool cost_fused = false;  // the last ba_backsubstitute evaluated the trial cost as well (k_backsub_groups)
+  int* sing_counter() { return flags.p + 40 + (sing_epoch & 1); }
+  double host_cost() const {           // second, deterministic stage of the cost reduction (after a stream sync)
+    double s = 0.0;
+    for (int i = 0; i < cost_blocks; ++i) s += host_result->partial[i];
+    return s;
+  }
+  double* S = nullptr;       // nco*nco*36 (own or bound)
+  double* b = nullptr;       // nco*6
+
+  // timing
+  bool timing = false;
+  unsigned long long timing_mask = ~0ull;   // which kernel ids are bracketed with events
+  int timing_stride = 1;                    // bracket every n-th eligible launch (an event pair costs stream time)
+  unsigned timing_seen[BA_K_COUNT] = {0};
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<TimedLaunch> pending;
+  double ms[BA_K_COUNT] = {0};
+  long long launches[BA_K_COUNT] = {0};
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  int phys(int which) const { return which == BA_PARAMS_CUR ? cur : 1 - cur; }
+};
+
+#define HIPCHECK(h, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return (h)->fail(e_ == hipErrorOutOfMemory ? BA_ERR_NOMEM : BA_ERR_HIP, "%s failed: %s (%s:%d)", \
+                       #call, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+  } while (0)
+
+#define REQUIRE(h, cond, code, msg) \
+  do { if (!(cond)) return (h)->fail(code, "%s", msg); } while (0)
+
+namespace ba {
+
+hipEvent_t get_event(ba_handle* h);
+void resolve_timings(ba_handle* h);
+
+struct ScopedTimer {
+  // one event pair around `count` back-to-back launches of the same kernel (the cyclic-reduction levels):
+  // an event pair costs a few microseconds of stream time, seven of them per 0.4 ms step would show
+  ba_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;
+  bool on; int count;
+  ScopedTimer(ba_handle* h_, int id_, int count_ = 1)
+      : h(h_), id(id_), on(h_->timing && ((h_->timing_mask >> id_) & 1ull) && (h_->timing_seen[id_]++ % (unsigned)h_->timing_stride) == 0),
+        count(count_) {
+    if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+  }
+  ~ScopedTimer() {
+    if (on) {
+      (void)hipEventRecord(b, h->stream);
+      h->pending.push_back({id, a, b, count});
+      if (h->pending.size() >= 8192) resolve_timings(h);
+    }
+  }
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: remembered per handle (one handle = one device)
+hipError_t ensure_lds_attr(ba_handle* h, const void* fn);
+
+// Host-facing per-point / per-observation arrays go through the internal order of ba_set_problem:
+// rows of w doubles, perm[i] = the caller's index of internal row i.
+void rows_to_internal(const std::vector<int>& perm, const double* src, double* dst, int w);
+void rows_to_caller(const std::vector<int>& perm, const double* src, double* dst, int w);
+// device rows -> caller's host array (synchronises the stream when a permutation is in the way)
+int download_rows(ba_handle* h, const std::vector<int>& perm, const double* dev, double* host, size_t n, int w);
+
+inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + kBlock - 1) / kBlock); }
+DevProblem dev_problem(const ba_handle* h);
+
+inline size_t reduced_doubles(const ba_handle* h) { return (size_t)h->nco * (h->hb + 1) * 36; }
+int ensure_reduced(ba_handle* h);
+
+// ---- RCCL, resolved at run time (ba_comm_load): the library does not link against it, it uses the one the
+// process already has (torch's), so that there is a single RCCL instance per process
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok() const { return GetUniqueId && CommInitRank && AllReduce && CommDestroy; }
+};
+extern RcclApi g_rccl;
+
+#define RCCLCHECK(h, call)                                                                                   \
+  do {                                                                                                       \
+    ncclResult_t r_ = (call);                                                                                \
+    if (r_ != ncclSuccess)                                                                                   \
+      return (h)->fail(BA_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+  } while (0)
+
+// in-place sum over the shards of the band-stored [S | b] (contiguous), on the handle's stream (ba_core.hip)
+int comm_allreduce_reduced(ba_handle* h);
+void launch_copy_doubles(ba_handle* h, const double* src, double* dst, int n);
+
+// ---- ba_schur.hip
+// Which kernel forms the Schur reduction (bundle_adjuster.py:259-278) for this problem and these options.
+enum { KERN_PAIRS = 0, KERN_GROUPS, KERN_MFMA2 = 3, KERN_MFMA3, KERN_DENSE };      // (the values BA_INFO_SCHUR_KERNEL reports; 2 was the single-wavefront matrix-core kernel of round 1)
+int pick_schur_kernel(const ba_handle* h);
+inline bool kern_is_mfma(int k) { return k == KERN_MFMA2 || k == KERN_MFMA3; }
+
+// ---- ba_schur_window.hip: the window-group reductions
+int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam);
+int mfma3_launches(int nts);
+int launch_wide_all(ba_handle* h, int p, double damping, bool fuse_cam);
+int wide_launches(const ba_handle* h);
+int launch_rect(ba_handle* h, int p, double damping, bool fuse_cam);
+
+// ---- ba_points.hip: ba_linearize; with fuse (ba_lm_trial + MFMA reduction) the camera blocks are left to the reduction kernel
+int launch_point_blocks(ba_handle* h, int p, double* Wd);
+int launch_camera_blocks(ba_handle* h, int p, bool clear);
+int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double damping, double rcond);
+
+// ---- ba_solve.hip (cyclic reduction up to 11 cameras per node, the one-workgroup band solver, the solve spread over ranks)
+// and ba_solve_wide.hip (wider bands); each leaves the solution in h->dC and the status in flags[1]
+int solve_bcr_wide(ba_handle* h, const unsigned char* dmask);
+int solve_bcr_big(ba_handle* h, const unsigned char* dmask);
+int solve_dense_chol(ba_handle* h, const unsigned char* dmask);
+// k_bcr_assemble (ba_bcr.h): band (+ mask) -> D, U, f of the nodes of cb cameras; clears the status word
+void launch_bcr_assemble(ba_handle* h, dim3 grid, int cb, const unsigned char* dmask, double* xsol, int* done, const int* nodes);
+// ba_bcr_split.hip / ba_bcr_levels.hip: the node kernels, instantiated per cameras-per-node
+hipError_t launch_bcr_fused(ba_handle* h, int hb, int nwork, hipStream_t st, int N, int s_first, double* D, const double* U, double* f,
+                            double* P, double* Q, double* G, double* gv, int* info, double* x, const int* work, int* done);
+hipError_t launch_bcr_split(ba_handle* h, int hb, int cnt, hipStream_t st, int N, int s, double* D, const double* U, double* f,
+                            double* P, double* Q, double* G, double* gv, int* info, double* x);
+hipError_t launch_bcr_eliminate(ba_handle* h, int hb, int cnt, size_t lds, hipStream_t st, int N, int s, double* D, double* U, double* f,
+                                double* P, double* Q, double* G, int* info, double* x);
+hipError_t launch_bcr_lu(ba_handle* h, int hb, int cnt, hipStream_t st, int N, int s, double* D, double* U, double* f, double* P, double* Q,
+                         double* G, int* info, double* x);
+// ba_band_solve.hip, ba_band_solve_masked.hip
+hipError_t launch_band_solve_masked(ba_handle* h, int hb, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+                                    const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info);
+hipError_t launch_band_solve(ba_handle* h, int hb, size_t lds, hipStream_t stream, int nco, int ch, const double* S, const double* b,
+                             const unsigned char* mask, double* U, double* y, double* dinv, double* x, int* info);
+bool dist_plan_static(int nco, int hb, int nranks, int* cb_out, int* N_out, int* P_out);
+int dist_build_plan(ba_handle* h, int rank, int nranks);
+int dist_stage(ba_handle* h, int stage, const uint8_t* cam_param_mask, size_t* count);
+
+inline int big_node_cameras(int hb) { return (hb + 1) & ~1; }      // cb >= hb, even: B = 6 cb is a multiple of the panel kernel's 12-column steps
+
+}  // namespace ba

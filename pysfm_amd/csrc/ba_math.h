@@ -1,5 +1,5 @@
 // ba_math.h - per-observation / per-block arithmetic of the bundle-adjustment
-// inner loop, written once and inlined into the gfx950 kernels (ba_kernels.hip).
+// inner loop, written once and inlined into the gfx950 kernels (ba_obs_kernels.h, ba_schur_kernels.h, ba_schur_window_kernels.h).
 // Every function is plain fp64 register arithmetic on tiny fixed-size blocks
 // (<= 6x6): no MFMA, no memory traffic.  Reference citations are to
 // alexflint/pysfm.

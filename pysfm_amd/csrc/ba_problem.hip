@@ -1,0 +1,648 @@
+// ba_problem.hip - ba_set_problem: the internal order of points and observations and the work lists of the kernels.
+#include "ba_internal.h"
+
+
+using namespace ba;
+
+extern "C" {
+
+int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
+                   const int32_t* obs_pt, const double* obs_z, const double* K,
+                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
+  REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
+  REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
+          "ba_set_problem: NULL argument");
+  REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
+  HIPCHECK(h, hipSetDevice(h->device));
+
+  // validate; caller-order CSR by point (any observation order is accepted: stable counting sort)
+  std::vector<int> coff((size_t)nt + 1, 0);
+  for (int64_t n = 0; n < nobs; ++n) {
+    const int c = obs_cam[n], k = obs_pt[n];
+    if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%lld]=%d out of range", (long long)n, c);
+    if (k < 0 || k >= nt) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%lld]=%d out of range", (long long)n, k);
+    coff[(size_t)k + 1] += 1;
+  }
+  for (int k = 0; k < nt; ++k) coff[(size_t)k + 1] += coff[k];
+  // optimised-camera positions must be a permutation of 0..nco-1
+  int nco = 0;
+  for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) ++nco;
+  {
+    std::vector<char> seen((size_t)nco, 0);
+    for (int i = 0; i < nc; ++i) {
+      const int p = cam_opt_pos[i];
+      if (p < 0) continue;
+      if (p >= nco || seen[p]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: cam_opt_pos is not a permutation of 0..nco-1");
+      seen[p] = 1;
+    }
+  }
+  // ---- internal order.  The reference visits tracks and their measurements in any order
+  // (bundle_adjuster.py:222-226); the kernels want (a) a track's observations by ascending optimised-camera
+  // position, frozen cameras first, and (b) tracks with identical camera lists next to each other, lists
+  // ordered by their first optimised camera (image sequences: the reduction's LDS window slides along the
+  // band).  So: rank the cameras (frozen ones by index, then the optimised ones by position), sort each
+  // track's observations by rank, sort the tracks by (first optimised position, rank list).  `pperm` /
+  // `operm` map internal point / observation indices to the caller's; every host-facing array goes through
+  // them (identity for a scene that already comes in this order: then they stay empty).
+  std::vector<int> by_pt((size_t)nobs);                      // caller observation ids, grouped by caller point
+  {
+    std::vector<int> cursor(coff.begin(), coff.end() - 1);
+    for (int64_t n = 0; n < nobs; ++n) by_pt[(size_t)cursor[obs_pt[n]]++] = (int)n;
+  }
+  std::vector<int> crank((size_t)nc);
+  {
+    int f = 0;
+    const int nfrozen = nc - nco;
+    for (int i = 0; i < nc; ++i) crank[i] = cam_opt_pos[i] < 0 ? f++ : nfrozen + cam_opt_pos[i];
+  }
+  const bool sort_points = h->opt.sort_points;
+  if (sort_points) {
+    for (int k = 0; k < nt; ++k) {
+      int* b0 = by_pt.data() + coff[k];
+      int* b1 = by_pt.data() + coff[(size_t)k + 1];
+      auto less = [&](int a, int b) { return crank[obs_cam[a]] < crank[obs_cam[b]]; };
+      if (!std::is_sorted(b0, b1, less)) std::stable_sort(b0, b1, less);
+    }
+  }
+  for (int k = 0; k < nt; ++k) {                             // each (camera, track) pair at most once (bundle.py: a dict per track)
+    std::vector<int> seen;
+    const int L = coff[(size_t)k + 1] - coff[k];
+    if (sort_points) {
+      for (int q = coff[k] + 1; q < coff[(size_t)k + 1]; ++q)
+        if (obs_cam[by_pt[q]] == obs_cam[by_pt[q - 1]])
+          return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in camera %d", k, obs_cam[by_pt[q]]);
+    } else if (L > 1) {
+      seen.assign(by_pt.begin() + coff[k], by_pt.begin() + coff[(size_t)k + 1]);
+      for (int& v : seen) v = obs_cam[v];
+      std::sort(seen.begin(), seen.end());
+      if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
+        return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in one camera", k);
+    }
+  }
+  std::vector<int> pperm((size_t)nt);
+  for (int k = 0; k < nt; ++k) pperm[k] = k;
+  if (sort_points && nt > 1) {
+    std::vector<int> minpos((size_t)nt, INT32_MAX);
+    for (int k = 0; k < nt; ++k)
+      for (int q = coff[k]; q < coff[(size_t)k + 1]; ++q) {
+        const int p = cam_opt_pos[obs_cam[by_pt[q]]];
+        if (p >= 0) { minpos[k] = p; break; }               // (sorted by rank: the first optimised one is the smallest)
+      }
+    auto less = [&](int a, int b) {
+      if (minpos[a] != minpos[b]) return minpos[a] < minpos[b];
+      const int la = coff[(size_t)a + 1] - coff[a], lb = coff[(size_t)b + 1] - coff[b];
+      const int* pa = by_pt.data() + coff[a];
+      const int* pb = by_pt.data() + coff[b];
+      for (int q = 0; q < std::min(la, lb); ++q) {
+        const int ra = crank[obs_cam[pa[q]]], rb = crank[obs_cam[pb[q]]];
+        if (ra != rb) return ra < rb;
+      }
+      return la < lb;
+    };
+    if (!std::is_sorted(pperm.begin(), pperm.end(), less)) std::stable_sort(pperm.begin(), pperm.end(), less);
+  }
+  // internal observation arrays + CSR
+  std::vector<int> ic((size_t)nobs), ip((size_t)nobs), operm((size_t)nobs), off((size_t)nt + 1, 0);
+  std::vector<double2> iz((size_t)nobs);
+  std::vector<unsigned char> ipt_opt((size_t)nt);
+  {
+    size_t w = 0;
+    for (int i = 0; i < nt; ++i) {
+      const int k = pperm[i];
+      ipt_opt[i] = pt_opt[k];
+      for (int q = coff[k]; q < coff[(size_t)k + 1]; ++q, ++w) {
+        const int n = by_pt[q];
+        operm[w] = n; ic[w] = obs_cam[n]; ip[w] = i;
+        iz[w] = double2{obs_z[2 * (size_t)n], obs_z[2 * (size_t)n + 1]};
+      }
+      off[(size_t)i + 1] = (int)w;
+    }
+  }
+  bool pid = true, oid = true;
+  for (int i = 0; i < nt && pid; ++i) pid = pperm[i] == i;
+  for (int64_t n = 0; n < nobs && oid; ++n) oid = operm[(size_t)n] == (int)n;
+  h->pperm = pid ? std::vector<int>() : pperm;
+  h->operm = oid ? std::vector<int>() : operm;
+  // from here on everything is in internal order
+  obs_cam = ic.data(); obs_pt = ip.data(); pt_opt = ipt_opt.data();
+
+  // Schur work units: (point, row tile, col tile >= row tile)
+  std::vector<SchurUnit> units;
+  units.reserve((size_t)nt);
+  long long maxL = 0;
+  for (int k = 0; k < nt; ++k) {
+    const int L = off[(size_t)k + 1] - off[k];
+    maxL = std::max<long long>(maxL, L);
+    for (int r = 0; r < L; r += kTile)
+      for (int c = r; c < L; c += kTile) units.push_back({k, r, c});
+  }
+  // camera-ordered view of the observations for k_camera_blocks: counting sort by camera
+  std::vector<int> cam_off((size_t)nc + 1, 0), perm((size_t)nobs);
+  for (int64_t n = 0; n < nobs; ++n) cam_off[(size_t)obs_cam[n] + 1] += 1;
+  for (int i = 0; i < nc; ++i) cam_off[(size_t)i + 1] += cam_off[i];
+  {
+    std::vector<int> cursor(cam_off.begin(), cam_off.end() - 1);
+    for (int64_t n = 0; n < nobs; ++n) perm[(size_t)cursor[obs_cam[n]]++] = (int)n;
+  }
+  std::vector<CamUnit> cam_units;
+  // one wavefront per unit: few cameras with long observation lists (dense visibility) would leave the chip
+  // empty at kCamChunk observations per unit, so shrink the chunk until there are about 500 units (measured: 100 000 observations of 100 cameras: 28 us at 2048 per unit, 14 at 256, 19 at 64); many
+  // cameras with ~1000 observations each keep one unit per camera (one atomic result per camera)
+  const int cam_chunk = (int)std::min<int64_t>(kCamChunk, std::max<int64_t>(64, (nobs / 512 + 63) / 64 * 64));
+  for (int i = 0; i < nc; ++i)
+    for (int s = cam_off[i]; s < cam_off[(size_t)i + 1]; s += cam_chunk)
+      cam_units.push_back({i, s, std::min(s + cam_chunk, cam_off[(size_t)i + 1])});
+  // block half-bandwidth of the reduced system: widest spread of optimised-camera
+  // positions within one track
+  int hb = 0;
+  for (int k = 0; k < nt; ++k) {
+    int lo = INT32_MAX, hi = -1;
+    for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+      const int p = cam_opt_pos[obs_cam[n]];
+      if (p < 0) continue;
+      lo = std::min(lo, p); hi = std::max(hi, p);
+    }
+    if (hi >= 0) hb = std::max(hb, hi - lo);
+  }
+  hb = std::max(hb, std::min(h->min_hb, std::max(0, nco - 1)));   // sharded adjuster: every rank uses the widest band
+  // Schur chunks: consecutive units whose optimised-camera positions fit a window of wn
+  // band rows, so that a workgroup can accumulate them in an LDS tile
+  int wn = (int)(kSchurTileBytes / (((size_t)(hb + 1) * 36 + 6) * sizeof(double)));
+  wn = std::min(wn, 64);
+  if (wn < hb + 2 || nco == 0) wn = 0;                 // band too wide for an LDS tile: global atomics only
+  std::vector<SchurChunk> chunks;
+  {
+    std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
+    for (int k = 0; k < nt; ++k)
+      for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+        const int p = cam_opt_pos[obs_cam[n]];
+        if (p < 0) continue;
+        plo[k] = std::min(plo[k], p); phi[k] = std::max(phi[k], p);
+      }
+    int begin = 0, lo = INT32_MAX, hi = -1;
+    for (int u = 0; u < (int)units.size(); ++u) {
+      const int k = units[u].pt;
+      const int nlo = std::min(lo, plo[k]), nhi = std::max(hi, phi[k]);
+      const bool fits = wn == 0 || nhi < 0 || nhi - nlo + 1 <= wn;
+      if (u > begin && (!fits || u - begin >= kSchurChunkUnits)) {
+        chunks.push_back({begin, u, lo == INT32_MAX ? 0 : lo});
+        begin = u; lo = plo[k]; hi = phi[k];
+      } else {
+        lo = nlo; hi = nhi;
+      }
+    }
+    if (!units.empty()) chunks.push_back({begin, (int)units.size(), lo == INT32_MAX ? 0 : lo});
+  }
+  // Groups: runs of consecutive points (internal order) with identical observation lists.
+  //   groups / gchunks   <= kGroupMaxPts points each: k_schur_groups (vector kernel, track length <= 15) and the
+  //                      group-packed point kernels k_linearize_groups / k_backsub_groups (<= kGm3MaxL)
+  //   mgroups / mchunks  longer runs for the matrix-core reductions; mchunks under the LDS window `wn` of the older
+  //                      kernels (track length <= 10), m3chunks under k_schur_groups_mfma3's own window
+  std::vector<SchurGroup> groups, mgroups;
+  std::vector<SchurChunk> gchunks, mchunks, m3chunks;
+  int group_rounds = 0;
+  bool groups_worth = false;
+  bool groups_ascending = true;                      // optimised positions ascend along every track
+  Gm3Params gm3{0, 0, 0, 0, 0, 1, 1};
+  if (maxL >= 1 && maxL <= kGm3MaxL) {
+    auto build_groups = [&](int max_pts, std::vector<SchurGroup>& gs, std::vector<int>& glo, std::vector<int>& ghi) {
+      for (int k = 0; k < nt;) {
+        const int L = off[(size_t)k + 1] - off[k];
+        if (L == 0) { ++k; continue; }
+        int e = k + 1;
+        while (e < nt && e - k < max_pts && off[(size_t)e + 1] - off[e] == L &&
+               std::equal(obs_cam + off[k], obs_cam + off[k] + L, obs_cam + off[e]))
+          ++e;
+        int lo = INT32_MAX, hi = -1;
+        for (int n = off[k]; n < off[k] + L; ++n) {
+          const int p = cam_opt_pos[obs_cam[n]];
+          if (p >= 0) {
+            if (p <= hi) groups_ascending = false;
+            lo = std::min(lo, p); hi = std::max(hi, p);
+          }
+        }
+        gs.push_back({k, e, L, 0});
+        glo.push_back(lo); ghi.push_back(hi);
+        k = e;
+      }
+    };
+    // consecutive groups whose optimised positions fit a window of `win` band rows (win == 0: no window, by count only)
+    auto chunk_groups = [&](int limit, int win, const std::vector<SchurGroup>& gs, const std::vector<int>& glo, const std::vector<int>& ghi,
+                            std::vector<SchurChunk>& out) {
+      int begin = 0, lo = INT32_MAX, hi = -1;
+      for (int g = 0; g < (int)gs.size(); ++g) {
+        const int nlo = std::min(lo, glo[g]), nhi = std::max(hi, ghi[g]);
+        const bool fits = win == 0 || nhi < 0 || nhi - nlo + 1 <= win;
+        if (g > begin && (!fits || g - begin >= limit)) {
+          out.push_back({begin, g, lo == INT32_MAX ? 0 : lo});
+          begin = g; lo = glo[g]; hi = ghi[g];
+        } else {
+          lo = nlo; hi = nhi;
+        }
+      }
+      if (!gs.empty()) out.push_back({begin, (int)gs.size(), lo == INT32_MAX ? 0 : lo});
+    };
+    std::vector<int> glo, ghi, mlo, mhi;
+    build_groups(kGroupMaxPts, groups, glo, ghi);
+    if (maxL <= kGroupMaxL) chunk_groups(kGroupChunk, wn, groups, glo, ghi, gchunks);
+    // MFMA kernels: one group per wavefront pair, and the epilogue is expensive, so runs are cut
+    // only where the chip would otherwise idle: about one group per wavefront-pair slot (4 per CU)
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+    const int slots = std::max(1, ncu * (kGmBlock / kWave));
+    // The kernel lasts as long as its longest group (one round of workgroups), so: natural runs of points with
+    // identical camera lists, runs longer than `cap` cut into EQUAL parts of whole batches, and the smallest cap
+    // for which the groups still fit the wavefront-pair slots of one round (config 3: 991 runs of 101 +- 23
+    // points, cap 120 -> 1021 groups in 256 workgroups; a fixed 1.25 x mean cap gave groups of 126).
+    std::vector<SchurGroup> runs;
+    std::vector<int> rlo, rhi;
+    build_groups(INT32_MAX, runs, rlo, rhi);
+    auto split_runs = [&](int cap, bool emit) -> size_t {
+      size_t count = 0;
+      for (size_t r = 0; r < runs.size(); ++r) {
+        const int n = runs[r].pt_end - runs[r].pt_begin;
+        const int k = (n + cap - 1) / cap;
+        const int part = ((n + k - 1) / k + kGmPts - 1) / kGmPts * kGmPts;
+        for (int b = runs[r].pt_begin; b < runs[r].pt_end; b += part) {
+          ++count;
+          if (emit) {
+            mgroups.push_back({b, std::min(b + part, runs[r].pt_end), runs[r].L, 0});
+            mlo.push_back(rlo[r]); mhi.push_back(rhi[r]);
+          }
+        }
+      }
+      return count;
+    };
+    int cap = std::max(kGroupMaxPts, (int)(((nt + slots - 1) / slots + kGmPts - 1) / kGmPts * kGmPts));
+    int longest = 0;
+    for (const SchurGroup& r : runs) longest = std::max(longest, r.pt_end - r.pt_begin);
+    while (cap < longest && split_runs(cap, false) > (size_t)slots) cap += kGmPts;     // (beyond the longest run nothing changes)
+    if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);     // tuning aid (ba_set_option "gm_cap")
+    split_runs(cap, true);
+    if (maxL <= kGmMaxL && wn > 0) chunk_groups(kGmChunk, wn, mgroups, mlo, mhi, mchunks);
+    // worth it only when points really share camera lists
+    const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
+    groups_worth = mean_group >= 2.0;
+    if (groups_worth && maxL <= kGroupMaxL && wn > 0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
+  }
+  // Window groups for k_schur_groups_mfma3: consecutive points (internal order: by first optimised position) whose
+  // optimised cameras all lie within `wmax` consecutive positions - identical camera lists are NOT required, so tracks
+  // of different lengths, tracks with missing observations and tracks that start anywhere all join.  wmax = the
+  // widest window that costs no more 16-row tiles than the widest track needs.
+  std::vector<WinGroup> wgroups;
+  std::vector<int> wtab;
+  bool wgroups_worth = false;
+  std::vector<RectGroup> rgroups;
+  std::vector<int> rtab, wide_list;
+  int wide_begin[kGwMaxTiles - kGwMinTiles + 2] = {0};
+  int nlong_points = 0;
+  {
+    std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
+    int maxspan = 0;
+    for (int k = 0; k < nt; ++k) {
+      for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+        const int p = cam_opt_pos[obs_cam[n]];
+        if (p < 0) continue;
+        plo[k] = std::min(plo[k], p); phi[k] = std::max(phi[k], p);
+      }
+      if (phi[k] >= 0) maxspan = std::max(maxspan, phi[k] - plo[k] + 1);
+    }
+    bool sorted_by_lo = true;                          // (the internal sort guarantees it; "sort_points" = 0 may not)
+    for (int k = 1, last = -1; k < nt && sorted_by_lo; ++k) {
+      if (phi[k - 1] >= 0) last = plo[k - 1];
+      if (phi[k] >= 0 && plo[k] < last) sorted_by_lo = false;
+    }
+    // Points whose optimised cameras span MORE than the widest window (features that survive for a long stretch of a video):
+    // their cameras are cut along a grid of SEGMENTS of kRectSeg positions, and what a point adds to S is a sum over the pairs
+    // (A <= B) of segments it touches, S[A, B] -= U_A^T D U_B: k_schur_rect_mfma over the points that touch both (rgroups).
+    // A == B also carries the right-hand side and the camera blocks - every observation lies in exactly one segment.
+    auto is_long = [&](int k) { return phi[k] >= 0 && phi[k] - plo[k] + 1 > kGm3MaxSpan; };
+    long long nlong = 0;
+    int shortspan = 0;
+    for (int k = 0; k < nt; ++k) {
+      if (phi[k] < 0) continue;
+      if (is_long(k)) ++nlong; else shortspan = std::max(shortspan, phi[k] - plo[k] + 1);
+    }
+    const bool hybrid = nlong > 0 && sorted_by_lo && nco > 0;
+    struct SegTask { int qa, qb; std::vector<int> pts; };
+    std::vector<SegTask> rect_tasks;
+    if (hybrid) {
+      maxspan = shortspan;
+      nlong_points = (int)nlong;
+      std::map<long long, int> rect_id;
+      for (int k = 0; k < nt; ++k) {
+        if (!is_long(k)) continue;
+        std::vector<int> segs;
+        for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
+          const int p = cam_opt_pos[obs_cam[n]];
+          if (p >= 0) segs.push_back(p / kRectSeg);
+        }
+        std::sort(segs.begin(), segs.end());
+        segs.erase(std::unique(segs.begin(), segs.end()), segs.end());
+        for (size_t x = 0; x < segs.size(); ++x) {
+          for (size_t y = x; y < segs.size(); ++y) {
+            const long long key = ((long long)segs[x] << 32) | (unsigned)segs[y];
+            auto jt = rect_id.find(key);
+            if (jt == rect_id.end()) { jt = rect_id.emplace(key, (int)rect_tasks.size()).first; rect_tasks.push_back({segs[x], segs[y], {}}); }
+            rect_tasks[jt->second].pts.push_back(k);
+          }
+        }
+      }
+    }
+    if ((maxspan >= 1 || hybrid) && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
+      gm3.nts = (6 * maxspan + 15) / 16;
+      gm3.Ld = 16 * gm3.nts;
+      const int wmax = std::max(1, std::min(kGm3MaxSpan, gm3.Ld / 6));
+      // natural groups: extend while the window still holds everybody
+      struct Run { int b, e, lo, hi; };
+      std::vector<Run> runs;
+      for (int k = 0; k < nt;) {
+        if (phi[k] < 0 || (hybrid && is_long(k))) { ++k; continue; }      // (points without an optimised camera add nothing to S or b; long ones are members of their segments' groups)
+        int e = k + 1, lo = plo[k], hi = phi[k];
+        while (e < nt && !(hybrid && is_long(e)) && (phi[e] < 0 || std::max(hi, phi[e]) - lo + 1 <= wmax)) {
+          if (phi[e] >= 0) hi = std::max(hi, phi[e]);
+          ++e;
+        }
+        while (e > k + 1 && phi[e - 1] < 0) --e;       // no trailing points without cameras
+        runs.push_back({k, e, lo, hi});
+        k = e;
+      }
+      // cut long groups into equal parts so that one round of workgroups holds them all and none lasts much longer
+      // than the rest (as for the identical-list groups above)
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+      const int slots = std::max(1, ncu * kGm2Pairs);
+      auto parts_of = [&](const Run& r, int cap) { return (r.e - r.b + cap - 1) / cap; };
+      int cap = std::max(kGroupMaxPts, (int)(((nt + slots - 1) / slots + kGmPts - 1) / kGmPts * kGmPts));
+      int longest = 0;
+      for (const Run& r : runs) longest = std::max(longest, r.e - r.b);
+      auto count = [&](int c) { size_t n = 0; for (const Run& r : runs) n += parts_of(r, c); return n; };
+      while (cap < longest && count(cap) > (size_t)slots) cap += kGmPts;
+      if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);
+      std::vector<int> wlo, whi;
+      for (const Run& r : runs) {
+        const int n = r.e - r.b, k = parts_of(r, cap);
+        const int part = ((n + k - 1) / k + kGmPts - 1) / kGmPts * kGmPts;
+        for (int b0 = r.b; b0 < r.e; b0 += part) {
+          const int e0 = std::min(b0 + part, r.e);
+          int lo = INT32_MAX, hi = -1;
+          for (int q = b0; q < e0; ++q)
+            if (phi[q] >= 0) { lo = std::min(lo, plo[q]); hi = std::max(hi, phi[q]); }
+          if (hi < 0) continue;
+          const int W = hi - lo + 1;
+          WinGroup g{b0, e0, W, lo, (int)wtab.size(), 0, 0, 0};
+          wtab.resize(wtab.size() + (size_t)(e0 - b0) * W, -1);
+          for (int q = b0; q < e0; ++q)
+            for (int n2 = off[q]; n2 < off[(size_t)q + 1]; ++n2) {
+              const int p = cam_opt_pos[obs_cam[n2]];
+              if (p >= 0) wtab[(size_t)g.tab + (size_t)(q - b0) * W + (p - lo)] = n2;
+            }
+          wgroups.push_back(g);
+          wlo.push_back(lo); whi.push_back(hi);
+        }
+      }
+      // groups of 27 .. 40 cameras go through k_schur_wide_mfma (every observation linearised once): narrow ones first.  When the
+      // narrow ones are few beside them (tracks cut short by the end of the sequence), they go the same way - their own two to
+      // five launches of k_schur_groups_mfma3 would each last as long as one group
+      {
+        auto tiles = [&](int g) { return (6 * wgroups[g].W + 15) >> 4; };
+        long long pn = 0, pw = 0;
+        for (size_t g = 0; g < wgroups.size(); ++g) (tiles((int)g) >= kGwMinTiles ? pw : pn) += wgroups[g].pt_end - wgroups[g].pt_begin;
+        const bool all_wide = pw > 0 && 4 * pn <= pw;
+        auto cls = [&](int g) { return (tiles(g) >= kGwMinTiles || all_wide) ? std::max(tiles(g), kGwMinTiles) : 0; };      // 0: narrow
+        std::vector<int> order(wgroups.size());
+        for (size_t g = 0; g < order.size(); ++g) order[g] = (int)g;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cls(x) < cls(y); });
+        std::vector<WinGroup> wg2(wgroups.size());
+        std::vector<int> lo2(wgroups.size()), hi2(wgroups.size()), cl2(wgroups.size());
+        for (size_t g = 0; g < order.size(); ++g) { wg2[g] = wgroups[order[g]]; lo2[g] = wlo[order[g]]; hi2[g] = whi[order[g]]; cl2[g] = cls(order[g]); }
+        wgroups.swap(wg2); wlo.swap(lo2); whi.swap(hi2);
+        for (size_t g = 0; g < cl2.size(); ++g)
+          if (cl2[g] > 0) wide_list.push_back((int)g);
+        for (int t = kGwMinTiles; t <= kGwMaxTiles + 1; ++t) {      // wide_list is sorted by class: where class t begins
+          int n = 0;
+          for (size_t g = 0; g < cl2.size(); ++g) n += (cl2[g] > 0 && cl2[g] < t) ? 1 : 0;
+          wide_begin[t - kGwMinTiles] = n;
+        }
+      }
+      const int nshort_groups = (int)wgroups.size() - (int)wide_list.size();
+      if (nshort_groups > 0) {                              // the narrow groups' launches: as many tiles as THEY need
+        int wn = 1;
+        for (int g = 0; g < nshort_groups; ++g) wn = std::max(wn, wgroups[g].W);
+        gm3.nts = (6 * wn + 15) / 16;
+        gm3.Ld = 16 * gm3.nts;
+      }
+      // points per group: a group is one serial chain of batches on one workgroup, and there are few long tracks - halve the
+      // groups until they fill the chip twice (24 points at least: an epilogue of up to 144 tiles is paid per group)
+      int rect_pts = kRectGroupPts;
+      for (; rect_pts > 24; rect_pts /= 2) {
+        size_t ngr = 0;
+        for (const SegTask& t : rect_tasks) ngr += (t.pts.size() + rect_pts - 1) / rect_pts;
+        if (ngr >= (size_t)2 * ncu) break;                 // one workgroup per group, one workgroup per compute unit (its consumers' registers)
+      }
+      // groups of the pairs of segments: table rows of 2 kRectSeg columns [A | B] (A == B: the B half stays empty)
+      for (const SegTask& t : rect_tasks) {
+        const int loA = t.qa * kRectSeg, loB = t.qb * kRectSeg, WB = std::min(kRectSeg, nco - loB);
+        const size_t parts = (t.pts.size() + rect_pts - 1) / rect_pts, part = (t.pts.size() + parts - 1) / parts;
+        for (size_t b0 = 0; b0 < t.pts.size(); b0 += part) {
+          const int cnt = (int)std::min<size_t>(part, t.pts.size() - b0);
+          RectGroup g{cnt, (int)rtab.size(), 0, loA, loB, WB, 0, 0};
+          rtab.insert(rtab.end(), t.pts.begin() + b0, t.pts.begin() + b0 + cnt);
+          g.tab = (int)rtab.size();
+          rtab.resize(rtab.size() + (size_t)cnt * 2 * kRectSeg, -1);
+          for (int q = 0; q < cnt; ++q) {
+            const int k = t.pts[b0 + q];
+            for (int n2 = off[k]; n2 < off[(size_t)k + 1]; ++n2) {
+              const int p = cam_opt_pos[obs_cam[n2]];
+              if (p >= loA && p < loA + kRectSeg) rtab[(size_t)g.tab + (size_t)q * 2 * kRectSeg + (p - loA)] = n2;
+              else if (t.qa != t.qb && p >= loB && p < loB + WB) rtab[(size_t)g.tab + (size_t)q * 2 * kRectSeg + kRectSeg + (p - loB)] = n2;
+            }
+          }
+          rgroups.push_back(g);
+        }
+      }
+      // staging: four wavefront pairs with two buffers each must fit in LDS next to the (optional) accumulation window
+      auto finish_set = [&](int g0, int g1, Gm3Params& G, std::vector<SchurChunk>& out) {
+        if (g1 <= g0) return;
+        const size_t lds_total = 160 * 1024, fixed = schur_mfma3_lds_bytes(0, 0, 0, hb + 1) + 1024;
+        G.wb1 = 1;                                        // rows of the LDS window: as many blocks as the widest group spans
+        for (int g = g0; g < g1; ++g) G.wb1 = std::max(G.wb1, std::min(hb + 1, wgroups[g].W));
+        for (G.np_cap = kGmPts; G.np_cap >= 1; --G.np_cap) {
+          int kmax = 4;
+          for (int g = g0; g < g1; ++g) kmax = std::max(kmax, (3 * gm3_np(wgroups[g].W, G.np_cap) + 3) / 4 * 4);
+          G.Kbuf = kmax;
+          if ((size_t)kGm2Pairs * 2 * G.Kbuf * G.Ld * sizeof(double) <= 96 * 1024) break;
+        }
+        G.np_cap = std::max(1, G.np_cap);
+        const size_t staging = (size_t)kGm2Pairs * 2 * G.Kbuf * G.Ld * sizeof(double);
+        const size_t rowbytes = ((size_t)G.wb1 * 36 + 6) * sizeof(double);
+        int w3 = (int)((lds_total - fixed - staging) / rowbytes);
+        w3 = std::min(w3, std::max(16, G.wb1 + 6));
+        if (w3 < G.wb1 + 1 || !h->opt.lds_window) w3 = 0;
+        G.wn = w3;
+        int begin = g0, lo = INT32_MAX, hi = -1;          // chunks of <= kGmChunk groups under the LDS window
+        for (int g = g0; g < g1; ++g) {
+          const int nlo = std::min(lo, wlo[g]), nhi = std::max(hi, whi[g]);
+          const bool fits = w3 == 0 || nhi - nlo + 1 <= w3;
+          if (g > begin && (!fits || g - begin >= kGmChunk)) {
+            out.push_back({begin, g, lo});
+            begin = g; lo = wlo[g]; hi = whi[g];
+          } else {
+            lo = nlo; hi = nhi;
+          }
+        }
+        out.push_back({begin, g1, lo});
+      };
+      finish_set(0, nshort_groups, gm3, m3chunks);
+      // an epilogue per >= 12 points (the short tracks' groups decide; a scene of nothing but long tracks: its segment groups)
+      long long covered = 0;
+      for (const WinGroup& g : wgroups) covered += g.pt_end - g.pt_begin;
+      wgroups_worth = wgroups.empty() ? !rgroups.empty() : covered >= 12ll * (long long)wgroups.size();
+    }
+  }
+  // lanes per point: smallest power of two >= mean track length, in [1, 64]
+  int glog = 0;
+  const double meanL = nt > 0 ? (double)nobs / nt : 1.0;
+  while ((1 << glog) < meanL && glog < 6) ++glog;
+
+  h->nc = nc; h->nt = nt; h->nco = nco; h->hb = hb; h->nobs = nobs; h->glog = glog;
+  std::memcpy(h->K, K, sizeof h->K);
+  h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
+  h->h_pt_opt.assign(pt_opt, pt_opt + nt);
+  h->nunits = (int)units.size();
+  h->nchunks = (int)chunks.size();
+  h->schur_wn = wn;
+  h->ngchunks = (int)gchunks.size();
+  h->nmchunks = (int)mchunks.size();
+  h->nm3chunks = (int)m3chunks.size();
+  h->nwgroups = (int)wgroups.size();
+  h->gm3_uniform_ks = !m3chunks.empty();
+  for (const SchurChunk& c : m3chunks)
+    for (int g = c.begin; g < c.end; ++g) h->gm3_uniform_ks = h->gm3_uniform_ks && gm3_np(wgroups[g].W, gm3.np_cap) == kGmPts;
+  h->wgroups_worth = wgroups_worth;
+  h->nrgroups = (int)rgroups.size();
+  h->nwide = (int)wide_list.size();
+  std::memcpy(h->wide_begin, wide_begin, sizeof wide_begin);
+  h->nlong_points = rgroups.empty() ? 0 : nlong_points;
+  h->gm3 = gm3;
+  h->groups_worth = groups_worth;
+  h->nmgroups_total = (int)mgroups.size();
+  h->groups_ascending = groups_ascending;
+  h->ngroups = (int)groups.size();
+  {
+    long long covered = 0;
+    for (const SchurGroup& g : groups) covered += g.pt_end - g.pt_begin;
+    h->point_groups = groups_worth && covered == nt;        // (points without observations are in no group)
+  }
+  h->group_rounds = group_rounds;
+  h->group_maxL = maxL;
+  h->ncam_units = (int)cam_units.size();
+
+  HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, nobs)));
+  HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, nobs)));
+  HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, nobs)));
+  HIPCHECK(h, h->pt_off.resize((size_t)nt + 1));
+  HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
+  HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
+  HIPCHECK(h, h->wide_list.resize(std::max<size_t>(1, wide_list.size())));
+  if (!wide_list.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->wide_list.p, wide_list.data(), wide_list.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, h->rgroups.resize(std::max<size_t>(1, rgroups.size())));
+  HIPCHECK(h, h->rtab.resize(std::max<size_t>(1, rtab.size())));
+  if (!rgroups.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->rgroups.p, rgroups.data(), rgroups.size() * sizeof(RectGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->rtab.p, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
+  HIPCHECK(h, h->chunks.resize(std::max<size_t>(1, chunks.size())));
+  if (!chunks.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, h->groups.resize(std::max<size_t>(1, groups.size())));
+  HIPCHECK(h, h->gchunks.resize(std::max<size_t>(1, gchunks.size())));
+  HIPCHECK(h, h->mchunks.resize(std::max<size_t>(1, mchunks.size())));
+  HIPCHECK(h, h->m3chunks.resize(std::max<size_t>(1, m3chunks.size())));
+  if (!m3chunks.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, h->wgroups.resize(std::max<size_t>(1, wgroups.size())));
+  HIPCHECK(h, h->wtab.resize(std::max<size_t>(1, wtab.size())));
+  if (!wgroups.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->wgroups.p, wgroups.data(), wgroups.size() * sizeof(WinGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->wtab.p, wtab.data(), wtab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(h, h->mgroups.resize(std::max<size_t>(1, mgroups.size())));
+  if (!mgroups.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->mgroups.p, mgroups.data(), mgroups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
+  if (!mchunks.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->mchunks.p, mchunks.data(), mchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  if (!groups.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->groups.p, groups.data(), groups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
+    if (!gchunks.empty())
+      HIPCHECK(h, hipMemcpyAsync(h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(h, h->cam_perm.resize(std::max<size_t>(1, perm.size())));
+  HIPCHECK(h, h->cam_units.resize(std::max<size_t>(1, cam_units.size())));
+  if (!perm.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->cam_perm.p, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (!cam_units.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->cam_units.p, cam_units.data(), cam_units.size() * sizeof(CamUnit), hipMemcpyHostToDevice, h->stream));
+  if (nobs) {
+    HIPCHECK(h, hipMemcpyAsync(h->obs_cam.p, obs_cam, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->obs_pt.p, obs_pt, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->obs_z.p, iz.data(), nobs * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(h, hipMemcpyAsync(h->pt_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (nc) HIPCHECK(h, hipMemcpyAsync(h->cam_opt_pos.p, cam_opt_pos, nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (nt) HIPCHECK(h, hipMemcpyAsync(h->pt_opt.p, pt_opt, nt, hipMemcpyHostToDevice, h->stream));
+  if (!units.empty())
+    HIPCHECK(h, hipMemcpyAsync(h->units.p, units.data(), units.size() * sizeof(SchurUnit), hipMemcpyHostToDevice, h->stream));
+
+  for (int i = 0; i < 2; ++i) {
+    HIPCHECK(h, h->cams[i].resize(std::max<size_t>(1, (size_t)nc * 12)));
+    HIPCHECK(h, h->X[i].resize(std::max<size_t>(1, (size_t)nt * 3)));
+  }
+  HIPCHECK(h, h->HCC.resize(std::max<size_t>(1, (size_t)nc * 36)));
+  HIPCHECK(h, h->bC.resize(std::max<size_t>(1, (size_t)nc * 6)));
+  HIPCHECK(h, h->HPP.resize(std::max<size_t>(1, (size_t)nt * 6)));
+  HIPCHECK(h, h->bP.resize(std::max<size_t>(1, (size_t)nt * 3)));
+  HIPCHECK(h, h->HPPinv.resize(std::max<size_t>(1, (size_t)nt * 6)));
+  HIPCHECK(h, h->dC.resize(((size_t)nco + 16) * 6));     // padded: the cyclic-reduction solve writes whole super-blocks
+  HIPCHECK(h, h->ysol.resize(std::max<size_t>(1, (size_t)nco * 6)));
+  HIPCHECK(h, h->dinv.resize(std::max<size_t>(1, (size_t)nco * 6)));
+  HIPCHECK(h, h->mask.resize(std::max<size_t>(1, (size_t)nco * 6)));
+  HIPCHECK(h, h->dP.resize(std::max<size_t>(1, (size_t)nt * 3)));
+  HIPCHECK(h, h->flags.resize(64));
+  HIPCHECK(h, hipMemsetAsync(h->flags.p, 0, 64 * sizeof(int), h->stream));
+  {
+    std::vector<int> opt_cam(std::max(1, nco), 0);
+    for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) opt_cam[cam_opt_pos[i]] = i;
+    HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
+    HIPCHECK(h, hipMemcpyAsync(h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+  }
+  // a reduced system bound for another problem size is no longer valid
+  h->S = nullptr; h->b = nullptr;
+  h->have_problem = true;
+  h->dist.on = false;                 // (a cut of the solve over the ranks belongs to the problem it was made for: ba_dist_enable)
+  h->have_params[0] = h->have_params[1] = false;
+  h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
+  h->cur = 0;
+  HIPCHECK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
+  return BA_OK;
+}
+
+int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_problem_info: call ba_set_problem first");
+  REQUIRE(h, out && n >= 1, BA_ERR_INVALID_ARG, "ba_problem_info: bad argument");
+  const int kern = pick_schur_kernel(h);
+  const int64_t v[BA_INFO_COUNT] = {
+      h->pperm.empty() ? 0 : 1, h->operm.empty() ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
+      h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
+      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf};
+  for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];
+  return BA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// ba_schur.hip - ba_schur: damping, point-block inversion and the Schur reduction into the reduced camera system.
+#include "ba_internal.h"
+
+#include "ba_schur_kernels.h"
+
+using namespace ba;
+
+namespace ba {
+
+int pick_schur_kernel(const ba_handle* h) {
+  if (h->dense_mode && h->nt > 0 && h->nco > 0) return KERN_DENSE;
+  const bool asc = h->groups_ascending && h->group_maxL >= 1;
+  const bool m3 = (h->nm3chunks > 0 && h->nwgroups > 0) || h->nrgroups > 0 || h->nwide > 0;           // window groups: no identical camera lists needed
+  const bool m12 = asc && h->nmchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGmMaxL;      // the L <= 10 kernels
+  const bool vec = h->ngchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGroupMaxL;
+  switch (h->opt.schur) {
+    case SCHUR_PAIRS: return KERN_PAIRS;
+    case SCHUR_GROUPS: return vec ? KERN_GROUPS : KERN_PAIRS;
+    case SCHUR_MFMA2: return m12 ? KERN_MFMA2 : KERN_PAIRS;
+    case SCHUR_MFMA: return m3 ? KERN_MFMA3 : KERN_PAIRS;
+    default: break;
+  }
+  if (h->groups_worth && m12) return KERN_MFMA2;          // runs of identical camera lists, track length <= 10: the fixed-shape kernel (with the
+                                                          // camera blocks folded in it is 6 % faster than the general one's <0, 4, 64, 5> instance)
+  if (m3 && h->wgroups_worth) return KERN_MFMA3;
+  if (h->groups_worth && vec && h->group_rounds >= 1 && h->group_rounds <= 2) return KERN_GROUPS;
+  return KERN_PAIRS;
+}
+
+
+}  // namespace ba
+
+extern "C" {
+
+int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_schur: bad parameter set");
+  const int p = h->phys(which);
+  REQUIRE(h, h->have_linearization && h->have_params[p], BA_ERR_STATE, "ba_schur: call ba_linearize first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  int rc = ensure_reduced(h);
+  if (rc != BA_OK) return rc;
+  const int kern = pick_schur_kernel(h);         // (ba_set_option "schur" forces one: tests)
+  const bool dense = kern == KERN_DENSE;
+  const bool use_mfma = kern_is_mfma(kern);
+  const bool use_groups = kern == KERN_GROUPS;
+  // point blocks and camera blocks: normally in HPP / bP (k_linearize) and HCC / bC (k_camera_blocks);
+  // ba_lm_trial leaves both to the MFMA reduction, which linearises every observation anyway
+  if (!h->point_blocks_valid) {
+    rc = launch_point_blocks(h, h->lin_phys, nullptr);
+    if (rc != BA_OK) return rc;
+  }
+  const bool hybrid = kern == KERN_MFMA3 && h->nrgroups > 0;       // long tracks: rectangular groups between their segments
+  const bool fuse_cam = use_mfma && !h->cam_blocks_valid;
+  if (!h->cam_blocks_valid && !fuse_cam) {
+    rc = launch_camera_blocks(h, h->lin_phys, true);
+    if (rc != BA_OK) return rc;
+  }
+  // the producer / consumer reductions and the dense one work from the factorised point inverses, which the merged
+  // inversion + initialisation launch below writes (or has written, for the same damping)
+  const bool want_fac = kern == KERN_MFMA2 || kern == KERN_MFMA3 || dense;
+  const bool have_inv = h->inv_valid && h->inv_damping == damping && h->inv_rcond == pinv_rcond && (!want_fac || h->fac_valid);
+  h->inv_valid = false;
+  if (want_fac) HIPCHECK(h, h->fac.resize((size_t)9 * std::max(1, h->nt)));
+  if (!have_inv) h->fac_valid = false;
+  const long long ninit = (long long)reduced_doubles(h) + (long long)h->nco * 6;
+  if (!have_inv && h->nt > 0 && h->nco > 0) {
+    // point inverses and the initialisation of [S | b] are independent: one launch for both
+    h->sing_epoch ^= 1;     // this call counts singular blocks in sing_counter(); the kernel clears the other one
+    ScopedTimer tm(h, BA_K_POINT_INVERT);
+    const unsigned nbi = blocks_for(h->nt);
+    hipLaunchKernelGGL(k_point_invert_schur_init, dim3(nbi + blocks_for(ninit)), dim3(kBlock), 0, h->stream, (int)nbi, h->nt,
+                       h->HPP.p, damping, pinv_rcond, h->HPPinv.p, h->sing_counter(),
+                       h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), h->nco, h->hb + 1, h->opt_cam.p, h->HCC.p, h->bC.p, h->S,
+                       h->b, fuse_cam ? 0 : 1, h->bP.p, want_fac ? h->fac.p : (double*)nullptr);
+    h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
+    h->fac_valid = want_fac;
+  } else {
+    if (have_inv) {
+      h->inv_valid = true;        // already inverted for this (damping, rcond)
+    } else if (h->nt > 0) {
+      h->sing_epoch ^= 1;
+      ScopedTimer tm(h, BA_K_POINT_INVERT);
+      hipLaunchKernelGGL(k_point_invert, dim3(blocks_for(h->nt)), dim3(kBlock), 0, h->stream, h->nt, h->HPP.p,
+                         damping, pinv_rcond, h->HPPinv.p, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1));
+      h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
+    } else {
+      HIPCHECK(h, hipMemsetAsync(h->flags.p + 40, 0, 2 * sizeof(int), h->stream));
+    }
+    if (h->nco > 0) {
+      ScopedTimer tm(h, BA_K_SCHUR_INIT);       // clears the band and writes the damped diagonal + b in one pass
+      hipLaunchKernelGGL(k_schur_init, dim3(blocks_for(ninit)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, h->opt_cam.p,
+                         h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
+    }
+  }
+  if (dense) {
+    // dense visibility: the reduction is one symmetric matrix product over all points (the kernels below
+    // would do 36 global atomics per (pair, point): 258 M of them at 100 cameras x 1000 tracks)
+    const int M = 6 * h->nco, R = 3 * h->nt;
+    const int T = (M + kSyrkTile - 1) / kSyrkTile, pairs = T * (T + 1) / 2;
+    int nsplit = std::max(1, std::min(16, (768 + pairs - 1) / pairs));
+    const int chunk = ((R + nsplit - 1) / nsplit + kSyrkKc - 1) / kSyrkKc * kSyrkKc;
+    nsplit = (R + chunk - 1) / chunk;
+    HIPCHECK(h, h->dUd.resize((size_t)R * M)); HIPCHECK(h, h->dDd.resize(R)); HIPCHECK(h, h->dyd.resize(R));
+    HIPCHECK(h, h->dpart.resize((size_t)nsplit * M * M));
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, 5);
+    HIPCHECK(h, hipMemsetAsync(h->dUd.p, 0, (size_t)R * M * sizeof(double), h->stream));
+    const long long n = std::max<long long>(h->nobs, (long long)h->nt);
+    hipLaunchKernelGGL(k_dense_stage, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
+                       h->fac.p, h->bP.p, M, h->dUd.p, h->dDd.p, h->dyd.p);
+    hipLaunchKernelGGL(k_dense_syrk, dim3(T, T, nsplit), dim3(1024), 0, h->stream, M, R, chunk, h->dUd.p, h->dDd.p, h->dpart.p);
+    hipLaunchKernelGGL(k_dense_apply, dim3(blocks_for(reduced_doubles(h))), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, M, nsplit,
+                       h->dpart.p, h->S);
+    hipLaunchKernelGGL(k_dense_rhs, dim3((M + kBlock - 1) / kBlock, (R + kDenseRhsRows - 1) / kDenseRhsRows), dim3(kBlock), 0,
+                       h->stream, M, R, h->dUd.p, h->dyd.p, h->b);
+  } else if (kern == KERN_MFMA3) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS, (h->nm3chunks ? mfma3_launches(h->gm3.nts) : 0) + (hybrid ? 1 : 0) + wide_launches(h));
+    rc = launch_mfma3_all(h, p, damping, fuse_cam);
+    if (rc != BA_OK) return rc;
+    if (h->nwide > 0) {
+      rc = launch_wide_all(h, p, damping, fuse_cam);
+      if (rc != BA_OK) return rc;
+    }
+    if (hybrid) {
+      rc = launch_rect(h, p, damping, fuse_cam);
+      if (rc != BA_OK) return rc;
+    }
+  } else if (kern == KERN_MFMA2) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma2));
+    hipLaunchKernelGGL(k_schur_groups_mfma2, dim3(h->nmchunks), dim3(kGm2Block), schur_mfma2_lds_bytes(h->schur_wn, h->hb + 1), h->stream,
+                       dev_problem(h), h->cams[p].p, h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->fac.p, h->S, h->b, damping,
+                       fuse_cam ? 1 : 0);
+  } else if (use_groups) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    const int NW = kGroupBlock / kWave;
+    const size_t lds = (size_t)NW * 64 * 24 * sizeof(double) + (size_t)NW * 16 * sizeof(int) +
+                       (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups<1>));
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups<2>));
+    const int maxpairs_rounds = h->group_rounds >= 1 ? h->group_rounds : 2;
+    if (maxpairs_rounds == 1)
+      hipLaunchKernelGGL(k_schur_groups<1>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+    else
+      hipLaunchKernelGGL(k_schur_groups<2>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                         h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+  } else if (h->nchunks > 0) {
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    const int NW = kSchurBlock / kWave;
+    const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int) +
+                       (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
+    HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_pairs));
+    hipLaunchKernelGGL(k_schur_pairs, dim3(h->nchunks), dim3(kSchurBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+                       h->X[p].p, h->units.p, h->chunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+  }
+  HIPCHECK(h, hipGetLastError());
+  h->have_schur = true;
+  h->have_backsub = h->have_solution = false;
+  if (pinv_rcond < 0.0 && !h->defer) {   // plain-inverse mode must report singular blocks (numpy.linalg.inv raises)
+    int nsing = 0;
+    HIPCHECK(h, hipMemcpyAsync(&nsing, h->sing_counter(), sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (nsing > 0) return h->fail(BA_ERR_SINGULAR, "ba_schur: %d singular 3x3 point block(s) in plain-inverse mode", nsing);
+  }
+  return BA_OK;
+}
+
+int ba_reduced_layout(ba_handle* h, int32_t* nco, int32_t* half_bandwidth, int64_t* S_doubles) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_reduced_layout: call ba_set_problem first");
+  if (nco) *nco = h->nco;
+  if (half_bandwidth) *half_bandwidth = h->hb;
+  if (S_doubles) *S_doubles = (int64_t)reduced_doubles(h);
+  return BA_OK;
+}
+
+int ba_get_reduced(ba_handle* h, double* S, double* b) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_get_reduced: call ba_schur first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  const int nco = h->nco, hb1 = h->hb + 1;
+  std::vector<double> band(S ? reduced_doubles(h) : 0);
+  if (S && nco) HIPCHECK(h, hipMemcpyAsync(band.data(), h->S, band.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (b && nco) HIPCHECK(h, hipMemcpyAsync(b, h->b, (size_t)nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (S && nco) {   // expand the block band to the reference's dense (nco,nco,6,6), mirroring the upper triangle
+    std::memset(S, 0, (size_t)nco * nco * 36 * sizeof(double));
+    for (int i = 0; i < nco; ++i)
+      for (int d = 0; d < hb1 && i + d < nco; ++d) {
+        const double* src = &band[((size_t)i * hb1 + d) * 36];
+        double* up = S + ((size_t)i * nco + (i + d)) * 36;
+        std::memcpy(up, src, 36 * sizeof(double));
+        if (d > 0) {
+          double* lo = S + ((size_t)(i + d) * nco + i) * 36;
+          for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 6; ++c) lo[c * 6 + a] = src[a * 6 + c];
+        }
+      }
+  }
+  return BA_OK;
+}
+
+int ba_get_point_inverses(ba_handle* h, double* out) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur && out, BA_ERR_STATE, "ba_get_point_inverses: call ba_schur first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  std::vector<double> s6((size_t)h->nt * 6);
+  if (h->nt) HIPCHECK(h, hipMemcpyAsync(s6.data(), h->HPPinv.p, s6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  for (int k = 0; k < h->nt; ++k) {
+    const double* s = &s6[(size_t)k * 6];
+    double* d = out + (size_t)(h->pperm.empty() ? k : h->pperm[k]) * 9;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[1]; d[4] = s[3]; d[5] = s[4]; d[6] = s[2]; d[7] = s[4]; d[8] = s[5];
+  }
+  return BA_OK;
+}
+
+int ba_reduced_device_ptrs(ba_handle* h, void** S_blocks, void** b) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_reduced_device_ptrs: call ba_set_problem first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  int rc = ensure_reduced(h);
+  if (rc != BA_OK) return rc;
+  if (S_blocks) *S_blocks = h->S;
+  if (b) *b = h->b;
+  return BA_OK;
+}
+
+int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_bind_reduced_buffers: call ba_set_problem first");
+  h->S = (double*)S_blocks_dev;
+  h->b = (double*)b_dev;
+  h->have_schur = false;
+  return BA_OK;
+}
+
+int ba_set_dense_visibility(ba_handle* h, int32_t on) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  h->dense_mode = on != 0;
+  h->inv_valid = false;
+  if (!on) { h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); }
+  return BA_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// ba_solve_wide.hip - the reduced camera system for half-bandwidths beyond 11: cyclic reduction with three kernels per level (ba_bcr_wide.h), with nodes in device memory (ba_bcr_big.h), dense blocked Cholesky (ba_dense.h).
+#include "ba_internal.h"
+
+#include "ba_bcr_wide.h"
+#include "ba_dense.h"
+#include "ba_bcr_big.h"
+
+using namespace ba;
+
+namespace ba {
+
+// factor + solve of one level (both are templates on the half-bandwidth)
+template <int HB>
+hipError_t launch_bcrw_factor_hb(ba_handle* h, int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
+                                 double* f, double* P, double* Q, double* G, int* info) {
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcrw_factor<HB>); e != hipSuccess) return e;
+  if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcrw_solve_mfma<HB>); e != hipSuccess) return e;
+  constexpr int B = 6 * HB;
+  hipLaunchKernelGGL(k_bcrw_factor<HB>, dim3(cnt), dim3(kBcrElimThreads), bcrw_factor_lds_bytes(B), st, N, s, D, L, Lv, info);
+  const int ntile = (3 * B + 1 + 15) / 16;
+  hipLaunchKernelGGL(k_bcrw_solve_mfma<HB>, dim3(cnt, (ntile + 3) / 4), dim3(1024), bcrw_solve_lds_bytes(B), st, N, s, L, Lv, U, f,
+                     P, Q, G, info);
+  return hipSuccess;
+}
+
+hipError_t launch_bcrw_factor(ba_handle* h, int hb, int cnt, hipStream_t st, int N, int s, const double* D, double* L, double* Lv, const double* U,
+                              double* f, double* P, double* Q, double* G, int* info) {
+#define BA_HB_CASE(K) case K: return launch_bcrw_factor_hb<K>(h, cnt, st, N, s, D, L, Lv, U, f, P, Q, G, info);
+  switch (hb) {
+    BA_HB_CASE(12) BA_HB_CASE(13) BA_HB_CASE(14) BA_HB_CASE(15) BA_HB_CASE(16) BA_HB_CASE(17) BA_HB_CASE(18) BA_HB_CASE(19)
+    BA_HB_CASE(20) BA_HB_CASE(21) BA_HB_CASE(22) BA_HB_CASE(23)
+    default: return hipErrorInvalidValue;
+  }
+#undef BA_HB_CASE
+}
+
+// Block cyclic reduction for half-bandwidths 12..21 (ba_bcr_wide.h): three kernels per level.
+int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
+  const int hb = h->hb, B = 6 * hb, N = (h->nco + hb - 1) / hb;
+  const size_t BB = (size_t)B * B;
+  HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
+  HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB)); HIPCHECK(h, h->bcrL.resize(N * BB));
+  HIPCHECK(h, h->bcrF.resize((size_t)N * B));
+  HIPCHECK(h, h->bcrLv.resize((size_t)N * ((B + 11) / 12) * 144));
+  HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
+  {
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
+    launch_bcr_assemble(h, dim3(N), hb, dmask, nullptr, nullptr, nullptr);
+  }
+  std::vector<int> strides;
+  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
+  const int nt = (B + kBcrwPTile - 1) / kBcrwPTile, ntask = nt * (nt + 1) + nt * nt + 1;
+  {
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, 3 * (int)strides.size());
+    for (int s : strides) {
+      const int cnt = (N / s + 1) / 2;
+      HIPCHECK(h, launch_bcrw_factor(h, hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrL.p, h->bcrLv.p, h->bcrU.p, h->bcrF.p, h->bcrP.p,
+                                     h->bcrQ.p, h->bcrG.p, h->flags.p + 1));
+      hipLaunchKernelGGL(k_bcrw_products, dim3(cnt, ntask), dim3(1024), 0, h->stream, N, B, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->flags.p + 1);
+    }
+  }
+  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)strides.size());
+  for (int q = (int)strides.size() - 1; q >= 0; --q) {
+    const int s = strides[q], cnt = (N / s + 1) / 2;
+    hipLaunchKernelGGL(k_bcrw_backsolve, dim3(cnt), dim3(1024), 0, h->stream, N, B, s, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->bcrG.p,
+                       h->dC.p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+// Block cyclic reduction with nodes too large for LDS (ba_bcr_big.h): half-bandwidths beyond kBcrwMaxHB.  A level is a batched
+// partial dense Cholesky of one 3B x 3B matrix per eliminated node.
+
+int solve_bcr_big(ba_handle* h, const unsigned char* dmask) {
+  const int hb = h->hb, cb = big_node_cameras(hb), B = 6 * cb, N = (h->nco + cb - 1) / cb, n = 3 * B;
+  const size_t BB = (size_t)B * B, KS = big_matrix_doubles(B);
+  HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrF.resize((size_t)N * B));
+  HIPCHECK(h, h->bigK.resize((size_t)N * KS));
+  HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_panel));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_big_backsolve));
+  int* info = h->flags.p + 1;
+  {
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
+    const int rounds = (int)((BB + 3 * kBcrThreads - 1) / (3 * kBcrThreads));        // (three entries per thread and round)
+    launch_bcr_assemble(h, dim3(N, std::max(1, std::min(rounds, 2048 / N))), cb, dmask, nullptr, nullptr, nullptr);
+  }
+  struct Level { int s, cnt; size_t base; };
+  std::vector<Level> levels;
+  size_t slots = 0;
+  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) { levels.push_back({s, (N / s + 1) / 2, slots}); slots += (N / s + 1) / 2; }
+  const int npanels = (B + kDcNB - 1) / kDcNB;
+  {
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)levels.size() * (2 * npanels + 2));
+    for (const Level& L : levels) {
+      double* K = h->bigK.p + L.base * KS;
+      hipLaunchKernelGGL(k_big_gather, dim3(std::min(n + 1, 128), L.cnt), dim3(256), 0, h->stream, N, B, L.s, h->bcrD.p, h->bcrU.p,
+                         h->bcrF.p, K, KS);
+      for (int k0 = 0; k0 < B; k0 += kDcNB) {
+        const int nb = std::min(kDcNB, B - k0), kn = k0 + nb, total = n - kn + 1;      // every row below the block + the right-hand side row
+        hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows, 1, L.cnt), dim3(1024), dense_panel_lds_bytes(), h->stream,
+                           n, k0, nb, total, K, info, KS);
+        const int T = (total + kDcTile - 1) / kDcTile;
+        hipLaunchKernelGGL(k_dense_update, dim3(T, T, L.cnt), dim3(1024), 0, h->stream, n, k0, nb, total, K, KS);
+      }
+      const int nsurv = (N + 1) / (2 * L.s);       // nodes m = 2 s (y + 1) - 1 < N
+      if (nsurv > 0)
+        hipLaunchKernelGGL(k_big_scatter, dim3(std::min(B + 1, 64), nsurv), dim3(256), 0, h->stream, N, B, L.s, L.cnt, h->bcrD.p, h->bcrU.p,
+                           h->bcrF.p, K, KS);
+    }
+  }
+  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)levels.size());
+  for (int q = (int)levels.size() - 1; q >= 0; --q) {
+    const Level& L = levels[q];
+    hipLaunchKernelGGL(k_big_backsolve, dim3(L.cnt), dim3(1024), big_backsolve_lds_bytes(B), h->stream, N, B, L.s,
+                       h->bigK.p + L.base * KS, KS, h->dC.p, info);
+  }
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+// Dense Cholesky of the whole reduced system (ba_dense.h): bands wider than the cyclic reduction's blocks.
+int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
+  const int n = 6 * h->nco;
+  HIPCHECK(h, h->denseA.resize((size_t)(n + 1) * n));
+  HIPCHECK(h, h->dC.resize((size_t)n + 16));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_panel));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_backsolve));
+  int* info = h->flags.p + 1;
+  double* A = h->denseA.p;
+  const int nsteps = (n + kDcNB - 1) / kDcNB;
+  ScopedTimer tm(h, BA_K_DENSE_SOLVE, 2 * nsteps + 1);
+  hipLaunchKernelGGL(k_dense_gather, dim3(n + 1), dim3(256), 0, h->stream, h->nco, h->hb, h->S, h->b, dmask, A, info);
+  const int bw = std::min(n, 6 * (h->hb + 1) - 1);            // S[r][c] = 0 for |r - c| > bw
+  for (int k0 = 0; k0 < n; k0 += kDcNB) {
+    const int nb = std::min(kDcNB, n - k0), kn = k0 + nb;
+    const int total = std::min(n, kn + bw) - kn + 1;           // rows below the block that can be non-zero + the rhs row
+    hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows), dim3(1024), dense_panel_lds_bytes(), h->stream, n,
+                       k0, nb, total, A, info);
+    if (total > 1) {
+      const int T = (total + kDcTile - 1) / kDcTile;
+      hipLaunchKernelGGL(k_dense_update, dim3(T, T), dim3(1024), 0, h->stream, n, k0, nb, total, A);
+    }
+  }
+  hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(1024), dense_backsolve_lds_bytes(n), h->stream, n, bw, A, h->dC.p, info);
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+}  // namespace ba

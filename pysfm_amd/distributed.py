@@ -98,11 +98,11 @@ def _stream_of(backend):
     return ctx() if ctx is not None else contextlib.nullcontext()
 
 
-TRIAL_TIMED_OUT_WORD = float(1 << 40)      # kTrialTimedOutWord of csrc/ba_kernels.h
+TRIAL_TIMED_OUT_WORD = float(1 << 40)      # kTrialTimedOutWord of csrc/ba_types.h
 
 
 def trial_status_of_sum(total, world, own_parts):
-    """Solver status from the status word of the shards' trial records after their SUM over the ranks (csrc/ba_kernels.h
+    """Solver status from the status word of the shards' trial records after their SUM over the ranks (csrc/ba_types.h
     trial_status_of_sum): a rank whose solve timed out wrote 2^40 instead of its status, more than any sum of pivot indices,
     so a time-out stays a time-out (SOLVE_TIMED_OUT) instead of turning into a pivot index.  Otherwise every rank solved the
     same system (total / world) or, with the solve spread over the ranks (own_parts), its own part: any non-zero = failed."""

@@ -34,7 +34,7 @@ def be():
     b.close()
 
 
-DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1, fuse_lin=0,
+DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1,
                        sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1)
 
 
@@ -1012,25 +1012,6 @@ def test_two_ranks_on_one_gpu_walk_the_single_gpu_trajectory(tmp_path):
         close(r['costs'], np.array(ba.costs), 1e-9)
         close(r['t'], t1, 1e-8)
         close(r['X'], X1, 1e-8)
-
-
-def test_fused_linearisation_variant_of_the_trial():
-    """Option fuse_lin=1: k_schur_groups_mfma also forms HPP, bP and HPPinv (no k_linearize / k_point_invert
-    launch).  Slower than the default and therefore off, but it must give the same trial."""
-    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
-    s = banded(60, 3000, track_len=8, outlier_frac=.02)
-    out = {}
-    for tag in ('default', 'fused'):
-        b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
-                                    sensor_model=sensor_model.CauchyModel(.05))
-        ba = BundleAdjuster(verbose=False)
-        ba.backend.set_option('fuse_lin', tag == 'fused')
-        ba.set_bundle(b)
-        ba.optimize(max_steps=5)
-        out[tag] = (np.array(ba.costs),) + ba.backend.get_params(0)
-        ba.backend.close()
-    for x, y in zip(out['fused'], out['default']):
-        close(x, y, 1e-9)
 
 
 @pytest.mark.parametrize('collectives', ['library', 'torch'])

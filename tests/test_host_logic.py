@@ -547,7 +547,7 @@ def test_few_of_many_tracks_after_an_edit_of_the_track_objects():
 
 def test_a_timed_out_solve_survives_the_sum_over_the_ranks():
     """The shards' trial records are SUMMED over the ranks; a time-out on one rank (or on all of them) must come out as
-    SOLVE_TIMED_OUT, a pivot index as a pivot index (csrc/ba_kernels.h trial_status_word / trial_status_of_sum)."""
+    SOLVE_TIMED_OUT, a pivot index as a pivot index (csrc/ba_types.h trial_status_word / trial_status_of_sum)."""
     from pysfm_amd._capi import SOLVE_TIMED_OUT
     from pysfm_amd.distributed import TRIAL_TIMED_OUT_WORD, trial_status_of_sum
     word = lambda st: TRIAL_TIMED_OUT_WORD if st == SOLVE_TIMED_OUT else float(st)
