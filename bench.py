@@ -317,6 +317,9 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     ba = BundleAdjuster(device=device, verbose=False)
     t0 = time.time()
     ba.set_bundle(bundle)
+    t_setup_first = time.time() - t0                # (the handle's first problem: device allocations included)
+    t0 = time.time()
+    ba.set_bundle(bundle)
     t_setup = time.time() - t0
     be = ba.backend
     one_trial, state = make_trial_runner(ba, be)
@@ -349,7 +352,16 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
            'linearise_schur_pass_fraction_of_kernel_time': pass_ms / max(1e-12, sum(kms.values())),
            'obs_jacobians_per_s': nobs / max(1e-9, pass_ms * 1e-3),
            'schur_kernel': info.get('schur_kernel'), 'half_bandwidth': be.half_bandwidth, 'solve_kind': getattr(be, 'last_solve_kind', None),
-           'trials_by_solver_and_outcome': dict(state['paths']), 'set_bundle_s': t_setup}
+           'trials_by_solver_and_outcome': dict(state['paths']), 'set_bundle_s': t_setup, 'set_bundle_first_s': t_setup_first}
+    # what a caller feels: BundleAdjuster.set_bundle + optimize(25 steps), the adjusted bundle back on the host
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ba.set_bundle(bundle)
+    ba.optimize(max_steps=25)
+    _ = ba.bundle
+    torch.cuda.synchronize()
+    out['end_to_end_optimize_s'] = time.time() - t0
+    out['end_to_end_lm_trials'] = int(ba.lm_trials)
     be.close()
     return out
 
@@ -513,6 +525,9 @@ def main():
         # (cut where the distributed reduced solve wants the tracks cut, when it is going to be used; balanced by observations otherwise)
         use_plan = args.distributed_solve == 'on' or (args.distributed_solve == 'auto' and args.config == 5 and world > 1)
         track_ids = shard_tracks(bundle, rank, world, plan=ba.backend.dist_plan if use_plan else None)
+    t_setup_first = time.time()
+    ba.set_bundle(bundle, track_ids=track_ids)
+    t_setup_first = time.time() - t_setup_first     # (the handle's first problem: library start-up and device allocations included)
     t_setup = time.time()
     ba.set_bundle(bundle, track_ids=track_ids)
     t_setup = time.time() - t_setup
@@ -733,7 +748,8 @@ def main():
                              'achieved_tflops': sflops / (schur_ms * 1e-3) / 1e12 if schur_ms else None,
                              'peak_tflops': FP64_MATRIX_PEAK_TFLOPS,
                              'note': 'fp64 MFMA is used where the path is GEMM-shaped (Schur reduction, cyclic-reduction nodes)'},
-            'set_bundle_s': t_setup,          # host-side bookkeeping + internal order + work lists + upload (outside the timed region)
+            'set_bundle_s': t_setup,          # id bookkeeping (host) + internal order, work lists (device + O(points) on the host) + upload (outside the timed region)
+            'set_bundle_first_s': t_setup_first,
             'problem_info': be.problem_info(),
             'kernel_ms_per_step': {k: v['ms'] / nprof for k, v in ours.items()},
             'kernel_launches_per_step': {k: v['launches'] / nprof for k, v in ours.items()},
@@ -746,6 +762,18 @@ def main():
                                'timed_trials_by_solver_and_outcome': timed_paths},
         }
         out.update(lm)
+        if comm is None and not args.no_lm:
+            # what a caller feels: BundleAdjuster.set_bundle + optimize(25 steps), the adjusted bundle back on the host
+            torch.cuda.synchronize()
+            t0 = time.time()
+            ba.set_bundle(bundle, track_ids=track_ids)
+            t1 = time.time()
+            ba.optimize(max_steps=25)
+            t2 = time.time()
+            _ = ba.bundle
+            torch.cuda.synchronize()
+            out['end_to_end_optimize_s'] = time.time() - t0
+            out['end_to_end_parts_s'] = {'set_bundle': t1 - t0, 'optimize': t2 - t1, 'bundle_to_host': time.time() - t2, 'lm_trials': int(ba.lm_trials)}
         plain3 = (args.config == 3 and args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
                   and not args.drop_observations and not args.shuffle_points and args.sensor is None and args.outliers is None and not args.long_tracks)
         if ngpus == 1 and comm is None and plain3 and not args.no_other_configs:

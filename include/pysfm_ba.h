@@ -210,23 +210,23 @@ int ba_bind_reduced_buffers(ba_handle* h, void* S_band_dev, void* b_dev);
 int ba_set_dense_visibility(ba_handle* h, int32_t on);
 
 /* ---- BundleAdjuster.solve_motion_normal_eqns (bundle_adjuster.py:281-312)
- * Device-resident Cholesky solve of the reduced camera system, by block half-bandwidth hb:
- * block cyclic reduction with LDS-resident nodes (hb <= 23), a single-workgroup band Cholesky (fewer than 4
- * super-blocks), block cyclic reduction with nodes in device memory - every level a batched partial dense Cholesky
- * (hb > 23 and at least four nodes of hb cameras: BA_SOLVE_BCR_BIG, any number of cameras), or a dense blocked
- * Cholesky of the whole matrix (hb > 23 and fewer nodes, up to 16000 unknowns).
+ * Device-resident solve of the reduced camera system.  Cholesky first, by block half-bandwidth hb: block cyclic
+ * reduction with LDS-resident nodes (hb <= 23), a single-workgroup band Cholesky (fewer than 4 super-blocks), block
+ * cyclic reduction with nodes in device memory - every level a batched partial dense Cholesky (hb > 23 and at least
+ * four nodes of hb cameras: BA_SOLVE_BCR_BIG, any number of cameras), or a dense blocked Cholesky of the whole matrix
+ * (hb > 23 and fewer nodes, up to 16000 unknowns).  A system the Cholesky solver reports as not positive definite is
+ * solved again by LU with partial pivoting, which is what the reference's numpy.linalg.solve does with it (option
+ * device_lu, default on): the cyclic reduction with LU nodes for hb <= 11 (BA_SOLVE_BCR_LU: pivoting inside a node),
+ * LU down the band for every other shape (BA_SOLVE_BAND_LU: gesv's pivot choices on the same matrix; also what
+ * option solver = lu forces, and what systems no Cholesky solver takes go through).
  * cam_param_mask[nco*6] (host, may be NULL = all kept): 0 deletes that camera parameter
  * from the system (its solution entry is 0).  *info: 0 = solved, solution stays on the
- * device for ba_backsubstitute / ba_get_solution; > 0 = pivot `info` was not positive and, for half-bandwidths
- * up to 11, the second attempt - the same cyclic reduction with LU nodes (partial pivoting inside a node: what the
- * reference's numpy.linalg.solve does with a matrix that is not positive definite; option device_lu, kind
- * BA_SOLVE_BCR_LU) - met a singular node
- * (use ba_flatten_reduced + LU, which has the reference's LinAlgError
- * semantics; 0x7f000001 = the back-substitution of the cyclic reduction gave up waiting for a value that
- * never came - a bug upstream, reported instead of hanging the GPU; treat like any other failed solve);
- * -1 = too large for the device solvers (same fallback).
- * ba_last_solve_kind: which solver the last ba_solve_reduced launched. */
-enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY, BA_SOLVE_BCR_LU, BA_SOLVE_BCR_BIG };
+ * device for ba_backsubstitute / ba_get_solution; > 0 = the LU met an exactly zero pivot (1-based column, gesv's info:
+ * where the reference raises LinAlgError -> NormalEquationsIllconditioned) - or, with device_lu off, the index of the
+ * Cholesky pivot that was not positive; 0x7f000001 = a workgroup of the one-launch cyclic reduction gave up waiting for
+ * another - a fault of the solver, reported instead of hanging the GPU (solve again with option solver = lu).
+ * ba_last_solve_kind: which solver produced the state of the last ba_solve_reduced. */
+enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY, BA_SOLVE_BCR_LU, BA_SOLVE_BCR_BIG, BA_SOLVE_BAND_LU };
 #define BA_SOLVE_TIMED_OUT 0x7f000001   /* *info of a cyclic reduction whose workgroups gave up waiting for each other */
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);

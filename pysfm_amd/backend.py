@@ -13,16 +13,6 @@ import numpy as np
 from . import _capi as capi
 from ._capi import PARAMS_CUR, PARAMS_TRIAL  # noqa: F401  (re-exported)
 
-DEVICE_CHOLESKY_MAX_UNKNOWNS = 16000   # (= kDcMaxN of ba_dense.h)
-# A reduced system the device Cholesky rejects as not positive definite goes through LU like the reference's
-# (numpy.linalg.solve) - up to this many unknowns (the sizes of the reference's own data sets: 594 at 100
-# cameras; LU takes 1-3 ms there).  Beyond, the system is reported as ill-conditioned instead, which the LM
-# loop answers exactly as it answers the reference's LinAlgError: raise the damping and try again
-# (bundle_adjuster.py:134-140).  S is symmetric positive definite in exact arithmetic for damping > 0, so a
-# failed fp64 Cholesky means a condition number beyond 1e15 - an LU step of such a system carries no digits
-# (it happens at the noise floor, when the damping has decayed to ~1e-10 and the free scale of a monocular
-# reconstruction makes S numerically singular; at 1000 cameras every such LU costs 70 ms = 200 trials).
-LU_FALLBACK_MAX_UNKNOWNS = 2048
 # the dense-visibility REDUCTION (ba_set_dense_visibility) is worth it once the band is this wide; it does not decide the
 # solver: half-bandwidths up to 23 (kBcrwMaxHB of ba_bcr_wide.h) still go through the wide cyclic reduction, the dense
 # blocked Cholesky takes over beyond
@@ -36,12 +26,11 @@ class SingularPointBlock(np.linalg.LinAlgError):
 
 
 class ReducedSystemSingular(Exception):
-    """LU of the reduced camera system hit an exactly zero pivot."""
+    """The LU of the reduced camera system met an exactly zero pivot (where numpy.linalg.solve raises LinAlgError)."""
 
 
 class HipBackend(object):
-    lu_fallback_max_unknowns = LU_FALLBACK_MAX_UNKNOWNS     # per instance: BundleAdjuster(lu_fallback_max_unknowns=...)
-    device_lu = True                    # ba_solve_reduced retries a not-positive-definite system with LU nodes (option device_lu)
+    device_lu = True                    # ba_solve_reduced solves a not-positive-definite system again by LU with partial pivoting (option device_lu)
     poison_after_set_problem = False    # tests/conftest.py sets it: every problem starts from NaNs in all LDS / workspace (ba_debug_poison)
 
     def __init__(self, device=0):
@@ -56,7 +45,6 @@ class HipBackend(object):
         self.nc = self.nt = self.nco = self.nobs = 0
         self._torch = None
         self._S_t = self._b_t = self._Sb_t = None
-        self._A_t = self._rhs_t = None
         self._dense = self._dense_keep = None
         self._attach_torch()
 
@@ -97,7 +85,7 @@ class HipBackend(object):
         if getattr(self, '_h', None):
             self._lib.ba_destroy(self._h)
             self._h = None
-        self._S_t = self._b_t = self._A_t = self._rhs_t = self._trial_t = None
+        self._S_t = self._b_t = self._trial_t = None
         self._dense = self._dense_keep = None
 
     def __del__(self):
@@ -112,7 +100,6 @@ class HipBackend(object):
     def debug_poison(self):
         """Test aid (ba_debug_poison): NaNs into every LDS and workspace buffer, cached intermediates forgotten."""
         self._check(self._lib.ba_debug_poison(self._h))
-        self._host_dC = None
 
     def set_option(self, name, value):
         """Test / measurement switch of the library (include/pysfm_ba.h ba_set_option); the defaults are the
@@ -145,7 +132,6 @@ class HipBackend(object):
         self._check(self._lib.ba_reduced_layout(self._h, C.byref(nco), C.byref(hb), C.byref(nS)))
         self.nco, self.half_bandwidth, self.S_doubles = nco.value, hb.value, nS.value
         self._S_t = self._b_t = None
-        self._host_dC = None
         if self._torch is not None:
             self._bind_reduced()
         self._bind_dense()
@@ -265,81 +251,42 @@ class HipBackend(object):
 
     def solve_reduced(self, cam_param_mask=None):
         """Solve the reduced camera system with the masked camera parameters deleted
-        (solve_motion_normal_eqns, bundle_adjuster.py:281-312).  The solution stays on
-        the device for backsubstitute(); get_solution() fetches it.
-        Path 1 (last_solve_path 'band' / 'dense_cholesky', last_solve_kind says which kernel
-        family): Cholesky on the device inside ba_solve_reduced - block cyclic reduction for
-        block half-bandwidths up to 23 (one kernel per level up to 11, three beyond), with nodes in device memory beyond ('bcr_big': a batched partial dense Cholesky per level), a dense blocked Cholesky when there are fewer than four such nodes.  Path 2 ('dense'),
-        when the system is not positive definite or has more than 16000 unknowns: LU of the
-        flattened system, the reference's own factorisation (numpy.linalg.solve = gesv,
-        bundle_adjuster.py:303), here rocSOLVER through torch.linalg.solve_ex - on the GPU as
-        well.  Raises ReducedSystemSingular where the reference's solve would raise."""
-        self._host_dC = None
+        (solve_motion_normal_eqns, bundle_adjuster.py:281-312), entirely on the device (ba_solve_reduced): Cholesky by
+        band shape (last_solve_kind 'bcr', 'bcr_wide', 'bcr_big', 'band', 'dense_cholesky'), and - when the system is not
+        positive definite - LU with partial pivoting, the reference's own factorisation ('bcr_lu' for nodes of up to 11
+        cameras, 'band_lu' otherwise; last_solve_path 'lu').  The solution stays on the device for backsubstitute();
+        get_solution() fetches it.  Raises ReducedSystemSingular where the reference's solve raises (an exactly zero pivot)."""
         n = self.nco * 6
         mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
         assert mask is None or mask.shape == (n,)
         info = C.c_int32(0)
         self._check(self._lib.ba_solve_reduced(self._h, capi.bptr(mask), C.byref(info)))
-        self._note_solve(info.value)
-        if info.value == 0:
-            return
         if info.value == capi.SOLVE_TIMED_OUT:
             import warnings
             warnings.warn('pysfm_amd: the device solve of the reduced system timed out (status 0x%x): a solver fault, '
                           'not a property of the matrix; solving through LU' % info.value, RuntimeWarning)
-        elif info.value > 0 and n > self.lu_fallback_max_unknowns:
+            self._check(self._lib.ba_set_option(self._h, b'solver', b'lu'))
+            try:
+                self._check(self._lib.ba_solve_reduced(self._h, capi.bptr(mask), C.byref(info)))
+            finally:
+                self._check(self._lib.ba_set_option(self._h, b'solver', b'auto'))
+        self._note_solve(info.value)
+        if info.value != 0:
             raise ReducedSystemSingular
-        keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
-        dC = np.zeros(n)
-        dC[keep] = self._solve_dense(keep)
-        self._host_dC = dC.reshape(-1, 6)
-
-    def _solve_dense(self, keep):
-        n = len(keep)
-        if n == 0:
-            return np.zeros(0)
-        torch = self._torch
-        if torch is None:
-            raise capi.HipDeviceError('the dense reduced solve needs torch with a visible GPU for its device buffers')
-        dev = torch.device('cuda', self.device)
-        if self._A_t is None or self._A_t.numel() < n * n:
-            self._A_t = torch.empty(n * n, dtype=torch.float64, device=dev)
-            self._rhs_t = torch.empty(max(n, self.nco * 6), dtype=torch.float64, device=dev)
-        A = self._A_t[:n * n].view(n, n)
-        rhs = self._rhs_t[:n]
-        self._check(self._lib.ba_flatten_reduced(self._h, capi.iptr(keep), n, C.c_void_p(A.data_ptr()),
-                                                 C.c_void_p(rhs.data_ptr())))
-        # only systems the device Cholesky solvers refused get here (not positive definite, or too large for
-        # them): rocSOLVER's Cholesky first when the size was the reason (2-3x faster than its LU: n = 3000:
-        # 10.5 ms against 28 ms), then LU, the reference's own factorisation, with its singular-matrix semantics
-        with self.stream_ctx():
-            if n > DEVICE_CHOLESKY_MAX_UNKNOWNS:
-                L, info = torch.linalg.cholesky_ex(A, check_errors=False)
-                if int(info.item()) == 0:
-                    return torch.cholesky_solve(rhs.unsqueeze(1), L).squeeze(1).cpu().numpy()
-            x, info = torch.linalg.solve_ex(A, rhs.unsqueeze(1), check_errors=False)
-            if int(info.item()) != 0:
-                raise ReducedSystemSingular
-            return x.squeeze(1).cpu().numpy()
 
     def get_solution(self):
         """dC[nco,6] of the last solve_reduced()."""
-        if self._host_dC is not None:
-            return self._host_dC.copy()
         dC = np.empty((self.nco, 6))
         self._check(self._lib.ba_get_solution(self._h, capi.dptr(dC)))
         return dC
 
     def backsubstitute(self, which, dC=None, fetch=True):
         """dC None: use the solution of solve_reduced()."""
-        if dC is None:
-            dC = self._host_dC
         if dC is not None:
             dC = capi.f64(dC, (-1, 6))
             assert len(dC) == self.nco
         dP = np.empty((self.nt, 3)) if fetch else None
         self._check(self._lib.ba_backsubstitute(self._h, which, capi.dptr(dC), capi.dptr(dP)))
-        self._host_dC = None
         return dP
 
     def apply_update(self, src, dst, motion=None, structure=None):
@@ -354,7 +301,6 @@ class HipBackend(object):
         not apply (band too wide / not SPD) and the caller must take the stepwise path."""
         mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
         cost, info = C.c_double(), C.c_int32()
-        self._host_dC = None
         self._check(self._lib.ba_lm_trial(self._h, float(damping), -1.0 if rcond is None else float(rcond),
                                           capi.bptr(mask), C.byref(cost), C.byref(info)))
         self._note_solve(info.value)
@@ -363,7 +309,6 @@ class HipBackend(object):
     # the same trial in two halves around the all-reduce of the sharded adjuster
     def lm_trial_begin(self, damping, rcond):
         """ba_lm_trial_begin: linearise + Schur reduction of this rank's shard, nothing read back."""
-        self._host_dC = None
         self._check(self._lib.ba_lm_trial_begin(self._h, float(damping), -1.0 if rcond is None else float(rcond)))
 
     def lm_trial_end(self, cam_param_mask=None):
@@ -427,14 +372,12 @@ class HipBackend(object):
         self._note_solve(0)
 
     def _note_solve(self, info):
-        """last_solve_kind: the device solver ba_solve_reduced launched ('bcr', 'bcr_wide', 'band',
-        'dense_cholesky', 'bcr_big'; 'bcr_lu' = the cyclic reduction with LU nodes, after 'bcr' found the system not positive definite); last_solve_path: 'band' / 'dense_cholesky' when it succeeded, 'dense' when
-        the flattened system went (or has to go) through LU instead."""
+        """last_solve_kind: the device solver whose state ba_solve_reduced left ('bcr', 'bcr_wide', 'band', 'dense_cholesky',
+        'bcr_big'; 'bcr_lu' / 'band_lu' = LU with partial pivoting after the Cholesky solver found the system not positive
+        definite, or by option); last_solve_path: 'lu' for those two, 'dense_cholesky' or 'band' for the Cholesky solvers."""
         self.last_solve_kind = capi.SOLVE_KINDS[self._lib.ba_last_solve_kind(self._h)]
-        if info != 0:
-            self.last_solve_path = 'dense'
-        else:
-            self.last_solve_path = 'dense_cholesky' if self.last_solve_kind == 'dense_cholesky' else 'band'
+        self.last_solve_path = 'lu' if self.last_solve_kind in ('bcr_lu', 'band_lu') else \
+            'dense_cholesky' if self.last_solve_kind == 'dense_cholesky' else 'band'
 
     def trial_result(self):
         """Device tensor [TRIAL_PARTIALS cost partials | singular point blocks | solver status]."""

@@ -245,9 +245,15 @@ class Bundle(object):
         in the order the reference's loops visit them (tracks outer, cameras inner;
         bundle_adjuster.py:222-226)."""
         cam, trk, z = self.observation_table()
+        cids = np.asarray(camera_ids, np.int64).reshape(-1)
+        tids = np.asarray(track_ids, np.int64).reshape(-1)
+        ascending = lambda a: len(a) < 2 or bool(np.all(a[1:] > a[:-1]))
+        everything = lambda a, n: len(a) == n and (n == 0 or (a[0] == 0 and a[-1] == n - 1 and ascending(a)))
+        if everything(cids, len(self.cameras)) and everything(tids, len(self.tracks)):
+            # all cameras x all tracks in their own order (BundleAdjuster(bundle) without ids): the table as it is
+            return np.ascontiguousarray(cam, np.int32), np.ascontiguousarray(trk, np.int32), np.ascontiguousarray(z, float)
         cpos = -np.ones(max(len(self.cameras), 1), np.int64)
-        cpos[np.asarray(camera_ids, np.int64)] = np.arange(len(camera_ids))
-        tids = np.asarray(track_ids, np.int64)
+        cpos[cids] = np.arange(len(cids))
         if len(tids) * 4 < len(self.tracks) and len(trk):
             # few of many tracks (the sliding-window caller: 100 of 1000, window after window): only their rows of the
             # table (sorted by track) instead of a pass over all of it
@@ -264,12 +270,16 @@ class Bundle(object):
             ci, ti, zz = cpos[cam[rows]], np.repeat(np.arange(len(tids)), cnt), z[rows]
             keep = ci >= 0
             ci, ti, zz = ci[keep], ti[keep], zz[keep]
+            in_order = ascending(cids)                      # (rows come track position by track position, cameras ascending by id)
         else:
             tpos = -np.ones(max(len(self.tracks), 1), np.int64)
             tpos[tids] = np.arange(len(tids))
             ci, ti = cpos[cam], tpos[trk]
             keep = (ci >= 0) & (ti >= 0)
             ci, ti, zz = ci[keep], ti[keep], z[keep]
+            in_order = ascending(cids) and ascending(tids)  # (the table is sorted by (track id, camera id): so is what is left of it)
+        if in_order:
+            return ci.astype(np.int32), ti.astype(np.int32), np.ascontiguousarray(zz)
         order = np.lexsort((ci, ti))
         return ci[order].astype(np.int32), ti[order].astype(np.int32), np.ascontiguousarray(zz[order])
 

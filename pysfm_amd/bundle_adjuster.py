@@ -26,25 +26,53 @@ from copy import copy
 import numpy as np
 
 from ._capi import PARAMS_CUR, PARAMS_TRIAL, SOLVE_TIMED_OUT as SOLVER_TIMED_OUT
-from .backend import LU_FALLBACK_MAX_UNKNOWNS, ReducedSystemSingular
+from .backend import ReducedSystemSingular
 from .sensor_model import device_params_of
 
 
 ############################################################################
-def select(L, mask):
-    """Subset of L by boolean mask or by explicit ids (bundle_adjuster.py:11-24)."""
+def _select_arrays(L, mask):
+    """select() on arrays: (subset, positions of the subset in L), both as int64 arrays."""
     L = np.asarray(L)
     mask = np.asarray(mask)
     if mask.dtype.kind == 'b':
         assert len(mask) == len(L)
-        subset = L[mask]
-    else:
-        assert mask.dtype.kind == L.dtype.kind
-        assert set(mask.tolist()).issubset(L.tolist()), 'Mask contained some items not in L'
-        subset = mask
-    lookup = {v: i for i, v in enumerate(L.tolist())}
-    subset_indices = [lookup[v] for v in subset.tolist()]
-    return subset, subset_indices
+        idx = np.nonzero(mask)[0]
+        return L[idx], idx
+    assert mask.dtype.kind == L.dtype.kind
+    order = np.argsort(L, kind='stable')
+    where = np.searchsorted(L, mask, sorter=order) if len(L) else np.zeros(len(mask), np.int64)
+    ok = len(L) > 0 and np.all(where < len(L))
+    idx = order[np.minimum(where, max(len(L) - 1, 0))] if len(L) else where
+    assert ok and np.array_equal(L[idx], mask), 'Mask contained some items not in L'
+    return mask, idx
+
+
+def select(L, mask):
+    """Subset of L by boolean mask or by explicit ids (bundle_adjuster.py:11-24)."""
+    subset, idx = _select_arrays(L, mask)
+    return subset, idx.tolist()
+
+
+def _id_list(name):
+    """The reference keeps its id / index lists as Python lists (callers read them: bundle_adjuster_unittest.py:38); at a
+    million tracks building them costs more than the whole device-side set-up, so they live as arrays and become lists
+    when somebody asks."""
+    arr, cache = '_%s_arr' % name, '_%s_list' % name
+
+    def get(self):
+        lst = self.__dict__.get(cache)
+        if lst is None:
+            a = self.__dict__.get(arr)
+            if a is None:
+                return None
+            lst = self.__dict__[cache] = a.tolist()
+        return lst
+
+    def put(self, value):
+        self.__dict__[arr] = np.asarray(value, np.int64).reshape(-1)
+        self.__dict__[cache] = None
+    return property(get, put)
 
 
 ############################################################################
@@ -61,16 +89,25 @@ class BundleAdjuster(object):
     # (bundle_adjuster.py:37).
     SCHUR_COMPLIMENT_PINV_THRESHOLD = 1e-5
 
-    def __init__(self, bundle=None, backend=None, device=0, comm=None, verbose=True, lu_fallback_max_unknowns=None):
+    # ids / positions of the selected and of the optimised cameras and tracks (bundle_adjuster.py:63-101): lists, as in the reference
+    camera_ids = _id_list('camera_ids')
+    track_ids = _id_list('track_ids')
+    optim_camera_ids = _id_list('optim_camera_ids')
+    optim_camera_indices = _id_list('optim_camera_indices')
+    optim_track_ids = _id_list('optim_track_ids')
+    optim_track_indices = _id_list('optim_track_indices')
+
+    @property
+    def camera_id_set(self):
+        return set(self.camera_ids)
+
+    def __init__(self, bundle=None, backend=None, device=0, comm=None, verbose=True):
         '''bundle: a Bundle (ours, or any object with the reference Bundle's attributes).
         backend: compute backend; default = a new HipBackend on `device`.
         comm: optional pysfm_amd.distributed.ShardComm - this process then holds one
         shard of the tracks and the reduced camera system is all-reduced over RCCL.
-        lu_fallback_max_unknowns: a reduced system the device Cholesky rejects as not positive
-        definite is solved by LU like the reference's (numpy.linalg.solve, bundle_adjuster.py:303)
-        up to this many unknowns and reported as ill-conditioned beyond (None = the backend's
-        default, backend.LU_FALLBACK_MAX_UNKNOWNS; float('inf') = strict reference behaviour).'''
-        self._lu_max = lu_fallback_max_unknowns
+        A reduced system the device Cholesky finds not positive definite is solved again on the device by LU with
+        partial pivoting, like the reference's (numpy.linalg.solve, bundle_adjuster.py:303), at any size.'''
         self.num_steps = 0
         self.converged = False
         self.costs = []
@@ -97,8 +134,6 @@ class BundleAdjuster(object):
         if self._backend is None:
             from .backend import HipBackend      # raises if libpysfm_ba.so / the GPU is missing
             self._backend = HipBackend(self._device)
-        if self._lu_max is not None and hasattr(self._backend, 'lu_fallback_max_unknowns'):
-            self._backend.lu_fallback_max_unknowns = self._lu_max
         if self._comm is not None and not getattr(self, '_comm_checked', False):
             # the shards' collectives move into the library when they can (RCCL on the handle's own stream);
             # every rank takes the same decision (ShardComm.enable_direct agrees on it)
@@ -119,7 +154,10 @@ class BundleAdjuster(object):
             for pos, idx in enumerate(self.camera_ids):
                 b.cameras[idx].R = R[pos].copy()
                 b.cameras[idx].t = t[pos].copy()
-            b.reconstruction[np.asarray(self.track_ids, int)] = X
+            if self._all_tracks:
+                b.reconstruction = X
+            else:
+                b.reconstruction[self._track_ids_arr] = X
             self._host_bundle = b
             self._host_stale = False
         return self._host_bundle
@@ -128,13 +166,14 @@ class BundleAdjuster(object):
     def bundle(self, b):
         self._host_bundle = b
         self._host_stale = False
-        if getattr(self, 'camera_ids', None) is not None:
+        if self.camera_ids is not None:
             self._upload(b, PARAMS_CUR)
 
     def _params_of(self, bundle):
         R = np.array([bundle.cameras[i].R for i in self.camera_ids], float).reshape(-1, 3, 3)
         t = np.array([bundle.cameras[i].t for i in self.camera_ids], float).reshape(-1, 3)
-        X = np.asarray(bundle.reconstruction, float)[np.asarray(self.track_ids, int)].reshape(-1, 3)
+        X = np.asarray(bundle.reconstruction, float)
+        X = (X if self._all_tracks else X[self._track_ids_arr]).reshape(-1, 3)
         return R, t, X
 
     def _upload(self, bundle, which):
@@ -142,7 +181,8 @@ class BundleAdjuster(object):
         self.backend.set_params(which, *params)
         if which == PARAMS_CUR:
             self._cur_cost = None                    # cached cost of the current set
-            self._uploaded_cur = params              # what the device's current set holds (compute_cost compares)
+            # what the device's current set holds (compute_cost compares) - a copy where `params` aliases the caller's arrays
+            self._uploaded_cur = params[:2] + (params[2].copy() if self._all_tracks else params[2],)
 
     # ------------------------------------------------------------------ set_bundle
     def set_bundle(self, bundle, camera_ids=None, track_ids=None, camera_mask=None, track_mask=None):
@@ -154,56 +194,52 @@ class BundleAdjuster(object):
         self._host_bundle = bundle
         self._host_stale = False
 
+        ncam_all, ntrk_all = len(bundle.cameras), len(bundle.tracks)
         if camera_ids is None:
-            self.camera_ids = list(range(len(bundle.cameras)))
+            cam_ids = np.arange(ncam_all, dtype=np.int64)
         else:
-            self.camera_ids = [c for c in camera_ids]
-            if self.camera_ids:
-                assert isinstance(self.camera_ids[0], (int, np.integer))
-                assert min(self.camera_ids) >= 0
-                assert max(self.camera_ids) < len(bundle.cameras)
-            self.camera_ids = [int(c) for c in self.camera_ids]
-
+            cam_ids = np.asarray(list(camera_ids) if not isinstance(camera_ids, np.ndarray) else camera_ids)
+            if len(cam_ids):
+                assert cam_ids.dtype.kind in 'iu'
+                assert cam_ids.min() >= 0
+                assert cam_ids.max() < ncam_all
+            cam_ids = cam_ids.astype(np.int64).reshape(-1)
         if track_ids is None:
-            self.track_ids = list(range(len(bundle.tracks)))
+            trk_ids = np.arange(ntrk_all, dtype=np.int64)
         else:
-            self.track_ids = [t for t in track_ids]
-            if self.track_ids:              # (a shard of a sharded adjuster may be empty)
-                assert isinstance(self.track_ids[0], (int, np.integer))
-                assert min(self.track_ids) >= 0
-                assert max(self.track_ids) < len(bundle.tracks)
-            self.track_ids = [int(t) for t in self.track_ids]
-
-        self.camera_id_set = set(self.camera_ids)
+            trk_ids = np.asarray(list(track_ids) if not isinstance(track_ids, np.ndarray) else track_ids)
+            if len(trk_ids):              # (a shard of a sharded adjuster may be empty)
+                assert trk_ids.dtype.kind in 'iu'
+                assert trk_ids.min() >= 0
+                assert trk_ids.max() < ntrk_all
+            trk_ids = trk_ids.astype(np.int64).reshape(-1)
+        self.camera_ids, self.track_ids = cam_ids, trk_ids
+        self._all_tracks = track_ids is None or (len(trk_ids) == ntrk_all and np.array_equal(trk_ids, np.arange(ntrk_all)))
 
         if camera_mask is None:
-            assert len(self.camera_ids) > 1, 'Cannot optimize just one camera'
-            self.optim_camera_ids = self.camera_ids[1:]
-            self.optim_camera_indices = list(range(1, len(self.camera_ids)))
+            assert len(cam_ids) > 1, 'Cannot optimize just one camera'
+            self.optim_camera_ids, self.optim_camera_indices = cam_ids[1:], np.arange(1, len(cam_ids))
         else:
-            ids, self.optim_camera_indices = select(self.camera_ids, camera_mask)
-            self.optim_camera_ids = [int(c) for c in ids]
-
+            self.optim_camera_ids, self.optim_camera_indices = _select_arrays(cam_ids, camera_mask)
         if track_mask is None:
-            self.optim_track_ids = copy(self.track_ids)
-            self.optim_track_indices = list(range(len(self.track_ids)))
+            self.optim_track_ids, self.optim_track_indices = trk_ids, np.arange(len(trk_ids))
         else:
-            ids, self.optim_track_indices = select(self.track_ids, track_mask)
-            self.optim_track_ids = [int(t) for t in ids]
+            self.optim_track_ids, self.optim_track_indices = _select_arrays(trk_ids, track_mask)
+        optim_camera_indices, optim_track_indices = self._optim_camera_indices_arr, self._optim_track_indices_arr
 
-        assert len(self.optim_track_ids) == len(self.optim_track_indices)
-        assert len(self.optim_camera_ids) == len(self.optim_camera_indices)
-
-        nc, nt = len(self.camera_ids), len(self.track_ids)
+        nc, nt = len(cam_ids), len(trk_ids)
         # device problem: observation SoA ordered by track position, flags, positions
         if hasattr(bundle, 'select_observations'):
-            obs_cam, obs_pt, obs_z = bundle.select_observations(self.camera_ids, self.track_ids)
+            obs_cam, obs_pt, obs_z = bundle.select_observations(cam_ids, trk_ids)
         else:
             obs_cam, obs_pt, obs_z = _select_observations_generic(bundle, self.camera_ids, self.track_ids)
         cam_opt_pos = -np.ones(nc, np.int32)
-        cam_opt_pos[np.asarray(self.optim_camera_indices, int)] = np.arange(len(self.optim_camera_indices))
-        pt_opt = np.zeros(nt, np.uint8)
-        pt_opt[np.asarray(self.optim_track_indices, int)] = 1
+        cam_opt_pos[optim_camera_indices] = np.arange(len(optim_camera_indices))
+        if track_mask is None:
+            pt_opt = np.ones(nt, np.uint8)
+        else:
+            pt_opt = np.zeros(nt, np.uint8)
+            pt_opt[optim_track_indices] = 1
         self._cam_opt_pos, self._pt_opt = cam_opt_pos, pt_opt
         self._nobs = len(obs_cam)
 
@@ -333,10 +369,7 @@ class BundleAdjuster(object):
                 next_cost = cost
             elif info == SOLVER_TIMED_OUT:
                 self._note_solver_timeout(damping)                 # a solver bug, not a property of the system: said loudly,
-            elif info > 0 and not self._device_lu_applies(be) and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):
-                self._note_ill_conditioned(be, damping)
-                return None, None                              # not positive definite, too large for LU: ill-conditioned
-            # (otherwise the stepwise path below solves again: cyclic reduction with LU nodes on the device, or LU of the flattened system)
+            # (info > 0: not positive definite - the stepwise path below solves again, by LU with partial pivoting on the device)
         elif self._comm is not None and hasattr(be, 'lm_trial_begin'):
             # sharded: the same batch in two halves around the all-reduce of [S | b]; the ranks' trial
             # costs are summed on the device, one synchronisation per trial
@@ -367,9 +400,6 @@ class BundleAdjuster(object):
                     next_cost = cost
                 elif info == SOLVER_TIMED_OUT:
                     self._note_solver_timeout(damping)
-                elif info > 0 and not self._device_lu_applies(be) and be.nco * 6 > getattr(be, 'lu_fallback_max_unknowns', LU_FALLBACK_MAX_UNKNOWNS):
-                    self._note_ill_conditioned(be, damping)
-                    return None, None
         if next_cost is None:
             try:
                 self._compute_update_device(damping, param_mask, fetch=False)
@@ -385,23 +415,6 @@ class BundleAdjuster(object):
             self._cur_cost = next_cost
             return True, next_cost
         return False, next_cost
-
-    @staticmethod
-    def _device_lu_applies(be):
-        """A reduced system the device Cholesky reported as not positive definite is solved again on the device by the cyclic
-        reduction with LU nodes (ba_solve_reduced, option device_lu) - the reference's own LU semantics at any size - when the
-        solver was the narrow cyclic reduction and the adjuster is not sharded over ranks with the solve spread over them."""
-        return bool(getattr(be, 'device_lu', False)) and getattr(be, 'last_solve_kind', None) == 'bcr' and not getattr(be, 'dist_on', False)
-
-    def _note_ill_conditioned(self, be, damping):
-        """The device Cholesky found the reduced system not positive definite and it is too large for the LU
-        fallback: the trial is reported as ill-conditioned (the LM loop raises the damping, as it does for the
-        reference's LinAlgError).  Counted, and said once, so that a trajectory that differs from the
-        reference's LU-based one can be diagnosed (lu_fallback_max_unknowns=float('inf') is the strict mode)."""
-        self.cholesky_rejections = getattr(self, 'cholesky_rejections', 0) + 1
-        if self.cholesky_rejections == 1:
-            self._say('reduced system (%d unknowns) not positive definite at damping %g: reported as ill-conditioned '
-                      '(LU fallback only up to %s unknowns)' % (be.nco * 6, damping, getattr(be, 'lu_fallback_max_unknowns', 0)))
 
     def _note_solver_timeout(self, damping):
         """A workgroup of the one-launch cyclic reduction gave up waiting for its neighbours (status word
@@ -467,8 +480,8 @@ class BundleAdjuster(object):
             be.solve_reduced(None if np.all(cam_param_mask) else cam_param_mask)
         except ReducedSystemSingular:
             raise NormalEquationsIllconditioned
-        if getattr(be, 'last_solve_kind', None) == 'bcr_lu':
-            self.lu_node_solves = getattr(self, 'lu_node_solves', 0) + 1      # (diagnostics: how often the LU semantics were needed)
+        if getattr(be, 'last_solve_path', None) == 'lu':
+            self.lu_solves = getattr(self, 'lu_solves', 0) + 1               # (diagnostics: how often the LU semantics were needed)
         dC = be.get_solution() if fetch else None
         dP = be.backsubstitute(PARAMS_CUR, None, fetch=fetch)
         return dC, dP
@@ -483,7 +496,7 @@ class BundleAdjuster(object):
         '''Solve the normal equations using the Schur complement.  Returns
         (update-for-cameras [nco,6], update-for-points [nto,3]) - bundle_adjuster.py:176-208.'''
         dC, dP = self._compute_update_device(damping, param_mask, fetch=True)
-        return -dC, -dP[np.asarray(self.optim_track_indices, int)]
+        return -dC, -dP[self._optim_track_indices_arr]
 
     def prepare_schur_complement(self):
         '''Hessian blocks HCC, HPP, HCP and gradients bC, bP (bundle_adjuster.py:211-234).'''
@@ -582,7 +595,7 @@ class BundleAdjuster(object):
     def backsubstitute(self, dC):
         '''Point updates from the camera update (bundle_adjuster.py:316-331).'''
         dP = self.backend.backsubstitute(PARAMS_CUR, np.asarray(dC, float), fetch=True)
-        return dP[np.asarray(self.optim_track_indices, int)]
+        return dP[self._optim_track_indices_arr]
 
     # ------------------------------------------------------------------ parameter update
     def _apply_on_device(self, motion, structure, bundle):
@@ -605,7 +618,7 @@ class BundleAdjuster(object):
         '''reconstruction[idx] += delta for the optimised tracks (bundle_adjuster.py:340-343).'''
         assert np.shape(delta) == (len(self.optim_track_ids), 3)
         full = np.zeros((len(self.track_ids), 3))
-        full[np.asarray(self.optim_track_indices, int)] = delta
+        full[self._optim_track_indices_arr] = delta
         _, _, X = self._apply_on_device(np.zeros((len(self.optim_camera_ids), 6)), full, bundle)
         for pos, idx in zip(self.optim_track_indices, self.optim_track_ids):
             bundle.reconstruction[idx] = X[pos]

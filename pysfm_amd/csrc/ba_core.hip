@@ -37,15 +37,6 @@ hipError_t ensure_lds_attr(ba_handle* h, const void* fn) {
   return e;
 }
 
-// Host-facing per-point / per-observation arrays go through the internal order of ba_set_problem:
-// rows of w doubles, perm[i] = the caller's index of internal row i.
-void rows_to_internal(const std::vector<int>& perm, const double* src, double* dst, int w) {
-  for (size_t i = 0; i < perm.size(); ++i) std::memcpy(dst + i * w, src + (size_t)perm[i] * w, w * sizeof(double));
-}
-void rows_to_caller(const std::vector<int>& perm, const double* src, double* dst, int w) {
-  for (size_t i = 0; i < perm.size(); ++i) std::memcpy(dst + (size_t)perm[i] * w, src + i * w, w * sizeof(double));
-}
-
 DevProblem dev_problem(const ba_handle* h) {
   DevProblem P;
   P.nc = h->nc; P.nt = h->nt; P.nco = h->nco; P.hb = h->hb; P.nobs = h->nobs;
@@ -72,16 +63,40 @@ int ensure_reduced(ba_handle* h) {
   return BA_OK;
 }
 
-int download_rows(ba_handle* h, const std::vector<int>& perm, const double* dev, double* host, size_t n, int w) {
+// Host-facing per-point / per-observation arrays go through the internal order of ba_set_problem on the DEVICE
+// (k_rows_permute: rows of w doubles, perm[i] = the caller's index of internal row i; nullptr = identity).
+__global__ __launch_bounds__(256) void k_rows_permute(long long n, int w, const int* __restrict__ perm, const double* __restrict__ src,
+                                                      double* __restrict__ dst, int to_internal) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * w) return;
+  const long long i = t / w;
+  const int a = (int)(t - i * w);
+  const long long j = perm[i];
+  if (to_internal) dst[i * w + a] = src[j * w + a];
+  else dst[j * w + a] = src[i * w + a];
+}
+
+int download_rows(ba_handle* h, const int* dev_perm, const double* dev, double* host, size_t n, int w) {
   if (n == 0) return BA_OK;
-  if (perm.empty()) {
-    HIPCHECK(h, hipMemcpyAsync(host, dev, n * w * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (dev_perm) {
+    HIPCHECK(h, h->scratch2.resize(n * w));
+    hipLaunchKernelGGL(k_rows_permute, dim3((unsigned)((n * w + 255) / 256)), dim3(256), 0, h->stream, (long long)n, w, dev_perm, dev, h->scratch2.p, 0);
+    dev = h->scratch2.p;
+  }
+  HIPCHECK(h, hipMemcpyAsync(host, dev, n * w * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (dev_perm) HIPCHECK(h, hipStreamSynchronize(h->stream));      // (scratch2 is free again)
+  return BA_OK;
+}
+
+int upload_rows(ba_handle* h, const int* dev_perm, const double* host, double* dev, size_t n, int w) {
+  if (n == 0) return BA_OK;
+  if (!dev_perm) {
+    HIPCHECK(h, hipMemcpyAsync(dev, host, n * w * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return BA_OK;
   }
-  std::vector<double> tmp(n * w);
-  HIPCHECK(h, hipMemcpyAsync(tmp.data(), dev, n * w * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
-  rows_to_caller(perm, tmp.data(), host, w);
+  HIPCHECK(h, h->scratch2.resize(n * w));
+  HIPCHECK(h, hipMemcpyAsync(h->scratch2.p, host, n * w * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_rows_permute, dim3((unsigned)((n * w + 255) / 256)), dim3(256), 0, h->stream, (long long)n, w, dev_perm, h->scratch2.p, dev, 1);
   return BA_OK;
 }
 
@@ -201,7 +216,14 @@ int ba_destroy(ba_handle* h) {
   h->HCC.release(); h->bC.release(); h->HPP.release(); h->bP.release(); h->HPPinv.release();
   h->W.release(); h->S_own.release(); h->b_own.release(); h->dC.release(); h->Ufac.release(); h->ysol.release(); h->dinv.release();
   h->bcrD.release(); h->bcrU.release(); h->bcrF.release(); h->bcrP.release(); h->bcrQ.release(); h->bcrG.release(); h->bcrGv.release(); h->bcr_order.release(); h->bcr_work.release(); h->bcr_done.release(); h->bcr_trace.release(); h->dist.rows.release(); h->dist.sep.release(); h->dist.sep_owner.release(); h->dist.root.release(); h->dist.root_owner.release(); h->dist.work.release(); h->rgroups.release(); h->rtab.release(); h->dist.order.release(); h->dist.asm_nodes.release(); h->dist.xown.release(); h->bcrL.release(); h->bcrLv.release(); h->denseA.release(); h->bigK.release(); h->fac.release(); h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); h->mask.release(); h->dP.release();
-  h->scratch.release(); h->flags.release();
+  h->scratch.release(); h->scratch2.release(); h->flags.release(); h->d_pperm.release(); h->d_operm.release();
+  {
+    auto& su = h->su;
+    su.rc.release(); su.rp.release(); su.by_pt.release(); su.cnt.release(); su.coff.release(); su.Lint.release(); su.plo.release(); su.phi.release();
+    su.iota.release(); su.crank.release(); su.flags.release(); su.vals.release(); su.key.release(); su.key2.release(); su.tkey.release(); su.tkey2.release();
+    su.rz.release(); su.rpo.release(); su.same.release(); su.tmp.release();
+    if (su.host) (void)hipHostFree(su.host);
+  }
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -324,13 +346,7 @@ int ba_set_params(ba_handle* h, int which, const double* R, const double* t, con
     std::memcpy(&packed[(size_t)i * 12 + 9], t + (size_t)i * 3, 3 * sizeof(double));
   }
   if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->cams[p].p, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  std::vector<double> Xi;
-  if (h->nt && !h->pperm.empty()) {
-    Xi.resize((size_t)h->nt * 3);
-    rows_to_internal(h->pperm, X, Xi.data(), 3);
-    X = Xi.data();
-  }
-  if (h->nt) HIPCHECK(h, hipMemcpyAsync(h->X[p].p, X, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->nt) { const int rc = upload_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, X, h->X[p].p, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   h->have_params[p] = true;
   if (which == BA_PARAMS_CUR) h->have_linearization = h->have_schur = h->have_backsub = false;
@@ -345,7 +361,7 @@ int ba_get_params(ba_handle* h, int which, double* R, double* t, double* X) {
   HIPCHECK(h, hipSetDevice(h->device));
   std::vector<double> packed((size_t)h->nc * 12);
   if (h->nc) HIPCHECK(h, hipMemcpyAsync(packed.data(), h->cams[p].p, packed.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (X) { const int rc = download_rows(h, h->pperm, h->X[p].p, X, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
+  if (X) { const int rc = download_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, h->X[p].p, X, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < h->nc; ++i) {
     if (R) std::memcpy(R + (size_t)i * 9, &packed[(size_t)i * 12], 9 * sizeof(double));

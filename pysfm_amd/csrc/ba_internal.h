@@ -134,18 +134,30 @@ struct ba_handle {
   DevBuf<int> cam_perm;
   DevBuf<CamUnit> cam_units;
   int ncam_units = 0;
-  std::vector<int> h_cam_opt_pos;
-  std::vector<unsigned char> h_pt_opt;
-  // internal order (ba_set_problem): internal point i = the caller's track pperm[i], internal observation n = the
-  // caller's operm[n]; empty = identity
-  std::vector<int> pperm, operm;
+  bool cam_units_built = false, pair_units_built = false;      // work lists of kernels off the trial's path: built on first use
+  // internal order (ba_set_problem): internal point i = the caller's track pperm[i], internal observation n = the caller's
+  // operm[n].  On the device always; the host copy of pperm only when it is not the identity (empty = identity).
+  std::vector<int> pperm;
+  DevBuf<int> d_pperm, d_operm;
+  bool operm_identity = true;
+  // per internal point, kept on the host for the work lists that are built lazily: CSR offsets, lowest / highest optimised position
+  std::vector<int> h_off, h_plo, h_phi;
+  // ba_set_problem's own device buffers (kept between calls: the sliding-window caller sets a problem per window)
+  struct Setup {
+    DevBuf<int> rc, rp, by_pt, cnt, coff, Lint, plo, phi, iota, crank, flags, vals;
+    DevBuf<unsigned long long> key, key2, tkey, tkey2;
+    DevBuf<double2> rz;
+    DevBuf<unsigned char> rpo, same, tmp;
+    void* host = nullptr;              // pinned staging for the read-backs
+    size_t host_bytes = 0;
+  } su;
 
   // parameters: cams[which] = nc x [R(9) | t(3)], X[which] = nt x 3
   DevBuf<double> cams[2], X[2];
   int cur = 0;               // physical index of BA_PARAMS_CUR
 
   // normal-equation blocks
-  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, bigK, fac, dUd, dDd, dyd, dpart, comm_dev;
+  DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, scratch2, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, bigK, fac, dUd, dDd, dyd, dpart, comm_dev;
   DevBuf<unsigned char> mask;
   DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)
   int bcr_order_n = 0;
@@ -246,11 +258,9 @@ struct ScopedTimer {
 hipError_t ensure_lds_attr(ba_handle* h, const void* fn);
 
 // Host-facing per-point / per-observation arrays go through the internal order of ba_set_problem:
-// rows of w doubles, perm[i] = the caller's index of internal row i.
-void rows_to_internal(const std::vector<int>& perm, const double* src, double* dst, int w);
-void rows_to_caller(const std::vector<int>& perm, const double* src, double* dst, int w);
+// rows of w doubles, perm[i] = the caller's index of internal row i (on the device: k_rows_permute).
 // device rows -> caller's host array (synchronises the stream when a permutation is in the way)
-int download_rows(ba_handle* h, const std::vector<int>& perm, const double* dev, double* host, size_t n, int w);
+int download_rows(ba_handle* h, const int* dev_perm, const double* dev, double* host, size_t n, int w);
 
 inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + kBlock - 1) / kBlock); }
 DevProblem dev_problem(const ba_handle* h);
@@ -295,6 +305,15 @@ int launch_wide_all(ba_handle* h, int p, double damping, bool fuse_cam);
 int wide_launches(const ba_handle* h);
 int launch_rect(ba_handle* h, int p, double damping, bool fuse_cam);
 
+// ---- ba_sort.hip (rocPRIM) and ba_problem.hip
+hipError_t sort_pairs_u64(ba_handle* h, const unsigned long long* keys_in, unsigned long long* keys_out, const int* values_in,
+                          int* values_out, size_t n, int end_bit);
+hipError_t exclusive_scan_i32(ba_handle* h, const int* in, int* out, size_t n);
+int ensure_cam_units(ba_handle* h);        // cam_perm / cam_units of k_camera_blocks
+int ensure_pair_units(ba_handle* h);       // units / chunks of k_schur_pairs
+// host rows (caller's order) -> device rows (internal order) and back; perm = h->d_pperm.p / h->d_operm.p or nullptr (identity)
+int upload_rows(ba_handle* h, const int* dev_perm, const double* host, double* dev, size_t n, int w);
+
 // ---- ba_points.hip: ba_linearize; with fuse (ba_lm_trial + MFMA reduction) the camera blocks are left to the reduction kernel
 int launch_point_blocks(ba_handle* h, int p, double* Wd);
 int launch_camera_blocks(ba_handle* h, int p, bool clear);
@@ -305,6 +324,7 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
 int solve_bcr_wide(ba_handle* h, const unsigned char* dmask);
 int solve_bcr_big(ba_handle* h, const unsigned char* dmask);
 int solve_dense_chol(ba_handle* h, const unsigned char* dmask);
+int solve_band_lu(ba_handle* h, const unsigned char* dmask);      // LU with partial pivoting, any band width (ba_band_lu.h)
 // k_bcr_assemble (ba_bcr.h): band (+ mask) -> D, U, f of the nodes of cb cameras; clears the status word
 void launch_bcr_assemble(ba_handle* h, dim3 grid, int cb, const unsigned char* dmask, double* xsol, int* done, const int* nodes);
 // ba_bcr_split.hip / ba_bcr_levels.hip: the node kernels, instantiated per cameras-per-node

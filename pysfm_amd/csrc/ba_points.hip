@@ -31,6 +31,7 @@ int launch_camera_blocks(ba_handle* h, int p, bool clear) {
     HIPCHECK(h, hipMemsetAsync(h->HCC.p, 0, (size_t)h->nc * 36 * sizeof(double), h->stream));
     HIPCHECK(h, hipMemsetAsync(h->bC.p, 0, (size_t)h->nc * 6 * sizeof(double), h->stream));
   }
+  if (int rc = ensure_cam_units(h); rc != BA_OK) return rc;      // (the camera-ordered observation lists are built on first use)
   if (h->ncam_units > 0) {
     ScopedTimer tm(h, BA_K_CAMERA_BLOCKS);
     const int per_block = kBlock / kWave;
@@ -118,10 +119,10 @@ int ba_eval_observations(ba_handle* h, int which, double* e, double* r, double* 
   }
   HIPCHECK(h, hipGetLastError());
   int rc = BA_OK;
-  if (e && rc == BA_OK) rc = download_rows(h, h->operm, de, e, N, 2);
-  if (r && rc == BA_OK) rc = download_rows(h, h->operm, dr, r, N, 2);
-  if (Jc && rc == BA_OK) rc = download_rows(h, h->operm, dJc, Jc, N, 12);
-  if (Jp && rc == BA_OK) rc = download_rows(h, h->operm, dJp, Jp, N, 6);
+  if (e && rc == BA_OK) rc = download_rows(h, h->operm_identity ? nullptr : h->d_operm.p, de, e, N, 2);
+  if (r && rc == BA_OK) rc = download_rows(h, h->operm_identity ? nullptr : h->d_operm.p, dr, r, N, 2);
+  if (Jc && rc == BA_OK) rc = download_rows(h, h->operm_identity ? nullptr : h->d_operm.p, dJc, Jc, N, 12);
+  if (Jp && rc == BA_OK) rc = download_rows(h, h->operm_identity ? nullptr : h->d_operm.p, dJp, Jp, N, 6);
   if (rc != BA_OK) return rc;
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   return BA_OK;
@@ -176,10 +177,10 @@ int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP
     hpp6.resize((size_t)h->nt * 6);
     HIPCHECK(h, hipMemcpyAsync(hpp6.data(), h->HPP.p, hpp6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
-  if (bP) { const int rc = download_rows(h, h->pperm, h->bP.p, bP, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
+  if (bP) { const int rc = download_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, h->bP.p, bP, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   if (W && h->nobs) {
     REQUIRE(h, h->W.p && h->W.n >= (size_t)h->nobs * 18, BA_ERR_STATE, "ba_get_blocks: W was not stored (ba_linearize store_W=0)");
-    const int rc = download_rows(h, h->operm, h->W.p, W, (size_t)h->nobs, 18);
+    const int rc = download_rows(h, h->operm_identity ? nullptr : h->d_operm.p, h->W.p, W, (size_t)h->nobs, 18);
     if (rc != BA_OK) return rc;
   }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -234,7 +235,7 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
     }
   }
   HIPCHECK(h, hipGetLastError());
-  if (dP) { const int rc = download_rows(h, h->pperm, h->dP.p, dP, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
+  if (dP) { const int rc = download_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, h->dP.p, dP, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   if (dC || dP) HIPCHECK(h, hipStreamSynchronize(h->stream));   // dC is caller memory
   h->have_backsub = true;
   return BA_OK;
@@ -252,14 +253,7 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   if (motion) {
     sign = 1.0;
     if (h->nco) HIPCHECK(h, hipMemcpyAsync(h->dC.p, motion, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (h->nt && !h->pperm.empty()) {
-      std::vector<double> si((size_t)h->nt * 3);
-      rows_to_internal(h->pperm, structure, si.data(), 3);
-      HIPCHECK(h, hipMemcpyAsync(h->dP.p, si.data(), si.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      HIPCHECK(h, hipStreamSynchronize(h->stream));         // `si` goes out of scope
-    } else if (h->nt) {
-      HIPCHECK(h, hipMemcpyAsync(h->dP.p, structure, (size_t)h->nt * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    }
+    if (h->nt) { const int rc = upload_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, structure, h->dP.p, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
     h->have_backsub = h->have_solution = false;   // dC / dP now hold the caller's update
   } else {
     REQUIRE(h, h->have_backsub, BA_ERR_STATE, "ba_apply_update: no update on the device (call ba_backsubstitute)");
@@ -295,7 +289,7 @@ int ba_triangulate(ba_handle* h, int which, double rcond, double* X) {
   HIPCHECK(h, hipGetLastError());
   if (which == BA_PARAMS_CUR) h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
   if (X && h->nt) {
-    const int rc = download_rows(h, h->pperm, h->X[p].p, X, (size_t)h->nt, 3);
+    const int rc = download_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, h->X[p].p, X, (size_t)h->nt, 3);
     if (rc != BA_OK) return rc;
     HIPCHECK(h, hipStreamSynchronize(h->stream));
   }

@@ -1,186 +1,97 @@
 // ba_problem.hip - ba_set_problem: the internal order of points and observations and the work lists of the kernels.
+//
+// The observations arrive in any order (the reference walks `tracks` and their `measurements` dicts as they come,
+// bundle_adjuster.py:222-226).  Everything that touches every observation runs on the device (ba_setup_kernels.h): range
+// checks, ordering by (track, camera rank) - skipped when the input is already in that order -, the duplicate check, the
+// order of the tracks, CSR offsets, the gather into the internal arrays, the per-point summaries, the (point, window
+// column) tables.  The host plans the work lists from the per-point summaries (a few passes over the POINTS) and uploads
+// them.  Work lists of kernels that are not on the trial's path (k_camera_blocks, k_schur_pairs) are built on first use.
 #include "ba_internal.h"
 
+#include "ba_setup_kernels.h"
 
 using namespace ba;
 
-extern "C" {
+namespace {
 
-int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
-                   const int32_t* obs_pt, const double* obs_z, const double* K,
-                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
-  if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
-  REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
-  REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
-          "ba_set_problem: NULL argument");
-  REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
-  HIPCHECK(h, hipSetDevice(h->device));
+inline int bits_for(unsigned long long count) {      // bits that hold 0 .. count - 1
+  int b = 1;
+  while (b < 63 && (1ull << b) < count) ++b;
+  return b;
+}
 
-  // validate; caller-order CSR by point (any observation order is accepted: stable counting sort)
-  std::vector<int> coff((size_t)nt + 1, 0);
-  for (int64_t n = 0; n < nobs; ++n) {
-    const int c = obs_cam[n], k = obs_pt[n];
-    if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%lld]=%d out of range", (long long)n, c);
-    if (k < 0 || k >= nt) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%lld]=%d out of range", (long long)n, k);
-    coff[(size_t)k + 1] += 1;
-  }
-  for (int k = 0; k < nt; ++k) coff[(size_t)k + 1] += coff[k];
-  // optimised-camera positions must be a permutation of 0..nco-1
-  int nco = 0;
-  for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) ++nco;
-  {
-    std::vector<char> seen((size_t)nco, 0);
+hipError_t pinned_staging(ba_handle* h, size_t bytes) {
+  auto& su = h->su;
+  if (su.host && su.host_bytes >= bytes) return hipSuccess;
+  if (su.host) (void)hipHostFree(su.host);
+  su.host = nullptr; su.host_bytes = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipHostMalloc(&su.host, want, hipHostMallocDefault);
+  if (e == hipSuccess) su.host_bytes = want;
+  return e;
+}
+
+inline unsigned grid_for(long long n) { return (unsigned)std::max<long long>(1, (n + 255) / 256); }
+
+}  // namespace
+
+namespace ba {
+
+// camera-ordered view of the observations for k_camera_blocks (only when HCC / bC are asked for through the API or a
+// reduction kernel that does not form the camera blocks itself is in use): a stable sort by camera on the device, units on the host
+int ensure_cam_units(ba_handle* h) {
+  if (h->cam_units_built) return BA_OK;
+  const int nc = h->nc;
+  const long long N = h->nobs;
+  auto& su = h->su;
+  std::vector<CamUnit> cam_units;
+  if (N > 0 && nc > 0) {
+    HIPCHECK(h, su.cnt.resize((size_t)nc + 1));
+    HIPCHECK(h, su.key.resize((size_t)N)); HIPCHECK(h, su.key2.resize((size_t)N)); HIPCHECK(h, su.vals.resize((size_t)N));
+    HIPCHECK(h, h->cam_perm.resize((size_t)N));
+    HIPCHECK(h, hipMemsetAsync(su.cnt.p, 0, ((size_t)nc + 1) * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_setup_cam_hist, dim3(grid_for(N)), dim3(256), 0, h->stream, N, h->obs_cam.p, su.cnt.p, su.key.p);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(N)), dim3(256), 0, h->stream, (int)N, su.vals.p);
+    HIPCHECK(h, sort_pairs_u64(h, su.key.p, su.key2.p, su.vals.p, h->cam_perm.p, (size_t)N, bits_for((unsigned long long)nc)));
+    std::vector<int> cnt((size_t)nc);
+    HIPCHECK(h, hipMemcpyAsync(cnt.data(), su.cnt.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    // one wavefront per unit: few cameras with long observation lists (dense visibility) would leave the chip
+    // empty at kCamChunk observations per unit, so shrink the chunk until there are about 500 units (measured: 100 000 observations of 100 cameras: 28 us at 2048 per unit, 14 at 256, 19 at 64); many
+    // cameras with ~1000 observations each keep one unit per camera (one atomic result per camera)
+    const int cam_chunk = (int)std::min<int64_t>(kCamChunk, std::max<int64_t>(64, (N / 512 + 63) / 64 * 64));
+    int begin = 0;
     for (int i = 0; i < nc; ++i) {
-      const int p = cam_opt_pos[i];
-      if (p < 0) continue;
-      if (p >= nco || seen[p]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: cam_opt_pos is not a permutation of 0..nco-1");
-      seen[p] = 1;
+      const int end = begin + cnt[i];
+      for (int s = begin; s < end; s += cam_chunk) cam_units.push_back({i, s, std::min(s + cam_chunk, end)});
+      begin = end;
     }
   }
-  // ---- internal order.  The reference visits tracks and their measurements in any order
-  // (bundle_adjuster.py:222-226); the kernels want (a) a track's observations by ascending optimised-camera
-  // position, frozen cameras first, and (b) tracks with identical camera lists next to each other, lists
-  // ordered by their first optimised camera (image sequences: the reduction's LDS window slides along the
-  // band).  So: rank the cameras (frozen ones by index, then the optimised ones by position), sort each
-  // track's observations by rank, sort the tracks by (first optimised position, rank list).  `pperm` /
-  // `operm` map internal point / observation indices to the caller's; every host-facing array goes through
-  // them (identity for a scene that already comes in this order: then they stay empty).
-  std::vector<int> by_pt((size_t)nobs);                      // caller observation ids, grouped by caller point
-  {
-    std::vector<int> cursor(coff.begin(), coff.end() - 1);
-    for (int64_t n = 0; n < nobs; ++n) by_pt[(size_t)cursor[obs_pt[n]]++] = (int)n;
+  HIPCHECK(h, h->cam_units.resize(std::max<size_t>(1, cam_units.size())));
+  if (!cam_units.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->cam_units.p, cam_units.data(), cam_units.size() * sizeof(CamUnit), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
   }
-  std::vector<int> crank((size_t)nc);
-  {
-    int f = 0;
-    const int nfrozen = nc - nco;
-    for (int i = 0; i < nc; ++i) crank[i] = cam_opt_pos[i] < 0 ? f++ : nfrozen + cam_opt_pos[i];
-  }
-  const bool sort_points = h->opt.sort_points;
-  if (sort_points) {
-    for (int k = 0; k < nt; ++k) {
-      int* b0 = by_pt.data() + coff[k];
-      int* b1 = by_pt.data() + coff[(size_t)k + 1];
-      auto less = [&](int a, int b) { return crank[obs_cam[a]] < crank[obs_cam[b]]; };
-      if (!std::is_sorted(b0, b1, less)) std::stable_sort(b0, b1, less);
-    }
-  }
-  for (int k = 0; k < nt; ++k) {                             // each (camera, track) pair at most once (bundle.py: a dict per track)
-    std::vector<int> seen;
-    const int L = coff[(size_t)k + 1] - coff[k];
-    if (sort_points) {
-      for (int q = coff[k] + 1; q < coff[(size_t)k + 1]; ++q)
-        if (obs_cam[by_pt[q]] == obs_cam[by_pt[q - 1]])
-          return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in camera %d", k, obs_cam[by_pt[q]]);
-    } else if (L > 1) {
-      seen.assign(by_pt.begin() + coff[k], by_pt.begin() + coff[(size_t)k + 1]);
-      for (int& v : seen) v = obs_cam[v];
-      std::sort(seen.begin(), seen.end());
-      if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
-        return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in one camera", k);
-    }
-  }
-  std::vector<int> pperm((size_t)nt);
-  for (int k = 0; k < nt; ++k) pperm[k] = k;
-  if (sort_points && nt > 1) {
-    std::vector<int> minpos((size_t)nt, INT32_MAX);
-    for (int k = 0; k < nt; ++k)
-      for (int q = coff[k]; q < coff[(size_t)k + 1]; ++q) {
-        const int p = cam_opt_pos[obs_cam[by_pt[q]]];
-        if (p >= 0) { minpos[k] = p; break; }               // (sorted by rank: the first optimised one is the smallest)
-      }
-    auto less = [&](int a, int b) {
-      if (minpos[a] != minpos[b]) return minpos[a] < minpos[b];
-      const int la = coff[(size_t)a + 1] - coff[a], lb = coff[(size_t)b + 1] - coff[b];
-      const int* pa = by_pt.data() + coff[a];
-      const int* pb = by_pt.data() + coff[b];
-      for (int q = 0; q < std::min(la, lb); ++q) {
-        const int ra = crank[obs_cam[pa[q]]], rb = crank[obs_cam[pb[q]]];
-        if (ra != rb) return ra < rb;
-      }
-      return la < lb;
-    };
-    if (!std::is_sorted(pperm.begin(), pperm.end(), less)) std::stable_sort(pperm.begin(), pperm.end(), less);
-  }
-  // internal observation arrays + CSR
-  std::vector<int> ic((size_t)nobs), ip((size_t)nobs), operm((size_t)nobs), off((size_t)nt + 1, 0);
-  std::vector<double2> iz((size_t)nobs);
-  std::vector<unsigned char> ipt_opt((size_t)nt);
-  {
-    size_t w = 0;
-    for (int i = 0; i < nt; ++i) {
-      const int k = pperm[i];
-      ipt_opt[i] = pt_opt[k];
-      for (int q = coff[k]; q < coff[(size_t)k + 1]; ++q, ++w) {
-        const int n = by_pt[q];
-        operm[w] = n; ic[w] = obs_cam[n]; ip[w] = i;
-        iz[w] = double2{obs_z[2 * (size_t)n], obs_z[2 * (size_t)n + 1]};
-      }
-      off[(size_t)i + 1] = (int)w;
-    }
-  }
-  bool pid = true, oid = true;
-  for (int i = 0; i < nt && pid; ++i) pid = pperm[i] == i;
-  for (int64_t n = 0; n < nobs && oid; ++n) oid = operm[(size_t)n] == (int)n;
-  h->pperm = pid ? std::vector<int>() : pperm;
-  h->operm = oid ? std::vector<int>() : operm;
-  // from here on everything is in internal order
-  obs_cam = ic.data(); obs_pt = ip.data(); pt_opt = ipt_opt.data();
+  h->ncam_units = (int)cam_units.size();
+  h->cam_units_built = true;
+  return BA_OK;
+}
 
-  // Schur work units: (point, row tile, col tile >= row tile)
+// Schur work units (point, row tile, col tile >= row tile) of k_schur_pairs and their chunks: consecutive units whose
+// optimised-camera positions fit a window of wn band rows, so that a workgroup can accumulate them in an LDS tile
+int ensure_pair_units(ba_handle* h) {
+  if (h->pair_units_built) return BA_OK;
+  const int nt = h->nt, wn = h->schur_wn;
+  const std::vector<int>&off = h->h_off, &plo = h->h_plo, &phi = h->h_phi;
   std::vector<SchurUnit> units;
   units.reserve((size_t)nt);
-  long long maxL = 0;
   for (int k = 0; k < nt; ++k) {
     const int L = off[(size_t)k + 1] - off[k];
-    maxL = std::max<long long>(maxL, L);
     for (int r = 0; r < L; r += kTile)
       for (int c = r; c < L; c += kTile) units.push_back({k, r, c});
   }
-  // camera-ordered view of the observations for k_camera_blocks: counting sort by camera
-  std::vector<int> cam_off((size_t)nc + 1, 0), perm((size_t)nobs);
-  for (int64_t n = 0; n < nobs; ++n) cam_off[(size_t)obs_cam[n] + 1] += 1;
-  for (int i = 0; i < nc; ++i) cam_off[(size_t)i + 1] += cam_off[i];
-  {
-    std::vector<int> cursor(cam_off.begin(), cam_off.end() - 1);
-    for (int64_t n = 0; n < nobs; ++n) perm[(size_t)cursor[obs_cam[n]]++] = (int)n;
-  }
-  std::vector<CamUnit> cam_units;
-  // one wavefront per unit: few cameras with long observation lists (dense visibility) would leave the chip
-  // empty at kCamChunk observations per unit, so shrink the chunk until there are about 500 units (measured: 100 000 observations of 100 cameras: 28 us at 2048 per unit, 14 at 256, 19 at 64); many
-  // cameras with ~1000 observations each keep one unit per camera (one atomic result per camera)
-  const int cam_chunk = (int)std::min<int64_t>(kCamChunk, std::max<int64_t>(64, (nobs / 512 + 63) / 64 * 64));
-  for (int i = 0; i < nc; ++i)
-    for (int s = cam_off[i]; s < cam_off[(size_t)i + 1]; s += cam_chunk)
-      cam_units.push_back({i, s, std::min(s + cam_chunk, cam_off[(size_t)i + 1])});
-  // block half-bandwidth of the reduced system: widest spread of optimised-camera
-  // positions within one track
-  int hb = 0;
-  for (int k = 0; k < nt; ++k) {
-    int lo = INT32_MAX, hi = -1;
-    for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
-      const int p = cam_opt_pos[obs_cam[n]];
-      if (p < 0) continue;
-      lo = std::min(lo, p); hi = std::max(hi, p);
-    }
-    if (hi >= 0) hb = std::max(hb, hi - lo);
-  }
-  hb = std::max(hb, std::min(h->min_hb, std::max(0, nco - 1)));   // sharded adjuster: every rank uses the widest band
-  // Schur chunks: consecutive units whose optimised-camera positions fit a window of wn
-  // band rows, so that a workgroup can accumulate them in an LDS tile
-  int wn = (int)(kSchurTileBytes / (((size_t)(hb + 1) * 36 + 6) * sizeof(double)));
-  wn = std::min(wn, 64);
-  if (wn < hb + 2 || nco == 0) wn = 0;                 // band too wide for an LDS tile: global atomics only
   std::vector<SchurChunk> chunks;
   {
-    std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
-    for (int k = 0; k < nt; ++k)
-      for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
-        const int p = cam_opt_pos[obs_cam[n]];
-        if (p < 0) continue;
-        plo[k] = std::min(plo[k], p); phi[k] = std::max(phi[k], p);
-      }
     int begin = 0, lo = INT32_MAX, hi = -1;
     for (int u = 0; u < (int)units.size(); ++u) {
       const int k = units[u].pt;
@@ -195,6 +106,181 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     }
     if (!units.empty()) chunks.push_back({begin, (int)units.size(), lo == INT32_MAX ? 0 : lo});
   }
+  HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
+  HIPCHECK(h, h->chunks.resize(std::max<size_t>(1, chunks.size())));
+  if (!units.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(h->units.p, units.data(), units.size() * sizeof(SchurUnit), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+  }
+  h->nunits = (int)units.size();
+  h->nchunks = (int)chunks.size();
+  h->pair_units_built = true;
+  return BA_OK;
+}
+
+}  // namespace ba
+
+extern "C" {
+
+int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
+                   const int32_t* obs_pt, const double* obs_z, const double* K,
+                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
+  REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
+  REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
+          "ba_set_problem: NULL argument");
+  REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
+  HIPCHECK(h, hipSetDevice(h->device));
+  h->have_problem = false;
+
+  // ---- cameras (host, O(nc)): optimised-camera positions must be a permutation of 0..nco-1; the RANK of a camera orders a
+  // track's observations: frozen cameras by index, then the optimised ones by position
+  int nco = 0;
+  for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) ++nco;
+  std::vector<int> crank((size_t)std::max(1, nc)), opt_cam((size_t)std::max(1, nco), 0);
+  {
+    std::vector<char> seen((size_t)nco, 0);
+    int f = 0;
+    const int nfrozen = nc - nco;
+    for (int i = 0; i < nc; ++i) {
+      const int p = cam_opt_pos[i];
+      if (p < 0) { crank[i] = f++; continue; }
+      if (p >= nco || seen[p]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: cam_opt_pos is not a permutation of 0..nco-1");
+      seen[p] = 1;
+      crank[i] = nfrozen + p;
+      opt_cam[p] = i;
+    }
+  }
+  const bool sort_points = h->opt.sort_points;
+  const long long N = nobs;
+  auto& su = h->su;
+  const int rank_bits = bits_for((unsigned long long)std::max(1, nc)), track_bits = bits_for((unsigned long long)std::max(1, nt));
+
+  // ---- the caller's arrays to the device
+  HIPCHECK(h, su.rc.resize(std::max<size_t>(1, N))); HIPCHECK(h, su.rp.resize(std::max<size_t>(1, N))); HIPCHECK(h, su.rz.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, su.key.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, su.cnt.resize((size_t)nt + 2)); HIPCHECK(h, su.coff.resize((size_t)nt + 2)); HIPCHECK(h, su.Lint.resize((size_t)nt + 2));
+  HIPCHECK(h, su.crank.resize(crank.size())); HIPCHECK(h, su.rpo.resize(std::max(1, nt))); HIPCHECK(h, su.flags.resize(SF_COUNT));
+  HIPCHECK(h, su.plo.resize(std::max(1, nt))); HIPCHECK(h, su.phi.resize(std::max(1, nt))); HIPCHECK(h, su.same.resize(std::max(1, nt)));
+  HIPCHECK(h, su.tkey.resize(std::max(1, nt))); HIPCHECK(h, su.tkey2.resize(std::max(1, nt))); HIPCHECK(h, su.iota.resize(std::max(1, nt)));
+  HIPCHECK(h, h->d_pperm.resize(std::max(1, nt))); HIPCHECK(h, h->d_operm.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, h->pt_off.resize((size_t)nt + 2)); HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc))); HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
+  HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
+  const size_t staging = ((size_t)3 * nt + 8) * sizeof(int) + (size_t)nt + SF_COUNT * sizeof(int) + (size_t)nt * sizeof(int) + 64;
+  HIPCHECK(h, pinned_staging(h, staging));
+  if (N) {
+    HIPCHECK(h, hipMemcpyAsync(su.rc.p, obs_cam, (size_t)N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(su.rp.p, obs_pt, (size_t)N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(su.rz.p, obs_z, (size_t)N * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+  }
+  if (nc) {
+    HIPCHECK(h, hipMemcpyAsync(su.crank.p, crank.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(h, hipMemcpyAsync(h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (nt) HIPCHECK(h, hipMemcpyAsync(su.rpo.p, pt_opt, (size_t)nt, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipMemsetAsync(su.cnt.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
+  HIPCHECK(h, hipMemsetAsync(su.Lint.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_setup_init, dim3(1), dim3(256), 0, h->stream, su.flags.p);
+  // ---- validate, count per track, and find out whether the observations already come ordered by (track, camera rank)
+  if (N) hipLaunchKernelGGL(k_setup_keys, dim3(grid_for(N)), dim3(256), 0, h->stream, N, nc, nt, su.rc.p, su.rp.p, su.crank.p, rank_bits,
+                            su.key.p, su.cnt.p, su.flags.p);
+  int* hflags = static_cast<int*>(su.host);
+  HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));        // (obs_cam / obs_pt / obs_z / pt_opt are caller memory: not read after this point)
+  if (hflags[SF_BAD] != 0x7fffffff) {
+    const int n = hflags[SF_BAD], c = obs_cam[n], k = obs_pt[n];
+    if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%d]=%d out of range", n, c);
+    return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%d]=%d out of range", n, k);
+  }
+  // ---- order by (track, rank): a stable radix sort of (key, index) pairs, only if needed
+  const int* by_pt = nullptr;                        // position in the sorted order -> caller's observation index (nullptr: identity)
+  const unsigned long long* sorted_keys = su.key.p;
+  if (hflags[SF_UNSORTED]) {
+    HIPCHECK(h, su.key2.resize((size_t)N)); HIPCHECK(h, su.vals.resize((size_t)N)); HIPCHECK(h, su.by_pt.resize((size_t)N));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(N)), dim3(256), 0, h->stream, (int)N, su.vals.p);
+    HIPCHECK(h, sort_pairs_u64(h, su.key.p, su.key2.p, su.vals.p, su.by_pt.p, (size_t)N, rank_bits + track_bits));
+    hipLaunchKernelGGL(k_setup_dups, dim3(grid_for(N)), dim3(256), 0, h->stream, N, su.key2.p, su.flags.p);
+    sorted_keys = su.key2.p;
+    if (sort_points) {
+      by_pt = su.by_pt.p;
+    } else if (hflags[SF_UNSORTED_PT]) {
+      // without the internal sort a track keeps its observations in the caller's order: grouped by track, nothing else
+      hipLaunchKernelGGL(k_setup_track_keys_only, dim3(grid_for(N)), dim3(256), 0, h->stream, N, su.rp.p, su.key.p);
+      HIPCHECK(h, sort_pairs_u64(h, su.key.p, su.key2.p, su.vals.p, su.by_pt.p, (size_t)N, track_bits));
+      by_pt = su.by_pt.p;
+      sorted_keys = nullptr;                         // (the duplicate's key is gone: the message names no track)
+    }
+  }
+  // ---- CSR by caller track, the tracks' order, CSR in that order, the internal arrays
+  HIPCHECK(h, exclusive_scan_i32(h, su.cnt.p, su.coff.p, (size_t)nt + 1));
+  if (nt) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.iota.p);
+    if (sort_points && nt > 1) {
+      hipLaunchKernelGGL(k_setup_track_keys, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, nco, su.coff.p, by_pt, su.rc.p, h->cam_opt_pos.p,
+                         su.crank.p, su.tkey.p);
+      HIPCHECK(h, sort_pairs_u64(h, su.tkey.p, su.tkey2.p, su.iota.p, h->d_pperm.p, (size_t)nt, 32 + bits_for((unsigned long long)nco + 1)));
+      hipLaunchKernelGGL(k_setup_order_check, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.tkey.p, su.tkey2.p, su.flags.p);
+    }
+    hipLaunchKernelGGL(k_setup_choose_order, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, (sort_points && nt > 1) ? 0 : 1, h->d_pperm.p,
+                       su.cnt.p, su.Lint.p, su.flags.p);
+  }
+  HIPCHECK(h, exclusive_scan_i32(h, su.Lint.p, h->pt_off.p, (size_t)nt + 1));
+  if (nt) {
+    hipLaunchKernelGGL(k_setup_gather, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->d_pperm.p, su.coff.p, h->pt_off.p, by_pt, su.rc.p,
+                       su.rz.p, su.rpo.p, h->obs_cam.p, h->obs_pt.p, h->obs_z.p, h->d_operm.p, h->pt_opt.p, su.flags.p);
+    hipLaunchKernelGGL(k_setup_point_summary, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->pt_off.p, h->obs_cam.p, h->cam_opt_pos.p,
+                       su.plo.p, su.phi.p, su.same.p, su.flags.p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  // ---- the per-point summaries come back: everything below is O(points)
+  int* hoff = hflags + SF_COUNT;
+  int* hplo = hoff + nt + 2;
+  int* hphi = hplo + nt;
+  int* hperm = hphi + nt;
+  unsigned char* same = reinterpret_cast<unsigned char*>(hperm + nt);
+  HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(hoff, h->pt_off.p, ((size_t)nt + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (nt) {
+    HIPCHECK(h, hipMemcpyAsync(hplo, su.plo.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(hphi, su.phi.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(hperm, h->d_pperm.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(same, su.same.p, (size_t)nt, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  const int* flags = hflags;
+  if (flags[SF_DUP] != 0x7fffffff) {                 // each (camera, track) pair at most once (bundle.py: a dict per track)
+    unsigned long long key = 0;
+    if (sorted_keys) {
+      HIPCHECK(h, hipMemcpy(&key, sorted_keys + flags[SF_DUP], sizeof key, hipMemcpyDeviceToHost));
+      return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in one camera", (int)(key >> rank_bits));
+    }
+    return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: a track has two observations in one camera");
+  }
+  h->h_off.assign(hoff, hoff + nt + 1);
+  h->h_plo.assign(hplo, hplo + nt);
+  h->h_phi.assign(hphi, hphi + nt);
+  if (flags[SF_PERM]) h->pperm.assign(hperm, hperm + nt); else h->pperm.clear();
+  h->operm_identity = flags[SF_OPERM] == 0;
+  const int* off = h->h_off.data();
+  const int* plo = h->h_plo.data();
+  const int* phi = h->h_phi.data();
+  const long long maxL = flags[SF_MAXL];
+  long long nunits = 0;                              // work units of k_schur_pairs (built on first use: ensure_pair_units)
+  for (int k = 0; k < nt; ++k) {
+    const long long T = (off[(size_t)k + 1] - off[k] + kTile - 1) / kTile;
+    nunits += T * (T + 1) / 2;
+  }
+  // block half-bandwidth of the reduced system: widest spread of optimised-camera positions within one track
+  int hb = flags[SF_HB];
+  hb = std::max(hb, std::min(h->min_hb, std::max(0, nco - 1)));   // sharded adjuster: every rank uses the widest band
+  // LDS window of the older reduction kernels: wn band rows
+  int wn = (int)(kSchurTileBytes / (((size_t)(hb + 1) * 36 + 6) * sizeof(double)));
+  wn = std::min(wn, 64);
+  if (wn < hb + 2 || nco == 0) wn = 0;                 // band too wide for an LDS tile: global atomics only
   // Groups: runs of consecutive points (internal order) with identical observation lists.
   //   groups / gchunks   <= kGroupMaxPts points each: k_schur_groups (vector kernel, track length <= 15) and the
   //                      group-packed point kernels k_linearize_groups / k_backsub_groups (<= kGm3MaxL)
@@ -204,7 +290,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   std::vector<SchurChunk> gchunks, mchunks, m3chunks;
   int group_rounds = 0;
   bool groups_worth = false;
-  bool groups_ascending = true;                      // optimised positions ascend along every track
+  const bool groups_ascending = flags[SF_NOT_ASC] == 0;      // optimised positions ascend along every track (always, with the internal sort)
   Gm3Params gm3{0, 0, 0, 0, 0, 1, 1};
   if (maxL >= 1 && maxL <= kGm3MaxL) {
     auto build_groups = [&](int max_pts, std::vector<SchurGroup>& gs, std::vector<int>& glo, std::vector<int>& ghi) {
@@ -212,19 +298,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         const int L = off[(size_t)k + 1] - off[k];
         if (L == 0) { ++k; continue; }
         int e = k + 1;
-        while (e < nt && e - k < max_pts && off[(size_t)e + 1] - off[e] == L &&
-               std::equal(obs_cam + off[k], obs_cam + off[k] + L, obs_cam + off[e]))
-          ++e;
-        int lo = INT32_MAX, hi = -1;
-        for (int n = off[k]; n < off[k] + L; ++n) {
-          const int p = cam_opt_pos[obs_cam[n]];
-          if (p >= 0) {
-            if (p <= hi) groups_ascending = false;
-            lo = std::min(lo, p); hi = std::max(hi, p);
-          }
-        }
+        while (e < nt && e - k < max_pts && same[e]) ++e;      // (same[e]: the camera list of point e equals that of point e - 1)
         gs.push_back({k, e, L, 0});
-        glo.push_back(lo); ghi.push_back(hi);
+        glo.push_back(plo[k]); ghi.push_back(phi[k]);
         k = e;
       }
     };
@@ -249,8 +325,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     if (maxL <= kGroupMaxL) chunk_groups(kGroupChunk, wn, groups, glo, ghi, gchunks);
     // MFMA kernels: one group per wavefront pair, and the epilogue is expensive, so runs are cut
     // only where the chip would otherwise idle: about one group per wavefront-pair slot (4 per CU)
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+    const int ncu = h->ncu;
     const int slots = std::max(1, ncu * (kGmBlock / kWave));
     // The kernel lasts as long as its longest group (one round of workgroups), so: natural runs of points with
     // identical camera lists, runs longer than `cap` cut into EQUAL parts of whole batches, and the smallest cap
@@ -292,23 +367,17 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   // of different lengths, tracks with missing observations and tracks that start anywhere all join.  wmax = the
   // widest window that costs no more 16-row tiles than the widest track needs.
   std::vector<WinGroup> wgroups;
-  std::vector<int> wtab;
+  size_t wtab_size = 0;
+  std::vector<int> hobs;
   bool wgroups_worth = false;
   std::vector<RectGroup> rgroups;
   std::vector<int> rtab, wide_list;
   int wide_begin[kGwMaxTiles - kGwMinTiles + 2] = {0};
   int nlong_points = 0;
   {
-    std::vector<int> plo((size_t)nt, INT32_MAX), phi((size_t)nt, -1);
     int maxspan = 0;
-    for (int k = 0; k < nt; ++k) {
-      for (int n = off[k]; n < off[(size_t)k + 1]; ++n) {
-        const int p = cam_opt_pos[obs_cam[n]];
-        if (p < 0) continue;
-        plo[k] = std::min(plo[k], p); phi[k] = std::max(phi[k], p);
-      }
+    for (int k = 0; k < nt; ++k)
       if (phi[k] >= 0) maxspan = std::max(maxspan, phi[k] - plo[k] + 1);
-    }
     bool sorted_by_lo = true;                          // (the internal sort guarantees it; "sort_points" = 0 may not)
     for (int k = 1, last = -1; k < nt && sorted_by_lo; ++k) {
       if (phi[k - 1] >= 0) last = plo[k - 1];
@@ -331,6 +400,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     if (hybrid) {
       maxspan = shortspan;
       nlong_points = (int)nlong;
+      // (the one place where the host looks at observations: the few long tracks' cameras)
+      hobs.resize((size_t)nobs);
+      HIPCHECK(h, hipMemcpyAsync(hobs.data(), h->obs_cam.p, (size_t)nobs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(h, hipStreamSynchronize(h->stream));
+      obs_cam = hobs.data();
       std::map<long long, int> rect_id;
       for (int k = 0; k < nt; ++k) {
         if (!is_long(k)) continue;
@@ -371,8 +445,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       }
       // cut long groups into equal parts so that one round of workgroups holds them all and none lasts much longer
       // than the rest (as for the identical-list groups above)
-      int ncu = 256;
-      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+      const int ncu = h->ncu;
       const int slots = std::max(1, ncu * kGm2Pairs);
       auto parts_of = [&](const Run& r, int cap) { return (r.e - r.b + cap - 1) / cap; };
       int cap = std::max(kGroupMaxPts, (int)(((nt + slots - 1) / slots + kGmPts - 1) / kGmPts * kGmPts));
@@ -392,13 +465,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
             if (phi[q] >= 0) { lo = std::min(lo, plo[q]); hi = std::max(hi, phi[q]); }
           if (hi < 0) continue;
           const int W = hi - lo + 1;
-          WinGroup g{b0, e0, W, lo, (int)wtab.size(), 0, 0, 0};
-          wtab.resize(wtab.size() + (size_t)(e0 - b0) * W, -1);
-          for (int q = b0; q < e0; ++q)
-            for (int n2 = off[q]; n2 < off[(size_t)q + 1]; ++n2) {
-              const int p = cam_opt_pos[obs_cam[n2]];
-              if (p >= 0) wtab[(size_t)g.tab + (size_t)(q - b0) * W + (p - lo)] = n2;
-            }
+          if (wtab_size + (size_t)(e0 - b0) * W > (size_t)INT32_MAX) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: the window-group tables exceed 2^31 entries");
+          WinGroup g{b0, e0, W, lo, (int)wtab_size, 0, 0, 0};
+          wtab_size += (size_t)(e0 - b0) * W;               // (filled on the device: k_setup_fill_wtab)
           wgroups.push_back(g);
           wlo.push_back(lo); whi.push_back(hi);
         }
@@ -509,10 +578,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
 
   h->nc = nc; h->nt = nt; h->nco = nco; h->hb = hb; h->nobs = nobs; h->glog = glog;
   std::memcpy(h->K, K, sizeof h->K);
-  h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
-  h->h_pt_opt.assign(pt_opt, pt_opt + nt);
-  h->nunits = (int)units.size();
-  h->nchunks = (int)chunks.size();
+  h->nunits = (int)std::min<long long>(nunits, INT32_MAX);
+  h->nchunks = 0;
+  h->pair_units_built = h->cam_units_built = false;
   h->schur_wn = wn;
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
@@ -538,14 +606,8 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   }
   h->group_rounds = group_rounds;
   h->group_maxL = maxL;
-  h->ncam_units = (int)cam_units.size();
+  h->ncam_units = 0;
 
-  HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, nobs)));
-  HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, nobs)));
-  HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, nobs)));
-  HIPCHECK(h, h->pt_off.resize((size_t)nt + 1));
-  HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc)));
-  HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
   HIPCHECK(h, h->wide_list.resize(std::max<size_t>(1, wide_list.size())));
   if (!wide_list.empty())
     HIPCHECK(h, hipMemcpyAsync(h->wide_list.p, wide_list.data(), wide_list.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -555,10 +617,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     HIPCHECK(h, hipMemcpyAsync(h->rgroups.p, rgroups.data(), rgroups.size() * sizeof(RectGroup), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->rtab.p, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   }
-  HIPCHECK(h, h->units.resize(std::max<size_t>(1, units.size())));
-  HIPCHECK(h, h->chunks.resize(std::max<size_t>(1, chunks.size())));
-  if (!chunks.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->groups.resize(std::max<size_t>(1, groups.size())));
   HIPCHECK(h, h->gchunks.resize(std::max<size_t>(1, gchunks.size())));
   HIPCHECK(h, h->mchunks.resize(std::max<size_t>(1, mchunks.size())));
@@ -566,10 +624,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   if (!m3chunks.empty())
     HIPCHECK(h, hipMemcpyAsync(h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, h->wgroups.resize(std::max<size_t>(1, wgroups.size())));
-  HIPCHECK(h, h->wtab.resize(std::max<size_t>(1, wtab.size())));
+  HIPCHECK(h, h->wtab.resize(std::max<size_t>(1, wtab_size)));
   if (!wgroups.empty()) {
     HIPCHECK(h, hipMemcpyAsync(h->wgroups.p, wgroups.data(), wgroups.size() * sizeof(WinGroup), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->wtab.p, wtab.data(), wtab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->wtab.p, 0xff, wtab_size * sizeof(int), h->stream));        // -1: "the point does not see this camera"
+    hipLaunchKernelGGL(k_setup_fill_wtab, dim3((unsigned)wgroups.size()), dim3(256), 0, h->stream, h->wgroups.p, h->pt_off.p, h->obs_cam.p,
+                       h->cam_opt_pos.p, h->wtab.p);
   }
   HIPCHECK(h, h->mgroups.resize(std::max<size_t>(1, mgroups.size())));
   if (!mgroups.empty())
@@ -581,23 +641,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     if (!gchunks.empty())
       HIPCHECK(h, hipMemcpyAsync(h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
   }
-  HIPCHECK(h, h->cam_perm.resize(std::max<size_t>(1, perm.size())));
-  HIPCHECK(h, h->cam_units.resize(std::max<size_t>(1, cam_units.size())));
-  if (!perm.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->cam_perm.p, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  if (!cam_units.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->cam_units.p, cam_units.data(), cam_units.size() * sizeof(CamUnit), hipMemcpyHostToDevice, h->stream));
-  if (nobs) {
-    HIPCHECK(h, hipMemcpyAsync(h->obs_cam.p, obs_cam, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->obs_pt.p, obs_pt, nobs * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->obs_z.p, iz.data(), nobs * sizeof(double2), hipMemcpyHostToDevice, h->stream));
-  }
-  HIPCHECK(h, hipMemcpyAsync(h->pt_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  if (nc) HIPCHECK(h, hipMemcpyAsync(h->cam_opt_pos.p, cam_opt_pos, nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  if (nt) HIPCHECK(h, hipMemcpyAsync(h->pt_opt.p, pt_opt, nt, hipMemcpyHostToDevice, h->stream));
-  if (!units.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->units.p, units.data(), units.size() * sizeof(SchurUnit), hipMemcpyHostToDevice, h->stream));
-
   for (int i = 0; i < 2; ++i) {
     HIPCHECK(h, h->cams[i].resize(std::max<size_t>(1, (size_t)nc * 12)));
     HIPCHECK(h, h->X[i].resize(std::max<size_t>(1, (size_t)nt * 3)));
@@ -614,13 +657,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->dP.resize(std::max<size_t>(1, (size_t)nt * 3)));
   HIPCHECK(h, h->flags.resize(64));
   HIPCHECK(h, hipMemsetAsync(h->flags.p, 0, 64 * sizeof(int), h->stream));
-  {
-    std::vector<int> opt_cam(std::max(1, nco), 0);
-    for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) opt_cam[cam_opt_pos[i]] = i;
-    HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
-    HIPCHECK(h, hipMemcpyAsync(h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
-  }
   // a reduced system bound for another problem size is no longer valid
   h->S = nullptr; h->b = nullptr;
   h->have_problem = true;
@@ -632,13 +668,14 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   return BA_OK;
 }
 
+
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_problem_info: call ba_set_problem first");
   REQUIRE(h, out && n >= 1, BA_ERR_INVALID_ARG, "ba_problem_info: bad argument");
   const int kern = pick_schur_kernel(h);
   const int64_t v[BA_INFO_COUNT] = {
-      h->pperm.empty() ? 0 : 1, h->operm.empty() ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
+      h->pperm.empty() ? 0 : 1, h->operm_identity ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
       h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
       kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf};
   for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];

@@ -145,7 +145,9 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     else
       hipLaunchKernelGGL(k_schur_groups<2>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
                          h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
-  } else if (h->nchunks > 0) {
+  } else if (h->nunits > 0) {
+    rc = ensure_pair_units(h);                          // (the pair kernel's work list is built on first use)
+    if (rc != BA_OK) return rc;
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     const int NW = kSchurBlock / kWave;
     const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int) +

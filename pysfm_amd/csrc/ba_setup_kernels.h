@@ -211,16 +211,4 @@ __global__ __launch_bounds__(256) void k_setup_cam_hist(long long N, const int* 
   keys[n] = (u64)c;
 }
 
-// rows through a permutation on the device: dst[i] = src[perm[i]] (to_internal) or dst[perm[i]] = src[i]
-__global__ __launch_bounds__(256) void k_rows_permute(long long n, int w, const int* __restrict__ perm, const double* __restrict__ src,
-                                                      double* __restrict__ dst, int to_internal) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n * w) return;
-  const long long i = t / w;
-  const int a = (int)(t - i * w);
-  const long long j = perm[i];
-  if (to_internal) dst[i * w + a] = src[j * w + a];
-  else dst[j * w + a] = src[i * w + a];
-}
-
 }  // namespace ba

@@ -370,7 +370,8 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const bool use_dense = !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);
   const bool use_bcrw = !use_dense && !use_bcr && (force ? (force == SOLVER_BCR && bcrw_ok) : bcrw_ok);
-  if (force == SOLVER_LU || (!use_big && !use_dense && !use_bcr && !use_bcrw && !band_ok)) { *info = -1; return BA_OK; }     // caller's dense LU
+  // nothing of the above applies (or option solver = lu): LU with partial pivoting, the reference's own factorisation
+  const bool use_lu = force == SOLVER_LU || (!use_big && !use_dense && !use_bcr && !use_bcrw && !band_ok);
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, h->Ufac.resize(std::max<size_t>(1, reduced_doubles(h))));
   const unsigned char* dmask = nullptr;
@@ -387,8 +388,11 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const size_t lds_budget = 160 * 1024;
   const int ch = band_solve_chunk(h->hb, lds_budget);
   size_t lds = 0;
-  h->solve_kind = use_big ? BA_SOLVE_BCR_BIG : use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
-  if (use_big) {
+  h->solve_kind = use_lu ? BA_SOLVE_BAND_LU : use_big ? BA_SOLVE_BCR_BIG : use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
+  if (use_lu) {
+    int rc = solve_band_lu(h, dmask);
+    if (rc != BA_OK) return rc;
+  } else if (use_big) {
     int rc = solve_bcr_big(h, dmask);
     if (rc != BA_OK) return rc;
   } else if (use_dense) {
@@ -401,7 +405,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     int rc = solve_bcr_wide(h, dmask);
     if (rc != BA_OK) return rc;
   } else {
-    if (ch < 1) { *info = -1; return BA_OK; }
+    if (ch < 1) return h->fail(BA_ERR_STATE, "ba_solve_reduced: no LDS for the band solver at half-bandwidth %d", h->hb);
     lds = band_solve_lds_bytes(h->hb, ch);
     ScopedTimer tm(h, BA_K_BAND_SOLVE);
     hipError_t le = launch_band_solve(h, h->hb, lds, h->stream, h->nco, ch, h->S, h->b, dmask, h->Ufac.p, h->ysol.p,
@@ -414,14 +418,15 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   int inf = inf6[0];
-  if (inf > 0 && inf != kBcrTimedOut && use_bcr && h->opt.device_lu) {
-    // not positive definite: the reference's LU would still solve it (bundle_adjuster.py:302-305) - cyclic reduction with LU nodes
-    int rc = solve_bcr_lu(h, dmask);
+  if (inf > 0 && inf != kBcrTimedOut && !use_lu && h->opt.device_lu) {
+    // not positive definite: the reference's LU would still solve it (bundle_adjuster.py:302-305) - the cyclic reduction with
+    // LU nodes where the nodes are narrow, LU with partial pivoting down the band otherwise
+    int rc = use_bcr ? solve_bcr_lu(h, dmask) : solve_band_lu(h, dmask);
     if (rc != BA_OK) return rc;
     int inf2 = 0;
     HIPCHECK(h, hipMemcpyAsync(&inf2, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    h->solve_kind = BA_SOLVE_BCR_LU;
+    h->solve_kind = use_bcr ? BA_SOLVE_BCR_LU : BA_SOLVE_BAND_LU;
     inf = inf2;
   }
 #ifdef BA_BCR_PROFILE

@@ -4,6 +4,7 @@
 #include "ba_bcr_wide.h"
 #include "ba_dense.h"
 #include "ba_bcr_big.h"
+#include "ba_band_lu.h"
 
 using namespace ba;
 
@@ -144,6 +145,34 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
     }
   }
   hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(1024), dense_backsolve_lds_bytes(n), h->stream, n, bw, A, h->dC.p, info);
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+// LU with partial pivoting of the (masked) reduced system (ba_band_lu.h): the reference's own factorisation, for systems the
+// Cholesky solvers report as not positive definite and for option solver = lu.  Leaves the solution in h->dC and gesv's info
+// (0, or the 1-based column of an exactly zero pivot) in flags[1].
+int solve_band_lu(ba_handle* h, const unsigned char* dmask) {
+  const int n = 6 * h->nco;
+  LuShape s;
+  s.n = n;
+  s.bw = std::min(n - 1, 6 * h->hb + 5);
+  s.W = (int)std::min<long long>(3ll * s.bw + 1, n);
+  HIPCHECK(h, h->denseA.resize((size_t)n * s.W + (size_t)n + (size_t)s.bw + 8));
+  HIPCHECK(h, h->dC.resize((size_t)n + 16));
+  double* A = h->denseA.p;
+  double* rhs = A + (size_t)n * s.W;
+  double* mult = rhs + n;
+  int* info = h->flags.p + 1;
+  ScopedTimer tm(h, BA_K_DENSE_SOLVE, 2 * n + 2);
+  hipLaunchKernelGGL(k_lu_assemble, dim3(n), dim3(256), 0, h->stream, s, h->nco, h->hb, h->S, h->b, dmask, A, rhs, info);
+  for (int j = 0; j < n; ++j) {
+    hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(kLuThreads), 0, h->stream, s, j, A, rhs, mult, info);
+    const int rows = std::min(n - 1, j + s.bw) - j;
+    if (rows > 0)
+      hipLaunchKernelGGL(k_lu_update, dim3((rows + kLuRowsPerBlock - 1) / kLuRowsPerBlock), dim3(256), 0, h->stream, s, j, A, rhs, mult, info);
+  }
+  hipLaunchKernelGGL(k_lu_backsolve, dim3(1), dim3(kLuThreads), 0, h->stream, s, A, rhs, h->dC.p, info);
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
 }

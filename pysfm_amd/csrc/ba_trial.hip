@@ -54,9 +54,6 @@ int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* 
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, next_cost && info, BA_ERR_INVALID_ARG, "ba_lm_trial: NULL output");
   *info = 0;
-  // the dense-visibility reduction is driven by the caller (its matrix product is a library call), and systems
-  // too large for the dense device solve go to the caller's LU: do not linearise and reduce just to find that out
-  if (h->have_problem && h->hb > kBcrwMaxHB && 6 * h->nco > kDcMaxN) { *info = -1; return BA_OK; }
   int32_t pre = 0;
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
   const bool dist = h->comm && h->dist.on && h->hb <= kBcrMaxHB;

@@ -586,19 +586,52 @@ def test_lm_on_wide_band_scenes_follows_the_oracle(nc, nt, L, long_every, long_l
     ba.backend.close()
 
 
+# ------------------------------------------------------------------ the LM loop at full size, from the hard start (bundle_adjuster.py:117-162)
+@pytest.mark.parametrize('sensor,outliers', [('gaussian', 0.), ('huber', .1)], ids=['config3-gaussian', 'config4-huber'])
+def test_full_size_lm_trajectory_from_the_hard_start_vs_oracle(sensor, outliers):
+    """BASELINE configs 3 and 4 at full size (1000 cameras / 100 000 points / 1 000 000 observations), from the generator's
+    `params` start (every camera and point perturbed, SURVEY 8d - the start the bench's 46-trial run leaves from): the first
+    six outer steps of BundleAdjuster.optimize against the oracle's LM loop - the same sequence of dampings and accept /
+    reject decisions trial by trial, every trial's cost and the accepted costs to 1e-6, the final translations and points to
+    1e-6.  (One flipped decision would send the two trajectories apart: this is what pins the damping schedule at scale.)"""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    nc, nt, steps = 1000, 100000, 6
+    s = banded(nc, nt, outlier_frac=outliers, init_mode='params')
+    sen = O.Sensor.gaussian(1.) if sensor == 'gaussian' else O.Sensor.huber(.06)
+    model = sensor_model.GaussianModel(1.) if sensor == 'gaussian' else sensor_model.HuberModel(.06)
+    flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=model)
+    ba = BundleAdjuster(b, verbose=False)
+    ba.optimize(max_steps=steps)
+    assert ba.backend.last_solve_kind == 'bcr' and ba.backend.problem_info()['schur_mfma'] == 1
+    trace = []
+    ref = O.lm_optimize(sen, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, max_steps=steps, trace=trace)
+    got = [(d, o == 'accepted', c) for d, o, c in ba.trial_log]
+    want = [(tr['damping'], tr['next'] < tr['cur'], tr['next']) for tr in trace]
+    assert len(got) == len(want) and len(want) >= steps, (got, want)
+    for g, w in zip(got, want):
+        assert g[1] == w[1] and abs(g[0] - w[0]) <= 1e-12 * w[0], (got, want)
+        assert abs(g[2] - w[2]) <= 1e-6 * abs(w[2]), (got, want)
+    assert ba.num_steps == ref['num_steps'] and ba.converged == ref['converged']
+    close(np.array(ba.costs), np.array(ref['costs']), 1e-6)
+    assert ba.costs[-1] < 1e-2 * ba.costs[0]                     # (the hard start: the cost falls by orders of magnitude on the way)
+    out = ba.bundle
+    close(out.ts(), ref['t'], 1e-6, 1e-8)
+    close(out.reconstruction, ref['X'], 1e-6, 1e-8)
+    close(out.Rs(), ref['R'], 1e-6)
+    ba.backend.close()
+
+
 # ------------------------------------------------------------------ LU semantics beyond the fallback size
 def test_large_reduced_systems_follow_the_reference_lu_trajectory():
-    """More unknowns than the LU fallback takes (400 cameras: 2394 > backend.LU_FALLBACK_MAX_UNKNOWNS): the reference solves
+    """400 cameras, 2394 unknowns: the reference solves
     the reduced system by LU (numpy.linalg.solve, bundle_adjuster.py:302-305), which also 'succeeds' on a numerically singular
-    matrix; the GPU path solves by Cholesky and reports a failed factorisation as ill-conditioned (damping x 10, exactly what
-    the LM loop does with a rejected step).  The two must walk the same LM trajectory: identical accept / reject sequence
+    matrix; the GPU path solves by Cholesky and, where that fails, again by LU on the device.  The two must walk the same LM trajectory: identical accept / reject sequence
     (ill-conditioned counting as rejected), accepted costs to 1e-6 - from round 1's hard start to the noise floor, and
     restarted at the floor with the damping at 1e-13, where S is singular along the scale gauge to working precision.
     (scripts/lu_semantics_experiment.py prints the two sequences side by side.)"""
     from pysfm_amd import Bundle, BundleAdjuster
-    from pysfm_amd.backend import LU_FALLBACK_MAX_UNKNOWNS
     nc, nt = 400, 6000
-    assert (nc - 1) * 6 > LU_FALLBACK_MAX_UNKNOWNS
     s = banded(nc, nt, init_mode='params')
     flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
     sen = O.Sensor.gaussian(1.)
@@ -623,13 +656,10 @@ def test_large_reduced_systems_follow_the_reference_lu_trajectory():
 
 def test_lm_on_systems_that_are_not_positive_definite_follows_the_reference_lu():
     """LM trials on reduced systems that are indefinite on purpose (NEGATIVE damping): the reference's LU solves every one of
-    them (bundle_adjuster.py:302-305) and the loop accepts or rejects the step by its cost.  2394 unknowns: beyond the
-    flattened-LU fallback, so every trial here goes through the cyclic reduction with LU nodes - same decision, same trial cost,
+    them (bundle_adjuster.py:302-305) and the loop accepts or rejects the step by its cost.  2394 unknowns: every trial here goes through the cyclic reduction with LU nodes - same decision, same trial cost,
     same trial parameters as the oracle's LU; none reported ill-conditioned."""
     from pysfm_amd import Bundle, BundleAdjuster
-    from pysfm_amd.backend import LU_FALLBACK_MAX_UNKNOWNS
     nc, nt = 400, 6000
-    assert (nc - 1) * 6 > LU_FALLBACK_MAX_UNKNOWNS
     s = banded(nc, nt)
     flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
     sen = O.Sensor.gaussian(1.)
@@ -640,7 +670,7 @@ def test_lm_on_systems_that_are_not_positive_definite_follows_the_reference_lu()
     cur = O.cost(sen, s['K'], R, t, X, *a[4:], *flags)
     for n, damping in enumerate((-.6, -.3, -.85, -.5)):
         accepted, nxt = ba.trial(damping, None, cur)
-        assert accepted is not None and ba.lu_node_solves == n + 1 and ba.backend.last_solve_kind == 'bcr_lu'
+        assert accepted is not None and ba.lu_solves == n + 1 and ba.backend.last_solve_kind == 'bcr_lu'
         mu, su = O.compute_update(sen, s['K'], R, t, X, *a[4:], *flags, damping=damping)
         R2, t2, X2 = O.apply_update(R, t, X, mu, su, *flags)
         ref_next = O.cost(sen, s['K'], R2, t2, X2, *a[4:], *flags)
@@ -677,7 +707,7 @@ def test_lu_semantics_at_1000_cameras_on_the_device():
     got = [(d, o) for d, o, c in ba.trial_log]
     want = [(tr['damping'], 'accepted' if tr['next'] < tr['cur'] else 'rejected') for tr in trace]
     assert all(o != 'ill-conditioned' for d, o in got), got             # LU semantics: every trial returns a step
-    assert getattr(ba, 'cholesky_rejections', 0) == 0                    # (whether the LU nodes were needed depends on the round-off: ba.lu_node_solves)
+    assert getattr(ba, 'cholesky_rejections', 0) == 0                    # (whether the LU nodes were needed depends on the round-off: ba.lu_solves)
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert g[1] == w[1] and abs(g[0] - w[0]) <= 1e-12 * w[0], (got, want)

@@ -17,7 +17,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from conftest import load_golden
 from oracle import ba_oracle as O
 
-from contextlib import nullcontext as _nullcontext
 
 pytestmark = pytest.mark.gpu
 
@@ -792,9 +791,9 @@ def test_big_node_cyclic_reduction_matches_lapack(be, nc, L):
             assert np.all(x[m == 0] == 0)
     be.set_option('solver', 'bcr')
     if nc <= 217:
-        be.schur(0, -3., 1e-5)                        # negative damping: not positive definite - reported, the caller's LU takes over
+        be.schur(0, -3., 1e-5)                        # negative damping: not positive definite - reported, solved again by LU down the band
         be.solve_reduced(None)
-        assert be.last_solve_kind == 'bcr_big' and be.last_solve_path == 'dense'
+        assert be.last_solve_kind == 'band_lu' and be.last_solve_path == 'lu'
         close(be.get_solution().reshape(-1), _dense_reference(be), 1e-7)
 
 
@@ -814,17 +813,20 @@ def test_dense_cholesky_equals_cyclic_reduction(be):
     close(be.get_solution(), x0, 1e-10)
 
 
-def test_lu_fallback_runs_on_the_gpu(be):
-    """Option solver=lu keeps the device Cholesky out: the flattened system goes through rocSOLVER (the path
-    systems that are not positive definite take) and must agree with LAPACK."""
+def test_lu_down_the_band_by_option(be):
+    """Option solver=lu keeps the device Cholesky out: LU with partial pivoting down the band (ba_band_lu.h, the path
+    systems that are not positive definite take beyond nodes of 11 cameras) must agree with LAPACK."""
     nc, L = 160, 30
     s = banded(nc, 20 * nc, track_len=L)
     flags = default_flags(nc, 20 * nc)
     load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
     be.set_option('solver', 'lu')
     dC, dP = hip_update(be, 5.)
-    assert be.last_solve_path == 'dense'
+    assert be.last_solve_kind == 'band_lu' and be.last_solve_path == 'lu'
     close(dC.reshape(-1), _dense_reference(be), 1e-9)
+    mask = (np.random.RandomState(3).rand(be.nco * 6) > .1).astype(np.uint8)
+    be.solve_reduced(mask)
+    close(be.get_solution().reshape(-1), _dense_reference(be, mask), 1e-9)
 
 
 def test_dense_cholesky_reports_non_positive_pivot(be):
@@ -833,7 +835,7 @@ def test_dense_cholesky_reports_non_positive_pivot(be):
     be.linearize(0)
     be.schur(0, -3., 1e-5)
     be.solve_reduced(None)
-    assert be.last_solve_kind == 'dense_cholesky' and be.last_solve_path == 'dense'       # LU took over
+    assert be.last_solve_kind == 'band_lu' and be.last_solve_path == 'lu'                  # LU took over
     x = be.get_solution().reshape(-1)
     S, b = be.get_reduced()
     n = be.nco * 6
@@ -849,11 +851,11 @@ def test_band_solver_reports_non_positive_pivot(be):
     be.linearize(0)
     be.schur(0, -3., 1e-5)                    # (1 + lambda) < 0 flips the sign of every diagonal
     be.solve_reduced(None)
-    assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'band'
+    assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'lu'
     x_lu = be.get_solution().reshape(-1)
     be.set_option('solver', 'band')
     be.solve_reduced(None)
-    assert be.last_solve_kind == 'band' and be.last_solve_path == 'dense'
+    assert be.last_solve_kind == 'band_lu' and be.last_solve_path == 'lu'
     close(x_lu, be.get_solution().reshape(-1), 1e-9)
     S, b = be.get_reduced()
     x = be.get_solution().reshape(-1)
@@ -861,18 +863,15 @@ def test_band_solver_reports_non_positive_pivot(be):
     close(A @ x, b.reshape(-1), 1e-9)
 
 
-def test_large_system_that_is_not_positive_definite_is_reported_ill_conditioned(be):
-    """More unknowns than the LU fallback takes (backend.LU_FALLBACK_MAX_UNKNOWNS), and the device's LU nodes switched
-    off (option device_lu = 0: round 2's behaviour, still what wide bands get): a failed Cholesky is answered like the
-    reference's LinAlgError (NormalEquationsIllconditioned -> the LM loop raises the damping, bundle_adjuster.py:134-140)
-    instead of a dense LU of the flattened system.  With the LU nodes (the default) the same system is SOLVED on the
-    device, as the reference's LU solves it."""
-    from pysfm_amd.backend import ReducedSystemSingular, LU_FALLBACK_MAX_UNKNOWNS
-    nc = LU_FALLBACK_MAX_UNKNOWNS // 6 + 40
+def test_a_system_that_is_not_positive_definite_without_the_device_lu(be):
+    """Option device_lu = 0 (round 2's behaviour): a failed Cholesky is answered like the reference's LinAlgError
+    (NormalEquationsIllconditioned -> the LM loop raises the damping, bundle_adjuster.py:134-140).  With the device LU (the
+    default) the same system is SOLVED, as the reference's LU solves it."""
+    from pysfm_amd.backend import ReducedSystemSingular
+    nc = 380
     s = banded(nc, 3 * nc, track_len=6)
     flags = default_flags(nc, 3 * nc)
     load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
-    assert be.nco * 6 > LU_FALLBACK_MAX_UNKNOWNS
     be.linearize(0)
     be.schur(0, -3., 1e-5)                    # (1 + lambda) < 0: indefinite
     be.set_option('device_lu', 0)
@@ -883,7 +882,7 @@ def test_large_system_that_is_not_positive_definite_is_reported_ill_conditioned(
     be.set_option('device_lu', 1)
     be.schur(0, -3., 1e-5)
     be.solve_reduced(None)
-    assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'band'
+    assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'lu'
     info, _ = be.lm_trial(-3., 1e-5, None)    # (the one-batch trial only reports: the caller solves again, stepwise)
     assert info > 0
     be.schur(0, 10., 1e-5)                    # and the same scene, damped properly, solves on the device
@@ -1106,13 +1105,16 @@ def test_triangulation_degenerate_tracks(be):
     assert np.sqrt(np.mean(np.sum(e * e, axis=1))) < 3 * .02
 
 
-@pytest.mark.parametrize('nc,L', [(64, 4), (300, 10), (1000, 10), (257, 12)])
+@pytest.mark.parametrize('nc,L', [(64, 4), (300, 10), (1000, 10), (257, 12), (120, 16), (200, 23), (150, 32), (400, 80), (30, 30)])
 def test_not_positive_definite_systems_are_solved_like_the_reference_lu(be, nc, L):
     """The reference solves its reduced system by LU (numpy.linalg.solve, bundle_adjuster.py:302-305): a symmetric matrix that is
     NOT positive definite is still solved.  A NEGATIVE damping makes such a system on purpose (diag(H) scaled by 0.4: indefinite,
-    far from singular): the device Cholesky must report it, the cyclic reduction with LU nodes (k_bcr_eliminate_lu: partial
-    pivoting inside a node) must solve it, and the solution must be LAPACK's - for the whole system and with parameters masked."""
-    nt = 30 * nc
+    far from singular): the device Cholesky must report it - whichever solver the band width selects: half-bandwidths 3 .. 11
+    (cyclic reduction), 15 and 22 (three kernels per level), 31 and 79 (nodes in device memory), 29 of 29 cameras (dense) -, the
+    LU must solve it (k_bcr_eliminate_lu: partial pivoting inside a node, up to 11 cameras per node; ba_band_lu.h: partial
+    pivoting down the band, gesv's own pivot choices, beyond), and the solution must be LAPACK's - for the whole system and
+    with parameters masked."""
+    nt = (30 if L <= 12 else 12) * nc
     s = banded(nc, nt, track_len=L)
     flags = default_flags(nc, nt)
     load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
@@ -1138,13 +1140,11 @@ def test_not_positive_definite_systems_are_solved_like_the_reference_lu(be, nc, 
             np.linalg.cholesky(A)
     for mask in (None, (np.arange(n) % 11 != 3).astype(np.uint8)):
         be.set_option('device_lu', 0)
-        with pytest.raises(Exception) if n > be.lu_fallback_max_unknowns else _nullcontext():
+        with pytest.raises(Exception):                                                # (without the device LU: reported, not solved)
             be.solve_reduced(mask)
-        if n <= be.lu_fallback_max_unknowns:
-            assert be.last_solve_path == 'dense'                                      # (without the device LU: the flattened system through rocSOLVER)
         be.set_option('device_lu', 1)
         be.solve_reduced(mask)
-        assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'band'
+        assert be.last_solve_kind == ('bcr_lu' if hb <= 11 else 'band_lu') and be.last_solve_path == 'lu'
         x = be.get_solution().reshape(-1)
         keep = np.arange(n) if mask is None else np.nonzero(mask)[0]
         ref = np.linalg.solve(A[np.ix_(keep, keep)], b[keep])
@@ -1350,3 +1350,61 @@ def test_batch_driver_end_to_end(tmp_path):
     ref = O.lm_optimize(O.Sensor.gaussian(1.), b.K, b.Rs()[:40], b.ts()[:40], X0, cam[m], trk[m], z[m],
                         np.arange(40, dtype=np.int32) - 1, np.ones(5, bool), cam_param_mask=mask, max_steps=6)
     close(ba.costs, ref['costs'], LM)
+
+
+# ------------------------------------------------------------------ a foreign Bundle class
+def test_a_reference_style_bundle_of_plain_objects_walks_the_golden_trajectory():
+    """BundleAdjuster takes any object with the reference Bundle's attributes (bundle.py:128-146: K, cameras[i].R / .t,
+    tracks[j].measurements, reconstruction, sensor_model, clone_params, check_consistency) - here plain classes that share
+    nothing with pysfm_amd.bundle, observations gathered by _select_observations_generic - and reproduces the reference's
+    own LM trajectory on bundle_unittest.create_test_bundle (36 observations, Cauchy)."""
+    from pysfm_amd import BundleAdjuster
+    g = load_golden('scene_4x10_cauchy')
+
+    class Cam(object):
+        def __init__(self, R, t):
+            self.R, self.t = np.array(R, float), np.array(t, float)
+
+    class Trk(object):
+        def __init__(self):
+            self.measurements = {}
+
+    class Cauchy(object):                                         # (only the name and .sigma travel to the device: sensor_model.device_params_of)
+        def __init__(self, sigma):
+            self.sigma = sigma
+
+    class ForeignBundle(object):
+        def __init__(self):
+            self.K, self.cameras, self.tracks, self.reconstruction, self.sensor_model = None, [], [], None, None
+
+        def check_consistency(self):
+            assert np.shape(self.K) == (3, 3) and np.shape(self.reconstruction) == (len(self.tracks), 3)
+
+        def clone_params(self):
+            c = ForeignBundle()
+            c.K, c.tracks, c.sensor_model = self.K.copy(), self.tracks, self.sensor_model
+            c.cameras = [Cam(k.R, k.t) for k in self.cameras]
+            c.reconstruction = self.reconstruction.copy()
+            return c
+
+    Cauchy.__name__ = 'CauchyModel'
+    fb = ForeignBundle()
+    fb.K = np.array(g['K'], float)
+    fb.cameras = [Cam(R, t) for R, t in zip(g['R'], g['t'])]
+    fb.tracks = [Trk() for _ in range(len(g['X']))]
+    order = np.random.RandomState(0).permutation(len(g['obs_cam']))          # (dict insertion order must not matter)
+    for n in order:
+        fb.tracks[int(g['obs_pt'][n])].measurements[int(g['obs_cam'][n])] = np.array(g['obs_z'][n], float)
+    fb.reconstruction = np.array(g['X'], float)
+    fb.sensor_model = Cauchy(float(g['sensor_sigma']))
+    ba = BundleAdjuster(fb, verbose=False)
+    ba.optimize(max_steps=10)
+    assert ba.num_steps == int(g['lm_num_steps']) and ba.converged == bool(g['lm_converged'])
+    close(np.array(ba.costs), g['lm_costs'], 1e-7)
+    out = ba.bundle
+    assert isinstance(out, ForeignBundle) and out is not fb
+    assert np.array_equal(fb.cameras[2].R, g['R'][2])                        # the caller's bundle is never mutated (bundle_adjuster.py:151)
+    close(np.array([c.R for c in out.cameras]), g['lm_R'], 1e-6)
+    close(np.array([c.t for c in out.cameras]), g['lm_t'], 1e-6, 1e-9)
+    close(out.reconstruction, g['lm_X'], 1e-6)
+    ba.backend.close()

@@ -382,7 +382,6 @@ def test_solver_timeout_is_not_reported_as_ill_conditioned():
     ba = BundleAdjuster(bundle_of(g), backend=be, verbose=False)
     ref = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
     be.lm_trial = lambda damping, rcond, mask=None: (SOLVE_TIMED_OUT, float('nan'))
-    be.lu_fallback_max_unknowns = 0                                     # (even with every non-SPD system declared ill-conditioned)
     with pytest.warns(RuntimeWarning, match='timed out'):
         ba.optimize(max_steps=2)
     ref.optimize(max_steps=2)
