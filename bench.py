@@ -426,6 +426,9 @@ CONFIGS = {2: dict(cams=100, points=10000), 3: dict(cams=1000, points=100000),
            4: dict(cams=1000, points=100000, sensor='huber', outliers=.1), 5: dict(cams=10000, points=1000000, strong=True)}
 
 
+PHASE = ['start']      # what this rank is doing (the watchdog of multi-GPU runs reports it)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -462,6 +465,8 @@ def main():
                          "centre (default for config 5, where 'params' throws cameras 20 units off and no LM run recovers)")
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other configurations (`other_configs`)')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not run the two rocprofv3 --pmc passes that measure `roofline.traffic` live')
+    ap.add_argument('--rank-timeout', type=float, default=900., metavar='SECONDS',
+                    help='multi-GPU runs: a rank that has not finished after this long prints what it was doing and exits (rank 0: a JSON line with "error")')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)       # the run rocprofv3 wraps: a few trials, no JSON line
     args = ap.parse_args()
     global PMC_WORKLOAD
@@ -482,6 +487,23 @@ def main():
     from pysfm_amd import synthetic_data as sd
     from pysfm_amd._capi import PARAMS_CUR
 
+    if world > 1:
+        # a rank stuck in a collective (a communicator that never forms, a peer that died) must not become a silent driver
+        # time-out: after --rank-timeout seconds every rank says where it was and leaves; rank 0 leaves a JSON line with "error"
+        import threading
+
+        def give_up():
+            msg = 'bench.py rank %d/%d: no result after %.0f s, last phase: %s' % (rank, world, args.rank_timeout, PHASE[0])
+            sys.stderr.write(msg + '\n')
+            sys.stderr.flush()
+            if rank == 0:
+                print(json.dumps({'metric': 'LM-iter throughput (obs/sec) + final reproj RMSE, 1k-cam/100k-pt/1M-obs scene', 'value': None, 'unit': 'obs/s',
+                                  'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'error': msg}), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(args.rank_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU path)'
     comm = None
     if world > 1 or args.force_comm:
@@ -492,8 +514,10 @@ def main():
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local_rank)
+        PHASE[0] = 'torch.distributed.init_process_group(nccl)'
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         from pysfm_amd.distributed import ShardComm, shard_tracks
+        PHASE[0] = 'ShardComm: agreeing on the collectives (%s)' % args.collectives
         comm = ShardComm(collectives=args.collectives)
     ngpus = world
 
@@ -525,6 +549,7 @@ def main():
         # (cut where the distributed reduced solve wants the tracks cut, when it is going to be used; balanced by observations otherwise)
         use_plan = args.distributed_solve == 'on' or (args.distributed_solve == 'auto' and args.config == 5 and world > 1)
         track_ids = shard_tracks(bundle, rank, world, plan=ba.backend.dist_plan if use_plan else None)
+    PHASE[0] = 'set_bundle (ba_comm_init with the library collectives, the band width agreed over the ranks)'
     t_setup_first = time.time()
     ba.set_bundle(bundle, track_ids=track_ids)
     t_setup_first = time.time() - t_setup_first     # (the handle's first problem: library start-up and device allocations included)
@@ -544,6 +569,7 @@ def main():
     # ---- (untimed) the full LM run: final cost + reprojection RMSE
     lm = {}
     if not args.no_lm:
+        PHASE[0] = 'the untimed optimize(25 steps)'
         sync()
         t0 = time.time()
         ba.optimize(max_steps=25)
@@ -574,6 +600,7 @@ def main():
         be = ba.backend
 
     # ---- timed region: K complete LM trials, continuing the LM schedule
+    PHASE[0] = 'warm-up and timed trials'
     one_trial, state = make_trial_runner(ba, be)
     if args.pmc_child:
         # the run rocprofv3 --pmc wraps (live_pmc_traffic): a few complete trials, nothing printed

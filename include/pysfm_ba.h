@@ -46,7 +46,11 @@ typedef enum ba_status {
 typedef enum ba_sensor_kind {
   BA_SENSOR_GAUSS = 0,  /* params = L row-major 2x2, L = chol(cov^-1): r = L e      */
   BA_SENSOR_CAUCHY = 1, /* params[0] = sigma                                        */
-  BA_SENSOR_HUBER = 2   /* params[0] = k                                            */
+  BA_SENSOR_HUBER = 2,  /* params[0] = k                                            */
+  BA_SENSOR_TABLE = 3   /* any isotropic robustifier r = h(|e|) e (the reference's plug-in point, sensor_model.py:19-32),
+                         * sampled: params = [log2 rho_0, nodes per octave, n, h_0, m_0, ..., h_(n-1), m_(n-1)] with node i
+                         * at rho_i = 2^(log2 rho_0 + i / nodes per octave), h_i = h(rho_i), m_i = dh/d(log2 rho) there;
+                         * cubic Hermite interpolation in log2 rho on the device; h = h_0 below rho_0              */
 } ba_sensor_kind;
 
 /* Two resident parameter sets: the accepted bundle and the LM trial
@@ -82,6 +86,7 @@ int ba_synchronize(ba_handle* h);
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
  *   "gm_cap"        n                                      points per group of the MFMA reduction (0 = automatic)
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
+ *   "trial_graph"   1 | 0                                  ba_lm_trial replays its launches as one hipGraph per (damping, parameter-set parity); default 0
  * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap") take effect at
  * the next ba_set_problem. */
 int ba_set_option(ba_handle* h, const char* name, const char* value);

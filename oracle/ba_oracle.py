@@ -25,7 +25,7 @@ Data model (all fp64 / int32, row-major):
 """
 import numpy as np
 
-GAUSS, CAUCHY, HUBER = 0, 1, 2
+GAUSS, CAUCHY, HUBER, MODEL = 0, 1, 2, 3      # MODEL: any object with the four-method protocol (Sensor.from_model)
 CAUCHY_LINEAR_WINDOW = 1e-5       # sensor_model.py:39
 SO3_EXP_EPS = 1e-8                # lie.py:26
 
@@ -62,6 +62,14 @@ class Sensor(object):
     def huber(cls, k):
         return cls(HUBER, k=k)
 
+    @classmethod
+    def from_model(cls, model):
+        """Any object with the reference's protocol (sensor_model.py:19-32), called once per observation exactly as
+        Bundle.residual / Bundle.Jresidual call it (bundle.py:251-252, 269-273).  Small scenes only: a Python loop."""
+        s = cls(MODEL)
+        s.model = model
+        return s
+
 
 def sensor_residual(sensor, e):
     """r = residual_from_error(e) for e[N,2].
@@ -69,6 +77,8 @@ def sensor_residual(sensor, e):
     e = np.asarray(e, float)
     if sensor.kind == GAUSS:
         return e @ sensor.L.T
+    if sensor.kind == MODEL:
+        return np.array([sensor.model.residual_from_error(x) for x in e], float).reshape(-1, 2)
     rho = np.sqrt(np.sum(e * e, axis=1))
     if sensor.kind == CAUCHY:
         s = sensor.sigma
@@ -97,6 +107,8 @@ def sensor_jacobian(sensor, e):
     I = np.eye(2)
     if sensor.kind == GAUSS:
         return np.broadcast_to(sensor.L, (n, 2, 2)).copy()
+    if sensor.kind == MODEL:
+        return np.array([sensor.model.Jresidual_from_error(x) for x in e], float).reshape(-1, 2, 2)
     rho = np.sqrt(np.sum(e * e, axis=1))
     ee = e[:, :, None] * e[:, None, :]
     if sensor.kind == CAUCHY:

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 BA_OK = 0
 BA_ERR_INVALID_ARG, BA_ERR_NO_DEVICE, BA_ERR_HIP, BA_ERR_STATE, BA_ERR_SINGULAR, BA_ERR_NOMEM = \
     -1, -2, -3, -4, -5, -6
-SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER = 0, 1, 2
+SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER, SENSOR_TABLE = 0, 1, 2, 3
 PARAMS_CUR, PARAMS_TRIAL = 0, 1
 KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 'backsub',
               'update', 'flatten', 'band_solve', 'eval', 'camera_blocks', 'triangulate',

@@ -15,7 +15,7 @@
 
 namespace ba {
 
-enum { SENSOR_GAUSS = 0, SENSOR_CAUCHY = 1, SENSOR_HUBER = 2 };
+enum { SENSOR_GAUSS = 0, SENSOR_CAUCHY = 1, SENSOR_HUBER = 2, SENSOR_TABLE = 3 };
 
 struct Sensor {
   int kind;
@@ -25,6 +25,13 @@ struct Sensor {
   int fast;       // set by the host, uniform over a launch: bit 0 = Gaussian with L = I (r = e, Jr = I),
                   // bit 1 = K = I.  The kernels are bound by fp64 issue, and these two cases (the reference's
                   // own defaults: bundle.py:139, synthetic_data.py K = eye) skip a fifth of the per-observation work.
+  // SENSOR_TABLE: any isotropic robustifier r = h(rho) e, rho = |e| (the reference's plug-in point, sensor_model.py:19-32:
+  // an object with four methods) - h sampled by the host on a grid uniform in log2(rho): node i at rho_i = 2^(u0 + i / inv_du)
+  // holds {h(rho_i), dh/du(rho_i)}; cubic Hermite interpolation in u (h to ~1e-13, its derivative to ~3e-10 at 256 nodes per
+  // octave).  J = h I + (h'(rho) / rho) e e^T.  Below the first node h is the constant tab[0]; beyond the last, the last cell's cubic.
+  const double* tab;
+  int tab_n;
+  double tab_u0, tab_inv_du;
 };
 enum { FAST_UNIT_GAUSS = 1, FAST_K_IDENTITY = 2 };
 
@@ -32,6 +39,7 @@ enum { FAST_UNIT_GAUSS = 1, FAST_K_IDENTITY = 2 };
 // Gaussian: sensor_model.py:23-29.  Cauchy: sensor_model.py:48-69, including
 // its linear window |e| < 1e-5 and its log(1 + rho^2/sigma^2) (not log1p).
 // Huber: rho_H(s) = s^2 (s <= k), 2ks - k^2 otherwise, same vector-residual form.
+// Table: any isotropic robustifier the caller defines in Python, interpolated (see Sensor).
 BA_HD void sensor_eval(const Sensor& s, double e0, double e1, double r[2], double J[4]) {
   if (s.kind == SENSOR_GAUSS) {
     r[0] = s.L[0] * e0 + s.L[1] * e1;
@@ -60,6 +68,29 @@ BA_HD void sensor_eval(const Sensor& s, double e0, double e1, double r[2], doubl
     J[1] = e0 * e1 * a + (-e0 * e1 * ir) * c;
     J[2] = J[1];
     J[3] = e1 * e1 * a + (rho - e1 * e1 * ir) * c;
+    return;
+  }
+  if (s.kind == SENSOR_TABLE) {
+    double h = s.tab[0], q = 0.0;                         // q = h'(rho) / rho
+    if (rho2 > 0.0) {
+      const double t = (0.5 * log2(rho2) - s.tab_u0) * s.tab_inv_du;
+      if (t > 0.0) {
+        int i = (int)t;
+        if (i > s.tab_n - 2) i = s.tab_n - 2;
+        const double f = t - (double)i, du = 1.0 / s.tab_inv_du;
+        const double h0 = s.tab[2 * i], m0 = s.tab[2 * i + 1] * du, h1 = s.tab[2 * i + 2], m1 = s.tab[2 * i + 3] * du;
+        // Hermite cubic on [0, 1]: c0 + c1 f + c2 f^2 + c3 f^3
+        const double c2 = 3.0 * (h1 - h0) - 2.0 * m0 - m1, c3 = 2.0 * (h0 - h1) + m0 + m1;
+        h = h0 + f * (m0 + f * (c2 + f * c3));
+        const double dhdu = (m0 + f * (2.0 * c2 + 3.0 * f * c3)) * s.tab_inv_du;
+        q = dhdu * 1.4426950408889634 / rho2;           // dh/drho = dh/du / (rho ln 2); then / rho
+      }
+    }
+    r[0] = e0 * h; r[1] = e1 * h;
+    J[0] = h + e0 * e0 * q;
+    J[1] = e0 * e1 * q;
+    J[2] = J[1];
+    J[3] = h + e1 * e1 * q;
     return;
   }
   // Huber

@@ -232,6 +232,7 @@ int ba_reduced_device_ptrs(ba_handle* h, void** S_blocks, void** b) {
 int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_bind_reduced_buffers: call ba_set_problem first");
+  drop_trial_graphs(h);
   h->S = (double*)S_blocks_dev;
   h->b = (double*)b_dev;
   h->have_schur = false;
@@ -240,6 +241,7 @@ int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
 
 int ba_set_dense_visibility(ba_handle* h, int32_t on) {
   if (!h) return BA_ERR_INVALID_ARG;
+  drop_trial_graphs(h);
   h->dense_mode = on != 0;
   h->inv_valid = false;
   if (!on) { h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); }

@@ -99,9 +99,50 @@ class HuberModel(_DeviceSensorModel):
         return HuberModel(self.k)
 
 
+# ---- any isotropic robustifier, sampled (the reference's plug-in point: an object with the four methods, sensor_model.py:19-32)
+TABLE_LOG2_RHO_MIN, TABLE_LOG2_RHO_MAX, TABLE_NODES_PER_OCTAVE = -40., 40., 256
+
+
+def tabulate(model):
+    """(kind, params) of BA_SENSOR_TABLE for a model whose residual is isotropic, r = h(|e|) e.  Along e = (rho, 0) the
+    model's own Jacobian is diag(h + h' rho, h): h and h' come from Jresidual_from_error, no differencing.  Sampled on a grid
+    uniform in log2(rho), 256 nodes per octave from 2^-40 to 2^40, which the device interpolates (cubic Hermite: h to ~1e-13,
+    its derivative to ~3e-10 where h is smooth).  Raises TypeError for a model that is not isotropic - its Jacobian is then
+    not of the form h I + (h'/rho) e e^T, which is all the device evaluates."""
+    n = int((TABLE_LOG2_RHO_MAX - TABLE_LOG2_RHO_MIN) * TABLE_NODES_PER_OCTAVE) + 1
+    u = TABLE_LOG2_RHO_MIN + np.arange(n) / float(TABLE_NODES_PER_OCTAVE)
+    rho = np.exp2(u)
+    tab = np.empty((n, 2))
+    for i in range(n):
+        J = np.asarray(model.Jresidual_from_error(np.array([rho[i], 0.])), float)
+        h = J[1, 1]
+        tab[i, 0] = h
+        tab[i, 1] = (J[0, 0] - h) * np.log(2.)              # dh/du = h'(rho) rho ln 2,  h' rho = J00 - J11
+    if not np.all(np.isfinite(tab)):
+        raise TypeError('sensor model %r: residual Jacobian is not finite on [2^%g, 2^%g]' % (model, TABLE_LOG2_RHO_MIN, TABLE_LOG2_RHO_MAX))
+    # isotropy: at a few errors off the axes, r = h(|e|) e and J = h I + (h'/rho) e e^T with the sampled h, h'
+    rs = np.random.RandomState(7)
+    for scale in (1e-3, 3e-2, 1., 40.):
+        e = rs.randn(2) * scale
+        r_ = np.sqrt(e.dot(e))
+        i = int(round((np.log2(r_) - TABLE_LOG2_RHO_MIN) * TABLE_NODES_PER_OCTAVE))
+        en = e * (rho[i] / r_)                                # the same direction, on a node
+        h, hp_rho = tab[i, 0], tab[i, 1] / np.log(2.)
+        want_r = h * en
+        want_J = h * np.eye(2) + (hp_rho / (rho[i] * rho[i])) * np.outer(en, en)
+        got_r = np.asarray(model.residual_from_error(en), float)
+        got_J = np.asarray(model.Jresidual_from_error(en), float)
+        tol = 1e-9 * max(abs(h), 1e-300)
+        if np.max(np.abs(got_r - want_r)) > tol * rho[i] or np.max(np.abs(got_J - want_J)) > 1e-7 * max(np.max(np.abs(want_J)), 1e-300):
+            raise TypeError('sensor model %r is not isotropic (r = h(|e|) e): it has no device form' % (model,))
+    return capi.SENSOR_TABLE, np.concatenate(([TABLE_LOG2_RHO_MIN, float(TABLE_NODES_PER_OCTAVE), float(n)], tab.reshape(-1)))
+
+
 def device_params_of(model):
-    """(kind, params) for our models and for duck-typed reference models
-    (classes named GaussianModel with .L / CauchyModel with .sigma)."""
+    """(kind, params) for our models, for duck-typed reference models (classes named GaussianModel with .L / CauchyModel
+    with .sigma), and - the reference's plug-in point, sensor_model.py:19-32 / bundle.py:269-273 - for ANY object with
+    residual_from_error / Jresidual_from_error whose residual is isotropic: sampled once into a table (tabulate; cached on
+    the object) that the kernels interpolate."""
     if hasattr(model, 'device_params'):
         return model.device_params()
     name = type(model).__name__
@@ -111,7 +152,35 @@ def device_params_of(model):
         return capi.SENSOR_CAUCHY, np.array([model.sigma], float)
     if name == 'HuberModel' and hasattr(model, 'k'):
         return capi.SENSOR_HUBER, np.array([model.k], float)
-    raise TypeError('sensor model %r has no device form: use GaussianModel, CauchyModel or HuberModel' % (model,))
+    if hasattr(model, 'residual_from_error') and hasattr(model, 'Jresidual_from_error'):
+        cached = getattr(model, '_pysfm_amd_table', None)
+        if cached is None:
+            cached = tabulate(model)
+            try:
+                model._pysfm_amd_table = cached
+            except AttributeError:
+                pass
+        return cached
+    raise TypeError('sensor model %r has no device form: it needs residual_from_error and Jresidual_from_error' % (model,))
+
+
+class TabulatedModel(_DeviceSensorModel):
+    """Device-evaluated view of a caller-defined isotropic model: residual_from_error / Jresidual_from_error go through
+    the interpolated table on the GPU (ba_eval_sensor) - what the kernels see of the model - cost_from_error is the
+    model's own.  `validate(TabulatedModel(m))` is the reference's self-check (sensor_model.py:76-99) of the device form."""
+
+    def __init__(self, model):
+        self.model = model
+        self._params = device_params_of(model)
+
+    def device_params(self):
+        return self._params
+
+    def cost_from_error(self, x):
+        return self.model.cost_from_error(x)
+
+    def clone(self):
+        return TabulatedModel(self.model.clone() if hasattr(self.model, 'clone') else self.model)
 
 
 def validate(sensor_model):

@@ -70,3 +70,27 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+class GemanMcClure(object):
+    """A robustifier the library does not know: cost = |e|^2 / (|e|^2 + s^2), residual e / sqrt(|e|^2 + s^2) - a plain
+    object with the reference's four-method protocol (sensor_model.py:19-32)."""
+
+    def __init__(self, s):
+        self.s = s
+
+    def cost_from_error(self, e):
+        e = np.asarray(e, float)
+        return float(e.dot(e) / (e.dot(e) + self.s ** 2))
+
+    def residual_from_error(self, e):
+        e = np.asarray(e, float)
+        return e / np.sqrt(e.dot(e) + self.s ** 2)
+
+    def Jresidual_from_error(self, e):
+        e = np.asarray(e, float)
+        d = e.dot(e) + self.s ** 2
+        return np.eye(2) / np.sqrt(d) - np.outer(e, e) / d ** 1.5
+
+    def clone(self):
+        return GemanMcClure(self.s)

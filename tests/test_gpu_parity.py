@@ -34,7 +34,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1,
-                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1)
+                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, trial_graph=0)
 
 
 @pytest.fixture(autouse=True)
@@ -509,6 +509,17 @@ def test_config3_full_lm_converges(config3, init_mode):
     assert ba2.costs[-1] <= ba2.costs[0] and ba2.costs[0] - ba2.costs[-1] <= 1e-2 * ba.costs[-1]
 
 
+def _device_lu(be, mask):
+    """The same device-resident system through LU with partial pivoting down the band (option solver = lu, ba_band_lu.h):
+    an independent factorisation to compare the Cholesky solvers with."""
+    be.set_option('solver', 'lu')
+    be.solve_reduced(mask)
+    assert be.last_solve_kind == 'band_lu'
+    x = be.get_solution().reshape(-1)
+    be.set_option('solver', 'auto')
+    return x
+
+
 def test_band_solver_vs_dense_lu(be):
     """k_band_solve (block Cholesky on the band) against the dense LU path on the same
     device-resident system, with and without masked camera parameters."""
@@ -525,10 +536,9 @@ def test_band_solver_vs_dense_lu(be):
         be.solve_reduced(mask)
         assert be.last_solve_path == 'band'
         x = be.get_solution().reshape(-1)
-        keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
-        xd = np.zeros(n)
-        xd[keep] = be._solve_dense(keep)
+        xd = _device_lu(be, mask)
         close(x, xd, 1e-9)
+        close(xd, _dense_reference(be, mask), 1e-9)
         if mask is not None:
             assert np.all(x[mask == 0] == 0)
         mu, su = O.compute_update(sensor, *a, *flags, damping=1., cam_param_mask=None if mask is None else mask.astype(bool))
@@ -561,9 +571,7 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
                 assert be.last_solve_path == 'band'
                 assert be.last_solve_kind == ('band' if solver == 'band' or (solver == 'bcr1' and L > 12) else 'bcr' if L <= 12 else 'bcr_wide')
             sol[solver] = be.get_solution().reshape(-1)
-        keep = np.arange(n, dtype=np.int32) if mask is None else np.nonzero(mask)[0].astype(np.int32)
-        xd = np.zeros(n)
-        xd[keep] = be._solve_dense(keep)
+        xd = _device_lu(be, mask)
         close(sol['bcr'], xd, 1e-9)
         close(sol['band'], xd, 1e-9)
         close(sol['bcr'], sol['band'], 1e-10)
@@ -1407,4 +1415,70 @@ def test_a_reference_style_bundle_of_plain_objects_walks_the_golden_trajectory()
     close(np.array([c.R for c in out.cameras]), g['lm_R'], 1e-6)
     close(np.array([c.t for c in out.cameras]), g['lm_t'], 1e-6, 1e-9)
     close(out.reconstruction, g['lm_X'], 1e-6)
+    ba.backend.close()
+
+
+def test_trial_replayed_as_a_graph_equals_the_direct_launches():
+    """Option trial_graph: ba_lm_trial captures its launches per (damping, parameter-set parity) and replays them as one
+    hipGraph.  The LM run through replayed graphs - accepted and rejected trials, dampings that come back - must be the run
+    of the direct launches: same decisions, same costs to the last digits (the same kernels on the same data; only the order
+    of fp64 atomics may differ), same final parameters."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    s = banded(120, 6000, track_len=8, outlier_frac=.03, init_mode='params')
+    out = {}
+    for tag in ('direct', 'graph'):
+        b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
+                                    sensor_model=sensor_model.CauchyModel(.05))
+        ba = BundleAdjuster(verbose=False)
+        ba.backend.set_option('trial_graph', tag == 'graph')
+        ba.set_bundle(b)
+        ba.optimize(max_steps=12)
+        assert ba.lm_trials >= 14
+        out[tag] = (np.array(ba.costs), [(d, o) for d, o, c in ba.trial_log], np.array([c for d, o, c in ba.trial_log])) + ba.backend.get_params(0)
+        ba.backend.close()
+    assert out['graph'][1] == out['direct'][1]
+    for k in (0, 2, 3, 4, 5):
+        close(out['graph'][k], out['direct'][k], 1e-10)
+
+
+# ------------------------------------------------------------------ the sensor-model plug-in point (sensor_model.py:19-32)
+def test_a_caller_defined_robustifier_runs_on_the_device(be):
+    """A Geman-McClure model defined HERE, as a plain object with the reference's four methods, handed to the adjuster as
+    bundle.sensor_model: the kernels evaluate it through the sampled table (BA_SENSOR_TABLE).  (1) the reference's own
+    self-check, sensor_model.validate, on the device form; (2) residual and Jacobian on the device against the Python
+    model over eight decades of |e|; (3) an LM run on the reference's 5-camera / 50-point scene against the oracle driven
+    by the same Python model, called per observation as the reference calls it (bundle.py:251-252, 269-273): same
+    decisions, costs to 1e-6, parameters to 1e-6."""
+    from conftest import GemanMcClure
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    from pysfm_amd import synthetic_data as sd
+    m = GemanMcClure(.05)
+    sensor_model.validate(sensor_model.TabulatedModel(m))
+    be.set_sensor(*sensor_model.device_params_of(m))
+    rs = np.random.RandomState(1)
+    e = rs.randn(4000, 2) * 10 ** rs.uniform(-5, 3, (4000, 1))
+    e[:3] = [[0., 0.], [1e-300, 0.], [0., -3e-14]]
+    r, J = be.eval_sensor(e)
+    r0 = np.array([m.residual_from_error(x) for x in e])
+    J0 = np.array([m.Jresidual_from_error(x) for x in e])
+    assert np.max(np.abs(r - r0) / np.maximum(np.abs(r0).max(axis=1, keepdims=True), 1e-300)) <= 1e-11
+    assert np.max(np.abs(J - J0) / np.abs(J0).max(axis=(1, 2), keepdims=True)) <= 2e-9
+    K, Rs, ts, pts, msm = sd.generate_sequence(5, 50)
+    b = Bundle.FromArrays(K, Rs, ts, pts, msm)
+    b.sensor_model = m
+    ba = BundleAdjuster(b, verbose=False)
+    ba.optimize(max_steps=8)
+    cam, pt, z = b.select_observations(range(5), range(50))
+    flags = (np.arange(5, dtype=np.int32) - 1, np.ones(50, bool))
+    trace = []
+    ref = O.lm_optimize(O.Sensor.from_model(m), K, Rs, ts, pts, cam, pt, z, *flags, max_steps=8, trace=trace)
+    got = [(d, o == 'accepted') for d, o, c in ba.trial_log]
+    want = [(tr['damping'], tr['next'] < tr['cur']) for tr in trace]
+    assert len(got) == len(want) and all(g[1] == w[1] and abs(g[0] - w[0]) <= 1e-12 * w[0] for g, w in zip(got, want)), (got, want)
+    assert ba.num_steps == ref['num_steps'] and ba.converged == ref['converged']
+    close(np.array(ba.costs), np.array(ref['costs']), 1e-6)
+    out = ba.bundle
+    close(out.ts(), ref['t'], 1e-6, 1e-9)
+    close(out.reconstruction, ref['X'], 1e-6)
+    assert ba.costs[-1] < ba.costs[0]
     ba.backend.close()

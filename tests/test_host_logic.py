@@ -580,3 +580,40 @@ def test_algebra_and_optimize_helper_modules():
     assert np.allclose(np.diag(Bd), 3.) and np.allclose(A, 1.) and Bd[0, 1] == 1.
     optimize.apply_lm_damping_inplace(A, 1.)
     assert np.allclose(np.diag(A), 2.) and optimize.skew is algebra.skew
+
+
+def test_a_caller_defined_sensor_model_is_sampled_into_a_table():
+    """The reference's plug-in point (sensor_model.py:19-32, bundle.py:269-273): any object with the four methods.  An
+    isotropic one gets a device form - BA_SENSOR_TABLE, h(rho) and dh/dlog2(rho) on a grid the kernels interpolate; here
+    the interpolation formula of csrc/ba_math.h mirrored in NumPy against the model itself; an anisotropic one is refused."""
+    from conftest import GemanMcClure
+    from pysfm_amd._capi import SENSOR_TABLE
+    m = GemanMcClure(.05)
+    kind, p = sensor_model.device_params_of(m)
+    assert kind == SENSOR_TABLE and sensor_model.device_params_of(m)[1] is p          # sampled once, cached on the object
+    u0, inv_du, n = p[0], p[1], int(p[2])
+    tab = p[3:].reshape(n, 2)
+    rs = np.random.RandomState(0)
+    for _ in range(300):
+        e = rs.randn(2) * 10 ** rs.uniform(-4, 2)
+        rho2 = e.dot(e)
+        t = (0.5 * np.log2(rho2) - u0) * inv_du
+        i = min(int(t), n - 2)
+        f, du = t - i, 1. / inv_du
+        h0, m0, h1, m1 = tab[i, 0], tab[i, 1] * du, tab[i + 1, 0], tab[i + 1, 1] * du
+        c2, c3 = 3 * (h1 - h0) - 2 * m0 - m1, 2 * (h0 - h1) + m0 + m1
+        h = h0 + f * (m0 + f * (c2 + f * c3))
+        q = (m0 + f * (2 * c2 + 3 * f * c3)) * inv_du / np.log(2.) / rho2
+        close(h * e, m.residual_from_error(e), 1e-11)
+        close(h * np.eye(2) + q * np.outer(e, e), m.Jresidual_from_error(e), 1e-8)
+
+    class Anisotropic(GemanMcClure):
+        def residual_from_error(self, e):
+            return GemanMcClure.residual_from_error(self, e) * np.array([1., 2.])
+
+        def Jresidual_from_error(self, e):
+            return GemanMcClure.Jresidual_from_error(self, e) * np.array([[1.], [2.]])
+    with pytest.raises(TypeError, match='not isotropic'):
+        sensor_model.device_params_of(Anisotropic(.05))
+    with pytest.raises(TypeError, match='no device form'):
+        sensor_model.device_params_of(object())
