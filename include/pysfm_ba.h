@@ -86,7 +86,6 @@ int ba_synchronize(ba_handle* h);
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
  *   "gm_cap"        n                                      points per group of the MFMA reduction (0 = automatic)
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
- *   "trial_graph"   1 | 0                                  ba_lm_trial replays its launches as one hipGraph per (damping, parameter-set parity); default 0
  * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap") take effect at
  * the next ba_set_problem. */
 int ba_set_option(ba_handle* h, const char* name, const char* value);

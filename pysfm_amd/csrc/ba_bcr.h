@@ -541,18 +541,6 @@ __device__ __forceinline__ void bcr_st16(double* p, bcr_d2 v) {       // (acknow
 #ifndef BA_BCR_WIDE_HANDOVER
 #define BA_BCR_WIDE_HANDOVER 1      // fused kernel: the inputs of a node and the factor it hands on move 16 bytes per lane
 #endif
-#ifndef BA_BCR_FLAG_SLEEP
-#define BA_BCR_FLAG_SLEEP 1
-#endif
-__device__ __forceinline__ void bcr_lds_wait(int* flag, int need) {
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(BA_BCR_FLAG_SLEEP);
-}
-#ifndef BA_BCR_LDS_FLAGS
-#define BA_BCR_LDS_FLAGS 0          // split / fused node kernels: LDS counters instead of the two barriers of a block step (measured: slower)
-#endif
-#ifndef BA_BCR_TWO_STAGE
-#define BA_BCR_TWO_STAGE 0          // fused kernel: a second, early word per role for its factor (see bcr_split_node)
-#endif
 #ifndef BA_BCR_STORE_FIRST
 #define BA_BCR_STORE_FIRST 1        // fused kernel: the factors P / Q leave for memory BEFORE the neighbour products (their latency rides under the MFMAs)
 #endif
@@ -606,32 +594,13 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
 
   if (tid == 0) { bad[0] = 0; bad[1] = 0; }      // bad[1]: wavefronts of this workgroup whose factor stores have landed (fused kernel)
-  // BA_BCR_LDS_FLAGS: the two barriers of a block step as counters in LDS (who waits for whom is written at the waits below):
-  // wavefront 0, whose pivot chain is the length of the node, then never waits for a wavefront that is not ahead of it anyway
-  int* cP1 = reinterpret_cast<int*>(Li + 384 + kBcrIdtDoubles + 8);      // helper wavefronts (1..15) done with phase 1, summed over the steps
-  int* cP2 = cP1 + 1;                                                    // panel wavefronts (0..3) done with phase 2, summed over the steps
-  int* fLi = cP1 + 2;                                                    // diagonal blocks factored so far (their inverses are in Li)
-  if (tid == 0) { *cP1 = 0; *cP2 = 0; *fLi = 1; }                        // (block 0 is factored before the barrier that ends the prologue)
   if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
   double* Idt = Li + 384;
   bcr_identity_table(Idt, tid);
-  // FUSED, a role with a coupling to form (TWO_STAGE): the factors it is formed from are published early by their producers
-  // (right after their factorisation, before their neighbour products), D_i late (after those products): all wavefronts
-  // fetch P_j, Q_j and 15 of them form the coupling while wavefront 0 alone waits for D_i, fetches it and factors block 0
-  // (BA_BCR_TWO_STAGE, measured and left off: the early word is seen only 0.35 us before the late one - the stores of the
-  // factor take as long to be acknowledged as the neighbour products take to run - and wavefront 0 alone needs 3.3 us for
-  // fetching D_i and factoring block 0, against 2.4 us for the coupling product it runs beside: 98.0 us for the seven
-  // levels of config 3 against 95.9 us with one word per role, everything fetched by all wavefronts at once)
-  const bool two_stage = FUSED && BA_BCR_TWO_STAGE && s > 1 && role < 2 && dep.pq[0] != nullptr;
   if constexpr (FUSED) {
     // (selects, not indexing: a runtime index would put the struct into scratch memory)
-    if (two_stage) {
-      const int* word = tid == 0 ? dep.pq[0] : dep.pq[1];
-      if (tid < 2 && word) bcr_wait_done(word, dep.status);
-    } else {
-      const int* word = tid == 0 ? dep.d[0] : tid == 1 ? dep.d[1] : tid == 2 ? dep.pq[0] : dep.pq[1];
-      if (tid < 4 && word) bcr_wait_done(word, dep.status);
-    }
+    const int* word = tid == 0 ? dep.d[0] : tid == 1 ? dep.d[1] : tid == 2 ? dep.pq[0] : dep.pq[1];
+    if (tid < 4 && word) bcr_wait_done(word, dep.status);
     __syncthreads();
   }
   BA_TLINE(1);
@@ -650,7 +619,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     // FUSED, above the first level: D_i and the two factors as 16-byte pairs (entries 2 q, 2 q + 1 share a row: B is even),
     // half as many trips to memory; pairs past the end read pair 0 again (never stored)
     constexpr int NPAIR = B * B / 2, NITW = (NPAIR + kBcrElimThreads - 1) / kBcrElimThreads;
-    const bool wide = FUSED && BA_BCR_WIDE_HANDOVER && NITW <= 2 && s > 1 && !two_stage;
+    const bool wide = FUSED && BA_BCR_WIDE_HANDOVER && NITW <= 2 && s > 1;
     if (wide) {
       const double* pd = Dm + (size_t)i * BB;
       const double* pa = prod ? Pm + (size_t)j * BB : pd;
@@ -682,7 +651,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + it * kBcrElimThreads;
       const bool ok = e < B * B;
-      vd[it] = (ok && !two_stage) ? bcr_ld<FUSED>(Dm + (size_t)i * BB + e) : 0.0;
+      vd[it] = ok ? bcr_ld<FUSED>(Dm + (size_t)i * BB + e) : 0.0;
       va[it] = (ok && direct) ? srcU[e] : (ok && prod) ? bcr_ld<FUSED>(Pm + (size_t)j * BB + e) : 0.0;
       vb[it] = (ok && prod) ? bcr_ld<FUSED>(Qm + (size_t)j * BB + e) : 0.0;
     }
@@ -691,7 +660,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
       const int e = tid + it * kBcrElimThreads;
       if (e < B * B) {
         const int rr = e / B, cc = e - rr * B;
-        if (!two_stage) G[rr * ld + cc] = vd[it];
+        G[rr * ld + cc] = vd[it];
         if (direct) {
           if (role == 0) R[cc * ld + rr] = va[it];                  // T[i,l] = T[l,i]^T
           else R[rr * ld + cc] = va[it];                            // T[i,r]
@@ -704,8 +673,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
       }
     }
     }
-    if (!two_stage)
-      for (int e = tid; e < B; e += kBcrElimThreads) g[e] = bcr_ld<FUSED>(fm + (size_t)i * B + e);
+    for (int e = tid; e < B; e += kBcrElimThreads) g[e] = bcr_ld<FUSED>(fm + (size_t)i * B + e);
     __syncthreads();
     BA_TLINE(2);
 #ifdef BA_BCR_PROFILE
@@ -716,32 +684,6 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   //      from the factors of the node eliminated one level down
   constexpr int NBLK = (B + 11) / 12;
   if (wave == 0) {
-    if constexpr (FUSED) {
-      if (two_stage) {
-        // D_i, f_i: once everybody who adds to them has (one lane per word), fetched by this wavefront alone in two rounds
-        const int* word = lane == 0 ? dep.d[0] : dep.d[1];
-        if (lane < 2 && word) bcr_wait_done(word, dep.status);
-        constexpr int NW = (B * B + 63) / 64, H0 = (NW + 1) / 2;
-        const double gv = lane < B ? bcr_ld<true>(fm + (size_t)i * B + lane) : 0.0;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int w0 = half ? H0 : 0, w1 = half ? NW : H0;
-          double v[H0];
-#pragma unroll
-          for (int w = 0; w < H0; ++w) {
-            const int e = lane + 64 * (w0 + w);
-            v[w] = (w0 + w < w1 && e < B * B) ? bcr_ld<true>(Dm + (size_t)i * BB + e) : 0.0;
-          }
-#pragma unroll
-          for (int w = 0; w < H0; ++w) {
-            const int e = lane + 64 * (w0 + w);
-            if (w0 + w < w1 && e < B * B) { const int rr = e / B, cc = e - rr * B; G[rr * ld + cc] = v[w]; }
-          }
-        }
-        for (int e = lane; e < B; e += 64) g[e] = e == lane ? gv : bcr_ld<true>(fm + (size_t)i * B + e);
-        lds_wave_sync();
-      }
-    }
     __builtin_amdgcn_s_setprio(3);
     if (B >= 12) bcr_diag_block<12, false>(G, ld, dinv, bad, 0, lane, Li, Idt);
     else bcr_diag_block<6, false>(G, ld, dinv, bad, 0, lane, Li, Idt);
@@ -846,7 +788,6 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
     const int kn = k0 + nb;                                 // first unknown after this block
     // ---------------- phase 1 (block 0 was factored above, next to the prologue; it has no late updates)
-    if (BA_BCR_LDS_FLAGS && kb > 0 && wave != 0) bcr_lds_wait(cP2, 4 * kb);      // the helpers need the whole panel of block kb - 1
 #ifdef BA_BCR_PROFILE
     const long long q0 = clock64();
 #endif
@@ -975,20 +916,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
 #ifdef BA_BCR_PROFILE
     if (i == 3 * s - 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q0);      // phase 1 of one block step, per wavefront
 #endif
-    if (BA_BCR_LDS_FLAGS) {
-      if (kb > 0) {
-        if (wave == 0) gm2_post(fLi, kb + 1, lane);                        // the inverse of diagonal block kb is in Li
-        else { lds_wave_sync(); if (lane == 0) __hip_atomic_fetch_add(cP1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      }
-      if (wave < 4) {
-        // the panel needs the helpers' updates of block column kb (and wavefront 0's prefetch their update of the next diagonal
-        // tile): all of phase 1 of this step; wavefronts 1..3 also the inverse of the diagonal block
-        if (kb > 0) bcr_lds_wait(cP1, 15 * kb);
-        if (wave > 0) bcr_lds_wait(fLi, kb + 1);
-      }
-    } else if (kb > 0) {
-      __syncthreads();
-    }
+    if (kb > 0) __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long q1 = clock64();
     pst[3] += q1 - q0;
@@ -999,12 +927,11 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
         if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
         bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
       }
-      if (BA_BCR_LDS_FLAGS) { lds_wave_sync(); if (lane == 0) __hip_atomic_fetch_add(cP2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
     }
 #if defined(BA_BCR_PROFILE) && defined(BA_BCR_TRACE_PH2)
     if (i == 3 * s - 1 && s == 2 && role == 0 && kb == BA_BCR_TRACE_KB && lane == 0) info[44 + wave] = (int)(clock64() - q1);      // phase 2 of one block step, per wavefront
 #endif
-    if (!BA_BCR_LDS_FLAGS) __syncthreads();
+    __syncthreads();
 #ifdef BA_BCR_PROFILE
     const long long q2 = clock64();
     pst[4] += q2 - q1;
@@ -1013,7 +940,6 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
 #ifdef BA_BCR_PROFILE
   const long long pt2 = clock64();
 #endif
-  if (BA_BCR_LDS_FLAGS && rhs_ct >= 0) bcr_lds_wait(fLi, NBLK);                // (the last diagonal block's inverse)
   if (rhs_ct >= 0) {
     // the last block row of the right-hand sides: Y = L_pp^-1 racc[NBLK - 1] (nothing below it)
     constexpr int KL = 12 * (NBLK - 1), NL = B - KL;          // last block: start and size (12 or 6)
@@ -1061,7 +987,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     // ... and is PUBLISHED as soon as every wavefront's stores have been acknowledged - which each wavefront checks when its
     // matrix products are done, right before its first atomic (no stall: the stores left a microsecond earlier); the last one
     // to arrive says so.  The consumers form their coupling from it while this workgroup is still adding to its neighbour.
-    bool arrived = !(FUSED && BA_BCR_STORE_FIRST && BA_BCR_TWO_STAGE);
+    bool arrived = false;
     auto arrive = [&] {
       if constexpr (FUSED && BA_BCR_STORE_FIRST) {
         if (!arrived) {
@@ -1392,8 +1318,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, 
     dep.d[1] = right >= 0 ? done + 4 * right + 2 : nullptr;
     if (role < 2) {
       const int j = role == 0 ? i - h : i + h;             // the node eliminated between i and this role's neighbour
-      dep.pq[0] = done + 4 * j + (BA_BCR_TWO_STAGE ? 0 : 2);
-      dep.pq[1] = done + 4 * j + (BA_BCR_TWO_STAGE ? 1 : 3);
+      dep.pq[0] = done + 4 * j + 2;
+      dep.pq[1] = done + 4 * j + 3;
     }
   }
   const bool ok = bcr_split_node<HB, true>(sm, N, s, i, role, Dm, Um, fm, Pm, Qm, Gi, gm, info, xout, dep, tline);
@@ -1404,7 +1330,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, 
     if (!ok) __hip_atomic_store(done + 4 * i + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (not positive definite: nobody may wait)
     __hip_atomic_store(done + 4 * i + 2 + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (threadIdx.x == 0 && role == 2 && !BA_BCR_TWO_STAGE)      // the inverse role: G^-1 and g are in memory (the back-substitution items wait for this)
+  if (threadIdx.x == 0 && role == 2)      // the inverse role: G^-1 and g are in memory (the back-substitution items wait for this)
     __hip_atomic_store(done + 4 * i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef BA_BCR_PROFILE
   if (tline && threadIdx.x == 0) tline[5] = wall_clock64();

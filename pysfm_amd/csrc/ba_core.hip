@@ -37,12 +37,6 @@ hipError_t ensure_lds_attr(ba_handle* h, const void* fn) {
   return e;
 }
 
-void drop_trial_graphs(ba_handle* h) {
-  for (auto& g : h->trial_graphs) (void)hipGraphExecDestroy(g.second.exec);
-  h->trial_graphs.clear();
-  h->trials_since_problem = 0;
-}
-
 DevProblem dev_problem(const ba_handle* h) {
   DevProblem P;
   P.nc = h->nc; P.nt = h->nt; P.nco = h->nco; P.hb = h->hb; P.nobs = h->nobs;
@@ -214,7 +208,6 @@ int ba_destroy(ba_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   (void)ba_comm_destroy(h);
-  drop_trial_graphs(h);
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   h->obs_cam.release(); h->obs_pt.release(); h->pt_off.release(); h->cam_opt_pos.release(); h->opt_cam.release();
@@ -285,13 +278,11 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "fused_backsolve") ok = flag(h->opt.fused_backsolve);
   else if (n == "fused_eliminate") ok = flag(h->opt.fused_eliminate);
   else if (n == "device_lu") ok = flag(h->opt.device_lu);
-  else if (n == "trial_graph") ok = flag(h->opt.trial_graph);
   else if (n == "fast_paths") ok = flag(h->opt.fast_paths);
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);
   if (!ok) return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: bad value '%s' for option '%s'", value, name);
   h->inv_valid = h->fac_valid = false;          // a different kernel family may need different by-products
-  drop_trial_graphs(h);
   return BA_OK;
 }
 
@@ -300,7 +291,6 @@ int ba_set_stream(ba_handle* h, void* hip_stream) {
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   resolve_timings(h);
-  drop_trial_graphs(h);
   if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
   if (hip_stream) {
     h->stream = (hipStream_t)hip_stream;
@@ -320,7 +310,7 @@ int ba_synchronize(ba_handle* h) {
 
 int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams) {
   if (!h) return BA_ERR_INVALID_ARG;
-  Sensor s{kind, {1, 0, 0, 1}, 1.0, 1.0, 0, nullptr, 0, 0.0, 1.0};
+  Sensor s{kind, {1, 0, 0, 1}, 1.0, 1.0, 0};
   switch (kind) {
     case BA_SENSOR_GAUSS:
       REQUIRE(h, params && nparams == 4, BA_ERR_INVALID_ARG, "ba_set_sensor: Gaussian needs 4 params (L row-major)");
@@ -346,14 +336,17 @@ int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams) {
       HIPCHECK(h, hipStreamSynchronize(h->stream));       // (kernels in flight may still read the previous table)
       HIPCHECK(h, h->sensor_table.resize((size_t)2 * n));
       HIPCHECK(h, hipMemcpy(h->sensor_table.p, params + 3, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice));
-      s.tab = h->sensor_table.p; s.tab_n = n; s.tab_u0 = params[0]; s.tab_inv_du = params[1];
+      {      // (address and shape in the fields the other kinds use: ba_math.h Sensor)
+        const unsigned long long bits = reinterpret_cast<unsigned long long>(h->sensor_table.p);
+        std::memcpy(&s.L[0], &bits, 8);
+        s.L[1] = params[0]; s.L[2] = params[1]; s.L[3] = (double)n;
+      }
       break;
     }
     default:
       return h->fail(BA_ERR_INVALID_ARG, "ba_set_sensor: unknown kind %d", kind);
   }
   h->sensor = s;
-  drop_trial_graphs(h);
   h->have_linearization = h->have_schur = h->have_backsub = false;
   return BA_OK;
 }
@@ -487,7 +480,6 @@ int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb) {
 int ba_bind_trial_result(ba_handle* h, void* result_dev) {
   if (!h) return BA_ERR_INVALID_ARG;
   static_assert(BA_TRIAL_PARTIALS == kCostBlocks, "header and kernel disagree on the number of cost partials");
-  drop_trial_graphs(h);
   h->trial_result_dev = static_cast<double*>(result_dev);
   return BA_OK;
 }

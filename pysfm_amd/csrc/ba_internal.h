@@ -62,7 +62,6 @@ struct Options {
   bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
   bool device_lu = true;           // a reduced system the Cholesky solve reports as not positive definite is solved again by the cyclic reduction with LU nodes
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
-  bool trial_graph = false;        // ba_lm_trial replays its launches as a hipGraph (one graph per damping value and parameter-set parity)
 };
 
 }  // namespace ba
@@ -101,7 +100,7 @@ struct ba_handle {
   double trial_rcond = 0.0;          // ba_lm_trial_begin -> ba_lm_trial_end
   int glog = 0;              // lanes per point = 2^glog
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0, FAST_UNIT_GAUSS, nullptr, 0, 0.0, 1.0};
+  Sensor sensor{SENSOR_GAUSS, {1, 0, 0, 1}, 1.0, 1.0, FAST_UNIT_GAUSS};
   DevBuf<double> sensor_table;       // BA_SENSOR_TABLE: the sampled robustifier
   DevBuf<int> obs_cam, obs_pt, pt_off, cam_opt_pos, opt_cam, keep;
   DevBuf<double2> obs_z;
@@ -183,15 +182,6 @@ struct ba_handle {
     size_t xcount[3] = {0, 0, 0};       // doubles of the three exchanges
   } dist;
   bool have_solution = false;
-  // option trial_graph: the launches of one ba_lm_trial, captured once per (parameter-set parity, counter parity, damping, rcond)
-  struct TrialGraph {
-    hipGraphExec_t exec = nullptr;
-    // what the captured calls left in the handle (they are not run again on a replay)
-    int sing_epoch, solve_kind, lin_phys, cost_blocks;
-    bool cost_fused, inv_valid, fac_valid, point_blocks_valid, cam_blocks_valid;
-  };
-  std::map<std::vector<unsigned long long>, TrialGraph> trial_graphs;
-  int trials_since_problem = 0;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
   DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
                             // counters (alternate per ba_schur call)
@@ -278,7 +268,6 @@ DevProblem dev_problem(const ba_handle* h);
 
 inline size_t reduced_doubles(const ba_handle* h) { return (size_t)h->nco * (h->hb + 1) * 36; }
 int ensure_reduced(ba_handle* h);
-void drop_trial_graphs(ba_handle* h);      // (option trial_graph: captured launches belong to one problem, sensor, option set and stream)
 
 // ---- RCCL, resolved at run time (ba_comm_load): the library does not link against it, it uses the one the
 // process already has (torch's), so that there is a single RCCL instance per process

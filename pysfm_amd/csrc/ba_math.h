@@ -27,11 +27,10 @@ struct Sensor {
                   // own defaults: bundle.py:139, synthetic_data.py K = eye) skip a fifth of the per-observation work.
   // SENSOR_TABLE: any isotropic robustifier r = h(rho) e, rho = |e| (the reference's plug-in point, sensor_model.py:19-32:
   // an object with four methods) - h sampled by the host on a grid uniform in log2(rho): node i at rho_i = 2^(u0 + i / inv_du)
-  // holds {h(rho_i), dh/du(rho_i)}; cubic Hermite interpolation in u (h to ~1e-13, its derivative to ~3e-10 at 256 nodes per
-  // octave).  J = h I + (h'(rho) / rho) e e^T.  Below the first node h is the constant tab[0]; beyond the last, the last cell's cubic.
-  const double* tab;
-  int tab_n;
-  double tab_u0, tab_inv_du;
+  // holds (h(rho_i), dh/du(rho_i)); cubic Hermite interpolation in u (h to ~1e-13, its derivative to ~3e-10 at 256 nodes per
+  // octave).  J = h I + (h'(rho) / rho) e e^T.  Below the first node h is the constant tab[0]; beyond the last, the last cell's
+  // cubic.  The table's address and shape travel in the fields the other kinds use (the struct is a kernel argument of every
+  // launch): L[0] = the device address (bit pattern), L[1] = u0, L[2] = inv_du, L[3] = number of nodes.
 };
 enum { FAST_UNIT_GAUSS = 1, FAST_K_IDENTITY = 2 };
 
@@ -40,6 +39,10 @@ enum { FAST_UNIT_GAUSS = 1, FAST_K_IDENTITY = 2 };
 // its linear window |e| < 1e-5 and its log(1 + rho^2/sigma^2) (not log1p).
 // Huber: rho_H(s) = s^2 (s <= k), 2ks - k^2 otherwise, same vector-residual form.
 // Table: any isotropic robustifier the caller defines in Python, interpolated (see Sensor).
+// TABLE: whether this instance can evaluate SENSOR_TABLE.  The kernels on the trial's fast path are compiled without it (their
+// registers and code size are what they were); a handle whose sensor model is a table takes the general kernels (k_linearize,
+// k_camera_blocks, k_schur_pairs / the dense reduction, k_backsub, k_cost), which are.
+template <bool TABLE = false>
 BA_HD void sensor_eval(const Sensor& s, double e0, double e1, double r[2], double J[4]) {
   if (s.kind == SENSOR_GAUSS) {
     r[0] = s.L[0] * e0 + s.L[1] * e1;
@@ -70,19 +73,24 @@ BA_HD void sensor_eval(const Sensor& s, double e0, double e1, double r[2], doubl
     J[3] = e1 * e1 * a + (rho - e1 * e1 * ir) * c;
     return;
   }
-  if (s.kind == SENSOR_TABLE) {
-    double h = s.tab[0], q = 0.0;                         // q = h'(rho) / rho
+  if (TABLE && s.kind == SENSOR_TABLE) {
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &s.L[0], 8);
+    const double* tab = reinterpret_cast<const double*>(bits);
+    const double u0 = s.L[1], inv_du = s.L[2];
+    const int n = (int)s.L[3];
+    double h = tab[0], q = 0.0;                           // q = h'(rho) / rho
     if (rho2 > 0.0) {
-      const double t = (0.5 * log2(rho2) - s.tab_u0) * s.tab_inv_du;
+      const double t = (0.5 * log2(rho2) - u0) * inv_du;
       if (t > 0.0) {
         int i = (int)t;
-        if (i > s.tab_n - 2) i = s.tab_n - 2;
-        const double f = t - (double)i, du = 1.0 / s.tab_inv_du;
-        const double h0 = s.tab[2 * i], m0 = s.tab[2 * i + 1] * du, h1 = s.tab[2 * i + 2], m1 = s.tab[2 * i + 3] * du;
+        if (i > n - 2) i = n - 2;
+        const double f = t - (double)i, du = 1.0 / inv_du;
+        const double h0 = tab[2 * i], m0 = tab[2 * i + 1] * du, h1 = tab[2 * i + 2], m1 = tab[2 * i + 3] * du;
         // Hermite cubic on [0, 1]: c0 + c1 f + c2 f^2 + c3 f^3
         const double c2 = 3.0 * (h1 - h0) - 2.0 * m0 - m1, c3 = 2.0 * (h0 - h1) + m0 + m1;
         h = h0 + f * (m0 + f * (c2 + f * c3));
-        const double dhdu = (m0 + f * (2.0 * c2 + 3.0 * f * c3)) * s.tab_inv_du;
+        const double dhdu = (m0 + f * (2.0 * c2 + 3.0 * f * c3)) * inv_du;
         q = dhdu * 1.4426950408889634 / rho2;           // dh/drho = dh/du / (rho ln 2); then / rho
       }
     }
@@ -131,23 +139,25 @@ BA_HD void reproj_error(const double* K, const double* cam, const double* x,
 }
 
 // residual only (Bundle.residual, bundle.py:251-252)
+template <bool TABLE = false>
 BA_HD void obs_residual(const double* K, const double* cam, const double* x, double z0, double z1,
                         const Sensor& s, double e[2], double r[2]) {
   double p[3], J[4], iz;
   reproj_error(K, cam, x, z0, z1, p, e, iz, s.fast);
   if (s.fast & FAST_UNIT_GAUSS) { r[0] = e[0]; r[1] = e[1]; return; }
-  sensor_eval(s, e[0], e[1], r, J);
+  sensor_eval<TABLE>(s, e[0], e[1], r, J);
 }
 
 // Bundle.Jresidual (bundle.py:255-277): Jc = Jr [J_R | J_t] (2x6), Jp = Jr J_x (2x3)
 //   Jpr (bundle.py:8-11), J_t = Jpr K, J_x = J_t R, J_R = J_x skew(-x) (lie.py:38-40)
+template <bool TABLE = false>
 BA_HD void obs_linearize(const double* K, const double* cam, const double* x, double z0, double z1,
                          const Sensor& s, double e[2], double r[2], double Jc[12], double Jp[6]) {
   double p[3], Jr[4], iz;
   reproj_error(K, cam, x, z0, z1, p, e, iz, s.fast);
   const bool unit = (s.fast & FAST_UNIT_GAUSS) != 0;
   if (unit) { r[0] = e[0]; r[1] = e[1]; }
-  else sensor_eval(s, e[0], e[1], r, Jr);
+  else sensor_eval<TABLE>(s, e[0], e[1], r, Jr);
   const double jp02 = -(p[0] * iz) * iz;
   const double jp12 = -(p[1] * iz) * iz;
   double Jt[6], Jx[6], JR[6];

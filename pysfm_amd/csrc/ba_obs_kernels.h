@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem P, const double* __r
     double cm[12], e[2], r[2];
     load_cam(cams, c, cm);
     const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
-    obs_residual(P.K, cm, x, z.x, z.y, P.sensor, e, r);
+    obs_residual<true>(P.K, cm, x, z.x, z.y, P.sensor, e, r);
     acc += r[0] * r[0] + r[1] * r[1];
   }
   acc = wave_sum(acc);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_eval(DevProblem P, const double* __r
   double cm[12], e[2], r[2], Jc[12], Jp[6];
   load_cam(cams, c, cm);
   const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
-  obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+  obs_linearize<true>(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
   if (oe) { oe[2 * n] = e[0]; oe[2 * n + 1] = e[1]; }
   if (orr) { orr[2 * n] = r[0]; orr[2 * n + 1] = r[1]; }
   if (oJc) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_sensor(Sensor s, long long n, c
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   double rr[2], JJ[4];
-  sensor_eval(s, e[2 * i], e[2 * i + 1], rr, JJ);
+  sensor_eval<true>(s, e[2 * i], e[2 * i + 1], rr, JJ);
   if (r) { r[2 * i] = rr[0]; r[2 * i + 1] = rr[1]; }
   if (J) {
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     const double2 z = P.obs_z[n];
     double cm[12], e[2], r[2], Jc[12], Jp[6];
     load_cam(cams, c, cm);
-    obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+    obs_linearize<true>(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
     hpp[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
     hpp[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
     hpp[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevProblem P, const do
     const double2 z = P.obs_z[n];
     const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
     double e[2], r[2], Jc[12], Jp[6];
-    obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+    obs_linearize<true>(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
     int idx = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
     const double2 z = P.obs_z[n];
     double cm[12], e[2], r[2], Jc[12], Jp[6];
     load_cam(cams, c, cm);
-    obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+    obs_linearize<true>(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
     const double* d = dC + (size_t)pos * 6;
     double v0 = 0.0, v1 = 0.0;
 #pragma unroll

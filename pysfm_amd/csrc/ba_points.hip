@@ -11,7 +11,7 @@ int launch_point_blocks(ba_handle* h, int p, double* Wd) {
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_LINEARIZE);
     const long long threads = (long long)h->nt << h->glog;
-    if (!Wd && h->point_groups && !h->opt.point_kernels_v1) {
+    if (!Wd && h->point_groups && !h->opt.point_kernels_v1 && h->sensor.kind != SENSOR_TABLE) {
       const int per_block = kBlock / kWave;
       hipLaunchKernelGGL(k_linearize_groups, dim3((h->ngroups + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
                          dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p);
@@ -217,7 +217,7 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
     ScopedTimer tm(h, BA_K_BACKSUB);
     const long long threads = (long long)h->nt << h->glog;
     h->cost_fused = false;
-    if (h->point_groups && !h->opt.point_kernels_v1) {
+    if (h->point_groups && !h->opt.point_kernels_v1 && h->sensor.kind != SENSOR_TABLE) {
       // inside ba_lm_trial the cost of the trial set rides along as well (k_cost's work)
       const int per_block = kBlock / kWave;
       const int nblk = std::min(kCostBlocks, (h->ngroups + per_block - 1) / per_block);

@@ -9,6 +9,7 @@ namespace ba {
 
 int pick_schur_kernel(const ba_handle* h) {
   if (h->dense_mode && h->nt > 0 && h->nco > 0) return KERN_DENSE;
+  if (h->sensor.kind == SENSOR_TABLE) return KERN_PAIRS;      // (a caller-defined sensor model: the kernels compiled with the table evaluation)
   const bool asc = h->groups_ascending && h->group_maxL >= 1;
   const bool m3 = (h->nm3chunks > 0 && h->nwgroups > 0) || h->nrgroups > 0 || h->nwide > 0;           // window groups: no identical camera lists needed
   const bool m12 = asc && h->nmchunks > 0 && h->schur_wn > 0 && h->group_maxL <= kGmMaxL;      // the L <= 10 kernels
@@ -157,6 +158,23 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                        h->X[p].p, h->units.p, h->chunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
   }
   HIPCHECK(h, hipGetLastError());
+#ifdef BA_BCR_PROFILE
+  if (h->opt.solve_trace && kern == KERN_MFMA2 && !h->defer) {
+    // when the workgroups of the reduction started and ended, relative to the first start (us)
+    const int n = std::min(h->nmchunks, kSchurTraceMax);
+    std::vector<long long> tr((size_t)2 * n);
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_schur_trace), tr.size() * sizeof(long long)));
+    long long t0 = LLONG_MAX;
+    for (int w = 0; w < n; ++w) t0 = std::min(t0, tr[2 * w]);
+    std::vector<double> st(n), en(n);
+    for (int w = 0; w < n; ++w) { st[w] = (tr[2 * w] - t0) * 0.01; en[w] = (tr[2 * w + 1] - t0) * 0.01; }
+    std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+    auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)std::min<double>(v.size() - 1, f * v.size())]; };
+    fprintf(stderr, "[k_schur_groups_mfma2: %d workgroups] start: last %.1f us | end: first %.1f, 10 %% %.1f, median %.1f, 90 %% %.1f, last %.1f us after the first start\n",
+            n, st.back(), en.front(), q(en, .1), q(en, .5), q(en, .9), en.back());
+  }
+#endif
   h->have_schur = true;
   h->have_backsub = h->have_solution = false;
   if (pinv_rcond < 0.0 && !h->defer) {   // plain-inverse mode must report singular blocks (numpy.linalg.inv raises)
@@ -232,7 +250,6 @@ int ba_reduced_device_ptrs(ba_handle* h, void** S_blocks, void** b) {
 int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_bind_reduced_buffers: call ba_set_problem first");
-  drop_trial_graphs(h);
   h->S = (double*)S_blocks_dev;
   h->b = (double*)b_dev;
   h->have_schur = false;
@@ -241,7 +258,6 @@ int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
 
 int ba_set_dense_visibility(ba_handle* h, int32_t on) {
   if (!h) return BA_ERR_INVALID_ARG;
-  drop_trial_graphs(h);
   h->dense_mode = on != 0;
   h->inv_valid = false;
   if (!on) { h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kSchurBlock) void k_schur_pairs(DevProblem P, const
         const double2 z = P.obs_z[n];
         double cm[12], e[2], r[2], Jc[12], Jp[6], W[18];
         load_cam(cams, c, cm);
-        obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+        obs_linearize<true>(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
         block_W(Jc, Jp, W);
         const int pos = P.cam_opt_pos[c];
         if (isRow) {
@@ -439,6 +439,12 @@ __global__ __launch_bounds__(kGroupBlock) void k_schur_groups(DevProblem P, cons
 // fac[k] = {D0, D1, D2, L10, L20, L21, v0, v1, v2}.
 // --------------------------------------------------------------------------
 
+#ifdef BA_BCR_PROFILE
+// PROFILE builds: when every workgroup of k_schur_groups_mfma2 started and ended (100 MHz wall clock): the rows of S are
+// final when the LAST workgroup that touches them ends - how early that is decides what a consumer could overlap with
+constexpr int kSchurTraceMax = 4096;
+__device__ long long g_schur_trace[2 * kSchurTraceMax];
+#endif
 __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, const double* __restrict__ cams,
                                                                   const double* __restrict__ X,
                                                                   const SchurGroup* __restrict__ groups,
@@ -463,6 +469,7 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
   const bool producer = wv < kGm2Pairs;
 #ifdef BA_BCR_PROFILE
   const long long pkk = clock64();
+  if (threadIdx.x == 0 && blockIdx.x < kSchurTraceMax) g_schur_trace[2 * blockIdx.x] = wall_clock64();      // (option solve_trace prints the spread)
 #endif
   const SchurChunk ck = chunks[blockIdx.x];
   const int p0 = ck.p0;
@@ -760,6 +767,8 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
     if (v != 0.0 && p0 + i / 6 < P.nco) atomic_add_f64(b + (size_t)p0 * 6 + i, v);
   }
 #ifdef BA_BCR_PROFILE
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < kSchurTraceMax) g_schur_trace[2 * blockIdx.x + 1] = wall_clock64();
   if (blockIdx.x == 100 && lane == 0 && (wv == 0 || wv == 4))
     printf("[k_schur_groups_mfma2 wg 100 %s] batches %lld: total %lld cycles, waiting for the partner %lld, epilogue %lld; workgroup setup %lld, tail (barrier + flush) %lld\n",
            wv == 0 ? "producer" : "consumer", pn, pk1 - pk0, pw, pe, pk0 - pkk, clock64() - pk1);
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_stage(DevProblem P, const doub
   const double x[3] = {X[3 * (size_t)k], X[3 * (size_t)k + 1], X[3 * (size_t)k + 2]};
   double cm[12], e[2], r[2], Jc[12], Jp[6], W[18];
   load_cam(cams, c, cm);
-  obs_linearize(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
+  obs_linearize<true>(P.K, cm, x, z.x, z.y, P.sensor, e, r, Jc, Jp);
   block_W(Jc, Jp, W);
   const double l10 = fac[9 * (size_t)k + 3], l20 = fac[9 * (size_t)k + 4], l21 = fac[9 * (size_t)k + 5];
   const size_t row = (size_t)3 * k * M + 6 * (size_t)pos;

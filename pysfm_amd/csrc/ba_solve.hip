@@ -56,7 +56,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
       }
       h->bcr_work_elim = (int)work.size();
       // ... followed by the back-substitution items, root down (k_bcr_eliminate_fused role 3): the whole solve behind
-      // k_bcr_assemble is then ONE launch.  (Not with the two-stage words, which use the word the inverse role publishes.)
+      // k_bcr_assemble is then ONE launch.
       for (int q = (int)strides.size() - 1; q >= 0; --q)
         for (int k = 0, cnt = (N / strides[q] + 1) / 2; k < cnt; ++k) {
           const int i = strides[q] * (2 * k + 1) - 1;
@@ -67,7 +67,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
       HIPCHECK(h, hipStreamSynchronize(h->stream));          // `work` goes out of scope
       h->bcr_work_n = N; h->bcr_work_s = s_fused; h->bcr_work_len = (int)work.size();
     }
-    const bool back_in_launch = s_fused && h->opt.fused_backsolve && !BA_BCR_TWO_STAGE && N <= 8 * h->ncu;
+    const bool back_in_launch = s_fused && h->opt.fused_backsolve && N <= 8 * h->ncu;
     nwork = s_fused ? (back_in_launch ? h->bcr_work_len : h->bcr_work_elim) : 0;
     if (s_fused) HIPCHECK(h, h->bcr_done.resize((size_t)4 * N));
   }
@@ -101,7 +101,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   int split_stride = INT32_MAX;                            // the first (smallest-stride) level eliminated by the split kernel
   for (size_t q = 0; q < strides.size(); ++q)
     if (level_split[q]) { split_stride = strides[q]; break; }
-  if (s_fused && h->opt.fused_backsolve && !BA_BCR_TWO_STAGE && N <= 8 * h->ncu) return BA_OK;      // (done inside k_bcr_eliminate_fused)
+  if (s_fused && h->opt.fused_backsolve && N <= 8 * h->ncu) return BA_OK;      // (done inside k_bcr_eliminate_fused)
   if (h->opt.fused_backsolve && N <= 8 * h->ncu && top >= 0) {
     // every node's workgroup is resident at once: all levels in ONE launch, handing x down through flags
     if (h->bcr_order_n != N) {

@@ -49,70 +49,12 @@ int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_in
   return rc;
 }
 
-// Option trial_graph: the launches of a trial (linearise, invert + initialise, reduce, assemble, eliminate + back-substitute,
-// back-substitute the points + trial set + cost) replayed as ONE hipGraph launch.  What the launches depend on besides the
-// problem - which physical parameter set is current, which of the two singular-block counters is in use, damping, rcond - is
-// the key of the graph; the first trial with a key runs under stream capture (the usual calls, nothing executes), later ones
-// replay.  A measurement aid (rejected table): the host-side cost of a graph launch decides whether it pays.
-static int trial_through_graph(ba_handle* h, double damping, double pinv_rcond) {
-  unsigned long long db, rb;
-  std::memcpy(&db, &damping, 8); std::memcpy(&rb, &pinv_rcond, 8);
-  const std::vector<unsigned long long> key{(unsigned long long)(h->cur * 2 + (h->sing_epoch & 1)), db, rb};
-  auto it = h->trial_graphs.find(key);
-  if (it == h->trial_graphs.end()) {
-    if (h->trial_graphs.size() > 256) {                  // (an LM run visits a few dozen dampings; do not hoard)
-      for (auto& g : h->trial_graphs) (void)hipGraphExecDestroy(g.second.exec);
-      h->trial_graphs.clear();
-    }
-    HIPCHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int32_t pre = 0;
-    int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
-    if (rc == BA_OK) rc = ba_lm_trial_end(h, nullptr, &pre);
-    hipGraph_t graph = nullptr;
-    const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
-    if (rc != BA_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ec != hipSuccess || !graph) return h->fail(BA_ERR_HIP, "ba_lm_trial: stream capture failed: %s", hipGetErrorString(ec));
-    if (pre != 0) { (void)hipGraphDestroy(graph); return h->fail(BA_ERR_STATE, "ba_lm_trial: option trial_graph needs a device solver for this band"); }
-    ba_handle::TrialGraph g;
-    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) return h->fail(BA_ERR_HIP, "ba_lm_trial: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
-    g.sing_epoch = h->sing_epoch; g.solve_kind = h->solve_kind; g.lin_phys = h->lin_phys; g.cost_blocks = h->cost_blocks;
-    g.cost_fused = h->cost_fused; g.inv_valid = h->inv_valid; g.fac_valid = h->fac_valid;
-    g.point_blocks_valid = h->point_blocks_valid; g.cam_blocks_valid = h->cam_blocks_valid;
-    it = h->trial_graphs.emplace(key, g).first;
-  } else {
-    const ba_handle::TrialGraph& g = it->second;
-    h->sing_epoch = g.sing_epoch; h->solve_kind = g.solve_kind; h->lin_phys = g.lin_phys; h->cost_blocks = g.cost_blocks;
-    h->cost_fused = g.cost_fused; h->inv_valid = g.inv_valid; h->fac_valid = g.fac_valid;
-    h->point_blocks_valid = g.point_blocks_valid; h->cam_blocks_valid = g.cam_blocks_valid;
-    h->inv_damping = damping; h->inv_rcond = pinv_rcond; h->trial_rcond = pinv_rcond;
-    h->have_linearization = h->have_schur = h->have_solution = h->have_backsub = true;
-    h->have_params[h->phys(BA_PARAMS_TRIAL)] = true;
-  }
-  HIPCHECK(h, hipGraphLaunch(it->second.exec, h->stream));
-  return BA_OK;
-}
-
 int ba_lm_trial(ba_handle* h, double damping, double pinv_rcond, const uint8_t* cam_param_mask, double* next_cost,
                 int32_t* info) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, next_cost && info, BA_ERR_INVALID_ARG, "ba_lm_trial: NULL output");
   *info = 0;
   int32_t pre = 0;
-  ++h->trials_since_problem;
-  if (h->opt.trial_graph && !h->comm && !cam_param_mask && !h->timing && h->trials_since_problem > 2 && h->have_params[h->phys(BA_PARAMS_CUR)]) {
-    const int rcg = trial_through_graph(h, damping, pinv_rcond);
-    if (rcg != BA_OK) return rcg;
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
-    const int st0 = h->host_result->singular_points, st1 = h->host_result->solve_info;
-    *next_cost = h->host_cost();
-    if (pinv_rcond < 0.0 && st0 > 0)
-      return h->fail(BA_ERR_SINGULAR, "ba_lm_trial: %d singular 3x3 point block(s) in plain-inverse mode", st0);
-    *info = st1;
-    if (st1 != 0) h->have_solution = h->have_backsub = false;
-    return BA_OK;
-  }
   int rc = ba_lm_trial_begin(h, damping, pinv_rcond);
   const bool dist = h->comm && h->dist.on && h->hb <= kBcrMaxHB;
   if (dist) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library options on the GPU box: `gpurun -- bash scripts/ab_options.sh "" "trial_graph=1" ...`: three alternating runs
+# A/B of library options on the GPU box: `gpurun -- bash scripts/ab_options.sh "" "fast_paths=0" ...`: three alternating runs
 # of bench.py per option set; prints min / median of five 20-step windows, the kernel sum and the per-kernel microseconds.
 cd $GRAFT_REPO_ROOT
 for rep in 1 2 3; do for V in "$@"; do

@@ -34,7 +34,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1,
-                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, trial_graph=0)
+                       sort_points=1, gm_cap=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1)
 
 
 @pytest.fixture(autouse=True)
@@ -1416,29 +1416,6 @@ def test_a_reference_style_bundle_of_plain_objects_walks_the_golden_trajectory()
     close(np.array([c.t for c in out.cameras]), g['lm_t'], 1e-6, 1e-9)
     close(out.reconstruction, g['lm_X'], 1e-6)
     ba.backend.close()
-
-
-def test_trial_replayed_as_a_graph_equals_the_direct_launches():
-    """Option trial_graph: ba_lm_trial captures its launches per (damping, parameter-set parity) and replays them as one
-    hipGraph.  The LM run through replayed graphs - accepted and rejected trials, dampings that come back - must be the run
-    of the direct launches: same decisions, same costs to the last digits (the same kernels on the same data; only the order
-    of fp64 atomics may differ), same final parameters."""
-    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
-    s = banded(120, 6000, track_len=8, outlier_frac=.03, init_mode='params')
-    out = {}
-    for tag in ('direct', 'graph'):
-        b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
-                                    sensor_model=sensor_model.CauchyModel(.05))
-        ba = BundleAdjuster(verbose=False)
-        ba.backend.set_option('trial_graph', tag == 'graph')
-        ba.set_bundle(b)
-        ba.optimize(max_steps=12)
-        assert ba.lm_trials >= 14
-        out[tag] = (np.array(ba.costs), [(d, o) for d, o, c in ba.trial_log], np.array([c for d, o, c in ba.trial_log])) + ba.backend.get_params(0)
-        ba.backend.close()
-    assert out['graph'][1] == out['direct'][1]
-    for k in (0, 2, 3, 4, 5):
-        close(out['graph'][k], out['direct'][k], 1e-10)
 
 
 # ------------------------------------------------------------------ the sensor-model plug-in point (sensor_model.py:19-32)
