@@ -593,10 +593,13 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   constexpr size_t BB = (size_t)B * B;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
 
-  if (tid == 0) { bad[0] = 0; bad[1] = 0; }      // bad[1]: wavefronts of this workgroup whose factor stores have landed (fused kernel)
+  if (tid == 0) { bad[0] = 0; bad[1] = 0; }
   if (tid < 384) Li[tid] = 0.0;      // (a 6-unknown node never writes rows / columns 6..11 of it, and 0 x stale-LDS-NaN = NaN)
   double* Idt = Li + 384;
   bcr_identity_table(Idt, tid);
+  // ... and the words behind the table, up to the end of the node's LDS: a 6-unknown node's 16-row tile reads reach them with a
+  // zero factor (tests/test_gpu_fuzz.py poisons LDS with NaNs between problems: the counters that once lived here hid it)
+  if (tid >= 156 && tid < 176) Idt[tid] = 0.0;
   if constexpr (FUSED) {
     // (selects, not indexing: a runtime index would put the struct into scratch memory)
     const int* word = tid == 0 ? dep.d[0] : tid == 1 ? dep.d[1] : tid == 2 ? dep.pq[0] : dep.pq[1];
@@ -984,20 +987,6 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
         }
       }
     }
-    // ... and is PUBLISHED as soon as every wavefront's stores have been acknowledged - which each wavefront checks when its
-    // matrix products are done, right before its first atomic (no stall: the stores left a microsecond earlier); the last one
-    // to arrive says so.  The consumers form their coupling from it while this workgroup is still adding to its neighbour.
-    bool arrived = false;
-    auto arrive = [&] {
-      if constexpr (FUSED && BA_BCR_STORE_FIRST) {
-        if (!arrived) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0 && atomicAdd(bad + 1, 1) == kBcrElimThreads / 64 - 1 && dep.my_pq)
-            __hip_atomic_store(dep.my_pq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          arrived = true;
-        }
-      }
-    };
     // ---- this role's neighbour update: D_nb -= R^T R (lower tiles), f_nb -= R^T g; R is kept for the back-substitution
     const int nbr = role == 0 ? l : r;
     constexpr int NT = (B + 15) / 16, KST = (B + 3) / 4;
@@ -1013,7 +1002,6 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
           bcr_edge_task(q, NTF, RB, false, EB, lane, acol, bcol);
           const double v = bcr_mfma4_blocks<B>(R, R, ld, acol, bcol, lane);
           const int row = acol + (lane >> 4), col = bcol + (lane & 3);
-          arrive();
           if (row < B && col <= row) atomic_add_f64(dst + (size_t)row * B + col, -v);
         }
     }
@@ -1039,14 +1027,12 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
       }
       double* dst = Dm + (size_t)nbr * BB;
       const int col = 16 * tj + lr;
-      arrive();
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = 16 * ti + lk + 4 * v;
         if (row < B && col <= row) atomic_add_f64(dst + (size_t)row * B + col, -(acc[v] + acc2[v]));
       }
     }
-    arrive();                                                                    // (wavefronts without a tile)
     for (int c = kBcrElimThreads - 1 - tid; c < B; c += kBcrElimThreads) {       // the last wavefronts have fewer tiles
       double acc = 0.0;
       for (int k = 0; k < B; ++k) acc += R[k * ld + c] * g[k];
