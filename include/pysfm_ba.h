@@ -235,9 +235,10 @@ enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOL
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);
 int ba_get_solution(ba_handle* h, double* dC /*[nco*6] host*/);
-/* Dense path: flat (6nco x 6nco) system with rows/cols of masked camera parameters
- * deleted (bundle_adjuster.py:290-299).  keep[nkeep] lists the kept flat parameter
- * indices (host).  A_dev[nkeep*nkeep], rhs_dev[nkeep] are caller-owned DEVICE buffers. */
+/* For callers that want the reduced system as the reference forms it before its solve: the flat (6nco x 6nco) matrix
+ * with rows / columns of masked camera parameters deleted (bundle_adjuster.py:290-299).  keep[nkeep] lists the kept
+ * flat parameter indices (host).  A_dev[nkeep*nkeep], rhs_dev[nkeep] are caller-owned DEVICE buffers.  (The library's
+ * own solve does not go through it.) */
 int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A_dev, void* rhs_dev);
 
 /* ---- BundleAdjuster.backsubstitute (bundle_adjuster.py:316-331)
