@@ -165,6 +165,72 @@ def test_shuffled_config3_takes_the_matrix_core_path(be):
     close(costs[1], costs[0], 1e-6)
 
 
+# ------------------------------------------------------------------ ba_set_problem on the device (ba_setup_kernels.h)
+def test_device_side_setup_edge_cases(be):
+    """The device validates and orders whatever arrives: a repeated (camera, track) pair hidden in a shuffled input, an index
+    out of range in the middle of a long input, tracks without observations and tracks seen by frozen cameras only (they go
+    last, add nothing to S), a camera / track count whose sort key does not fit 32 bits, and the caller's order kept when it is
+    already good.  Every accepted scene must give the oracle's trial whatever order it came in."""
+    sensor = O.Sensor.gaussian(1.)
+    s = banded(90, 2700, track_len=7)
+    cam, pt, z = s['obs_cam'].copy(), s['obs_pt'].copy(), s['obs_z'].copy()
+    flags = default_flags(90, 2700)
+    K = s['K']
+    o = np.random.RandomState(5).permutation(len(cam))
+    # (1) duplicates and range errors, sorted and shuffled
+    for order in (np.arange(len(cam)), o):
+        c2, p2 = np.r_[cam[order], cam[order][777]], np.r_[pt[order], pt[order][777]]
+        with pytest.raises(ValueError, match='two observations'):
+            be.set_problem(90, 2700, c2, p2, np.r_[z[order], z[order][777:778]], K, *flags)
+        c3 = cam[order].copy()
+        c3[5000] = 90
+        with pytest.raises(ValueError, match='out of range'):
+            be.set_problem(90, 2700, c3, pt[order], z[order], K, *flags)
+        p3 = pt[order].copy()
+        p3[123] = -1
+        with pytest.raises(ValueError, match='out of range'):
+            be.set_problem(90, 2700, cam[order], p3, z[order], K, *flags)
+    # (2) empty tracks, tracks of frozen cameras only, a frozen camera in the middle; shuffled
+    cam_opt_pos = np.arange(90, dtype=np.int32) - 1
+    cam_opt_pos[40] = -1
+    cam_opt_pos[41:] -= 1
+    keep = ~np.isin(pt, [3, 4, 2699])                                       # three tracks lose all their observations
+    only_frozen = (pt == 10) & ~np.isin(cam, [0, 40])                        # ... and one keeps those of the frozen cameras only (if any)
+    keep &= ~only_frozen
+    a = (K, s['R0'], s['t0'], s['X0'], cam[keep], pt[keep], z[keep])
+    oo = np.random.RandomState(6).permutation(int(keep.sum()))
+    b = (K, s['R0'], s['t0'], s['X0'], cam[keep][oo], pt[keep][oo], z[keep][oo])
+    mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, flags[1], damping=2., return_parts=True)
+    for arrays in (a, b):
+        load_problem(be, *arrays, cam_opt_pos, flags[1], sensor)
+        be.linearize(0)
+        be.schur(0, 2., 1e-5)
+        S, bb = be.get_reduced()
+        close(S, parts['S'], TIGHT)
+        close(bb, parts['b'], TIGHT)
+        info, cost = be.lm_trial(2., 1e-5, None)
+        assert info == 0
+        close(-be.get_solution(), mu, 1e-8)
+    # (3) the caller's order is kept when it is as good as the sorted one, and only then
+    load_problem(be, *a, cam_opt_pos, flags[1], sensor)
+    assert be.problem_info()['points_permuted'] == 1                          # (the empty tracks move to the end)
+    load_problem(be, K, s['R0'], s['t0'], s['X0'], cam, pt, z, *flags, sensor)
+    assert be.problem_info()['points_permuted'] == 0 and be.problem_info()['obs_permuted'] == 0
+    # (4) many cameras x many tracks: (track, rank) keys beyond 32 bits; a handful of observations, shuffled
+    nc, nt = 70000, 40000
+    rs = np.random.RandomState(8)
+    pts = rs.choice(nt, 300, replace=False)
+    c4 = (rs.randint(1, nc - 3, len(pts))[:, None] + np.arange(3)[None, :]).reshape(-1).astype(np.int32)      # (three consecutive cameras each: hb = 2)
+    p4 = np.repeat(pts, 3).astype(np.int32)
+    q = rs.permutation(len(c4))
+    be.set_problem(nc, nt, c4[q], p4[q], rs.randn(len(c4), 2), K, *default_flags(nc, nt))
+    info = be.problem_info()
+    assert info['max_track_len'] == 3 and info['points_permuted'] == 1
+    dup = np.r_[q, q[17]]
+    with pytest.raises(ValueError, match='two observations'):
+        be.set_problem(nc, nt, c4[dup], p4[dup], rs.randn(len(dup), 2), K, *default_flags(nc, nt))
+
+
 # ------------------------------------------------------------------ config 4 at full size
 @pytest.mark.parametrize('sensor', [O.Sensor.huber(.06), O.Sensor.cauchy(.05)], ids=['huber', 'cauchy'])
 def test_config4_properties_1000x100k_outliers(be, sensor):
