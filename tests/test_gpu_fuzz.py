@@ -95,7 +95,18 @@ def test_random_scene_full_step_vs_oracle(be, seed):
     try:
         mu, su, parts = O.compute_update(sensor, *a, cp, po, damping=c['damping'], cam_param_mask=cmask, return_parts=True)
     except O.NormalEquationsIllconditioned:
-        pytest.skip('degenerate draw: a camera lost all its observations, the reference LU itself raises')
+        # a degenerate draw (seed 57: nine cameras lost all their observations): the reference's LU raises on the singular
+        # system (bundle_adjuster.py:302-305) - the device must say the same, through its own LU, and the LM loop treats the
+        # trial as ill-conditioned
+        from pysfm_amd.backend import ReducedSystemSingular
+        be.linearize(0)
+        be.schur(0, c['damping'], 1e-5)
+        with pytest.raises(ReducedSystemSingular):
+            be.solve_reduced(c['mask'])
+        assert be.last_solve_path == 'lu'
+        info, _ = be.lm_trial(c['damping'], 1e-5, c['mask'])
+        assert info > 0
+        return
     be.linearize(0)
     blk = be.get_blocks()
     for k in ('HCC', 'bC', 'HPP', 'bP'):
