@@ -354,6 +354,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     int longest = 0;
     for (const SchurGroup& r : runs) longest = std::max(longest, r.pt_end - r.pt_begin);
     while (cap < longest && split_runs(cap, false) > (size_t)slots) cap += kGmPts;     // (beyond the longest run nothing changes)
+    // More runs than slots (config 5; a shard of it; any scene a little larger than one round): several workgroups per compute
+    // unit, one after the other, and the cap above has grown past every run - the 500-point runs at the two ends of a camera
+    // track then last four times as long as everybody else.  Measured (scripts/gm_cap_sweep.sh: a workgroup costs 13.4 us +
+    // 2.0 us per batch of its longest group): parts of at most 60 points are the best size for every multi-round scene tried
+    // (1250 cameras x 125k points: 278 -> 101 us; config 5: 722 -> 658 us).
+    if (split_runs(cap, false) > (size_t)slots) cap = kGmMultiRoundCap;
     if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);     // tuning aid (ba_set_option "gm_cap")
     split_runs(cap, true);
     if (maxL <= kGmMaxL && wn > 0) chunk_groups(kGmChunk, wn, mgroups, mlo, mhi, mchunks);
@@ -453,6 +459,10 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       for (const Run& r : runs) longest = std::max(longest, r.e - r.b);
       auto count = [&](int c) { size_t n = 0; for (const Run& r : runs) n += parts_of(r, c); return n; };
       while (cap < longest && count(cap) > (size_t)slots) cap += kGmPts;
+      // several rounds of workgroups (see the identical-list groups above): parts of 60 points while that is a matter of two or
+      // three rounds (1250 cameras / 125k points, 30 % of the observations dropped: 120 -> 111 us; track length 16 at 2000 cameras:
+      // 402 -> 342 us), of 120 beyond (a window group pays more per group than a run: config 5 with 30 % dropped: 628 against 722 us)
+      if (count(cap) > (size_t)slots) cap = count(2 * kGmMultiRoundCap) > (size_t)4 * slots ? 2 * kGmMultiRoundCap : kGmMultiRoundCap;
       if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);
       std::vector<int> wlo, whi;
       for (const Run& r : runs) {

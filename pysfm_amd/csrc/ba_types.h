@@ -71,6 +71,7 @@ constexpr int kGmChunk = 4;                            // groups per workgroup: 
 constexpr int kGmPts = 6;                              // points per batch
 constexpr int kGmK = 20;                               // staged k rows: 3 per point, two zero rows
 constexpr int kGmLd = 64;                              // staged row length (60 used)
+constexpr int kGmMultiRoundCap = 60;                   // points per group when the groups need several rounds of workgroups (ba_set_problem)
 
 // ---- k_schur_groups_mfma2
 constexpr int kGm2Block = 512;
