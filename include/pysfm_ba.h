@@ -85,8 +85,9 @@ int ba_synchronize(ba_handle* h);
  *   "fuse_cost" "fuse_cam"   1 | 0                         pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1)
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
  *   "gm_cap"        n                                      points per group of the MFMA reduction (0 = automatic)
+ *   "gm_chunk"      n                                      groups per workgroup of the MFMA reductions (0 = automatic: 4, or 8 over several rounds)
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
- * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap") take effect at
+ * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap", "gm_chunk") take effect at
  * the next ba_set_problem. */
 int ba_set_option(ba_handle* h, const char* name, const char* value);
 /* Test aid: fills the LDS of every compute unit and every workspace buffer of the handle (normal-equation blocks, reduced

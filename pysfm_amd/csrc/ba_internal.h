@@ -56,6 +56,7 @@ struct Options {
   bool fuse_cam = true;            // camera blocks inside the MFMA reduction
   bool sort_points = true;         // internal point order (ba_set_problem); off = the caller's order as given
   int gm_cap = 0;                  // points per MFMA group (0 = chosen by ba_set_problem)
+  int gm_chunk = 0;                // groups per workgroup of the MFMA reductions (0 = chosen by ba_set_problem)
   bool lds_window = true;          // k_schur_groups_mfma3 accumulates in an LDS window of the band when one fits
   bool fast_paths = true;          // K = I / unit-Gaussian short cuts of the per-observation arithmetic (ba_math.h)
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip

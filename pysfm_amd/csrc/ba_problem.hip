@@ -359,10 +359,28 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     // track then last four times as long as everybody else.  Measured (scripts/gm_cap_sweep.sh: a workgroup costs 13.4 us +
     // 2.0 us per batch of its longest group): parts of at most 60 points are the best size for every multi-round scene tried
     // (1250 cameras x 125k points: 278 -> 101 us; config 5: 722 -> 658 us).
-    if (split_runs(cap, false) > (size_t)slots) cap = kGmMultiRoundCap;
+    const bool multi_round = split_runs(cap, false) > (size_t)slots;
+    if (multi_round) cap = kGmMultiRoundCap;
     if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);     // tuning aid (ba_set_option "gm_cap")
     split_runs(cap, true);
-    if (maxL <= kGmMaxL && wn > 0) chunk_groups(kGmChunk, wn, mgroups, mlo, mhi, mchunks);
+    // Groups per workgroup: one per wavefront pair when everything runs at once.  With several rounds, one, two or three per
+    // pair: a workgroup's set-up and flush (about 5 of its 13.4 us of fixed cost) are then paid once for two or three times the
+    // work - but fewer, longer workgroups quantise worse over the compute units, so: the count that minimises
+    // rounds x (5 + groups per pair x (8.4 + 2.0 x batches)) us, rounds rounded up while there are fewer than three
+    // (scripts/gm_cap_sweep.sh, profiles/r04_gm_cap_sweep.txt: predicted / measured 100 / 102, 124 / 121, 90 / 93 us for 4, 8, 12
+    // groups per workgroup at 1250 cameras x 125k points, 676 / 658, 641 / 597, 639 / 596 us at config 5).
+    int gm_chunk = kGmChunk;
+    if (multi_round) {
+      const double G = (double)mgroups.size(), batches = std::ceil(std::min<double>(cap, 1.15 * nt / std::max(1.0, G)) / kGmPts);
+      double best = 0.0;
+      for (int c = kGmChunk; c <= 3 * kGmChunk; c += kGmChunk) {
+        const double wgs = std::ceil(G / c) / h->ncu, rounds = wgs <= 1.0 ? 1.0 : wgs < 3.0 ? std::ceil(wgs) : wgs + 0.5;
+        const double t = rounds * (5.0 + (c / kGmChunk) * (8.4 + 2.0 * batches));
+        if (c == kGmChunk || t < best) { best = t; gm_chunk = c; }
+      }
+    }
+    if (h->opt.gm_chunk > 0) gm_chunk = h->opt.gm_chunk;
+    if (maxL <= kGmMaxL && wn > 0) chunk_groups(gm_chunk, wn, mgroups, mlo, mhi, mchunks);
     // worth it only when points really share camera lists
     const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
     groups_worth = mean_group >= 2.0;
@@ -373,6 +391,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   // of different lengths, tracks with missing observations and tracks that start anywhere all join.  wmax = the
   // widest window that costs no more 16-row tiles than the widest track needs.
   std::vector<WinGroup> wgroups;
+  int gm3_chunk = kGmChunk;                          // window groups per workgroup
   size_t wtab_size = 0;
   std::vector<int> hobs;
   bool wgroups_worth = false;
@@ -462,7 +481,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       // several rounds of workgroups (see the identical-list groups above): parts of 60 points while that is a matter of two or
       // three rounds (1250 cameras / 125k points, 30 % of the observations dropped: 120 -> 111 us; track length 16 at 2000 cameras:
       // 402 -> 342 us), of 120 beyond (a window group pays more per group than a run: config 5 with 30 % dropped: 628 against 722 us)
-      if (count(cap) > (size_t)slots) cap = count(2 * kGmMultiRoundCap) > (size_t)4 * slots ? 2 * kGmMultiRoundCap : kGmMultiRoundCap;
+      const bool multi_round = count(cap) > (size_t)slots;
+      if (multi_round) cap = count(2 * kGmMultiRoundCap) > (size_t)4 * slots ? 2 * kGmMultiRoundCap : kGmMultiRoundCap;
+      gm3_chunk = h->opt.gm_chunk > 0 ? h->opt.gm_chunk : kGmChunk;       // (window groups: more than one per pair was slower wherever measured)
       if (h->opt.gm_cap > 0) cap = std::max(kGmPts, h->opt.gm_cap);
       std::vector<int> wlo, whi;
       for (const Run& r : runs) {
@@ -561,11 +582,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
         w3 = std::min(w3, std::max(16, G.wb1 + 6));
         if (w3 < G.wb1 + 1 || !h->opt.lds_window) w3 = 0;
         G.wn = w3;
-        int begin = g0, lo = INT32_MAX, hi = -1;          // chunks of <= kGmChunk groups under the LDS window
+        int begin = g0, lo = INT32_MAX, hi = -1;          // chunks of <= gm3_chunk groups under the LDS window
         for (int g = g0; g < g1; ++g) {
           const int nlo = std::min(lo, wlo[g]), nhi = std::max(hi, whi[g]);
           const bool fits = w3 == 0 || nhi - nlo + 1 <= w3;
-          if (g > begin && (!fits || g - begin >= kGmChunk)) {
+          if (g > begin && (!fits || g - begin >= gm3_chunk)) {
             out.push_back({begin, g, lo});
             begin = g; lo = wlo[g]; hi = whi[g];
           } else {
