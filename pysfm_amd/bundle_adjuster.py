@@ -7,6 +7,7 @@ the reference keeps in Python: id / mask bookkeeping (``set_bundle``) and the
 damping / accept / reject schedule (``optimize``).  Every numeric step is a HIP
 kernel behind the C ABI of include/pysfm_ba.h:
 
+    set_bundle                -> ba_set_problem             validation, internal order, work lists: on the device
     optimize / step           -> ba_lm_trial                one LM trial = one batch of launches, one synchronisation
     compute_cost              -> ba_cost                    (k_cost; inside a trial: fused into k_backsub_groups)
     prepare_schur_complement  -> ba_linearize               (k_linearize_groups | k_linearize, k_camera_blocks)
@@ -14,14 +15,14 @@ kernel behind the C ABI of include/pysfm_ba.h:
                                                              other scenes: k_schur_groups, k_schur_pairs, k_dense_*)
     solve_motion_normal_eqns  -> ba_solve_reduced           (block cyclic reduction k_bcr_* / k_bcrw_*; k_band_solve for tiny
                                                              systems; dense blocked Cholesky k_dense_* for wide bands;
-                                                             LU (rocSOLVER) when the system is not positive definite)
+                                                             LU with partial pivoting, k_bcr_eliminate_lu / k_lu_*, when
+                                                             the system is not positive definite)
     backsubstitute            -> ba_backsubstitute          (k_backsub_groups | k_backsub)
     update_motion / update_structure -> ba_apply_update     (k_apply_update; inside a trial: fused into the back-substitution)
 
 During ``optimize`` the accepted and the trial parameter sets both live on the GPU;
 ``self.bundle`` is materialised on the host only when somebody reads it.
 """
-from copy import copy
 
 import numpy as np
 
