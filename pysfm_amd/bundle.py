@@ -270,9 +270,14 @@ class Bundle(object):
                 np.cumsum(np.bincount(trk, minlength=len(self.tracks)), out=off[1:])
                 if self._table is not None:
                     self._track_offsets = off
-            cnt = off[tids + 1] - off[tids]
-            rows = np.repeat(off[tids] - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(int(cnt.sum()))
-            ci, ti, zz = cpos[cam[rows]], np.repeat(np.arange(len(tids)), cnt), z[rows]
+            if len(tids) and int(tids[-1]) - int(tids[0]) + 1 == len(tids) and ascending(tids):
+                # a consecutive stretch of tracks (window_slam.py:19: the first `num_tracks` of them): one slice of the table
+                rows = slice(int(off[tids[0]]), int(off[tids[-1] + 1]))
+                ci, ti, zz = cpos[cam[rows]], trk[rows].astype(np.int64) - int(tids[0]), z[rows]
+            else:
+                cnt = off[tids + 1] - off[tids]
+                rows = np.repeat(off[tids] - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(int(cnt.sum()))
+                ci, ti, zz = cpos[cam[rows]], np.repeat(np.arange(len(tids)), cnt), z[rows]
             keep = ci >= 0
             ci, ti, zz = ci[keep], ti[keep], zz[keep]
             in_order = ascending(cids)                      # (rows come track position by track position, cameras ascending by id)
