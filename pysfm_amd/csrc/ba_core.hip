@@ -223,6 +223,7 @@ int ba_destroy(ba_handle* h) {
     su.iota.release(); su.crank.release(); su.flags.release(); su.vals.release(); su.key.release(); su.key2.release(); su.tkey.release(); su.tkey2.release();
     su.rz.release(); su.rpo.release(); su.same.release(); su.tmp.release();
     if (su.host) (void)hipHostFree(su.host);
+    if (su.up) (void)hipHostFree(su.up);
   }
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);

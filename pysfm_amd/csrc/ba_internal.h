@@ -152,6 +152,8 @@ struct ba_handle {
     DevBuf<unsigned char> rpo, same, tmp;
     void* host = nullptr;              // pinned staging for the read-backs
     size_t host_bytes = 0;
+    void* up = nullptr;                // pinned arena for the small uploads
+    size_t up_bytes = 0, up_used = 0;
   } su;
 
   // parameters: cams[which] = nc x [R(9) | t(3)], X[which] = nt x 3

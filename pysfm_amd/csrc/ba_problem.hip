@@ -33,6 +33,28 @@ hipError_t pinned_staging(ba_handle* h, size_t bytes) {
 
 inline unsigned grid_for(long long n) { return (unsigned)std::max<long long>(1, (n + 255) / 256); }
 
+// Small uploads go through a pinned arena: an H2D copy from pageable memory is staged synchronously by the runtime (10 - 15 us
+// apiece, a dozen of them per problem - most of ba_set_problem for the sliding-window caller's 1000 observations); from pinned
+// memory it is an asynchronous enqueue.  The arena is reset where nothing can be in flight from it (at the start of
+// ba_set_problem and after its second synchronisation); what does not fit goes the ordinary way.
+constexpr size_t kArenaBytes = 8u << 20, kArenaMaxItem = 2u << 20;
+void arena_reset(ba_handle* h) {
+  auto& su = h->su;
+  if (!su.up && hipHostMalloc(&su.up, kArenaBytes, hipHostMallocDefault) == hipSuccess) su.up_bytes = kArenaBytes;
+  su.up_used = 0;
+}
+hipError_t stage_h2d(ba_handle* h, void* dst, const void* src, size_t bytes) {
+  auto& su = h->su;
+  const size_t aligned = (bytes + 63) & ~(size_t)63;
+  if (bytes <= kArenaMaxItem && su.up && su.up_used + aligned <= su.up_bytes) {
+    void* p = static_cast<char*>(su.up) + su.up_used;
+    std::memcpy(p, src, bytes);
+    su.up_used += aligned;
+    src = p;
+  }
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+}
+
 }  // namespace
 
 namespace ba {
@@ -171,17 +193,18 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
   const size_t staging = ((size_t)3 * nt + 8) * sizeof(int) + (size_t)nt + SF_COUNT * sizeof(int) + (size_t)nt * sizeof(int) + 64;
   HIPCHECK(h, pinned_staging(h, staging));
+  arena_reset(h);
   if (N) {
-    HIPCHECK(h, hipMemcpyAsync(su.rc.p, obs_cam, (size_t)N * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(su.rp.p, obs_pt, (size_t)N * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(su.rz.p, obs_z, (size_t)N * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, su.rc.p, obs_cam, (size_t)N * sizeof(int)));
+    HIPCHECK(h, stage_h2d(h, su.rp.p, obs_pt, (size_t)N * sizeof(int)));
+    HIPCHECK(h, stage_h2d(h, su.rz.p, obs_z, (size_t)N * sizeof(double2)));
   }
   if (nc) {
-    HIPCHECK(h, hipMemcpyAsync(su.crank.p, crank.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, su.crank.p, crank.data(), (size_t)nc * sizeof(int)));
+    HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
   }
-  HIPCHECK(h, hipMemcpyAsync(h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  if (nt) HIPCHECK(h, hipMemcpyAsync(su.rpo.p, pt_opt, (size_t)nt, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
+  if (nt) HIPCHECK(h, stage_h2d(h, su.rpo.p, pt_opt, (size_t)nt));
   HIPCHECK(h, hipMemsetAsync(su.cnt.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
   HIPCHECK(h, hipMemsetAsync(su.Lint.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
   hipLaunchKernelGGL(k_setup_init, dim3(1), dim3(256), 0, h->stream, su.flags.p);
@@ -251,6 +274,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     HIPCHECK(h, hipMemcpyAsync(same, su.same.p, (size_t)nt, hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
+  arena_reset(h);                                    // (everything uploaded so far has arrived)
   const int* flags = hflags;
   if (flags[SF_DUP] != 0x7fffffff) {                 // each (camera, track) pair at most once (bundle.py: a dict per track)
     unsigned long long key = 0;
@@ -641,36 +665,36 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
 
   HIPCHECK(h, h->wide_list.resize(std::max<size_t>(1, wide_list.size())));
   if (!wide_list.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->wide_list.p, wide_list.data(), wide_list.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, h->wide_list.p, wide_list.data(), wide_list.size() * sizeof(int)));
   HIPCHECK(h, h->rgroups.resize(std::max<size_t>(1, rgroups.size())));
   HIPCHECK(h, h->rtab.resize(std::max<size_t>(1, rtab.size())));
   if (!rgroups.empty()) {
-    HIPCHECK(h, hipMemcpyAsync(h->rgroups.p, rgroups.data(), rgroups.size() * sizeof(RectGroup), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->rtab.p, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, h->rgroups.p, rgroups.data(), rgroups.size() * sizeof(RectGroup)));
+    HIPCHECK(h, stage_h2d(h, h->rtab.p, rtab.data(), rtab.size() * sizeof(int)));
   }
   HIPCHECK(h, h->groups.resize(std::max<size_t>(1, groups.size())));
   HIPCHECK(h, h->gchunks.resize(std::max<size_t>(1, gchunks.size())));
   HIPCHECK(h, h->mchunks.resize(std::max<size_t>(1, mchunks.size())));
   HIPCHECK(h, h->m3chunks.resize(std::max<size_t>(1, m3chunks.size())));
   if (!m3chunks.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, h->m3chunks.p, m3chunks.data(), m3chunks.size() * sizeof(SchurChunk)));
   HIPCHECK(h, h->wgroups.resize(std::max<size_t>(1, wgroups.size())));
   HIPCHECK(h, h->wtab.resize(std::max<size_t>(1, wtab_size)));
   if (!wgroups.empty()) {
-    HIPCHECK(h, hipMemcpyAsync(h->wgroups.p, wgroups.data(), wgroups.size() * sizeof(WinGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, h->wgroups.p, wgroups.data(), wgroups.size() * sizeof(WinGroup)));
     HIPCHECK(h, hipMemsetAsync(h->wtab.p, 0xff, wtab_size * sizeof(int), h->stream));        // -1: "the point does not see this camera"
     hipLaunchKernelGGL(k_setup_fill_wtab, dim3((unsigned)wgroups.size()), dim3(256), 0, h->stream, h->wgroups.p, h->pt_off.p, h->obs_cam.p,
                        h->cam_opt_pos.p, h->wtab.p);
   }
   HIPCHECK(h, h->mgroups.resize(std::max<size_t>(1, mgroups.size())));
   if (!mgroups.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->mgroups.p, mgroups.data(), mgroups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, h->mgroups.p, mgroups.data(), mgroups.size() * sizeof(SchurGroup)));
   if (!mchunks.empty())
-    HIPCHECK(h, hipMemcpyAsync(h->mchunks.p, mchunks.data(), mchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, h->mchunks.p, mchunks.data(), mchunks.size() * sizeof(SchurChunk)));
   if (!groups.empty()) {
-    HIPCHECK(h, hipMemcpyAsync(h->groups.p, groups.data(), groups.size() * sizeof(SchurGroup), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, stage_h2d(h, h->groups.p, groups.data(), groups.size() * sizeof(SchurGroup)));
     if (!gchunks.empty())
-      HIPCHECK(h, hipMemcpyAsync(h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk), hipMemcpyHostToDevice, h->stream));
+      HIPCHECK(h, stage_h2d(h, h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk)));
   }
   for (int i = 0; i < 2; ++i) {
     HIPCHECK(h, h->cams[i].resize(std::max<size_t>(1, (size_t)nc * 12)));
