@@ -283,6 +283,38 @@ int ba_lm_trial_end(ba_handle* h, const uint8_t* cam_param_mask, int32_t* pre_in
 /* the tail of ba_lm_trial_end once a solution is on the device: back-substitution, trial set, trial cost */
 int ba_lm_trial_finish(ba_handle* h);
 
+/* ---- the whole loop of BundleAdjuster.optimize() / step() (bundle_adjuster.py:117-162) for a problem that fits ONE compute
+ * unit, as one resident workgroup (pysfm_amd/csrc/ba_resident.h): <= 10 optimised cameras, <= 32 cameras, tracks of <= 16
+ * observations, a closed-form sensor model, no parameter mask, no communicator.  The sliding-window caller
+ * (window_slam.py:17-48) solves one such problem per frame; at that size a trial costs 68 us through ba_lm_trial (six
+ * launches and one synchronisation for a thousand observations) and ~25 us here, with no round trip to the host between trials.
+ *   ba_lm_resident_fits  1 when the handle's problem, sensor model and options allow it, else 0
+ *   ba_lm_resident       runs the reference's schedule on the device from the state given (damping, steps taken, inside a
+ *                        step or not, converged, cost of the current set or < 0 when unknown) until it converges, max_steps
+ *                        are taken, the log is full, or a trial needs the general path; the current parameter set is updated
+ *                        in place, *log says what happened trial by trial.  exit_reason: 0 done, 1 log full (call again
+ *                        with the state of the log), 2 the reduced system of the next trial is not positive definite
+ *                        (exit_info = gesv-style index of the pivot), 3 a singular point block in plain-inverse mode - for 2
+ *                        and 3 the caller runs that one trial through ba_lm_trial / the stepwise calls and comes back. */
+#define BA_RESIDENT_MAX_TRIALS 1000
+typedef struct ba_resident_log {
+  int32_t ntrials, nsteps, converged, in_step;
+  int32_t exit_reason, exit_info, accepted, have_cost0;
+  double damping, cost0, cur_cost, reserved;
+  double trial_damping[BA_RESIDENT_MAX_TRIALS];
+  double trial_cost[BA_RESIDENT_MAX_TRIALS];
+  int32_t trial_accepted[BA_RESIDENT_MAX_TRIALS];
+} ba_resident_log;
+int ba_lm_resident_fits(ba_handle* h);
+int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
+                   double improvement_threshold, double pinv_rcond, double cur_cost, ba_resident_log* log);
+/* with option solve_trace: 16 words per trial for the first 64 trials of the last ba_lm_resident - wall_clock64 (100 MHz) at the
+ * phase boundaries [0..7], [8] = 1 when the trial linearised */
+int ba_lm_resident_trace(ba_handle* h, int64_t* out /* [64 * 16] */);
+/* ... and the reduced system of its FIRST trial as the workgroups assembled it (dense, 6 nco x 6 nco | 6 nco) with the solution
+ * they found: what the parity tests compare with ba_get_reduced / ba_get_solution of the stepwise path */
+int ba_lm_resident_debug(ba_handle* h, double* S_out, double* b_out, double* dC_out);
+
 /* ---- the reduced solve SPREAD OVER THE RANKS of a sharded adjuster (pysfm_amd/csrc/ba_dist.h; no counterpart in the
  * single-process reference: same arithmetic as ba_solve_reduced, bundle_adjuster.py:281-312).  For block-banded systems whose
  * band is too large to be summed over the ranks and solved by each of them (BASELINE config 5).  The elimination tree of the

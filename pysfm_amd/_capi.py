@@ -35,6 +35,19 @@ _ip = C.POINTER(C.c_int32)
 _bp = C.POINTER(C.c_uint8)
 _h = C.c_void_p
 
+RESIDENT_MAX_TRIALS = 1000       # BA_RESIDENT_MAX_TRIALS
+RESIDENT_DONE, RESIDENT_LOG_FULL, RESIDENT_NOT_POSITIVE_DEFINITE, RESIDENT_SINGULAR_POINT = 0, 1, 2, 3
+
+
+class ResidentLog(C.Structure):
+    """ba_resident_log of include/pysfm_ba.h: what ba_lm_resident did, trial by trial."""
+    _fields_ = [('ntrials', C.c_int32), ('nsteps', C.c_int32), ('converged', C.c_int32), ('in_step', C.c_int32),
+                ('exit_reason', C.c_int32), ('exit_info', C.c_int32), ('accepted', C.c_int32), ('have_cost0', C.c_int32),
+                ('damping', C.c_double), ('cost0', C.c_double), ('cur_cost', C.c_double), ('reserved', C.c_double),
+                ('trial_damping', C.c_double * RESIDENT_MAX_TRIALS), ('trial_cost', C.c_double * RESIDENT_MAX_TRIALS),
+                ('trial_accepted', C.c_int32 * RESIDENT_MAX_TRIALS)]
+
+
 # name -> (restype, argtypes); one entry per function declared in include/pysfm_ba.h
 PROTOTYPES = {
     'ba_create': (C.c_int, [C.c_int, C.POINTER(_h)]),
@@ -69,6 +82,11 @@ PROTOTYPES = {
     'ba_apply_update': (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp]),
     'ba_lm_trial': (C.c_int, [_h, C.c_double, C.c_double, _bp, _dp, C.POINTER(C.c_int32)]),
     'ba_bind_trial_result': (C.c_int, [_h, C.c_void_p]),
+    'ba_lm_resident_fits': (C.c_int, [_h]),
+    'ba_lm_resident_trace': (C.c_int, [_h, C.POINTER(C.c_int64)]),
+    'ba_lm_resident_debug': (C.c_int, [_h, _dp, _dp, _dp]),
+    'ba_lm_resident': (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.POINTER(ResidentLog)]),
     'ba_set_dense_visibility': (C.c_int, [_h, C.c_int32]),
     'ba_measure_copy_bandwidth': (C.c_int, [_h, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     'ba_set_min_half_bandwidth': (C.c_int, [_h, C.c_int32]),

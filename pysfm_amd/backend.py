@@ -306,6 +306,28 @@ class HipBackend(object):
         self._note_solve(info.value)
         return info.value, cost.value
 
+    def lm_resident_fits(self):
+        """ba_lm_resident_fits: does the problem (and its sensor model, and the options) fit the one-workgroup loop?"""
+        return bool(self._lib.ba_lm_resident_fits(self._h))
+
+    def lm_resident(self, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, rcond, cur_cost):
+        """ba_lm_resident: the loop of optimize() / step() on the device, from the given state of the schedule.
+        Returns the log (capi.ResidentLog); the current parameter set has moved iff log.accepted."""
+        if getattr(self, '_res_log', None) is None:
+            self._res_log = capi.ResidentLog()
+        log = self._res_log
+        self._check(self._lib.ba_lm_resident(self._h, int(max_steps), int(steps_taken), int(bool(in_step)), int(bool(converged)),
+                                             float(damping), float(improvement_threshold), -1.0 if rcond is None else float(rcond),
+                                             -1.0 if cur_cost is None else float(cur_cost), C.byref(log)))
+        return log
+
+    def lm_resident_debug(self):
+        """ba_lm_resident_debug (option solve_trace): [S | b] and dC of the first trial of the last lm_resident."""
+        n = 6 * self.nco
+        S, b, dC = np.empty((n, n)), np.empty(n), np.empty(n)
+        self._check(self._lib.ba_lm_resident_debug(self._h, capi.dptr(S), capi.dptr(b), capi.dptr(dC)))
+        return S, b, dC
+
     # the same trial in two halves around the all-reduce of the sharded adjuster
     def lm_trial_begin(self, damping, rcond):
         """ba_lm_trial_begin: linearise + Schur reduction of this rank's shard, nothing read back."""

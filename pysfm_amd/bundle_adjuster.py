@@ -307,10 +307,15 @@ class BundleAdjuster(object):
         self.lm_trials = 0
         self.trial_log = []
         self.converged = False
-        self._cur_cost = self._cost(PARAMS_CUR)
-        self.costs = [self._cur_cost]
-        while not self.converged and self.num_steps < max_steps:
-            self.step(param_mask, improvement_threshold)
+        if self._resident_applies(param_mask):
+            self._cur_cost = None
+            self.costs = []
+            self._resident_steps(max_steps, improvement_threshold)
+        else:
+            self._cur_cost = self._cost(PARAMS_CUR)
+            self.costs = [self._cur_cost]
+            while not self.converged and self.num_steps < max_steps:
+                self.step(param_mask, improvement_threshold)
         if self.converged:
             self._say('Converged after %d steps' % self.num_steps)
         else:
@@ -320,6 +325,11 @@ class BundleAdjuster(object):
         '''One outer iteration of optimize(): retry with growing damping until a trial
         lowers the cost (bundle_adjuster.py:128-157; cf. optimize.py:110-135).
         Returns self.converged.'''
+        if self._resident_applies(param_mask):
+            if self.converged:                       # (the loop below would not run either)
+                self.num_steps += 1
+                return True
+            return self._resident_steps(self.num_steps + 1, improvement_threshold)
         # the cost of the current set is the cost of the trial that was accepted last (same kernel, same
         # data, deterministic summation order): no need to evaluate it again at the top of every step
         cur_cost = getattr(self, '_cur_cost', None)
@@ -344,6 +354,83 @@ class BundleAdjuster(object):
             else:
                 self._damping *= 10.
                 self.converged = self._damping > 1e+8
+        return self.converged
+
+    # ------------------------------------------------------------------ the loop on the device (small problems)
+    resident = True          # False: always the Python loop over ba_lm_trial
+
+    def _resident_applies(self, param_mask):
+        """A problem that fits one compute unit (a sliding window, the reference's own test scenes) runs the whole
+        loop of optimize() / step() as ONE resident workgroup (csrc/ba_resident.h): the same schedule, taken on the
+        device, replayed here from its log."""
+        if not self.resident or self._comm is not None:
+            return False
+        if param_mask is not None and not np.all(param_mask):
+            return False
+        be = self.backend
+        return hasattr(be, 'lm_resident_fits') and be.lm_resident_fits()
+
+    def _resident_steps(self, max_steps, improvement_threshold):
+        """Outer iterations until self.num_steps == max_steps or convergence (the loop of optimize(), bundle_adjuster.py:128-157),
+        on the device.  A trial the resident loop cannot take (a reduced system that is not positive definite: the reference
+        solves it by LU; a singular point block in plain-inverse mode: the reference raises) goes through trial() and the
+        loop resumes on the device."""
+        from ._capi import RESIDENT_DONE, RESIDENT_LOG_FULL
+        be = self.backend
+        in_step = False
+        if not hasattr(self, 'costs') or self.costs is None:
+            self.costs = []
+        while True:
+            steps_before = self.num_steps
+            log = be.lm_resident(max_steps, self.num_steps, in_step, self.converged, self._damping, improvement_threshold,
+                                 self.SCHUR_COMPLIMENT_PINV_THRESHOLD, self._cur_cost)
+            if self._cur_cost is None and log.have_cost0:
+                self._cur_cost = log.cost0
+            if not self.costs and self._cur_cost is not None:
+                self.costs = [self._cur_cost]
+            step_no = steps_before
+            for k in range(log.ntrials):
+                damping, cost, acc = log.trial_damping[k], log.trial_cost[k], bool(log.trial_accepted[k])
+                if not in_step:
+                    step_no += 1
+                    in_step = True
+                    self._say('Step %d: cost=%f, damping=%f' % (step_no, self._cur_cost, damping))
+                self.trial_log.append((damping, 'accepted' if acc else 'rejected', cost))
+                if acc:
+                    self.costs.append(cost)
+                    self._cur_cost = cost
+                    in_step = False
+            self.lm_trials += log.ntrials
+            self.num_steps, self.converged, self._damping, in_step = log.nsteps, bool(log.converged), log.damping, bool(log.in_step)
+            if log.accepted:
+                self._host_stale = True
+            self._have_blocks = False
+            self._blocks_cache = None
+            self._have_W = False
+            if log.exit_reason == RESIDENT_DONE:
+                break
+            if log.exit_reason == RESIDENT_LOG_FULL:
+                continue
+            # one trial through the general path, the schedule of step() around it
+            if self._cur_cost is None:
+                self._cur_cost = self._cost(PARAMS_CUR)
+                self.costs = self.costs or [self._cur_cost]
+            cur_cost = self._cur_cost
+            accepted, next_cost = self.trial(self._damping, None, cur_cost)
+            self.trial_log.append((self._damping, 'ill-conditioned' if accepted is None else 'accepted' if accepted else 'rejected', next_cost))
+            if accepted:
+                self._damping *= .1
+                self.costs.append(next_cost)
+                self.converged = abs(cur_cost - next_cost) < improvement_threshold
+                in_step = False
+            else:
+                self._damping *= 10.
+                self.converged = self._damping > 1e+8
+                in_step = True
+        if self._cur_cost is None:                    # no trial ran (no step to take, or the damping already beyond its range)
+            self._cur_cost = self._cost(PARAMS_CUR)
+        if not self.costs:
+            self.costs = [self._cur_cost]
         return self.converged
 
     def trial(self, damping, param_mask, cur_cost):

@@ -226,6 +226,9 @@ int ba_destroy(ba_handle* h) {
     if (su.up) (void)hipHostFree(su.up);
   }
   if (h->host_result) (void)hipHostFree(h->host_result);
+  if (h->res_log) (void)hipHostFree(h->res_log);
+  if (h->res_trace) (void)hipHostFree(h->res_trace);
+  h->res_xb.release(); h->res_epoch.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BA_OK;
@@ -280,6 +283,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "fused_eliminate") ok = flag(h->opt.fused_eliminate);
   else if (n == "device_lu") ok = flag(h->opt.device_lu);
   else if (n == "fast_paths") ok = flag(h->opt.fast_paths);
+  else if (n == "resident") ok = flag(h->opt.resident);
   else if (n == "gm_chunk") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0 && c <= 64; if (ok) h->opt.gm_chunk = (int)c; }
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);

@@ -62,6 +62,7 @@ struct Options {
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
   bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
   bool device_lu = true;           // a reduced system the Cholesky solve reports as not positive definite is solved again by the cyclic reduction with LU nodes
+  bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
 
@@ -190,6 +191,11 @@ struct ba_handle {
                             // counters (alternate per ba_schur call)
   int sing_epoch = 0;       // which of the two counters the latest ba_schur used
   HostResult* host_result = nullptr;   // pinned, device-visible: cost + status words of a trial
+  DevBuf<double> res_xb;               // ba_lm_resident: the exchange buffer of its workgroups
+  DevBuf<long long> res_epoch;         // ... their epoch words (never reset: a launch starts above res_epoch0)
+  long long res_epoch0 = 0;
+  void* res_log = nullptr;             // ... and its pinned log (ResidentLog of ba_resident.h)
+  void* res_trace = nullptr;           // ... and, with option solve_trace, clock stamps of its first 64 trials
   int cost_blocks = 0;      // partials the last k_cost launch wrote
   bool cost_fused = false;  // the last ba_backsubstitute evaluated the trial cost as well (k_backsub_groups)
   int* sing_counter() { return flags.p + 40 + (sing_epoch & 1); }

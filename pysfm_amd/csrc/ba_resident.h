@@ -1,0 +1,719 @@
+// ba_resident.h - the whole Levenberg-Marquardt loop of BundleAdjuster.optimize() (bundle_adjuster.py:117-162) for a SMALL
+// problem as one resident launch: a sliding window of <= 10 optimised cameras and up to a thousand tracks
+// (window_slam.py:17-48 runs one such problem per frame; the reference's own tests and its config-1 scenes are this size).
+//
+// At this size the six launches of ba_lm_trial cost 68 us per trial of which the kernels' own work is a fraction: every launch
+// starts a grid for a thousand observations, the host synchronises to take the accept / reject decision, the next trial
+// starts cold.  Here a small cluster of workgroups stays resident for the whole loop: workgroup g owns 32 points (their
+// observations, W = Jc^T Jp in registers, their point blocks in LDS), every workgroup keeps both camera sets and takes the
+// decisions of the reference's schedule itself; workgroup 0 leaves a log of (damping, outcome, cost) per trial that the Python
+// side replays into costs / trial_log / num_steps.  No launch, no host synchronisation, no PCIe traffic between trials.
+//
+// One trial (p = point, j = its j-th observation, pos = optimised position of a camera):
+//   1 linearise  lane group of 16 = one point, lane = observation: r, Jc, Jp (ba_math.h), W = Jc^T Jp kept in registers,
+//                Jc | r to LDS for the camera blocks, HPP / bP by a DPP butterfly over the group.  SKIPPED after a rejected
+//                trial: the parameters have not moved (prepare_schur_complement would recompute the same numbers,
+//                bundle_adjuster.py:211-234).
+//   2 damp+pinv  every lane of the group: (1 + damping) on the diagonal, pinv / inv of the 3 x 3 block, its L D L^T, U = W L into
+//                the k-major staging array At[3 p + k][6 pos + a] (zeros where a camera does not see the point), D and
+//                y = D L^T bP beside it                                                       (bundle_adjuster.py:238-256)
+//   3 reduce     camera blocks HCC / bC of my points: thread = (pos, entry), points in index order; P_g = At^T diag(D) At on the
+//                fp64 matrix cores, one wavefront per 16 x 16 tile of the upper triangle; At^T y with vector FMAs
+//                                                                                                (bundle_adjuster.py:259-278)
+//   exchange 1   every workgroup publishes its partial sums (relaxed agent-scope stores, one epoch word), waits for the others
+//                and adds ALL partials in workgroup order: every workgroup holds the same [S | b], bit for bit
+//   4 solve      S = damped HCC - P, b = bC - At^T y; Cholesky by block columns of one camera: the update of a block column from
+//                the columns left of it is spread over the workgroup, its 6 x 6 pivot chain runs in one wavefront with a lane
+//                per row and v_readlane broadcasts; the right-hand side rides along as one more row; back-substitution in the
+//                same wavefront.  Every workgroup solves (redundantly: a hand-over costs more than 8 us of one CU's time is
+//                worth).  A pivot <= 0 ends the run (exit reason 2): the host repeats that trial through the general path,
+//                which solves it as the reference's gesv would                                 (bundle_adjuster.py:281-312)
+//   5 back-sub   dP = HPPinv (bP - sum W^T dC), the trial set = perturb(-dC), x - dP, and the cost of my points at the trial set
+//                                                                                       (bundle_adjuster.py:316-343, 165-171)
+//   exchange 2   the cost partials; every workgroup adds them in workgroup order and takes the same decision.
+// fp64 throughout; every sum has a fixed order: results are reproducible run to run and identical in every workgroup.
+#pragma once
+
+#include "ba_device.h"
+
+namespace ba {
+
+constexpr int kResThreads = 256;                    // 4 wavefronts, one per SIMD: 512 VGPRs each (the loop's state stays in registers)
+constexpr int kResG = 16;                           // lanes per point
+constexpr int kResP = kResThreads / kResG;          // points per workgroup
+constexpr int kResWaves = kResThreads / 64;
+constexpr int kResK = 3 * kResP;                    // staged k rows
+constexpr int kResLd = 64;                          // staged row length (4 tiles)
+constexpr int kResMaxNco = 10;                      // optimised cameras: 60 unknowns, one lane per row of the factorisation
+constexpr int kResMaxNc = 32;
+constexpr int kResMaxGroups = 32;                   // workgroups of a launch
+constexpr int kResMaxNt = kResP * kResMaxGroups;
+constexpr int kResMaxL = kResG;
+constexpr int kResSLd = 65;                         // row length of S in LDS (odd: rows fall on different banks)
+constexpr int kResJcLd = 15;                        // Jc (12) | r (2), padded to an odd length
+constexpr int kResMaxTrials = 1000;
+constexpr int kResTiles = 10;                       // upper 16 x 16 tiles of a 64 x 64 matrix
+constexpr int kResRecTiles = kResTiles * 256;       // a workgroup's record in the exchange buffer: its tiles (accumulator layout) ...
+constexpr int kResRecRhs = kResRecTiles;            // ... the right-hand side partial [64]
+constexpr int kResRecCam = kResRecRhs + 64;         // ... the camera blocks of its points [nco * 27 <= 270]
+constexpr int kResRecScal = kResRecCam + 272;       // ... [0] cost of its points at the current set, [1] singular point blocks, [2] trial cost
+constexpr int kResRec = kResRecScal + 8;
+constexpr int kResRecMisc = kResRec - kResRecRhs;   // right-hand side | camera blocks | scalars: what a thread adds up pair by pair
+constexpr int kResMaxSpins = 1 << 22;
+
+enum { RES_DONE = 0, RES_LOG_FULL = 1, RES_NOT_POSITIVE_DEFINITE = 2, RES_SINGULAR_POINT = 3, RES_TIMED_OUT = 4 };
+
+struct ResidentLog {
+  int ntrials, nsteps, converged, in_step;
+  int exit_reason, exit_info, accepted, have_cost0;
+  double damping, cost0, cur_cost, pad;
+  double trial_damping[kResMaxTrials];
+  double trial_cost[kResMaxTrials];
+  int trial_accepted[kResMaxTrials];
+};
+
+struct ResidentArgs {
+  int nc, nt, nco, maxL, nobs, ngroups;
+  const int* obs_cam;
+  const double2* obs_z;
+  const int* pt_off;
+  const int* cam_opt_pos;
+  const unsigned char* pt_opt;
+  double K[9];
+  Sensor sensor;
+  double* cams;                 // the current set, in and out
+  double* X;
+  double* xb;                   // exchange buffer: ngroups records of kResRec doubles
+  long long* epoch;             // [2 * ngroups]: what each workgroup has published (partial sums | trial cost)
+  long long epoch0;             // epochs of this launch start above it (the words are never reset)
+  // the schedule
+  int max_steps, max_trials, nsteps, in_step, converged;
+  double damping, improvement_threshold, rcond, cur_cost;      // cur_cost < 0: not known yet
+  ResidentLog* log;             // pinned host memory
+  long long* trace;             // optional: clock stamps at the phase boundaries of the first trials, 16 per trial (workgroup 0)
+  double* dbg;                  // optional: [S | b] (lower triangle, 61 x 65) and dC (64) of the FIRST trial, for the parity tests
+};
+
+// LDS carve-up of a workgroup
+struct ResidentLds {
+  int cam, X, HPP, Hinv, HCC, Dk, red, misc, dC, z, stage;     // offsets in doubles
+  int flag_i, off_i, pos_i, tab_b, opt_b, oc_b;                // offsets in bytes
+  size_t bytes;
+};
+__host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
+  ResidentLds l;
+  int o = 0;
+  l.cam = o; o += 2 * nc * 12;
+  l.X = o; o += 2 * kResP * 3;
+  l.HPP = o; o += kResP * 9 + 1;                  // HPP (6) | bP (3) per point, undamped
+  l.Hinv = o; o += kResP * 9 + 1;                 // HPPinv (6) | HPPinv bP (3)
+  l.HCC = o; o += nco * 27 + (nco & 1);           // 21 + 6 per optimised camera, undamped, summed over the workgroups
+  l.Dk = o; o += 2 * kResK;                       // D | y
+  l.red = o; o += kResWaves * 64 + 16;            // partial right-hand sides [waves][64], wavefront partials
+  l.misc = o; o += kResRecMisc;                   // the summed right-hand side | camera blocks | scalars
+  l.dC = o; o += 64;
+  l.z = o; o += 2 * kResP * maxL;                 // the measurements of my points
+  l.stage = o;
+  const int at = kResK * kResLd + kResP * maxL * kResJcLd;
+  const int sm = 66 * kResSLd;
+  o += at > sm ? at : sm;
+  o += o & 1;
+  size_t b = (size_t)o * 8;
+  l.flag_i = (int)b; b += 16;                     // status words of a trial
+  l.off_i = (int)b; b += (size_t)(kResP + 1) * 4;
+  l.pos_i = (int)b; b += (size_t)nc * 4;
+  l.tab_b = (int)b; b += (size_t)kResP * nco;
+  l.opt_b = (int)b; b += (size_t)kResP;
+  l.oc_b = (int)b; b += (size_t)kResP * maxL;     // camera of an observation
+  l.bytes = (b + 15) & ~(size_t)15;
+  return l;
+}
+
+typedef double res_acc __attribute__((ext_vector_type(4)));
+typedef double res_d2 __attribute__((ext_vector_type(2)));
+
+// what crosses workgroups inside the launch: relaxed agent-scope accesses (they bypass / write through the caches that are
+// not coherent across the chip's eight L2s; no fences - ba_bcr.h has the long story)
+__device__ __forceinline__ void res_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double res_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// a value every lane holds alike, said so to the compiler (scalar registers, uniform branches)
+__device__ __forceinline__ int res_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double res_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// my stores have been acknowledged -> one word says so
+__device__ __forceinline__ void res_publish(long long* word, long long epoch, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  if (tid == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every workgroup has published `epoch`: lane g of the first wavefront polls word g.  False: timed out.
+__device__ __forceinline__ bool res_wait_all(const long long* words, int stride, int ngroups, long long epoch, int tid, int* timed_out) {
+  if (tid < 64) {
+    bool ok = tid >= ngroups;
+    for (int spins = 0; !__all(ok); ++spins) {
+      if (!ok) ok = __hip_atomic_load(words + (size_t)tid * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+      if (spins >= kResMaxSpins) { if (tid == 0) *timed_out = 1; break; }
+      if (!__all(ok)) __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  lds_barrier();
+  return res_uniform(*timed_out) == 0;
+}
+
+__global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = blockIdx.x, G = A.ngroups;
+  const int nc = A.nc, nt = A.nt, nco = A.nco, maxL = A.maxL, n = 6 * nco;
+  const ResidentLds lo = resident_lds(nc, nco, maxL);
+  double* camL = sm + lo.cam;
+  double* XL = sm + lo.X;
+  double* HPPl = sm + lo.HPP;
+  double* Hinvl = sm + lo.Hinv;
+  double* HCCl = sm + lo.HCC;
+  double* Dk = sm + lo.Dk;
+  double* yk = Dk + kResK;
+  double* red = sm + lo.red;
+  double* dCl = sm + lo.dC;
+  double* miscL = sm + lo.misc;
+  double* At = sm + lo.stage;
+  double* JC = At + kResK * kResLd;
+  double* Sm = sm + lo.stage;                      // aliases At / JC: used after the reduction only
+  unsigned char* base = reinterpret_cast<unsigned char*>(sm);
+  int* sflag = reinterpret_cast<int*>(base + lo.flag_i);      // [0]: pivot index of a failed factorisation, [1]: timed out
+  int* offL = reinterpret_cast<int*>(base + lo.off_i);
+  int* posL = reinterpret_cast<int*>(base + lo.pos_i);
+  signed char* tabj = reinterpret_cast<signed char*>(base + lo.tab_b);
+  unsigned char* optL = base + lo.opt_b;
+  unsigned char* ocL = base + lo.oc_b;
+  double2* zL = reinterpret_cast<double2*>(sm + lo.z);
+
+  // ---- once per launch: the cameras, my points and their observations, the (point, position) -> observation table
+  const int p0 = grp * kResP, np = min(kResP, nt - p0);        // my points [p0, p0 + np)
+  const int ob0 = A.pt_off[p0], nob = A.pt_off[p0 + np] - ob0;
+  int cur = 0;                                     // which of the two LDS parameter sets is the current one
+  for (int i = tid; i < nc * 12; i += kResThreads) camL[i] = A.cams[i];
+  for (int i = tid; i < np * 3; i += kResThreads) XL[i] = A.X[(size_t)p0 * 3 + i];
+  for (int i = tid; i <= np; i += kResThreads) offL[i] = A.pt_off[p0 + i] - ob0;
+  for (int i = tid; i < nc; i += kResThreads) posL[i] = A.cam_opt_pos[i];
+  for (int i = tid; i < np; i += kResThreads) optL[i] = A.pt_opt[p0 + i];
+  for (int i = tid; i < kResP * nco; i += kResThreads) tabj[i] = -1;
+  for (int i = tid; i < nob; i += kResThreads) { ocL[i] = (unsigned char)A.obs_cam[ob0 + i]; zL[i] = A.obs_z[ob0 + i]; }
+  if (tid == 0) { sflag[0] = 0; sflag[1] = 0; }
+  lds_barrier();
+  for (int p = tid; p < np; p += kResThreads)
+    for (int q = offL[p]; q < offL[p + 1]; ++q) {
+      const int pos = posL[ocL[q]];
+      if (pos >= 0) tabj[p * nco + pos] = (signed char)(q - offL[p]);
+    }
+  lds_barrier();
+
+  // the schedule's state: identical in every thread of every workgroup (all decisions are taken on sums every workgroup
+  // forms from the same numbers in the same order)
+  double damping = A.damping, cur_cost = A.cur_cost;
+  int nsteps = A.nsteps, in_step = A.in_step, converged = A.converged, ntrials = 0, accepted_any = 0;
+  int exit_reason = RES_DONE, exit_info = 0;
+  bool need_lin = true, have_cost0 = false;
+  double cost0 = 0.0;
+  long long epoch = A.epoch0;
+
+  // my observation: lane group of 16 = point slot pl, lane j = the point's j-th observation
+  const int pl = tid >> 4, j = tid & 15;
+  const bool pv = pl < np;
+  const int ob = pv ? offL[pl] : 0, L = pv ? offL[pl + 1] - ob : 0;
+  const bool ov = j < L;
+  const int oi = ob + j;
+  const int ocam = ov ? ocL[oi] : 0;
+  const int pos = ov ? posL[ocam] : -1;
+  const bool popt = pv && optL[pl] != 0;
+  double2 z = {0.0, 0.0};
+  if (ov) z = zL[oi];
+  double W[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) W[i] = 0.0;
+
+  const int NT = (n + 15) >> 4, ntiles = NT * (NT + 1) / 2;
+  const int ln = lane & 15, lk = lane >> 4;
+  int tti[3] = {0, 0, 0}, ttj[3] = {0, 0, 0};      // my tiles: wave, wave + 4, wave + 8
+  bool own[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) { own[t] = wave + kResWaves * t < ntiles; if (own[t]) tri_decode(wave + kResWaves * t, NT, tti[t], ttj[t]); }
+  double* myrec = A.xb + (size_t)grp * kResRec;
+
+  int tr_i = 0;
+#define RES_STAMP(k) do { if (A.trace && grp == 0 && tid == 0 && tr_i < 64) A.trace[tr_i * 16 + (k)] = (long long)wall_clock64(); } while (0)
+  for (;;) {
+    // ---- BundleAdjuster.optimize / step (bundle_adjuster.py:117-162)
+    if (!in_step) {
+      if (converged || nsteps >= A.max_steps) break;
+      ++nsteps;
+      in_step = 1;
+    }
+    if (converged || !(damping < 1e+8)) { in_step = 0; continue; }      // the inner loop of step() ends
+    if (ntrials >= A.max_trials) { exit_reason = RES_LOG_FULL; break; }
+
+    RES_STAMP(0);
+    if (A.trace && grp == 0 && tid == 0 && tr_i < 64) A.trace[tr_i * 16 + 10] = (long long)clock64();
+    const double* cm_cur = camL + cur * nc * 12;
+    const double* X_cur = XL + cur * kResP * 3;
+    double* cm_tr = camL + (1 - cur) * nc * 12;
+    double* X_tr = XL + (1 - cur) * kResP * 3;
+    const double dampf = 1.0 + damping;
+    const double ldl_tol = sym3_ldl_tolerance(A.rcond);
+    const double x[3] = {pv ? X_cur[3 * pl] : 0.0, pv ? X_cur[3 * pl + 1] : 0.0, pv ? X_cur[3 * pl + 2] : 0.0};
+
+    double hpp[6], bp[3];
+    double lin_cost = 0.0;
+    if (need_lin) {
+      double r[2] = {0.0, 0.0}, Jc[12], Jp[6];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
+      if (ov) {
+        double cm[12], e[2];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cm[i] = cm_cur[ocam * 12 + i];
+        obs_linearize<false>(A.K, cm, x, z.x, z.y, A.sensor, e, r, Jc, Jp);
+        if (pos >= 0 && popt) lin_cost = r[0] * r[0] + r[1] * r[1];
+        if (pos >= 0) {
+          double* jq = JC + (pl * maxL + j) * kResJcLd;
+#pragma unroll
+          for (int i = 0; i < 12; ++i) jq[i] = Jc[i];
+          jq[12] = r[0]; jq[13] = r[1];
+        }
+      }
+      block_W(Jc, Jp, W);
+      hpp[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
+      hpp[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
+      hpp[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+      hpp[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
+      hpp[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
+      hpp[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+      bp[0] = Jp[0] * r[0] + Jp[3] * r[1];
+      bp[1] = Jp[1] * r[0] + Jp[4] * r[1];
+      bp[2] = Jp[2] * r[0] + Jp[5] * r[1];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) hpp[i] = group_sum<16>(hpp[i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bp[i] = group_sum<16>(bp[i]);
+      if (pv && j == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) HPPl[pl * 9 + i] = hpp[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) HPPl[pl * 9 + 6 + i] = bp[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) hpp[i] = pv ? HPPl[pl * 9 + i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bp[i] = pv ? HPPl[pl * 9 + 6 + i] : 0.0;
+    }
+    // ---- damping, inverse, its factors (apply_damping, pinv: bundle_adjuster.py:238-256)
+    double Hi[6], Dd[3], Lo[3];
+    hpp[0] *= dampf; hpp[3] *= dampf; hpp[5] *= dampf;
+    bool singular = false;
+    if (A.rcond >= 0.0) sym3_pinv_fast(hpp, A.rcond, Hi);
+    else singular = !sym3_inv(hpp, Hi) && pv;
+    sym3_ldl(Hi, ldl_tol, Dd, Lo);
+    if (j == 0) {
+      if (pv) {
+        double tp[3];
+        sym3_apply(Hi, bp, tp);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Hinvl[pl * 9 + i] = Hi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Hinvl[pl * 9 + 6 + i] = tp[i];
+      }
+      const double y0 = bp[0] + Lo[0] * bp[1] + Lo[1] * bp[2], y1 = bp[1] + Lo[2] * bp[2], y2 = bp[2];
+      Dk[3 * pl] = pv ? Dd[0] : 0.0; Dk[3 * pl + 1] = pv ? Dd[1] : 0.0; Dk[3 * pl + 2] = pv ? Dd[2] : 0.0;
+      yk[3 * pl] = pv ? Dd[0] * y0 : 0.0; yk[3 * pl + 1] = pv ? Dd[1] * y1 : 0.0; yk[3 * pl + 2] = pv ? Dd[2] * y2 : 0.0;
+    }
+    // U = W L of my observation; zeros for the position j of this point if no camera there sees it
+    if (pos >= 0) {
+      double* q = At + (3 * pl) * kResLd + 6 * pos;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        q[a] = W[a * 3] + Lo[0] * W[a * 3 + 1] + Lo[1] * W[a * 3 + 2];
+        q[kResLd + a] = W[a * 3 + 1] + Lo[2] * W[a * 3 + 2];
+        q[2 * kResLd + a] = W[a * 3 + 2];
+      }
+    }
+    if (j < nco && (!pv || tabj[pl * nco + j] < 0)) {
+      double* q = At + (3 * pl) * kResLd + 6 * j;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { q[a] = 0.0; q[kResLd + a] = 0.0; q[2 * kResLd + a] = 0.0; }
+    }
+    const int nsing = __syncthreads_count(singular && j == 0);      // (a full barrier: the LDS writes above are visible below)
+    RES_STAMP(1);
+
+    // ---- camera blocks of my points (bundle_adjuster.py:230, 233), in index order: thread = (pos, entry of HCC | bC)
+    if (need_lin) {
+      for (int ct = tid; ct < nco * 27; ct += kResThreads) {
+        const int cpos = ct / 27, cent = ct - cpos * 27;
+        int ca = 0, cb = 0;                              // entry -> (a, b) of the upper triangle, or (a, -) of bC
+        if (cent < 21) { int e = cent; while (e >= 6 - ca) { e -= 6 - ca; ++ca; } cb = ca + e; } else { ca = cent - 21; cb = -1; }
+        double acc = 0.0;
+        {
+          constexpr int q0 = 0;
+          double v[kResP];
+#pragma unroll
+          for (int u = 0; u < kResP; ++u) {
+            const int q = q0 + u;
+            const int jj = q < np ? tabj[q * nco + cpos] : -1;
+            const double* jq = JC + (min(q, kResP - 1) * maxL + (jj < 0 ? 0 : jj)) * kResJcLd;
+            const double t = cb >= 0 ? jq[ca] * jq[cb] + jq[6 + ca] * jq[6 + cb] : jq[ca] * jq[12] + jq[6 + ca] * jq[13];
+            v[u] = jj < 0 ? 0.0 : t;
+          }
+#pragma unroll
+          for (int u = 0; u < kResP; ++u) acc += v[u];
+        }
+        res_st(myrec + kResRecCam + ct, acc);
+      }
+    }
+    // ---- P_g = At^T diag(D) At on the matrix cores, At^T y beside it
+    {
+      // (all kResK rows every time: rows of point slots beyond my last point are zeros)
+      constexpr int KS = kResK / 4;
+      double dkv[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dkv[ks] = Dk[4 * ks + lk];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (!own[t]) continue;
+        const double* a0 = At + 16 * tti[t] + ln + lk * kResLd;
+        const double* b0 = At + 16 * ttj[t] + ln + lk * kResLd;
+        double av[KS], bv[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { av[ks] = a0[4 * ks * kResLd]; bv[ks] = b0[4 * ks * kResLd]; }
+        res_acc acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks] * dkv[ks], acc, 0, 0, 0);
+        // my record: tiles in the accumulator layout [tile][lane][4]
+        double* q = myrec + ((size_t)(wave + kResWaves * t) * 64 + lane) * 4;
+        // (plain agent-scope stores: the compiler knows the wait states between a matrix-core result and a store that reads it;
+        //  inside an asm statement it does not - rows 4..7 x columns 12..15 of every tile came out stale)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) res_st(q + v, acc[v]);
+      }
+      const int r = tid & 63, sl = tid >> 6;      // kResK / kResWaves k rows per slice
+      double rhs_part = 0.0;
+      if (r < n) {
+#pragma unroll
+        for (int q = 0; q < kResK / kResWaves; ++q) {
+          const int k = sl * (kResK / kResWaves) + q;
+          rhs_part = fma(At[k * kResLd + r], yk[k], rhs_part);
+        }
+      }
+      red[sl * 64 + r] = rhs_part;
+    }
+    if (need_lin) {
+      const double c = wave_sum(lin_cost);
+      if (lane == 0) red[kResWaves * 64 + wave] = c;
+    }
+    lds_barrier();
+    if (tid < 64) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < kResWaves; ++q) s += red[q * 64 + tid];
+      res_st(myrec + kResRecRhs + tid, s);
+    }
+    if (tid == 64) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < kResWaves; ++w) s += red[kResWaves * 64 + w];
+      res_st(myrec + kResRecScal, need_lin ? s : 0.0);
+      res_st(myrec + kResRecScal + 1, (double)nsing);
+    }
+    RES_STAMP(2);
+    // ---- exchange 1: everybody's partial sums, added in workgroup order
+    ++epoch;
+    res_publish(A.epoch + 2 * grp, epoch, tid);
+    if (!res_wait_all(A.epoch, 2, G, epoch, tid, sflag + 1)) { exit_reason = RES_TIMED_OUT; break; }
+    RES_STAMP(3);
+    {
+      // tiles: C[row = 16 ti + lk + 4 v][col = 16 tj + ln], ti <= tj: entry (col, row) of the lower triangle of S
+      res_acc ssum[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) ssum[t] = res_acc{0.0, 0.0, 0.0, 0.0};
+      double m0 = 0.0, m1 = 0.0;                      // pair `tid` of the right-hand side | camera blocks | scalars
+      const bool mine = 2 * tid < kResRecMisc;
+      for (int g0 = 0; g0 < G; g0 += 4) {
+        double tv[4][3][4], mv[4][2];
+        // every load of the batch in flight before the first use
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* rec = A.xb + (size_t)min(g0 + u, G - 1) * kResRec;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const double* q = rec + ((size_t)(wave + kResWaves * t) * 64 + lane) * 4;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tv[u][t][v] = own[t] ? res_ld(q + v) : 0.0;
+          }
+          mv[u][0] = mine ? res_ld(rec + kResRecRhs + 2 * tid) : 0.0;
+          mv[u][1] = mine ? res_ld(rec + kResRecRhs + 2 * tid + 1) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (g0 + u >= G) continue;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ssum[t][v] += tv[u][t][v];
+          m0 += mv[u][0]; m1 += mv[u][1];
+        }
+      }
+      if (mine) { miscL[2 * tid] = m0; miscL[2 * tid + 1] = m1; }
+      lds_barrier();
+      const double c0sum = miscL[kResRecScal - kResRecRhs];
+      if (res_uniform(miscL[kResRecScal - kResRecRhs + 1]) > 0.0) { exit_reason = RES_SINGULAR_POINT; break; }      // plain-inverse mode: the general path raises (bundle_adjuster.py:254)
+      if (need_lin) {
+        for (int ct = tid; ct < nco * 27; ct += kResThreads) HCCl[ct] = miscL[kResRecCam - kResRecRhs + ct];
+        if (!have_cost0) {
+          cost0 = res_uniform(c0sum);
+          have_cost0 = true;
+          if (cur_cost < 0.0) cur_cost = cost0;
+        }
+      }
+      const double rsum = tid < 64 ? miscL[tid] : 0.0;
+      lds_barrier();                                  // HCC is in LDS; nobody reads At any more
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (!own[t]) continue;
+        const int ti = tti[t], tj = ttj[t];
+        const int col = 16 * tj + ln;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * ti + lk + 4 * v;
+          if (row <= col && col < n) {
+            double h = 0.0;
+            const int pr = row / 6, pc = col / 6;
+            if (pr == pc) {
+              const int a = row - 6 * pr, b = col - 6 * pc;
+              h = HCCl[pr * 27 + (a * (11 - a)) / 2 + b];             // entry (a, b >= a) of the upper triangle, rows first
+              if (a == b) h *= dampf;
+            }
+            Sm[col * kResSLd + row] = h - ssum[t][v];
+          }
+        }
+      }
+      if (tid < n) Sm[n * kResSLd + tid] = HCCl[(tid / 6) * 27 + 21 + tid % 6] - rsum;
+    }
+    lds_barrier();
+    if (A.dbg && grp == 0 && ntrials == 0)
+      for (int i = tid; i < (n + 1) * kResSLd; i += kResThreads) A.dbg[i] = Sm[i];
+    RES_STAMP(4);
+
+    // ---- Cholesky by block columns of one camera; row n = the right-hand side (becomes L^-1 b)
+#define RES_CSTAMP(k) do { if (A.trace && grp == 0 && tid == 0 && ntrials == 0) A.trace[(32 + J) * 16 + (k)] = (long long)clock64(); } while (0)
+    for (int J = 0; J < nco; ++J) {
+      const int c0 = 6 * J;
+      RES_CSTAMP(0);
+      if (J > 0) {
+        // rows i >= c0 (row n included), columns c0 .. c0 + 5: minus the products with the columns left of c0; `split` threads
+        // share an entry (the sum over m in interleaved parts, then a DPP butterfly)
+        const int E = (n + 1 - c0) * 6;
+        const int split = E <= 32 ? 8 : E <= 64 ? 4 : E <= 128 ? 2 : 1;
+        for (int t = tid; t < ((E * split + kResThreads - 1) / kResThreads) * kResThreads; t += kResThreads) {
+          const int e = t / split, s = t - e * split;
+          const int i = c0 + e / 6, c = c0 + e % 6;
+          double s0 = 0.0, s1 = 0.0;
+          if (e < E) {
+            const double* ri = Sm + i * kResSLd;
+            const double* rc = Sm + c * kResSLd;
+            for (int m = s; m < c0; m += 8 * split) {
+              double rv[8], cv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int mm = m + u * split;
+                rv[u] = mm < c0 ? ri[mm] : 0.0;
+                cv[u] = mm < c0 ? rc[mm] : 0.0;
+              }
+#pragma unroll
+              for (int u = 0; u < 8; u += 2) { s0 = fma(rv[u], cv[u], s0); s1 = fma(rv[u + 1], cv[u + 1], s1); }
+            }
+          }
+          double sum = s0 + s1;
+          if (split >= 2) sum += dpp_pair<0xB1>(sum);
+          if (split >= 4) sum += dpp_pair<0x4E>(sum);
+          if (split >= 8) sum += dpp_pair<0x141>(sum);
+          if (e < E && s == 0 && c <= i) Sm[i * kResSLd + c] -= sum;
+        }
+        RES_CSTAMP(1);
+        lds_barrier();
+      }
+      RES_CSTAMP(2);
+      if (wave == 0) {
+        const int i = c0 + lane;                    // my row
+        const bool rv = i <= n;
+        double a[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[c] = rv ? Sm[i * kResSLd + c0 + c] : 0.0;
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double d = lane_bcast(a[c], c);
+          if (!(d > 0.0) || !(d < INFINITY)) { bad = true; if (lane == 0) sflag[0] = c0 + c + 1; break; }
+          const double inv = rsqrt_cubic(d);
+          a[c] *= inv;                              // lane c: sqrt(d); lanes below: the column of L
+#pragma unroll
+          for (int c2 = c + 1; c2 < 6; ++c2) a[c2] = fma(-a[c], lane_bcast(a[c], c2), a[c2]);
+        }
+        if (!bad && rv) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) Sm[i * kResSLd + c0 + c] = a[c];
+        }
+      }
+      RES_CSTAMP(3);
+      lds_barrier();
+      RES_CSTAMP(4);
+      if (res_uniform(sflag[0])) break;
+    }
+    if (res_uniform(sflag[0])) { exit_reason = RES_NOT_POSITIVE_DEFINITE; exit_info = res_uniform(sflag[0]); break; }
+    RES_STAMP(5);
+    // ---- L^T x = y in one wavefront: lane i holds its unknown; the rows of a camera block are fetched together
+    if (wave == 0) {
+      const bool rv = lane < n;
+      double v = rv ? Sm[n * kResSLd + lane] : 0.0;
+      const double invd = rv ? 1.0 / Sm[lane * kResSLd + lane] : 0.0;
+      double xs = 0.0;
+      for (int J = nco - 1; J >= 0; --J) {
+        double lq[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) lq[u] = lane < 6 * J + u ? Sm[(6 * J + u) * kResSLd + lane] : 0.0;
+#pragma unroll
+        for (int u = 5; u >= 0; --u) {
+          const int q = 6 * J + u;
+          const double xq = lane_bcast(v * invd, q);
+          if (lane == q) xs = xq;
+          v = fma(-lq[u], xq, v);
+        }
+      }
+      if (rv) dCl[lane] = xs;
+    }
+    lds_barrier();
+    if (A.dbg && grp == 0 && ntrials == 0 && tid < 64) A.dbg[66 * kResSLd + tid] = tid < n ? dCl[tid] : 0.0;
+    RES_STAMP(6);
+
+    // ---- the trial set: cameras (update_motion with the sign of compute_update, bundle_adjuster.py:203-208, 334-337)
+    for (int c = tid; c < nc; c += kResThreads) {
+      const int cp = posL[c];
+      double cm[12], out[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) cm[q] = cm_cur[c * 12 + q];
+      if (cp >= 0) {
+        double d[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d[q] = -dCl[cp * 6 + q];
+        camera_perturb(cm, d, out);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) out[q] = cm[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) cm_tr[c * 12 + q] = out[q];
+    }
+    lds_barrier();
+    // ---- back-substitution, the trial points and the trial cost (bundle_adjuster.py:316-331, 340-343, 165-171)
+    double tc = 0.0;
+    {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      if (pos >= 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double d = dCl[pos * 6 + a];
+          v0 = fma(W[a * 3], d, v0);
+          v1 = fma(W[a * 3 + 1], d, v1);
+          v2 = fma(W[a * 3 + 2], d, v2);
+        }
+      }
+      v0 = group_sum<16>(v0); v1 = group_sum<16>(v1); v2 = group_sum<16>(v2);
+      if (pv) {
+        const double* hq = Hinvl + pl * 9;
+        const double* bq = HPPl + pl * 9 + 6;
+        const double w[3] = {bq[0] - v0, bq[1] - v1, bq[2] - v2};
+        const double Hq[6] = {hq[0], hq[1], hq[2], hq[3], hq[4], hq[5]};
+        double dp[3];
+        sym3_apply(Hq, w, dp);
+        const double xt[3] = {popt ? x[0] - dp[0] : x[0], popt ? x[1] - dp[1] : x[1], popt ? x[2] - dp[2] : x[2]};
+        if (j == 0) { X_tr[3 * pl] = xt[0]; X_tr[3 * pl + 1] = xt[1]; X_tr[3 * pl + 2] = xt[2]; }
+        if (pos >= 0 && popt) {
+          double cm[12], e[2], r[2];
+#pragma unroll
+          for (int q = 0; q < 12; ++q) cm[q] = cm_tr[ocam * 12 + q];
+          obs_residual<false>(A.K, cm, xt, z.x, z.y, A.sensor, e, r);
+          tc = r[0] * r[0] + r[1] * r[1];
+        }
+      }
+    }
+    tc = wave_sum(tc);
+    if (lane == 0) red[kResWaves * 64 + wave] = tc;
+    lds_barrier();
+    if (tid == 0) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < kResWaves; ++w) s += red[kResWaves * 64 + w];
+      res_st(myrec + kResRecScal + 2, s);
+    }
+    RES_STAMP(7);
+    // ---- exchange 2: the cost of the trial set
+    ++epoch;
+    res_publish(A.epoch + 2 * grp + 1, epoch, tid);
+    if (!res_wait_all(A.epoch + 1, 2, G, epoch, tid, sflag + 1)) { exit_reason = RES_TIMED_OUT; break; }
+    double next_cost = 0.0;
+    for (int g0 = 0; g0 < G; g0 += 8) {
+      double cv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cv[u] = res_ld(A.xb + (size_t)min(g0 + u, G - 1) * kResRec + kResRecScal + 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) next_cost += g0 + u < G ? cv[u] : 0.0;
+    }
+    next_cost = res_uniform(next_cost);
+    // ---- accept / reject and the damping schedule (bundle_adjuster.py:136-157)
+    const bool accept = next_cost < cur_cost;
+    if (grp == 0 && tid == 0) {
+      A.log->trial_damping[ntrials] = damping;
+      A.log->trial_cost[ntrials] = next_cost;
+      A.log->trial_accepted[ntrials] = accept ? 1 : 0;
+    }
+    RES_STAMP(8);
+    if (A.trace && grp == 0 && tid == 0 && tr_i < 64) A.trace[tr_i * 16 + 11] = (long long)clock64();
+    if (A.trace && grp == 0 && tid == 0 && tr_i < 64) A.trace[tr_i * 16 + 15] = need_lin ? 1 : 0;
+    ++tr_i;
+    ++ntrials;
+    if (accept) {
+      damping *= 0.1;
+      converged = fabs(cur_cost - next_cost) < A.improvement_threshold;
+      cur_cost = next_cost;
+      cur = 1 - cur;
+      need_lin = true;
+      accepted_any = 1;
+      in_step = 0;
+    } else {
+      damping *= 10.0;
+      converged = damping > 1e+8;
+      need_lin = false;
+    }
+  }
+
+  // ---- the current set back to device memory (my points; workgroup 0: the cameras), the state of the schedule to the log
+  if (accepted_any) {
+    const double* cm_cur = camL + cur * nc * 12;
+    const double* X_cur = XL + cur * kResP * 3;
+    if (grp == 0)
+      for (int i = tid; i < nc * 12; i += kResThreads) A.cams[i] = cm_cur[i];
+    for (int i = tid; i < np * 3; i += kResThreads) A.X[(size_t)p0 * 3 + i] = X_cur[i];
+  }
+  if (grp == 0 && tid == 0) {
+    ResidentLog* g = A.log;
+    g->ntrials = ntrials; g->nsteps = nsteps; g->converged = converged; g->in_step = in_step;
+    g->exit_reason = exit_reason; g->exit_info = exit_info; g->accepted = accepted_any; g->have_cost0 = have_cost0 ? 1 : 0;
+    g->damping = damping; g->cost0 = cost0; g->cur_cost = cur_cost;
+  }
+}
+
+}  // namespace ba

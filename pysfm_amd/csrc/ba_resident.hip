@@ -1,0 +1,116 @@
+// ba_resident.hip - ba_lm_resident: the Levenberg-Marquardt loop of a small problem as one resident workgroup (ba_resident.h).
+#include "ba_internal.h"
+#include "ba_resident.h"
+
+using namespace ba;
+
+static_assert(sizeof(ba_resident_log) == sizeof(ResidentLog), "the log of include/pysfm_ba.h and ba_resident.h must agree");
+static_assert(BA_RESIDENT_MAX_TRIALS == kResMaxTrials, "the log of include/pysfm_ba.h and ba_resident.h must agree");
+
+namespace {
+
+bool resident_fits(const ba_handle* h, ResidentLds* lds_out) {
+  if (!h->opt.resident || !h->have_problem || h->comm || h->dense_mode) return false;
+  if (h->sensor.kind == SENSOR_TABLE) return false;
+  if (h->nco < 1 || h->nco > kResMaxNco || h->nc > kResMaxNc || h->nt < 1 || h->nt > kResMaxNt) return false;
+  if (h->group_maxL < 1 || h->group_maxL > kResMaxL || h->nobs < 1 || h->nobs > (1 << 20)) return false;
+  const ResidentLds l = resident_lds(h->nc, h->nco, h->group_maxL);
+  if (l.bytes > 157 * 1024) return false;
+  if (lds_out) *lds_out = l;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ba_lm_resident_fits(ba_handle* h) {
+  if (!h) return 0;
+  return resident_fits(h, nullptr) ? 1 : 0;
+}
+
+int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
+                   double improvement_threshold, double pinv_rcond, double cur_cost, ba_resident_log* log) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, log, BA_ERR_INVALID_ARG, "ba_lm_resident: NULL log");
+  REQUIRE(h, h->have_problem && h->have_params[h->phys(BA_PARAMS_CUR)], BA_ERR_STATE, "ba_lm_resident: set problem and parameters first");
+  ResidentLds lds;
+  REQUIRE(h, resident_fits(h, &lds), BA_ERR_STATE, "ba_lm_resident: the problem does not fit one compute unit (ba_lm_resident_fits)");
+  HIPCHECK(h, hipSetDevice(h->device));
+  const int G = (h->nt + kResP - 1) / kResP;
+  if (h->res_xb.n < (size_t)G * kResRec || h->res_epoch.n < (size_t)2 * G) {
+    HIPCHECK(h, h->res_xb.resize((size_t)kResMaxGroups * kResRec));
+    HIPCHECK(h, h->res_epoch.resize((size_t)2 * kResMaxGroups));
+    HIPCHECK(h, hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream));
+    h->res_epoch0 = 0;
+  }
+  if (!h->res_log) HIPCHECK(h, hipHostMalloc(&h->res_log, sizeof(ResidentLog), hipHostMallocDefault));
+  {
+    // (the kernel has a few static LDS words of its own: ask for less than the whole 160 KB)
+    const void* fn = (const void*)k_resident_lm;
+    if (std::find(h->lds_attr_done.begin(), h->lds_attr_done.end(), fn) == h->lds_attr_done.end()) {
+      HIPCHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      h->lds_attr_done.push_back(fn);
+    }
+  }
+  const int p = h->phys(BA_PARAMS_CUR);
+  ResidentArgs a;
+  a.nc = h->nc; a.nt = h->nt; a.nco = h->nco; a.maxL = h->group_maxL; a.nobs = (int)h->nobs;
+  a.ngroups = G;
+  a.obs_cam = h->obs_cam.p; a.obs_z = h->obs_z.p; a.pt_off = h->pt_off.p; a.cam_opt_pos = h->cam_opt_pos.p; a.pt_opt = h->pt_opt.p;
+  for (int i = 0; i < 9; ++i) a.K[i] = h->K[i];
+  a.sensor = h->sensor;
+  if (!h->opt.fast_paths) a.sensor.fast = 0;
+  a.cams = h->cams[p].p; a.X = h->X[p].p; a.xb = h->res_xb.p; a.epoch = h->res_epoch.p; a.epoch0 = h->res_epoch0;
+  a.max_steps = max_steps; a.max_trials = kResMaxTrials; a.nsteps = steps_taken; a.in_step = in_step ? 1 : 0; a.converged = converged ? 1 : 0;
+  a.damping = damping; a.improvement_threshold = improvement_threshold; a.rcond = pinv_rcond; a.cur_cost = cur_cost;
+  a.log = static_cast<ResidentLog*>(h->res_log);
+  a.trace = nullptr;
+  a.dbg = nullptr;
+  if (h->opt.solve_trace) {
+    if (!h->res_trace) HIPCHECK(h, hipHostMalloc(&h->res_trace, 64 * 16 * sizeof(long long) + (66 * kResSLd + 64) * sizeof(double), hipHostMallocDefault));
+    memset(h->res_trace, 0, 64 * 16 * sizeof(long long));
+    a.trace = static_cast<long long*>(h->res_trace);
+    a.dbg = reinterpret_cast<double*>(a.trace + 64 * 16);
+  }
+  a.log->ntrials = -1;
+  hipLaunchKernelGGL(k_resident_lm, dim3(G), dim3(kResThreads), lds.bytes, h->stream, a);
+  HIPCHECK(h, hipGetLastError());
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  REQUIRE(h, a.log->ntrials >= 0, BA_ERR_HIP, "ba_lm_resident: the kernel left no log");
+  h->res_epoch0 += 2 * ((long long)a.log->ntrials + 2);
+  if (a.log->exit_reason == RES_TIMED_OUT) {
+    // a workgroup gave up waiting for the others: a fault of the kernel or of the GPU, never a property of the problem
+    (void)hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream);
+    h->res_epoch0 = 0;
+    h->have_params[p] = false;
+    return h->fail(BA_ERR_HIP, "ba_lm_resident: the workgroups of the resident loop lost each other (timed out after %d trials)", a.log->ntrials);
+  }
+  memcpy(log, h->res_log, sizeof(ResidentLog));
+  // the current set has moved (or not): nothing that was derived from it on the device is valid any more
+  if (log->accepted) {
+    h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
+    h->point_blocks_valid = h->cam_blocks_valid = h->inv_valid = h->fac_valid = false;
+  }
+  return BA_OK;
+}
+
+int ba_lm_resident_trace(ba_handle* h, int64_t* out) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, out && h->res_trace, BA_ERR_STATE, "ba_lm_resident_trace: set option solve_trace and run ba_lm_resident first");
+  memcpy(out, h->res_trace, 64 * 16 * sizeof(long long));
+  return BA_OK;
+}
+
+int ba_lm_resident_debug(ba_handle* h, double* S_out, double* b_out, double* dC_out) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, S_out && b_out && dC_out && h->res_trace, BA_ERR_STATE, "ba_lm_resident_debug: set option solve_trace and run ba_lm_resident first");
+  const double* d = reinterpret_cast<const double*>(static_cast<const long long*>(h->res_trace) + 64 * 16);
+  const int n = 6 * h->nco;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) S_out[(size_t)i * n + j] = i >= j ? d[i * kResSLd + j] : d[j * kResSLd + i];
+  for (int i = 0; i < n; ++i) { b_out[i] = d[n * kResSLd + i]; dC_out[i] = d[66 * kResSLd + i]; }
+  return BA_OK;
+}
+
+}  // extern "C"
