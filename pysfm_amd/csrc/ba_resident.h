@@ -53,12 +53,14 @@ constexpr int kResSLd = 65;                         // row length of S in LDS (o
 constexpr int kResJcLd = 15;                        // Jc (12) | r (2), padded to an odd length
 constexpr int kResMaxTrials = 1000;
 constexpr int kResTiles = 10;                       // upper 16 x 16 tiles of a 64 x 64 matrix
-constexpr int kResRecTiles = kResTiles * 256;       // a workgroup's record in the exchange buffer: its tiles (accumulator layout) ...
-constexpr int kResRecRhs = kResRecTiles;            // ... the right-hand side partial [64]
-constexpr int kResRecCam = kResRecRhs + 64;         // ... the camera blocks of its points [nco * 27 <= 270]
-constexpr int kResRecScal = kResRecCam + 272;       // ... [0] cost of its points at the current set, [1] singular point blocks, [2] trial cost
-constexpr int kResRec = kResRecScal + 8;
-constexpr int kResRecMisc = kResRec - kResRecRhs;   // right-hand side | camera blocks | scalars: what a thread adds up pair by pair
+// A workgroup's record in the exchange buffer, laid out by the THREAD that adds it up (element-major, so that a wavefront's
+// load reads 512 contiguous bytes): thread t owns 14 doubles = its three
+// accumulator tiles (4 doubles each) and pair t of the "misc" block: right-hand side [64] | camera blocks [272] | scalars [8]
+// ([0] cost of its points at the current set, [1] singular point blocks, [2] trial cost).  Seven 16-byte loads per record.
+constexpr int kResRecPerThread = 14;
+constexpr int kResRec = kResRecPerThread * 256;
+constexpr int kResMiscRhs = 0, kResMiscCam = 64, kResMiscScal = kResMiscCam + 272, kResMisc = kResMiscScal + 8;
+__host__ __device__ constexpr int res_misc_at(int idx) { return (12 + (idx & 1)) * 256 + (idx >> 1); }      // element e of thread t lives at e * 256 + t
 constexpr int kResMaxSpins = 1 << 22;
 
 enum { RES_DONE = 0, RES_LOG_FULL = 1, RES_NOT_POSITIVE_DEFINITE = 2, RES_SINGULAR_POINT = 3, RES_TIMED_OUT = 4 };
@@ -96,7 +98,7 @@ struct ResidentArgs {
 
 // LDS carve-up of a workgroup
 struct ResidentLds {
-  int cam, X, HPP, Hinv, HCC, Dk, red, misc, dC, z, stage;     // offsets in doubles
+  int cam, X, HPP, Hinv, HCC, Dk, red, misc, part, dC, z, stage;     // offsets in doubles
   int flag_i, off_i, pos_i, tab_b, opt_b, oc_b;                // offsets in bytes
   size_t bytes;
 };
@@ -110,7 +112,8 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.HCC = o; o += nco * 27 + (nco & 1);           // 21 + 6 per optimised camera, undamped, summed over the workgroups
   l.Dk = o; o += 2 * kResK;                       // D | y
   l.red = o; o += kResWaves * 64 + 16;            // partial right-hand sides [waves][64], wavefront partials
-  l.misc = o; o += kResRecMisc;                   // the summed right-hand side | camera blocks | scalars
+  l.misc = o; o += kResMisc;                   // the summed right-hand side | camera blocks | scalars
+  l.part = o; o += (kResWaves - 1) * 6 * 64;      // the factorisation's partial sums of wavefronts 1 .. 3
   l.dC = o; o += 64;
   l.z = o; o += 2 * kResP * maxL;                 // the measurements of my points
   l.stage = o;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   double* red = sm + lo.red;
   double* dCl = sm + lo.dC;
   double* miscL = sm + lo.misc;
+  double* part = sm + lo.part;
   double* At = sm + lo.stage;
   double* JC = At + kResK * kResLd;
   double* Sm = sm + lo.stage;                      // aliases At / JC: used after the reduction only
@@ -364,15 +368,16 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
 #pragma unroll
           for (int u = 0; u < kResP; ++u) {
             const int q = q0 + u;
-            const int jj = q < np ? tabj[q * nco + cpos] : -1;
-            const double* jq = JC + (min(q, kResP - 1) * maxL + (jj < 0 ? 0 : jj)) * kResJcLd;
+            const int jr = tabj[q * nco + cpos];                 // (rows of point slots beyond my last point hold -1)
+            const int jj = q < np ? jr : -1;
+            const double* jq = JC + (q * maxL + max(jj, 0)) * kResJcLd;
             const double t = cb >= 0 ? jq[ca] * jq[cb] + jq[6 + ca] * jq[6 + cb] : jq[ca] * jq[12] + jq[6 + ca] * jq[13];
             v[u] = jj < 0 ? 0.0 : t;
           }
 #pragma unroll
           for (int u = 0; u < kResP; ++u) acc += v[u];
         }
-        res_st(myrec + kResRecCam + ct, acc);
+        res_st(myrec + res_misc_at(kResMiscCam + ct), acc);
       }
     }
     // ---- P_g = At^T diag(D) At on the matrix cores, At^T y beside it
@@ -394,11 +399,11 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks] * dkv[ks], acc, 0, 0, 0);
         // my record: tiles in the accumulator layout [tile][lane][4]
-        double* q = myrec + ((size_t)(wave + kResWaves * t) * 64 + lane) * 4;
+        double* q = myrec + (4 * t) * 256 + tid;
         // (plain agent-scope stores: the compiler knows the wait states between a matrix-core result and a store that reads it;
         //  inside an asm statement it does not - rows 4..7 x columns 12..15 of every tile came out stale)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) res_st(q + v, acc[v]);
+        for (int v = 0; v < 4; ++v) res_st(q + v * 256, acc[v]);
       }
       const int r = tid & 63, sl = tid >> 6;      // kResK / kResWaves k rows per slice
       double rhs_part = 0.0;
@@ -420,14 +425,14 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       double s = 0.0;
 #pragma unroll
       for (int q = 0; q < kResWaves; ++q) s += red[q * 64 + tid];
-      res_st(myrec + kResRecRhs + tid, s);
+      res_st(myrec + res_misc_at(kResMiscRhs + tid), s);
     }
     if (tid == 64) {
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < kResWaves; ++w) s += red[kResWaves * 64 + w];
-      res_st(myrec + kResRecScal, need_lin ? s : 0.0);
-      res_st(myrec + kResRecScal + 1, (double)nsing);
+      res_st(myrec + res_misc_at(kResMiscScal), need_lin ? s : 0.0);
+      res_st(myrec + res_misc_at(kResMiscScal + 1), (double)nsing);
     }
     RES_STAMP(2);
     // ---- exchange 1: everybody's partial sums, added in workgroup order
@@ -441,38 +446,34 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) ssum[t] = res_acc{0.0, 0.0, 0.0, 0.0};
       double m0 = 0.0, m1 = 0.0;                      // pair `tid` of the right-hand side | camera blocks | scalars
-      const bool mine = 2 * tid < kResRecMisc;
+      const bool mine = 2 * tid < kResMisc;
+      const double* mybase = A.xb + tid;
       for (int g0 = 0; g0 < G; g0 += 4) {
-        double tv[4][3][4], mv[4][2];
-        // every load of the batch in flight before the first use
+        // four records in flight before the first use (compiler-visible agent-scope loads: it counts the waits itself)
+        double v[4][kResRecPerThread];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const double* rec = A.xb + (size_t)min(g0 + u, G - 1) * kResRec;
+          const double* q = mybase + (size_t)min(g0 + u, G - 1) * kResRec;
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            const double* q = rec + ((size_t)(wave + kResWaves * t) * 64 + lane) * 4;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) tv[u][t][v] = own[t] ? res_ld(q + v) : 0.0;
-          }
-          mv[u][0] = mine ? res_ld(rec + kResRecRhs + 2 * tid) : 0.0;
-          mv[u][1] = mine ? res_ld(rec + kResRecRhs + 2 * tid + 1) : 0.0;
+          for (int e = 0; e < kResRecPerThread; ++e) v[u][e] = res_ld(q + e * 256);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          if (g0 + u >= G) continue;
+          const bool in = g0 + u < G;
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) ssum[t][v] += tv[u][t][v];
-          m0 += mv[u][0]; m1 += mv[u][1];
+            for (int e = 0; e < 4; ++e) ssum[t][e] += in && own[t] ? v[u][4 * t + e] : 0.0;
+          m0 += in && mine ? v[u][12] : 0.0;
+          m1 += in && mine ? v[u][13] : 0.0;
         }
       }
       if (mine) { miscL[2 * tid] = m0; miscL[2 * tid + 1] = m1; }
       lds_barrier();
-      const double c0sum = miscL[kResRecScal - kResRecRhs];
-      if (res_uniform(miscL[kResRecScal - kResRecRhs + 1]) > 0.0) { exit_reason = RES_SINGULAR_POINT; break; }      // plain-inverse mode: the general path raises (bundle_adjuster.py:254)
+      const double c0sum = miscL[kResMiscScal];
+      if (res_uniform(miscL[kResMiscScal + 1]) > 0.0) { exit_reason = RES_SINGULAR_POINT; break; }      // plain-inverse mode: the general path raises (bundle_adjuster.py:254)
       if (need_lin) {
-        for (int ct = tid; ct < nco * 27; ct += kResThreads) HCCl[ct] = miscL[kResRecCam - kResRecRhs + ct];
+        for (int ct = tid; ct < nco * 27; ct += kResThreads) HCCl[ct] = miscL[kResMiscCam + ct];
         if (!have_cost0) {
           cost0 = res_uniform(c0sum);
           have_cost0 = true;
@@ -508,64 +509,82 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       for (int i = tid; i < (n + 1) * kResSLd; i += kResThreads) A.dbg[i] = Sm[i];
     RES_STAMP(4);
 
-    // ---- Cholesky by block columns of one camera; row n = the right-hand side (becomes L^-1 b)
+    // ---- Cholesky by block columns of one camera; row n = the right-hand side (becomes L^-1 b).  lane = row of the block
+    //      column (row c0 + lane), wavefront = a quarter of the columns left of it
 #define RES_CSTAMP(k) do { if (A.trace && grp == 0 && tid == 0 && ntrials == 0) A.trace[(32 + J) * 16 + (k)] = (long long)clock64(); } while (0)
     for (int J = 0; J < nco; ++J) {
       const int c0 = 6 * J;
+      const int i = c0 + lane;
+      const bool rv = i <= n;
       RES_CSTAMP(0);
+      double up[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (J > 0) {
-        // rows i >= c0 (row n included), columns c0 .. c0 + 5: minus the products with the columns left of c0; `split` threads
-        // share an entry (the sum over m in interleaved parts, then a DPP butterfly)
-        const int E = (n + 1 - c0) * 6;
-        const int split = E <= 32 ? 8 : E <= 64 ? 4 : E <= 128 ? 2 : 1;
-        for (int t = tid; t < ((E * split + kResThreads - 1) / kResThreads) * kResThreads; t += kResThreads) {
-          const int e = t / split, s = t - e * split;
-          const int i = c0 + e / 6, c = c0 + e % 6;
-          double s0 = 0.0, s1 = 0.0;
-          if (e < E) {
-            const double* ri = Sm + i * kResSLd;
-            const double* rc = Sm + c * kResSLd;
-            for (int m = s; m < c0; m += 8 * split) {
-              double rv[8], cv[8];
+        // S[i][c0 + c] -= sum over m < c0 of L[i][m] L[c0 + c][m]: my share of the m (m = wave, wave + 4, ...), four per round trip
+        const double* ri = Sm + (rv ? i : 0) * kResSLd;
+        for (int m0 = wave; m0 < c0; m0 += 4 * kResWaves) {
+          double li[4], lc[4][6];
+          // (every load unconditional, at a clamped position: a load under a uniform condition becomes a branch, and a dozen
+          //  of them a maze of branches that costs more than the loads)
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                const int mm = m + u * split;
-                rv[u] = mm < c0 ? ri[mm] : 0.0;
-                cv[u] = mm < c0 ? rc[mm] : 0.0;
-              }
+          for (int u = 0; u < 4; ++u) {
+            const int m = m0 + u * kResWaves;
+            const int mc = min(m, c0 - 1);
+            li[u] = ri[mc] * (m < c0 ? 1.0 : 0.0);
 #pragma unroll
-              for (int u = 0; u < 8; u += 2) { s0 = fma(rv[u], cv[u], s0); s1 = fma(rv[u + 1], cv[u + 1], s1); }
-            }
+            for (int c = 0; c < 6; ++c) lc[u][c] = Sm[(c0 + c) * kResSLd + mc];
           }
-          double sum = s0 + s1;
-          if (split >= 2) sum += dpp_pair<0xB1>(sum);
-          if (split >= 4) sum += dpp_pair<0x4E>(sum);
-          if (split >= 8) sum += dpp_pair<0x141>(sum);
-          if (e < E && s == 0 && c <= i) Sm[i * kResSLd + c] -= sum;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) up[c] = fma(li[u], lc[u][c], up[c]);
+        }
+        if (wave > 0) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) part[((wave - 1) * 6 + c) * 64 + lane] = up[c];
         }
         RES_CSTAMP(1);
         lds_barrier();
       }
       RES_CSTAMP(2);
       if (wave == 0) {
-        const int i = c0 + lane;                    // my row
-        const bool rv = i <= n;
         double a[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) a[c] = rv ? Sm[i * kResSLd + c0 + c] : 0.0;
+        for (int c = 0; c < 6; ++c) a[c] = Sm[min(i, n) * kResSLd + c0 + c];
+        if (J > 0) {
+          double pr[18];
+#pragma unroll
+          for (int q = 0; q < 18; ++q) pr[q] = part[q * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);          // (every load in flight before the first sum: one round trip, not nine)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) a[c] -= ((up[c] + pr[c]) + pr[6 + c]) + pr[12 + c];
+        }
+        // The pivot chain without a division on it: step c multiplies the rest of the block by the pivot instead of dividing the
+        // column by it, a' = (p mu) a - (a_c mu) l with mu = 2^-exponent(p) (exact), so that after step c every entry carries
+        // the factor sigma_{c+1} = sigma_c p mu (within 2^6 of 1); column c of L is a_c / sqrt(sigma_c p), formed at the end by
+        // six independent 1 / sqrt in six lanes.  (One v_rsq + Newton per pivot ON the chain costs 310 cycles a pivot.)
+        double sigma = 1.0, sp = 1.0;
         bool bad = false;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          const double d = lane_bcast(a[c], c);
-          if (!(d > 0.0) || !(d < INFINITY)) { bad = true; if (lane == 0) sflag[0] = c0 + c + 1; break; }
-          const double inv = rsqrt_cubic(d);
-          a[c] *= inv;                              // lane c: sqrt(d); lanes below: the column of L
+          const double p = lane_bcast(a[c], c);
+          bad = bad | !(p > 0.0) | !(p < INFINITY);
+          const int ex = (__double2hiint(p) >> 20) & 0x7ff;
+          const double mu = __hiloint2double((2046 - ex) << 20, 0);       // 2^-(ex - 1023)
+          const double sgp = sigma * p;
+          if (lane == c) sp = sgp;
+          sigma = sgp * mu;
+          const double pm = p * mu, am = a[c] * mu;
 #pragma unroll
-          for (int c2 = c + 1; c2 < 6; ++c2) a[c2] = fma(-a[c], lane_bcast(a[c], c2), a[c2]);
+          for (int c2 = c + 1; c2 < 6; ++c2) a[c2] = fma(pm, a[c2], -(am * lane_bcast(a[c], c2)));
         }
-        if (!bad && rv) {
+        const double f = rsqrt_cubic(sp);             // lane c < 6: 1 / sqrt(sigma_c p_c)
+        bad = bad | !(lane_bcast(sigma, 0) < INFINITY);
+        if (bad) {
+          if (lane == 0) sflag[0] = c0 + 1;
+        } else if (rv) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) Sm[i * kResSLd + c0 + c] = a[c];
+          for (int c = 0; c < 6; ++c) Sm[i * kResSLd + c0 + c] = a[c] * lane_bcast(f, c);
         }
       }
       RES_CSTAMP(3);
@@ -657,7 +676,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < kResWaves; ++w) s += red[kResWaves * 64 + w];
-      res_st(myrec + kResRecScal + 2, s);
+      res_st(myrec + res_misc_at(kResMiscScal + 2), s);
     }
     RES_STAMP(7);
     // ---- exchange 2: the cost of the trial set
@@ -668,7 +687,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
     for (int g0 = 0; g0 < G; g0 += 8) {
       double cv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) cv[u] = res_ld(A.xb + (size_t)min(g0 + u, G - 1) * kResRec + kResRecScal + 2);
+      for (int u = 0; u < 8; ++u) cv[u] = res_ld(A.xb + (size_t)min(g0 + u, G - 1) * kResRec + res_misc_at(kResMiscScal + 2));
 #pragma unroll
       for (int u = 0; u < 8; ++u) next_cost += g0 + u < G ? cv[u] : 0.0;
     }
