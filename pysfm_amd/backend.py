@@ -148,7 +148,10 @@ class HipBackend(object):
         torch = self._torch
         dev = torch.device('cuda', self.device)
         nS, nb = max(1, self.S_doubles), max(1, self.nco * 6)
-        self._Sb_t = torch.empty(nS + nb, dtype=torch.float64, device=dev)   # [S | b]: one collective
+        # (the sliding-window caller sets problem after problem of one shape: the same tensor serves them all)
+        if getattr(self, '_Sb_shape', None) != (nS, nb):
+            self._Sb_t = torch.empty(nS + nb, dtype=torch.float64, device=dev)   # [S | b]: one collective
+            self._Sb_shape = (nS, nb)
         self._S_t, self._b_t = self._Sb_t[:nS], self._Sb_t[nS:]
         self._check(self._lib.ba_bind_reduced_buffers(self._h, C.c_void_p(self._S_t.data_ptr()),
                                                       C.c_void_p(self._b_t.data_ptr())))

@@ -88,6 +88,66 @@ class Track(object):
     __str__ = __repr__
 
 
+class _Cameras(list):
+    """`Bundle.cameras` over stacked pose arrays: a list whose Camera objects are made on first access.  clone_params of a
+    hundred cameras is two array copies instead of two hundred, and the sliding-window caller, which clones the bundle
+    twice per frame and touches ten cameras of it, pays for those ten.  A Camera that has been handed out is the truth
+    from then on (its R / t may be replaced or edited in place): stacked() reads it back."""
+
+    def __init__(self, R, t):
+        list.__init__(self, [None] * len(R))
+        self._R, self._t = R, t            # poses of the entries that are still None
+
+    def _make(self, i):
+        k = Camera.__new__(Camera)        # (no validation: rows of arrays that were validated when they came in)
+        k.idx, k.R, k.t = i, self._R[i].copy(), self._t[i].copy()
+        list.__setitem__(self, i, k)
+        return k
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        c = list.__getitem__(self, i)
+        if c is None:
+            c = self._make(i if i >= 0 else i + len(self))
+        return c
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __reversed__(self):
+        for i in range(len(self) - 1, -1, -1):
+            yield self[i]
+
+    def stacked(self):
+        """(R [n,3,3], t [n,3]) of all cameras, new arrays."""
+        n = len(self)
+        R, t = np.empty((n, 3, 3)), np.empty((n, 3))
+        m = min(n, len(self._R))
+        R[:m], t[:m] = self._R[:m], self._t[:m]
+        for i, c in enumerate(list.__iter__(self)):
+            if c is not None:
+                R[i], t[i] = c.R, c.t
+        return R, t
+
+    def poses(self, ids):
+        """(R, t) of the cameras `ids` without making objects for them."""
+        get = list.__getitem__
+        if len(self) > len(self._R):                      # (cameras appended since: they have no row)
+            R, t = self.stacked()
+            return R[ids], t[ids]
+        R, t = self._R[ids], self._t[ids]                 # (fancy indexing: copies)
+        for pos, i in enumerate(ids):
+            c = get(self, int(i))
+            if c is not None:
+                R[pos], t[pos] = c.R, c.t
+        return R, t
+
+    def __reduce_ex__(self, protocol):
+        return (list, (list(self),))                      # copies and pickles are plain lists of Camera objects
+
+
 class _LazyTracks(object):
     """Sequence of Track views over a CSR observation table (array-native bundles)."""
 
@@ -146,9 +206,10 @@ class Bundle(object):
             assert cam.min() >= 0 and cam.max() < len(self.cameras), \
                 'There are %d cameras but a track has a measurement for camera %d' % \
                 (len(self.cameras), int(cam.max() if cam.max() >= len(self.cameras) else cam.min()))
-        for camera in self.cameras:
-            assert camera.R.shape == (3, 3)
-            assert camera.t.shape == (3,)
+        for camera in (list.__iter__(self.cameras) if isinstance(self.cameras, _Cameras) else self.cameras):
+            if camera is not None:                           # (cameras nobody has touched are rows of validated arrays)
+                assert camera.R.shape == (3, 3)
+                assert camera.t.shape == (3,)
 
     # ------------------------------------------------------------------ building
     def add_camera(self, camera=None):
@@ -187,8 +248,7 @@ class Bundle(object):
         assert measurement_mask.shape == measurements.shape[:-1]
         b = cls()
         b.K = K.copy()
-        for R, t in zip(Rs, ts):
-            b.add_camera(Camera(R.copy(), t.copy()))
+        b.cameras = _Cameras(Rs.copy(), ts.copy())
         for j in range(measurements.shape[1]):
             camera_ids = np.nonzero(measurement_mask[:, j])[0].tolist()
             b.tracks.append(Track(camera_ids, measurements[camera_ids, j]))
@@ -203,8 +263,7 @@ class Bundle(object):
         b.K = np.array(K, float)
         Rs, ts = np.asarray(Rs, float), np.asarray(ts, float)
         assert Rs.shape[1:] == (3, 3) and ts.shape == (len(Rs), 3)
-        for R, t in zip(Rs, ts):
-            b.add_camera(Camera(R.copy(), t.copy()))
+        b.cameras = _Cameras(Rs.copy(), ts.copy())
         b.reconstruction = np.array(pts, float)
         nt = len(b.reconstruction)
         obs_cam = np.asarray(obs_cam, np.int64)
@@ -294,9 +353,13 @@ class Bundle(object):
         return ci[order].astype(np.int32), ti[order].astype(np.int32), np.ascontiguousarray(zz[order])
 
     def Rs(self):
+        if isinstance(self.cameras, _Cameras):
+            return self.cameras.stacked()[0]
         return np.array([cam.R for cam in self.cameras])
 
     def ts(self):
+        if isinstance(self.cameras, _Cameras):
+            return self.cameras.stacked()[1]
         return np.array([cam.t for cam in self.cameras])
 
     def projection_matrices(self):
@@ -389,15 +452,11 @@ class Bundle(object):
         """Deep-copy cameras and points, share tracks and sensor model (bundle.py:301-310)."""
         b = Bundle()
         b.K = self.K.copy()
-        # (no validation on the way: the copies of valid cameras are valid - 18 000 Camera.__init__ calls were a fifth of the
-        # sliding-window caller's wall-clock)
-        new = Camera.__new__
-        cams = []
-        for c in self.cameras:
-            k = new(Camera)
-            k.idx, k.R, k.t = c.idx, c.R.copy(), c.t.copy()
-            cams.append(k)
-        b.cameras = cams
+        if isinstance(self.cameras, _Cameras):
+            b.cameras = _Cameras(*self.cameras.stacked())
+        else:
+            b.cameras = _Cameras(np.array([c.R for c in self.cameras], float).reshape(-1, 3, 3),
+                                 np.array([c.t for c in self.cameras], float).reshape(-1, 3))
         b.reconstruction = self.reconstruction.copy()
         b.tracks = self.tracks
         b._table = self._table

@@ -171,8 +171,12 @@ class BundleAdjuster(object):
             self._upload(b, PARAMS_CUR)
 
     def _params_of(self, bundle):
-        R = np.array([bundle.cameras[i].R for i in self.camera_ids], float).reshape(-1, 3, 3)
-        t = np.array([bundle.cameras[i].t for i in self.camera_ids], float).reshape(-1, 3)
+        poses = getattr(bundle.cameras, 'poses', None)
+        if poses is not None:
+            R, t = poses(self.camera_ids)
+        else:
+            R = np.array([bundle.cameras[i].R for i in self.camera_ids], float).reshape(-1, 3, 3)
+            t = np.array([bundle.cameras[i].t for i in self.camera_ids], float).reshape(-1, 3)
         X = np.asarray(bundle.reconstruction, float)
         X = (X if self._all_tracks else X[self._track_ids_arr]).reshape(-1, 3)
         return R, t, X

@@ -62,6 +62,7 @@ struct Options {
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
   bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
   bool device_lu = true;           // a reduced system the Cholesky solve reports as not positive definite is solved again by the cyclic reduction with LU nodes
+  bool host_setup = true;          // ba_set_problem: small problems are ordered on the host (off: always the device pipeline)
   bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
@@ -155,6 +156,8 @@ struct ba_handle {
     size_t host_bytes = 0;
     void* up = nullptr;                // pinned arena for the small uploads
     size_t up_bytes = 0, up_used = 0;
+    bool up_pending = false;           // uploads from the arena may still be in flight
+    bool up_pageable = false;          // something did not fit the arena: the caller's memory is read until the stream is idle
   } su;
 
   // parameters: cams[which] = nc x [R(9) | t(3)], X[which] = nt x 3

@@ -41,6 +41,7 @@ constexpr size_t kArenaBytes = 8u << 20, kArenaMaxItem = 2u << 20;
 void arena_reset(ba_handle* h) {
   auto& su = h->su;
   if (!su.up && hipHostMalloc(&su.up, kArenaBytes, hipHostMallocDefault) == hipSuccess) su.up_bytes = kArenaBytes;
+  if (su.up_pending) { (void)hipStreamSynchronize(h->stream); su.up_pending = false; }      // (a small problem leaves without waiting for its uploads)
   su.up_used = 0;
 }
 hipError_t stage_h2d(ba_handle* h, void* dst, const void* src, size_t bytes) {
@@ -51,8 +52,126 @@ hipError_t stage_h2d(ba_handle* h, void* dst, const void* src, size_t bytes) {
     std::memcpy(p, src, bytes);
     su.up_used += aligned;
     src = p;
+  } else {
+    su.up_pageable = true;                       // (the caller's memory must outlive the copy: synchronise before returning)
   }
   return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+}
+
+
+// ---- ba_set_problem's front end for SMALL problems, on the host.  The device pipeline (a dozen launches, a radix sort, two
+// synchronisations) costs 0.2 ms whatever the size; the sliding-window caller sets a problem of a thousand observations per
+// frame, where the same work is a few microseconds of one core.  Same decisions, same internal order (the track key is the
+// one of k_setup_track_keys, bit for bit), same staging layout for the planning code that follows.
+constexpr long long kHostFrontMaxObs = 8192;
+
+int host_front_end(ba_handle* h, int nc, int nt, long long N, int nco, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_z,
+                   const int32_t* cam_opt_pos, const uint8_t* pt_opt, const std::vector<int>& crank, int rank_bits, int* hflags, int* hoff,
+                   int* hplo, int* hphi, int* hperm, unsigned char* same) {
+  typedef unsigned long long u64;
+  for (int i = 0; i < SF_COUNT; ++i) hflags[i] = (i == SF_BAD || i == SF_DUP) ? 0x7fffffff : 0;
+  std::vector<u64> key((size_t)N);
+  std::vector<int> cnt((size_t)nt + 1, 0), by((size_t)N);
+  bool unsorted = false;
+  for (long long n = 0; n < N; ++n) {
+    const int c = obs_cam[n], k = obs_pt[n];
+    if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%d]=%d out of range", (int)n, c);
+    if (k < 0 || k >= nt) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%d]=%d out of range", (int)n, k);
+    key[n] = ((u64)k << rank_bits) | (u64)crank[c];
+    ++cnt[k];
+    if (n > 0 && key[n - 1] > key[n]) unsorted = true;
+    by[n] = (int)n;
+  }
+  if (unsorted) std::stable_sort(by.begin(), by.end(), [&](int a, int b) { return key[a] < key[b]; });
+  for (long long q = 1; q < N; ++q)
+    if (key[by[q]] == key[by[q - 1]])
+      return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in one camera", (int)(key[by[q]] >> rank_bits));
+  std::vector<int> coff((size_t)nt + 1, 0);
+  for (int k = 0; k < nt; ++k) coff[(size_t)k + 1] = coff[k] + cnt[k];
+  // the tracks' order: (first optimised position, hash of the camera-rank list), stable
+  std::vector<int> pperm((size_t)nt);
+  for (int k = 0; k < nt; ++k) pperm[k] = k;
+  if (nt > 1) {
+    std::vector<u64> tkey((size_t)nt);
+    for (int k = 0; k < nt; ++k) {
+      const int b = coff[k], e = coff[(size_t)k + 1];
+      u64 hsh = 0x9E3779B97F4A7C15ull ^ (u64)(e - b);
+      int minpos = nco;
+      for (int q = b; q < e; ++q) {
+        const int c = obs_cam[by[q]];
+        const int p = cam_opt_pos[c];
+        if (p >= 0 && p < minpos) minpos = p;
+        hsh ^= (u64)crank[c] + 0x9E3779B97F4A7C15ull + (hsh << 6) + (hsh >> 2);
+        hsh *= 0xD6E8FEB86659FD93ull;
+      }
+      hsh ^= hsh >> 32;
+      tkey[k] = ((u64)minpos << 32) | (hsh & 0xffffffffull);
+    }
+    std::vector<int> sorted(pperm);
+    std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) { return tkey[a] < tkey[b]; });
+    bool desc = false;
+    int runs_orig = 0, runs_sorted = 0;
+    for (int i = 1; i < nt; ++i) {
+      if ((tkey[i] >> 32) < (tkey[i - 1] >> 32)) desc = true;
+      runs_orig += tkey[i] != tkey[i - 1];
+      runs_sorted += tkey[sorted[i]] != tkey[sorted[i - 1]];
+    }
+    hflags[SF_DESC] = desc; hflags[SF_RUNS_ORIG] = runs_orig; hflags[SF_RUNS_SORTED] = runs_sorted;
+    if (desc || runs_orig != runs_sorted) {          // the caller's order is not as good as the sorted one
+      pperm.swap(sorted);
+      for (int i = 0; i < nt; ++i) if (pperm[i] != i) hflags[SF_PERM] = 1;
+    }
+  }
+  // the internal arrays and the per-point summaries
+  std::vector<int> icam((size_t)N), ipt((size_t)N), operm((size_t)N);
+  std::vector<double> iz((size_t)2 * N);
+  std::vector<unsigned char> iopt((size_t)nt);
+  hoff[0] = 0;
+  int maxL = 0, hbw = 0;
+  for (int i = 0; i < nt; ++i) {
+    const int k = pperm[i], src = coff[k], L = cnt[k], dst = hoff[i];
+    hoff[i + 1] = dst + L;
+    hperm[i] = k;
+    iopt[i] = pt_opt[k];
+    int lo = 0x7fffffff, hi = -1;
+    bool asc = true;
+    for (int q = 0; q < L; ++q) {
+      const int n = by[(size_t)src + q];
+      operm[(size_t)dst + q] = n;
+      icam[(size_t)dst + q] = obs_cam[n];
+      ipt[(size_t)dst + q] = i;
+      iz[2 * ((size_t)dst + q)] = obs_z[2 * (size_t)n]; iz[2 * ((size_t)dst + q) + 1] = obs_z[2 * (size_t)n + 1];
+      if (n != dst + q) hflags[SF_OPERM] = 1;
+      const int p = cam_opt_pos[obs_cam[n]];
+      if (p < 0) continue;
+      if (p <= hi) asc = false;
+      lo = std::min(lo, p); hi = std::max(hi, p);
+    }
+    hplo[i] = lo; hphi[i] = hi;
+    if (hi >= 0) hbw = std::max(hbw, hi - lo);
+    if (!asc) hflags[SF_NOT_ASC] = 1;
+    maxL = std::max(maxL, L);
+    bool sm = false;
+    if (i > 0) {
+      const int pb = hoff[i - 1];
+      sm = dst - pb == L;
+      for (int q = 0; sm && q < L; ++q) sm = icam[(size_t)pb + q] == icam[(size_t)dst + q];
+    }
+    same[i] = sm ? 1 : 0;
+  }
+  hflags[SF_MAXL] = maxL; hflags[SF_HB] = hbw;
+  if (N) {
+    HIPCHECK(h, stage_h2d(h, h->obs_cam.p, icam.data(), (size_t)N * sizeof(int)));
+    HIPCHECK(h, stage_h2d(h, h->obs_pt.p, ipt.data(), (size_t)N * sizeof(int)));
+    HIPCHECK(h, stage_h2d(h, h->obs_z.p, iz.data(), (size_t)N * sizeof(double2)));
+    HIPCHECK(h, stage_h2d(h, h->d_operm.p, operm.data(), (size_t)N * sizeof(int)));
+  }
+  HIPCHECK(h, stage_h2d(h, h->pt_off.p, hoff, ((size_t)nt + 1) * sizeof(int)));
+  if (nt) {
+    HIPCHECK(h, stage_h2d(h, h->pt_opt.p, iopt.data(), (size_t)nt));
+    HIPCHECK(h, stage_h2d(h, h->d_pperm.p, hperm, (size_t)nt * sizeof(int)));
+  }
+  return BA_OK;
 }
 
 }  // namespace
@@ -194,16 +313,27 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   const size_t staging = ((size_t)3 * nt + 8) * sizeof(int) + (size_t)nt + SF_COUNT * sizeof(int) + (size_t)nt * sizeof(int) + 64;
   HIPCHECK(h, pinned_staging(h, staging));
   arena_reset(h);
+  su.up_pageable = false;
+  if (nc) HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
+  HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
+  int* hflags = static_cast<int*>(su.host);
+  int* hoff = hflags + SF_COUNT;
+  int* hplo = hoff + nt + 2;
+  int* hphi = hplo + nt;
+  int* hperm = hphi + nt;
+  unsigned char* same = reinterpret_cast<unsigned char*>(hperm + nt);
+  const unsigned long long* sorted_keys = nullptr;
+  const bool host_front = sort_points && N <= kHostFrontMaxObs && h->opt.host_setup;
+  if (host_front) {
+    const int rc = host_front_end(h, nc, nt, N, nco, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, crank, rank_bits, hflags, hoff, hplo, hphi, hperm, same);
+    if (rc != BA_OK) return rc;
+  } else {
   if (N) {
     HIPCHECK(h, stage_h2d(h, su.rc.p, obs_cam, (size_t)N * sizeof(int)));
     HIPCHECK(h, stage_h2d(h, su.rp.p, obs_pt, (size_t)N * sizeof(int)));
     HIPCHECK(h, stage_h2d(h, su.rz.p, obs_z, (size_t)N * sizeof(double2)));
   }
-  if (nc) {
-    HIPCHECK(h, stage_h2d(h, su.crank.p, crank.data(), (size_t)nc * sizeof(int)));
-    HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
-  }
-  HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
+  if (nc) HIPCHECK(h, stage_h2d(h, su.crank.p, crank.data(), (size_t)nc * sizeof(int)));
   if (nt) HIPCHECK(h, stage_h2d(h, su.rpo.p, pt_opt, (size_t)nt));
   HIPCHECK(h, hipMemsetAsync(su.cnt.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
   HIPCHECK(h, hipMemsetAsync(su.Lint.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
@@ -211,7 +341,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   // ---- validate, count per track, and find out whether the observations already come ordered by (track, camera rank)
   if (N) hipLaunchKernelGGL(k_setup_keys, dim3(grid_for(N)), dim3(256), 0, h->stream, N, nc, nt, su.rc.p, su.rp.p, su.crank.p, rank_bits,
                             su.key.p, su.cnt.p, su.flags.p);
-  int* hflags = static_cast<int*>(su.host);
   HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));        // (obs_cam / obs_pt / obs_z / pt_opt are caller memory: not read after this point)
   if (hflags[SF_BAD] != 0x7fffffff) {
@@ -221,7 +350,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   }
   // ---- order by (track, rank): a stable radix sort of (key, index) pairs, only if needed
   const int* by_pt = nullptr;                        // position in the sorted order -> caller's observation index (nullptr: identity)
-  const unsigned long long* sorted_keys = su.key.p;
+  sorted_keys = su.key.p;
   if (hflags[SF_UNSORTED]) {
     HIPCHECK(h, su.key2.resize((size_t)N)); HIPCHECK(h, su.vals.resize((size_t)N)); HIPCHECK(h, su.by_pt.resize((size_t)N));
     hipLaunchKernelGGL(k_iota, dim3(grid_for(N)), dim3(256), 0, h->stream, (int)N, su.vals.p);
@@ -260,11 +389,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   }
   HIPCHECK(h, hipGetLastError());
   // ---- the per-point summaries come back: everything below is O(points)
-  int* hoff = hflags + SF_COUNT;
-  int* hplo = hoff + nt + 2;
-  int* hphi = hplo + nt;
-  int* hperm = hphi + nt;
-  unsigned char* same = reinterpret_cast<unsigned char*>(hperm + nt);
   HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipMemcpyAsync(hoff, h->pt_off.p, ((size_t)nt + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (nt) {
@@ -275,6 +399,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   arena_reset(h);                                    // (everything uploaded so far has arrived)
+  }
   const int* flags = hflags;
   if (flags[SF_DUP] != 0x7fffffff) {                 // each (camera, track) pair at most once (bundle.py: a dict per track)
     unsigned long long key = 0;
@@ -719,7 +844,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->have_params[0] = h->have_params[1] = false;
   h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
   h->cur = 0;
-  HIPCHECK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
+  // host vectors go out of scope: what went through the pinned arena needs no wait (the next arena_reset waits if it must)
+  if (su.up_pageable) HIPCHECK(h, hipStreamSynchronize(h->stream));
+  else su.up_pending = true;
   return BA_OK;
 }
 
