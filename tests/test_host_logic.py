@@ -617,3 +617,96 @@ def test_a_caller_defined_sensor_model_is_sampled_into_a_table():
         sensor_model.device_params_of(Anisotropic(.05))
     with pytest.raises(TypeError, match='no device form'):
         sensor_model.device_params_of(object())
+
+
+# ------------------------------------------------------------------ the loop taken on the device, replayed from its log
+class _ResidentDouble(OracleBackend):
+    """OracleBackend + the two entry points of the resident loop (backend.lm_resident_fits / lm_resident), with the schedule of
+    csrc/ba_resident.h restated in Python: runs trials until done, until its log is full (`capacity`), or until it meets a
+    trial it refuses (`refuse`: indices of trials, counted over the whole run, that end the launch with exit reason 2)."""
+
+    def __init__(self, capacity=1000, refuse=()):
+        OracleBackend.__init__(self)
+        self.capacity, self.refuse, self.seen, self.launches = capacity, set(refuse), 0, 0
+
+    def lm_resident_fits(self):
+        return True
+
+    def lm_resident(self, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, rcond, cur_cost):
+        from types import SimpleNamespace
+        self.launches += 1
+        log = SimpleNamespace(ntrials=0, nsteps=steps_taken, converged=int(bool(converged)), in_step=int(bool(in_step)), exit_reason=0,
+                              exit_info=0, accepted=0, have_cost0=0, damping=damping, cost0=0., cur_cost=-1. if cur_cost is None else cur_cost,
+                              trial_damping=[], trial_cost=[], trial_accepted=[])
+        while True:
+            if not log.in_step:
+                if log.converged or log.nsteps >= max_steps:
+                    break
+                log.nsteps += 1
+                log.in_step = 1
+            if log.converged or not (log.damping < 1e+8):
+                log.in_step = 0
+                continue
+            if log.ntrials >= self.capacity:
+                log.exit_reason = 1
+                break
+            if not log.have_cost0:
+                log.cost0, log.have_cost0 = self.cost(0), 1
+                if log.cur_cost < 0:
+                    log.cur_cost = log.cost0
+            if self.seen in self.refuse:
+                self.refuse.discard(self.seen)
+                log.exit_reason, log.exit_info = 2, 7
+                break
+            self.seen += 1
+            self.linearize(0); self.schur(0, log.damping, rcond); self.solve_reduced(None)
+            self.backsubstitute(0, fetch=False); self.apply_update(0, 1)
+            cost = self.cost(1)
+            acc = cost < log.cur_cost
+            log.trial_damping.append(log.damping); log.trial_cost.append(cost); log.trial_accepted.append(int(acc))
+            log.ntrials += 1
+            if acc:
+                self.swap_params()
+                log.damping *= .1
+                log.converged = int(abs(log.cur_cost - cost) < improvement_threshold)
+                log.cur_cost, log.accepted, log.in_step = cost, 1, 0
+            else:
+                log.damping *= 10.
+                log.converged = int(log.damping > 1e+8)
+        return log
+
+
+@pytest.mark.parametrize('name,steps', [('scene_4x10_cauchy', 10), ('scene_5x50_gauss', 5), ('scene_planar_lm', 50)])
+@pytest.mark.parametrize('capacity,refuse', [(1000, ()), (3, ()), (1000, (0, 4, 5)), (2, (1, 6))])
+def test_the_log_of_the_resident_loop_replays_into_the_reference_walk(name, steps, capacity, refuse):
+    g = load_golden(name)
+    plain = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    plain.optimize(max_steps=steps)
+    be = _ResidentDouble(capacity, refuse)
+    ba = BundleAdjuster(bundle_of(g), backend=be, verbose=False)
+    ba.optimize(max_steps=steps)
+    assert be.launches >= (2 if refuse or capacity < 5 else 1)
+    assert (ba.num_steps, ba.converged, ba.lm_trials) == (plain.num_steps, plain.converged, plain.lm_trials)
+    assert ba.num_steps == int(g['lm_num_steps']) and ba.converged == bool(g['lm_converged'])
+    assert [(d, o) for d, o, _ in ba.trial_log] == [(d, o) for d, o, _ in plain.trial_log]
+    close(ba.costs, plain.costs, 1e-12)
+    close(ba.costs, g['lm_costs'], 1e-6)
+    assert ba._damping == plain._damping
+    close(ba.bundle.reconstruction, plain.bundle.reconstruction, 1e-12)
+    # step by step, the same walk
+    be2 = _ResidentDouble(capacity, refuse)
+    st = BundleAdjuster(bundle_of(g), backend=be2, verbose=False)
+    st.num_steps, st.converged, st.costs, st.trial_log, st.lm_trials, st._damping, st._cur_cost = 0, False, [], [], 0, 10., None
+    while not st.converged and st.num_steps < steps:
+        st.step()
+    assert st.trial_log == ba.trial_log and st.costs == ba.costs and st.num_steps == ba.num_steps
+    # a parameter mask, a switched-off loop: the Python loop
+    off = BundleAdjuster(bundle_of(g), backend=_ResidentDouble(), verbose=False)
+    off.resident = False
+    off.optimize(max_steps=2)
+    assert off.backend.launches == 0
+    masked = BundleAdjuster(bundle_of(g), backend=_ResidentDouble(), verbose=False)
+    m = np.ones(masked.num_optim_params() if hasattr(masked, 'num_optim_params') else len(masked.optim_camera_ids) * 6 + len(masked.optim_track_ids) * 3, bool)
+    m[2] = False
+    masked.optimize(param_mask=m, max_steps=2)
+    assert masked.backend.launches == 0
