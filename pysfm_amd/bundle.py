@@ -316,6 +316,23 @@ class Bundle(object):
         if everything(cids, len(self.cameras)) and everything(tids, len(self.tracks)):
             # all cameras x all tracks in their own order (BundleAdjuster(bundle) without ids): the table as it is
             return np.ascontiguousarray(cam, np.int32), np.ascontiguousarray(trk, np.int32), np.ascontiguousarray(z, float)
+        if (self._table is not None and len(cids) and len(tids) and len(trk) and int(cids[-1]) - int(cids[0]) + 1 == len(cids)
+                and ascending(cids)):
+            # a window of consecutive cameras over an array-native bundle (window_slam.py:17-48: frame after frame): the table
+            # is sorted by (track, camera), so what a track contributes is ONE stretch of its rows - two binary searches per
+            # track instead of a pass over every row of the selected tracks
+            nc_all = max(len(self.cameras), 1)
+            key = getattr(self, '_table_key', None)
+            if key is None or len(key) != len(trk):
+                key = self._table_key = trk.astype(np.int64) * nc_all + cam
+            base = tids * nc_all
+            lo = np.searchsorted(key, base + int(cids[0]), 'left')
+            hi = np.searchsorted(key, base + int(cids[-1]), 'right')
+            cnt = hi - lo
+            total = int(cnt.sum())
+            rows = np.repeat(lo - (np.cumsum(cnt) - cnt), cnt) + np.arange(total)
+            return ((cam[rows] - int(cids[0])).astype(np.int32), np.repeat(np.arange(len(tids), dtype=np.int32), cnt),
+                    np.ascontiguousarray(z[rows]))
         cpos = -np.ones(max(len(self.cameras), 1), np.int64)
         cpos[cids] = np.arange(len(cids))
         if len(tids) * 4 < len(self.tracks) and len(trk):
@@ -450,7 +467,7 @@ class Bundle(object):
     # ------------------------------------------------------------------ copies / transforms
     def clone_params(self):
         """Deep-copy cameras and points, share tracks and sensor model (bundle.py:301-310)."""
-        b = Bundle()
+        b = Bundle.__new__(Bundle)                        # (not __init__: it builds a default sensor model only to drop it)
         b.K = self.K.copy()
         if isinstance(self.cameras, _Cameras):
             b.cameras = _Cameras(*self.cameras.stacked())
@@ -460,6 +477,9 @@ class Bundle(object):
         b.reconstruction = self.reconstruction.copy()
         b.tracks = self.tracks
         b._table = self._table
+        for name in ('_table_key', '_track_offsets'):      # (what was derived from the immutable table travels with it)
+            if name in self.__dict__:
+                b.__dict__[name] = self.__dict__[name]
         b.sensor_model = self.sensor_model
         return b
 

@@ -540,8 +540,13 @@ def test_few_of_many_tracks_after_an_edit_of_the_track_objects():
     # an array-native bundle (immutable table) still caches its offsets
     t = Bundle.FromObservations(np.eye(3), [np.eye(3)] * 3, np.zeros((3, 3)), np.ones((12, 3)),
                                 [0, 2] * 12, np.repeat(np.arange(12), 2), np.zeros((24, 2)))
-    t.select_observations([0, 1, 2], [1, 5])
+    c_w, t_w, _ = t.select_observations([0, 1, 2], [1, 5])                 # a window of consecutive cameras: binary searches in the table's key
+    assert c_w.tolist() == [0, 2, 0, 2] and t_w.tolist() == [0, 0, 1, 1]
+    assert getattr(t, '_table_key', None) is not None and getattr(b, '_table_key', None) is None
+    c_s, t_s, _ = t.select_observations([2, 0], [1, 5])                    # any other camera list: the tracks' rows
+    assert c_s.tolist() == [0, 1, 0, 1] and t_s.tolist() == [0, 0, 1, 1]      # (positions in the camera list, the list's order)
     assert getattr(t, '_track_offsets', None) is not None and getattr(b, '_track_offsets', None) is None
+    assert t.clone_params().__dict__.get('_table_key') is t._table_key
 
 
 def test_a_timed_out_solve_survives_the_sum_over_the_ranks():
