@@ -98,7 +98,7 @@ struct ResidentArgs {
 
 // LDS carve-up of a workgroup
 struct ResidentLds {
-  int cam, X, HPP, Hinv, HCC, Dk, red, misc, part, dC, z, stage;     // offsets in doubles
+  int cam, X, HPP, Hinv, HCC, Dk, red, misc, dC, z, stage;     // offsets in doubles
   int flag_i, off_i, pos_i, tab_b, opt_b, oc_b;                // offsets in bytes
   size_t bytes;
 };
@@ -113,7 +113,6 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.Dk = o; o += 2 * kResK;                       // D | y
   l.red = o; o += kResWaves * 64 + 16;            // partial right-hand sides [waves][64], wavefront partials
   l.misc = o; o += kResMisc;                   // the summed right-hand side | camera blocks | scalars
-  l.part = o; o += (kResWaves - 1) * 6 * 64;      // the factorisation's partial sums of wavefronts 1 .. 3
   l.dC = o; o += 64;
   l.z = o; o += 2 * kResP * maxL;                 // the measurements of my points
   l.stage = o;
@@ -166,6 +165,34 @@ __device__ __forceinline__ bool res_wait_all(const long long* words, int stride,
   return res_uniform(*timed_out) == 0;
 }
 
+// Block column J of the factorisation, rows r0 + (0 .. 15): S[row][6 J + c] -= sum over m < 6 J of L[row][m] L[6 J + c][m] on the
+// matrix cores (a 16 x 16 tile of which six columns are wanted).  J is a template parameter: the number of k steps and the
+// lanes of the last, partial one are known to the compiler - no load under a condition, no branch.
+template <int J>
+__device__ __forceinline__ void res_update_block_column(double* __restrict__ Sm, int r0, int n, int ln, int lk) {
+  constexpr int c0 = 6 * J, KS = (c0 + 3) / 4;
+  const double* ar = Sm + min(r0 + ln, n) * kResSLd + lk;
+  const double* br = Sm + min(c0 + ln, n) * kResSLd + lk;
+  double av[KS], bv[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; }
+  if (c0 % 4 != 0) {                              // entries at k >= c0 are not factors yet: zeros in their place (not times zero)
+    const bool in = 4 * (KS - 1) + lk < c0;
+    av[KS - 1] = in ? av[KS - 1] : 0.0;
+    bv[KS - 1] = in ? bv[KS - 1] : 0.0;
+  }
+  res_acc acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+  if (ln < 6) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = r0 + lk + 4 * v;
+      if (row <= n && c0 + ln <= row) Sm[row * kResSLd + c0 + ln] -= acc[v];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -183,7 +210,6 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   double* red = sm + lo.red;
   double* dCl = sm + lo.dC;
   double* miscL = sm + lo.misc;
-  double* part = sm + lo.part;
   double* At = sm + lo.stage;
   double* JC = At + kResK * kResLd;
   double* Sm = sm + lo.stage;                      // aliases At / JC: used after the reduction only
@@ -517,31 +543,22 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       const int i = c0 + lane;
       const bool rv = i <= n;
       RES_CSTAMP(0);
-      double up[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (J > 0) {
-        // S[i][c0 + c] -= sum over m < c0 of L[i][m] L[c0 + c][m]: my share of the m (m = wave, wave + 4, ...), four per round trip
-        const double* ri = Sm + (rv ? i : 0) * kResSLd;
-        for (int m0 = wave; m0 < c0; m0 += 4 * kResWaves) {
-          double li[4], lc[4][6];
-          // (every load unconditional, at a clamped position: a load under a uniform condition becomes a branch, and a dozen
-          //  of them a maze of branches that costs more than the loads)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int m = m0 + u * kResWaves;
-            const int mc = min(m, c0 - 1);
-            li[u] = ri[mc] * (m < c0 ? 1.0 : 0.0);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) lc[u][c] = Sm[(c0 + c) * kResSLd + mc];
+        // S[i][c0 + c] -= sum over m < c0 of L[i][m] L[c0 + c][m] on the matrix cores: wavefront w takes the rows c0 + 16 w ..
+        // (res_update_block_column)
+        const int r0 = c0 + 16 * wave;
+        if (r0 <= n) {
+          switch (J) {
+            case 1: res_update_block_column<1>(Sm, r0, n, ln, lk); break;
+            case 2: res_update_block_column<2>(Sm, r0, n, ln, lk); break;
+            case 3: res_update_block_column<3>(Sm, r0, n, ln, lk); break;
+            case 4: res_update_block_column<4>(Sm, r0, n, ln, lk); break;
+            case 5: res_update_block_column<5>(Sm, r0, n, ln, lk); break;
+            case 6: res_update_block_column<6>(Sm, r0, n, ln, lk); break;
+            case 7: res_update_block_column<7>(Sm, r0, n, ln, lk); break;
+            case 8: res_update_block_column<8>(Sm, r0, n, ln, lk); break;
+            default: res_update_block_column<9>(Sm, r0, n, ln, lk); break;
           }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) up[c] = fma(li[u], lc[u][c], up[c]);
-        }
-        if (wave > 0) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) part[((wave - 1) * 6 + c) * 64 + lane] = up[c];
         }
         RES_CSTAMP(1);
         lds_barrier();
@@ -551,14 +568,6 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
         double a[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) a[c] = Sm[min(i, n) * kResSLd + c0 + c];
-        if (J > 0) {
-          double pr[18];
-#pragma unroll
-          for (int q = 0; q < 18; ++q) pr[q] = part[q * 64 + lane];
-          __builtin_amdgcn_sched_barrier(0);          // (every load in flight before the first sum: one round trip, not nine)
-#pragma unroll
-          for (int c = 0; c < 6; ++c) a[c] -= ((up[c] + pr[c]) + pr[6 + c]) + pr[12 + c];
-        }
         // The pivot chain without a division on it: step c multiplies the rest of the block by the pivot instead of dividing the
         // column by it, a' = (p mu) a - (a_c mu) l with mu = 2^-exponent(p) (exact), so that after step c every entry carries
         // the factor sigma_{c+1} = sigma_c p mu (within 2^6 of 1); column c of L is a_c / sqrt(sigma_c p), formed at the end by
