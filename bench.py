@@ -366,6 +366,45 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     return out
 
 
+def small_problems():
+    """The reference's own scale: BASELINE configs[0] (5 cameras x 50 tracks) and the sliding-window caller (window_slam.py:17-48,
+    one 10-camera x 100-track problem per frame, 91 frames).  At this size optimize() is ONE resident launch
+    (pysfm_amd/csrc/ba_resident.h); `python_loop` is the same call with the loop over ba_lm_trial in Python."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model, synthetic_data as sd, window_slam
+    out = {}
+    s = sd.generate_banded_scene(5, 50, track_len=5, init_perturbation=.03)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=sensor_model.GaussianModel(1.))
+    for name, resident in (('resident', True), ('python_loop', False)):
+        ba = BundleAdjuster(verbose=False)
+        ba.resident = resident
+        ba.set_bundle(b)
+        ba.optimize()
+        t0 = time.time()
+        for _ in range(20):
+            ba.set_bundle(b)
+            ba.optimize()
+            _ = ba.bundle
+        out['config1_set_bundle_optimize_bundle_s_' + name] = (time.time() - t0) / 20
+        out['config1_lm_trials'] = int(ba.lm_trials)
+        ba.backend.close()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'scene_oleg_100x1000.npz')
+    if os.path.exists(path):
+        g = np.load(path)
+        wb = Bundle.FromObservations(g['K'], g['R'].reshape(-1, 3, 3), g['t'], g['X'], g['obs_cam'], g['obs_pt'], g['obs_z'],
+                                     sensor_model=sensor_model.GaussianModel(1.))
+        try:
+            for name, resident in (('resident', True), ('python_loop', False)):
+                BundleAdjuster.resident = resident
+                window_slam.run(wb, 10, num_tracks=100, max_steps=3, verbose=False)
+                t0 = time.time()
+                _, hist = window_slam.run(wb, 10, num_tracks=100, verbose=False)
+                out['window_slam_91_windows_10x100_s_' + name] = time.time() - t0
+                out['window_slam_accepted_steps'] = int(sum(len(h) for h in hist) - len(hist))
+        finally:
+            BundleAdjuster.resident = True
+    return out
+
+
 def live_pmc_traffic(argv, kernels, timeout_s=150):
     """`roofline.traffic` measured in THIS run: two rocprofv3 passes of this same command (`--pmc FETCH_SIZE`, then
     `--pmc WRITE_SIZE`: the two do not fit one pass; counters only, no trace domains), a few trials each, and per kernel
@@ -814,6 +853,10 @@ def main():
                     oc[spec[0]] = {'error': repr(e)}
             oc['wall_s'] = time.time() - t_oc
             out['other_configs'] = oc
+            try:
+                out['small_problems'] = small_problems()
+            except Exception as e:
+                out['small_problems'] = {'error': repr(e)}
         if ngpus == 1 and not args.no_cpu_baseline:
             if nc <= 1500 and nt <= 150000:
                 out['cpu_baseline'] = cpu_baseline(s)
