@@ -6,6 +6,6 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/r04c
 python scripts/resident_check.py > gpurun_out/r04c/resident_check.txt 2>&1
 python scripts/window_slam_profile.py --profile > gpurun_out/r04c/window_slam_profile.txt 2>&1
-( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/r04c/prof" -o slam -- python "$OLDPWD/scripts/window_slam_profile.py" ) > gpurun_out/r04c/rocprof.log 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/r04c/prof" -o slam -- python "$OLDPWD/scripts/window_slam_profile.py" ) > gpurun_out/r04c/rocprof.log 2>&1
 find gpurun_out/r04c/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04c/kernel_stats.csv \;
 ls -la gpurun_out/r04c
