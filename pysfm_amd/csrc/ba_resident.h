@@ -165,33 +165,61 @@ __device__ __forceinline__ bool res_wait_all(const long long* words, int stride,
   return res_uniform(*timed_out) == 0;
 }
 
-// Block column J of the factorisation, rows r0 + (0 .. 15): S[row][6 J + c] -= sum over m < 6 J of L[row][m] L[6 J + c][m] on the
-// matrix cores (a 16 x 16 tile of which six columns are wanted).  J is a template parameter: the number of k steps and the
-// lanes of the last, partial one are known to the compiler - no load under a condition, no branch.
-template <int J>
-__device__ __forceinline__ void res_update_block_column(double* __restrict__ Sm, int r0, int n, int ln, int lk) {
-  constexpr int c0 = 6 * J, KS = (c0 + 3) / 4;
-  const double* ar = Sm + min(r0 + ln, n) * kResSLd + lk;
-  const double* br = Sm + min(c0 + ln, n) * kResSLd + lk;
+// Block column JT of the factorisation, row tile `tile` (rows 6 JT + 16 tile ..): S[row][6 JT + c] -= sum over K0 <= m < K1 of
+// L[row][m] L[6 JT + c][m] on the matrix cores (a 16 x 16 tile of which six columns are wanted).  Template parameters: the
+// number of k steps and the lanes of the partial ones are known to the compiler - no load under a condition, no branch.
+template <int JT, int K0, int K1>
+__device__ __forceinline__ void res_update_cols(double* __restrict__ Sm, int tile, int n, int ln, int lk) {
+  constexpr int c0 = 6 * JT, S0 = K0 / 4, S1 = (K1 + 3) / 4, KS = S1 - S0;
+  const int r0 = c0 + 16 * tile;
+  if (r0 > n) return;                             // (uniform: a wavefront takes one tile)
+  const double* ar = Sm + min(r0 + ln, n) * kResSLd + 4 * S0 + lk;
+  const double* br = Sm + min(c0 + ln, n) * kResSLd + 4 * S0 + lk;
   double av[KS], bv[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; }
-  if (c0 % 4 != 0) {                              // entries at k >= c0 are not factors yet: zeros in their place (not times zero)
-    const bool in = 4 * (KS - 1) + lk < c0;
-    av[KS - 1] = in ? av[KS - 1] : 0.0;
-    bv[KS - 1] = in ? bv[KS - 1] : 0.0;
+  // entries outside [K0, K1) are other panels' (or not factors yet, or never written): zeros in their place, not times zero
+  if (K0 % 4 != 0) {
+    const bool in = 4 * S0 + lk >= K0;
+    av[0] = in ? av[0] : 0.0; bv[0] = in ? bv[0] : 0.0;
   }
-  res_acc acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
-  if (ln < 6) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = r0 + lk + 4 * v;
-      if (row <= n && c0 + ln <= row) Sm[row * kResSLd + c0 + ln] -= acc[v];
-    }
+  if (K1 % 4 != 0) {
+    const bool in = 4 * (S1 - 1) + lk < K1;
+    av[KS - 1] = in ? av[KS - 1] : 0.0; bv[KS - 1] = in ? bv[KS - 1] : 0.0;
   }
+  // the accumulator starts as the tile of S itself (its loads travel with the operands'), the products come off it: one LDS
+  // round trip instead of read - wait - subtract - write
+  res_acc acc;
+  bool wr[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = r0 + lk + 4 * v;
+    wr[v] = ln < 6 && row <= n && c0 + ln <= row;
+    acc[v] = Sm[min(row, n) * kResSLd + c0 + min(ln, 5)];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], -bv[ks], acc, 0, 0, 0);
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    if (wr[v]) Sm[(r0 + lk + 4 * v) * kResSLd + c0 + ln] = acc[v];
 }
+// what block column J + 1 gets from the columns left of panel J (while panel J is being factorised) ...
+template <int J>
+__device__ __forceinline__ void res_update_ahead(double* __restrict__ Sm, int tile, int n, int ln, int lk) {
+  if constexpr (J >= 1) res_update_cols<J + 1, 0, 6 * J>(Sm, tile, n, ln, lk);
+}
+// ... and from panel J itself
+template <int J>
+__device__ __forceinline__ void res_update_panel(double* __restrict__ Sm, int tile, int n, int ln, int lk) {
+  res_update_cols<J + 1, 6 * J, 6 * J + 6>(Sm, tile, n, ln, lk);
+}
+#define RES_SWITCH_J(fn, ...)                                                                 \
+  switch (J) {                                                                                \
+    case 0: fn<0>(__VA_ARGS__); break; case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; \
+    case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; case 5: fn<5>(__VA_ARGS__); break; \
+    case 6: fn<6>(__VA_ARGS__); break; case 7: fn<7>(__VA_ARGS__); break; default: fn<8>(__VA_ARGS__); break; \
+  }
 
 __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -535,33 +563,18 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       for (int i = tid; i < (n + 1) * kResSLd; i += kResThreads) A.dbg[i] = Sm[i];
     RES_STAMP(4);
 
-    // ---- Cholesky by block columns of one camera; row n = the right-hand side (becomes L^-1 b).  lane = row of the block
-    //      column (row c0 + lane), wavefront = a quarter of the columns left of it
+    // ---- Cholesky by block columns of one camera; row n = the right-hand side (becomes L^-1 b)
 #define RES_CSTAMP(k) do { if (A.trace && grp == 0 && tid == 0 && ntrials == 0) A.trace[(32 + J) * 16 + (k)] = (long long)clock64(); } while (0)
     for (int J = 0; J < nco; ++J) {
       const int c0 = 6 * J;
       const int i = c0 + lane;
       const bool rv = i <= n;
       RES_CSTAMP(0);
-      if (J > 0) {
-        // S[i][c0 + c] -= sum over m < c0 of L[i][m] L[c0 + c][m] on the matrix cores: wavefront w takes the rows c0 + 16 w ..
-        // (res_update_block_column)
-        const int r0 = c0 + 16 * wave;
-        if (r0 <= n) {
-          switch (J) {
-            case 1: res_update_block_column<1>(Sm, r0, n, ln, lk); break;
-            case 2: res_update_block_column<2>(Sm, r0, n, ln, lk); break;
-            case 3: res_update_block_column<3>(Sm, r0, n, ln, lk); break;
-            case 4: res_update_block_column<4>(Sm, r0, n, ln, lk); break;
-            case 5: res_update_block_column<5>(Sm, r0, n, ln, lk); break;
-            case 6: res_update_block_column<6>(Sm, r0, n, ln, lk); break;
-            case 7: res_update_block_column<7>(Sm, r0, n, ln, lk); break;
-            case 8: res_update_block_column<8>(Sm, r0, n, ln, lk); break;
-            default: res_update_block_column<9>(Sm, r0, n, ln, lk); break;
-          }
-        }
-        RES_CSTAMP(1);
-        lds_barrier();
+      // While wavefront 0 runs the pivot chain of panel J, the others give block column J + 1 what the columns left of the
+      // panel owe it (tiles 0 .. 3 over wavefronts 1, 2, 3, 1); the panel's own share follows the chain.
+      if (wave > 0 && J >= 1 && J + 1 < nco) {
+        RES_SWITCH_J(res_update_ahead, Sm, wave - 1, n, ln, lk);
+        if (wave == 1) RES_SWITCH_J(res_update_ahead, Sm, 3, n, ln, lk);
       }
       RES_CSTAMP(2);
       if (wave == 0) {
@@ -600,6 +613,11 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       lds_barrier();
       RES_CSTAMP(4);
       if (res_uniform(sflag[0])) break;
+      if (J + 1 < nco) {
+        RES_SWITCH_J(res_update_panel, Sm, wave, n, ln, lk);
+        lds_barrier();
+      }
+      RES_CSTAMP(5);
     }
     if (res_uniform(sflag[0])) { exit_reason = RES_NOT_POSITIVE_DEFINITE; exit_info = res_uniform(sflag[0]); break; }
     RES_STAMP(5);
