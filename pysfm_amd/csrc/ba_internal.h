@@ -146,6 +146,10 @@ struct ba_handle {
   bool operm_identity = true;
   // per internal point, kept on the host for the work lists that are built lazily: CSR offsets, lowest / highest optimised position
   std::vector<int> h_off, h_plo, h_phi;
+  std::vector<unsigned char> h_same;   // point i has the camera list of point i - 1
+  std::vector<int> h_cam_opt_pos;      // the caller's cam_opt_pos
+  std::vector<int> plan_flags;         // the set-up's status record (SF_* of ba_setup_kernels.h)
+  bool plan_pending = false;           // the work lists of the general kernels are not built yet (ensure_plan)
   // ba_set_problem's own device buffers (kept between calls: the sliding-window caller sets a problem per window)
   struct Setup {
     DevBuf<int> rc, rp, by_pt, cnt, coff, Lint, plo, phi, iota, crank, flags, vals;
@@ -322,6 +326,8 @@ int launch_rect(ba_handle* h, int p, double damping, bool fuse_cam);
 hipError_t sort_pairs_u64(ba_handle* h, const unsigned long long* keys_in, unsigned long long* keys_out, const int* values_in,
                           int* values_out, size_t n, int end_bit);
 hipError_t exclusive_scan_i32(ba_handle* h, const int* in, int* out, size_t n);
+int ensure_plan(ba_handle* h);             // groups / chunks / windows of the general kernels, if ba_set_problem left them for later
+bool resident_shape(const ba_handle* h);   // the problem's shape fits the resident loop (ba_resident.h)
 int ensure_cam_units(ba_handle* h);        // cam_perm / cam_units of k_camera_blocks
 int ensure_pair_units(ba_handle* h);       // units / chunks of k_schur_pairs
 // host rows (caller's order) -> device rows (internal order) and back; perm = h->d_pperm.p / h->d_operm.p or nullptr (identity)

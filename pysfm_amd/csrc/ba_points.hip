@@ -45,6 +45,7 @@ int launch_camera_blocks(ba_handle* h, int p, bool clear) {
 
 // ba_linearize; with fuse (ba_lm_trial + a matrix-core reduction) the camera blocks are left to the reduction kernel
 int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double damping, double rcond) {
+  { const int rc = ensure_plan(h); if (rc != BA_OK) return rc; }
   const int p = h->phys(which);
   HIPCHECK(h, hipSetDevice(h->device));
   double* Wd = nullptr;
@@ -200,6 +201,7 @@ int ba_get_blocks(ba_handle* h, double* HCC, double* bC, double* HPP, double* bP
 }
 
 int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
+  if (h) { const int rc = ensure_plan(h); if (rc != BA_OK) return rc; }
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_backsubstitute: bad parameter set");
   const int p = h->phys(which);

@@ -260,176 +260,21 @@ int ensure_pair_units(ba_handle* h) {
   return BA_OK;
 }
 
-}  // namespace ba
 
-extern "C" {
-
-int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
-                   const int32_t* obs_pt, const double* obs_z, const double* K,
-                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
-  if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
-  REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
-  REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
-          "ba_set_problem: NULL argument");
-  REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
-  HIPCHECK(h, hipSetDevice(h->device));
-  h->have_problem = false;
-
-  // ---- cameras (host, O(nc)): optimised-camera positions must be a permutation of 0..nco-1; the RANK of a camera orders a
-  // track's observations: frozen cameras by index, then the optimised ones by position
-  int nco = 0;
-  for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) ++nco;
-  std::vector<int> crank((size_t)std::max(1, nc)), opt_cam((size_t)std::max(1, nco), 0);
-  {
-    std::vector<char> seen((size_t)nco, 0);
-    int f = 0;
-    const int nfrozen = nc - nco;
-    for (int i = 0; i < nc; ++i) {
-      const int p = cam_opt_pos[i];
-      if (p < 0) { crank[i] = f++; continue; }
-      if (p >= nco || seen[p]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: cam_opt_pos is not a permutation of 0..nco-1");
-      seen[p] = 1;
-      crank[i] = nfrozen + p;
-      opt_cam[p] = i;
-    }
-  }
-  const bool sort_points = h->opt.sort_points;
-  const long long N = nobs;
-  auto& su = h->su;
-  const int rank_bits = bits_for((unsigned long long)std::max(1, nc)), track_bits = bits_for((unsigned long long)std::max(1, nt));
-
-  // ---- the caller's arrays to the device
-  HIPCHECK(h, su.rc.resize(std::max<size_t>(1, N))); HIPCHECK(h, su.rp.resize(std::max<size_t>(1, N))); HIPCHECK(h, su.rz.resize(std::max<size_t>(1, N)));
-  HIPCHECK(h, su.key.resize(std::max<size_t>(1, N)));
-  HIPCHECK(h, su.cnt.resize((size_t)nt + 2)); HIPCHECK(h, su.coff.resize((size_t)nt + 2)); HIPCHECK(h, su.Lint.resize((size_t)nt + 2));
-  HIPCHECK(h, su.crank.resize(crank.size())); HIPCHECK(h, su.rpo.resize(std::max(1, nt))); HIPCHECK(h, su.flags.resize(SF_COUNT));
-  HIPCHECK(h, su.plo.resize(std::max(1, nt))); HIPCHECK(h, su.phi.resize(std::max(1, nt))); HIPCHECK(h, su.same.resize(std::max(1, nt)));
-  HIPCHECK(h, su.tkey.resize(std::max(1, nt))); HIPCHECK(h, su.tkey2.resize(std::max(1, nt))); HIPCHECK(h, su.iota.resize(std::max(1, nt)));
-  HIPCHECK(h, h->d_pperm.resize(std::max(1, nt))); HIPCHECK(h, h->d_operm.resize(std::max<size_t>(1, N)));
-  HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, N)));
-  HIPCHECK(h, h->pt_off.resize((size_t)nt + 2)); HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc))); HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
-  HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
-  const size_t staging = ((size_t)3 * nt + 8) * sizeof(int) + (size_t)nt + SF_COUNT * sizeof(int) + (size_t)nt * sizeof(int) + 64;
-  HIPCHECK(h, pinned_staging(h, staging));
-  arena_reset(h);
-  su.up_pageable = false;
-  if (nc) HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
-  HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
-  int* hflags = static_cast<int*>(su.host);
-  int* hoff = hflags + SF_COUNT;
-  int* hplo = hoff + nt + 2;
-  int* hphi = hplo + nt;
-  int* hperm = hphi + nt;
-  unsigned char* same = reinterpret_cast<unsigned char*>(hperm + nt);
-  const unsigned long long* sorted_keys = nullptr;
-  const bool host_front = sort_points && N <= kHostFrontMaxObs && h->opt.host_setup;
-  if (host_front) {
-    const int rc = host_front_end(h, nc, nt, N, nco, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, crank, rank_bits, hflags, hoff, hplo, hphi, hperm, same);
-    if (rc != BA_OK) return rc;
-  } else {
-  if (N) {
-    HIPCHECK(h, stage_h2d(h, su.rc.p, obs_cam, (size_t)N * sizeof(int)));
-    HIPCHECK(h, stage_h2d(h, su.rp.p, obs_pt, (size_t)N * sizeof(int)));
-    HIPCHECK(h, stage_h2d(h, su.rz.p, obs_z, (size_t)N * sizeof(double2)));
-  }
-  if (nc) HIPCHECK(h, stage_h2d(h, su.crank.p, crank.data(), (size_t)nc * sizeof(int)));
-  if (nt) HIPCHECK(h, stage_h2d(h, su.rpo.p, pt_opt, (size_t)nt));
-  HIPCHECK(h, hipMemsetAsync(su.cnt.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
-  HIPCHECK(h, hipMemsetAsync(su.Lint.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
-  hipLaunchKernelGGL(k_setup_init, dim3(1), dim3(256), 0, h->stream, su.flags.p);
-  // ---- validate, count per track, and find out whether the observations already come ordered by (track, camera rank)
-  if (N) hipLaunchKernelGGL(k_setup_keys, dim3(grid_for(N)), dim3(256), 0, h->stream, N, nc, nt, su.rc.p, su.rp.p, su.crank.p, rank_bits,
-                            su.key.p, su.cnt.p, su.flags.p);
-  HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));        // (obs_cam / obs_pt / obs_z / pt_opt are caller memory: not read after this point)
-  if (hflags[SF_BAD] != 0x7fffffff) {
-    const int n = hflags[SF_BAD], c = obs_cam[n], k = obs_pt[n];
-    if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%d]=%d out of range", n, c);
-    return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%d]=%d out of range", n, k);
-  }
-  // ---- order by (track, rank): a stable radix sort of (key, index) pairs, only if needed
-  const int* by_pt = nullptr;                        // position in the sorted order -> caller's observation index (nullptr: identity)
-  sorted_keys = su.key.p;
-  if (hflags[SF_UNSORTED]) {
-    HIPCHECK(h, su.key2.resize((size_t)N)); HIPCHECK(h, su.vals.resize((size_t)N)); HIPCHECK(h, su.by_pt.resize((size_t)N));
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(N)), dim3(256), 0, h->stream, (int)N, su.vals.p);
-    HIPCHECK(h, sort_pairs_u64(h, su.key.p, su.key2.p, su.vals.p, su.by_pt.p, (size_t)N, rank_bits + track_bits));
-    hipLaunchKernelGGL(k_setup_dups, dim3(grid_for(N)), dim3(256), 0, h->stream, N, su.key2.p, su.flags.p);
-    sorted_keys = su.key2.p;
-    if (sort_points) {
-      by_pt = su.by_pt.p;
-    } else if (hflags[SF_UNSORTED_PT]) {
-      // without the internal sort a track keeps its observations in the caller's order: grouped by track, nothing else
-      hipLaunchKernelGGL(k_setup_track_keys_only, dim3(grid_for(N)), dim3(256), 0, h->stream, N, su.rp.p, su.key.p);
-      HIPCHECK(h, sort_pairs_u64(h, su.key.p, su.key2.p, su.vals.p, su.by_pt.p, (size_t)N, track_bits));
-      by_pt = su.by_pt.p;
-      sorted_keys = nullptr;                         // (the duplicate's key is gone: the message names no track)
-    }
-  }
-  // ---- CSR by caller track, the tracks' order, CSR in that order, the internal arrays
-  HIPCHECK(h, exclusive_scan_i32(h, su.cnt.p, su.coff.p, (size_t)nt + 1));
-  if (nt) {
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.iota.p);
-    if (sort_points && nt > 1) {
-      hipLaunchKernelGGL(k_setup_track_keys, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, nco, su.coff.p, by_pt, su.rc.p, h->cam_opt_pos.p,
-                         su.crank.p, su.tkey.p);
-      HIPCHECK(h, sort_pairs_u64(h, su.tkey.p, su.tkey2.p, su.iota.p, h->d_pperm.p, (size_t)nt, 32 + bits_for((unsigned long long)nco + 1)));
-      hipLaunchKernelGGL(k_setup_order_check, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.tkey.p, su.tkey2.p, su.flags.p);
-    }
-    hipLaunchKernelGGL(k_setup_choose_order, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, (sort_points && nt > 1) ? 0 : 1, h->d_pperm.p,
-                       su.cnt.p, su.Lint.p, su.flags.p);
-  }
-  HIPCHECK(h, exclusive_scan_i32(h, su.Lint.p, h->pt_off.p, (size_t)nt + 1));
-  if (nt) {
-    hipLaunchKernelGGL(k_setup_gather, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->d_pperm.p, su.coff.p, h->pt_off.p, by_pt, su.rc.p,
-                       su.rz.p, su.rpo.p, h->obs_cam.p, h->obs_pt.p, h->obs_z.p, h->d_operm.p, h->pt_opt.p, su.flags.p);
-    hipLaunchKernelGGL(k_setup_point_summary, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->pt_off.p, h->obs_cam.p, h->cam_opt_pos.p,
-                       su.plo.p, su.phi.p, su.same.p, su.flags.p);
-  }
-  HIPCHECK(h, hipGetLastError());
-  // ---- the per-point summaries come back: everything below is O(points)
-  HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(h, hipMemcpyAsync(hoff, h->pt_off.p, ((size_t)nt + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  if (nt) {
-    HIPCHECK(h, hipMemcpyAsync(hplo, su.plo.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(hphi, su.phi.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(hperm, h->d_pperm.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(same, su.same.p, (size_t)nt, hipMemcpyDeviceToHost, h->stream));
-  }
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
-  arena_reset(h);                                    // (everything uploaded so far has arrived)
-  }
-  const int* flags = hflags;
-  if (flags[SF_DUP] != 0x7fffffff) {                 // each (camera, track) pair at most once (bundle.py: a dict per track)
-    unsigned long long key = 0;
-    if (sorted_keys) {
-      HIPCHECK(h, hipMemcpy(&key, sorted_keys + flags[SF_DUP], sizeof key, hipMemcpyDeviceToHost));
-      return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in one camera", (int)(key >> rank_bits));
-    }
-    return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: a track has two observations in one camera");
-  }
-  h->h_off.assign(hoff, hoff + nt + 1);
-  h->h_plo.assign(hplo, hplo + nt);
-  h->h_phi.assign(hphi, hphi + nt);
-  if (flags[SF_PERM]) h->pperm.assign(hperm, hperm + nt); else h->pperm.clear();
-  h->operm_identity = flags[SF_OPERM] == 0;
+// ---- the work lists of the general kernels (groups, chunks, windows, segment pairs) from what ba_set_problem kept of the scene
+int ensure_plan(ba_handle* h) {
+  if (!h->plan_pending) return BA_OK;
+  const int nt = h->nt, nco = h->nco, hb = h->hb, wn = h->schur_wn;
+  const long long nobs = h->nobs, maxL = h->group_maxL;
   const int* off = h->h_off.data();
   const int* plo = h->h_plo.data();
   const int* phi = h->h_phi.data();
-  const long long maxL = flags[SF_MAXL];
-  long long nunits = 0;                              // work units of k_schur_pairs (built on first use: ensure_pair_units)
-  for (int k = 0; k < nt; ++k) {
-    const long long T = (off[(size_t)k + 1] - off[k] + kTile - 1) / kTile;
-    nunits += T * (T + 1) / 2;
-  }
-  // block half-bandwidth of the reduced system: widest spread of optimised-camera positions within one track
-  int hb = flags[SF_HB];
-  hb = std::max(hb, std::min(h->min_hb, std::max(0, nco - 1)));   // sharded adjuster: every rank uses the widest band
-  // LDS window of the older reduction kernels: wn band rows
-  int wn = (int)(kSchurTileBytes / (((size_t)(hb + 1) * 36 + 6) * sizeof(double)));
-  wn = std::min(wn, 64);
-  if (wn < hb + 2 || nco == 0) wn = 0;                 // band too wide for an LDS tile: global atomics only
+  const unsigned char* same = h->h_same.data();
+  const int* flags = h->plan_flags.data();
+  const int* cam_opt_pos = h->h_cam_opt_pos.data();
+  const int* obs_cam = nullptr;                   // (fetched from the device by the one branch that looks at observations)
+  (void)nobs; (void)hb; (void)nco; (void)plo; (void)obs_cam;
+  HIPCHECK(h, hipSetDevice(h->device));
   // Groups: runs of consecutive points (internal order) with identical observation lists.
   //   groups / gchunks   <= kGroupMaxPts points each: k_schur_groups (vector kernel, track length <= 15) and the
   //                      group-packed point kernels k_linearize_groups / k_backsub_groups (<= kGm3MaxL)
@@ -751,17 +596,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
       wgroups_worth = wgroups.empty() ? !rgroups.empty() : covered >= 12ll * (long long)wgroups.size();
     }
   }
-  // lanes per point: smallest power of two >= mean track length, in [1, 64]
-  int glog = 0;
-  const double meanL = nt > 0 ? (double)nobs / nt : 1.0;
-  while ((1 << glog) < meanL && glog < 6) ++glog;
-
-  h->nc = nc; h->nt = nt; h->nco = nco; h->hb = hb; h->nobs = nobs; h->glog = glog;
-  std::memcpy(h->K, K, sizeof h->K);
-  h->nunits = (int)std::min<long long>(nunits, INT32_MAX);
-  h->nchunks = 0;
-  h->pair_units_built = h->cam_units_built = false;
-  h->schur_wn = wn;
   h->ngchunks = (int)gchunks.size();
   h->nmchunks = (int)mchunks.size();
   h->nm3chunks = (int)m3chunks.size();
@@ -785,9 +619,6 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     h->point_groups = groups_worth && covered == nt;        // (points without observations are in no group)
   }
   h->group_rounds = group_rounds;
-  h->group_maxL = maxL;
-  h->ncam_units = 0;
-
   HIPCHECK(h, h->wide_list.resize(std::max<size_t>(1, wide_list.size())));
   if (!wide_list.empty())
     HIPCHECK(h, stage_h2d(h, h->wide_list.p, wide_list.data(), wide_list.size() * sizeof(int)));
@@ -821,6 +652,203 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     if (!gchunks.empty())
       HIPCHECK(h, stage_h2d(h, h->gchunks.p, gchunks.data(), gchunks.size() * sizeof(SchurChunk)));
   }
+  h->plan_pending = false;
+  if (h->su.up_pageable) { HIPCHECK(h, hipStreamSynchronize(h->stream)); h->su.up_pageable = false; }
+  else h->su.up_pending = true;
+  return BA_OK;
+}
+
+}  // namespace ba
+
+extern "C" {
+
+int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
+                   const int32_t* obs_pt, const double* obs_z, const double* K,
+                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
+  REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
+  REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
+          "ba_set_problem: NULL argument");
+  REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
+  HIPCHECK(h, hipSetDevice(h->device));
+  h->have_problem = false;
+
+  // ---- cameras (host, O(nc)): optimised-camera positions must be a permutation of 0..nco-1; the RANK of a camera orders a
+  // track's observations: frozen cameras by index, then the optimised ones by position
+  int nco = 0;
+  for (int i = 0; i < nc; ++i) if (cam_opt_pos[i] >= 0) ++nco;
+  std::vector<int> crank((size_t)std::max(1, nc)), opt_cam((size_t)std::max(1, nco), 0);
+  {
+    std::vector<char> seen((size_t)nco, 0);
+    int f = 0;
+    const int nfrozen = nc - nco;
+    for (int i = 0; i < nc; ++i) {
+      const int p = cam_opt_pos[i];
+      if (p < 0) { crank[i] = f++; continue; }
+      if (p >= nco || seen[p]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: cam_opt_pos is not a permutation of 0..nco-1");
+      seen[p] = 1;
+      crank[i] = nfrozen + p;
+      opt_cam[p] = i;
+    }
+  }
+  const bool sort_points = h->opt.sort_points;
+  const long long N = nobs;
+  auto& su = h->su;
+  const int rank_bits = bits_for((unsigned long long)std::max(1, nc)), track_bits = bits_for((unsigned long long)std::max(1, nt));
+
+  // ---- the caller's arrays to the device
+  HIPCHECK(h, su.rc.resize(std::max<size_t>(1, N))); HIPCHECK(h, su.rp.resize(std::max<size_t>(1, N))); HIPCHECK(h, su.rz.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, su.key.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, su.cnt.resize((size_t)nt + 2)); HIPCHECK(h, su.coff.resize((size_t)nt + 2)); HIPCHECK(h, su.Lint.resize((size_t)nt + 2));
+  HIPCHECK(h, su.crank.resize(crank.size())); HIPCHECK(h, su.rpo.resize(std::max(1, nt))); HIPCHECK(h, su.flags.resize(SF_COUNT));
+  HIPCHECK(h, su.plo.resize(std::max(1, nt))); HIPCHECK(h, su.phi.resize(std::max(1, nt))); HIPCHECK(h, su.same.resize(std::max(1, nt)));
+  HIPCHECK(h, su.tkey.resize(std::max(1, nt))); HIPCHECK(h, su.tkey2.resize(std::max(1, nt))); HIPCHECK(h, su.iota.resize(std::max(1, nt)));
+  HIPCHECK(h, h->d_pperm.resize(std::max(1, nt))); HIPCHECK(h, h->d_operm.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, N)));
+  HIPCHECK(h, h->pt_off.resize((size_t)nt + 2)); HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc))); HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
+  HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
+  const size_t staging = ((size_t)3 * nt + 8) * sizeof(int) + (size_t)nt + SF_COUNT * sizeof(int) + (size_t)nt * sizeof(int) + 64;
+  HIPCHECK(h, pinned_staging(h, staging));
+  arena_reset(h);
+  su.up_pageable = false;
+  if (nc) HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
+  HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
+  int* hflags = static_cast<int*>(su.host);
+  int* hoff = hflags + SF_COUNT;
+  int* hplo = hoff + nt + 2;
+  int* hphi = hplo + nt;
+  int* hperm = hphi + nt;
+  unsigned char* same = reinterpret_cast<unsigned char*>(hperm + nt);
+  const unsigned long long* sorted_keys = nullptr;
+  const bool host_front = sort_points && N <= kHostFrontMaxObs && h->opt.host_setup;
+  if (host_front) {
+    const int rc = host_front_end(h, nc, nt, N, nco, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, crank, rank_bits, hflags, hoff, hplo, hphi, hperm, same);
+    if (rc != BA_OK) return rc;
+  } else {
+  if (N) {
+    HIPCHECK(h, stage_h2d(h, su.rc.p, obs_cam, (size_t)N * sizeof(int)));
+    HIPCHECK(h, stage_h2d(h, su.rp.p, obs_pt, (size_t)N * sizeof(int)));
+    HIPCHECK(h, stage_h2d(h, su.rz.p, obs_z, (size_t)N * sizeof(double2)));
+  }
+  if (nc) HIPCHECK(h, stage_h2d(h, su.crank.p, crank.data(), (size_t)nc * sizeof(int)));
+  if (nt) HIPCHECK(h, stage_h2d(h, su.rpo.p, pt_opt, (size_t)nt));
+  HIPCHECK(h, hipMemsetAsync(su.cnt.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
+  HIPCHECK(h, hipMemsetAsync(su.Lint.p, 0, ((size_t)nt + 2) * sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_setup_init, dim3(1), dim3(256), 0, h->stream, su.flags.p);
+  // ---- validate, count per track, and find out whether the observations already come ordered by (track, camera rank)
+  if (N) hipLaunchKernelGGL(k_setup_keys, dim3(grid_for(N)), dim3(256), 0, h->stream, N, nc, nt, su.rc.p, su.rp.p, su.crank.p, rank_bits,
+                            su.key.p, su.cnt.p, su.flags.p);
+  HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));        // (obs_cam / obs_pt / obs_z / pt_opt are caller memory: not read after this point)
+  if (hflags[SF_BAD] != 0x7fffffff) {
+    const int n = hflags[SF_BAD], c = obs_cam[n], k = obs_pt[n];
+    if (c < 0 || c >= nc) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_cam[%d]=%d out of range", n, c);
+    return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: obs_pt[%d]=%d out of range", n, k);
+  }
+  // ---- order by (track, rank): a stable radix sort of (key, index) pairs, only if needed
+  const int* by_pt = nullptr;                        // position in the sorted order -> caller's observation index (nullptr: identity)
+  sorted_keys = su.key.p;
+  if (hflags[SF_UNSORTED]) {
+    HIPCHECK(h, su.key2.resize((size_t)N)); HIPCHECK(h, su.vals.resize((size_t)N)); HIPCHECK(h, su.by_pt.resize((size_t)N));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(N)), dim3(256), 0, h->stream, (int)N, su.vals.p);
+    HIPCHECK(h, sort_pairs_u64(h, su.key.p, su.key2.p, su.vals.p, su.by_pt.p, (size_t)N, rank_bits + track_bits));
+    hipLaunchKernelGGL(k_setup_dups, dim3(grid_for(N)), dim3(256), 0, h->stream, N, su.key2.p, su.flags.p);
+    sorted_keys = su.key2.p;
+    if (sort_points) {
+      by_pt = su.by_pt.p;
+    } else if (hflags[SF_UNSORTED_PT]) {
+      // without the internal sort a track keeps its observations in the caller's order: grouped by track, nothing else
+      hipLaunchKernelGGL(k_setup_track_keys_only, dim3(grid_for(N)), dim3(256), 0, h->stream, N, su.rp.p, su.key.p);
+      HIPCHECK(h, sort_pairs_u64(h, su.key.p, su.key2.p, su.vals.p, su.by_pt.p, (size_t)N, track_bits));
+      by_pt = su.by_pt.p;
+      sorted_keys = nullptr;                         // (the duplicate's key is gone: the message names no track)
+    }
+  }
+  // ---- CSR by caller track, the tracks' order, CSR in that order, the internal arrays
+  HIPCHECK(h, exclusive_scan_i32(h, su.cnt.p, su.coff.p, (size_t)nt + 1));
+  if (nt) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.iota.p);
+    if (sort_points && nt > 1) {
+      hipLaunchKernelGGL(k_setup_track_keys, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, nco, su.coff.p, by_pt, su.rc.p, h->cam_opt_pos.p,
+                         su.crank.p, su.tkey.p);
+      HIPCHECK(h, sort_pairs_u64(h, su.tkey.p, su.tkey2.p, su.iota.p, h->d_pperm.p, (size_t)nt, 32 + bits_for((unsigned long long)nco + 1)));
+      hipLaunchKernelGGL(k_setup_order_check, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.tkey.p, su.tkey2.p, su.flags.p);
+    }
+    hipLaunchKernelGGL(k_setup_choose_order, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, (sort_points && nt > 1) ? 0 : 1, h->d_pperm.p,
+                       su.cnt.p, su.Lint.p, su.flags.p);
+  }
+  HIPCHECK(h, exclusive_scan_i32(h, su.Lint.p, h->pt_off.p, (size_t)nt + 1));
+  if (nt) {
+    hipLaunchKernelGGL(k_setup_gather, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->d_pperm.p, su.coff.p, h->pt_off.p, by_pt, su.rc.p,
+                       su.rz.p, su.rpo.p, h->obs_cam.p, h->obs_pt.p, h->obs_z.p, h->d_operm.p, h->pt_opt.p, su.flags.p);
+    hipLaunchKernelGGL(k_setup_point_summary, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->pt_off.p, h->obs_cam.p, h->cam_opt_pos.p,
+                       su.plo.p, su.phi.p, su.same.p, su.flags.p);
+  }
+  HIPCHECK(h, hipGetLastError());
+  // ---- the per-point summaries come back: everything below is O(points)
+  HIPCHECK(h, hipMemcpyAsync(hflags, su.flags.p, SF_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(hoff, h->pt_off.p, ((size_t)nt + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (nt) {
+    HIPCHECK(h, hipMemcpyAsync(hplo, su.plo.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(hphi, su.phi.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(hperm, h->d_pperm.p, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(same, su.same.p, (size_t)nt, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  arena_reset(h);                                    // (everything uploaded so far has arrived)
+  }
+  const int* flags = hflags;
+  if (flags[SF_DUP] != 0x7fffffff) {                 // each (camera, track) pair at most once (bundle.py: a dict per track)
+    unsigned long long key = 0;
+    if (sorted_keys) {
+      HIPCHECK(h, hipMemcpy(&key, sorted_keys + flags[SF_DUP], sizeof key, hipMemcpyDeviceToHost));
+      return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: track %d has two observations in one camera", (int)(key >> rank_bits));
+    }
+    return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: a track has two observations in one camera");
+  }
+  h->h_off.assign(hoff, hoff + nt + 1);
+  h->h_plo.assign(hplo, hplo + nt);
+  h->h_phi.assign(hphi, hphi + nt);
+  if (flags[SF_PERM]) h->pperm.assign(hperm, hperm + nt); else h->pperm.clear();
+  h->operm_identity = flags[SF_OPERM] == 0;
+  const int* off = h->h_off.data();
+  const long long maxL = flags[SF_MAXL];
+  long long nunits = 0;                              // work units of k_schur_pairs (built on first use: ensure_pair_units)
+  for (int k = 0; k < nt; ++k) {
+    const long long T = (off[(size_t)k + 1] - off[k] + kTile - 1) / kTile;
+    nunits += T * (T + 1) / 2;
+  }
+  // block half-bandwidth of the reduced system: widest spread of optimised-camera positions within one track
+  int hb = flags[SF_HB];
+  hb = std::max(hb, std::min(h->min_hb, std::max(0, nco - 1)));   // sharded adjuster: every rank uses the widest band
+  // LDS window of the older reduction kernels: wn band rows
+  int wn = (int)(kSchurTileBytes / (((size_t)(hb + 1) * 36 + 6) * sizeof(double)));
+  wn = std::min(wn, 64);
+  if (wn < hb + 2 || nco == 0) wn = 0;                 // band too wide for an LDS tile: global atomics only
+  // lanes per point: smallest power of two >= mean track length, in [1, 64]
+  int glog = 0;
+  const double meanL = nt > 0 ? (double)nobs / nt : 1.0;
+  while ((1 << glog) < meanL && glog < 6) ++glog;
+
+  h->nc = nc; h->nt = nt; h->nco = nco; h->hb = hb; h->nobs = nobs; h->glog = glog;
+  std::memcpy(h->K, K, sizeof h->K);
+  h->nunits = (int)std::min<long long>(nunits, INT32_MAX);
+  h->nchunks = 0;
+  h->pair_units_built = h->cam_units_built = false;
+  h->schur_wn = wn;
+  h->group_maxL = maxL;
+  h->ncam_units = 0;
+  h->plan_flags.assign(flags, flags + SF_COUNT);
+  h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
+  h->h_same.assign(same, same + nt);
+  // The work lists of the general kernels: at once - or, for a problem the resident loop takes whole (ba_resident.h), when a
+  // general kernel first asks for them (ensure_plan): the sliding-window caller sets a problem per frame and never does
+  h->plan_pending = true;
+  if (!resident_shape(h)) {
+    const int rc = ensure_plan(h);
+    if (rc != BA_OK) return rc;
+  }
   for (int i = 0; i < 2; ++i) {
     HIPCHECK(h, h->cams[i].resize(std::max<size_t>(1, (size_t)nc * 12)));
     HIPCHECK(h, h->X[i].resize(std::max<size_t>(1, (size_t)nt * 3)));
@@ -852,6 +880,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
 
 
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
+  if (h && h->have_problem) { const int rc = ensure_plan(h); if (rc != BA_OK) return rc; }
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_problem_info: call ba_set_problem first");
   REQUIRE(h, out && n >= 1, BA_ERR_INVALID_ARG, "ba_problem_info: bad argument");

@@ -7,6 +7,19 @@ using namespace ba;
 static_assert(sizeof(ba_resident_log) == sizeof(ResidentLog), "the log of include/pysfm_ba.h and ba_resident.h must agree");
 static_assert(BA_RESIDENT_MAX_TRIALS == kResMaxTrials, "the log of include/pysfm_ba.h and ba_resident.h must agree");
 
+namespace ba {
+
+// the shape of the problem (not yet its sensor model or its communicator) fits the resident loop: ba_set_problem leaves the
+// work lists of the general kernels for later then (ensure_plan)
+bool resident_shape(const ba_handle* h) {
+  if (!h->opt.resident || h->comm) return false;
+  if (h->nco < 1 || h->nco > kResMaxNco || h->nc > kResMaxNc || h->nt < 1 || h->nt > kResMaxNt) return false;
+  if (h->group_maxL < 1 || h->group_maxL > kResMaxL || h->nobs < 1 || h->nobs > (1 << 20)) return false;
+  return resident_lds(h->nc, h->nco, h->group_maxL).bytes <= 157 * 1024;
+}
+
+}  // namespace ba
+
 namespace {
 
 bool resident_fits(const ba_handle* h, ResidentLds* lds_out) {

@@ -34,6 +34,7 @@ int pick_schur_kernel(const ba_handle* h) {
 extern "C" {
 
 int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
+  if (h) { const int rc = ensure_plan(h); if (rc != BA_OK) return rc; }
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_schur: bad parameter set");
   const int p = h->phys(which);

@@ -9,6 +9,7 @@ extern "C" {
 int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem && h->have_params[h->phys(BA_PARAMS_CUR)], BA_ERR_STATE, "ba_lm_trial: set problem and parameters first");
+  { const int rc = ensure_plan(h); if (rc != BA_OK) return rc; }
   h->defer = true;
   // with the MFMA reduction the camera blocks come out of the reduction itself: one launch and one pass
   // over the observations less
