@@ -34,7 +34,7 @@
 // fp64 throughout; every sum has a fixed order: results are reproducible run to run and identical in every workgroup.
 #pragma once
 
-#include "ba_device.h"
+#include "ba_bcr_blocks.h"     // the diagonal-block and panel routines of the cyclic reduction's nodes
 
 namespace ba {
 
@@ -98,7 +98,7 @@ struct ResidentArgs {
 
 // LDS carve-up of a workgroup
 struct ResidentLds {
-  int cam, X, HPP, Hinv, HCC, Dk, red, misc, dC, z, stage;     // offsets in doubles
+  int cam, X, HPP, Hinv, HCC, Dk, red, misc, dC, fact, z, stage;     // offsets in doubles
   int flag_i, off_i, pos_i, tab_b, opt_b, oc_b;                // offsets in bytes
   size_t bytes;
 };
@@ -114,6 +114,7 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.red = o; o += kResWaves * 64 + 16;            // partial right-hand sides [waves][64], wavefront partials
   l.misc = o; o += kResMisc;                   // the summed right-hand side | camera blocks | scalars
   l.dC = o; o += 64;
+  l.fact = o; o += 192 + kBcrIdtDoubles + 64;     // the factorisation: inverse of the diagonal block [16][12], identity table, 1 / diagonal
   l.z = o; o += 2 * kResP * maxL;                 // the measurements of my points
   l.stage = o;
   const int at = kResK * kResLd + kResP * maxL * kResJcLd;
@@ -165,60 +166,55 @@ __device__ __forceinline__ bool res_wait_all(const long long* words, int stride,
   return res_uniform(*timed_out) == 0;
 }
 
-// Block column JT of the factorisation, row tile `tile` (rows 6 JT + 16 tile ..): S[row][6 JT + c] -= sum over K0 <= m < K1 of
-// L[row][m] L[6 JT + c][m] on the matrix cores (a 16 x 16 tile of which six columns are wanted).  Template parameters: the
-// number of k steps and the lanes of the partial ones are known to the compiler - no load under a condition, no branch.
-template <int JT, int K0, int K1>
-__device__ __forceinline__ void res_update_cols(double* __restrict__ Sm, int tile, int n, int ln, int lk) {
-  constexpr int c0 = 6 * JT, S0 = K0 / 4, S1 = (K1 + 3) / 4, KS = S1 - S0;
-  const int r0 = c0 + 16 * tile;
+// Columns [C0, C0 + NW) of the factorisation (NW = 12, or 6 at the end), row tile `tile` (rows C0 + 16 tile ..):
+// S[row][C0 + c] -= sum over K0 <= m < K1 of L[row][m] L[C0 + c][m] on the matrix cores (a 16 x 16 tile of which NW columns are
+// wanted).  Template parameters: the k steps are known to the compiler - no load under a condition, no branch.  The accumulator
+// starts as the tile of S itself (its loads travel with the operands'), the products come off it: one LDS round trip.
+template <int K0, int K1, int C0, int NW>
+__device__ __forceinline__ void res_update_block(double* __restrict__ Sm, int tile, int n, int ln, int lk) {
+  static_assert(K0 % 4 == 0 && K1 % 4 == 0, "whole k steps");
+  constexpr int KS = (K1 - K0) / 4;
+  const int r0 = C0 + 16 * tile;
   if (r0 > n) return;                             // (uniform: a wavefront takes one tile)
-  const double* ar = Sm + min(r0 + ln, n) * kResSLd + 4 * S0 + lk;
-  const double* br = Sm + min(c0 + ln, n) * kResSLd + 4 * S0 + lk;
+  const double* ar = Sm + min(r0 + ln, n) * kResSLd + K0 + lk;
+  const double* br = Sm + min(C0 + ln, n) * kResSLd + K0 + lk;
   double av[KS], bv[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; }
-  // entries outside [K0, K1) are other panels' (or not factors yet, or never written): zeros in their place, not times zero
-  if (K0 % 4 != 0) {
-    const bool in = 4 * S0 + lk >= K0;
-    av[0] = in ? av[0] : 0.0; bv[0] = in ? bv[0] : 0.0;
-  }
-  if (K1 % 4 != 0) {
-    const bool in = 4 * (S1 - 1) + lk < K1;
-    av[KS - 1] = in ? av[KS - 1] : 0.0; bv[KS - 1] = in ? bv[KS - 1] : 0.0;
-  }
-  // the accumulator starts as the tile of S itself (its loads travel with the operands'), the products come off it: one LDS
-  // round trip instead of read - wait - subtract - write
   res_acc acc;
   bool wr[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int row = r0 + lk + 4 * v;
-    wr[v] = ln < 6 && row <= n && c0 + ln <= row;
-    acc[v] = Sm[min(row, n) * kResSLd + c0 + min(ln, 5)];
+    wr[v] = ln < NW && row <= n && C0 + ln <= row;
+    acc[v] = Sm[min(row, n) * kResSLd + C0 + min(ln, NW - 1)];
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], -bv[ks], acc, 0, 0, 0);
 #pragma unroll
   for (int v = 0; v < 4; ++v)
-    if (wr[v]) Sm[(r0 + lk + 4 * v) * kResSLd + c0 + ln] = acc[v];
+    if (wr[v]) Sm[(r0 + lk + 4 * v) * kResSLd + C0 + ln] = acc[v];
 }
-// what block column J + 1 gets from the columns left of panel J (while panel J is being factorised) ...
-template <int J>
-__device__ __forceinline__ void res_update_ahead(double* __restrict__ Sm, int tile, int n, int ln, int lk) {
-  if constexpr (J >= 1) res_update_cols<J + 1, 0, 6 * J>(Sm, tile, n, ln, lk);
+// step S of the factorisation (columns 12 S .. 12 S + 11): what the NEXT block of columns gets from the columns left of this
+// step's (while this step's diagonal block is being factorised) ...
+template <int S>
+__device__ __forceinline__ void res_update_ahead(double* __restrict__ Sm, int tile, int n, int nw, int ln, int lk) {
+  if constexpr (S >= 1) {
+    if (nw == 12) res_update_block<0, 12 * S, 12 * S + 12, 12>(Sm, tile, n, ln, lk);
+    else res_update_block<0, 12 * S, 12 * S + 12, 6>(Sm, tile, n, ln, lk);
+  }
 }
-// ... and from panel J itself
-template <int J>
-__device__ __forceinline__ void res_update_panel(double* __restrict__ Sm, int tile, int n, int ln, int lk) {
-  res_update_cols<J + 1, 6 * J, 6 * J + 6>(Sm, tile, n, ln, lk);
+// ... and from this step's own panel
+template <int S>
+__device__ __forceinline__ void res_update_panel(double* __restrict__ Sm, int tile, int n, int nw, int ln, int lk) {
+  if (nw == 12) res_update_block<12 * S, 12 * S + 12, 12 * S + 12, 12>(Sm, tile, n, ln, lk);
+  else res_update_block<12 * S, 12 * S + 12, 12 * S + 12, 6>(Sm, tile, n, ln, lk);
 }
-#define RES_SWITCH_J(fn, ...)                                                                 \
-  switch (J) {                                                                                \
+#define RES_SWITCH_STEP(fn, ...)                                                              \
+  switch (step) {                                                                             \
     case 0: fn<0>(__VA_ARGS__); break; case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; \
-    case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; case 5: fn<5>(__VA_ARGS__); break; \
-    case 6: fn<6>(__VA_ARGS__); break; case 7: fn<7>(__VA_ARGS__); break; default: fn<8>(__VA_ARGS__); break; \
+    default: fn<3>(__VA_ARGS__); break;                                                       \
   }
 
 __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
@@ -238,6 +234,9 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   double* red = sm + lo.red;
   double* dCl = sm + lo.dC;
   double* miscL = sm + lo.misc;
+  double* LiL = sm + lo.fact;
+  double* IdtL = LiL + 192;
+  double* dinvL = IdtL + kBcrIdtDoubles;
   double* At = sm + lo.stage;
   double* JC = At + kResK * kResLd;
   double* Sm = sm + lo.stage;                      // aliases At / JC: used after the reduction only
@@ -262,6 +261,8 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   for (int i = tid; i < kResP * nco; i += kResThreads) tabj[i] = -1;
   for (int i = tid; i < nob; i += kResThreads) { ocL[i] = (unsigned char)A.obs_cam[ob0 + i]; zL[i] = A.obs_z[ob0 + i]; }
   if (tid == 0) { sflag[0] = 0; sflag[1] = 0; }
+  if (tid < 192) LiL[tid] = 0.0;                  // (rows 12 .. 15 stay zero; a 6-column block leaves the rest of it alone)
+  bcr_identity_table(IdtL, tid);
   lds_barrier();
   for (int p = tid; p < np; p += kResThreads)
     for (int q = offL[p]; q < offL[p + 1]; ++q) {
@@ -563,61 +564,39 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       for (int i = tid; i < (n + 1) * kResSLd; i += kResThreads) A.dbg[i] = Sm[i];
     RES_STAMP(4);
 
-    // ---- Cholesky by block columns of one camera; row n = the right-hand side (becomes L^-1 b)
-#define RES_CSTAMP(k) do { if (A.trace && grp == 0 && tid == 0 && ntrials == 0) A.trace[(32 + J) * 16 + (k)] = (long long)clock64(); } while (0)
-    for (int J = 0; J < nco; ++J) {
-      const int c0 = 6 * J;
-      const int i = c0 + lane;
-      const bool rv = i <= n;
+    // ---- Cholesky in steps of 12 columns (two cameras; 6 at the end when the cameras are odd); row n = the right-hand side
+    //      (becomes L^-1 b).  The diagonal block and the panel below it are the cyclic reduction's (ba_bcr_blocks.h): the block
+    //      is factorised in one wavefront, a lane per column in every 16-lane row, every broadcast of the pivot chain fused
+    //      into its v_fmac_f64 (DPP row_newbcast) - 85 cycles per pivot, and the lanes left over carry the identity along, so
+    //      that the block's inverse comes out too; the panel is X = A L^-T on the matrix cores.  While wavefront 0 runs a
+    //      block's chain the others give the next block of columns what the columns left of this step owe it.
+#define RES_CSTAMP(k) do { if (A.trace && grp == 0 && tid == 0 && ntrials == 0) A.trace[(32 + step) * 16 + (k)] = (long long)clock64(); } while (0)
+    for (int step = 0; 12 * step < n; ++step) {
+      const int k0 = 12 * step, nbw = min(12, n - k0), kn = k0 + nbw;      // this step's columns [k0, kn), the next block from kn
+      const int nwn = min(12, n - kn);                                      // ... of nwn columns (0: this is the last step)
       RES_CSTAMP(0);
-      // While wavefront 0 runs the pivot chain of panel J, the others give block column J + 1 what the columns left of the
-      // panel owe it (tiles 0 .. 3 over wavefronts 1, 2, 3, 1); the panel's own share follows the chain.
-      if (wave > 0 && J >= 1 && J + 1 < nco) {
-        RES_SWITCH_J(res_update_ahead, Sm, wave - 1, n, ln, lk);
-        if (wave == 1) RES_SWITCH_J(res_update_ahead, Sm, 3, n, ln, lk);
+      if (wave == 0) {
+        if (nbw == 12) bcr_diag_block<12, true>(Sm, kResSLd, dinvL, sflag, k0, lane, LiL, IdtL);
+        else bcr_diag_block<6, true>(Sm, kResSLd, dinvL, sflag, k0, lane, LiL, IdtL);
+      } else if (nwn > 0) {
+        RES_SWITCH_STEP(res_update_ahead, Sm, wave - 1, n, nwn, ln, lk);
+        if (wave == 1) RES_SWITCH_STEP(res_update_ahead, Sm, 3, n, nwn, ln, lk);
+      }
+      RES_CSTAMP(1);
+      lds_barrier();
+      if (res_uniform(sflag[0])) break;
+      // the panel: rows kn .. n (the right-hand side among them), a tile of 16 per wavefront
+      {
+        double pr[3];
+        if (kn + 16 * wave <= n) bcr_panel_tile(Sm, kResSLd, n + 1, k0, kn + 16 * wave, LiL, ln, lk, pr, nbw);
       }
       RES_CSTAMP(2);
-      if (wave == 0) {
-        double a[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) a[c] = Sm[min(i, n) * kResSLd + c0 + c];
-        // The pivot chain without a division on it: step c multiplies the rest of the block by the pivot instead of dividing the
-        // column by it, a' = (p mu) a - (a_c mu) l with mu = 2^-exponent(p) (exact), so that after step c every entry carries
-        // the factor sigma_{c+1} = sigma_c p mu (within 2^6 of 1); column c of L is a_c / sqrt(sigma_c p), formed at the end by
-        // six independent 1 / sqrt in six lanes.  (One v_rsq + Newton per pivot ON the chain costs 310 cycles a pivot.)
-        double sigma = 1.0, sp = 1.0;
-        bool bad = false;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const double p = lane_bcast(a[c], c);
-          bad = bad | !(p > 0.0) | !(p < INFINITY);
-          const int ex = (__double2hiint(p) >> 20) & 0x7ff;
-          const double mu = __hiloint2double((2046 - ex) << 20, 0);       // 2^-(ex - 1023)
-          const double sgp = sigma * p;
-          if (lane == c) sp = sgp;
-          sigma = sgp * mu;
-          const double pm = p * mu, am = a[c] * mu;
-#pragma unroll
-          for (int c2 = c + 1; c2 < 6; ++c2) a[c2] = fma(pm, a[c2], -(am * lane_bcast(a[c], c2)));
-        }
-        const double f = rsqrt_cubic(sp);             // lane c < 6: 1 / sqrt(sigma_c p_c)
-        bad = bad | !(lane_bcast(sigma, 0) < INFINITY);
-        if (bad) {
-          if (lane == 0) sflag[0] = c0 + 1;
-        } else if (rv) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) Sm[i * kResSLd + c0 + c] = a[c] * lane_bcast(f, c);
-        }
-      }
-      RES_CSTAMP(3);
       lds_barrier();
-      RES_CSTAMP(4);
-      if (res_uniform(sflag[0])) break;
-      if (J + 1 < nco) {
-        RES_SWITCH_J(res_update_panel, Sm, wave, n, ln, lk);
+      if (nwn > 0) {
+        RES_SWITCH_STEP(res_update_panel, Sm, wave, n, nwn, ln, lk);
         lds_barrier();
       }
-      RES_CSTAMP(5);
+      RES_CSTAMP(3);
     }
     if (res_uniform(sflag[0])) { exit_reason = RES_NOT_POSITIVE_DEFINITE; exit_info = res_uniform(sflag[0]); break; }
     RES_STAMP(5);
@@ -625,7 +604,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
     if (wave == 0) {
       const bool rv = lane < n;
       double v = rv ? Sm[n * kResSLd + lane] : 0.0;
-      const double invd = rv ? 1.0 / Sm[lane * kResSLd + lane] : 0.0;
+      const double invd = rv ? dinvL[lane] : 0.0;
       double xs = 0.0;
       for (int J = nco - 1; J >= 0; --J) {
         double lq[6];
