@@ -289,3 +289,26 @@ def test_window_slam_same_result_with_either_loop():
     close(o1.Rs(), o2.Rs(), 1e-7)
     close(o1.ts(), o2.ts(), 1e-7, 1e-9)
     close(o1.reconstruction, o2.reconstruction, 1e-7)
+
+
+def test_degenerate_shapes():
+    """One workgroup, one point; tracks nobody in the window sees; a camera that sees nothing; two cameras."""
+    from pysfm_amd import Bundle
+    sensor = O.Sensor.gaussian(1.)
+    # tracks 0 .. 11 of a 6-camera scene, cameras 3 .. 5 only: the first tracks have no observation in the window
+    b, _ = small_scene(6, 40, 3, 41, sensor)
+    kw = dict(camera_ids=[3, 4, 5], track_ids=list(range(0, 30)))
+    a, r = run(b, False, **kw), run(b, True, **kw)
+    same_walk(a, r)
+    # two cameras, one of them free; a single track
+    for nc, nt, L in ((2, 7, 2), (3, 1, 3), (2, 1, 2)):
+        b, _ = small_scene(nc, nt, L, 50 + nt, sensor)
+        same_walk(run(b, False, max_steps=6), run(b, True, max_steps=6), rtol=1e-7)
+    # a camera in the window that observes none of the selected tracks (its block of the reduced system is zero: the
+    # reference's solve raises, the damping grows - both loops alike)
+    K, R, t, X, cam, pt, z = small_scene(5, 30, 3, 43, sensor)[1]
+    keep = cam != 2
+    b = Bundle.FromObservations(K, R, t, X, cam[keep], pt[keep], z[keep], sensor_model=model_of(sensor))
+    a, r = run(b, False, max_steps=4), run(b, True, max_steps=4)
+    assert [(d, o) for d, o, _ in a.trial_log] == [(d, o) for d, o, _ in r.trial_log]
+    close(r.costs, a.costs, 1e-8)
