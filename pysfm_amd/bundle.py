@@ -202,10 +202,13 @@ class Bundle(object):
             'shape was ' + str(np.shape(self.reconstruction))
         assert np.sum(np.square(self.reconstruction)) > 1e-8, 'reconstruction must be initialized'
         cam, trk, z = self.observation_table()
-        if len(cam):
+        checked = self._table is not None and self.__dict__.get('_table_cameras_checked') == len(self.cameras)
+        if len(cam) and not checked:                         # (the table of an array-native bundle is immutable: checked once)
             assert cam.min() >= 0 and cam.max() < len(self.cameras), \
                 'There are %d cameras but a track has a measurement for camera %d' % \
                 (len(self.cameras), int(cam.max() if cam.max() >= len(self.cameras) else cam.min()))
+            if self._table is not None:
+                self._table_cameras_checked = len(self.cameras)
         for camera in (list.__iter__(self.cameras) if isinstance(self.cameras, _Cameras) else self.cameras):
             if camera is not None:                           # (cameras nobody has touched are rows of validated arrays)
                 assert camera.R.shape == (3, 3)
@@ -477,7 +480,7 @@ class Bundle(object):
         b.reconstruction = self.reconstruction.copy()
         b.tracks = self.tracks
         b._table = self._table
-        for name in ('_table_key', '_track_offsets'):      # (what was derived from the immutable table travels with it)
+        for name in ('_table_key', '_track_offsets', '_table_cameras_checked'):      # (what was derived from the immutable table travels with it)
             if name in self.__dict__:
                 b.__dict__[name] = self.__dict__[name]
         b.sensor_model = self.sensor_model

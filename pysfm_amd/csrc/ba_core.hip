@@ -227,6 +227,7 @@ int ba_destroy(ba_handle* h) {
   }
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->res_log) (void)hipHostFree(h->res_log);
+  if (h->io) (void)hipHostFree(h->io);
   if (h->res_trace) (void)hipHostFree(h->res_trace);
   h->res_xb.release(); h->res_epoch.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -358,6 +359,20 @@ int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams) {
   return BA_OK;
 }
 
+// Small parameter sets travel through a pinned buffer of the handle: a copy from / to pageable memory is staged synchronously by
+// the runtime (10 - 15 us apiece; the sliding-window caller uploads and fetches a parameter set per frame).
+static hipError_t io_buffer(ba_handle* h, size_t bytes) {
+  if (h->io_pending) { (void)hipStreamSynchronize(h->stream); h->io_pending = false; }      // (the last upload may still be reading it)
+  if (h->io && h->io_bytes >= bytes) return hipSuccess;
+  if (h->io) (void)hipHostFree(h->io);
+  h->io = nullptr; h->io_bytes = 0;
+  const size_t want = std::max<size_t>(bytes, 64 << 10);
+  const hipError_t e = hipHostMalloc(&h->io, want, hipHostMallocDefault);
+  if (e == hipSuccess) h->io_bytes = want;
+  return e;
+}
+constexpr size_t kIoMaxBytes = 4u << 20;
+
 int ba_set_params(ba_handle* h, int which, const double* R, const double* t, const double* X) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_set_params: call ba_set_problem first");
@@ -365,14 +380,27 @@ int ba_set_params(ba_handle* h, int which, const double* R, const double* t, con
   REQUIRE(h, (h->nc == 0 || (R && t)) && (h->nt == 0 || X), BA_ERR_INVALID_ARG, "ba_set_params: NULL argument");
   HIPCHECK(h, hipSetDevice(h->device));
   const int p = h->phys(which);
-  std::vector<double> packed((size_t)h->nc * 12);
-  for (int i = 0; i < h->nc; ++i) {
-    std::memcpy(&packed[(size_t)i * 12], R + (size_t)i * 9, 9 * sizeof(double));
-    std::memcpy(&packed[(size_t)i * 12 + 9], t + (size_t)i * 3, 3 * sizeof(double));
+  const size_t ncam = (size_t)h->nc * 12, nx = (size_t)h->nt * 3;
+  const bool small = (ncam + nx) * sizeof(double) <= kIoMaxBytes;
+  std::vector<double> pageable;
+  double* packed;
+  if (small) {
+    HIPCHECK(h, io_buffer(h, (ncam + nx) * sizeof(double)));
+    packed = static_cast<double*>(h->io);
+    if (nx) std::memcpy(packed + ncam, X, nx * sizeof(double));
+    X = packed + ncam;
+  } else {
+    pageable.resize(ncam);
+    packed = pageable.data();
   }
-  if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->cams[p].p, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  for (int i = 0; i < h->nc; ++i) {
+    std::memcpy(packed + (size_t)i * 12, R + (size_t)i * 9, 9 * sizeof(double));
+    std::memcpy(packed + (size_t)i * 12 + 9, t + (size_t)i * 3, 3 * sizeof(double));
+  }
+  if (h->nc) HIPCHECK(h, hipMemcpyAsync(h->cams[p].p, packed, ncam * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->nt) { const int rc = upload_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, X, h->X[p].p, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (small) h->io_pending = true;                 // (everything later is ordered behind the copies on the handle's stream)
+  else HIPCHECK(h, hipStreamSynchronize(h->stream));
   h->have_params[p] = true;
   if (which == BA_PARAMS_CUR) h->have_linearization = h->have_schur = h->have_backsub = false;
   return BA_OK;
@@ -384,13 +412,26 @@ int ba_get_params(ba_handle* h, int which, double* R, double* t, double* X) {
   const int p = h->phys(which);
   REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_get_params: parameter set is empty");
   HIPCHECK(h, hipSetDevice(h->device));
-  std::vector<double> packed((size_t)h->nc * 12);
-  if (h->nc) HIPCHECK(h, hipMemcpyAsync(packed.data(), h->cams[p].p, packed.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (X) { const int rc = download_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, h->X[p].p, X, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
+  const size_t ncam = (size_t)h->nc * 12, nx = X ? (size_t)h->nt * 3 : 0;
+  const bool small = (ncam + nx) * sizeof(double) <= kIoMaxBytes;
+  std::vector<double> pageable;
+  double* packed;
+  double* xdst = X;
+  if (small) {
+    HIPCHECK(h, io_buffer(h, (ncam + nx) * sizeof(double)));
+    packed = static_cast<double*>(h->io);
+    xdst = packed + ncam;
+  } else {
+    pageable.resize(ncam);
+    packed = pageable.data();
+  }
+  if (h->nc) HIPCHECK(h, hipMemcpyAsync(packed, h->cams[p].p, ncam * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (X) { const int rc = download_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, h->X[p].p, xdst, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
   HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (small && nx) std::memcpy(X, xdst, nx * sizeof(double));
   for (int i = 0; i < h->nc; ++i) {
-    if (R) std::memcpy(R + (size_t)i * 9, &packed[(size_t)i * 12], 9 * sizeof(double));
-    if (t) std::memcpy(t + (size_t)i * 3, &packed[(size_t)i * 12 + 9], 3 * sizeof(double));
+    if (R) std::memcpy(R + (size_t)i * 9, packed + (size_t)i * 12, 9 * sizeof(double));
+    if (t) std::memcpy(t + (size_t)i * 3, packed + (size_t)i * 12 + 9, 3 * sizeof(double));
   }
   return BA_OK;
 }

@@ -202,6 +202,9 @@ struct ba_handle {
   DevBuf<long long> res_epoch;         // ... their epoch words (never reset: a launch starts above res_epoch0)
   long long res_epoch0 = 0;
   void* res_log = nullptr;             // ... and its pinned log (ResidentLog of ba_resident.h)
+  void* io = nullptr;                  // pinned staging of ba_set_params / ba_get_params (small parameter sets)
+  size_t io_bytes = 0;
+  bool io_pending = false;             // an upload from it may still be in flight
   void* res_trace = nullptr;           // ... and, with option solve_trace, clock stamps of its first 64 trials
   int cost_blocks = 0;      // partials the last k_cost launch wrote
   bool cost_fused = false;  // the last ba_backsubstitute evaluated the trial cost as well (k_backsub_groups)

@@ -99,7 +99,15 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
     h->have_params[p] = false;
     return h->fail(BA_ERR_HIP, "ba_lm_resident: the workgroups of the resident loop lost each other (timed out after %d trials)", a.log->ntrials);
   }
-  memcpy(log, h->res_log, sizeof(ResidentLog));
+  {
+    // the header and what the trials wrote (the log is 20 KB, a window's run fills a fiftieth of it)
+    const ResidentLog* src = a.log;
+    const size_t nt = (size_t)std::min(src->ntrials, kResMaxTrials);
+    memcpy(log, src, offsetof(ResidentLog, trial_damping));
+    memcpy(log->trial_damping, src->trial_damping, nt * sizeof(double));
+    memcpy(log->trial_cost, src->trial_cost, nt * sizeof(double));
+    memcpy(log->trial_accepted, src->trial_accepted, nt * sizeof(int));
+  }
   // the current set has moved (or not): nothing that was derived from it on the device is valid any more
   if (log->accepted) {
     h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
