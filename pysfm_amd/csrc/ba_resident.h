@@ -1,5 +1,5 @@
 // ba_resident.h - the whole Levenberg-Marquardt loop of BundleAdjuster.optimize() (bundle_adjuster.py:117-162) for a SMALL
-// problem as one resident launch: a sliding window of <= 10 optimised cameras and up to a thousand tracks
+// problem as one resident launch: a sliding window of <= 16 optimised cameras and up to 512 tracks
 // (window_slam.py:17-48 runs one such problem per frame; the reference's own tests and its config-1 scenes are this size).
 //
 // At this size the six launches of ba_lm_trial cost 68 us per trial of which the kernels' own work is a fraction: every launch
@@ -43,24 +43,29 @@ constexpr int kResG = 16;                           // lanes per point
 constexpr int kResP = kResThreads / kResG;          // points per workgroup
 constexpr int kResWaves = kResThreads / 64;
 constexpr int kResK = 3 * kResP;                    // staged k rows
-constexpr int kResLd = 64;                          // staged row length (4 tiles)
-constexpr int kResMaxNco = 10;                      // optimised cameras: 60 unknowns, one lane per row of the factorisation
+constexpr int kResMaxNco = 16;                      // optimised cameras: 96 unknowns
+constexpr int kResMaxN = 6 * kResMaxNco;
+constexpr int kResLd = kResMaxN;                    // staged row length (6 tiles)
+constexpr int kResMaxTileRows = kResMaxN / 16;      // 16 x 16 tiles per side
+constexpr int kResOwn = (kResMaxTileRows * (kResMaxTileRows + 1) / 2 + 3) / 4;      // upper tiles per wavefront at most: 6 of 21
 constexpr int kResMaxNc = 32;
 constexpr int kResMaxGroups = 32;                   // workgroups of a launch
 constexpr int kResMaxNt = kResP * kResMaxGroups;
 constexpr int kResMaxL = kResG;
-constexpr int kResSLd = 65;                         // row length of S in LDS (odd: rows fall on different banks)
+constexpr int kResSLd = kResMaxN + 1;               // row length of S in LDS (odd: rows fall on different banks)
 constexpr int kResJcLd = 15;                        // Jc (12) | r (2), padded to an odd length
 constexpr int kResMaxTrials = 1000;
-constexpr int kResTiles = 10;                       // upper 16 x 16 tiles of a 64 x 64 matrix
 // A workgroup's record in the exchange buffer, laid out by the THREAD that adds it up (element-major, so that a wavefront's
-// load reads 512 contiguous bytes): thread t owns 14 doubles = its three
-// accumulator tiles (4 doubles each) and pair t of the "misc" block: right-hand side [64] | camera blocks [272] | scalars [8]
-// ([0] cost of its points at the current set, [1] singular point blocks, [2] trial cost).  Seven 16-byte loads per record.
-constexpr int kResRecPerThread = 14;
+// load reads 512 contiguous bytes): thread t owns 28 doubles = its (at most six) accumulator tiles, 4 doubles each, and the pairs
+// t and t + 256 of the "misc" block: right-hand side [96] | camera blocks [16 x 27] | scalars [8] ([0] cost of its points at
+// the current set, [1] singular point blocks, [2] trial cost).  Tiles a problem does not have are neither stored nor loaded.
+constexpr int kResRecPerThread = 4 * kResOwn + 4;
 constexpr int kResRec = kResRecPerThread * 256;
-constexpr int kResMiscRhs = 0, kResMiscCam = 64, kResMiscScal = kResMiscCam + 272, kResMisc = kResMiscScal + 8;
-__host__ __device__ constexpr int res_misc_at(int idx) { return (12 + (idx & 1)) * 256 + (idx >> 1); }      // element e of thread t lives at e * 256 + t
+constexpr int kResMiscRhs = 0, kResMiscCam = kResMaxN, kResMiscScal = kResMiscCam + 27 * kResMaxNco, kResMisc = kResMiscScal + 8;
+static_assert(kResMisc <= 4 * 256, "two pairs of the misc block per thread");
+__host__ __device__ constexpr int res_misc_at(int idx) {      // element e of thread t lives at e * 256 + t
+  return (4 * kResOwn + 2 * ((idx >> 1) >= 256 ? 1 : 0) + (idx & 1)) * 256 + ((idx >> 1) & 255);
+}
 constexpr int kResMaxSpins = 1 << 22;
 
 enum { RES_DONE = 0, RES_LOG_FULL = 1, RES_NOT_POSITIVE_DEFINITE = 2, RES_SINGULAR_POINT = 3, RES_TIMED_OUT = 4 };
@@ -93,7 +98,7 @@ struct ResidentArgs {
   double damping, improvement_threshold, rcond, cur_cost;      // cur_cost < 0: not known yet
   ResidentLog* log;             // pinned host memory
   long long* trace;             // optional: clock stamps at the phase boundaries of the first trials, 16 per trial (workgroup 0)
-  double* dbg;                  // optional: [S | b] (lower triangle, 61 x 65) and dC (64) of the FIRST trial, for the parity tests
+  double* dbg;                  // optional: [S | b] (lower triangle, 98 x 97) and dC (128) of the FIRST trial, for the parity tests
 };
 
 // LDS carve-up of a workgroup
@@ -113,12 +118,12 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.Dk = o; o += 2 * kResK;                       // D | y
   l.red = o; o += kResWaves * 64 + 16;            // partial right-hand sides [waves][64], wavefront partials
   l.misc = o; o += kResMisc;                   // the summed right-hand side | camera blocks | scalars
-  l.dC = o; o += 64;
-  l.fact = o; o += 192 + kBcrIdtDoubles + 64;     // the factorisation: inverse of the diagonal block [16][12], identity table, 1 / diagonal
+  l.dC = o; o += 128;
+  l.fact = o; o += 192 + kBcrIdtDoubles + 128;     // the factorisation: inverse of the diagonal block [16][12], identity table, 1 / diagonal
   l.z = o; o += 2 * kResP * maxL;                 // the measurements of my points
   l.stage = o;
   const int at = kResK * kResLd + kResP * maxL * kResJcLd;
-  const int sm = 66 * kResSLd;
+  const int sm = (kResMaxN + 2) * kResSLd;
   o += at > sm ? at : sm;
   o += o & 1;
   size_t b = (size_t)o * 8;
@@ -214,7 +219,8 @@ __device__ __forceinline__ void res_update_panel(double* __restrict__ Sm, int ti
 #define RES_SWITCH_STEP(fn, ...)                                                              \
   switch (step) {                                                                             \
     case 0: fn<0>(__VA_ARGS__); break; case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; \
-    default: fn<3>(__VA_ARGS__); break;                                                       \
+    case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; case 5: fn<5>(__VA_ARGS__); break; \
+    default: fn<6>(__VA_ARGS__); break;                                                       \
   }
 
 __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
@@ -297,10 +303,15 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
 
   const int NT = (n + 15) >> 4, ntiles = NT * (NT + 1) / 2;
   const int ln = lane & 15, lk = lane >> 4;
-  int tti[3] = {0, 0, 0}, ttj[3] = {0, 0, 0};      // my tiles: wave, wave + 4, wave + 8
-  bool own[3];
+  int tti[kResOwn], ttj[kResOwn];                   // my tiles: wave, wave + 4, wave + 8, ...
+  bool own[kResOwn];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) { own[t] = wave + kResWaves * t < ntiles; if (own[t]) tri_decode(wave + kResWaves * t, NT, tti[t], ttj[t]); }
+  for (int t = 0; t < kResOwn; ++t) {
+    tti[t] = ttj[t] = 0;
+    own[t] = wave + kResWaves * t < ntiles;
+    if (own[t]) tri_decode(wave + kResWaves * t, NT, tti[t], ttj[t]);
+  }
+  const bool more_tiles = ntiles > 3 * kResWaves;      // (uniform over the launch: beyond 10 cameras)
   double* myrec = A.xb + (size_t)grp * kResRec;
 
   int tr_i = 0;
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) dkv[ks] = Dk[4 * ks + lk];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < kResOwn; ++t) {
         if (!own[t]) continue;
         const double* a0 = At + 16 * tti[t] + ln + lk * kResLd;
         const double* b0 = At + 16 * ttj[t] + ln + lk * kResLd;
@@ -460,29 +471,36 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) res_st(q + v * 256, acc[v]);
       }
-      const int r = tid & 63, sl = tid >> 6;      // kResK / kResWaves k rows per slice
       double rhs_part = 0.0;
-      if (r < n) {
+      if (n <= 64) {                                  // (uniform) four slices of the k rows ...
+        const int r = tid & 63, sl = tid >> 6;
+        if (r < n) {
 #pragma unroll
-        for (int q = 0; q < kResK / kResWaves; ++q) {
-          const int k = sl * (kResK / kResWaves) + q;
-          rhs_part = fma(At[k * kResLd + r], yk[k], rhs_part);
+          for (int q = 0; q < kResK / 4; ++q) {
+            const int k = sl * (kResK / 4) + q;
+            rhs_part = fma(At[k * kResLd + r], yk[k], rhs_part);
+          }
         }
+        red[sl * 64 + r] = rhs_part;
+      } else {                                        // ... or two
+        const int r = tid & 127, sl = tid >> 7;
+        if (r < n) {
+#pragma unroll
+          for (int q = 0; q < kResK / 2; ++q) {
+            const int k = sl * (kResK / 2) + q;
+            rhs_part = fma(At[k * kResLd + r], yk[k], rhs_part);
+          }
+        }
+        red[sl * 128 + r] = rhs_part;
       }
-      red[sl * 64 + r] = rhs_part;
     }
     if (need_lin) {
       const double c = wave_sum(lin_cost);
       if (lane == 0) red[kResWaves * 64 + wave] = c;
     }
     lds_barrier();
-    if (tid < 64) {
-      double s = 0.0;
-#pragma unroll
-      for (int q = 0; q < kResWaves; ++q) s += red[q * 64 + tid];
-      res_st(myrec + res_misc_at(kResMiscRhs + tid), s);
-    }
-    if (tid == 64) {
+    if (tid < n) res_st(myrec + res_misc_at(kResMiscRhs + tid), n <= 64 ? (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]) : red[tid] + red[128 + tid]);
+    if (tid == 128) {
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < kResWaves; ++w) s += red[kResWaves * 64 + w];
@@ -497,20 +515,23 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
     RES_STAMP(3);
     {
       // tiles: C[row = 16 ti + lk + 4 v][col = 16 tj + ln], ti <= tj: entry (col, row) of the lower triangle of S
-      res_acc ssum[3];
+      res_acc ssum[kResOwn];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) ssum[t] = res_acc{0.0, 0.0, 0.0, 0.0};
-      double m0 = 0.0, m1 = 0.0;                      // pair `tid` of the right-hand side | camera blocks | scalars
-      const bool mine = 2 * tid < kResMisc;
+      for (int t = 0; t < kResOwn; ++t) ssum[t] = res_acc{0.0, 0.0, 0.0, 0.0};
+      double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;  // pairs `tid` and `tid + 256` of the right-hand side | camera blocks | scalars
+      const bool mine2 = 2 * (tid + 256) < kResMisc;
       const double* mybase = A.xb + tid;
       for (int g0 = 0; g0 < G; g0 += 4) {
         // four records in flight before the first use (compiler-visible agent-scope loads: it counts the waits itself)
-        double v[4][kResRecPerThread];
+        double v[4][16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const double* q = mybase + (size_t)min(g0 + u, G - 1) * kResRec;
 #pragma unroll
-          for (int e = 0; e < kResRecPerThread; ++e) v[u][e] = res_ld(q + e * 256);
+          for (int e = 0; e < 12; ++e) v[u][e] = res_ld(q + e * 256);
+          v[u][12] = res_ld(q + (4 * kResOwn) * 256); v[u][13] = res_ld(q + (4 * kResOwn + 1) * 256);
+          v[u][14] = v[u][15] = 0.0;
+          if (mine2) { v[u][14] = res_ld(q + (4 * kResOwn + 2) * 256); v[u][15] = res_ld(q + (4 * kResOwn + 3) * 256); }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -519,11 +540,33 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
           for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) ssum[t][e] += in && own[t] ? v[u][4 * t + e] : 0.0;
-          m0 += in && mine ? v[u][12] : 0.0;
-          m1 += in && mine ? v[u][13] : 0.0;
+          m0 += in ? v[u][12] : 0.0;
+          m1 += in ? v[u][13] : 0.0;
+          m2 += in && mine2 ? v[u][14] : 0.0;
+          m3 += in && mine2 ? v[u][15] : 0.0;
         }
       }
-      if (mine) { miscL[2 * tid] = m0; miscL[2 * tid + 1] = m1; }
+      if (more_tiles) {                               // more than 10 cameras: my tiles 3 .. 5
+        for (int g0 = 0; g0 < G; g0 += 4) {
+          double v[4][12];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double* q = mybase + (size_t)min(g0 + u, G - 1) * kResRec + 12 * 256;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) v[u][e] = res_ld(q + e * 256);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool in = g0 + u < G;
+#pragma unroll
+            for (int t = 3; t < kResOwn; ++t)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ssum[t][e] += in && own[t] ? v[u][4 * (t - 3) + e] : 0.0;
+          }
+        }
+      }
+      miscL[2 * tid] = m0; miscL[2 * tid + 1] = m1;
+      if (mine2) { miscL[2 * (tid + 256)] = m2; miscL[2 * (tid + 256) + 1] = m3; }
       lds_barrier();
       const double c0sum = miscL[kResMiscScal];
       if (res_uniform(miscL[kResMiscScal + 1]) > 0.0) { exit_reason = RES_SINGULAR_POINT; break; }      // plain-inverse mode: the general path raises (bundle_adjuster.py:254)
@@ -535,10 +578,10 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
           if (cur_cost < 0.0) cur_cost = cost0;
         }
       }
-      const double rsum = tid < 64 ? miscL[tid] : 0.0;
+      const double rsum = tid < kResMaxN ? miscL[tid] : 0.0;
       lds_barrier();                                  // HCC is in LDS; nobody reads At any more
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < kResOwn; ++t) {
         if (!own[t]) continue;
         const int ti = tti[t], tj = ttj[t];
         const int col = 16 * tj + ln;
@@ -579,29 +622,29 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
         if (nbw == 12) bcr_diag_block<12, true>(Sm, kResSLd, dinvL, sflag, k0, lane, LiL, IdtL);
         else bcr_diag_block<6, true>(Sm, kResSLd, dinvL, sflag, k0, lane, LiL, IdtL);
       } else if (nwn > 0) {
-        RES_SWITCH_STEP(res_update_ahead, Sm, wave - 1, n, nwn, ln, lk);
-        if (wave == 1) RES_SWITCH_STEP(res_update_ahead, Sm, 3, n, nwn, ln, lk);
+        for (int tile = wave - 1; kn + 16 * tile <= n; tile += kResWaves - 1) RES_SWITCH_STEP(res_update_ahead, Sm, tile, n, nwn, ln, lk);
       }
       RES_CSTAMP(1);
       lds_barrier();
       if (res_uniform(sflag[0])) break;
       // the panel: rows kn .. n (the right-hand side among them), a tile of 16 per wavefront
-      {
+      for (int i0 = kn + 16 * wave; i0 <= n; i0 += 16 * kResWaves) {
         double pr[3];
-        if (kn + 16 * wave <= n) bcr_panel_tile(Sm, kResSLd, n + 1, k0, kn + 16 * wave, LiL, ln, lk, pr, nbw);
+        bcr_panel_tile(Sm, kResSLd, n + 1, k0, i0, LiL, ln, lk, pr, nbw);
       }
       RES_CSTAMP(2);
       lds_barrier();
       if (nwn > 0) {
-        RES_SWITCH_STEP(res_update_panel, Sm, wave, n, nwn, ln, lk);
+        for (int tile = wave; kn + 16 * tile <= n; tile += kResWaves) RES_SWITCH_STEP(res_update_panel, Sm, tile, n, nwn, ln, lk);
         lds_barrier();
       }
       RES_CSTAMP(3);
     }
     if (res_uniform(sflag[0])) { exit_reason = RES_NOT_POSITIVE_DEFINITE; exit_info = res_uniform(sflag[0]); break; }
     RES_STAMP(5);
-    // ---- L^T x = y in one wavefront: lane i holds its unknown; the rows of a camera block are fetched together
-    if (wave == 0) {
+    // ---- L^T x = y in one wavefront: lane i holds the unknown i (and 64 + i beyond 10 cameras); the rows of a camera block
+    //      are fetched together
+    if (wave == 0 && n <= 64) {
       const bool rv = lane < n;
       double v = rv ? Sm[n * kResSLd + lane] : 0.0;
       const double invd = rv ? dinvL[lane] : 0.0;
@@ -609,19 +652,44 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       for (int J = nco - 1; J >= 0; --J) {
         double lq[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) lq[u] = lane < 6 * J + u ? Sm[(6 * J + u) * kResSLd + lane] : 0.0;
+        for (int u = 0; u < 6; ++u) lq[u] = Sm[(6 * J + u) * kResSLd + lane];
 #pragma unroll
         for (int u = 5; u >= 0; --u) {
           const int q = 6 * J + u;
           const double xq = lane_bcast(v * invd, q);
           if (lane == q) xs = xq;
-          v = fma(-lq[u], xq, v);
+          v = fma(lane < q ? -lq[u] : 0.0, xq, v);
         }
       }
       if (rv) dCl[lane] = xs;
+    } else if (wave == 0) {
+      const bool rv0 = lane < n, rv1 = 64 + lane < n;
+      double v0 = rv0 ? Sm[n * kResSLd + lane] : 0.0, v1 = rv1 ? Sm[n * kResSLd + 64 + lane] : 0.0;
+      const double i0 = rv0 ? dinvL[lane] : 0.0, i1 = rv1 ? dinvL[64 + lane] : 0.0;
+      double x0 = 0.0, x1 = 0.0;
+      for (int J = nco - 1; J >= 0; --J) {
+        double l0[6], l1[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int q = 6 * J + u;
+          l0[u] = Sm[q * kResSLd + lane];
+          l1[u] = Sm[q * kResSLd + min(64 + lane, kResMaxN - 1)];
+        }
+#pragma unroll
+        for (int u = 5; u >= 0; --u) {
+          const int q = 6 * J + u;
+          const double t = q < 64 ? v0 * i0 : v1 * i1;
+          const double xq = lane_bcast(t, q & 63);
+          if (lane == (q & 63)) { if (q < 64) x0 = xq; else x1 = xq; }
+          v0 = fma(lane < q ? -l0[u] : 0.0, xq, v0);
+          v1 = fma(64 + lane < q ? -l1[u] : 0.0, xq, v1);
+        }
+      }
+      if (rv0) dCl[lane] = x0;
+      if (rv1) dCl[64 + lane] = x1;
     }
     lds_barrier();
-    if (A.dbg && grp == 0 && ntrials == 0 && tid < 64) A.dbg[66 * kResSLd + tid] = tid < n ? dCl[tid] : 0.0;
+    if (A.dbg && grp == 0 && ntrials == 0 && tid < 128) A.dbg[(kResMaxN + 2) * kResSLd + tid] = tid < n ? dCl[tid] : 0.0;
     RES_STAMP(6);
 
     // ---- the trial set: cameras (update_motion with the sign of compute_update, bundle_adjuster.py:203-208, 334-337)

@@ -81,7 +81,7 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   a.trace = nullptr;
   a.dbg = nullptr;
   if (h->opt.solve_trace) {
-    if (!h->res_trace) HIPCHECK(h, hipHostMalloc(&h->res_trace, 64 * 16 * sizeof(long long) + (66 * kResSLd + 64) * sizeof(double), hipHostMallocDefault));
+    if (!h->res_trace) HIPCHECK(h, hipHostMalloc(&h->res_trace, 64 * 16 * sizeof(long long) + ((kResMaxN + 2) * kResSLd + 128) * sizeof(double), hipHostMallocDefault));
     memset(h->res_trace, 0, 64 * 16 * sizeof(long long));
     a.trace = static_cast<long long*>(h->res_trace);
     a.dbg = reinterpret_cast<double*>(a.trace + 64 * 16);
@@ -130,7 +130,7 @@ int ba_lm_resident_debug(ba_handle* h, double* S_out, double* b_out, double* dC_
   const int n = 6 * h->nco;
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) S_out[(size_t)i * n + j] = i >= j ? d[i * kResSLd + j] : d[j * kResSLd + i];
-  for (int i = 0; i < n; ++i) { b_out[i] = d[n * kResSLd + i]; dC_out[i] = d[66 * kResSLd + i]; }
+  for (int i = 0; i < n; ++i) { b_out[i] = d[n * kResSLd + i]; dC_out[i] = d[(kResMaxN + 2) * kResSLd + i]; }
   return BA_OK;
 }
 

@@ -43,7 +43,7 @@ def compare(name, bundle, **kw):
 ok = True
 rng = np.random.default_rng(5)
 for model in (sensor_model.GaussianModel(1.), sensor_model.CauchyModel(.05), sensor_model.GaussianModel(.3)):
-    for nc, nt, L in ((5, 50, 5), (10, 100, 10), (8, 200, 6), (10, 37, 4), (4, 300, 4)):
+    for nc, nt, L in ((5, 50, 5), (10, 100, 10), (8, 200, 6), (10, 37, 4), (4, 300, 4), (14, 120, 12), (17, 256, 16), (12, 90, 5)):
         sc = synthetic_data.generate_banded_scene(nc, nt, track_len=L, seed=int(rng.integers(1 << 30)), msm_noise=.01, init_perturbation=.03,
                                                   outlier_frac=0. if isinstance(model, sensor_model.GaussianModel) else .05)
         b = Bundle.FromObservations(sc['K'], sc['R0'], sc['t0'], sc['X0'], sc['obs_cam'], sc['obs_pt'], sc['obs_z'], sensor_model=model)

@@ -85,7 +85,8 @@ SENSORS = [O.Sensor.gaussian(1.), O.Sensor.cauchy(.05), O.Sensor.huber(.06), O.S
 
 
 @pytest.mark.parametrize('nc,nt,L,kw', [(5, 50, 5, {}), (10, 100, 10, {}), (10, 37, 4, dict(ragged=True)), (8, 200, 6, dict(shuffle=True)),
-                                        (4, 300, 4, {}), (11, 512, 11, dict(ragged=True, shuffle=True))])
+                                        (4, 300, 4, {}), (11, 512, 11, dict(ragged=True, shuffle=True)), (14, 120, 12, {}), (17, 256, 16, dict(ragged=True)),
+                                        (12, 90, 5, dict(shuffle=True))])
 @pytest.mark.parametrize('si', range(len(SENSORS)))
 def test_resident_loop_takes_the_walk_of_the_python_loop(nc, nt, L, kw, si):
     sensor = SENSORS[si]
@@ -211,8 +212,8 @@ def test_a_trial_the_resident_loop_cannot_take_goes_through_the_general_path():
 def test_what_is_not_a_resident_problem_takes_the_python_loop():
     from pysfm_amd import BundleAdjuster, sensor_model
     from conftest import GemanMcClure
-    b, _ = small_scene(14, 60, 12, 2, O.Sensor.gaussian(1.))
-    ba = BundleAdjuster(b, verbose=False)                                  # 13 optimised cameras
+    b, _ = small_scene(18, 60, 12, 2, O.Sensor.gaussian(1.))
+    ba = BundleAdjuster(b, verbose=False)                                  # 17 optimised cameras: one more than the loop takes
     assert not ba._resident_applies(None)
     ba.set_bundle(b, camera_ids=list(range(8)))
     assert ba._resident_applies(None)
