@@ -229,7 +229,7 @@ int ba_destroy(ba_handle* h) {
   if (h->res_log) (void)hipHostFree(h->res_log);
   if (h->io) (void)hipHostFree(h->io);
   if (h->res_trace) (void)hipHostFree(h->res_trace);
-  h->res_xb.release(); h->res_epoch.release();
+  h->res_xb.release(); h->res_epoch.release(); h->res_cost.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BA_OK;

@@ -201,6 +201,8 @@ struct ba_handle {
   DevBuf<double> res_xb;               // ba_lm_resident: the exchange buffer of its workgroups
   DevBuf<long long> res_epoch;         // ... their epoch words (never reset: a launch starts above res_epoch0)
   long long res_epoch0 = 0;
+  DevBuf<double> res_cost;             // ... their trial-cost words [2][32] (by the parity of the trial)
+  int res_parity = 0;
   void* res_log = nullptr;             // ... and its pinned log (ResidentLog of ba_resident.h)
   void* io = nullptr;                  // pinned staging of ba_set_params / ba_get_params (small parameter sets)
   size_t io_bytes = 0;

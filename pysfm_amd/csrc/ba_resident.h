@@ -22,15 +22,17 @@
 //                                                                                                (bundle_adjuster.py:259-278)
 //   exchange 1   every workgroup publishes its partial sums (relaxed agent-scope stores, one epoch word), waits for the others
 //                and adds ALL partials in workgroup order: every workgroup holds the same [S | b], bit for bit
-//   4 solve      S = damped HCC - P, b = bC - At^T y; Cholesky by block columns of one camera: the update of a block column from
-//                the columns left of it is spread over the workgroup, its 6 x 6 pivot chain runs in one wavefront with a lane
-//                per row and v_readlane broadcasts; the right-hand side rides along as one more row; back-substitution in the
-//                same wavefront.  Every workgroup solves (redundantly: a hand-over costs more than 8 us of one CU's time is
-//                worth).  A pivot <= 0 ends the run (exit reason 2): the host repeats that trial through the general path,
-//                which solves it as the reference's gesv would                                 (bundle_adjuster.py:281-312)
+//   4 solve      S = damped HCC - P, b = bC - At^T y; Cholesky in steps of 12 columns with the diagonal-block and panel routines
+//                of the cyclic reduction (ba_bcr_blocks.h), the updates of the next block of columns on the matrix cores, the
+//                part of them that does not depend on the current step running beside its pivot chain; the right-hand side
+//                rides along as one more row; back-substitution in one wavefront.  Every workgroup solves (redundantly: a
+//                hand-over costs more than 10 us of one CU's time are worth).  A pivot <= 0 ends the run (exit reason 2):
+//                the host repeats that trial through the general path, which solves it as the reference's gesv would
+//                                                                                                (bundle_adjuster.py:281-312)
 //   5 back-sub   dP = HPPinv (bP - sum W^T dC), the trial set = perturb(-dC), x - dP, and the cost of my points at the trial set
 //                                                                                       (bundle_adjuster.py:316-343, 165-171)
-//   exchange 2   the cost partials; every workgroup adds them in workgroup order and takes the same decision.
+//   exchange 2   the cost partials, one word per workgroup that IS its own flag (a NaN no computation produces says "not yet");
+//                every workgroup adds them in workgroup order and takes the same decision.
 // fp64 throughout; every sum has a fixed order: results are reproducible run to run and identical in every workgroup.
 #pragma once
 
@@ -67,6 +69,7 @@ __host__ __device__ constexpr int res_misc_at(int idx) {      // element e of th
   return (4 * kResOwn + 2 * ((idx >> 1) >= 256 ? 1 : 0) + (idx & 1)) * 256 + ((idx >> 1) & 255);
 }
 constexpr int kResMaxSpins = 1 << 22;
+constexpr long long kResNotYet = 0x7FFA5A5A5A5A5A5All;      // a NaN no computation produces: the trial cost of a workgroup that is not there yet
 
 enum { RES_DONE = 0, RES_LOG_FULL = 1, RES_NOT_POSITIVE_DEFINITE = 2, RES_SINGULAR_POINT = 3, RES_TIMED_OUT = 4 };
 
@@ -93,6 +96,8 @@ struct ResidentArgs {
   double* xb;                   // exchange buffer: ngroups records of kResRec doubles
   long long* epoch;             // [2 * ngroups]: what each workgroup has published (partial sums | trial cost)
   long long epoch0;             // epochs of this launch start above it (the words are never reset)
+  double* cost_slots;           // [2][kResMaxGroups]: the workgroups' trial costs, by the parity of the trial; kResNotYet between uses
+  int parity0;                  // parity of this launch's first trial
   // the schedule
   int max_steps, max_trials, nsteps, in_step, converged;
   double damping, improvement_threshold, rcond, cur_cost;      // cur_cost < 0: not known yet
@@ -513,6 +518,9 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
     res_publish(A.epoch + 2 * grp, epoch, tid);
     if (!res_wait_all(A.epoch, 2, G, epoch, tid, sflag + 1)) { exit_reason = RES_TIMED_OUT; break; }
     RES_STAMP(3);
+    // (everybody is in this trial: nobody reads the last trial's cost words any more - mine goes back to "not yet")
+    const int par = (A.parity0 + ntrials) & 1;
+    if (tid == 0) __hip_atomic_store(reinterpret_cast<long long*>(A.cost_slots) + (1 - par) * kResMaxGroups + grp, kResNotYet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
       // tiles: C[row = 16 ti + lk + 4 v][col = 16 tj + ln], ti <= tj: entry (col, row) of the lower triangle of S
       res_acc ssum[kResOwn];
@@ -746,25 +754,30 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
     tc = wave_sum(tc);
     if (lane == 0) red[kResWaves * 64 + wave] = tc;
     lds_barrier();
-    if (tid == 0) {
-      double s = 0.0;
-#pragma unroll
-      for (int w = 0; w < kResWaves; ++w) s += red[kResWaves * 64 + w];
-      res_st(myrec + res_misc_at(kResMiscScal + 2), s);
-    }
     RES_STAMP(7);
-    // ---- exchange 2: the cost of the trial set
-    ++epoch;
-    res_publish(A.epoch + 2 * grp + 1, epoch, tid);
-    if (!res_wait_all(A.epoch + 1, 2, G, epoch, tid, sflag + 1)) { exit_reason = RES_TIMED_OUT; break; }
-    double next_cost = 0.0;
-    for (int g0 = 0; g0 < G; g0 += 8) {
-      double cv[8];
+    // ---- exchange 2: the cost of the trial set.  One word per workgroup, which is its own flag.
+    if (tid < 64) {
+      long long* slots = reinterpret_cast<long long*>(A.cost_slots) + par * kResMaxGroups;
+      if (tid == 0) {
+        double s = 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) cv[u] = res_ld(A.xb + (size_t)min(g0 + u, G - 1) * kResRec + res_misc_at(kResMiscScal + 2));
-#pragma unroll
-      for (int u = 0; u < 8; ++u) next_cost += g0 + u < G ? cv[u] : 0.0;
+        for (int w = 0; w < kResWaves; ++w) s += red[kResWaves * 64 + w];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the word went back to "not yet" long ago: now for certain)
+        __hip_atomic_store(slots + grp, __double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      long long bits = 0;
+      bool ok = tid >= G;
+      for (int spins = 0; !__all(ok); ++spins) {
+        if (!ok) { bits = __hip_atomic_load(slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = bits != kResNotYet; }
+        if (spins >= kResMaxSpins) { if (tid == 0) sflag[1] = 1; break; }
+        if (!__all(ok)) __builtin_amdgcn_s_sleep(1);
+      }
+      if (tid < G) miscL[tid] = __longlong_as_double(bits);
     }
+    lds_barrier();
+    if (res_uniform(sflag[1])) { exit_reason = RES_TIMED_OUT; break; }
+    double next_cost = 0.0;
+    for (int g = 0; g < G; ++g) next_cost += miscL[g];
     next_cost = res_uniform(next_cost);
     // ---- accept / reject and the damping schedule (bundle_adjuster.py:136-157)
     const bool accept = next_cost < cur_cost;

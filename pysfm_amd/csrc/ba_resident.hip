@@ -22,6 +22,15 @@ bool resident_shape(const ba_handle* h) {
 
 namespace {
 
+// every cost word says "not yet" (at allocation, and after a launch that lost its workgroups)
+int resident_reset_cost_words(ba_handle* h) {
+  long long init[2 * kResMaxGroups];
+  for (long long& w : init) w = kResNotYet;
+  HIPCHECK(h, hipMemcpy(h->res_cost.p, init, sizeof init, hipMemcpyHostToDevice));
+  h->res_parity = 0;
+  return BA_OK;
+}
+
 bool resident_fits(const ba_handle* h, ResidentLds* lds_out) {
   if (!h->opt.resident || !h->have_problem || h->comm || h->dense_mode) return false;
   if (h->sensor.kind == SENSOR_TABLE) return false;
@@ -56,6 +65,9 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
     HIPCHECK(h, h->res_epoch.resize((size_t)2 * kResMaxGroups));
     HIPCHECK(h, hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream));
     h->res_epoch0 = 0;
+    HIPCHECK(h, h->res_cost.resize((size_t)2 * kResMaxGroups));
+    const int rc = resident_reset_cost_words(h);
+    if (rc != BA_OK) return rc;
   }
   if (!h->res_log) HIPCHECK(h, hipHostMalloc(&h->res_log, sizeof(ResidentLog), hipHostMallocDefault));
   {
@@ -75,6 +87,7 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   a.sensor = h->sensor;
   if (!h->opt.fast_paths) a.sensor.fast = 0;
   a.cams = h->cams[p].p; a.X = h->X[p].p; a.xb = h->res_xb.p; a.epoch = h->res_epoch.p; a.epoch0 = h->res_epoch0;
+  a.cost_slots = h->res_cost.p; a.parity0 = h->res_parity;
   a.max_steps = max_steps; a.max_trials = kResMaxTrials; a.nsteps = steps_taken; a.in_step = in_step ? 1 : 0; a.converged = converged ? 1 : 0;
   a.damping = damping; a.improvement_threshold = improvement_threshold; a.rcond = pinv_rcond; a.cur_cost = cur_cost;
   a.log = static_cast<ResidentLog*>(h->res_log);
@@ -92,10 +105,12 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   REQUIRE(h, a.log->ntrials >= 0, BA_ERR_HIP, "ba_lm_resident: the kernel left no log");
   h->res_epoch0 += 2 * ((long long)a.log->ntrials + 2);
+  h->res_parity = (h->res_parity + a.log->ntrials) & 1;
   if (a.log->exit_reason == RES_TIMED_OUT) {
     // a workgroup gave up waiting for the others: a fault of the kernel or of the GPU, never a property of the problem
     (void)hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream);
     h->res_epoch0 = 0;
+    (void)resident_reset_cost_words(h);
     h->have_params[p] = false;
     return h->fail(BA_ERR_HIP, "ba_lm_resident: the workgroups of the resident loop lost each other (timed out after %d trials)", a.log->ntrials);
   }
