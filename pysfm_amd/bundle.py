@@ -125,7 +125,7 @@ class _Cameras(list):
         n = len(self)
         R, t = np.empty((n, 3, 3)), np.empty((n, 3))
         m = min(n, len(self._R))
-        R[:m], t[:m] = self._R[:m], self._t[:m]
+        R[:m], t[:m] = self._R[:m], self._t[:m]           # (rows of entries that are still None; objects override below)
         for i, c in enumerate(list.__iter__(self)):
             if c is not None:
                 R[i], t[i] = c.R, c.t
@@ -146,6 +146,30 @@ class _Cameras(list):
 
     def __reduce_ex__(self, protocol):
         return (list, (list(self),))                      # copies and pickles are plain lists of Camera objects
+
+    # whatever moves entries about first makes every camera a real object (the rows of the stacked arrays are tied to positions)
+    def _all(self):
+        for i in range(len(self)):
+            self[i]
+        return self
+
+    def __delitem__(self, i): list.__delitem__(self._all(), i)
+    def insert(self, i, c): list.insert(self._all(), i, c)
+    def pop(self, *a): return list.pop(self._all(), *a)
+    def remove(self, c): list.remove(self._all(), c)
+    def reverse(self): list.reverse(self._all())
+    def sort(self, *a, **k): list.sort(self._all(), *a, **k)
+    def index(self, *a): return list.index(self._all(), *a)
+    def count(self, c): return list.count(self._all(), c)
+    def __contains__(self, c): return list.__contains__(self._all(), c)
+    def __eq__(self, other): return list(self) == list(other) if isinstance(other, list) else NotImplemented
+    def __ne__(self, other): return not self == other
+    __hash__ = None
+
+    def __setitem__(self, i, c):
+        if isinstance(i, slice):
+            self._all()
+        list.__setitem__(self, i, c)
 
 
 class _LazyTracks(object):

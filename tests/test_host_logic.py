@@ -715,3 +715,40 @@ def test_the_log_of_the_resident_loop_replays_into_the_reference_walk(name, step
     m[2] = False
     masked.optimize(param_mask=m, max_steps=2)
     assert masked.backend.launches == 0
+
+
+def test_cameras_over_stacked_arrays_behave_like_a_list():
+    """Bundle.cameras of an array-native bundle makes Camera objects on first access (bundle._Cameras): a list all the same."""
+    import copy
+    import pickle
+    rs = np.random.RandomState(3)
+    R = np.array([np.linalg.qr(rs.randn(3, 3))[0] for _ in range(6)])
+    t = rs.randn(6, 3)
+    b = Bundle.FromObservations(np.eye(3), R, t, np.ones((4, 3)), [0, 1, 2, 3, 4, 5, 0, 1], [0, 0, 1, 1, 2, 2, 3, 3], np.zeros((8, 2)))
+    cams = b.cameras
+    assert isinstance(cams, list) and len(cams) == 6
+    assert np.array_equal(cams[2].R, R[2]) and cams[-1].idx == 5 and cams[2] is cams[2]
+    cams[2].perturb(np.array([.1, 0, 0, 1., 2., 3.]))                          # an object that was handed out is the truth
+    cams[4].t[:] = 7.                                                         # ... also when edited in place
+    assert np.allclose(b.ts()[2], t[2] + [1., 2., 3.]) and np.all(b.ts()[4] == 7.) and np.array_equal(b.ts()[0], t[0])
+    c = b.clone_params()
+    assert np.array_equal(c.Rs(), b.Rs()) and np.array_equal(c.ts(), b.ts())
+    c.cameras[4].t[:] = 0.
+    c.cameras[0].R = np.eye(3)
+    assert np.all(b.ts()[4] == 7.) and np.array_equal(b.Rs()[0], R[0])          # a clone is deep
+    assert [k.idx for k in cams[1:4]] == [1, 2, 3] and [k.idx for k in reversed(cams)] == [5, 4, 3, 2, 1, 0]
+    d = copy.deepcopy(b)
+    p = pickle.loads(pickle.dumps(b.cameras))
+    assert type(p) is list and np.array_equal(p[2].t, b.ts()[2]) and np.array_equal(d.ts(), b.ts())
+    # entries that move: everything becomes an object first
+    e = b.clone_params()
+    last = e.cameras.pop()
+    assert last.idx == 5 and len(e.cameras) == 5 and np.array_equal(e.Rs(), b.Rs()[:5])
+    e.cameras.insert(0, last)
+    assert np.array_equal(e.ts()[0], b.ts()[5]) and np.array_equal(e.ts()[1:], b.ts()[:5])
+    del e.cameras[0]
+    e.add_camera(Camera(np.eye(3), np.array([1., 1., 1.])))
+    assert len(e.cameras) == 6 and e.cameras[5].idx == 5 and np.array_equal(e.ts()[5], [1., 1., 1.])
+    assert e.cameras[3] in e.cameras and e.cameras.index(e.cameras[3]) == 3
+    e.cameras[1:3] = [Camera(np.eye(3), np.zeros(3)), Camera(np.eye(3), np.ones(3))]
+    assert np.array_equal(e.ts()[2], np.ones(3)) and np.array_equal(e.ts()[3], b.ts()[3])
