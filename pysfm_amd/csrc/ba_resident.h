@@ -1,5 +1,5 @@
 // ba_resident.h - the whole Levenberg-Marquardt loop of BundleAdjuster.optimize() (bundle_adjuster.py:117-162) for a SMALL
-// problem as one resident launch: a sliding window of <= 16 optimised cameras and up to 512 tracks
+// problem as one resident launch: a sliding window of <= 16 optimised cameras and up to 1024 tracks
 // (window_slam.py:17-48 runs one such problem per frame; the reference's own tests and its config-1 scenes are this size).
 //
 // At this size the six launches of ba_lm_trial cost 68 us per trial of which the kernels' own work is a fraction: every launch
@@ -51,7 +51,7 @@ constexpr int kResLd = kResMaxN;                    // staged row length (6 tile
 constexpr int kResMaxTileRows = kResMaxN / 16;      // 16 x 16 tiles per side
 constexpr int kResOwn = (kResMaxTileRows * (kResMaxTileRows + 1) / 2 + 3) / 4;      // upper tiles per wavefront at most: 6 of 21
 constexpr int kResMaxNc = 32;
-constexpr int kResMaxGroups = 32;                   // workgroups of a launch
+constexpr int kResMaxGroups = 64;                   // workgroups of a launch (a lane of the first wavefront polls each)
 constexpr int kResMaxNt = kResP * kResMaxGroups;
 constexpr int kResMaxL = kResG;
 constexpr int kResSLd = kResMaxN + 1;               // row length of S in LDS (odd: rows fall on different banks)

@@ -85,7 +85,7 @@ SENSORS = [O.Sensor.gaussian(1.), O.Sensor.cauchy(.05), O.Sensor.huber(.06), O.S
 
 
 @pytest.mark.parametrize('nc,nt,L,kw', [(5, 50, 5, {}), (10, 100, 10, {}), (10, 37, 4, dict(ragged=True)), (8, 200, 6, dict(shuffle=True)),
-                                        (4, 300, 4, {}), (11, 512, 11, dict(ragged=True, shuffle=True)), (14, 120, 12, {}), (17, 256, 16, dict(ragged=True)),
+                                        (4, 300, 4, {}), (11, 512, 11, dict(ragged=True, shuffle=True)), (9, 1024, 7, {}), (14, 120, 12, {}), (17, 256, 16, dict(ragged=True)),
                                         (12, 90, 5, dict(shuffle=True))])
 @pytest.mark.parametrize('si', range(len(SENSORS)))
 def test_resident_loop_takes_the_walk_of_the_python_loop(nc, nt, L, kw, si):
