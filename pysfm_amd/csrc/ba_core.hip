@@ -221,7 +221,7 @@ int ba_destroy(ba_handle* h) {
     auto& su = h->su;
     su.rc.release(); su.rp.release(); su.by_pt.release(); su.cnt.release(); su.coff.release(); su.Lint.release(); su.plo.release(); su.phi.release();
     su.iota.release(); su.crank.release(); su.flags.release(); su.vals.release(); su.key.release(); su.key2.release(); su.tkey.release(); su.tkey2.release();
-    su.rz.release(); su.rpo.release(); su.same.release(); su.tmp.release();
+    su.rz.release(); su.rpo.release(); su.same.release(); su.tmp.release(); su.blob.release();
     if (su.host) (void)hipHostFree(su.host);
     if (su.up) (void)hipHostFree(su.up);
   }
@@ -286,6 +286,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "fast_paths") ok = flag(h->opt.fast_paths);
   else if (n == "resident") ok = flag(h->opt.resident);
   else if (n == "host_setup") ok = flag(h->opt.host_setup);
+  else if (n == "packed_upload") ok = flag(h->opt.packed_upload);
   else if (n == "gm_chunk") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0 && c <= 64; if (ok) h->opt.gm_chunk = (int)c; }
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }
   else return h->fail(BA_ERR_INVALID_ARG, "ba_set_option: unknown option '%s'", name);

@@ -62,6 +62,7 @@ struct Options {
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
   bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
   bool device_lu = true;           // a reduced system the Cholesky solve reports as not positive definite is solved again by the cyclic reduction with LU nodes
+  bool packed_upload = true;       // ... and their arrays travel as one copy + one scatter launch (off: a copy per array)
   bool host_setup = true;          // ba_set_problem: small problems are ordered on the host (off: always the device pipeline)
   bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
@@ -156,6 +157,7 @@ struct ba_handle {
     DevBuf<unsigned long long> key, key2, tkey, tkey2;
     DevBuf<double2> rz;
     DevBuf<unsigned char> rpo, same, tmp;
+    DevBuf<unsigned> blob;             // device mirror of a packed upload (k_setup_scatter)
     void* host = nullptr;              // pinned staging for the read-backs
     size_t host_bytes = 0;
     void* up = nullptr;                // pinned arena for the small uploads

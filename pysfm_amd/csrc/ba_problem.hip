@@ -59,6 +59,66 @@ hipError_t stage_h2d(ba_handle* h, void* dst, const void* src, size_t bytes) {
 }
 
 
+// ---- a dozen small uploads as ONE copy and ONE launch: the pieces are packed behind a table of (destination, offset, words)
+// in the pinned arena, the block goes to a device mirror in one hipMemcpyAsync, and k_setup_scatter moves every piece to its
+// buffer.  (An asynchronous copy costs 4 - 5 us of host time whatever its size; the sliding-window caller's problem has nine.)
+constexpr int kPackMaxPieces = 30;
+struct PackPiece { unsigned long long dst; unsigned off_words; unsigned words; };
+struct PackTable { int n; int total_words; PackPiece piece[kPackMaxPieces]; };
+constexpr size_t kPackHeaderBytes = 512;
+static_assert(sizeof(PackTable) <= kPackHeaderBytes, "the table sits at the head of the block");
+
+__global__ __launch_bounds__(256) void k_setup_scatter(const unsigned* __restrict__ blob) {
+  const PackTable* tab = reinterpret_cast<const PackTable*>(blob);
+  const unsigned w = blockIdx.x * 256 + threadIdx.x;
+  if ((int)w >= tab->total_words) return;
+  int d = 0;
+  while (d + 1 < tab->n && w >= tab->piece[d + 1].off_words) ++d;
+  const PackPiece pc = tab->piece[d];
+  reinterpret_cast<unsigned*>(pc.dst)[w - pc.off_words] = blob[kPackHeaderBytes / 4 + w];
+}
+
+struct Packer {
+  ba_handle* h;
+  char* base = nullptr;          // the block in the arena
+  PackTable* tab = nullptr;
+  size_t cap = 0;
+  bool ok = false;
+  explicit Packer(ba_handle* h_, size_t payload_bytes) : h(h_) {
+    auto& su = h->su;
+    const size_t need = kPackHeaderBytes + payload_bytes + 64 * kPackMaxPieces;
+    const size_t start = (su.up_used + 63) & ~(size_t)63;
+    if (!su.up || start + need > su.up_bytes) return;           // (does not fit the arena: the caller copies piece by piece)
+    base = static_cast<char*>(su.up) + start;
+    su.up_used = start + need;
+    tab = reinterpret_cast<PackTable*>(base);
+    tab->n = 0; tab->total_words = 0;
+    cap = payload_bytes / 4 + 16 * kPackMaxPieces;
+    ok = true;
+  }
+  // dst must have room for the piece rounded up to 4 bytes
+  void add(void* dst, const void* src, size_t bytes) {
+    const unsigned words = (unsigned)((bytes + 3) / 4);
+    if (!words) return;
+    PackPiece& pc = tab->piece[tab->n++];
+    pc.dst = reinterpret_cast<unsigned long long>(dst);
+    pc.off_words = (unsigned)tab->total_words;
+    pc.words = words;
+    std::memcpy(base + kPackHeaderBytes + (size_t)tab->total_words * 4, src, bytes);
+    tab->total_words += (int)words;
+  }
+  int flush() {
+    if (!tab->n) return BA_OK;
+    const size_t bytes = kPackHeaderBytes + (size_t)tab->total_words * 4;
+    HIPCHECK(h, h->su.blob.resize((bytes + 3) / 4 + 64));
+    HIPCHECK(h, hipMemcpyAsync(h->su.blob.p, base, bytes, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_setup_scatter, dim3((unsigned)((tab->total_words + 255) / 256)), dim3(256), 0, h->stream, h->su.blob.p);
+    HIPCHECK(h, hipGetLastError());
+    return BA_OK;
+  }
+};
+
+
 // ---- ba_set_problem's front end for SMALL problems, on the host.  The device pipeline (a dozen launches, a radix sort, two
 // synchronisations) costs 0.2 ms whatever the size; the sliding-window caller sets a problem of a thousand observations per
 // frame, where the same work is a few microseconds of one core.  Same decisions, same internal order (the track key is the
@@ -66,7 +126,7 @@ hipError_t stage_h2d(ba_handle* h, void* dst, const void* src, size_t bytes) {
 constexpr long long kHostFrontMaxObs = 8192;
 
 int host_front_end(ba_handle* h, int nc, int nt, long long N, int nco, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_z,
-                   const int32_t* cam_opt_pos, const uint8_t* pt_opt, const std::vector<int>& crank, int rank_bits, int* hflags, int* hoff,
+                   const int32_t* cam_opt_pos, const uint8_t* pt_opt, const std::vector<int>& crank, const std::vector<int>& opt_cam, int rank_bits, int* hflags, int* hoff,
                    int* hplo, int* hphi, int* hperm, unsigned char* same) {
   typedef unsigned long long u64;
   for (int i = 0; i < SF_COUNT; ++i) hflags[i] = (i == SF_BAD || i == SF_DUP) ? 0x7fffffff : 0;
@@ -160,19 +220,25 @@ int host_front_end(ba_handle* h, int nc, int nt, long long N, int nco, const int
     same[i] = sm ? 1 : 0;
   }
   hflags[SF_MAXL] = maxL; hflags[SF_HB] = hbw;
-  if (N) {
-    HIPCHECK(h, stage_h2d(h, h->obs_cam.p, icam.data(), (size_t)N * sizeof(int)));
-    HIPCHECK(h, stage_h2d(h, h->obs_pt.p, ipt.data(), (size_t)N * sizeof(int)));
-    HIPCHECK(h, stage_h2d(h, h->obs_z.p, iz.data(), (size_t)N * sizeof(double2)));
-    HIPCHECK(h, stage_h2d(h, h->d_operm.p, operm.data(), (size_t)N * sizeof(int)));
-  }
-  HIPCHECK(h, stage_h2d(h, h->pt_off.p, hoff, ((size_t)nt + 1) * sizeof(int)));
-  if (nt) {
-    HIPCHECK(h, stage_h2d(h, h->pt_opt.p, iopt.data(), (size_t)nt));
-    HIPCHECK(h, stage_h2d(h, h->d_pperm.p, hperm, (size_t)nt * sizeof(int)));
-  }
+  Packer pk(h, (size_t)N * 32 + (size_t)nt * 16 + (size_t)nc * 8 + 256);
+  auto put = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    if (!bytes) return hipSuccess;
+    if (pk.ok && h->opt.packed_upload && pk.tab->n < kPackMaxPieces) { pk.add(dst, src, bytes); return hipSuccess; }
+    return stage_h2d(h, dst, src, bytes);
+  };
+  HIPCHECK(h, put(h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
+  HIPCHECK(h, put(h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
+  HIPCHECK(h, put(h->obs_cam.p, icam.data(), (size_t)N * sizeof(int)));
+  HIPCHECK(h, put(h->obs_pt.p, ipt.data(), (size_t)N * sizeof(int)));
+  HIPCHECK(h, put(h->obs_z.p, iz.data(), (size_t)N * sizeof(double2)));
+  HIPCHECK(h, put(h->d_operm.p, operm.data(), (size_t)N * sizeof(int)));
+  HIPCHECK(h, put(h->pt_off.p, hoff, ((size_t)nt + 1) * sizeof(int)));
+  HIPCHECK(h, put(h->pt_opt.p, iopt.data(), (size_t)nt));
+  HIPCHECK(h, put(h->d_pperm.p, hperm, (size_t)nt * sizeof(int)));
+  if (pk.ok && h->opt.packed_upload) { const int rc = pk.flush(); if (rc != BA_OK) return rc; }
   return BA_OK;
 }
+
 
 }  // namespace
 
@@ -706,14 +772,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   HIPCHECK(h, su.tkey.resize(std::max(1, nt))); HIPCHECK(h, su.tkey2.resize(std::max(1, nt))); HIPCHECK(h, su.iota.resize(std::max(1, nt)));
   HIPCHECK(h, h->d_pperm.resize(std::max(1, nt))); HIPCHECK(h, h->d_operm.resize(std::max<size_t>(1, N)));
   HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, N)));
-  HIPCHECK(h, h->pt_off.resize((size_t)nt + 2)); HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc))); HIPCHECK(h, h->pt_opt.resize(std::max(1, nt)));
+  HIPCHECK(h, h->pt_off.resize((size_t)nt + 2)); HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc))); HIPCHECK(h, h->pt_opt.resize((size_t)nt + 4));
   HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
   const size_t staging = ((size_t)3 * nt + 8) * sizeof(int) + (size_t)nt + SF_COUNT * sizeof(int) + (size_t)nt * sizeof(int) + 64;
   HIPCHECK(h, pinned_staging(h, staging));
   arena_reset(h);
   su.up_pageable = false;
-  if (nc) HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
-  HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
   int* hflags = static_cast<int*>(su.host);
   int* hoff = hflags + SF_COUNT;
   int* hplo = hoff + nt + 2;
@@ -723,9 +787,11 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   const unsigned long long* sorted_keys = nullptr;
   const bool host_front = sort_points && N <= kHostFrontMaxObs && h->opt.host_setup;
   if (host_front) {
-    const int rc = host_front_end(h, nc, nt, N, nco, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, crank, rank_bits, hflags, hoff, hplo, hphi, hperm, same);
+    const int rc = host_front_end(h, nc, nt, N, nco, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, crank, opt_cam, rank_bits, hflags, hoff, hplo, hphi, hperm, same);
     if (rc != BA_OK) return rc;
   } else {
+  if (nc) HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
+  HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
   if (N) {
     HIPCHECK(h, stage_h2d(h, su.rc.p, obs_cam, (size_t)N * sizeof(int)));
     HIPCHECK(h, stage_h2d(h, su.rp.p, obs_pt, (size_t)N * sizeof(int)));
