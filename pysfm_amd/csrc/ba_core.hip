@@ -227,6 +227,7 @@ int ba_destroy(ba_handle* h) {
   }
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->res_log) (void)hipHostFree(h->res_log);
+  if (h->res_out) (void)hipHostFree(h->res_out);
   if (h->io) (void)hipHostFree(h->io);
   if (h->res_trace) (void)hipHostFree(h->res_trace);
   h->res_xb.release(); h->res_epoch.release(); h->res_cost.release();
@@ -252,6 +253,7 @@ int ba_debug_poison(ba_handle* h) {
   HIPCHECK(h, hipGetLastError());
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   h->have_params[1 - h->cur] = false;
+  h->params_written(1 - h->cur);
   h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
   h->inv_valid = h->fac_valid = h->point_blocks_valid = h->cam_blocks_valid = false;
   return BA_OK;
@@ -381,6 +383,7 @@ int ba_set_params(ba_handle* h, int which, const double* R, const double* t, con
   REQUIRE(h, (h->nc == 0 || (R && t)) && (h->nt == 0 || X), BA_ERR_INVALID_ARG, "ba_set_params: NULL argument");
   HIPCHECK(h, hipSetDevice(h->device));
   const int p = h->phys(which);
+  h->params_written(p);
   const size_t ncam = (size_t)h->nc * 12, nx = (size_t)h->nt * 3;
   const bool small = (ncam + nx) * sizeof(double) <= kIoMaxBytes;
   std::vector<double> pageable;
@@ -412,6 +415,20 @@ int ba_get_params(ba_handle* h, int which, double* R, double* t, double* X) {
   REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_get_params: bad parameter set");
   const int p = h->phys(which);
   REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_get_params: parameter set is empty");
+  if (h->res_out_phys == p && h->res_out) {
+    // the resident loop left this very set in pinned memory (internal point order): no copy, no synchronisation
+    const double* src = h->res_out;
+    for (int i = 0; i < h->nc; ++i) {
+      if (R) std::memcpy(R + (size_t)i * 9, src + (size_t)i * 12, 9 * sizeof(double));
+      if (t) std::memcpy(t + (size_t)i * 3, src + (size_t)i * 12 + 9, 3 * sizeof(double));
+    }
+    if (X) {
+      const double* xs = src + (size_t)h->nc * 12;
+      if (h->pperm.empty()) std::memcpy(X, xs, (size_t)h->nt * 3 * sizeof(double));
+      else for (int i = 0; i < h->nt; ++i) std::memcpy(X + (size_t)h->pperm[i] * 3, xs + (size_t)i * 3, 3 * sizeof(double));
+    }
+    return BA_OK;
+  }
   HIPCHECK(h, hipSetDevice(h->device));
   const size_t ncam = (size_t)h->nc * 12, nx = X ? (size_t)h->nt * 3 : 0;
   const bool small = (ncam + nx) * sizeof(double) <= kIoMaxBytes;

@@ -209,6 +209,10 @@ struct ba_handle {
   void* io = nullptr;                  // pinned staging of ba_set_params / ba_get_params (small parameter sets)
   size_t io_bytes = 0;
   bool io_pending = false;             // an upload from it may still be in flight
+  double* res_out = nullptr;           // ... and, pinned, the parameter set it ended on: [nc x 12 | nt x 3] in the internal order
+  size_t res_out_doubles = 0;
+  int res_out_phys = -1;               // the physical set the copy mirrors (-1: none; whoever writes a set says so: params_written)
+  void params_written(int phys) { if (res_out_phys == phys) res_out_phys = -1; }
   void* res_trace = nullptr;           // ... and, with option solve_trace, clock stamps of its first 64 trials
   int cost_blocks = 0;      // partials the last k_cost launch wrote
   bool cost_fused = false;  // the last ba_backsubstitute evaluated the trial cost as well (k_backsub_groups)

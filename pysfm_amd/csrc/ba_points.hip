@@ -215,6 +215,7 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
   }
   // inside ba_lm_trial the update of the trial parameter set rides along (one launch less)
   const bool fuse_update = h->defer && which == BA_PARAMS_CUR && h->nt > 0;
+  if (fuse_update) h->params_written(1 - p);
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_BACKSUB);
     const long long threads = (long long)h->nt << h->glog;
@@ -247,6 +248,7 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, (src == 0 || src == 1) && (dst == 0 || dst == 1), BA_ERR_INVALID_ARG, "ba_apply_update: bad parameter set");
   const int ps = h->phys(src), pd = h->phys(dst);
+  h->params_written(pd);
   REQUIRE(h, h->have_problem && h->have_params[ps], BA_ERR_STATE, "ba_apply_update: source parameter set is empty");
   REQUIRE(h, (motion == nullptr) == (structure == nullptr), BA_ERR_INVALID_ARG,
           "ba_apply_update: give both motion and structure, or neither");
@@ -278,6 +280,7 @@ int ba_triangulate(ba_handle* h, int which, double rcond, double* X) {
   REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_triangulate: bad parameter set");
   const int p = h->phys(which);
   REQUIRE(h, h->have_problem && h->have_params[p], BA_ERR_STATE, "ba_triangulate: set problem and parameters first");
+  h->params_written(p);
   HIPCHECK(h, hipSetDevice(h->device));
   if (rcond < 0) rcond = 2.220446049250313e-16 * std::max<double>(3.0, 2.0 * 64);   // numpy's default scale
   // QR of the 2L x 3 system (k_triangulate): full-rank systems are solved to cond(A) * eps like lstsq's; the rank decision

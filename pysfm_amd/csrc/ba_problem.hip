@@ -739,6 +739,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   REQUIRE(h, nobs == 0 || (obs_cam && obs_pt && obs_z), BA_ERR_INVALID_ARG, "ba_set_problem: NULL observation array");
   HIPCHECK(h, hipSetDevice(h->device));
   h->have_problem = false;
+  h->res_out_phys = -1;
 
   // ---- cameras (host, O(nc)): optimised-camera positions must be a permutation of 0..nco-1; the RANK of a camera orders a
   // track's observations: frozen cameras by index, then the optimised ones by position

@@ -93,6 +93,7 @@ struct ResidentArgs {
   Sensor sensor;
   double* cams;                 // the current set, in and out
   double* X;
+  double* out;                  // pinned host memory: the set the run ends on, [nc x 12 | nt x 3] (what ba_get_params will be asked for)
   double* xb;                   // exchange buffer: ngroups records of kResRec doubles
   long long* epoch;             // [2 * ngroups]: what each workgroup has published (partial sums | trial cost)
   long long epoch0;             // epochs of this launch start above it (the words are never reset)
@@ -807,12 +808,15 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   }
 
   // ---- the current set back to device memory (my points; workgroup 0: the cameras), the state of the schedule to the log
-  if (accepted_any) {
+  {
     const double* cm_cur = camL + cur * nc * 12;
     const double* X_cur = XL + cur * kResP * 3;
     if (grp == 0)
-      for (int i = tid; i < nc * 12; i += kResThreads) A.cams[i] = cm_cur[i];
-    for (int i = tid; i < np * 3; i += kResThreads) A.X[(size_t)p0 * 3 + i] = X_cur[i];
+      for (int i = tid; i < nc * 12; i += kResThreads) { if (accepted_any) A.cams[i] = cm_cur[i]; A.out[i] = cm_cur[i]; }
+    for (int i = tid; i < np * 3; i += kResThreads) {
+      if (accepted_any) A.X[(size_t)p0 * 3 + i] = X_cur[i];
+      A.out[(size_t)nc * 12 + (size_t)p0 * 3 + i] = X_cur[i];
+    }
   }
   if (grp == 0 && tid == 0) {
     ResidentLog* g = A.log;

@@ -71,6 +71,16 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   }
   if (!h->res_log) HIPCHECK(h, hipHostMalloc(&h->res_log, sizeof(ResidentLog), hipHostMallocDefault));
   {
+    const size_t need = (size_t)h->nc * 12 + (size_t)h->nt * 3;
+    if (h->res_out_doubles < need) {
+      if (h->res_out) (void)hipHostFree(h->res_out);
+      h->res_out = nullptr; h->res_out_doubles = 0;
+      HIPCHECK(h, hipHostMalloc((void**)&h->res_out, (need + 1024) * sizeof(double), hipHostMallocDefault));
+      h->res_out_doubles = need + 1024;
+    }
+    h->res_out_phys = -1;
+  }
+  {
     // (the kernel has a few static LDS words of its own: ask for less than the whole 160 KB)
     const void* fn = (const void*)k_resident_lm;
     if (std::find(h->lds_attr_done.begin(), h->lds_attr_done.end(), fn) == h->lds_attr_done.end()) {
@@ -86,7 +96,7 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   for (int i = 0; i < 9; ++i) a.K[i] = h->K[i];
   a.sensor = h->sensor;
   if (!h->opt.fast_paths) a.sensor.fast = 0;
-  a.cams = h->cams[p].p; a.X = h->X[p].p; a.xb = h->res_xb.p; a.epoch = h->res_epoch.p; a.epoch0 = h->res_epoch0;
+  a.cams = h->cams[p].p; a.X = h->X[p].p; a.out = h->res_out; a.xb = h->res_xb.p; a.epoch = h->res_epoch.p; a.epoch0 = h->res_epoch0;
   a.cost_slots = h->res_cost.p; a.parity0 = h->res_parity;
   a.max_steps = max_steps; a.max_trials = kResMaxTrials; a.nsteps = steps_taken; a.in_step = in_step ? 1 : 0; a.converged = converged ? 1 : 0;
   a.damping = damping; a.improvement_threshold = improvement_threshold; a.rcond = pinv_rcond; a.cur_cost = cur_cost;
@@ -106,6 +116,7 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   REQUIRE(h, a.log->ntrials >= 0, BA_ERR_HIP, "ba_lm_resident: the kernel left no log");
   h->res_epoch0 += 2 * ((long long)a.log->ntrials + 2);
   h->res_parity = (h->res_parity + a.log->ntrials) & 1;
+  if (a.log->exit_reason != RES_TIMED_OUT) h->res_out_phys = p;      // (the kernel left the set it ended on in pinned memory)
   if (a.log->exit_reason == RES_TIMED_OUT) {
     // a workgroup gave up waiting for the others: a fault of the kernel or of the GPU, never a property of the problem
     (void)hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream);
