@@ -144,7 +144,6 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
 }
 
 typedef double res_acc __attribute__((ext_vector_type(4)));
-typedef double res_d2 __attribute__((ext_vector_type(2)));
 
 // what crosses workgroups inside the launch: relaxed agent-scope accesses (they bypass / write through the caches that are
 // not coherent across the chip's eight L2s; no fences - ba_bcr.h has the long story)
