@@ -1,4 +1,5 @@
-// ba_resident.hip - ba_lm_resident: the Levenberg-Marquardt loop of a small problem as one resident workgroup (ba_resident.h).
+// ba_resident.hip - ba_lm_resident: the Levenberg-Marquardt loop of a small problem as one resident launch of a few
+// workgroups (ba_resident.h).
 #include "ba_internal.h"
 #include "ba_resident.h"
 
@@ -31,14 +32,10 @@ int resident_reset_cost_words(ba_handle* h) {
   return BA_OK;
 }
 
+// ... and its sensor model, its state and the handle's mode allow it too
 bool resident_fits(const ba_handle* h, ResidentLds* lds_out) {
-  if (!h->opt.resident || !h->have_problem || h->comm || h->dense_mode) return false;
-  if (h->sensor.kind == SENSOR_TABLE) return false;
-  if (h->nco < 1 || h->nco > kResMaxNco || h->nc > kResMaxNc || h->nt < 1 || h->nt > kResMaxNt) return false;
-  if (h->group_maxL < 1 || h->group_maxL > kResMaxL || h->nobs < 1 || h->nobs > (1 << 20)) return false;
-  const ResidentLds l = resident_lds(h->nc, h->nco, h->group_maxL);
-  if (l.bytes > 157 * 1024) return false;
-  if (lds_out) *lds_out = l;
+  if (!h->have_problem || h->dense_mode || h->sensor.kind == SENSOR_TABLE || !resident_shape(h)) return false;
+  if (lds_out) *lds_out = resident_lds(h->nc, h->nco, h->group_maxL);
   return true;
 }
 
@@ -57,7 +54,7 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   REQUIRE(h, log, BA_ERR_INVALID_ARG, "ba_lm_resident: NULL log");
   REQUIRE(h, h->have_problem && h->have_params[h->phys(BA_PARAMS_CUR)], BA_ERR_STATE, "ba_lm_resident: set problem and parameters first");
   ResidentLds lds;
-  REQUIRE(h, resident_fits(h, &lds), BA_ERR_STATE, "ba_lm_resident: the problem does not fit one compute unit (ba_lm_resident_fits)");
+  REQUIRE(h, resident_fits(h, &lds), BA_ERR_STATE, "ba_lm_resident: not a problem for the resident loop (ba_lm_resident_fits)");
   HIPCHECK(h, hipSetDevice(h->device));
   const int G = (h->nt + kResP - 1) / kResP;
   if (h->res_xb.n < (size_t)G * kResRec || h->res_epoch.n < (size_t)2 * G) {
