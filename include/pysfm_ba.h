@@ -285,7 +285,7 @@ int ba_lm_trial_finish(ba_handle* h);
 
 /* ---- the whole loop of BundleAdjuster.optimize() / step() (bundle_adjuster.py:117-162) for a problem that fits a few compute
  * units, as one resident launch of a few workgroups (pysfm_amd/csrc/ba_resident.h): <= 16 optimised cameras, <= 32 cameras, <= 1024 tracks of <= 16
- * observations, a closed-form sensor model, no parameter mask, no communicator.  The sliding-window caller
+ * observations, no parameter mask, no communicator.  The sliding-window caller
  * (window_slam.py:17-48) solves one such problem per frame; at that size a trial costs 68 us through ba_lm_trial (six
  * launches and one synchronisation for a thousand observations) and ~31 us here, with no round trip to the host between trials.
  *   ba_lm_resident_fits  1 when the handle's problem, sensor model and options allow it, else 0

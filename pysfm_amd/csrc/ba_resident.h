@@ -228,6 +228,9 @@ __device__ __forceinline__ void res_update_panel(double* __restrict__ Sm, int ti
     default: fn<6>(__VA_ARGS__); break;                                                       \
   }
 
+// TABLE: the sensor model may be a caller-defined robustifier sampled into a table (ba_math.h SENSOR_TABLE); its own instance,
+// so that the closed-form models keep their registers
+template <bool TABLE>
 __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
         double cm[12], e[2];
 #pragma unroll
         for (int i = 0; i < 12; ++i) cm[i] = cm_cur[ocam * 12 + i];
-        obs_linearize<false>(A.K, cm, x, z.x, z.y, A.sensor, e, r, Jc, Jp);
+        obs_linearize<TABLE>(A.K, cm, x, z.x, z.y, A.sensor, e, r, Jc, Jp);
         if (pos >= 0 && popt) lin_cost = r[0] * r[0] + r[1] * r[1];
         if (pos >= 0) {
           double* jq = JC + (pl * maxL + j) * kResJcLd;
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
           double cm[12], e[2], r[2];
 #pragma unroll
           for (int q = 0; q < 12; ++q) cm[q] = cm_tr[ocam * 12 + q];
-          obs_residual<false>(A.K, cm, xt, z.x, z.y, A.sensor, e, r);
+          obs_residual<TABLE>(A.K, cm, xt, z.x, z.y, A.sensor, e, r);
           tc = r[0] * r[0] + r[1] * r[1];
         }
       }

@@ -34,7 +34,7 @@ int resident_reset_cost_words(ba_handle* h) {
 
 // ... and its sensor model, its state and the handle's mode allow it too
 bool resident_fits(const ba_handle* h, ResidentLds* lds_out) {
-  if (!h->have_problem || h->dense_mode || h->sensor.kind == SENSOR_TABLE || !resident_shape(h)) return false;
+  if (!h->have_problem || h->dense_mode || !resident_shape(h)) return false;
   if (lds_out) *lds_out = resident_lds(h->nc, h->nco, h->group_maxL);
   return true;
 }
@@ -79,7 +79,7 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   }
   {
     // (the kernel has a few static LDS words of its own: ask for less than the whole 160 KB)
-    const void* fn = (const void*)k_resident_lm;
+    const void* fn = h->sensor.kind == SENSOR_TABLE ? (const void*)k_resident_lm<true> : (const void*)k_resident_lm<false>;
     if (std::find(h->lds_attr_done.begin(), h->lds_attr_done.end(), fn) == h->lds_attr_done.end()) {
       HIPCHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
       h->lds_attr_done.push_back(fn);
@@ -107,7 +107,8 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
     a.dbg = reinterpret_cast<double*>(a.trace + 64 * 16);
   }
   a.log->ntrials = -1;
-  hipLaunchKernelGGL(k_resident_lm, dim3(G), dim3(kResThreads), lds.bytes, h->stream, a);
+  if (h->sensor.kind == SENSOR_TABLE) hipLaunchKernelGGL(k_resident_lm<true>, dim3(G), dim3(kResThreads), lds.bytes, h->stream, a);
+  else hipLaunchKernelGGL(k_resident_lm<false>, dim3(G), dim3(kResThreads), lds.bytes, h->stream, a);
   HIPCHECK(h, hipGetLastError());
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   REQUIRE(h, a.log->ntrials >= 0, BA_ERR_HIP, "ba_lm_resident: the kernel left no log");
