@@ -285,7 +285,7 @@ int ba_lm_trial_finish(ba_handle* h);
 
 /* ---- the whole loop of BundleAdjuster.optimize() / step() (bundle_adjuster.py:117-162) for a problem that fits a few compute
  * units, as one resident launch of a few workgroups (pysfm_amd/csrc/ba_resident.h): <= 16 optimised cameras, <= 32 cameras, <= 1024 tracks of <= 16
- * observations, no parameter mask, no communicator.  The sliding-window caller
+ * observations, no communicator.  The sliding-window caller
  * (window_slam.py:17-48) solves one such problem per frame; at that size a trial costs 68 us through ba_lm_trial (six
  * launches and one synchronisation for a thousand observations) and ~31 us here, with no round trip to the host between trials.
  *   ba_lm_resident_fits  1 when the handle's problem, sensor model and options allow it, else 0
@@ -307,7 +307,8 @@ typedef struct ba_resident_log {
 } ba_resident_log;
 int ba_lm_resident_fits(ba_handle* h);
 int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
-                   double improvement_threshold, double pinv_rcond, double cur_cost, ba_resident_log* log);
+                   double improvement_threshold, double pinv_rcond, double cur_cost,
+                   const uint8_t* cam_param_mask /* [6 nco] as in ba_solve_reduced, or NULL */, ba_resident_log* log);
 /* with option solve_trace: 16 words per trial for the first 64 trials of the last ba_lm_resident - wall_clock64 (100 MHz) at the
  * phase boundaries [0..7], [8] = 1 when the trial linearised */
 int ba_lm_resident_trace(ba_handle* h, int64_t* out /* [64 * 16] */);

@@ -313,15 +313,17 @@ class HipBackend(object):
         """ba_lm_resident_fits: does the problem (and its sensor model, and the options) fit the one-workgroup loop?"""
         return bool(self._lib.ba_lm_resident_fits(self._h))
 
-    def lm_resident(self, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, rcond, cur_cost):
+    def lm_resident(self, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, rcond, cur_cost, cam_param_mask=None):
         """ba_lm_resident: the loop of optimize() / step() on the device, from the given state of the schedule.
         Returns the log (capi.ResidentLog); the current parameter set has moved iff log.accepted."""
         if getattr(self, '_res_log', None) is None:
             self._res_log = capi.ResidentLog()
         log = self._res_log
+        mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
+        assert mask is None or mask.shape == (self.nco * 6,)
         self._check(self._lib.ba_lm_resident(self._h, int(max_steps), int(steps_taken), int(bool(in_step)), int(bool(converged)),
                                              float(damping), float(improvement_threshold), -1.0 if rcond is None else float(rcond),
-                                             -1.0 if cur_cost is None else float(cur_cost), C.byref(log)))
+                                             -1.0 if cur_cost is None else float(cur_cost), capi.bptr(mask), C.byref(log)))
         return log
 
     def lm_resident_debug(self):

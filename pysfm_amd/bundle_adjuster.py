@@ -314,7 +314,7 @@ class BundleAdjuster(object):
         if self._resident_applies(param_mask):
             self._cur_cost = None
             self.costs = []
-            self._resident_steps(max_steps, improvement_threshold)
+            self._resident_steps(max_steps, improvement_threshold, param_mask)
         else:
             self._cur_cost = self._cost(PARAMS_CUR)
             self.costs = [self._cur_cost]
@@ -333,7 +333,7 @@ class BundleAdjuster(object):
             if self.converged:                       # (the loop below would not run either)
                 self.num_steps += 1
                 return True
-            return self._resident_steps(self.num_steps + 1, improvement_threshold)
+            return self._resident_steps(self.num_steps + 1, improvement_threshold, param_mask)
         # the cost of the current set is the cost of the trial that was accepted last (same kernel, same
         # data, deterministic summation order): no need to evaluate it again at the top of every step
         cur_cost = getattr(self, '_cur_cost', None)
@@ -369,12 +369,10 @@ class BundleAdjuster(object):
         device, replayed here from its log."""
         if not self.resident or self._comm is not None:
             return False
-        if param_mask is not None and not np.all(param_mask):
-            return False
         be = self.backend
         return hasattr(be, 'lm_resident_fits') and be.lm_resident_fits()
 
-    def _resident_steps(self, max_steps, improvement_threshold):
+    def _resident_steps(self, max_steps, improvement_threshold, param_mask=None):
         """Outer iterations until self.num_steps == max_steps or convergence (the loop of optimize(), bundle_adjuster.py:128-157),
         on the device.  A trial the resident loop cannot take (a reduced system that is not positive definite: the reference
         solves it by LU; a singular point block in plain-inverse mode: the reference raises) goes through trial() and the
@@ -382,12 +380,17 @@ class BundleAdjuster(object):
         from ._capi import RESIDENT_DONE, RESIDENT_LOG_FULL
         be = self.backend
         in_step = False
+        cam_mask = None                                 # (camera parameters deleted from the solve; the common case costs no array work)
+        if param_mask is not None:
+            cam_mask = self._cam_param_mask(param_mask)
+            if np.all(cam_mask):
+                cam_mask = None
         if not hasattr(self, 'costs') or self.costs is None:
             self.costs = []
         while True:
             steps_before = self.num_steps
             log = be.lm_resident(max_steps, self.num_steps, in_step, self.converged, self._damping, improvement_threshold,
-                                 self.SCHUR_COMPLIMENT_PINV_THRESHOLD, self._cur_cost)
+                                 self.SCHUR_COMPLIMENT_PINV_THRESHOLD, self._cur_cost, cam_mask)
             if self._cur_cost is None and log.have_cost0:
                 self._cur_cost = log.cost0
             if not self.costs and self._cur_cost is not None:
@@ -420,7 +423,7 @@ class BundleAdjuster(object):
                 self._cur_cost = self._cost(PARAMS_CUR)
                 self.costs = self.costs or [self._cur_cost]
             cur_cost = self._cur_cost
-            accepted, next_cost = self.trial(self._damping, None, cur_cost)
+            accepted, next_cost = self.trial(self._damping, param_mask, cur_cost)
             self.trial_log.append((self._damping, 'ill-conditioned' if accepted is None else 'accepted' if accepted else 'rejected', next_cost))
             if accepted:
                 self._damping *= .1

@@ -102,6 +102,8 @@ struct ResidentArgs {
   // the schedule
   int max_steps, max_trials, nsteps, in_step, converged;
   double damping, improvement_threshold, rcond, cur_cost;      // cur_cost < 0: not known yet
+  int have_mask;                // camera parameters deleted from the solve (solve_motion_normal_eqns' param_mask, bundle_adjuster.py:290-299)
+  unsigned char mask[kResMaxN]; // ... 1 = kept
   ResidentLog* log;             // pinned host memory
   long long* trace;             // optional: clock stamps at the phase boundaries of the first trials, 16 per trial (workgroup 0)
   double* dbg;                  // optional: [S | b] (lower triangle, 98 x 97) and dC (128) of the FIRST trial, for the parity tests
@@ -110,7 +112,7 @@ struct ResidentArgs {
 // LDS carve-up of a workgroup
 struct ResidentLds {
   int cam, X, HPP, Hinv, HCC, Dk, red, misc, dC, fact, z, stage;     // offsets in doubles
-  int flag_i, off_i, pos_i, tab_b, opt_b, oc_b;                // offsets in bytes
+  int flag_i, off_i, pos_i, tab_b, opt_b, oc_b, mask_b;        // offsets in bytes
   size_t bytes;
 };
 __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
@@ -139,6 +141,7 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.tab_b = (int)b; b += (size_t)kResP * nco;
   l.opt_b = (int)b; b += (size_t)kResP;
   l.oc_b = (int)b; b += (size_t)kResP * maxL;     // camera of an observation
+  l.mask_b = (int)b; b += kResMaxN;               // kept camera parameters
   l.bytes = (b + 15) & ~(size_t)15;
   return l;
 }
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   signed char* tabj = reinterpret_cast<signed char*>(base + lo.tab_b);
   unsigned char* optL = base + lo.opt_b;
   unsigned char* ocL = base + lo.oc_b;
+  unsigned char* maskL = base + lo.mask_b;
   double2* zL = reinterpret_cast<double2*>(sm + lo.z);
 
   // ---- once per launch: the cameras, my points and their observations, the (point, position) -> observation table
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   for (int i = tid; i < kResP * nco; i += kResThreads) tabj[i] = -1;
   for (int i = tid; i < nob; i += kResThreads) { ocL[i] = (unsigned char)A.obs_cam[ob0 + i]; zL[i] = A.obs_z[ob0 + i]; }
   if (tid == 0) { sflag[0] = 0; sflag[1] = 0; }
+  if (tid < kResMaxN) maskL[tid] = A.have_mask ? A.mask[tid] : 1;
   if (tid < 192) LiL[tid] = 0.0;                  // (rows 12 .. 15 stay zero; a 6-column block leaves the rest of it alone)
   bcr_identity_table(IdtL, tid);
   lds_barrier();
@@ -607,11 +612,13 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
               h = HCCl[pr * 27 + (a * (11 - a)) / 2 + b];             // entry (a, b >= a) of the upper triangle, rows first
               if (a == b) h *= dampf;
             }
-            Sm[col * kResSLd + row] = h - ssum[t][v];
+            // a deleted parameter keeps an identity row / column and a zero right-hand side: its update is zero
+            const bool kept = maskL[row] && maskL[col];
+            Sm[col * kResSLd + row] = kept ? h - ssum[t][v] : (row == col ? 1.0 : 0.0);
           }
         }
       }
-      if (tid < n) Sm[n * kResSLd + tid] = HCCl[(tid / 6) * 27 + 21 + tid % 6] - rsum;
+      if (tid < n) Sm[n * kResSLd + tid] = maskL[tid] ? HCCl[(tid / 6) * 27 + 21 + tid % 6] - rsum : 0.0;
     }
     lds_barrier();
     if (A.dbg && grp == 0 && ntrials == 0)

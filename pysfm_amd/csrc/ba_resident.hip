@@ -49,7 +49,8 @@ int ba_lm_resident_fits(ba_handle* h) {
 }
 
 int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
-                   double improvement_threshold, double pinv_rcond, double cur_cost, ba_resident_log* log) {
+                   double improvement_threshold, double pinv_rcond, double cur_cost, const uint8_t* cam_param_mask,
+                   ba_resident_log* log) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, log, BA_ERR_INVALID_ARG, "ba_lm_resident: NULL log");
   REQUIRE(h, h->have_problem && h->have_params[h->phys(BA_PARAMS_CUR)], BA_ERR_STATE, "ba_lm_resident: set problem and parameters first");
@@ -97,6 +98,9 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   a.cost_slots = h->res_cost.p; a.parity0 = h->res_parity;
   a.max_steps = max_steps; a.max_trials = kResMaxTrials; a.nsteps = steps_taken; a.in_step = in_step ? 1 : 0; a.converged = converged ? 1 : 0;
   a.damping = damping; a.improvement_threshold = improvement_threshold; a.rcond = pinv_rcond; a.cur_cost = cur_cost;
+  a.have_mask = cam_param_mask ? 1 : 0;
+  memset(a.mask, 1, sizeof a.mask);
+  if (cam_param_mask) for (int i = 0; i < 6 * h->nco; ++i) a.mask[i] = cam_param_mask[i] ? 1 : 0;
   a.log = static_cast<ResidentLog*>(h->res_log);
   a.trace = nullptr;
   a.dbg = nullptr;

@@ -637,7 +637,7 @@ class _ResidentDouble(OracleBackend):
     def lm_resident_fits(self):
         return True
 
-    def lm_resident(self, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, rcond, cur_cost):
+    def lm_resident(self, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, rcond, cur_cost, cam_param_mask=None):
         from types import SimpleNamespace
         self.launches += 1
         log = SimpleNamespace(ntrials=0, nsteps=steps_taken, converged=int(bool(converged)), in_step=int(bool(in_step)), exit_reason=0,
@@ -664,7 +664,7 @@ class _ResidentDouble(OracleBackend):
                 log.exit_reason, log.exit_info = 2, 7
                 break
             self.seen += 1
-            self.linearize(0); self.schur(0, log.damping, rcond); self.solve_reduced(None)
+            self.linearize(0); self.schur(0, log.damping, rcond); self.solve_reduced(cam_param_mask)
             self.backsubstitute(0, fetch=False); self.apply_update(0, 1)
             cost = self.cost(1)
             acc = cost < log.cur_cost
@@ -710,11 +710,17 @@ def test_the_log_of_the_resident_loop_replays_into_the_reference_walk(name, step
     off.resident = False
     off.optimize(max_steps=2)
     assert off.backend.launches == 0
+    # a mask over camera parameters travels with the launch: the same walk as the Python loop with that mask
+    nparams = len(ba.optim_camera_ids) * 6 + len(ba.optim_track_ids) * 3
+    m = np.ones(nparams, bool)
+    m[[2, 7]] = False
+    pm = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    pm.optimize(param_mask=m, max_steps=3)
     masked = BundleAdjuster(bundle_of(g), backend=_ResidentDouble(), verbose=False)
-    m = np.ones(masked.num_optim_params() if hasattr(masked, 'num_optim_params') else len(masked.optim_camera_ids) * 6 + len(masked.optim_track_ids) * 3, bool)
-    m[2] = False
-    masked.optimize(param_mask=m, max_steps=2)
-    assert masked.backend.launches == 0
+    masked.optimize(param_mask=m, max_steps=3)
+    assert masked.backend.launches >= 1
+    assert [(d, o) for d, o, _ in masked.trial_log] == [(d, o) for d, o, _ in pm.trial_log]
+    close(masked.costs, pm.costs, 1e-12)
 
 
 def test_cameras_over_stacked_arrays_behave_like_a_list():
