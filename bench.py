@@ -181,7 +181,17 @@ def cpu_baseline(s, loop_obs=10000):
     c1 = O.cost(sen, s['K'], R2, t2, X2, *a[4:], *flags)
     dt = time.time() - t0 - t_asm                      # (the stand-alone assembly above is timed on its own, not twice)
     N = len(s['obs_cam'])
-    return dict(value=N / dt, unit='obs/s', cores=int(threads), kind='port',
+    # (iii) the reference's own scale, BASELINE configs[0]: the whole optimize() of the 5-camera x 50-track scene of small_problems()
+    from pysfm_amd import synthetic_data as sd1
+    s1 = sd1.generate_banded_scene(5, 50, track_len=5, init_perturbation=.03)
+    a1 = (s1['K'], s1['R0'], s1['t0'], s1['X0'], s1['obs_cam'], s1['obs_pt'], s1['obs_z'])
+    f1 = (np.arange(5, dtype=np.int32) - 1, np.ones(50, bool))
+    t1 = time.time()
+    r1 = O.lm_optimize(sen, *a1, *f1)
+    dt1 = time.time() - t1
+    config1 = {'optimize_s': dt1, 'costs': len(r1['costs']), 'cores': int(threads),
+               'sample': 'oracle lm_optimize (vectorised port) of the 5-camera / 50-track / 250-observation scene; small_problems.config1_* is the same scene on the GPU'}
+    return dict(value=N / dt, unit='obs/s', cores=int(threads), kind='port', config1=config1,
                 sample='one full LM trial of oracle/ba_oracle.py (vectorised NumPy port of the reference) on the FULL %d-camera / '
                        '%d-point / %d-observation scene: %.1f s (cost %.4f -> %.4f); assembly alone %.2f s'
                        % (nc, nt, N, dt, c0, c1, t_asm),
