@@ -144,6 +144,20 @@ class _Cameras(list):
                 R[pos], t[pos] = c.R, c.t
         return R, t
 
+    def set_poses(self, ids, R, t):
+        """Camera ids[k] gets the pose (R[k], t[k]): the rows of the stacked arrays, or the object if one has been handed out."""
+        get = list.__getitem__
+        if len(self) > len(self._R):                      # (cameras appended since: they have no row)
+            for pos, i in enumerate(ids):
+                c = self[int(i)]
+                c.R, c.t = R[pos].copy(), t[pos].copy()
+            return
+        self._R[ids], self._t[ids] = R, t
+        for pos, i in enumerate(ids):
+            c = get(self, int(i))
+            if c is not None:
+                c.R, c.t = R[pos].copy(), t[pos].copy()
+
     def __reduce_ex__(self, protocol):
         return (list, (list(self),))                      # copies and pickles are plain lists of Camera objects
 

@@ -152,9 +152,13 @@ class BundleAdjuster(object):
         if self._host_stale:
             R, t, X = self.backend.get_params(PARAMS_CUR)
             b = self._host_bundle.clone_params()
-            for pos, idx in enumerate(self.camera_ids):
-                b.cameras[idx].R = R[pos].copy()
-                b.cameras[idx].t = t[pos].copy()
+            set_poses = getattr(b.cameras, 'set_poses', None)
+            if set_poses is not None:                # (rows of the stacked arrays: no Camera object is made for a pose nobody looks at)
+                set_poses(self.camera_ids, R, t)
+            else:
+                for pos, idx in enumerate(self.camera_ids):
+                    b.cameras[idx].R = R[pos].copy()
+                    b.cameras[idx].t = t[pos].copy()
             if self._all_tracks:
                 b.reconstruction = X
             else:
@@ -396,8 +400,8 @@ class BundleAdjuster(object):
             if not self.costs and self._cur_cost is not None:
                 self.costs = [self._cur_cost]
             step_no = steps_before
-            for k in range(log.ntrials):
-                damping, cost, acc = log.trial_damping[k], log.trial_cost[k], bool(log.trial_accepted[k])
+            nlog = log.ntrials                      # (one slice per array: a ctypes index per entry costs more than the loop body)
+            for damping, cost, acc in zip(log.trial_damping[:nlog], log.trial_cost[:nlog], log.trial_accepted[:nlog]):
                 if not in_step:
                     step_no += 1
                     in_step = True

@@ -758,3 +758,20 @@ def test_cameras_over_stacked_arrays_behave_like_a_list():
     assert e.cameras[3] in e.cameras and e.cameras.index(e.cameras[3]) == 3
     e.cameras[1:3] = [Camera(np.eye(3), np.zeros(3)), Camera(np.eye(3), np.ones(3))]
     assert np.array_equal(e.ts()[2], np.ones(3)) and np.array_equal(e.ts()[3], b.ts()[3])
+
+
+def test_set_poses_of_stacked_cameras():
+    rs = np.random.RandomState(4)
+    R = np.array([np.linalg.qr(rs.randn(3, 3))[0] for _ in range(5)])
+    t = rs.randn(5, 3)
+    b = Bundle.FromObservations(np.eye(3), R, t, np.ones((2, 3)), [0, 1, 2, 3], [0, 0, 1, 1], np.zeros((4, 2)))
+    held = b.cameras[3]                                  # an object that has been handed out
+    newR, newt = np.array([np.eye(3), 2 * np.eye(3)]), np.array([[1., 2., 3.], [4., 5., 6.]])
+    b.cameras.set_poses(np.array([1, 3]), newR, newt)
+    assert np.array_equal(b.cameras[1].t, [1., 2., 3.]) and np.array_equal(held.t, [4., 5., 6.]) and np.array_equal(held.R, 2 * np.eye(3))
+    assert np.array_equal(b.ts()[[0, 2, 4]], t[[0, 2, 4]]) and np.array_equal(b.Rs()[1], np.eye(3))
+    newt[0, 0] = 99.                                     # the bundle keeps copies
+    assert b.cameras[1].t[0] == 1. and b.ts()[1, 0] == 1.
+    b.add_camera(Camera(np.eye(3), np.zeros(3)))
+    b.cameras.set_poses(np.array([5, 0]), newR, newt)
+    assert np.array_equal(b.ts()[5], newt[0]) and np.array_equal(b.ts()[0], newt[1])
