@@ -835,4 +835,8 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   }
 }
 
+#undef RES_STAMP
+#undef RES_CSTAMP
+#undef RES_SWITCH_STEP
+
 }  // namespace ba
