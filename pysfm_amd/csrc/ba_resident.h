@@ -667,10 +667,13 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       double v = rv ? Sm[n * kResSLd + lane] : 0.0;
       const double invd = rv ? dinvL[lane] : 0.0;
       double xs = 0.0;
-      for (int J = nco - 1; J >= 0; --J) {
-        double lq[6];
+      double lq[6], ln6[6];                           // the rows of this camera block, and of the next one (fetched a block ahead)
 #pragma unroll
-        for (int u = 0; u < 6; ++u) lq[u] = Sm[(6 * J + u) * kResSLd + lane];
+      for (int u = 0; u < 6; ++u) lq[u] = Sm[(6 * (nco - 1) + u) * kResSLd + lane];
+      for (int J = nco - 1; J >= 0; --J) {
+        const int Jn = max(J - 1, 0);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) ln6[u] = Sm[(6 * Jn + u) * kResSLd + lane];
 #pragma unroll
         for (int u = 5; u >= 0; --u) {
           const int q = 6 * J + u;
@@ -678,6 +681,8 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
           if (lane == q) xs = xq;
           v = fma(lane < q ? -lq[u] : 0.0, xq, v);
         }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) lq[u] = ln6[u];
       }
       if (rv) dCl[lane] = xs;
     } else if (wave == 0) {
