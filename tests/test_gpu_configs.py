@@ -833,7 +833,7 @@ def test_bench_line_keeps_the_drivers_contract():
     assert isinstance(d['config'].get('workload'), str) and 'model' not in d['config']
     assert d['value'] > 1e8 and abs(d['value'] - 1e6 * d['steps'] / (d['ms_per_step'] * 1e-3 * d['steps'])) / d['value'] < 1e-6
     r = d['roofline']
-    assert r['bound'] in ('hbm', 'mfma', 'latency') and r['unit'] in ('GB/s', 'TFLOP/s') and r['peak'] > 0
+    assert r['bound'] in ('hbm', 'mfma') and r['limited_by'] in ('hbm', 'mfma', 'latency') and r['unit'] in ('GB/s', 'TFLOP/s') and r['peak'] > 0
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['avg_launch_ms'] > 0 and r['launches'] > 0
     assert r['traffic'] is None or r['traffic'] > 0
     assert isinstance(r['traffic_stale_possible'], bool) and (r['traffic_source'] == 'live') != r['traffic_stale_possible'] or r['traffic'] is None
