@@ -65,6 +65,7 @@ struct Options {
   bool packed_upload = true;       // ... and their arrays travel as one copy + one scatter launch (off: a copy per array)
   bool host_setup = true;          // ba_set_problem: small problems are ordered on the host (off: always the device pipeline)
   bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
+  int resident_scatter_min = 5;    // ... whose launches of at least this many workgroups add their partial sums up in slices (two stages)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
 };
 

@@ -4,7 +4,7 @@
 //
 // At this size the six launches of ba_lm_trial cost 68 us per trial of which the kernels' own work is a fraction: every launch
 // starts a grid for a thousand observations, the host synchronises to take the accept / reject decision, the next trial
-// starts cold.  Here a small cluster of workgroups stays resident for the whole loop: workgroup g owns 32 points (their
+// starts cold.  Here a small cluster of workgroups stays resident for the whole loop: workgroup g owns 16 points (their
 // observations, W = Jc^T Jp in registers, their point blocks in LDS), every workgroup keeps both camera sets and takes the
 // decisions of the reference's schedule itself; workgroup 0 leaves a log of (damping, outcome, cost) per trial that the Python
 // side replays into costs / trial_log / num_steps.  No launch, no host synchronisation, no PCIe traffic between trials.
@@ -21,11 +21,16 @@
 //                fp64 matrix cores, one wavefront per 16 x 16 tile of the upper triangle; At^T y with vector FMAs
 //                                                                                                (bundle_adjuster.py:259-278)
 //   exchange 1   every workgroup publishes its partial sums (relaxed agent-scope stores, one epoch word), waits for the others
-//                and adds ALL partials in workgroup order: every workgroup holds the same [S | b], bit for bit
+//                and adds ALL partials in workgroup order: every workgroup holds the same [S | b], bit for bit.  From five
+//                workgroups on in two stages: workgroup g adds up slice g of all records, everybody fetches the record of sums
+//                (G^2 records through the fabric otherwise: 64 workgroups 110 -> 59 us per trial)
 //   4 solve      S = damped HCC - P, b = bC - At^T y; Cholesky in steps of 12 columns with the diagonal-block and panel routines
-//                of the cyclic reduction (ba_bcr_blocks.h), the updates of the next block of columns on the matrix cores, the
-//                part of them that does not depend on the current step running beside its pivot chain; the right-hand side
-//                rides along as one more row; back-substitution in one wavefront.  Every workgroup solves (redundantly: a
+//                of the cyclic reduction (ba_bcr_blocks.h), the updates of the next block of columns on the matrix cores.
+//                Wavefront 0 is the critical path and nothing else: diagonal block (its INVERSE comes out of the same chain),
+//                first tile of the panel, that tile's update of the next diagonal block straight from registers, next block;
+//                the other three do the rest of the panel, its updates and the look-ahead beside the pivot chain.  The
+//                right-hand side rides along as one more row; back-substitution in one wavefront, a block at a time through
+//                the inverses of the diagonal blocks (no chain of dependent unknowns).  Every workgroup solves (redundantly: a
 //                hand-over costs more than 10 us of one CU's time are worth).  A pivot <= 0 ends the run (exit reason 2):
 //                the host repeats that trial through the general path, which solves it as the reference's gesv would
 //                                                                                                (bundle_adjuster.py:281-312)
@@ -56,6 +61,7 @@ constexpr int kResMaxNt = kResP * kResMaxGroups;
 constexpr int kResMaxL = kResG;
 constexpr int kResSLd = kResMaxN + 1;               // row length of S in LDS (odd: rows fall on different banks)
 constexpr int kResJcLd = 15;                        // Jc (12) | r (2), padded to an odd length
+constexpr int kResSteps = kResMaxN / 12;               // block steps of the factorisation (12 columns each)
 constexpr int kResMaxTrials = 1000;
 // A workgroup's record in the exchange buffer, laid out by the THREAD that adds it up (element-major, so that a wavefront's
 // load reads 512 contiguous bytes): thread t owns 28 doubles = its (at most six) accumulator tiles, 4 doubles each, and the pairs
@@ -99,6 +105,7 @@ struct ResidentArgs {
   long long epoch0;             // epochs of this launch start above it (the words are never reset)
   double* cost_slots;           // [2][kResMaxGroups]: the workgroups' trial costs, by the parity of the trial; kResNotYet between uses
   int parity0;                  // parity of this launch's first trial
+  int scatter_min;              // launches of at least this many workgroups add the records up in slices (exchange 1 in two stages)
   // the schedule
   int max_steps, max_trials, nsteps, in_step, converged;
   double damping, improvement_threshold, rcond, cur_cost;      // cur_cost < 0: not known yet
@@ -127,7 +134,7 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.red = o; o += kResWaves * 64 + 16;            // partial right-hand sides [waves][64], wavefront partials
   l.misc = o; o += kResMisc;                   // the summed right-hand side | camera blocks | scalars
   l.dC = o; o += 128;
-  l.fact = o; o += 192 + kBcrIdtDoubles + 128;     // the factorisation: inverse of the diagonal block [16][12], identity table, 1 / diagonal
+  l.fact = o; o += kResSteps * 192 + kBcrIdtDoubles;      // the factorisation: the inverses of the diagonal blocks [step][16][12], identity table
   l.z = o; o += 2 * kResP * maxL;                 // the measurements of my points
   l.stage = o;
   const int at = kResK * kResLd + kResP * maxL * kResJcLd;
@@ -179,6 +186,34 @@ __device__ __forceinline__ bool res_wait_all(const long long* words, int stride,
   return res_uniform(*timed_out) == 0;
 }
 
+// Exchange 1 in two stages, stage one: KN elements per thread of my slice of the records, every record's in flight at once
+// (eight records a batch), added in workgroup order; the sums go to the sum record.
+template <int KN>
+__device__ __forceinline__ void res_reduce_slice(const double* __restrict__ xb, double* __restrict__ sumrec, int G, const int (&off)[4],
+                                                 const bool (&val)[4]) {
+  double s[KN];
+#pragma unroll
+  for (int k = 0; k < KN; ++k) s[k] = 0.0;
+  for (int g0 = 0; g0 < G; g0 += 8) {
+    double v[8][KN];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double* q = xb + (size_t)min(g0 + u, G - 1) * kResRec;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) v[u][k] = res_ld(q + off[k]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool in = g0 + u < G;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) s[k] += in ? v[u][k] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KN; ++k)
+    if (val[k]) res_st(sumrec + off[k], s[k]);
+}
+
 // Columns [C0, C0 + NW) of the factorisation (NW = 12, or 6 at the end), row tile `tile` (rows C0 + 16 tile ..):
 // S[row][C0 + c] -= sum over K0 <= m < K1 of L[row][m] L[C0 + c][m] on the matrix cores (a 16 x 16 tile of which NW columns are
 // wanted).  Template parameters: the k steps are known to the compiler - no load under a condition, no branch.  The accumulator
@@ -224,6 +259,67 @@ __device__ __forceinline__ void res_update_panel(double* __restrict__ Sm, int ti
   if (nw == 12) res_update_block<12 * S, 12 * S + 12, 12 * S + 12, 12>(Sm, tile, n, ln, lk);
   else res_update_block<12 * S, 12 * S + 12, 12 * S + 12, 6>(Sm, tile, n, ln, lk);
 }
+// Wavefront 0 between two diagonal blocks (the cyclic reduction's bcr_prefetch_tile0 / bcr_urgent_tile0, rows clamped to the
+// matrix): the tile that holds the next diagonal block, rows kn .. kn + 15, owes this step's panel C -= X X^T over the first 16
+// rows X of the panel - the tile wavefront 0 has just computed and still holds in registers, in the layout of both operands.
+__device__ __forceinline__ res_acc res_prefetch_tile0(const double* __restrict__ Sm, int n, int kn, int ln, int lk) {
+  res_acc acc;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) acc[v] = Sm[min(kn + lk + 4 * v, n) * kResSLd + kn + ln];
+  return acc;
+}
+
+// L^T x = y in one wavefront, lane i holding the unknown i (TWO: and 64 + i), block by block from the last: what the factorisation
+// left of a diagonal block is the INVERSE of its factor, so a block is x_k = Li^T (y_k - sum over later blocks) - twelve
+// independent broadcasts, no chain of dependent unknowns - and then comes off the unknowns before it through the panel rows.
+template <bool TWO, int NB>
+__device__ __forceinline__ void res_backsolve_block(const double* __restrict__ Sm, const double* __restrict__ Li, int k0, int lane, int c1,
+                                                    double& v0, double& v1, double& x0, double& x1) {
+  const int i0 = lane - k0, i1 = 64 + lane - k0;                         // my position in the block, by slot
+  const bool in0 = i0 >= 0 && i0 < NB, in1 = TWO && i1 >= 0 && i1 < NB;
+  const int ic = in0 ? i0 : (in1 ? i1 : 0);
+  double li[NB], r0[NB], r1[NB];
+#pragma unroll
+  for (int p = 0; p < NB; ++p) {
+    li[p] = Li[p * 12 + ic];
+    r0[p] = Sm[(k0 + p) * kResSLd + lane];
+    r1[p] = TWO ? Sm[(k0 + p) * kResSLd + c1] : 0.0;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double xa = 0.0, xb = 0.0;
+#pragma unroll
+  for (int p = 0; p < NB; ++p) {
+    const int g = k0 + p;
+    const double tp = lane_bcast(!TWO || g < 64 ? v0 : v1, g & 63);
+    if (p & 1) xb = fma(li[p], tp, xb); else xa = fma(li[p], tp, xa);
+  }
+  const double xs = in0 || in1 ? xa + xb : 0.0;
+  x0 = in0 ? xs : x0;
+  x1 = in1 ? xs : x1;
+  const bool b0 = lane < k0, b1 = 64 + lane < k0;                        // unknowns before the block
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const double xq = lane_bcast(xs, (k0 + q) & 63);
+    v0 = fma(b0 ? -r0[q] : 0.0, xq, v0);
+    if (TWO) v1 = fma(b1 ? -r1[q] : 0.0, xq, v1);
+  }
+}
+template <bool TWO>
+__device__ __forceinline__ void res_backsolve(const double* __restrict__ Sm, const double* __restrict__ LiL, double* __restrict__ dCl, int n, int lane) {
+  double v0 = lane < n ? Sm[n * kResSLd + lane] : 0.0;
+  double v1 = TWO && 64 + lane < n ? Sm[n * kResSLd + 64 + lane] : 0.0;
+  double x0 = 0.0, x1 = 0.0;
+  const int c1 = min(64 + lane, kResMaxN - 1);
+  int s = (n + 11) / 12 - 1;
+  if (n - 12 * s < 12) {                              // (an odd number of cameras: the last block has one)
+    res_backsolve_block<TWO, 6>(Sm, LiL + s * 192, 12 * s, lane, c1, v0, v1, x0, x1);
+    --s;
+  }
+  for (; s >= 0; --s) res_backsolve_block<TWO, 12>(Sm, LiL + s * 192, 12 * s, lane, c1, v0, v1, x0, x1);
+  if (lane < n) dCl[lane] = x0;
+  if (TWO && 64 + lane < n) dCl[64 + lane] = x1;
+}
+
 #define RES_SWITCH_STEP(fn, ...)                                                              \
   switch (step) {                                                                             \
     case 0: fn<0>(__VA_ARGS__); break; case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; \
@@ -252,8 +348,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   double* dCl = sm + lo.dC;
   double* miscL = sm + lo.misc;
   double* LiL = sm + lo.fact;
-  double* IdtL = LiL + 192;
-  double* dinvL = IdtL + kBcrIdtDoubles;
+  double* IdtL = LiL + kResSteps * 192;
   double* At = sm + lo.stage;
   double* JC = At + kResK * kResLd;
   double* Sm = sm + lo.stage;                      // aliases At / JC: used after the reduction only
@@ -280,7 +375,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   for (int i = tid; i < nob; i += kResThreads) { ocL[i] = (unsigned char)A.obs_cam[ob0 + i]; zL[i] = A.obs_z[ob0 + i]; }
   if (tid == 0) { sflag[0] = 0; sflag[1] = 0; }
   if (tid < kResMaxN) maskL[tid] = A.have_mask ? A.mask[tid] : 1;
-  if (tid < 192) LiL[tid] = 0.0;                  // (rows 12 .. 15 stay zero; a 6-column block leaves the rest of it alone)
+  for (int i = tid; i < kResSteps * 192; i += kResThreads) LiL[i] = 0.0;      // (rows 12 .. 15 stay zero; a 6-column block leaves the rest of its own alone)
   bcr_identity_table(IdtL, tid);
   lds_barrier();
   for (int p = tid; p < np; p += kResThreads)
@@ -537,47 +632,86 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
       double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;  // pairs `tid` and `tid + 256` of the right-hand side | camera blocks | scalars
       const bool mine2 = 2 * (tid + 256) < kResMisc;
       const double* mybase = A.xb + tid;
-      for (int g0 = 0; g0 < G; g0 += 4) {
-        // four records in flight before the first use (compiler-visible agent-scope loads: it counts the waits itself)
-        double v[4][16];
+      if (G >= A.scatter_min) {                       // (uniform over the launch)
+        // Many workgroups: a record per workgroup read by every workgroup is G^2 records through the fabric.  Two stages
+        // instead - workgroup g adds up slice g of all records (in workgroup order, as below: the same bits), publishes, and
+        // everybody fetches the one record of sums.
+        const int NR = (more_tiles ? 4 * kResOwn : 12) + 4;      // rows of 256 elements in use: tiles | the misc block
+        const int E = NR * 256;
+        const int chunk = ((E + G - 1) / G + 63) & ~63;
+        const int e0 = grp * chunk, e1 = min(e0 + chunk, E);
+        double* sumrec = A.xb + (size_t)G * kResRec;
+        for (int eb = e0; eb < e1; eb += 4 * 256) {
+          int off[4];
+          bool val[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double* q = mybase + (size_t)min(g0 + u, G - 1) * kResRec;
-#pragma unroll
-          for (int e = 0; e < 12; ++e) v[u][e] = res_ld(q + e * 256);
-          v[u][12] = res_ld(q + (4 * kResOwn) * 256); v[u][13] = res_ld(q + (4 * kResOwn + 1) * 256);
-          v[u][14] = v[u][15] = 0.0;
-          if (mine2) { v[u][14] = res_ld(q + (4 * kResOwn + 2) * 256); v[u][15] = res_ld(q + (4 * kResOwn + 3) * 256); }
+          for (int k = 0; k < 4; ++k) {
+            const int idx = eb + 256 * k + tid;
+            val[k] = idx < e1;
+            const int ic = min(idx, E - 1), r = ic >> 8;
+            off[k] = (r < NR - 4 ? r : 4 * kResOwn + r - (NR - 4)) * 256 + (ic & 255);
+          }
+          const int kn = (min(e1 - eb, 4 * 256) + 255) >> 8;
+          if (kn == 1) res_reduce_slice<1>(A.xb, sumrec, G, off, val);
+          else if (kn == 2) res_reduce_slice<2>(A.xb, sumrec, G, off, val);
+          else if (kn == 3) res_reduce_slice<3>(A.xb, sumrec, G, off, val);
+          else res_reduce_slice<4>(A.xb, sumrec, G, off, val);
         }
+        res_publish(A.epoch + 2 * grp + 1, epoch, tid);
+        if (!res_wait_all(A.epoch + 1, 2, G, epoch, tid, sflag + 1)) { exit_reason = RES_TIMED_OUT; break; }
+        const double* q = sumrec + tid;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool in = g0 + u < G;
+        for (int t = 0; t < kResOwn; ++t) {
+          if (t >= 3 && !more_tiles) break;            // (uniform)
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ssum[t][e] += in && own[t] ? v[u][4 * t + e] : 0.0;
-          m0 += in ? v[u][12] : 0.0;
-          m1 += in ? v[u][13] : 0.0;
-          m2 += in && mine2 ? v[u][14] : 0.0;
-          m3 += in && mine2 ? v[u][15] : 0.0;
+          for (int e = 0; e < 4; ++e) ssum[t][e] = res_ld(q + (4 * t + e) * 256);      // (tiles that are not mine: never used)
         }
-      }
-      if (more_tiles) {                               // more than 10 cameras: my tiles 3 .. 5
-        for (int g0 = 0; g0 < G; g0 += 4) {
-          double v[4][12];
+        m0 = res_ld(q + (4 * kResOwn) * 256); m1 = res_ld(q + (4 * kResOwn + 1) * 256);
+        if (mine2) { m2 = res_ld(q + (4 * kResOwn + 2) * 256); m3 = res_ld(q + (4 * kResOwn + 3) * 256); }
+      } else {
+        for (int g0 = 0; g0 < G; g0 += 2) {
+          // (at most two workgroups here) both records in flight before the first use (compiler-visible agent-scope loads: it
+          // counts the waits itself); more would not fit the registers
+          double v[2][16];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double* q = mybase + (size_t)min(g0 + u, G - 1) * kResRec + 12 * 256;
+          for (int u = 0; u < 2; ++u) {
+            const double* q = mybase + (size_t)min(g0 + u, G - 1) * kResRec;
 #pragma unroll
             for (int e = 0; e < 12; ++e) v[u][e] = res_ld(q + e * 256);
+            v[u][12] = res_ld(q + (4 * kResOwn) * 256); v[u][13] = res_ld(q + (4 * kResOwn + 1) * 256);
+            v[u][14] = v[u][15] = 0.0;
+            if (mine2) { v[u][14] = res_ld(q + (4 * kResOwn + 2) * 256); v[u][15] = res_ld(q + (4 * kResOwn + 3) * 256); }
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 2; ++u) {
             const bool in = g0 + u < G;
 #pragma unroll
-            for (int t = 3; t < kResOwn; ++t)
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) ssum[t][e] += in && own[t] ? v[u][4 * (t - 3) + e] : 0.0;
+              for (int e = 0; e < 4; ++e) ssum[t][e] += in && own[t] ? v[u][4 * t + e] : 0.0;
+            m0 += in ? v[u][12] : 0.0;
+            m1 += in ? v[u][13] : 0.0;
+            m2 += in && mine2 ? v[u][14] : 0.0;
+            m3 += in && mine2 ? v[u][15] : 0.0;
+          }
+        }
+        if (more_tiles) {                               // more than 10 cameras: my tiles 3 .. 5
+          for (int g0 = 0; g0 < G; g0 += 2) {
+            double v[2][12];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const double* q = mybase + (size_t)min(g0 + u, G - 1) * kResRec + 12 * 256;
+#pragma unroll
+              for (int e = 0; e < 12; ++e) v[u][e] = res_ld(q + e * 256);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const bool in = g0 + u < G;
+#pragma unroll
+              for (int t = 3; t < kResOwn; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ssum[t][e] += in && own[t] ? v[u][4 * (t - 3) + e] : 0.0;
+            }
           }
         }
       }
@@ -631,85 +765,54 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
     //      into its v_fmac_f64 (DPP row_newbcast) - 85 cycles per pivot, and the lanes left over carry the identity along, so
     //      that the block's inverse comes out too; the panel is X = A L^-T on the matrix cores.  While wavefront 0 runs a
     //      block's chain the others give the next block of columns what the columns left of this step owe it.
-#define RES_CSTAMP(k) do { if (A.trace && grp == 0 && tid == 0 && ntrials == 0) A.trace[(32 + step) * 16 + (k)] = (long long)clock64(); } while (0)
+#define RES_CSTAMP(k) do { if (A.trace && grp == 0 && tid == 0 && ntrials == 3) A.trace[(32 + step) * 16 + (k)] = (long long)clock64(); } while (0)
+    //      Wavefront 0 owns the critical path - diagonal block, the first tile of the panel below it (which holds the rows of the
+    //      NEXT diagonal block), that tile's update - and goes straight on to the next diagonal block; the other three do the rest
+    //      of the panel, its update of the next block of columns and the look-ahead while that block's chain runs: two barriers
+    //      a step.
     for (int step = 0; 12 * step < n; ++step) {
       const int k0 = 12 * step, nbw = min(12, n - k0), kn = k0 + nbw;      // this step's columns [k0, kn), the next block from kn
       const int nwn = min(12, n - kn);                                      // ... of nwn columns (0: this is the last step)
+      double* LiS = LiL + step * 192;
       RES_CSTAMP(0);
       if (wave == 0) {
-        if (nbw == 12) bcr_diag_block<12, true>(Sm, kResSLd, dinvL, sflag, k0, lane, LiL, IdtL);
-        else bcr_diag_block<6, true>(Sm, kResSLd, dinvL, sflag, k0, lane, LiL, IdtL);
+        if (nbw == 12) bcr_diag_block<12, false>(Sm, kResSLd, nullptr, sflag, k0, lane, LiS, IdtL);
+        else bcr_diag_block<6, false>(Sm, kResSLd, nullptr, sflag, k0, lane, LiS, IdtL);
       } else if (nwn > 0) {
         for (int tile = wave - 1; kn + 16 * tile <= n; tile += kResWaves - 1) RES_SWITCH_STEP(res_update_ahead, Sm, tile, n, nwn, ln, lk);
       }
       RES_CSTAMP(1);
       lds_barrier();
       if (res_uniform(sflag[0])) break;
-      // the panel: rows kn .. n (the right-hand side among them), a tile of 16 per wavefront
-      for (int i0 = kn + 16 * wave; i0 <= n; i0 += 16 * kResWaves) {
+      // the panel: rows kn .. n (the right-hand side among them), a tile of 16 per wavefront.  Wavefront 0 takes the first and
+      // gives the next diagonal block what it owes this panel straight from its registers
+      if (wave == 0) {
+        res_acc acc = {0.0, 0.0, 0.0, 0.0};
+        if (nwn > 0) acc = res_prefetch_tile0(Sm, n, kn, ln, lk);
         double pr[3];
-        bcr_panel_tile(Sm, kResSLd, n + 1, k0, i0, LiL, ln, lk, pr, nbw);
+        bcr_panel_tile(Sm, kResSLd, n + 1, k0, kn, LiS, ln, lk, pr, nbw);
+        if (nwn > 0) bcr_urgent_tile0(Sm, kResSLd, n + 1, kn, nwn, ln, lk, pr, acc);
+      } else {
+        for (int i0 = kn + 16 * wave; i0 <= n; i0 += 16 * (kResWaves - 1)) {
+          double pr[3];
+          bcr_panel_tile(Sm, kResSLd, n + 1, k0, i0, LiS, ln, lk, pr, nbw);
+        }
       }
       RES_CSTAMP(2);
       lds_barrier();
-      if (nwn > 0) {
-        for (int tile = wave; kn + 16 * tile <= n; tile += kResWaves) RES_SWITCH_STEP(res_update_panel, Sm, tile, n, nwn, ln, lk);
-        lds_barrier();
-      }
+      // the tiles below it in the other wavefronts, before their look-ahead of the next step - wavefront 0 is on the next
+      // diagonal block by then
+      if (nwn > 0 && wave != 0)
+        for (int tile = wave; kn + 16 * tile <= n; tile += kResWaves - 1) RES_SWITCH_STEP(res_update_panel, Sm, tile, n, nwn, ln, lk);
       RES_CSTAMP(3);
     }
+    lds_barrier();
     if (res_uniform(sflag[0])) { exit_reason = RES_NOT_POSITIVE_DEFINITE; exit_info = res_uniform(sflag[0]); break; }
     RES_STAMP(5);
-    // ---- L^T x = y in one wavefront: lane i holds the unknown i (and 64 + i beyond 10 cameras); the rows of a camera block
-    //      are fetched together
-    if (wave == 0 && n <= 64) {
-      const bool rv = lane < n;
-      double v = rv ? Sm[n * kResSLd + lane] : 0.0;
-      const double invd = rv ? dinvL[lane] : 0.0;
-      double xs = 0.0;
-      double lq[6], ln6[6];                           // the rows of this camera block, and of the next one (fetched a block ahead)
-#pragma unroll
-      for (int u = 0; u < 6; ++u) lq[u] = Sm[(6 * (nco - 1) + u) * kResSLd + lane];
-      for (int J = nco - 1; J >= 0; --J) {
-        const int Jn = max(J - 1, 0);
-#pragma unroll
-        for (int u = 0; u < 6; ++u) ln6[u] = Sm[(6 * Jn + u) * kResSLd + lane];
-#pragma unroll
-        for (int u = 5; u >= 0; --u) {
-          const int q = 6 * J + u;
-          const double xq = lane_bcast(v * invd, q);
-          if (lane == q) xs = xq;
-          v = fma(lane < q ? -lq[u] : 0.0, xq, v);
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) lq[u] = ln6[u];
-      }
-      if (rv) dCl[lane] = xs;
-    } else if (wave == 0) {
-      const bool rv0 = lane < n, rv1 = 64 + lane < n;
-      double v0 = rv0 ? Sm[n * kResSLd + lane] : 0.0, v1 = rv1 ? Sm[n * kResSLd + 64 + lane] : 0.0;
-      const double i0 = rv0 ? dinvL[lane] : 0.0, i1 = rv1 ? dinvL[64 + lane] : 0.0;
-      double x0 = 0.0, x1 = 0.0;
-      for (int J = nco - 1; J >= 0; --J) {
-        double l0[6], l1[6];
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const int q = 6 * J + u;
-          l0[u] = Sm[q * kResSLd + lane];
-          l1[u] = Sm[q * kResSLd + min(64 + lane, kResMaxN - 1)];
-        }
-#pragma unroll
-        for (int u = 5; u >= 0; --u) {
-          const int q = 6 * J + u;
-          const double t = q < 64 ? v0 * i0 : v1 * i1;
-          const double xq = lane_bcast(t, q & 63);
-          if (lane == (q & 63)) { if (q < 64) x0 = xq; else x1 = xq; }
-          v0 = fma(lane < q ? -l0[u] : 0.0, xq, v0);
-          v1 = fma(64 + lane < q ? -l1[u] : 0.0, xq, v1);
-        }
-      }
-      if (rv0) dCl[lane] = x0;
-      if (rv1) dCl[64 + lane] = x1;
+    // ---- L^T x = y in one wavefront (res_backsolve)
+    if (wave == 0) {
+      if (n <= 64) res_backsolve<false>(Sm, LiL, dCl, n, lane);
+      else res_backsolve<true>(Sm, LiL, dCl, n, lane);
     }
     lds_barrier();
     if (A.dbg && grp == 0 && ntrials == 0 && tid < 128) A.dbg[(kResMaxN + 2) * kResSLd + tid] = tid < n ? dCl[tid] : 0.0;

@@ -58,8 +58,8 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   REQUIRE(h, resident_fits(h, &lds), BA_ERR_STATE, "ba_lm_resident: not a problem for the resident loop (ba_lm_resident_fits)");
   HIPCHECK(h, hipSetDevice(h->device));
   const int G = (h->nt + kResP - 1) / kResP;
-  if (h->res_xb.n < (size_t)G * kResRec || h->res_epoch.n < (size_t)2 * G) {
-    HIPCHECK(h, h->res_xb.resize((size_t)kResMaxGroups * kResRec));
+  if (h->res_xb.n < (size_t)(G + 1) * kResRec || h->res_epoch.n < (size_t)2 * G) {
+    HIPCHECK(h, h->res_xb.resize((size_t)(kResMaxGroups + 1) * kResRec));      // + the record of sums
     HIPCHECK(h, h->res_epoch.resize((size_t)2 * kResMaxGroups));
     HIPCHECK(h, hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream));
     h->res_epoch0 = 0;
@@ -96,6 +96,7 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   if (!h->opt.fast_paths) a.sensor.fast = 0;
   a.cams = h->cams[p].p; a.X = h->X[p].p; a.out = h->res_out; a.xb = h->res_xb.p; a.epoch = h->res_epoch.p; a.epoch0 = h->res_epoch0;
   a.cost_slots = h->res_cost.p; a.parity0 = h->res_parity;
+  a.scatter_min = h->opt.resident_scatter_min;
   a.max_steps = max_steps; a.max_trials = kResMaxTrials; a.nsteps = steps_taken; a.in_step = in_step ? 1 : 0; a.converged = converged ? 1 : 0;
   a.damping = damping; a.improvement_threshold = improvement_threshold; a.rcond = pinv_rcond; a.cur_cost = cur_cost;
   a.have_mask = cam_param_mask ? 1 : 0;

@@ -246,6 +246,25 @@ def test_what_is_not_a_resident_problem_takes_the_python_loop():
         ba.backend.set_option('resident', '1')
 
 
+@pytest.mark.parametrize('nc,nt,L', [(10, 40, 5), (10, 100, 10), (14, 120, 12), (17, 256, 16), (9, 1024, 4)])
+def test_both_forms_of_the_exchange_end_on_the_same_bits(nc, nt, L):
+    """Exchange 1 of the resident loop (csrc/ba_resident.h): every workgroup adds up every record, or - from five workgroups
+    on - each adds up a slice of all records and everybody fetches the sums.  The same numbers in the same order either way."""
+    from pysfm_amd import BundleAdjuster
+    b, _ = small_scene(nc, nt, L, 7, O.Sensor.cauchy(.05), outliers=.05, ragged=True)
+    out = []
+    for scatter_min in ('1000', '2'):
+        ba = BundleAdjuster(verbose=False)
+        ba.backend.set_option('resident_scatter_min', scatter_min)
+        ba.set_bundle(b)
+        assert ba._resident_applies(None)
+        ba.optimize(max_steps=6)
+        out.append((ba.trial_log, ba.costs, ba.bundle.Rs(), ba.bundle.ts(), np.asarray(ba.bundle.reconstruction)))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    for x, y in zip(out[0][2:], out[1][2:]):
+        assert np.array_equal(x, y)
+
+
 def test_host_side_and_device_side_set_up_agree():
     """ba_set_problem orders small problems on the host (csrc/ba_problem.hip host_front_end): the same internal order,
     the same work lists, the same numbers as the device pipeline."""
