@@ -118,8 +118,8 @@ struct ResidentArgs {
 
 // LDS carve-up of a workgroup
 struct ResidentLds {
-  int cam, X, HPP, Hinv, HCC, Dk, red, misc, dC, fact, z, stage;     // offsets in doubles
-  int flag_i, off_i, pos_i, tab_b, opt_b, oc_b, mask_b;        // offsets in bytes
+  int cam, X, HPP, Hinv, Dk, red, misc, dC, fact, z, stage;     // offsets in doubles
+  int flag_i, off_i, pos_i, stab_i, tab_b, opt_b, oc_b, mask_b;        // offsets in bytes
   size_t bytes;
 };
 __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
@@ -129,7 +129,6 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.X = o; o += 2 * kResP * 3;
   l.HPP = o; o += kResP * 9 + 1;                  // HPP (6) | bP (3) per point, undamped
   l.Hinv = o; o += kResP * 9 + 1;                 // HPPinv (6) | HPPinv bP (3)
-  l.HCC = o; o += nco * 27 + (nco & 1);           // 21 + 6 per optimised camera, undamped, summed over the workgroups
   l.Dk = o; o += 2 * kResK;                       // D | y
   l.red = o; o += kResWaves * 64 + 16;            // partial right-hand sides [waves][64], wavefront partials
   l.misc = o; o += kResMisc;                   // the summed right-hand side | camera blocks | scalars
@@ -145,6 +144,7 @@ __host__ __device__ inline ResidentLds resident_lds(int nc, int nco, int maxL) {
   l.flag_i = (int)b; b += 16;                     // status words of a trial
   l.off_i = (int)b; b += (size_t)(kResP + 1) * 4;
   l.pos_i = (int)b; b += (size_t)nc * 4;
+  l.stab_i = (int)b; b += (size_t)4 * kResOwn * kResThreads * 4;      // where my accumulator entries go in S (res_s_entry)
   l.tab_b = (int)b; b += (size_t)kResP * nco;
   l.opt_b = (int)b; b += (size_t)kResP;
   l.oc_b = (int)b; b += (size_t)kResP * maxL;     // camera of an observation
@@ -185,6 +185,21 @@ __device__ __forceinline__ bool res_wait_all(const long long* words, int stride,
   lds_barrier();
   return res_uniform(*timed_out) == 0;
 }
+
+// Entry (row, col) of the upper triangle of S, as the thread that holds its sum in an accumulator tile needs it once a trial:
+// where it goes in LDS (the lower triangle, [col][row]) | which entry of the camera blocks it starts from (diagonal blocks only)
+// | is it damped | is its parameter kept (solve_motion_normal_eqns' mask) | is it on the diagonal | is it there at all.
+// Packed once per launch: no division, no branch in the trial loop.
+__device__ __forceinline__ unsigned res_s_entry(int row, int col, int n, bool mine, const unsigned char* __restrict__ maskL) {
+  if (!mine || row > col || col >= n) return 0u;
+  const int pr = row / 6, pc = col / 6, a = row - 6 * pr, b = col - 6 * pc;
+  unsigned w = (unsigned)(col * kResSLd + row) | 1u << 27;
+  if (pr == pc) w |= (unsigned)(pr * 27 + (a * (11 - a)) / 2 + b) << 14 | 1u << 23;      // entry (a, b >= a) of the camera's block, rows first
+  if (row == col) w |= 1u << 24;
+  if (maskL[row] && maskL[col]) w |= 1u << 25;
+  return w;
+}
+static_assert((kResMaxN + 1) * kResSLd < (1 << 14) && kResMaxNco * 27 < (1 << 9), "res_s_entry's fields");
 
 // Exchange 1 in two stages, stage one: KN elements per thread of my slice of the records, every record's in flight at once
 // (eight records a batch), added in workgroup order; the sums go to the sum record.
@@ -341,7 +356,6 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   double* XL = sm + lo.X;
   double* HPPl = sm + lo.HPP;
   double* Hinvl = sm + lo.Hinv;
-  double* HCCl = sm + lo.HCC;
   double* Dk = sm + lo.Dk;
   double* yk = Dk + kResK;
   double* red = sm + lo.red;
@@ -356,6 +370,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   int* sflag = reinterpret_cast<int*>(base + lo.flag_i);      // [0]: pivot index of a failed factorisation, [1]: timed out
   int* offL = reinterpret_cast<int*>(base + lo.off_i);
   int* posL = reinterpret_cast<int*>(base + lo.pos_i);
+  unsigned* stabL = reinterpret_cast<unsigned*>(base + lo.stab_i);
   signed char* tabj = reinterpret_cast<signed char*>(base + lo.tab_b);
   unsigned char* optL = base + lo.opt_b;
   unsigned char* ocL = base + lo.oc_b;
@@ -420,6 +435,10 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
     if (own[t]) tri_decode(wave + kResWaves * t, NT, tti[t], ttj[t]);
   }
   const bool more_tiles = ntiles > 3 * kResWaves;      // (uniform over the launch: beyond 10 cameras)
+#pragma unroll
+  for (int t = 0; t < kResOwn; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) stabL[(4 * t + v) * kResThreads + tid] = res_s_entry(16 * tti[t] + lk + 4 * v, 16 * ttj[t] + ln, n, own[t], maskL);
   double* myrec = A.xb + (size_t)grp * kResRec;
 
   int tr_i = 0;
@@ -657,8 +676,10 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
           else if (kn == 3) res_reduce_slice<3>(A.xb, sumrec, G, off, val);
           else res_reduce_slice<4>(A.xb, sumrec, G, off, val);
         }
+        RES_STAMP(9);
         res_publish(A.epoch + 2 * grp + 1, epoch, tid);
         if (!res_wait_all(A.epoch + 1, 2, G, epoch, tid, sflag + 1)) { exit_reason = RES_TIMED_OUT; break; }
+        RES_STAMP(12);
         const double* q = sumrec + tid;
 #pragma unroll
         for (int t = 0; t < kResOwn; ++t) {
@@ -716,43 +737,55 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
         }
       }
       miscL[2 * tid] = m0; miscL[2 * tid + 1] = m1;
+      RES_STAMP(13);
       if (mine2) { miscL[2 * (tid + 256)] = m2; miscL[2 * (tid + 256) + 1] = m3; }
       lds_barrier();
       const double c0sum = miscL[kResMiscScal];
       if (res_uniform(miscL[kResMiscScal + 1]) > 0.0) { exit_reason = RES_SINGULAR_POINT; break; }      // plain-inverse mode: the general path raises (bundle_adjuster.py:254)
-      if (need_lin) {
-        for (int ct = tid; ct < nco * 27; ct += kResThreads) HCCl[ct] = miscL[kResMiscCam + ct];
-        if (!have_cost0) {
-          cost0 = res_uniform(c0sum);
-          have_cost0 = true;
-          if (cur_cost < 0.0) cur_cost = cost0;
-        }
+      if (need_lin && !have_cost0) {
+        cost0 = res_uniform(c0sum);
+        have_cost0 = true;
+        if (cur_cost < 0.0) cur_cost = cost0;
       }
+      // S = damped camera blocks - sums, b = bC - sums (the camera blocks of a trial that did not linearise are the records' own
+      // of the trial before: the same numbers).  Sm aliases At: everybody has been through a barrier since the last read of it.
       const double rsum = tid < kResMaxN ? miscL[tid] : 0.0;
-      lds_barrier();                                  // HCC is in LDS; nobody reads At any more
+      const double bc = tid < n ? miscL[kResMiscCam + (tid / 6) * 27 + 21 + tid % 6] : 0.0;
+      {
+        unsigned w[12];
+        double hv[12];
 #pragma unroll
-      for (int t = 0; t < kResOwn; ++t) {
-        if (!own[t]) continue;
-        const int ti = tti[t], tj = ttj[t];
-        const int col = 16 * tj + ln;
+        for (int e = 0; e < 12; ++e) w[e] = stabL[e * kResThreads + tid];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * ti + lk + 4 * v;
-          if (row <= col && col < n) {
-            double h = 0.0;
-            const int pr = row / 6, pc = col / 6;
-            if (pr == pc) {
-              const int a = row - 6 * pr, b = col - 6 * pc;
-              h = HCCl[pr * 27 + (a * (11 - a)) / 2 + b];             // entry (a, b >= a) of the upper triangle, rows first
-              if (a == b) h *= dampf;
-            }
-            // a deleted parameter keeps an identity row / column and a zero right-hand side: its update is zero
-            const bool kept = maskL[row] && maskL[col];
-            Sm[col * kResSLd + row] = kept ? h - ssum[t][v] : (row == col ? 1.0 : 0.0);
-          }
+        for (int e = 0; e < 12; ++e) hv[e] = miscL[kResMiscCam + ((w[e] >> 14) & 511)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+          double h = w[e] & 1u << 23 ? hv[e] : 0.0;
+          h = w[e] & 1u << 24 ? h * dampf : h;
+          // a deleted parameter keeps an identity row / column and a zero right-hand side: its update is zero
+          const double val = w[e] & 1u << 25 ? h - ssum[e >> 2][e & 3] : (w[e] & 1u << 24 ? 1.0 : 0.0);
+          if (w[e] & 1u << 27) Sm[w[e] & 16383] = val;
         }
       }
-      if (tid < n) Sm[n * kResSLd + tid] = maskL[tid] ? HCCl[(tid / 6) * 27 + 21 + tid % 6] - rsum : 0.0;
+      if (more_tiles) {
+        unsigned w[4 * kResOwn - 12];
+        double hv[4 * kResOwn - 12];
+#pragma unroll
+        for (int e = 12; e < 4 * kResOwn; ++e) w[e - 12] = stabL[e * kResThreads + tid];
+#pragma unroll
+        for (int e = 12; e < 4 * kResOwn; ++e) hv[e - 12] = miscL[kResMiscCam + ((w[e - 12] >> 14) & 511)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 12; e < 4 * kResOwn; ++e) {
+          const unsigned x = w[e - 12];
+          double h = x & 1u << 23 ? hv[e - 12] : 0.0;
+          h = x & 1u << 24 ? h * dampf : h;
+          const double val = x & 1u << 25 ? h - ssum[e >> 2][e & 3] : (x & 1u << 24 ? 1.0 : 0.0);
+          if (x & 1u << 27) Sm[x & 16383] = val;
+        }
+      }
+      if (tid < n) Sm[n * kResSLd + tid] = maskL[tid] ? bc - rsum : 0.0;
     }
     lds_barrier();
     if (A.dbg && grp == 0 && ntrials == 0)

@@ -95,8 +95,9 @@ names = ('linearise / damp / stage', 'camera blocks + matrix cores', 'publish + 
 for k in range(min(ba.lm_trials, 10)):
     d = np.diff(tr[k, :9]) * 0.01
     print('trial %d (linearised %d): total %.1f us: ' % (k, tr[k, 15], (tr[k, 8] - tr[k, 0]) * 0.01) + ', '.join('%s %.1f' % (n, x) for n, x in zip(names, d)))
+print('inside "sum partials, S" (two-stage exchange), us: slices added up and stored %s, published + everybody seen %s, sums fetched %s, S built %s' % tuple(np.round((tr[1:6, b] - tr[1:6, a]) * 0.01, 2) for a, b in ((3, 9), (9, 12), (12, 13), (13, 4))))
 print('shader clock during the trials: %s MHz' % np.round((tr[:8, 11] - tr[:8, 10]) / ((tr[:8, 8] - tr[:8, 0]) * 0.01), 0))
 for J in range(5):
-    print('  step %d (cycles): diagonal block (others: look-ahead) %d, barrier + panel %d, barrier + panel into the next block + barrier %d' % (J, tr[32 + J, 1] - tr[32 + J, 0], tr[32 + J, 2] - tr[32 + J, 1], tr[32 + J, 3] - tr[32 + J, 2]))
+    print('  step %d (wavefront 0, cycles): diagonal block %d, barrier + first panel tile + its update of the next diagonal block %d, barrier %d' % (J, tr[32 + J, 1] - tr[32 + J, 0], tr[32 + J, 2] - tr[32 + J, 1], tr[32 + J, 3] - tr[32 + J, 2]))
 print('between trials: %s us' % np.round((tr[1:ba.lm_trials, 0] - tr[:ba.lm_trials - 1, 8]) * 0.01, 1)[:8])
 print('ALL OK' if ok else 'MISMATCH')
