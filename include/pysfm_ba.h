@@ -287,15 +287,19 @@ int ba_lm_trial_finish(ba_handle* h);
  * units, as one resident launch of a few workgroups (pysfm_amd/csrc/ba_resident.h): <= 16 optimised cameras, <= 32 cameras, <= 1024 tracks of <= 16
  * observations, no communicator.  The sliding-window caller
  * (window_slam.py:17-48) solves one such problem per frame; at that size a trial costs 68 us through ba_lm_trial (six
- * launches and one synchronisation for a thousand observations) and ~31 us here, with no round trip to the host between trials.
+ * launches and one synchronisation for a thousand observations) and ~26 us here, with no round trip to the host between trials.
  *   ba_lm_resident_fits  1 when the handle's problem, sensor model and options allow it, else 0
  *   ba_lm_resident       runs the reference's schedule on the device from the state given (damping, steps taken, inside a
  *                        step or not, converged, cost of the current set or < 0 when unknown) until it converges, max_steps
  *                        are taken, the log is full, or a trial needs the general path; the current parameter set is updated
  *                        in place, *log says what happened trial by trial.  exit_reason: 0 done, 1 log full (call again
  *                        with the state of the log), 2 the reduced system of the next trial is not positive definite
- *                        (exit_info = gesv-style index of the pivot), 3 a singular point block in plain-inverse mode - for 2
- *                        and 3 the caller runs that one trial through ba_lm_trial / the stepwise calls and comes back. */
+ *                        (exit_info = 1 + the first unknown of the block of 12 columns in which the factorisation broke down), 3 a
+ *                        singular point block in plain-inverse mode - for 2 and 3 the caller runs that one trial through
+ *                        ba_lm_trial / the stepwise calls and comes back.
+ *   ba_lm_resident_begin / _end   the same in two halves: _begin launches and returns, _end waits and fills *log.  For a caller
+ *                        with host work that does not depend on the run (window_slam.py prepares the NEXT window on a second
+ *                        handle meanwhile); nothing else may be asked of the handle in between. */
 #define BA_RESIDENT_MAX_TRIALS 1000
 typedef struct ba_resident_log {
   int32_t ntrials, nsteps, converged, in_step;
@@ -309,6 +313,9 @@ int ba_lm_resident_fits(ba_handle* h);
 int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
                    double improvement_threshold, double pinv_rcond, double cur_cost,
                    const uint8_t* cam_param_mask /* [6 nco] as in ba_solve_reduced, or NULL */, ba_resident_log* log);
+int ba_lm_resident_begin(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
+                         double improvement_threshold, double pinv_rcond, double cur_cost, const uint8_t* cam_param_mask);
+int ba_lm_resident_end(ba_handle* h, ba_resident_log* log);
 /* with option solve_trace: 16 words per trial for the first 64 trials of the last ba_lm_resident - wall_clock64 (100 MHz) at the
  * phase boundaries [0..7], [8] = 1 when the trial linearised */
 int ba_lm_resident_trace(ba_handle* h, int64_t* out /* [64 * 16] */);

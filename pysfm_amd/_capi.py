@@ -87,6 +87,8 @@ PROTOTYPES = {
     'ba_lm_resident_debug': (C.c_int, [_h, _dp, _dp, _dp]),
     'ba_lm_resident': (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                  _bp, C.POINTER(ResidentLog)]),
+    'ba_lm_resident_begin': (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _bp]),
+    'ba_lm_resident_end': (C.c_int, [_h, C.POINTER(ResidentLog)]),
     'ba_set_dense_visibility': (C.c_int, [_h, C.c_int32]),
     'ba_measure_copy_bandwidth': (C.c_int, [_h, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     'ba_set_min_half_bandwidth': (C.c_int, [_h, C.c_int32]),

@@ -326,6 +326,22 @@ class HipBackend(object):
                                              -1.0 if cur_cost is None else float(cur_cost), capi.bptr(mask), C.byref(log)))
         return log
 
+    def lm_resident_begin(self, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, rcond, cur_cost, cam_param_mask=None):
+        """ba_lm_resident_begin: lm_resident's launch and nothing that waits for it; lm_resident_end() collects the log.  Nothing
+        else may be asked of this backend in between."""
+        mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
+        assert mask is None or mask.shape == (self.nco * 6,)
+        self._check(self._lib.ba_lm_resident_begin(self._h, int(max_steps), int(steps_taken), int(bool(in_step)), int(bool(converged)),
+                                                   float(damping), float(improvement_threshold), -1.0 if rcond is None else float(rcond),
+                                                   -1.0 if cur_cost is None else float(cur_cost), capi.bptr(mask)))
+
+    def lm_resident_end(self):
+        """ba_lm_resident_end: waits for the launch of lm_resident_begin; the log as lm_resident returns it."""
+        if getattr(self, '_res_log', None) is None:
+            self._res_log = capi.ResidentLog()
+        self._check(self._lib.ba_lm_resident_end(self._h, C.byref(self._res_log)))
+        return self._res_log
+
     def lm_resident_debug(self):
         """ba_lm_resident_debug (option solve_trace): [S | b] and dC of the first trial of the last lm_resident."""
         n = 6 * self.nco

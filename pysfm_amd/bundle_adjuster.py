@@ -194,11 +194,13 @@ class BundleAdjuster(object):
             self._uploaded_cur = params[:2] + (params[2].copy() if self._all_tracks else params[2],)
 
     # ------------------------------------------------------------------ set_bundle
-    def set_bundle(self, bundle, camera_ids=None, track_ids=None, camera_mask=None, track_mask=None):
+    def set_bundle(self, bundle, camera_ids=None, track_ids=None, camera_mask=None, track_mask=None, upload=True):
         '''Configure the bundle this adjuster operates on (bundle_adjuster.py:54-114).
         camera_ids / track_ids select the cameras / tracks whose measurements are used;
         camera_mask / track_mask (bool array over the selection, or a list of ids)
-        select what is updated.  Default: all cameras but the first, all tracks.'''
+        select what is updated.  Default: all cameras but the first, all tracks.
+        upload=False: the problem only - which cameras, tracks and observations; the parameter values follow with
+        `adjuster.bundle = b` (a bundle of the same structure), before anything is computed.'''
         bundle.check_consistency()
         self._host_bundle = bundle
         self._host_stale = False
@@ -267,7 +269,8 @@ class BundleAdjuster(object):
         be.set_problem(nc, nt, obs_cam, obs_pt, obs_z, np.asarray(bundle.K, float), cam_opt_pos, pt_opt)
         self._configure_distributed_solve(be, cam_opt_pos, obs_cam, obs_pt, nt)
         be.set_sensor(*device_params_of(bundle.sensor_model))
-        self._upload(bundle, PARAMS_CUR)
+        if upload:
+            self._upload(bundle, PARAMS_CUR)
         self._have_blocks = False
         self._blocks_cache = None
         self._have_W = False
@@ -329,6 +332,35 @@ class BundleAdjuster(object):
         else:
             self._say('Failed to converge after %d steps' % self.num_steps)
 
+    def optimize_begin(self, param_mask=None, max_steps=25, init_damping=10., improvement_threshold=1e-4):
+        """optimize() in two halves, for a caller with host work that does not depend on the result (window_slam.run prepares
+        the next window on a second adjuster): where the loop runs on the device as one launch (_resident_applies) this starts
+        it and returns; optimize_end() waits and replays the log.  Anywhere else optimize_end() runs the whole of optimize().
+        Nothing else may be asked of this adjuster in between."""
+        self._begun = (param_mask, max_steps, init_damping, improvement_threshold, False)
+        be = self.backend
+        if not (self._resident_applies(param_mask) and hasattr(be, 'lm_resident_begin')):
+            return
+        self._damping = init_damping
+        self.num_steps = 0
+        self.lm_trials = 0
+        self.trial_log = []
+        self.converged = False
+        self._cur_cost = None
+        self.costs = []
+        be.lm_resident_begin(max_steps, 0, False, False, init_damping, improvement_threshold, self.SCHUR_COMPLIMENT_PINV_THRESHOLD,
+                             None, self._resident_cam_mask(param_mask))
+        self._begun = (param_mask, max_steps, init_damping, improvement_threshold, True)
+
+    def optimize_end(self):
+        """The second half of optimize_begin()."""
+        param_mask, max_steps, init_damping, improvement_threshold, launched = self._begun
+        self._begun = None
+        if not launched:
+            return self.optimize(param_mask, max_steps, init_damping, improvement_threshold)
+        self._resident_steps(max_steps, improvement_threshold, param_mask, launched=True)
+        self._say('Converged after %d steps' % self.num_steps if self.converged else 'Failed to converge after %d steps' % self.num_steps)
+
     def step(self, param_mask=None, improvement_threshold=1e-4):
         '''One outer iteration of optimize(): retry with growing damping until a trial
         lowers the cost (bundle_adjuster.py:128-157; cf. optimize.py:110-135).
@@ -376,25 +408,31 @@ class BundleAdjuster(object):
         be = self.backend
         return hasattr(be, 'lm_resident_fits') and be.lm_resident_fits()
 
-    def _resident_steps(self, max_steps, improvement_threshold, param_mask=None):
+    def _resident_cam_mask(self, param_mask):
+        """Camera parameters deleted from the solve, or None (the common case costs no array work)."""
+        if param_mask is None:
+            return None
+        cam_mask = self._cam_param_mask(param_mask)
+        return None if np.all(cam_mask) else cam_mask
+
+    def _resident_steps(self, max_steps, improvement_threshold, param_mask=None, launched=False):
         """Outer iterations until self.num_steps == max_steps or convergence (the loop of optimize(), bundle_adjuster.py:128-157),
-        on the device.  A trial the resident loop cannot take (a reduced system that is not positive definite: the reference
+        on the device (launched: the first launch has been made, optimize_begin).  A trial the resident loop cannot take (a reduced system that is not positive definite: the reference
         solves it by LU; a singular point block in plain-inverse mode: the reference raises) goes through trial() and the
         loop resumes on the device."""
         from ._capi import RESIDENT_DONE, RESIDENT_LOG_FULL
         be = self.backend
         in_step = False
-        cam_mask = None                                 # (camera parameters deleted from the solve; the common case costs no array work)
-        if param_mask is not None:
-            cam_mask = self._cam_param_mask(param_mask)
-            if np.all(cam_mask):
-                cam_mask = None
+        cam_mask = self._resident_cam_mask(param_mask)
         if not hasattr(self, 'costs') or self.costs is None:
             self.costs = []
         while True:
             steps_before = self.num_steps
-            log = be.lm_resident(max_steps, self.num_steps, in_step, self.converged, self._damping, improvement_threshold,
-                                 self.SCHUR_COMPLIMENT_PINV_THRESHOLD, self._cur_cost, cam_mask)
+            if launched:                             # (optimize_begin has made this call's launch)
+                log, launched = be.lm_resident_end(), False
+            else:
+                log = be.lm_resident(max_steps, self.num_steps, in_step, self.converged, self._damping, improvement_threshold,
+                                     self.SCHUR_COMPLIMENT_PINV_THRESHOLD, self._cur_cost, cam_mask)
             if self._cur_cost is None and log.have_cost0:
                 self._cur_cost = log.cost0
             if not self.costs and self._cur_cost is not None:

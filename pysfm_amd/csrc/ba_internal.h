@@ -206,6 +206,8 @@ struct ba_handle {
   long long res_epoch0 = 0;
   DevBuf<double> res_cost;             // ... their trial-cost words [2][32] (by the parity of the trial)
   int res_parity = 0;
+  bool res_inflight = false;            // ... a launch ba_lm_resident_begin made and ba_lm_resident_end has not collected yet
+  int res_inflight_phys = 0;
   void* res_log = nullptr;             // ... and its pinned log (ResidentLog of ba_resident.h)
   void* io = nullptr;                  // pinned staging of ba_set_params / ba_get_params (small parameter sets)
   size_t io_bytes = 0;

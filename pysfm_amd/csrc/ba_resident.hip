@@ -48,11 +48,11 @@ int ba_lm_resident_fits(ba_handle* h) {
   return resident_fits(h, nullptr) ? 1 : 0;
 }
 
-int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
-                   double improvement_threshold, double pinv_rcond, double cur_cost, const uint8_t* cam_param_mask,
-                   ba_resident_log* log) {
+// the launch, and nothing that waits for it
+int ba_lm_resident_begin(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
+                         double improvement_threshold, double pinv_rcond, double cur_cost, const uint8_t* cam_param_mask) {
   if (!h) return BA_ERR_INVALID_ARG;
-  REQUIRE(h, log, BA_ERR_INVALID_ARG, "ba_lm_resident: NULL log");
+  REQUIRE(h, !h->res_inflight, BA_ERR_STATE, "ba_lm_resident_begin: the last launch has not been collected (ba_lm_resident_end)");
   REQUIRE(h, h->have_problem && h->have_params[h->phys(BA_PARAMS_CUR)], BA_ERR_STATE, "ba_lm_resident: set problem and parameters first");
   ResidentLds lds;
   REQUIRE(h, resident_fits(h, &lds), BA_ERR_STATE, "ba_lm_resident: not a problem for the resident loop (ba_lm_resident_fits)");
@@ -115,6 +115,20 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
   if (h->sensor.kind == SENSOR_TABLE) hipLaunchKernelGGL(k_resident_lm<true>, dim3(G), dim3(kResThreads), lds.bytes, h->stream, a);
   else hipLaunchKernelGGL(k_resident_lm<false>, dim3(G), dim3(kResThreads), lds.bytes, h->stream, a);
   HIPCHECK(h, hipGetLastError());
+  h->res_inflight = true;
+  h->res_inflight_phys = p;
+  return BA_OK;
+}
+
+// ... and the wait: the log, the state of the handle after the run
+int ba_lm_resident_end(ba_handle* h, ba_resident_log* log) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, log, BA_ERR_INVALID_ARG, "ba_lm_resident_end: NULL log");
+  REQUIRE(h, h->res_inflight, BA_ERR_STATE, "ba_lm_resident_end: no launch to collect (ba_lm_resident_begin)");
+  h->res_inflight = false;
+  const int p = h->res_inflight_phys;
+  struct { ResidentLog* log; } a = {static_cast<ResidentLog*>(h->res_log)};
+  HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   REQUIRE(h, a.log->ntrials >= 0, BA_ERR_HIP, "ba_lm_resident: the kernel left no log");
   h->res_epoch0 += 2 * ((long long)a.log->ntrials + 2);
@@ -143,6 +157,15 @@ int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t
     h->point_blocks_valid = h->cam_blocks_valid = h->inv_valid = h->fac_valid = false;
   }
   return BA_OK;
+}
+
+int ba_lm_resident(ba_handle* h, int32_t max_steps, int32_t steps_taken, int32_t in_step, int32_t converged, double damping,
+                   double improvement_threshold, double pinv_rcond, double cur_cost, const uint8_t* cam_param_mask,
+                   ba_resident_log* log) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, log, BA_ERR_INVALID_ARG, "ba_lm_resident: NULL log");
+  const int rc = ba_lm_resident_begin(h, max_steps, steps_taken, in_step, converged, damping, improvement_threshold, pinv_rcond, cur_cost, cam_param_mask);
+  return rc != BA_OK ? rc : ba_lm_resident_end(h, log);
 }
 
 int ba_lm_resident_trace(ba_handle* h, int64_t* out) {

@@ -323,6 +323,63 @@ def test_window_slam_same_result_with_either_loop():
     close(o1.reconstruction, o2.reconstruction, 1e-7)
 
 
+def test_window_slam_with_the_next_window_set_up_during_this_one():
+    """window_slam.run(overlap=True): two adjusters taking turns, window i + 1's problem set up while window i's loop runs on
+    the device (optimize_begin / optimize_end), its values when window i is back.  The same bits as one adjuster doing
+    everything in turn - with the loop on the device, and with the Python loop (where optimize_end does all the work)."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model, window_slam
+    g = load_golden('scene_oleg_100x1000')
+    b = Bundle.FromObservations(g['K'], g['R'].reshape(-1, 3, 3), g['t'], g['X'], g['obs_cam'], g['obs_pt'], g['obs_z'],
+                                sensor_model=sensor_model.GaussianModel(1.))
+    try:
+        for resident in (True, False):
+            BundleAdjuster.resident = resident
+            seen = []
+            o1, h1 = window_slam.run(b, 10, num_tracks=100, max_steps=5, verbose=False, overlap=False)
+            o2, h2 = window_slam.run(b, 10, num_tracks=100, max_steps=5, verbose=False, overlap=True,
+                                     on_window=lambda i, ba: seen.append((i, ba.num_steps, list(ba.camera_ids))))
+            if resident:                              # (every sum of the device loop has a fixed order; the general kernels add with atomics)
+                assert h1 == h2
+                assert np.array_equal(o1.Rs(), o2.Rs()) and np.array_equal(o1.ts(), o2.ts()) and np.array_equal(o1.reconstruction, o2.reconstruction)
+            assert [len(h) for h in h1] == [len(h) for h in h2]
+            close(np.concatenate(h1), np.concatenate(h2), 1e-8)
+            close(o1.Rs(), o2.Rs(), 1e-7)
+            close(o1.ts(), o2.ts(), 1e-7, 1e-9)
+            close(o1.reconstruction, o2.reconstruction, 1e-7)
+            assert [i for i, _, _ in seen] == list(range(91)) and all(c == list(range(i, i + 10)) for i, _, c in seen)
+    finally:
+        BundleAdjuster.resident = True
+
+
+def test_optimize_in_two_halves():
+    """optimize_begin / optimize_end = optimize, for a problem the device loop takes (a launch and a wait) and for one it does
+    not (optimize_end does everything); with a parameter mask; a trial that has to go through the general path in between."""
+    from pysfm_amd import BundleAdjuster
+    mask = np.ones(6 * 7 + 3 * 60, bool)
+    mask[[2, 9, 17]] = False
+    for nc, nt, L, kw in ((10, 100, 10, {}), (20, 200, 10, {}), (8, 60, 6, dict(param_mask=mask))):
+        b, _ = small_scene(nc, nt, L, 3, O.Sensor.gaussian(1.))
+        a = BundleAdjuster(b, verbose=False)
+        a.optimize(max_steps=6, **kw)
+        r = BundleAdjuster(b, verbose=False)
+        r.optimize_begin(max_steps=6, **kw)
+        r.optimize_end()
+        assert (a.num_steps, a.converged, a.lm_trials) == (r.num_steps, r.converged, r.lm_trials)
+        assert [(d, o) for d, o, _ in a.trial_log] == [(d, o) for d, o, _ in r.trial_log]
+        if a._resident_applies(kw.get('param_mask')):      # (every sum of the device loop has a fixed order; the general kernels add with atomics)
+            assert a.trial_log == r.trial_log and a.costs == r.costs
+            assert np.array_equal(a.bundle.Rs(), r.bundle.Rs()) and np.array_equal(a.bundle.reconstruction, r.bundle.reconstruction)
+        close(r.costs, a.costs, 1e-9)
+        close(r.bundle.Rs(), a.bundle.Rs(), 1e-8)
+        close(r.bundle.reconstruction, a.bundle.reconstruction, 1e-8)
+    # a launch that was never collected is refused loudly, not silently overwritten
+    r = BundleAdjuster(b, verbose=False)
+    r.optimize_begin(max_steps=2)
+    with pytest.raises(Exception):
+        r.backend.lm_resident_begin(2, 0, False, False, 10., 1e-4, r.SCHUR_COMPLIMENT_PINV_THRESHOLD, None)
+    r.optimize_end()
+
+
 def test_degenerate_shapes():
     """One workgroup, one point; tracks nobody in the window sees; a camera that sees nothing; two cameras."""
     from pysfm_amd import Bundle
