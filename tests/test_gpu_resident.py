@@ -372,6 +372,15 @@ def test_optimize_in_two_halves():
         close(r.costs, a.costs, 1e-9)
         close(r.bundle.Rs(), a.bundle.Rs(), 1e-8)
         close(r.bundle.reconstruction, a.bundle.reconstruction, 1e-8)
+    # a trial the device loop cannot take (next to no damping: the reduced system is singular along its gauge) goes through the
+    # general path between two launches, the first of which optimize_begin made
+    b6, _ = small_scene(6, 40, 6, 8, O.Sensor.gaussian(1.))
+    a, r = BundleAdjuster(b6, verbose=False), BundleAdjuster(b6, verbose=False)
+    a.optimize(init_damping=1e-13)
+    r.optimize_begin(init_damping=1e-13)
+    r.optimize_end()
+    assert [(d, o) for d, o, _ in a.trial_log] == [(d, o) for d, o, _ in r.trial_log] and (a.num_steps, a.converged) == (r.num_steps, r.converged)
+    close(r.costs[-1:], a.costs[-1:], 1e-6)
     # a launch that was never collected is refused loudly, not silently overwritten
     r = BundleAdjuster(b, verbose=False)
     r.optimize_begin(max_steps=2)
