@@ -4,6 +4,8 @@
 // The window-group kernels are in ba_schur_window_kernels.h.  gfx950 (MI355X, CDNA4).
 #pragma once
 
+#include <type_traits>
+
 #include "ba_device.h"
 
 namespace ba {
@@ -618,32 +620,44 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma2(DevProblem P, 
       mfma_acc acc[10];
 #pragma unroll
       for (int t = 0; t < 10; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
-      for (int ib = 0; ib < nb; ++ib) {
+      // the batches of the group.  How many 16 x 16 tiles a side the window has is a property of the group: a compile-time
+      // constant inside the loop (a uniform `if (tj < nts)` around every MFMA is a scalar branch around every MFMA - fifty a
+      // batch, and nothing can be scheduled across them)
+      auto consume = [&](auto nts_c) {
+        constexpr int NTS = decltype(nts_c)::value;
+        for (int ib = 0; ib < nb; ++ib) {
 #ifdef BA_BCR_PROFILE
-        const long long w0 = clock64();
+          const long long w0 = clock64();
 #endif
-        gm2_wait(fStaged, nbatch + 1);
+          gm2_wait(fStaged, nbatch + 1);
 #ifdef BA_BCR_PROFILE
-        pw += clock64() - w0; ++pn;
+          pw += clock64() - w0; ++pn;
 #endif
-        const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
-        const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
+          const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
+          const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
 #pragma unroll
-        for (int s4 = 0; s4 < kGmK / 4; ++s4) {
-          double ta[4], wb[4];
-          const double dk = mD[4 * s4 + lk];
+          for (int s4 = 0; s4 < kGmK / 4; ++s4) {
+            double ta[4], wb[4];
+            const double dk = mD[4 * s4 + lk];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) wb[t] = mU[(4 * s4 + lk) * kGmLd + 16 * t + lr];
-          if (s4 == kGmK / 4 - 1) { ++nbatch; gm2_post(fConsumed, nbatch, lane); }     // everything of this buffer is in registers
+            for (int t = 0; t < 4; ++t) wb[t] = mU[(4 * s4 + lk) * kGmLd + 16 * t + lr];
+            if (s4 == kGmK / 4 - 1) { ++nbatch; gm2_post(fConsumed, nbatch, lane); }     // everything of this buffer is in registers
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ta[t] = wb[t] * dk;
-          int q = 0;
+            for (int t = 0; t < 4; ++t) ta[t] = wb[t] * dk;
+            int q = 0;
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti)
+            for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-            for (int tj = ti; tj < 4; ++tj, ++q)
-              if (tj < nts) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ti], wb[tj], acc[q], 0, 0, 0);
+              for (int tj = ti; tj < 4; ++tj, ++q)
+                if (tj < NTS) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ti], wb[tj], acc[q], 0, 0, 0);
+          }
         }
+      };
+      switch (nts) {
+        case 1: consume(std::integral_constant<int, 1>{}); break;
+        case 2: consume(std::integral_constant<int, 2>{}); break;
+        case 3: consume(std::integral_constant<int, 3>{}); break;
+        default: consume(std::integral_constant<int, 4>{}); break;
       }
       lds_wave_sync();                                          // mPos
 #ifdef BA_BCR_PROFILE

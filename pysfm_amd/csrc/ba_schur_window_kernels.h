@@ -4,6 +4,8 @@
 // (k_schur_rect_mfma).  gfx950 (MI355X, CDNA4).
 #pragma once
 
+#include <type_traits>
+
 #include "ba_device.h"
 
 namespace ba {
@@ -190,29 +192,41 @@ __global__ __launch_bounds__(kGm2Block) void k_schur_groups_mfma3(DevProblem P, 
       mfma_acc acc[NTILE];
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
-      const bool any = nts > TJ0;                                // this launch's tile columns exist for the group
-      for (int ib = 0; ib < nb; ++ib) {
-        gm2_wait(fStaged, nbatch + 1);
-        const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
-        const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
+      // the batches of the group, the number of tile columns it has in this launch a compile-time constant inside the loop
+      // (k_schur_groups_mfma2 has the story: a uniform condition around a load or an MFMA is a scalar branch around it)
+      auto consume = [&](auto nts_c) {
+        constexpr int NTS = decltype(nts_c)::value;             // min(nts, TJ1) > TJ0
+        for (int ib = 0; ib < nb; ++ib) {
+          gm2_wait(fStaged, nbatch + 1);
+          const double* mU = sU + (pair * 2 + (nbatch & 1)) * BUF;
+          const double* mD = sD + (pair * 2 + (nbatch & 1)) * kGm2DRows;
 #pragma unroll KSC ? KSC : 1
-        for (int s4 = 0; s4 < (KSC ? KSC : ks); ++s4) {
-          double ta[TJ1], wb[TJ1];
-          const double dk = mD[4 * s4 + lk];
-          const double* row = mU + (4 * s4 + lk) * Ld + lr;
+          for (int s4 = 0; s4 < (KSC ? KSC : ks); ++s4) {
+            double ta[NTS], wb[NTS];
+            const double dk = mD[4 * s4 + lk];
+            const double* row = mU + (4 * s4 + lk) * Ld + lr;
 #pragma unroll
-          for (int t = 0; t < TJ1; ++t) wb[t] = (t < nts && any) ? row[16 * t] : 0.0;
-          if (s4 == ks - 1) { ++nbatch; gm2_post(fConsumed, nbatch, lane); }     // everything of this buffer is in registers
+            for (int t = 0; t < NTS; ++t) wb[t] = row[16 * t];
+            if (s4 == ks - 1) { ++nbatch; gm2_post(fConsumed, nbatch, lane); }     // everything of this buffer is in registers
 #pragma unroll
-          for (int t = 0; t < TJ1; ++t) ta[t] = wb[t] * dk;
-          int q = 0;
+            for (int t = 0; t < NTS; ++t) ta[t] = wb[t] * dk;
+            int q = 0;
 #pragma unroll
-          for (int tj = TJ0; tj < TJ1; ++tj)
+            for (int tj = TJ0; tj < TJ1; ++tj)
 #pragma unroll
-            for (int ti = 0; ti <= tj; ++ti, ++q)
-              if (tj < nts) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ti], wb[tj], acc[q], 0, 0, 0);
+              for (int ti = 0; ti <= tj; ++ti, ++q)
+                if (tj < NTS) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ti], wb[tj], acc[q], 0, 0, 0);
+          }
         }
-      }
+      };
+      const int ntc = nts < TJ1 ? nts : TJ1;
+      auto dispatch = [&](auto self, auto c) {
+        constexpr int V = decltype(c)::value;
+        if constexpr (V >= TJ1) consume(std::integral_constant<int, TJ1>{});
+        else if (ntc == V) consume(c);
+        else self(self, std::integral_constant<int, V + 1>{});
+      };
+      dispatch(dispatch, std::integral_constant<int, TJ0 + 1>{});
       lds_wave_sync();                                          // mPos
       // ---- epilogue (see k_schur_groups_mfma2): C/D layout lane -> column n = 16 tj + lane%16, register v -> row
       // m = 16 ti + lane/16 + 4 v; block (i, j), i <= j, at row pos_i, offset (pos_j - pos_i) * 36 + a * 6 + c
