@@ -119,7 +119,9 @@ struct ba_handle {
   int nmchunks = 0, nmgroups_total = 0;
   bool groups_ascending = false;
   int ngchunks = 0, group_rounds = 0;   // group_rounds == 0: k_schur_groups not applicable
-  bool groups_worth = false;            // points really share camera lists (mean run >= 2 points)
+  bool groups_worth = false;            // points really share camera lists (mean run >= 9 points): the run-by-run lineariser / back-substitution pay
+  bool mgroups_any = false;             // ... at least two points a run: the run-by-run reduction where there are no window groups
+  bool mgroups_worth = false;           // ... nearly all of them in full runs (mean >= 20 of 24): the run-by-run matrix-core reduction pays
   Gm3Params gm3{0, 0, 0, 0, 0, 1, 1};   // k_schur_groups_mfma3: tile count, staged row length, k-rows per buffer, points per batch, window
   DevBuf<SchurChunk> m3chunks;          // its chunks (window rows gm3.wn may differ from schur_wn)
   DevBuf<WinGroup> wgroups;             // its groups: points whose optimised cameras share a window of <= 24 positions

@@ -349,7 +349,11 @@ int ensure_plan(ba_handle* h) {
   std::vector<SchurGroup> groups, mgroups;
   std::vector<SchurChunk> gchunks, mchunks, m3chunks;
   int group_rounds = 0;
-  bool groups_worth = false;
+  // points per run of identical camera lists (runs are cut at kGroupMaxPts = 24) from which the kernels that work run by run pay:
+  // the lineariser / back-substitution a wavefront per run (below, their lanes idle), the matrix-core reduction a run per
+  // wavefront pair with an epilogue of its own (every extra run costs a pair ~20 us: only scenes that are ALL long runs)
+  constexpr double kGroupsWorthMean = 9.0, kMfmaGroupsWorthMean = 20.0;
+  bool groups_worth = false, mgroups_worth = false, mgroups_any = false;
   const bool groups_ascending = flags[SF_NOT_ASC] == 0;      // optimised positions ascend along every track (always, with the internal sort)
   Gm3Params gm3{0, 0, 0, 0, 0, 1, 1};
   if (maxL >= 1 && maxL <= kGm3MaxL) {
@@ -443,7 +447,12 @@ int ensure_plan(ba_handle* h) {
     if (maxL <= kGmMaxL && wn > 0) chunk_groups(gm_chunk, wn, mgroups, mlo, mhi, mchunks);
     // worth it only when points really share camera lists
     const double mean_group = groups.empty() ? 0.0 : (double)nt / groups.size();
-    groups_worth = mean_group >= 2.0;
+    // (a run of identical camera lists is worked on six points at a time and has an epilogue of its own: with runs of two or three
+    //  points - a fifth of the observations missing - the run kernels took 2.5 times what the window groups and the point-per-
+    //  lane-group kernels take: 0.73 against 0.29 ms per trial)
+    groups_worth = mean_group >= kGroupsWorthMean;
+    mgroups_worth = mean_group >= kMfmaGroupsWorthMean;
+    mgroups_any = mean_group >= 2.0;               // (still better than the vector kernels where there are no window groups)
     if (groups_worth && maxL <= kGroupMaxL && wn > 0) group_rounds = (int)((maxL * (maxL + 1) / 2 + 63) / 64);
   }
   // Window groups for k_schur_groups_mfma3: consecutive points (internal order: by first optimised position) whose
@@ -676,6 +685,8 @@ int ensure_plan(ba_handle* h) {
   h->nlong_points = rgroups.empty() ? 0 : nlong_points;
   h->gm3 = gm3;
   h->groups_worth = groups_worth;
+  h->mgroups_worth = mgroups_worth;
+  h->mgroups_any = mgroups_any;
   h->nmgroups_total = (int)mgroups.size();
   h->groups_ascending = groups_ascending;
   h->ngroups = (int)groups.size();

@@ -21,9 +21,10 @@ int pick_schur_kernel(const ba_handle* h) {
     case SCHUR_MFMA: return m3 ? KERN_MFMA3 : KERN_PAIRS;
     default: break;
   }
-  if (h->groups_worth && m12) return KERN_MFMA2;          // runs of identical camera lists, track length <= 10: the fixed-shape kernel (with the
+  if (h->mgroups_worth && m12) return KERN_MFMA2;          // runs of identical camera lists, track length <= 10: the fixed-shape kernel (with the
                                                           // camera blocks folded in it is 6 % faster than the general one's <0, 4, 64, 5> instance)
   if (m3 && h->wgroups_worth) return KERN_MFMA3;
+  if (h->mgroups_any && m12) return KERN_MFMA2;
   if (h->groups_worth && vec && h->group_rounds >= 1 && h->group_rounds <= 2) return KERN_GROUPS;
   return KERN_PAIRS;
 }
