@@ -52,10 +52,12 @@ scenes = [('oleg 100 x 1000 (real tracks)', Bundle.FromObservations(g['K'], g['R
           ('300 x 20000 L=16', scene(300, 20000, 16)),
           ('300 x 20000 L=16, 10 % missing', scene(300, 20000, 16, .1)),
           ('200 x 10000 L=24, 5 % missing', scene(200, 10000, 24, .05)),
+          ('300 x 20000 L=12, 10 % missing', scene(300, 20000, 12, .1)),
+          ('300 x 20000 L=13', scene(300, 20000, 13)),
           ('1000 x 20000 L=10 (20 points a camera step)', scene(1000, 20000, 10)),
           ('1000 x 5000 L=10 (5 points a camera step)', scene(1000, 5000, 10))]
 alts = [('auto', {}), ('schur=mfma2', {'schur': 'mfma2'}), ('schur=mfma', {'schur': 'mfma'}), ('schur=groups', {'schur': 'groups'}), ('schur=pairs', {'schur': 'pairs'}),
-        ('point_kernels=v1', {'point_kernels': 'v1'})]
+        ('point_kernels=v1', {'point_kernels': 'v1'}), ('fuse_cam=0', {'fuse_cam': '0'})]
 for name, b in scenes:
     out = []
     ref = None
