@@ -13,7 +13,10 @@ int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   h->defer = true;
   // with the MFMA reduction the camera blocks come out of the reduction itself: one launch and one pass
   // over the observations less
-  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(pick_schur_kernel(h));
+  // ... up to six tiles a side of the widest window (tracks of 16 cameras): beyond, the reduction is several launches over
+  // the observations and a separate k_camera_blocks is the cheaper way (tracks of 18 .. 40: 7 - 22 % of the trial)
+  const int kern = pick_schur_kernel(h);
+  const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(kern) && (kern != KERN_MFMA3 || h->gm3.nts <= 6);
   int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
   h->defer = false;
