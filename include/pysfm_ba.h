@@ -296,7 +296,9 @@ int ba_lm_trial_finish(ba_handle* h);
  *                        with the state of the log), 2 the reduced system of the next trial is not positive definite
  *                        (exit_info = 1 + the first unknown of the block of 12 columns in which the factorisation broke down), 3 a
  *                        singular point block in plain-inverse mode - for 2 and 3 the caller runs that one trial through
- *                        ba_lm_trial / the stepwise calls and comes back.
+ *                        ba_lm_trial / the stepwise calls and comes back; 4 the workgroups of the launch lost each other (compute
+ *                        units taken away underneath it): NOTHING happened - no trial is logged, the current set is the one the
+ *                        launch was given - and the caller goes on through ba_lm_trial (exit_info = trials the launch had walked).
  *   ba_lm_resident_begin / _end   the same in two halves: _begin launches and returns, _end waits and fills *log.  For a caller
  *                        with host work that does not depend on the run (window_slam.py prepares the NEXT window on a second
  *                        handle meanwhile); nothing else may be asked of the handle in between. */

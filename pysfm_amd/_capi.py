@@ -36,7 +36,7 @@ _bp = C.POINTER(C.c_uint8)
 _h = C.c_void_p
 
 RESIDENT_MAX_TRIALS = 1000       # BA_RESIDENT_MAX_TRIALS
-RESIDENT_DONE, RESIDENT_LOG_FULL, RESIDENT_NOT_POSITIVE_DEFINITE, RESIDENT_SINGULAR_POINT = 0, 1, 2, 3
+RESIDENT_DONE, RESIDENT_LOG_FULL, RESIDENT_NOT_POSITIVE_DEFINITE, RESIDENT_SINGULAR_POINT, RESIDENT_TIMED_OUT = 0, 1, 2, 3, 4
 
 
 class ResidentLog(C.Structure):

@@ -185,6 +185,18 @@ class _Cameras(list):
             self._all()
         list.__setitem__(self, i, c)
 
+    # what reads the raw storage at C level (concatenation, repetition, copies) would hand out the None placeholders
+    def __add__(self, other): return list(self) + list(other)
+    def __radd__(self, other): return list(other) + list(self)
+    def __mul__(self, n): return list(self) * n
+    __rmul__ = __mul__
+    def copy(self): return list(self)
+    def __iadd__(self, other):
+        list.extend(self, other)
+        return self
+    def __imul__(self, n):
+        raise TypeError('a camera list over stacked poses cannot be repeated in place')
+
 
 class _LazyTracks(object):
     """Sequence of Track views over a CSR observation table (array-native bundles)."""
@@ -362,10 +374,13 @@ class Bundle(object):
             # a window of consecutive cameras over an array-native bundle (window_slam.py:17-48: frame after frame): the table
             # is sorted by (track, camera), so what a track contributes is ONE stretch of its rows - two binary searches per
             # track instead of a pass over every row of the selected tracks
-            nc_all = max(len(self.cameras), 1)
-            key = getattr(self, '_table_key', None)
-            if key is None or len(key) != len(trk):
-                key = self._table_key = trk.astype(np.int64) * nc_all + cam
+            # (the multiplier is cached WITH the key: add_camera() on an array-native bundle changes len(cameras), and a key built
+            #  with another multiplier than `base` finds the wrong rows without any error)
+            cached = getattr(self, '_table_key', None)
+            if cached is None or len(cached[1]) != len(trk):
+                nc_key = max(len(self.cameras), int(cam.max()) + 1 if len(cam) else 1, 1)
+                cached = self._table_key = (nc_key, trk.astype(np.int64) * nc_key + cam)
+            nc_all, key = cached
             base = tids * nc_all
             lo = np.searchsorted(key, base + int(cids[0]), 'left')
             hi = np.searchsorted(key, base + int(cids[-1]), 'right')

@@ -420,7 +420,7 @@ class BundleAdjuster(object):
         on the device (launched: the first launch has been made, optimize_begin).  A trial the resident loop cannot take (a reduced system that is not positive definite: the reference
         solves it by LU; a singular point block in plain-inverse mode: the reference raises) goes through trial() and the
         loop resumes on the device."""
-        from ._capi import RESIDENT_DONE, RESIDENT_LOG_FULL
+        from ._capi import RESIDENT_DONE, RESIDENT_LOG_FULL, RESIDENT_TIMED_OUT
         be = self.backend
         in_step = False
         cam_mask = self._resident_cam_mask(param_mask)
@@ -433,6 +433,18 @@ class BundleAdjuster(object):
             else:
                 log = be.lm_resident(max_steps, self.num_steps, in_step, self.converged, self._damping, improvement_threshold,
                                      self.SCHUR_COMPLIMENT_PINV_THRESHOLD, self._cur_cost, cam_mask)
+            if log.exit_reason == RESIDENT_TIMED_OUT:
+                # the launch's workgroups lost each other (compute units taken away underneath it, a partitioned device):
+                # nothing happened on the device, the schedule stands where it stood - the Python loop takes over for good
+                import warnings
+                warnings.warn('pysfm_amd: the resident loop timed out; continuing with the loop over ba_lm_trial', RuntimeWarning)
+                self.resident = False
+                self.resident_timeouts = getattr(self, 'resident_timeouts', 0) + 1
+                if in_step:
+                    self.num_steps -= 1                 # (step() counts the step we are in the middle of again)
+                while not self.converged and self.num_steps < max_steps:
+                    self.step(param_mask, improvement_threshold)
+                return self.converged
             if self._cur_cost is None and log.have_cost0:
                 self._cur_cost = log.cost0
             if not self.costs and self._cur_cost is not None:

@@ -961,10 +961,12 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   {
     const double* cm_cur = camL + cur * nc * 12;
     const double* X_cur = XL + cur * kResP * 3;
+    // (a launch whose workgroups lost each other leaves the set it was given untouched: they may not agree on how far they came)
+    const bool write_back = accepted_any && exit_reason != RES_TIMED_OUT;
     if (grp == 0)
-      for (int i = tid; i < nc * 12; i += kResThreads) { if (accepted_any) A.cams[i] = cm_cur[i]; A.out[i] = cm_cur[i]; }
+      for (int i = tid; i < nc * 12; i += kResThreads) { if (write_back) A.cams[i] = cm_cur[i]; A.out[i] = cm_cur[i]; }
     for (int i = tid; i < np * 3; i += kResThreads) {
-      if (accepted_any) A.X[(size_t)p0 * 3 + i] = X_cur[i];
+      if (write_back) A.X[(size_t)p0 * 3 + i] = X_cur[i];
       A.out[(size_t)nc * 12 + (size_t)p0 * 3 + i] = X_cur[i];
     }
   }

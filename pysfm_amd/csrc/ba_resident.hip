@@ -16,6 +16,8 @@ bool resident_shape(const ba_handle* h) {
   if (!h->opt.resident || h->comm) return false;
   if (h->nco < 1 || h->nco > kResMaxNco || h->nc > kResMaxNc || h->nt < 1 || h->nt > kResMaxNt) return false;
   if (h->group_maxL < 1 || h->group_maxL > kResMaxL || h->nobs < 1 || h->nobs > (1 << 20)) return false;
+  // its workgroups wait for each other and each fills the LDS of a compute unit: all of them must be resident at once
+  if ((h->nt + kResP - 1) / kResP > h->ncu) return false;
   return resident_lds(h->nc, h->nco, h->group_maxL).bytes <= 157 * 1024;
 }
 
@@ -139,8 +141,13 @@ int ba_lm_resident_end(ba_handle* h, ba_resident_log* log) {
     (void)hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream);
     h->res_epoch0 = 0;
     (void)resident_reset_cost_words(h);
-    h->have_params[p] = false;
-    return h->fail(BA_ERR_HIP, "ba_lm_resident: the workgroups of the resident loop lost each other (timed out after %d trials)", a.log->ntrials);
+    // the kernel wrote nothing back (ba_resident.h): the current set is the one the launch was given, and the log says so -
+    // no trial, nothing accepted, the schedule where it was.  The caller goes on through ba_lm_trial.
+    h->err = "ba_lm_resident: the workgroups of the resident loop lost each other (timed out); nothing was changed";
+    memset(log, 0, offsetof(ResidentLog, trial_damping));
+    log->exit_reason = RES_TIMED_OUT;
+    log->exit_info = a.log->ntrials;
+    return BA_OK;
   }
   {
     // the header and what the trials wrote (the log is 20 KB, a window's run fills a fiftieth of it)

@@ -138,6 +138,18 @@ def tabulate(model):
     return capi.SENSOR_TABLE, np.concatenate(([TABLE_LOG2_RHO_MIN, float(TABLE_NODES_PER_OCTAVE), float(n)], tab.reshape(-1)))
 
 
+_FINGERPRINT_RADII = (2. ** -20, 1e-3, .05, .7, 1., 3.1, 40., 2. ** 20)
+
+
+def _fingerprint(model):
+    """The entries of the model's Jacobian along e = (rho, 0) at a few radii: what the table is built from."""
+    out = []
+    for rho in _FINGERPRINT_RADII:
+        J = np.asarray(model.Jresidual_from_error(np.array([rho, 0.])), float)
+        out += [float(J[0, 0]), float(J[1, 1])]
+    return tuple(out)
+
+
 def device_params_of(model):
     """(kind, params) for our models, for duck-typed reference models (classes named GaussianModel with .L / CauchyModel
     with .sigma), and - the reference's plug-in point, sensor_model.py:19-32 / bundle.py:269-273 - for ANY object with
@@ -153,14 +165,18 @@ def device_params_of(model):
     if name == 'HuberModel' and hasattr(model, 'k'):
         return capi.SENSOR_HUBER, np.array([model.k], float)
     if hasattr(model, 'residual_from_error') and hasattr(model, 'Jresidual_from_error'):
+        # cached on the object WITH a fingerprint of the model as it is now - h and h' rho at a few radii - so that a model
+        # whose parameters the caller changed afterwards (sigma = ...), or a clone() that carried the attribute along, is
+        # sampled again instead of running the device on the old robustifier
+        fp = _fingerprint(model)
         cached = getattr(model, '_pysfm_amd_table', None)
-        if cached is None:
-            cached = tabulate(model)
+        if cached is None or cached[0] != fp:
+            cached = (fp, tabulate(model))
             try:
                 model._pysfm_amd_table = cached
             except AttributeError:
                 pass
-        return cached
+        return cached[1]
     raise TypeError('sensor model %r has no device form: it needs residual_from_error and Jresidual_from_error' % (model,))
 
 

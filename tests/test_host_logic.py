@@ -630,9 +630,10 @@ class _ResidentDouble(OracleBackend):
     csrc/ba_resident.h restated in Python: runs trials until done, until its log is full (`capacity`), or until it meets a
     trial it refuses (`refuse`: indices of trials, counted over the whole run, that end the launch with exit reason 2)."""
 
-    def __init__(self, capacity=1000, refuse=()):
+    def __init__(self, capacity=1000, refuse=(), lose_launch=None):
         OracleBackend.__init__(self)
         self.capacity, self.refuse, self.seen, self.launches = capacity, set(refuse), 0, 0
+        self.lose_launch = lose_launch        # the launch (counted from 1) whose workgroups "lose each other": exit reason 4, nothing done
 
     def lm_resident_fits(self):
         return True
@@ -643,6 +644,9 @@ class _ResidentDouble(OracleBackend):
         log = SimpleNamespace(ntrials=0, nsteps=steps_taken, converged=int(bool(converged)), in_step=int(bool(in_step)), exit_reason=0,
                               exit_info=0, accepted=0, have_cost0=0, damping=damping, cost0=0., cur_cost=-1. if cur_cost is None else cur_cost,
                               trial_damping=[], trial_cost=[], trial_accepted=[])
+        if self.launches == self.lose_launch:
+            log.exit_reason, log.nsteps, log.in_step, log.converged, log.damping = 4, 0, 0, 0, 0.      # (the C side zeroes the header)
+            return log
         while True:
             if not log.in_step:
                 if log.converged or log.nsteps >= max_steps:
@@ -721,6 +725,77 @@ def test_the_log_of_the_resident_loop_replays_into_the_reference_walk(name, step
     assert masked.backend.launches >= 1
     assert [(d, o) for d, o, _ in masked.trial_log] == [(d, o) for d, o, _ in pm.trial_log]
     close(masked.costs, pm.costs, 1e-12)
+
+
+@pytest.mark.parametrize('capacity,lose', [(1000, 1), (3, 2), (2, 3)])
+def test_a_resident_launch_that_times_out_hands_over_to_the_python_loop(capacity, lose):
+    """ADVICE round 4: exit reason 4 (the workgroups lost each other) leaves the device's current set and the schedule untouched;
+    optimize() must neither raise nor lose the state - it finishes on the general loop and walks the reference's walk."""
+    g = load_golden('scene_5x50_gauss')
+    plain = BundleAdjuster(bundle_of(g), backend=OracleBackend(), verbose=False)
+    plain.optimize(max_steps=5)
+    be = _ResidentDouble(capacity, lose_launch=lose)
+    ba = BundleAdjuster(bundle_of(g), backend=be, verbose=False)
+    with pytest.warns(RuntimeWarning, match='resident loop timed out'):
+        ba.optimize(max_steps=5)
+    assert be.launches == lose and ba.resident is False and ba.resident_timeouts == 1
+    assert (ba.num_steps, ba.converged, ba.lm_trials) == (plain.num_steps, plain.converged, plain.lm_trials)
+    assert [(d, o) for d, o, _ in ba.trial_log] == [(d, o) for d, o, _ in plain.trial_log]
+    close(ba.costs, plain.costs, 1e-12)
+    close(ba.bundle.reconstruction, plain.bundle.reconstruction, 1e-12)
+
+
+def test_select_observations_after_add_camera_on_an_array_native_bundle():
+    """the cached (track, camera) key of the consecutive-camera fast path carries its own multiplier."""
+    rs = np.random.RandomState(11)
+    nc, nt = 6, 9
+    cam, trk = np.nonzero(rs.rand(nc, nt) < .7)
+    b = Bundle.FromObservations(np.eye(3), np.tile(np.eye(3), (nc, 1, 1)), np.zeros((nc, 3)), np.ones((nt, 3)), cam, trk, rs.randn(len(cam), 2))
+    want = b.select_observations(range(1, 4), [7, 2, 3])
+    b.add_camera()
+    got = b.select_observations(range(1, 4), [7, 2, 3])                     # first call after the camera count changed
+    for a, w in zip(got, want):
+        assert np.array_equal(a, w)
+    b2 = Bundle.FromObservations(np.eye(3), np.tile(np.eye(3), (nc, 1, 1)), np.zeros((nc, 3)), np.ones((nt, 3)), cam, trk, rs.randn(len(cam), 2))
+    first = b2.select_observations(range(1, 4), [7, 2, 3])                  # key cached with nc = 6 ...
+    b2.add_camera()
+    again = b2.select_observations(range(1, 4), [7, 2, 3])                  # ... and used with nc = 7
+    for a, w in zip(again, first):
+        assert np.array_equal(a, w)
+    ci, ti, _ = again
+    assert ci.min() >= 0 and ci.max() <= 2 and ti.max() <= 2
+
+
+def test_a_foreign_sensor_model_is_sampled_again_when_its_parameters_change():
+    """the table cached on a caller's model carries a fingerprint of the model it was sampled from."""
+    class Geman(object):
+        def __init__(self, s): self.s = s
+        def cost_from_error(self, e): r = self.residual_from_error(e); return float(np.dot(r, r))
+        def residual_from_error(self, e):
+            e = np.asarray(e, float); return e / np.sqrt(self.s * self.s + e.dot(e))
+        def Jresidual_from_error(self, e):
+            e = np.asarray(e, float); d = self.s * self.s + e.dot(e)
+            return np.eye(2) / np.sqrt(d) - np.outer(e, e) / d ** 1.5
+    m = Geman(.5)
+    k1, p1 = sensor_model.device_params_of(m)
+    k1b, p1b = sensor_model.device_params_of(m)
+    assert p1b is p1                                                         # unchanged model: the cached table
+    m.s = 2.
+    k2, p2 = sensor_model.device_params_of(m)
+    assert not np.array_equal(p1, p2)
+    _, fresh = sensor_model.tabulate(Geman(2.))
+    assert np.array_equal(p2, fresh)
+
+
+def test_cameras_over_stacked_arrays_concatenate_and_copy():
+    """list operations that read the raw storage must not hand out the lazy placeholders."""
+    R = np.tile(np.eye(3), (4, 1, 1)); t = np.arange(12.).reshape(4, 3)
+    b = Bundle.FromObservations(np.eye(3), R, t, np.ones((2, 3)), [0, 1, 2, 3], [0, 0, 1, 1], np.zeros((4, 2)))
+    extra = Camera(np.eye(3), np.ones(3))
+    both = b.cameras + [extra]
+    assert type(both) is list and len(both) == 5 and all(c is not None for c in both) and np.array_equal(both[2].t, t[2])
+    assert all(c is not None for c in [extra] + b.cameras) and all(c is not None for c in b.cameras * 2)
+    assert all(c is not None for c in b.cameras.copy()) and len(2 * b.cameras) == 8
 
 
 def test_cameras_over_stacked_arrays_behave_like_a_list():
