@@ -47,7 +47,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mf
 # What binds each kernel at the bench sizes; `roofline.limited_by` reports it.  The contract prices
 # `achieved` against HBM for every kernel that is not MFMA-bound, so `frac` is always achieved / 8 TB/s.
 KERNEL_BOUND = {'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
-                'dense_solve': 'latency', 'schur_pairs': 'mfma', 'linearize': 'hbm', 'backsub': 'hbm', 'cost': 'hbm',
+                'dense_solve': 'latency', 'schur_pairs': 'mfma', 'linearize': 'fp64 issue + gather latency', 'backsub': 'fp64 issue', 'cost': 'hbm',
                 'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
 # timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
 KERNEL_NAMES = {'linearize': 'k_linearize_groups (k_linearize when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init',
@@ -66,6 +66,49 @@ def schur_flops(nobs, nt):
     T = W HPPinv (6x3x3) and L(L+1)/2 block products T W^T (6x3x6), 2 flops per FMA."""
     L = nobs / max(nt, 1)
     return nt * (L * 54 + L * (L + 1) / 2 * 108) * 2
+
+
+FP64_RIDGE_FLOP_PER_BYTE = FP64_MATRIX_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)      # 9.8: above it the fp64 pipe is the roof, not HBM
+LINEARISE_FLOPS_PER_OBS = 450.   # SURVEY 8(d): projection, chain rule, Jc^T Jc, Jp^T Jp, Jc^T Jp, J^T r
+
+
+def useful_flops(kernel, nc, nco, nt, nobs, hb):
+    """Useful fp64 flops of one trial's launches of `kernel` (2 per FMA; what the algorithm needs ONCE - a kernel that
+    linearises an observation again, pads its tiles or factors a block redundantly is not credited for it).
+    SURVEY 8(d): 0.45 kflop per observation for the linearisation, (108 + 216 L) per observation for the Schur products
+    over all ordered camera pairs of a track - S is symmetric, so the reduction is credited with the upper half,
+    schur_flops()."""
+    L = nobs / max(nt, 1)
+    if kernel == 'linearize':
+        return LINEARISE_FLOPS_PER_OBS * nobs
+    if kernel == 'schur_pairs':
+        return schur_flops(nobs, nt)
+    if kernel == 'point_invert':          # damping, 3x3 eigen-solve (Jacobi sweeps), pinv, L D L^T: ~400 per point
+        return 400. * nt
+    if kernel == 'backsub':               # Jc dC (24), Jp^T (.) (12) per observation, HPPinv (.) per point, Rodrigues per camera, the trial cost
+        return (36. + 60.) * nobs + 18. * nt + 120. * nc
+    if kernel == 'cost':
+        return 60. * nobs
+    if kernel in ('bcr_eliminate', 'bcr_backsolve', 'bcr_assemble'):
+        # block cyclic reduction, N nodes of B = 6 hb unknowns: per node Cholesky B^3/3, P and Q (two triangular solves with B
+        # right-hand sides, B^3 each), G^-1 (B^3/3), P^T P and Q^T Q (symmetric, B^3 each), the two couplings of the next
+        # level (2 B^3 each): 8.67 B^3; back-substitution 3 matrix-vector products (6 B^2)
+        B = 6. * max(hb, 1)
+        N = -(-nco // max(hb, 1))
+        if kernel == 'bcr_eliminate':
+            return N * (26. / 3. * B ** 3 + 6. * B * B)
+        if kernel == 'bcr_backsolve':
+            return N * 6. * B * B
+        return 0.
+    return 0.
+
+
+def minimal_bytes(kernel, nc, nco, nt, nobs, nunits, hb):
+    """What `kernel` MUST move (inputs in, results out), where that is less than algorithmic_bytes: the reduced solve reads the
+    band and the right-hand side and writes the solution - its D, U, P, Q, G^-1 workspace is the algorithm's own."""
+    if kernel in ('bcr_eliminate', 'band_solve', 'dense_solve'):
+        return 288 * nco * (hb + 1) + 2 * 48 * nco
+    return algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb)
 
 
 def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb, launches=1.):
@@ -415,6 +458,76 @@ def small_problems():
     return out
 
 
+# the reference itself (lib2to3 translation, 1 core Xeon 2.1 GHz) on its own dataset, data/oleg_synthetic
+REFERENCE_ON_OLEG = {'prepare_schur_complement_s': 3.54, 'compute_schur_complement_s': 24.65, 'solve_s': 0.0145, 'backsubstitute_s': 0.14,
+                     'compute_cost_s': 0.92, 'compute_update_s': 28.3, 'hardware': '1 core Intel Xeon 2.1 GHz (the survey container)',
+                     'source': 'BASELINE.md, "Reference path measured during the survey" (bundle_adjuster.py:165-331 on data/oleg_synthetic)'}
+
+
+def reference_dataset():
+    """The ONE input on which a number of the reference exists: its own data/oleg_synthetic (100 cameras x 1000 tracks, every
+    track seen by every camera, 100 000 observations; committed as tests/golden/scene_oleg_100x1000.npz together with the
+    reference's own compute_update(10.) on it).  compute_update(10.) and optimize(max_steps=10) as the reference's callers
+    run them (batch_ba.py:34-35, test_bundle.py:252-253), wall clock and per kernel, beside BASELINE.md's timings of the
+    reference, and the update checked against the reference's."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    path = os.path.join(ROOT, 'tests', 'golden', 'scene_oleg_100x1000.npz')
+    if not os.path.exists(path):
+        return {'error': 'fixture missing: ' + path}
+    g = np.load(path)
+    model = sensor_model.GaussianModel(1.) if int(g['sensor_kind']) == 0 else sensor_model.CauchyModel(float(g['sensor_sigma']))
+    b = Bundle.FromObservations(g['K'], g['R'].reshape(-1, 3, 3), g['t'], g['X'], g['obs_cam'], g['obs_pt'], g['obs_z'], sensor_model=model)
+    import torch
+    ba = BundleAdjuster(verbose=False)
+    ba.set_bundle(b)
+    be = ba.backend
+    ba.compute_update(10.)                                # warm-up: code objects, work lists
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.time()
+    for _ in range(reps):
+        mu, su = ba.compute_update(10.)
+    torch.cuda.synchronize()
+    t_update = (time.time() - t0) / reps
+    dC_ref = np.asarray(g['l10_dC'])
+    err = float(np.max(np.abs(-mu - dC_ref)) / np.max(np.abs(dC_ref)))
+    t0 = time.time()
+    for _ in range(reps):
+        c = ba.compute_cost(ba.bundle)
+    t_cost = (time.time() - t0) / reps
+    be.enable_timing(True)
+    be.timings(reset=True)
+    for _ in range(reps):
+        ba.compute_update(10.)
+    tm = {k: v['ms'] / reps for k, v in be.timings(reset=True).items() if v['launches'] > 0}
+    be.enable_timing(False)
+    ba.set_bundle(b)
+    ba.optimize(max_steps=10)
+    t0 = time.time()
+    ba.set_bundle(b)
+    ba.optimize(max_steps=10)
+    _ = ba.bundle
+    torch.cuda.synchronize()
+    t_opt = time.time() - t0
+    trials = int(ba.lm_trials)
+    tb = Bundle.FromObservations(g['K'], g['R'].reshape(-1, 3, 3), g['t'], g['X'], g['obs_cam'], g['obs_pt'], g['obs_z'], sensor_model=model)
+    tb.triangulate_all()
+    t0 = time.time()
+    tb.triangulate_all()
+    t_tri = time.time() - t0
+    out = {'workload': "the reference's own dataset data/oleg_synthetic: 100 cameras x 1000 tracks, dense visibility, 100 000 observations "
+                       '(tests/golden/scene_oleg_100x1000.npz), Gaussian model, camera 0 frozen',
+           'compute_update_s': t_update, 'compute_update_obs_per_s': len(g['obs_cam']) / t_update,
+           'compute_update_max_rel_diff_to_the_reference': err, 'compute_cost_s': t_cost, 'cost': float(c), 'cost_of_the_reference': float(g['l10_cost']),
+           'kernel_ms_per_compute_update': tm, 'schur_kernel': be.problem_info().get('schur_kernel'), 'half_bandwidth': be.half_bandwidth,
+           'solve_kind': getattr(be, 'last_solve_kind', None),
+           'set_bundle_optimize_10_steps_bundle_s': t_opt, 'optimize_lm_trials': trials, 'optimize_steps': int(ba.num_steps),
+           'optimize_costs': [float(ba.costs[0]), float(ba.costs[-1])], 'triangulate_all_s': t_tri,
+           'reference': REFERENCE_ON_OLEG, 'speedup_of_compute_update_over_the_reference': REFERENCE_ON_OLEG['compute_update_s'] / t_update}
+    be.close()
+    return out
+
+
 def live_pmc_traffic(argv, kernels, timeout_s=150):
     """`roofline.traffic` measured in THIS run: two rocprofv3 passes of this same command (`--pmc FETCH_SIZE`, then
     `--pmc WRITE_SIZE`: the two do not fit one pass; counters only, no trace domains), a few trials each, and per kernel
@@ -760,20 +873,53 @@ def main():
         sflops = schur_flops(nobs_local, be.nt)
         # the whole reduction of one trial (one launch up to track length 13, two to four beyond: DESIGN.md)
         schur_ms = ours['schur_pairs']['ms'] / nprof if 'schur_pairs' in ours else None
-        bound = KERNEL_BOUND.get(dom, 'hbm')
-        # the contract's `bound` is the roof `frac` is priced against ("hbm" | "mfma"); what actually limits the kernel is `limited_by`
-        roof = {'bound': bound if bound in ('hbm', 'mfma') else 'hbm', 'limited_by': bound, 'kernel': KERNEL_NAMES.get(dom, 'k_' + dom), 'timer': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+        limited = KERNEL_BOUND.get(dom, 'hbm')
+        # Which roof binds: the kernel's arithmetic intensity (useful flops of its launches in one trial / the bytes they must
+        # move) against the fp64 ridge, 78.6 TF / 8 TB/s = 9.8 flop/B.  Above it `frac` is priced against the fp64 matrix /
+        # vector peak ("mfma"), below against HBM; the other roof's numbers ride along (hbm_* / fp64_*), and `limited_by`
+        # says what the counters and time lines show actually limits the kernel (profiles/r05_sq_counters.csv).
+        n_launch = max(1., (ours[dom]['launches'] / nprof) if dom in ours else 1.)
+        step_ms = avg_ms * n_launch                                     # this kernel's launches of ONE trial
+        flops = useful_flops(dom, be.nc, nco, be.nt, nobs_local, hb)
+        if dom == 'bcr_eliminate' and 'bcr_backsolve' not in ours:
+            flops += useful_flops('bcr_backsolve', be.nc, nco, be.nt, nobs_local, hb)
+        min_bytes = minimal_bytes(dom, be.nc, nco, be.nt, nobs_local, be.nt, hb)
+        intensity = flops / max(1., min_bytes)
+        tflops = flops / (step_ms * 1e-3) / 1e12
+        priced = 'mfma' if intensity > FP64_RIDGE_FLOP_PER_BYTE else 'hbm'
+        roof = {'bound': priced, 'limited_by': limited, 'kernel': KERNEL_NAMES.get(dom, 'k_' + dom), 'timer': dom,
+                'achieved': tflops if priced == 'mfma' else achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS if priced == 'mfma' else HBM_PEAK_GBS,
+                'unit': 'TFLOP/s' if priced == 'mfma' else 'GB/s',
+                'frac': tflops / FP64_MATRIX_PEAK_TFLOPS if priced == 'mfma' else achieved / HBM_PEAK_GBS,
+                'traffic': traffic, 'traffic_source': traffic_src,
                 'traffic_stale_possible': bool(traffic is not None and traffic_src != 'live'), 'traffic_note': live_note,
+                'flops': flops, 'frac_fp64': tflops / FP64_MATRIX_PEAK_TFLOPS, 'fp64_achieved_tflops': tflops, 'fp64_peak_tflops': FP64_MATRIX_PEAK_TFLOPS,
+                'arithmetic_intensity_flop_per_byte': intensity, 'ridge_flop_per_byte': FP64_RIDGE_FLOP_PER_BYTE,
+                'bytes_in_plus_out_per_trial': min_bytes, 'hbm_achieved_GBps': achieved, 'hbm_frac': achieved / HBM_PEAK_GBS,
+                'hbm_frac_in_plus_out': min_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
-                'algorithmic_bytes_per_launch': B, 'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'],
+                'algorithmic_bytes_per_launch': B, 'avg_launch_ms': avg_ms, 'launches': tm_dom['launches'], 'launches_per_trial': n_launch,
                 'note': 'HIP events on the launch stream during the timed steps, every %d-th step; back-to-back launches of one kernel ' % ev_stride +
-                        'share one event pair, avg = elapsed / launches; algorithmic bytes per launch = bytes of the whole step / its launches.  limited_by = what limits this kernel '
-                        '(latency: a chain of dependent pivots, neither HBM nor the matrix cores); achieved / frac are priced against HBM'}
-        if bound == 'mfma' and schur_ms:
-            roof.update({'achieved': sflops / (schur_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': sflops / (schur_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'useful_flops_per_reduction': sflops,
-                         'reduction_ms': schur_ms, 'hbm_GBps': achieved})
+                        'share one event pair, avg = elapsed / launches.  flops = useful fp64 flops of this kernel per trial (bench.py useful_flops); '
+                        'algorithmic_bytes_per_launch counts the workspace the algorithm itself writes and re-reads (hbm_achieved_GBps), '
+                        'bytes_in_plus_out_per_trial only what must cross HBM.  limited_by: latency = a chain of dependent pivots and hand-overs '
+                        'between workgroups, neither roof'}
+        if dom == 'schur_pairs' and schur_ms:
+            roof.update({'useful_flops_per_reduction': sflops, 'reduction_ms': schur_ms})
+        # every kernel of the trial against both roofs
+        per_kernel = {}
+        for k, v in ours.items():
+            kms = v['ms'] / nprof
+            if not kms > 0.:
+                continue
+            kb = ab(k) * (v['launches'] / nprof)
+            kf = useful_flops(k, be.nc, nco, be.nt, nobs_local, hb)
+            mb = minimal_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, hb)
+            per_kernel[k] = {'ms_per_trial': kms, 'flops': kf, 'bytes': kb, 'bytes_in_plus_out': mb, 'intensity': kf / max(1., mb),
+                             'bound': 'mfma' if kf / max(1., mb) > FP64_RIDGE_FLOP_PER_BYTE else 'hbm', 'limited_by': KERNEL_BOUND.get(k, 'hbm'),
+                             'GBps': kb / (kms * 1e-3) / 1e9, 'frac_hbm': kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'tflops': kf / (kms * 1e-3) / 1e12, 'frac_fp64': kf / (kms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS}
+        roof['per_kernel'] = per_kernel
         # the pass BASELINE's metric counts: linearise + point inversion + Schur reduction
         pass_kernels = [k for k in ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs') if k in ours]
         pass_ms = sum(ours[k]['ms'] for k in pass_kernels) / nprof
@@ -819,6 +965,11 @@ def main():
                 'traffic_source': 'live' if pass_traffic_live else 'committed summary (possibly stale)',
                 'traffic_per_kernel': {k: traffic_of(k)[0] for k in ours},
                 'obs_jacobians_per_s': nobs_local / max(1e-9, pass_ms * 1e-3),
+                'flops': LINEARISE_FLOPS_PER_OBS * nobs_local + sflops + 400. * be.nt,
+                'arithmetic_intensity_flop_per_byte': (LINEARISE_FLOPS_PER_OBS * nobs_local + sflops + 400. * be.nt) / pass_bytes,
+                'bound': 'mfma' if (LINEARISE_FLOPS_PER_OBS * nobs_local + sflops + 400. * be.nt) / pass_bytes > FP64_RIDGE_FLOP_PER_BYTE else 'hbm',
+                'achieved_tflops': (LINEARISE_FLOPS_PER_OBS * nobs_local + sflops + 400. * be.nt) / max(1e-9, pass_ms * 1e-3) / 1e12,
+                'frac_fp64': (LINEARISE_FLOPS_PER_OBS * nobs_local + sflops + 400. * be.nt) / max(1e-9, pass_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                 'note': 'bytes: observations 20/obs + cameras + points + point blocks and inverses (96 + 72 per point) + band S + b, each once; '
                         'W is never materialised'},
             'matrix_cores': {'kernel': 'k_schur_groups_mfma2 / k_schur_groups_mfma3 (timer schur_pairs)', 'useful_flops_per_reduction': sflops,
@@ -862,6 +1013,10 @@ def main():
                     oc[spec[0]] = quick_config(local_rank, *spec, scene_cache=cache)
                 except Exception as e:                     # one failing variant must not take the headline line with it
                     oc[spec[0]] = {'error': repr(e)}
+            try:
+                oc['reference_dataset_oleg_100x1000'] = reference_dataset()
+            except Exception as e:
+                oc['reference_dataset_oleg_100x1000'] = {'error': repr(e)}
             oc['wall_s'] = time.time() - t_oc
             out['other_configs'] = oc
             try:

@@ -86,6 +86,8 @@ int ba_synchronize(ba_handle* h);
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
  *   "gm_cap"        n                                      points per group of the MFMA reduction (0 = automatic)
  *   "gm_chunk"      n                                      groups per workgroup of the MFMA reductions (0 = automatic: 4, or 8 over several rounds)
+ *   "camera_order"  auto | off | always                    internal order of the optimised cameras (see ba_set_problem): auto = when the
+ *                                                          caller's order is not provably as narrow as an order can be
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
  * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap", "gm_chunk") take effect at
  * the next ba_set_problem. */
@@ -102,6 +104,12 @@ int ba_debug_poison(ba_handle* h);
  * identical camera lists next to each other, lists ordered by their first optimised camera - so that every
  * scene reaches the grouped kernels; all host-facing per-track / per-observation arrays (X, HPP, bP, dP, W,
  * e, r, Jc, Jp) are in the caller's order.  Option "sort_points" = 0 keeps the caller's order as it is.
+ * The same holds for the OPTIMISED CAMERAS: the reference's dense S does not care in which order optim_camera_ids lists the
+ * cameras (bundle_adjuster.py:259-312); the band stored here does, so when the widest spread of positions inside a track is
+ * larger than a track of that length needs, the library orders the cameras itself (Cuthill-McKee on the co-visibility
+ * hypergraph, pysfm_amd/csrc/ba_order.hip) and keeps that order if the band gets narrower.  Every array the ABI takes or returns
+ * by optimised position (S, b, dC, cam_param_mask, motion updates) stays in the CALLER's positions.  Not done for a handle with a
+ * communicator or a minimum band width set (the ranks of a sharded adjuster share one layout).
  *   obs_cam[nobs], obs_pt[nobs]  positions;  obs_z[nobs*2] measurements
  *   K[9]                         calibration (general 3x3)
  *   cam_opt_pos[nc]              position in optim_camera_ids, or -1 (frozen)
@@ -129,9 +137,17 @@ enum {
                                   producer-consumer any L <= 24), 5 dense visibility                                                   */
   BA_INFO_MFMA_POINTS_PER_BATCH_CAP,
   BA_INFO_MFMA_K_ROWS,
+  BA_INFO_CAMERAS_PERMUTED,    /* 1: the library ordered the optimised cameras itself (see ba_set_problem)                */
+  BA_INFO_CALLER_HALF_BANDWIDTH, /* the half-bandwidth the caller's camera order would have had                         */
   BA_INFO_COUNT
 };
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);
+
+/* The camera ordering ba_set_problem applies, as a pure function (no handle, no GPU): nco optimised cameras, nlists camera
+ * lists (list l = the optimised positions list_pos[list_off[l] .. list_off[l + 1]) one track sees; duplicates allowed).
+ * new_pos[p] = the position Cuthill-McKee on the co-visibility hypergraph gives the caller's position p (a permutation of
+ * 0 .. nco - 1); *half_bandwidth = the widest spread of new positions inside a list (either output may be NULL). */
+int ba_order_cameras(int32_t nco, int32_t nlists, const int32_t* list_off, const int32_t* list_pos, int32_t* new_pos, int32_t* half_bandwidth);
 
 /* ---- multi-GPU: the shards' collectives inside the library (one all-reduce of the reduced camera
  * system per linearisation, plus the 16 KB trial record), issued with RCCL on the handle's OWN stream - no

@@ -44,6 +44,12 @@ int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A
   if (nkeep == 0) return BA_OK;
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, h->keep.resize(nkeep));
+  std::vector<int> ikeep;
+  if (!h->cpos_in.empty()) {                     // flat parameter indices by the caller's camera positions -> the internal ones
+    ikeep.resize(nkeep);
+    for (int i = 0; i < nkeep; ++i) ikeep[i] = h->cpos_in[keep[i] / 6] * 6 + keep[i] % 6;
+    keep = ikeep.data();
+  }
   HIPCHECK(h, hipMemcpyAsync(h->keep.p, keep, nkeep * sizeof(int), hipMemcpyHostToDevice, h->stream));
   {
     ScopedTimer tm(h, BA_K_FLATTEN);

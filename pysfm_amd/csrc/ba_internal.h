@@ -67,7 +67,9 @@ struct Options {
   bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
   int resident_scatter_min = 5;    // ... whose launches of at least this many workgroups add their partial sums up in slices (two stages)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
+  int camera_order = 0;            // internal order of the optimised cameras (ba_order.hip): 0 auto (when the caller's is not provably as narrow as it can be), 1 off, 2 always try
 };
+enum { CAMORDER_AUTO = 0, CAMORDER_OFF, CAMORDER_ALWAYS };
 
 }  // namespace ba
 
@@ -151,7 +153,14 @@ struct ba_handle {
   // per internal point, kept on the host for the work lists that are built lazily: CSR offsets, lowest / highest optimised position
   std::vector<int> h_off, h_plo, h_phi;
   std::vector<unsigned char> h_same;   // point i has the camera list of point i - 1
-  std::vector<int> h_cam_opt_pos;      // the caller's cam_opt_pos
+  std::vector<int> h_cam_opt_pos;      // cam_opt_pos in the INTERNAL camera order (what the device holds)
+  // internal order of the optimised cameras (ba_order.hip): the caller's position p sits at internal position cpos_in[p], internal
+  // position q is the caller's cpos_out[q]; both empty = the caller's order.  Everything the C ABI takes or returns by optimised
+  // position goes through cam_rows_in / cam_rows_out.
+  std::vector<int> cpos_in, cpos_out;
+  int caller_hb = 0;                   // half-bandwidth the caller's camera order would have had
+  std::vector<unsigned char> mask_host; // the mask of the last solve in the internal order (outlives its asynchronous upload)
+  std::vector<double> rows_host;       // ... and the last per-camera rows that went up
   std::vector<int> plan_flags;         // the set-up's status record (SF_* of ba_setup_kernels.h)
   bool plan_pending = false;           // the work lists of the general kernels are not built yet (ensure_plan)
   // ba_set_problem's own device buffers (kept between calls: the sliding-window caller sets a problem per window)
@@ -294,6 +303,26 @@ hipError_t ensure_lds_attr(ba_handle* h, const void* fn);
 // rows of w doubles, perm[i] = the caller's index of internal row i (on the device: k_rows_permute).
 // device rows -> caller's host array (synchronises the stream when a permutation is in the way)
 int download_rows(ba_handle* h, const int* dev_perm, const double* dev, double* host, size_t n, int w);
+
+// rows of w values per optimised camera, caller's order -> internal order (`tmp` must outlive any asynchronous use of the result)
+template <typename T>
+inline const T* cam_rows_in(const ba_handle* h, const T* caller, std::vector<T>& tmp, int w) {
+  if (!caller || h->cpos_in.empty()) return caller;
+  tmp.resize((size_t)h->nco * w);
+  for (int p = 0; p < h->nco; ++p) std::copy(caller + (size_t)p * w, caller + (size_t)(p + 1) * w, tmp.begin() + (size_t)h->cpos_in[p] * w);
+  return tmp.data();
+}
+// ... and back, in place: data[q] (internal position q) -> data[cpos_out[q]]
+template <typename T>
+inline void cam_rows_out(const ba_handle* h, T* data, int w) {
+  if (!data || h->cpos_out.empty()) return;
+  std::vector<T> tmp(data, data + (size_t)h->nco * w);
+  for (int q = 0; q < h->nco; ++q) std::copy(tmp.begin() + (size_t)q * w, tmp.begin() + (size_t)(q + 1) * w, data + (size_t)h->cpos_out[q] * w);
+}
+
+// ---- ba_order.hip: Cuthill-McKee on the co-visibility hypergraph
+void cuthill_mckee_order(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, std::vector<int>& newpos);
+int order_half_bandwidth(const std::vector<int>& loff, const std::vector<int>& lpos, const std::vector<int>& newpos);
 
 inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + kBlock - 1) / kBlock); }
 DevProblem dev_problem(const ba_handle* h);

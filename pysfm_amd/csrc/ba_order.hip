@@ -1,0 +1,139 @@
+// ba_order.hip - the INTERNAL ORDER OF THE OPTIMISED CAMERAS (host code; no kernel).
+//
+// The reference builds a dense S[nco, nco, 6, 6] and solves it whatever the co-visibility pattern is
+// (bundle_adjuster.py:259-312).  Here S is a block band whose half-width is the widest spread of optimised-camera positions
+// inside one track - so the same scene handed over with its cameras in another order (an unordered image collection, ids
+// assigned by a database) would turn a 0.25 ms banded trial into a dense one.  ba_set_problem therefore chooses its own order
+// of the optimised cameras when the caller's is not provably as narrow as it can be: Cuthill-McKee on the co-visibility
+// hypergraph (cameras = nodes, tracks = hyper-edges), which needs no camera-camera adjacency - a breadth-first walk expands
+// every track once, O(observations of the DISTINCT camera lists).  Everything the C ABI hands over or returns by optimised
+// position (S, b, dC, masks, motion updates) goes through the permutation at the boundary (ba_handle::cpos_in / cpos_out).
+#include "ba_internal.h"
+
+namespace ba {
+
+namespace {
+
+struct Hyper {
+  int n = 0;                         // cameras (optimised positions)
+  std::vector<int> loff, lpos;       // distinct camera lists: positions lpos[loff[l] .. loff[l + 1])
+  std::vector<int> coff, clist;      // camera -> the lists it is in
+  std::vector<long long> deg;        // sum over its lists of (length - 1): the degree with multiplicities
+};
+
+// breadth-first from `start` over cameras not yet placed (placed[c] != 0): the visiting order (neighbours by ascending degree,
+// then by position: deterministic), the level of the last camera, and the cameras of the last level
+struct Walker {
+  const Hyper& g;
+  std::vector<int> cstamp, lstamp, level;
+  int stamp = 0;
+  explicit Walker(const Hyper& g_) : g(g_), cstamp(g_.n, 0), lstamp(g_.loff.size(), 0), level(g_.n, 0) {}
+  void walk(int start, const std::vector<char>& placed, std::vector<int>& order) {
+    ++stamp;
+    order.clear();
+    order.push_back(start);
+    cstamp[start] = stamp; level[start] = 0;
+    std::vector<int> fresh;
+    for (size_t q = 0; q < order.size(); ++q) {
+      const int u = order[q];
+      fresh.clear();
+      for (int e = g.coff[u]; e < g.coff[u + 1]; ++e) {
+        const int l = g.clist[e];
+        if (lstamp[l] == stamp) continue;          // every list is expanded once: by the first of its cameras the walk reaches
+        lstamp[l] = stamp;
+        for (int k = g.loff[l]; k < g.loff[l + 1]; ++k) {
+          const int d = g.lpos[k];
+          if (cstamp[d] == stamp || placed[d]) continue;
+          cstamp[d] = stamp; level[d] = level[u] + 1;
+          fresh.push_back(d);
+        }
+      }
+      std::sort(fresh.begin(), fresh.end(), [&](int a, int b) { return g.deg[a] != g.deg[b] ? g.deg[a] < g.deg[b] : a < b; });
+      order.insert(order.end(), fresh.begin(), fresh.end());
+    }
+  }
+};
+
+}  // namespace
+
+// Half-bandwidth the lists would have under `newpos` (caller position -> new position).
+int order_half_bandwidth(const std::vector<int>& loff, const std::vector<int>& lpos, const std::vector<int>& newpos) {
+  int hb = 0;
+  for (size_t l = 0; l + 1 < loff.size(); ++l) {
+    int lo = INT32_MAX, hi = -1;
+    for (int k = loff[l]; k < loff[l + 1]; ++k) { const int p = newpos[lpos[k]]; lo = std::min(lo, p); hi = std::max(hi, p); }
+    if (hi >= 0) hb = std::max(hb, hi - lo);
+  }
+  return hb;
+}
+
+// Cuthill-McKee order of nco cameras from the distinct camera lists (positions in the caller's order).  newpos[p] = the new
+// position of the caller's position p.  Start of every component: a pseudo-peripheral camera (George & Liu: walk, take the
+// lowest-degree camera of the last level, repeat while the depth grows).  Cameras no track sees keep their relative order
+// at the end.
+void cuthill_mckee_order(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, std::vector<int>& newpos) {
+  Hyper g;
+  g.n = nco; g.loff = loff; g.lpos = lpos;
+  const int nl = (int)loff.size() - 1;
+  g.coff.assign((size_t)nco + 1, 0);
+  g.deg.assign((size_t)nco, 0);
+  for (int l = 0; l < nl; ++l)
+    for (int k = loff[l]; k < loff[l + 1]; ++k) { ++g.coff[(size_t)lpos[k] + 1]; g.deg[lpos[k]] += loff[l + 1] - loff[l] - 1; }
+  for (int c = 0; c < nco; ++c) g.coff[(size_t)c + 1] += g.coff[c];
+  g.clist.resize(lpos.size());
+  {
+    std::vector<int> fill(g.coff.begin(), g.coff.end() - 1);
+    for (int l = 0; l < nl; ++l)
+      for (int k = loff[l]; k < loff[l + 1]; ++k) g.clist[fill[lpos[k]]++] = l;
+  }
+  std::vector<int> by_deg((size_t)nco);
+  for (int c = 0; c < nco; ++c) by_deg[c] = c;
+  std::sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return g.deg[a] != g.deg[b] ? g.deg[a] < g.deg[b] : a < b; });
+  std::vector<char> placed((size_t)nco, 0);
+  std::vector<int> order, full;
+  full.reserve((size_t)nco);
+  Walker w(g);
+  for (int c0 : by_deg) {
+    if (placed[c0] || g.coff[c0] == g.coff[(size_t)c0 + 1]) continue;
+    int start = c0, depth = -1;
+    for (int it = 0; it < 8; ++it) {
+      w.walk(start, placed, order);
+      const int d = w.level[order.back()];
+      if (d <= depth) break;
+      depth = d;
+      int best = order.back();
+      for (size_t q = order.size(); q-- > 0 && w.level[order[q]] == d;)
+        if (g.deg[order[q]] < g.deg[best] || (g.deg[order[q]] == g.deg[best] && order[q] < best)) best = order[q];
+      if (best == start) break;
+      start = best;
+    }
+    w.walk(start, placed, order);
+    for (int c : order) placed[c] = 1;
+    full.insert(full.end(), order.begin(), order.end());
+  }
+  for (int c = 0; c < nco; ++c)
+    if (!placed[c]) full.push_back(c);
+  newpos.assign((size_t)nco, 0);
+  for (int q = 0; q < nco; ++q) newpos[full[q]] = q;
+}
+
+}  // namespace ba
+
+extern "C" int ba_order_cameras(int32_t nco, int32_t nlists, const int32_t* list_off, const int32_t* list_pos, int32_t* new_pos,
+                                int32_t* half_bandwidth) {
+  if (nco < 0 || nlists < 0 || (nlists > 0 && (!list_off || !list_pos))) return BA_ERR_INVALID_ARG;
+  std::vector<int> loff(1, 0), lpos;
+  for (int l = 0; l < nlists; ++l) {
+    if (list_off[l + 1] < list_off[l]) return BA_ERR_INVALID_ARG;
+    for (int k = list_off[l]; k < list_off[l + 1]; ++k) {
+      if (list_pos[k] < 0 || list_pos[k] >= nco) return BA_ERR_INVALID_ARG;
+      lpos.push_back(list_pos[k]);
+    }
+    loff.push_back((int)lpos.size());
+  }
+  std::vector<int> newpos;
+  ba::cuthill_mckee_order(nco, loff, lpos, newpos);
+  if (new_pos) std::copy(newpos.begin(), newpos.end(), new_pos);
+  if (half_bandwidth) *half_bandwidth = ba::order_half_bandwidth(loff, lpos, newpos);
+  return BA_OK;
+}

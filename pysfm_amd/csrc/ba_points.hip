@@ -210,7 +210,8 @@ int ba_backsubstitute(ba_handle* h, int which, const double* dC, double* dP) {
           "ba_backsubstitute: dC is NULL and no device solution exists (ba_solve_reduced)");
   HIPCHECK(h, hipSetDevice(h->device));
   if (dC && h->nco) {
-    HIPCHECK(h, hipMemcpyAsync(h->dC.p, dC, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const double* src = cam_rows_in(h, dC, h->rows_host, 6);
+    HIPCHECK(h, hipMemcpyAsync(h->dC.p, src, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->have_solution = true;
   }
   // inside ba_lm_trial the update of the trial parameter set rides along (one launch less)
@@ -256,7 +257,8 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   double sign = -1.0;
   if (motion) {
     sign = 1.0;
-    if (h->nco) HIPCHECK(h, hipMemcpyAsync(h->dC.p, motion, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const double* src = cam_rows_in(h, motion, h->rows_host, 6);
+    if (h->nco) HIPCHECK(h, hipMemcpyAsync(h->dC.p, src, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (h->nt) { const int rc = upload_rows(h, h->pperm.empty() ? nullptr : h->d_pperm.p, structure, h->dP.p, (size_t)h->nt, 3); if (rc != BA_OK) return rc; }
     h->have_backsub = h->have_solution = false;   // dC / dP now hold the caller's update
   } else {

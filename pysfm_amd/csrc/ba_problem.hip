@@ -737,12 +737,12 @@ int ensure_plan(ba_handle* h) {
 
 }  // namespace ba
 
-extern "C" {
+namespace {
 
-int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
-                   const int32_t* obs_pt, const double* obs_z, const double* K,
-                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
-  if (!h) return BA_ERR_INVALID_ARG;
+// the problem with the optimised cameras at the positions given (ba_set_problem below chooses them)
+int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
+                     const int32_t* obs_pt, const double* obs_z, const double* K,
+                     const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
   REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
   REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
   REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
@@ -956,6 +956,59 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   return BA_OK;
 }
 
+// The internal order of the optimised cameras (ba_order.hip).  The problem has been set up in the caller's order; when that order
+// is not provably as narrow as an order can be (a track of L optimised cameras spreads over at least L - 1 positions), the
+// distinct camera lists come back from the device, Cuthill-McKee orders the cameras, and - if the band gets narrower - the
+// problem is set up again with the cameras at their new positions.  Costs nothing for a scene that arrives in sequence order.
+int choose_camera_order(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam, const int32_t* obs_pt,
+                        const double* obs_z, const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
+  const int nco = h->nco, hb0 = h->plan_flags[SF_HB];
+  h->caller_hb = hb0;
+  if (h->opt.camera_order == CAMORDER_OFF || h->min_hb > 0 || h->comm || nco < 3 || nobs == 0) return BA_OK;      // (sharded: the ranks must agree on one layout)
+  if (h->opt.camera_order != CAMORDER_ALWAYS && (hb0 <= std::max<long long>(1, h->group_maxL - 1) || resident_shape(h))) return BA_OK;
+  // the distinct camera lists, as optimised positions in the caller's order
+  std::vector<int> hobs((size_t)nobs);
+  HIPCHECK(h, hipMemcpyAsync(hobs.data(), h->obs_cam.p, (size_t)nobs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  std::vector<int> loff(1, 0), lpos;
+  for (int i = 0; i < nt; ++i) {
+    if (i > 0 && h->h_same[i]) continue;
+    const size_t before = lpos.size();
+    for (int n = h->h_off[i]; n < h->h_off[(size_t)i + 1]; ++n) {
+      const int p = cam_opt_pos[hobs[n]];
+      if (p >= 0) lpos.push_back(p);
+    }
+    if (lpos.size() - before >= 2) loff.push_back((int)lpos.size()); else lpos.resize(before);
+  }
+  std::vector<int> newpos;
+  cuthill_mckee_order(nco, loff, lpos, newpos);
+  const int hb1 = order_half_bandwidth(loff, lpos, newpos);
+  if (hb1 >= hb0) return BA_OK;
+  std::vector<int32_t> cop((size_t)nc);
+  for (int i = 0; i < nc; ++i) cop[i] = cam_opt_pos[i] >= 0 ? newpos[cam_opt_pos[i]] : -1;
+  const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cop.data(), pt_opt);
+  if (rc != BA_OK) return rc;
+  h->cpos_in = newpos;
+  h->cpos_out.assign((size_t)nco, 0);
+  for (int p = 0; p < nco; ++p) h->cpos_out[newpos[p]] = p;
+  h->caller_hb = hb0;
+  return BA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
+                   const int32_t* obs_pt, const double* obs_z, const double* K,
+                   const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  h->cpos_in.clear(); h->cpos_out.clear();
+  const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
+  if (rc != BA_OK) return rc;
+  return choose_camera_order(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
+}
+
 
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   if (h && h->have_problem) { const int rc = ensure_plan(h); if (rc != BA_OK) return rc; }
@@ -966,7 +1019,7 @@ int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   const int64_t v[BA_INFO_COUNT] = {
       h->pperm.empty() ? 0 : 1, h->operm_identity ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
       h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
-      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf};
+      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf, h->cpos_in.empty() ? 0 : 1, h->caller_hb};
   for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];
   return BA_OK;
 }

@@ -103,7 +103,8 @@ int ba_lm_resident_begin(ba_handle* h, int32_t max_steps, int32_t steps_taken, i
   a.damping = damping; a.improvement_threshold = improvement_threshold; a.rcond = pinv_rcond; a.cur_cost = cur_cost;
   a.have_mask = cam_param_mask ? 1 : 0;
   memset(a.mask, 1, sizeof a.mask);
-  if (cam_param_mask) for (int i = 0; i < 6 * h->nco; ++i) a.mask[i] = cam_param_mask[i] ? 1 : 0;
+  if (cam_param_mask)
+    for (int i = 0; i < 6 * h->nco; ++i) a.mask[h->cpos_in.empty() ? i : h->cpos_in[i / 6] * 6 + i % 6] = cam_param_mask[i] ? 1 : 0;
   a.log = static_cast<ResidentLog*>(h->res_log);
   a.trace = nullptr;
   a.dbg = nullptr;
@@ -187,9 +188,10 @@ int ba_lm_resident_debug(ba_handle* h, double* S_out, double* b_out, double* dC_
   REQUIRE(h, S_out && b_out && dC_out && h->res_trace, BA_ERR_STATE, "ba_lm_resident_debug: set option solve_trace and run ba_lm_resident first");
   const double* d = reinterpret_cast<const double*>(static_cast<const long long*>(h->res_trace) + 64 * 16);
   const int n = 6 * h->nco;
+  auto at = [&](int i) { return h->cpos_out.empty() ? i : h->cpos_out[i / 6] * 6 + i % 6; };      // internal parameter index -> the caller's
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) S_out[(size_t)i * n + j] = i >= j ? d[i * kResSLd + j] : d[j * kResSLd + i];
-  for (int i = 0; i < n; ++i) { b_out[i] = d[n * kResSLd + i]; dC_out[i] = d[(kResMaxN + 2) * kResSLd + i]; }
+    for (int j = 0; j < n; ++j) S_out[(size_t)at(i) * n + at(j)] = i >= j ? d[i * kResSLd + j] : d[j * kResSLd + i];
+  for (int i = 0; i < n; ++i) { b_out[at(i)] = d[n * kResSLd + i]; dC_out[at(i)] = d[(kResMaxN + 2) * kResSLd + i]; }
   return BA_OK;
 }
 

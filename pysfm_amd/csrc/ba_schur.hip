@@ -208,18 +208,21 @@ int ba_get_reduced(ba_handle* h, double* S, double* b) {
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   if (S && nco) {   // expand the block band to the reference's dense (nco,nco,6,6), mirroring the upper triangle
     std::memset(S, 0, (size_t)nco * nco * 36 * sizeof(double));
+    const int* out = h->cpos_out.empty() ? nullptr : h->cpos_out.data();      // internal position -> the caller's
     for (int i = 0; i < nco; ++i)
       for (int d = 0; d < hb1 && i + d < nco; ++d) {
         const double* src = &band[((size_t)i * hb1 + d) * 36];
-        double* up = S + ((size_t)i * nco + (i + d)) * 36;
+        const int r = out ? out[i] : i, q = out ? out[i + d] : i + d;
+        double* up = S + ((size_t)r * nco + q) * 36;
         std::memcpy(up, src, 36 * sizeof(double));
         if (d > 0) {
-          double* lo = S + ((size_t)(i + d) * nco + i) * 36;
+          double* lo = S + ((size_t)q * nco + r) * 36;
           for (int a = 0; a < 6; ++a)
             for (int c = 0; c < 6; ++c) lo[c * 6 + a] = src[a * 6 + c];
         }
       }
   }
+  cam_rows_out(h, b, 6);
   return BA_OK;
 }
 

@@ -259,7 +259,8 @@ int dist_upload_mask(ba_handle* h, const uint8_t* cam_param_mask, const unsigned
   bool all = true;
   for (int i = 0; i < h->nco * 6; ++i) all = all && cam_param_mask[i];
   if (all) return BA_OK;
-  HIPCHECK(h, hipMemcpyAsync(h->mask.p, cam_param_mask, (size_t)h->nco * 6, hipMemcpyHostToDevice, h->stream));
+  const unsigned char* m = cam_rows_in(h, cam_param_mask, h->mask_host, 6);
+  HIPCHECK(h, hipMemcpyAsync(h->mask.p, m, (size_t)h->nco * 6, hipMemcpyHostToDevice, h->stream));
   *dmask = h->mask.p;
   return BA_OK;
 }
@@ -379,7 +380,8 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     bool all = true;
     for (int i = 0; i < h->nco * 6; ++i) all = all && cam_param_mask[i];
     if (!all) {
-      HIPCHECK(h, hipMemcpyAsync(h->mask.p, cam_param_mask, (size_t)h->nco * 6, hipMemcpyHostToDevice, h->stream));
+      const unsigned char* m = cam_rows_in(h, cam_param_mask, h->mask_host, 6);      // (the caller's positions -> the internal camera order)
+      HIPCHECK(h, hipMemcpyAsync(h->mask.p, m, (size_t)h->nco * 6, hipMemcpyHostToDevice, h->stream));
       dmask = h->mask.p;
     }
   }
@@ -493,6 +495,7 @@ int ba_get_solution(ba_handle* h, double* dC) {
   HIPCHECK(h, hipSetDevice(h->device));
   if (h->nco) HIPCHECK(h, hipMemcpyAsync(dC, h->dC.p, (size_t)h->nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
+  cam_rows_out(h, dC, 6);                       // internal camera order -> the caller's positions
   return BA_OK;
 }
 

@@ -850,3 +850,62 @@ def test_set_poses_of_stacked_cameras():
     b.add_camera(Camera(np.eye(3), np.zeros(3)))
     b.cameras.set_poses(np.array([5, 0]), newR, newt)
     assert np.array_equal(b.ts()[5], newt[0]) and np.array_equal(b.ts()[0], newt[1])
+
+
+# ------------------------------------------------------------------ the internal camera order (csrc/ba_order.hip; no GPU needed)
+def _order_cameras(nco, lists):
+    import ctypes as C
+    from pysfm_amd import _capi as capi
+    lib = capi.load()
+    off = np.zeros(len(lists) + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    pos = np.concatenate([np.asarray(l, np.int32) for l in lists]).astype(np.int32) if lists else np.zeros(0, np.int32)
+    new = np.empty(nco, np.int32)
+    hb = C.c_int32()
+    rc = lib.ba_order_cameras(nco, len(lists), capi.iptr(off), capi.iptr(pos), capi.iptr(new), C.cast(C.byref(hb), capi._ip))
+    assert rc == capi.BA_OK
+    assert sorted(new.tolist()) == list(range(nco))                  # a permutation
+    spread = max([int(new[l].max() - new[l].min()) for l in map(np.asarray, lists) if len(l)] + [0])
+    assert spread == hb.value
+    return new, hb.value
+
+
+@pytest.mark.parametrize('nco,L,drop,seed', [(60, 10, 0., 1), (400, 10, 0., 2), (400, 10, .3, 3), (300, 16, .1, 4), (150, 3, 0., 5), (1000, 10, .2, 6)])
+def test_camera_order_recovers_the_band_of_a_shuffled_sequence(nco, L, drop, seed):
+    """Tracks of L consecutive cameras (some observations missing), camera positions shuffled: the caller's order spreads a
+    track over most of the sequence, Cuthill-McKee on the co-visibility hypergraph finds an order as narrow as the sequence's own."""
+    rs = np.random.RandomState(seed)
+    perm = rs.permutation(nco)
+    lists, true_hb = [], 0
+    for k in range(6 * nco):
+        c0 = rs.randint(0, nco - L + 1)
+        cams = np.arange(c0, c0 + L)
+        cams = cams[rs.rand(L) >= drop]
+        if len(cams) < 2:
+            continue
+        true_hb = max(true_hb, int(cams.max() - cams.min()))
+        lists.append(perm[cams])
+    caller_hb = max(int(l.max() - l.min()) for l in lists)
+    new, hb = _order_cameras(nco, lists)
+    assert caller_hb > nco // 2
+    assert hb <= true_hb + (0 if drop == 0. else 2), (hb, true_hb)
+
+
+def test_camera_order_components_and_unseen_cameras():
+    """Two sequences that share no track and a few cameras nobody sees: every component gets a stretch of its own, unseen cameras
+    go to the end in their own order."""
+    rs = np.random.RandomState(9)
+    nco = 90
+    perm = rs.permutation(nco)
+    lists = [perm[np.arange(c, c + 5)] for c in range(0, 36)] + [perm[np.arange(c, c + 5)] for c in range(45, 76)]      # cameras 0..39 and 45..79; 40..44, 80..89 unseen
+    new, hb = _order_cameras(nco, lists)
+    assert hb == 4
+    a, b = np.sort(new[perm[np.arange(0, 40)]]), np.sort(new[perm[np.arange(45, 80)]])
+    assert a[-1] - a[0] == 39 and b[-1] - b[0] == 34                 # contiguous stretches
+    unseen = perm[np.r_[40:45, 80:90]]
+    assert np.all(new[unseen] >= 75) and np.all(np.diff(new[np.sort(unseen)]) > 0)
+    # degenerate inputs
+    new, hb = _order_cameras(5, [])
+    assert new.tolist() == [0, 1, 2, 3, 4] and hb == 0
+    new, hb = _order_cameras(1, [[0]])
+    assert new.tolist() == [0] and hb == 0
