@@ -330,12 +330,29 @@ def with_long_tracks(s, nc, nt, L, every, llen, seed=3):
     return out
 
 
+def with_cameras_renumbered(s, seed=5):
+    """The same scene with its cameras renumbered at random (ids as a database assigns them, an unordered image collection):
+    camera c becomes camera perm[c].  The caller's order of the optimised cameras then spreads every track over most of the
+    sequence; ba_set_problem orders the cameras itself (pysfm_amd/csrc/ba_order.hip)."""
+    rs = np.random.RandomState(seed)
+    nc = len(s['R0'])
+    perm = rs.permutation(nc)
+    out = dict(s)
+    for k in ('R0', 't0', 'R', 't'):
+        a = np.empty_like(s[k])
+        a[perm] = s[k]
+        out[k] = a
+    out['obs_cam'] = perm[s['obs_cam']].astype(np.int32)
+    return out
+
+
 PASS_KERNELS = ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs')
 OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config2', 2, 'gaussian', 0., False, 0.),
     ('config4_huber', 4, 'huber', .1, False, 0.),
     ('config4_cauchy', 4, 'cauchy', .1, False, 0.),
     ('config3_shuffled', 3, 'gaussian', 0., True, 0.),
+    ('config3_cameras_renumbered', 3, 'gaussian', 0., False, 0., 10, None, 'cameras'),      # the cameras in random order: the library finds the band itself
     ('config3_30pct_dropped', 3, 'gaussian', 0., False, .3),
     ('config3_2pct_tracks_of_80_cameras', 3, 'gaussian', 0., False, 0., 10, (50, 80)),      # a few long tracks: pairs of 32-camera segments on the matrix cores, half-bandwidth 79
     ('config5_one_gpu', 5, 'gaussian', 0., False, 0.),
@@ -343,7 +360,7 @@ OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
 ]
 
 
-def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, track_len=10, long_tracks=None, steps=20, warmup=8, scene_cache=None):
+def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, track_len=10, long_tracks=None, variant=None, steps=20, warmup=8, scene_cache=None):
     """`other_configs`: a short run of one of the other BASELINE configurations / scene shapes on this GPU, the same
     complete LM trial per step, timed the same way (no events in the timed window; the per-kernel numbers come from
     bracketed trials before it)."""
@@ -363,6 +380,8 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
             scene_cache[key] = s
     if long_tracks:                                 # (every, length): every `every`-th point seen by `length` consecutive cameras
         s = with_long_tracks(s, nc, nt, track_len, long_tracks[0], long_tracks[1])
+    if variant == 'cameras':
+        s = with_cameras_renumbered(s)
     obs_cam, obs_pt, obs_z, X0 = scene_variant(s, track_len, shuffle, drop)
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
@@ -397,7 +416,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     info = be.problem_info()
     out = {'workload': 'BASELINE configs[%d]%s: %d cameras / %d points / %d observations, %s sensor model%s%s%s' % (
                cfg_id - 1, ('' if track_len == 10 else ' with track length %d' % track_len) + ('' if not long_tracks else ' and every %d-th point seen by %d cameras' % tuple(long_tracks)), nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
-               ', tracks and observations in random order' if shuffle else '',
+               (', tracks and observations in random order' if shuffle else '') + (', cameras renumbered at random' if variant == 'cameras' else ''),
                ', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * drop) if drop else ''),
            'init_mode': init_mode, 'steps': steps, 'warmup': warmup + 1, 'ms_per_step': 1e3 * dt / steps, 'obs_per_s': nobs * steps / dt,
            'dominant_kernel': None if dom is None else KERNEL_NAMES.get(dom, 'k_' + dom), 'dominant_kernel_ms_per_step': None if dom is None else kms[dom],
@@ -405,6 +424,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
            'linearise_schur_pass_fraction_of_kernel_time': pass_ms / max(1e-12, sum(kms.values())),
            'obs_jacobians_per_s': nobs / max(1e-9, pass_ms * 1e-3),
            'schur_kernel': info.get('schur_kernel'), 'half_bandwidth': be.half_bandwidth, 'solve_kind': getattr(be, 'last_solve_kind', None),
+           'cameras_permuted': info.get('cameras_permuted'), 'caller_half_bandwidth': info.get('caller_half_bandwidth'),
            'trials_by_solver_and_outcome': dict(state['paths']), 'set_bundle_s': t_setup, 'set_bundle_first_s': t_setup_first}
     # what a caller feels: BundleAdjuster.set_bundle + optimize(25 steps), the adjusted bundle back on the host
     torch.cuda.synchronize()
@@ -602,6 +622,7 @@ def main():
     ap.add_argument('--pts-per-gpu', type=int, default=None, help='override: points per GPU (weak scaling)')
     ap.add_argument('--track-len', type=int, default=10)
     ap.add_argument('--shuffle-points', action='store_true')
+    ap.add_argument('--shuffle-cameras', action='store_true', help='renumber the cameras at random: the library orders the optimised cameras itself')
     ap.add_argument('--drop-observations', type=float, default=0., metavar='FRAC',
                     help='drop this fraction of the observations at random (every track keeps two): camera lists no longer repeat')
     ap.add_argument('--long-tracks', default=None, metavar='EVERY,LENGTH',
@@ -632,7 +653,7 @@ def main():
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)       # the run rocprofv3 wraps: a few trials, no JSON line
     args = ap.parse_args()
     global PMC_WORKLOAD
-    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations and not args.long_tracks
+    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations and not args.long_tracks and not args.shuffle_cameras
     PMC_WORKLOAD = ('config3' if args.config == 3 else 'config%d' % args.config) if plain and args.gpus == 1 and args.sensor is None and args.outliers is None else 'none'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -695,6 +716,8 @@ def main():
     if args.long_tracks:
         every, llen = [int(v) for v in args.long_tracks.split(',')]
         s = with_long_tracks(s, nc, nt, args.track_len, every, llen)
+    if args.shuffle_cameras:
+        s = with_cameras_renumbered(s)
     obs_cam, obs_pt, obs_z, X0 = scene_variant(s, args.track_len, args.shuffle_points, args.drop_observations) if not args.long_tracks \
         else (s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0'])
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
@@ -749,6 +772,8 @@ def main():
             # the same LM run from the generator's other initial guess (round 1 / SURVEY 8d used 'params', round 2 'pose')
             other = 'pose' if init_mode == 'params' else 'params'
             s2 = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers, init_mode=other)
+            if args.shuffle_cameras:
+                s2 = with_cameras_renumbered(s2)
             oc2, op2, oz2, X02 = scene_variant(s2, args.track_len, args.shuffle_points, args.drop_observations)
             ba.set_bundle(Bundle.FromObservations(s2['K'], s2['R0'], s2['t0'], X02, oc2, op2, oz2, sensor_model=model))
             ba.optimize(max_steps=25)
@@ -855,6 +880,7 @@ def main():
             child += ['--cams', str(args.cams)] if args.cams else []
             child += ['--pts-per-gpu', str(args.pts_per_gpu)] if args.pts_per_gpu else []
             child += ['--shuffle-points'] if args.shuffle_points else []
+            child += ['--shuffle-cameras'] if args.shuffle_cameras else []
             child += ['--drop-observations', str(args.drop_observations)] if args.drop_observations else []
             child += ['--sensor', args.sensor] if args.sensor else []
             child += ['--outliers', str(args.outliers)] if args.outliers is not None else []
@@ -943,6 +969,7 @@ def main():
                                       '+RCCL all-reduce' if comm is not None else '', sensor_name,
                                       ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
                                       (', tracks and observations handed over in random order' if args.shuffle_points else '') +
+                                      (', cameras renumbered at random' if args.shuffle_cameras else '') +
                                       (', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * args.drop_observations) if args.drop_observations else '')),
                        'cameras': nc, 'points': nt, 'observations': nobs_total, 'track_len': args.track_len,
                        'init_mode': init_mode, 'shuffled': bool(args.shuffle_points), 'parallelism': 'points sharded x%d' % ngpus,
@@ -1003,7 +1030,7 @@ def main():
             out['end_to_end_optimize_s'] = time.time() - t0
             out['end_to_end_parts_s'] = {'set_bundle': t1 - t0, 'optimize': t2 - t1, 'bundle_to_host': time.time() - t2, 'lm_trials': int(ba.lm_trials)}
         plain3 = (args.config == 3 and args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
-                  and not args.drop_observations and not args.shuffle_points and args.sensor is None and args.outliers is None and not args.long_tracks)
+                  and not args.drop_observations and not args.shuffle_points and not args.shuffle_cameras and args.sensor is None and args.outliers is None and not args.long_tracks)
         if ngpus == 1 and comm is None and plain3 and not args.no_other_configs:
             # the other BASELINE configurations and scene shapes, a short run each on this same GPU (the headline handle is idle)
             t_oc = time.time()

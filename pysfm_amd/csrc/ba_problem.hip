@@ -920,13 +920,7 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   h->plan_flags.assign(flags, flags + SF_COUNT);
   h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
   h->h_same.assign(same, same + nt);
-  // The work lists of the general kernels: at once - or, for a problem the resident loop takes whole (ba_resident.h), when a
-  // general kernel first asks for them (ensure_plan): the sliding-window caller sets a problem per frame and never does
-  h->plan_pending = true;
-  if (!resident_shape(h)) {
-    const int rc = ensure_plan(h);
-    if (rc != BA_OK) return rc;
-  }
+  h->plan_pending = true;      // (ba_set_problem builds them once the order of the cameras is settled)
   for (int i = 0; i < 2; ++i) {
     HIPCHECK(h, h->cams[i].resize(std::max<size_t>(1, (size_t)nc * 12)));
     HIPCHECK(h, h->X[i].resize(std::max<size_t>(1, (size_t)nt * 3)));
@@ -1004,9 +998,17 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
                    const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
   if (!h) return BA_ERR_INVALID_ARG;
   h->cpos_in.clear(); h->cpos_out.clear();
-  const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
+  int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
   if (rc != BA_OK) return rc;
-  return choose_camera_order(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
+  rc = choose_camera_order(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
+  if (rc != BA_OK) { h->have_problem = false; return rc; }
+  // The work lists of the general kernels: at once - or, for a problem the resident loop takes whole (ba_resident.h), when a
+  // general kernel first asks for them (ensure_plan): the sliding-window caller sets a problem per frame and never does
+  if (!resident_shape(h)) {
+    rc = ensure_plan(h);
+    if (rc != BA_OK) { h->have_problem = false; return rc; }
+  }
+  return BA_OK;
 }
 
 
