@@ -46,11 +46,12 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mf
 
 # What binds each kernel at the bench sizes; `roofline.limited_by` reports it.  The contract prices
 # `achieved` against HBM for every kernel that is not MFMA-bound, so `frac` is always achieved / 8 TB/s.
-KERNEL_BOUND = {'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
+KERNEL_BOUND = {'border_schur': 'atomics', 'border_solve': 'latency', 'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
                 'dense_solve': 'latency', 'schur_pairs': 'mfma', 'linearize': 'fp64 issue + gather latency', 'backsub': 'fp64 issue', 'cost': 'hbm',
                 'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
 # timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
-KERNEL_NAMES = {'linearize': 'k_linearize_groups (k_linearize when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init',
+KERNEL_NAMES = {'border_schur': 'k_schur_border (+ k_border_clear)', 'border_solve': 'k_border_prepare, k_bcr_apply (a launch per level, forward and back), k_border_reduce, k_border_solve, k_border_correct',
+                'linearize': 'k_linearize_groups (k_linearize when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init',
                 'schur_pairs': 'k_schur_groups_mfma2 | k_schur_groups_mfma3 (k_schur_groups / k_schur_pairs otherwise)',
                 'backsub': 'k_backsub_groups (k_backsub when points do not come in runs)',
                 'bcr_eliminate': 'k_bcr_eliminate_fused: all elimination levels of the cyclic reduction AND its back-substitution in one launch (k_bcr_eliminate per level where a level is wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
@@ -346,6 +347,17 @@ def with_cameras_renumbered(s, seed=5):
     return out
 
 
+def with_loop_closures(s, n=10, seed=21):
+    """The scene with n extra tracks that each tie a camera i to the camera half a sequence further on (a loop closure): the
+    band of the reduced system would become as wide as that; the library moves the far cameras to a border
+    (pysfm_amd/csrc/ba_border.h)."""
+    from pysfm_amd import synthetic_data as sd
+    nc = len(s['R0'])
+    rs = np.random.RandomState(seed)
+    first = np.sort(rs.choice(np.arange(1, nc // 2 - 1), n, replace=False))
+    return sd.add_loop_closure_tracks(s, [(int(i), int(i) + nc // 2) for i in first])
+
+
 PASS_KERNELS = ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs')
 OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config2', 2, 'gaussian', 0., False, 0.),
@@ -353,9 +365,11 @@ OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config4_cauchy', 4, 'cauchy', .1, False, 0.),
     ('config3_shuffled', 3, 'gaussian', 0., True, 0.),
     ('config3_cameras_renumbered', 3, 'gaussian', 0., False, 0., 10, None, 'cameras'),      # the cameras in random order: the library finds the band itself
+    ('config3_10_loop_closure_tracks', 3, 'gaussian', 0., False, 0., 10, None, 'loops'),      # camera i and camera i + 500 see the same point, ten times: band + border
     ('config3_30pct_dropped', 3, 'gaussian', 0., False, .3),
     ('config3_2pct_tracks_of_80_cameras', 3, 'gaussian', 0., False, 0., 10, (50, 80)),      # a few long tracks: pairs of 32-camera segments on the matrix cores, half-bandwidth 79
     ('config5_one_gpu', 5, 'gaussian', 0., False, 0.),
+    ('config5_10_loop_closure_tracks', 5, 'gaussian', 0., False, 0., 10, None, 'loops'),
     ('config3_track_length_32', 3, 'gaussian', 0., False, 0., 32),      # long tracks: windows of 32 cameras on the matrix cores (k_schur_wide_mfma), cyclic reduction with 192-unknown nodes in device memory
 ]
 
@@ -382,6 +396,9 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
         s = with_long_tracks(s, nc, nt, track_len, long_tracks[0], long_tracks[1])
     if variant == 'cameras':
         s = with_cameras_renumbered(s)
+    if variant == 'loops':
+        s = with_loop_closures(s)
+        nt = len(s['X0'])
     obs_cam, obs_pt, obs_z, X0 = scene_variant(s, track_len, shuffle, drop)
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
@@ -416,7 +433,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     info = be.problem_info()
     out = {'workload': 'BASELINE configs[%d]%s: %d cameras / %d points / %d observations, %s sensor model%s%s%s' % (
                cfg_id - 1, ('' if track_len == 10 else ' with track length %d' % track_len) + ('' if not long_tracks else ' and every %d-th point seen by %d cameras' % tuple(long_tracks)), nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
-               (', tracks and observations in random order' if shuffle else '') + (', cameras renumbered at random' if variant == 'cameras' else ''),
+               (', tracks and observations in random order' if shuffle else '') + (', cameras renumbered at random' if variant == 'cameras' else '') + (', plus 10 loop-closure tracks (camera i and camera i + half the sequence)' if variant == 'loops' else ''),
                ', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * drop) if drop else ''),
            'init_mode': init_mode, 'steps': steps, 'warmup': warmup + 1, 'ms_per_step': 1e3 * dt / steps, 'obs_per_s': nobs * steps / dt,
            'dominant_kernel': None if dom is None else KERNEL_NAMES.get(dom, 'k_' + dom), 'dominant_kernel_ms_per_step': None if dom is None else kms[dom],
@@ -424,7 +441,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
            'linearise_schur_pass_fraction_of_kernel_time': pass_ms / max(1e-12, sum(kms.values())),
            'obs_jacobians_per_s': nobs / max(1e-9, pass_ms * 1e-3),
            'schur_kernel': info.get('schur_kernel'), 'half_bandwidth': be.half_bandwidth, 'solve_kind': getattr(be, 'last_solve_kind', None),
-           'cameras_permuted': info.get('cameras_permuted'), 'caller_half_bandwidth': info.get('caller_half_bandwidth'),
+           'cameras_permuted': info.get('cameras_permuted'), 'caller_half_bandwidth': info.get('caller_half_bandwidth'), 'border_cameras': info.get('border_cameras'),
            'trials_by_solver_and_outcome': dict(state['paths']), 'set_bundle_s': t_setup, 'set_bundle_first_s': t_setup_first}
     # what a caller feels: BundleAdjuster.set_bundle + optimize(25 steps), the adjusted bundle back on the host
     torch.cuda.synchronize()
@@ -623,6 +640,7 @@ def main():
     ap.add_argument('--track-len', type=int, default=10)
     ap.add_argument('--shuffle-points', action='store_true')
     ap.add_argument('--shuffle-cameras', action='store_true', help='renumber the cameras at random: the library orders the optimised cameras itself')
+    ap.add_argument('--loop-closures', type=int, default=0, metavar='N', help='add N tracks that tie a camera to the camera half a sequence further on (band + border)')
     ap.add_argument('--drop-observations', type=float, default=0., metavar='FRAC',
                     help='drop this fraction of the observations at random (every track keeps two): camera lists no longer repeat')
     ap.add_argument('--long-tracks', default=None, metavar='EVERY,LENGTH',
@@ -653,7 +671,7 @@ def main():
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)       # the run rocprofv3 wraps: a few trials, no JSON line
     args = ap.parse_args()
     global PMC_WORKLOAD
-    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations and not args.long_tracks and not args.shuffle_cameras
+    plain = args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option and not args.drop_observations and not args.long_tracks and not args.shuffle_cameras and not args.loop_closures
     PMC_WORKLOAD = ('config3' if args.config == 3 else 'config%d' % args.config) if plain and args.gpus == 1 and args.sensor is None and args.outliers is None else 'none'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -718,6 +736,9 @@ def main():
         s = with_long_tracks(s, nc, nt, args.track_len, every, llen)
     if args.shuffle_cameras:
         s = with_cameras_renumbered(s)
+    if args.loop_closures:
+        s = with_loop_closures(s, args.loop_closures)
+        nt = len(s['X0'])
     obs_cam, obs_pt, obs_z, X0 = scene_variant(s, args.track_len, args.shuffle_points, args.drop_observations) if not args.long_tracks \
         else (s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0'])
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
@@ -774,6 +795,8 @@ def main():
             s2 = sd.generate_banded_scene(nc, nt, track_len=args.track_len, outlier_frac=outliers, init_mode=other)
             if args.shuffle_cameras:
                 s2 = with_cameras_renumbered(s2)
+            if args.loop_closures:
+                s2 = with_loop_closures(s2, args.loop_closures)
             oc2, op2, oz2, X02 = scene_variant(s2, args.track_len, args.shuffle_points, args.drop_observations)
             ba.set_bundle(Bundle.FromObservations(s2['K'], s2['R0'], s2['t0'], X02, oc2, op2, oz2, sensor_model=model))
             ba.optimize(max_steps=25)
@@ -881,6 +904,7 @@ def main():
             child += ['--pts-per-gpu', str(args.pts_per_gpu)] if args.pts_per_gpu else []
             child += ['--shuffle-points'] if args.shuffle_points else []
             child += ['--shuffle-cameras'] if args.shuffle_cameras else []
+            child += ['--loop-closures', str(args.loop_closures)] if args.loop_closures else []
             child += ['--drop-observations', str(args.drop_observations)] if args.drop_observations else []
             child += ['--sensor', args.sensor] if args.sensor else []
             child += ['--outliers', str(args.outliers)] if args.outliers is not None else []
@@ -1030,7 +1054,7 @@ def main():
             out['end_to_end_optimize_s'] = time.time() - t0
             out['end_to_end_parts_s'] = {'set_bundle': t1 - t0, 'optimize': t2 - t1, 'bundle_to_host': time.time() - t2, 'lm_trials': int(ba.lm_trials)}
         plain3 = (args.config == 3 and args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
-                  and not args.drop_observations and not args.shuffle_points and not args.shuffle_cameras and args.sensor is None and args.outliers is None and not args.long_tracks)
+                  and not args.drop_observations and not args.shuffle_points and not args.shuffle_cameras and not args.loop_closures and args.sensor is None and args.outliers is None and not args.long_tracks)
         if ngpus == 1 and comm is None and plain3 and not args.no_other_configs:
             # the other BASELINE configurations and scene shapes, a short run each on this same GPU (the headline handle is idle)
             t_oc = time.time()

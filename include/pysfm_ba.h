@@ -61,7 +61,7 @@ typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_se
 enum {
   BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
   BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_TRIANGULATE,
-  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_DENSE_SOLVE, BA_K_COUNT
+  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_DENSE_SOLVE, BA_K_BORDER_SCHUR, BA_K_BORDER_SOLVE, BA_K_COUNT
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -88,6 +88,7 @@ int ba_synchronize(ba_handle* h);
  *   "gm_chunk"      n                                      groups per workgroup of the MFMA reductions (0 = automatic: 4, or 8 over several rounds)
  *   "camera_order"  auto | off | always                    internal order of the optimised cameras (see ba_set_problem): auto = when the
  *                                                          caller's order is not provably as narrow as an order can be
+ *   "border"        1 | 0                                  band + border layouts of the reduced system (see ba_set_problem; default 1)
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
  * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap", "gm_chunk") take effect at
  * the next ba_set_problem. */
@@ -110,6 +111,13 @@ int ba_debug_poison(ba_handle* h);
  * hypergraph, pysfm_amd/csrc/ba_order.hip) and keeps that order if the band gets narrower.  Every array the ABI takes or returns
  * by optimised position (S, b, dC, cam_param_mask, motion updates) stays in the CALLER's positions.  Not done for a handle with a
  * communicator or a minimum band width set (the ranks of a sharded adjuster share one layout).
+ * BAND + BORDER: a camera sequence with a few long-range tracks (a loop closure: camera 3 and camera 503 see the same point)
+ * has a narrow band but for those tracks.  When the band would be wider than the narrow cyclic reduction takes (11 cameras) and
+ * moving at most 21 cameras out of it makes it fit, those cameras become a border, S = [[B, C], [C^T, D]] with B the band of the
+ * others (pysfm_amd/csrc/ba_border.h): ba_reduced_layout then describes B (rows of the border cameras unused), ba_get_reduced /
+ * ba_get_solution return the full system / solution as always.  The layout with the lowest modelled solve cost among {caller's
+ * order, Cuthill-McKee order} x {as it is, with a border} is taken (BA_INFO_BORDER_CAMERAS, BA_INFO_HALF_BANDWIDTH say which).
+ * A bordered system that is not positive definite is reported through *info of the solve (no LU fallback there).
  *   obs_cam[nobs], obs_pt[nobs]  positions;  obs_z[nobs*2] measurements
  *   K[9]                         calibration (general 3x3)
  *   cam_opt_pos[nc]              position in optim_camera_ids, or -1 (frozen)
@@ -139,6 +147,7 @@ enum {
   BA_INFO_MFMA_K_ROWS,
   BA_INFO_CAMERAS_PERMUTED,    /* 1: the library ordered the optimised cameras itself (see ba_set_problem)                */
   BA_INFO_CALLER_HALF_BANDWIDTH, /* the half-bandwidth the caller's camera order would have had                         */
+  BA_INFO_BORDER_CAMERAS,      /* cameras in the border of the reduced system (band + border, see ba_set_problem)          */
   BA_INFO_COUNT
 };
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);

@@ -51,7 +51,10 @@ int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A
     keep = ikeep.data();
   }
   HIPCHECK(h, hipMemcpyAsync(h->keep.p, keep, nkeep * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  {
+  if (h->nbc > 0) {                               // band + border (ba_border.h)
+    const int rc = border_flatten(h, nkeep, (double*)A_dev, (double*)rhs_dev);
+    if (rc != BA_OK) return rc;
+  } else {
     ScopedTimer tm(h, BA_K_FLATTEN);
     hipLaunchKernelGGL(k_flatten, dim3(blocks_for((long long)nkeep * nkeep)), dim3(kBlock), 0, h->stream, h->nco, h->hb,
                        nkeep, h->keep.p, h->S, h->b, (double*)A_dev, (double*)rhs_dev);

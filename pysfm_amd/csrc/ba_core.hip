@@ -51,6 +51,12 @@ DevProblem dev_problem(const ba_handle* h) {
   return P;
 }
 
+DevProblem dev_problem_band(const ba_handle* h) {
+  DevProblem P = dev_problem(h);
+  if (h->nbc > 0) P.cam_opt_pos = h->cam_band_pos.p;
+  return P;
+}
+
 int ensure_reduced(ba_handle* h) {
   if (!h->S) {
     HIPCHECK(h, h->S_own.resize(std::max<size_t>(1, reduced_doubles(h))));
@@ -159,7 +165,7 @@ const char* ba_kernel_name(int id) {
   static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
                                           "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
                                           "k_band_solve", "k_eval", "k_camera_blocks", "k_triangulate",
-                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve", "k_dense_solve"};
+                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve", "k_dense_solve", "k_schur_border", "k_border_solve"};
   return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
 }
 
@@ -290,6 +296,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "resident_scatter_min") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 2 && c <= 1000; if (ok) h->opt.resident_scatter_min = (int)c; }
   else if (n == "host_setup") ok = flag(h->opt.host_setup);
   else if (n == "camera_order") ok = choice({"auto", "off", "always"}, h->opt.camera_order);
+  else if (n == "border") ok = flag(h->opt.border);
   else if (n == "packed_upload") ok = flag(h->opt.packed_upload);
   else if (n == "gm_chunk") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0 && c <= 64; if (ok) h->opt.gm_chunk = (int)c; }
   else if (n == "gm_cap") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0; if (ok) h->opt.gm_cap = (int)c; }

@@ -67,9 +67,11 @@ struct Options {
   bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
   int resident_scatter_min = 5;    // ... whose launches of at least this many workgroups add their partial sums up in slices (two stages)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
+  bool border = true;              // ... and a border for the cameras at the far end of a few long-range tracks (ba_border.h)
   int camera_order = 0;            // internal order of the optimised cameras (ba_order.hip): 0 auto (when the caller's is not provably as narrow as it can be), 1 off, 2 always try
 };
 enum { CAMORDER_AUTO = 0, CAMORDER_OFF, CAMORDER_ALWAYS };
+constexpr int kBordMaxCamsHost = 21;       // (= kBordMaxCams of ba_border.h: 126 border unknowns fit the LDS of the border solve)
 
 }  // namespace ba
 
@@ -159,6 +161,15 @@ struct ba_handle {
   // position goes through cam_rows_in / cam_rows_out.
   std::vector<int> cpos_in, cpos_out;
   int caller_hb = 0;                   // half-bandwidth the caller's camera order would have had
+  // band + border (ba_border.h): the last nbc optimised positions are BORDER cameras - the band's kernels see them as cameras that
+  // are not optimised (cam_band_pos), their blocks live in bord (C, D) and their solution comes out of the border solve
+  int nbc = 0;
+  DevBuf<int> cam_band_pos;            // [nc]: optimised position of a band camera, -1 for border and frozen cameras (= cam_opt_pos without a border)
+  DevBuf<int> bord_obs;                // [BorderBlock x nbord_obs | the blocks' pairs of observations] (ba_border.h)
+  int nbord_obs = 0, bord_ld = 0;      // ... the number of blocks; row length of C, D (6 nbc rounded up to 16)
+  size_t bord_rows = 0;                // rows of C / F: the nodes of the cyclic reduction (>= 6 band cameras)
+  DevBuf<double> bordC, bordF, bordD;  // C (as the reduction leaves it), F (work: C -> Y), [D | M | rv | x2]
+  int band_cams() const { return nco - nbc; }
   std::vector<unsigned char> mask_host; // the mask of the last solve in the internal order (outlives its asynchronous upload)
   std::vector<double> rows_host;       // ... and the last per-camera rows that went up
   std::vector<int> plan_flags;         // the set-up's status record (SF_* of ba_setup_kernels.h)
@@ -320,12 +331,23 @@ inline void cam_rows_out(const ba_handle* h, T* data, int w) {
   for (int q = 0; q < h->nco; ++q) std::copy(tmp.begin() + (size_t)q * w, tmp.begin() + (size_t)(q + 1) * w, data + (size_t)h->cpos_out[q] * w);
 }
 
+// ---- ba_border.hip: the border of the reduced system (ba_border.h)
+int border_setup(ba_handle* h);                                  // after the problem is set: the border cameras' observations, buffers
+int border_schur(ba_handle* h, int p, double damping);            // the blocks of the border cameras (C, D, the border part of b)
+int border_solve(ba_handle* h, const unsigned char* dmask);       // after the band solve: Y = B^-1 C, the border system, the correction of dC
+int border_get_dense(ba_handle* h, std::vector<double>& C, std::vector<double>& D);      // host copies of C [6 n1][ld], D [ld][ld]
+int border_flatten(ba_handle* h, int nkeep, double* A_dev, double* rhs_dev);              // ba_flatten_reduced with a border (h->keep holds the indices)
+// Which cameras go to a border so that the others fit a band of half-width <= t: is_border[p] by position in the order given
+// (lists: distinct camera lists as positions in that order).  Returns their number, or -1 when more than kmax would be needed.
+int choose_border(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, int t, int kmax, std::vector<char>& is_border);
+
 // ---- ba_order.hip: Cuthill-McKee on the co-visibility hypergraph
 void cuthill_mckee_order(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, std::vector<int>& newpos);
 int order_half_bandwidth(const std::vector<int>& loff, const std::vector<int>& lpos, const std::vector<int>& newpos);
 
 inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + kBlock - 1) / kBlock); }
 DevProblem dev_problem(const ba_handle* h);
+DevProblem dev_problem_band(const ba_handle* h);      // ... as the reductions into the band see it: border cameras are not optimised
 
 inline size_t reduced_doubles(const ba_handle* h) { return (size_t)h->nco * (h->hb + 1) * 36; }
 int ensure_reduced(ba_handle* h);

@@ -117,6 +117,42 @@ void cuthill_mckee_order(int nco, const std::vector<int>& loff, const std::vecto
   for (int q = 0; q < nco; ++q) newpos[full[q]] = q;
 }
 
+// Which cameras go to a border (ba_border.h) so that what is left of every list spreads over at most t positions.  Lists by
+// descending spread; of a list that is still too wide, the largest set of cameras inside one window of t + 1 positions stays,
+// the others go (a loop closure: the far end of the track; a ring: one side of the seam).  -1: more than kmax cameras.
+int choose_border(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, int t, int kmax, std::vector<char>& is_border) {
+  is_border.assign((size_t)nco, 0);
+  const int nl = (int)loff.size() - 1;
+  std::vector<std::pair<int, int>> wide;               // (spread, list) of the lists wider than t
+  for (int l = 0; l < nl; ++l) {
+    int lo = INT32_MAX, hi = -1;
+    for (int k = loff[l]; k < loff[l + 1]; ++k) { lo = std::min(lo, lpos[k]); hi = std::max(hi, lpos[k]); }
+    if (hi - lo > t) wide.push_back({hi - lo, l});
+  }
+  std::sort(wide.begin(), wide.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+  int k = 0;
+  std::vector<int> v;
+  for (const auto& w : wide) {
+    const int l = w.second;
+    v.clear();
+    for (int q = loff[l]; q < loff[l + 1]; ++q)
+      if (!is_border[lpos[q]]) v.push_back(lpos[q]);
+    std::sort(v.begin(), v.end());
+    if (v.empty() || v.back() - v.front() <= t) continue;
+    size_t best_a = 0, best_n = 0;
+    for (size_t a = 0, b = 0; a < v.size(); ++a) {      // the window [v[a], v[a] + t] that keeps the most cameras
+      while (b < v.size() && v[b] - v[a] <= t) ++b;
+      if (b - a > best_n) { best_n = b - a; best_a = a; }
+    }
+    for (size_t q = 0; q < v.size(); ++q)
+      if (q < best_a || q >= best_a + best_n) {
+        is_border[v[q]] = 1;
+        if (++k > kmax) return -1;
+      }
+  }
+  return k;
+}
+
 }  // namespace ba
 
 extern "C" int ba_order_cameras(int32_t nco, int32_t nlists, const int32_t* list_off, const int32_t* list_pos, int32_t* new_pos,

@@ -126,7 +126,7 @@ struct Packer {
 constexpr long long kHostFrontMaxObs = 8192;
 
 int host_front_end(ba_handle* h, int nc, int nt, long long N, int nco, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_z,
-                   const int32_t* cam_opt_pos, const uint8_t* pt_opt, const std::vector<int>& crank, const std::vector<int>& opt_cam, int rank_bits, int* hflags, int* hoff,
+                   const int32_t* cam_opt_pos, const int32_t* cam_band_pos, const uint8_t* pt_opt, const std::vector<int>& crank, const std::vector<int>& opt_cam, int rank_bits, int* hflags, int* hoff,
                    int* hplo, int* hphi, int* hperm, unsigned char* same) {
   typedef unsigned long long u64;
   for (int i = 0; i < SF_COUNT; ++i) hflags[i] = (i == SF_BAD || i == SF_DUP) ? 0x7fffffff : 0;
@@ -159,7 +159,7 @@ int host_front_end(ba_handle* h, int nc, int nt, long long N, int nco, const int
       int minpos = nco;
       for (int q = b; q < e; ++q) {
         const int c = obs_cam[by[q]];
-        const int p = cam_opt_pos[c];
+        const int p = cam_band_pos[c];
         if (p >= 0 && p < minpos) minpos = p;
         hsh ^= (u64)crank[c] + 0x9E3779B97F4A7C15ull + (hsh << 6) + (hsh >> 2);
         hsh *= 0xD6E8FEB86659FD93ull;
@@ -202,7 +202,7 @@ int host_front_end(ba_handle* h, int nc, int nt, long long N, int nco, const int
       ipt[(size_t)dst + q] = i;
       iz[2 * ((size_t)dst + q)] = obs_z[2 * (size_t)n]; iz[2 * ((size_t)dst + q) + 1] = obs_z[2 * (size_t)n + 1];
       if (n != dst + q) hflags[SF_OPERM] = 1;
-      const int p = cam_opt_pos[obs_cam[n]];
+      const int p = cam_band_pos[obs_cam[n]];
       if (p < 0) continue;
       if (p <= hi) asc = false;
       lo = std::min(lo, p); hi = std::max(hi, p);
@@ -227,6 +227,7 @@ int host_front_end(ba_handle* h, int nc, int nt, long long N, int nco, const int
     return stage_h2d(h, dst, src, bytes);
   };
   HIPCHECK(h, put(h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
+  if (cam_band_pos != cam_opt_pos) HIPCHECK(h, put(h->cam_band_pos.p, cam_band_pos, (size_t)nc * sizeof(int)));
   HIPCHECK(h, put(h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
   HIPCHECK(h, put(h->obs_cam.p, icam.data(), (size_t)N * sizeof(int)));
   HIPCHECK(h, put(h->obs_pt.p, ipt.data(), (size_t)N * sizeof(int)));
@@ -717,7 +718,7 @@ int ensure_plan(ba_handle* h) {
     HIPCHECK(h, stage_h2d(h, h->wgroups.p, wgroups.data(), wgroups.size() * sizeof(WinGroup)));
     HIPCHECK(h, hipMemsetAsync(h->wtab.p, 0xff, wtab_size * sizeof(int), h->stream));        // -1: "the point does not see this camera"
     hipLaunchKernelGGL(k_setup_fill_wtab, dim3((unsigned)wgroups.size()), dim3(256), 0, h->stream, h->wgroups.p, h->pt_off.p, h->obs_cam.p,
-                       h->cam_opt_pos.p, h->wtab.p);
+                       h->nbc > 0 ? h->cam_band_pos.p : h->cam_opt_pos.p, h->wtab.p);
   }
   HIPCHECK(h, h->mgroups.resize(std::max<size_t>(1, mgroups.size())));
   if (!mgroups.empty())
@@ -740,9 +741,12 @@ int ensure_plan(ba_handle* h) {
 namespace {
 
 // the problem with the optimised cameras at the positions given (ba_set_problem below chooses them)
+// cam_band_pos (nbc > 0 border cameras, ba_border.h): the positions as the band sees them - a border camera (true position >=
+// nco - nbc) is -1 there, like a camera that is not optimised; nullptr = no border
 int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam,
                      const int32_t* obs_pt, const double* obs_z, const double* K,
-                     const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
+                     const int32_t* cam_opt_pos, const uint8_t* pt_opt, const int32_t* cam_band_pos = nullptr, int nbc = 0) {
+  if (!cam_band_pos) { cam_band_pos = cam_opt_pos; nbc = 0; }
   REQUIRE(h, nc >= 0 && nt >= 0 && nobs >= 0, BA_ERR_INVALID_ARG, "ba_set_problem: negative size");
   REQUIRE(h, nobs < (1ll << 31) - 64, BA_ERR_INVALID_ARG, "ba_set_problem: nobs must fit int32");
   REQUIRE(h, K && (nc == 0 || cam_opt_pos) && (nt == 0 || pt_opt), BA_ERR_INVALID_ARG,
@@ -786,6 +790,9 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   HIPCHECK(h, h->obs_cam.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_pt.resize(std::max<size_t>(1, N))); HIPCHECK(h, h->obs_z.resize(std::max<size_t>(1, N)));
   HIPCHECK(h, h->pt_off.resize((size_t)nt + 2)); HIPCHECK(h, h->cam_opt_pos.resize(std::max(1, nc))); HIPCHECK(h, h->pt_opt.resize((size_t)nt + 4));
   HIPCHECK(h, h->opt_cam.resize(opt_cam.size()));
+  if (nbc > 0) HIPCHECK(h, h->cam_band_pos.resize(std::max(1, nc)));
+  h->nbc = nbc;
+  const int* dev_band_pos = nbc > 0 ? h->cam_band_pos.p : h->cam_opt_pos.p;
   const size_t staging = ((size_t)3 * nt + 8) * sizeof(int) + (size_t)nt + SF_COUNT * sizeof(int) + (size_t)nt * sizeof(int) + 64;
   HIPCHECK(h, pinned_staging(h, staging));
   arena_reset(h);
@@ -799,10 +806,11 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   const unsigned long long* sorted_keys = nullptr;
   const bool host_front = sort_points && N <= kHostFrontMaxObs && h->opt.host_setup;
   if (host_front) {
-    const int rc = host_front_end(h, nc, nt, N, nco, obs_cam, obs_pt, obs_z, cam_opt_pos, pt_opt, crank, opt_cam, rank_bits, hflags, hoff, hplo, hphi, hperm, same);
+    const int rc = host_front_end(h, nc, nt, N, nco, obs_cam, obs_pt, obs_z, cam_opt_pos, cam_band_pos, pt_opt, crank, opt_cam, rank_bits, hflags, hoff, hplo, hphi, hperm, same);
     if (rc != BA_OK) return rc;
   } else {
   if (nc) HIPCHECK(h, stage_h2d(h, h->cam_opt_pos.p, cam_opt_pos, (size_t)nc * sizeof(int)));
+  if (nc && nbc > 0) HIPCHECK(h, stage_h2d(h, h->cam_band_pos.p, cam_band_pos, (size_t)nc * sizeof(int)));
   HIPCHECK(h, stage_h2d(h, h->opt_cam.p, opt_cam.data(), opt_cam.size() * sizeof(int)));
   if (N) {
     HIPCHECK(h, stage_h2d(h, su.rc.p, obs_cam, (size_t)N * sizeof(int)));
@@ -848,7 +856,7 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   if (nt) {
     hipLaunchKernelGGL(k_iota, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.iota.p);
     if (sort_points && nt > 1) {
-      hipLaunchKernelGGL(k_setup_track_keys, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, nco, su.coff.p, by_pt, su.rc.p, h->cam_opt_pos.p,
+      hipLaunchKernelGGL(k_setup_track_keys, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, nco, su.coff.p, by_pt, su.rc.p, dev_band_pos,
                          su.crank.p, su.tkey.p);
       HIPCHECK(h, sort_pairs_u64(h, su.tkey.p, su.tkey2.p, su.iota.p, h->d_pperm.p, (size_t)nt, 32 + bits_for((unsigned long long)nco + 1)));
       hipLaunchKernelGGL(k_setup_order_check, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, su.tkey.p, su.tkey2.p, su.flags.p);
@@ -860,7 +868,7 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   if (nt) {
     hipLaunchKernelGGL(k_setup_gather, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->d_pperm.p, su.coff.p, h->pt_off.p, by_pt, su.rc.p,
                        su.rz.p, su.rpo.p, h->obs_cam.p, h->obs_pt.p, h->obs_z.p, h->d_operm.p, h->pt_opt.p, su.flags.p);
-    hipLaunchKernelGGL(k_setup_point_summary, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->pt_off.p, h->obs_cam.p, h->cam_opt_pos.p,
+    hipLaunchKernelGGL(k_setup_point_summary, dim3(grid_for(nt)), dim3(256), 0, h->stream, nt, h->pt_off.p, h->obs_cam.p, dev_band_pos,
                        su.plo.p, su.phi.p, su.same.p, su.flags.p);
   }
   HIPCHECK(h, hipGetLastError());
@@ -918,7 +926,7 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   h->group_maxL = maxL;
   h->ncam_units = 0;
   h->plan_flags.assign(flags, flags + SF_COUNT);
-  h->h_cam_opt_pos.assign(cam_opt_pos, cam_opt_pos + nc);
+  h->h_cam_opt_pos.assign(cam_band_pos, cam_band_pos + nc);
   h->h_same.assign(same, same + nt);
   h->plan_pending = true;      // (ba_set_problem builds them once the order of the cameras is settled)
   for (int i = 0; i < 2; ++i) {
@@ -950,10 +958,25 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   return BA_OK;
 }
 
-// The internal order of the optimised cameras (ba_order.hip).  The problem has been set up in the caller's order; when that order
+// What a solve of the reduced system costs, in microseconds, by the shape the layout gives it (measured on config-3-sized scenes:
+// profiles/r04b_sweep.json, r04e_kernel_choice_probe.txt) - only good enough to rank the candidates of choose_camera_layout.
+double layout_cost_us(int hb, int nco, int border_cams) {
+  const double scale = std::max(1.0, nco / 1000.0);
+  double t;
+  if (hb <= kBcrMaxHB) t = 100.0 * std::pow(std::max(hb, 3) / 9.0, 1.5) * std::max(1.0, std::log2(std::max(2.0, (double)nco / std::max(1, hb))) / 7.0);
+  else if (hb <= kBcrwMaxHB) t = (250.0 + 45.0 * (hb - kBcrMaxHB)) * scale;
+  else t = (800.0 + 14.0 * (hb - kBcrwMaxHB)) * scale;
+  if (border_cams > 0) t += 50.0 + 12.0 * border_cams * scale;
+  return t;
+}
+
+// The internal layout of the optimised cameras: their ORDER (ba_order.hip) and, for scenes that are a sequence plus a few
+// long-range tracks, a BORDER (ba_border.h).  The problem has been set up in the caller's order; when that order
 // is not provably as narrow as an order can be (a track of L optimised cameras spreads over at least L - 1 positions), the
-// distinct camera lists come back from the device, Cuthill-McKee orders the cameras, and - if the band gets narrower - the
-// problem is set up again with the cameras at their new positions.  Costs nothing for a scene that arrives in sequence order.
+// distinct camera lists come back from the device and the candidates are ranked by what their solve would cost: the caller's
+// order and the Cuthill-McKee order, each as it is and - when its band is wider than the narrow cyclic reduction takes - with
+// the cameras that make it so moved to a border.  If anything beats the caller's order, the problem is set up again with the
+// cameras at their new positions.  Costs nothing for a scene that arrives in sequence order.
 int choose_camera_order(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam, const int32_t* obs_pt,
                         const double* obs_z, const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
   const int nco = h->nco, hb0 = h->plan_flags[SF_HB];
@@ -974,19 +997,56 @@ int choose_camera_order(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, cons
     }
     if (lpos.size() - before >= 2) loff.push_back((int)lpos.size()); else lpos.resize(before);
   }
-  std::vector<int> newpos;
-  cuthill_mckee_order(nco, loff, lpos, newpos);
-  const int hb1 = order_half_bandwidth(loff, lpos, newpos);
-  if (hb1 >= hb0) return BA_OK;
-  std::vector<int32_t> cop((size_t)nc);
-  for (int i = 0; i < nc; ++i) cop[i] = cam_opt_pos[i] >= 0 ? newpos[cam_opt_pos[i]] : -1;
-  const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cop.data(), pt_opt);
+  struct Cand { std::vector<int> pos; int hb; int k; std::vector<char> isb; double cost; };
+  std::vector<Cand> cands;
+  auto add = [&](const std::vector<int>& pos) {
+    std::vector<int> mapped(lpos.size());
+    for (size_t q = 0; q < lpos.size(); ++q) mapped[q] = pos[lpos[q]];
+    std::vector<int> ident((size_t)nco);
+    for (int p = 0; p < nco; ++p) ident[p] = p;
+    const int hb = order_half_bandwidth(loff, mapped, ident);
+    cands.push_back({pos, hb, 0, {}, layout_cost_us(hb, nco, 0)});
+    // ... with a border: only where it brings the band down to what the narrow cyclic reduction takes
+    if (hb > kBcrMaxHB && h->opt.border && nco >= 4 * kBcrMaxHB) {
+      for (int t = kBcrMaxHB; t >= 1; --t) {
+        std::vector<char> isb;                          // by position in this candidate's order
+        const int k = choose_border(nco, loff, mapped, t, kBordMaxCamsHost, isb);
+        if (k <= 0) break;                              // (narrower only ever needs more border cameras)
+        cands.push_back({pos, t, k, isb, layout_cost_us(t, nco - k, k)});
+      }
+    }
+  };
+  std::vector<int> ident((size_t)nco), cm;
+  for (int p = 0; p < nco; ++p) ident[p] = p;
+  add(ident);
+  cuthill_mckee_order(nco, loff, lpos, cm);
+  add(cm);
+  size_t best = 0;
+  for (size_t c = 1; c < cands.size(); ++c)
+    if (cands[c].cost < cands[best].cost * (1.0 - 1e-9)) best = c;
+  if (best == 0) return BA_OK;
+  const Cand& B = cands[best];
+  // final positions: the band cameras in the candidate's order, the border cameras behind them
+  std::vector<int> newpos((size_t)nco), inv((size_t)nco);
+  for (int p = 0; p < nco; ++p) inv[B.pos[p]] = p;        // position in the candidate's order -> caller's position
+  int nb_ = 0, nborder = 0;
+  const int n1 = nco - B.k;
+  for (int q = 0; q < nco; ++q) {
+    const bool isb = B.k > 0 && B.isb[q];
+    newpos[inv[q]] = isb ? n1 + nborder++ : nb_++;
+  }
+  std::vector<int32_t> cop((size_t)nc), cband((size_t)nc);
+  for (int i = 0; i < nc; ++i) {
+    cop[i] = cam_opt_pos[i] >= 0 ? newpos[cam_opt_pos[i]] : -1;
+    cband[i] = cop[i] >= n1 ? -1 : cop[i];
+  }
+  const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cop.data(), pt_opt, B.k > 0 ? cband.data() : nullptr, B.k);
   if (rc != BA_OK) return rc;
   h->cpos_in = newpos;
   h->cpos_out.assign((size_t)nco, 0);
   for (int p = 0; p < nco; ++p) h->cpos_out[newpos[p]] = p;
   h->caller_hb = hb0;
-  return BA_OK;
+  return border_setup(h);
 }
 
 }  // namespace
@@ -1021,7 +1081,7 @@ int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   const int64_t v[BA_INFO_COUNT] = {
       h->pperm.empty() ? 0 : 1, h->operm_identity ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
       h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
-      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf, h->cpos_in.empty() ? 0 : 1, h->caller_hb};
+      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf, h->cpos_in.empty() ? 0 : 1, h->caller_hb, h->nbc};
   for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];
   return BA_OK;
 }

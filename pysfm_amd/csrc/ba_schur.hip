@@ -66,7 +66,9 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   h->inv_valid = false;
   if (want_fac) HIPCHECK(h, h->fac.resize((size_t)9 * std::max(1, h->nt)));
   if (!have_inv) h->fac_valid = false;
-  const long long ninit = (long long)reduced_doubles(h) + (long long)h->nco * 6;
+  // (with a border, ba_border.h, the band and its right-hand side end at the band cameras: border_schur below clears and fills the rest)
+  const int n1 = h->band_cams();
+  const long long ninit = (long long)n1 * (h->hb + 1) * 36 + (long long)n1 * 6;
   if (!have_inv && h->nt > 0 && h->nco > 0) {
     // point inverses and the initialisation of [S | b] are independent: one launch for both
     h->sing_epoch ^= 1;     // this call counts singular blocks in sing_counter(); the kernel clears the other one
@@ -74,7 +76,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     const unsigned nbi = blocks_for(h->nt);
     hipLaunchKernelGGL(k_point_invert_schur_init, dim3(nbi + blocks_for(ninit)), dim3(kBlock), 0, h->stream, (int)nbi, h->nt,
                        h->HPP.p, damping, pinv_rcond, h->HPPinv.p, h->sing_counter(),
-                       h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), h->nco, h->hb + 1, h->opt_cam.p, h->HCC.p, h->bC.p, h->S,
+                       h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), n1, h->hb + 1, h->opt_cam.p, h->HCC.p, h->bC.p, h->S,
                        h->b, fuse_cam ? 0 : 1, h->bP.p, want_fac ? h->fac.p : (double*)nullptr);
     h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
     h->fac_valid = want_fac;
@@ -92,7 +94,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     }
     if (h->nco > 0) {
       ScopedTimer tm(h, BA_K_SCHUR_INIT);       // clears the band and writes the damped diagonal + b in one pass
-      hipLaunchKernelGGL(k_schur_init, dim3(blocks_for(ninit)), dim3(kBlock), 0, h->stream, h->nco, h->hb + 1, h->opt_cam.p,
+      hipLaunchKernelGGL(k_schur_init, dim3(blocks_for(ninit)), dim3(kBlock), 0, h->stream, n1, h->hb + 1, h->opt_cam.p,
                          h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
     }
   }
@@ -132,7 +134,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
     HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups_mfma2));
     hipLaunchKernelGGL(k_schur_groups_mfma2, dim3(h->nmchunks), dim3(kGm2Block), schur_mfma2_lds_bytes(h->schur_wn, h->hb + 1), h->stream,
-                       dev_problem(h), h->cams[p].p, h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->fac.p, h->S, h->b, damping,
+                       dev_problem_band(h), h->cams[p].p, h->X[p].p, h->mgroups.p, h->mchunks.p, h->schur_wn, h->fac.p, h->S, h->b, damping,
                        fuse_cam ? 1 : 0);
   } else if (use_groups) {
     ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
@@ -143,10 +145,10 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_groups<2>));
     const int maxpairs_rounds = h->group_rounds >= 1 ? h->group_rounds : 2;
     if (maxpairs_rounds == 1)
-      hipLaunchKernelGGL(k_schur_groups<1>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+      hipLaunchKernelGGL(k_schur_groups<1>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem_band(h), h->cams[p].p,
                          h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
     else
-      hipLaunchKernelGGL(k_schur_groups<2>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+      hipLaunchKernelGGL(k_schur_groups<2>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem_band(h), h->cams[p].p,
                          h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
   } else if (h->nunits > 0) {
     rc = ensure_pair_units(h);                          // (the pair kernel's work list is built on first use)
@@ -156,10 +158,14 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     const size_t lds = (size_t)NW * kTile * 18 * 2 * sizeof(double) + (size_t)NW * kTile * 2 * sizeof(int) +
                        (size_t)h->schur_wn * ((size_t)(h->hb + 1) * 36 + 6) * sizeof(double);
     HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_pairs));
-    hipLaunchKernelGGL(k_schur_pairs, dim3(h->nchunks), dim3(kSchurBlock), lds, h->stream, dev_problem(h), h->cams[p].p,
+    hipLaunchKernelGGL(k_schur_pairs, dim3(h->nchunks), dim3(kSchurBlock), lds, h->stream, dev_problem_band(h), h->cams[p].p,
                        h->X[p].p, h->units.p, h->chunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
   }
   HIPCHECK(h, hipGetLastError());
+  if (h->nbc > 0) {                                     // every block that involves a border camera (ba_border.h)
+    rc = border_schur(h, p, damping);
+    if (rc != BA_OK) return rc;
+  }
 #ifdef BA_BCR_PROFILE
   if (h->opt.solve_trace && kern == KERN_MFMA2 && !h->defer) {
     // when the workgroups of the reduction started and ended, relative to the first start (us)
@@ -221,6 +227,29 @@ int ba_get_reduced(ba_handle* h, double* S, double* b) {
             for (int c = 0; c < 6; ++c) lo[c * 6 + a] = src[a * 6 + c];
         }
       }
+  }
+  if (S && nco && h->nbc > 0) {   // ... and the blocks of the border cameras (ba_border.h): C [6 n1][ld], D [ld][ld]
+    std::vector<double> C, D;
+    const int rcb = border_get_dense(h, C, D);
+    if (rcb != BA_OK) return rcb;
+    const int* out = h->cpos_out.empty() ? nullptr : h->cpos_out.data();
+    const int n1 = h->band_cams(), ld = h->bord_ld;
+    auto put = [&](int i, int j, int u, int v, double val) {      // entry (u, v) of block (internal i, internal j)
+      const int r = out ? out[i] : i, q = out ? out[j] : j;
+      S[((size_t)r * nco + q) * 36 + u * 6 + v] = val;
+    };
+    for (int jb = 0; jb < h->nbc; ++jb) {
+      for (int i = 0; i < n1; ++i)
+        for (int u = 0; u < 6; ++u)
+          for (int v = 0; v < 6; ++v) {
+            const double val = C[(size_t)(6 * i + u) * ld + 6 * jb + v];
+            put(i, n1 + jb, u, v, val);
+            put(n1 + jb, i, v, u, val);
+          }
+      for (int ib = 0; ib < h->nbc; ++ib)
+        for (int u = 0; u < 6; ++u)
+          for (int v = 0; v < 6; ++v) put(n1 + ib, n1 + jb, u, v, D[(size_t)(6 * ib + u) * ld + 6 * jb + v]);
+    }
   }
   cam_rows_out(h, b, 6);
   return BA_OK;

@@ -15,7 +15,7 @@ int launch_mfma3(ba_handle* h, const M3Launch& L, int p, double damping, bool fu
   Gm3Params G = L.G;
   G.do_rhs = first ? 1 : 0;
   hipLaunchKernelGGL((k_schur_groups_mfma3<TJ0, TJ1, LDC, KSC>), dim3(L.nchunks), dim3(kGm2Block),
-                     schur_mfma3_lds_bytes(G.Kbuf, G.Ld, G.wn, G.wb1), h->stream, dev_problem(h), h->cams[p].p, h->X[p].p,
+                     schur_mfma3_lds_bytes(G.Kbuf, G.Ld, G.wn, G.wb1), h->stream, dev_problem_band(h), h->cams[p].p, h->X[p].p,
                      h->wgroups.p, h->wtab.p, h->opt_cam.p, L.chunks, G, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
   return BA_OK;
 }
@@ -46,7 +46,7 @@ int launch_wide(ba_handle* h, int p, double damping, bool fuse_cam) {
   const int g0 = h->wide_begin[NT - kGwMinTiles], n = h->wide_begin[NT - kGwMinTiles + 1] - g0;
   if (n <= 0) return BA_OK;
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_wide_mfma<NT>));
-  hipLaunchKernelGGL(k_schur_wide_mfma<NT>, dim3(n), dim3(kGwBlock), schur_wide_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
+  hipLaunchKernelGGL(k_schur_wide_mfma<NT>, dim3(n), dim3(kGwBlock), schur_wide_lds_bytes(), h->stream, dev_problem_band(h), h->cams[p].p,
                      h->X[p].p, h->wgroups.p, h->wide_list.p + g0, h->wtab.p, h->opt_cam.p, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
   return BA_OK;
 }
@@ -72,7 +72,7 @@ int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 
 // k_schur_rect_mfma: the products between the segments of tracks that span more than 40 cameras
 int launch_rect(ba_handle* h, int p, double damping, bool fuse_cam) {
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_schur_rect_mfma));
-  hipLaunchKernelGGL(k_schur_rect_mfma, dim3(h->nrgroups), dim3(kRectBlock), schur_rect_lds_bytes(), h->stream, dev_problem(h), h->cams[p].p,
+  hipLaunchKernelGGL(k_schur_rect_mfma, dim3(h->nrgroups), dim3(kRectBlock), schur_rect_lds_bytes(), h->stream, dev_problem_band(h), h->cams[p].p,
                      h->X[p].p, h->rgroups.p, h->nrgroups, h->rtab.p, h->opt_cam.p, h->fac.p, h->S, h->b, damping, fuse_cam ? 1 : 0);
   return BA_OK;
 }

@@ -11,12 +11,14 @@ namespace ba {
 // Cameras per node of the narrow cyclic reduction: the half-bandwidth - or, for systems of at most kBcrMaxHB cameras (the
 // sliding-window caller's 10-camera windows, the reference's own small scenes), ALL of them: one node, one workgroup, one
 // 6 nco x 6 nco Cholesky with the node kernel's pivot chain (~10 us where k_band_solve's nco dependent 6 x 6 pivots take 33).
-inline int bcr_node_size(const ba_handle* h) { return h->nco <= kBcrMaxHB ? std::max(1, h->nco) : std::max(1, h->hb); }
+// (With a border, ba_border.h, the band ends at the band cameras: the border cameras behind them are "cameras past the end".)
+inline int bcr_node_size(const ba_handle* h) { return h->band_cams() <= kBcrMaxHB ? std::max(1, h->band_cams()) : std::max(1, h->hb); }
 
 // Block cyclic reduction over super-blocks of hb cameras (ba_bcr.h): log2(N) levels, one
 // workgroup per eliminated node.  Leaves the solution in h->dC and the status in flags[1].
 int solve_bcr(ba_handle* h, const unsigned char* dmask) {
-  const int hb = bcr_node_size(h), B = 6 * hb, N = (h->nco + hb - 1) / hb;      // (hb: cameras per node from here on)
+  const int n1 = h->band_cams();
+  const int hb = bcr_node_size(h), B = 6 * hb, N = (n1 + hb - 1) / hb;      // (hb: cameras per node from here on)
   const size_t BB = (size_t)B * B;
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
@@ -73,7 +75,7 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   }
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1], marks the solution "not there yet", clears done[]
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, n1, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, s_fused ? h->bcr_done.p : nullptr);
   }
   {
@@ -346,6 +348,28 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   REQUIRE(h, info, BA_ERR_INVALID_ARG, "ba_solve_reduced: info is NULL");
   if (h->nco == 0) { *info = 0; h->have_solution = true; return BA_OK; }
   const int force = h->opt.solver;                 // ba_set_option "solver"
+  if (h->nbc > 0) {
+    // band + border (ba_border.h): the cyclic reduction factors the band and solves for its right-hand side, its kept factors
+    // take the border's columns through, one workgroup solves the border system.  A system that is not positive definite is
+    // REPORTED (*info > 0: the caller raises the damping, as for a LinAlgError of the reference) - the LU solvers do not know the border.
+    REQUIRE(h, force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1, BA_ERR_STATE, "ba_solve_reduced: a problem with border cameras is solved by the cyclic reduction (option camera_order = off sets it up without a border)");
+    REQUIRE(h, h->band_cams() <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrMaxHB), BA_ERR_STATE, "ba_solve_reduced: border with a band the cyclic reduction does not take");
+    HIPCHECK(h, hipSetDevice(h->device));
+    const unsigned char* dmaskb = nullptr;
+    if (int rcm = dist_upload_mask(h, cam_param_mask, &dmaskb); rcm != BA_OK) return rcm;
+    h->solve_kind = BA_SOLVE_BCR;
+    int rcb = solve_bcr(h, dmaskb);
+    if (rcb == BA_OK) rcb = border_solve(h, dmaskb);
+    if (rcb != BA_OK) return rcb;
+    HIPCHECK(h, hipGetLastError());
+    if (h->defer) { *info = 0; h->have_solution = true; return BA_OK; }
+    int infb = 0;
+    HIPCHECK(h, hipMemcpyAsync(&infb, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    *info = infb;
+    h->have_solution = infb == 0;
+    return BA_OK;
+  }
   const int nodes = h->hb > 0 ? (h->nco + h->hb - 1) / h->hb : 0;
   const bool bcr_ok = h->nco <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrMaxHB);      // (any number of nodes: even two levels beat k_band_solve's chain of nco pivots)
   const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && nodes >= 4;

@@ -102,6 +102,31 @@ def generate_banded_scene(ncams, npts, track_len=10, seed=654, spacing=.2, msm_n
                 obs_cam=obs_cam, obs_pt=obs_pt, obs_z=z, outliers=outliers)
 
 
+def add_loop_closure_tracks(s, pairs, width=1, seed=77, msm_noise=.02, init_perturbation=.01):
+    """The scene with extra tracks that tie far-apart cameras together (a loop closure): for every (i, j) of `pairs` one new
+    point, between the two cameras in x, observed by cameras i .. i + width - 1 and j .. j + width - 1 (measurements from the
+    true parameters + noise; K = I, so a camera "sees" whatever is in front of it).  A block-banded reduced system stops being
+    one: the reference's dense S does not care (bundle_adjuster.py:259-278), a band does."""
+    rs = np.random.RandomState(seed)
+    nt = len(s['X'])
+    cams, pts, Xn = [], [], []
+    for k, (i, j) in enumerate(pairs):
+        ci = np.r_[np.arange(i, i + width), np.arange(j, j + width)]
+        centres = -np.einsum('nji,nj->ni', s['R'][ci], s['t'][ci])
+        x = np.array([centres[:, 0].mean(), rs.rand() * 2 - 1, 4 + 4 * rs.rand()])
+        Xn.append(x)
+        cams.append(ci)
+        pts.append(np.full(len(ci), nt + k))
+    cams, pts, Xn = np.concatenate(cams).astype(np.int32), np.concatenate(pts).astype(np.int32), np.array(Xn)
+    p = np.einsum('nij,nj->ni', s['R'][cams], Xn[pts - nt]) + s['t'][cams]
+    z = p[:, :2] / p[:, 2:3] + rs.randn(len(cams), 2) * msm_noise
+    out = dict(s)
+    out.update(X=np.vstack((s['X'], Xn)), X0=np.vstack((s['X0'], Xn + rs.randn(*Xn.shape) * init_perturbation)),
+               obs_cam=np.concatenate((s['obs_cam'], cams)), obs_pt=np.concatenate((s['obs_pt'], pts)),
+               obs_z=np.vstack((s['obs_z'], z)), outliers=np.concatenate((s['outliers'], np.zeros(len(cams), bool))))
+    return out
+
+
 def _so3_exp_batch(w):
     th = np.sqrt(np.sum(w * w, axis=1))
     small = th < 1e-8

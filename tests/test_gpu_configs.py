@@ -982,3 +982,104 @@ def test_cameras_in_any_order_lm_run_and_band_at_config3_shape():
     close(np.array(costs1), np.array(costs0), 1e-9)
     close(ts1[perm], ts0, 1e-6, 1e-9)
     assert info1['schur_mfma'] == 1
+
+
+# ------------------------------------------------------------------ band + border (csrc/ba_border.h): a sequence with a few long-range tracks
+def _loop_scene(nc, nt, L, pairs, width, **kw):
+    from pysfm_amd import synthetic_data as sd
+    return sd.add_loop_closure_tracks(banded(nc, nt, track_len=L, **kw), pairs, width=width)
+
+
+@pytest.mark.parametrize('sensor,L,width,npairs', [(O.Sensor.gaussian(1.), 10, 1, 6), (O.Sensor.cauchy(.05), 8, 3, 4), (O.Sensor.huber(.06), 6, 2, 9)])
+def test_loop_closure_tracks_band_plus_border_vs_oracle(be, sensor, L, width, npairs):
+    """A camera sequence plus a few tracks that tie far-apart cameras together: the reference's dense S takes them like any
+    other track (bundle_adjuster.py:259-312); here the cameras at their far end become a border of the band (csrc/ba_border.h).
+    Everything that crosses the C ABI - S (band, border columns and border block expanded), b, the solution with and without
+    masked camera parameters, the point updates, the whole trial, the flat matrix - against the oracle."""
+    nc, nt = 160, 4000
+    rs = np.random.RandomState(4)
+    pairs = [(int(i), int(i) + 60 + int(rs.randint(0, 30))) for i in rs.choice(60, npairs, replace=False) + 2]
+    s = _loop_scene(nc, nt, L, pairs, width, outlier_frac=.02)
+    nt = len(s['X0'])
+    cam_opt_pos = np.arange(nc, dtype=np.int32) - 1
+    pt_opt = np.ones(nt, np.uint8)
+    pt_opt[::11] = 0
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
+    info = be.problem_info()
+    assert 0 < info['border_cameras'] <= npairs * width and info['half_bandwidth'] <= 11 and info['caller_half_bandwidth'] >= 60, info
+    nco = be.nco
+    close(be.cost(0), O.cost(sensor, *a, cam_opt_pos, pt_opt), 1e-12)
+    mask = (rs.rand(nco * 6) > .04).astype(np.uint8)
+    # mask a parameter of a border camera and one of a camera it shares a track with, whatever the draw
+    far = pairs[0][1] - 1
+    mask[6 * far + 2] = 0
+    mask[6 * (pairs[0][0] - 1) + 4] = 0
+    for m in (None, mask):
+        mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=1.5, cam_param_mask=None if m is None else m.astype(bool), return_parts=True)
+        be.linearize(0)
+        be.schur(0, 1.5, 1e-5)
+        S, b = be.get_reduced()
+        close(S, parts['S'], TIGHT)
+        close(b, parts['b'], TIGHT)
+        be.solve_reduced(m)
+        assert be.last_solve_kind == 'bcr'
+        dC = be.get_solution()
+        close(-dC, mu, 1e-8)
+        if m is not None:
+            assert np.all(dC.reshape(-1)[m == 0] == 0.)
+        dP = be.backsubstitute(0)
+        close(-dP[pt_opt.astype(bool)], su, 1e-8)
+        infoT, cost = be.lm_trial(1.5, 1e-5, m)
+        assert infoT == 0
+        S2, b2 = be.get_reduced()                       # (the trial's fused kernels: camera blocks inside the reduction)
+        close(S2, parts['S'], TIGHT)
+        close(b2, parts['b'], TIGHT)
+        R2, t2, X2 = O.apply_update(s['R0'], s['t0'], s['X0'], mu, su, cam_opt_pos, pt_opt)
+        Rg, tg, Xg = be.get_params(1)
+        close(Xg, X2, 1e-9)
+        close(tg, t2, 1e-9)
+        close(cost, O.cost(sensor, s['K'], R2, t2, X2, *a[4:], cam_opt_pos, pt_opt), 1e-8)
+    import ctypes as C
+    import torch
+    from pysfm_amd import _capi as capi
+    be.linearize(0)
+    be.schur(0, 1.5, 1e-5)
+    keepi = np.nonzero(mask)[0].astype(np.int32)
+    A = torch.zeros(len(keepi), len(keepi), dtype=torch.float64, device='cuda')
+    rhs = torch.zeros(len(keepi), dtype=torch.float64, device='cuda')
+    be._check(be._lib.ba_flatten_reduced(be._h, capi.iptr(keepi), len(keepi), C.c_void_p(A.data_ptr()), C.c_void_p(rhs.data_ptr())))
+    Af, bf = O.flatten_reduced(parts['S'], parts['b'])
+    close(A.cpu().numpy(), Af[np.ix_(keepi, keepi)], TIGHT)
+    close(rhs.cpu().numpy(), bf[keepi], TIGHT)
+    # without the border: the same numbers through the wide band
+    be.set_option('border', 0)
+    load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
+    assert be.problem_info()['border_cameras'] == 0
+    be.linearize(0)
+    be.schur(0, 1.5, 1e-5)
+    be.solve_reduced(mask)
+    close(-be.get_solution(), mu, 1e-8)
+
+
+def test_loop_closure_lm_run_matches_the_oracle_walk():
+    """optimize() on a sequence with loop-closure tracks (band + border inside) against the oracle's walk of the reference's loop:
+    same decisions, accepted costs to 1e-6."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    nc, nt = 120, 2500
+    pairs = [(5, 80), (9, 100), (30, 111), (31, 112), (40, 95)]
+    s = _loop_scene(nc, nt, 9, pairs, 2)
+    nt = len(s['X0'])
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=sensor_model.GaussianModel(1.))
+    ba = BundleAdjuster(b, verbose=False)
+    assert ba.backend.problem_info()['border_cameras'] > 0
+    ba.optimize(max_steps=8)
+    flags = (np.arange(nc, dtype=np.int32) - 1, np.ones(nt, bool))
+    trace = []
+    ref = O.lm_optimize(O.Sensor.gaussian(1.), s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, max_steps=8, trace=trace)
+    got = [(d, o == 'accepted') for d, o, _ in ba.trial_log]
+    want = [(tr['damping'], tr['next'] < tr['cur']) for tr in trace]
+    assert got == want, (got, want)
+    close(np.array(ba.costs), np.array(ref['costs']), 1e-6)
+    close(ba.bundle.ts(), ref['t'], 1e-6, 1e-8)
+    ba.backend.close()
