@@ -32,17 +32,23 @@ typedef double bord_acc4 __attribute__((ext_vector_type(4)));
 //   pc <  n1 (a band camera):   C[pc, ja] = - sum W_c HPPinv W_a^T           (T_a = W_a HPPinv)
 //   pc >= n1 (a border camera): D[pc - n1, ja] = - sum W_c HPPinv W_a^T      (both orders of a pair of border cameras are listed)
 // C row-major [rows][ld] with row 6 pos + u, column 6 ja + v; D row-major [ld][ld]; b2 = the border part of b.
-struct BorderBlock { int begin, end, pc, ja; };
+// A block's pairs are walked in CHUNKS of kBordChunkPairs (one wavefront each, two pairs a lane) that leave partial sums (two pairs a lane; 64-pair chunks measured slower: 24.6 against 19.2 us at config 3 with ten border cameras);
+// k_border_sum adds a block's chunks up in their order and writes the block.
+struct BorderBlock { int begin, end, pc, ja; };              // pairs [begin, end); its chunks start at chunk index `first` = see BorderChunk
+struct BorderChunk { int block, begin, end, pad; };
+constexpr int kBordChunkPairs = 128;
+constexpr int kBordPartial = 42;                             // 36 entries + 6 of the right-hand side
 
 template <bool TABLE>
 __global__ __launch_bounds__(kBlock) void k_schur_border(DevProblem P, const double* __restrict__ cams, const double* __restrict__ X,
-                                                         const BorderBlock* __restrict__ blocks, int nblocks, const int2* __restrict__ pairs,
-                                                         int n1, double damping, const double* __restrict__ HPPinv,
-                                                         const double* __restrict__ bP, double* __restrict__ C, double* __restrict__ D, int ld,
-                                                         double* __restrict__ b2) {
+                                                         const BorderBlock* __restrict__ blocks, const BorderChunk* __restrict__ chunks, int nchunks,
+                                                         const int2* __restrict__ pairs, int n1, double damping, const double* __restrict__ HPPinv,
+                                                         const double* __restrict__ bP, double* __restrict__ partial) {
   const int wv = (int)((blockIdx.x * (unsigned)kBlock + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-  if (wv >= nblocks) return;
-  const BorderBlock bk = blocks[wv];
+  if (wv >= nchunks) return;
+  const BorderChunk ck = chunks[wv];
+  BorderBlock bk = blocks[ck.block];
+  bk.begin = ck.begin; bk.end = ck.end;
   const bool diag = bk.pc == n1 + bk.ja;
   double acc[36], rhs[6];
 #pragma unroll
@@ -93,9 +99,25 @@ __global__ __launch_bounds__(kBlock) void k_schur_border(DevProblem P, const dou
 #pragma unroll
     for (int i = 0; i < 6; ++i) { const double t = wave_sum(rhs[i]); if (lane == i) myr = t; }
   }
+  if (lane < 36) partial[(size_t)wv * kBordPartial + lane] = mine;
+  if (lane < 6) partial[(size_t)wv * kBordPartial + 36 + lane] = myr;
+}
+
+// ... the chunks of a block added up in their order: 42 threads a block (chunk_first[b] .. chunk_first[b + 1] are its chunks)
+__global__ __launch_bounds__(kBlock) void k_border_sum(const BorderBlock* __restrict__ blocks, int nblocks, const int* __restrict__ chunk_first,
+                                                       const double* __restrict__ partial, int n1, double* __restrict__ C, double* __restrict__ D, int ld,
+                                                       double* __restrict__ b2) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  const int b = t / kBordPartial, i = t % kBordPartial;
+  if (b >= nblocks) return;
+  const BorderBlock bk = blocks[b];
+  const bool diag = bk.pc == n1 + bk.ja;
+  if (i >= 36 && !diag) return;
+  double sacc = 0.0;
+  for (int c = chunk_first[b]; c < chunk_first[b + 1]; ++c) sacc += partial[(size_t)c * kBordPartial + i];
+  if (i >= 36) { b2[6 * bk.ja + i - 36] = sacc; return; }
   double* dst = bk.pc < n1 ? C + (size_t)(6 * bk.pc) * ld + 6 * bk.ja : D + (size_t)(6 * (bk.pc - n1)) * ld + 6 * bk.ja;
-  if (lane < 36) dst[(size_t)(lane / 6) * ld + lane % 6] = mine;
-  if (diag && lane < 6) b2[6 * bk.ja + lane] = myr;
+  dst[(size_t)(i / 6) * ld + i % 6] = sacc;
 }
 
 // ---- F = C with the rows / columns of masked camera parameters cleared; M [nb][nb] = D with masked border parameters turned into
@@ -127,13 +149,26 @@ __global__ __launch_bounds__(kBlock) void k_border_prepare(long long rowsF, int 
 // A(i, k) = Am[i * ra + k * ca] (LDS; rows / columns past the matrix are zero there), X[k * ldx + j] (LDS, 16 columns).
 // Layout of v_mfma_f64_16x16x4_f64: lane (lr = lane & 15, lk = lane >> 4) feeds A[lr][lk] and X[lk][lr]; it receives
 // acc[v] = entry (lk + 4 v, lr).
+// k0, k1 are multiples of 16: four k-steps at a time, their eight operands in registers before the first of their MFMAs and the
+// next four's loads issued before it too (an LDS round trip per MFMA would be three times the MFMA).
 __device__ __forceinline__ void bord_tile_mac(bord_acc4& acc, const double* __restrict__ Am, int ra, int ca, int i0, const double* __restrict__ Xs,
                                               int ldx, int k0, int k1, int lr, int lk, bool negate) {
-  const double* ap = Am + (size_t)(i0 + lr) * ra + (size_t)lk * ca;
-  const double* xp = Xs + (size_t)lk * ldx + lr;
-  for (int k = k0; k < k1; k += 4) {
-    const double a = ap[(size_t)k * ca], x = xp[(size_t)k * ldx];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -a : a, x, acc, 0, 0, 0);
+  if (k0 >= k1) return;
+  const double* ap = Am + (i0 + lr) * ra + lk * ca;
+  const double* xp = Xs + lk * ldx + lr;
+  const int sa = 4 * ca, sx = 4 * ldx;
+  double a[4], x[4], an[4], xn[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] = ap[k0 * ca + q * sa]; x[q] = xp[k0 * ldx + q * sx]; }
+  for (int k = k0; k < k1; k += 16) {
+    const bool more = k + 16 < k1;
+    const int kn = more ? k + 16 : k;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { an[q] = ap[kn * ca + q * sa]; xn[q] = xp[kn * ldx + q * sx]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -a[q] : a[q], x[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = an[q]; x[q] = xn[q]; }
   }
 }
 
@@ -221,18 +256,29 @@ __global__ __launch_bounds__(kBordThreads) void k_bcr_apply(int N, int B, int s,
     bord_acc4 acc[SLOTS];
 #pragma unroll
     for (int q = 0; q < SLOTS; ++q) acc[q] = bord_acc4{0, 0, 0, 0};
+    BordMatrixRegs<NRT> g, m;
+    BordRhsRegs<NRT> f;
+    bord_load_matrix<NRT>(g, Gi + (size_t)(j - s) * BB, B, true, true, wave, lane);
+    bord_load_matrix<NRT>(m, Qm + (size_t)(j - s) * BB, B, false, true, wave, lane);
+    bord_load_rhs<NRT>(f, F, ld, j - s, B, col0, true, tid);
+    double fj[SLOTS][4];                                     // my entries of F_j (the update is added to them at the end: no read-modify-write round trip there)
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 16 * (wave + 4 * q) + lk + 4 * v;
+        fj[q][v] = (wave + 4 * q < NRT && r < B) ? F[((size_t)j * B + r) * ld + col0 + lr] : 0.0;
+      }
     for (int side = 0; side < 2; ++side) {
       const int i = side == 0 ? j - s : j + s;
       if (i >= N) break;                                     // (uniform over the workgroup)
-      {
-        BordMatrixRegs<NRT> g, m;
-        BordRhsRegs<NRT> f;
-        bord_load_matrix<NRT>(g, Gi + (size_t)i * BB, B, true, true, wave, lane);
-        bord_load_matrix<NRT>(m, (side == 0 ? Qm : Pm) + (size_t)i * BB, B, false, true, wave, lane);
-        bord_load_rhs<NRT>(f, F, ld, i, B, col0, true, tid);
-        bord_store_matrix<NRT>(g, A0, wave, lane);
-        bord_store_matrix<NRT>(m, A1, wave, lane);
-        bord_store_rhs<NRT>(f, X0, tid);
+      bord_store_matrix<NRT>(g, A0, wave, lane);
+      bord_store_matrix<NRT>(m, A1, wave, lane);
+      bord_store_rhs<NRT>(f, X0, tid);
+      if (side == 0 && j + s < N) {                          // the other neighbour's operands on their way meanwhile
+        bord_load_matrix<NRT>(g, Gi + (size_t)(j + s) * BB, B, true, true, wave, lane);
+        bord_load_matrix<NRT>(m, Pm + (size_t)(j + s) * BB, B, false, true, wave, lane);
+        bord_load_rhs<NRT>(f, F, ld, j + s, B, col0, true, tid);
       }
       __syncthreads();
       // T = G_i^-1 F_i   (lower triangular: k <= row)
@@ -258,7 +304,7 @@ __global__ __launch_bounds__(kBordThreads) void k_bcr_apply(int N, int B, int s,
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int r = 16 * rt + lk + 4 * v;
-          if (r < B) F[((size_t)j * B + r) * ld + col0 + lr] += acc[q][v];
+          if (r < B) F[((size_t)j * B + r) * ld + col0 + lr] = fj[q][v] + acc[q][v];
         }
     }
   } else {
@@ -323,47 +369,65 @@ __global__ __launch_bounds__(kBordThreads) void k_bcr_apply(int N, int B, int s,
 // ---- M -= C^T Y, rv -= C^T y over the rows of the band cameras (M [nb][nb] full and symmetric: the node kernel of the cyclic
 // reduction factors it).  One workgroup per chunk of kBordRedRows rows; the tiles (tu <= tv) of 16 x 16 over its wavefronts,
 // operands straight from memory, all of a tile's loads before its first MFMA; an off-diagonal tile is added to both triangles.
-constexpr int kBordRedRows = 32;
-__global__ __launch_bounds__(kBordThreads) void k_border_reduce(int rows1, int ld, int nb, const double* __restrict__ C, const double* __restrict__ Y,
-                                                                const double* __restrict__ y, const unsigned char* __restrict__ mask2,
-                                                                double* __restrict__ M, double* __restrict__ rv) {
+// Only the band cameras that share a track with a border camera have rows in C: `rcams` lists them (set-up).  A workgroup owns
+// one 16 x 16 tile (tu <= tv; blockIdx.x = tile, the last one = the right-hand side) and four chunks of kBordRedCams cameras, one
+// per wavefront (blockIdx.y * 4 + wave); the four partial tiles meet in LDS and leave as ONE set of atomics.
+// (Global fp64 atomics run at ~9 per nanosecond on the whole device whatever their addresses - measured: the first version of the
+// border reduction, 3.6 M atomics in 0.42 ms - and only the LOWER triangle of M is kept: all the node kernel reads.)
+constexpr int kBordRedCams = 8, kBordRedRows = 6 * kBordRedCams;
+__global__ __launch_bounds__(kBordThreads) void k_border_reduce(int nrcams, const int* __restrict__ rcams, int ld, int nb, const double* __restrict__ C,
+                                                                const double* __restrict__ Y, const double* __restrict__ y,
+                                                                const unsigned char* __restrict__ mask2, double* __restrict__ M, double* __restrict__ rv) {
+  __shared__ double part[kBordThreads / 64][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-  const int r0 = blockIdx.x * kBordRedRows;
+  const int c0 = (blockIdx.y * (kBordThreads / 64) + wave) * kBordRedCams;
   const int nt = ld / 16, ntiles = nt * (nt + 1) / 2;
-  for (int tile = wave; tile < ntiles; tile += kBordThreads / 64) {
-    int tu, tv;
-    tri_decode(tile, nt, tu, tv);
-    double a[kBordRedRows / 4], x[kBordRedRows / 4];
+  const int tile = blockIdx.x;
+  int rows[kBordRedCams];
 #pragma unroll
-    for (int q = 0; q < kBordRedRows / 4; ++q) {
-      const int kk = r0 + 4 * q + lk;
-      const bool in = kk < rows1;
-      // (C as the reduction left it: the column of a masked border parameter - mask2[.] == 0 - must not reach its identity row of M;
-      //  Y's masked columns and rows are zero already)
-      const bool cu = 16 * tu + lr < nb && !(mask2 && !mask2[16 * tu + lr]);
-      a[q] = (in && cu) ? C[(size_t)kk * ld + 16 * tu + lr] : 0.0;
-      x[q] = in ? Y[(size_t)kk * ld + 16 * tv + lr] : 0.0;
+  for (int q = 0; q < kBordRedCams; ++q) rows[q] = c0 + q < nrcams ? 6 * rcams[c0 + q] : -1;
+  if (tile == ntiles) {                                   // rv -= C^T y: lane = column (and + 64)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = lane + 64 * hh;
+      double p[kBordRedRows];
+#pragma unroll
+      for (int q = 0; q < kBordRedRows; ++q) { const int kk = rows[q / 6] + q % 6; p[q] = (rows[q / 6] >= 0 && c < nb) ? C[(size_t)kk * ld + c] * y[kk] : 0.0; }
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < kBordRedRows; ++q) sacc += p[q];
+      part[wave][c] = sacc;
     }
-    bord_acc4 acc = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < kBordRedRows / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], x[q], acc, 0, 0, 0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int u = 16 * tu + lk + 4 * v, w = 16 * tv + lr;
-      if (u < nb && w < nb) {
-        atomic_add_f64(M + (size_t)u * nb + w, acc[v]);
-        if (tu != tv) atomic_add_f64(M + (size_t)w * nb + u, acc[v]);
-      }
-    }
+    __syncthreads();
+    if (tid < nb && !(mask2 && !mask2[tid])) atomic_add_f64(rv + tid, -(part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]));
+    return;
   }
-  if (tid < nb && !(mask2 && !mask2[tid])) {
-    double part[kBordRedRows];
+  int tu, tv;
+  tri_decode(tile, nt, tu, tv);
+  // (C as the reduction left it: the column of a masked border parameter - mask2[.] == 0 - must not reach its identity row of M;
+  //  Y's masked columns and rows are zero already)
+  const bool cu = 16 * tu + lr < nb && !(mask2 && !mask2[16 * tu + lr]);
+  double a[kBordRedRows / 4], x[kBordRedRows / 4];
 #pragma unroll
-    for (int q = 0; q < kBordRedRows; ++q) part[q] = r0 + q < rows1 ? C[(size_t)(r0 + q) * ld + tid] * y[r0 + q] : 0.0;
-    double sacc = 0.0;
+  for (int q = 0; q < kBordRedRows / 4; ++q) {            // this lane's rows: k = 4 q + lk
+    const int k = 4 * q + lk;
+    int base = rows[0];
 #pragma unroll
-    for (int q = 0; q < kBordRedRows; ++q) sacc += part[q];
-    atomic_add_f64(rv + tid, -sacc);
+    for (int m = 1; m < kBordRedCams; ++m) base = (k / 6 == m) ? rows[m] : base;
+    const int kk = base + k % 6;
+    a[q] = (base >= 0 && cu) ? C[(size_t)kk * ld + 16 * tu + lr] : 0.0;
+    x[q] = base >= 0 ? Y[(size_t)kk * ld + 16 * tv + lr] : 0.0;
+  }
+  bord_acc4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < kBordRedRows / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], x[q], acc, 0, 0, 0);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) part[wave][(lk + 4 * v) * 16 + lr] = acc[v];
+  __syncthreads();
+  {
+    const int i = tid >> 4, j = tid & 15;                 // entry (16 tu + i, 16 tv + j) of C^T Y: the lower triangle takes it as (w, u)
+    const int u = 16 * tu + i, w = 16 * tv + j;
+    if (u < nb && w < nb && (tu != tv || w >= u)) atomic_add_f64(M + (size_t)w * nb + u, part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
   }
 }
 

@@ -78,10 +78,32 @@ int border_setup(ba_handle* h) {
     }
   }
   h->nbord_obs = (int)blocks.size();
-  HIPCHECK(h, h->bord_obs.resize(std::max<size_t>(4, blocks.size() * 4 + pairs.size() * 2)));      // [blocks | pairs]
+  // chunks of a block's pairs (one wavefront each), where a block's chunks start, the band cameras that have a block
+  std::vector<BorderChunk> chunks;
+  std::vector<int> chunk_first(blocks.size() + 1, 0), rcams;
+  for (size_t b = 0; b < blocks.size(); ++b) {
+    chunk_first[b] = (int)chunks.size();
+    for (int e = blocks[b].begin; e < blocks[b].end; e += kBordChunkPairs) chunks.push_back({(int)b, e, std::min(e + kBordChunkPairs, blocks[b].end), 0});
+    if (blocks[b].pc < n1) rcams.push_back(blocks[b].pc);
+  }
+  chunk_first[blocks.size()] = (int)chunks.size();
+  std::sort(rcams.begin(), rcams.end());
+  rcams.erase(std::unique(rcams.begin(), rcams.end()), rcams.end());
+  h->bord_nchunks = (int)chunks.size();
+  h->bord_nrcams = (int)rcams.size();
+  // bord_obs = [blocks | chunks | chunk_first | rcams | pairs]
+  h->bord_off_chunks = blocks.size() * 4;
+  h->bord_off_first = h->bord_off_chunks + chunks.size() * 4;
+  h->bord_off_rcams = h->bord_off_first + chunk_first.size();
+  h->bord_off_pairs = (h->bord_off_rcams + rcams.size() + 1) & ~(size_t)1;
+  HIPCHECK(h, h->bord_obs.resize(std::max<size_t>(4, h->bord_off_pairs + pairs.size() * 2)));
+  HIPCHECK(h, h->bord_partial.resize(std::max<size_t>(1, chunks.size() * kBordPartial)));
   if (!blocks.empty()) {
     HIPCHECK(h, hipMemcpyAsync(h->bord_obs.p, blocks.data(), blocks.size() * sizeof(BorderBlock), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->bord_obs.p + blocks.size() * 4, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->bord_obs.p + h->bord_off_chunks, chunks.data(), chunks.size() * sizeof(BorderChunk), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->bord_obs.p + h->bord_off_first, chunk_first.data(), chunk_first.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!rcams.empty()) HIPCHECK(h, hipMemcpyAsync(h->bord_obs.p + h->bord_off_rcams, rcams.data(), rcams.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->bord_obs.p + h->bord_off_pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
   }
   HIPCHECK(h, h->bordC.resize(h->bord_rows * ld));
   HIPCHECK(h, h->bordF.resize(h->bord_rows * ld));
@@ -98,17 +120,21 @@ int border_setup(ba_handle* h) {
 int border_schur(ba_handle* h, int p, double damping) {
   if (h->nbc <= 0) return BA_OK;
   const int n1 = h->band_cams(), ld = h->bord_ld, nblocks = h->nbord_obs;
-  ScopedTimer tm(h, BA_K_BORDER_SCHUR, 1);
+  ScopedTimer tm(h, BA_K_BORDER_SCHUR, 2);
   if (nblocks > 0) {
     const BorderBlock* blocks = reinterpret_cast<const BorderBlock*>(h->bord_obs.p);
-    const int2* pairs = reinterpret_cast<const int2*>(h->bord_obs.p + (size_t)nblocks * 4);
-    const unsigned grid = (unsigned)((nblocks + kBlock / 64 - 1) / (kBlock / 64));
+    const BorderChunk* chunks = reinterpret_cast<const BorderChunk*>(h->bord_obs.p + h->bord_off_chunks);
+    const int2* pairs = reinterpret_cast<const int2*>(h->bord_obs.p + h->bord_off_pairs);
+    const int nchunks = h->bord_nchunks;
+    const unsigned grid = (unsigned)((nchunks + kBlock / 64 - 1) / (kBlock / 64));
     if (h->sensor.kind == SENSOR_TABLE)
-      hipLaunchKernelGGL(k_schur_border<true>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p, blocks, nblocks, pairs, n1,
-                         damping, h->HPPinv.p, h->bP.p, h->bordC.p, h->bordD.p, ld, h->b + (size_t)6 * n1);
+      hipLaunchKernelGGL(k_schur_border<true>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p, blocks, chunks, nchunks, pairs, n1,
+                         damping, h->HPPinv.p, h->bP.p, h->bord_partial.p);
     else
-      hipLaunchKernelGGL(k_schur_border<false>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p, blocks, nblocks, pairs, n1,
-                         damping, h->HPPinv.p, h->bP.p, h->bordC.p, h->bordD.p, ld, h->b + (size_t)6 * n1);
+      hipLaunchKernelGGL(k_schur_border<false>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem(h), h->cams[p].p, h->X[p].p, blocks, chunks, nchunks, pairs, n1,
+                         damping, h->HPPinv.p, h->bP.p, h->bord_partial.p);
+    hipLaunchKernelGGL(k_border_sum, dim3(blocks_for((long long)nblocks * kBordPartial)), dim3(kBlock), 0, h->stream, blocks, nblocks, h->bord_obs.p + h->bord_off_first,
+                       h->bord_partial.p, n1, h->bordC.p, h->bordD.p, ld, h->b + (size_t)6 * n1);
   }
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
@@ -132,8 +158,10 @@ int border_solve(ba_handle* h, const unsigned char* dmask) {
     default: rc = launch_apply_levels<5>(h, N, B, ld); break;
   }
   if (rc != BA_OK) return rc;
-  hipLaunchKernelGGL(k_border_reduce, dim3((unsigned)((rows1 + kBordRedRows - 1) / kBordRedRows)), dim3(kBordThreads), 0, h->stream, rows1, ld, nb, h->bordC.p,
-                     h->bordF.p, h->dC.p, dmask ? dmask + rows1 : nullptr, bord_M(h), bord_rv(h));
+  if (h->bord_nrcams > 0)
+    hipLaunchKernelGGL(k_border_reduce, dim3((unsigned)((ld / 16) * (ld / 16 + 1) / 2 + 1), (unsigned)((h->bord_nrcams + 4 * kBordRedCams - 1) / (4 * kBordRedCams))),
+                       dim3(kBordThreads), 0, h->stream, h->bord_nrcams,
+                       h->bord_obs.p + h->bord_off_rcams, ld, nb, h->bordC.p, h->bordF.p, h->dC.p, dmask ? dmask + rows1 : nullptr, bord_M(h), bord_rv(h));
   if (h->nbc <= kBcrMaxHB) {
     // the border system as ONE node of the cyclic reduction (its root: factor, solve): the node kernel's pivot chain
     const size_t Bb = (size_t)nb, BB = Bb * Bb;

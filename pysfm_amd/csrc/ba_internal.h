@@ -168,6 +168,9 @@ struct ba_handle {
   DevBuf<int> bord_obs;                // [BorderBlock x nbord_obs | the blocks' pairs of observations] (ba_border.h)
   int nbord_obs = 0, bord_ld = 0;      // ... the number of blocks; row length of C, D (6 nbc rounded up to 16)
   size_t bord_rows = 0;                // rows of C / F: the nodes of the cyclic reduction (>= 6 band cameras)
+  int bord_nchunks = 0, bord_nrcams = 0;      // chunks of the blocks' pairs (one wavefront each); band cameras that have a block in C
+  size_t bord_off_chunks = 0, bord_off_first = 0, bord_off_rcams = 0, bord_off_pairs = 0;      // where they sit in bord_obs (ints)
+  DevBuf<double> bord_partial;         // the chunks' partial sums
   DevBuf<double> bordC, bordF, bordD;  // C (as the reduction leaves it), F (work: C -> Y), [D | M | rv | x2]
   int band_cams() const { return nco - nbc; }
   std::vector<unsigned char> mask_host; // the mask of the last solve in the internal order (outlives its asynchronous upload)

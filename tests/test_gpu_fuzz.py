@@ -62,6 +62,20 @@ def make_case(seed):
         X0[new_id] = s['X0']
         o = rs.permutation(len(cam))
         cam, pt, z = cam[o], new_id[pt[o]].astype(np.int32), z[o]
+    if seed % 7 == 3 and nc >= 60 and not long_tracks:                              # a few loop-closure tracks (round 5): band + border
+        npairs = int(rs.randint(1, 7))
+        far = rs.choice(np.arange(nc // 2 + 4, nc - 3), npairs, replace=False)
+        near = rs.choice(np.arange(1, nc // 2 - 8), npairs, replace=False)
+        width = int(rs.randint(1, 3))
+        ecam = np.concatenate([np.r_[np.arange(a, a + width), np.arange(b, b + width)] for a, b in zip(near, far)])
+        ept = np.repeat(nt + np.arange(npairs), 2 * width)
+        Xn = np.c_[s['X'][:npairs, 0] * 0 + rs.rand(npairs) * nc * .2, rs.rand(npairs) * 2 - 1, 4 + 4 * rs.rand(npairs)]
+        pr = np.einsum('nij,nj->ni', s['R'][ecam], Xn[ept - nt]) + s['t'][ecam]
+        cam = np.concatenate((cam, ecam)).astype(np.int32)
+        pt = np.concatenate((pt, ept)).astype(np.int32)
+        z = np.vstack((z, pr[:, :2] / pr[:, 2:3] + rs.randn(len(ecam), 2) * .02))
+        X0 = np.vstack((X0, Xn + rs.randn(npairs, 3) * .01))
+        nt += npairs
     frozen = set([0] if rs.rand() < .7 else []) | set(rs.choice(nc, int(rs.randint(0, 3)), replace=False).tolist())
     if len(frozen) == nc:
         frozen = {0}
@@ -82,6 +96,7 @@ def make_case(seed):
 
 
 KERNELS_SEEN = set()
+LAYOUTS_SEEN = {'cameras_permuted': 0, 'border': 0}
 
 
 @pytest.mark.parametrize('seed', range(84))
@@ -89,7 +104,10 @@ def test_random_scene_full_step_vs_oracle(be, seed):
     c = make_case(seed)
     a, cp, po, sensor = c['a'], c['cam_opt_pos'], c['pt_opt'], c['sensor']
     load_problem(be, *a, cp, po, sensor)
-    KERNELS_SEEN.add(be.problem_info()['schur_kernel'])
+    info0 = be.problem_info()
+    KERNELS_SEEN.add(info0['schur_kernel'])
+    LAYOUTS_SEEN['cameras_permuted'] += info0['cameras_permuted']
+    LAYOUTS_SEEN['border'] += 1 if info0['border_cameras'] > 0 else 0
     close(be.cost(0), O.cost(sensor, *a, cp, po), 1e-12, atol=1e-300)
     cmask = None if c['mask'] is None else c['mask'].astype(bool)
     try:
@@ -137,8 +155,10 @@ def test_random_scene_full_step_vs_oracle(be, seed):
 
 
 def test_the_sweep_reached_the_matrix_core_kernels():
-    """(runs after the sweep) both producer / consumer reductions and the pair kernel were exercised."""
+    """(runs after the sweep) both producer / consumer reductions and the pair kernel were exercised - and the camera orders
+    and borders the library chooses itself (round 5)."""
     assert {0, 4} <= KERNELS_SEEN, KERNELS_SEEN
+    assert LAYOUTS_SEEN['cameras_permuted'] > 0 and LAYOUTS_SEEN['border'] > 0, LAYOUTS_SEEN
 
 
 def test_results_do_not_depend_on_what_ran_before_on_the_handle(be):
