@@ -411,6 +411,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     ba.set_bundle(bundle)
     t_setup = time.time() - t0
     be = ba.backend
+    be.set_option('reuse_linearization', 0)         # a timed step is a COMPLETE trial: nothing kept from the trial before (the end-to-end run below keeps the default)
     one_trial, state = make_trial_runner(ba, be)
     one_trial()                                     # lazy code-object loading
     be.enable_timing(True)
@@ -443,7 +444,9 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
            'schur_kernel': info.get('schur_kernel'), 'half_bandwidth': be.half_bandwidth, 'solve_kind': getattr(be, 'last_solve_kind', None),
            'cameras_permuted': info.get('cameras_permuted'), 'caller_half_bandwidth': info.get('caller_half_bandwidth'), 'border_cameras': info.get('border_cameras'),
            'trials_by_solver_and_outcome': dict(state['paths']), 'set_bundle_s': t_setup, 'set_bundle_first_s': t_setup_first}
-    # what a caller feels: BundleAdjuster.set_bundle + optimize(25 steps), the adjusted bundle back on the host
+    # what a caller feels: BundleAdjuster.set_bundle + optimize(25 steps), the adjusted bundle back on the host (library defaults:
+    # a trial that follows a rejected one reuses the linearisation of the unchanged current set)
+    be.set_option('reuse_linearization', 1)
     torch.cuda.synchronize()
     t0 = time.time()
     ba.set_bundle(bundle)
@@ -452,6 +455,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     torch.cuda.synchronize()
     out['end_to_end_optimize_s'] = time.time() - t0
     out['end_to_end_lm_trials'] = int(ba.lm_trials)
+    out['end_to_end_linearizations_reused'] = be.problem_info().get('linearizations_reused')
     be.close()
     return out
 
@@ -785,7 +789,22 @@ def main():
         sq, cnt = float(np.sum(e * e)), float(len(e))
         if comm is not None:
             sq, cnt = comm.allreduce_scalar(sq), comm.allreduce_scalar(cnt)
-        lm = dict(final_reproj_rmse=float(np.sqrt(sq / cnt)), lm_steps=ba.num_steps,
+        # "next to the CPU restatement's value on the same scene and seed" - the oracle's own 25-step walk of this
+        # scene (oracle/gen_golden_lm25.py ran it in the build container, ~25 minutes; tests/golden/<name>_lm25.npz)
+        oracle_run = None
+        golden = {(3, 'gaussian', 'params'): 'config3', (3, 'gaussian', 'pose'): 'config3_pose', (4, 'huber', 'params'): 'config4_huber'}.get((args.config, sensor_name, init_mode))
+        if golden and plain and not args.shuffle_points:
+            path = os.path.join(ROOT, 'tests', 'golden', golden + '_lm25.npz')
+            if os.path.exists(path):
+                gd = np.load(path)
+                oracle_run = dict(final_reproj_rmse=float(gd['rmse_final']), initial_reproj_rmse=float(gd['rmse_initial']), lm_steps=int(gd['num_steps']),
+                                  lm_trials=int(len(gd['trial_damping'])), lm_converged=bool(gd['converged']), lm_cost_initial=float(gd['costs'][0]),
+                                  lm_cost_final=float(gd['costs'][-1]), oracle_wall_s=float(gd['oracle_wall_s']), source='tests/golden/%s_lm25.npz' % golden,
+                                  note='oracle/ba_oracle.py lm_optimize (NumPy restatement of bundle_adjuster.py:117-162) on the same scene and seed, run in the build '
+                                       'container; the two walks take the same decisions up to the first step accepted at a damping below 1e-2 and are two samples '
+                                       'of an ill-conditioned sequence after it (tests/test_gpu_configs.py::test_full_lm25_run_against_the_oracle_golden_walk)')
+        lm = dict(final_reproj_rmse=float(np.sqrt(sq / cnt)), final_reproj_rmse_oracle=None if oracle_run is None else oracle_run['final_reproj_rmse'],
+                  oracle_lm_run=oracle_run, lm_steps=ba.num_steps,
                   lm_trials=int(ba.lm_trials), lm_converged=bool(ba.converged),
                   lm_cost_initial=ba.costs[0], lm_cost_final=ba.costs[-1], lm_wall_s=lm_wall,
                   lm_cholesky_rejections=int(getattr(ba, 'cholesky_rejections', 0)))
@@ -811,6 +830,9 @@ def main():
 
     # ---- timed region: K complete LM trials, continuing the LM schedule
     PHASE[0] = 'warm-up and timed trials'
+    # a timed step is a COMPLETE trial, nothing kept from the trial before: the library's reuse of the linearisation after a
+    # rejected trial (default on; it is what end_to_end_optimize_s and the untimed LM run above have) is switched off here
+    be.set_option('reuse_linearization', 0)
     one_trial, state = make_trial_runner(ba, be)
     if args.pmc_child:
         # the run rocprofv3 --pmc wraps (live_pmc_traffic): a few complete trials, nothing printed
@@ -1043,6 +1065,7 @@ def main():
         out.update(lm)
         if comm is None and not args.no_lm:
             # what a caller feels: BundleAdjuster.set_bundle + optimize(25 steps), the adjusted bundle back on the host
+            be.set_option('reuse_linearization', 1)
             torch.cuda.synchronize()
             t0 = time.time()
             ba.set_bundle(bundle, track_ids=track_ids)
@@ -1052,7 +1075,10 @@ def main():
             _ = ba.bundle
             torch.cuda.synchronize()
             out['end_to_end_optimize_s'] = time.time() - t0
-            out['end_to_end_parts_s'] = {'set_bundle': t1 - t0, 'optimize': t2 - t1, 'bundle_to_host': time.time() - t2, 'lm_trials': int(ba.lm_trials)}
+            out['end_to_end_parts_s'] = {'set_bundle': t1 - t0, 'optimize': t2 - t1, 'bundle_to_host': time.time() - t2, 'lm_trials': int(ba.lm_trials),
+                                         'linearizations_reused': be.problem_info().get('linearizations_reused'),
+                                         'note': 'library defaults: a trial that follows a rejected one reuses the linearisation of the unchanged current set '
+                                                 '(the timed steps above do not: option reuse_linearization = 0 there)'}
         plain3 = (args.config == 3 and args.cams is None and args.pts_per_gpu is None and args.track_len == 10 and not args.option
                   and not args.drop_observations and not args.shuffle_points and not args.shuffle_cameras and not args.loop_closures and args.sensor is None and args.outliers is None and not args.long_tracks)
         if ngpus == 1 and comm is None and plain3 and not args.no_other_configs:

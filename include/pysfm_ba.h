@@ -88,6 +88,8 @@ int ba_synchronize(ba_handle* h);
  *   "gm_chunk"      n                                      groups per workgroup of the MFMA reductions (0 = automatic: 4, or 8 over several rounds)
  *   "camera_order"  auto | off | always                    internal order of the optimised cameras (see ba_set_problem): auto = when the
  *                                                          caller's order is not provably as narrow as an order can be
+ *   "reuse_linearization" 1 | 0                            ba_lm_trial after a rejected trial does not form the point blocks of the unchanged
+ *                                                          current set again (default 1; 0: every trial linearises, as the reference does)
  *   "border"        1 | 0                                  band + border layouts of the reduced system (see ba_set_problem; default 1)
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
  * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap", "gm_chunk") take effect at
@@ -148,6 +150,7 @@ enum {
   BA_INFO_CAMERAS_PERMUTED,    /* 1: the library ordered the optimised cameras itself (see ba_set_problem)                */
   BA_INFO_CALLER_HALF_BANDWIDTH, /* the half-bandwidth the caller's camera order would have had                         */
   BA_INFO_BORDER_CAMERAS,      /* cameras in the border of the reduced system (band + border, see ba_set_problem)          */
+  BA_INFO_LINEARIZATIONS_REUSED, /* trials of ba_lm_trial since ba_set_problem that reused the linearisation of an unchanged current set */
   BA_INFO_COUNT
 };
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);

@@ -67,6 +67,7 @@ struct Options {
   bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
   int resident_scatter_min = 5;    // ... whose launches of at least this many workgroups add their partial sums up in slices (two stages)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
+  bool reuse_linearization = true; // ba_lm_trial after a rejected trial: the point blocks of the unchanged current set are not formed again
   bool border = true;              // ... and a border for the cameras at the far end of a few long-range tracks (ba_border.h)
   int camera_order = 0;            // internal order of the optimised cameras (ba_order.hip): 0 auto (when the caller's is not provably as narrow as it can be), 1 off, 2 always try
 };
@@ -97,6 +98,7 @@ struct ba_handle {
   bool have_params[2] = {false, false};
   bool have_linearization = false, have_schur = false, have_backsub = false;
   int lin_phys = 0;                  // physical parameter set of the linearisation
+  long long lin_reused = 0;          // trials that found the linearisation of the current set still valid (ba_lm_trial_begin)
   bool point_blocks_valid = false;   // HPP / bP hold the point blocks of the linearisation (ba_lm_trial leaves them to the reduction too)
   bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
   bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)

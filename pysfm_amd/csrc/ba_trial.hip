@@ -17,7 +17,14 @@ int ba_lm_trial_begin(ba_handle* h, double damping, double pinv_rcond) {
   // the observations and a separate k_camera_blocks is the cheaper way (tracks of 18 .. 40: 7 - 22 % of the trial)
   const int kern = pick_schur_kernel(h);
   const bool fuse = h->opt.schur == SCHUR_AUTO && h->opt.fuse_cam && kern_is_mfma(kern) && (kern != KERN_MFMA3 || h->gm3.nts <= 6);
-  int rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
+  // After a REJECTED trial the current set is what it was: its point blocks (and, where the reduction does not form them itself,
+  // its camera blocks) are still on the device - the reference recomputes identical blocks there (bundle_adjuster.py:132-140,
+  // SURVEY 3.1).  Everything that writes the current set or changes the model clears have_linearization.
+  const bool reuse = h->opt.reuse_linearization && h->have_linearization && h->lin_phys == h->phys(BA_PARAMS_CUR) && h->point_blocks_valid &&
+                     (fuse || h->cam_blocks_valid);
+  int rc = BA_OK;
+  if (reuse) { h->have_schur = h->have_backsub = false; ++h->lin_reused; }
+  else rc = linearize_impl(h, BA_PARAMS_CUR, 0, fuse, damping, pinv_rcond);
   if (rc == BA_OK) rc = ba_schur(h, BA_PARAMS_CUR, damping, pinv_rcond);
   h->defer = false;
   h->trial_rcond = pinv_rcond;

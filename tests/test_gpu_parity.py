@@ -34,7 +34,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1,
-                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1)
+                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1, reuse_linearization=1)
 
 
 @pytest.fixture(autouse=True)
