@@ -254,11 +254,12 @@ def free_port():
     return port
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU."""
+def spawn_ranks(n, one_gpu=False):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU (one_gpu: all of them on GPU 0,
+    --ranks-on-one-gpu)."""
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not one_gpu:
         sys.stderr.write('bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to run fewer ranks than asked for\n' % (n, have))
         sys.exit(2)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
@@ -654,6 +655,10 @@ def main():
     ap.add_argument('--outliers', type=float, default=None)
     ap.add_argument('--windows', type=int, default=5, help='extra timed windows of --steps trials after the headline one (min / median)')
     ap.add_argument('--force-comm', action='store_true', help='run the sharded path with a one-rank RCCL group on one GPU')
+    ap.add_argument('--ranks-on-one-gpu', action='store_true',
+                    help='N > 1 without N GPUs: every rank on GPU 0, a gloo process group, the collectives through torch.distributed (staged through the '
+                         'host).  NOT a scaling measurement - it exercises the rank code of this file end to end (spawn, rendezvous, sharding, the band width '
+                         'agreed over the ranks, the distributed solve, the watchdog, the JSON line); `value` then says what one GPU does with N processes on it')
     ap.add_argument('--collectives', default='library', choices=['library', 'torch'])
     ap.add_argument('--distributed-solve', default='auto', choices=['auto', 'on', 'off'],
                     help='N > 1: spread the reduced camera solve over the ranks (three small sums per trial) instead of summing the whole '
@@ -679,10 +684,12 @@ def main():
     PMC_WORKLOAD = ('config3' if args.config == 3 else 'config%d' % args.config) if plain and args.gpus == 1 and args.sensor is None and args.outliers is None else 'none'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        spawn_ranks(args.gpus)                      # does not return
+        spawn_ranks(args.gpus, args.ranks_on_one_gpu)      # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.ranks_on_one_gpu:
+        local_rank = 0
     if world != args.gpus:
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
         sys.exit(2)
@@ -720,10 +727,14 @@ def main():
             os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local_rank)
         PHASE[0] = 'torch.distributed.init_process_group(nccl)'
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.ranks_on_one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         from pysfm_amd.distributed import ShardComm, shard_tracks
         PHASE[0] = 'ShardComm: agreeing on the collectives (%s)' % args.collectives
-        comm = ShardComm(collectives=args.collectives)
+        comm = ShardComm(collectives='torch' if args.ranks_on_one_gpu else args.collectives)
+        comm.local_rank = local_rank
     ngpus = world
 
     # ---- scene (identical on every rank), then this rank's shard of the tracks
@@ -1018,7 +1029,9 @@ def main():
                                       (', cameras renumbered at random' if args.shuffle_cameras else '') +
                                       (', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * args.drop_observations) if args.drop_observations else '')),
                        'cameras': nc, 'points': nt, 'observations': nobs_total, 'track_len': args.track_len,
-                       'init_mode': init_mode, 'shuffled': bool(args.shuffle_points), 'parallelism': 'points sharded x%d' % ngpus,
+                       'init_mode': init_mode, 'shuffled': bool(args.shuffle_points),
+                       'parallelism': 'points sharded x%d' % ngpus + (' (ALL RANKS ON ONE GPU, gloo: a functional run of the rank code, not a scaling measurement)' if args.ranks_on_one_gpu else ''),
+                       'ranks_on_one_gpu': bool(args.ranks_on_one_gpu),
                        'library_options': args.option or None,
                        'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False)
                                                                  else 'torch.distributed (RCCL): ' + str(getattr(comm, 'direct_fallback_reason', None))),
