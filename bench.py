@@ -1023,7 +1023,7 @@ def main():
                                    % (args.config - 1, '' if (args.cams is None and args.pts_per_gpu is None and args.track_len == 10) else ' (modified by flags)',
                                       nc, nt, nobs_total, args.track_len,
                                       ' (%s scaling: %d points / %d obs on this GPU)' % ('strong' if strong else 'weak', be.nt, nobs_local) if ngpus > 1 else '',
-                                      '+RCCL all-reduce' if comm is not None else '', sensor_name,
+                                      ('+gloo all-reduce' if args.ranks_on_one_gpu else '+RCCL all-reduce') if comm is not None else '', sensor_name,
                                       ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
                                       (', tracks and observations handed over in random order' if args.shuffle_points else '') +
                                       (', cameras renumbered at random' if args.shuffle_cameras else '') +
@@ -1034,7 +1034,7 @@ def main():
                        'ranks_on_one_gpu': bool(args.ranks_on_one_gpu),
                        'library_options': args.option or None,
                        'collectives': None if comm is None else ('RCCL inside the library (ba_comm_*)' if getattr(be, 'direct_comm', False)
-                                                                 else 'torch.distributed (RCCL): ' + str(getattr(comm, 'direct_fallback_reason', None))),
+                                                                 else 'torch.distributed (%s): ' % ('gloo, staged through the host' if args.ranks_on_one_gpu else 'RCCL') + str(getattr(comm, 'direct_fallback_reason', None))),
                        'reduced_solve': None if comm is None else (
                            'spread over the ranks: %(cams_per_node)d cameras per node, %(nodes)d nodes, %(nodes_per_rank)d per rank, %(separators)d separators '
                            'eliminated by every rank; three sums per trial (shared band rows, separators + subtree roots, solution)' % be._dist_info
