@@ -356,12 +356,19 @@ __device__ __forceinline__ double lds_sum_in_order(const double* p, int L) {
   }
   return sum;
 }
+// Row length of the per-value LDS rows: lane (slot, oi) adds up value c = oi of its point from row c, so the lanes of a point read
+// nine rows at the same offset - with rows of 64 doubles (512 bytes) all nine fall on the same banks (SQ_LDS_BANK_CONFLICT: 74 % of the
+// kernel's LDS-active cycles, profiles/r05a_sq_counters.csv).  65: the rows two banks apart - measured 0.5 us of the lineariser's 20, within the noise
+// of the trial (an LDS pass of nine values is a small part of a kernel that linearises 60 observations per wavefront and batch).
+#ifndef BA_LIN_ROW
+#define BA_LIN_ROW 65
+#endif
 __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const double* __restrict__ cams,
                                                              const double* __restrict__ X,
                                                              const SchurGroup* __restrict__ groups, int ngroups,
                                                              double* __restrict__ HCC, double* __restrict__ bC,
                                                              double* __restrict__ HPP, double* __restrict__ bP) {
-  __shared__ double sx[kBlock / kWave][9][64];
+  __shared__ double sx[kBlock / kWave][9][BA_LIN_ROW];
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (HCC) {                                           // as k_linearize: the camera-block kernels accumulate with atomics
     const long long nthreads = (long long)gridDim.x * kBlock;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
   const int n0 = P.pt_off[gr.pt_begin] + oi;
   double cm[12];
   load_cam(cams, P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]], cm);
-  double (*mx)[64] = sx[wv];
+  double (*mx)[BA_LIN_ROW] = sx[wv];
   for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
     const int k = kb + slot;
     const bool live = stager && k < gr.pt_end;
@@ -412,6 +419,9 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
 // point hold its observations and the old camera; the updated camera R exp(sign dC), t + sign dt is
 // formed once per group per lane, the updated point comes from the point's first lane through LDS.
 // Partials and status words go where k_cost puts them (one partial per workgroup, <= kCostBlocks).
+#ifndef BA_BS_ROW
+#define BA_BS_ROW 65
+#endif
 #ifndef BA_BACKSUB_WAVES
 #define BA_BACKSUB_WAVES 3      // 168 VGPRs, 12 bytes of scratch per lane; with the next batch's inputs in flight: 27.5 us at config 3 (4 waves: 164 bytes of scratch per lane, 45 us; 2 waves: 35 us; without the prefetch 4 waves were best: 31.2 us)
 #endif
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
                                                            const int* __restrict__ singular_points,
                                                            const int* __restrict__ solve_info, HostResult* __restrict__ host,
                                                            double* __restrict__ dev_result) {
-  __shared__ double sx[kBlock / kWave][3][64], sw[kBlock / kWave][3][64], wsum[kBlock / kWave];
+  __shared__ double sx[kBlock / kWave][3][BA_BS_ROW], sw[kBlock / kWave][3][BA_BS_ROW], wsum[kBlock / kWave];
   __shared__ double spx[kBlock / kWave][kGroupMaxPts][4];          // the group's updated points (x, y, z, optimised?) for the cost pass
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (cams_dst) {                                      // fused update_motion, as in k_backsub
@@ -450,8 +460,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
     }
   }
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  double (*mx)[64] = sx[wv];
-  double (*mw)[64] = sw[wv];
+  double (*mx)[BA_BS_ROW] = sx[wv];
+  double (*mw)[BA_BS_ROW] = sw[wv];
   const bool want_cost = host != nullptr && X_dst != nullptr;
   double cost_acc = 0.0;
   for (int g = blockIdx.x * (kBlock / kWave) + wv; g < ngroups; g += gridDim.x * (kBlock / kWave)) {   // wave-uniform
