@@ -116,9 +116,43 @@ int border_setup(ba_handle* h) {
   return BA_OK;
 }
 
-// C, D and the border part of b: one wavefront per block, every block written once (ba_border.h)
+int border_join(ba_handle* h) {
+  if (!h->bord_pending) return BA_OK;
+  HIPCHECK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  h->bord_pending = false;
+  return BA_OK;
+}
+
+namespace {
+// launches of the scope go to the side stream (the launch helpers and timers all use h->stream)
+struct OnSideStream {
+  ba_handle* h; hipStream_t keep;
+  explicit OnSideStream(ba_handle* h_) : h(h_), keep(h_->stream) { h->stream = h->side; }
+  ~OnSideStream() { h->stream = keep; }
+};
+int side_fork(ba_handle* h) {
+  if (!h->side) {
+    HIPCHECK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIPCHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  HIPCHECK(h, hipEventRecord(h->ev_fork, h->stream));          // everything enqueued so far (the point inverses; the consumers of the last trial's C, D) ...
+  HIPCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));     // ... comes before what the side stream does next
+  return BA_OK;
+}
+int side_mark(ba_handle* h) {
+  HIPCHECK(h, hipEventRecord(h->ev_join, h->side));
+  h->bord_pending = true;
+  return BA_OK;
+}
+}  // namespace
+
+// C, D and the border part of b: one wavefront per chunk of a block's pairs, every block written once (ba_border.h) - on the side
+// stream: nothing of the band is read or written (the band's right-hand side ends at the band cameras)
 int border_schur(ba_handle* h, int p, double damping) {
   if (h->nbc <= 0) return BA_OK;
+  if (int rc = side_fork(h); rc != BA_OK) return rc;
+  OnSideStream on_side(h);
   const int n1 = h->band_cams(), ld = h->bord_ld, nblocks = h->nbord_obs;
   ScopedTimer tm(h, BA_K_BORDER_SCHUR, 2);
   if (nblocks > 0) {
@@ -137,7 +171,7 @@ int border_schur(ba_handle* h, int p, double damping) {
                        h->bord_partial.p, n1, h->bordC.p, h->bordD.p, ld, h->b + (size_t)6 * n1);
   }
   HIPCHECK(h, hipGetLastError());
-  return BA_OK;
+  return side_mark(h);
 }
 
 // After solve_bcr (the factors of B in bcrP / bcrQ / bcrG, y = B^-1 b1 in dC): the columns of C through the same tree, the border
@@ -146,9 +180,19 @@ int border_solve(ba_handle* h, const unsigned char* dmask) {
   if (h->nbc <= 0) return BA_OK;
   const int n1 = h->band_cams(), cb = bcr_cams_per_node(h), B = 6 * cb, N = (n1 + cb - 1) / cb;
   const int ld = h->bord_ld, nb = 6 * h->nbc, rows1 = 6 * n1;
+  if (h->bord_pending) {
+    // the copy of C into the work array and the start of M, rv need C, D, b2 and the mask, nothing of the band's solve: still on the side stream
+    OnSideStream on_side(h);
+    if (dmask) { HIPCHECK(h, hipEventRecord(h->ev_fork, on_side.keep)); HIPCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0)); }      // (the mask's upload is on the main stream)
+    hipLaunchKernelGGL(k_border_prepare, dim3(blocks_for((long long)h->bord_rows * ld + (long long)nb * nb)), dim3(kBlock), 0, h->stream, (long long)h->bord_rows, rows1,
+                       ld, nb, h->bordC.p, h->bordD.p, h->b + (size_t)rows1, dmask, h->bordF.p, bord_M(h), bord_rv(h), bord_info(h));
+    if (int rc = side_mark(h); rc != BA_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(k_border_prepare, dim3(blocks_for((long long)h->bord_rows * ld + (long long)nb * nb)), dim3(kBlock), 0, h->stream, (long long)h->bord_rows, rows1,
+                       ld, nb, h->bordC.p, h->bordD.p, h->b + (size_t)rows1, dmask, h->bordF.p, bord_M(h), bord_rv(h), bord_info(h));
+  }
+  if (int rc = border_join(h); rc != BA_OK) return rc;
   ScopedTimer tm(h, BA_K_BORDER_SOLVE, 1);
-  hipLaunchKernelGGL(k_border_prepare, dim3(blocks_for((long long)h->bord_rows * ld + (long long)nb * nb)), dim3(kBlock), 0, h->stream, (long long)h->bord_rows, rows1,
-                     ld, nb, h->bordC.p, h->bordD.p, h->b + (size_t)rows1, dmask, h->bordF.p, bord_M(h), bord_rv(h), bord_info(h));
   int rc = BA_OK;
   switch ((B + 15) / 16) {
     case 1: rc = launch_apply_levels<1>(h, N, B, ld); break;
@@ -179,6 +223,7 @@ int border_solve(ba_handle* h, const unsigned char* dmask) {
 }
 
 int border_get_dense(ba_handle* h, std::vector<double>& C, std::vector<double>& D) {
+  if (int rc = border_join(h); rc != BA_OK) return rc;
   const size_t ld = h->bord_ld, rows1 = (size_t)6 * h->band_cams();
   C.resize(rows1 * ld); D.resize(ld * ld);
   if (rows1) HIPCHECK(h, hipMemcpyAsync(C.data(), h->bordC.p, C.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -188,6 +233,7 @@ int border_get_dense(ba_handle* h, std::vector<double>& C, std::vector<double>& 
 }
 
 int border_flatten(ba_handle* h, int nkeep, double* A_dev, double* rhs_dev) {
+  if (int rc = border_join(h); rc != BA_OK) return rc;
   ScopedTimer tm(h, BA_K_FLATTEN);
   hipLaunchKernelGGL(k_flatten_bordered, dim3(blocks_for((long long)nkeep * nkeep)), dim3(kBlock), 0, h->stream, h->band_cams(), h->hb, nkeep, h->keep.p, h->S,
                      h->b, h->bordC.p, h->bordD.p, h->bord_ld, A_dev, rhs_dev);

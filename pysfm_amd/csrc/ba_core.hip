@@ -238,6 +238,9 @@ int ba_destroy(ba_handle* h) {
   if (h->res_trace) (void)hipHostFree(h->res_trace);
   h->res_xb.release(); h->res_epoch.release(); h->res_cost.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
   return BA_OK;
 }
@@ -249,7 +252,7 @@ int ba_debug_poison(ba_handle* h) {
   hipLaunchKernelGGL(k_poison_lds, dim3(8 * h->ncu), dim3(1024), 160 * 1024, h->stream, 160 * 1024 / 8);
   DevBuf<double>* bufs[] = {&h->HCC, &h->bC, &h->HPP, &h->bP, &h->HPPinv, &h->W, &h->dC, &h->dP, &h->scratch, &h->Ufac, &h->ysol, &h->dinv,
                             &h->bcrD, &h->bcrU, &h->bcrF, &h->bcrP, &h->bcrQ, &h->bcrG, &h->bcrGv, &h->bcrL, &h->bcrLv, &h->denseA, &h->bigK, &h->fac,
-                            &h->dUd, &h->dDd, &h->dyd, &h->dpart, &h->cams[1 - h->cur], &h->X[1 - h->cur]};
+                            &h->dUd, &h->dDd, &h->dyd, &h->dpart, &h->cams[1 - h->cur], &h->X[1 - h->cur], &h->bordF, &h->bord_partial};
   for (DevBuf<double>* b : bufs)
     if (b->p && b->n) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, h->stream, b->p, b->n);
   if (h->bcr_done.p && h->bcr_done.n >= 2)          // the "handed on" words of k_bcr_eliminate_fused: garbage that reads as "done" unless k_bcr_assemble clears it

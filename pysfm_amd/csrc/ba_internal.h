@@ -173,6 +173,12 @@ struct ba_handle {
   int bord_nchunks = 0, bord_nrcams = 0;      // chunks of the blocks' pairs (one wavefront each); band cameras that have a block in C
   size_t bord_off_chunks = 0, bord_off_first = 0, bord_off_rcams = 0, bord_off_pairs = 0;      // where they sit in bord_obs (ints)
   DevBuf<double> bord_partial;         // the chunks' partial sums
+  // The border's blocks need the point inverses and nothing of the band: they are formed on a SIDE stream beside the band's
+  // reduction and the cyclic reduction (which leaves two thirds of the compute units idle) and join the main stream before the
+  // first kernel that reads them (border_join).
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool bord_pending = false;           // work on the side stream that the main stream has not waited for yet
   DevBuf<double> bordC, bordF, bordD;  // C (as the reduction leaves it), F (work: C -> Y), [D | M | rv | x2]
   int band_cams() const { return nco - nbc; }
   std::vector<unsigned char> mask_host; // the mask of the last solve in the internal order (outlives its asynchronous upload)
@@ -340,6 +346,7 @@ inline void cam_rows_out(const ba_handle* h, T* data, int w) {
 int border_setup(ba_handle* h);                                  // after the problem is set: the border cameras' observations, buffers
 int border_schur(ba_handle* h, int p, double damping);            // the blocks of the border cameras (C, D, the border part of b)
 int border_solve(ba_handle* h, const unsigned char* dmask);       // after the band solve: Y = B^-1 C, the border system, the correction of dC
+int border_join(ba_handle* h);                                     // the main stream waits for the side stream's border kernels
 int border_get_dense(ba_handle* h, std::vector<double>& C, std::vector<double>& D);      // host copies of C [6 n1][ld], D [ld][ld]
 int border_flatten(ba_handle* h, int nkeep, double* A_dev, double* rhs_dev);              // ba_flatten_reduced with a border (h->keep holds the indices)
 // Which cameras go to a border so that the others fit a band of half-width <= t: is_border[p] by position in the order given

@@ -208,6 +208,7 @@ int ba_get_reduced(ba_handle* h, double* S, double* b) {
   REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_get_reduced: call ba_schur first");
   HIPCHECK(h, hipSetDevice(h->device));
   const int nco = h->nco, hb1 = h->hb + 1;
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;      // (the border part of b comes from the side stream)
   std::vector<double> band(S ? reduced_doubles(h) : 0);
   if (S && nco) HIPCHECK(h, hipMemcpyAsync(band.data(), h->S, band.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (b && nco) HIPCHECK(h, hipMemcpyAsync(b, h->b, (size_t)nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -272,6 +273,7 @@ int ba_get_point_inverses(ba_handle* h, double* out) {
 
 int ba_reduced_device_ptrs(ba_handle* h, void** S_blocks, void** b) {
   if (!h) return BA_ERR_INVALID_ARG;
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;
   REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_reduced_device_ptrs: call ba_set_problem first");
   HIPCHECK(h, hipSetDevice(h->device));
   int rc = ensure_reduced(h);
