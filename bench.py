@@ -367,6 +367,7 @@ OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config3_shuffled', 3, 'gaussian', 0., True, 0.),
     ('config3_cameras_renumbered', 3, 'gaussian', 0., False, 0., 10, None, 'cameras'),      # the cameras in random order: the library finds the band itself
     ('config3_10_loop_closure_tracks', 3, 'gaussian', 0., False, 0., 10, None, 'loops'),      # camera i and camera i + 500 see the same point, ten times: band + border
+    ('config3_cameras_renumbered_10_loop_closure_tracks', 3, 'gaussian', 0., False, 0., 10, None, 'loops+cameras'),      # both at once: the ordering leaves the weak ties out, the border takes them
     ('config3_30pct_dropped', 3, 'gaussian', 0., False, .3),
     ('config3_2pct_tracks_of_80_cameras', 3, 'gaussian', 0., False, 0., 10, (50, 80)),      # a few long tracks: pairs of 32-camera segments on the matrix cores, half-bandwidth 79
     ('config5_one_gpu', 5, 'gaussian', 0., False, 0.),
@@ -395,11 +396,11 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
             scene_cache[key] = s
     if long_tracks:                                 # (every, length): every `every`-th point seen by `length` consecutive cameras
         s = with_long_tracks(s, nc, nt, track_len, long_tracks[0], long_tracks[1])
-    if variant == 'cameras':
-        s = with_cameras_renumbered(s)
-    if variant == 'loops':
+    if variant in ('loops', 'loops+cameras'):
         s = with_loop_closures(s)
         nt = len(s['X0'])
+    if variant in ('cameras', 'loops+cameras'):
+        s = with_cameras_renumbered(s)
     obs_cam, obs_pt, obs_z, X0 = scene_variant(s, track_len, shuffle, drop)
     model = {'gaussian': sensor_model.GaussianModel(1.), 'cauchy': sensor_model.CauchyModel(.05),
              'huber': sensor_model.HuberModel(.06)}[sensor_name]
@@ -435,7 +436,7 @@ def quick_config(device, label, cfg_id, sensor_name, outliers, shuffle, drop, tr
     info = be.problem_info()
     out = {'workload': 'BASELINE configs[%d]%s: %d cameras / %d points / %d observations, %s sensor model%s%s%s' % (
                cfg_id - 1, ('' if track_len == 10 else ' with track length %d' % track_len) + ('' if not long_tracks else ' and every %d-th point seen by %d cameras' % tuple(long_tracks)), nc, nt, nobs, sensor_name, ' + %.0f %% gross outliers' % (100 * outliers) if outliers else '',
-               (', tracks and observations in random order' if shuffle else '') + (', cameras renumbered at random' if variant == 'cameras' else '') + (', plus 10 loop-closure tracks (camera i and camera i + half the sequence)' if variant == 'loops' else ''),
+               (', tracks and observations in random order' if shuffle else '') + (', cameras renumbered at random' if variant in ('cameras', 'loops+cameras') else '') + (', plus 10 loop-closure tracks (camera i and camera i + half the sequence)' if variant in ('loops', 'loops+cameras') else ''),
                ', %.0f %% of the observations dropped at random (ragged tracks)' % (100 * drop) if drop else ''),
            'init_mode': init_mode, 'steps': steps, 'warmup': warmup + 1, 'ms_per_step': 1e3 * dt / steps, 'obs_per_s': nobs * steps / dt,
            'dominant_kernel': None if dom is None else KERNEL_NAMES.get(dom, 'k_' + dom), 'dominant_kernel_ms_per_step': None if dom is None else kms[dom],

@@ -160,6 +160,13 @@ int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);
  * new_pos[p] = the position Cuthill-McKee on the co-visibility hypergraph gives the caller's position p (a permutation of
  * 0 .. nco - 1); *half_bandwidth = the widest spread of new positions inside a list (either output may be NULL). */
 int ba_order_cameras(int32_t nco, int32_t nlists, const int32_t* list_off, const int32_t* list_pos, int32_t* new_pos, int32_t* half_bandwidth);
+/* ... and the whole layout decision of ba_set_problem as a pure function: the candidates {caller's order, Cuthill-McKee, Cuthill-McKee
+ * without the few single-point lists that tie far-apart cameras} x {as it is, with a border of at most 21 cameras that brings the
+ * band down to <= 11} ranked by a model of their solve cost.  list_points[l] = points that have list l (NULL: not known).
+ * new_pos[p]: final position of the caller's position p - positions >= *band_cameras are border cameras; *half_bandwidth: the
+ * band's.  The caller's order comes back unchanged (band_cameras = nco) when nothing beats it. */
+int ba_plan_camera_layout(int32_t nco, int32_t nlists, const int32_t* list_off, const int32_t* list_pos, const int32_t* list_points,
+                          int32_t allow_border, int32_t* new_pos, int32_t* band_cameras, int32_t* half_bandwidth);
 
 /* ---- multi-GPU: the shards' collectives inside the library (one all-reduce of the reduced camera
  * system per linearisation, plus the 16 KB trial record), issued with RCCL on the handle's OWN stream - no

@@ -351,6 +351,8 @@ int border_get_dense(ba_handle* h, std::vector<double>& C, std::vector<double>& 
 int border_flatten(ba_handle* h, int nkeep, double* A_dev, double* rhs_dev);              // ba_flatten_reduced with a border (h->keep holds the indices)
 // Which cameras go to a border so that the others fit a band of half-width <= t: is_border[p] by position in the order given
 // (lists: distinct camera lists as positions in that order).  Returns their number, or -1 when more than kmax would be needed.
+bool plan_camera_layout(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, const std::vector<int>& lmult, bool allow_border,
+                        std::vector<int>& newpos, int* n1_out, int* hb_out);
 int choose_border(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, int t, int kmax, std::vector<char>& is_border);
 
 // ---- ba_order.hip: Cuthill-McKee on the co-visibility hypergraph

@@ -153,7 +153,114 @@ int choose_border(int nco, const std::vector<int>& loff, const std::vector<int>&
   return k;
 }
 
+// What a solve of the reduced system costs, in microseconds, by the shape the layout gives it (measured on config-3-sized scenes:
+// profiles/r04b_sweep.json, r04e_kernel_choice_probe.txt, r05a_*) - only good enough to rank the candidates of plan_camera_layout.
+double layout_cost_us(int hb, int nco, int border_cams) {
+  const double scale = std::max(1.0, nco / 1000.0);
+  double t;
+  if (hb <= kBcrMaxHB) t = 100.0 * std::pow(std::max(hb, 3) / 9.0, 1.5) * std::max(1.0, std::log2(std::max(2.0, (double)nco / std::max(1, hb))) / 7.0);
+  else if (hb <= kBcrwMaxHB) t = (250.0 + 45.0 * (hb - kBcrMaxHB)) * scale;
+  else t = (800.0 + 14.0 * (hb - kBcrwMaxHB)) * scale;
+  if (border_cams > 0) t += 50.0 + 12.0 * border_cams * scale;
+  return t;
+}
+
+// The layout of nco optimised cameras (positions in the caller's order) from the distinct camera lists and the number of points
+// that have each: candidate ORDERS - the caller's, Cuthill-McKee on all lists, Cuthill-McKee on the lists that are not "weak ties"
+// (a few lists that a single point has: loop closures in a scene whose cameras also come in no particular order - with them the
+// breadth-first walk folds the loop into the band) - each as it is and, when its band is wider than the narrow cyclic
+// reduction takes, with a border (choose_border) for the half-widths 11 down to where it stops being feasible.  Ranked by
+// layout_cost_us.  Returns false when the caller's order without a border wins.  newpos[p] = final position of the caller's
+// position p: the band cameras first (n1 of them) in the winning order, the border cameras behind them.
+bool plan_camera_layout(int nco, const std::vector<int>& loff, const std::vector<int>& lpos, const std::vector<int>& lmult, bool allow_border,
+                        std::vector<int>& newpos, int* n1_out, int* hb_out) {
+  struct Cand { std::vector<int> pos; int hb; int k; std::vector<char> isb; double cost; };
+  std::vector<Cand> cands;
+  std::vector<int> ident((size_t)nco);
+  for (int p = 0; p < nco; ++p) ident[p] = p;
+  auto add = [&](const std::vector<int>& pos) {
+    std::vector<int> mapped(lpos.size());
+    for (size_t q = 0; q < lpos.size(); ++q) mapped[q] = pos[lpos[q]];
+    const int hb = order_half_bandwidth(loff, mapped, ident);
+    cands.push_back({pos, hb, 0, {}, layout_cost_us(hb, nco, 0)});
+    // ... with a border: only where it brings the band down to what the narrow cyclic reduction takes
+    if (hb > kBcrMaxHB && allow_border && nco >= 4 * kBcrMaxHB) {
+      for (int t = kBcrMaxHB; t >= 1; --t) {
+        std::vector<char> isb;                          // by position in this candidate's order
+        const int k = choose_border(nco, loff, mapped, t, kBordMaxCamsHost, isb);
+        if (k <= 0) break;                              // (narrower only ever needs more border cameras)
+        cands.push_back({pos, t, k, isb, layout_cost_us(t, nco - k, k)});
+      }
+    }
+  };
+  add(ident);
+  std::vector<int> cm;
+  cuthill_mckee_order(nco, loff, lpos, cm);
+  add(cm);
+  // without the weak ties: lists of a single point, when there are few of them (at most 64 and 5 % of the lists)
+  const int nl = (int)loff.size() - 1;
+  if (allow_border && (int)lmult.size() == nl && cands.back().hb > kBcrMaxHB) {
+    int weak = 0;
+    for (int l = 0; l < nl; ++l) weak += lmult[l] <= 1 ? 1 : 0;
+    if (weak > 0 && weak <= 64 && 20 * weak <= nl) {
+      std::vector<int> soff(1, 0), spos;
+      for (int l = 0; l < nl; ++l) {
+        if (lmult[l] <= 1) continue;
+        spos.insert(spos.end(), lpos.begin() + loff[l], lpos.begin() + loff[l + 1]);
+        soff.push_back((int)spos.size());
+      }
+      std::vector<int> cm2;
+      cuthill_mckee_order(nco, soff, spos, cm2);
+      add(cm2);
+    }
+  }
+  size_t best = 0;
+  for (size_t c = 1; c < cands.size(); ++c)
+    if (cands[c].cost < cands[best].cost * (1.0 - 1e-9)) best = c;
+  if (best == 0) return false;
+  const Cand& B = cands[best];
+  std::vector<int> inv((size_t)nco);
+  for (int p = 0; p < nco; ++p) inv[B.pos[p]] = p;        // position in the candidate's order -> caller's position
+  newpos.assign((size_t)nco, 0);
+  int nb_ = 0, nborder = 0;
+  const int n1 = nco - B.k;
+  for (int q = 0; q < nco; ++q) {
+    const bool isb = B.k > 0 && B.isb[q];
+    newpos[inv[q]] = isb ? n1 + nborder++ : nb_++;
+  }
+  *n1_out = n1;
+  *hb_out = B.hb;
+  return true;
+}
+
 }  // namespace ba
+
+extern "C" int ba_plan_camera_layout(int32_t nco, int32_t nlists, const int32_t* list_off, const int32_t* list_pos, const int32_t* list_points,
+                                     int32_t allow_border, int32_t* new_pos, int32_t* band_cameras, int32_t* half_bandwidth) {
+  if (nco < 0 || nlists < 0 || (nlists > 0 && (!list_off || !list_pos)) || !new_pos) return BA_ERR_INVALID_ARG;
+  std::vector<int> loff(1, 0), lpos, lmult;
+  for (int l = 0; l < nlists; ++l) {
+    if (list_off[l + 1] < list_off[l]) return BA_ERR_INVALID_ARG;
+    for (int k = list_off[l]; k < list_off[l + 1]; ++k) {
+      if (list_pos[k] < 0 || list_pos[k] >= nco) return BA_ERR_INVALID_ARG;
+      lpos.push_back(list_pos[k]);
+    }
+    loff.push_back((int)lpos.size());
+    lmult.push_back(list_points ? list_points[l] : 2);
+  }
+  std::vector<int> newpos;
+  int n1 = nco, hb = 0;
+  if (!ba::plan_camera_layout(nco, loff, lpos, lmult, allow_border != 0, newpos, &n1, &hb)) {
+    newpos.resize((size_t)nco);
+    for (int p = 0; p < nco; ++p) newpos[p] = p;
+    hb = ba::order_half_bandwidth(loff, lpos, newpos);
+    n1 = nco;
+  }
+  std::copy(newpos.begin(), newpos.end(), new_pos);
+  if (band_cameras) *band_cameras = n1;
+  if (half_bandwidth) *half_bandwidth = hb;
+  return BA_OK;
+}
 
 extern "C" int ba_order_cameras(int32_t nco, int32_t nlists, const int32_t* list_off, const int32_t* list_pos, int32_t* new_pos,
                                 int32_t* half_bandwidth) {

@@ -958,25 +958,13 @@ int set_problem_impl(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const i
   return BA_OK;
 }
 
-// What a solve of the reduced system costs, in microseconds, by the shape the layout gives it (measured on config-3-sized scenes:
-// profiles/r04b_sweep.json, r04e_kernel_choice_probe.txt) - only good enough to rank the candidates of choose_camera_layout.
-double layout_cost_us(int hb, int nco, int border_cams) {
-  const double scale = std::max(1.0, nco / 1000.0);
-  double t;
-  if (hb <= kBcrMaxHB) t = 100.0 * std::pow(std::max(hb, 3) / 9.0, 1.5) * std::max(1.0, std::log2(std::max(2.0, (double)nco / std::max(1, hb))) / 7.0);
-  else if (hb <= kBcrwMaxHB) t = (250.0 + 45.0 * (hb - kBcrMaxHB)) * scale;
-  else t = (800.0 + 14.0 * (hb - kBcrwMaxHB)) * scale;
-  if (border_cams > 0) t += 50.0 + 12.0 * border_cams * scale;
-  return t;
-}
-
 // The internal layout of the optimised cameras: their ORDER (ba_order.hip) and, for scenes that are a sequence plus a few
 // long-range tracks, a BORDER (ba_border.h).  The problem has been set up in the caller's order; when that order
 // is not provably as narrow as an order can be (a track of L optimised cameras spreads over at least L - 1 positions), the
 // distinct camera lists come back from the device and the candidates are ranked by what their solve would cost: the caller's
 // order and the Cuthill-McKee order, each as it is and - when its band is wider than the narrow cyclic reduction takes - with
-// the cameras that make it so moved to a border.  If anything beats the caller's order, the problem is set up again with the
-// cameras at their new positions.  Costs nothing for a scene that arrives in sequence order.
+// the cameras that make it so moved to a border (plan_camera_layout, ba_order.hip).  If anything beats the caller's order, the
+// problem is set up again with the cameras at their new positions.  Costs nothing for a scene that arrives in sequence order.
 int choose_camera_order(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int32_t* obs_cam, const int32_t* obs_pt,
                         const double* obs_z, const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
   const int nco = h->nco, hb0 = h->plan_flags[SF_HB];
@@ -997,50 +985,33 @@ int choose_camera_order(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, cons
     }
     if (lpos.size() - before >= 2) loff.push_back((int)lpos.size()); else lpos.resize(before);
   }
-  struct Cand { std::vector<int> pos; int hb; int k; std::vector<char> isb; double cost; };
-  std::vector<Cand> cands;
-  auto add = [&](const std::vector<int>& pos) {
-    std::vector<int> mapped(lpos.size());
-    for (size_t q = 0; q < lpos.size(); ++q) mapped[q] = pos[lpos[q]];
-    std::vector<int> ident((size_t)nco);
-    for (int p = 0; p < nco; ++p) ident[p] = p;
-    const int hb = order_half_bandwidth(loff, mapped, ident);
-    cands.push_back({pos, hb, 0, {}, layout_cost_us(hb, nco, 0)});
-    // ... with a border: only where it brings the band down to what the narrow cyclic reduction takes
-    if (hb > kBcrMaxHB && h->opt.border && nco >= 4 * kBcrMaxHB) {
-      for (int t = kBcrMaxHB; t >= 1; --t) {
-        std::vector<char> isb;                          // by position in this candidate's order
-        const int k = choose_border(nco, loff, mapped, t, kBordMaxCamsHost, isb);
-        if (k <= 0) break;                              // (narrower only ever needs more border cameras)
-        cands.push_back({pos, t, k, isb, layout_cost_us(t, nco - k, k)});
+  // ... and how many points have each of them (a list that ONE point has and that ties far-apart cameras is a loop closure)
+  std::vector<int> lmult;
+  {
+    int count = 0;
+    bool open = false;
+    for (int i = 0; i < nt; ++i) {
+      if (!(i > 0 && h->h_same[i])) {
+        if (open) lmult.push_back(count);
+        int nopt = 0;
+        for (int n = h->h_off[i]; n < h->h_off[(size_t)i + 1]; ++n) nopt += cam_opt_pos[hobs[n]] >= 0 ? 1 : 0;
+        open = nopt >= 2;
+        count = 0;
       }
+      ++count;
     }
-  };
-  std::vector<int> ident((size_t)nco), cm;
-  for (int p = 0; p < nco; ++p) ident[p] = p;
-  add(ident);
-  cuthill_mckee_order(nco, loff, lpos, cm);
-  add(cm);
-  size_t best = 0;
-  for (size_t c = 1; c < cands.size(); ++c)
-    if (cands[c].cost < cands[best].cost * (1.0 - 1e-9)) best = c;
-  if (best == 0) return BA_OK;
-  const Cand& B = cands[best];
-  // final positions: the band cameras in the candidate's order, the border cameras behind them
-  std::vector<int> newpos((size_t)nco), inv((size_t)nco);
-  for (int p = 0; p < nco; ++p) inv[B.pos[p]] = p;        // position in the candidate's order -> caller's position
-  int nb_ = 0, nborder = 0;
-  const int n1 = nco - B.k;
-  for (int q = 0; q < nco; ++q) {
-    const bool isb = B.k > 0 && B.isb[q];
-    newpos[inv[q]] = isb ? n1 + nborder++ : nb_++;
+    if (open) lmult.push_back(count);
   }
+  std::vector<int> newpos;
+  int n1 = nco, hb_planned = hb0;
+  if (!plan_camera_layout(nco, loff, lpos, lmult, h->opt.border, newpos, &n1, &hb_planned)) return BA_OK;      // the caller's order stays
+  const int k_border = nco - n1;
   std::vector<int32_t> cop((size_t)nc), cband((size_t)nc);
   for (int i = 0; i < nc; ++i) {
     cop[i] = cam_opt_pos[i] >= 0 ? newpos[cam_opt_pos[i]] : -1;
     cband[i] = cop[i] >= n1 ? -1 : cop[i];
   }
-  const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cop.data(), pt_opt, B.k > 0 ? cband.data() : nullptr, B.k);
+  const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cop.data(), pt_opt, k_border > 0 ? cband.data() : nullptr, k_border);
   if (rc != BA_OK) return rc;
   h->cpos_in = newpos;
   h->cpos_out.assign((size_t)nco, 0);

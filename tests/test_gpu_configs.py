@@ -990,8 +990,9 @@ def _loop_scene(nc, nt, L, pairs, width, **kw):
     return sd.add_loop_closure_tracks(banded(nc, nt, track_len=L, **kw), pairs, width=width)
 
 
-@pytest.mark.parametrize('sensor,L,width,npairs', [(O.Sensor.gaussian(1.), 10, 1, 6), (O.Sensor.cauchy(.05), 8, 3, 4), (O.Sensor.huber(.06), 6, 2, 9)])
-def test_loop_closure_tracks_band_plus_border_vs_oracle(be, sensor, L, width, npairs):
+@pytest.mark.parametrize('sensor,L,width,npairs,renumber', [(O.Sensor.gaussian(1.), 10, 1, 6, False), (O.Sensor.cauchy(.05), 8, 3, 4, False),
+                                                            (O.Sensor.huber(.06), 6, 2, 9, False), (O.Sensor.gaussian(1.), 9, 1, 7, True)])
+def test_loop_closure_tracks_band_plus_border_vs_oracle(be, sensor, L, width, npairs, renumber):
     """A camera sequence plus a few tracks that tie far-apart cameras together: the reference's dense S takes them like any
     other track (bundle_adjuster.py:259-312); here the cameras at their far end become a border of the band (csrc/ba_border.h).
     Everything that crosses the C ABI - S (band, border columns and border block expanded), b, the solution with and without
@@ -1001,6 +1002,16 @@ def test_loop_closure_tracks_band_plus_border_vs_oracle(be, sensor, L, width, np
     pairs = [(int(i), int(i) + 60 + int(rs.randint(0, 30))) for i in rs.choice(60, npairs, replace=False) + 2]
     s = _loop_scene(nc, nt, L, pairs, width, outlier_frac=.02)
     nt = len(s['X0'])
+    perm = np.arange(nc)
+    if renumber:                                         # ... and the cameras in no particular order (camera 0 stays the gauge camera)
+        s, perm = cameras_renumbered(s)
+        first = int(perm[0])
+        swap = perm.copy(); swap[perm == 0] = first; swap[0] = 0
+        for k in ('R0', 't0', 'R', 't'):
+            s[k][[0, first]] = s[k][[first, 0]]
+        oc = s['obs_cam'].copy(); s['obs_cam'][oc == 0] = first; s['obs_cam'][oc == first] = 0
+        perm = swap
+        pairs = [(int(perm[a]), int(perm[b])) for a, b in pairs]
     cam_opt_pos = np.arange(nc, dtype=np.int32) - 1
     pt_opt = np.ones(nt, np.uint8)
     pt_opt[::11] = 0
@@ -1008,13 +1019,14 @@ def test_loop_closure_tracks_band_plus_border_vs_oracle(be, sensor, L, width, np
     load_problem(be, *a, cam_opt_pos, pt_opt, sensor)
     info = be.problem_info()
     assert 0 < info['border_cameras'] <= npairs * width and info['half_bandwidth'] <= 11 and info['caller_half_bandwidth'] >= 60, info
+    assert info['cameras_permuted'] == 1
     nco = be.nco
     close(be.cost(0), O.cost(sensor, *a, cam_opt_pos, pt_opt), 1e-12)
     mask = (rs.rand(nco * 6) > .04).astype(np.uint8)
     # mask a parameter of a border camera and one of a camera it shares a track with, whatever the draw
-    far = pairs[0][1] - 1
+    far = max(pairs[0][1] - 1, 0)
     mask[6 * far + 2] = 0
-    mask[6 * (pairs[0][0] - 1) + 4] = 0
+    mask[6 * max(pairs[0][0] - 1, 0) + 4] = 0
     for m in (None, mask):
         mu, su, parts = O.compute_update(sensor, *a, cam_opt_pos, pt_opt, damping=1.5, cam_param_mask=None if m is None else m.astype(bool), return_parts=True)
         be.linearize(0)

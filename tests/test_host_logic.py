@@ -909,3 +909,72 @@ def test_camera_order_components_and_unseen_cameras():
     assert new.tolist() == [0, 1, 2, 3, 4] and hb == 0
     new, hb = _order_cameras(1, [[0]])
     assert new.tolist() == [0] and hb == 0
+
+
+def _plan_layout(nco, lists, points=None, allow_border=True):
+    import ctypes as C
+    from pysfm_amd import _capi as capi
+    lib = capi.load()
+    off = np.zeros(len(lists) + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    pos = np.concatenate([np.asarray(l, np.int32) for l in lists]).astype(np.int32)
+    pts = None if points is None else np.asarray(points, np.int32)
+    new = np.empty(nco, np.int32)
+    n1, hb = C.c_int32(), C.c_int32()
+    rc = lib.ba_plan_camera_layout(nco, len(lists), capi.iptr(off), capi.iptr(pos), capi.iptr(pts), int(allow_border), capi.iptr(new),
+                                   C.cast(C.byref(n1), capi._ip), C.cast(C.byref(hb), capi._ip))
+    assert rc == capi.BA_OK and sorted(new.tolist()) == list(range(nco))
+    # the band the layout leaves: the spread of the band cameras of every list
+    band = 0
+    for l in lists:
+        p = new[np.asarray(l)]
+        p = p[p < n1.value]
+        if len(p):
+            band = max(band, int(p.max() - p.min()))
+    assert band <= hb.value
+    return new, n1.value, hb.value
+
+
+def _sequence_lists(nco, L, per_list, rs):
+    lists, pts = [], []
+    for c0 in range(0, nco - L + 1):
+        lists.append(np.arange(c0, c0 + L))
+        pts.append(per_list)
+    return lists, pts
+
+
+@pytest.mark.parametrize('shuffle', [False, True])
+def test_camera_layout_puts_loop_closures_into_a_border(shuffle):
+    """A sequence of 400 cameras (tracks of 10, a hundred points a camera list) plus 8 single-point tracks that tie camera i to camera
+    i + 200: the far ends become the border, the band of the others is the sequence's own - also when the cameras come in no
+    particular order (the weak ties are left out of the ordering, or the breadth-first walk folds the loop into the band)."""
+    rs = np.random.RandomState(3)
+    nco, L = 400, 10
+    lists, pts = _sequence_lists(nco, L, 100, rs)
+    ties = [(int(i), int(i) + 200) for i in rs.choice(150, 8, replace=False) + 5]
+    for a, b in ties:
+        lists.append(np.array([a, b])); pts.append(1)
+    perm = rs.permutation(nco) if shuffle else np.arange(nco)
+    lists = [perm[l] for l in lists]
+    new, n1, hb = _plan_layout(nco, lists, pts)
+    assert hb == L - 1 and nco - n1 == 8, (hb, n1)
+    # one camera of every tie is in the border
+    for a, b in ties:
+        assert (new[perm[a]] >= n1) != (new[perm[b]] >= n1)
+    # without the border the band is what the ties make it
+    new0, n10, hb0 = _plan_layout(nco, lists, pts, allow_border=False)
+    assert n10 == nco and hb0 > 20
+
+
+def test_camera_layout_leaves_a_sequence_alone_and_cuts_a_ring_once():
+    rs = np.random.RandomState(4)
+    nco, L = 300, 8
+    lists, pts = _sequence_lists(nco, L, 50, rs)
+    new, n1, hb = _plan_layout(nco, lists, pts)
+    assert n1 == nco and hb == L - 1 and np.array_equal(new, np.arange(nco))      # the caller's order wins: nothing moves
+    # a ring: 40 tracks see the first four and the last four cameras
+    ring = lists + [np.r_[0:4, nco - 4:nco]] * 1
+    new, n1, hb = _plan_layout(nco, ring, pts + [40])
+    assert hb <= 11 and nco - n1 == 4, (hb, n1)
+    side = new[np.r_[0:4]] >= n1
+    assert side.all() or (new[np.r_[nco - 4:nco]] >= n1).all()
