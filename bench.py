@@ -73,6 +73,19 @@ FP64_RIDGE_FLOP_PER_BYTE = FP64_MATRIX_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
 LINEARISE_FLOPS_PER_OBS = 450.   # projection, chain rule, Jc^T Jc, Jp^T Jp, Jc^T Jp, J^T r
 
 
+BORDER_CAMS = [0]      # border cameras of the benched problem (problem_info): the border kernels' flops and bytes depend on it
+
+
+def border_shape(nc, nco, nt, nobs, hb):
+    """(pairs of observations the border blocks are formed from, nodes N and node size B of the band's cyclic reduction, row length ld of C)."""
+    k = BORDER_CAMS[0]
+    L = nobs / max(nt, 1)
+    pairs = k * (nobs / max(nc, 1)) * L
+    n1 = max(1, nco - k)
+    cb = max(hb, 1)
+    return pairs, -(-n1 // cb), 6 * cb, -(-6 * k // 16) * 16
+
+
 def useful_flops(kernel, nc, nco, nt, nobs, hb):
     """Useful fp64 flops of one trial's launches of `kernel` (2 per FMA; what the algorithm needs ONCE - a kernel that
     linearises an observation again, pads its tiles or factors a block redundantly is not credited for it).
@@ -90,6 +103,12 @@ def useful_flops(kernel, nc, nco, nt, nobs, hb):
         return (36. + 60.) * nobs + 18. * nt + 120. * nc
     if kernel == 'cost':
         return 60. * nobs
+    if kernel == 'border_schur':          # two linearisations and one 6x3x3 + 6x3x6 product per pair of observations
+        return border_shape(nc, nco, nt, nobs, hb)[0] * (2 * LINEARISE_FLOPS_PER_OBS + 2 * (54 + 108))
+    if kernel == 'border_solve':          # the border's columns through the tree (forward 3 B^2 ld, backward 6 B^2 ld per node, MACs x 2), C^T Y, the border system
+        pairs, N, B, ld = border_shape(nc, nco, nt, nobs, hb)
+        k6 = 6 * BORDER_CAMS[0]
+        return 9. * N * B * B * ld + 2. * (12 * max(hb, 1) * k6) * k6 * k6 / 6 + k6 ** 3 / 3.
     if kernel in ('bcr_eliminate', 'bcr_backsolve', 'bcr_assemble'):
         # block cyclic reduction, N nodes of B = 6 hb unknowns: per node Cholesky B^3/3, P and Q (two triangular solves with B
         # right-hand sides, B^3 each), G^-1 (B^3/3), P^T P and Q^T Q (symmetric, B^3 each), the two couplings of the next
@@ -148,6 +167,12 @@ def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb, launches=1.):
         return 48 * nt + 48 * nt + 72 * nt + 24 * nt + band + 48 * nco
     if kernel == 'update':
         return 2 * (96 * nc + 24 * nt) + 48 * nco + 24 * nt
+    if kernel == 'border_schur':          # per pair: two observations (20 B each) and the point's inverse; the blocks written once
+        pairs, N, B, ld = border_shape(nc, nco, nt, nobs, hb)
+        return int(pairs * (2 * 20 + 72) + 288 * BORDER_CAMS[0] * (2 * hb + 1 + BORDER_CAMS[0]))
+    if kernel == 'border_solve':          # C copied into F, F read and written once per level it takes part in (~4 passes), the factors G^-1, P, Q read twice
+        pairs, N, B, ld = border_shape(nc, nco, nt, nobs, hb)
+        return int(8 * (N * B * ld * (2 + 4) + 2 * 3 * N * B * B))
     return 0
 
 
@@ -918,6 +943,7 @@ def main():
         if dom_table != dom or not tm_dom['launches'] or not tm_dom['ms'] > 0.:
             dom, tm_dom = dom_table, ours.get(dom_table, tm_dom)
         nco, hb = be.nco, be.half_bandwidth
+        BORDER_CAMS[0] = int(be.problem_info().get('border_cameras', 0))
         def ab(k):
             n = (ours[k]['launches'] / nprof) if k in ours else 1.
             v = algorithmic_bytes(k, be.nc, nco, be.nt, nobs_local, be.nt, hb, launches=n)
