@@ -189,6 +189,13 @@ int ba_comm_allreduce_sum(ba_handle* h, double* values /*host, in place*/, int32
  * (the all-reduce adds the buffers element by element). */
 int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb);
 
+/* The layout of the optimised cameras for the following ba_set_problem calls, imposed by the caller instead of chosen by the
+ * library: new_pos[p] = internal position of the caller's position p (a permutation of 0 .. nco - 1; no border).  For the ranks of
+ * a sharded adjuster, which add their [S | b] buffers element by element and so must all use ONE layout: every rank plans it from
+ * the WHOLE scene (ba_plan_camera_layout with allow_border = 0: the same input gives the same layout) and imposes it; the band
+ * width they agree on (ba_set_min_half_bandwidth) is then the one of the new positions.  new_pos = NULL: the library chooses again. */
+int ba_set_camera_layout(ba_handle* h, const int32_t* new_pos, int32_t nco);
+
 /* bundle.sensor_model (sensor_model.py:19-32 protocol) */
 int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams);
 

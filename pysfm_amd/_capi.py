@@ -60,6 +60,7 @@ PROTOTYPES = {
     'ba_set_problem': (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, _dp, _dp, _ip, _bp]),
     'ba_problem_info': (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32]),
     'ba_order_cameras': (C.c_int, [C.c_int32, C.c_int32, _ip, _ip, _ip, _ip]),
+    'ba_set_camera_layout': (C.c_int, [_h, _ip, C.c_int32]),
     'ba_plan_camera_layout': (C.c_int, [C.c_int32, C.c_int32, _ip, _ip, _ip, C.c_int32, _ip, _ip, _ip]),
     'ba_set_sensor': (C.c_int, [_h, C.c_int, _dp, C.c_int]),
     'ba_set_params': (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),

@@ -117,6 +117,25 @@ class HipBackend(object):
         must store [S | b] in one common layout)."""
         self._check(self._lib.ba_set_min_half_bandwidth(self._h, int(min_hb)))
 
+    def set_camera_layout(self, new_pos):
+        """Impose the layout of the optimised cameras for the following set_problem calls (ba_set_camera_layout); None: the
+        library chooses again.  The ranks of a sharded adjuster share one layout."""
+        if new_pos is None:
+            self._check(self._lib.ba_set_camera_layout(self._h, None, 0))
+            return
+        new_pos = capi.i32(new_pos)
+        self._check(self._lib.ba_set_camera_layout(self._h, capi.iptr(new_pos), len(new_pos)))
+
+    def plan_camera_layout(self, nco, list_off, list_pos, list_points=None, allow_border=False):
+        """ba_plan_camera_layout (a pure function: no GPU work): (new_pos, band_cameras, half_bandwidth)."""
+        list_off, list_pos = capi.i32(list_off), capi.i32(list_pos)
+        pts = None if list_points is None else capi.i32(list_points)
+        new = np.empty(int(nco), np.int32)
+        n1, hb = C.c_int32(), C.c_int32()
+        self._check(self._lib.ba_plan_camera_layout(int(nco), len(list_off) - 1, capi.iptr(list_off), capi.iptr(list_pos), capi.iptr(pts), int(bool(allow_border)),
+                                                    capi.iptr(new), C.cast(C.byref(n1), capi._ip), C.cast(C.byref(hb), capi._ip)))
+        return new, n1.value, hb.value
+
     def set_problem(self, nc, nt, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt):
         obs_cam, obs_pt = capi.i32(obs_cam), capi.i32(obs_pt)
         obs_z = capi.f64(obs_z, (-1, 2))

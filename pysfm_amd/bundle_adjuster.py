@@ -256,9 +256,16 @@ class BundleAdjuster(object):
 
         be = self.backend
         if self._comm is not None and hasattr(be, 'set_min_half_bandwidth'):
-            # the ranks add their [S | b] buffers element by element: one band layout for all, i.e. the
+            # the ranks add their [S | b] buffers element by element: one band layout for all, i.e. ONE order of the optimised
+            # cameras (planned by every rank from the whole bundle: the same input, the same order) and the
             # widest spread of optimised-camera positions inside a track over ALL shards
+            layout = self._shared_camera_layout(bundle, cam_ids, cam_opt_pos) if hasattr(be, 'set_camera_layout') else None
+            if hasattr(be, 'set_camera_layout'):
+                be.set_camera_layout(layout)
+            self._shared_layout = layout
             pos = cam_opt_pos[np.asarray(obs_cam, int)]
+            if layout is not None:
+                pos = np.where(pos >= 0, layout[np.maximum(pos, 0)], -1)
             ok = pos >= 0
             lo = np.full(nt, np.iinfo(np.int32).max, np.int64)
             hi = np.full(nt, -1, np.int64)
@@ -276,6 +283,43 @@ class BundleAdjuster(object):
         self._have_W = False
         self._damp_factor = 1.
         self._say('Configured a bundle adjuster for %d cameras, %d tracks' % (nc, nt))
+
+    def _shared_camera_layout(self, bundle, cam_ids, cam_opt_pos):
+        """The order of the optimised cameras every rank of a sharded adjuster uses (csrc/ba_order.hip through
+        ba_plan_camera_layout, no border: the all-reduce payload is the band), planned from ALL tracks of the bundle so that
+        every rank arrives at the same one; None when the caller's order is as narrow as an order can be.  The ranks check
+        that they agree (a checksum over the group) and keep the caller's order otherwise."""
+        be = self.backend
+        cam, trk, _ = bundle.observation_table()
+        cpos = -np.ones(max(len(bundle.cameras), 1), np.int64)
+        cpos[cam_ids] = np.arange(len(cam_ids))
+        sel = cpos[np.asarray(cam, np.int64)]
+        pos = np.where(sel >= 0, cam_opt_pos[np.maximum(sel, 0)], -1).astype(np.int64)
+        ok = pos >= 0
+        pos, trk = pos[ok], np.asarray(trk, np.int64)[ok]            # (the table is sorted by (track, camera): so is what is left)
+        nco = int((cam_opt_pos >= 0).sum())
+        layout = None
+        if len(pos) and nco >= 3:
+            start = np.flatnonzero(np.r_[True, trk[1:] != trk[:-1]])
+            cnt = np.diff(np.r_[start, len(trk)])
+            lo, hi = np.minimum.reduceat(pos, start), np.maximum.reduceat(pos, start)
+            if int((hi - lo).max()) > max(1, int(cnt.max()) - 1):
+                # distinct camera lists, approximately (a 64-bit mix of length, ends, sum and sum of squares: two lists that collide
+                # are taken for one, which can only cost band width, never correctness)
+                p64 = pos.astype(np.uint64)
+                key = (cnt.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (lo.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) \
+                    ^ (hi.astype(np.uint64) * np.uint64(0x165667B19E3779F9)) ^ (np.add.reduceat(p64, start) * np.uint64(0xD6E8FEB86659FD93)) \
+                    ^ (np.add.reduceat(p64 * p64, start) * np.uint64(0xFF51AFD7ED558CCD))
+                _, rep = np.unique(key, return_index=True)
+                rep = rep[cnt[rep] >= 2]
+                off = np.r_[0, np.cumsum(cnt[rep])]
+                idx = np.repeat(start[rep] - off[:-1], cnt[rep]) + np.arange(off[-1])
+                new, n1, hb = be.plan_camera_layout(nco, off, pos[idx], None, allow_border=False)
+                if not np.array_equal(new, np.arange(nco)):
+                    layout = new.astype(np.int64)
+        chk = 0. if layout is None else float(np.dot(layout % 1000003, np.arange(1, len(layout) + 1) % 1000003) % 1000003) + 1.
+        same = self._comm.allreduce_max(chk) == chk and self._comm.allreduce_max(-chk) == -chk
+        return layout if self._comm._agree(same) else None
 
     # bytes of [S | b] above which the sharded adjuster spreads the reduced SOLVE over its ranks instead of summing the whole
     # band and solving it on every rank (csrc/ba_dist.h): below, one all-reduce of a few MB and a 0.1 ms solve are the faster way
@@ -299,6 +343,9 @@ class BundleAdjuster(object):
         if ok:
             cb, N, P = cut
             pos = cam_opt_pos[np.asarray(obs_cam, int)]
+            layout = getattr(self, '_shared_layout', None)
+            if layout is not None:                        # (the tree is cut along the library's camera positions)
+                pos = np.where(pos >= 0, layout[np.maximum(pos, 0)], -1)
             first = np.full(nt, np.iinfo(np.int64).max, np.int64)
             np.minimum.at(first, np.asarray(obs_pt, int)[pos >= 0], pos[pos >= 0])
             first = first[first < np.iinfo(np.int64).max]

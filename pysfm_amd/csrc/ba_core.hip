@@ -549,6 +549,20 @@ int ba_comm_allreduce_sum(ba_handle* h, double* values, int32_t n) {
   return BA_OK;
 }
 
+int ba_set_camera_layout(ba_handle* h, const int32_t* new_pos, int32_t nco) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  h->forced_pos.clear();
+  if (!new_pos) return BA_OK;
+  REQUIRE(h, nco >= 0, BA_ERR_INVALID_ARG, "ba_set_camera_layout: negative size");
+  std::vector<char> seen((size_t)nco, 0);
+  for (int p = 0; p < nco; ++p) {
+    if (new_pos[p] < 0 || new_pos[p] >= nco || seen[new_pos[p]]) return h->fail(BA_ERR_INVALID_ARG, "ba_set_camera_layout: new_pos is not a permutation of 0..nco-1");
+    seen[new_pos[p]] = 1;
+  }
+  h->forced_pos.assign(new_pos, new_pos + nco);
+  return BA_OK;
+}
+
 int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, min_hb >= 0, BA_ERR_INVALID_ARG, "ba_set_min_half_bandwidth: negative");

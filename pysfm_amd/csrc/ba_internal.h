@@ -162,6 +162,7 @@ struct ba_handle {
   // position q is the caller's cpos_out[q]; both empty = the caller's order.  Everything the C ABI takes or returns by optimised
   // position goes through cam_rows_in / cam_rows_out.
   std::vector<int> cpos_in, cpos_out;
+  std::vector<int> forced_pos;         // ba_set_camera_layout: the layout the caller imposes (a sharded adjuster's ranks share one)
   int caller_hb = 0;                   // half-bandwidth the caller's camera order would have had
   // band + border (ba_border.h): the last nbc optimised positions are BORDER cameras - the band's kernels see them as cameras that
   // are not optimised (cam_band_pos), their blocks live in bord (C, D) and their solution comes out of the border solve

@@ -969,6 +969,22 @@ int choose_camera_order(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, cons
                         const double* obs_z, const double* K, const int32_t* cam_opt_pos, const uint8_t* pt_opt) {
   const int nco = h->nco, hb0 = h->plan_flags[SF_HB];
   h->caller_hb = hb0;
+  if (!h->forced_pos.empty()) {
+    // the caller's layout (ba_set_camera_layout: the ranks of a sharded adjuster share one)
+    if ((int)h->forced_pos.size() != nco) return h->fail(BA_ERR_INVALID_ARG, "ba_set_problem: a layout for %d optimised cameras is imposed (ba_set_camera_layout), the problem has %d", (int)h->forced_pos.size(), nco);
+    bool ident = true;
+    for (int p = 0; p < nco; ++p) ident = ident && h->forced_pos[p] == p;
+    if (ident) return BA_OK;
+    std::vector<int32_t> cop((size_t)nc);
+    for (int i = 0; i < nc; ++i) cop[i] = cam_opt_pos[i] >= 0 ? h->forced_pos[cam_opt_pos[i]] : -1;
+    const int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cop.data(), pt_opt);
+    if (rc != BA_OK) return rc;
+    h->cpos_in = h->forced_pos;
+    h->cpos_out.assign((size_t)nco, 0);
+    for (int p = 0; p < nco; ++p) h->cpos_out[h->forced_pos[p]] = p;
+    h->caller_hb = hb0;
+    return BA_OK;
+  }
   if (h->opt.camera_order == CAMORDER_OFF || h->min_hb > 0 || h->comm || nco < 3 || nobs == 0) return BA_OK;      // (sharded: the ranks must agree on one layout)
   if (h->opt.camera_order != CAMORDER_ALWAYS && (hb0 <= std::max<long long>(1, h->group_maxL - 1) || resident_shape(h))) return BA_OK;
   // the distinct camera lists, as optimised positions in the caller's order

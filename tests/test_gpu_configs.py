@@ -531,7 +531,7 @@ def test_config5_trial_end_to_end_on_a_masked_sub_block(be, config5):
 
 
 # ------------------------------------------------------------------ sharded, config-5-shaped
-def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle, dist_solve=True, mask_some=False):
+def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle, dist_solve=True, mask_some=False, renumber=False):
     import sys
     for p in (ROOT, os.path.join(ROOT, 'tests')):
         if p not in sys.path:
@@ -545,6 +545,8 @@ def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle, dist_solve=True
     s = sd.generate_banded_scene(nc, nt)
     if shuffle:
         s = shuffled(s)[0]
+    if renumber:
+        s = cameras_renumbered(s)[0]
     b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
     comm = ShardComm()
     ba = BundleAdjuster(device=0, comm=comm, verbose=False)          # all ranks on GPU 0
@@ -562,7 +564,8 @@ def _c5_rank_worker(rank, world, port, out_dir, nc, nt, shuffle, dist_solve=True
     cams = np.unique(s['obs_cam'][np.isin(s['obs_pt'], ids)])
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), costs=np.array(ba.costs), X=X, R=R, t=t, trials=ba.lm_trials,
              nbytes=comm.bytes_reduced, hb=ba.backend.half_bandwidth, kind=ba.backend.last_solve_kind, cam_lo=cams.min(),
-             cam_hi=cams.max(), ntracks=len(ids), dist=int(getattr(ba, '_dist', False)), band_bytes=8 * ba.backend.S_doubles)
+             cam_hi=cams.max(), ntracks=len(ids), dist=int(getattr(ba, '_dist', False)), band_bytes=8 * ba.backend.S_doubles,
+             permuted=ba.backend.problem_info()['cameras_permuted'])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -1206,3 +1209,34 @@ def test_rejected_trials_reuse_the_linearisation():
     close(np.array([c for _, _, c in runs[0][0]]), np.array([c for _, _, c in runs[1][0]]), 1e-9)
     close(np.array(runs[0][1]), np.array(runs[1][1]), 1e-9)
     close(runs[0][2], runs[1][2], 1e-7, 1e-10)
+
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_on_one_gpu_cameras_in_no_order(tmp_path, world):
+    """The sharded adjuster on a scene whose cameras come in no particular order: the ranks add their [S | b] buffers element by
+    element, so they must all use ONE layout - every rank plans the order of the optimised cameras from the whole bundle
+    (BundleAdjuster._shared_camera_layout -> ba_plan_camera_layout -> ba_set_camera_layout) and they agree on the band of THAT order
+    (9, not 590).  The sharded walk must be the unsharded one."""
+    import socket
+    import torch.multiprocessing as mp
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd import synthetic_data as sd
+    nc, nt = 600, 15000
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(_c5_rank_worker, args=(world, port, str(tmp_path), nc, nt, False, False, False, True), nprocs=world, join=True)
+    s = cameras_renumbered(sd.generate_banded_scene(nc, nt))[0]
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(verbose=False)
+    ba.set_bundle(b)
+    assert ba.backend.half_bandwidth == 9
+    ba.optimize(max_steps=5)
+    R1, t1, X1 = ba.backend.get_params(0)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        assert int(d['hb']) == 9 and str(d['kind']) == 'bcr' and int(d['permuted']) == 1
+        assert int(d['trials']) == ba.lm_trials
+        close(d['costs'], np.array(ba.costs), 1e-9)
+        close(d['t'], t1, 1e-8)
+        close(d['X'], X1, 1e-8)
+    ba.backend.close()
