@@ -90,6 +90,7 @@ int ba_synchronize(ba_handle* h);
  *                                                          caller's order is not provably as narrow as an order can be
  *   "reuse_linearization" 1 | 0                            ba_lm_trial after a rejected trial does not form the point blocks of the unchanged
  *                                                          current set again (default 1; 0: every trial linearises, as the reference does)
+ *   "border_side_stream" 1 | 0                             the border's blocks on a side stream beside the cyclic reduction (default 1)
  *   "border"        1 | 0                                  band + border layouts of the reduced system (see ba_set_problem; default 1)
  *   "solve_trace"   1 | 0                                  per-phase cycle counts of the node kernels on stderr (PROFILE builds)
  * Unknown names / values: BA_ERR_INVALID_ARG.  Options that shape the work lists ("sort_points", "gm_cap", "gm_chunk") take effect at

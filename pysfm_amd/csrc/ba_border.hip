@@ -127,10 +127,11 @@ namespace {
 // launches of the scope go to the side stream (the launch helpers and timers all use h->stream)
 struct OnSideStream {
   ba_handle* h; hipStream_t keep;
-  explicit OnSideStream(ba_handle* h_) : h(h_), keep(h_->stream) { h->stream = h->side; }
+  explicit OnSideStream(ba_handle* h_) : h(h_), keep(h_->stream) { if (h->opt.border_side_stream) h->stream = h->side; }
   ~OnSideStream() { h->stream = keep; }
 };
 int side_fork(ba_handle* h) {
+  if (!h->opt.border_side_stream) return BA_OK;
   if (!h->side) {
     HIPCHECK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     HIPCHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -141,6 +142,7 @@ int side_fork(ba_handle* h) {
   return BA_OK;
 }
 int side_mark(ba_handle* h) {
+  if (!h->opt.border_side_stream) return BA_OK;
   HIPCHECK(h, hipEventRecord(h->ev_join, h->side));
   h->bord_pending = true;
   return BA_OK;
@@ -183,7 +185,7 @@ int border_solve(ba_handle* h, const unsigned char* dmask) {
   if (h->bord_pending) {
     // the copy of C into the work array and the start of M, rv need C, D, b2 and the mask, nothing of the band's solve: still on the side stream
     OnSideStream on_side(h);
-    if (dmask) { HIPCHECK(h, hipEventRecord(h->ev_fork, on_side.keep)); HIPCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0)); }      // (the mask's upload is on the main stream)
+    if (dmask && h->opt.border_side_stream) { HIPCHECK(h, hipEventRecord(h->ev_fork, on_side.keep)); HIPCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0)); }      // (the mask's upload is on the main stream)
     hipLaunchKernelGGL(k_border_prepare, dim3(blocks_for((long long)h->bord_rows * ld + (long long)nb * nb)), dim3(kBlock), 0, h->stream, (long long)h->bord_rows, rows1,
                        ld, nb, h->bordC.p, h->bordD.p, h->b + (size_t)rows1, dmask, h->bordF.p, bord_M(h), bord_rv(h), bord_info(h));
     if (int rc = side_mark(h); rc != BA_OK) return rc;

@@ -300,6 +300,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "host_setup") ok = flag(h->opt.host_setup);
   else if (n == "camera_order") ok = choice({"auto", "off", "always"}, h->opt.camera_order);
   else if (n == "border") ok = flag(h->opt.border);
+  else if (n == "border_side_stream") ok = flag(h->opt.border_side_stream);
   else if (n == "reuse_linearization") ok = flag(h->opt.reuse_linearization);
   else if (n == "packed_upload") ok = flag(h->opt.packed_upload);
   else if (n == "gm_chunk") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0 && c <= 64; if (ok) h->opt.gm_chunk = (int)c; }

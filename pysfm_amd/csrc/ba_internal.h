@@ -68,6 +68,7 @@ struct Options {
   int resident_scatter_min = 5;    // ... whose launches of at least this many workgroups add their partial sums up in slices (two stages)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
   bool reuse_linearization = true; // ba_lm_trial after a rejected trial: the point blocks of the unchanged current set are not formed again
+  bool border_side_stream = true;  // the border's blocks and the preparation of its solve on a side stream beside the cyclic reduction (off: in line)
   bool border = true;              // ... and a border for the cameras at the far end of a few long-range tracks (ba_border.h)
   int camera_order = 0;            // internal order of the optimised cameras (ba_order.hip): 0 auto (when the caller's is not provably as narrow as it can be), 1 off, 2 always try
 };

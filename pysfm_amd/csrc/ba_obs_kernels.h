@@ -358,7 +358,7 @@ __device__ __forceinline__ double lds_sum_in_order(const double* p, int L) {
 }
 // Row length of the per-value LDS rows: lane (slot, oi) adds up value c = oi of its point from row c, so the lanes of a point read
 // nine rows at the same offset - with rows of 64 doubles (512 bytes) all nine fall on the same banks (SQ_LDS_BANK_CONFLICT: 74 % of the
-// kernel's LDS-active cycles, profiles/r05a_sq_counters.csv).  65: the rows two banks apart - measured 0.5 us of the lineariser's 20, within the noise
+// kernel's LDS-active cycles, profiles/r05e_sq_counters.csv).  65: the rows two banks apart - measured 0.5 us of the lineariser's 20, within the noise
 // of the trial (an LDS pass of nine values is a small part of a kernel that linearises 60 observations per wavefront and batch).
 #ifndef BA_LIN_ROW
 #define BA_LIN_ROW 65
