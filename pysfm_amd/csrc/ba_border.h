@@ -114,7 +114,14 @@ __global__ __launch_bounds__(kBlock) void k_border_sum(const BorderBlock* __rest
   const bool diag = bk.pc == n1 + bk.ja;
   if (i >= 36 && !diag) return;
   double sacc = 0.0;
-  for (int c = chunk_first[b]; c < chunk_first[b + 1]; ++c) sacc += partial[(size_t)c * kBordPartial + i];
+  const int c0 = chunk_first[b], c1 = chunk_first[b + 1];
+  for (int cb = c0; cb < c1; cb += 8) {                   // eight records in flight, added in their order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = cb + u < c1 ? partial[(size_t)(cb + u) * kBordPartial + i] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sacc += v[u];
+  }
   if (i >= 36) { b2[6 * bk.ja + i - 36] = sacc; return; }
   double* dst = bk.pc < n1 ? C + (size_t)(6 * bk.pc) * ld + 6 * bk.ja : D + (size_t)(6 * (bk.pc - n1)) * ld + 6 * bk.ja;
   dst[(size_t)(i / 6) * ld + i % 6] = sacc;
@@ -387,17 +394,23 @@ __global__ __launch_bounds__(kBordThreads) void k_border_reduce(int nrcams, cons
 #pragma unroll
   for (int q = 0; q < kBordRedCams; ++q) rows[q] = c0 + q < nrcams ? 6 * rcams[c0 + q] : -1;
   if (tile == ntiles) {                                   // rv -= C^T y: lane = column (and + 64)
+    // (a camera at a time: its six rows of C and y in flight together - all 48 rows of the chunk at once spilled, 15 of the kernel's 19 us)
+    double sacc[2] = {0.0, 0.0};
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int c = lane + 64 * hh;
-      double p[kBordRedRows];
+    for (int m = 0; m < kBordRedCams; ++m) {
+      if (rows[m] < 0) continue;                          // (wave-uniform)
+      double yv[6], cv[2][6];
 #pragma unroll
-      for (int q = 0; q < kBordRedRows; ++q) { const int kk = rows[q / 6] + q % 6; p[q] = (rows[q / 6] >= 0 && c < nb) ? C[(size_t)kk * ld + c] * y[kk] : 0.0; }
-      double sacc = 0.0;
+      for (int u = 0; u < 6; ++u) {
+        yv[u] = y[rows[m] + u];
 #pragma unroll
-      for (int q = 0; q < kBordRedRows; ++q) sacc += p[q];
-      part[wave][c] = sacc;
+        for (int hh = 0; hh < 2; ++hh) cv[hh][u] = lane + 64 * hh < nb ? C[(size_t)(rows[m] + u) * ld + lane + 64 * hh] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) { sacc[0] += cv[0][u] * yv[u]; sacc[1] += cv[1][u] * yv[u]; }
     }
+    part[wave][lane] = sacc[0];
+    part[wave][lane + 64] = sacc[1];
     __syncthreads();
     if (tid < nb && !(mask2 && !mask2[tid])) atomic_add_f64(rv + tid, -(part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]));
     return;
@@ -499,7 +512,13 @@ __global__ __launch_bounds__(kBlock) void k_border_correct(int rows1, int nb, in
   const int r = t >> 2, q4 = t & 3;                   // four lanes per row
   if (r < rows1) {
     double sacc = 0.0;
-    for (int c = q4; c < nb; c += 4) sacc += Y[(size_t)r * ld + c] * x2[c];
+    for (int c0 = q4; c0 < nb; c0 += 32) {                // eight loads of a lane in flight
+      double yv[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int c = c0 + 4 * u; yv[u] = c < nb ? Y[(size_t)r * ld + c] : 0.0; xv[u] = c < nb ? x2[c] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sacc += yv[u] * xv[u];
+    }
     sacc += dpp_pair<0xB1>(sacc);
     sacc += dpp_pair<0x4E>(sacc);
     if (q4 == 0) dC[r] -= sacc;
