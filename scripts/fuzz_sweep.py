@@ -26,7 +26,8 @@ for seed in range(first, last):
     load_problem(be, *a, cp, po, sensor)
     info, cost = be.lm_trial(c['damping'], 1e-5, c['mask'])
     S, b = be.get_reduced()
-    key = (be.problem_info()['schur_kernel'], be.last_solve_kind)
+    pinfo = be.problem_info()
+    key = (pinfo['schur_kernel'], be.last_solve_kind, 'permuted' if pinfo['cameras_permuted'] else 'caller order', 'border %s' % ('yes' if pinfo['border_cameras'] else 'no'))
     kinds[key] = kinds.get(key, 0) + 1
     eS = np.abs(S - parts['S']).max() / np.abs(parts['S']).max(); eb = np.abs(b - parts['b']).max() / max(1e-300, np.abs(parts['b']).max())
     R2, t2, X2 = O.apply_update(a[1], a[2], a[3], mu, su, cp, po)
