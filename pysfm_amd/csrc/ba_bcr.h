@@ -458,7 +458,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate(int N, int s,
 #ifndef BA_BCR_PRODUCT_WAVES
 #define BA_BCR_PRODUCT_WAVES 15     // wavefronts of the prologue's coupling product: all but the chain's (15), or only those of SIMDs 1..3 (12)
 #endif
-__host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)4 * B * (B + 1) + 4 * B + 8 + 560) * sizeof(double); }
+// (nodes of 12 and 13 cameras, B = 72 / 78: three matrices - the coupling product's result shares its LDS with one of its operands, see bcr_split_node)
+__host__ __device__ inline size_t bcr_split_lds_bytes(int B) { return ((size_t)(B > 6 * kBcrMaxHB ? 3 : 4) * B * (B + 1) + 4 * B + 8 + 560) * sizeof(double); }
 
 // Four independent 4 x 4 blocks of A^T Bm (all B rows of the two k-major operands) in one chain of v_mfma_f64_4x4x4_4b_f64
 // (tools/mfma4_probe.hip: lane 16 k + 4 b + i feeds A_b[i][k], lane 16 k + 4 b + j feeds B_b[k][j], D_b[i][j] comes out in
@@ -530,6 +531,16 @@ __device__ __forceinline__ void bcr_ld16(const double* p0, const double* p1, con
                : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5)
                : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5) : "memory");
 }
+__device__ __forceinline__ void bcr_ld16(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4,
+                                         const double* p5, const double* p6, const double* p7, const double* p8, bcr_d2& v0, bcr_d2& v1,
+                                         bcr_d2& v2, bcr_d2& v3, bcr_d2& v4, bcr_d2& v5, bcr_d2& v6, bcr_d2& v7, bcr_d2& v8) {
+  asm volatile("global_load_dwordx4 %0, %9, off sc1\n\tglobal_load_dwordx4 %1, %10, off sc1\n\tglobal_load_dwordx4 %2, %11, off sc1\n\t"
+               "global_load_dwordx4 %3, %12, off sc1\n\tglobal_load_dwordx4 %4, %13, off sc1\n\tglobal_load_dwordx4 %5, %14, off sc1\n\t"
+               "global_load_dwordx4 %6, %15, off sc1\n\tglobal_load_dwordx4 %7, %16, off sc1\n\tglobal_load_dwordx4 %8, %17, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7), "=&v"(v8)
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "v"(p8) : "memory");
+}
 __device__ __forceinline__ void bcr_ld16(const double* p0, const double* p1, bcr_d2& v0, bcr_d2& v1) {
   asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
@@ -540,6 +551,12 @@ __device__ __forceinline__ void bcr_st16(double* p, bcr_d2 v) {       // (acknow
 
 #ifndef BA_BCR_WIDE_HANDOVER
 #define BA_BCR_WIDE_HANDOVER 1      // fused kernel: the inputs of a node and the factor it hands on move 16 bytes per lane
+#endif
+#ifndef BA_BCR_WIDE_MAX_ROUNDS
+#define BA_BCR_WIDE_MAX_ROUNDS 3    // ... for nodes whose B x B / 2 pairs are at most that many per thread (3: up to 13 cameras)
+#endif
+#ifndef BA_BCR_RHS_ON_SIMD0
+#define BA_BCR_RHS_ON_SIMD0 1       // nodes of 12, 13 cameras: right-hand-side wavefronts on the pivot chain's SIMD (0: none, as for the narrower nodes)
 #endif
 #ifndef BA_BCR_STORE_FIRST
 #define BA_BCR_STORE_FIRST 1        // fused kernel: the factors P / Q leave for memory BEFORE the neighbour products (their latency rides under the MFMAs)
@@ -579,9 +596,13 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
 #define BA_TLINE(k)
 #endif
   constexpr int B = 6 * HB, ld = B + 1;
+  // Nodes of more than kBcrMaxHB cameras (B = 72, 78): four matrices do not fit the 160 KB, and Ta only lives until the coupling
+  // product R = -A^T Bm has been formed - R takes its place: the product stays in the registers it left the matrix cores in
+  // until every wavefront has read its operands (one barrier more per node; the narrower nodes keep the layout they had).
+  constexpr bool kAlias = B > 6 * kBcrMaxHB;
   double* G = sm;                       // [B][ld]  D_i -> its Cholesky factor L (lower)
   double* R = G + (size_t)B * ld;       // [B][ld]  right-hand sides of this role: T_il | T_ir | I  ->  P | Q | G^-1
-  double* Ta = R + (size_t)B * ld;      // [B][ld]  prologue: factors of the node eliminated one level down
+  double* Ta = kAlias ? R : R + (size_t)B * ld;      // [B][ld]  prologue: factors of the node eliminated one level down
   double* Tb = Ta + (size_t)B * ld;     // [B][ld]
   double* g = Tb + (size_t)B * ld;      // [B]
   double* dinv = g + B;                 // [B]
@@ -622,17 +643,19 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     // FUSED, above the first level: D_i and the two factors as 16-byte pairs (entries 2 q, 2 q + 1 share a row: B is even),
     // half as many trips to memory; pairs past the end read pair 0 again (never stored)
     constexpr int NPAIR = B * B / 2, NITW = (NPAIR + kBcrElimThreads - 1) / kBcrElimThreads;
-    const bool wide = FUSED && BA_BCR_WIDE_HANDOVER && NITW <= 2 && s > 1;
+    const bool wide = FUSED && BA_BCR_WIDE_HANDOVER && NITW <= BA_BCR_WIDE_MAX_ROUNDS && s > 1;
     if (wide) {
       const double* pd = Dm + (size_t)i * BB;
       const double* pa = prod ? Pm + (size_t)j * BB : pd;
       const double* pb = prod ? Qm + (size_t)j * BB : pd;
-      const int q0 = tid, q1 = tid + kBcrElimThreads;
-      const int o0 = 2 * (q0 < NPAIR ? q0 : 0), o1 = 2 * (q1 < NPAIR ? q1 : 0);
-      bcr_d2 d0, a0, b0, d1 = {0.0, 0.0}, a1 = {0.0, 0.0}, b1 = {0.0, 0.0};
-      if (!prod) { bcr_ld16(pd + o0, pd + o1, d0, d1); a0 = b0 = d0; }      // (the inverse role: D_i only)
+      const int q0 = tid, q1 = tid + kBcrElimThreads, q2 = tid + 2 * kBcrElimThreads;
+      const int o0 = 2 * (q0 < NPAIR ? q0 : 0), o1 = 2 * (q1 < NPAIR ? q1 : 0), o2 = 2 * (q2 < NPAIR ? q2 : 0);
+      bcr_d2 d0, a0, b0, d1 = {0.0, 0.0}, a1 = {0.0, 0.0}, b1 = {0.0, 0.0}, d2 = {0.0, 0.0}, a2 = {0.0, 0.0}, b2 = {0.0, 0.0};
+      if (!prod && NITW == 3) { bcr_ld16(pd + o0, pd + o1, pd + o2, d0, d1, d2); a0 = b0 = d0; }      // (the inverse role: D_i only)
+      else if (!prod) { bcr_ld16(pd + o0, pd + o1, d0, d1); a0 = b0 = d0; }
       else if (NITW == 1) bcr_ld16(pd + o0, pa + o0, pb + o0, d0, a0, b0);
-      else bcr_ld16(pd + o0, pa + o0, pb + o0, pd + o1, pa + o1, pb + o1, d0, a0, b0, d1, a1, b1);
+      else if (NITW == 2) bcr_ld16(pd + o0, pa + o0, pb + o0, pd + o1, pa + o1, pb + o1, d0, a0, b0, d1, a1, b1);
+      else bcr_ld16(pd + o0, pa + o0, pb + o0, pd + o1, pa + o1, pb + o1, pd + o2, pa + o2, pb + o2, d0, a0, b0, d1, a1, b1, d2, a2, b2);
       auto put = [&](int q, bcr_d2 dv, bcr_d2 av, bcr_d2 bv) {
         if (q < NPAIR) {
           const int e = 2 * q, rr = e / B, cc = e - rr * B, o = rr * ld + cc;
@@ -647,6 +670,7 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
       };
       put(q0, d0, a0, b0);
       if (NITW > 1) put(q1, d1, a1, b1);
+      if (NITW > 2) put(q2, d2, a2, b2);
     }
     double vd[NIT], va[NIT], vb[NIT];
     if (!wide) {
@@ -686,6 +710,15 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   // ---- block 0's diagonal factor (wavefront 0: it needs D_i only) WHILE the other wavefronts form this role's coupling
   //      from the factors of the node eliminated one level down
   constexpr int NBLK = (B + 11) / 12;
+  // (kAlias: the tasks of a wavefront of the coupling product, held in registers over a barrier)
+  constexpr int PNT = (B + 15) / 16, PEB = 16 * (PNT - 1), PEE = B - PEB, PRB = (PEE + 3) / 4;
+  constexpr bool kPEdge4 = PNT > 1 && PEE <= 8;
+  constexpr int PNTF = kPEdge4 ? PNT - 1 : PNT, PNF = PNTF * PNTF, PNS = kPEdge4 ? 2 * PNTF * PRB + 1 : 0;
+  constexpr int pbase = PNF < 15 ? PNF : 0, pnsw = 15 - pbase;
+  constexpr int MAXT = kAlias ? (PNF + 14) / 15 : 1, MAXE = kAlias && kPEdge4 ? (PNS + pnsw - 1) / pnsw : 1;
+  static_assert(!kAlias || BA_BCR_PRODUCT_WAVES == 15, "nodes of more than 11 cameras: the coupling product on wavefronts 1..15");
+  mfma_acc ptile[MAXT];
+  double pedge[MAXE];
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
     if (B >= 12) bcr_diag_block<12, false>(G, ld, dinv, bad, 0, lane, Li, Idt);
@@ -694,6 +727,52 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
 #ifdef BA_BCR_PROFILE
     pst[2] += clock64() - pt0 - pst[0];
 #endif
+  } else if (kAlias && s > 1 && role < 2) {
+    constexpr int KST = (B + 3) / 4;
+    const double* A = role == 0 ? Tb : Ta;
+    const double* Bm = role == 0 ? Ta : Tb;
+    const int p = wave - 1;
+    if constexpr (kPEdge4) {
+#pragma unroll
+      for (int u = 0; u < MAXE; ++u) {
+        const int q = p - pbase + u * pnsw;
+        pedge[u] = 0.0;
+        if (p >= pbase && q < PNS) {
+          int acol, bcol;
+          bcr_edge_task(q, PNTF, PRB, true, PEB, lane, acol, bcol);
+          pedge[u] = bcr_mfma4_blocks<B>(A, Bm, ld, acol, bcol, lane);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+      const int task = p + 15 * u;
+      ptile[u] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+      if (task < PNF) {
+        const int ti = task / PNTF, tj = task - ti * PNTF;
+        // (B = 78: the operands in two halves of K - all of them at once, next to the tiles held over the barrier, do not fit 128 registers)
+        constexpr int NH = KST > 18 ? 2 : 1, KH = (KST + NH - 1) / NH;
+        mfma_acc acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int half = 0; half < NH; ++half) {
+          double ar[KH], br[KH];
+#pragma unroll
+          for (int q = 0; q < KH; ++q) {
+            const int ks = half * KH + q, k = 4 * ks + lk;
+            const bool in = ks < KST && (4 * ks + 3 < B || k < B);
+            const int kc = in ? k : 0;
+            const double a_ = A[kc * ld + 16 * ti + lr], b_ = Bm[kc * ld + 16 * tj + lr];
+            ar[q] = in ? a_ : 0.0; br[q] = in ? b_ : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < KH; q += 2) {
+            if (half * KH + q < KST) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[q], br[q], acc, 0, 0, 0);
+            if (q + 1 < KH && half * KH + q + 1 < KST) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[q + 1], br[q + 1], acc2, 0, 0, 0);
+          }
+        }
+        ptile[u] = acc + acc2;
+      }
+    }
   } else if (s > 1 && role < 2) {
     // R = -A^T Bm with (A, Bm) = (Q_j, P_j) for the left role, (P_j', Q_j') for the right one: 16 x 16 output tiles over
     // wavefronts 1..15, K in steps of 4 (lane -> column 16 t + lane % 16 of the k-major operand, k = 4 ks + lane / 16)
@@ -747,6 +826,38 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
 #ifdef BA_BCR_PROFILE
   if (BA_BCR_TRACE_KB == 0 && i == 3 * s - 1 && s == 2 && role == 0 && lane == 0) info[44 + wave] = (int)(clock64() - pt0 - pst[0]);      // prologue, per wavefront
 #endif
+  if constexpr (kAlias) {
+    if (s > 1 && role < 2) {              // (the same for every wavefront of the workgroup)
+      __syncthreads();                    // every operand of the product has been read: R may take Ta's place
+      if (wave != 0) {
+        const int p = wave - 1;
+        if constexpr (kPEdge4) {
+#pragma unroll
+          for (int u = 0; u < MAXE; ++u) {
+            const int q = p - pbase + u * pnsw;
+            if (p >= pbase && q < PNS) {
+              int acol, bcol;
+              bcr_edge_task(q, PNTF, PRB, true, PEB, lane, acol, bcol);
+              const int row = acol + (lane >> 4), col = bcol + (lane & 3);
+              if (row < B && col < B) R[row * ld + col] = -pedge[u];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+          const int task = p + 15 * u;
+          if (task < PNF) {
+            const int ti = task / PNTF, tj = task - ti * PNTF, col = 16 * tj + lr;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int row = 16 * ti + lk + 4 * v;
+              if (row < B && col < B) R[row * ld + col] = -ptile[u][v];
+            }
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
   BA_TLINE(3);
 
@@ -763,9 +874,28 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   };
   constexpr int nct = (ncol + 15) >> 4;
   // late-update workers: the wavefronts of SIMDs 1..3 (wave % 4 != 0): 12 slots; SIMD 0 belongs to the pivot chain
-  const int myslot = (wave & 3) ? wave - 1 - (wave >> 2) : -1;
+  int myslot_ = (wave & 3) ? wave - 1 - (wave >> 2) : -1;
   // the last nct of them own 16 columns of the right-hand sides each (none of the wavefronts 0..3, which compute the panel in phase 2)
-  const int rhs_ct = (myslot >= 12 - nct) ? 11 - myslot : -1;
+  int rhs_ct_ = (myslot_ >= 12 - nct) ? 11 - myslot_ : -1;
+  int nworkers_ = 12 - nct;
+  if constexpr (kAlias && BA_BCR_RHS_ON_SIMD0 > 0) {
+    // Nodes of 12 and 13 cameras: five 16-column tiles of right-hand sides at 6 - 7 block rows each are 90 - 105 MFMAs a step,
+    // the late updates 30 - 42 more: on the matrix cores of three SIMDs that is MORE than the pivot chain takes (phase 1 of a
+    // step: 4.9 - 6.1 k cycles on the SIMDs with two right-hand-side wavefronts against 3.0 k of wavefront 0).  One tile goes
+    // to a wavefront of SIMD 0 (the chain's: it pays a little), the others one per SIMD + one; the late updates in the order
+    // heaviest first to the SIMDs with one right-hand-side wavefront.
+    static_assert(nct == 5, "five right-hand-side tiles");
+    if (BA_BCR_RHS_ON_SIMD0 == 1) {
+      rhs_ct_ = wave == 13 ? 0 : wave == 14 ? 1 : wave == 15 ? 2 : wave == 10 ? 3 : wave == 4 ? 4 : -1;
+      myslot_ = wave == 1 ? 0 : wave == 3 ? 1 : wave == 5 ? 2 : wave == 7 ? 3 : wave == 9 ? 4 : wave == 11 ? 5 : wave == 2 ? 6 : wave == 6 ? 7 : -1;
+      nworkers_ = 8;
+    } else {
+      rhs_ct_ = wave == 13 ? 0 : wave == 14 ? 1 : wave == 15 ? 2 : wave == 8 ? 3 : wave == 4 ? 4 : -1;
+      myslot_ = wave == 1 ? 0 : wave == 3 ? 1 : wave == 2 ? 2 : wave == 5 ? 3 : wave == 7 ? 4 : wave == 6 ? 5 : wave == 9 ? 6 : wave == 11 ? 7 : wave == 10 ? 8 : -1;
+      nworkers_ = 9;
+    }
+  }
+  const int myslot = myslot_, rhs_ct = rhs_ct_, nworkers = nworkers_;
   const int rhs_col = 16 * (rhs_ct >= 0 ? rhs_ct : 0) + lr;
   const bool rhs_cok = rhs_col < ncol;
   int rhs_xst;
@@ -786,6 +916,17 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
   bcr_acc4 cpre = {0.0, 0.0, 0.0, 0.0};                     // and the tile it updates there
 #pragma unroll 1
   for (int kb = 0; kb < NBLK; ++kb) {
+    // Seven block rows of right-hand sides in registers (B = 78): what a lane derives from its number - tile offsets, the
+    // addresses of its right-hand-side column - is formed again at every step.  Hoisted out of this loop those values did not fit
+    // the 128 registers next to seven accumulator tiles: they were spilled and came back from scratch memory in the middle of
+    // a step (phase 1 took 8.7 k cycles a step instead of 4.2 k).
+    int lane_v = lane;
+    if constexpr (NBLK >= 7) asm volatile("" : "+v"(lane_v));
+    const int lane = lane_v, lr = lane_v & 15, lk = lane_v >> 4;
+    const int rhs_col = 16 * (rhs_ct >= 0 ? rhs_ct : 0) + lr;
+    const bool rhs_cok = rhs_col < ncol;
+    int rhs_xst;
+    const int rhs_xoff = rhs_column(rhs_cok ? rhs_col : ncol - 1, rhs_xst);
     const int k0 = 12 * kb;
     const bool last = kb == NBLK - 1;
     const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
@@ -848,37 +989,80 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
           if (r == kb - 1) cur = racc[r];
         // every operand of this step in ONE LDS round trip, before the first MFMA: the rows of panel kb-1 for all block rows
         // (those above kb are fetched for nothing - cheaper than a round trip per row, which is what a branch per row compiles to)
-        const double l0 = Lp[lr * 12 + lk], l1 = Lp[lr * 12 + 4 + lk], l2 = Lp[lr * 12 + 8 + lk];
-        double a[NBLK > 1 ? NBLK - 1 : 1][3];
-#pragma unroll
-        for (int r = 1; r < NBLK; ++r) {
-          const int arow = 12 * r + lr < B ? 12 * r + lr : B - 1;        // rows past the end repeat the last one (results never used)
-          const int ao = arow * ld + kp + lk;
-          a[r - 1][0] = sm[ao]; a[r - 1][1] = sm[ao + 4]; a[r - 1][2] = sm[ao + 8];
-        }
-#pragma unroll
-        for (int r = 1; r < NBLK; ++r) asm volatile("" : "+v"(a[r - 1][0]), "+v"(a[r - 1][1]), "+v"(a[r - 1][2]));
-        mfma_acc y = {0.0, 0.0, 0.0, 0.0};
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, cur[0], y, 0, 0, 0);
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, cur[1], y, 0, 0, 0);
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(l2, cur[2], y, 0, 0, 0);
-        const int ro = rhs_xoff + __mul24(kp + lk, rhs_xst), r4 = 4 * rhs_xst;
-        if (rhs_cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
-        const double ny0 = -y[0], ny1 = -y[1], ny2 = -y[2];
-#pragma unroll
-        for (int r = 1; r < NBLK; ++r) {
-          if (r >= kb) {                                       // (wave-uniform)
-            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][0], ny0, racc[r], 0, 0, 0);
-            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][1], ny1, racc[r], 0, 0, 0);
-            racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][2], ny2, racc[r], 0, 0, 0);
+        if constexpr (NBLK <= 6) {
+          const double l0 = Lp[lr * 12 + lk], l1 = Lp[lr * 12 + 4 + lk], l2 = Lp[lr * 12 + 8 + lk];
+          double a[NBLK > 1 ? NBLK - 1 : 1][3];
+  #pragma unroll
+          for (int r = 1; r < NBLK; ++r) {
+            const int arow = 12 * r + lr < B ? 12 * r + lr : B - 1;        // rows past the end repeat the last one (results never used)
+            const int ao = arow * ld + kp + lk;
+            a[r - 1][0] = sm[ao]; a[r - 1][1] = sm[ao + 4]; a[r - 1][2] = sm[ao + 8];
+          }
+  #pragma unroll
+          for (int r = 1; r < NBLK; ++r) asm volatile("" : "+v"(a[r - 1][0]), "+v"(a[r - 1][1]), "+v"(a[r - 1][2]));
+          mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, cur[0], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, cur[1], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(l2, cur[2], y, 0, 0, 0);
+          const int ro = rhs_xoff + __mul24(kp + lk, rhs_xst), r4 = 4 * rhs_xst;
+          if (rhs_cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+          const double ny0 = -y[0], ny1 = -y[1], ny2 = -y[2];
+  #pragma unroll
+          for (int r = 1; r < NBLK; ++r) {
+            if (r >= kb) {                                       // (wave-uniform)
+              racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][0], ny0, racc[r], 0, 0, 0);
+              racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][1], ny1, racc[r], 0, 0, 0);
+              racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r - 1][2], ny2, racc[r], 0, 0, 0);
+            }
+          }
+        } else {
+          // (seven block rows, B = 78: the rows' operands two rows at a time, the next two in flight under the MFMAs of these - all
+          //  at once do not fit next to seven accumulator tiles in 128 registers)
+          constexpr int NRB = NBLK <= 6 ? (NBLK > 1 ? NBLK - 1 : 1) : 2;      // block rows per round trip
+          constexpr int NBAT = NBLK > 1 ? (NBLK - 1 + NRB - 1) / NRB : 0;
+          const double l0 = Lp[lr * 12 + lk], l1 = Lp[lr * 12 + 4 + lk], l2 = Lp[lr * 12 + 8 + lk];
+          double a[2][NRB][3];
+          auto fetch = [&](int bt, double (&dst)[NRB][3]) {
+  #pragma unroll
+            for (int q = 0; q < NRB; ++q) {
+              const int r = 1 + bt * NRB + q;
+              if (r < NBLK) {
+                const int arow = 12 * r + lr < B ? 12 * r + lr : B - 1;      // rows past the end repeat the last one (results never used)
+                const int ao = arow * ld + kp + lk;
+                dst[q][0] = sm[ao]; dst[q][1] = sm[ao + 4]; dst[q][2] = sm[ao + 8];
+              }
+            }
+          };
+          if (NBAT > 0) fetch(0, a[0]);
+  #pragma unroll
+          for (int q = 0; q < NRB; ++q) asm volatile("" : "+v"(a[0][q][0]), "+v"(a[0][q][1]), "+v"(a[0][q][2]));
+          mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, cur[0], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, cur[1], y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(l2, cur[2], y, 0, 0, 0);
+          const int ro = rhs_xoff + __mul24(kp + lk, rhs_xst), r4 = 4 * rhs_xst;
+          if (rhs_cok) { sm[ro] = y[0]; sm[ro + r4] = y[1]; sm[ro + 2 * r4] = y[2]; }
+          const double ny0 = -y[0], ny1 = -y[1], ny2 = -y[2];
+  #pragma unroll
+          for (int bt = 0; bt < NBAT; ++bt) {
+            if (bt + 1 < NBAT) fetch(bt + 1, a[(bt + 1) & 1]);
+  #pragma unroll
+            for (int q = 0; q < NRB; ++q) {
+              const int r = 1 + bt * NRB + q;
+              if (r < NBLK && r >= kb) {                           // (wave-uniform)
+                racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bt & 1][q][0], ny0, racc[r], 0, 0, 0);
+                racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bt & 1][q][1], ny1, racc[r], 0, 0, 0);
+                racc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bt & 1][q][2], ny2, racc[r], 0, 0, 0);
+              }
+            }
           }
         }
       }
-    } else if (myslot >= 0 && myslot < 12 - nct) {
+    } else if (myslot >= 0 && myslot < nworkers) {
       const int kp = k0 - 12;
       const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
       const int nsu = ((B - k0 + 15) >> 4) - 1;             // tiles of block column kb below the one wavefront 0 takes
-      for (int task = myslot; task < ngt + nsu; task += 12 - nct) {
+      for (int task = myslot; task < ngt + nsu; task += nworkers) {
         if (task >= ngt) { urgent_tile(task - ngt + 1); continue; }
         // lower tiles of D right of block column kb: C -= A B with K = 12, A = panel of block kp (16 rows of the tile), B = panel^T
         const int gtile = task, c0 = kn + 16 * gtile;
@@ -925,8 +1109,9 @@ __device__ __forceinline__ bool bcr_split_node(double* __restrict__ sm, int N, i
     pst[3] += q1 - q0;
 #endif
     // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
-    if (wave < 4) {
-      if (kn + 16 * wave < B) {                              // (nb == 12 here; at most 4 tiles)
+    constexpr int NPT = (B - 12 + 15) / 16 > 4 ? (B - 12 + 15) / 16 : 4;      // tiles of the widest panel (B = 78: five - wavefront 4, idle in phase 1, takes the fifth)
+    if (wave < NPT) {
+      if (kn + 16 * wave < B) {                              // (nb == 12 here)
         if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
         bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
       }
@@ -1122,7 +1307,7 @@ __device__ __forceinline__ double bcr_wait_value(const double* p, int* status) {
 
 // node i of the back-substitution: stage P_i, Q_i, G_i^-1, g_i (COHERENT: they were written by workgroups of this same launch -
 // relaxed agent-scope loads), wait for x_l, x_r, form and publish x_i
-template <bool COHERENT>
+template <bool COHERENT, int U = (kBcrSplitMaxHB * 6 * kBcrSplitMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads>      // (U: entries of a B x B matrix per thread)
 __device__ __forceinline__ void bcr_backsolve_node(double* __restrict__ sm, int N, int B, int i, const double* gm,
                                                    const double* Pm, const double* Qm, const double* Gi, double* x, int* status) {
   const int ld = B + 1;
@@ -1139,7 +1324,6 @@ __device__ __forceinline__ void bcr_backsolve_node(double* __restrict__ sm, int 
   if (!haveL && !haveR) return;          // the root: its elimination kernel wrote x_i
   const size_t BB = (size_t)B * B;
   {
-    constexpr int U = (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
     double vp[U], vq[U], vg[U];
     const double wv = tid < B ? bcr_ld<COHERENT>(gm + (size_t)i * B + tid) : 0.0;
 #pragma unroll
@@ -1273,8 +1457,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_eliminate_fused(int N, 
       if (threadIdx.x < 3 && word) bcr_wait_done(word, info);
     }
     __syncthreads();
-    if (s >= s_first) bcr_backsolve_node<true>(sm, N, 6 * HB, i, gm, Pm, Qm, Gi, xout, info);
-    else bcr_backsolve_node<false>(sm, N, 6 * HB, i, fm, Pm, Qm, Gi, xout, info);
+    constexpr int UB = HB <= kBcrMaxHB ? (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads : (36 * HB * HB + kBcrElimThreads - 1) / kBcrElimThreads;
+    if (s >= s_first) bcr_backsolve_node<true, UB>(sm, N, 6 * HB, i, gm, Pm, Qm, Gi, xout, info);
+    else bcr_backsolve_node<false, UB>(sm, N, 6 * HB, i, fm, Pm, Qm, Gi, xout, info);
     return;
   }
 #ifdef BA_BCR_PROFILE
@@ -1476,10 +1661,10 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_backsolve(int N, int B,
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;
   const size_t BB = (size_t)B * B;
-  // all loads first (up to 5 entries of each matrix per thread: B <= 66), then the LDS stores: one memory
+  // all loads first (up to 6 entries of each matrix per thread: B <= 78), then the LDS stores: one memory
   // round trip for the whole staging instead of one per loop iteration
   {
-    constexpr int U = (kBcrMaxHB * 6 * kBcrMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
+    constexpr int U = (kBcrSplitMaxHB * 6 * kBcrSplitMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
     double vp[U], vq[U], vg[U];
     const double wv = tid < B ? fm[(size_t)i * B + tid] : 0.0;
     const double xlv = (tid < B && haveL) ? x[(size_t)l * B + tid] : 0.0;

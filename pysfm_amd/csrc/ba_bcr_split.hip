@@ -1,4 +1,4 @@
-// ba_bcr_split.hip - the node of the cyclic reduction spread over three workgroups: one launch per level (k_bcr_eliminate_split) or all levels and the back-substitution in one launch (k_bcr_eliminate_fused); instantiated per cameras-per-node 1..11.
+// ba_bcr_split.hip - the node of the cyclic reduction spread over three workgroups: one launch per level (k_bcr_eliminate_split) or all levels and the back-substitution in one launch (k_bcr_eliminate_fused); instantiated per cameras-per-node 1..13.
 #include "ba_internal.h"
 
 #define BA_BCR_TEMPLATES_ONLY 1
@@ -39,7 +39,7 @@ hipError_t launch_bcr_fused(ba_handle* h, int hb, int nwork, hipStream_t st, int
 #define BA_HB_CASE(K) case K: return launch_bcr_fused_hb<K>(h, nwork, st, N, s_first, D, U, f, P, Q, G, gv, info, x, work, done);
   switch (hb) {
     BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
-    BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11)
+    BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11) BA_HB_CASE(12) BA_HB_CASE(13)
     default: return hipErrorInvalidValue;
   }
 #undef BA_HB_CASE
@@ -50,7 +50,7 @@ hipError_t launch_bcr_split(ba_handle* h, int hb, int cnt, hipStream_t st, int N
 #define BA_HB_CASE(K) case K: return launch_bcr_split_hb<K>(h, cnt, st, N, s, D, U, f, P, Q, G, gv, info, x);
   switch (hb) {
     BA_HB_CASE(1) BA_HB_CASE(2) BA_HB_CASE(3) BA_HB_CASE(4) BA_HB_CASE(5) BA_HB_CASE(6) BA_HB_CASE(7) BA_HB_CASE(8)
-    BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11)
+    BA_HB_CASE(9) BA_HB_CASE(10) BA_HB_CASE(11) BA_HB_CASE(12) BA_HB_CASE(13)
     default: return hipErrorInvalidValue;
   }
 #undef BA_HB_CASE

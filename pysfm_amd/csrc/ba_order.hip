@@ -158,8 +158,8 @@ int choose_border(int nco, const std::vector<int>& loff, const std::vector<int>&
 double layout_cost_us(int hb, int nco, int border_cams) {
   const double scale = std::max(1.0, nco / 1000.0);
   double t;
-  if (hb <= kBcrMaxHB) t = 100.0 * std::pow(std::max(hb, 3) / 9.0, 1.5) * std::max(1.0, std::log2(std::max(2.0, (double)nco / std::max(1, hb))) / 7.0);
-  else if (hb <= kBcrwMaxHB) t = (250.0 + 45.0 * (hb - kBcrMaxHB)) * scale;
+  if (hb <= kBcrSplitMaxHB) t = 100.0 * std::pow(std::max(hb, 3) / 9.0, 1.5) * std::max(1.0, std::log2(std::max(2.0, (double)nco / std::max(1, hb))) / 7.0);
+  else if (hb <= kBcrwMaxHB) t = (250.0 + 45.0 * (hb - kBcrMaxHB)) * scale;      // (12, 13: 151, 193 us through the one-launch kernel; 14: 290)
   else t = (800.0 + 14.0 * (hb - kBcrwMaxHB)) * scale;
   if (border_cams > 0) t += 50.0 + 12.0 * border_cams * scale;
   return t;

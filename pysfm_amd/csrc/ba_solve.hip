@@ -29,14 +29,16 @@ int solve_bcr(ba_handle* h, const unsigned char* dmask) {
   // round of workgroups; one compute unit per node (k_bcr_eliminate) on the wide levels below them and with "bcr1".
   // (A split level takes its couplings from the factors of the level below, whichever kernel wrote them; a one-unit
   // level needs the couplings U the split kernel does not form: so never one-unit above split - node counts only fall.)
-  const bool split = h->opt.solver != SOLVER_BCR1;
+  // (nodes of 12 and 13 cameras: the one-unit kernel's four matrices do not fit in LDS - every level is a split one)
+  const bool wide_node = hb > kBcrMaxHB;
+  const bool split = h->opt.solver != SOLVER_BCR1 || wide_node;
   std::vector<char> level_split;
   const size_t lds = bcr_lds_bytes(B);
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
   for (int s : strides) {
     const int cnt = (N / s + 1) / 2;
-    level_split.push_back(split && (3 * cnt <= h->ncu || (!level_split.empty() && level_split.back())));
+    level_split.push_back(split && (wide_node || 3 * cnt <= h->ncu || (!level_split.empty() && level_split.back())));
   }
   // the split levels in ONE launch (k_bcr_eliminate_fused): its work list = the (node, role) pairs of those levels, leaves first
   int s_fused = 0, nwork = 0;
@@ -371,7 +373,9 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     return BA_OK;
   }
   const int nodes = h->hb > 0 ? (h->nco + h->hb - 1) / h->hb : 0;
-  const bool bcr_ok = h->nco <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrMaxHB);      // (any number of nodes: even two levels beat k_band_solve's chain of nco pivots)
+  // (any number of nodes: even two levels beat k_band_solve's chain of nco pivots; nodes of 12 and 13 cameras exist spread over
+  //  three workgroups only: option solver = bcr1 means the wide solver's one-unit-per-node kernels there)
+  const bool bcr_ok = h->nco <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrMaxHB) || (h->hb <= kBcrSplitMaxHB && h->hb >= 1 && force != SOLVER_BCR1);
   const bool bcrw_ok = h->hb >= kBcrwMinHB && h->hb <= kBcrwMaxHB && nodes >= 4;
   const bool band_ok = h->hb <= kMaxBandSolve;       // (the single-workgroup band Cholesky is instantiated up to there)
   const bool dense_ok = 6 * h->nco <= kDcMaxN && force != SOLVER_LU;
@@ -392,9 +396,9 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need - have > free_b - free_b / 16) use_big = false;
     }
   }
-  const bool use_dense = !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR))));
+  const bool use_dense = !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);
-  const bool use_bcrw = !use_dense && !use_bcr && (force ? (force == SOLVER_BCR && bcrw_ok) : bcrw_ok);
+  const bool use_bcrw = !use_dense && !use_bcr && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcrw_ok) : bcrw_ok);
   // nothing of the above applies (or option solver = lu): LU with partial pivoting, the reference's own factorisation
   const bool use_lu = force == SOLVER_LU || (!use_big && !use_dense && !use_bcr && !use_bcrw && !band_ok);
   HIPCHECK(h, hipSetDevice(h->device));
@@ -447,12 +451,13 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   if (inf > 0 && inf != kBcrTimedOut && !use_lu && h->opt.device_lu) {
     // not positive definite: the reference's LU would still solve it (bundle_adjuster.py:302-305) - the cyclic reduction with
     // LU nodes where the nodes are narrow, LU with partial pivoting down the band otherwise
-    int rc = use_bcr ? solve_bcr_lu(h, dmask) : solve_band_lu(h, dmask);
+    const bool lu_nodes = use_bcr && bcr_node_size(h) <= kBcrMaxHB;      // (k_bcr_eliminate_lu keeps a node's B x (3 B + 1) matrix in LDS)
+    int rc = lu_nodes ? solve_bcr_lu(h, dmask) : solve_band_lu(h, dmask);
     if (rc != BA_OK) return rc;
     int inf2 = 0;
     HIPCHECK(h, hipMemcpyAsync(&inf2, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    h->solve_kind = use_bcr ? BA_SOLVE_BCR_LU : BA_SOLVE_BAND_LU;
+    h->solve_kind = lu_nodes ? BA_SOLVE_BCR_LU : BA_SOLVE_BAND_LU;
     inf = inf2;
   }
 #ifdef BA_BCR_PROFILE

@@ -166,6 +166,7 @@ __host__ __device__ inline size_t band_solve_lds_bytes(int hb, int ch) {
 
 // ---- limits of the reduced-system solvers (ba_solve_reduced picks by half-bandwidth and size)
 constexpr int kBcrMaxHB = 11;                  // ba_bcr.h: 4 matrices of B x (B+1) doubles must fit in LDS (B = 66: 145 KB)
+constexpr int kBcrSplitMaxHB = 13;             // ba_bcr.h: the node over three workgroups (k_bcr_eliminate_split / _fused) needs three matrices of its own (B = 78: 148 KB)
 constexpr int kBcrwMinHB = kBcrMaxHB + 1;      // ba_bcr_wide.h
 constexpr int kBcrwMaxHB = 23;                 // B = 138: one B x (B+1) fp64 matrix = 150 KB of the 160 KB LDS (track length 24)
 constexpr int kDcMaxN = 16000;                 // ba_dense.h: k_dense_backsolve keeps w[n] in LDS

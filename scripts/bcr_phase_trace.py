@@ -1,5 +1,5 @@
 """Per-phase shader-cycle counts of k_bcr_eliminate (library built with `make PROFILE=1`).
-usage (GPU box): python scripts/bcr_phase_trace.py [cams] [points] [solver: bcr | bcr1]"""
+usage (GPU box): python scripts/bcr_phase_trace.py [cams] [points] [solver: bcr | bcr1] [track length]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ from pysfm_amd import synthetic_data as sd                          # noqa: E402
 
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
-s = sd.generate_banded_scene(nc, nt)
+s = sd.generate_banded_scene(nc, nt, track_len=int(sys.argv[4]) if len(sys.argv) > 4 else 10)
 b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'],
                             sensor_model=sensor_model.GaussianModel(1.))
 ba = BundleAdjuster(verbose=False)

@@ -908,7 +908,7 @@ def test_cameras_in_any_order_full_step_vs_oracle(be, sensor, L, drop):
         close(S, parts['S'], TIGHT)
         close(b, parts['b'], TIGHT)
         be.solve_reduced(m)
-        assert be.last_solve_kind == ('bcr' if info['half_bandwidth'] <= 11 else 'bcr_wide')
+        assert be.last_solve_kind == ('bcr' if info['half_bandwidth'] <= 13 else 'bcr_wide')
         dC = be.get_solution()
         close(-dC, mu, 1e-8)
         if m is not None:

@@ -547,7 +547,8 @@ def test_band_solver_vs_dense_lu(be):
 
 
 @pytest.mark.parametrize('nc,L', [(80, 7), (37, 3), (200, 10), (23, 2), (64, 5), (1500, 10), (700, 11), (400, 12), (300, 13), (500, 16), (400, 22), (97, 19), (300, 23), (260, 24),
-                                  (120, 4), (150, 6), (160, 8), (180, 9)])      # (with these every half-bandwidth 1..11 of the node kernels: 16 x 16 tiles with and without the 4 x 4 x 4 edge)
+                                  (120, 4), (150, 6), (160, 8), (180, 9),      # (with these every half-bandwidth 1..11 of the node kernels: 16 x 16 tiles with and without the 4 x 4 x 4 edge)
+                                  (1000, 13), (1000, 14), (333, 14), (29, 13), (3100, 14), (53, 15)])      # (nodes of 12 and 13 cameras: three matrices in LDS, ba_bcr.h; 3100: levels wider than the chip)
 def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
     """The multi-CU block-cyclic-reduction solve against the single-workgroup band Cholesky and
     the dense LU on the same device-resident system (odd sizes: padded last super-block,
@@ -562,14 +563,16 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
     n = (nc - 1) * 6
     for mask in (None, (np.arange(n) % 7 != 3).astype(np.uint8)):
         sol = {}
-        for solver in ('bcr', 'bcr1', 'band'):            # hb <= 11: a node over three CUs (bcr) / on one (bcr1); 12..21: ba_bcr_wide.h
+        for solver in ('bcr', 'bcr1', 'band'):            # hb <= 11: a node over three CUs (bcr) / on one (bcr1); 12, 13: over three CUs (bcr) / ba_bcr_wide.h (bcr1); .. 23: ba_bcr_wide.h
             be.set_option('solver', solver)
             be.solve_reduced(mask)
-            if L > 22 and solver != 'bcr':                 # no single-workgroup band solver this wide: the dense Cholesky stands in
+            if L > 22 and solver == 'band':                # no single-workgroup band solver this wide: the dense Cholesky stands in
                 assert be.last_solve_kind == 'dense_cholesky'
             else:
                 assert be.last_solve_path == 'band'
-                assert be.last_solve_kind == ('band' if solver == 'band' or (solver == 'bcr1' and L > 12) else 'bcr' if L <= 12 else 'bcr_wide')
+                few = (nc - 1 + L - 2) // (L - 1) < 4        # (the wide solver wants four nodes to reduce over)
+                assert be.last_solve_kind == ('band' if solver == 'band' or (few and L > 14) or (few and L > 12 and solver == 'bcr1') else
+                                              'bcr' if L <= 12 or (L <= 14 and solver == 'bcr') else 'bcr_wide'), (solver, be.last_solve_kind)
             sol[solver] = be.get_solution().reshape(-1)
         xd = _device_lu(be, mask)
         close(sol['bcr'], xd, 1e-9)
@@ -1113,7 +1116,7 @@ def test_triangulation_degenerate_tracks(be):
     assert np.sqrt(np.mean(np.sum(e * e, axis=1))) < 3 * .02
 
 
-@pytest.mark.parametrize('nc,L', [(64, 4), (300, 10), (1000, 10), (257, 12), (120, 16), (200, 23), (150, 32), (400, 80), (30, 30)])
+@pytest.mark.parametrize('nc,L', [(64, 4), (300, 10), (1000, 10), (257, 12), (230, 13), (120, 16), (200, 23), (150, 32), (400, 80), (30, 30)])
 def test_not_positive_definite_systems_are_solved_like_the_reference_lu(be, nc, L):
     """The reference solves its reduced system by LU (numpy.linalg.solve, bundle_adjuster.py:302-305): a symmetric matrix that is
     NOT positive definite is still solved.  A NEGATIVE damping makes such a system on purpose (diag(H) scaled by 0.4: indefinite,
@@ -1166,7 +1169,7 @@ def test_not_positive_definite_systems_are_solved_like_the_reference_lu(be, nc, 
         assert np.all(np.isfinite(dP))
 
 
-@pytest.mark.parametrize('nc,nt,L,reps', [(1000, 20000, 10, 200), (97, 3000, 7, 300), (523, 9000, 11, 150), (12, 400, 3, 300)])
+@pytest.mark.parametrize('nc,nt,L,reps', [(1000, 20000, 10, 200), (97, 3000, 7, 300), (523, 9000, 11, 150), (12, 400, 3, 300), (1000, 12000, 13, 150), (611, 8000, 14, 150)])
 def test_one_launch_solve_repeats_itself_and_equals_the_per_level_launches(be, nc, nt, L, reps):
     """k_bcr_eliminate_fused hands data from workgroup to workgroup INSIDE one launch (words in memory, relaxed agent-scope
     accesses, no fences): a stale read would show as a solve that differs from the others.  The same reduced system solved
