@@ -26,7 +26,9 @@ int launch_mfma3_set(ba_handle* h, const M3Launch& L, int p, double damping, boo
   if (nts < 1 || nts > 15) return h->fail(BA_ERR_STATE, "k_schur_groups_mfma3: %d tiles per side", nts);
   // windows of at most 10 cameras with 6 points per batch everywhere (the north-star scenes): row length and k-steps fixed
   if (nts == 4 && L.G.np_cap == kGmPts && L.G.Kbuf == kGmK && L.uniform_ks) return launch_mfma3<0, 4, 64, 5>(h, L, p, damping, fuse_cam, true);
-  int rc = nts == 5 ? launch_mfma3<0, 5>(h, L, p, damping, fuse_cam, true) : launch_mfma3<0, 4>(h, L, p, damping, fuse_cam, true);
+  // (windows of 11 .. 13 cameras: the row length fixed as well - addresses of the staged rows become immediates)
+  int rc = nts == 5 ? (L.G.Ld == 80 ? launch_mfma3<0, 5, 80, 0>(h, L, p, damping, fuse_cam, true) : launch_mfma3<0, 5>(h, L, p, damping, fuse_cam, true))
+                    : launch_mfma3<0, 4>(h, L, p, damping, fuse_cam, true);
   if (rc == BA_OK && nts >= 6) rc = launch_mfma3<4, 6>(h, L, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, L, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, L, p, damping, fuse_cam, false);
