@@ -80,7 +80,8 @@ int ba_synchronize(ba_handle* h);
  *   "fused_backsolve" 1 | 0                                all back-substitution levels of the cyclic reduction in one launch (when its
  *                                                          nodes fit the chip at once) / one launch per level
  *   "solver"        auto | bcr | band | dense | lu | bcr1  force the reduced solver (lu: always report -1 = caller's LU; bcr1: the
- *                                                          cyclic reduction with one compute unit per node instead of three)
+ *                                                          cyclic reduction with one compute unit per node instead of three -
+ *                                                          for nodes of 12 and 13 cameras that is the wide solver's kernels)
  *   "point_kernels" auto | v1                              lanes-per-point k_linearize / k_backsub instead of the group-packed ones
  *   "fuse_cost" "fuse_cam"   1 | 0                         pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1)
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
@@ -259,7 +260,8 @@ int ba_set_dense_visibility(ba_handle* h, int32_t on);
 
 /* ---- BundleAdjuster.solve_motion_normal_eqns (bundle_adjuster.py:281-312)
  * Device-resident solve of the reduced camera system.  Cholesky first, by block half-bandwidth hb: block cyclic
- * reduction with LDS-resident nodes (hb <= 23), a single-workgroup band Cholesky (fewer than 4 super-blocks), block
+ * reduction with LDS-resident nodes (hb <= 23: all levels and the back-substitution in ONE launch up to 13 cameras per node,
+ * four kernels per level beyond), a single-workgroup band Cholesky (fewer than 4 super-blocks), block
  * cyclic reduction with nodes in device memory - every level a batched partial dense Cholesky (hb > 23 and at least
  * four nodes of hb cameras: BA_SOLVE_BCR_BIG, any number of cameras), or a dense blocked Cholesky of the whole matrix
  * (hb > 23 and fewer nodes, up to 16000 unknowns).  A system the Cholesky solver reports as not positive definite is

@@ -14,7 +14,7 @@ from . import _capi as capi
 from ._capi import PARAMS_CUR, PARAMS_TRIAL  # noqa: F401  (re-exported)
 
 # the dense-visibility REDUCTION (ba_set_dense_visibility) is worth it once the band is this wide; it does not decide the
-# solver: half-bandwidths up to 23 (kBcrwMaxHB of ba_bcr_wide.h) still go through the wide cyclic reduction, the dense
+# solver: half-bandwidths up to 13 go through the one-launch cyclic reduction, up to 23 (kBcrwMaxHB of ba_bcr_wide.h) through the wide one, the dense
 # blocked Cholesky takes over beyond
 DENSE_MIN_HALF_BANDWIDTH = 21
 DENSE_MIN_FILL = 0.25             # observed fraction of the (camera, track) pairs
