@@ -27,7 +27,7 @@ def make_case(seed):
         L = int(rs.choice([5, 10, 12, 18, 30]))
         nc = int(rs.randint(200, 320))
     elif seed < 60:
-        L = int(rs.choice([2, 3, 5, 7, 9, 10, 11, 12, 13, 15, 16, 17, 19, 21, 24]))
+        L = int(rs.choice([2, 3, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 21, 24]))
         nc = int(rs.randint(max(L + 3, 12), 90))
     else:                                                  # long tracks (round 3): windows of 25 .. 40 cameras
         L = int(rs.choice([25, 27, 30, 32, 33, 36, 40]))
