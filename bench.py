@@ -397,6 +397,8 @@ OTHER_CONFIGS = [   # label, BASELINE config, sensor, outliers, shuffle, drop
     ('config3_2pct_tracks_of_80_cameras', 3, 'gaussian', 0., False, 0., 10, (50, 80)),      # a few long tracks: pairs of 32-camera segments on the matrix cores, half-bandwidth 79
     ('config5_one_gpu', 5, 'gaussian', 0., False, 0.),
     ('config5_10_loop_closure_tracks', 5, 'gaussian', 0., False, 0., 10, None, 'loops'),
+    ('config3_track_length_13', 3, 'gaussian', 0., False, 0., 13),      # nodes of 12 cameras: since round 5 in the one-launch cyclic reduction (0.44 ms before)
+    ('config3_track_length_16', 3, 'gaussian', 0., False, 0., 16),      # windows of six tiles a side (two launches of the reduction), cyclic reduction with four kernels per level
     ('config3_track_length_32', 3, 'gaussian', 0., False, 0., 32),      # long tracks: windows of 32 cameras on the matrix cores (k_schur_wide_mfma), cyclic reduction with 192-unknown nodes in device memory
 ]
 
