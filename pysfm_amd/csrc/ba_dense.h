@@ -65,12 +65,12 @@ __global__ __launch_bounds__(256) void k_dense_gather(int nco, int hb, const dou
 // list index idx -> matrix row:
 __device__ __forceinline__ int dense_row(int idx, int total, int kn, int n) { return idx == total - 1 ? n : kn + idx; }
 
-// blockIdx.z: one of several matrices (batch_stride doubles apart: the big-node cyclic reduction of ba_bcr_big.h)
-__global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int total, double* __restrict__ A,
-                                                      int* __restrict__ info, size_t batch_stride = 0) {
+// One workgroup of a panel step (chunk = which kDcRows rows of the list are mine).  fnb > 0: the block column has NOT yet received
+// what it owes to the panel before it, P = A[., fk0 .. fk0 + fnb) - the rows this workgroup holds take it here,
+// C -= P_rows P_diag^T (k_dense_step: the step's own trailing update runs beside it on the rest of the matrix).
+__device__ __forceinline__ void dense_panel_body(int n, int k0, int nb, int total, double* __restrict__ A, int* __restrict__ info,
+                                                 int chunk, int fk0, int fnb, double* __restrict__ sm) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
-  A += (size_t)blockIdx.z * batch_stride;
-  extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int ld = kDcLd;
   double* G = sm;                                  // [kDcM][ld]: rows 0..nb-1 = A_kk, rows nb.. = my panel rows
   double* dinv = G + (size_t)kDcM * ld;            // [48]
@@ -79,13 +79,83 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   const int kn = k0 + nb;
-  const int q0 = blockIdx.x * kDcRows;             // my first panel row, as an index into the row list
+  const int q0 = chunk * kDcRows;                  // my first panel row, as an index into the row list
   const int cnt = max(0, min(kDcRows, total - q0));
   const int M = nb + cnt;
   if (tid == 0) *bad = 0;
   if (tid < 192) Li[tid] = 0.0;
   double* Idt = Li + 192;
   bcr_identity_table(Idt, tid);
+  if (fnb > 0) {
+    // ---- the rows I hold have not yet received the update of the panel before mine: C -= P_rows P_diag^T, P = A[., fk0 .. fk0 + fnb).
+    // P's rows (the diagonal block's nb, then mine) go through LDS IN G'S PLACE (lanes along a row: whole cache lines; operands read
+    // straight from memory, a lane a row, cost 21 us a step); the tiles of C come from memory into the accumulators, and G is
+    // written from them once every wavefront has read its operands.
+    __builtin_amdgcn_s_setprio(2);                  // a panel workgroup is the step's critical path: ahead of the update's wavefronts on this unit
+    double* X = G;                                  // [M][ld]
+    {
+      constexpr int U = ((kDcNB + kDcRows) * kDcNB + 1023) / 1024;
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = tid + 1024 * u, row = e / kDcNB, col = e - row * kDcNB;
+        const int gr = row < nb ? k0 + row : dense_row(q0 + row - nb, total, kn, n);
+        v[u] = (row < M && col < fnb) ? A[(size_t)gr * n + fk0 + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = tid + 1024 * u, row = e / kDcNB, col = e - row * kDcNB;
+        if (row < kDcNB + kDcRows) X[row * ld + col] = v[u];
+      }
+    }
+    const int ntr = (M + 15) >> 4, ntc = (nb + 15) >> 4;          // <= 7 x 3 tiles: at most two per wavefront
+    mfma_acc hold[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    // (the tiles' own entries first: their loads are in flight while P arrives in LDS)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = wave + 16 * u;
+      if (t < ntr * ntc) {
+        const int tr = t / ntc, tc = t - tr * ntc, col = 16 * tc + lr;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * tr + lk + 4 * v;
+          const bool ok = row < M && col < nb && (row >= nb || col <= row);
+          const int gr = row < nb ? k0 + row : dense_row(q0 + (row < M ? row : nb) - nb, total, kn, n);
+          hold[u][v] = ok ? A[(size_t)gr * n + k0 + col] : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = wave + 16 * u;
+      if (t < ntr * ntc) {
+        const int tr = t / ntc, tc = t - tr * ntc;
+        const double* pa = X + (16 * tr + lr) * ld + lk;
+        const double* pb = X + (16 * tc + lr) * ld + lk;
+        double av[kDcNB / 4], bv[kDcNB / 4];
+#pragma unroll
+        for (int q = 0; q < kDcNB / 4; ++q) { av[q] = pa[4 * q]; bv[q] = -pb[4 * q]; }
+#pragma unroll
+        for (int q = 0; q < kDcNB / 4; ++q) hold[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], hold[u], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                // every operand has been read: G takes X's place
+    for (int e = tid; e < kDcM * ld; e += 1024) G[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = wave + 16 * u;
+      if (t < ntr * ntc) {
+        const int tr = t / ntc, tc = t - tr * ntc, col = 16 * tc + lr;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * tr + lk + 4 * v;
+          if (row < M && col < nb && (row >= nb || col <= row)) G[row * ld + col] = hold[u][v];
+        }
+      }
+    }
+  } else
   // fill: 9 entries per thread, loads first (their latencies overlap), then the LDS stores
   {
     constexpr int NE = kDcM * kDcNB, U = (NE + 1023) / 1024;
@@ -105,14 +175,17 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
     }
     if (tid < kDcM) G[tid * ld + kDcNB] = 0.0;      // the padding column
   }
+
   __syncthreads();
 #pragma unroll 1
   for (int j0 = 0; j0 < nb; j0 += 12) {
     const int nbi = nb - j0 < 12 ? nb - j0 : 12;    // 12, or 6 at the very end of the matrix
     const int jn = j0 + nbi;
     if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);                // (k_dense_step: wavefronts of the trailing update share this compute unit)
       if (nbi == 12) bcr_diag_block<12>(G, ld, dinv, bad, j0, lane, Li, Idt);
       else bcr_diag_block<6>(G, ld, dinv, bad, j0, lane, Li, Idt);
+      if (fnb > 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     // rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront (below a 6-unknown block: the right-hand side row)
@@ -152,21 +225,30 @@ __global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int
     const int row = e / kDcNB, col = e - row * kDcNB;
     if (col >= nb) continue;
     if (row < nb) {
-      if (blockIdx.x == 0 && col <= row) A[(size_t)(k0 + row) * n + k0 + col] = col == row ? dinv[row] : G[row * ld + col];
+      if (chunk == 0 && col <= row) A[(size_t)(k0 + row) * n + k0 + col] = col == row ? dinv[row] : G[row * ld + col];
     } else {
       A[(size_t)dense_row(q0 + row - nb, total, kn, n) * n + k0 + col] = G[row * ld + col];
     }
   }
 }
 
-// ---- trailing update: A[i][j] -= sum_c P[i][c] P[j][c] for kn <= j <= i <= n, P = A[., k0 .. k0 + nb)
-__global__ __launch_bounds__(1024) void k_dense_update(int n, int k0, int nb, int total, double* __restrict__ A, size_t batch_stride = 0) {
+__global__ __launch_bounds__(1024) void k_dense_panel(int n, int k0, int nb, int total, double* __restrict__ A,
+                                                      int* __restrict__ info, size_t batch_stride = 0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  dense_panel_body(n, k0, nb, total, A + (size_t)blockIdx.z * batch_stride, info, blockIdx.x, 0, 0, sm);
+}
+
+// ---- trailing update: A[i][j] -= sum_c P[i][c] P[j][c] for kn <= j <= i <= n, P = A[., k0 .. k0 + nb); tile (ti, tj) of the
+// trailing rows' list.  kn: the first row of the region that is updated (the step's own k0 + nb - or, in k_dense_step, the row
+// behind the NEXT block column, whose workgroups fold this update into their panel step), total: rows of that region + 1.
+__host__ __device__ inline size_t dense_update_lds_bytes() { return (size_t)2 * kDcTile * kDcLd * sizeof(double); }
+__device__ __forceinline__ void dense_update_body(int n, int k0, int nb, int kn, int total, double* __restrict__ A, int ti, int tj,
+                                                  double* __restrict__ sm) {
   typedef double mfma_acc __attribute__((ext_vector_type(4)));
-  A += (size_t)blockIdx.z * batch_stride;
-  __shared__ double Pi[kDcTile * kDcLd], Pj[kDcTile * kDcLd];
-  const int ti = blockIdx.x, tj = blockIdx.y;
+  double* Pi = sm;                                 // [kDcTile][kDcLd]
+  double* Pj = sm + kDcTile * kDcLd;
   if (tj > ti) return;
-  const int kn = k0 + nb, i0 = kDcTile * ti, j0 = kDcTile * tj;          // list indices
+  const int i0 = kDcTile * ti, j0 = kDcTile * tj;                        // list indices
   if (j0 >= total - 1) return;                                            // the last entry (row n) is not a column
   const int tid = threadIdx.x;
   {
@@ -205,6 +287,36 @@ __global__ __launch_bounds__(1024) void k_dense_update(int n, int k0, int nb, in
 #pragma unroll
   for (int v = 0; v < 4; ++v)
     if (cok && rowb + 4 * v < total) *Cp[v] = acc[v];
+}
+
+__global__ __launch_bounds__(1024) void k_dense_update(int n, int k0, int nb, int total, double* __restrict__ A, size_t batch_stride = 0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  dense_update_body(n, k0, nb, k0 + nb, total, A + (size_t)blockIdx.z * batch_stride, blockIdx.x, blockIdx.y, sm);
+}
+
+__host__ __device__ inline size_t dense_step_lds_bytes() { return dense_panel_lds_bytes() > dense_update_lds_bytes() ? dense_panel_lds_bytes() : dense_update_lds_bytes(); }
+// ---- ONE launch per block column (round 5).  The panel step of block column k + 1 needs nothing of step k's trailing update
+// but the part that lands on its own columns - and every panel workgroup can form that part for the rows it holds (the
+// diagonal block's, redundantly, and its own 64): so the workgroups of panel k + 1 (blockIdx.x < npanel, the update folded in) run
+// BESIDE those of update k on everything right of block column k + 1 (the lower-triangular tiles, in a line).  A step costs
+// max(panel, update) instead of their sum, and half the launches; no workgroup waits for another.
+//   n1 / total1: rows of block column k + 1 = [k1, k1 + n1) and of the list behind it (as k_dense_panel's nb / total)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_dense_step(int n, int k0, int nb, int k1, int n1, int total1, int npanel, int T,
+                                                     double* __restrict__ A, int* __restrict__ info, size_t batch_stride = 0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  A += (size_t)blockIdx.z * batch_stride;
+  if ((int)blockIdx.x < npanel) {
+    dense_panel_body(n, k1, n1, total1, A, info, blockIdx.x, k0, nb, sm);
+    return;
+  }
+  // tile t of the lower triangle, row by row: t = ti (ti + 1) / 2 + tj
+  const int t = blockIdx.x - npanel;
+  int ti = (int)((__fsqrt_rn(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  while (ti * (ti + 1) / 2 > t) --ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  if (ti >= T) return;
+  dense_update_body(n, k0, nb, k1 + n1, total1, A, ti, tj, sm);
 }
 
 // ---- x = L^-T y (y = row n of A), one workgroup; x[n] out.  Block columns right to left; per block

@@ -80,6 +80,7 @@ int solve_bcr_big(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->bigK.resize((size_t)N * KS));
   HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_panel));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_step));
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_big_backsolve));
   int* info = h->flags.p + 1;
   {
@@ -93,17 +94,32 @@ int solve_bcr_big(ba_handle* h, const unsigned char* dmask) {
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) { levels.push_back({s, (N / s + 1) / 2, slots}); slots += (N / s + 1) / 2; }
   const int npanels = (B + kDcNB - 1) / kDcNB;
   {
-    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)levels.size() * (2 * npanels + 2));
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (int)levels.size() * ((h->opt.dense_lookahead ? npanels + 1 : 2 * npanels) + 2));
     for (const Level& L : levels) {
       double* K = h->bigK.p + L.base * KS;
       hipLaunchKernelGGL(k_big_gather, dim3(std::min(n + 1, 128), L.cnt), dim3(256), 0, h->stream, N, B, L.s, h->bcrD.p, h->bcrU.p,
                          h->bcrF.p, K, KS);
+      // the first panel step, then ONE launch per block column: panel step of the next column beside this column's trailing update
+      // (k_dense_step); the last column's update on its own (the trailing 2 B x 2 B block is what the level is for)
       for (int k0 = 0; k0 < B; k0 += kDcNB) {
         const int nb = std::min(kDcNB, B - k0), kn = k0 + nb, total = n - kn + 1;      // every row below the block + the right-hand side row
-        hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows, 1, L.cnt), dim3(1024), dense_panel_lds_bytes(), h->stream,
-                           n, k0, nb, total, K, info, KS);
-        const int T = (total + kDcTile - 1) / kDcTile;
-        hipLaunchKernelGGL(k_dense_update, dim3(T, T, L.cnt), dim3(1024), 0, h->stream, n, k0, nb, total, K, KS);
+        if (k0 == 0)
+          hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows, 1, L.cnt), dim3(1024), dense_panel_lds_bytes(), h->stream,
+                             n, k0, nb, total, K, info, KS);
+        if (kn < B && h->opt.dense_lookahead) {
+          const int n1 = std::min(kDcNB, B - kn), total1 = n - (kn + n1) + 1;
+          const int npanel = (total1 + kDcRows - 1) / kDcRows, T = (total1 + kDcTile - 1) / kDcTile;
+          hipLaunchKernelGGL(k_dense_step, dim3(npanel + T * (T + 1) / 2, 1, L.cnt), dim3(1024), dense_step_lds_bytes(), h->stream, n, k0, nb,
+                             kn, n1, total1, npanel, T, K, info, KS);
+        } else {
+          const int T = (total + kDcTile - 1) / kDcTile;
+          hipLaunchKernelGGL(k_dense_update, dim3(T, T, L.cnt), dim3(1024), dense_update_lds_bytes(), h->stream, n, k0, nb, total, K, KS);
+          if (kn < B) {
+            const int n1 = std::min(kDcNB, B - kn), total1 = n - (kn + n1) + 1;
+            hipLaunchKernelGGL(k_dense_panel, dim3((total1 + kDcRows - 1) / kDcRows, 1, L.cnt), dim3(1024), dense_panel_lds_bytes(), h->stream,
+                               n, kn, n1, total1, K, info, KS);
+          }
+        }
       }
       const int nsurv = (N + 1) / (2 * L.s);       // nodes m = 2 s (y + 1) - 1 < N
       if (nsurv > 0)
@@ -127,21 +143,32 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->denseA.resize((size_t)(n + 1) * n));
   HIPCHECK(h, h->dC.resize((size_t)n + 16));
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_panel));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_step));
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_backsolve));
   int* info = h->flags.p + 1;
   double* A = h->denseA.p;
   const int nsteps = (n + kDcNB - 1) / kDcNB;
-  ScopedTimer tm(h, BA_K_DENSE_SOLVE, 2 * nsteps + 1);
+  ScopedTimer tm(h, BA_K_DENSE_SOLVE, (h->opt.dense_lookahead ? nsteps : 2 * nsteps - 1) + 2);
   hipLaunchKernelGGL(k_dense_gather, dim3(n + 1), dim3(256), 0, h->stream, h->nco, h->hb, h->S, h->b, dmask, A, info);
   const int bw = std::min(n, 6 * (h->hb + 1) - 1);            // S[r][c] = 0 for |r - c| > bw
   for (int k0 = 0; k0 < n; k0 += kDcNB) {
     const int nb = std::min(kDcNB, n - k0), kn = k0 + nb;
     const int total = std::min(n, kn + bw) - kn + 1;           // rows below the block that can be non-zero + the rhs row
-    hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows), dim3(1024), dense_panel_lds_bytes(), h->stream, n,
-                       k0, nb, total, A, info);
-    if (total > 1) {
+    if (k0 == 0)
+      hipLaunchKernelGGL(k_dense_panel, dim3((total + kDcRows - 1) / kDcRows), dim3(1024), dense_panel_lds_bytes(), h->stream, n,
+                         k0, nb, total, A, info);
+    if (kn >= n) break;                                        // (the last block column: only the right-hand side row is behind it - done by its panel step)
+    const int n1 = std::min(kDcNB, n - kn), kn1 = kn + n1, total1 = std::min(n, kn1 + bw) - kn1 + 1;
+    if (h->opt.dense_lookahead) {
+      // the next block column's panel step beside this one's trailing update (k_dense_step)
+      const int npanel = (total1 + kDcRows - 1) / kDcRows, T = (total1 + kDcTile - 1) / kDcTile;
+      hipLaunchKernelGGL(k_dense_step, dim3(npanel + T * (T + 1) / 2), dim3(1024), dense_step_lds_bytes(), h->stream, n, k0, nb, kn, n1, total1,
+                         npanel, T, A, info);
+    } else {
       const int T = (total + kDcTile - 1) / kDcTile;
-      hipLaunchKernelGGL(k_dense_update, dim3(T, T), dim3(1024), 0, h->stream, n, k0, nb, total, A);
+      hipLaunchKernelGGL(k_dense_update, dim3(T, T), dim3(1024), dense_update_lds_bytes(), h->stream, n, k0, nb, total, A);
+      hipLaunchKernelGGL(k_dense_panel, dim3((total1 + kDcRows - 1) / kDcRows), dim3(1024), dense_panel_lds_bytes(), h->stream, n,
+                         kn, n1, total1, A, info);
     }
   }
   hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(1024), dense_backsolve_lds_bytes(n), h->stream, n, bw, A, h->dC.p, info);
