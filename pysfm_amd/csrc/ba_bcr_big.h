@@ -83,10 +83,58 @@ __global__ __launch_bounds__(256) void k_big_scatter(int N, int B, int s, int cn
   }
 }
 
+// t_i += (rows of [Y_a; Y_c] of this workgroup)^T (their part of [x_a; x_c]): what the neighbours' solutions take out of node i's
+// right-hand side, spread over ceil(2 B / kBigMvRows) workgroups per node (round 5).  Inside k_big_backsolve ONE workgroup streamed
+// the 2 B x B doubles of a node (3.7 MB at B = 480: 40 of the kernel's 92 us).  t is cleared once per solve.
+constexpr int kBigMvRows = 64;
+__global__ __launch_bounds__(1024) void k_big_backsolve_rhs(int N, int B, int s, const double* __restrict__ K, size_t batch_stride,
+                                                            const double* __restrict__ x, double* __restrict__ t,
+                                                            const int* __restrict__ info) {
+  __shared__ double red[1024];
+  __shared__ double xs[kBigMvRows];
+  if (*info != 0) return;
+  const int i = s * (2 * blockIdx.y + 1) - 1, a = i - s, c = i + s;
+  const int n = 3 * B, tid = threadIdx.x;
+  const double* Ki = K + (size_t)blockIdx.y * batch_stride;
+  const int r0g = a >= 0 ? 0 : B, r1g = c < N ? 2 * B : B;          // (rows of a neighbour that does not exist are zeros)
+  const int rb = r0g + blockIdx.x * kBigMvRows, re = min(r1g, rb + kBigMvRows);
+  if (rb >= re) return;
+  if (tid < re - rb) {
+    const int r = rb + tid, node = r < B ? a : c;
+    xs[tid] = x[(size_t)node * B + (r < B ? r : r - B)];
+  }
+  __syncthreads();
+  const int cols = min((B + 63) & ~63, 1024), ng = max(1, 1024 / cols), g = tid / cols, k = tid - g * cols;
+  for (int k0 = 0; k0 < B; k0 += cols) {
+    double acc = 0.0;
+    if (g < ng && k0 + k < B) {
+      const double* p = Ki + (size_t)B * n + k0 + k;
+      int r = rb + g;
+      for (; r + 7 * ng < re; r += 8 * ng) {                         // eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * ng) * n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u] * xs[r + u * ng - rb];
+      }
+      for (; r < re; r += ng) acc += p[(size_t)r * n] * xs[r - rb];
+    }
+    if (g < ng) red[g * cols + k] = acc;
+    __syncthreads();
+    if (tid < cols && k0 + tid < B) {
+      double sum = 0.0;
+      for (int q = 0; q < ng; ++q) sum += red[q * cols + tid];
+      atomic_add_f64(t + (size_t)i * B + k0 + tid, sum);
+    }
+    __syncthreads();
+  }
+}
+
 // x_i = L^-T (y_f - Y_a x_a - Y_c x_c) for the nodes eliminated at stride s; x is the solution vector itself (node i's
-// unknowns are x[i B ..]: 6 cb cameras' worth)
+// unknowns are x[i B ..]: 6 cb cameras' worth).  tpre: Y_a x_a + Y_c x_c formed by k_big_backsolve_rhs (null: formed here).
 __global__ __launch_bounds__(1024) void k_big_backsolve(int N, int B, int s, const double* __restrict__ K, size_t batch_stride,
-                                                        double* __restrict__ x, const int* __restrict__ info) {
+                                                        double* __restrict__ x, const int* __restrict__ info,
+                                                        const double* __restrict__ tpre = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   if (*info != 0) return;
   const int i = s * (2 * blockIdx.x + 1) - 1, a = i - s, c = i + s;
@@ -95,6 +143,9 @@ __global__ __launch_bounds__(1024) void k_big_backsolve(int N, int B, int s, con
   double* w = sm;                                                    // [B]: the body's vector
   double* xn = sm + dense_backsolve_lds_bytes(B) / sizeof(double);   // [2 B]: x_a | x_c
   double* red = w + B + kDcNB * kDcLd + kDcNB;                       // [1024] (the body's own scratch, free until it starts)
+  if (tpre) {
+    for (int j = tid; j < B; j += 1024) w[j] = Ki[(size_t)n * n + j] - tpre[(size_t)i * B + j];
+  } else {
   for (int j = tid; j < 2 * B; j += 1024) {
     const int node = j < B ? a : c;
     xn[j] = (node >= 0 && node < N) ? x[(size_t)node * B + (j < B ? j : j - B)] : 0.0;
@@ -128,6 +179,7 @@ __global__ __launch_bounds__(1024) void k_big_backsolve(int N, int B, int s, con
       w[k0 + tid] = Ki[(size_t)n * n + k0 + tid] - t;
     }
     __syncthreads();
+  }
   }
   dense_backsolve_body(B, n, B, Ki, sm);
   for (int j = tid; j < B; j += 1024) x[(size_t)i * B + j] = w[j];

@@ -78,6 +78,7 @@ int solve_bcr_big(ba_handle* h, const unsigned char* dmask) {
   const size_t BB = (size_t)B * B, KS = big_matrix_doubles(B);
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrF.resize((size_t)N * B));
   HIPCHECK(h, h->bigK.resize((size_t)N * KS));
+  HIPCHECK(h, h->bcrGv.resize((size_t)N * B));
   HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_panel));
   HIPCHECK(h, ensure_lds_attr(h, (const void*)k_dense_step));
@@ -127,11 +128,19 @@ int solve_bcr_big(ba_handle* h, const unsigned char* dmask) {
                            h->bcrF.p, K, KS);
     }
   }
-  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)levels.size());
+  // back-substitution, root down: what the neighbours' solutions take out of a node's right-hand side over many workgroups
+  // (k_big_backsolve_rhs, into bcrGv), then one workgroup per node for the triangular solve
+  const bool split_rhs = h->opt.dense_lookahead;
+  if (split_rhs) HIPCHECK(h, hipMemsetAsync(h->bcrGv.p, 0, (size_t)N * B * sizeof(double), h->stream));
+  ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)levels.size() * (split_rhs ? 2 : 1));
   for (int q = (int)levels.size() - 1; q >= 0; --q) {
     const Level& L = levels[q];
+    const bool has_nb = N > 1 && !(L.cnt == 1 && 2 * L.s - 1 >= N);      // (the root has no neighbours)
+    if (split_rhs && has_nb)
+      hipLaunchKernelGGL(k_big_backsolve_rhs, dim3((2 * B + kBigMvRows - 1) / kBigMvRows, L.cnt), dim3(1024), 0, h->stream, N, B, L.s,
+                         h->bigK.p + L.base * KS, KS, h->dC.p, h->bcrGv.p, info);
     hipLaunchKernelGGL(k_big_backsolve, dim3(L.cnt), dim3(1024), big_backsolve_lds_bytes(B), h->stream, N, B, L.s,
-                       h->bigK.p + L.base * KS, KS, h->dC.p, info);
+                       h->bigK.p + L.base * KS, KS, h->dC.p, info, split_rhs ? h->bcrGv.p : nullptr);
   }
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
