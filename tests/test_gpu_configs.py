@@ -1145,7 +1145,7 @@ def test_full_lm25_run_against_the_oracle_golden_walk(name):
 def test_device_solve_is_as_accurate_as_lapack_where_the_walk_is_sensitive():
     """Config 3 after five LM steps, damping 1e-3 (the first place where the device's walk and the oracle's part): on the SAME
     [S | b], the device's solution leaves a residual ||S dC - b|| / ||b|| no larger than twice that of numpy.linalg.solve (LAPACK
-    gesv, what the reference calls: bundle_adjuster.py:303) and agrees with LAPACK's Cholesky solution as closely as LAPACK's LU
+    gesv, what the reference calls: bundle_adjuster.py:303; or five units of round-off, whichever is larger) and agrees with LAPACK's Cholesky solution as closely as LAPACK's LU
     does - the sensitivity is the system's (condition number > 1e12), not the solver's."""
     import scipy.linalg as sl
     from pysfm_amd import Bundle, BundleAdjuster, sensor_model
@@ -1168,7 +1168,9 @@ def test_device_solve_is_as_accurate_as_lapack_where_the_walk_is_sensitive():
     x_lu = np.linalg.solve(A, rhs)
     x_ch = sl.cho_solve(sl.cho_factor(A), rhs)
     res = lambda x: np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs)
-    assert res(x_dev) <= 2. * max(res(x_lu), res(x_ch)), (res(x_dev), res(x_lu), res(x_ch))
+    # (twice LAPACK's, or five units of round-off: the scene after five steps is not the same to the last bit from run to run - LAPACK's own
+    #  residual came out between 2.6e-16 and 7e-16 - and the order of the device's fp64 atomics is not either)
+    assert res(x_dev) <= max(2. * max(res(x_lu), res(x_ch)), 1.1e-15), (res(x_dev), res(x_lu), res(x_ch))
     assert np.linalg.norm(x_dev - x_ch) <= 2. * np.linalg.norm(x_lu - x_ch) + 1e-14 * np.linalg.norm(x_ch)
     ba.backend.close()
 
