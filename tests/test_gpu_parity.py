@@ -267,6 +267,40 @@ def test_bundle_adjuster_optimize_vs_reference(name, steps):
     close(su, osu, SOLVE)
 
 
+def test_renumbered_cameras_and_loop_closures_vs_reference(be):
+    """tests/golden/scene_loop_closure_60x424.npz (oracle/gen_golden_layout.py): numbers of the REFERENCE on a scene whose 60 cameras are
+    numbered at random and four of whose points tie cameras 30 apart along the sequence.  The reference's reduced system is dense
+    (bundle_adjuster.py:259-312); the library orders the cameras itself and makes the far ends of the loop closures a border of the
+    band (ba_order.hip, ba_border.h) - S, b, dC, dP in the CALLER's positions, the update and the LM walk must be the reference's."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model
+    g = load_golden('scene_loop_closure_60x424')
+    load_problem(be, *scene(g), g['l2_cam_opt_pos'], g['l2_pt_opt'].astype(np.uint8), sensor_of(g))
+    info = be.problem_info()
+    assert info['cameras_permuted'] == 1 and info['border_cameras'] > 0 and info['half_bandwidth'] <= 11 and info['caller_half_bandwidth'] > 30, info
+    be.linearize(0)
+    be.schur(0, 2., 1e-5)
+    S, b = be.get_reduced()
+    close(S, g['l2_S'], TIGHT)
+    close(b, g['l2_b'], TIGHT)
+    dC, dP = hip_update(be, 2.)
+    assert be.last_solve_kind == 'bcr'
+    close(dC, g['l2_dC'], SOLVE)
+    close(dP, g['l2_dP'], SOLVE)
+    close(be.cost(0), g['l2_cost'], 1e-12)
+    b0 = Bundle.FromObservations(*scene(g), sensor_model=sensor_model.GaussianModel(1.))
+    ba = BundleAdjuster(b0, verbose=False)
+    mu, su = ba.compute_update(2.)
+    close(mu, g['update_l2_motion'], SOLVE)
+    close(su, g['update_l2_structure'], SOLVE)
+    ba = BundleAdjuster(b0, verbose=False)
+    ba.optimize(max_steps=4)
+    assert ba.num_steps == int(g['lm_num_steps']) and ba.converged == bool(g['lm_converged'])
+    close(ba.costs, g['lm_costs'], LM)
+    close(ba.bundle.Rs(), g['lm_R'], LM)
+    close(ba.bundle.ts(), g['lm_t'], LM, 1e-9)
+    close(ba.bundle.reconstruction, g['lm_X'], LM)
+
+
 def test_bundle_api_on_device():
     from pysfm_amd import Bundle, sensor_model
     g = load_golden('scene_4x10_cauchy')

@@ -178,6 +178,41 @@ def test_lm_trajectory_matches_reference(name, steps):
     close(out['X'], g['lm_X'], 1e-6)
 
 
+def test_loop_closure_scene_with_renumbered_cameras_matches_reference():
+    """oracle/gen_golden_layout.py: 60 cameras renumbered at random, tracks of 5 + four loop-closure points - the reference's dense
+    reduced system does not know about camera order (bundle_adjuster.py:259-312); the oracle on the same arrays must reproduce its
+    S, b, dC, dP, update and LM walk."""
+    g = load_golden('scene_loop_closure_60x424')
+    s = sensor_of(g)
+    nc, nt = len(g['R']), len(g['X'])
+    HCC, HPP, W, bC, bP = O.normal_blocks(s, *scene_args(g), nc, nt)
+    for k, v in (('HCC', HCC), ('HPP', HPP), ('bC', bC), ('bP', bP)):
+        close(v, g['l2_' + k])
+    HPPi = O.invert_point_blocks(O.damp_blocks(HPP, 2.), 1e-5)
+    S, b = O.schur_complement(O.damp_blocks(HCC, 2.), HPPi, W, bC, bP, g['obs_cam'], g['obs_pt'], g['l2_cam_opt_pos'])
+    close(S, g['l2_S'])
+    close(b, g['l2_b'])
+    dC = O.solve_reduced(S, b, np.ones(S.shape[0] * 6, bool))
+    close(dC, g['l2_dC'])
+    close(O.backsubstitute(dC, HPPi, W, bP, g['obs_cam'], g['obs_pt'], g['l2_cam_opt_pos'], nt), g['l2_dP'])
+    close(O.cost(s, *scene_args(g), g['l2_cam_opt_pos'], g['l2_pt_opt']), g['l2_cost'])
+    mu, su = O.compute_update(s, *scene_args(g), g['l2_cam_opt_pos'], g['l2_pt_opt'], damping=2.)
+    close(mu, g['update_l2_motion'])
+    close(su, g['update_l2_structure'])
+    trace = []
+    out = O.lm_optimize(s, *scene_args(g), g['l2_cam_opt_pos'], g['l2_pt_opt'], max_steps=4, trace=trace)
+    assert out['num_steps'] == int(g['lm_num_steps']) and out['converged'] == bool(g['lm_converged'])
+    close(out['costs'], g['lm_costs'], 1e-7)
+    close([tr['next'] for tr in trace], g['lm_trials'][:, 1], 1e-7)
+    # the scene is what its name says: the cameras of a track are far apart in the caller's numbering, and four tracks tie
+    # cameras that are 30 apart along the sequence
+    spread = np.zeros(nt, int)
+    for k in range(nt):
+        c = g['obs_cam'][g['obs_pt'] == k]
+        spread[k] = c.max() - c.min()
+    assert np.median(spread) > 20
+
+
 def test_known_answers_5x50():
     g = load_golden('scene_5x50_gauss')
     want = [0.1515770559897651, 0.14507108508956248, 0.12678104023107856,
