@@ -123,7 +123,9 @@ int ba_debug_poison(ba_handle* h);
  * others (pysfm_amd/csrc/ba_border.h): ba_reduced_layout then describes B (rows of the border cameras unused), ba_get_reduced /
  * ba_get_solution return the full system / solution as always.  The layout with the lowest modelled solve cost among {caller's
  * order, Cuthill-McKee order} x {as it is, with a border} is taken (BA_INFO_BORDER_CAMERAS, BA_INFO_HALF_BANDWIDTH say which).
- * A bordered system that is not positive definite is reported through *info of the solve (no LU fallback there).
+ * A bordered system that is not positive definite is reported through *info of the solve (the device's LU solvers do not know the
+ * border; the Python host then solves ba_get_reduced's arrays with numpy.linalg.solve - the reference's own call - and hands the
+ * solution back through ba_set_solution, up to 16000 unknowns).
  *   obs_cam[nobs], obs_pt[nobs]  positions;  obs_z[nobs*2] measurements
  *   K[9]                         calibration (general 3x3)
  *   cam_opt_pos[nc]              position in optim_camera_ids, or -1 (frozen)
@@ -283,6 +285,9 @@ enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOL
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);
 int ba_get_solution(ba_handle* h, double* dC /*[nco*6] host*/);
+/* the caller's own solution of the reduced system (e.g. numpy.linalg.solve of ba_get_reduced's arrays) in place of the device's:
+ * ba_backsubstitute / ba_apply_update / ba_get_solution use it from here on; clears the solver's status word */
+int ba_set_solution(ba_handle* h, const double* dC /*[nco*6] host*/);
 /* For callers that want the reduced system as the reference forms it before its solve: the flat (6nco x 6nco) matrix
  * with rows / columns of masked camera parameters deleted (bundle_adjuster.py:290-299).  keep[nkeep] lists the kept
  * flat parameter indices (host).  A_dev[nkeep*nkeep], rhs_dev[nkeep] are caller-owned DEVICE buffers.  (The library's

@@ -80,6 +80,7 @@ PROTOTYPES = {
     'ba_solve_reduced': (C.c_int, [_h, _bp, C.POINTER(C.c_int32)]),
     'ba_last_solve_kind': (C.c_int, [_h]),
     'ba_get_solution': (C.c_int, [_h, _dp]),
+    'ba_set_solution': (C.c_int, [_h, _dp]),
     'ba_flatten_reduced': (C.c_int, [_h, _ip, C.c_int32, C.c_void_p, C.c_void_p]),
     'ba_backsubstitute': (C.c_int, [_h, C.c_int, _dp, _dp]),
     'ba_apply_update': (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp]),

@@ -295,8 +295,36 @@ class HipBackend(object):
             finally:
                 self._check(self._lib.ba_set_option(self._h, b'solver', before.encode()))
         self._note_solve(info.value)
+        if info.value > 0 and info.value != capi.SOLVE_TIMED_OUT and self.device_lu and self._host_lu_of_bordered_system(mask):
+            return
         if info.value != 0:
             raise ReducedSystemSingular
+
+    HOST_LU_MAX_UNKNOWNS = 16000            # (the dense matrix of the fall-back below: 2 GB)
+
+    def _host_lu_of_bordered_system(self, mask):
+        """A band + border system (csrc/ba_border.h) that is NOT positive definite: the device's LU solvers do not know the border, the
+        reference's numpy.linalg.solve takes any nonsingular matrix (bundle_adjuster.py:302-305).  Up to HOST_LU_MAX_UNKNOWNS unknowns the
+        system comes to the host, is solved there exactly as the reference does, and the solution goes back to the device
+        (ba_set_solution): last_solve_kind 'host_lu', last_solve_path 'lu'.  Returns False when this does not apply (no border, too
+        large, exactly singular): the caller then reports the system as the reference reports a LinAlgError."""
+        n = self.nco * 6
+        if n > self.HOST_LU_MAX_UNKNOWNS or self.problem_info().get('border_cameras', 0) <= 0:
+            return False
+        S, b = self.get_reduced()
+        A = S.transpose(0, 2, 1, 3).reshape(n, n)
+        keep = np.ones(n, bool) if mask is None else mask.astype(bool)
+        try:
+            x = np.linalg.solve(A[np.ix_(keep, keep)], b.reshape(n)[keep])
+        except np.linalg.LinAlgError:
+            return False
+        if not np.all(np.isfinite(x)):
+            return False
+        dC = np.zeros(n)
+        dC[keep] = x
+        self._check(self._lib.ba_set_solution(self._h, capi.dptr(dC)))
+        self.last_solve_kind, self.last_solve_path = 'host_lu', 'lu'
+        return True
 
     def get_solution(self):
         """dC[nco,6] of the last solve_reduced()."""

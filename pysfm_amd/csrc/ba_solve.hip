@@ -528,6 +528,25 @@ int ba_get_solution(ba_handle* h, double* dC) {
   return BA_OK;
 }
 
+// A solution of the reduced system computed by the caller (solve_motion_normal_eqns on host arrays, bundle_adjuster.py:281-312:
+// the Python host's LU of a band + border system that is not positive definite) becomes the device's: what ba_backsubstitute,
+// ba_apply_update and ba_get_solution use from here on.  dC in the caller's positions.
+int ba_set_solution(ba_handle* h, const double* dC) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_schur && dC, BA_ERR_STATE, "ba_set_solution: call ba_schur first (and pass a solution)");
+  HIPCHECK(h, hipSetDevice(h->device));
+  HIPCHECK(h, h->dC.resize((size_t)h->nco * 6 + 16));
+  if (h->nco) {
+    const double* src = cam_rows_in(h, dC, h->rows_host, 6);
+    HIPCHECK(h, hipMemcpyAsync(h->dC.p, src, (size_t)h->nco * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->flags.p + 1, 0, sizeof(int), h->stream));      // the status word of the solve this replaces
+    HIPCHECK(h, hipStreamSynchronize(h->stream));                                 // (rows_host / dC are the caller's and ours to reuse)
+  }
+  h->have_solution = true;
+  h->have_backsub = false;
+  return BA_OK;
+}
+
 int ba_dist_plan(int32_t nco, int32_t half_bandwidth, int32_t nranks, int32_t* cams_per_node, int32_t* nodes, int32_t* nodes_per_rank) {
   int cb = 0, N = 0, P = 0;
   if (!dist_plan_static(nco, half_bandwidth, nranks, &cb, &N, &P)) return BA_ERR_STATE;

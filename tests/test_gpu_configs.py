@@ -1142,6 +1142,45 @@ def test_full_lm25_run_against_the_oracle_golden_walk(name):
     ba.backend.close()
 
 
+def test_band_plus_border_system_that_is_not_positive_definite_is_solved_like_the_reference_lu(be):
+    """The reference solves its reduced system by LU (numpy.linalg.solve, bundle_adjuster.py:302-305) - also one that is not positive
+    definite.  A NEGATIVE damping makes such a system (indefinite, far from singular) on a scene with loop closures, where the
+    device solves band + border by Cholesky only: the C layer reports it (*info > 0, like every Cholesky solver), the Python host
+    then takes the system to numpy.linalg.solve - the reference's own call - and hands the solution back (ba_set_solution), so that
+    the back-substitution and the update run on the device as after any other solve."""
+    nc, nt = 120, 3000
+    s = _loop_scene(nc, nt, 8, [(5, 70), (20, 95), (33, 101)], 2)
+    nt = len(s['X0'])
+    flags = default_flags(nc, nt)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, *flags, O.Sensor.gaussian(1.))
+    assert be.problem_info()['border_cameras'] > 0
+    be.linearize(0)
+    be.schur(0, -.6, 1e-5)
+    S, b = be.get_reduced()
+    n = be.nco * 6
+    A = S.transpose(0, 2, 1, 3).reshape(n, n)
+    w = np.linalg.eigvalsh(A)
+    assert w[0] < 0 < w[-1] and np.min(np.abs(w)) > 1e-9 * np.max(np.abs(w))      # indefinite, not singular
+    for mask in (None, (np.arange(n) % 11 != 3).astype(np.uint8)):
+        be.set_option('device_lu', 0)
+        with pytest.raises(Exception):                                                # (without the LU semantics: reported, not solved)
+            be.solve_reduced(mask)
+        be.set_option('device_lu', 1)
+        be.solve_reduced(mask)
+        assert be.last_solve_kind == 'host_lu' and be.last_solve_path == 'lu'
+        x = be.get_solution().reshape(-1)
+        keep = np.arange(n) if mask is None else np.nonzero(mask)[0]
+        ref = np.linalg.solve(A[np.ix_(keep, keep)], b.reshape(-1)[keep])
+        close(x[keep], ref, 1e-12)
+        assert mask is None or np.all(x[mask == 0] == 0)
+        dP = be.backsubstitute(0)
+        assert np.all(np.isfinite(dP))
+        mu, su = O.compute_update(O.Sensor.gaussian(1.), *a, *flags, damping=-.6, cam_param_mask=None if mask is None else mask.astype(bool))
+        close(-x.reshape(-1, 6), mu, 1e-7)
+        close(-dP, su, 1e-7)
+
+
 def test_device_solve_is_as_accurate_as_lapack_where_the_walk_is_sensitive():
     """Config 3 after five LM steps, damping 1e-3 (the first place where the device's walk and the oracle's part): on the SAME
     [S | b], the device's solution leaves a residual ||S dC - b|| / ||b|| no larger than twice that of numpy.linalg.solve (LAPACK
