@@ -118,7 +118,7 @@ int ba_debug_poison(ba_handle* h);
  * by optimised position (S, b, dC, cam_param_mask, motion updates) stays in the CALLER's positions.  Not done for a handle with a
  * communicator or a minimum band width set (the ranks of a sharded adjuster share one layout).
  * BAND + BORDER: a camera sequence with a few long-range tracks (a loop closure: camera 3 and camera 503 see the same point)
- * has a narrow band but for those tracks.  When the band would be wider than the narrow cyclic reduction takes (11 cameras) and
+ * has a narrow band but for those tracks.  When the band would be wider than the narrow cyclic reduction's one-unit nodes (11 cameras) and
  * moving at most 21 cameras out of it makes it fit, those cameras become a border, S = [[B, C], [C^T, D]] with B the band of the
  * others (pysfm_amd/csrc/ba_border.h): ba_reduced_layout then describes B (rows of the border cameras unused), ba_get_reduced /
  * ba_get_solution return the full system / solution as always.  The layout with the lowest modelled solve cost among {caller's

@@ -184,8 +184,9 @@ bool plan_camera_layout(int nco, const std::vector<int>& loff, const std::vector
     const int hb = order_half_bandwidth(loff, mapped, ident);
     cands.push_back({pos, hb, 0, {}, layout_cost_us(hb, nco, 0)});
     // ... with a border: only where it brings the band down to what the narrow cyclic reduction takes
+    // (a band the one-launch cyclic reduction takes: up to kBcrSplitMaxHB cameras wide - its kept factors are what k_bcr_apply reads)
     if (hb > kBcrMaxHB && allow_border && nco >= 4 * kBcrMaxHB) {
-      for (int t = kBcrMaxHB; t >= 1; --t) {
+      for (int t = std::min(hb - 1, kBcrSplitMaxHB); t >= 1; --t) {
         std::vector<char> isb;                          // by position in this candidate's order
         const int k = choose_border(nco, loff, mapped, t, kBordMaxCamsHost, isb);
         if (k <= 0) break;                              // (narrower only ever needs more border cameras)

@@ -355,7 +355,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     // take the border's columns through, one workgroup solves the border system.  A system that is not positive definite is
     // REPORTED (*info > 0: the caller raises the damping, as for a LinAlgError of the reference) - the LU solvers do not know the border.
     REQUIRE(h, force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1, BA_ERR_STATE, "ba_solve_reduced: a problem with border cameras is solved by the cyclic reduction (option camera_order = off sets it up without a border)");
-    REQUIRE(h, h->band_cams() <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrMaxHB), BA_ERR_STATE, "ba_solve_reduced: border with a band the cyclic reduction does not take");
+    REQUIRE(h, h->band_cams() <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrSplitMaxHB), BA_ERR_STATE, "ba_solve_reduced: border with a band the cyclic reduction does not take");
     HIPCHECK(h, hipSetDevice(h->device));
     const unsigned char* dmaskb = nullptr;
     if (int rcm = dist_upload_mask(h, cam_param_mask, &dmaskb); rcm != BA_OK) return rcm;
