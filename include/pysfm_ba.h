@@ -79,6 +79,7 @@ int ba_synchronize(ba_handle* h);
  *                                                          sensor model (the reference's defaults); 0: the general formulas always
  *   "fused_backsolve" 1 | 0                                all back-substitution levels of the cyclic reduction in one launch (when its
  *                                                          nodes fit the chip at once) / one launch per level
+ *   "bcrw_merged"   1 | 0                                  wide cyclic reduction (nodes of 14 .. 23 cameras): factorisation and substitution of a level in one kernel / two
  *   "dense_lookahead" 1 | 0                                dense Cholesky / big-node levels: one launch per block column (the next panel step beside the
  *                                                          trailing update) / two
  *   "solver"        auto | bcr | band | dense | lu | bcr1  force the reduced solver (lu: always report -1 = caller's LU; bcr1: the

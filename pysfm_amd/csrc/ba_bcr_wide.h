@@ -14,6 +14,8 @@
 // (The first form of the solve, one lane per right-hand side with L through scalar loads, took 442 us per level.)
 #pragma once
 
+#include <type_traits>
+
 #include "ba_bcr_blocks.h"
 
 namespace ba {
@@ -21,6 +23,11 @@ namespace ba {
 constexpr int kBcrwLvLdsMaxB = 126;            // up to here the inverses of the diagonal blocks sit in LDS next to L; beyond, in L2
 
 __host__ __device__ inline size_t bcrw_factor_lds_bytes(int B) { return ((size_t)B * (B + 1) + B + 16 + 192 + kBcrIdtDoubles) * sizeof(double); }
+#ifndef BA_BCRW_FS_THREADS
+#define BA_BCRW_FS_THREADS 512
+#endif
+constexpr int kBcrwFsThreads = BA_BCRW_FS_THREADS;
+__host__ __device__ inline size_t bcrw_factor_solve_lds_bytes(int B) { return bcrw_factor_lds_bytes(B) + 192 * sizeof(double); }
 __host__ __device__ inline size_t bcrw_solve_lds_bytes(int B) {
   return ((size_t)B * (B + 1) + (B <= kBcrwLvLdsMaxB ? (size_t)((B + 11) / 12) * 144 : 0) + 64) * sizeof(double);
 }
@@ -164,6 +171,221 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcrw_factor(int N, int s, c
     Lm[(size_t)i * BB + e] = cc < rr ? G[rr * ld + cc] : (cc == rr ? dinv[rr] : 0.0);
   }
 }
+
+// ---- factor AND solve in one kernel (round 5): one workgroup per (node, 64 right-hand-side columns).  k_bcrw_factor keeps ONE compute
+// unit per node busy with the chain of B pivots while the rest of the chip waits, then k_bcrw_solve_mfma reads L back on six
+// workgroups per node.  Here each of those workgroups factors D_i for itself (redundant - the chain cannot be shared, and the
+// compute units are idle anyway), and four of its eight wavefronts (4 .. 7; 512 threads: 256 registers each, the right-hand sides
+// alone are 72 at B = 138) take 16 columns each of [T_il | T_ir | I | f] through
+// the substitution WHILE the factorisation runs, left-looking: at block step kb they finish Y_kb-1 = L_pp^-1 acc (the inverse of
+// diagonal block kb - 1 is in LDS since the step before) and form acc = R_kb - sum_{j < kb} L[kb, j] Y_j from the panels that are
+// final - 3 + 3 kb MFMAs, under the 12 pivots of wavefront 0.  The right-hand sides live in registers as in k_bcrw_solve_mfma
+// (3 NBLK values a lane).  A level: factor 17.9 + solve 12.9 us -> one launch (hb = 15).
+template <int HB>
+__global__ __launch_bounds__(kBcrwFsThreads) void k_bcrw_factor_solve(int N, int s, const double* __restrict__ Dm,
+                                                                      const double* __restrict__ Um, double* __restrict__ fm,
+                                                                      double* __restrict__ Pm, double* __restrict__ Qm,
+                                                                      double* __restrict__ Gi, int* __restrict__ info) {
+  typedef double mfma_acc __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int B = 6 * HB, ld = B + 1;
+  double* G = sm;                       // [B][ld]
+  double* dinv = G + (size_t)B * ld;    // [B]
+  int* bad = reinterpret_cast<int*>(dinv + B + 2);
+  double* Li = dinv + B + 16;           // [2][16][12]: inverse of diagonal block kb in half kb & 1 (rows 12..15 stay zero)
+  const int tid = threadIdx.x;
+  const int i = s * (2 * blockIdx.x + 1) - 1;
+  if (i >= N) return;
+  constexpr size_t BB = (size_t)B * B;
+  if (tid == 0) *bad = 0;
+  if (tid < 384) Li[tid] = 0.0;
+  double* Idt = Li + 384;
+  bcr_identity_table(Idt, tid);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  constexpr int NBLK = (B + 11) / 12;
+  // ---- my 16 right-hand-side columns (wavefronts 12 .. 15; as in k_bcrw_solve_mfma)
+  const int l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  constexpr int ncol = 3 * B + 1;
+  constexpr int NW = kBcrwFsThreads / 64;                    // wavefront 0: the chain; 1 .. NW - 5: the trailing updates; the last four: right-hand sides
+  const bool rhs_wave = wave >= NW - 4;
+  const int ct = blockIdx.y * 4 + (wave - (NW - 4));
+  const int c = 16 * ct + lr;
+  const bool live = rhs_wave && c < ncol;
+  const int grp = c < B ? 0 : c < 2 * B ? 1 : c < 3 * B ? 2 : 3;
+  const int cc = c - grp * B;
+  const bool loads = live && ((grp == 0 && haveL) || (grp == 1 && haveR) || grp == 3);
+  const double* rbase = !loads ? fm + (size_t)i * B
+                        : grp == 0 ? Um + (size_t)l * BB + (size_t)cc * B      // T[i,l] = T[l,i]^T
+                        : grp == 1 ? Um + (size_t)i * BB + cc                  // T[i,r]
+                                   : fm + (size_t)i * B;
+  const int rstride = (loads && grp == 1) ? B : 1;
+  const bool ident = live && grp == 2;
+  auto rhs = [&](int row) -> double {
+    const int rc = row < B ? row : B - 1;
+    const double v = rbase[rc * rstride];                    // always finite: a valid entry of U or f
+    return v * ((loads && row < B) ? 1.0 : 0.0) + ((ident && row == cc) ? 1.0 : 0.0);
+  };
+  double* out = grp == 0 ? Pm + (size_t)i * BB + cc : grp == 1 ? Qm + (size_t)i * BB + cc : grp == 2 ? Gi + (size_t)i * BB + cc
+                                                                                              : fm + (size_t)i * B;
+  const int ost = grp == 3 ? 1 : B;
+  // identity columns are zero above their own row: the whole tile is zero in block rows above its first column
+  const int c_lo = 16 * ct, zero_rows = (rhs_wave && c_lo >= 2 * B && c_lo + 15 < 3 * B) ? c_lo - 2 * B : 0;
+  double ny[NBLK][3];                                        // R (until its block row is solved), then -Y
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) ny[kb][v] = rhs_wave ? rhs(12 * kb + lk + 4 * v) : 0.0;
+  bcrw_fill<B, kBcrwFsThreads, 16>(G, Dm + (size_t)i * BB, tid);      // (the right-hand sides' loads are in flight under it)
+  __syncthreads();
+  mfma_acc racc = {ny[0][0], ny[0][1], ny[0][2], 0.0};      // R_kb - sum_{j < kb} L[kb, j] Y_j of the block row that is solved next
+  // one block row of the substitution: Y_p = L_pp^-1 racc (stored), then racc for block row p + 1
+  // (the block row a template parameter: with a run-time index the compiler keeps ny[][] in scratch memory)
+  auto rhs_step_c = [&](auto pc) __attribute__((always_inline)) {      // p = 0 .. NBLK - 1: the block row whose diagonal inverse is in Li[p & 1]
+    constexpr int p = decltype(pc)::value;
+    const double* Lp = Li + 192 * (p & 1);
+    constexpr int r0 = 12 * p;
+    if (r0 + 12 <= zero_rows) {                              // (wave-uniform) identity columns right of this block row: Y_p = 0
+      ny[p][0] = 0.0; ny[p][1] = 0.0; ny[p][2] = 0.0;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const int row = r0 + lk + 4 * v;
+        if (live && row < B) out[(size_t)row * ost] = 0.0;
+      }
+    } else {
+      mfma_acc y = {0.0, 0.0, 0.0, 0.0};
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + lk], racc[0], y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 4 + lk], racc[1], y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[lr * 12 + 8 + lk], racc[2], y, 0, 0, 0);
+      ny[p][0] = -y[0]; ny[p][1] = -y[1]; ny[p][2] = -y[2];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const int row = r0 + lk + 4 * v;
+        if (live && row < B) out[(size_t)row * ost] = y[v];
+      }
+    }
+    if constexpr (p + 1 < NBLK) {
+      // racc of block row p + 1: its right-hand side, then the panels 0 .. p (rows of block p + 1) times Y_0 .. Y_p
+      constexpr int kb = p + 1, k0r = 12 * kb;
+      constexpr bool tail = kb == NBLK - 1 && B % 12 != 0;   // 6 real rows: rows 6 .. 11 of the A operand lie beyond L - ZERO, not "whatever is there"
+      const double rowok = (!tail || k0r + lr < B) ? 1.0 : 0.0;
+      const int arow = (tail && k0r + lr >= B) ? B - 1 : k0r + lr;
+      racc = mfma_acc{ny[kb][0], ny[kb][1], ny[kb][2], 0.0};
+#pragma unroll
+      for (int j = 0; j < kb; ++j) {
+        if (12 * j + 12 > zero_rows) {                       // (wave-uniform; Y_j = 0 above the identity columns' first row)
+          const double* ap = G + arow * ld + 12 * j + lk;
+          const double a0 = tail ? ap[0] * rowok : ap[0], a1 = tail ? ap[4] * rowok : ap[4], a2 = tail ? ap[8] * rowok : ap[8];
+          racc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, ny[j][0], racc, 0, 0, 0);
+          racc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, ny[j][1], racc, 0, 0, 0);
+          racc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, ny[j][2], racc, 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto rhs_step = [&](int p) __attribute__((always_inline)) {
+    auto go = [&](auto self, auto c) __attribute__((always_inline)) {
+      constexpr int V = decltype(c)::value;
+      if constexpr (V < NBLK) {
+        if (p == V) rhs_step_c(c);
+        else self(self, std::integral_constant<int, V + 1>{});
+      }
+    };
+    go(go, std::integral_constant<int, 0>{});
+  };
+  double pr[3] = {0.0, 0.0, 0.0};                           // wavefront 0: the first tile of the panel, handed from phase 2 to the next phase 1
+  bcr_acc4 cpre = {0.0, 0.0, 0.0, 0.0};                     // and the tile it updates there
+#pragma unroll 1
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const int k0 = 12 * kb;
+    const bool last = kb == NBLK - 1;
+    const int nb = last ? B - k0 : 12;                      // this block: 12, or 6 at the end
+    const int kn = k0 + nb;
+    // ---------------- phase 1: diagonal factor (wavefront 0) | the late part of the previous step's update
+    // what block column kb still owes to the panel of block kb - 1 (C -= panel panel^T, K = 12), one 16-row tile per call: the
+    // tile holding the diagonal block by wavefront 0 right before it factors it, the tiles below as tasks of the other wavefronts
+    auto urgent_tile = [&](int t) {
+      const int kp = k0 - 12, i0 = k0 + 16 * t;
+      const int ao = (i0 + lr) * ld + kp + lk, bo = (k0 + lr) * ld + kp + lk, cb = (i0 + lk) * ld + k0 + lr;
+      mfma_acc acc = {sm[cb], sm[cb + 4 * ld], sm[cb + 8 * ld], sm[cb + 12 * ld]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao], -sm[bo], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 4], -sm[bo + 4], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[ao + 8], -sm[bo + 8], acc, 0, 0, 0);
+      if (i0 + 16 <= B) {                                    // (wave-uniform) all 16 rows exist: one lane mask for the four stores
+        if (lr < nb) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) sm[cb + 4 * v * ld] = acc[v];
+        }
+      } else {
+        const int rl = lr < nb ? B - i0 - lk : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < rl) sm[cb + 4 * v * ld] = acc[v];
+      }
+    };
+    if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);                        // the pivot chain is the critical path: ahead of the right-hand-side wavefront on its SIMD
+      if (kb > 0) { bcr_urgent_tile0(sm, ld, B, k0, nb, lr, lk, pr, cpre); lds_wave_sync(); }
+      double* Lik = Li + 192 * (kb & 1);
+      if (nb == 12) {
+        bcr_diag_block<12>(G, ld, dinv, bad, k0, lane, Lik, Idt);
+      } else {
+        for (int e = lane; e < 144; e += 64) Lik[e] = 0.0;
+        lds_wave_sync();
+        bcr_diag_block<6>(G, ld, dinv, bad, k0, lane, Lik, Idt);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    } else if (rhs_wave) {
+      if (kb > 0 && 16 * ct < ncol) rhs_step(kb - 1);
+    } else if (kb > 0) {
+      const int kp = k0 - 12;
+      const int ngt = (B - kn + 15) >> 4;                   // column tiles of the trailing matrix right of this block
+      const int nsu = ((B - k0 + 15) >> 4) - 1;             // tiles of block column kb below the one wavefront 0 takes
+      for (int task = wave - 1; task < ngt + nsu; task += NW - 5) {      // (wavefronts 1 .. NW - 5)
+        if (task >= ngt) { urgent_tile(task - ngt + 1); continue; }
+        const int c0 = kn + 16 * task;
+        const bool cok = c0 + lr < B, full = c0 + 15 < B;
+        const int bo = (c0 + lr) * ld + kp + lk;
+        const double nb0 = -sm[bo], nb1 = -sm[bo + 4], nb2 = -sm[bo + 8];
+        const int co = lk * ld + c0 + lr, c4 = 4 * ld;
+        const int t1 = (B - kn + 15) >> 4;
+        int ao = (kn + 16 * task + lr) * ld + kp + lk;
+        int cb = co + (kn + 16 * task) * ld;
+        int rows = B - (kn + 16 * task);
+        for (int t = task; t < t1; ++t) {                    // lower tiles of this column tile, top to bottom
+          const double a0 = sm[ao], a1 = sm[ao + 4], a2 = sm[ao + 8];
+          mfma_acc acc = {sm[cb], sm[cb + c4], sm[cb + 2 * c4], sm[cb + 3 * c4]};
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, nb0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, nb1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, nb2, acc, 0, 0, 0);
+          if (full && rows >= 16) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sm[cb + v * c4] = acc[v];
+          } else {
+            const int rl = cok ? rows - lk : 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              if (4 * v < rl) sm[cb + v * c4] = acc[v];
+          }
+          ao += 16 * ld; cb += 16 * ld; rows -= 16;
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- phase 2: panel, rows below the diagonal block: X = A L_kk^-T, one 16-row tile per wavefront
+    if (kn + 16 * wave < B) {                                // (B <= 138: at most 8 tiles; nb == 12 here)
+      if (wave == 0) cpre = bcr_prefetch_tile0(sm, ld, kn, lr, lk);
+      bcr_panel_tile(G, ld, B, k0, kn + 16 * wave, Li + 192 * (kb & 1), lr, lk, pr);
+    }
+    __syncthreads();
+  }
+  if (*bad) {
+    if (tid == 0 && blockIdx.y == 0) atomicMax(info, i * B + *bad);
+    return;                                                  // (what the right-hand-side wavefronts stored is never read: the status word says so)
+  }
+  if (rhs_wave && 16 * ct < ncol) rhs_step(NBLK - 1);        // the last block row: its diagonal inverse came with the last step
+}
+
 
 // ---- solve on the matrix cores: one workgroup (4 wavefronts) per (node, 4 column tiles of 16 right-hand
 // sides); L and the inverses of its 12 x 12 diagonal blocks sit in LDS, a wavefront walks its tile block

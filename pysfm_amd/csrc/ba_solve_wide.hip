@@ -17,8 +17,15 @@ hipError_t launch_bcrw_factor_hb(ba_handle* h, int cnt, hipStream_t st, int N, i
   if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcrw_factor<HB>); e != hipSuccess) return e;
   if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcrw_solve_mfma<HB>); e != hipSuccess) return e;
   constexpr int B = 6 * HB;
-  hipLaunchKernelGGL(k_bcrw_factor<HB>, dim3(cnt), dim3(kBcrElimThreads), bcrw_factor_lds_bytes(B), st, N, s, D, L, Lv, info);
   const int ntile = (3 * B + 1 + 15) / 16;
+  if (h->opt.bcrw_merged) {
+    // factor and solve in ONE kernel: every workgroup of a node's right-hand sides factors D_i for itself (k_bcrw_factor_solve)
+    if (hipError_t e = ensure_lds_attr(h, (const void*)k_bcrw_factor_solve<HB>); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bcrw_factor_solve<HB>, dim3(cnt, (ntile + 3) / 4), dim3(kBcrwFsThreads), bcrw_factor_solve_lds_bytes(B), st, N, s, D, U, f,
+                       P, Q, G, info);
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(k_bcrw_factor<HB>, dim3(cnt), dim3(kBcrElimThreads), bcrw_factor_lds_bytes(B), st, N, s, D, L, Lv, info);
   hipLaunchKernelGGL(k_bcrw_solve_mfma<HB>, dim3(cnt, (ntile + 3) / 4), dim3(1024), bcrw_solve_lds_bytes(B), st, N, s, L, Lv, U, f,
                      P, Q, G, info);
   return hipSuccess;
@@ -52,7 +59,7 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
   const int nt = (B + kBcrwPTile - 1) / kBcrwPTile, ntask = nt * (nt + 1) + nt * nt + 1;
   {
-    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, 3 * (int)strides.size());
+    ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (h->opt.bcrw_merged ? 2 : 3) * (int)strides.size());
     for (int s : strides) {
       const int cnt = (N / s + 1) / 2;
       HIPCHECK(h, launch_bcrw_factor(h, hb, cnt, h->stream, N, s, h->bcrD.p, h->bcrL.p, h->bcrLv.p, h->bcrU.p, h->bcrF.p, h->bcrP.p,
