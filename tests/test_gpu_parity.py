@@ -276,7 +276,7 @@ def test_renumbered_cameras_and_loop_closures_vs_reference(be):
     g = load_golden('scene_loop_closure_60x424')
     load_problem(be, *scene(g), g['l2_cam_opt_pos'], g['l2_pt_opt'].astype(np.uint8), sensor_of(g))
     info = be.problem_info()
-    assert info['cameras_permuted'] == 1 and info['border_cameras'] > 0 and info['half_bandwidth'] <= 11 and info['caller_half_bandwidth'] > 30, info
+    assert info['cameras_permuted'] == 1 and info['border_cameras'] > 0 and info['half_bandwidth'] <= 13 and info['caller_half_bandwidth'] > 30, info
     be.linearize(0)
     be.schur(0, 2., 1e-5)
     S, b = be.get_reduced()
