@@ -638,4 +638,102 @@ __global__ __launch_bounds__(1024) void k_bcrw_backsolve(int N, int B, int s, co
   }
 }
 
+// ---- ALL back-substitution levels in one launch (round 5; nodes of up to kBcrwFusedBackMaxHB cameras): the scheme of
+// k_bcr_backsolve_fused (ba_bcr.h) for nodes whose three matrices do not fit in LDS - every node's workgroup takes a ticket, fetches
+// ITS SHARE OF P, Q, G^-1 INTO REGISTERS (16 lanes a row: 2 x 7 entries of each matrix a thread at B = 102) while the levels above are
+// still at work, polls the solution entries of its two neighbours one level up (k_bcr_assemble marked x "not yet"), forms x_i and
+// publishes it.  `order`: the nodes from the root down, so that a workgroup only waits for workgroups that started before it.
+constexpr int kBcrwFusedBackMaxHB = 21;      // (two rounds of 1024 threads at 16 lanes a row: B <= 128)
+__device__ __forceinline__ double bcrw_wait_value(const double* p, int* status) {      // (bcr_wait_value of ba_bcr.h: bounded, looks at the status word)
+  double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int spins = 0; __double_as_longlong(v) == kBcrNotYet; ++spins) {
+    if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
+}
+
+template <int HB>
+__global__ __launch_bounds__(1024) void k_bcrw_backsolve_fused(int N, const double* __restrict__ gm, const double* __restrict__ Pm,
+                                                               const double* __restrict__ Qm, const double* __restrict__ Gi, double* x,
+                                                               const int* __restrict__ order, int* ticket) {
+  constexpr int B = 6 * HB, R = (16 * B + 1023) / 1024, E = (B + 15) / 16;
+  __shared__ double w[B], xl[B], xr[B];
+  __shared__ int my_ticket[2];
+  int* status = ticket - kBcrTicketWord;
+  const int tid = threadIdx.x;
+  if (tid == 0) {                                            // (one thread reads the status word and takes the ticket: see k_bcr_backsolve_fused)
+    const int st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    my_ticket[1] = st;
+    my_ticket[0] = st != 0 ? 0 : atomicAdd(ticket, 1);
+  }
+  __syncthreads();
+  if (my_ticket[1] != 0) return;                             // a failed elimination leaves solution entries unwritten: nobody may wait for them
+  const int i = order[my_ticket[0]];
+  const int s = (i + 1) & -(i + 1), l = i - s, r = i + s;
+  const bool haveL = l >= 0, haveR = r < N;
+  constexpr size_t BB = (size_t)B * B;
+  const int q = tid & 15;
+  // my share of the three matrices: row (or column, for G^-T) task >> 4 of round rd, entries q, q + 16, ...
+  double vp[R][E], vq[R][E], vg[R][E];
+#pragma unroll
+  for (int rd = 0; rd < R; ++rd) {
+    const int kraw = (rd * 1024 + tid) >> 4, k = kraw < B ? kraw : B - 1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = q + 16 * e, cc = c < B ? c : 0;
+      const double a = Pm[(size_t)i * BB + (size_t)k * B + cc], b = Qm[(size_t)i * BB + (size_t)k * B + cc];
+      vp[rd][e] = (c < B && kraw < B && haveL) ? a : 0.0;
+      vq[rd][e] = (c < B && kraw < B && haveR) ? b : 0.0;
+      const int kk = k + c, kc = kk < B ? kk : k;            // x[m] = sum_{kk >= m} Ginv[kk][m] w[kk]: m = k here
+      const double g = Gi[(size_t)i * BB + (size_t)kc * B + k];
+      vg[rd][e] = (kk < B && kraw < B) ? g : 0.0;
+    }
+  }
+  if (tid < B) {
+    w[tid] = gm[(size_t)i * B + tid];
+    xl[tid] = haveL ? bcrw_wait_value(x + (size_t)l * B + tid, status) : 0.0;
+    xr[tid] = haveR ? bcrw_wait_value(x + (size_t)r * B + tid, status) : 0.0;
+  }
+  __syncthreads();
+  double part[R];
+#pragma unroll
+  for (int rd = 0; rd < R; ++rd) {                           // w -= P xl + Q xr
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = q + 16 * e, cc = c < B ? c : 0;
+      acc += vp[rd][e] * xl[cc] + vq[rd][e] * xr[cc];
+    }
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    acc += dpp_pair<0x141>(acc);
+    acc += dpp_pair<0x140>(acc);
+    part[rd] = acc;
+  }
+#pragma unroll
+  for (int rd = 0; rd < R; ++rd) {
+    const int kraw = (rd * 1024 + tid) >> 4;
+    if (q == 0 && kraw < B) w[kraw] -= part[rd];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rd = 0; rd < R; ++rd) {                           // x = (G^-1)^T w
+    const int mraw = (rd * 1024 + tid) >> 4, m = mraw < B ? mraw : B - 1;
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int kk = m + q + 16 * e;
+      acc += vg[rd][e] * w[kk < B ? kk : m];
+    }
+    acc += dpp_pair<0xB1>(acc);
+    acc += dpp_pair<0x4E>(acc);
+    acc += dpp_pair<0x141>(acc);
+    acc += dpp_pair<0x140>(acc);
+    if (q == 0 && mraw < B) __hip_atomic_store(x + (size_t)i * B + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace ba

@@ -52,12 +52,26 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, h->bcrLv.resize((size_t)N * ((B + 11) / 12) * 144));
   HIPCHECK(h, h->dC.resize((size_t)N * B + 16));
   {
-    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]
-    launch_bcr_assemble(h, dim3(N), hb, dmask, nullptr, nullptr, nullptr);
+    ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1]; marks the solution "not there yet" for the one-launch back-substitution
+    launch_bcr_assemble(h, dim3(N), hb, dmask, h->dC.p, nullptr, nullptr);
   }
   std::vector<int> strides;
   for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
   const int nt = (B + kBcrwPTile - 1) / kBcrwPTile, ntask = nt * (nt + 1) + nt * nt + 1;
+  const bool back_fused = h->opt.fused_backsolve && hb <= kBcrwFusedBackMaxHB && N <= 8 * h->ncu;
+  if (back_fused && h->bcr_order_n != N) {
+    std::vector<int> order;                      // the nodes level by level from the root down (as solve_bcr's)
+    for (int q = (int)strides.size() - 1; q >= 0; --q)
+      for (int k = 0, cnt = (N / strides[q] + 1) / 2; k < cnt; ++k) {
+        const int i = strides[q] * (2 * k + 1) - 1;
+        if (i < N) order.push_back(i);
+      }
+    if ((int)order.size() != N) return h->fail(BA_ERR_STATE, "cyclic reduction: %d of %d nodes in the level lists", (int)order.size(), N);
+    HIPCHECK(h, h->bcr_order.resize((size_t)N));
+    HIPCHECK(h, hipMemcpyAsync(h->bcr_order.p, order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));          // `order` goes out of scope
+    h->bcr_order_n = N;
+  }
   {
     ScopedTimer tm(h, BA_K_BCR_ELIMINATE, (h->opt.bcrw_merged ? 2 : 3) * (int)strides.size());
     for (int s : strides) {
@@ -66,6 +80,20 @@ int solve_bcr_wide(ba_handle* h, const unsigned char* dmask) {
                                      h->bcrQ.p, h->bcrG.p, h->flags.p + 1));
       hipLaunchKernelGGL(k_bcrw_products, dim3(cnt, ntask), dim3(1024), 0, h->stream, N, B, s, h->bcrD.p, h->bcrU.p, h->bcrF.p, h->bcrP.p, h->bcrQ.p, h->flags.p + 1);
     }
+  }
+  if (back_fused) {
+    ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, 1);
+    int* ticket = h->flags.p + 1 + kBcrTicketWord;
+    switch (hb) {
+#define BA_HB_CASE(K) case K: hipLaunchKernelGGL(k_bcrw_backsolve_fused<K>, dim3(N), dim3(1024), 0, h->stream, N, h->bcrF.p, h->bcrP.p, h->bcrQ.p, \
+                                                 h->bcrG.p, h->dC.p, h->bcr_order.p, ticket); break;
+      BA_HB_CASE(12) BA_HB_CASE(13) BA_HB_CASE(14) BA_HB_CASE(15) BA_HB_CASE(16) BA_HB_CASE(17) BA_HB_CASE(18) BA_HB_CASE(19)
+      BA_HB_CASE(20) BA_HB_CASE(21)
+#undef BA_HB_CASE
+      default: return h->fail(BA_ERR_STATE, "k_bcrw_backsolve_fused: half-bandwidth %d", hb);
+    }
+    HIPCHECK(h, hipGetLastError());
+    return BA_OK;
   }
   ScopedTimer tmb(h, BA_K_BCR_BACKSOLVE, (int)strides.size());
   for (int q = (int)strides.size() - 1; q >= 0; --q) {

@@ -26,9 +26,12 @@ be.set_params(0, s['R0'], s['t0'], s['X0'])
 be.linearize(0)
 be.schur(0, 10., 1e-5)
 be.set_option('fused_eliminate', 0)
+be.set_option('fused_backsolve', 0)            # (nodes of 14 .. 21 cameras: the one-launch back-substitution of ba_bcr_wide.h is what is stressed)
 be.solve_reduced(None)
 ref = be.get_solution()
+kind = be.last_solve_kind
 be.set_option('fused_eliminate', 1)
+be.set_option('fused_backsolve', 1)
 worst, t0 = 0., time.time()
 for r in range(reps):
     if r % 3 == 2:
@@ -37,7 +40,7 @@ for r in range(reps):
         be.schur(0, 10., 1e-5)
     be.solve_reduced(None)
     x = be.get_solution()
-    assert be.last_solve_kind == 'bcr' and be.last_solve_path == 'band', (be.last_solve_kind, be.last_solve_path)
+    assert be.last_solve_kind == kind and kind in ('bcr', 'bcr_wide') and be.last_solve_path == 'band', (be.last_solve_kind, be.last_solve_path)
     d = np.max(np.abs(x - ref)) / np.max(np.abs(ref))
     assert np.all(np.isfinite(x)) and d <= 1e-11, (r, d)
     worst = max(worst, d)

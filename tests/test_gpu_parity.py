@@ -1231,6 +1231,33 @@ def test_one_launch_solve_repeats_itself_and_equals_the_per_level_launches(be, n
         assert np.all(np.isfinite(x)) and np.max(np.abs(x - ref)) <= 1e-13 * np.max(np.abs(ref)), r
 
 
+@pytest.mark.parametrize('nc,nt,L,reps', [(600, 8000, 16, 120), (500, 6000, 22, 90), (2200, 20000, 15, 60)])
+def test_one_launch_back_substitution_of_the_wide_cyclic_reduction_repeats_itself(be, nc, nt, L, reps):
+    """k_bcrw_backsolve_fused (nodes of 14 .. 21 cameras): every node's workgroup holds its share of P, Q, G^-1 in registers and polls
+    the solution entries of its neighbours one level up - the hand-over protocol of k_bcr_backsolve_fused.  The same system solved
+    `reps` times (every third time from poisoned workspace, re-reduced) must agree with the back-substitution of one launch per
+    level to 1e-13 of its largest entry, and no solve may time out."""
+    s = banded(nc, nt, track_len=L)
+    flags = default_flags(nc, nt)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    be.linearize(0)
+    be.schur(0, 10., 1e-5)
+    be.set_option('fused_backsolve', 0)
+    be.solve_reduced(None)
+    assert be.last_solve_kind == 'bcr_wide'
+    ref = be.get_solution()
+    be.set_option('fused_backsolve', 1)
+    for r in range(reps):
+        if r % 3 == 2:
+            be.debug_poison()
+            be.linearize(0)
+            be.schur(0, 10., 1e-5)
+        be.solve_reduced(None)
+        assert be.last_solve_kind == 'bcr_wide'
+        x = be.get_solution()
+        assert np.all(np.isfinite(x)) and np.max(np.abs(x - ref)) <= 1e-13 * np.max(np.abs(ref)), r
+
+
 def test_triangulation_of_low_parallax_tracks_equals_lstsq(be):
     """triangulate.py:17 hands the 2L x 3 system to numpy.linalg.lstsq.  Tracks seen under very little parallax (cameras a
     few 1e-4 apart looking at points 5 - 50 units away: condition numbers 1e4 ... 1e6) must come out like lstsq's: the QR in
