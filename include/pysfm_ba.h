@@ -79,6 +79,7 @@ int ba_synchronize(ba_handle* h);
  *                                                          sensor model (the reference's defaults); 0: the general formulas always
  *   "fused_backsolve" 1 | 0                                all back-substitution levels of the cyclic reduction in one launch (when its
  *                                                          nodes fit the chip at once) / one launch per level
+ *   "six_tile_launch" 1 | 0                                window reduction: tile columns 0 .. 5 in the first launch (one launch less for windows of 14+ cameras) / 0 .. 3
  *   "bcrw_merged"   1 | 0                                  wide cyclic reduction (nodes of 14 .. 23 cameras): factorisation and substitution of a level in one kernel / two
  *   "dense_lookahead" 1 | 0                                dense Cholesky / big-node levels: one launch per block column (the next panel step beside the
  *                                                          trailing update) / two

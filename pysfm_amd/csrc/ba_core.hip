@@ -293,6 +293,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "lds_window") ok = flag(h->opt.lds_window);
   else if (n == "fused_backsolve") ok = flag(h->opt.fused_backsolve);
   else if (n == "dense_lookahead") ok = flag(h->opt.dense_lookahead);
+  else if (n == "six_tile_launch") ok = flag(h->opt.six_tile_launch);
   else if (n == "bcrw_merged") ok = flag(h->opt.bcrw_merged);
   else if (n == "fused_eliminate") ok = flag(h->opt.fused_eliminate);
   else if (n == "device_lu") ok = flag(h->opt.device_lu);

@@ -61,6 +61,7 @@ struct Options {
   bool fast_paths = true;          // K = I / unit-Gaussian short cuts of the per-observation arithmetic (ba_math.h)
   bool fused_backsolve = true;     // all back-substitution levels of the cyclic reduction in one launch when the nodes fit the chip
   bool bcrw_merged = true;         // wide cyclic reduction: factorisation and substitution of a level in one kernel (k_bcrw_factor_solve)
+  bool six_tile_launch = true;     // k_schur_groups_mfma3: tile columns 0 .. 5 of the window in the first launch (21 accumulator tiles)
   bool dense_lookahead = true;     // dense / big-node factorisation: the next block column's panel step beside this one's trailing update (k_dense_step)
   bool fused_eliminate = true;     // all split elimination levels of the cyclic reduction in one launch (k_bcr_eliminate_fused)
   bool device_lu = true;           // a reduced system the Cholesky solve reports as not positive definite is solved again by the cyclic reduction with LU nodes

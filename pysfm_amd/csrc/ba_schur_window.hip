@@ -27,9 +27,14 @@ int launch_mfma3_set(ba_handle* h, const M3Launch& L, int p, double damping, boo
   // windows of at most 10 cameras with 6 points per batch everywhere (the north-star scenes): row length and k-steps fixed
   if (nts == 4 && L.G.np_cap == kGmPts && L.G.Kbuf == kGmK && L.uniform_ks) return launch_mfma3<0, 4, 64, 5>(h, L, p, damping, fuse_cam, true);
   // (windows of 11 .. 13 cameras: the row length fixed as well - addresses of the staged rows become immediates)
-  int rc = nts == 5 ? (L.G.Ld == 80 ? launch_mfma3<0, 5, 80, 0>(h, L, p, damping, fuse_cam, true) : launch_mfma3<0, 5>(h, L, p, damping, fuse_cam, true))
+  // Windows of six tiles a side and more: the first launch takes SIX tile columns (21 accumulator tiles).  The compiler spills about a
+  // hundred registers for it - and the launch is still 30 us cheaper than the two it replaces (<0, 4> and <4, 6>: 140 -> 109 us at
+  // tracks of 14 cameras): a launch is bound by its producers, who linearise every observation again (round 5; option six_tile_launch).
+  const bool six = nts >= 6 && h->opt.six_tile_launch;
+  int rc = six ? launch_mfma3<0, 6>(h, L, p, damping, fuse_cam, true)
+         : nts == 5 ? (L.G.Ld == 80 ? launch_mfma3<0, 5, 80, 0>(h, L, p, damping, fuse_cam, true) : launch_mfma3<0, 5>(h, L, p, damping, fuse_cam, true))
                     : launch_mfma3<0, 4>(h, L, p, damping, fuse_cam, true);
-  if (rc == BA_OK && nts >= 6) rc = launch_mfma3<4, 6>(h, L, p, damping, fuse_cam, false);
+  if (rc == BA_OK && nts >= 6 && !six) rc = launch_mfma3<4, 6>(h, L, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, L, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, L, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts >= 9) rc = launch_mfma3<8, 9>(h, L, p, damping, fuse_cam, false);
@@ -69,7 +74,7 @@ int wide_launches(const ba_handle* h) {
 int launch_mfma3_all(ba_handle* h, int p, double damping, bool fuse_cam) {
   return launch_mfma3_set(h, M3Launch{h->gm3, h->m3chunks.p, h->nm3chunks, h->gm3_uniform_ks}, p, damping, fuse_cam);
 }
-int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 : nts - 5; }
+int mfma3_launches(int nts) { return nts <= 5 ? 1 : nts == 6 ? 2 : nts <= 8 ? 3 : nts - 5; }      // (one less from six tiles a side on with option six_tile_launch)
 
 // k_schur_rect_mfma: the products between the segments of tracks that span more than 40 cameras
 int launch_rect(ba_handle* h, int p, double damping, bool fuse_cam) {
