@@ -26,18 +26,27 @@ int launch_mfma3_set(ba_handle* h, const M3Launch& L, int p, double damping, boo
   if (nts < 1 || nts > 15) return h->fail(BA_ERR_STATE, "k_schur_groups_mfma3: %d tiles per side", nts);
   // windows of at most 10 cameras with 6 points per batch everywhere (the north-star scenes): row length and k-steps fixed
   if (nts == 4 && L.G.np_cap == kGmPts && L.G.Kbuf == kGmK && L.uniform_ks) return launch_mfma3<0, 4, 64, 5>(h, L, p, damping, fuse_cam, true);
-  // (windows of 11 .. 13 cameras: the row length fixed as well - addresses of the staged rows become immediates)
-  // Windows of six tiles a side and more: the first launch takes SIX tile columns (21 accumulator tiles).  The compiler spills about a
-  // hundred registers for it - and the launch is still 30 us cheaper than the two it replaces (<0, 4> and <4, 6>: 140 -> 109 us at
-  // tracks of 14 cameras): a launch is bound by its producers, who linearise every observation again (round 5; option six_tile_launch).
+  // Windows of six tiles a side and more (round 5; option six_tile_launch).  A launch is bound by its producers, who linearise every
+  // observation again - so the fewer launches the better, spilled registers and all: tile columns 0 .. 5 in one launch (21 accumulator
+  // tiles, 104 spilled registers) are 109 us where <0, 4> + <4, 6> were 140 (tracks of 14 cameras); columns 0 .. 6 (28 tiles, 378
+  // spilled) 204 us where <0, 6> + <6, 7> were 226 (17 cameras).  Eight and nine columns in one launch are where it ends (36 / 45
+  // tiles: 3.7 / 1.4 ms).  Measured splits:   7 tiles a side: <0,7>   8: <0,6> + <6,8> (278 us; <0,7> + <7,8>: 287)
+  //                                             9: <0,7> + <7,9> (367 us; <0,6> + <6,8> + <8,9>: 402)
   const bool six = nts >= 6 && h->opt.six_tile_launch;
-  int rc = six ? launch_mfma3<0, 6>(h, L, p, damping, fuse_cam, true)
+  const bool seven = six && (nts == 7 || nts >= 9);          // the first launch takes seven columns
+  int rc = seven ? launch_mfma3<0, 7>(h, L, p, damping, fuse_cam, true)
+         : six ? launch_mfma3<0, 6>(h, L, p, damping, fuse_cam, true)
+         // (windows of 11 .. 13 cameras: the row length fixed as well - addresses of the staged rows become immediates)
          : nts == 5 ? (L.G.Ld == 80 ? launch_mfma3<0, 5, 80, 0>(h, L, p, damping, fuse_cam, true) : launch_mfma3<0, 5>(h, L, p, damping, fuse_cam, true))
                     : launch_mfma3<0, 4>(h, L, p, damping, fuse_cam, true);
-  if (rc == BA_OK && nts >= 6 && !six) rc = launch_mfma3<4, 6>(h, L, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, L, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, L, p, damping, fuse_cam, false);
-  if (rc == BA_OK && nts >= 9) rc = launch_mfma3<8, 9>(h, L, p, damping, fuse_cam, false);
+  if (seven) {
+    if (rc == BA_OK && nts >= 9) rc = launch_mfma3<7, 9>(h, L, p, damping, fuse_cam, false);
+  } else {
+    if (rc == BA_OK && nts >= 6 && !six) rc = launch_mfma3<4, 6>(h, L, p, damping, fuse_cam, false);
+    if (rc == BA_OK && nts == 7) rc = launch_mfma3<6, 7>(h, L, p, damping, fuse_cam, false);
+    if (rc == BA_OK && nts >= 8) rc = launch_mfma3<6, 8>(h, L, p, damping, fuse_cam, false);
+    if (rc == BA_OK && nts >= 9) rc = launch_mfma3<8, 9>(h, L, p, damping, fuse_cam, false);
+  }
   // windows of 25 .. 40 cameras (tracks that long: video): one launch per further tile column (tj + 1 <= 15 tiles each)
   if (rc == BA_OK && nts >= 10) rc = launch_mfma3<9, 10>(h, L, p, damping, fuse_cam, false);
   if (rc == BA_OK && nts >= 11) rc = launch_mfma3<10, 11>(h, L, p, damping, fuse_cam, false);

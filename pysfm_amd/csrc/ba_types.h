@@ -87,7 +87,7 @@ __host__ __device__ inline size_t schur_mfma2_lds_bytes(int wn, int hb1) {
 constexpr int kGm3MaxL = 24;                            // track length up to which the launches re-linearise at most four times
 constexpr int kGm3MaxSpan = 40;                         // widest window: 15 tiles per side, the last tile COLUMN alone fills the 15 accumulator tiles of a launch
 constexpr int kGm3PosLen = 64;                          // optimised positions of a group's cameras (40 used)
-constexpr int kGm3MaxTiles = 21;                        // accumulator tiles of one launch (15 fit without register spills; 21: launch_mfma3_set, ba_schur_window.hip)
+constexpr int kGm3MaxTiles = 28;                        // accumulator tiles of one launch (15 fit without register spills; 21 and 28: launch_mfma3_set, ba_schur_window.hip)
 
 struct Gm3Params { int nts; int Ld; int Kbuf; int np_cap; int wn; int do_rhs; int wb1; };      // wb1: blocks per row of the LDS window (the widest group)
 // A group of k_schur_groups_mfma3: consecutive points (internal order) whose optimised cameras all lie in the window of
