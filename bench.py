@@ -25,7 +25,8 @@ One "step" = one complete LM trial, nothing cached or skipped:
 value = observations x steps / wall time, summed over all GPUs (max over ranks of the
 time).  Inputs are resident in HBM before the timed region starts.
 
-Rank 0 prints ONE JSON line; see DESIGN.md for `roofline` and `cpu_baseline`.
+Rank 0 prints ONE short JSON line (<= 4 KB: the contract's keys, `roofline`, `cpu_baseline`) as the last line of stdout and writes
+everything else it measured to bench_detail.json (--detail-out); see DESIGN.md for `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
@@ -705,6 +706,11 @@ def main():
     ap.add_argument('--no-live-pmc', action='store_true', help='do not run the two rocprofv3 --pmc passes that measure `roofline.traffic` live')
     ap.add_argument('--rank-timeout', type=float, default=900., metavar='SECONDS',
                     help='multi-GPU runs: a rank that has not finished after this long prints what it was doing and exits (rank 0: a JSON line with "error")')
+    ap.add_argument('--detail-out', default=None, metavar='PATH',
+                    help='where the full record goes (default bench_detail.json beside this file, and a copy under gpurun_out/ when that exists); '
+                         'the last stdout line is the short headline the driver parses')
+    ap.add_argument('--full-line', action='store_true',
+                    help='experiments (scripts/ab_*.sh): print the WHOLE record as the last line instead of the short headline')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)       # the run rocprofv3 wraps: a few trials, no JSON line
     args = ap.parse_args()
     global PMC_WORKLOAD
@@ -1163,7 +1169,75 @@ def main():
     import ctypes
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        detail_path = write_detail(out, args.detail_out)
+        print(json.dumps(out if args.full_line else headline(out, detail_path)), flush=True)
+
+
+HEADLINE_MAX_BYTES = 4096      # the driver reads the LAST stdout line and keeps only a few KB of tail: the line it parses stays short
+
+
+def write_detail(out, path):
+    """Everything the run measured (other configurations, per-kernel rooflines, small problems, problem_info ...) goes to a side
+    file; the headline line names it.  A second copy under gpurun_out/ (when that directory exists) travels back from a GPU box."""
+    path = path or os.path.join(ROOT, 'bench_detail.json')
+    written = None
+    for p in [path] + ([os.path.join(ROOT, 'gpurun_out', os.path.basename(path))] if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else []):
+        try:
+            with open(p, 'w') as f:
+                json.dump(out, f)
+                f.write('\n')
+            written = written or p
+        except OSError as e:
+            sys.stderr.write('bench.py: could not write %s: %s\n' % (p, e))
+    return written
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def headline(out, detail_path=None):
+    """The ONE line the driver parses: the contract's keys, `roofline` and `cpu_baseline` reduced to their numbers, at most
+    HEADLINE_MAX_BYTES long.  Everything else is in the detail file (write_detail)."""
+    if out is None or 'error' in out:
+        return out
+    h = _pick(out, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'))
+    c = out.get('config', {})
+    h['config'] = _pick(c, ('workload', 'cameras', 'points', 'observations', 'track_len', 'init_mode', 'parallelism', 'collectives', 'library_options'))
+    h['config'] = {k: v for k, v in h['config'].items() if v is not None}
+    r = out.get('roofline', {})
+    h['roofline'] = _pick(r, ('bound', 'limited_by', 'achieved', 'peak', 'unit', 'frac', 'flops', 'traffic', 'traffic_source', 'traffic_stale_possible',
+                              'algorithmic_bytes_per_launch', 'avg_launch_ms', 'launches', 'launches_per_trial', 'hbm_achieved_GBps', 'hbm_frac',
+                              'bytes_in_plus_out_per_trial', 'measured_copy_GBps'))
+    h['roofline']['kernel'] = str(r.get('kernel', '')).split(':')[0].split(' (')[0][:60]
+    p = out.get('roofline_linearise_schur_pass', {})
+    h['linearise_schur_pass'] = _pick(p, ('ms', 'obs_jacobians_per_s', 'algorithmic_bytes', 'achieved_GBps', 'frac_of_hbm_peak', 'traffic', 'traffic_over_algorithmic',
+                                          'bound', 'achieved_tflops', 'frac_fp64'))
+    if out.get('kernel_ms_per_step'):
+        h['kernel_us_per_step'] = {k: round(1e3 * v, 2) for k, v in out['kernel_ms_per_step'].items() if v > 0}
+    w = out.get('ms_per_step_windows') or {}
+    h['ms_per_step_windows'] = _pick(w, ('n', 'min', 'median', 'max'))
+    for k in ('final_reproj_rmse', 'final_reproj_rmse_oracle', 'lm_steps', 'lm_trials', 'lm_converged', 'end_to_end_optimize_s', 'set_bundle_s'):
+        if k in out:
+            h[k] = out[k]
+    cb = out.get('cpu_baseline')
+    if cb:
+        h['cpu_baseline'] = _pick(cb, ('value', 'unit', 'cores', 'kind'))
+        h['cpu_baseline']['sample'] = str(cb.get('sample', ''))[:320]
+        if 'per_observation_loop' in cb:
+            h['cpu_baseline']['per_observation_loop_obs_per_s_1_core'] = cb['per_observation_loop'].get('value')
+    if detail_path:
+        h['detail'] = os.path.relpath(detail_path, ROOT)
+    line = json.dumps(h)
+    for drop in ('kernel_us_per_step', 'linearise_schur_pass', 'ms_per_step_windows'):      # never over the limit, whatever a flag adds
+        if len(line) <= HEADLINE_MAX_BYTES:
+            break
+        h.pop(drop, None)
+        line = json.dumps(h)
+    if len(line) > HEADLINE_MAX_BYTES:
+        h['config']['workload'] = h['config']['workload'][:200]
+        h.get('cpu_baseline', {}).pop('sample', None)
+    return h
 
 
 def comm_max(comm, x):

@@ -11,7 +11,7 @@ timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m
 echo "pytest rc=$?" >> $O/pytest.log
 tail -4 $O/pytest.log
 for opt in "fused_eliminate=0" "fused_eliminate=1" "fused_eliminate=0" "fused_eliminate=1"; do
-  timeout 600 python bench.py --no-other-configs --no-live-pmc --no-cpu-baseline --no-lm --option $opt 2> /dev/null | tail -1 | python -c "
+  timeout 600 python bench.py --full-line --no-other-configs --no-live-pmc --no-cpu-baseline --no-lm --option $opt 2> /dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$opt', 'ms/step %.4f' % d['ms_per_step'], d['ms_per_step_windows']['min'], d['ms_per_step_windows']['median'], {k: round(v, 5) for k, v in d['kernel_ms_per_step'].items()})

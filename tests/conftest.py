@@ -47,6 +47,10 @@ def pytest_collection_modifyitems(config, items):
         have_gpu = torch.cuda.is_available()
     except Exception:
         have_gpu = False
+    # `-x` must reach every golden-fixture test (the ones that pin the HIP path to the reference's own numbers: fast) before any
+    # full-size, statistics-flavoured one: parity -> resident -> fuzz -> configs; everything that needs no GPU first
+    order = {'test_gpu_parity.py': 1, 'test_gpu_resident.py': 2, 'test_gpu_fuzz.py': 3, 'test_gpu_configs.py': 4}
+    items.sort(key=lambda it: order.get(os.path.basename(str(it.fspath)), 0))          # (stable: the order inside a file stays)
     if have_gpu:
         # every problem of every GPU test starts from NaNs in all LDS and workspace buffers (a read of something nobody
         # wrote must show, not depend on what ran before)

@@ -978,3 +978,39 @@ def test_camera_layout_leaves_a_sequence_alone_and_cuts_a_ring_once():
     assert hb <= 11 and nco - n1 == 4, (hb, n1)
     side = new[np.r_[0:4]] >= n1
     assert side.all() or (new[np.r_[nco - 4:nco]] >= n1).all()
+
+
+# ------------------------------------------------------------------ the bench line the driver parses
+def test_bench_headline_of_a_full_record_is_short_and_keeps_the_contract():
+    """Round 5's last stdout line was the whole 31 KB record and the driver could not parse it.  `bench.headline` reduces a full
+    record (here: the committed one of that very run) to the line the driver reads: at most 4 KB, the contract's keys, `roofline`
+    and `cpu_baseline` with their numbers; a record with everything the flags can add stays under the limit too."""
+    import json
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import bench
+    full = json.loads(open(os.path.join(ROOT, 'profiles', 'r05f_bench_default.json')).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    h = bench.headline(full, os.path.join(ROOT, 'bench_detail.json'))
+    line = json.dumps(h)
+    assert len(line) <= bench.HEADLINE_MAX_BYTES == 4096, len(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+        assert h[k] == full[k], k
+    assert h['config']['workload'] == full['config']['workload'] and 'model' not in h['config']
+    assert h['config']['cameras'] == 1000 and h['config']['points'] == 100000 and h['config']['observations'] == 1000000
+    r = h['roofline']
+    for k in ('bound', 'limited_by', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'algorithmic_bytes_per_launch', 'flops', 'hbm_frac'):
+        assert r[k] == full['roofline'][k], k
+    assert r['kernel'] == 'k_bcr_eliminate_fused' and 'per_kernel' not in r
+    c = h['cpu_baseline']
+    assert c['value'] == full['cpu_baseline']['value'] and c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == 'obs/s' and len(c['sample']) <= 320
+    assert h['final_reproj_rmse'] == full['final_reproj_rmse'] and h['final_reproj_rmse_oracle'] == full['final_reproj_rmse_oracle']
+    assert h['detail'] == 'bench_detail.json'
+    for k in ('other_configs', 'small_problems', 'problem_info', 'roofline_linearise_schur_pass'):
+        assert k not in h
+    # the worst case: long option lists, a long workload string, many timers
+    fat = dict(full)
+    fat['config'] = dict(full['config'], workload=full['config']['workload'] * 6, library_options=['solver=bcr1'] * 40)
+    fat['kernel_ms_per_step'] = {'kernel_number_%d' % i: .001 * (i + 1) for i in range(80)}
+    assert len(json.dumps(bench.headline(fat, None))) <= 4096
+    assert bench.headline({'error': 'a rank gave up'}) == {'error': 'a rank gave up'}
