@@ -47,7 +47,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mf
 
 # What binds each kernel at the bench sizes; `roofline.limited_by` reports it.  The contract prices
 # `achieved` against HBM for every kernel that is not MFMA-bound, so `frac` is always achieved / 8 TB/s.
-KERNEL_BOUND = {'border_schur': 'atomics', 'border_solve': 'latency', 'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
+KERNEL_BOUND = {'border_schur': 'atomics', 'border_solve': 'latency', 'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_refine': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
                 'dense_solve': 'latency', 'schur_pairs': 'mfma', 'linearize': 'fp64 issue + gather latency', 'backsub': 'fp64 issue', 'cost': 'hbm',
                 'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
 # timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
@@ -56,7 +56,8 @@ KERNEL_NAMES = {'border_schur': 'k_schur_border (+ k_border_clear)', 'border_sol
                 'schur_pairs': 'k_schur_groups_mfma2 | k_schur_groups_mfma3 (k_schur_groups / k_schur_pairs otherwise)',
                 'backsub': 'k_backsub_groups (k_backsub when points do not come in runs)',
                 'bcr_eliminate': 'k_bcr_eliminate_fused: all elimination levels of the cyclic reduction AND its back-substitution in one launch (k_bcr_eliminate per level where a level is wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
-                'bcr_backsolve': 'k_bcr_backsolve_fused (k_bcr_backsolve / k_bcrw_backsolve per level otherwise)', 'bcr_assemble': 'k_bcr_assemble', 'cost': 'k_cost',
+                'bcr_backsolve': 'k_bcr_backsolve_fused (k_bcr_backsolve / k_bcrw_backsolve per level otherwise)',
+                'bcr_refine': 'k_bcr_residual + k_bcr_refine: one step of iterative refinement through the kept factors (trials damped below 1e-2)', 'bcr_assemble': 'k_bcr_assemble', 'cost': 'k_cost',
                 'camera_blocks': 'k_camera_blocks', 'dense_solve': 'k_dense_gather/panel/update/backsolve', 'band_solve': 'k_band_solve'}
 # reference rates measured in SURVEY.md section 6 (the reference itself, imported in the build container, 1 core Xeon 2.1 GHz)
 SURVEY_REFERENCE_RATES = {'assemble_obs_per_s': 2.8e4, 'whole_update_obs_per_s': 3.5e3,
@@ -110,6 +111,10 @@ def useful_flops(kernel, nc, nco, nt, nobs, hb):
         pairs, N, B, ld = border_shape(nc, nco, nt, nobs, hb)
         k6 = 6 * BORDER_CAMS[0]
         return 9. * N * B * B * ld + 2. * (12 * max(hb, 1) * k6) * k6 * k6 / 6 + k6 ** 3 / 3.
+    if kernel == 'bcr_refine':            # r = b - S x over the band (2 flops per entry of the full band), then two sweeps of three B x B matrix-vector products per node
+        B = 6. * max(hb, 1)
+        N = -(-nco // max(hb, 1))
+        return 2. * 36. * nco * (2 * hb + 1) + N * 12. * B * B
     if kernel in ('bcr_eliminate', 'bcr_backsolve', 'bcr_assemble'):
         # block cyclic reduction, N nodes of B = 6 hb unknowns: per node Cholesky B^3/3, P and Q (two triangular solves with B
         # right-hand sides, B^3 each), G^-1 (B^3/3), P^T P and Q^T Q (symmetric, B^3 each), the two couplings of the next
@@ -162,6 +167,10 @@ def algorithmic_bytes(kernel, nc, nco, nt, nobs, nunits, hb, launches=1.):
         if kernel == 'bcr_eliminate':     # read D, T[l,i], T[i,r]; write G^-1, P, Q, T[l,r]; RMW D_l, D_r
             return int(8 * N * (11 * B * B + 6 * B) / max(1., launches))
         return int(8 * N * (3 * B * B + 4 * B) / max(1., launches))
+    if kernel == 'bcr_refine':            # per AVERAGE launch of its two: the band, b and x once; G^-1, P, Q of every node once per sweep
+        B = 6 * max(hb, 1)
+        N = -(-nco // max(hb, 1))
+        return int((band + 3 * 48 * nco + 2 * 8 * N * (3 * B * B + 4 * B)) / max(1., launches))
     if kernel == 'flatten':
         return band + 288 * nco * nco
     if kernel == 'point_invert':          # HPP read, HPPinv + its factorisation written, [S | b] initialised

@@ -61,7 +61,7 @@ typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_se
 enum {
   BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
   BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_TRIANGULATE,
-  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_DENSE_SOLVE, BA_K_BORDER_SCHUR, BA_K_BORDER_SOLVE, BA_K_COUNT
+  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_DENSE_SOLVE, BA_K_BORDER_SCHUR, BA_K_BORDER_SOLVE, BA_K_BCR_REFINE, BA_K_COUNT
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -159,6 +159,7 @@ enum {
   BA_INFO_CALLER_HALF_BANDWIDTH, /* the half-bandwidth the caller's camera order would have had                         */
   BA_INFO_BORDER_CAMERAS,      /* cameras in the border of the reduced system (band + border, see ba_set_problem)          */
   BA_INFO_LINEARIZATIONS_REUSED, /* trials of ba_lm_trial since ba_set_problem that reused the linearisation of an unchanged current set */
+  BA_INFO_SOLVES_REFINED,      /* reduced solves since ba_set_problem that took the step of iterative refinement (option refine) */
   BA_INFO_COUNT
 };
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);
@@ -203,6 +204,11 @@ int ba_set_min_half_bandwidth(ba_handle* h, int32_t min_hb);
  * the WHOLE scene (ba_plan_camera_layout with allow_border = 0: the same input gives the same layout) and imposes it; the band
  * width they agree on (ba_set_min_half_bandwidth) is then the one of the new positions.  new_pos = NULL: the library chooses again. */
 int ba_set_camera_layout(ba_handle* h, const int32_t* new_pos, int32_t nco);
+/* The layout ba_set_problem ended up with: new_pos[p] (nco entries) = the INTERNAL position of the caller's optimised position p
+ * (the identity when BA_INFO_CAMERAS_PERMUTED is 0), *band_cameras = how many internal positions form the band (nco minus the
+ * border cameras, which sit last).  Host arrays cross this API in the caller's positions and need none of this; the DEVICE views
+ * (ba_reduced_device_ptrs, ba_bind_reduced_buffers, ba_reduced_layout) are in the internal order - see there. */
+int ba_get_camera_layout(ba_handle* h, int32_t* new_pos, int32_t* band_cameras);
 
 /* bundle.sensor_model (sensor_model.py:19-32 protocol) */
 int ba_set_sensor(ba_handle* h, int kind, const double* params, int nparams);
@@ -252,7 +258,14 @@ int ba_get_point_inverses(ba_handle* h, double* HPP_inv);
 
 /* Device views of the reduced system for the collective and the dense solver
  * (sizes: ba_reduced_layout).  With ba_bind_reduced_buffers the caller supplies the
- * device memory (e.g. one torch tensor holding [S | b]) instead. */
+ * device memory (e.g. one torch tensor holding [S | b]) instead.
+ * These views are in the INTERNAL order of the optimised cameras (camera_order = auto is the default: an unordered scene is
+ * reordered, BA_INFO_CAMERAS_PERMUTED): row / block i belongs to the caller's position p with new_pos[p] == i
+ * (ba_get_camera_layout).  With border cameras (BA_INFO_BORDER_CAMERAS > 0) the band covers the first band_cameras positions
+ * only; the border's blocks live in library-owned buffers and band rows past band_cameras are not meaningful.  A caller that
+ * solves from the device views itself sets option camera_order = off and border = 0 before ba_set_problem (the caller's order,
+ * one band, as wide as that order makes it) - or reads the system through ba_get_reduced / ba_flatten_reduced, which are in the
+ * caller's positions whatever the layout. */
 int ba_reduced_device_ptrs(ba_handle* h, void** S_band, void** b);
 int ba_bind_reduced_buffers(ba_handle* h, void* S_band_dev, void* b_dev);
 

@@ -126,6 +126,15 @@ class HipBackend(object):
         new_pos = capi.i32(new_pos)
         self._check(self._lib.ba_set_camera_layout(self._h, capi.iptr(new_pos), len(new_pos)))
 
+    def camera_layout(self):
+        """(new_pos[nco], band_cameras) of the problem as ba_set_problem laid it out (ba_get_camera_layout): the caller's optimised
+        position p sits at internal position new_pos[p]; the first band_cameras internal positions form the band, the border
+        cameras follow.  The device views of the reduced system (reduced_tensors) are in that internal order."""
+        new_pos = np.zeros(max(1, self.nco), np.int32)
+        band = C.c_int32(0)
+        self._check(self._lib.ba_get_camera_layout(self._h, capi.iptr(new_pos), C.byref(band)))
+        return new_pos[:self.nco], band.value
+
     def plan_camera_layout(self, nco, list_off, list_pos, list_points=None, allow_border=False):
         """ba_plan_camera_layout (a pure function: no GPU work): (new_pos, band_cameras, half_bandwidth)."""
         list_off, list_pos = capi.i32(list_off), capi.i32(list_pos)
@@ -288,6 +297,13 @@ class HipBackend(object):
             import warnings
             warnings.warn('pysfm_amd: the device solve of the reduced system timed out (status 0x%x): a solver fault, '
                           'not a property of the matrix; solving through LU' % info.value, RuntimeWarning)
+            if self.problem_info().get('border_cameras', 0) > 0:
+                # band + border: the device's LU solvers do not know the border (ba_solve_reduced refuses solver = lu there) - the
+                # host solves it the way the reference does; where that does not apply either, the trial is lost like an ill-conditioned one
+                if self._host_lu_of_bordered_system(mask):
+                    return
+                self._note_solve(info.value)
+                raise ReducedSystemSingular
             before = getattr(self, '_options', {}).get('solver', 'auto')      # (a caller's / test's own choice comes back afterwards)
             self._check(self._lib.ba_set_option(self._h, b'solver', b'lu'))
             try:

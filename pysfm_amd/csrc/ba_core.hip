@@ -165,7 +165,7 @@ const char* ba_kernel_name(int id) {
   static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
                                           "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
                                           "k_band_solve", "k_eval", "k_camera_blocks", "k_triangulate",
-                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve", "k_dense_solve", "k_schur_border", "k_border_solve"};
+                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve", "k_dense_solve", "k_schur_border", "k_border_solve", "k_bcr_refine"};
   return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
 }
 
@@ -233,6 +233,7 @@ int ba_destroy(ba_handle* h) {
   }
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->res_log) (void)hipHostFree(h->res_log);
+  if (h->res_exit) (void)hipHostFree(h->res_exit);
   if (h->res_out) (void)hipHostFree(h->res_out);
   if (h->io) (void)hipHostFree(h->io);
   if (h->res_trace) (void)hipHostFree(h->res_trace);
@@ -300,8 +301,10 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "fast_paths") ok = flag(h->opt.fast_paths);
   else if (n == "resident") ok = flag(h->opt.resident);
   else if (n == "resident_scatter_min") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 2 && c <= 1000; if (ok) h->opt.resident_scatter_min = (int)c; }
+  else if (n == "resident_fault") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= -1 && c < 64; if (ok) h->opt.resident_fault = (int)c; }
   else if (n == "host_setup") ok = flag(h->opt.host_setup);
   else if (n == "camera_order") ok = choice({"auto", "off", "always"}, h->opt.camera_order);
+  else if (n == "refine") ok = choice({"auto", "1", "0"}, h->opt.refine);
   else if (n == "border") ok = flag(h->opt.border);
   else if (n == "border_side_stream") ok = flag(h->opt.border_side_stream);
   else if (n == "reuse_linearization") ok = flag(h->opt.reuse_linearization);
@@ -332,6 +335,7 @@ int ba_set_stream(ba_handle* h, void* hip_stream) {
 int ba_synchronize(ba_handle* h) {
   if (!h) return BA_ERR_INVALID_ARG;
   HIPCHECK(h, hipSetDevice(h->device));
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;      // (the side stream's border kernels are the handle's work too: the main stream waits for them first)
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   return BA_OK;
 }
@@ -399,6 +403,7 @@ int ba_set_params(ba_handle* h, int which, const double* R, const double* t, con
   REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_set_params: bad parameter set");
   REQUIRE(h, (h->nc == 0 || (R && t)) && (h->nt == 0 || X), BA_ERR_INVALID_ARG, "ba_set_params: NULL argument");
   HIPCHECK(h, hipSetDevice(h->device));
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;      // (border kernels of an earlier ba_schur may still be reading what this call writes: side stream, ba_border.hip)
   const int p = h->phys(which);
   h->params_written(p);
   const size_t ncam = (size_t)h->nc * 12, nx = (size_t)h->nt * 3;
@@ -476,6 +481,15 @@ int ba_swap_params(ba_handle* h) {
   REQUIRE(h, h->have_problem && h->have_params[1 - h->cur], BA_ERR_STATE, "ba_swap_params: trial set is empty");
   h->cur = 1 - h->cur;
   h->have_linearization = h->have_schur = h->have_backsub = false;
+  return BA_OK;
+}
+
+int ba_get_camera_layout(ba_handle* h, int32_t* new_pos, int32_t* band_cameras) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_get_camera_layout: call ba_set_problem first");
+  REQUIRE(h, new_pos || h->nco == 0, BA_ERR_INVALID_ARG, "ba_get_camera_layout: new_pos is NULL");
+  for (int p = 0; p < h->nco; ++p) new_pos[p] = h->cpos_in.empty() ? p : h->cpos_in[p];
+  if (band_cameras) *band_cameras = h->band_cams();
   return BA_OK;
 }
 

@@ -68,14 +68,18 @@ struct Options {
   bool packed_upload = true;       // ... and their arrays travel as one copy + one scatter launch (off: a copy per array)
   bool host_setup = true;          // ba_set_problem: small problems are ordered on the host (off: always the device pipeline)
   bool resident = true;            // ba_lm_resident applies to problems that fit one compute unit (off: ba_lm_resident_fits says no)
+  int resident_fault = -1;         // test aid: the workgroup of the resident loop that reports a time-out whatever happened (-1: none)
   int resident_scatter_min = 5;    // ... whose launches of at least this many workgroups add their partial sums up in slices (two stages)
   bool solve_trace = false;        // per-phase cycle counts of the node kernels (PROFILE builds)
   bool reuse_linearization = true; // ba_lm_trial after a rejected trial: the point blocks of the unchanged current set are not formed again
   bool border_side_stream = true;  // the border's blocks and the preparation of its solve on a side stream beside the cyclic reduction (off: in line)
   bool border = true;              // ... and a border for the cameras at the far end of a few long-range tracks (ba_border.h)
+  int refine = 0;                  // one step of iterative refinement behind the cyclic reduction (ba_bcr_refine.h): 0 auto (damping below kRefineBelowDamping), 1 always, 2 never
   int camera_order = 0;            // internal order of the optimised cameras (ba_order.hip): 0 auto (when the caller's is not provably as narrow as it can be), 1 off, 2 always try
 };
 enum { CAMORDER_AUTO = 0, CAMORDER_OFF, CAMORDER_ALWAYS };
+enum { REFINE_AUTO = 0, REFINE_ON, REFINE_OFF };
+constexpr double kRefineBelowDamping = 1e-2;      // where the LM walk starts to feel the last digits of the reduced solve
 constexpr int kBordMaxCamsHost = 21;       // (= kBordMaxCams of ba_border.h: 126 border unknowns fit the LDS of the border solve)
 
 }  // namespace ba
@@ -107,6 +111,8 @@ struct ba_handle {
   bool cam_blocks_valid = false;     // HCC / bC hold the camera blocks of the linearisation (ba_lm_trial may leave them to the reduction)
   bool inv_valid = false;            // HPPinv holds pinv of the damped point blocks for (inv_damping, inv_rcond)
   double inv_damping = 0.0, inv_rcond = 0.0;
+  double schur_damping = 0.0;        // the damping of the reduced system [S | b] holds (the last ba_schur)
+  long long refined = 0;             // solves that took the refinement step
   bool dense_mode = false;           // ba_set_dense_visibility: the reduction is one SYRK over all points (k_dense_*)
   double* trial_result_dev = nullptr; // bound by ba_bind_trial_result: device copy of the cost partials + status words
   ncclComm_t comm = nullptr;          // ba_comm_init: the shards' communicator; collectives run on `stream`
@@ -212,6 +218,9 @@ struct ba_handle {
   // normal-equation blocks
   DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, scratch2, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, bigK, fac, dUd, dDd, dyd, dpart, comm_dev;
   DevBuf<unsigned char> mask;
+  DevBuf<double> bcrRr, bcrRg, bcrRx, bcrRs;   // refinement step (ba_bcr_refine.h): residual, g and d per node, the contribution slots
+  DevBuf<int> bcr_rwork;     // ... its work list: 2 node + sweep, forward items leaves first, then backward items root down (for bcr_rwork_n nodes)
+  int bcr_rwork_n = 0;
   DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)
   int bcr_order_n = 0;
   DevBuf<int> bcr_work, bcr_done;   // k_bcr_eliminate_fused: 4 node + role of every workgroup, leaves first; "handed on" words [4 N]
@@ -246,6 +255,9 @@ struct ba_handle {
   int res_parity = 0;
   bool res_inflight = false;            // ... a launch ba_lm_resident_begin made and ba_lm_resident_end has not collected yet
   int res_inflight_phys = 0;
+  DevBuf<double> res_stage;            // ... the set a launch ends on, before the host commits it (ba_lm_resident_end)
+  int* res_exit = nullptr;             // ... pinned: every workgroup's (exit reason, trials walked)
+  int res_inflight_groups = 0;
   void* res_log = nullptr;             // ... and its pinned log (ResidentLog of ba_resident.h)
   void* io = nullptr;                  // pinned staging of ba_set_params / ba_get_params (small parameter sets)
   size_t io_bytes = 0;

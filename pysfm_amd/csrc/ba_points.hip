@@ -48,6 +48,7 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
   { const int rc = ensure_plan(h); if (rc != BA_OK) return rc; }
   const int p = h->phys(which);
   HIPCHECK(h, hipSetDevice(h->device));
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;      // (border kernels of an earlier ba_schur may still be reading what this call writes: side stream, ba_border.hip)
   double* Wd = nullptr;
   if (store_W) {
     HIPCHECK(h, h->W.resize(std::max<size_t>(1, (size_t)h->nobs * 18)));
@@ -254,6 +255,8 @@ int ba_apply_update(ba_handle* h, int src, int dst, const double* motion, const 
   REQUIRE(h, (motion == nullptr) == (structure == nullptr), BA_ERR_INVALID_ARG,
           "ba_apply_update: give both motion and structure, or neither");
   HIPCHECK(h, hipSetDevice(h->device));
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;      // (border kernels of an earlier ba_schur may still be reading what this call writes: side stream, ba_border.hip)
+
   double sign = -1.0;
   if (motion) {
     sign = 1.0;

@@ -1062,6 +1062,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   if (!h) return BA_ERR_INVALID_ARG;
   h->cpos_in.clear(); h->cpos_out.clear();
   h->lin_reused = 0;
+  h->refined = 0;
   int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
   if (rc != BA_OK) return rc;
   rc = choose_camera_order(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
@@ -1085,7 +1086,7 @@ int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   const int64_t v[BA_INFO_COUNT] = {
       h->pperm.empty() ? 0 : 1, h->operm_identity ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
       h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
-      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf, h->cpos_in.empty() ? 0 : 1, h->caller_hb, h->nbc, h->lin_reused};
+      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf, h->cpos_in.empty() ? 0 : 1, h->caller_hb, h->nbc, h->lin_reused, h->refined};
   for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];
   return BA_OK;
 }

@@ -97,8 +97,11 @@ struct ResidentArgs {
   const unsigned char* pt_opt;
   double K[9];
   Sensor sensor;
-  double* cams;                 // the current set, in and out
-  double* X;
+  const double* cams;           // the current set the launch is given (read only: a launch whose workgroups lose each other must leave it as it was)
+  const double* X;
+  double* stage;                // device memory, [nc x 12 | nt x 3]: the set the run ends on - the HOST copies it over the current set once every workgroup has reported the same ending
+  int* group_exit;              // pinned host memory, [2 * ngroups]: every workgroup's (exit reason, trials walked)
+  int fault_group;              // test aid (option resident_fault): this workgroup REPORTS a time-out whatever happened (-1: none)
   double* out;                  // pinned host memory: the set the run ends on, [nc x 12 | nt x 3] (what ba_get_params will be asked for)
   double* xb;                   // exchange buffer: ngroups records of kResRec doubles
   long long* epoch;             // [2 * ngroups]: what each workgroup has published (partial sums | trial cost)
@@ -961,14 +964,17 @@ __global__ __launch_bounds__(kResThreads) void k_resident_lm(ResidentArgs A) {
   {
     const double* cm_cur = camL + cur * nc * 12;
     const double* X_cur = XL + cur * kResP * 3;
-    // (a launch whose workgroups lost each other leaves the set it was given untouched: they may not agree on how far they came)
-    const bool write_back = accepted_any && exit_reason != RES_TIMED_OUT;
+    // Never over the set the launch was given: workgroups that lost each other need not agree on how far they came (one passes its
+    // last wait and ends DONE while another's spin budget runs out on the same epoch), and a set updated by some of them only would
+    // corrupt the optimisation silently.  Every workgroup writes its slice to a staging copy and says how it ended; the host
+    // commits the copy when all of them ended alike (ba_lm_resident_end).
     if (grp == 0)
-      for (int i = tid; i < nc * 12; i += kResThreads) { if (write_back) A.cams[i] = cm_cur[i]; A.out[i] = cm_cur[i]; }
+      for (int i = tid; i < nc * 12; i += kResThreads) { A.stage[i] = cm_cur[i]; A.out[i] = cm_cur[i]; }
     for (int i = tid; i < np * 3; i += kResThreads) {
-      if (write_back) A.X[(size_t)p0 * 3 + i] = X_cur[i];
+      A.stage[(size_t)nc * 12 + (size_t)p0 * 3 + i] = X_cur[i];
       A.out[(size_t)nc * 12 + (size_t)p0 * 3 + i] = X_cur[i];
     }
+    if (tid == 0) { A.group_exit[2 * grp] = grp == A.fault_group ? (int)RES_TIMED_OUT : exit_reason; A.group_exit[2 * grp + 1] = ntrials; }
   }
   if (grp == 0 && tid == 0) {
     ResidentLog* g = A.log;

@@ -59,6 +59,7 @@ int ba_lm_resident_begin(ba_handle* h, int32_t max_steps, int32_t steps_taken, i
   ResidentLds lds;
   REQUIRE(h, resident_fits(h, &lds), BA_ERR_STATE, "ba_lm_resident: not a problem for the resident loop (ba_lm_resident_fits)");
   HIPCHECK(h, hipSetDevice(h->device));
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;      // (border kernels of an earlier ba_schur may still be reading what this call writes: side stream, ba_border.hip)
   const int G = (h->nt + kResP - 1) / kResP;
   if (h->res_xb.n < (size_t)(G + 1) * kResRec || h->res_epoch.n < (size_t)2 * G) {
     HIPCHECK(h, h->res_xb.resize((size_t)(kResMaxGroups + 1) * kResRec));      // + the record of sums
@@ -70,6 +71,9 @@ int ba_lm_resident_begin(ba_handle* h, int32_t max_steps, int32_t steps_taken, i
     if (rc != BA_OK) return rc;
   }
   if (!h->res_log) HIPCHECK(h, hipHostMalloc(&h->res_log, sizeof(ResidentLog), hipHostMallocDefault));
+  if (!h->res_exit) HIPCHECK(h, hipHostMalloc((void**)&h->res_exit, 2 * kResMaxGroups * sizeof(int), hipHostMallocDefault));
+  HIPCHECK(h, h->res_stage.resize((size_t)h->nc * 12 + (size_t)h->nt * 3));
+  for (int i = 0; i < 2 * kResMaxGroups; ++i) h->res_exit[i] = -1;
   {
     const size_t need = (size_t)h->nc * 12 + (size_t)h->nt * 3;
     if (h->res_out_doubles < need) {
@@ -96,7 +100,7 @@ int ba_lm_resident_begin(ba_handle* h, int32_t max_steps, int32_t steps_taken, i
   for (int i = 0; i < 9; ++i) a.K[i] = h->K[i];
   a.sensor = h->sensor;
   if (!h->opt.fast_paths) a.sensor.fast = 0;
-  a.cams = h->cams[p].p; a.X = h->X[p].p; a.out = h->res_out; a.xb = h->res_xb.p; a.epoch = h->res_epoch.p; a.epoch0 = h->res_epoch0;
+  a.cams = h->cams[p].p; a.X = h->X[p].p; a.stage = h->res_stage.p; a.group_exit = h->res_exit; a.fault_group = h->opt.resident_fault; a.out = h->res_out; a.xb = h->res_xb.p; a.epoch = h->res_epoch.p; a.epoch0 = h->res_epoch0;
   a.cost_slots = h->res_cost.p; a.parity0 = h->res_parity;
   a.scatter_min = h->opt.resident_scatter_min;
   a.max_steps = max_steps; a.max_trials = kResMaxTrials; a.nsteps = steps_taken; a.in_step = in_step ? 1 : 0; a.converged = converged ? 1 : 0;
@@ -120,6 +124,7 @@ int ba_lm_resident_begin(ba_handle* h, int32_t max_steps, int32_t steps_taken, i
   HIPCHECK(h, hipGetLastError());
   h->res_inflight = true;
   h->res_inflight_phys = p;
+  h->res_inflight_groups = G;
   return BA_OK;
 }
 
@@ -136,13 +141,18 @@ int ba_lm_resident_end(ba_handle* h, ba_resident_log* log) {
   REQUIRE(h, a.log->ntrials >= 0, BA_ERR_HIP, "ba_lm_resident: the kernel left no log");
   h->res_epoch0 += 2 * ((long long)a.log->ntrials + 2);
   h->res_parity = (h->res_parity + a.log->ntrials) & 1;
-  if (a.log->exit_reason != RES_TIMED_OUT) h->res_out_phys = p;      // (the kernel left the set it ended on in pinned memory)
-  if (a.log->exit_reason == RES_TIMED_OUT) {
+  // every workgroup must have ended the same way after the same number of trials: anything else (one that gave up waiting for the
+  // others, or - same fault, seen from the other side - one that finished while another gave up) is a launch that did not happen
+  bool agreed = a.log->exit_reason != RES_TIMED_OUT;
+  for (int g = 0; g < h->res_inflight_groups; ++g)
+    agreed = agreed && h->res_exit[2 * g] == a.log->exit_reason && h->res_exit[2 * g + 1] == a.log->ntrials;
+  if (agreed) h->res_out_phys = p;      // (the kernel left the set it ended on in pinned memory)
+  if (!agreed) {
     // a workgroup gave up waiting for the others: a fault of the kernel or of the GPU, never a property of the problem
     (void)hipMemsetAsync(h->res_epoch.p, 0, h->res_epoch.n * sizeof(long long), h->stream);
     h->res_epoch0 = 0;
     (void)resident_reset_cost_words(h);
-    // the kernel wrote nothing back (ba_resident.h): the current set is the one the launch was given, and the log says so -
+    // the kernel writes to a staging copy only (ba_resident.h): the current set is the one the launch was given, and the log says so -
     // no trial, nothing accepted, the schedule where it was.  The caller goes on through ba_lm_trial.
     h->err = "ba_lm_resident: the workgroups of the resident loop lost each other (timed out); nothing was changed";
     memset(log, 0, offsetof(ResidentLog, trial_damping));
@@ -159,8 +169,11 @@ int ba_lm_resident_end(ba_handle* h, ba_resident_log* log) {
     memcpy(log->trial_cost, src->trial_cost, nt * sizeof(double));
     memcpy(log->trial_accepted, src->trial_accepted, nt * sizeof(int));
   }
-  // the current set has moved (or not): nothing that was derived from it on the device is valid any more
+  // the current set has moved (or not): the staging copy becomes the current set (two small copies behind the kernel, nobody waits
+  // for them), and nothing that was derived from the old one on the device is valid any more
   if (log->accepted) {
+    HIPCHECK(h, hipMemcpyAsync(h->cams[p].p, h->res_stage.p, (size_t)h->nc * 12 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->X[p].p, h->res_stage.p + (size_t)h->nc * 12, (size_t)h->nt * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     h->have_linearization = h->have_schur = h->have_backsub = h->have_solution = false;
     h->point_blocks_valid = h->cam_blocks_valid = h->inv_valid = h->fac_valid = false;
   }

@@ -40,7 +40,9 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   REQUIRE(h, which == 0 || which == 1, BA_ERR_INVALID_ARG, "ba_schur: bad parameter set");
   const int p = h->phys(which);
   REQUIRE(h, h->have_linearization && h->have_params[p], BA_ERR_STATE, "ba_schur: call ba_linearize first");
+  h->schur_damping = damping;
   HIPCHECK(h, hipSetDevice(h->device));
+  if (int rcj = border_join(h); rcj != BA_OK) return rcj;      // (border kernels of an earlier ba_schur may still be reading what this call writes: side stream, ba_border.hip)
   int rc = ensure_reduced(h);
   if (rc != BA_OK) return rc;
   const int kern = pick_schur_kernel(h);         // (ba_set_option "schur" forces one: tests)

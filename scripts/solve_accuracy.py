@@ -1,35 +1,73 @@
-"""How accurate is the device's reduced solve where the LM walk is sensitive (damping 1e-3 at config 3)?  Walks optimize() to
-the first trial at that damping, takes [S | b] of that trial from the device, and compares ||S dC - b|| / ||b|| of the device's
-solution with LAPACK's (numpy.linalg.solve = gesv, what the reference calls, bundle_adjuster.py:303) and with Cholesky's."""
+"""How accurate is the device's reduced solve where the LM walk is sensitive (config 3 after five LM steps, damping 1e-3, condition
+number ~1e13)?  Uploads the ORACLE's [S | b] of that trial (tests/golden/config3_reduced_damping1e-3.npz, oracle/gen_golden_reduced.py:
+the same bits every run) into the device's band and solves it REPEAT times without and with the step of iterative refinement
+(csrc/ba_bcr_refine.h; option refine), against LAPACK's LU (numpy.linalg.solve = gesv, what the reference calls,
+bundle_adjuster.py:302-305) and LAPACK's Cholesky of the same numbers.
+
+    python scripts/solve_accuracy.py [REPEAT=20]      ->  the table kept as profiles/r06_solve_accuracy.txt
+
+Columns: relative residual ||S x - b|| / ||b||, normwise backward error ||S x - b|| / (||S||_2 ||x|| + ||b||) in units of
+eps = 2^-52, distance to LAPACK's Cholesky solution relative to LAPACK LU's distance to it."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
-import scipy.linalg as sl
-from pysfm_amd import Bundle, BundleAdjuster, sensor_model, synthetic_data as sd
-from pysfm_amd._capi import PARAMS_CUR
-nc, nt = 1000, 100000
-s = sd.generate_banded_scene(nc, nt, init_mode='params')
-b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], sensor_model=sensor_model.GaussianModel(1.))
-ba = BundleAdjuster(b, verbose=False)
-ba.optimize(max_steps=int(sys.argv[1]) if len(sys.argv) > 1 else 5)
-print('walk so far', [(d, o) for d, o, _ in ba.trial_log], 'next damping', ba._damping)
-be = ba.backend
-for damping in (ba._damping, 1e-3, 1e-4, 1e-2):
-    be.linearize(PARAMS_CUR)
-    be.schur(PARAMS_CUR, damping, 1e-5)
-    S, rhs = be.get_reduced()
-    n = be.nco * 6
-    A = S.transpose(0, 2, 1, 3).reshape(n, n)
-    rhs = rhs.reshape(n)
-    be.solve_reduced(None)
-    x_dev = be.get_solution().reshape(n)
-    t0 = time.time(); x_lu = np.linalg.solve(A, rhs); t_lu = time.time() - t0
-    try:
-        x_ch = sl.cho_solve(sl.cho_factor(A), rhs)
-    except Exception as e:
-        x_ch = None
-    res = lambda x: np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs)
-    ev = np.linalg.eigvalsh(A)
-    print('damping %g: cond %.2e | residual device %.2e  LAPACK LU %.2e  LAPACK Cholesky %s | |x_dev - x_lu| / |x_lu| %.2e  |x_ch - x_lu| / |x_lu| %s  (%s)'
-          % (damping, ev[-1] / ev[0], res(x_dev), res(x_lu), 'n/a' if x_ch is None else '%.2e' % res(x_ch), np.linalg.norm(x_dev - x_lu) / np.linalg.norm(x_lu),
-             'n/a' if x_ch is None else '%.2e' % (np.linalg.norm(x_ch - x_lu) / np.linalg.norm(x_lu)), be.last_solve_kind))
+import torch
+from pysfm_amd import synthetic_data as sd
+from pysfm_amd.backend import HipBackend
+from pysfm_amd._capi import PARAMS_CUR, SENSOR_GAUSS
+
+REPEAT = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+EPS = 2. ** -52
+g = np.load(os.path.join(ROOT, 'tests', 'golden', 'config3_reduced_damping1e-3.npz'))
+band, rhs, x_lu, x_ch, norm2 = g['band'], g['b'].reshape(-1), g['x_lu'], g['x_chol'], float(g['norm2'])
+nco, hb = band.shape[0], band.shape[1] - 1
+n = 6 * nco
+A = np.zeros((nco, nco, 6, 6))
+for d in range(hb + 1):
+    i = np.arange(nco - d)
+    A[i, i + d] = band[i, d]
+    A[i + d, i] = band[i, d].transpose(0, 2, 1)
+A = A.transpose(0, 2, 1, 3).reshape(n, n)
+res = lambda x: np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs)
+bwd = lambda x: np.linalg.norm(A @ x - rhs) / (norm2 * np.linalg.norm(x) + np.linalg.norm(rhs)) / EPS
+dist = lambda x: np.linalg.norm(x - x_ch) / np.linalg.norm(x_lu - x_ch)
+print('system: %d unknowns, half-bandwidth %d cameras, cond %.2e, ||S||_2 ||x|| / ||b|| = %.2e' % (n, hb, float(g['cond']), norm2 * np.linalg.norm(x_ch) / np.linalg.norm(rhs)))
+print('%-28s %12s %14s %22s' % ('solver', 'residual', 'backward / eps', '|x - x_chol| / |x_lu - x_chol|'))
+print('%-28s %12.3e %14.3f %22.3f' % ('LAPACK LU (gesv)', res(x_lu), bwd(x_lu), 1.))
+print('%-28s %12.3e %14.3f %22.3f' % ('LAPACK Cholesky (potrf)', res(x_ch), bwd(x_ch), 0.))
+
+s = sd.generate_banded_scene(1000, 100000, init_mode='params')
+be = HipBackend(0)
+be.set_problem(1000, 100000, s['obs_cam'], s['obs_pt'], s['obs_z'], s['K'], np.arange(1000, dtype=np.int32) - 1, np.ones(100000, np.uint8))
+be.set_sensor(SENSOR_GAUSS, [1., 0., 0., 1.])
+be.set_params(PARAMS_CUR, s['R0'], s['t0'], s['X0'])
+assert be.nco == nco and be.half_bandwidth == hb
+for refine in ('0', 'auto', '1'):
+    be.set_option('refine', refine)
+    rows = []
+    for rep in range(REPEAT):
+        be.linearize(PARAMS_CUR)
+        be.schur(PARAMS_CUR, float(g['damping']), 1e-5)          # (state only: the golden system replaces what it formed)
+        be.synchronize()                                          # (the handle works on a stream of its own: its kernels first, then the copies)
+        S_t, b_t = be.reduced_tensors()
+        S_t.copy_(torch.from_numpy(band.reshape(-1)))
+        b_t.copy_(torch.from_numpy(rhs))
+        torch.cuda.synchronize()
+        be.solve_reduced(None)
+        x = be.get_solution().reshape(n)
+        rows.append((res(x), bwd(x), dist(x)))
+    rows = np.array(rows)
+    print('%-28s %12.3e %14.3f %22.3f   (worst of %d; best %.3e %.3f %.3f; %d distinct answers; solver %s, %d solves refined)'
+          % ('device, refine = %s' % refine, rows[:, 0].max(), rows[:, 1].max(), rows[:, 2].max(), REPEAT, rows[:, 0].min(), rows[:, 1].min(), rows[:, 2].min(),
+             len(set(map(tuple, rows))), be.last_solve_kind, be.problem_info()['solves_refined']))
+# what the step costs: HIP events around the solve's kernels, 50 solves each
+for refine in ('0', '1'):
+    be.set_option('refine', refine)
+    be.enable_timing(True)
+    be.timings(reset=True)
+    for rep in range(50):
+        be.solve_reduced(None)
+    tm = be.timings(reset=True)
+    be.enable_timing(False)
+    print('refine = %s: %s' % (refine, {k: '%.1f us' % (1e3 * v['ms'] / 50) for k, v in tm.items() if v['launches']}))

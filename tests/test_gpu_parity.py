@@ -34,7 +34,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1,
-                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1, reuse_linearization=1)
+                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1, reuse_linearization=1, refine='auto')
 
 
 @pytest.fixture(autouse=True)
@@ -462,6 +462,97 @@ def config3():
     return banded(1000, 100000)
 
 
+# ------------------------------------------------------------------ the solve where the walk is sensitive: a golden [S | b], the same bits every run
+EPS = 2. ** -52
+
+
+@pytest.fixture(scope='module')
+def golden_reduced():
+    """tests/golden/config3_reduced_damping1e-3.npz (oracle/gen_golden_reduced.py): the ORACLE's reduced system of config 3 after five
+    LM steps at damping 1e-3 (condition number ~1e13), LAPACK's LU and Cholesky solutions of exactly these numbers."""
+    g = load_golden('config3_reduced_damping1e-3')
+    band, rhs = g['band'], g['b'].reshape(-1)
+    nco, hb = band.shape[0], band.shape[1] - 1
+    A = np.zeros((nco, nco, 6, 6))
+    for d in range(hb + 1):
+        i = np.arange(nco - d)
+        A[i, i + d] = band[i, d]
+        A[i + d, i] = band[i, d].transpose(0, 2, 1)
+    A = A.transpose(0, 2, 1, 3).reshape(6 * nco, 6 * nco)
+    return dict(g, A=A, rhs=rhs, nco=nco, hb=hb)
+
+
+def solve_golden_reduced(be, config3, g, refine, mask=None):
+    """The golden [S | b] copied into the device's band (no device arithmetic before the solve), solved by ba_solve_reduced."""
+    import torch
+    s = config3
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *default_flags(1000, 100000), O.Sensor.gaussian(1.))
+    assert be.nco == g['nco'] and be.half_bandwidth == g['hb'] and not be.problem_info()['cameras_permuted']
+    be.set_option('refine', refine)
+    be.linearize(0)
+    be.schur(0, float(g['damping']), 1e-5)               # (state and the damping the option looks at; the golden system replaces what it formed)
+    be.synchronize()                                         # (the handle works on a stream of its own: its kernels first, then the copies)
+    S_t, b_t = be.reduced_tensors()
+    S_t.copy_(torch.from_numpy(np.ascontiguousarray(g['band']).reshape(-1)))
+    b_t.copy_(torch.from_numpy(g['rhs']))
+    torch.cuda.synchronize()
+    before = be.problem_info()['solves_refined']
+    be.solve_reduced(mask)
+    assert be.last_solve_kind == 'bcr'
+    assert be.problem_info()['solves_refined'] - before == (0 if refine == '0' else 1)
+    return be.get_solution().reshape(-1)
+
+
+def test_golden_reduced_system_backward_error(be, config3, golden_reduced):
+    """bundle_adjuster.py:302-305 solves the reduced system with LAPACK's gesv.  On the golden system the device's solution - the block
+    cyclic reduction followed by one step of iterative refinement through its kept factors (csrc/ba_bcr_refine.h; on by default below
+    damping 1e-2) - has a normwise backward error ||S x - b|| / (||S||_2 ||x|| + ||b||) of at most 4 eps AND leaves a residual
+    ||S x - b|| / ||b|| no larger than 1.5 times the larger of LAPACK's two (LU, Cholesky): the input is the same bits every run, the
+    refinement's sums are in a fixed order, the residual it corrects is formed in twice the working precision."""
+    g = golden_reduced
+    A, rhs = g['A'], g['rhs']
+    res = lambda x: np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs)
+    bwd = lambda x: np.linalg.norm(A @ x - rhs) / (float(g['norm2']) * np.linalg.norm(x) + np.linalg.norm(rhs))
+    lapack = max(res(g['x_lu']), res(g['x_chol']))
+    x = solve_golden_reduced(be, config3, g, 'auto')
+    assert np.all(np.isfinite(x))
+    assert bwd(x) <= 4 * EPS, (bwd(x) / EPS, bwd(g['x_lu']) / EPS)
+    assert res(x) <= 1.5 * lapack, (res(x), res(g['x_lu']), res(g['x_chol']))
+    # the cyclic reduction alone (refine = 0) is within a few units of round-off as well - and the step does not make it worse
+    x0 = solve_golden_reduced(be, config3, g, '0')
+    assert bwd(x0) <= 4 * EPS and res(x0) <= 4 * lapack, (res(x0), lapack)
+    assert res(x) <= res(x0) * 1.05
+
+
+def test_golden_reduced_system_solution_vs_lapack(be, config3, golden_reduced):
+    """The device's solution of the golden system agrees with LAPACK's Cholesky solution at least as closely as LAPACK's own LU does
+    (times two): what is left is the system's sensitivity (condition number ~1e13), not the solver's.  Separate from the backward-error
+    test so that neither can hide the other."""
+    g = golden_reduced
+    x = solve_golden_reduced(be, config3, g, 'auto')
+    d_lu = np.linalg.norm(g['x_lu'] - g['x_chol'])
+    assert np.linalg.norm(x - g['x_chol']) <= 2. * d_lu + 1e-14 * np.linalg.norm(g['x_chol']), (np.linalg.norm(x - g['x_chol']), d_lu)
+    assert np.linalg.norm(x - g['x_lu']) <= 3. * d_lu + 1e-14 * np.linalg.norm(g['x_chol'])
+
+
+def test_golden_reduced_system_refinement_with_masked_parameters(be, config3, golden_reduced):
+    """param_mask deletes rows and columns (bundle_adjuster.py:292-300): the refinement's residual is that of the REDUCED system -
+    masked rows stay exactly zero, the rest solves the deleted system as LAPACK does."""
+    g = golden_reduced
+    n = 6 * g['nco']
+    mask = (np.arange(n) % 7 != 2).astype(np.uint8)
+    mask[6 * 400:6 * 403] = 0                                  # three whole cameras
+    keep = np.nonzero(mask)[0]
+    x = solve_golden_reduced(be, config3, g, '1', mask)
+    assert np.all(x[mask == 0] == 0.)
+    A, rhs = g['A'][np.ix_(keep, keep)], g['rhs'][keep]
+    ref = np.linalg.solve(A, rhs)
+    res = lambda v: np.linalg.norm(A @ v - rhs) / np.linalg.norm(rhs)
+    assert res(x[keep]) <= 1.5 * res(ref) + 2 * EPS, (res(x[keep]), res(ref))
+    x0 = solve_golden_reduced(be, config3, g, '0', mask)
+    close(x[keep], x0[keep], 1e-4)                             # (two answers of an ill-conditioned system: equal to its sensitivity)
+
+
 def test_config3_properties_1000x100k(be, config3):
     """BASELINE config 3 size (1000 cams / 100k pts / 1M obs).  The oracle is too slow for
     the full Schur here, so check size-independent properties plus the cheap oracle parts."""
@@ -620,6 +711,27 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
         close(be.get_solution().reshape(-1), sol['bcr'], 1e-13)
         if mask is not None:
             assert np.all(sol['bcr'][mask == 0] == 0)
+        # one step of iterative refinement through the kept factors (csrc/ba_bcr_refine.h; the damping of this test does not switch it
+        # on by itself): the same solution, a residual that is no larger, masked rows still exactly zero - nodes over three compute
+        # units and on one, every node size, level counts that are not powers of two, levels wider than the chip
+        if L <= 14:
+            for solver in ('bcr', 'bcr1') if L <= 12 else ('bcr',):
+                be.set_option('solver', solver)
+                be.set_option('refine', '1')
+                before = be.problem_info()['solves_refined']
+                be.solve_reduced(mask)
+                be.set_option('refine', 'auto')
+                assert be.last_solve_kind == 'bcr' and be.problem_info()['solves_refined'] == before + 1
+                xr = be.get_solution().reshape(-1)
+                close(xr, sol[solver], 1e-10)
+                assert mask is None or np.all(xr[mask == 0] == 0)
+                if nc <= 1000:
+                    S, rhs = be.get_reduced()
+                    A, rhs = S.transpose(0, 2, 1, 3).reshape(n, n), rhs.reshape(n)
+                    keep = np.arange(n) if mask is None else np.nonzero(mask)[0]
+                    A, rhs = A[np.ix_(keep, keep)], rhs[keep]
+                    res = lambda v: np.linalg.norm(A @ v[keep] - rhs) / np.linalg.norm(rhs)
+                    assert res(xr) <= 1.2 * res(sol[solver]) + 2.2e-16, (solver, res(xr), res(sol[solver]))
 
 
 @pytest.mark.parametrize('nc,L,sensor', [(40, 10, O.Sensor.cauchy(.05)), (30, 4, O.Sensor.gaussian(1.)),

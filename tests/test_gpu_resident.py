@@ -410,3 +410,43 @@ def test_degenerate_shapes():
     a, r = run(b, False, max_steps=4), run(b, True, max_steps=4)
     assert [(d, o) for d, o, _ in a.trial_log] == [(d, o) for d, o, _ in r.trial_log]
     close(r.costs, a.costs, 1e-8)
+
+
+@pytest.mark.parametrize('fault', [0, 3, 6])
+def test_a_launch_whose_workgroups_disagree_changes_nothing(fault):
+    """Round-5 ADVICE: workgroups of the resident loop that lose each other need not agree on how they ended - one passes its last
+    wait and ends DONE (it used to write its slice of the current set back) while another's spin budget runs out on the same
+    epoch (it wrote nothing): a partially updated set the host believed untouched.  Now every workgroup writes to a staging copy
+    and reports (reason, trials); the host commits the copy only when all reports are alike.  Option resident_fault makes ONE
+    workgroup report a time-out after a perfectly normal run: the launch must then count as not having happened - the current
+    set on the device bit for bit the one it was given - and the Python loop takes over and ends where it ends without the fault."""
+    import warnings
+    from pysfm_amd import BundleAdjuster
+    b, _ = small_scene(10, 100, 10, 77, O.Sensor.cauchy(.05), outliers=.05)
+    clean = run(b, False, max_steps=6)
+    ba = BundleAdjuster(verbose=False)
+    ba.set_bundle(b)
+    be = ba.backend
+    assert ba._resident_applies(None) and (be.nt + 15) // 16 == 7
+    be.set_option('resident_fault', fault)
+    before = be.get_params(0)
+    log = be.lm_resident(6, 0, False, False, 10., 1e-4, 1e-5, -1., None)
+    from pysfm_amd._capi import RESIDENT_TIMED_OUT
+    assert log.exit_reason == RESIDENT_TIMED_OUT and log.ntrials == 0 and not log.accepted
+    after = be.get_params(0)
+    for x, y in zip(before, after):
+        assert np.array_equal(x, y)
+    # ... and through the adjuster: a warning, the loop over ba_lm_trial from the same start, the same end
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ba.optimize(max_steps=6)
+    assert any('resident loop timed out' in str(x.message) for x in w) and ba.resident_timeouts == 1 and ba.resident is False
+    same_walk(clean, ba)
+    be.set_option('resident_fault', -1)
+    # without the fault the same handle's next launch commits
+    ba2 = BundleAdjuster(verbose=False)
+    ba2.set_bundle(b)
+    ba2.optimize(max_steps=6)
+    assert getattr(ba2, 'resident_timeouts', 0) == 0
+    same_walk(clean, ba2)
+    ba.backend.close(); ba2.backend.close(); clean.backend.close()
