@@ -61,7 +61,7 @@ typedef enum ba_param_set { BA_PARAMS_CUR = 0, BA_PARAMS_TRIAL = 1 } ba_param_se
 enum {
   BA_K_COST = 0, BA_K_LINEARIZE, BA_K_POINT_INVERT, BA_K_SCHUR_INIT, BA_K_SCHUR_PAIRS,
   BA_K_BACKSUB, BA_K_UPDATE, BA_K_FLATTEN, BA_K_BAND_SOLVE, BA_K_EVAL, BA_K_CAMERA_BLOCKS, BA_K_TRIANGULATE,
-  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_DENSE_SOLVE, BA_K_BORDER_SCHUR, BA_K_BORDER_SOLVE, BA_K_BCR_REFINE, BA_K_COUNT
+  BA_K_BCR_ASSEMBLE, BA_K_BCR_ELIMINATE, BA_K_BCR_BACKSOLVE, BA_K_DENSE_SOLVE, BA_K_BORDER_SCHUR, BA_K_BORDER_SOLVE, BA_K_BCR_REFINE, BA_K_PCG_SOLVE, BA_K_COUNT
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -258,7 +258,8 @@ int ba_get_point_inverses(ba_handle* h, double* HPP_inv);
 
 /* Device views of the reduced system for the collective and the dense solver
  * (sizes: ba_reduced_layout).  With ba_bind_reduced_buffers the caller supplies the
- * device memory (e.g. one torch tensor holding [S | b]) instead.
+ * device memory (e.g. one torch tensor holding [S | b]) instead.  (A caller that WRITES the band itself keeps every block no
+ * track touches zero: on sparse layouts - BA_SOLVE_PCG - only those blocks are initialised again by the next ba_schur.)
  * These views are in the INTERNAL order of the optimised cameras (camera_order = auto is the default: an unordered scene is
  * reordered, BA_INFO_CAMERAS_PERMUTED): row / block i belongs to the caller's position p with new_pos[p] == i
  * (ba_get_camera_layout).  With border cameras (BA_INFO_BORDER_CAMERAS > 0) the band covers the first band_cameras positions
@@ -295,8 +296,13 @@ int ba_set_dense_visibility(ba_handle* h, int32_t on);
  * Cholesky pivot that was not positive; 0x7f000001 = a workgroup of the one-launch cyclic reduction gave up waiting for
  * another - a fault of the solver, reported instead of hanging the GPU (solve again with option solver = lu).
  * ba_last_solve_kind: which solver produced the state of the last ba_solve_reduced. */
-enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY, BA_SOLVE_BCR_LU, BA_SOLVE_BCR_BIG, BA_SOLVE_BAND_LU };
+enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOLVE_DENSE_CHOLESKY, BA_SOLVE_BCR_LU, BA_SOLVE_BCR_BIG, BA_SOLVE_BAND_LU, BA_SOLVE_PCG };
 #define BA_SOLVE_TIMED_OUT 0x7f000001   /* *info of a cyclic reduction whose workgroups gave up waiting for each other */
+#define BA_SOLVE_STALLED 0x7f000002     /* *info of conjugate gradients (BA_SOLVE_PCG) that did not converge within their iteration budget */
+/* Conjugate gradients over the blocks of S the tracks define (csrc/ba_pcg.h; solver = pcg, or chosen when the scene has no narrow
+ * band under any camera order: at least 1500 optimised cameras, at most a tenth of the band's blocks non-zero): the blocks of the
+ * upper triangle that can be non-zero, the iterations and ||r|| / ||b|| of the last such solve, the fraction of the band they fill. */
+int ba_pcg_info(ba_handle* h, int64_t* blocks, int32_t* iterations, double* rel_residual, double* band_fill);
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);
 int ba_get_solution(ba_handle* h, double* dC /*[nco*6] host*/);

@@ -20,13 +20,14 @@ SENSOR_GAUSS, SENSOR_CAUCHY, SENSOR_HUBER, SENSOR_TABLE = 0, 1, 2, 3
 PARAMS_CUR, PARAMS_TRIAL = 0, 1
 KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 'backsub',
               'update', 'flatten', 'band_solve', 'eval', 'camera_blocks', 'triangulate',
-              'bcr_assemble', 'bcr_eliminate', 'bcr_backsolve', 'dense_solve', 'border_schur', 'border_solve', 'bcr_refine')
+              'bcr_assemble', 'bcr_eliminate', 'bcr_backsolve', 'dense_solve', 'border_schur', 'border_solve', 'bcr_refine', 'pcg_solve')
 K_COUNT = len(KERNEL_IDS)
 INFO_KEYS = ('points_permuted', 'obs_permuted', 'groups', 'mfma_groups', 'point_groups', 'max_track_len',
              'half_bandwidth', 'schur_mfma', 'schur_groups', 'lds_window_rows', 'pair_units', 'schur_kernel',
              'mfma_points_per_batch_cap', 'mfma_k_rows', 'cameras_permuted', 'caller_half_bandwidth', 'border_cameras', 'linearizations_reused', 'solves_refined')      # BA_INFO_*
-SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky', 'bcr_lu', 'bcr_big', 'band_lu')
+SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky', 'bcr_lu', 'bcr_big', 'band_lu', 'pcg')
 SOLVE_TIMED_OUT = 0x7f000001            # BA_SOLVE_TIMED_OUT of include/pysfm_ba.h
+SOLVE_STALLED = 0x7f000002              # BA_SOLVE_STALLED: conjugate gradients out of iterations
 DIST_INFO_KEYS = ('on', 'cams_per_node', 'nodes', 'nodes_per_rank', 'node_lo', 'node_hi', 'cam_lo', 'cam_hi',
                   'exchange1_doubles', 'exchange2_doubles', 'exchange3_doubles', 'separators')      # ba_dist_info
 
@@ -62,6 +63,7 @@ PROTOTYPES = {
     'ba_order_cameras': (C.c_int, [C.c_int32, C.c_int32, _ip, _ip, _ip, _ip]),
     'ba_set_camera_layout': (C.c_int, [_h, _ip, C.c_int32]),
     'ba_get_camera_layout': (C.c_int, [_h, _ip, C.POINTER(C.c_int32)]),
+    'ba_pcg_info': (C.c_int, [_h, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'ba_plan_camera_layout': (C.c_int, [C.c_int32, C.c_int32, _ip, _ip, _ip, C.c_int32, _ip, _ip, _ip]),
     'ba_set_sensor': (C.c_int, [_h, C.c_int, _dp, C.c_int]),
     'ba_set_params': (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),

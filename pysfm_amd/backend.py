@@ -135,6 +135,13 @@ class HipBackend(object):
         self._check(self._lib.ba_get_camera_layout(self._h, capi.iptr(new_pos), C.byref(band)))
         return new_pos[:self.nco], band.value
 
+    def pcg_info(self):
+        """ba_pcg_info: the blocks of S (upper triangle) the tracks define, iterations and ||r|| / ||b|| of the last solve by
+        conjugate gradients (csrc/ba_pcg.h), the fraction of the band those blocks fill."""
+        blocks, it, rel, fill = C.c_int64(0), C.c_int32(0), C.c_double(0.), C.c_double(0.)
+        self._check(self._lib.ba_pcg_info(self._h, C.byref(blocks), C.byref(it), C.byref(rel), C.byref(fill)))
+        return dict(blocks=blocks.value, iterations=it.value, rel_residual=rel.value, band_fill=fill.value)
+
     def plan_camera_layout(self, nco, list_off, list_pos, list_points=None, allow_border=False):
         """ba_plan_camera_layout (a pure function: no GPU work): (new_pos, band_cameras, half_bandwidth)."""
         list_off, list_pos = capi.i32(list_off), capi.i32(list_pos)
@@ -485,7 +492,7 @@ class HipBackend(object):
         definite, or by option); last_solve_path: 'lu' for those two, 'dense_cholesky' or 'band' for the Cholesky solvers."""
         self.last_solve_kind = capi.SOLVE_KINDS[self._lib.ba_last_solve_kind(self._h)]
         self.last_solve_path = 'lu' if self.last_solve_kind in ('bcr_lu', 'band_lu') else \
-            'dense_cholesky' if self.last_solve_kind == 'dense_cholesky' else 'band'
+            'dense_cholesky' if self.last_solve_kind == 'dense_cholesky' else 'pcg' if self.last_solve_kind == 'pcg' else 'band'
 
     def trial_result(self):
         """Device tensor [TRIAL_PARTIALS cost partials | singular point blocks | solver status]."""

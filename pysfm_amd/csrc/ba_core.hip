@@ -165,7 +165,7 @@ const char* ba_kernel_name(int id) {
   static const char* names[BA_K_COUNT] = {"k_cost", "k_linearize", "k_point_invert", "k_schur_init",
                                           "k_schur_pairs", "k_backsub", "k_apply_update", "k_flatten",
                                           "k_band_solve", "k_eval", "k_camera_blocks", "k_triangulate",
-                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve", "k_dense_solve", "k_schur_border", "k_border_solve", "k_bcr_refine"};
+                                          "k_bcr_assemble", "k_bcr_eliminate", "k_bcr_backsolve", "k_dense_solve", "k_schur_border", "k_border_solve", "k_bcr_refine", "k_pcg"};
   return (id >= 0 && id < BA_K_COUNT) ? names[id] : "?";
 }
 
@@ -234,6 +234,7 @@ int ba_destroy(ba_handle* h) {
   if (h->host_result) (void)hipHostFree(h->host_result);
   if (h->res_log) (void)hipHostFree(h->res_log);
   if (h->res_exit) (void)hipHostFree(h->res_exit);
+  if (h->pcg.host_state) (void)hipHostFree(h->pcg.host_state);
   if (h->res_out) (void)hipHostFree(h->res_out);
   if (h->io) (void)hipHostFree(h->io);
   if (h->res_trace) (void)hipHostFree(h->res_trace);
@@ -258,6 +259,7 @@ int ba_debug_poison(ba_handle* h) {
     if (b->p && b->n) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, h->stream, b->p, b->n);
   if (h->bcr_done.p && h->bcr_done.n >= 2)          // the "handed on" words of k_bcr_eliminate_fused: garbage that reads as "done" unless k_bcr_assemble clears it
     hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((h->bcr_done.n / 2 + 255) / 256)), dim3(256), 0, h->stream, reinterpret_cast<double*>(h->bcr_done.p), h->bcr_done.n / 2);
+  h->pcg.band_clean = false;
   if (h->S) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)((reduced_doubles(h) + 255) / 256)), dim3(256), 0, h->stream, h->S, reduced_doubles(h));
   if (h->b && h->nco) hipLaunchKernelGGL(k_poison_doubles, dim3((unsigned)(((size_t)h->nco * 6 + 255) / 256)), dim3(256), 0, h->stream, h->b, (size_t)h->nco * 6);
   HIPCHECK(h, hipGetLastError());
@@ -285,7 +287,10 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   };
   bool ok = false;
   if (n == "schur") ok = choice({"auto", "pairs", "groups", "mfma2", "mfma"}, h->opt.schur);
-  else if (n == "solver") ok = choice({"auto", "bcr", "band", "dense", "lu", "bcr1"}, h->opt.solver);
+  else if (n == "solver") ok = choice({"auto", "bcr", "band", "dense", "lu", "bcr1", "pcg"}, h->opt.solver);
+  else if (n == "pcg_tol") { char* end = nullptr; const double c = strtod(value, &end); ok = end && *end == 0 && c > 0.0 && c < 1.0; if (ok) h->opt.pcg_tol = c; }
+  else if (n == "pcg_max_iter") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0 && c <= 10000000; if (ok) h->opt.pcg_max_iter = (int)c; }
+  else if (n == "pcg_batch") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 1 && c <= 100000; if (ok) h->opt.pcg_batch = (int)c; }
   else if (n == "point_kernels") { int c = 0; ok = choice({"auto", "v1"}, c); if (ok) h->opt.point_kernels_v1 = c == 1; }
   else if (n == "fuse_cost") ok = flag(h->opt.fuse_cost);
   else if (n == "fuse_cam") ok = flag(h->opt.fuse_cam);

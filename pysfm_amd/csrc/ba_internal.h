@@ -42,12 +42,14 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+struct PcgStateRaw { int last_iter, done_iter, breakdown, pad; double rr, bb; };      // = PcgState of ba_pcg.h
+
 struct TimedLaunch { int id; hipEvent_t a, b; int count; };
 
 // Test / measurement switches (ba_set_option).  The defaults are the product path; nothing in the library
 // reads the environment.
 enum { SCHUR_AUTO = 0, SCHUR_PAIRS, SCHUR_GROUPS, SCHUR_MFMA2, SCHUR_MFMA };
-enum { SOLVER_AUTO = 0, SOLVER_BCR, SOLVER_BAND, SOLVER_DENSE, SOLVER_LU, SOLVER_BCR1 };
+enum { SOLVER_AUTO = 0, SOLVER_BCR, SOLVER_BAND, SOLVER_DENSE, SOLVER_LU, SOLVER_BCR1, SOLVER_PCG };
 struct Options {
   int schur = SCHUR_AUTO;
   int solver = SOLVER_AUTO;
@@ -74,11 +76,17 @@ struct Options {
   bool reuse_linearization = true; // ba_lm_trial after a rejected trial: the point blocks of the unchanged current set are not formed again
   bool border_side_stream = true;  // the border's blocks and the preparation of its solve on a side stream beside the cyclic reduction (off: in line)
   bool border = true;              // ... and a border for the cameras at the far end of a few long-range tracks (ba_border.h)
+  double pcg_tol = 1e-12;          // conjugate gradients (ba_pcg.h): converged at ||r|| <= pcg_tol ||b||
+  int pcg_max_iter = 0;            // ... iteration budget (0: max(1000, min(20000, 4 nco)))
+  int pcg_batch = 50;              // ... iterations enqueued between two looks at the state
   int refine = 0;                  // one step of iterative refinement behind the cyclic reduction (ba_bcr_refine.h): 0 auto (damping below kRefineBelowDamping), 1 always, 2 never
   int camera_order = 0;            // internal order of the optimised cameras (ba_order.hip): 0 auto (when the caller's is not provably as narrow as it can be), 1 off, 2 always try
 };
 enum { CAMORDER_AUTO = 0, CAMORDER_OFF, CAMORDER_ALWAYS };
 enum { REFINE_AUTO = 0, REFINE_ON, REFINE_OFF };
+constexpr int kPcgStalled = 0x7f000002;            // status word of conjugate gradients that ran out of iterations (BA_SOLVE_STALLED)
+constexpr int kPcgMinCams = 1500;                  // auto: from here on (dense Cholesky: 25 ms and growing with the cube) ...
+constexpr double kPcgMaxFill = 0.10;               // ... and when at most this fraction of the band's blocks can be non-zero
 constexpr double kRefineBelowDamping = 1e-2;      // where the LM walk starts to feel the last digits of the reduced solve
 constexpr int kBordMaxCamsHost = 21;       // (= kBordMaxCams of ba_border.h: 126 border unknowns fit the LDS of the border solve)
 
@@ -242,6 +250,22 @@ struct ba_handle {
     DevBuf<double> xown;
     size_t xcount[3] = {0, 0, 0};       // doubles of the three exchanges
   } dist;
+  // conjugate gradients over the blocks of S the tracks define (ba_pcg.h / ba_pcg.hip)
+  struct PcgPlan {
+    bool built = false;
+    long long nnz = 0, upper = 0;       // blocks of the full symmetric pattern; of its upper triangle (diagonal included)
+    DevBuf<int> rowptr, col;
+    DevBuf<long long> blk;              // block index in the band: lo (hb + 1) + (hi - lo)
+    DevBuf<long long> ublk;             // ... of the upper triangle's blocks alone (what the reductions write)
+    bool band_clean = false;            // every block of the band outside the pattern is zero (one full initialisation, nothing scribbled since)
+    DevBuf<double> minv, r, z, q, p[2], part;
+    DevBuf<PcgStateRaw> state;
+    PcgStateRaw* host_state = nullptr;  // pinned
+    int host_status = 0;
+    int iterations = 0;                 // of the last solve
+    int last_status = 0;
+    double rel_residual = 0.0;
+  } pcg;
   bool have_solution = false;
   bool defer = false;        // inside ba_lm_trial: leave status words / cost on the device, one read-back at the end
   DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
@@ -441,6 +465,10 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
 int solve_bcr_wide(ba_handle* h, const unsigned char* dmask);
 int solve_bcr_big(ba_handle* h, const unsigned char* dmask);
 int solve_dense_chol(ba_handle* h, const unsigned char* dmask);
+int solve_pcg(ba_handle* h, const unsigned char* dmask);          // conjugate gradients over the blocks the tracks define (ba_pcg.hip)
+bool sparse_layout(ba_handle* h);                                 // a wide band of mostly structural zeros: the pattern-driven initialisation and solver apply
+int launch_schur_init_sparse(ba_handle* h, double damping, int use_hcc);
+double pcg_band_fill(ba_handle* h);                               // fraction of the band's blocks that can be non-zero (builds the pattern)
 int solve_band_lu(ba_handle* h, const unsigned char* dmask);      // LU with partial pivoting, any band width (ba_band_lu.h)
 // k_bcr_assemble (ba_bcr.h): band (+ mask) -> D, U, f of the nodes of cb cameras; clears the status word
 void launch_bcr_assemble(ba_handle* h, dim3 grid, int cb, const unsigned char* dmask, double* xsol, int* done, const int* nodes);

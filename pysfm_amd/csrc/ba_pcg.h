@@ -1,0 +1,296 @@
+// ba_pcg.h - the reduced camera system of an UNORDERED scene: conjugate gradients with a block-Jacobi preconditioner over the
+// blocks of S that the co-visibility graph defines (solve_motion_normal_eqns, bundle_adjuster.py:281-312; SURVEY 8f1 "block-Jacobi PCG").
+//
+// The reference solves a dense S whatever its pattern.  The direct solvers here want a band (ba_bcr*.h) or pay O(n^3)
+// (ba_dense.h: 63 ms at 2000 cameras; beyond 2666 cameras only LU down the band is left: 34 s at 5000).  A photo collection in which
+// every camera shares points with a few dozen others ANYWHERE has no narrow band under any order, but its S is sparse: 1-3 % of
+// the blocks.  S stays where the reductions put it - the block band of the Cuthill-McKee order, mostly zeros - and a list of
+// the blocks that can be non-zero (built once per problem from the tracks' camera lists, ba_pcg.hip) drives the product:
+//     x = 0, r = b, z = M^-1 r, p = z          M = the 6 x 6 diagonal blocks of S (their inverses: k_pcg_minv)
+//     q = S p, alpha = (r.z) / (p.q), x += alpha p, r -= alpha q, z = M^-1 r, beta = (r.z)' / (r.z), p = z + beta p
+// Two launches per iteration, no grid barrier, no atomics: k_pcg_product forms p for the rows it owns and q = S p (a wavefront per
+// block row, eight blocks in flight, 288 contiguous bytes each), k_pcg_update the rest; every scalar product leaves a partial sum
+// per workgroup, and the NEXT launch's workgroups each add the partials up for themselves, in the same order - so all of them
+// see the same alpha, beta and residual norm to the last bit and take the same decision to stop (a launch after convergence
+// returns at once: the host enqueues iterations in batches and looks at the state in between).
+// Masked camera parameters (param_mask) are rows and columns deleted: their entries of r, z, p, q stay exactly zero.
+// A diagonal block that is not positive definite, or p.q <= 0 (S indefinite): status word > 0, as from the Cholesky solvers.
+#pragma once
+
+#include "ba_internal.h"
+#include "ba_device.h"
+
+namespace ba {
+
+constexpr int kPcgRowsPerBlock = 4;          // k_pcg_product: a wavefront per block row
+constexpr int kPcgUnknownsPerBlock = 252;     // k_pcg_start / k_pcg_update: whole cameras per workgroup (42 of them), a thread per unknown, four threads idle
+
+struct PcgState {                            // device memory, copied to the host between batches
+  int last_iter;                             // the iteration the latest k_pcg_product saw
+  int done_iter;                             // -1, or the iteration at which r.r <= tol^2 b.b
+  int breakdown;                             // p.q <= 0 at this iteration + 1 (S is not positive definite), else 0
+  int pad;
+  double rr, bb;                             // r.r at last_iter, b.b
+};
+
+// sum of n partials, every thread of the workgroup gets it (same order in every workgroup: same bits)
+__device__ __forceinline__ double pcg_block_sum(const double* __restrict__ part, int n, double* lds /*[kBlock]*/) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) s += part[i];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = kBlock / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) lds[threadIdx.x] += lds[threadIdx.x + w];
+    __syncthreads();
+  }
+  const double out = lds[0];
+  __syncthreads();
+  return out;
+}
+
+// this workgroup's contribution to a scalar product -> part[blockIdx.x]
+__device__ __forceinline__ void pcg_block_partial(double v, double* __restrict__ part, double* lds) {
+  lds[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = kBlock / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) lds[threadIdx.x] += lds[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = lds[0];
+  __syncthreads();
+}
+
+// M^-1: inverses of the diagonal blocks (masked parameters: identity rows and columns), one thread per camera.
+// A block that is not positive definite: status word = camera + 1 (smallest wins), its inverse = identity.
+__global__ __launch_bounds__(kBlock) void k_pcg_minv(int nco, int hb1, const double* __restrict__ S, const unsigned char* __restrict__ mask,
+                                                     double* __restrict__ minv, int* __restrict__ info) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nco) return;
+  const double* D = S + band_block(i, i, hb1);
+  double A[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = a; b < 6; ++b) {
+      const bool keep = !mask || (mask[6 * i + a] && mask[6 * i + b]);
+      A[a][b] = keep ? D[a * 6 + b] : (a == b ? 1.0 : 0.0);      // (the band holds the diagonal blocks by their upper triangle)
+    }
+  // U^T U = A in place (upper), then W = U^-1 (upper), A^-1 = W W^T
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double d = A[k][k];
+#pragma unroll
+    for (int m = 0; m < k; ++m) d -= A[m][k] * A[m][k];
+    ok = ok && d > 0.0;
+    const double u = ok ? sqrt(d) : 1.0;
+    A[k][k] = u;
+#pragma unroll
+    for (int c = k + 1; c < 6; ++c) {
+      double v = A[k][c];
+#pragma unroll
+      for (int m = 0; m < k; ++m) v -= A[m][k] * A[m][c];
+      A[k][c] = v / u;
+    }
+  }
+  double W[6][6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+      if (r > c) { W[r][c] = 0.0; continue; }
+      double v = r == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = r + 1; m <= c; ++m) v -= A[r][m] * W[m][c];
+      W[r][c] = v / A[r][r];
+    }
+  }
+  double* out = minv + (size_t)i * 36;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) v += (m >= a && m >= b) ? W[a][m] * W[b][m] : 0.0;
+      out[a * 6 + b] = ok ? v : (a == b ? 1.0 : 0.0);
+    }
+  if (!ok) {
+    // the smallest failing camera + 1 wins (0 = fine): compare-and-swap loop on the status word
+    int old = *info;
+    while (old == 0 || old > i + 1) {
+      const int seen = atomicCAS(info, old, i + 1);
+      if (seen == old) break;
+      old = seen;
+    }
+  }
+}
+
+// x = 0, r = b (masked), z = M^-1 r, partial sums of r.z and b.b; a thread per unknown.  Clears the state.
+__global__ __launch_bounds__(kBlock) void k_pcg_start(int n, const double* __restrict__ b, const unsigned char* __restrict__ mask,
+                                                      const double* __restrict__ minv, double* __restrict__ x, double* __restrict__ r,
+                                                      double* __restrict__ z, double* __restrict__ part_rz, double* __restrict__ part_rr,
+                                                      PcgState* __restrict__ st) {
+  __shared__ double lds[kBlock];
+  const int u = blockIdx.x * kPcgUnknownsPerBlock + threadIdx.x;
+  double rz = 0.0, rr = 0.0;
+  if (u < n && threadIdx.x < kPcgUnknownsPerBlock) {
+    const int i = u / 6, a = u - 6 * i;
+    double zv = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double rc = (!mask || mask[6 * i + c]) ? b[6 * i + c] : 0.0;
+      zv += minv[(size_t)i * 36 + a * 6 + c] * rc;
+    }
+    const bool keep = !mask || mask[u];
+    const double rv = keep ? b[u] : 0.0;
+    zv = keep ? zv : 0.0;
+    x[u] = 0.0; r[u] = rv; z[u] = zv;
+    rz = rv * zv; rr = rv * rv;
+  }
+  pcg_block_partial(rz, part_rz, lds);
+  pcg_block_partial(rr, part_rr, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st->last_iter = -1; st->done_iter = -1; st->breakdown = 0; st->rr = 0.0; st->bb = 0.0; }
+}
+
+// Iteration k, first half: beta from the partial sums of the two latest r.z, p = z + beta p_old for the rows this workgroup owns,
+// q = S p for them, the partial sum of p.q.  nparts = partials of the update kernel's grid.
+__global__ __launch_bounds__(kBlock) void k_pcg_product(int k, int nco, int hb1, const double* __restrict__ S, const int* __restrict__ rowptr,
+                                                        const int* __restrict__ col, const long long* __restrict__ blk,
+                                                        const double* __restrict__ z, const double* __restrict__ p_old,
+                                                        double* __restrict__ p_new, double* __restrict__ q,
+                                                        const double* __restrict__ part_rz /*[2][nparts]*/, const double* __restrict__ part_rr /*[2][nparts]*/,
+                                                        int nparts, double tol2, double* __restrict__ part_pq, PcgState* __restrict__ st) {
+  __shared__ double lds[kBlock];
+  const double rz_new = pcg_block_sum(part_rz + (size_t)(k & 1) * nparts, nparts, lds);
+  const double rr = pcg_block_sum(part_rr + (size_t)(k & 1) * nparts, nparts, lds);
+  const double bb = k == 0 ? rr : st->bb;                 // (r = b at the start; written below by workgroup 0 of iteration 0, read from iteration 1 on)
+  if (st->done_iter >= 0 || st->breakdown) return;        // (decided by an earlier launch: every workgroup reads the same words)
+  const bool done = rr <= tol2 * bb;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->last_iter = k; st->rr = rr;
+    if (k == 0) st->bb = rr;
+  }
+  if (done) {
+    // (all workgroups take this branch together: the sums above are the same bits everywhere.  The word itself is written by the
+    //  UPDATE launch of this iteration - after every workgroup of this launch has read it.)
+    return;
+  }
+  double beta = 0.0;
+  if (k > 0) {
+    const double rz_old = pcg_block_sum(part_rz + (size_t)((k - 1) & 1) * nparts, nparts, lds);
+    beta = rz_new / rz_old;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * kPcgRowsPerBlock + wave;
+  const int a = lane & 7, ks = lane >> 3;
+  const int aa = a < 6 ? a : 5;
+  double acc = 0.0;
+  if (i < nco) {
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int e = e0 + ks; e < e1; e += 8) {
+      const int j = col[e];
+      const double* B = S + blk[e] * 36;
+      const bool flip = j < i, diag = j == i;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const bool tr = flip || (diag && aa > c);          // (blocks are kept for i <= j, the diagonal ones by their upper triangle)
+        const double sv = B[tr ? c * 6 + aa : aa * 6 + c];
+        const double pv = z[6 * (size_t)j + c] + (k > 0 ? beta * p_old[6 * (size_t)j + c] : 0.0);
+        acc += sv * pv;
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  double pq = 0.0;
+  if (i < nco && lane < 6) {
+    const size_t u = 6 * (size_t)i + lane;
+    const double pv = z[u] + (k > 0 ? beta * p_old[u] : 0.0);
+    p_new[u] = pv;
+    q[u] = acc;
+    pq = pv * acc;
+  }
+  pcg_block_partial(pq, part_pq, lds);
+}
+
+// Iteration k, second half: alpha = (r.z) / (p.q); x += alpha p, r -= alpha q (masked rows stay zero), z = M^-1 r; partial sums of
+// the new r.z and r.r into the other parity.  A thread per unknown; nprod = partials of the product kernel's grid.
+__global__ __launch_bounds__(kBlock) void k_pcg_update(int k, int n, const unsigned char* __restrict__ mask, const double* __restrict__ minv,
+                                                       const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x,
+                                                       double* __restrict__ r, double* __restrict__ z, double* __restrict__ part_rz,
+                                                       double* __restrict__ part_rr, int nparts, const double* __restrict__ part_pq, int nprod,
+                                                       double tol2, PcgState* __restrict__ st) {
+  __shared__ double lds[kBlock];
+  __shared__ double rs[kBlock];
+  const double rz = pcg_block_sum(part_rz + (size_t)(k & 1) * nparts, nparts, lds);
+  const double rr = pcg_block_sum(part_rr + (size_t)(k & 1) * nparts, nparts, lds);
+  const double bb = st->bb;
+  if (st->done_iter >= 0 || st->breakdown) return;
+  if (rr <= tol2 * bb) {
+    // converged at iteration k (the product launch of this iteration returned without touching anything): say so - the word is
+    // only ever read at the START of a launch, and every workgroup of this one has read it above... not necessarily: a workgroup
+    // that starts late would see it set and return, which is what it would do anyway (same branch, nothing to write).
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->done_iter = k;
+    return;
+  }
+  const double pq = pcg_block_sum(part_pq, nprod, lds);
+  if (!(pq > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->breakdown = k + 1;
+    return;
+  }
+  const double alpha = rz / pq;
+  const int u = blockIdx.x * kPcgUnknownsPerBlock + threadIdx.x;
+  const bool in = u < n && threadIdx.x < kPcgUnknownsPerBlock;
+  const bool keep = in && (!mask || mask[u]);
+  double rv = 0.0;
+  if (in) {
+    x[u] += keep ? alpha * p[u] : 0.0;
+    rv = keep ? r[u] - alpha * q[u] : 0.0;
+    r[u] = rv;
+  }
+  rs[threadIdx.x] = rv;
+  __syncthreads();
+  double zv = 0.0;
+  if (in) {
+    // (the camera's six residual entries are this workgroup's: it owns whole cameras)
+    const int i = u / 6, a = u - 6 * i, base = 6 * i - blockIdx.x * kPcgUnknownsPerBlock;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) zv += minv[(size_t)i * 36 + a * 6 + c] * rs[base + c];
+    zv = keep ? zv : 0.0;
+  }
+  if (in) z[u] = zv;
+  pcg_block_partial(rv * zv, part_rz + (size_t)((k + 1) & 1) * nparts, lds);
+  pcg_block_partial(rv * rv, part_rr + (size_t)((k + 1) & 1) * nparts, lds);
+}
+
+__global__ void k_pcg_set_status(int* info, int v) { *info = v; }
+
+// schur_init_body of ba_schur_kernels.h over a LIST of blocks (the upper triangle of the pattern) instead of the whole band
+__global__ __launch_bounds__(kBlock) void k_schur_init_blocks(long long nblocks, const long long* __restrict__ ublk, int nco, int hb1,
+                                                              const int* __restrict__ opt_cam, const double* __restrict__ HCC,
+                                                              const double* __restrict__ bC, double damping, double* __restrict__ S,
+                                                              double* __restrict__ b, int use_hcc) {
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (tid < nblocks * 36) {
+    const int e = (int)(tid % 36);
+    const long long blk = ublk[tid / 36];
+    const int d = (int)(blk % hb1), pos = (int)(blk / hb1);
+    double v = 0.0;
+    if (d == 0 && use_hcc) {
+      const int a = e / 6, c = e % 6;
+      const int lo = a < c ? a : c, hi = a < c ? c : a;
+      v = HCC[(size_t)opt_cam[pos] * 36 + lo * 6 + hi];
+      if (a == c) v *= (1.0 + damping);
+    }
+    S[blk * 36 + e] = v;
+  } else if (tid < nblocks * 36 + (long long)nco * 6) {
+    const long long q = tid - nblocks * 36;
+    b[q] = use_hcc ? bC[(size_t)opt_cam[q / 6] * 6 + q % 6] : 0.0;
+  }
+}
+
+static_assert(sizeof(PcgState) == sizeof(PcgStateRaw), "PcgState mirrors PcgStateRaw of ba_internal.h");
+
+}  // namespace ba

@@ -1,0 +1,176 @@
+// ba_pcg.hip - ba_solve_reduced for scenes whose co-visibility is no band: the list of the blocks of S that can be non-zero (once per
+// problem, from the tracks' camera lists) and the preconditioned conjugate gradients over it (ba_pcg.h).
+#include "ba_internal.h"
+
+#include "ba_pcg.h"
+
+#include <algorithm>
+
+using namespace ba;
+
+namespace ba {
+
+// The pattern of S: block (i, j) can be non-zero iff some track is seen by the optimised cameras at positions i and j
+// (bundle_adjuster.py:270-276 visits exactly those).  Rows of the FULL symmetric pattern, sorted by column; a block lives in the
+// band at (min, max).  Built on the host from the observation list in the internal order (one download, 4 bytes per observation;
+// a point with the camera list of its predecessor adds nothing), uploaded once per problem.
+int pcg_build_pattern(ba_handle* h) {
+  auto& g = h->pcg;
+  if (g.built) return BA_OK;
+  const int nco = h->nco, hb1 = h->hb + 1;
+  std::vector<int> cam((size_t)h->nobs);
+  if (h->nobs) HIPCHECK(h, hipMemcpyAsync(cam.data(), h->obs_cam.p, (size_t)h->nobs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  std::vector<std::vector<int>> rows((size_t)nco);
+  for (int i = 0; i < nco; ++i) rows[i].push_back(i);                       // the diagonal blocks always exist (HCC)
+  std::vector<int> pos;
+  for (int k = 0; k < h->nt; ++k) {
+    if (k > 0 && k < (int)h->h_same.size() && h->h_same[k]) continue;      // the camera list of the point before it
+    pos.clear();
+    for (int n = h->h_off[k]; n < h->h_off[k + 1]; ++n) {
+      const int c = cam[n];
+      const int q = c >= 0 && c < h->nc ? h->h_cam_opt_pos[c] : -1;
+      if (q >= 0) pos.push_back(q);
+    }
+    for (size_t a = 0; a < pos.size(); ++a)
+      for (size_t b = 0; b < pos.size(); ++b)
+        if (a != b) rows[pos[a]].push_back(pos[b]);
+  }
+  std::vector<int> rowptr((size_t)nco + 1, 0), col;
+  std::vector<long long> blk, ublk;
+  long long upper = 0;
+  for (int i = 0; i < nco; ++i) {
+    auto& r = rows[i];
+    std::sort(r.begin(), r.end());
+    r.erase(std::unique(r.begin(), r.end()), r.end());
+    for (int j : r) {
+      const int lo = std::min(i, j), hi = std::max(i, j);
+      if (hi - lo > h->hb) return h->fail(BA_ERR_STATE, "pcg: cameras %d and %d share a track but the band is %d wide", lo, hi, h->hb);
+      col.push_back(j);
+      blk.push_back((long long)lo * hb1 + (hi - lo));
+      upper += j >= i;
+      if (j >= i) ublk.push_back((long long)lo * hb1 + (hi - lo));
+    }
+    rowptr[i + 1] = (int)col.size();
+    std::vector<int>().swap(r);
+  }
+  g.nnz = (long long)col.size();
+  g.upper = upper;
+  HIPCHECK(h, g.rowptr.resize(rowptr.size()));
+  HIPCHECK(h, g.col.resize(std::max<size_t>(1, col.size())));
+  HIPCHECK(h, g.blk.resize(std::max<size_t>(1, blk.size())));
+  HIPCHECK(h, g.ublk.resize(std::max<size_t>(1, ublk.size())));
+  HIPCHECK(h, hipMemcpyAsync(g.rowptr.p, rowptr.data(), rowptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (!col.empty()) {
+    HIPCHECK(h, hipMemcpyAsync(g.col.p, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(g.blk.p, blk.data(), blk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(g.ublk.p, ublk.data(), ublk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(h, hipStreamSynchronize(h->stream));            // (the host vectors go out of scope)
+  g.built = true;
+  return BA_OK;
+}
+
+// Fraction of the band's blocks that can be non-zero (1 = a full band: nothing for an iterative solver to gain).
+double pcg_band_fill(ba_handle* h) {
+  if (pcg_build_pattern(h) != BA_OK || h->nco == 0) return 1.0;
+  return (double)h->pcg.upper / ((double)h->nco * (h->hb + 1));
+}
+
+// Is this a scene for the sparse path - a wide band of mostly structural zeros, large enough for a dense factorisation to hurt, no
+// border, the solver left to the library (or set to pcg)?  Builds the pattern on the first call of a problem.
+bool sparse_layout(ba_handle* h) {
+  if (h->nbc > 0 || h->dense_mode || h->nco == 0 || h->hb <= kBcrwMaxHB || h->comm) return false;
+  if (h->opt.solver == SOLVER_PCG) return pcg_build_pattern(h) == BA_OK;
+  if (h->opt.solver != SOLVER_AUTO || h->nco < kPcgMinCams) return false;
+  return pcg_band_fill(h) <= kPcgMaxFill;
+}
+
+// [S | b] initialised over the blocks of the pattern only (k_schur_init visits the whole band: 6.5 GB at 5000 cameras, 1.5 ms a
+// trial): valid once everything outside the pattern is known to be zero (band_clean: after one full initialisation of this
+// problem's band that nothing has scribbled over since).
+int launch_schur_init_sparse(ba_handle* h, double damping, int use_hcc) {
+  auto& g = h->pcg;
+  const long long n = g.upper * 36 + (long long)h->nco * 6;
+  hipLaunchKernelGGL(k_schur_init_blocks, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, g.upper, g.ublk.p, h->nco, h->hb + 1, h->opt_cam.p,
+                     h->HCC.p, h->bC.p, damping, h->S, h->b, use_hcc);
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+// Preconditioned conjugate gradients on [S | b] (mask: deleted parameters).  Leaves the solution in h->dC and the status word in
+// flags[1]: 0 = converged to ||r|| <= tol ||b||; > 0 = a diagonal block or S itself is not positive definite (camera + 1, or nco + 1);
+// kPcgStalled = no convergence within the iteration budget (the caller treats both like a failed Cholesky).
+int solve_pcg(ba_handle* h, const unsigned char* dmask) {
+  auto& g = h->pcg;
+  if (int rc = pcg_build_pattern(h); rc != BA_OK) return rc;
+  const int nco = h->nco, n = 6 * nco, hb1 = h->hb + 1;
+  const int nparts = (n + kPcgUnknownsPerBlock - 1) / kPcgUnknownsPerBlock;
+  const int nprod = (nco + kPcgRowsPerBlock - 1) / kPcgRowsPerBlock;
+  HIPCHECK(h, g.minv.resize((size_t)nco * 36));
+  HIPCHECK(h, g.r.resize((size_t)n)); HIPCHECK(h, g.z.resize((size_t)n)); HIPCHECK(h, g.q.resize((size_t)n));
+  HIPCHECK(h, g.p[0].resize((size_t)n)); HIPCHECK(h, g.p[1].resize((size_t)n));
+  HIPCHECK(h, g.part.resize((size_t)4 * nparts + nprod));
+  HIPCHECK(h, g.state.resize(1));
+  if (!g.host_state) HIPCHECK(h, hipHostMalloc((void**)&g.host_state, sizeof(PcgStateRaw), hipHostMallocDefault));
+  double* part_rz = g.part.p, *part_rr = g.part.p + (size_t)2 * nparts, *part_pq = g.part.p + (size_t)4 * nparts;
+  const double tol = h->opt.pcg_tol, tol2 = tol * tol;
+  const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : std::max(1000, std::min(20000, 4 * nco));
+  ScopedTimer tm(h, BA_K_PCG_SOLVE);
+  HIPCHECK(h, hipMemsetAsync(h->flags.p + 1, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_pcg_minv, dim3(blocks_for(nco)), dim3(kBlock), 0, h->stream, nco, hb1, h->S, dmask, g.minv.p, h->flags.p + 1);
+  hipLaunchKernelGGL(k_pcg_start, dim3(nparts), dim3(kBlock), 0, h->stream, n, h->b, dmask, g.minv.p, h->dC.p, g.r.p, g.z.p, part_rz, part_rr, reinterpret_cast<PcgState*>(g.state.p));
+  int k = 0, status = 0;
+  double rr_checked = -1.0;
+  int k_checked = 0;
+  g.iterations = 0;
+  while (true) {
+    // (short batches first: a launch after convergence costs ~3 us, a look at the state a synchronisation - damped systems converge in 6 .. 30 iterations)
+    const int batch = std::min(std::min(h->opt.pcg_batch, k < 8 ? 8 : k), max_iter - k);
+    for (int e = k + batch; k < e; ++k) {
+      hipLaunchKernelGGL(k_pcg_product, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, h->S, g.rowptr.p, g.col.p, g.blk.p, g.z.p,
+                         g.p[k & 1].p, g.p[(k + 1) & 1].p, g.q.p, part_rz, part_rr, nparts, tol2, part_pq, reinterpret_cast<PcgState*>(g.state.p));
+      hipLaunchKernelGGL(k_pcg_update, dim3(nparts), dim3(kBlock), 0, h->stream, k, n, dmask, g.minv.p, g.p[(k + 1) & 1].p, g.q.p, h->dC.p,
+                         g.r.p, g.z.p, part_rz, part_rr, nparts, part_pq, nprod, tol2, reinterpret_cast<PcgState*>(g.state.p));
+    }
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipMemcpyAsync(g.host_state, g.state.p, sizeof(PcgStateRaw), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(&g.host_status, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    const PcgStateRaw& st = *g.host_state;
+    g.iterations = st.done_iter >= 0 ? st.done_iter : st.last_iter + 1;
+    g.rel_residual = st.bb > 0.0 ? sqrt(st.rr / st.bb) : 0.0;
+    if (g.host_status > 0) { status = g.host_status; break; }                     // a diagonal block that is not positive definite
+    if (st.breakdown) { status = nco + 1; break; }                              // p.S p <= 0: S is not positive definite
+    if (st.done_iter >= 0) break;
+    if (!(st.rr == st.rr)) { status = nco + 1; break; }                         // NaNs: nothing to wait for
+    // no progress: the residual has not come down by a factor of ten over the last quarter of the budget
+    if (rr_checked >= 0.0 && k - k_checked >= max_iter / 4) {
+      if (st.rr > .01 * rr_checked) { status = kPcgStalled; break; }
+      rr_checked = st.rr; k_checked = k;
+    } else if (rr_checked < 0.0) { rr_checked = st.rr; k_checked = k; }
+    if (k >= max_iter) { status = kPcgStalled; break; }
+  }
+  if (status != 0 && g.host_status == 0) hipLaunchKernelGGL(k_pcg_set_status, dim3(1), dim3(1), 0, h->stream, h->flags.p + 1, status);
+  HIPCHECK(h, hipGetLastError());
+  g.last_status = status;
+  return BA_OK;
+}
+
+}  // namespace ba
+
+extern "C" {
+
+int ba_pcg_info(ba_handle* h, int64_t* blocks, int32_t* iterations, double* rel_residual, double* band_fill) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, h->have_problem, BA_ERR_STATE, "ba_pcg_info: call ba_set_problem first");
+  HIPCHECK(h, hipSetDevice(h->device));
+  if (int rc = pcg_build_pattern(h); rc != BA_OK) return rc;
+  if (blocks) *blocks = h->pcg.upper;
+  if (iterations) *iterations = h->pcg.iterations;
+  if (rel_residual) *rel_residual = h->pcg.rel_residual;
+  if (band_fill) *band_fill = h->nco ? (double)h->pcg.upper / ((double)h->nco * (h->hb + 1)) : 1.0;
+  return BA_OK;
+}
+
+}  // extern "C"

@@ -71,6 +71,23 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   // (with a border, ba_border.h, the band and its right-hand side end at the band cameras: border_schur below clears and fills the rest)
   const int n1 = h->band_cams();
   const long long ninit = (long long)n1 * (h->hb + 1) * 36 + (long long)n1 * 6;
+  const bool sparse_init = sparse_layout(h) && h->pcg.band_clean;      // (false the first time: that call clears the whole band)
+  if (sparse_init) {
+    if (have_inv) h->inv_valid = true;
+    else if (h->nt > 0) {
+      h->sing_epoch ^= 1;
+      ScopedTimer tm(h, BA_K_POINT_INVERT);
+      hipLaunchKernelGGL(k_point_invert, dim3(blocks_for(h->nt)), dim3(kBlock), 0, h->stream, h->nt, h->HPP.p,
+                         damping, pinv_rcond, h->HPPinv.p, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), h->bP.p, want_fac ? h->fac.p : (double*)nullptr);
+      h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = pinv_rcond;
+      h->fac_valid = want_fac;
+    } else {
+      HIPCHECK(h, hipMemsetAsync(h->flags.p + 40, 0, 2 * sizeof(int), h->stream));
+    }
+    ScopedTimer tm(h, BA_K_SCHUR_INIT);
+    rc = launch_schur_init_sparse(h, damping, fuse_cam ? 0 : 1);
+    if (rc != BA_OK) return rc;
+  } else
   if (!have_inv && h->nt > 0 && h->nco > 0) {
     // point inverses and the initialisation of [S | b] are independent: one launch for both
     h->sing_epoch ^= 1;     // this call counts singular blocks in sing_counter(); the kernel clears the other one
@@ -100,6 +117,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                          h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
     }
   }
+  if (!sparse_init && h->nco > 0) h->pcg.band_clean = !dense;      // (the whole band has just been initialised; the dense reduction writes all of it)
   if (dense) {
     // dense visibility: the reduction is one symmetric matrix product over all points (the kernels below
     // would do 36 global atomics per (pair, point): 258 M of them at 100 cameras x 1000 tracks)
@@ -291,6 +309,7 @@ int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
   h->S = (double*)S_blocks_dev;
   h->b = (double*)b_dev;
   h->have_schur = false;
+  h->pcg.band_clean = false;
   return BA_OK;
 }
 

@@ -48,8 +48,9 @@ __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* _
                                                          double damping, double rcond,
                                                          double* __restrict__ HPPinv,
                                                          int* __restrict__ singular_count,
-                                                         int* __restrict__ next_count) {
-  point_invert_body(blockIdx.x * kBlock + threadIdx.x, nt, HPP, damping, rcond, HPPinv, singular_count, next_count);
+                                                         int* __restrict__ next_count, const double* __restrict__ bP = nullptr,
+                                                         double* __restrict__ fac = nullptr) {
+  point_invert_body(blockIdx.x * kBlock + threadIdx.x, nt, HPP, damping, rcond, HPPinv, singular_count, next_count, bP, fac);
 }
 
 // --------------------------------------------------------------------------

@@ -459,11 +459,17 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need - have > free_b - free_b / 16) use_big = false;
     }
   }
-  const bool use_dense = !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1))));
+  // a scene without a narrow band under any order (an unordered photo collection): conjugate gradients over the blocks the tracks
+  // define (ba_pcg.h) - by option, or when the band is wide, mostly structural zeros, and large enough for a dense factorisation to hurt
+  const bool pcg_forced = force == SOLVER_PCG;
+  const bool use_pcg = h->nco > 0 && (pcg_forced || (force == SOLVER_AUTO && !bcr_ok && !bcrw_ok && h->hb > kBcrwMaxHB && h->nco >= kPcgMinCams &&
+                                                     pcg_band_fill(h) <= kPcgMaxFill));
+  if (use_pcg) use_big = false;
+  const bool use_dense = !use_pcg && !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);
   const bool use_bcrw = !use_dense && !use_bcr && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcrw_ok) : bcrw_ok);
   // nothing of the above applies (or option solver = lu): LU with partial pivoting, the reference's own factorisation
-  const bool use_lu = force == SOLVER_LU || (!use_big && !use_dense && !use_bcr && !use_bcrw && !band_ok);
+  const bool use_lu = !use_pcg && (force == SOLVER_LU || (!use_big && !use_dense && !use_bcr && !use_bcrw && !band_ok));
   HIPCHECK(h, hipSetDevice(h->device));
   HIPCHECK(h, h->Ufac.resize(std::max<size_t>(1, reduced_doubles(h))));
   const unsigned char* dmask = nullptr;
@@ -481,8 +487,17 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const size_t lds_budget = 160 * 1024;
   const int ch = band_solve_chunk(h->hb, lds_budget);
   size_t lds = 0;
-  h->solve_kind = use_lu ? BA_SOLVE_BAND_LU : use_big ? BA_SOLVE_BCR_BIG : use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
-  if (use_lu) {
+  h->solve_kind = use_pcg ? BA_SOLVE_PCG : use_lu ? BA_SOLVE_BAND_LU : use_big ? BA_SOLVE_BCR_BIG : use_dense ? BA_SOLVE_DENSE_CHOLESKY : use_bcr ? BA_SOLVE_BCR : use_bcrw ? BA_SOLVE_BCR_WIDE : BA_SOLVE_BAND;
+  if (use_pcg) {
+    int rc = solve_pcg(h, dmask);
+    if (rc != BA_OK) return rc;
+    if (h->pcg.last_status != 0 && !pcg_forced && dense_ok) {
+      // chosen by the library and it did not converge (or found the matrix not positive definite): the dense factorisation has the last word
+      h->solve_kind = BA_SOLVE_DENSE_CHOLESKY;
+      rc = solve_dense_chol(h, dmask);
+      if (rc != BA_OK) return rc;
+    }
+  } else if (use_lu) {
     int rc = solve_band_lu(h, dmask);
     if (rc != BA_OK) return rc;
   } else if (use_big) {
@@ -511,7 +526,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   HIPCHECK(h, hipMemcpyAsync(inf6, h->flags.p + 1, sizeof(inf6), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   int inf = inf6[0];
-  if (inf > 0 && inf != kBcrTimedOut && !use_lu && h->opt.device_lu) {
+  if (inf > 0 && inf != kBcrTimedOut && !use_lu && h->opt.device_lu && h->solve_kind != BA_SOLVE_PCG) {
     // not positive definite: the reference's LU would still solve it (bundle_adjuster.py:302-305) - the cyclic reduction with
     // LU nodes where the nodes are narrow, LU with partial pivoting down the band otherwise
     const bool lu_nodes = use_bcr && bcr_node_size(h) <= kBcrMaxHB;      // (k_bcr_eliminate_lu keeps a node's B x (3 B + 1) matrix in LDS)

@@ -102,6 +102,45 @@ def generate_banded_scene(ncams, npts, track_len=10, seed=654, spacing=.2, msm_n
                 obs_cam=obs_cam, obs_pt=obs_pt, obs_z=z, outliers=outliers)
 
 
+def generate_collection_scene(ncams, npts, partners=20, track_len=4, seed=654, extent=3., msm_noise=.02, init_perturbation=.01,
+                              init_seed=1888):
+    """An unordered photo collection: cameras scattered over a (extent x extent) patch at z = 0, all looking roughly along +z
+    at points in the slab z in [4, 8] above it; camera c shares tracks with `partners` cameras drawn at random from ALL the
+    others (no locality, no order), and every point is seen by one camera and `track_len` - 1 of that camera's partners.  The
+    co-visibility graph is a random graph of degree ~2 * partners: no camera order makes its reduced system a narrow band
+    (the reference's dense S does not care, bundle_adjuster.py:259-312).  K = I, measurement noise N(0, msm_noise^2); the
+    initial guess is the truth perturbed about each camera's own centre ('pose' mode of generate_banded_scene); camera 0 is
+    the gauge camera.  Same dict as generate_banded_scene."""
+    assert ncams > partners >= track_len - 1 >= 1
+    rs = np.random.RandomState(seed)
+    centers = np.c_[rs.rand(ncams, 2) * extent, rs.randn(ncams) * .02]
+    R = _so3_exp_batch(rs.randn(ncams, 3) * .02)
+    t = -np.einsum('nij,nj->ni', R, centers)
+    part = np.empty((ncams, partners), np.int64)
+    for c in range(ncams):
+        o = rs.choice(ncams - 1, partners, replace=False)
+        part[c] = o + (o >= c)                                   # (anyone but c itself)
+    first = rs.randint(0, ncams, npts)
+    order = np.argsort(first, kind='stable')                     # (points ordered by their first camera: as a track database would list them)
+    first = first[order]
+    pick = np.argsort(rs.rand(npts, partners), axis=1)[:, :track_len - 1]
+    cams = np.c_[first, part[first[:, None], pick]]
+    cams.sort(axis=1)
+    X = np.c_[rs.rand(npts, 2) * extent, 4 + 4 * rs.rand(npts)]
+    obs_cam = cams.reshape(-1).astype(np.int32)
+    obs_pt = np.repeat(np.arange(npts, dtype=np.int32), track_len)
+    p = np.einsum('nij,nj->ni', R[obs_cam], X[obs_pt]) + t[obs_cam]
+    z = p[:, :2] / p[:, 2:3] + rs.randn(len(obs_cam), 2) * msm_noise
+    ri = np.random.RandomState(init_seed)
+    dcam = ri.randn(ncams, 6) * init_perturbation
+    dcam[0] = 0.
+    R0 = np.einsum('nij,njk->nik', R, _so3_exp_batch(dcam[:, :3]))
+    t0 = -np.einsum('nij,nj->ni', R0, centers + dcam[:, 3:])
+    X0 = X + ri.randn(npts, 3) * init_perturbation
+    return dict(K=np.eye(3), R=R, t=t, X=X, R0=R0, t0=t0, X0=X0, obs_cam=obs_cam, obs_pt=obs_pt, obs_z=z,
+                outliers=np.zeros(len(obs_cam), bool))
+
+
 def add_loop_closure_tracks(s, pairs, width=1, seed=77, msm_noise=.02, init_perturbation=.01):
     """The scene with extra tracks that tie far-apart cameras together (a loop closure): for every (i, j) of `pairs` one new
     point, between the two cameras in x, observed by cameras i .. i + width - 1 and j .. j + width - 1 (measurements from the

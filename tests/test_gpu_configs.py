@@ -1189,11 +1189,11 @@ def test_band_plus_border_system_that_is_not_positive_definite_is_solved_like_th
         close(-dP, su, 1e-7)
 
 
-def test_device_solve_is_as_accurate_as_lapack_where_the_walk_is_sensitive():
-    """Config 3 after five LM steps, damping 1e-3 (the first place where the device's walk and the oracle's part): on the SAME
-    [S | b], the device's solution leaves a residual ||S dC - b|| / ||b|| no larger than twice that of numpy.linalg.solve (LAPACK
-    gesv, what the reference calls: bundle_adjuster.py:303; or five units of round-off, whichever is larger) and agrees with LAPACK's Cholesky solution as closely as LAPACK's LU
-    does - the sensitivity is the system's (condition number > 1e12), not the solver's."""
+@pytest.fixture(scope='module')
+def sensitive_solve():
+    """Config 3 after five LM steps of the DEVICE's own walk, damping 1e-3 (the first place where the device's walk and the oracle's
+    part): [S | b] as the device formed it (fp64 atomics upstream: not the same bits every run - the deterministic version of these
+    checks is tests/test_gpu_parity.py::test_golden_reduced_system_*), the device's solution, LAPACK's LU and Cholesky solutions."""
     import scipy.linalg as sl
     from pysfm_amd import Bundle, BundleAdjuster, sensor_model
     from pysfm_amd._capi import PARAMS_CUR
@@ -1209,17 +1209,37 @@ def test_device_solve_is_as_accurate_as_lapack_where_the_walk_is_sensitive():
     n = be.nco * 6
     A = S.transpose(0, 2, 1, 3).reshape(n, n)
     rhs = rhs.reshape(n)
+    before = be.problem_info()['solves_refined']
     be.solve_reduced(None)
-    assert be.last_solve_kind == 'bcr'
+    assert be.last_solve_kind == 'bcr' and be.problem_info()['solves_refined'] == before + 1      # (damping below 1e-2: the refinement step is on by default)
     x_dev = be.get_solution().reshape(n)
-    x_lu = np.linalg.solve(A, rhs)
-    x_ch = sl.cho_solve(sl.cho_factor(A), rhs)
-    res = lambda x: np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs)
-    # (twice LAPACK's, or five units of round-off: the scene after five steps is not the same to the last bit from run to run - LAPACK's own
-    #  residual came out between 2.6e-16 and 7e-16 - and the order of the device's fp64 atomics is not either)
-    assert res(x_dev) <= max(2. * max(res(x_lu), res(x_ch)), 1.1e-15), (res(x_dev), res(x_lu), res(x_ch))
-    assert np.linalg.norm(x_dev - x_ch) <= 2. * np.linalg.norm(x_lu - x_ch) + 1e-14 * np.linalg.norm(x_ch)
+    be.set_option('refine', '0')
+    be.solve_reduced(None)
+    x_raw = be.get_solution().reshape(n)
+    be.set_option('refine', 'auto')
+    out = dict(A=A, rhs=rhs, x_dev=x_dev, x_raw=x_raw, x_lu=np.linalg.solve(A, rhs), x_ch=sl.cho_solve(sl.cho_factor(A), rhs))
     ba.backend.close()
+    return out
+
+
+def test_device_solve_leaves_a_residual_no_larger_than_lapack_where_the_walk_is_sensitive(sensitive_solve):
+    """On the SAME [S | b] the device's solution leaves a residual ||S dC - b|| / ||b|| no larger than 1.5 times the larger of LAPACK's
+    two (numpy.linalg.solve = gesv, what the reference calls: bundle_adjuster.py:303; Cholesky).  Round 5 met this bound only with a
+    floor of five units of round-off under it (the cyclic reduction alone: 2.4 - 2.6 times LAPACK); since round 6 the solve takes one
+    step of iterative refinement through its kept factors below damping 1e-2 (csrc/ba_bcr_refine.h) - no floor."""
+    d = sensitive_solve
+    res = lambda x: np.linalg.norm(d['A'] @ x - d['rhs']) / np.linalg.norm(d['rhs'])
+    lapack = max(res(d['x_lu']), res(d['x_ch']))
+    assert res(d['x_dev']) <= 1.5 * lapack, (res(d['x_dev']), res(d['x_lu']), res(d['x_ch']))
+    assert res(d['x_dev']) <= res(d['x_raw']) * 1.05 and res(d['x_raw']) <= 6. * lapack, (res(d['x_dev']), res(d['x_raw']), lapack)
+
+
+def test_device_solve_agrees_with_lapack_cholesky_as_closely_as_lapack_lu_does(sensitive_solve):
+    """... and it agrees with LAPACK's Cholesky solution as closely as LAPACK's LU does - the sensitivity is the system's (condition
+    number > 1e12), not the solver's.  Its own test: the residual bound above cannot hide it."""
+    d = sensitive_solve
+    assert np.linalg.norm(d['x_dev'] - d['x_ch']) <= 2. * np.linalg.norm(d['x_lu'] - d['x_ch']) + 1e-14 * np.linalg.norm(d['x_ch'])
+    assert np.linalg.norm(d['x_raw'] - d['x_ch']) <= 2. * np.linalg.norm(d['x_lu'] - d['x_ch']) + 1e-14 * np.linalg.norm(d['x_ch'])
 
 
 def test_rejected_trials_reuse_the_linearisation():

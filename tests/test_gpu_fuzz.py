@@ -20,6 +20,16 @@ def be():
     b.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_options(request):
+    """The shared backend goes back to the product path after every test."""
+    yield
+    if 'be' in request.fixturenames:
+        b = request.getfixturevalue('be')
+        for k, v in DEFAULT_OPTIONS.items():
+            b.set_option(k, v)
+
+
 def make_case(seed):
     rs = np.random.RandomState(1000 + seed)
     long_tracks = seed >= 72                               # a few tracks that span 45 .. 120 cameras beside the others (round 3): pairs of segments
@@ -152,6 +162,63 @@ def test_random_scene_full_step_vs_oracle(be, seed):
     close(tg, t2, tol, atol=1e-12)
     ref_cost = O.cost(sensor, a[0], R2, t2, X2, a[4], a[5], a[6], cp, po)
     assert abs(cost - ref_cost) <= max(1e-8, 10 * tol) * max(ref_cost, 1e-300)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_unordered_collection_full_step_vs_oracle(be, seed):
+    """The sweep's other family of scenes (round 6): unordered photo collections - every camera shares tracks with cameras drawn at
+    random from all the others, no camera order gives a band - of random size, track length, sensor model, with frozen cameras,
+    tracks that are not optimised, masked parameters and shuffled input, through conjugate gradients over the blocks the tracks
+    define (csrc/ba_pcg.h; forced by option below 1500 cameras) and, on the same handle, through the dense Cholesky."""
+    from pysfm_amd import synthetic_data as sd
+    rs = np.random.RandomState(5000 + seed)
+    nc = int(rs.randint(120, 420))
+    L = int(rs.choice([2, 3, 4, 5]))
+    partners = int(rs.randint(max(L, 4), 16))
+    nt = int(rs.randint(8 * nc, 25 * nc))
+    s = sd.generate_collection_scene(nc, nt, partners=partners, track_len=L, seed=int(rs.randint(1, 10000)))
+    cam, pt, z, X0 = s['obs_cam'], s['obs_pt'], s['obs_z'], s['X0']
+    if rs.rand() < .5:
+        new_id = rs.permutation(nt)
+        X0 = np.empty_like(s['X0'])
+        X0[new_id] = s['X0']
+        o = rs.permutation(len(cam))
+        cam, pt, z = cam[o], new_id[pt[o]].astype(np.int32), z[o]
+    frozen = set([0]) | set(rs.choice(nc, int(rs.randint(0, 4)), replace=False).tolist())
+    cp = -np.ones(nc, np.int32)
+    opt = [c for c in range(nc) if c not in frozen]
+    if rs.rand() < .4:
+        opt = rs.permutation(opt).tolist()
+    cp[opt] = np.arange(len(opt))
+    po = (rs.rand(nt) >= float(rs.choice([0., .15]))).astype(np.uint8)
+    sensor = [O.Sensor.gaussian(1.), O.Sensor.cauchy(.05), O.Sensor.huber(.06)][int(rs.randint(0, 3))]
+    mask = (rs.rand(len(opt) * 6) > .1).astype(np.uint8) if rs.rand() < .5 else None
+    damping = float(rs.choice([.5, 10.]))
+    a = (s['K'], s['R0'], s['t0'], X0, cam, pt, z)
+    load_problem(be, *a, cp, po, sensor)
+    be.set_option('solver', 'pcg')
+    mu, su, parts = O.compute_update(sensor, *a, cp, po, damping=damping, cam_param_mask=None if mask is None else mask.astype(bool), return_parts=True)
+    info, cost = be.lm_trial(damping, 1e-5, mask)
+    assert info == 0 and be.last_solve_kind == 'pcg'
+    S, b = be.get_reduced()
+    close(S, parts['S'], 1e-11)
+    close(b, parts['b'], 1e-11)
+    dC = be.get_solution()
+    close(-dC, mu, 1e-8)
+    R2, t2, X2 = O.apply_update(a[1], a[2], a[3], mu, su, cp, po)
+    Rg, tg, Xg = be.get_params(1)
+    close(Xg, X2, 1e-8, atol=1e-12)
+    close(tg, t2, 1e-8, atol=1e-12)
+    ref_cost = O.cost(sensor, a[0], R2, t2, X2, a[4], a[5], a[6], cp, po)
+    assert abs(cost - ref_cost) <= 1e-7 * ref_cost
+    # a second trial on the same problem: only the pattern's blocks are initialised again - the band outside it must still be zero
+    info, cost2 = be.lm_trial(damping, 1e-5, mask)
+    S2, b2 = be.get_reduced()
+    close(S2, parts['S'], 1e-11)
+    assert info == 0 and abs(cost2 - cost) <= 1e-9 * cost
+    be.set_option('solver', 'dense')
+    info, cost3 = be.lm_trial(damping, 1e-5, mask)
+    assert info == 0 and be.last_solve_kind == 'dense_cholesky' and abs(cost3 - cost) <= 1e-8 * cost
 
 
 def test_the_sweep_reached_the_matrix_core_kernels():

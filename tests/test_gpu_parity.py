@@ -34,7 +34,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1,
-                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1, reuse_linearization=1, refine='auto')
+                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1, reuse_linearization=1, refine='auto', pcg_max_iter=0)
 
 
 @pytest.fixture(autouse=True)
@@ -454,6 +454,98 @@ def test_empty_and_degenerate_inputs(be):
         be.set_problem(3, 4, [1, 1], [2, 2], np.zeros((2, 2)), K, *flags)      # a (camera, track) pair twice
     with pytest.raises(ValueError):
         be.set_problem(3, 4, [0, 5], [0, 1], np.zeros((2, 2)), K, *flags)      # camera out of range
+
+
+# ------------------------------------------------------------------ scenes without a band: conjugate gradients over the blocks the tracks define
+@pytest.mark.parametrize('damping,masked', [(10., False), (1., False), (10., True), (.1, False)])
+def test_unordered_photo_collection_solved_by_conjugate_gradients_vs_oracle(be, damping, masked):
+    """An unordered photo collection (every camera shares tracks with cameras drawn at random from ALL the others: no order of the
+    cameras makes the reduced system a narrow band) - the reference's dense S does not care (bundle_adjuster.py:259-312).  The
+    library's solver for such scenes: conjugate gradients with a block-Jacobi preconditioner over the blocks of S the tracks define
+    (csrc/ba_pcg.h; chosen by itself from 1500 cameras on, by option here).  S, b against the oracle as for any scene; dC and dP
+    against the oracle's LAPACK solve to 1e-8; masked parameters exactly zero; the dense Cholesky of the same device-resident system
+    agrees to 1e-9."""
+    from pysfm_amd import synthetic_data as sd
+    nc, nt = 300, 6000
+    s = sd.generate_collection_scene(nc, nt, partners=8, track_len=3)
+    flags = default_flags(nc, nt)
+    sensor = O.Sensor.cauchy(.05)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    load_problem(be, *a, *flags, sensor)
+    assert be.half_bandwidth > 150                                   # (no band worth the name)
+    n = be.nco * 6
+    mask = None
+    if masked:
+        mask = (np.arange(n) % 9 != 4).astype(np.uint8)
+        mask[6 * 17:6 * 19] = 0
+    be.set_option('solver', 'pcg')
+    be.linearize(0)
+    be.schur(0, damping, 1e-5)
+    be.solve_reduced(mask)
+    assert be.last_solve_kind == 'pcg' and be.last_solve_path == 'pcg'
+    info = be.pcg_info()
+    assert 0 < info['iterations'] < 1000 and info['rel_residual'] <= 1e-12 and info['band_fill'] < .25, info
+    x = be.get_solution().reshape(-1)
+    dP = be.backsubstitute(0)
+    mu, su, parts = O.compute_update(sensor, *a, *flags, damping=damping, cam_param_mask=None if mask is None else mask.astype(bool), return_parts=True)
+    S, b = be.get_reduced()
+    close(S, parts['S'], 1e-11)
+    close(b, parts['b'], 1e-11)
+    # the pattern: exactly the blocks the oracle's S has
+    nz = np.abs(parts['S']).sum(axis=(2, 3)) > 0
+    assert info['blocks'] == int(np.triu(nz).sum())
+    close(-x.reshape(-1, 6), mu, 1e-8)
+    close(-dP, su, 1e-8)
+    assert mask is None or np.all(x[mask == 0] == 0)
+    be.set_option('solver', 'dense')
+    be.solve_reduced(mask)
+    assert be.last_solve_kind == 'dense_cholesky'
+    close(x, be.get_solution().reshape(-1), 1e-9)
+
+
+def test_unordered_photo_collection_lm_walk_vs_oracle():
+    """optimize() of an unordered collection with every reduced system solved by conjugate gradients: the walk of the oracle
+    (LAPACK's LU of the dense S, bundle_adjuster.py:117-162) - same decisions, costs to 1e-6 - down to damping 1e-4, where the
+    block-Jacobi preconditioned iteration needs a few hundred steps."""
+    from pysfm_amd import Bundle, BundleAdjuster, sensor_model, synthetic_data as sd
+    nc, nt = 300, 6000
+    s = sd.generate_collection_scene(nc, nt, partners=8, track_len=3)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    trace = []
+    ref = O.lm_optimize(O.Sensor.gaussian(1.), *a, *default_flags(nc, nt), max_steps=7, trace=trace)
+    b = Bundle.FromObservations(*a, sensor_model=sensor_model.GaussianModel(1.))
+    ba = BundleAdjuster(verbose=False)
+    ba.backend.set_option('solver', 'pcg')
+    ba.set_bundle(b)
+    ba.optimize(max_steps=7)
+    assert ba.backend.last_solve_kind == 'pcg'
+    assert [(d, o == 'accepted') for d, o, _ in ba.trial_log] == [(t['damping'], t['next'] < t['cur']) for t in trace]
+    close(ba.costs, ref['costs'], 1e-6)
+    close(ba.bundle.reconstruction, ref['X'], 1e-6)
+    ba.backend.close()
+
+
+def test_conjugate_gradients_report_what_they_cannot_solve(be):
+    """A reduced system that is not positive definite (negative damping) and one they cannot finish within their budget: *info > 0 -
+    the caller raises the damping, as for a LinAlgError of the reference (bundle_adjuster.py:302-305) - never a wrong answer."""
+    from pysfm_amd import synthetic_data as sd
+    from pysfm_amd.backend import ReducedSystemSingular
+    nc, nt = 200, 3000
+    s = sd.generate_collection_scene(nc, nt, partners=8, track_len=3)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *default_flags(nc, nt), O.Sensor.gaussian(1.))
+    be.set_option('solver', 'pcg')
+    be.linearize(0)
+    be.schur(0, -.9, 1e-5)
+    with pytest.raises(ReducedSystemSingular):
+        be.solve_reduced(None)
+    be.schur(0, 1., 1e-5)
+    be.set_option('pcg_max_iter', 3)
+    with pytest.raises(ReducedSystemSingular):
+        be.solve_reduced(None)
+    assert be.last_solve_kind == 'pcg'
+    be.set_option('pcg_max_iter', 0)
+    be.solve_reduced(None)
+    assert be.pcg_info()['rel_residual'] <= 1e-12
 
 
 # ------------------------------------------------------------------ full-size properties
