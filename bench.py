@@ -48,7 +48,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mf
 # What binds each kernel at the bench sizes; `roofline.limited_by` reports it.  The contract prices
 # `achieved` against HBM for every kernel that is not MFMA-bound, so `frac` is always achieved / 8 TB/s.
 KERNEL_BOUND = {'border_schur': 'atomics', 'border_solve': 'latency', 'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_refine': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
-                'dense_solve': 'latency', 'schur_pairs': 'mfma', 'linearize': 'fp64 issue + gather latency', 'backsub': 'fp64 issue', 'cost': 'hbm',
+                'dense_solve': 'latency', 'pcg_solve': 'hbm', 'schur_pairs': 'mfma', 'linearize': 'fp64 issue + gather latency', 'backsub': 'fp64 issue', 'cost': 'hbm',
                 'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
 # timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
 KERNEL_NAMES = {'border_schur': 'k_schur_border (+ k_border_clear)', 'border_solve': 'k_border_prepare, k_bcr_apply (a launch per level, forward and back), k_border_reduce, k_border_solve, k_border_correct',
@@ -535,6 +535,52 @@ def small_problems():
                 out['window_slam_accepted_steps'] = int(sum(len(h) for h in hist) - len(hist))
         finally:
             BundleAdjuster.resident = True
+    return out
+
+
+def unordered_collection(nc=5000, nt=200000, partners=8, track_len=3):
+    """A scene with no band under any camera order (synthetic_data.generate_collection_scene: every camera shares tracks with cameras
+    drawn at random from all the others): the reduced system is solved by conjugate gradients over the blocks the tracks define
+    (csrc/ba_pcg.h).  Round 5: LU down a band 4500 cameras wide, 34.5 s a trial."""
+    import torch
+    from pysfm_amd import Bundle, BundleAdjuster, synthetic_data as sd
+    from pysfm_amd._capi import PARAMS_CUR
+    s = sd.generate_collection_scene(nc, nt, partners=partners, track_len=track_len)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(verbose=False)
+    ba.set_bundle(b)
+    t0 = time.time()
+    ba.set_bundle(b)
+    t_setup = time.time() - t0
+    be = ba.backend
+    cur = ba._cost(PARAMS_CUR)
+    ba.trial(10., None, cur)                           # (the first solve of a problem builds the list of blocks)
+    out = {'cameras': nc, 'points': nt, 'observations': int(be.nobs), 'half_bandwidth': int(be.half_bandwidth), 'set_bundle_s': t_setup, 'trials': {}}
+    for damping in (10., 1., .1, .01):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            acc, nxt = ba.trial(damping, None, cur)
+        torch.cuda.synchronize()
+        info = be.pcg_info()
+        out['trials']['damping_%g' % damping] = {'ms_per_trial': 1e3 * (time.time() - t0) / 5, 'accepted': bool(acc), 'solver': be.last_solve_kind,
+                                                 'iterations': info['iterations'], 'rel_residual': info['rel_residual']}
+    out['blocks_upper'] = info['blocks']
+    out['band_fill'] = info['band_fill']
+    be.enable_timing(True)
+    be.timings(reset=True)
+    for _ in range(3):
+        ba.trial(10., None, cur)
+    out['kernel_ms_per_step'] = {k: v['ms'] / 3 for k, v in be.timings(reset=True).items() if v['launches']}
+    be.enable_timing(False)
+    t0 = time.time()
+    ba.set_bundle(b)
+    ba.optimize(max_steps=10)
+    torch.cuda.synchronize()
+    out['optimize_10_steps_s'] = time.time() - t0
+    out['optimize_costs'] = [float(c) for c in ba.costs]
+    out['optimize_trials'] = [(d, o) for d, o, _ in ba.trial_log]
+    ba.backend.close()
     return out
 
 
@@ -1151,6 +1197,10 @@ def main():
                 oc['reference_dataset_oleg_100x1000'] = reference_dataset()
             except Exception as e:
                 oc['reference_dataset_oleg_100x1000'] = {'error': repr(e)}
+            try:
+                oc['unordered_collection_5000_cameras'] = unordered_collection()
+            except Exception as e:
+                oc['unordered_collection_5000_cameras'] = {'error': repr(e)}
             oc['wall_s'] = time.time() - t_oc
             out['other_configs'] = oc
             try:

@@ -857,6 +857,11 @@ def test_bench_line_keeps_the_drivers_contract():
     assert oc['config3_track_length_32']['ms_per_step'] < 3.0 and oc['config3_track_length_32']['schur_kernel'] == 4 and oc['config3_track_length_32']['solve_kind'] == 'bcr_big'
     lt = oc['config3_2pct_tracks_of_80_cameras']
     assert lt['ms_per_step'] < 4.0 and lt['schur_kernel'] == 4 and lt['half_bandwidth'] == 79 and lt['solve_kind'] == 'bcr_big'
+    # a scene with no band at all (round 6): conjugate gradients over the blocks the tracks define - 34.5 s a trial in round 5
+    uc = oc['unordered_collection_5000_cameras']
+    assert 'error' not in uc, uc
+    assert all(t['solver'] == 'pcg' and t['rel_residual'] <= 1e-12 for t in uc['trials'].values()), uc['trials']
+    assert uc['trials']['damping_10']['ms_per_trial'] < 10. and uc['band_fill'] < .05
     assert d['config']['init_mode'] in ('params', 'pose') and full['lm_other_start']['init_mode'] != d['config']['init_mode']
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and isinstance(c['sample'], str) and c['unit'] == d['unit']
