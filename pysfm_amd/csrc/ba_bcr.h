@@ -37,14 +37,20 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, i
                                                               double* __restrict__ Dm, double* __restrict__ Um,
                                                               double* __restrict__ fm, int* __restrict__ info,
                                                               double* __restrict__ xsol = nullptr, int* __restrict__ done = nullptr,
-                                                              const int* __restrict__ nodes = nullptr) {
+                                                              const int* __restrict__ nodes = nullptr, double* __restrict__ mark = nullptr,
+                                                              long long mark_n = 0) {
   const int B = 6 * cb, hb1 = hb + 1;
   const int I = nodes ? nodes[blockIdx.x] : blockIdx.x;      // (a rank of the distributed solve assembles its own nodes and the separators only)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *info = 0;                                    // status word of this solve (the eliminate levels only ever set it)
     info[kBcrTicketWord] = 0;                     // ticket counter of k_bcr_backsolve_fused
     info[kBcrTicketWord - 1] = 0;                 // ... and of k_bcr_eliminate_fused (kBcrElimTicketWord)
+    info[kBcrRefineTicketWord] = 0;               // ... and of k_bcr_refine (ba_bcr_refine.h)
   }
+  // everything the refinement step behind this solve will wait on: "not yet" (ba_bcr_refine.h; only when the step is going to run)
+  if (blockIdx.y == 0)
+    for (long long e = (long long)blockIdx.x * kBcrThreads + threadIdx.x; e < mark_n; e += (long long)gridDim.x * kBcrThreads)
+      mark[e] = __longlong_as_double(kBcrNotYet);
   if (done && threadIdx.x < 4) done[4 * I + threadIdx.x] = 0;      // "this (node, role) has handed its results on": not yet
   // every load of a thread is issued before its first store (one round trip to memory instead of one per entry): the address
   // of an entry that is not in the band is that of S[0], its value is then multiplied away - a select on the loaded value

@@ -23,6 +23,7 @@ namespace ba {
 constexpr int kBcrThreads = 1024;                // assemble (111 nodes at config 3: few workgroups, so make them wide)
 constexpr int kBcrElimThreads = 1024;           // eliminate / backsolve: 16 wavefronts per node
 constexpr int kBcrTicketWord = 61;             // info[61]: tickets of k_bcr_backsolve_fused (info = flags + 1, 64 flag words)
+constexpr int kBcrRefineTicketWord = 58;       // info[58]: tickets of k_bcr_refine
 constexpr long long kBcrNotYet = 0x7FFA5A5A5A5A5A5All;    // a NaN no computation produces: the mark of a solution entry that is not there yet
 constexpr int kBcrMaxSpins = 1 << 20;           // bounded waits of the one-launch kernels: polls of ~1 us each
 constexpr int kBcrTimedOut = 0x7f000001;        // status word of a workgroup that gave up waiting for another (BA_SOLVE_TIMED_OUT)

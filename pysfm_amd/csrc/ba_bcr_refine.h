@@ -4,20 +4,22 @@
 // The reference solves its reduced system with LAPACK's gesv (bundle_adjuster.py:302-305).  The cyclic reduction multiplies by
 // explicit inverses of the nodes' Cholesky factors; on the damped system of a monocular scene at damping 1e-3 (condition number
 // 1e13) that leaves a residual ||S x - b|| about 2.5 times LAPACK's.  The cure is the textbook one:
-//     r = b - S x          (k_bcr_residual: every product and sum carried in twice the working precision - TwoProduct /
-//                           TwoSum, Ogita-Rump-Oishi's Dot2 - so that r is the residual of x and not the round-off of forming it)
+//     r = b - S x          (every product and sum carried in twice the working precision - TwoProduct / TwoSum,
+//                           Ogita-Rump-Oishi's Dot2 - so that r is the residual of x and not the round-off of forming it)
 //     S d = r              (k_bcr_refine: r goes up and down the SAME elimination tree, two matrix-vector products per node and
 //                           direction; nothing is factored again)
 //     x += d
-// Two launches behind the solve, ~25 us at 111 nodes (the solve: 105): switched on where the walk is sensitive to the last digits
-// of the solve (option refine = auto: damping below 1e-2), always (1) or never (0).
+// One launch behind the solve, ~38 us at 111 nodes (the solve: 105; twelve dependent hand-overs between workgroups at ~2 us each
+// and ~11 us of its own): switched on where the walk is sensitive to the last digits of the solve (option refine = auto: damping
+// below 1e-2), always (1) or never (0).
 //
 // k_bcr_refine is ONE launch for both sweeps, in the manner of k_bcr_eliminate_fused: a workgroup takes a ticket when it starts
-// and works on work[ticket] - the N forward items level by level from the leaves up, then the N backward items from the root
-// down - so it only ever waits for workgroups that started before it.  What crosses workgroups (a node's contributions
-// P^T g, Q^T g to its neighbours' right-hand sides, g itself, the corrections d) is written once into a slot of its own that
-// k_bcr_residual marked "not yet" (relaxed agent-scope accesses; the consumer polls the data itself, ba_bcr.h), and a right-hand
-// side adds its contributions up in a fixed order: the same bits every run.
+// and works on work[ticket] - the residual items, then the N forward items level by level from the leaves up, then the backward
+// items from the root down - so it only ever waits for workgroups that started before it.  What crosses workgroups (a node's contributions
+// P^T g, Q^T g to its neighbours' right-hand sides, g itself, the corrections d) is written once into a slot of its own that the
+// solve's k_bcr_assemble marked "not yet" (relaxed agent-scope accesses; the consumer polls the data itself, ba_bcr.h), and a
+// right-hand side adds its contributions up in a fixed order: the same bits every run.  A forward item forms its node's rows of
+// the residual itself, before it starts to wait.
 #pragma once
 
 #include "ba_bcr.h"
@@ -52,20 +54,13 @@ __device__ __forceinline__ void dd_add(double& hi, double& lo, double h2, double
 #ifndef BA_BCR_TEMPLATES_ONLY
 constexpr int kRefineMaxTerms = ((2 * kBcrSplitMaxHB + 1) * 6 + 15) / 16;      // entries of a band row per lane, 16 lanes a row: 11
 
-// r = b - S x for the rows of node I (cb cameras; the band's half-width is hb <= cb), sixteen lanes per row: a lane's entries of
-// S and x are all on their way before the first is used (a load per term of a dependent chain costs the kernel a memory round
-// trip per term: 15 us instead of 3).  Rows of cameras past the end and masked parameters: 0 (k_bcr_assemble made them identity
-// rows).  Also marks everything k_bcr_refine waits on as "not yet" and clears its ticket counter.
-__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_residual(int n1, int hb, int cb, const double* __restrict__ S,
-                                                                  const double* __restrict__ b, const unsigned char* __restrict__ mask,
-                                                                  const double* __restrict__ x, double* __restrict__ rr,
-                                                                  double* __restrict__ gq, double* __restrict__ xq,
-                                                                  double* __restrict__ slots, int slot_doubles, int* __restrict__ info) {
-  const int B = 6 * cb, hb1 = hb + 1, I = blockIdx.x, tid = threadIdx.x;
-  if (I == 0 && tid == 0) info[kBcrTicketWord] = 0;
-  const double not_yet = __longlong_as_double(kBcrNotYet);
-  for (int e = tid; e < B; e += kBcrElimThreads) { gq[(size_t)I * B + e] = not_yet; xq[(size_t)I * B + e] = not_yet; }
-  for (int e = tid; e < slot_doubles; e += kBcrElimThreads) slots[(size_t)I * slot_doubles + e] = not_yet;
+// r = b - S x for the rows of node I (cb cameras; the band's half-width is hb <= cb) into LDS, sixteen lanes per row: a lane's entries of
+// S and x are all on their way before the first is used (a load per term of a dependent chain costs a memory round trip per
+// term: 15 us instead of 3 for the stand-alone kernel this once was).  Rows of cameras past the end and masked parameters: 0
+// (k_bcr_assemble made them identity rows).
+__device__ __forceinline__ void refine_residual_rows(int I, int n1, int hb, int cb, const double* __restrict__ S, const double* __restrict__ b,
+                                                     const unsigned char* __restrict__ mask, const double* __restrict__ x, double* __restrict__ out /*LDS [B]*/) {
+  const int B = 6 * cb, hb1 = hb + 1, tid = threadIdx.x;
   for (int base = 0; base < 16 * B; base += kBcrElimThreads) {
     const int task = base + tid, rraw = task >> 4, q = task & 15;
     const int r = rraw < B ? rraw : B - 1;                      // (rows past the end repeat the last: DPP sources must be live lanes)
@@ -95,15 +90,16 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_residual(int n1, int hb
     dd_add(hi, lo, dpp_pair<0x4E>(hi), dpp_pair<0x4E>(lo));
     dd_add(hi, lo, dpp_pair<0x141>(hi), dpp_pair<0x141>(lo));
     dd_add(hi, lo, dpp_pair<0x140>(hi), dpp_pair<0x140>(lo));
-    if (q == 0 && rraw < B) rr[(size_t)I * B + r] = live ? __dadd_rn(hi, lo) : 0.0;
+    if (q == 0 && rraw < B) out[r] = live ? __dadd_rn(hi, lo) : 0.0;
   }
 }
 
 // bcr_wait_value (ba_bcr.h) with the poll of the value and the look at the status word on their way TOGETHER, and no sleep: a poll
 // is one memory round trip instead of two and a nap - with fourteen hand-overs on the critical path (seven levels up, seven
 // down) the poll interval is a tenth of the kernel.  One wavefront per workgroup polls.
-__device__ __forceinline__ double refine_wait(const double* p, int* status) {
+__device__ __forceinline__ double refine_wait(const double* p, int* status, int nowait = 0) {
   double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nowait) return 0.0;
   for (int spins = 0; __double_as_longlong(v) == kBcrNotYet; ++spins) {
     if (spins >= kBcrMaxSpins) { atomicMax(status, kBcrTimedOut); break; }
     const double v2 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -130,10 +126,11 @@ __device__ __forceinline__ double refine_sum16(double acc) {
 // from the LDS copy into REGISTERS before the item starts to wait, so that what follows the arrival of the awaited vector is
 // vector traffic only: LDS write, barrier, five LDS reads, the FMAs, four DPP steps.
 template <int ROUNDS>      // 16 B / 1024 rounded up: 1 (B <= 64) or 2
-__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, int LV, int rows, const double* __restrict__ rr,
+__global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, int LV, int n1, int hb, const double* __restrict__ S,
+                                                                const double* __restrict__ bvec, const unsigned char* __restrict__ mask,
                                                                 const double* __restrict__ Pm, const double* __restrict__ Qm,
-                                                                const double* __restrict__ Gi, double* gq, double* xq, double* slots,
-                                                                double* __restrict__ x, const int* __restrict__ work, int* ticket) {
+                                                                const double* __restrict__ Gi, double* rq, double* gq, double* xq, double* slots,
+                                                                double* __restrict__ x, const int* __restrict__ work, int* ticket, int nowait) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, ld = B + 1;
   double* MP = sm;                       // [B][ld] P
@@ -143,7 +140,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
   double* xl = w + B;                    // [B]
   double* xr = xl + B;                   // [B]
   int* my_ticket = reinterpret_cast<int*>(xr + B);
-  int* status = ticket - kBcrTicketWord;
+  int* status = ticket - kBcrRefineTicketWord;
+  const int rows = 6 * n1;
   // (ONE thread reads the status word and takes the ticket: k_bcr_backsolve_fused.  A failed solve leaves nothing to refine.)
   if (tid == 0) {
     const int st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -153,8 +151,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
   __syncthreads();
   if (my_ticket[1] != 0) return;
   const int item = work[my_ticket[0]];
-  const int i = item >> 1;
-  const bool back = item & 1;
+  const int i = item >> 2;
+  const bool back = (item & 3) == 1, resid = (item & 3) == 2;
   const int s = (i + 1) & -(i + 1);      // the level that eliminated node i: i = s (2 k + 1) - 1
   const int l = i - s, r = i + s;
   const bool haveL = l >= 0, haveR = r < N;
@@ -163,6 +161,19 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
   const size_t slot_node = (size_t)2 * LV * B;
   int lv = 0;
   while ((1 << lv) < s) ++lv;            // this node's level: contributions come from levels 0 .. lv - 1
+  // r_i = this node's rows of b - S x, in twice the working precision: the RESIDUAL items, first in the work list (so that the
+  // forward items, which wait for them, only ever wait for workgroups that started before them), one per node but the root
+  // (its forward item forms its own: it has time) - off the forward sweep's critical path, where forming r_i sat for 6 us.
+  // (x is the solve's: the first correction lands in it after the root's forward item has heard from every node, i.e. after every
+  // node's rows have been formed.)
+  if (resid || (root && !back)) {
+    refine_residual_rows(i, n1, hb, B / 6, S, bvec, mask, x, xr);
+    __syncthreads();
+    if (resid) {
+      if (tid < B) __hip_atomic_store(rq + (size_t)i * B + tid, xr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
   // stage P_i, Q_i, G_i^-1 (written by the solve's launches: plain loads), all loads of a thread before its first store
   {
     constexpr int U = (kBcrSplitMaxHB * 6 * kBcrSplitMaxHB * 6 + kBcrElimThreads - 1) / kBcrElimThreads;
@@ -218,10 +229,10 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
         c[u] = want ? __hip_atomic_load(mine + (size_t)u * B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
       // ... then, in a fixed order, waited for where needed and subtracted
-      double acc = rr[(size_t)i * B + tid];
+      double acc = root ? xr[tid] : refine_wait(rq + (size_t)i * B + tid, status, nowait);
 #pragma unroll
       for (int u = 0; u < 2 * kRefineMaxLevels; ++u) {
-        if (__double_as_longlong(c[u]) == kBcrNotYet) c[u] = refine_wait(mine + (size_t)u * B, status);
+        if (__double_as_longlong(c[u]) == kBcrNotYet) c[u] = refine_wait(mine + (size_t)u * B, status, nowait);
         acc -= c[u];
       }
       w[tid] = acc;
@@ -282,9 +293,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
     const double g0 = __hip_atomic_load(gq + (size_t)i * B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double a0 = haveL ? __hip_atomic_load(xq + (size_t)l * B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     double a1 = haveR ? __hip_atomic_load(xq + (size_t)r * B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    w[tid] = __double_as_longlong(g0) == kBcrNotYet ? refine_wait(gq + (size_t)i * B + tid, status) : g0;
-    if (__double_as_longlong(a0) == kBcrNotYet) a0 = refine_wait(xq + (size_t)l * B + tid, status);
-    if (__double_as_longlong(a1) == kBcrNotYet) a1 = refine_wait(xq + (size_t)r * B + tid, status);
+    w[tid] = __double_as_longlong(g0) == kBcrNotYet ? refine_wait(gq + (size_t)i * B + tid, status, nowait) : g0;
+    if (__double_as_longlong(a0) == kBcrNotYet) a0 = refine_wait(xq + (size_t)l * B + tid, status, nowait);
+    if (__double_as_longlong(a1) == kBcrNotYet) a1 = refine_wait(xq + (size_t)r * B + tid, status, nowait);
     xl[tid] = a0;
     xr[tid] = a1;
   }

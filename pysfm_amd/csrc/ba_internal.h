@@ -79,6 +79,7 @@ struct Options {
   double pcg_tol = 1e-12;          // conjugate gradients (ba_pcg.h): converged at ||r|| <= pcg_tol ||b||
   int pcg_max_iter = 0;            // ... iteration budget (0: max(1000, min(20000, 4 nco)))
   int pcg_batch = 50;              // ... iterations enqueued between two looks at the state
+  int refine_debug = 0;            // experiment: 1 = the refinement's items do not wait for each other (wrong numbers, the kernel's floor time)
   int refine = 0;                  // one step of iterative refinement behind the cyclic reduction (ba_bcr_refine.h): 0 auto (damping below kRefineBelowDamping), 1 always, 2 never
   int camera_order = 0;            // internal order of the optimised cameras (ba_order.hip): 0 auto (when the caller's is not provably as narrow as it can be), 1 off, 2 always try
 };
@@ -226,7 +227,7 @@ struct ba_handle {
   // normal-equation blocks
   DevBuf<double> HCC, bC, HPP, bP, HPPinv, W, S_own, b_own, dC, dP, scratch, scratch2, Ufac, ysol, dinv, bcrD, bcrU, bcrF, bcrP, bcrQ, bcrG, bcrGv, bcrL, bcrLv, denseA, bigK, fac, dUd, dDd, dyd, dpart, comm_dev;
   DevBuf<unsigned char> mask;
-  DevBuf<double> bcrRr, bcrRg, bcrRx, bcrRs;   // refinement step (ba_bcr_refine.h): residual, g and d per node, the contribution slots
+  DevBuf<double> bcrRm;      // refinement step (ba_bcr_refine.h): [g | d | contribution slots] of every node - what its items wait on, marked by k_bcr_assemble
   DevBuf<int> bcr_rwork;     // ... its work list: 2 node + sweep, forward items leaves first, then backward items root down (for bcr_rwork_n nodes)
   int bcr_rwork_n = 0;
   DevBuf<int> bcr_order;     // k_bcr_backsolve_fused: the nodes level by level from the root down (for bcr_order_n nodes)

@@ -17,7 +17,7 @@ inline int bcr_node_size(const ba_handle* h) { return h->band_cams() <= kBcrMaxH
 
 // Block cyclic reduction over super-blocks of hb cameras (ba_bcr.h): log2(N) levels, one
 // workgroup per eliminated node.  Leaves the solution in h->dC and the status in flags[1].
-static int solve_bcr_factor(ba_handle* h, const unsigned char* dmask);
+static int solve_bcr_factor(ba_handle* h, const unsigned char* dmask, double* mark, long long mark_n);
 
 // Does this solve take the refinement step (ba_bcr_refine.h)?  Not with a border (its solve goes on from the factors), not when
 // the solve is spread over ranks (ba_dist.h); option refine = auto: where the reduced system is damped less than kRefineBelowDamping.
@@ -26,60 +26,69 @@ static bool refine_wanted(const ba_handle* h) {
   return h->opt.refine == REFINE_ON || h->schur_damping < kRefineBelowDamping;
 }
 
-// x += S^-1 (b - S x) through the kept factors of the cyclic reduction (every level's G^-1, P, Q are in bcrG / bcrP / bcrQ whichever
-// kernel eliminated it): k_bcr_residual + k_bcr_refine.
-static int refine_bcr(ba_handle* h, const unsigned char* dmask) {
+struct RefinePlan { int N, B, LV; size_t slot_doubles, doubles; };
+static RefinePlan refine_plan(const ba_handle* h) {
   const int n1 = h->band_cams();
   const int hb = bcr_node_size(h), B = 6 * hb, N = (n1 + hb - 1) / hb;
-  std::vector<int> strides;
-  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
-  const int LV = (int)strides.size();
-  if (LV > kRefineMaxLevels) return BA_OK;                   // (more than 65535 nodes: the solve stands as it is)
+  int LV = 0;
+  for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) ++LV;
   const size_t slot_doubles = (size_t)2 * LV * B;
-  HIPCHECK(h, h->bcrRr.resize((size_t)N * B)); HIPCHECK(h, h->bcrRg.resize((size_t)N * B)); HIPCHECK(h, h->bcrRx.resize((size_t)N * B));
-  HIPCHECK(h, h->bcrRs.resize((size_t)N * slot_doubles));
+  return {N, B, LV, slot_doubles, (size_t)N * (3 * B + slot_doubles)};       // [r | g | d | contribution slots]
+}
+
+// x += S^-1 (b - S x) through the kept factors of the cyclic reduction (every level's G^-1, P, Q are in bcrG / bcrP / bcrQ whichever
+// kernel eliminated it): ONE launch behind the solve (k_bcr_refine); what it waits on was marked by the solve's k_bcr_assemble.
+static int refine_bcr(ba_handle* h, const unsigned char* dmask) {
+  const RefinePlan rp = refine_plan(h);
+  const int N = rp.N, B = rp.B, LV = rp.LV;
   if (h->bcr_rwork_n != N) {
-    std::vector<int> work;
+    std::vector<int> strides, work;
+    for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
+    auto is_root = [&](int i) { const int s = (i + 1) & -(i + 1); return i - s < 0 && i + s >= N; };
+    for (int i = 0; i < N; ++i)
+      if (!is_root(i)) work.push_back(4 * i + 2);                       // residual items first: nobody they wait for, everybody waits for them
     for (int q = 0; q < LV; ++q)
       for (int k = 0, cnt = (N / strides[q] + 1) / 2; k < cnt; ++k) {
         const int i = strides[q] * (2 * k + 1) - 1;
-        if (i < N) work.push_back(2 * i);
+        if (i < N) work.push_back(4 * i);
       }
     for (int q = LV - 1; q >= 0; --q)
       for (int k = 0, cnt = (N / strides[q] + 1) / 2; k < cnt; ++k) {
         const int i = strides[q] * (2 * k + 1) - 1;
-        if (i < N && (i - strides[q] >= 0 || i + strides[q] < N)) work.push_back(2 * i + 1);      // (the root's forward item goes straight on to its correction)
+        if (i < N && !is_root(i)) work.push_back(4 * i + 1);      // (the root's forward item goes straight on to its correction)
       }
-    if ((int)work.size() != 2 * N - 1) return h->fail(BA_ERR_STATE, "refinement: %d of %d items in the level lists", (int)work.size(), 2 * N - 1);
+    if ((int)work.size() != 3 * N - 2) return h->fail(BA_ERR_STATE, "refinement: %d of %d items in the level lists", (int)work.size(), 3 * N - 2);
     HIPCHECK(h, h->bcr_rwork.resize(work.size()));
     HIPCHECK(h, hipMemcpyAsync(h->bcr_rwork.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));          // `work` goes out of scope
     h->bcr_rwork_n = N;
   }
+  double* rq = h->bcrRm.p, *gq = rq + (size_t)N * B, *xq = gq + (size_t)N * B, *slots = xq + (size_t)N * B;
   const size_t lds = ((size_t)3 * B * (B + 1) + 3 * B + 8) * sizeof(double);
   const bool two_rounds = 16 * B > kBcrElimThreads;
   HIPCHECK(h, ensure_lds_attr(h, two_rounds ? (const void*)k_bcr_refine<2> : (const void*)k_bcr_refine<1>));
-  ScopedTimer tm(h, BA_K_BCR_REFINE, 2);
-  hipLaunchKernelGGL(k_bcr_residual, dim3(N), dim3(kBcrElimThreads), 0, h->stream, n1, h->hb, hb, h->S, h->b, dmask, h->dC.p, h->bcrRr.p, h->bcrRg.p,
-                     h->bcrRx.p, h->bcrRs.p, (int)slot_doubles, h->flags.p + 1);
+  ScopedTimer tm(h, BA_K_BCR_REFINE, 1);
   if (two_rounds)
-    hipLaunchKernelGGL(k_bcr_refine<2>, dim3(2 * N - 1), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, 6 * n1, h->bcrRr.p, h->bcrP.p, h->bcrQ.p,
-                       h->bcrG.p, h->bcrRg.p, h->bcrRx.p, h->bcrRs.p, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrTicketWord);
+    hipLaunchKernelGGL(k_bcr_refine<2>, dim3(3 * N - 2), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, h->band_cams(), h->hb, h->S, h->b, dmask,
+                       h->bcrP.p, h->bcrQ.p, h->bcrG.p, rq, gq, xq, slots, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrRefineTicketWord, h->opt.refine_debug);
   else
-    hipLaunchKernelGGL(k_bcr_refine<1>, dim3(2 * N - 1), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, 6 * n1, h->bcrRr.p, h->bcrP.p, h->bcrQ.p,
-                       h->bcrG.p, h->bcrRg.p, h->bcrRx.p, h->bcrRs.p, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrTicketWord);
+    hipLaunchKernelGGL(k_bcr_refine<1>, dim3(3 * N - 2), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, h->band_cams(), h->hb, h->S, h->b, dmask,
+                       h->bcrP.p, h->bcrQ.p, h->bcrG.p, rq, gq, xq, slots, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrRefineTicketWord, h->opt.refine_debug);
   HIPCHECK(h, hipGetLastError());
   ++h->refined;
   return BA_OK;
 }
 
 int solve_bcr(ba_handle* h, const unsigned char* dmask) {
-  int rc = solve_bcr_factor(h, dmask);
-  if (rc == BA_OK && refine_wanted(h)) rc = refine_bcr(h, dmask);
+  const RefinePlan rp = refine_plan(h);
+  const bool refine = refine_wanted(h) && rp.LV <= kRefineMaxLevels;      // (more than 4095 nodes: the solve stands as it is)
+  if (refine) HIPCHECK(h, h->bcrRm.resize(rp.doubles));
+  int rc = solve_bcr_factor(h, dmask, refine ? h->bcrRm.p : nullptr, refine ? (long long)rp.doubles : 0);
+  if (rc == BA_OK && refine) rc = refine_bcr(h, dmask);
   return rc;
 }
 
-static int solve_bcr_factor(ba_handle* h, const unsigned char* dmask) {
+static int solve_bcr_factor(ba_handle* h, const unsigned char* dmask, double* mark, long long mark_n) {
   const int n1 = h->band_cams();
   const int hb = bcr_node_size(h), B = 6 * hb, N = (n1 + hb - 1) / hb;      // (hb: cameras per node from here on)
   const size_t BB = (size_t)B * B;
@@ -141,7 +150,7 @@ static int solve_bcr_factor(ba_handle* h, const unsigned char* dmask) {
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1], marks the solution "not there yet", clears done[]
     hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, n1, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
-                       h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, s_fused ? h->bcr_done.p : nullptr);
+                       h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, s_fused ? h->bcr_done.p : nullptr, (const int*)nullptr, mark, mark_n);
   }
   {
     int launches = 0;
