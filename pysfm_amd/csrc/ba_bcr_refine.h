@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
                                                                 const double* __restrict__ bvec, const unsigned char* __restrict__ mask,
                                                                 const double* __restrict__ Pm, const double* __restrict__ Qm,
                                                                 const double* __restrict__ Gi, double* rq, double* gq, double* xq, double* slots,
-                                                                double* __restrict__ x, const int* __restrict__ work, int* ticket, int nowait) {
+                                                                double* __restrict__ x, const int* __restrict__ work, int* ticket, int nowait /* bit 0: experiment, nobody waits; bit 1: no residual items */) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, ld = B + 1;
   double* MP = sm;                       // [B][ld] P
@@ -166,7 +166,8 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
   // (its forward item forms its own: it has time) - off the forward sweep's critical path, where forming r_i sat for 6 us.
   // (x is the solve's: the first correction lands in it after the root's forward item has heard from every node, i.e. after every
   // node's rows have been formed.)
-  if (resid || (root && !back)) {
+  const bool own_resid = (nowait & 2) != 0;      // no residual items (more nodes than the chip holds workgroups: every forward item forms its own rows)
+  if (resid || ((root || own_resid) && !back)) {
     refine_residual_rows(i, n1, hb, B / 6, S, bvec, mask, x, xr);
     __syncthreads();
     if (resid) {
@@ -229,10 +230,10 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
         c[u] = want ? __hip_atomic_load(mine + (size_t)u * B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
       // ... then, in a fixed order, waited for where needed and subtracted
-      double acc = root ? xr[tid] : refine_wait(rq + (size_t)i * B + tid, status, nowait);
+      double acc = (root || own_resid) ? xr[tid] : refine_wait(rq + (size_t)i * B + tid, status, nowait & 1);
 #pragma unroll
       for (int u = 0; u < 2 * kRefineMaxLevels; ++u) {
-        if (__double_as_longlong(c[u]) == kBcrNotYet) c[u] = refine_wait(mine + (size_t)u * B, status, nowait);
+        if (__double_as_longlong(c[u]) == kBcrNotYet) c[u] = refine_wait(mine + (size_t)u * B, status, nowait & 1);
         acc -= c[u];
       }
       w[tid] = acc;
@@ -293,9 +294,9 @@ __global__ __launch_bounds__(kBcrElimThreads) void k_bcr_refine(int N, int B, in
     const double g0 = __hip_atomic_load(gq + (size_t)i * B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double a0 = haveL ? __hip_atomic_load(xq + (size_t)l * B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     double a1 = haveR ? __hip_atomic_load(xq + (size_t)r * B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    w[tid] = __double_as_longlong(g0) == kBcrNotYet ? refine_wait(gq + (size_t)i * B + tid, status, nowait) : g0;
-    if (__double_as_longlong(a0) == kBcrNotYet) a0 = refine_wait(xq + (size_t)l * B + tid, status, nowait);
-    if (__double_as_longlong(a1) == kBcrNotYet) a1 = refine_wait(xq + (size_t)r * B + tid, status, nowait);
+    w[tid] = __double_as_longlong(g0) == kBcrNotYet ? refine_wait(gq + (size_t)i * B + tid, status, nowait & 1) : g0;
+    if (__double_as_longlong(a0) == kBcrNotYet) a0 = refine_wait(xq + (size_t)l * B + tid, status, nowait & 1);
+    if (__double_as_longlong(a1) == kBcrNotYet) a1 = refine_wait(xq + (size_t)r * B + tid, status, nowait & 1);
     xl[tid] = a0;
     xr[tid] = a1;
   }

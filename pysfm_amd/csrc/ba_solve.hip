@@ -41,12 +41,15 @@ static RefinePlan refine_plan(const ba_handle* h) {
 static int refine_bcr(ba_handle* h, const unsigned char* dmask) {
   const RefinePlan rp = refine_plan(h);
   const int N = rp.N, B = rp.B, LV = rp.LV;
+  // residual items of their own (off the forward sweep's critical path) while the launch fits the chip about once; beyond that the
+  // sweep is bound by rounds of workgroups, not by hand-overs: a third fewer of them when every forward item forms its own rows
+  const bool resid_items = 3 * N - 2 <= 2 * h->ncu;
   if (h->bcr_rwork_n != N) {
     std::vector<int> strides, work;
     for (int s = 1; (N / s + 1) / 2 > 0; s *= 2) strides.push_back(s);
     auto is_root = [&](int i) { const int s = (i + 1) & -(i + 1); return i - s < 0 && i + s >= N; };
     for (int i = 0; i < N; ++i)
-      if (!is_root(i)) work.push_back(4 * i + 2);                       // residual items first: nobody they wait for, everybody waits for them
+      if (resid_items && !is_root(i)) work.push_back(4 * i + 2);       // residual items first: nobody they wait for, everybody waits for them
     for (int q = 0; q < LV; ++q)
       for (int k = 0, cnt = (N / strides[q] + 1) / 2; k < cnt; ++k) {
         const int i = strides[q] * (2 * k + 1) - 1;
@@ -57,7 +60,7 @@ static int refine_bcr(ba_handle* h, const unsigned char* dmask) {
         const int i = strides[q] * (2 * k + 1) - 1;
         if (i < N && !is_root(i)) work.push_back(4 * i + 1);      // (the root's forward item goes straight on to its correction)
       }
-    if ((int)work.size() != 3 * N - 2) return h->fail(BA_ERR_STATE, "refinement: %d of %d items in the level lists", (int)work.size(), 3 * N - 2);
+    if ((int)work.size() != (resid_items ? 3 * N - 2 : 2 * N - 1)) return h->fail(BA_ERR_STATE, "refinement: %d items in the level lists of %d nodes", (int)work.size(), N);
     HIPCHECK(h, h->bcr_rwork.resize(work.size()));
     HIPCHECK(h, hipMemcpyAsync(h->bcr_rwork.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));          // `work` goes out of scope
@@ -69,11 +72,11 @@ static int refine_bcr(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, ensure_lds_attr(h, two_rounds ? (const void*)k_bcr_refine<2> : (const void*)k_bcr_refine<1>));
   ScopedTimer tm(h, BA_K_BCR_REFINE, 1);
   if (two_rounds)
-    hipLaunchKernelGGL(k_bcr_refine<2>, dim3(3 * N - 2), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, h->band_cams(), h->hb, h->S, h->b, dmask,
-                       h->bcrP.p, h->bcrQ.p, h->bcrG.p, rq, gq, xq, slots, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrRefineTicketWord, h->opt.refine_debug);
+    hipLaunchKernelGGL(k_bcr_refine<2>, dim3(resid_items ? 3 * N - 2 : 2 * N - 1), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, h->band_cams(), h->hb, h->S, h->b, dmask,
+                       h->bcrP.p, h->bcrQ.p, h->bcrG.p, rq, gq, xq, slots, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrRefineTicketWord, (h->opt.refine_debug & 1) | (resid_items ? 0 : 2));
   else
-    hipLaunchKernelGGL(k_bcr_refine<1>, dim3(3 * N - 2), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, h->band_cams(), h->hb, h->S, h->b, dmask,
-                       h->bcrP.p, h->bcrQ.p, h->bcrG.p, rq, gq, xq, slots, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrRefineTicketWord, h->opt.refine_debug);
+    hipLaunchKernelGGL(k_bcr_refine<1>, dim3(resid_items ? 3 * N - 2 : 2 * N - 1), dim3(kBcrElimThreads), lds, h->stream, N, B, LV, h->band_cams(), h->hb, h->S, h->b, dmask,
+                       h->bcrP.p, h->bcrQ.p, h->bcrG.p, rq, gq, xq, slots, h->dC.p, h->bcr_rwork.p, h->flags.p + 1 + kBcrRefineTicketWord, (h->opt.refine_debug & 1) | (resid_items ? 0 : 2));
   HIPCHECK(h, hipGetLastError());
   ++h->refined;
   return BA_OK;
