@@ -48,7 +48,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix (= vector) peak; v_mf
 # What binds each kernel at the bench sizes; `roofline.limited_by` reports it.  The contract prices
 # `achieved` against HBM for every kernel that is not MFMA-bound, so `frac` is always achieved / 8 TB/s.
 KERNEL_BOUND = {'border_schur': 'atomics', 'border_solve': 'latency', 'bcr_eliminate': 'latency', 'bcr_backsolve': 'latency', 'bcr_refine': 'latency', 'bcr_assemble': 'hbm', 'band_solve': 'latency',
-                'dense_solve': 'latency', 'pcg_solve': 'hbm', 'schur_pairs': 'mfma', 'linearize': 'fp64 issue + gather latency', 'backsub': 'fp64 issue', 'cost': 'hbm',
+                'dense_solve': 'latency', 'pcg_solve': 'hbm', 'schur_pairs': 'mfma', 'linearize': 'latency', 'backsub': 'latency', 'cost': 'hbm',
                 'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
 # timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
 KERNEL_NAMES = {'border_schur': 'k_schur_border (+ k_border_clear)', 'border_solve': 'k_border_prepare, k_bcr_apply (a launch per level, forward and back), k_border_reduce, k_border_solve, k_border_correct',

@@ -83,9 +83,17 @@ int ba_synchronize(ba_handle* h);
  *   "bcrw_merged"   1 | 0                                  wide cyclic reduction (nodes of 14 .. 23 cameras): factorisation and substitution of a level in one kernel / two
  *   "dense_lookahead" 1 | 0                                dense Cholesky / big-node levels: one launch per block column (the next panel step beside the
  *                                                          trailing update) / two
- *   "solver"        auto | bcr | band | dense | lu | bcr1  force the reduced solver (lu: always report -1 = caller's LU; bcr1: the
+ *   "solver"        auto | bcr | band | dense | lu | bcr1 | pcg   force the reduced solver (lu: always report -1 = caller's LU; bcr1: the
  *                                                          cyclic reduction with one compute unit per node instead of three -
- *                                                          for nodes of 12 and 13 cameras that is the wide solver's kernels)
+ *                                                          for nodes of 12 and 13 cameras that is the wide solver's kernels; pcg:
+ *                                                          conjugate gradients over the blocks the tracks define, see ba_pcg_info)
+ *   "refine"        auto | 1 | 0                           one step of iterative refinement behind the cyclic reduction (residual in doubled
+ *                                                          precision, correction through the kept factors): auto = where the reduced system is
+ *                                                          damped below 1e-2; BA_INFO_SOLVES_REFINED counts
+ *   "pcg_tol" x   "pcg_max_iter" n   "pcg_batch" n         conjugate gradients: converged at ||r|| <= x ||b|| (1e-12); iteration budget (0 =
+ *                                                          max(1000, min(20000, 4 nco))); iterations enqueued between two looks at the state (50)
+ *   "resident_fault" g   "refine_debug" 1 | 0              test aids: workgroup g of the resident loop REPORTS a time-out (-1: none); the
+ *                                                          refinement's items do not wait for each other (wrong numbers: its floor time)
  *   "point_kernels" auto | v1                              lanes-per-point k_linearize / k_backsub instead of the group-packed ones
  *   "fuse_cost" "fuse_cam"   1 | 0                         pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1)
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
