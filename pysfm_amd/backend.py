@@ -293,7 +293,7 @@ class HipBackend(object):
         (solve_motion_normal_eqns, bundle_adjuster.py:281-312), entirely on the device (ba_solve_reduced): Cholesky by
         band shape (last_solve_kind 'bcr', 'bcr_wide', 'bcr_big', 'band', 'dense_cholesky'), and - when the system is not
         positive definite - LU with partial pivoting, the reference's own factorisation ('bcr_lu' for nodes of up to 11
-        cameras, 'band_lu' otherwise; last_solve_path 'lu').  The solution stays on the device for backsubstitute();
+        cameras, 'band_lu' otherwise; last_solve_path 'lu'; band + border systems too: csrc/ba_border.hip border_solve_lu).  The solution stays on the device for backsubstitute();
         get_solution() fetches it.  Raises ReducedSystemSingular where the reference's solve raises (an exactly zero pivot)."""
         n = self.nco * 6
         mask = None if cam_param_mask is None else np.ascontiguousarray(cam_param_mask, dtype=np.uint8)
@@ -304,13 +304,6 @@ class HipBackend(object):
             import warnings
             warnings.warn('pysfm_amd: the device solve of the reduced system timed out (status 0x%x): a solver fault, '
                           'not a property of the matrix; solving through LU' % info.value, RuntimeWarning)
-            if self.problem_info().get('border_cameras', 0) > 0:
-                # band + border: the device's LU solvers do not know the border (ba_solve_reduced refuses solver = lu there) - the
-                # host solves it the way the reference does; where that does not apply either, the trial is lost like an ill-conditioned one
-                if self._host_lu_of_bordered_system(mask):
-                    return
-                self._note_solve(info.value)
-                raise ReducedSystemSingular
             before = getattr(self, '_options', {}).get('solver', 'auto')      # (a caller's / test's own choice comes back afterwards)
             self._check(self._lib.ba_set_option(self._h, b'solver', b'lu'))
             try:
@@ -318,36 +311,8 @@ class HipBackend(object):
             finally:
                 self._check(self._lib.ba_set_option(self._h, b'solver', before.encode()))
         self._note_solve(info.value)
-        if info.value > 0 and info.value != capi.SOLVE_TIMED_OUT and self.device_lu and self._host_lu_of_bordered_system(mask):
-            return
         if info.value != 0:
             raise ReducedSystemSingular
-
-    HOST_LU_MAX_UNKNOWNS = 16000            # (the dense matrix of the fall-back below: 2 GB)
-
-    def _host_lu_of_bordered_system(self, mask):
-        """A band + border system (csrc/ba_border.h) that is NOT positive definite: the device's LU solvers do not know the border, the
-        reference's numpy.linalg.solve takes any nonsingular matrix (bundle_adjuster.py:302-305).  Up to HOST_LU_MAX_UNKNOWNS unknowns the
-        system comes to the host, is solved there exactly as the reference does, and the solution goes back to the device
-        (ba_set_solution): last_solve_kind 'host_lu', last_solve_path 'lu'.  Returns False when this does not apply (no border, too
-        large, exactly singular): the caller then reports the system as the reference reports a LinAlgError."""
-        n = self.nco * 6
-        if n > self.HOST_LU_MAX_UNKNOWNS or self.problem_info().get('border_cameras', 0) <= 0:
-            return False
-        S, b = self.get_reduced()
-        A = S.transpose(0, 2, 1, 3).reshape(n, n)
-        keep = np.ones(n, bool) if mask is None else mask.astype(bool)
-        try:
-            x = np.linalg.solve(A[np.ix_(keep, keep)], b.reshape(n)[keep])
-        except np.linalg.LinAlgError:
-            return False
-        if not np.all(np.isfinite(x)):
-            return False
-        dC = np.zeros(n)
-        dC[keep] = x
-        self._check(self._lib.ba_set_solution(self._h, capi.dptr(dC)))
-        self.last_solve_kind, self.last_solve_path = 'host_lu', 'lu'
-        return True
 
     def get_solution(self):
         """dC[nco,6] of the last solve_reduced()."""

@@ -504,6 +504,70 @@ __global__ __launch_bounds__(kBordThreads) void k_border_solve(int nb, const dou
   for (int c = tid; c < nb; c += kBordThreads) x2[c] = xs[c];
 }
 
+// ---- the band + border system that is NOT positive definite (border_solve_lu, ba_border.hip): a column of F out to a vector and a
+// solution back into it; the status of a column's solve folded into one word
+__global__ __launch_bounds__(kBlock) void k_border_column(int rows1, int ld, int c, double* __restrict__ F, double* __restrict__ v, int to_F,
+                                                          const int* __restrict__ info, int* __restrict__ acc) {
+  const int r = blockIdx.x * kBlock + threadIdx.x;
+  if (r == 0 && acc && *acc == 0 && *info != 0) *acc = *info;      // (the first column solve that failed: the next one's assembly clears the word)
+  if (r >= rows1) return;
+  if (to_F) F[(size_t)r * ld + c] = v[r];
+  else v[r] = F[(size_t)r * ld + c];
+}
+
+// (D - C^T Y) x2 = b2 - C^T y by Gaussian elimination with partial pivoting in LDS, one workgroup, a thread per row: what the reference's
+// numpy.linalg.solve would do to the border's Schur complement.  M holds its LOWER triangle (k_border_reduce).  A pivot that is exactly
+// zero: *binfo = its column + 1 (gesv's info).
+__global__ __launch_bounds__(kBordThreads) void k_border_solve_lu(int nb, const double* __restrict__ M, const double* __restrict__ rv, int* __restrict__ binfo,
+                                                                  double* __restrict__ x2) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lda = nb + 2 + ((nb & 1) ? 0 : 1), tid = threadIdx.x;      // (odd row stride; column nb = the right-hand side)
+  double* A = sm;                              // [nb][lda]
+  int* piv_row = reinterpret_cast<int*>(A + (size_t)nb * lda);      // [2]: the pivot's row, "zero pivot at"
+  for (int e = tid; e < nb * nb; e += kBordThreads) {
+    const int r = e / nb, c = e - r * nb;
+    A[r * lda + c] = c <= r ? M[(size_t)r * nb + c] : M[(size_t)c * nb + r];
+  }
+  for (int r = tid; r < nb; r += kBordThreads) A[r * lda + nb] = rv[r];
+  if (tid == 0) piv_row[1] = 0;
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    if (tid == 0) {                            // the entry of largest magnitude in column j from row j down (the first of equals: gesv)
+      int p = j;
+      double best = fabs(A[j * lda + j]);
+      for (int r = j + 1; r < nb; ++r) { const double v = fabs(A[r * lda + j]); if (v > best) { best = v; p = r; } }
+      piv_row[0] = p;
+      if (!(best > 0.0)) piv_row[1] = j + 1;
+    }
+    __syncthreads();
+    if (piv_row[1]) break;
+    const int p = piv_row[0];
+    if (p != j)
+      for (int c = j + tid; c <= nb; c += kBordThreads) { const double t = A[j * lda + c]; A[j * lda + c] = A[p * lda + c]; A[p * lda + c] = t; }
+    __syncthreads();
+    const double inv = 1.0 / A[j * lda + j];
+    if (tid > j && tid < nb) {
+      const double m = A[tid * lda + j] * inv;
+      for (int c = j + 1; c <= nb; ++c) A[tid * lda + c] -= m * A[j * lda + c];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (piv_row[1]) {
+    if (tid == 0) *binfo = piv_row[1];
+    for (int c = tid; c < nb; c += kBordThreads) x2[c] = 0.0;
+    return;
+  }
+  for (int j = nb - 1; j >= 0; --j) {          // U x = y (column nb), last unknown first
+    if (tid == 0) A[j * lda + nb] /= A[j * lda + j];
+    __syncthreads();
+    const double xj = A[j * lda + nb];
+    for (int r = tid; r < j; r += kBordThreads) A[r * lda + nb] -= A[r * lda + j] * xj;
+    __syncthreads();
+  }
+  for (int c = tid; c < nb; c += kBordThreads) x2[c] = A[c * lda + nb];
+}
+
 // ---- x1 = y - Y x2 for the band cameras, x2 behind them; the status of the border solve joins the solver's status word
 __global__ __launch_bounds__(kBlock) void k_border_correct(int rows1, int nb, int ld, const double* __restrict__ Y, const double* __restrict__ x2,
                                                            double* __restrict__ dC, const int* __restrict__ binfo, int* __restrict__ info) {

@@ -224,6 +224,49 @@ int border_solve(ba_handle* h, const unsigned char* dmask) {
   return BA_OK;
 }
 
+// The band + border system when it is NOT positive definite (the reference solves whatever is not singular: numpy.linalg.solve,
+// bundle_adjuster.py:302-305), on the device: block elimination with LU everywhere a Cholesky factor stood -
+//     Y = B^-1 C  column by column and  y = B^-1 b1  through the band's LU solver (the cyclic reduction with LU nodes up to 11
+//     cameras a node, LU with partial pivoting down the band beyond: pivots stay inside the band part), then
+//     (D - C^T Y) x2 = b2 - C^T y  by Gaussian elimination with partial pivoting in one workgroup,  x1 = y - Y x2.
+// 6 k + 1 band solves (k <= 21 border cameras) instead of one factorisation whose factors would take the columns through: the LU
+// nodes keep what the back-substitution needs, not what a second right-hand side's elimination would.  A rare path: 15 ms at 1000
+// cameras with ten border cameras - the host LU it replaces took the whole matrix over PCIe (288 MB) and a second.
+int border_solve_lu(ba_handle* h, const unsigned char* dmask) {
+  if (h->nbc <= 0) return BA_OK;
+  if (int rc = border_join(h); rc != BA_OK) return rc;
+  const int n1 = h->band_cams(), ld = h->bord_ld, nb = 6 * h->nbc, rows1 = 6 * n1;
+  const bool lu_nodes = bcr_cams_per_node(h) <= kBcrMaxHB;
+  ScopedTimer tm(h, BA_K_BORDER_SOLVE, 1);
+  hipLaunchKernelGGL(k_border_prepare, dim3(blocks_for((long long)h->bord_rows * ld + (long long)nb * nb)), dim3(kBlock), 0, h->stream, (long long)h->bord_rows, rows1,
+                     ld, nb, h->bordC.p, h->bordD.p, h->b + (size_t)rows1, dmask, h->bordF.p, bord_M(h), bord_rv(h), bord_info(h));
+  HIPCHECK(h, h->bordV.resize((size_t)rows1 + 64));
+  int* acc = h->flags.p + 48;                               // the first failure among the band solves (each of them clears flags[1] when it starts)
+  HIPCHECK(h, hipMemsetAsync(acc, 0, sizeof(int), h->stream));
+  const unsigned gcol = blocks_for(rows1);
+  for (int c = 0; c <= nb; ++c) {                            // the columns of C, then b1 (its solution stays in dC: y)
+    const bool last = c == nb;
+    if (!last) {
+      hipLaunchKernelGGL(k_border_column, dim3(gcol), dim3(kBlock), 0, h->stream, rows1, ld, c, h->bordF.p, h->bordV.p, 0, h->flags.p + 1, (int*)nullptr);
+    }
+    const int rc = lu_nodes ? solve_bcr_lu(h, dmask, n1, last ? h->b : h->bordV.p) : solve_band_lu(h, dmask, n1, last ? h->b : h->bordV.p);
+    if (rc != BA_OK) return rc;
+    if (!last) hipLaunchKernelGGL(k_border_column, dim3(gcol), dim3(kBlock), 0, h->stream, rows1, ld, c, h->bordF.p, h->dC.p, 1, h->flags.p + 1, acc);
+  }
+  if (h->bord_nrcams > 0)
+    hipLaunchKernelGGL(k_border_reduce, dim3((unsigned)((ld / 16) * (ld / 16 + 1) / 2 + 1), (unsigned)((h->bord_nrcams + 4 * kBordRedCams - 1) / (4 * kBordRedCams))),
+                       dim3(kBordThreads), 0, h->stream, h->bord_nrcams,
+                       h->bord_obs.p + h->bord_off_rcams, ld, nb, h->bordC.p, h->bordF.p, h->dC.p, dmask ? dmask + rows1 : nullptr, bord_M(h), bord_rv(h));
+  HIPCHECK(h, ensure_lds_attr(h, (const void*)k_border_solve_lu));
+  hipLaunchKernelGGL(k_border_solve_lu, dim3(1), dim3(kBordThreads), ((size_t)nb * (nb + 3) + 8) * sizeof(double), h->stream, nb, bord_M(h), bord_rv(h), bord_info(h), bord_x2(h));
+  // (a band solve that failed - an exactly singular band part - outranks the border's own status: the last solve's word is flags[1] itself)
+  hipLaunchKernelGGL(k_border_column, dim3(1), dim3(kBlock), 0, h->stream, 0, ld, 0, h->bordF.p, h->bordV.p, 0, acc, h->flags.p + 1);
+  hipLaunchKernelGGL(k_border_correct, dim3(blocks_for((long long)4 * (rows1 + nb))), dim3(kBlock), 0, h->stream, rows1, nb, ld, h->bordF.p, bord_x2(h), h->dC.p,
+                     bord_info(h), h->flags.p + 1);
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
 int border_get_dense(ba_handle* h, std::vector<double>& C, std::vector<double>& D) {
   if (int rc = border_join(h); rc != BA_OK) return rc;
   const size_t ld = h->bord_ld, rows1 = (size_t)6 * h->band_cams();

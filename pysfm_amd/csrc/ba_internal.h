@@ -199,6 +199,7 @@ struct ba_handle {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool bord_pending = false;           // work on the side stream that the main stream has not waited for yet
+  DevBuf<double> bordV;                // a column of C on its way through the band's LU solver (border_solve_lu)
   DevBuf<double> bordC, bordF, bordD;  // C (as the reduction leaves it), F (work: C -> Y), [D | M | rv | x2]
   int band_cams() const { return nco - nbc; }
   std::vector<unsigned char> mask_host; // the mask of the last solve in the internal order (outlives its asynchronous upload)
@@ -387,6 +388,8 @@ inline void cam_rows_out(const ba_handle* h, T* data, int w) {
 // ---- ba_border.hip: the border of the reduced system (ba_border.h)
 int border_setup(ba_handle* h);                                  // after the problem is set: the border cameras' observations, buffers
 int border_schur(ba_handle* h, int p, double damping);            // the blocks of the border cameras (C, D, the border part of b)
+int border_solve_lu(ba_handle* h, const unsigned char* dmask);    // the same for a system that is not positive definite: LU everywhere (ba_border.hip)
+int solve_bcr_lu(ba_handle* h, const unsigned char* dmask, int ncams = -1, const double* rhs = nullptr);      // cyclic reduction with LU nodes (ba_solve.hip)
 int border_solve(ba_handle* h, const unsigned char* dmask);       // after the band solve: Y = B^-1 C, the border system, the correction of dC
 int border_join(ba_handle* h);                                     // the main stream waits for the side stream's border kernels
 int border_get_dense(ba_handle* h, std::vector<double>& C, std::vector<double>& D);      // host copies of C [6 n1][ld], D [ld][ld]
@@ -470,7 +473,7 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask);          // conjugate g
 bool sparse_layout(ba_handle* h);                                 // a wide band of mostly structural zeros: the pattern-driven initialisation and solver apply
 int launch_schur_init_sparse(ba_handle* h, double damping, int use_hcc);
 double pcg_band_fill(ba_handle* h);                               // fraction of the band's blocks that can be non-zero (builds the pattern)
-int solve_band_lu(ba_handle* h, const unsigned char* dmask);      // LU with partial pivoting, any band width (ba_band_lu.h)
+int solve_band_lu(ba_handle* h, const unsigned char* dmask, int ncams = -1, const double* rhs = nullptr);      // LU with partial pivoting, any band width (ba_band_lu.h)
 // k_bcr_assemble (ba_bcr.h): band (+ mask) -> D, U, f of the nodes of cb cameras; clears the status word
 void launch_bcr_assemble(ba_handle* h, dim3 grid, int cb, const unsigned char* dmask, double* xsol, int* done, const int* nodes);
 // ba_bcr_split.hip / ba_bcr_levels.hip: the node kernels, instantiated per cameras-per-node

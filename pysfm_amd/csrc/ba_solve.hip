@@ -216,15 +216,18 @@ static int solve_bcr_factor(ba_handle* h, const unsigned char* dmask, double* ma
 
 // The cyclic reduction with LU nodes (k_bcr_eliminate_lu): for reduced systems the Cholesky solvers reported as not positive
 // definite.  Same layout and back-substitution as solve_bcr; leaves the solution in h->dC and the status in flags[1].
-int solve_bcr_lu(ba_handle* h, const unsigned char* dmask) {
-  const int hb = bcr_node_size(h), B = 6 * hb, N = (h->nco + hb - 1) / hb;
+int solve_bcr_lu(ba_handle* h, const unsigned char* dmask, int ncams, const double* rhs) {
+  // (ncams, rhs: the band part of a bordered system and any right-hand side of it - ba_border.hip; default: the whole system, b)
+  const int n1 = ncams >= 0 ? ncams : h->nco;
+  if (!rhs) rhs = h->b;
+  const int hb = bcr_node_size(h), B = 6 * hb, N = (n1 + hb - 1) / hb;
   const size_t BB = (size_t)B * B;
   HIPCHECK(h, h->bcrD.resize(N * BB)); HIPCHECK(h, h->bcrU.resize(N * BB)); HIPCHECK(h, h->bcrP.resize(N * BB));
   HIPCHECK(h, h->bcrQ.resize(N * BB)); HIPCHECK(h, h->bcrG.resize(N * BB));
   HIPCHECK(h, h->bcrF.resize((size_t)N * B));
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, n1, h->hb, hb, h->S, rhs, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p);
   }
   std::vector<int> strides;
@@ -428,21 +431,37 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   if (h->nbc > 0) {
     // band + border (ba_border.h): the cyclic reduction factors the band and solves for its right-hand side, its kept factors
     // take the border's columns through, one workgroup solves the border system.  A system that is not positive definite is
-    // REPORTED (*info > 0: the caller raises the damping, as for a LinAlgError of the reference) - the LU solvers do not know the border.
-    REQUIRE(h, force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1, BA_ERR_STATE, "ba_solve_reduced: a problem with border cameras is solved by the cyclic reduction (option camera_order = off sets it up without a border)");
+    // solved again with LU in every place of the block elimination (border_solve_lu: the reference's numpy.linalg.solve takes whatever
+    // is not singular); option solver = lu goes there at once.
+    REQUIRE(h, force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1 || force == SOLVER_LU, BA_ERR_STATE, "ba_solve_reduced: a problem with border cameras is solved by the cyclic reduction or by LU (option camera_order = off sets it up without a border)");
     REQUIRE(h, h->band_cams() <= kBcrMaxHB || (h->hb >= 1 && h->hb <= kBcrSplitMaxHB), BA_ERR_STATE, "ba_solve_reduced: border with a band the cyclic reduction does not take");
     HIPCHECK(h, hipSetDevice(h->device));
     const unsigned char* dmaskb = nullptr;
     if (int rcm = dist_upload_mask(h, cam_param_mask, &dmaskb); rcm != BA_OK) return rcm;
-    h->solve_kind = BA_SOLVE_BCR;
-    int rcb = solve_bcr(h, dmaskb);
-    if (rcb == BA_OK) rcb = border_solve(h, dmaskb);
+    const bool lu_nodes_b = bcr_node_size(h) <= kBcrMaxHB;
+    int rcb = BA_OK;
+    if (force == SOLVER_LU) {
+      h->solve_kind = lu_nodes_b ? BA_SOLVE_BCR_LU : BA_SOLVE_BAND_LU;
+      rcb = border_solve_lu(h, dmaskb);
+    } else {
+      h->solve_kind = BA_SOLVE_BCR;
+      rcb = solve_bcr(h, dmaskb);
+      if (rcb == BA_OK) rcb = border_solve(h, dmaskb);
+    }
     if (rcb != BA_OK) return rcb;
     HIPCHECK(h, hipGetLastError());
     if (h->defer) { *info = 0; h->have_solution = true; return BA_OK; }
     int infb = 0;
     HIPCHECK(h, hipMemcpyAsync(&infb, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (infb > 0 && infb != kBcrTimedOut && force != SOLVER_LU && h->opt.device_lu) {
+      // not positive definite: the reference's LU would still solve it (bundle_adjuster.py:302-305)
+      rcb = border_solve_lu(h, dmaskb);
+      if (rcb != BA_OK) return rcb;
+      HIPCHECK(h, hipMemcpyAsync(&infb, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(h, hipStreamSynchronize(h->stream));
+      h->solve_kind = lu_nodes_b ? BA_SOLVE_BCR_LU : BA_SOLVE_BAND_LU;
+    }
     *info = infb;
     h->have_solution = infb == 0;
     return BA_OK;
@@ -510,7 +529,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
       if (rc != BA_OK) return rc;
     }
   } else if (use_lu) {
-    int rc = solve_band_lu(h, dmask);
+    int rc = solve_band_lu(h, dmask, -1, nullptr);
     if (rc != BA_OK) return rc;
   } else if (use_big) {
     int rc = solve_bcr_big(h, dmask);
@@ -542,7 +561,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
     // not positive definite: the reference's LU would still solve it (bundle_adjuster.py:302-305) - the cyclic reduction with
     // LU nodes where the nodes are narrow, LU with partial pivoting down the band otherwise
     const bool lu_nodes = use_bcr && bcr_node_size(h) <= kBcrMaxHB;      // (k_bcr_eliminate_lu keeps a node's B x (3 B + 1) matrix in LDS)
-    int rc = lu_nodes ? solve_bcr_lu(h, dmask) : solve_band_lu(h, dmask);
+    int rc = lu_nodes ? solve_bcr_lu(h, dmask, -1, nullptr) : solve_band_lu(h, dmask, -1, nullptr);
     if (rc != BA_OK) return rc;
     int inf2 = 0;
     HIPCHECK(h, hipMemcpyAsync(&inf2, h->flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));

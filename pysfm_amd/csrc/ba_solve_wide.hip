@@ -223,8 +223,11 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask) {
 // LU with partial pivoting of the (masked) reduced system (ba_band_lu.h): the reference's own factorisation, for systems the
 // Cholesky solvers report as not positive definite and for option solver = lu.  Leaves the solution in h->dC and gesv's info
 // (0, or the 1-based column of an exactly zero pivot) in flags[1].
-int solve_band_lu(ba_handle* h, const unsigned char* dmask) {
-  const int n = 6 * h->nco;
+int solve_band_lu(ba_handle* h, const unsigned char* dmask, int ncams, const double* rhs_in) {
+  // (ncams, rhs_in: the band part of a bordered system and any right-hand side of it - ba_border.hip; default: the whole system, b)
+  const int n1 = ncams >= 0 ? ncams : h->nco;
+  if (!rhs_in) rhs_in = h->b;
+  const int n = 6 * n1;
   LuShape s;
   s.n = n;
   s.bw = std::min(n - 1, 6 * h->hb + 5);
@@ -236,7 +239,7 @@ int solve_band_lu(ba_handle* h, const unsigned char* dmask) {
   double* mult = rhs + n;
   int* info = h->flags.p + 1;
   ScopedTimer tm(h, BA_K_DENSE_SOLVE, 2 * n + 2);
-  hipLaunchKernelGGL(k_lu_assemble, dim3(n), dim3(256), 0, h->stream, s, h->nco, h->hb, h->S, h->b, dmask, A, rhs, info);
+  hipLaunchKernelGGL(k_lu_assemble, dim3(n), dim3(256), 0, h->stream, s, n1, h->hb, h->S, rhs_in, dmask, A, rhs, info);
   for (int j = 0; j < n; ++j) {
     hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(kLuThreads), 0, h->stream, s, j, A, rhs, mult, info);
     const int rows = std::min(n - 1, j + s.bw) - j;

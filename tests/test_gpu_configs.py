@@ -1155,19 +1155,21 @@ def test_full_lm25_run_against_the_oracle_golden_walk(name):
     ba.backend.close()
 
 
-def test_band_plus_border_system_that_is_not_positive_definite_is_solved_like_the_reference_lu(be):
+@pytest.mark.parametrize('L,kind', [(8, 'bcr_lu'), (13, 'band_lu')])      # (nodes of up to 11 cameras: LU nodes; a band of 12 beside the border: LU down the band)
+def test_band_plus_border_system_that_is_not_positive_definite_is_solved_like_the_reference_lu(be, L, kind):
     """The reference solves its reduced system by LU (numpy.linalg.solve, bundle_adjuster.py:302-305) - also one that is not positive
-    definite.  A NEGATIVE damping makes such a system (indefinite, far from singular) on a scene with loop closures, where the
-    device solves band + border by Cholesky only: the C layer reports it (*info > 0, like every Cholesky solver), the Python host
-    then takes the system to numpy.linalg.solve - the reference's own call - and hands the solution back (ba_set_solution), so that
-    the back-substitution and the update run on the device as after any other solve."""
+    definite.  A NEGATIVE damping makes such a system (indefinite, far from singular) on a scene with loop closures: the Cholesky
+    form of band + border reports it, and the device solves it again with LU in every place of the block elimination (round 6,
+    csrc/ba_border.hip border_solve_lu: the columns of C and b1 through the band's LU solver one by one, the border's Schur
+    complement by Gaussian elimination with partial pivoting) - rounds 5's host LU (the whole matrix over PCIe to
+    numpy.linalg.solve) is gone.  Option solver = lu goes there directly (what the time-out fallback of solve_reduced asks for)."""
     nc, nt = 120, 3000
-    s = _loop_scene(nc, nt, 8, [(5, 70), (20, 95), (33, 101)], 2)
+    s = _loop_scene(nc, nt, L, [(5, 70), (20, 95), (33, 101)], 2)
     nt = len(s['X0'])
     flags = default_flags(nc, nt)
     a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
     load_problem(be, *a, *flags, O.Sensor.gaussian(1.))
-    assert be.problem_info()['border_cameras'] > 0
+    assert be.problem_info()['border_cameras'] > 0 and be.half_bandwidth == L - 1
     be.linearize(0)
     be.schur(0, -.6, 1e-5)
     S, b = be.get_reduced()
@@ -1181,11 +1183,16 @@ def test_band_plus_border_system_that_is_not_positive_definite_is_solved_like_th
             be.solve_reduced(mask)
         be.set_option('device_lu', 1)
         be.solve_reduced(mask)
-        assert be.last_solve_kind == 'host_lu' and be.last_solve_path == 'lu'
+        assert be.last_solve_kind == kind and be.last_solve_path == 'lu'
         x = be.get_solution().reshape(-1)
         keep = np.arange(n) if mask is None else np.nonzero(mask)[0]
         ref = np.linalg.solve(A[np.ix_(keep, keep)], b.reshape(-1)[keep])
-        close(x[keep], ref, 1e-12)
+        close(x[keep], ref, 1e-10)
+        be.set_option('solver', 'lu')                                                # straight to the LU form (the time-out fallback's request)
+        be.solve_reduced(mask)
+        assert be.last_solve_kind == kind
+        close(be.get_solution().reshape(-1)[keep], ref, 1e-10)
+        be.set_option('solver', 'auto')
         assert mask is None or np.all(x[mask == 0] == 0)
         dP = be.backsubstitute(0)
         assert np.all(np.isfinite(dP))

@@ -1016,67 +1016,43 @@ def test_bench_headline_of_a_full_record_is_short_and_keeps_the_contract():
     assert bench.headline({'error': 'a rank gave up'}) == {'error': 'a rank gave up'}
 
 
-def test_a_timed_out_solve_of_a_bordered_system_falls_back_to_the_host_lu():
-    """Round-5 ADVICE: the time-out fallback of HipBackend.solve_reduced set option solver = lu and solved again - which
-    ba_solve_reduced refuses for a problem with border cameras (BA_ERR_STATE): a time-out of the one-launch cyclic reduction on a
-    bordered scene aborted the optimisation.  Now such a system goes to the host LU (the reference's own numpy.linalg.solve,
-    bundle_adjuster.py:302-305); the C library is never asked for solver = lu on it.  No GPU: the C library is a double that
-    injects the time-out status."""
+def test_a_timed_out_solve_falls_back_to_the_lu_solver_with_or_without_a_border():
+    """Round-5 ADVICE: the time-out fallback of HipBackend.solve_reduced sets option solver = lu and solves again - which
+    ba_solve_reduced used to refuse for a problem with border cameras (BA_ERR_STATE: a time-out of the one-launch cyclic reduction
+    on a bordered scene aborted the optimisation).  Since round 6 the C library solves band + border by LU too (border_solve_lu,
+    tests/test_gpu_configs.py), so the fallback is ONE path: warn, solver = lu, solve, the caller's option back - and no host
+    solve anywhere.  No GPU: the C library is a double that injects the time-out status."""
     import ctypes as C
     from pysfm_amd import backend as B
     from pysfm_amd._capi import SOLVE_TIMED_OUT
-    rs = np.random.RandomState(3)
-    nco = 4
-    n = 6 * nco
-    M = rs.randn(n, n)
-    A = M @ M.T + n * np.eye(n)
-    rhs = rs.randn(n)
     calls = []
 
     class Lib(object):
+        def __init__(self):
+            self.solver = b'auto'
+
         def ba_solve_reduced(self, h, mask, info):
-            calls.append('solve')
-            info._obj.value = SOLVE_TIMED_OUT
+            calls.append(('solve', self.solver))
+            info._obj.value = SOLVE_TIMED_OUT if self.solver != b'lu' else 0
             return 0
 
         def ba_set_option(self, h, name, value):
             calls.append(('option', name, value))
-            assert not (name == b'solver' and value == b'lu'), 'solver = lu on a bordered problem: ba_solve_reduced returns BA_ERR_STATE'
+            if name == b'solver':
+                self.solver = value
             return 0
 
         def ba_last_solve_kind(self, h):
-            return 1
+            return 5
 
-        def ba_set_solution(self, h, dC):
-            calls.append('set_solution')
-            got.append(np.ctypeslib.as_array(C.cast(dC, C.POINTER(C.c_double)), (n,)).copy())
-            return 0
-
-    got = []
-    be = B.HipBackend.__new__(B.HipBackend)
-    be._lib, be._h, be.nco, be.device_lu, be._options = Lib(), None, nco, True, {}
-    be.problem_info = lambda: {'border_cameras': 2}
-    be.get_reduced = lambda: (A.reshape(nco, 6, nco, 6).transpose(0, 2, 1, 3).copy(), rhs.reshape(nco, 6).copy())
-    be._check = lambda rc: None
-    for mask in (None, (np.arange(n) % 5 != 1).astype(np.uint8)):
-        del calls[:], got[:]
+    for border in (0, 3):
+        del calls[:]
+        be = B.HipBackend.__new__(B.HipBackend)
+        be._lib, be._h, be.nco, be.device_lu, be._options = Lib(), None, 4, True, {}
+        be.problem_info = lambda: {'border_cameras': border}
+        be._check = lambda rc: None
         with pytest.warns(RuntimeWarning, match='timed out'):
-            be.solve_reduced(mask)
-        assert calls == ['solve', 'set_solution'] and be.last_solve_kind == 'host_lu'
-        keep = np.ones(n, bool) if mask is None else mask.astype(bool)
-        ref = np.zeros(n)
-        ref[keep] = np.linalg.solve(A[np.ix_(keep, keep)], rhs[keep])
-        assert np.array_equal(got[0], ref)
-    # a border too large for the host (or a singular matrix): the trial is lost like an ill-conditioned one, not the optimisation
-    be.HOST_LU_MAX_UNKNOWNS = 8
-    with pytest.warns(RuntimeWarning, match='timed out'):
-        with pytest.raises(B.ReducedSystemSingular):
             be.solve_reduced(None)
-    # without a border the old path stands: solver = lu, solve again, the caller's option back
-    be.problem_info = lambda: {'border_cameras': 0}
-    del calls[:]
-    Lib.ba_set_option = lambda self, h, name, value: calls.append(('option', name, value)) or 0
-    with pytest.warns(RuntimeWarning, match='timed out'):
-        with pytest.raises(B.ReducedSystemSingular):
-            be.solve_reduced(None)
-    assert calls == ['solve', ('option', b'solver', b'lu'), 'solve', ('option', b'solver', b'auto')]
+        assert calls == [('solve', b'auto'), ('option', b'solver', b'lu'), ('solve', b'lu'), ('option', b'solver', b'auto')]
+        assert be.last_solve_kind == 'bcr_lu' and be.last_solve_path == 'lu'
+    assert not hasattr(B.HipBackend, '_host_lu_of_bordered_system')
