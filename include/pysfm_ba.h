@@ -133,9 +133,8 @@ int ba_debug_poison(ba_handle* h);
  * others (pysfm_amd/csrc/ba_border.h): ba_reduced_layout then describes B (rows of the border cameras unused), ba_get_reduced /
  * ba_get_solution return the full system / solution as always.  The layout with the lowest modelled solve cost among {caller's
  * order, Cuthill-McKee order} x {as it is, with a border} is taken (BA_INFO_BORDER_CAMERAS, BA_INFO_HALF_BANDWIDTH say which).
- * A bordered system that is not positive definite is reported through *info of the solve (the device's LU solvers do not know the
- * border; the Python host then solves ba_get_reduced's arrays with numpy.linalg.solve - the reference's own call - and hands the
- * solution back through ba_set_solution, up to 16000 unknowns).
+ * A bordered system that is not positive definite is solved again by LU like any other (the border's columns through the band's LU
+ * solver one by one, the border system by Gaussian elimination with partial pivoting: BA_SOLVE_BCR_LU / BA_SOLVE_BAND_LU).
  *   obs_cam[nobs], obs_pt[nobs]  positions;  obs_z[nobs*2] measurements
  *   K[9]                         calibration (general 3x3)
  *   cam_opt_pos[nc]              position in optim_camera_ids, or -1 (frozen)
