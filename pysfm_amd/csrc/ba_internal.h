@@ -259,6 +259,9 @@ struct ba_handle {
     DevBuf<int> rowptr, col;
     DevBuf<long long> blk;              // block index in the band: lo (hb + 1) + (hi - lo)
     DevBuf<long long> ublk;             // ... of the upper triangle's blocks alone (what the reductions write)
+    DevBuf<int> bptr;                   // k_schur_blocks: the upper blocks' lists of observation pairs, [upper + 1] offsets into ...
+    DevBuf<int2> pairs;                 // ... (observation of the camera at the lower position, of the camera at the higher position)
+    bool pairs_built = false;
     bool band_clean = false;            // every block of the band outside the pattern is zero (one full initialisation, nothing scribbled since)
     DevBuf<double> minv, r, z, q, p[2], part;
     DevBuf<PcgStateRaw> state;
@@ -472,6 +475,7 @@ int solve_dense_chol(ba_handle* h, const unsigned char* dmask);
 int solve_pcg(ba_handle* h, const unsigned char* dmask);          // conjugate gradients over the blocks the tracks define (ba_pcg.hip)
 bool sparse_layout(ba_handle* h);                                 // a wide band of mostly structural zeros: the pattern-driven initialisation and solver apply
 int launch_schur_init_sparse(ba_handle* h, double damping, int use_hcc);
+int launch_schur_blocks(ba_handle* h, int p);                     // the reduction block by block over the pattern's pair lists (k_schur_blocks)
 double pcg_band_fill(ba_handle* h);                               // fraction of the band's blocks that can be non-zero (builds the pattern)
 int solve_band_lu(ba_handle* h, const unsigned char* dmask, int ncams = -1, const double* rhs = nullptr);      // LU with partial pivoting, any band width (ba_band_lu.h)
 // k_bcr_assemble (ba_bcr.h): band (+ mask) -> D, U, f of the nodes of cb cameras; clears the status word

@@ -56,6 +56,63 @@ int pcg_build_pattern(ba_handle* h) {
   }
   g.nnz = (long long)col.size();
   g.upper = upper;
+  // ---- the upper blocks' lists of observation pairs (k_schur_blocks): block (i, j >= i) <- (observation of the camera at i, of the
+  // camera at j) for every point both see.  Two passes over the points: count, fill.  Not built beyond 64 M pairs (0.5 GB; the
+  // reduction then stays with k_schur_pairs).
+  g.pairs_built = false;
+  {
+    std::vector<int> ufirst((size_t)nco + 1, 0);             // index of row i's first upper block in ublk
+    {
+      long long u = 0;
+      for (int i = 0; i < nco; ++i) {
+        ufirst[i] = (int)u;
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) u += col[e] >= i;
+      }
+      ufirst[nco] = (int)u;
+    }
+    auto block_of = [&](int i, int j) {                      // i <= j: rank of j among row i's columns >= i
+      const int* b0 = col.data() + rowptr[i];
+      const int* b1 = col.data() + rowptr[i + 1];
+      const int* lo = std::lower_bound(b0, b1, i);
+      const int* at = std::lower_bound(lo, b1, j);
+      return ufirst[i] + (int)(at - lo);
+    };
+    std::vector<int> bptr((size_t)upper + 1, 0);
+    std::vector<std::pair<int, int>> po;                      // (position, observation) of a point's optimised cameras
+    long long total = 0;
+    for (int pass = 0; pass < 2 && total <= (64ll << 20); ++pass) {
+      std::vector<int2> pr;
+      std::vector<int> fill;
+      if (pass == 1) {
+        for (long long u = 0, s = 0; u <= upper; ++u) { const int c = u < upper ? bptr[u] : 0; bptr[u] = (int)s; s += c; }
+        pr.resize((size_t)total);
+        fill.assign(bptr.begin(), bptr.end() - 1);
+      }
+      for (int k = 0; k < h->nt; ++k) {
+        po.clear();
+        for (int n = h->h_off[k]; n < h->h_off[k + 1]; ++n) {
+          const int c = cam[n];
+          const int q = c >= 0 && c < h->nc ? h->h_cam_opt_pos[c] : -1;
+          if (q >= 0) po.push_back({q, n});
+        }
+        for (size_t a = 0; a < po.size(); ++a)
+          for (size_t b = 0; b < po.size(); ++b) {
+            if (po[a].first > po[b].first || (po[a].first == po[b].first && a != b)) continue;      // (upper triangle; the diagonal: every observation with itself)
+            const int u = block_of(po[a].first, po[b].first);
+            if (pass == 0) { ++bptr[u]; ++total; }
+            else pr[(size_t)fill[u]++] = int2{po[a].second, po[b].second};
+          }
+      }
+      if (pass == 1) {
+        HIPCHECK(h, g.bptr.resize(bptr.size()));
+        HIPCHECK(h, g.pairs.resize(std::max<size_t>(1, pr.size())));
+        HIPCHECK(h, hipMemcpyAsync(g.bptr.p, bptr.data(), bptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (!pr.empty()) HIPCHECK(h, hipMemcpyAsync(g.pairs.p, pr.data(), pr.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));        // (the host vectors go out of scope)
+        g.pairs_built = true;
+      }
+    }
+  }
   HIPCHECK(h, g.rowptr.resize(rowptr.size()));
   HIPCHECK(h, g.col.resize(std::max<size_t>(1, col.size())));
   HIPCHECK(h, g.blk.resize(std::max<size_t>(1, blk.size())));
@@ -94,6 +151,19 @@ int launch_schur_init_sparse(ba_handle* h, double damping, int use_hcc) {
   const long long n = g.upper * 36 + (long long)h->nco * 6;
   hipLaunchKernelGGL(k_schur_init_blocks, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, g.upper, g.ublk.p, h->nco, h->hb + 1, h->opt_cam.p,
                      h->HCC.p, h->bC.p, damping, h->S, h->b, use_hcc);
+  HIPCHECK(h, hipGetLastError());
+  return BA_OK;
+}
+
+int launch_schur_blocks(ba_handle* h, int p) {
+  auto& g = h->pcg;
+  const unsigned grid = blocks_for(g.upper * kSbLanes);
+  if (h->sensor.kind == SENSOR_TABLE)
+    hipLaunchKernelGGL(k_schur_blocks<true>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem_band(h), h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.upper,
+                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b);
+  else
+    hipLaunchKernelGGL(k_schur_blocks<false>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem_band(h), h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.upper,
+                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b);
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
 }

@@ -1064,6 +1064,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->lin_reused = 0;
   h->refined = 0;
   h->pcg.built = false;
+  h->pcg.pairs_built = false;
   h->pcg.band_clean = false;
   int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
   if (rc != BA_OK) return rc;

@@ -170,6 +170,11 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     else
       hipLaunchKernelGGL(k_schur_groups<2>, dim3(h->ngchunks), dim3(kGroupBlock), lds, h->stream, dev_problem_band(h), h->cams[p].p,
                          h->X[p].p, h->groups.p, h->gchunks.p, h->schur_wn, h->HPPinv.p, h->bP.p, h->S, h->b);
+  } else if (kern == KERN_PAIRS && !fuse_cam && sparse_layout(h) && h->pcg.pairs_built) {
+    // a scene without a band: every block of the pattern sums its own list of observation pairs (k_schur_blocks, ba_pcg.h) - no atomics
+    ScopedTimer tm(h, BA_K_SCHUR_PAIRS);
+    rc = launch_schur_blocks(h, p);
+    if (rc != BA_OK) return rc;
   } else if (h->nunits > 0) {
     rc = ensure_pair_units(h);                          // (the pair kernel's work list is built on first use)
     if (rc != BA_OK) return rc;
