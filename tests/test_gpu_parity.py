@@ -1727,3 +1727,28 @@ def test_a_caller_defined_robustifier_runs_on_the_device(be):
     close(out.reconstruction, ref['X'], 1e-6)
     assert ba.costs[-1] < ba.costs[0]
     ba.backend.close()
+
+
+def test_a_caller_defined_robustifier_on_an_unordered_collection(be):
+    """The table sensor model through the sparse path's kernels (k_schur_blocks<TABLE>, conjugate gradients): a Geman-McClure model
+    defined in the tests on a 150-camera collection - S, b, dC against the oracle driven by the same Python object."""
+    from conftest import GemanMcClure
+    from pysfm_amd import sensor_model
+    from pysfm_amd import synthetic_data as sd
+    m = GemanMcClure(.05)
+    nc, nt = 150, 1500
+    s = sd.generate_collection_scene(nc, nt, partners=6, track_len=3)
+    flags = default_flags(nc, nt)
+    a = (s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    be.set_problem(nc, nt, s['obs_cam'], s['obs_pt'], s['obs_z'], s['K'], *flags)
+    be.set_sensor(*sensor_model.device_params_of(m))
+    be.set_params(0, s['R0'], s['t0'], s['X0'])
+    be.debug_poison()
+    be.set_option('solver', 'pcg')
+    mu, su, parts = O.compute_update(O.Sensor.from_model(m), *a, *flags, damping=1., return_parts=True)
+    info, cost = be.lm_trial(1., 1e-5, None)
+    assert info == 0 and be.last_solve_kind == 'pcg'
+    S, b = be.get_reduced()
+    close(S, parts['S'], 2e-9)                               # (the table interpolates the model's Jacobian to 3e-10)
+    close(b, parts['b'], 2e-9)
+    close(-be.get_solution(), mu, 1e-7)
