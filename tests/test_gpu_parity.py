@@ -1752,3 +1752,25 @@ def test_a_caller_defined_robustifier_on_an_unordered_collection(be):
     close(S, parts['S'], 2e-9)                               # (the table interpolates the model's Jacobian to 3e-10)
     close(b, parts['b'], 2e-9)
     close(-be.get_solution(), mu, 1e-7)
+
+
+@pytest.mark.parametrize('name,tag,damping', [('scene_5x50_gauss', 'l10_', 10.), ('scene_4x10_cauchy', 'l2_', 2.), ('scene_oleg_10x50', 'l10_', 10.)])
+@pytest.mark.parametrize('option', [('refine', '1'), ('solver', 'pcg')])
+def test_small_reference_scenes_through_the_round_6_solver_paths(be, name, tag, damping, option):
+    """The reference's own small scenes (one node of the cyclic reduction: the refinement's tree is its root alone; a handful of block
+    rows for the conjugate gradients) through the refinement step and through conjugate gradients, by option: dC and dP equal to the
+    REFERENCE's own (the golden vectors) to 1e-8."""
+    g = load_golden(name)
+    load_problem(be, *scene(g), g[tag + 'cam_opt_pos'], g[tag + 'pt_opt'].astype(np.uint8), sensor_of(g))
+    be.set_option(*option)
+    be.linearize(0)
+    be.schur(0, damping, 1e-5)
+    before = be.problem_info()['solves_refined']
+    be.solve_reduced(None)
+    if option[0] == 'refine':
+        assert be.last_solve_kind == 'bcr' and be.problem_info()['solves_refined'] == before + 1
+    else:
+        assert be.last_solve_kind == 'pcg' and be.pcg_info()['rel_residual'] <= 1e-12
+    close(be.get_solution(), g[tag + 'dC'], 1e-8)
+    dP = be.backsubstitute(0)
+    close(dP[g[tag + 'pt_opt'].astype(bool)], g[tag + 'dP'], 1e-8)
