@@ -1324,3 +1324,39 @@ def test_ranks_on_one_gpu_cameras_in_no_order(tmp_path, world):
         close(d['t'], t1, 1e-8)
         close(d['X'], X1, 1e-8)
     ba.backend.close()
+
+
+def test_camera_layout_of_the_device_views(be):
+    """Round-5 ADVICE: ba_reduced_device_ptrs / ba_bind_reduced_buffers expose the band in the library's INTERNAL camera order; since
+    round 6 ba_get_camera_layout hands out that order.  On a scene with renumbered cameras and loop closures: new_pos is a
+    permutation, the border cameras sit behind the band, and block (new_pos[p], new_pos[q]) of the device's band is block (p, q) of
+    the system ba_get_reduced returns in the caller's positions."""
+    nc, nt = 90, 2500
+    s, perm = cameras_renumbered(_loop_scene(nc, nt, 7, [(4, 60), (15, 77)], 1))
+    nt = len(s['X0'])
+    flags = default_flags(nc, nt)
+    load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], *flags, O.Sensor.gaussian(1.))
+    info = be.problem_info()
+    new_pos, band = be.camera_layout()
+    assert info['cameras_permuted'] == 1 and sorted(new_pos.tolist()) == list(range(be.nco))
+    assert band == be.nco - info['border_cameras'] and info['border_cameras'] > 0
+    be.linearize(0)
+    be.schur(0, 3., 1e-5)
+    S, b = be.get_reduced()
+    be.synchronize()
+    S_t, b_t = be.reduced_tensors()
+    hb1 = be.half_bandwidth + 1
+    Sb = S_t.cpu().numpy().reshape(be.nco, hb1, 6, 6)
+    bb = b_t.cpu().numpy().reshape(be.nco, 6)
+    inv = np.empty(be.nco, int)
+    inv[new_pos] = np.arange(be.nco)                      # internal position -> the caller's
+    for i in range(band):
+        np.testing.assert_array_equal(bb[i], b[inv[i]])
+        for d in range(hb1):
+            if i + d < band:
+                blk = S[inv[i], inv[i + d]]
+                got = Sb[i, d]
+                if d == 0:
+                    np.testing.assert_array_equal(np.triu(got), np.triu(blk))
+                else:
+                    np.testing.assert_array_equal(got, blk)
