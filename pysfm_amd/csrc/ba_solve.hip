@@ -493,8 +493,9 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   // a scene without a narrow band under any order (an unordered photo collection): conjugate gradients over the blocks the tracks
   // define (ba_pcg.h) - by option, or when the band is wide, mostly structural zeros, and large enough for a dense factorisation to hurt
   const bool pcg_forced = force == SOLVER_PCG;
-  const bool use_pcg = h->nco > 0 && (pcg_forced || (force == SOLVER_AUTO && !bcr_ok && !bcrw_ok && h->hb > kBcrwMaxHB && h->nco >= kPcgMinCams &&
-                                                     pcg_band_fill(h) <= kPcgMaxFill));
+  // (the list of blocks comes from THIS handle's tracks: a shard of a sharded adjuster sees only its own, the dense-visibility mode has no list)
+  REQUIRE(h, !pcg_forced || (!h->comm && !h->dense_mode), BA_ERR_STATE, "ba_solve_reduced: solver = pcg needs the whole scene on one handle (no communicator) and the sparse reductions (no dense-visibility mode)");
+  const bool use_pcg = h->nco > 0 && (pcg_forced || (force == SOLVER_AUTO && !bcr_ok && !bcrw_ok && sparse_layout(h)));
   if (use_pcg) use_big = false;
   const bool use_dense = !use_pcg && !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);

@@ -1433,6 +1433,23 @@ def test_one_launch_solve_repeats_itself_and_equals_the_per_level_launches(be, n
         assert be.last_solve_kind == 'bcr' and be.last_solve_path == 'band'
         x = be.get_solution()
         assert np.all(np.isfinite(x)) and np.max(np.abs(x - ref)) <= 1e-13 * np.max(np.abs(ref)), r
+    # ... and the refinement step behind it (round 6): k_bcr_refine hands vectors from workgroup to workgroup the same way - residual
+    # items, forward items up the tree, backward items down, slots marked by the solve's k_bcr_assemble.  Every third time from
+    # poisoned workspace; the corrected solutions agree with each other and with the plain solve.
+    be.set_option('refine', '1')
+    first = None
+    for r in range(reps // 2):
+        if r % 3 == 2:
+            be.debug_poison()
+            be.linearize(0)
+            be.schur(0, 10., 1e-5)
+        be.solve_reduced(None)
+        assert be.last_solve_kind == 'bcr'
+        x = be.get_solution()
+        assert np.all(np.isfinite(x)) and np.max(np.abs(x - ref)) <= 1e-12 * np.max(np.abs(ref)), r
+        first = x if first is None else first
+        assert np.max(np.abs(x - first)) <= 1e-13 * np.max(np.abs(ref)), r
+    assert be.problem_info()['solves_refined'] >= reps // 2
 
 
 @pytest.mark.parametrize('nc,nt,L,reps', [(600, 8000, 16, 120), (500, 6000, 22, 90), (2200, 20000, 15, 60)])
