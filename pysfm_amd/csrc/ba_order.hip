@@ -220,6 +220,10 @@ bool plan_camera_layout(int nco, const std::vector<int>& loff, const std::vector
     if (cands[c].cost < cands[best].cost * (1.0 - 1e-9)) best = c;
   if (best == 0) return false;
   const Cand& B = cands[best];
+  // a band that stays far beyond what any band solver takes and comes out less than a quarter narrower than the caller's (an
+  // unordered photo collection: no order has a band; its solver - conjugate gradients over the blocks the tracks define, ba_pcg.h -
+  // does not care about the order): not worth setting the problem up a second time
+  if (B.k == 0 && B.hb > kBcrwMaxHB && 4ll * B.hb > 3ll * cands[0].hb) return false;
   std::vector<int> inv((size_t)nco);
   for (int p = 0; p < nco; ++p) inv[B.pos[p]] = p;        // position in the candidate's order -> caller's position
   newpos.assign((size_t)nco, 0);

@@ -8,6 +8,8 @@
 // them.  Work lists of kernels that are not on the trial's path (k_camera_blocks, k_schur_pairs) are built on first use.
 #include "ba_internal.h"
 
+#include <chrono>
+
 #include "ba_setup_kernels.h"
 
 using namespace ba;
@@ -489,7 +491,8 @@ int ensure_plan(ba_handle* h) {
       if (phi[k] < 0) continue;
       if (is_long(k)) ++nlong; else shortspan = std::max(shortspan, phi[k] - plo[k] + 1);
     }
-    const bool hybrid = nlong > 0 && sorted_by_lo && nco > 0;
+    bool hybrid = nlong > 0 && sorted_by_lo && nco > 0;
+    const int maxspan_all = maxspan;
     struct SegTask { int qa, qb; std::vector<int> pts; };
     std::vector<SegTask> rect_tasks;
     if (hybrid) {
@@ -518,6 +521,20 @@ int ensure_plan(ba_handle* h) {
             rect_tasks[jt->second].pts.push_back(k);
           }
         }
+      }
+      // Long tracks that are SCATTERED rather than long (an unordered photo collection: three cameras anywhere among five thousand)
+      // touch pairs of segments all over the matrix with one or two observations each: the segment kernel would linearise table
+      // rows of 64 entries that are 97 % empty, behind a table of 300 MB that takes 240 ms of every ba_set_problem to build (5000
+      // cameras).  When the long tracks fill less than a tenth of the positions they span, they are left to the general kernels
+      // (k_schur_pairs, or k_schur_blocks on the sparse path) and no table is built.
+      long long filled = 0, spanned = 0;
+      for (int k = 0; k < nt; ++k)
+        if (is_long(k)) { filled += off[(size_t)k + 1] - off[k]; spanned += phi[k] - plo[k] + 1; }
+      if (10 * filled < spanned) {
+        rect_tasks.clear();
+        hybrid = false;
+        nlong_points = 0;
+        maxspan = maxspan_all;
       }
     }
     if ((maxspan >= 1 || hybrid) && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
@@ -1066,15 +1083,23 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->pcg.built = false;
   h->pcg.pairs_built = false;
   h->pcg.band_clean = false;
+  // (option solve_trace: where the set-up's time goes, on stderr)
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (h->opt.solve_trace) fprintf(stderr, "[ba_set_problem] %s: %.2f ms since the call\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
   int rc = set_problem_impl(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
   if (rc != BA_OK) return rc;
+  lap("internal order of tracks and observations (set_problem_impl)");
   rc = choose_camera_order(h, nc, nt, nobs, obs_cam, obs_pt, obs_z, K, cam_opt_pos, pt_opt);
   if (rc != BA_OK) { h->have_problem = false; return rc; }
+  lap("layout of the optimised cameras (choose_camera_order)");
   // The work lists of the general kernels: at once - or, for a problem the resident loop takes whole (ba_resident.h), when a
   // general kernel first asks for them (ensure_plan): the sliding-window caller sets a problem per frame and never does
   if (!resident_shape(h)) {
     rc = ensure_plan(h);
     if (rc != BA_OK) { h->have_problem = false; return rc; }
+    lap("work lists of the general kernels (ensure_plan)");
   }
   return BA_OK;
 }
