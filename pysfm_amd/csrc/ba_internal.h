@@ -263,6 +263,8 @@ struct ba_handle {
     DevBuf<int2> pairs;                 // ... (observation of the camera at the lower position, of the camera at the higher position)
     bool pairs_built = false;
     bool band_clean = false;            // every block of the band outside the pattern is zero (one full initialisation, nothing scribbled since)
+    DevBuf<int> cidx;                   // ... and in the packed array of a solve: the (upper) block of every entry of the full pattern
+    DevBuf<double> packed;              // the pattern's upper blocks, contiguous (k_pcg_gather, once per solve)
     DevBuf<double> minv, r, z, q, p[2], part;
     DevBuf<PcgStateRaw> state;
     PcgStateRaw* host_state = nullptr;  // pinned

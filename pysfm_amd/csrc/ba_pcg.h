@@ -156,8 +156,10 @@ __global__ __launch_bounds__(kBlock) void k_pcg_start(int n, const double* __res
 
 // Iteration k, first half: beta from the partial sums of the two latest r.z, p = z + beta p_old for the rows this workgroup owns,
 // q = S p for them, the partial sum of p.q.  nparts = partials of the update kernel's grid.
-__global__ __launch_bounds__(kBlock) void k_pcg_product(int k, int nco, int hb1, const double* __restrict__ S, const int* __restrict__ rowptr,
-                                                        const int* __restrict__ col, const long long* __restrict__ blk,
+template <int WPR>      // wavefronts per block row: 1 (four rows a workgroup) or 4 (a workgroup a row: rows of dozens of blocks - 17 KB a row and iteration -
+                        // are a chain of eight dependent trips to memory for one wavefront, two for four)
+__global__ __launch_bounds__(kBlock) void k_pcg_product(int k, int nco, int hb1, const double* __restrict__ S /* the packed blocks */, const int* __restrict__ rowptr,
+                                                        const int* __restrict__ col, const int* __restrict__ blk /* index of the (upper) block in the packed array */,
                                                         const double* __restrict__ z, const double* __restrict__ p_old,
                                                         double* __restrict__ p_new, double* __restrict__ q,
                                                         const double* __restrict__ part_rz /*[2][nparts]*/, const double* __restrict__ part_rr /*[2][nparts]*/,
@@ -182,31 +184,64 @@ __global__ __launch_bounds__(kBlock) void k_pcg_product(int k, int nco, int hb1,
     const double rz_old = pcg_block_sum(part_rz + (size_t)((k - 1) & 1) * nparts, nparts, lds);
     beta = rz_new / rz_old;
   }
+  __shared__ double wsum[kBlock / 64][8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * kPcgRowsPerBlock + wave;
-  const int a = lane & 7, ks = lane >> 3;
-  const int aa = a < 6 ? a : 5;
-  double acc = 0.0;
+  constexpr int RPB = kPcgRowsPerBlock / WPR;            // rows per workgroup
+  const int i = blockIdx.x * RPB + wave / WPR, sub = wave % WPR;
+  // lane = (column c of a block, one of eight blocks in flight): a lane fetches ITS entry of the neighbour's p and the six entries of
+  // its column of the block - eight loads a block where a lane per row needed eighteen (the six entries of p twice over: z and
+  // p_old): the kernel is bound by the number of load instructions (47 -> 2x us at 5000 cameras), not by the 87 MB they move
+  const int c = lane & 7, ks = lane >> 3;
+  const int cc = c < 6 ? c : 5;
+  const bool active = c < 6;
+  double y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (i < nco) {
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
-    for (int e = e0 + ks; e < e1; e += 8) {
-      const int j = col[e];
-      const double* B = S + blk[e] * 36;
-      const bool flip = j < i, diag = j == i;
+    // two blocks a lane and round: the indices of both first, then all their loads, then the arithmetic - a round is two dependent
+    // trips to memory, and a row of 60 blocks over four wavefronts is ONE round
+    for (int e = e0 + 8 * sub + ks; e < e1; e += 16 * WPR) {
+      const int eb = e + 8 * WPR;
+      const bool two = eb < e1;
+      const int ja = col[e], jb = two ? col[eb] : ja;
+      const double* Ba = S + (size_t)blk[e] * 36;
+      const double* Bb = S + (size_t)(two ? blk[eb] : blk[e]) * 36;
+      double pa = z[6 * (size_t)ja + cc], pb = z[6 * (size_t)jb + cc];
+      double oa = 0.0, ob = 0.0;
+      if (k > 0) { oa = p_old[6 * (size_t)ja + cc]; ob = p_old[6 * (size_t)jb + cc]; }
+      double sa[6], sb[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const bool tr = flip || (diag && aa > c);          // (blocks are kept for i <= j, the diagonal ones by their upper triangle)
-        const double sv = B[tr ? c * 6 + aa : aa * 6 + c];
-        const double pv = z[6 * (size_t)j + c] + (k > 0 ? beta * p_old[6 * (size_t)j + c] : 0.0);
-        acc += sv * pv;
+      for (int a = 0; a < 6; ++a) {
+        // entry (a, c) of S_ij: stored as (a, c) of block (i, j) when i < j, as (c, a) of block (j, i) when j < i; the diagonal
+        // blocks by their upper triangle
+        const bool tra = ja < i || (ja == i && a > cc), trb = jb < i || (jb == i && a > cc);
+        sa[a] = Ba[tra ? cc * 6 + a : a * 6 + cc];
+        sb[a] = Bb[trb ? cc * 6 + a : a * 6 + cc];
       }
+      pa = active ? pa + beta * oa : 0.0;
+      pb = (active && two) ? pb + beta * ob : 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) y[a] += sa[a] * pa + sb[a] * pb;
     }
   }
-  acc += __shfl_xor(acc, 8, 64);
-  acc += __shfl_xor(acc, 16, 64);
-  acc += __shfl_xor(acc, 32, 64);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double v = y[a];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    y[a] = v;
+  }
+  double acc = lane == 0 ? y[0] : lane == 1 ? y[1] : lane == 2 ? y[2] : lane == 3 ? y[3] : lane == 4 ? y[4] : y[5];      // lane a < 6: entry a of the row
+  if (WPR > 1) {
+    if (lane < 8) wsum[wave][lane] = acc;
+    __syncthreads();
+    if (sub == 0 && lane < 8) {
+      acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < WPR; ++w) acc += wsum[wave + w][lane];
+    }
+  }
   double pq = 0.0;
-  if (i < nco && lane < 6) {
+  if (i < nco && sub == 0 && lane < 6) {
     const size_t u = 6 * (size_t)i + lane;
     const double pv = z[u] + (k > 0 ? beta * p_old[u] : 0.0);
     p_new[u] = pv;
@@ -267,6 +302,15 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(int k, int n, const unsig
 }
 
 __global__ void k_pcg_set_status(int* info, int v) { *info = v; }
+
+// The blocks of the pattern's upper triangle out of the band into ONE contiguous array, once per solve: in the band they lie 288 bytes
+// here, 288 bytes there over gigabytes (5000 cameras: 7 GB) - every block of every product a page of its own; packed they are 43 MB
+// that stay in the Infinity Cache from iteration to iteration.
+__global__ __launch_bounds__(kBlock) void k_pcg_gather(long long nblocks, const long long* __restrict__ ublk, const double* __restrict__ S,
+                                                       double* __restrict__ Sc) {
+  const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (t < nblocks * 36) Sc[t] = S[ublk[t / 36] * 36 + t % 36];
+}
 
 // schur_init_body of ba_schur_kernels.h over a LIST of blocks (the upper triangle of the pattern) instead of the whole band
 __global__ __launch_bounds__(kBlock) void k_schur_init_blocks(long long nblocks, const long long* __restrict__ ublk, int nco, int hb1,

@@ -77,6 +77,15 @@ int pcg_build_pattern(ba_handle* h) {
       const int* at = std::lower_bound(lo, b1, j);
       return ufirst[i] + (int)(at - lo);
     };
+    {
+      // every entry of the full pattern -> its (upper) block in the packed array of a solve (k_pcg_gather)
+      std::vector<int> cidx(col.size());
+      for (int i = 0; i < nco; ++i)
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) cidx[e] = col[e] >= i ? block_of(i, col[e]) : block_of(col[e], i);
+      HIPCHECK(h, g.cidx.resize(std::max<size_t>(1, cidx.size())));
+      if (!cidx.empty()) HIPCHECK(h, hipMemcpyAsync(g.cidx.p, cidx.data(), cidx.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      HIPCHECK(h, hipStreamSynchronize(h->stream));
+    }
     std::vector<int> bptr((size_t)upper + 1, 0);
     std::vector<std::pair<int, int>> po;                      // (position, observation) of a point's optimised cameras
     long long total = 0;
@@ -176,11 +185,14 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
   if (int rc = pcg_build_pattern(h); rc != BA_OK) return rc;
   const int nco = h->nco, n = 6 * nco, hb1 = h->hb + 1;
   const int nparts = (n + kPcgUnknownsPerBlock - 1) / kPcgUnknownsPerBlock;
-  const int nprod = (nco + kPcgRowsPerBlock - 1) / kPcgRowsPerBlock;
+  // a workgroup per block row where the rows hold dozens of blocks (a chain of dependent trips to memory per eight of them), four rows a workgroup otherwise
+  const bool wide_rows = g.nnz >= 24ll * nco;
+  const int nprod = wide_rows ? nco : (nco + kPcgRowsPerBlock - 1) / kPcgRowsPerBlock;
   HIPCHECK(h, g.minv.resize((size_t)nco * 36));
   HIPCHECK(h, g.r.resize((size_t)n)); HIPCHECK(h, g.z.resize((size_t)n)); HIPCHECK(h, g.q.resize((size_t)n));
   HIPCHECK(h, g.p[0].resize((size_t)n)); HIPCHECK(h, g.p[1].resize((size_t)n));
   HIPCHECK(h, g.part.resize((size_t)4 * nparts + nprod));
+  HIPCHECK(h, g.packed.resize(std::max<size_t>(1, (size_t)g.upper * 36)));
   HIPCHECK(h, g.state.resize(1));
   if (!g.host_state) HIPCHECK(h, hipHostMalloc((void**)&g.host_state, sizeof(PcgStateRaw), hipHostMallocDefault));
   double* part_rz = g.part.p, *part_rr = g.part.p + (size_t)2 * nparts, *part_pq = g.part.p + (size_t)4 * nparts;
@@ -189,6 +201,7 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
   ScopedTimer tm(h, BA_K_PCG_SOLVE);
   HIPCHECK(h, hipMemsetAsync(h->flags.p + 1, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_pcg_minv, dim3(blocks_for(nco)), dim3(kBlock), 0, h->stream, nco, hb1, h->S, dmask, g.minv.p, h->flags.p + 1);
+  hipLaunchKernelGGL(k_pcg_gather, dim3(blocks_for(g.upper * 36)), dim3(kBlock), 0, h->stream, g.upper, g.ublk.p, h->S, g.packed.p);
   hipLaunchKernelGGL(k_pcg_start, dim3(nparts), dim3(kBlock), 0, h->stream, n, h->b, dmask, g.minv.p, h->dC.p, g.r.p, g.z.p, part_rz, part_rr, reinterpret_cast<PcgState*>(g.state.p));
   int k = 0, status = 0;
   double rr_checked = -1.0;
@@ -198,8 +211,12 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
     // (short batches first: a launch after convergence costs ~3 us, a look at the state a synchronisation - damped systems converge in 6 .. 30 iterations)
     const int batch = std::min(std::min(h->opt.pcg_batch, k < 8 ? 8 : k), max_iter - k);
     for (int e = k + batch; k < e; ++k) {
-      hipLaunchKernelGGL(k_pcg_product, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, h->S, g.rowptr.p, g.col.p, g.blk.p, g.z.p,
-                         g.p[k & 1].p, g.p[(k + 1) & 1].p, g.q.p, part_rz, part_rr, nparts, tol2, part_pq, reinterpret_cast<PcgState*>(g.state.p));
+      if (wide_rows)
+        hipLaunchKernelGGL(k_pcg_product<4>, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, g.packed.p, g.rowptr.p, g.col.p, g.cidx.p, g.z.p,
+                           g.p[k & 1].p, g.p[(k + 1) & 1].p, g.q.p, part_rz, part_rr, nparts, tol2, part_pq, reinterpret_cast<PcgState*>(g.state.p));
+      else
+        hipLaunchKernelGGL(k_pcg_product<1>, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, g.packed.p, g.rowptr.p, g.col.p, g.cidx.p, g.z.p,
+                           g.p[k & 1].p, g.p[(k + 1) & 1].p, g.q.p, part_rz, part_rr, nparts, tol2, part_pq, reinterpret_cast<PcgState*>(g.state.p));
       hipLaunchKernelGGL(k_pcg_update, dim3(nparts), dim3(kBlock), 0, h->stream, k, n, dmask, g.minv.p, g.p[(k + 1) & 1].p, g.q.p, h->dC.p,
                          g.r.p, g.z.p, part_rz, part_rr, nparts, part_pq, nprod, tol2, reinterpret_cast<PcgState*>(g.state.p));
     }
