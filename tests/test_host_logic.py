@@ -980,6 +980,26 @@ def test_camera_layout_leaves_a_sequence_alone_and_cuts_a_ring_once():
     assert side.all() or (new[np.r_[nco - 4:nco]] >= n1).all()
 
 
+def test_camera_layout_leaves_an_unordered_collection_as_it_comes():
+    """A photo collection (every camera shares tracks with cameras drawn at random from all the others) has no band under any order:
+    Cuthill-McKee comes out a few per cent narrower than the caller's numbering, far beyond every band solver - not worth setting
+    the problem up a second time (the solver of such scenes, conjugate gradients over the blocks the tracks define, does not care
+    about the order).  The planner keeps the caller's order; a renumbered SEQUENCE is still found."""
+    from pysfm_amd import synthetic_data as sd
+    nco = 600
+    s = sd.generate_collection_scene(nco + 1, 12000, partners=8, track_len=3)
+    cams = s['obs_cam'].reshape(-1, 3)
+    lists = [np.sort(c[c > 0]) - 1 for c in cams]                 # optimised positions (camera 0 is the gauge camera)
+    lists = [l for l in lists if len(l) >= 2]
+    new, n1, hb = _plan_layout(nco, lists, [1] * len(lists))
+    assert n1 == nco and np.array_equal(new, np.arange(nco)) and hb > nco // 2, (n1, hb)
+    rs = np.random.RandomState(1)
+    seq, pts = _sequence_lists(nco, 10, 60, rs)
+    perm = rs.permutation(nco)
+    new, n1, hb = _plan_layout(nco, [perm[l] for l in seq], pts)
+    assert hb == 9 and n1 == nco and not np.array_equal(new, np.arange(nco))
+
+
 # ------------------------------------------------------------------ the bench line the driver parses
 def test_bench_headline_of_a_full_record_is_short_and_keeps_the_contract():
     """Round 5's last stdout line was the whole 31 KB record and the driver could not parse it.  `bench.headline` reduces a full
