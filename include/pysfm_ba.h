@@ -167,6 +167,7 @@ enum {
   BA_INFO_BORDER_CAMERAS,      /* cameras in the border of the reduced system (band + border, see ba_set_problem)          */
   BA_INFO_LINEARIZATIONS_REUSED, /* trials of ba_lm_trial since ba_set_problem that reused the linearisation of an unchanged current set */
   BA_INFO_SOLVES_REFINED,      /* reduced solves since ba_set_problem that took the step of iterative refinement (option refine) */
+  BA_INFO_PACKED_STORE,        /* 1: the reduced system is stored as the list of the blocks the tracks define, no band (scenes the sparse path takes whole; see ba_reduced_layout) */
   BA_INFO_COUNT
 };
 int ba_problem_info(ba_handle* h, int64_t* out, int32_t n);
@@ -255,7 +256,13 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond);
 /* Layout of the device-resident reduced system.  S is symmetric; only 6x6 blocks (i, j)
  * with i <= j <= i + hb can be non-zero, hb = widest spread of optimised-camera
  * positions inside one track (hb = nco-1 is a dense system).  Block (i, i+d) starts at
- * ((i*(hb+1) + d)*36 doubles; S_doubles = nco*(hb+1)*36.  b has nco*6 doubles. */
+ * ((i*(hb+1) + d)*36 doubles; S_doubles = nco*(hb+1)*36.  b has nco*6 doubles.
+ * PACKED STORE (BA_INFO_PACKED_STORE; option packed_store, default 1, read by ba_set_problem): a scene without a band under any
+ * camera order that the sparse path takes whole (BA_SOLVE_PCG: at least 1500 optimised cameras or solver = pcg set before
+ * ba_set_problem, at most a tenth of the band's blocks non-zero) keeps NO band: S is the list of the blocks its tracks define, block
+ * u at 36 u, S_doubles = 36 x (blocks of ba_pcg_info) - 43 MB instead of 7 GB at 5000 cameras.  half_bandwidth is still the spread
+ * of the camera order.  ba_get_reduced / ba_get_solution / the whole trial work as always; what needs a band refuses with
+ * BA_ERR_STATE: ba_flatten_reduced, the direct solvers (solver = dense | lu | ...), the dense-visibility mode, a communicator. */
 int ba_reduced_layout(ba_handle* h, int32_t* nco, int32_t* half_bandwidth, int64_t* S_doubles);
 /* S[nco*nco*36] laid out (nco,nco,6,6) and b[nco*6], expanded to the reference's dense
  * symmetric form (host) */

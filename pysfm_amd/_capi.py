@@ -24,7 +24,7 @@ KERNEL_IDS = ('cost', 'linearize', 'point_invert', 'schur_init', 'schur_pairs', 
 K_COUNT = len(KERNEL_IDS)
 INFO_KEYS = ('points_permuted', 'obs_permuted', 'groups', 'mfma_groups', 'point_groups', 'max_track_len',
              'half_bandwidth', 'schur_mfma', 'schur_groups', 'lds_window_rows', 'pair_units', 'schur_kernel',
-             'mfma_points_per_batch_cap', 'mfma_k_rows', 'cameras_permuted', 'caller_half_bandwidth', 'border_cameras', 'linearizations_reused', 'solves_refined')      # BA_INFO_*
+             'mfma_points_per_batch_cap', 'mfma_k_rows', 'cameras_permuted', 'caller_half_bandwidth', 'border_cameras', 'linearizations_reused', 'solves_refined', 'packed_store')      # BA_INFO_*
 SOLVE_KINDS = ('none', 'bcr', 'bcr_wide', 'band', 'dense_cholesky', 'bcr_lu', 'bcr_big', 'band_lu', 'pcg')
 SOLVE_TIMED_OUT = 0x7f000001            # BA_SOLVE_TIMED_OUT of include/pysfm_ba.h
 SOLVE_STALLED = 0x7f000002              # BA_SOLVE_STALLED: conjugate gradients out of iterations

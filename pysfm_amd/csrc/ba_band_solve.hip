@@ -38,6 +38,7 @@ extern "C" {
 int ba_flatten_reduced(ba_handle* h, const int32_t* keep, int32_t nkeep, void* A_dev, void* rhs_dev) {
   if (!h) return BA_ERR_INVALID_ARG;
   REQUIRE(h, h->have_schur, BA_ERR_STATE, "ba_flatten_reduced: call ba_schur first");
+  REQUIRE(h, !h->pcg.packed, BA_ERR_STATE, "ba_flatten_reduced: this problem's reduced system is stored as the list of its blocks (option packed_store = 0 before ba_set_problem keeps the band)");
   REQUIRE(h, nkeep >= 0 && (nkeep == 0 || (keep && A_dev && rhs_dev)), BA_ERR_INVALID_ARG, "ba_flatten_reduced: NULL argument");
   for (int i = 0; i < nkeep; ++i)
     if (keep[i] < 0 || keep[i] >= h->nco * 6) return h->fail(BA_ERR_INVALID_ARG, "ba_flatten_reduced: keep[%d] out of range", i);

@@ -108,6 +108,7 @@ int upload_rows(ba_handle* h, const int* dev_perm, const double* host, double* d
 
 // in-place sum over the shards of the band-stored [S | b] (contiguous), on the handle's stream
 int comm_allreduce_reduced(ba_handle* h) {
+  if (h->pcg.packed) return h->fail(BA_ERR_STATE, "the reduced system of this problem is stored as the list of ITS tracks' blocks: the shards of a sharded adjuster cannot add such lists up (set the communicator before ba_set_problem)");
   const size_t nS = reduced_doubles(h), nb = (size_t)h->nco * 6;
   if (nS + nb == 0) return BA_OK;
   if (h->b == h->S + nS) {                            // the usual case: one contiguous [S | b]
@@ -309,6 +310,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "resident_fault") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= -1 && c < 64; if (ok) h->opt.resident_fault = (int)c; }
   else if (n == "host_setup") ok = flag(h->opt.host_setup);
   else if (n == "camera_order") ok = choice({"auto", "off", "always"}, h->opt.camera_order);
+  else if (n == "packed_store") ok = flag(h->opt.packed_store);
   else if (n == "refine") ok = choice({"auto", "1", "0"}, h->opt.refine);
   else if (n == "refine_debug") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0 && c <= 7; if (ok) h->opt.refine_debug = (int)c; }
   else if (n == "border") ok = flag(h->opt.border);

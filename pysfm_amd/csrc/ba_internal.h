@@ -76,6 +76,7 @@ struct Options {
   bool reuse_linearization = true; // ba_lm_trial after a rejected trial: the point blocks of the unchanged current set are not formed again
   bool border_side_stream = true;  // the border's blocks and the preparation of its solve on a side stream beside the cyclic reduction (off: in line)
   bool border = true;              // ... and a border for the cameras at the far end of a few long-range tracks (ba_border.h)
+  bool packed_store = true;        // scenes the sparse path takes whole keep [S] as the list of the pattern's blocks, no band (0: the band of the camera order, as for every other scene)
   double pcg_tol = 1e-12;          // conjugate gradients (ba_pcg.h): converged at ||r|| <= pcg_tol ||b||
   int pcg_max_iter = 0;            // ... iteration budget (0: max(1000, min(20000, 4 nco)))
   int pcg_batch = 50;              // ... iterations enqueued between two looks at the state
@@ -262,9 +263,16 @@ struct ba_handle {
     DevBuf<int> bptr;                   // k_schur_blocks: the upper blocks' lists of observation pairs, [upper + 1] offsets into ...
     DevBuf<int2> pairs;                 // ... (observation of the camera at the lower position, of the camera at the higher position)
     bool pairs_built = false;
+    // PACKED: [S] holds the pattern's upper blocks ONLY, one after the other in the list's order (block u at 36 u) - no band at all
+    // (a band of 5000 cameras is 7 GB, of 30 000 it does not fit the device; the list is 43 MB and 260 MB).  Decided by ba_set_problem for
+    // scenes the sparse path takes whole (sparse_layout, pair lists built, no group kernel worth its while); the reductions, the
+    // initialisation, the conjugate gradients and ba_get_reduced follow the list, everything else that reads a band refuses.
+    bool packed = false;
+    DevBuf<int> udiag;                  // ... the list index of every camera's diagonal block
+    std::vector<long long> h_ublk;      // host copy of ublk (ba_get_reduced of a packed system)
     bool band_clean = false;            // every block of the band outside the pattern is zero (one full initialisation, nothing scribbled since)
     DevBuf<int> cidx;                   // ... and in the packed array of a solve: the (upper) block of every entry of the full pattern
-    DevBuf<double> packed;              // the pattern's upper blocks, contiguous (k_pcg_gather, once per solve)
+    DevBuf<double> packed_blocks;       // the pattern's upper blocks, contiguous (k_pcg_gather, once per solve; not needed when [S] is stored packed)
     DevBuf<double> minv, r, z, q, p[2], part;
     DevBuf<PcgStateRaw> state;
     PcgStateRaw* host_state = nullptr;  // pinned
@@ -413,7 +421,7 @@ inline unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1
 DevProblem dev_problem(const ba_handle* h);
 DevProblem dev_problem_band(const ba_handle* h);      // ... as the reductions into the band see it: border cameras are not optimised
 
-inline size_t reduced_doubles(const ba_handle* h) { return (size_t)h->nco * (h->hb + 1) * 36; }
+inline size_t reduced_doubles(const ba_handle* h) { return h->pcg.packed ? (size_t)h->pcg.upper * 36 : (size_t)h->nco * (h->hb + 1) * 36; }
 int ensure_reduced(ba_handle* h);
 
 // ---- RCCL, resolved at run time (ba_comm_load): the library does not link against it, it uses the one the

@@ -63,11 +63,12 @@ __device__ __forceinline__ void pcg_block_partial(double v, double* __restrict__
 
 // M^-1: inverses of the diagonal blocks (masked parameters: identity rows and columns), one thread per camera.
 // A block that is not positive definite: status word = camera + 1 (smallest wins), its inverse = identity.
-__global__ __launch_bounds__(kBlock) void k_pcg_minv(int nco, int hb1, const double* __restrict__ S, const unsigned char* __restrict__ mask,
+__global__ __launch_bounds__(kBlock) void k_pcg_minv(int nco, int hb1, const double* __restrict__ S, const int* __restrict__ udiag /* packed [S]: the list index of camera i's diagonal block */,
+                                                     const unsigned char* __restrict__ mask,
                                                      double* __restrict__ minv, int* __restrict__ info) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= nco) return;
-  const double* D = S + band_block(i, i, hb1);
+  const double* D = udiag ? S + (size_t)udiag[i] * 36 : S + band_block(i, i, hb1);
   double A[6][6];
 #pragma unroll
   for (int a = 0; a < 6; ++a)
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_gather(long long nblocks, const 
 __global__ __launch_bounds__(kBlock) void k_schur_init_blocks(long long nblocks, const long long* __restrict__ ublk, int nco, int hb1,
                                                               const int* __restrict__ opt_cam, const double* __restrict__ HCC,
                                                               const double* __restrict__ bC, double damping, double* __restrict__ S,
-                                                              double* __restrict__ b, int use_hcc) {
+                                                              double* __restrict__ b, int use_hcc, int packed) {
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (tid < nblocks * 36) {
     const int e = (int)(tid % 36);
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_init_blocks(long long nblocks,
       v = HCC[(size_t)opt_cam[pos] * 36 + lo * 6 + hi];
       if (a == c) v *= (1.0 + damping);
     }
-    S[blk * 36 + e] = v;
+    S[(packed ? tid / 36 : blk) * 36 + e] = v;
   } else if (tid < nblocks * 36 + (long long)nco * 6) {
     const long long q = tid - nblocks * 36;
     b[q] = use_hcc ? bC[(size_t)opt_cam[q / 6] * 6 + q % 6] : 0.0;
@@ -348,7 +349,7 @@ template <bool TABLE>
 __global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, const double* __restrict__ cams, const double* __restrict__ X,
                                                          const double* __restrict__ HPPinv, const double* __restrict__ bP, long long nblocks,
                                                          const long long* __restrict__ ublk, const int* __restrict__ bptr,
-                                                         const int2* __restrict__ pairs, int hb1, double* __restrict__ S, double* __restrict__ b) {
+                                                         const int2* __restrict__ pairs, int hb1, double* __restrict__ S, double* __restrict__ b, int packed) {
   const long long g = ((long long)blockIdx.x * kBlock + threadIdx.x) / kSbLanes;
   const int q = threadIdx.x & (kSbLanes - 1);
   const bool valid = g < nblocks;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, const dou
 #pragma unroll
   for (int a = 0; a < 6; ++a) bacc[a] = group_sum<kSbLanes>(bacc[a]);
   if (!valid) return;
-  double* Sb = S + blk * 36;
+  double* Sb = S + (packed ? gg : blk) * 36;
 #pragma unroll
   for (int e = 0; e < 36; ++e)
     if ((e & (kSbLanes - 1)) == q) Sb[e] -= acc[e];

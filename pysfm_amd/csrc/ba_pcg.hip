@@ -56,6 +56,7 @@ int pcg_build_pattern(ba_handle* h) {
   }
   g.nnz = (long long)col.size();
   g.upper = upper;
+  g.h_ublk = ublk;
   // ---- the upper blocks' lists of observation pairs (k_schur_blocks): block (i, j >= i) <- (observation of the camera at i, of the
   // camera at j) for every point both see.  Two passes over the points: count, fill.  Not built beyond 64 M pairs (0.5 GB; the
   // reduction then stays with k_schur_pairs).
@@ -77,6 +78,13 @@ int pcg_build_pattern(ba_handle* h) {
       const int* at = std::lower_bound(lo, b1, j);
       return ufirst[i] + (int)(at - lo);
     };
+    {
+      std::vector<int> udiag((size_t)std::max(1, nco));
+      for (int i = 0; i < nco; ++i) udiag[i] = ufirst[i];      // (a row's columns are sorted and the diagonal block always exists: its first upper block)
+      HIPCHECK(h, g.udiag.resize(udiag.size()));
+      HIPCHECK(h, hipMemcpyAsync(g.udiag.p, udiag.data(), udiag.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      HIPCHECK(h, hipStreamSynchronize(h->stream));
+    }
     {
       // every entry of the full pattern -> its (upper) block in the packed array of a solve (k_pcg_gather)
       std::vector<int> cidx(col.size());
@@ -146,6 +154,7 @@ double pcg_band_fill(ba_handle* h) {
 // Is this a scene for the sparse path - a wide band of mostly structural zeros, large enough for a dense factorisation to hurt, no
 // border, the solver left to the library (or set to pcg)?  Builds the pattern on the first call of a problem.
 bool sparse_layout(ba_handle* h) {
+  if (h->pcg.packed) return true;                           // (decided by ba_set_problem: the problem's [S] has no band to go back to)
   if (h->nbc > 0 || h->dense_mode || h->nco == 0 || h->hb <= kBcrwMaxHB || h->comm) return false;
   if (h->opt.solver == SOLVER_PCG) return pcg_build_pattern(h) == BA_OK;
   if (h->opt.solver != SOLVER_AUTO || h->nco < kPcgMinCams) return false;
@@ -159,7 +168,7 @@ int launch_schur_init_sparse(ba_handle* h, double damping, int use_hcc) {
   auto& g = h->pcg;
   const long long n = g.upper * 36 + (long long)h->nco * 6;
   hipLaunchKernelGGL(k_schur_init_blocks, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, g.upper, g.ublk.p, h->nco, h->hb + 1, h->opt_cam.p,
-                     h->HCC.p, h->bC.p, damping, h->S, h->b, use_hcc);
+                     h->HCC.p, h->bC.p, damping, h->S, h->b, use_hcc, g.packed ? 1 : 0);
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
 }
@@ -169,10 +178,10 @@ int launch_schur_blocks(ba_handle* h, int p) {
   const unsigned grid = blocks_for(g.upper * kSbLanes);
   if (h->sensor.kind == SENSOR_TABLE)
     hipLaunchKernelGGL(k_schur_blocks<true>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem_band(h), h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.upper,
-                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b);
+                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b, g.packed ? 1 : 0);
   else
     hipLaunchKernelGGL(k_schur_blocks<false>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem_band(h), h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.upper,
-                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b);
+                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b, g.packed ? 1 : 0);
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
 }
@@ -192,7 +201,8 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
   HIPCHECK(h, g.r.resize((size_t)n)); HIPCHECK(h, g.z.resize((size_t)n)); HIPCHECK(h, g.q.resize((size_t)n));
   HIPCHECK(h, g.p[0].resize((size_t)n)); HIPCHECK(h, g.p[1].resize((size_t)n));
   HIPCHECK(h, g.part.resize((size_t)4 * nparts + nprod));
-  HIPCHECK(h, g.packed.resize(std::max<size_t>(1, (size_t)g.upper * 36)));
+  if (!g.packed) HIPCHECK(h, g.packed_blocks.resize(std::max<size_t>(1, (size_t)g.upper * 36)));
+  const double* Sp = g.packed ? h->S : g.packed_blocks.p;      // the pattern's upper blocks, contiguous: [S] itself when it is stored that way
   HIPCHECK(h, g.state.resize(1));
   if (!g.host_state) HIPCHECK(h, hipHostMalloc((void**)&g.host_state, sizeof(PcgStateRaw), hipHostMallocDefault));
   double* part_rz = g.part.p, *part_rr = g.part.p + (size_t)2 * nparts, *part_pq = g.part.p + (size_t)4 * nparts;
@@ -200,8 +210,8 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
   const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : std::max(1000, std::min(20000, 4 * nco));
   ScopedTimer tm(h, BA_K_PCG_SOLVE);
   HIPCHECK(h, hipMemsetAsync(h->flags.p + 1, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(k_pcg_minv, dim3(blocks_for(nco)), dim3(kBlock), 0, h->stream, nco, hb1, h->S, dmask, g.minv.p, h->flags.p + 1);
-  hipLaunchKernelGGL(k_pcg_gather, dim3(blocks_for(g.upper * 36)), dim3(kBlock), 0, h->stream, g.upper, g.ublk.p, h->S, g.packed.p);
+  hipLaunchKernelGGL(k_pcg_minv, dim3(blocks_for(nco)), dim3(kBlock), 0, h->stream, nco, hb1, h->S, g.packed ? g.udiag.p : (const int*)nullptr, dmask, g.minv.p, h->flags.p + 1);
+  if (!g.packed) hipLaunchKernelGGL(k_pcg_gather, dim3(blocks_for(g.upper * 36)), dim3(kBlock), 0, h->stream, g.upper, g.ublk.p, h->S, g.packed_blocks.p);
   hipLaunchKernelGGL(k_pcg_start, dim3(nparts), dim3(kBlock), 0, h->stream, n, h->b, dmask, g.minv.p, h->dC.p, g.r.p, g.z.p, part_rz, part_rr, reinterpret_cast<PcgState*>(g.state.p));
   int k = 0, status = 0;
   double rr_checked = -1.0;
@@ -212,10 +222,10 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
     const int batch = std::min(std::min(h->opt.pcg_batch, k < 8 ? 8 : k), max_iter - k);
     for (int e = k + batch; k < e; ++k) {
       if (wide_rows)
-        hipLaunchKernelGGL(k_pcg_product<4>, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, g.packed.p, g.rowptr.p, g.col.p, g.cidx.p, g.z.p,
+        hipLaunchKernelGGL(k_pcg_product<4>, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, Sp, g.rowptr.p, g.col.p, g.cidx.p, g.z.p,
                            g.p[k & 1].p, g.p[(k + 1) & 1].p, g.q.p, part_rz, part_rr, nparts, tol2, part_pq, reinterpret_cast<PcgState*>(g.state.p));
       else
-        hipLaunchKernelGGL(k_pcg_product<1>, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, g.packed.p, g.rowptr.p, g.col.p, g.cidx.p, g.z.p,
+        hipLaunchKernelGGL(k_pcg_product<1>, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, Sp, g.rowptr.p, g.col.p, g.cidx.p, g.z.p,
                            g.p[k & 1].p, g.p[(k + 1) & 1].p, g.q.p, part_rz, part_rr, nparts, tol2, part_pq, reinterpret_cast<PcgState*>(g.state.p));
       hipLaunchKernelGGL(k_pcg_update, dim3(nparts), dim3(kBlock), 0, h->stream, k, n, dmask, g.minv.p, g.p[(k + 1) & 1].p, g.q.p, h->dC.p,
                          g.r.p, g.z.p, part_rz, part_rr, nparts, part_pq, nprod, tol2, reinterpret_cast<PcgState*>(g.state.p));

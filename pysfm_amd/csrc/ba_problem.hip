@@ -1083,6 +1083,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->pcg.built = false;
   h->pcg.pairs_built = false;
   h->pcg.band_clean = false;
+  h->pcg.packed = false;
   // (option solve_trace: where the set-up's time goes, on stderr)
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -1100,6 +1101,12 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     rc = ensure_plan(h);
     if (rc != BA_OK) { h->have_problem = false; return rc; }
     lap("work lists of the general kernels (ensure_plan)");
+    // A scene the sparse path takes whole (ba_pcg.h: a wide band of mostly structural zeros, the solver left to the library or set to
+    // pcg BEFORE this call, no group kernel worth its while): [S] is the list of the pattern's blocks and nothing else
+    if (h->opt.packed_store && !h->comm && h->nbc == 0 && h->min_hb == 0 && sparse_layout(h) && h->pcg.pairs_built && pick_schur_kernel(h) == KERN_PAIRS) {
+      h->pcg.packed = true;
+      lap("list of the blocks of S and their observation pairs (packed store)");
+    }
   }
   return BA_OK;
 }
@@ -1114,7 +1121,7 @@ int ba_problem_info(ba_handle* h, int64_t* out, int32_t n) {
   const int64_t v[BA_INFO_COUNT] = {
       h->pperm.empty() ? 0 : 1, h->operm_identity ? 0 : 1, h->ngroups, (int64_t)(kern == KERN_MFMA3 ? h->nwgroups : h->nmgroups_total), h->point_groups ? 1 : 0,
       h->group_maxL, h->hb, kern_is_mfma(kern) ? 1 : 0, kern != KERN_PAIRS && kern != KERN_DENSE ? 1 : 0,
-      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf, h->cpos_in.empty() ? 0 : 1, h->caller_hb, h->nbc, h->lin_reused, h->refined};
+      kern == KERN_MFMA3 ? h->gm3.wn : h->schur_wn, h->nunits, kern, h->gm3.np_cap, h->gm3.Kbuf, h->cpos_in.empty() ? 0 : 1, h->caller_hb, h->nbc, h->lin_reused, h->refined, h->pcg.packed ? 1 : 0};
   for (int i = 0; i < n && i < BA_INFO_COUNT; ++i) out[i] = v[i];
   return BA_OK;
 }

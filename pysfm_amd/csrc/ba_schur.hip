@@ -71,7 +71,8 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
   // (with a border, ba_border.h, the band and its right-hand side end at the band cameras: border_schur below clears and fills the rest)
   const int n1 = h->band_cams();
   const long long ninit = (long long)n1 * (h->hb + 1) * 36 + (long long)n1 * 6;
-  const bool sparse_init = sparse_layout(h) && h->pcg.band_clean;      // (false the first time: that call clears the whole band)
+  REQUIRE(h, !h->pcg.packed || (kern == KERN_PAIRS && h->pcg.pairs_built), BA_ERR_STATE, "ba_schur: this problem's reduced system is stored as the list of its blocks (packed store): only the block-wise reduction applies (options schur / packed_store are read by ba_set_problem)");
+  const bool sparse_init = sparse_layout(h) && (h->pcg.packed || h->pcg.band_clean);      // (a band: false the first time - that call clears the whole band)
   if (sparse_init) {
     if (have_inv) h->inv_valid = true;
     else if (h->nt > 0) {
@@ -238,6 +239,23 @@ int ba_get_reduced(ba_handle* h, double* S, double* b) {
   if (S && nco) HIPCHECK(h, hipMemcpyAsync(band.data(), h->S, band.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (b && nco) HIPCHECK(h, hipMemcpyAsync(b, h->b, (size_t)nco * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (S && nco && h->pcg.packed) {   // the list of the pattern's upper blocks -> the reference's dense (nco, nco, 6, 6)
+    std::memset(S, 0, (size_t)nco * nco * 36 * sizeof(double));
+    const int* out = h->cpos_out.empty() ? nullptr : h->cpos_out.data();
+    for (size_t u = 0; u < h->pcg.h_ublk.size(); ++u) {
+      const int i = (int)(h->pcg.h_ublk[u] / hb1), d = (int)(h->pcg.h_ublk[u] % hb1);
+      const double* src = &band[u * 36];
+      const int r = out ? out[i] : i, q = out ? out[i + d] : i + d;
+      std::memcpy(S + ((size_t)r * nco + q) * 36, src, 36 * sizeof(double));
+      if (d > 0) {
+        double* lo = S + ((size_t)q * nco + r) * 36;
+        for (int a = 0; a < 6; ++a)
+          for (int c = 0; c < 6; ++c) lo[c * 6 + a] = src[a * 6 + c];
+      }
+    }
+    if (b) cam_rows_out(h, b, 6);
+    return BA_OK;
+  }
   if (S && nco) {   // expand the block band to the reference's dense (nco,nco,6,6), mirroring the upper triangle
     std::memset(S, 0, (size_t)nco * nco * 36 * sizeof(double));
     const int* out = h->cpos_out.empty() ? nullptr : h->cpos_out.data();      // internal position -> the caller's
@@ -320,6 +338,7 @@ int ba_bind_reduced_buffers(ba_handle* h, void* S_blocks_dev, void* b_dev) {
 
 int ba_set_dense_visibility(ba_handle* h, int32_t on) {
   if (!h) return BA_ERR_INVALID_ARG;
+  REQUIRE(h, !(on && h->pcg.packed), BA_ERR_STATE, "ba_set_dense_visibility: this problem's reduced system is stored as the list of its blocks (packed store)");
   h->dense_mode = on != 0;
   h->inv_valid = false;
   if (!on) { h->dUd.release(); h->dDd.release(); h->dyd.release(); h->dpart.release(); }

@@ -495,7 +495,8 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   const bool pcg_forced = force == SOLVER_PCG;
   // (the list of blocks comes from THIS handle's tracks: a shard of a sharded adjuster sees only its own, the dense-visibility mode has no list)
   REQUIRE(h, !pcg_forced || (!h->comm && !h->dense_mode), BA_ERR_STATE, "ba_solve_reduced: solver = pcg needs the whole scene on one handle (no communicator) and the sparse reductions (no dense-visibility mode)");
-  const bool use_pcg = h->nco > 0 && (pcg_forced || (force == SOLVER_AUTO && !bcr_ok && !bcrw_ok && sparse_layout(h)));
+  REQUIRE(h, !h->pcg.packed || force == SOLVER_AUTO || pcg_forced, BA_ERR_STATE, "ba_solve_reduced: this problem's reduced system is stored as the list of its blocks (packed store): conjugate gradients are its solver (option packed_store = 0 before ba_set_problem keeps the band)");
+  const bool use_pcg = h->nco > 0 && (pcg_forced || h->pcg.packed || (force == SOLVER_AUTO && !bcr_ok && !bcrw_ok && sparse_layout(h)));
   if (use_pcg) use_big = false;
   const bool use_dense = !use_pcg && !use_big && dense_ok && (force == SOLVER_DENSE || (!band_ok && !(bcrw_ok && (force == SOLVER_AUTO || force == SOLVER_BCR || force == SOLVER_BCR1))));
   const bool use_bcr = !use_dense && (force ? ((force == SOLVER_BCR || force == SOLVER_BCR1) && bcr_ok) : bcr_ok);
@@ -523,7 +524,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   if (use_pcg) {
     int rc = solve_pcg(h, dmask);
     if (rc != BA_OK) return rc;
-    if (h->pcg.last_status != 0 && !pcg_forced && dense_ok) {
+    if (h->pcg.last_status != 0 && !pcg_forced && dense_ok && !h->pcg.packed) {
       // chosen by the library and it did not converge (or found the matrix not positive definite): the dense factorisation has the last word
       h->solve_kind = BA_SOLVE_DENSE_CHOLESKY;
       rc = solve_dense_chol(h, dmask);

@@ -195,8 +195,15 @@ def test_random_unordered_collection_full_step_vs_oracle(be, seed):
     mask = (rs.rand(len(opt) * 6) > .1).astype(np.uint8) if rs.rand() < .5 else None
     damping = float(rs.choice([.5, 10.]))
     a = (s['K'], s['R0'], s['t0'], X0, cam, pt, z)
+    # odd seeds: the solver chosen BEFORE the problem is set - the reduced system is then stored as the list of its blocks, no band at
+    # all (packed store: what the library does by itself from 1500 cameras on); even seeds: the band of the camera order, pcg by option
+    packed = seed % 2 == 1
+    if packed:
+        be.set_option('solver', 'pcg')
     load_problem(be, *a, cp, po, sensor)
     be.set_option('solver', 'pcg')
+    assert be.problem_info()['packed_store'] == int(packed)
+    assert not packed or be.S_doubles == 36 * be.pcg_info()['blocks']
     mu, su, parts = O.compute_update(sensor, *a, cp, po, damping=damping, cam_param_mask=None if mask is None else mask.astype(bool), return_parts=True)
     info, cost = be.lm_trial(damping, 1e-5, mask)
     assert info == 0 and be.last_solve_kind == 'pcg'
@@ -216,6 +223,11 @@ def test_random_unordered_collection_full_step_vs_oracle(be, seed):
     S2, b2 = be.get_reduced()
     close(S2, parts['S'], 1e-11)
     assert info == 0 and abs(cost2 - cost) <= 1e-9 * cost
+    if packed:                                           # what needs a band says so
+        be.set_option('solver', 'dense')
+        with pytest.raises(Exception):
+            be.solve_reduced(mask)
+        return
     be.set_option('solver', 'dense')
     info, cost3 = be.lm_trial(damping, 1e-5, mask)
     assert info == 0 and be.last_solve_kind == 'dense_cholesky' and abs(cost3 - cost) <= 1e-8 * cost

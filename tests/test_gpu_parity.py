@@ -34,7 +34,7 @@ def be():
 
 
 DEFAULT_OPTIONS = dict(schur='auto', solver='auto', point_kernels='auto', fuse_cost=1, fuse_cam=1,
-                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1, reuse_linearization=1, refine='auto', pcg_max_iter=0)
+                       sort_points=1, gm_cap=0, gm_chunk=0, lds_window=1, fused_backsolve=1, fused_eliminate=1, device_lu=1, fast_paths=1, camera_order='auto', border=1, reuse_linearization=1, refine='auto', pcg_max_iter=0, packed_store=1)
 
 
 @pytest.fixture(autouse=True)
@@ -515,8 +515,9 @@ def test_unordered_photo_collection_lm_walk_vs_oracle():
     ref = O.lm_optimize(O.Sensor.gaussian(1.), *a, *default_flags(nc, nt), max_steps=7, trace=trace)
     b = Bundle.FromObservations(*a, sensor_model=sensor_model.GaussianModel(1.))
     ba = BundleAdjuster(verbose=False)
-    ba.backend.set_option('solver', 'pcg')
+    ba.backend.set_option('solver', 'pcg')               # (before the problem is set: the packed store, no band at all)
     ba.set_bundle(b)
+    assert ba.backend.problem_info()['packed_store'] == 1 and ba.backend.S_doubles == 36 * ba.backend.pcg_info()['blocks']
     ba.optimize(max_steps=7)
     assert ba.backend.last_solve_kind == 'pcg'
     assert [(d, o == 'accepted') for d, o, _ in ba.trial_log] == [(t['damping'], t['next'] < t['cur']) for t in trace]
