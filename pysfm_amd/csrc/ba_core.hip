@@ -311,6 +311,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "host_setup") ok = flag(h->opt.host_setup);
   else if (n == "camera_order") ok = choice({"auto", "off", "always"}, h->opt.camera_order);
   else if (n == "packed_store") ok = flag(h->opt.packed_store);
+  else if (n == "sparse_stage") ok = flag(h->opt.sparse_stage);
   else if (n == "refine") ok = choice({"auto", "1", "0"}, h->opt.refine);
   else if (n == "refine_debug") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 0 && c <= 7; if (ok) h->opt.refine_debug = (int)c; }
   else if (n == "border") ok = flag(h->opt.border);

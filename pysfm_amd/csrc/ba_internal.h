@@ -76,6 +76,7 @@ struct Options {
   bool reuse_linearization = true; // ba_lm_trial after a rejected trial: the point blocks of the unchanged current set are not formed again
   bool border_side_stream = true;  // the border's blocks and the preparation of its solve on a side stream beside the cyclic reduction (off: in line)
   bool border = true;              // ... and a border for the cameras at the far end of a few long-range tracks (ba_border.h)
+  bool sparse_stage = false;       // sparse path's reduction in two steps: every observation linearised once, T and W left behind (288 bytes each) for the blocks to sum - measured SLOWER than every pair linearising its two observations itself (260 against 166 us at 5000 cameras): off, kept for the record
   bool packed_store = true;        // scenes the sparse path takes whole keep [S] as the list of the pattern's blocks, no band (0: the band of the camera order, as for every other scene)
   double pcg_tol = 1e-12;          // conjugate gradients (ba_pcg.h): converged at ||r|| <= pcg_tol ||b||
   int pcg_max_iter = 0;            // ... iteration budget (0: max(1000, min(20000, 4 nco)))
@@ -262,6 +263,9 @@ struct ba_handle {
     DevBuf<long long> ublk;             // ... of the upper triangle's blocks alone (what the reductions write)
     DevBuf<int> bptr;                   // k_schur_blocks: the upper blocks' lists of observation pairs, [upper + 1] offsets into ...
     DevBuf<int2> pairs;                 // ... (observation of the camera at the lower position, of the camera at the higher position)
+    DevBuf<int> cptr, cblk;             // ... cut into chunks of 16 pairs: a block's first chunk, a chunk's block
+    DevBuf<double> partial;             // ... what the chunks leave behind (48 doubles each), added up per block by k_schur_blocks_sum
+    long long nchunks = 0;
     bool pairs_built = false;
     // PACKED: [S] holds the pattern's upper blocks ONLY, one after the other in the list's order (block u at 36 u) - no band at all
     // (a band of 5000 cameras is 7 GB, of 30 000 it does not fit the device; the list is 43 MB and 260 MB).  Decided by ba_set_problem for
@@ -272,6 +276,7 @@ struct ba_handle {
     std::vector<long long> h_ublk;      // host copy of ublk (ba_get_reduced of a packed system)
     bool band_clean = false;            // every block of the band outside the pattern is zero (one full initialisation, nothing scribbled since)
     DevBuf<int> cidx;                   // ... and in the packed array of a solve: the (upper) block of every entry of the full pattern
+    DevBuf<double> TW;                  // k_sparse_stage: T = W HPPinv and W of every observation (36 doubles each)
     DevBuf<double> packed_blocks;       // the pattern's upper blocks, contiguous (k_pcg_gather, once per solve; not needed when [S] is stored packed)
     DevBuf<double> minv, r, z, q, p[2], part;
     DevBuf<PcgStateRaw> state;

@@ -125,6 +125,20 @@ int pcg_build_pattern(ba_handle* h) {
         HIPCHECK(h, g.pairs.resize(std::max<size_t>(1, pr.size())));
         HIPCHECK(h, hipMemcpyAsync(g.bptr.p, bptr.data(), bptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (!pr.empty()) HIPCHECK(h, hipMemcpyAsync(g.pairs.p, pr.data(), pr.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        // chunks of kSbChunk pairs: (block of chunk, first chunk of block)
+        std::vector<int> cptr((size_t)upper + 1, 0), cblk;
+        for (long long u = 0; u < upper; ++u) {
+          const int np = bptr[u + 1] - bptr[u], nch = std::max(1, (np + kSbChunk - 1) / kSbChunk);
+          cptr[u] = (int)cblk.size();
+          for (int c = 0; c < nch; ++c) cblk.push_back((int)u);
+        }
+        cptr[upper] = (int)cblk.size();
+        g.nchunks = (long long)cblk.size();
+        HIPCHECK(h, g.cptr.resize(cptr.size()));
+        HIPCHECK(h, g.cblk.resize(std::max<size_t>(1, cblk.size())));
+        HIPCHECK(h, g.partial.resize(std::max<size_t>(1, cblk.size() * kSbPartial)));
+        HIPCHECK(h, hipMemcpyAsync(g.cptr.p, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (!cblk.empty()) HIPCHECK(h, hipMemcpyAsync(g.cblk.p, cblk.data(), cblk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));        // (the host vectors go out of scope)
         g.pairs_built = true;
       }
@@ -175,13 +189,32 @@ int launch_schur_init_sparse(ba_handle* h, double damping, int use_hcc) {
 
 int launch_schur_blocks(ba_handle* h, int p) {
   auto& g = h->pcg;
-  const unsigned grid = blocks_for(g.upper * kSbLanes);
-  if (h->sensor.kind == SENSOR_TABLE)
-    hipLaunchKernelGGL(k_schur_blocks<true>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem_band(h), h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.upper,
-                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b, g.packed ? 1 : 0);
+  const unsigned grid = blocks_for(g.nchunks * kSbLanes);
+  const DevProblem P = dev_problem_band(h);
+  // every observation linearised once, T = W HPPinv and W left behind (288 bytes each), then the blocks sum their pairs from those -
+  // when the device has the room for it (6 M observations: 1.7 GB); otherwise every pair linearises its two observations itself
+  const size_t tw = (size_t)std::max<long long>(1, h->nobs) * 36;
+  bool staged = h->opt.sparse_stage;
+  if (staged && g.TW.n < tw) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || tw * sizeof(double) > free_b / 2) staged = false;
+    else HIPCHECK(h, g.TW.resize(tw));
+  }
+  if (staged) {
+    if (h->sensor.kind == SENSOR_TABLE)
+      hipLaunchKernelGGL(k_sparse_stage<true>, dim3(blocks_for(h->nobs)), dim3(kBlock), 0, h->stream, P, h->cams[p].p, h->X[p].p, h->HPPinv.p, g.TW.p);
+    else
+      hipLaunchKernelGGL(k_sparse_stage<false>, dim3(blocks_for(h->nobs)), dim3(kBlock), 0, h->stream, P, h->cams[p].p, h->X[p].p, h->HPPinv.p, g.TW.p);
+    hipLaunchKernelGGL(k_schur_blocks_staged, dim3(grid), dim3(kBlock), 0, h->stream, h->obs_pt.p, g.TW.p, h->bP.p, g.nchunks, g.cblk.p, g.cptr.p, g.ublk.p,
+                       g.bptr.p, g.pairs.p, h->hb + 1, g.partial.p);
+  } else if (h->sensor.kind == SENSOR_TABLE)
+    hipLaunchKernelGGL(k_schur_blocks<true>, dim3(grid), dim3(kBlock), 0, h->stream, P, h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.nchunks,
+                       g.cblk.p, g.cptr.p, g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, g.partial.p);
   else
-    hipLaunchKernelGGL(k_schur_blocks<false>, dim3(grid), dim3(kBlock), 0, h->stream, dev_problem_band(h), h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.upper,
-                       g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, h->S, h->b, g.packed ? 1 : 0);
+    hipLaunchKernelGGL(k_schur_blocks<false>, dim3(grid), dim3(kBlock), 0, h->stream, P, h->cams[p].p, h->X[p].p, h->HPPinv.p, h->bP.p, g.nchunks,
+                       g.cblk.p, g.cptr.p, g.ublk.p, g.bptr.p, g.pairs.p, h->hb + 1, g.partial.p);
+  hipLaunchKernelGGL(k_schur_blocks_sum, dim3(blocks_for(g.upper * kSbPartial)), dim3(kBlock), 0, h->stream, g.upper, g.cptr.p, g.ublk.p, h->hb + 1, g.partial.p,
+                     h->S, h->b, g.packed ? 1 : 0);
   HIPCHECK(h, hipGetLastError());
   return BA_OK;
 }
