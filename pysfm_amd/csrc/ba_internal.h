@@ -283,6 +283,7 @@ struct ba_handle {
     PcgStateRaw* host_state = nullptr;  // pinned
     int host_status = 0;
     int iterations = 0;                 // of the last solve
+    int prev_iterations = 0;            // ... when it converged (the next solve's first batch)
     int last_status = 0;
     double rel_residual = 0.0;
   } pcg;

@@ -252,7 +252,9 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
   g.iterations = 0;
   while (true) {
     // (short batches first: a launch after convergence costs ~3 us, a look at the state a synchronisation - damped systems converge in 6 .. 30 iterations)
-    const int batch = std::min(std::min(h->opt.pcg_batch, k < 8 ? 8 : k), max_iter - k);
+    // ... and the first batch is what the last solve of this problem needed plus one: consecutive trials of an LM walk need about the same
+    const int first = g.prev_iterations > 0 ? std::min(h->opt.pcg_batch, g.prev_iterations + 1) : 8;
+    const int batch = std::min(std::min(h->opt.pcg_batch, k == 0 ? first : std::max(8, k)), max_iter - k);
     for (int e = k + batch; k < e; ++k) {
       if (wide_rows)
         hipLaunchKernelGGL(k_pcg_product<4>, dim3(nprod), dim3(kBlock), 0, h->stream, k, nco, hb1, Sp, g.rowptr.p, g.col.p, g.cidx.p, g.z.p,
@@ -284,6 +286,7 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
   if (status != 0 && g.host_status == 0) hipLaunchKernelGGL(k_pcg_set_status, dim3(1), dim3(1), 0, h->stream, h->flags.p + 1, status);
   HIPCHECK(h, hipGetLastError());
   g.last_status = status;
+  g.prev_iterations = status == 0 ? g.iterations : 0;
   return BA_OK;
 }
 

@@ -1084,6 +1084,7 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
   h->pcg.pairs_built = false;
   h->pcg.band_clean = false;
   h->pcg.packed = false;
+  h->pcg.prev_iterations = 0;
   // (option solve_trace: where the set-up's time goes, on stderr)
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
