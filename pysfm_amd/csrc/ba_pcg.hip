@@ -5,6 +5,7 @@
 #include "ba_pcg.h"
 
 #include <algorithm>
+#include <chrono>
 
 using namespace ba;
 
@@ -17,6 +18,10 @@ namespace ba {
 int pcg_build_pattern(ba_handle* h) {
   auto& g = h->pcg;
   if (g.built) return BA_OK;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (h->opt.solve_trace) fprintf(stderr, "[pcg_build_pattern] %s: %.2f ms since the call\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
   const int nco = h->nco, hb1 = h->hb + 1;
   std::vector<int> cam((size_t)h->nobs);
   if (h->nobs) HIPCHECK(h, hipMemcpyAsync(cam.data(), h->obs_cam.p, (size_t)h->nobs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -36,6 +41,7 @@ int pcg_build_pattern(ba_handle* h) {
       for (size_t b = 0; b < pos.size(); ++b)
         if (a != b) rows[pos[a]].push_back(pos[b]);
   }
+  lap("rows collected");
   std::vector<int> rowptr((size_t)nco + 1, 0), col;
   std::vector<long long> blk, ublk;
   long long upper = 0;
@@ -54,6 +60,7 @@ int pcg_build_pattern(ba_handle* h) {
     rowptr[i + 1] = (int)col.size();
     std::vector<int>().swap(r);
   }
+  lap("rows sorted, pattern in CSR form");
   g.nnz = (long long)col.size();
   g.upper = upper;
   g.h_ublk = ublk;
@@ -96,6 +103,8 @@ int pcg_build_pattern(ba_handle* h) {
     }
     std::vector<int> bptr((size_t)upper + 1, 0);
     std::vector<std::pair<int, int>> po;                      // (position, observation) of a point's optimised cameras
+    std::vector<int> pair_block;
+    size_t seen = 0;
     long long total = 0;
     for (int pass = 0; pass < 2 && total <= (64ll << 20); ++pass) {
       std::vector<int2> pr;
@@ -115,11 +124,12 @@ int pcg_build_pattern(ba_handle* h) {
         for (size_t a = 0; a < po.size(); ++a)
           for (size_t b = 0; b < po.size(); ++b) {
             if (po[a].first > po[b].first || (po[a].first == po[b].first && a != b)) continue;      // (upper triangle; the diagonal: every observation with itself)
-            const int u = block_of(po[a].first, po[b].first);
-            if (pass == 0) { ++bptr[u]; ++total; }
-            else pr[(size_t)fill[u]++] = int2{po[a].second, po[b].second};
+            // (the block of a pair is looked up once - two binary searches in its row - and remembered for the second pass)
+            if (pass == 0) { const int u = block_of(po[a].first, po[b].first); pair_block.push_back(u); ++bptr[u]; ++total; }
+            else pr[(size_t)fill[pair_block[seen++]]++] = int2{po[a].second, po[b].second};
           }
       }
+      lap(pass == 0 ? "pairs counted" : "pairs filled");
       if (pass == 1) {
         HIPCHECK(h, g.bptr.resize(bptr.size()));
         HIPCHECK(h, g.pairs.resize(std::max<size_t>(1, pr.size())));
@@ -156,6 +166,7 @@ int pcg_build_pattern(ba_handle* h) {
   }
   HIPCHECK(h, hipStreamSynchronize(h->stream));            // (the host vectors go out of scope)
   g.built = true;
+  lap("uploaded");
   return BA_OK;
 }
 

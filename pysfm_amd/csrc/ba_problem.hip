@@ -492,7 +492,17 @@ int ensure_plan(ba_handle* h) {
       if (is_long(k)) ++nlong; else shortspan = std::max(shortspan, phi[k] - plo[k] + 1);
     }
     bool hybrid = nlong > 0 && sorted_by_lo && nco > 0;
-    const int maxspan_all = maxspan;
+    if (hybrid) {
+      // Long tracks that are SCATTERED rather than long (an unordered photo collection: three cameras anywhere among five thousand)
+      // touch pairs of segments all over the matrix with one or two observations each: the segment kernel would linearise table
+      // rows of 64 entries that are 97 % empty, behind a table of 300 MB that takes 240 ms of every ba_set_problem to build (5000
+      // cameras).  When the long tracks fill less than a tenth of the positions they span, they are left to the general kernels
+      // (k_schur_pairs, or k_schur_blocks on the sparse path) and no table is built.
+      long long filled = 0, spanned = 0;
+      for (int k = 0; k < nt; ++k)
+        if (is_long(k)) { filled += off[(size_t)k + 1] - off[k]; spanned += phi[k] - plo[k] + 1; }
+      if (10 * filled < spanned) hybrid = false;
+    }
     struct SegTask { int qa, qb; std::vector<int> pts; };
     std::vector<SegTask> rect_tasks;
     if (hybrid) {
@@ -521,20 +531,6 @@ int ensure_plan(ba_handle* h) {
             rect_tasks[jt->second].pts.push_back(k);
           }
         }
-      }
-      // Long tracks that are SCATTERED rather than long (an unordered photo collection: three cameras anywhere among five thousand)
-      // touch pairs of segments all over the matrix with one or two observations each: the segment kernel would linearise table
-      // rows of 64 entries that are 97 % empty, behind a table of 300 MB that takes 240 ms of every ba_set_problem to build (5000
-      // cameras).  When the long tracks fill less than a tenth of the positions they span, they are left to the general kernels
-      // (k_schur_pairs, or k_schur_blocks on the sparse path) and no table is built.
-      long long filled = 0, spanned = 0;
-      for (int k = 0; k < nt; ++k)
-        if (is_long(k)) { filled += off[(size_t)k + 1] - off[k]; spanned += phi[k] - plo[k] + 1; }
-      if (10 * filled < spanned) {
-        rect_tasks.clear();
-        hybrid = false;
-        nlong_points = 0;
-        maxspan = maxspan_all;
       }
     }
     if ((maxspan >= 1 || hybrid) && maxspan <= kGm3MaxSpan && sorted_by_lo && nco > 0) {
