@@ -259,7 +259,6 @@ struct ba_handle {
     bool built = false;
     long long nnz = 0, upper = 0;       // blocks of the full symmetric pattern; of its upper triangle (diagonal included)
     DevBuf<int> rowptr, col;
-    DevBuf<long long> blk;              // block index in the band: lo (hb + 1) + (hi - lo)
     DevBuf<long long> ublk;             // ... of the upper triangle's blocks alone (what the reductions write)
     DevBuf<int> bptr;                   // k_schur_blocks: the upper blocks' lists of observation pairs, [upper + 1] offsets into ...
     DevBuf<int2> pairs;                 // ... (observation of the camera at the lower position, of the camera at the higher position)

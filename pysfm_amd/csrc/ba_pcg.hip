@@ -43,7 +43,7 @@ int pcg_build_pattern(ba_handle* h) {
   }
   lap("rows collected");
   std::vector<int> rowptr((size_t)nco + 1, 0), col;
-  std::vector<long long> blk, ublk;
+  std::vector<long long> ublk;
   long long upper = 0;
   for (int i = 0; i < nco; ++i) {
     auto& r = rows[i];
@@ -53,7 +53,6 @@ int pcg_build_pattern(ba_handle* h) {
       const int lo = std::min(i, j), hi = std::max(i, j);
       if (hi - lo > h->hb) return h->fail(BA_ERR_STATE, "pcg: cameras %d and %d share a track but the band is %d wide", lo, hi, h->hb);
       col.push_back(j);
-      blk.push_back((long long)lo * hb1 + (hi - lo));
       upper += j >= i;
       if (j >= i) ublk.push_back((long long)lo * hb1 + (hi - lo));
     }
@@ -156,12 +155,10 @@ int pcg_build_pattern(ba_handle* h) {
   }
   HIPCHECK(h, g.rowptr.resize(rowptr.size()));
   HIPCHECK(h, g.col.resize(std::max<size_t>(1, col.size())));
-  HIPCHECK(h, g.blk.resize(std::max<size_t>(1, blk.size())));
   HIPCHECK(h, g.ublk.resize(std::max<size_t>(1, ublk.size())));
   HIPCHECK(h, hipMemcpyAsync(g.rowptr.p, rowptr.data(), rowptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (!col.empty()) {
     HIPCHECK(h, hipMemcpyAsync(g.col.p, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(g.blk.p, blk.data(), blk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(g.ublk.p, ublk.data(), ublk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
   }
   HIPCHECK(h, hipStreamSynchronize(h->stream));            // (the host vectors go out of scope)
