@@ -961,11 +961,13 @@ def main():
     be.enable_timing(not args.no_kernel_table, only=[dom], stride=ev_stride)
     sync()
     state['paths'] = {}
+    refined0 = be.problem_info().get('solves_refined', 0)
     t0 = time.time()
     for _ in range(args.steps):
         one_trial()
     sync()
     dt = time.time() - t0
+    timed_refined = be.problem_info().get('solves_refined', 0) - refined0      # (trials damped below 1e-2 take the solve's refinement step: +39 us each)
     timed_paths = dict(state['paths'])
     tm_dom = be.timings(reset=True)[dom]
     # further windows of the same length, no events at all: spread of the headline number
@@ -1163,7 +1165,7 @@ def main():
             'reduced_system': {'cameras_optimised': nco, 'block_half_bandwidth': hb,
                                'bytes': 8 * be.S_doubles, 'solve_path': getattr(be, 'last_solve_path', None),
                                'solve_kind': getattr(be, 'last_solve_kind', None),
-                               'timed_trials_by_solver_and_outcome': timed_paths},
+                               'timed_trials_by_solver_and_outcome': timed_paths, 'timed_trials_refined': int(timed_refined)},
         }
         out.update(lm)
         if comm is None and not args.no_lm:
@@ -1279,6 +1281,8 @@ def headline(out, detail_path=None):
     for k in ('final_reproj_rmse', 'final_reproj_rmse_oracle', 'lm_steps', 'lm_trials', 'lm_converged', 'end_to_end_optimize_s', 'set_bundle_s'):
         if k in out:
             h[k] = out[k]
+    if 'timed_trials_refined' in out.get('reduced_system', {}):
+        h['timed_trials_refined'] = out['reduced_system']['timed_trials_refined']      # of `steps`: those damped below 1e-2, whose solve takes the refinement step
     cb = out.get('cpu_baseline')
     if cb:
         h['cpu_baseline'] = _pick(cb, ('value', 'unit', 'cores', 'kind'))
