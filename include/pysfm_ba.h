@@ -317,6 +317,12 @@ enum { BA_SOLVE_NONE = 0, BA_SOLVE_BCR, BA_SOLVE_BCR_WIDE, BA_SOLVE_BAND, BA_SOL
  * band under any camera order: at least 1500 optimised cameras, at most a tenth of the band's blocks non-zero): the blocks of the
  * upper triangle that can be non-zero, the iterations and ||r|| / ||b|| of the last such solve, the fraction of the band they fill. */
 int ba_pcg_info(ba_handle* h, int64_t* blocks, int32_t* iterations, double* rel_residual, double* band_fill);
+/* A SHARDED scene on the sparse path: every rank hands over the camera lists of ALL the scene's tracks (list l = optimised positions
+ * list_pos[list_off[l] .. list_off[l + 1]) in the caller's order; duplicates welcome), for the following ba_set_problem calls: the
+ * list of blocks - the layout of the packed [S | b] the ranks add up element by element - is then the same on every rank, whatever
+ * tracks it holds; its own tracks supply the observation pairs.  The ranks must also take the same decisions (solver = pcg and
+ * schur = pairs set by all or by none before ba_set_problem: pysfm_amd.BundleAdjuster does).  nlists = 0: forget the lists. */
+int ba_set_pattern_lists(ba_handle* h, int32_t nlists, const int32_t* list_off, const int32_t* list_pos);
 int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info);
 int ba_last_solve_kind(const ba_handle* h);
 int ba_get_solution(ba_handle* h, double* dC /*[nco*6] host*/);

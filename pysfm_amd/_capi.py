@@ -63,6 +63,7 @@ PROTOTYPES = {
     'ba_order_cameras': (C.c_int, [C.c_int32, C.c_int32, _ip, _ip, _ip, _ip]),
     'ba_set_camera_layout': (C.c_int, [_h, _ip, C.c_int32]),
     'ba_get_camera_layout': (C.c_int, [_h, _ip, C.POINTER(C.c_int32)]),
+    'ba_set_pattern_lists': (C.c_int, [_h, C.c_int32, _ip, _ip]),
     'ba_pcg_info': (C.c_int, [_h, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'ba_plan_camera_layout': (C.c_int, [C.c_int32, C.c_int32, _ip, _ip, _ip, C.c_int32, _ip, _ip, _ip]),
     'ba_set_sensor': (C.c_int, [_h, C.c_int, _dp, C.c_int]),

@@ -135,6 +135,15 @@ class HipBackend(object):
         self._check(self._lib.ba_get_camera_layout(self._h, capi.iptr(new_pos), C.byref(band)))
         return new_pos[:self.nco], band.value
 
+    def set_pattern_lists(self, list_off=None, list_pos=None):
+        """ba_set_pattern_lists: the camera lists of ALL tracks of a sharded scene (optimised positions, the caller's order) for the
+        following set_problem calls, so that every rank's list of blocks is the same; None: forget them."""
+        if list_off is None or len(list_off) < 2:
+            self._check(self._lib.ba_set_pattern_lists(self._h, 0, None, None))
+            return
+        off, pos = capi.i32(list_off), capi.i32(list_pos)
+        self._check(self._lib.ba_set_pattern_lists(self._h, len(off) - 1, capi.iptr(off), capi.iptr(pos)))
+
     def pcg_info(self):
         """ba_pcg_info: the blocks of S (upper triangle) the tracks define, iterations and ||r|| / ||b|| of the last solve by
         conjugate gradients (csrc/ba_pcg.h), the fraction of the band those blocks fill."""

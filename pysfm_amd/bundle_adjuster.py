@@ -263,6 +263,11 @@ class BundleAdjuster(object):
             if hasattr(be, 'set_camera_layout'):
                 be.set_camera_layout(layout)
             self._shared_layout = layout
+            if hasattr(be, 'set_pattern_lists'):
+                if getattr(self, '_sparse_options_set', False):      # (an earlier bundle of this adjuster took the sparse path: the choice is made afresh)
+                    be.set_option('solver', 'auto'); be.set_option('schur', 'auto')
+                    self._sparse_options_set = False
+                be.set_pattern_lists(*(getattr(self, '_shared_lists', None) or (None, None)))
             pos = cam_opt_pos[np.asarray(obs_cam, int)]
             if layout is not None:
                 pos = np.where(pos >= 0, layout[np.maximum(pos, 0)], -1)
@@ -274,6 +279,17 @@ class BundleAdjuster(object):
             spread = np.where(hi >= 0, hi - lo, 0)
             be.set_min_half_bandwidth(int(self._comm.allreduce_max(int(spread.max()) if nt else 0)))
         be.set_problem(nc, nt, obs_cam, obs_pt, obs_z, np.asarray(bundle.K, float), cam_opt_pos, pt_opt)
+        if self._comm is not None and hasattr(be, 'set_pattern_lists') and getattr(self, '_shared_lists', None) is not None:
+            # A sharded scene without a band (an unordered photo collection): the sparse path - conjugate gradients over the blocks the
+            # tracks of the WHOLE scene define, [S | b] stored and summed over the ranks as that list - when all ranks see a scene for it
+            # (the same lists, the same agreed band width: the same answer) or the caller says so (`sparse` = True | False | None).
+            want = self.sparse
+            if want is None:
+                want = be.nco >= self.SPARSE_MIN_CAMERAS and be.half_bandwidth > 23 and be.pcg_info()['band_fill'] <= .1
+            if self._comm._agree(bool(want)) and not be.problem_info().get('packed_store', 0):
+                be.set_option('solver', 'pcg'); be.set_option('schur', 'pairs')
+                self._sparse_options_set = True
+                be.set_problem(nc, nt, obs_cam, obs_pt, obs_z, np.asarray(bundle.K, float), cam_opt_pos, pt_opt)
         self._configure_distributed_solve(be, cam_opt_pos, obs_cam, obs_pt, nt)
         be.set_sensor(*device_params_of(bundle.sensor_model))
         if upload:
@@ -299,6 +315,7 @@ class BundleAdjuster(object):
         pos, trk = pos[ok], np.asarray(trk, np.int64)[ok]            # (the table is sorted by (track, camera): so is what is left)
         nco = int((cam_opt_pos >= 0).sum())
         layout = None
+        self._shared_lists = None
         if len(pos) and nco >= 3:
             start = np.flatnonzero(np.r_[True, trk[1:] != trk[:-1]])
             cnt = np.diff(np.r_[start, len(trk)])
@@ -314,6 +331,8 @@ class BundleAdjuster(object):
                 rep = rep[cnt[rep] >= 2]
                 off = np.r_[0, np.cumsum(cnt[rep])]
                 idx = np.repeat(start[rep] - off[:-1], cnt[rep]) + np.arange(off[-1])
+                # (the distinct lists of ALL tracks: also what a sharded scene on the sparse path defines its blocks from - set_bundle)
+                self._shared_lists = (off.astype(np.int32), pos[idx].astype(np.int32))
                 new, n1, hb = be.plan_camera_layout(nco, off, pos[idx], None, allow_border=False)
                 if not np.array_equal(new, np.arange(nco)):
                     layout = new.astype(np.int64)
@@ -325,6 +344,8 @@ class BundleAdjuster(object):
     # band and solving it on every rank (csrc/ba_dist.h): below, one all-reduce of a few MB and a 0.1 ms solve are the faster way
     DISTRIBUTED_SOLVE_MIN_BYTES = 4 << 20
     distributed_solve = 'auto'           # 'auto' | True | False
+    sparse = None                        # sharded scenes: None = the library's rule (1500 optimised cameras, a tenth of the band's blocks), True | False
+    SPARSE_MIN_CAMERAS = 1500
 
     def _configure_distributed_solve(self, be, cam_opt_pos, obs_cam, obs_pt, nt):
         """Sharded adjuster: switch the trial to the solve that is spread over the ranks when it applies - the band is large,
@@ -336,6 +357,7 @@ class BundleAdjuster(object):
         comm = self._comm
         want = self.distributed_solve
         ok = bool(want) and comm.world_size > 1
+        ok = ok and not be.problem_info().get('packed_store', 0)      # (the sparse path has no band to cut: every rank solves)
         if want == 'auto':
             ok = ok and 8 * be.S_doubles >= self.DISTRIBUTED_SOLVE_MIN_BYTES
         cut = be.dist_plan(be.nco, be.half_bandwidth, comm.world_size) if ok else None

@@ -108,7 +108,7 @@ int upload_rows(ba_handle* h, const int* dev_perm, const double* host, double* d
 
 // in-place sum over the shards of the band-stored [S | b] (contiguous), on the handle's stream
 int comm_allreduce_reduced(ba_handle* h) {
-  if (h->pcg.packed) return h->fail(BA_ERR_STATE, "the reduced system of this problem is stored as the list of ITS tracks' blocks: the shards of a sharded adjuster cannot add such lists up (set the communicator before ba_set_problem)");
+  if (h->pcg.packed && !h->pcg.shared_lists) return h->fail(BA_ERR_STATE, "the reduced system of this problem is stored as the list of ITS tracks' blocks: the shards of a sharded adjuster cannot add such lists up (set the communicator before ba_set_problem)");
   const size_t nS = reduced_doubles(h), nb = (size_t)h->nco * 6;
   if (nS + nb == 0) return BA_OK;
   if (h->b == h->S + nS) {                            // the usual case: one contiguous [S | b]

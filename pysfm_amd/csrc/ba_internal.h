@@ -265,6 +265,10 @@ struct ba_handle {
     DevBuf<int> cptr, cblk;             // ... cut into chunks of 16 pairs: a block's first chunk, a chunk's block
     DevBuf<double> partial;             // ... what the chunks leave behind (48 doubles each), added up per block by k_schur_blocks_sum
     long long nchunks = 0;
+    // ba_set_pattern_lists: the camera lists of ALL tracks of a sharded scene (optimised positions in the caller's order) - a shard's
+    // own tracks define only part of the pattern, and the ranks add their [S | b] element by element: one list of blocks for all
+    std::vector<int> shared_loff, shared_lpos;
+    bool shared_lists = false;
     bool pairs_built = false;
     // PACKED: [S] holds the pattern's upper blocks ONLY, one after the other in the list's order (block u at 36 u) - no band at all
     // (a band of 5000 cameras is 7 GB, of 30 000 it does not fit the device; the list is 43 MB and 260 MB).  Decided by ba_set_problem for

@@ -29,7 +29,21 @@ int pcg_build_pattern(ba_handle* h) {
   std::vector<std::vector<int>> rows((size_t)nco);
   for (int i = 0; i < nco; ++i) rows[i].push_back(i);                       // the diagonal blocks always exist (HCC)
   std::vector<int> pos;
-  for (int k = 0; k < h->nt; ++k) {
+  if (g.shared_lists) {
+    // a sharded scene: the lists of ALL its tracks (ba_set_pattern_lists), not only of this rank's
+    for (size_t l = 0; l + 1 < g.shared_loff.size(); ++l) {
+      pos.clear();
+      for (int q = g.shared_loff[l]; q < g.shared_loff[l + 1]; ++q) {
+        const int p0 = g.shared_lpos[q];
+        if (p0 < 0 || p0 >= nco) return h->fail(BA_ERR_INVALID_ARG, "ba_set_pattern_lists: position %d of %d optimised cameras", p0, nco);
+        pos.push_back(h->cpos_in.empty() ? p0 : h->cpos_in[p0]);
+      }
+      for (size_t a = 0; a < pos.size(); ++a)
+        for (size_t b = 0; b < pos.size(); ++b)
+          if (a != b) rows[pos[a]].push_back(pos[b]);
+    }
+  }
+  for (int k = 0; k < h->nt && !g.shared_lists; ++k) {
     if (k > 0 && k < (int)h->h_same.size() && h->h_same[k]) continue;      // the camera list of the point before it
     pos.clear();
     for (int n = h->h_off[k]; n < h->h_off[k + 1]; ++n) {
@@ -177,7 +191,7 @@ double pcg_band_fill(ba_handle* h) {
 // border, the solver left to the library (or set to pcg)?  Builds the pattern on the first call of a problem.
 bool sparse_layout(ba_handle* h) {
   if (h->pcg.packed) return true;                           // (decided by ba_set_problem: the problem's [S] has no band to go back to)
-  if (h->nbc > 0 || h->dense_mode || h->nco == 0 || h->hb <= kBcrwMaxHB || h->comm) return false;
+  if (h->nbc > 0 || h->dense_mode || h->nco == 0 || h->hb <= kBcrwMaxHB || (h->comm && !h->pcg.shared_lists)) return false;
   if (h->opt.solver == SOLVER_PCG) return pcg_build_pattern(h) == BA_OK;
   if (h->opt.solver != SOLVER_AUTO || h->nco < kPcgMinCams) return false;
   return pcg_band_fill(h) <= kPcgMaxFill;
@@ -301,6 +315,21 @@ int solve_pcg(ba_handle* h, const unsigned char* dmask) {
 }  // namespace ba
 
 extern "C" {
+
+int ba_set_pattern_lists(ba_handle* h, int32_t nlists, const int32_t* list_off, const int32_t* list_pos) {
+  if (!h) return BA_ERR_INVALID_ARG;
+  auto& g = h->pcg;
+  g.shared_lists = false;
+  g.shared_loff.clear(); g.shared_lpos.clear();
+  g.built = false; g.pairs_built = false;
+  if (nlists <= 0) return BA_OK;
+  REQUIRE(h, list_off && list_pos && list_off[0] == 0, BA_ERR_INVALID_ARG, "ba_set_pattern_lists: NULL or malformed lists");
+  for (int l = 0; l < nlists; ++l) REQUIRE(h, list_off[l + 1] >= list_off[l], BA_ERR_INVALID_ARG, "ba_set_pattern_lists: offsets must ascend");
+  g.shared_loff.assign(list_off, list_off + nlists + 1);
+  g.shared_lpos.assign(list_pos, list_pos + list_off[nlists]);
+  g.shared_lists = true;
+  return BA_OK;
+}
 
 int ba_pcg_info(ba_handle* h, int64_t* blocks, int32_t* iterations, double* rel_residual, double* band_fill) {
   if (!h) return BA_ERR_INVALID_ARG;

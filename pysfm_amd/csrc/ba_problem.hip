@@ -1100,7 +1100,9 @@ int ba_set_problem(ba_handle* h, int32_t nc, int32_t nt, int64_t nobs, const int
     lap("work lists of the general kernels (ensure_plan)");
     // A scene the sparse path takes whole (ba_pcg.h: a wide band of mostly structural zeros, the solver left to the library or set to
     // pcg BEFORE this call, no group kernel worth its while): [S] is the list of the pattern's blocks and nothing else
-    if (h->opt.packed_store && !h->comm && h->nbc == 0 && h->min_hb == 0 && sparse_layout(h) && h->pcg.pairs_built && pick_schur_kernel(h) == KERN_PAIRS) {
+    // (a sharded adjuster: only with the lists of ALL the scene's tracks - ba_set_pattern_lists - and every rank deciding alike: the caller sees to that)
+    const bool whole = !h->comm && h->min_hb == 0 && h->forced_pos.empty();
+    if (h->opt.packed_store && (whole || h->pcg.shared_lists) && h->nbc == 0 && sparse_layout(h) && h->pcg.pairs_built && pick_schur_kernel(h) == KERN_PAIRS) {
       h->pcg.packed = true;
       lap("list of the blocks of S and their observation pairs (packed store)");
     }

@@ -494,7 +494,7 @@ int ba_solve_reduced(ba_handle* h, const uint8_t* cam_param_mask, int32_t* info)
   // define (ba_pcg.h) - by option, or when the band is wide, mostly structural zeros, and large enough for a dense factorisation to hurt
   const bool pcg_forced = force == SOLVER_PCG;
   // (the list of blocks comes from THIS handle's tracks: a shard of a sharded adjuster sees only its own, the dense-visibility mode has no list)
-  REQUIRE(h, !pcg_forced || (!h->comm && !h->dense_mode), BA_ERR_STATE, "ba_solve_reduced: solver = pcg needs the whole scene on one handle (no communicator) and the sparse reductions (no dense-visibility mode)");
+  REQUIRE(h, !pcg_forced || ((!h->comm || h->pcg.shared_lists) && !h->dense_mode), BA_ERR_STATE, "ba_solve_reduced: solver = pcg needs the whole scene on one handle (no communicator) and the sparse reductions (no dense-visibility mode)");
   REQUIRE(h, !h->pcg.packed || force == SOLVER_AUTO || pcg_forced, BA_ERR_STATE, "ba_solve_reduced: this problem's reduced system is stored as the list of its blocks (packed store): conjugate gradients are its solver (option packed_store = 0 before ba_set_problem keeps the band)");
   const bool use_pcg = h->nco > 0 && (pcg_forced || h->pcg.packed || (force == SOLVER_AUTO && !bcr_ok && !bcrw_ok && sparse_layout(h)));
   if (use_pcg) use_big = false;
@@ -673,7 +673,7 @@ int ba_dist_enable(ba_handle* h, int32_t rank, int32_t nranks) {
   REQUIRE(h, nranks < 2 || (rank >= 0 && rank < nranks), BA_ERR_INVALID_ARG, "ba_dist_enable: bad rank");
   HIPCHECK(h, hipSetDevice(h->device));
   h->dist.on = false;
-  if (nranks < 2 || h->dense_mode) return BA_OK;
+  if (nranks < 2 || h->dense_mode || h->pcg.packed) return BA_OK;   // (no band to cut: a dense or a packed store is solved by every rank)
   return dist_build_plan(h, rank, nranks);
 }
 

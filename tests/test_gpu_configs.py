@@ -1360,3 +1360,63 @@ def test_camera_layout_of_the_device_views(be):
                     np.testing.assert_array_equal(np.triu(got), np.triu(blk))
                 else:
                     np.testing.assert_array_equal(got, blk)
+
+
+def _collection_rank_worker(rank, world, port, out_dir, nc, nt):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd import synthetic_data as sd
+    from pysfm_amd.distributed import ShardComm, shard_tracks
+    s = sd.generate_collection_scene(nc, nt, partners=8, track_len=3)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    comm = ShardComm()
+    ba = BundleAdjuster(device=0, comm=comm, verbose=False)          # all ranks on GPU 0
+    ba.sparse = True                                                 # (the library's own rule starts at 1500 cameras)
+    ids = shard_tracks(b, rank, world)
+    ba.set_bundle(b, track_ids=ids)
+    info = ba.backend.problem_info()
+    ba.optimize(max_steps=5)
+    X = comm.gather_points(ba)
+    R, t, _ = ba.backend.get_params(0)
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), costs=np.array(ba.costs), X=X, R=R, t=t, trials=ba.lm_trials, packed=info['packed_store'],
+             kind=ba.backend.last_solve_kind, S_doubles=ba.backend.S_doubles, blocks=ba.backend.pcg_info()['blocks'], ntracks=len(ids))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_on_one_gpu_unordered_collection(tmp_path, world):
+    """A sharded scene WITHOUT a band (round 6): an unordered photo collection split by points over `world` processes on the one GPU.
+    The ranks add their [S | b] buffers element by element, so they need ONE layout: the list of the blocks that the tracks of the
+    WHOLE scene define (every rank derives it from the whole bundle: ba_set_pattern_lists), stored packed; a rank's own tracks supply
+    its blocks' observation pairs; every rank then solves the summed system by conjugate gradients.  The sharded walk must be the
+    unsharded one."""
+    import socket
+    import torch.multiprocessing as mp
+    from pysfm_amd import Bundle, BundleAdjuster
+    from pysfm_amd import synthetic_data as sd
+    nc, nt = 300, 6000
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(_collection_rank_worker, args=(world, port, str(tmp_path), nc, nt), nprocs=world, join=True)
+    s = sd.generate_collection_scene(nc, nt, partners=8, track_len=3)
+    b = Bundle.FromObservations(s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'])
+    ba = BundleAdjuster(verbose=False)
+    ba.backend.set_option('solver', 'pcg')
+    ba.set_bundle(b)
+    ba.optimize(max_steps=5)
+    R1, t1, X1 = ba.backend.get_params(0)
+    blocks = ba.backend.pcg_info()['blocks']
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        assert int(d['packed']) == 1 and str(d['kind']) == 'pcg' and int(d['blocks']) == blocks and int(d['S_doubles']) == 36 * blocks
+        assert int(d['trials']) == ba.lm_trials and 0 < int(d['ntracks']) < nt
+        close(d['costs'], np.array(ba.costs), 1e-9)
+        close(d['X'], X1, 1e-8, 1e-11)
+        close(d['t'], t1, 1e-8, 1e-11)
+    ba.backend.close()
