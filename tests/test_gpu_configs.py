@@ -1243,7 +1243,12 @@ def test_device_solve_leaves_a_residual_no_larger_than_lapack_where_the_walk_is_
     res = lambda x: np.linalg.norm(d['A'] @ x - d['rhs']) / np.linalg.norm(d['rhs'])
     lapack = max(res(d['x_lu']), res(d['x_ch']))
     assert res(d['x_dev']) <= 1.5 * lapack, (res(d['x_dev']), res(d['x_lu']), res(d['x_ch']))
-    assert res(d['x_dev']) <= res(d['x_raw']) * 1.05 and res(d['x_raw']) <= 6. * lapack, (res(d['x_dev']), res(d['x_raw']), lapack)
+    assert res(d['x_dev']) <= max(1.05 * res(d['x_raw']), lapack) and res(d['x_raw']) <= 6. * lapack, (res(d['x_dev']), res(d['x_raw']), lapack)
+    # ... and in the measure that does not depend on LAPACK's luck of the day: ||S x - b|| / || |S| |x| + |b| || (Oettli and Prager) at
+    # most 2 units of round-off refined, 4 unrefined (profiles/r06_golden_solve_spread.txt: 0.46 and 1.48 at most over 40 runs, LAPACK 0.58)
+    bwd = lambda x: np.linalg.norm(d['A'] @ x - d['rhs']) / np.linalg.norm(np.abs(d['A']) @ np.abs(x) + np.abs(d['rhs']))
+    eps = 2. ** -52
+    assert bwd(d['x_dev']) <= 2 * eps and bwd(d['x_raw']) <= 4 * eps, (bwd(d['x_dev']) / eps, bwd(d['x_raw']) / eps, bwd(d['x_lu']) / eps)
 
 
 def test_device_solve_agrees_with_lapack_cholesky_as_closely_as_lapack_lu_does(sensitive_solve):

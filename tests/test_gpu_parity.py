@@ -596,25 +596,32 @@ def solve_golden_reduced(be, config3, g, refine, mask=None):
     return be.get_solution().reshape(-1)
 
 
+def backward_error(A, rhs, x):
+    """||A x - b|| / || |A| |x| + |b| ||: the normwise backward error in the measure of Oettli and Prager (what LAPACK's own refinement
+    drivers bound) - ||A||_2 ||x|| in its place is 1e3 times larger on these systems and lets everything through."""
+    return np.linalg.norm(A @ x - rhs) / np.linalg.norm(np.abs(A) @ np.abs(x) + np.abs(rhs))
+
+
 def test_golden_reduced_system_backward_error(be, config3, golden_reduced):
     """bundle_adjuster.py:302-305 solves the reduced system with LAPACK's gesv.  On the golden system the device's solution - the block
     cyclic reduction followed by one step of iterative refinement through its kept factors (csrc/ba_bcr_refine.h; on by default below
-    damping 1e-2) - has a normwise backward error ||S x - b|| / (||S||_2 ||x|| + ||b||) of at most 4 eps AND leaves a residual
-    ||S x - b|| / ||b|| no larger than 1.5 times the larger of LAPACK's two (LU, Cholesky): the input is the same bits every run, the
-    refinement's sums are in a fixed order, the residual it corrects is formed in twice the working precision."""
+    damping 1e-2) - has a backward error ||S x - b|| / || |S| |x| + |b| || of at most 2 eps AND leaves a residual ||S x - b|| / ||b|| no
+    larger than 1.5 times the larger of LAPACK's two (LU, Cholesky).  The input is the same bits every run; the solution is not (the
+    cyclic reduction adds its Schur complements with atomics): scripts/golden_solve_spread.py, profiles/r06_golden_solve_spread.txt -
+    over 40 runs the refined solution's backward error is at most 0.46 eps (LAPACK: 0.58), its residual at most 3.8e-16 (LAPACK:
+    4.8e-16 and 2.8e-16); unrefined: 1.48 eps, 1.2e-15."""
     g = golden_reduced
     A, rhs = g['A'], g['rhs']
     res = lambda x: np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs)
-    bwd = lambda x: np.linalg.norm(A @ x - rhs) / (float(g['norm2']) * np.linalg.norm(x) + np.linalg.norm(rhs))
     lapack = max(res(g['x_lu']), res(g['x_chol']))
     x = solve_golden_reduced(be, config3, g, 'auto')
     assert np.all(np.isfinite(x))
-    assert bwd(x) <= 4 * EPS, (bwd(x) / EPS, bwd(g['x_lu']) / EPS)
+    assert backward_error(A, rhs, x) <= 2 * EPS, (backward_error(A, rhs, x) / EPS, backward_error(A, rhs, g['x_lu']) / EPS)
     assert res(x) <= 1.5 * lapack, (res(x), res(g['x_lu']), res(g['x_chol']))
     # the cyclic reduction alone (refine = 0) is within a few units of round-off as well - and the step does not make it worse
     x0 = solve_golden_reduced(be, config3, g, '0')
-    assert bwd(x0) <= 4 * EPS and res(x0) <= 4 * lapack, (res(x0), lapack)
-    assert res(x) <= res(x0) * 1.05
+    assert backward_error(A, rhs, x0) <= 4 * EPS and res(x0) <= 4 * lapack, (res(x0), lapack)
+    assert res(x) <= max(1.05 * res(x0), lapack)
 
 
 def test_golden_reduced_system_solution_vs_lapack(be, config3, golden_reduced):
@@ -640,9 +647,12 @@ def test_golden_reduced_system_refinement_with_masked_parameters(be, config3, go
     assert np.all(x[mask == 0] == 0.)
     A, rhs = g['A'][np.ix_(keep, keep)], g['rhs'][keep]
     ref = np.linalg.solve(A, rhs)
-    res = lambda v: np.linalg.norm(A @ v - rhs) / np.linalg.norm(rhs)
-    assert res(x[keep]) <= 1.5 * res(ref) + 2 * EPS, (res(x[keep]), res(ref))
+    # (not "1.5 x LAPACK's residual": on this deleted system LAPACK's happens to be 0.19 eps in the backward-error measure, the device's
+    #  0.1 ... 0.6 eps from run to run, and a step of refinement - the device's or one done on the host in long double - does not lower
+    #  it: rounding x + dx costs as much; profiles/r06_golden_solve_spread.txt)
+    assert backward_error(A, rhs, x[keep]) <= 2 * EPS, (backward_error(A, rhs, x[keep]) / EPS, backward_error(A, rhs, ref) / EPS)
     x0 = solve_golden_reduced(be, config3, g, '0', mask)
+    assert backward_error(A, rhs, x0[keep]) <= 4 * EPS
     close(x[keep], x0[keep], 1e-4)                             # (two answers of an ill-conditioned system: equal to its sensitivity)
 
 
