@@ -95,7 +95,7 @@ int ba_synchronize(ba_handle* h);
  *   "resident_fault" g   "refine_debug" 1 | 0              test aids: workgroup g of the resident loop REPORTS a time-out (-1: none); the
  *                                                          refinement's items do not wait for each other (wrong numbers: its floor time)
  *   "point_kernels" auto | v1                              lanes-per-point k_linearize / k_backsub instead of the group-packed ones
- *   "fuse_cost" "fuse_cam"   1 | 0                         pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1)
+ *   "fuse_cost" "fuse_cam" "fuse_invert"   1 | 0           pieces of ba_lm_trial folded into neighbouring kernels (defaults 1, 1, 1)
  *   "sort_points"   1 | 0                                  internal point order chosen by ba_set_problem (default 1; see there)
  *   "gm_cap"        n                                      points per group of the MFMA reduction (0 = automatic)
  *   "gm_chunk"      n                                      groups per workgroup of the MFMA reductions (0 = automatic: 4, or 8 over several rounds)

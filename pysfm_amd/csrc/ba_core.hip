@@ -294,6 +294,7 @@ int ba_set_option(ba_handle* h, const char* name, const char* value) {
   else if (n == "pcg_batch") { char* end = nullptr; const long c = strtol(value, &end, 10); ok = end && *end == 0 && c >= 1 && c <= 100000; if (ok) h->opt.pcg_batch = (int)c; }
   else if (n == "point_kernels") { int c = 0; ok = choice({"auto", "v1"}, c); if (ok) h->opt.point_kernels_v1 = c == 1; }
   else if (n == "fuse_cost") ok = flag(h->opt.fuse_cost);
+  else if (n == "fuse_invert") ok = flag(h->opt.fuse_invert);
   else if (n == "fuse_cam") ok = flag(h->opt.fuse_cam);
   else if (n == "sort_points") ok = flag(h->opt.sort_points);
   else if (n == "solve_trace") ok = flag(h->opt.solve_trace);

@@ -55,6 +55,7 @@ struct Options {
   int solver = SOLVER_AUTO;
   bool point_kernels_v1 = false;   // lanes-per-point k_linearize / k_backsub instead of the group-packed kernels
   bool fuse_cost = true;           // trial cost inside k_backsub_groups
+  bool fuse_invert = true;         // ba_lm_trial: point inverses and the clearing of [S | b] inside k_linearize_groups (no k_point_invert_schur_init launch)
   bool fuse_cam = true;            // camera blocks inside the MFMA reduction
   bool sort_points = true;         // internal point order (ba_set_problem); off = the caller's order as given
   int gm_cap = 0;                  // points per MFMA group (0 = chosen by ba_set_problem)
@@ -295,6 +296,7 @@ struct ba_handle {
   DevBuf<int> flags;        // [0] unused, [1] solver status, [2..15] solver instrumentation, [40],[41] singular-point
                             // counters (alternate per ba_schur call)
   int sing_epoch = 0;       // which of the two counters the latest ba_schur used
+  bool trial_init_done = false;   // the linearisation just launched has inverted the point blocks and cleared [S | b] (launch_point_blocks, fused): the next ba_schur launches neither
   HostResult* host_result = nullptr;   // pinned, device-visible: cost + status words of a trial
   DevBuf<double> res_xb;               // ba_lm_resident: the exchange buffer of its workgroups
   DevBuf<long long> res_epoch;         // ... their epoch words (never reset: a launch starts above res_epoch0)
@@ -482,7 +484,8 @@ int ensure_pair_units(ba_handle* h);       // units / chunks of k_schur_pairs
 int upload_rows(ba_handle* h, const int* dev_perm, const double* host, double* dev, size_t n, int w);
 
 // ---- ba_points.hip: ba_linearize; with fuse (ba_lm_trial + MFMA reduction) the camera blocks are left to the reduction kernel
-int launch_point_blocks(ba_handle* h, int p, double* Wd);
+int launch_point_blocks(ba_handle* h, int p, double* Wd, bool fused = false, double damping = 0.0, double rcond = 0.0);
+bool trial_init_fusable(ba_handle* h);                            // ba_lm_trial: the group lineariser may invert the point blocks and clear [S | b] itself
 int launch_camera_blocks(ba_handle* h, int p, bool clear);
 int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double damping, double rcond);
 

@@ -20,6 +20,7 @@
 #pragma once
 
 #include "ba_device.h"
+#include "ba_point_blocks.h"
 
 namespace ba {
 
@@ -377,22 +378,46 @@ __device__ __forceinline__ double lds_sum_in_order(const double* p, int L) {
 #ifndef BA_LIN_ROW
 #define BA_LIN_ROW 65
 #endif
-__global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const double* __restrict__ cams,
-                                                             const double* __restrict__ X,
-                                                             const SchurGroup* __restrict__ groups, int ngroups,
-                                                             double* __restrict__ HCC, double* __restrict__ bC,
-                                                             double* __restrict__ HPP, double* __restrict__ bP) {
-  __shared__ double sx[kBlock / kWave][9][BA_LIN_ROW];
+// What a trial adds to its linearisation (ba_lm_trial with a matrix-core reduction, `inv.HPPinv` set): the point blocks are
+// damped, inverted and factorised as soon as their sums exist - the lane that holds a point's first observation does what a
+// lane of k_point_invert does, from LDS instead of from memory - and the workgroups behind the groups' clear [S | b]
+// (schur_init_body; the camera blocks come out of the reduction): k_point_invert_schur_init's launch, 8 us at config 3, is gone.
+struct FusedInvert {
+  double damping, rcond;
+  double* HPPinv;              // null: the linearisation alone
+  double* fac;
+  int* singular_count;
+  int* next_count;
+  int group_blocks;            // workgroups [0, group_blocks) linearise, the rest initialise [S | b]
+  int n1, hb1;
+  double* S;
+  double* b;
+};
+template <bool FUSED>
+__device__ __forceinline__ void linearize_groups_body(double (*sx)[9][BA_LIN_ROW], double (*si)[9][kGroupMaxPts + 1], int (*srange)[2], const DevProblem& P, const double* __restrict__ cams,
+                                                      const double* __restrict__ X,
+                                                      const SchurGroup* __restrict__ groups, int ngroups,
+                                                      double* __restrict__ HCC, double* __restrict__ bC,
+                                                      double* __restrict__ HPP, double* __restrict__ bP, const FusedInvert& inv) {
+  if (FUSED && (int)blockIdx.x >= inv.group_blocks) {
+    schur_init_body((long long)(blockIdx.x - inv.group_blocks) * kBlock + threadIdx.x, inv.n1, inv.hb1, nullptr, nullptr, nullptr, inv.damping,
+                    inv.S, inv.b, 0);
+    return;
+  }
+  if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) *inv.next_count = 0;      // (the counter the NEXT inversion will use: point_invert_body)
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (HCC) {                                           // as k_linearize: the camera-block kernels accumulate with atomics
-    const long long nthreads = (long long)gridDim.x * kBlock;
+    const long long nthreads = (long long)(FUSED ? inv.group_blocks : gridDim.x) * kBlock;      // (the workgroups that are here)
     for (long long i = tid; i < (long long)P.nc * 36; i += nthreads) HCC[i] = 0.0;
     for (long long i = tid; i < (long long)P.nc * 6; i += nthreads) bC[i] = 0.0;
   }
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = blockIdx.x * (kBlock / kWave) + wv;
-  if (g >= ngroups) return;                            // whole wavefront
-  const SchurGroup gr = groups[g];
+  if (g >= ngroups) {                                  // whole wavefront
+    if constexpr (!FUSED) return;                      // (FUSED: an empty group - the inversion at the end is the workgroup's)
+  }
+  const SchurGroup gr = g < ngroups ? groups[g] : SchurGroup{0, 0, 1, 0};
+  if (FUSED && lane == 0) { srange[wv][0] = gr.pt_begin; srange[wv][1] = gr.pt_end; }
   const int L = gr.L, NP = 64 / L;
   const int slot = lane / L, oi = lane - slot * L;
   const bool stager = lane < NP * L;
@@ -400,6 +425,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
   double cm[12];
   load_cam(cams, P.obs_cam[stager ? n0 : P.pt_off[gr.pt_begin]], cm);
   double (*mx)[BA_LIN_ROW] = sx[wv];
+  double (*mi)[kGroupMaxPts + 1] = si ? si[wv] : nullptr;
   for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
     const int k = kb + slot;
     const bool live = stager && k < gr.pt_end;
@@ -422,10 +448,48 @@ __global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const
       for (int c = oi; c < 9; c += L) {
         const double sum = lds_sum_in_order(&mx[c][slot * L], L);
         if (c < 6) HPP[6 * (size_t)k + c] = sum; else bP[3 * (size_t)k + c - 6] = sum;
+        if (FUSED) mi[c][k - gr.pt_begin] = sum;
       }
     }
     lds_wave_sync();
   }
+  if constexpr (FUSED) {
+    // The point blocks of the workgroup's eight groups, one per thread (a group has at most kGroupMaxPts = 24 points): inverting
+    // each batch's six points as they came kept 6 of 64 lanes busy with the heaviest part of the kernel (37 us against 20 + 9.6
+    // for the two launches), each wavefront its own group's 24 of 64 lanes (28 us)
+    __syncthreads();
+    const int w = threadIdx.x / kGroupMaxPts, j = threadIdx.x - w * kGroupMaxPts;
+    if (w < kBlock / kWave) {
+      const int t = srange[w][0] + j;
+      if (t < srange[w][1]) {
+        double A[6], gv[3];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[c] = si[w][c][j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gv[c] = si[w][6 + c][j];
+        point_invert_values((size_t)t, A, gv, inv.damping, inv.rcond, inv.HPPinv, inv.singular_count, inv.fac);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_linearize_groups(DevProblem P, const double* __restrict__ cams,
+                                                             const double* __restrict__ X,
+                                                             const SchurGroup* __restrict__ groups, int ngroups,
+                                                             double* __restrict__ HCC, double* __restrict__ bC,
+                                                             double* __restrict__ HPP, double* __restrict__ bP) {
+  __shared__ double sx[kBlock / kWave][9][BA_LIN_ROW];
+  linearize_groups_body<false>(sx, nullptr, nullptr, P, cams, X, groups, ngroups, HCC, bC, HPP, bP, FusedInvert{});
+}
+// (four wavefronts a SIMD - all 4400 of config 3 at once: inlined, the inversion takes the kernel from 97 registers to 164;
+//  held at 128 it spills some of them around the inversion)
+__global__ __launch_bounds__(kBlock) void k_linearize_groups_trial(
+    DevProblem P, const double* __restrict__ cams, const double* __restrict__ X, const SchurGroup* __restrict__ groups, int ngroups,
+    double* __restrict__ HCC, double* __restrict__ bC, double* __restrict__ HPP, double* __restrict__ bP, FusedInvert inv) {
+  __shared__ double sx[kBlock / kWave][9][BA_LIN_ROW];
+  __shared__ double si[kBlock / kWave][9][kGroupMaxPts + 1];     // the sums of the groups' points, until the workgroup inverts them
+  __shared__ int srange[kBlock / kWave][2];                      // the points of each wavefront's group
+  linearize_groups_body<true>(sx, si, srange, P, cams, X, groups, ngroups, HCC, bC, HPP, bP, inv);
 }
 
 // With `host` given (ba_lm_trial: the trial parameter set is written here as well) the kernel also

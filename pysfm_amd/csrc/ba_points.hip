@@ -7,14 +7,42 @@ using namespace ba;
 
 namespace ba {
 
-int launch_point_blocks(ba_handle* h, int p, double* Wd) {
+bool trial_init_fusable(ba_handle* h) {
+  return h->opt.fuse_invert && h->nt > 0 && h->nco > 0 && h->point_groups && !h->opt.point_kernels_v1 && h->sensor.kind != SENSOR_TABLE &&
+         !h->pcg.packed && !sparse_layout(h) && ensure_reduced(h) == BA_OK;
+}
+
+// fused (ba_lm_trial_begin): the group lineariser also inverts the point blocks for `damping` and clears [S | b] - what the
+// ba_schur call that follows would launch k_point_invert_schur_init for (ba_schur.hip reads h->trial_init_done)
+int launch_point_blocks(ba_handle* h, int p, double* Wd, bool fused, double damping, double rcond) {
+  h->trial_init_done = false;
   if (h->nt > 0) {
     ScopedTimer tm(h, BA_K_LINEARIZE);
     const long long threads = (long long)h->nt << h->glog;
     if (!Wd && h->point_groups && !h->opt.point_kernels_v1 && h->sensor.kind != SENSOR_TABLE) {
       const int per_block = kBlock / kWave;
-      hipLaunchKernelGGL(k_linearize_groups, dim3((h->ngroups + per_block - 1) / per_block), dim3(kBlock), 0, h->stream,
-                         dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p);
+      const int gblocks = (h->ngroups + per_block - 1) / per_block;
+      FusedInvert inv{};
+      unsigned nblocks = gblocks;
+      if (fused) {
+        HIPCHECK(h, h->fac.resize((size_t)9 * std::max(1, h->nt)));
+        const int n1 = h->band_cams();
+        const long long ninit = (long long)n1 * (h->hb + 1) * 36 + (long long)n1 * 6;
+        h->sing_epoch ^= 1;        // (as ba_schur does: this inversion counts singular blocks in sing_counter(), the kernel clears the other counter)
+        inv = FusedInvert{damping, rcond, h->HPPinv.p, h->fac.p, h->sing_counter(), h->flags.p + 40 + ((h->sing_epoch ^ 1) & 1), gblocks, n1, h->hb + 1, h->S, h->b};
+        nblocks += blocks_for(ninit);
+      }
+      if (fused)
+        hipLaunchKernelGGL(k_linearize_groups_trial, dim3(nblocks), dim3(kBlock), 0, h->stream,
+                           dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, inv);
+      else
+        hipLaunchKernelGGL(k_linearize_groups, dim3(nblocks), dim3(kBlock), 0, h->stream,
+                           dev_problem(h), h->cams[p].p, h->X[p].p, h->groups.p, h->ngroups, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p);
+      if (fused) {
+        h->inv_valid = true; h->inv_damping = damping; h->inv_rcond = rcond;
+        h->fac_valid = true;
+        h->trial_init_done = true;
+      }
     } else {
       hipLaunchKernelGGL(k_linearize, dim3(blocks_for(threads)), dim3(kBlock), 0, h->stream, dev_problem(h),
                          h->cams[p].p, h->X[p].p, h->glog, h->HCC.p, h->bC.p, h->HPP.p, h->bP.p, Wd,
@@ -62,7 +90,7 @@ int linearize_impl(ba_handle* h, int which, int store_W, bool fuse, double dampi
   // fuse (ba_lm_trial with a matrix-core reduction): the reduction kernel linearises every observation anyway and
   // adds the camera blocks on the way, so k_camera_blocks is skipped (ba_schur / ba_get_blocks run it lazily
   // if another path asks for HCC / bC)
-  int rc = launch_point_blocks(h, p, Wd);
+  int rc = launch_point_blocks(h, p, Wd, fuse && trial_init_fusable(h), damping, rcond);
   if (rc == BA_OK && !fuse) rc = launch_camera_blocks(h, p, h->nt == 0);      // k_linearize cleared HCC / bC otherwise
   if (rc != BA_OK) return rc;
   HIPCHECK(h, hipGetLastError());

@@ -89,6 +89,9 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
     rc = launch_schur_init_sparse(h, damping, fuse_cam ? 0 : 1);
     if (rc != BA_OK) return rc;
   } else
+  if (have_inv && h->trial_init_done && fuse_cam) {
+    h->inv_valid = true;          // the trial's linearisation has done both (k_linearize_groups, launch_point_blocks): nothing to launch
+  } else
   if (!have_inv && h->nt > 0 && h->nco > 0) {
     // point inverses and the initialisation of [S | b] are independent: one launch for both
     h->sing_epoch ^= 1;     // this call counts singular blocks in sing_counter(); the kernel clears the other one
@@ -118,6 +121,7 @@ int ba_schur(ba_handle* h, int which, double damping, double pinv_rcond) {
                          h->HCC.p, h->bC.p, damping, h->S, h->b, fuse_cam ? 0 : 1);
     }
   }
+  h->trial_init_done = false;
   if (!sparse_init && h->nco > 0) h->pcg.band_clean = !dense;      // (the whole band has just been initialised; the dense reduction writes all of it)
   if (dense) {
     // dense visibility: the reduction is one symmetric matrix product over all points (the kernels below

@@ -7,43 +7,11 @@
 #include <type_traits>
 
 #include "ba_device.h"
+#include "ba_point_blocks.h"
 
 namespace ba {
 
-// --------------------------------------------------------------------------
-// apply_damping on HPP (bundle_adjuster.py:241-242, optimize.py:7-9) and the
-// per-point inverse (bundle_adjuster.py:252-256).  One point per lane.
-// --------------------------------------------------------------------------
-__device__ __forceinline__ void point_invert_body(int k, int nt, const double* __restrict__ HPP, double damping, double rcond,
-                                                  double* __restrict__ HPPinv, int* __restrict__ singular_count,
-                                                  int* __restrict__ next_count, const double* __restrict__ bP = nullptr,
-                                                  double* __restrict__ fac = nullptr) {
-  if (k == 0) *next_count = 0;      // the counter the NEXT call will use (two counters alternate: no memset launch)
-  if (k >= nt) return;
-  double A[6], out[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) A[i] = HPP[6 * (size_t)k + i];
-  const double f = 1.0 + damping;
-  A[0] *= f; A[3] *= f; A[5] *= f;
-  if (rcond >= 0.0) {
-    sym3_pinv_fast(A, rcond, out);
-  } else if (!sym3_inv(A, out)) {
-    atomicAdd(singular_count, 1);
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) HPPinv[6 * (size_t)k + i] = out[i];
-  if (fac) {                                   // HPPinv = L D L^T and HPPinv bP for k_schur_groups_mfma2
-    double f[9];
-    sym3_ldl(out, sym3_ldl_tolerance(rcond), f, f + 3);
-    const double g0 = bP[3 * (size_t)k], g1 = bP[3 * (size_t)k + 1], g2 = bP[3 * (size_t)k + 2];
-    f[6] = out[0] * g0 + out[1] * g1 + out[2] * g2;
-    f[7] = out[1] * g0 + out[3] * g1 + out[4] * g2;
-    f[8] = out[2] * g0 + out[4] * g1 + out[5] * g2;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) fac[9 * (size_t)k + i] = f[i];
-  }
-}
-
+// (point_invert_values / point_invert_body / schur_init_body: ba_point_blocks.h - the group lineariser of a trial runs them too)
 __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* __restrict__ HPP,
                                                          double damping, double rcond,
                                                          double* __restrict__ HPPinv,
@@ -51,34 +19,6 @@ __global__ __launch_bounds__(kBlock) void k_point_invert(int nt, const double* _
                                                          int* __restrict__ next_count, const double* __restrict__ bP = nullptr,
                                                          double* __restrict__ fac = nullptr) {
   point_invert_body(blockIdx.x * kBlock + threadIdx.x, nt, HPP, damping, rcond, HPPinv, singular_count, next_count, bP, fac);
-}
-
-// --------------------------------------------------------------------------
-// S[pos,pos] = damped HCC, b[pos] = bC for optimised cameras
-// (bundle_adjuster.py:238-240, 263-265); every other block of the band is cleared in the
-// same pass (one launch instead of two memsets + a scatter).  One thread per double of
-// [S | b]; `opt_cam[pos]` is the camera at optimised position pos.
-// --------------------------------------------------------------------------
-__device__ __forceinline__ void schur_init_body(long long tid, int nco, int hb1, const int* __restrict__ opt_cam,
-                                                const double* __restrict__ HCC, const double* __restrict__ bC,
-                                                double damping, double* __restrict__ S, double* __restrict__ b, int use_hcc) {
-  const long long nS = (long long)nco * hb1 * 36;
-  if (tid < nS) {
-    const int e = (int)(tid % 36);
-    const long long blk = tid / 36;
-    const int d = (int)(blk % hb1), pos = (int)(blk / hb1);
-    double v = 0.0;
-    if (d == 0 && use_hcc) {                     // (the MFMA reduction can add the camera blocks itself)
-      const int a = e / 6, c = e % 6;
-      const int lo = a < c ? a : c, hi = a < c ? c : a;
-      v = HCC[(size_t)opt_cam[pos] * 36 + lo * 6 + hi];
-      if (a == c) v *= (1.0 + damping);
-    }
-    S[tid] = v;
-  } else if (tid < nS + (long long)nco * 6) {
-    const long long q = tid - nS;
-    b[q] = use_hcc ? bC[(size_t)opt_cam[q / 6] * 6 + q % 6] : 0.0;
-  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_schur_init(int nco, int hb1, const int* __restrict__ opt_cam,

@@ -1183,6 +1183,40 @@ def test_lm_trial_entry_equals_stepwise_calls(be):
     close(be.get_params(0)[2], Xs, 0.)
 
 
+@pytest.mark.parametrize('L,rcond', [(10, 1e-5), (7, 1e-5), (3, 1e-5), (10, None)])
+def test_trial_lineariser_inverts_the_point_blocks_itself(be, L, rcond):
+    """ba_lm_trial with a matrix-core reduction (round 6, option fuse_invert): k_linearize_groups_trial damps, inverts and factorises
+    the point blocks of a workgroup's groups once they are summed and clears [S | b] - no k_point_invert_schur_init launch.  The
+    inverses are the SAME BITS as that launch's (the same device function on the same sums), the trial is the one the two launches
+    make, a trial after a rejected one (new damping, linearisation kept) still takes the launch, and plain-inverse mode (rcond None,
+    bundle_adjuster.py:252-256 without the pseudo-inverse) counts its singular blocks the same way."""
+    nc, nt = 60, 3000
+    s = banded(nc, nt, track_len=L, outlier_frac=.03)
+    cam_opt_pos = np.arange(nc, dtype=np.int32) - 1
+    pt_opt = np.ones(nt, np.uint8)
+    pt_opt[::11] = 0
+    sensor = O.Sensor.cauchy(.05)
+    out = {}
+    for fuse in (1, 0):
+        be.set_option('fuse_invert', fuse)
+        load_problem(be, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], cam_opt_pos, pt_opt, sensor)
+        assert be.problem_info()['schur_mfma'] == 1            # (the fused path belongs to the matrix-core reductions)
+        res = []
+        for lam in (10., 1., 1.):                              # (no swap in between: the second and third trial reuse the linearisation)
+            info, cost = be.lm_trial(lam, rcond, None)
+            assert info == 0
+            res.append((cost, be.get_point_inverses().copy(), be.get_solution().copy(), be.get_params(1)[2].copy()))
+        out[fuse] = res
+    be.set_option('fuse_invert', 1)
+    for (c1, i1, d1, x1), (c0, i0, d0, x0) in zip(out[1], out[0]):
+        assert np.array_equal(i1, i0)
+        close(d1, d0, 1e-11)
+        close(x1, x0, 1e-12)
+        assert abs(c1 - c0) <= 1e-12 * c0
+    HPP = O.normal_blocks(sensor, s['K'], s['R0'], s['t0'], s['X0'], s['obs_cam'], s['obs_pt'], s['obs_z'], nc, nt)[1]
+    close(out[1][1][1], O.invert_point_blocks(O.damp_blocks(HPP, 1.), rcond), 1e-9)
+
+
 @pytest.mark.parametrize('L', [2, 3, 7, 10, 13, 15])
 def test_group_packed_point_kernels_equal_lanes_per_point_kernels(be, L):
     """k_linearize_groups / k_backsub_groups (lane = (point slot, observation), trial cost fused into the
