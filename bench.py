@@ -52,7 +52,7 @@ KERNEL_BOUND = {'border_schur': 'atomics', 'border_solve': 'latency', 'bcr_elimi
                 'point_invert': 'hbm', 'schur_init': 'hbm', 'camera_blocks': 'hbm', 'update': 'hbm', 'flatten': 'hbm'}
 # timer id (include/pysfm_ba.h BA_K_*) -> the kernels that run under it on the product path
 KERNEL_NAMES = {'border_schur': 'k_schur_border (+ k_border_clear)', 'border_solve': 'k_border_prepare, k_bcr_apply (a launch per level, forward and back), k_border_reduce, k_border_solve, k_border_correct',
-                'linearize': 'k_linearize_groups (k_linearize when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init',
+                'linearize': 'k_linearize_groups_trial (with the point inverses and the clearing of [S | b]; k_linearize_groups / k_linearize outside a trial or when points do not come in runs)', 'point_invert': 'k_point_invert_schur_init (the trials after a rejected one)',
                 'schur_pairs': 'k_schur_groups_mfma2 | k_schur_groups_mfma3 (k_schur_groups / k_schur_pairs otherwise)',
                 'backsub': 'k_backsub_groups (k_backsub when points do not come in runs)',
                 'bcr_eliminate': 'k_bcr_eliminate_fused: all elimination levels of the cyclic reduction AND its back-substitution in one launch (k_bcr_eliminate per level where a level is wider than the chip; k_bcrw_* for half-bandwidths 12..23)',
@@ -205,7 +205,7 @@ def pmc_traffic(kernel):
         return None, None
     # the timer id 'schur_pairs' covers the interchangeable reduction kernels
     names = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_wide_mfma', 'k_schur_rect_mfma', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
-             'linearize': ['k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
+             'linearize': ['k_linearize_groups_trial', 'k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
              'point_invert': ['k_point_invert_schur_init', 'k_point_invert'],
              'bcr_eliminate': ['k_bcr_eliminate_split', 'k_bcr_eliminate']}.get(kernel, ['k_' + kernel])
     rows = list(csv.DictReader(open(files[-1])))
@@ -703,7 +703,7 @@ def live_pmc_traffic(argv, kernels, timeout_s=150):
 
 # timer id -> kernel names (without template arguments) that run under it, most specific first
 PMC_KERNEL_NAMES = {'schur_pairs': ['k_schur_groups_mfma2', 'k_schur_groups_mfma3', 'k_schur_wide_mfma', 'k_schur_rect_mfma', 'k_schur_groups_mfma', 'k_schur_groups', 'k_schur_pairs'],
-                    'linearize': ['k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
+                    'linearize': ['k_linearize_groups_trial', 'k_linearize_groups', 'k_linearize'], 'backsub': ['k_backsub_groups', 'k_backsub'],
                     'point_invert': ['k_point_invert_schur_init', 'k_point_invert'],
                     'bcr_eliminate': ['k_bcr_eliminate_fused', 'k_bcr_eliminate_split', 'k_bcr_eliminate'],
                     'bcr_backsolve': ['k_bcr_backsolve_fused', 'k_bcr_backsolve'], 'bcr_assemble': ['k_bcr_assemble'],
@@ -1099,7 +1099,9 @@ def main():
         pass_kernels = [k for k in ('linearize', 'camera_blocks', 'point_invert', 'schur_init', 'schur_pairs') if k in ours]
         pass_ms = sum(ours[k]['ms'] for k in pass_kernels) / nprof
         pass_bytes = 20 * nobs_local + 96 * be.nc + 24 * be.nt + 96 * be.nt + 72 * be.nt + 288 * nco * (hb + 1) + 48 * nco
-        pass_traffic = [traffic_of(k)[0] for k in pass_kernels]
+        # (per launch x launches per trial: the inversion kernel only runs in the trials after a rejected one - a trial that linearises
+        #  inverts inside k_linearize_groups_trial - and the reductions of long tracks are several launches)
+        pass_traffic = [None if traffic_of(k)[0] is None else traffic_of(k)[0] * (ours[k]['launches'] / nprof) for k in pass_kernels]
         pass_traffic_live = all(k in live for k in pass_kernels)
         pass_traffic = sum(pass_traffic) if pass_traffic and all(t is not None for t in pass_traffic) else None
         out = {
