@@ -833,8 +833,12 @@ def test_cyclic_reduction_vs_sequential_band_solver(be, nc, L):
                     A, rhs = S.transpose(0, 2, 1, 3).reshape(n, n), rhs.reshape(n)
                     keep = np.arange(n) if mask is None else np.nonzero(mask)[0]
                     A, rhs = A[np.ix_(keep, keep)], rhs[keep]
+                    # (in the measure with a margin - backward_error above: at the level of round-off a step of refinement need not lower
+                    #  ||S x - b||, rounding x + dx costs what it gains: profiles/r06_golden_solve_spread.txt - and loosely against the
+                    #  unrefined residual)
                     res = lambda v: np.linalg.norm(A @ v[keep] - rhs) / np.linalg.norm(rhs)
-                    assert res(xr) <= 1.2 * res(sol[solver]) + 2.2e-16, (solver, res(xr), res(sol[solver]))
+                    assert backward_error(A, rhs, xr[keep]) <= 2 * EPS, (solver, backward_error(A, rhs, xr[keep]) / EPS)
+                    assert res(xr) <= 2. * res(sol[solver]) + 4 * EPS, (solver, res(xr), res(sol[solver]))
 
 
 @pytest.mark.parametrize('nc,L,sensor', [(40, 10, O.Sensor.cauchy(.05)), (30, 4, O.Sensor.gaussian(1.)),
