@@ -31,6 +31,10 @@ namespace ba {
 // band (+ mask) -> D[N][B][B], U[N][B][B] = T[I,I+1], f[N][B]; cameras past nco and masked
 // parameters become identity rows with zero right-hand side.  Super-blocks of cb >= hb cameras (B = 6 cb; cb = hb
 // everywhere but in the solve that is spread over several GPUs, which picks cb so that the elimination tree splits evenly).
+// NIT: entries per thread and round.  3 everywhere (B = 54: one round; the wide solver's B = 138: seven) but in the narrow solve of a
+// trial, which launches ceil(B^2 / 1024) workgroups per node with ONE entry per thread: 333 workgroups instead of 111 at config 3,
+// the trial 2.5 us shorter (alternating runs, three out of three) though the kernel's own time hardly moves (5.4 -> 5.3 us).
+template <int NIT = 3>
 __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, int cb, const double* __restrict__ S,
                                                               const double* __restrict__ b,
                                                               const unsigned char* __restrict__ mask,
@@ -55,7 +59,6 @@ __global__ __launch_bounds__(kBcrThreads) void k_bcr_assemble(int nco, int hb, i
   // every load of a thread is issued before its first store (one round trip to memory instead of one per entry): the address
   // of an entry that is not in the band is that of S[0], its value is then multiplied away - a select on the loaded value
   // would compile to a branch around every load
-  constexpr int NIT = 3;             // entries per thread and round (B = 54: one round; the wide solver's B = 138: seven)
   for (int base = blockIdx.y * NIT * kBcrThreads; base < B * B; base += gridDim.y * NIT * kBcrThreads) {      // (gridDim.y > 1: the big nodes of ba_bcr_big.h)
   double vd[NIT], vu[NIT], kd[NIT], ku[NIT], idv[NIT];
 #pragma unroll

@@ -152,7 +152,7 @@ static int solve_bcr_factor(ba_handle* h, const unsigned char* dmask, double* ma
   }
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);       // also clears the status word flags[1], marks the solution "not there yet", clears done[]
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, n1, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble<1>, dim3(N, (B * B + kBcrThreads - 1) / kBcrThreads), dim3(kBcrThreads), 0, h->stream, n1, h->hb, hb, h->S, h->b, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, s_fused ? h->bcr_done.p : nullptr, (const int*)nullptr, mark, mark_n);
   }
   {
@@ -227,7 +227,7 @@ int solve_bcr_lu(ba_handle* h, const unsigned char* dmask, int ncams, const doub
   HIPCHECK(h, h->bcrF.resize((size_t)N * B));
   {
     ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
-    hipLaunchKernelGGL(k_bcr_assemble, dim3(N), dim3(kBcrThreads), 0, h->stream, n1, h->hb, hb, h->S, rhs, dmask, h->bcrD.p,
+    hipLaunchKernelGGL(k_bcr_assemble<3>, dim3(N), dim3(kBcrThreads), 0, h->stream, n1, h->hb, hb, h->S, rhs, dmask, h->bcrD.p,
                        h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p);
   }
   std::vector<int> strides;
@@ -370,7 +370,7 @@ int dist_stage(ba_handle* h, int stage, const uint8_t* cam_param_mask, size_t* c
     if (int rc = dist_upload_mask(h, cam_param_mask, &dmask); rc != BA_OK) return rc;
     {
       ScopedTimer tm(h, BA_K_BCR_ASSEMBLE);
-      hipLaunchKernelGGL(k_bcr_assemble, dim3(d.nasm), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, cb, h->S, h->b, dmask, h->bcrD.p,
+      hipLaunchKernelGGL(k_bcr_assemble<3>, dim3(d.nasm), dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, cb, h->S, h->b, dmask, h->bcrD.p,
                          h->bcrU.p, h->bcrF.p, h->flags.p + 1, h->dC.p, h->bcr_done.p, d.asm_nodes.p);
       hipLaunchKernelGGL(k_dist_zero_separators, dim3(8, std::max(1, d.nsep)), dim3(256), 0, h->stream, d.nsep, d.sep.p, d.sep_owner.p, d.rank, B,
                          h->bcrD.p, h->bcrF.p);
@@ -414,7 +414,7 @@ int dist_stage(ba_handle* h, int stage, const uint8_t* cam_param_mask, size_t* c
 
 
 void launch_bcr_assemble(ba_handle* h, dim3 grid, int cb, const unsigned char* dmask, double* xsol, int* done, const int* nodes) {
-  hipLaunchKernelGGL(k_bcr_assemble, grid, dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, cb, h->S, h->b, dmask, h->bcrD.p, h->bcrU.p, h->bcrF.p,
+  hipLaunchKernelGGL(k_bcr_assemble<3>, grid, dim3(kBcrThreads), 0, h->stream, h->nco, h->hb, cb, h->S, h->b, dmask, h->bcrD.p, h->bcrU.p, h->bcrF.p,
                      h->flags.p + 1, xsol, done, nodes);
 }
 
