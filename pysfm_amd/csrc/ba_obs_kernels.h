@@ -542,6 +542,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
   double (*mw)[BA_BS_ROW] = sw[wv];
   const bool want_cost = host != nullptr && X_dst != nullptr;
   double cost_acc = 0.0;
+#ifdef BA_BCR_PROFILE
+  long long st[12]; int ns = 0;
+#define BS_STAMP() do { if (ns < 12) st[ns++] = clock64(); } while (0)
+  long long fs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BS_FINE(q) do { asm volatile("" ::: "memory"); fs[q] = clock64(); asm volatile("" ::: "memory"); } while (0)
+  BS_STAMP();
+#else
+#define BS_STAMP()
+#define BS_FINE(q)
+#endif
   for (int g = blockIdx.x * (kBlock / kWave) + wv; g < ngroups; g += gridDim.x * (kBlock / kWave)) {   // wave-uniform
     const SchurGroup gr = groups[g];
     const int L = gr.L, NP = 64 / L;
@@ -569,9 +579,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
     };
     PointIn nxt;
     fetch(gr.pt_begin, nxt);
+#ifdef BA_BCR_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    BS_STAMP();
     for (int kb = gr.pt_begin; kb < gr.pt_end; kb += NP) {
       const int k = kb + slot;
       const bool live = stager && k < gr.pt_end;
+      BS_FINE(0);
       const PointIn cur = nxt;
       fetch(kb + NP, nxt);
       const double bpv = (live && oi < 3) ? bP[3 * (size_t)k + oi] : 0.0;
@@ -593,9 +608,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
           loc[2] = Jp[2] * v0 + Jp[5] * v1;
         }
       }
+      BS_FINE(1);
 #pragma unroll
       for (int q = 0; q < 3; ++q) mx[q][lane] = loc[q];
       lds_wave_sync();
+      BS_FINE(2);
       if (live) {                                        // lane q of a point adds component q of its L terms
         for (int q = oi; q < 3; q += L) {
           const double sum = lds_sum_in_order(&mx[q][slot * L], L);
@@ -603,6 +620,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
         }
       }
       lds_wave_sync();
+      BS_FINE(3);
       if (live && oi == 0) {
         double v[3], out[3];
 #pragma unroll
@@ -622,6 +640,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
         }
       }
       lds_wave_sync();
+      BS_FINE(4);
+      BS_STAMP();
     }
     // second pass over the group: compute_cost of the trial set (optimised camera AND optimised point).  Its
     // registers (updated camera, residual) replace the first pass's instead of adding to them.
@@ -644,7 +664,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BA_BACKS
       }
     }
     lds_wave_sync();
+    BS_STAMP();
   }
+#ifdef BA_BCR_PROFILE
+  if (blockIdx.x == 100 && threadIdx.x == 0) { printf("[k_backsub_groups wg 100 wave 0] cycles since start:"); for (int q = 1; q < ns; ++q) printf(" %lld", st[q] - st[0]); printf(" | last batch: inputs in hand .. linearised %lld, staged + sync %lld, sums (waits for bP) %lld, inverse applied + stores %lld\n", fs[1] - fs[0], fs[2] - fs[1], fs[3] - fs[2], fs[4] - fs[3]); }
+#endif
   if (!host) return;
   cost_acc = wave_sum(cost_acc);
   if (lane == 0) wsum[wv] = cost_acc;
